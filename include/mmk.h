@@ -1,0 +1,231 @@
+/*
+ * mmk.h — C ABI of the MI355X (gfx950) hot-path library `libmmk_hip.so`.
+ *
+ * Scope: the autoregressive generate path of ktonal/mimikit and its mu-law /
+ * STFT feature functionals.  The reference reaches this path
+ * through two *Python* protocols, not an FFI; each entry point below names the
+ * reference function it stands in for (paths relative to the reference root).
+ *
+ * Conventions
+ *   - every function returns MMK_OK (0) or a negative error code and never
+ *     throws; `mmk_last_error()` returns a thread-local message for the last
+ *     failure;
+ *   - all data buffers are CALLER-OWNED DEVICE pointers (e.g. torch
+ *     `tensor.data_ptr()`); sizes and strides are explicit, in ELEMENTS;
+ *   - the library allocates no device memory: plans take a caller-provided
+ *     workspace whose size is reported by `*_workspace_bytes`;
+ *   - kernels are enqueued on the `stream` argument (a `hipStream_t`, passed as
+ *     void*) and the library never synchronises it, except inside
+ *     `*_commit` which may wait for its own one-off graph capture;
+ *   - no torch / C++ types cross the boundary.
+ */
+#ifndef MMK_H_
+#define MMK_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MMK_ABI_VERSION 1
+
+#define MMK_OK 0
+#define MMK_ERR_INVALID (-1)     /* bad argument / shape / unsupported option value */
+#define MMK_ERR_HIP (-2)         /* a HIP runtime call failed */
+#define MMK_ERR_UNSUPPORTED (-3) /* option combination outside this library's coverage */
+#define MMK_ERR_WORKSPACE (-4)   /* workspace too small or misaligned */
+#define MMK_ERR_STATE (-5)       /* call sequence violated (e.g. generate before commit) */
+#define MMK_ERR_KEY (-6)         /* unknown / missing state_dict key */
+
+#define MMK_MAX_LAYERS 128
+#define MMK_MAX_COND 4
+#define MMK_MAX_TIERS 8
+#define MMK_MAX_MLP_HIDDEN 4
+
+typedef void* mmk_stream_t; /* hipStream_t */
+
+int mmk_abi_version(void);
+const char* mmk_last_error(void);
+
+/* ------------------------------------------------------------------------
+ * Feature functionals
+ * ---------------------------------------------------------------------- */
+
+/* MuLawCompress.torch_func (mimikit/features/functionals.py:330-338).
+ * codes[i] = int64(trunc((sign(x)·log1p(mu·|x|·C)/log1p(mu·C) + 1)/2·mu + 0.5)), mu = q_levels-1.
+ * `edges` holds the q_levels-1 ascending fp32 decision thresholds of that
+ * formula (edges[c-1] = smallest x whose code is >= c), so in-range inputs are
+ * quantised exactly as the reference does; inputs outside [edges[0], +1] fall
+ * back to direct fp32 evaluation of the formula (no clamp, as the reference). */
+int mmk_mulaw_compress_f32_i64(const float* x, int64_t* codes, int64_t n, int32_t q_levels,
+                               float compression, const float* edges, mmk_stream_t stream);
+
+/* MuLawExpand.torch_func (mimikit/features/functionals.py:361-369).
+ * `table` holds the q_levels expanded values of codes 0..q_levels-1; codes
+ * outside that range are evaluated directly in fp32. */
+int mmk_mulaw_expand_i64_f32(const int64_t* codes, float* x, int64_t n, int32_t q_levels,
+                             float compression, const float* table, mmk_stream_t stream);
+
+/* STFT.torch_func with coordinate="mag" == MagSpec.torch_func
+ * (mimikit/features/functionals.py:507-524, :576-606): periodic-Hann framed
+ * real FFT magnitudes.  x: (batch, n_samples) rows `x_row_stride` apart,
+ * already length-fixed by the caller (STFT._fix_length, :468-486).
+ * center != 0 pads n_fft/2 zeros on both sides (pad_mode="constant").
+ * out: (batch, n_frames, n_fft/2+1) contiguous, n_frames as returned by
+ * mmk_stft_n_frames.  n_fft must be a power of two in [64, 4096]. */
+int64_t mmk_stft_n_frames(int64_t n_samples, int32_t n_fft, int32_t hop, int32_t center);
+int mmk_stft_mag_f32(const float* x, int64_t x_row_stride, int32_t batch, int64_t n_samples,
+                     int32_t n_fft, int32_t hop, int32_t center, float* out, mmk_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * Building blocks (exported for unit parity tests and for host-side reuse)
+ * ---------------------------------------------------------------------- */
+
+/* floats needed to hold an (N x K) weight in MFMA fragment order */
+int64_t mmk_packed_weight_floats(int32_t n_rows, int32_t k_cols);
+/* W: (N, K) row-major fp32 with leading dimension ldw -> packed order */
+int mmk_pack_weight_f32(const float* w, int64_t ldw, int32_t n_rows, int32_t k_cols, float* packed,
+                        mmk_stream_t stream);
+/* Y[M,N] = act(X[M,K] @ W^T + bias); act: 0 none, 1 tanh, 2 sigmoid, 3 mish, 4 abs, 5 relu
+ * (nn.Linear / 1x1 nn.Conv1d as used by modules/io.py, networks/mlp.py) */
+int mmk_linear_f32(const float* x, int64_t ldx, int32_t m_rows, const float* packed_w, const float* bias,
+                   int32_t n_rows, int32_t k_cols, float* y, int64_t ldy, int32_t act, mmk_stream_t stream);
+
+/* MLP temperature column + CategoricalSampler
+ * (mimikit/networks/mlp.py:58-63, mimikit/modules/targets.py:37-52).
+ * logits: (rows, n_classes + has_temp_col) raw MLP outputs, `ld` apart.
+ * temperature == NULL -> argmax (first maximum on ties); otherwise one
+ * temperature per row and `uniforms` (one U[0,1) per row) drive inverse-CDF
+ * sampling of softmax(logits / T).  out[r * out_stride] receives the class. */
+int mmk_categorical_sample_f32_i64(const float* logits, int64_t ld, int32_t rows, int32_t n_classes,
+                                   int32_t has_temp_col, float min_temp, const float* temperature,
+                                   const float* uniforms, int64_t* out, int64_t out_stride,
+                                   mmk_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * WaveNet (mimikit/networks/wavenet_v2.py)
+ * ---------------------------------------------------------------------- */
+typedef struct mmk_wavenet_config {
+  int32_t n_layers;                        /* sum(blocks) */
+  int32_t kernel_size[MMK_MAX_LAYERS];     /* get_kernels_and_dilation :295-327 */
+  int32_t dilation[MMK_MAX_LAYERS];
+  int32_t q_levels;                        /* class_size of input 0 (EmbeddingIO) ; 0 -> LinearIO input */
+  int32_t in_dim;                          /* feature size of input 0 when q_levels == 0 */
+  int32_t dim_dilated;                     /* dims_dilated[0] */
+  int32_t residuals_dim;                   /* 0 = None */
+  int32_t skips_dim;                       /* 0 = None */
+  int32_t n_cond;                          /* len(dims_1x1) */
+  int32_t cond_in_dim[MMK_MAX_COND];       /* feature size of input 1+j (LinearIO) */
+  int32_t cond_dim[MMK_MAX_COND];          /* dims_1x1[j] */
+  int32_t bias;                            /* Config.bias */
+  int32_t gated;                           /* act_g is not None (Sigmoid) ; act_f = Tanh */
+  int32_t head_kind;                       /* 0: MLPIO + categorical sampler, 1: linear + Abs (magspec), 2: linear */
+  int32_t mlp_hidden;                      /* MLPIO.hidden_dim */
+  int32_t mlp_n_hidden;                    /* MLPIO.n_hidden_layers */
+  int32_t out_dim;                         /* q_levels of the target, or n_bins */
+  int32_t learn_temp;                      /* MLP.learn_temperature */
+  float min_temp;
+  int32_t max_batch;
+} mmk_wavenet_config;
+
+typedef struct mmk_wavenet_plan mmk_wavenet_plan;
+
+int mmk_wavenet_plan_create(const mmk_wavenet_config* cfg, mmk_wavenet_plan** out);
+void mmk_wavenet_plan_destroy(mmk_wavenet_plan* plan);
+/* bind one tensor of the network's state_dict by its reference key
+ * (SURVEY.md section 8(a) row a4), e.g. "layers.3.conv_dil.0.0.weight". */
+int mmk_wavenet_plan_bind(mmk_wavenet_plan* plan, const char* key, const float* dev_ptr, int64_t numel);
+int64_t mmk_wavenet_receptive_field(const mmk_wavenet_plan* plan); /* WaveNet.rf :337-339 */
+size_t mmk_wavenet_workspace_bytes(const mmk_wavenet_plan* plan);
+/* packs all bound weights into `workspace` and clears the dilation queues */
+int mmk_wavenet_commit(mmk_wavenet_plan* plan, void* workspace, size_t workspace_bytes, mmk_stream_t stream);
+/* Teacher-forced pass over positions [t_begin, t_end) of the inputs: fills the
+ * per-layer dilation queues exactly as a full-window WaveNet.forward
+ * (:276-293) over those positions would see them.  in0: int64 class indices
+ * (batch, T) when q_levels > 0, else fp32 (batch, T, in_dim).  cond[j]: fp32
+ * (batch, T, cond_in_dim[j]).  Strides in elements. */
+int mmk_wavenet_warmup(mmk_wavenet_plan* plan, int32_t batch, const void* in0, int64_t in0_row_stride,
+                       const float* const* cond, const int64_t* cond_row_stride, int64_t t_begin,
+                       int64_t t_end, mmk_stream_t stream);
+/* n_steps of GenerateLoopV2's hot loop (mimikit/loops/generate.py:207-219)
+ * fused with WaveNet.generate_step (:447-452): for t in [t0, t0+n_steps) the
+ * class drawn from the network output is written IN PLACE to in0[:, t].
+ * temperature: NULL (argmax) or `batch` floats; uniforms: (batch, n_steps). */
+int mmk_wavenet_generate(mmk_wavenet_plan* plan, int32_t batch, void* in0, int64_t in0_row_stride,
+                         const float* const* cond, const int64_t* cond_row_stride, int64_t t0,
+                         int64_t n_steps, const float* temperature, const float* uniforms,
+                         mmk_stream_t stream);
+/* raw head outputs of the most recent step: (batch, out_dim + learn_temp) fp32 */
+int mmk_wavenet_last_logits(mmk_wavenet_plan* plan, int32_t batch, float* out, int64_t ld, mmk_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * SampleRNN (mimikit/networks/sample_rnn_v2.py)
+ * ---------------------------------------------------------------------- */
+typedef struct mmk_srnn_config {
+  int32_t n_tiers;                         /* len(frame_sizes) (last tier has no RNN) */
+  int32_t frame_size[MMK_MAX_TIERS];
+  int32_t hidden_dim;
+  int32_t rnn_kind;                        /* 0 lstm, 1 gru, 2 rnn(tanh) */
+  int32_t rnn_bias;
+  int32_t h0_ones;                         /* h0_init == "ones" */
+  int32_t q_levels;
+  int32_t mlp_hidden, mlp_n_hidden, learn_temp;
+  float min_temp;
+  int32_t max_batch;
+} mmk_srnn_config;
+
+typedef struct mmk_srnn_plan mmk_srnn_plan;
+
+int mmk_srnn_plan_create(const mmk_srnn_config* cfg, mmk_srnn_plan** out);
+void mmk_srnn_plan_destroy(mmk_srnn_plan* plan);
+int mmk_srnn_plan_bind(mmk_srnn_plan* plan, const char* key, const float* dev_ptr, int64_t numel);
+size_t mmk_srnn_workspace_bytes(const mmk_srnn_plan* plan);
+int mmk_srnn_commit(mmk_srnn_plan* plan, void* workspace, size_t workspace_bytes, mmk_stream_t stream);
+/* SampleRNN.reset_hidden (:266-268) */
+int mmk_srnn_reset(mmk_srnn_plan* plan, mmk_stream_t stream);
+/* SampleRNN.before_generate warm-up (:226-234): runs the tier schedule for
+ * t in [rf, prompt_len - prompt_len % rf) on windows shifted by prompt_len % rf */
+int mmk_srnn_warmup(mmk_srnn_plan* plan, int32_t batch, const int64_t* idx, int64_t idx_row_stride,
+                    int64_t prompt_len, mmk_stream_t stream);
+/* n_steps of the generate loop fused with SampleRNN.generate_step (:236-260) */
+int mmk_srnn_generate(mmk_srnn_plan* plan, int32_t batch, int64_t* idx, int64_t idx_row_stride, int64_t t0,
+                      int64_t n_steps, const float* temperature, const float* uniforms, mmk_stream_t stream);
+int mmk_srnn_last_logits(mmk_srnn_plan* plan, int32_t batch, float* out, int64_t ld, mmk_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * Seq2SeqLSTMNetwork (mimikit/networks/s2s_lstm_v2.py)
+ * ---------------------------------------------------------------------- */
+typedef struct mmk_s2s_config {
+  int32_t in_dim;                          /* n_bins of the magspec input */
+  int32_t out_dim;                         /* n_bins of the target */
+  int32_t model_dim;
+  int32_t hop;
+  int32_t enc_n_lstm, dec_n_lstm;          /* coverage: 1 + 1 */
+  int32_t out_abs;                         /* output activation Abs */
+  int32_t max_batch;
+} mmk_s2s_config;
+
+typedef struct mmk_s2s_plan mmk_s2s_plan;
+
+int mmk_s2s_plan_create(const mmk_s2s_config* cfg, mmk_s2s_plan** out);
+void mmk_s2s_plan_destroy(mmk_s2s_plan* plan);
+int mmk_s2s_plan_bind(mmk_s2s_plan* plan, const char* key, const float* dev_ptr, int64_t numel);
+size_t mmk_s2s_workspace_bytes(const mmk_s2s_plan* plan);
+int mmk_s2s_commit(mmk_s2s_plan* plan, void* workspace, size_t workspace_bytes, mmk_stream_t stream);
+/* Seq2SeqLSTMNetwork.generate_step == forward (:246-266): x (batch, hop, in_dim)
+ * -> y (batch, hop, out_dim).  Row strides are per frame, batch strides per clip. */
+int mmk_s2s_step(mmk_s2s_plan* plan, int32_t batch, const float* x, int64_t x_batch_stride,
+                 int64_t x_frame_stride, float* y, int64_t y_batch_stride, int64_t y_frame_stride,
+                 mmk_stream_t stream);
+/* n_calls successive generate_steps on one (batch, T, n_bins) tensor, in place:
+ * call i reads frames [t0 + i*hop - hop, t0 + i*hop) and writes up to hop
+ * frames at t0 + i*hop (clipped at t_total), as loops/generate.py:207-219 does. */
+int mmk_s2s_generate(mmk_s2s_plan* plan, int32_t batch, float* frames, int64_t batch_stride,
+                     int64_t frame_stride, int64_t t0, int64_t n_steps, int64_t t_total, mmk_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MMK_H_ */

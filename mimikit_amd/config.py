@@ -1,0 +1,137 @@
+"""Dataclass configuration base.
+
+API shape follows the reference's ``mimikit/config.py`` (``Config`` :45-128,
+``Configurable`` :131-141, ``private_runtime_field`` :16-17): every config is a
+``@dataclass`` deriving from :class:`Config`; subclasses automatically get a
+``type`` field holding their qualified name; non-serialised runtime wiring is
+declared with :func:`private_runtime_field`.  The reference (de)serialises
+through OmegaConf, which is not part of this path: here ``serialize`` /
+``deserialize`` go through plain ``yaml`` (nested configs become mappings
+tagged by their ``type``).
+"""
+import abc
+import copy
+import dataclasses as dtc
+import sys
+from typing import Any, Dict, Tuple
+
+__all__ = ["private_runtime_field", "Config", "Configurable"]
+
+_RUNTIME_ONLY = "omegaconf_ignore"  # same metadata key as the reference, so views of it keep working
+_REGISTRY: Dict[str, type] = {}
+
+
+def private_runtime_field(default):
+    """A field that is not an ``__init__`` argument, is hidden from ``repr`` and
+    is skipped by serialisation; used for values wired in at build time
+    (``IOModule.in_dim`` etc.)."""
+    return dtc.field(init=False, repr=False, default_factory=lambda: default,
+                     metadata={_RUNTIME_ONLY: True})
+
+
+def _qualified_name(cls) -> str:
+    name = cls.__qualname__
+    mod = cls.__module__
+    if mod.startswith("mimikit_amd") or mod.startswith("mimikit"):
+        return name
+    return f"{mod}:{name}"
+
+
+def _resolve(type_name: str) -> type:
+    if type_name in _REGISTRY:
+        return _REGISTRY[type_name]
+    if ":" in type_name:
+        mod, qual = type_name.split(":")
+        obj: Any = sys.modules.get(mod)
+        for part in qual.split("."):
+            obj = getattr(obj, part, None)
+        if obj is not None:
+            return obj
+    raise ImportError(f"could not find config class '{type_name}' in the current environment")
+
+
+@dtc.dataclass
+class Config:
+    """Base of every configuration dataclass."""
+
+    def __init_subclass__(cls, type_field: bool = True, **kwargs):
+        super().__init_subclass__(**kwargs)
+        tag = _qualified_name(cls)
+        _REGISTRY[tag] = cls
+        if not type_field:
+            return
+        # inject `type: str = <qualified name>` as the first, non-init field
+        own = dict(cls.__dict__.get("__annotations__", {}))
+        cls.__annotations__ = {"type": str, **own}
+        cls.type = dtc.field(init=False, repr=False, default=tag)
+
+    # -- (de)serialisation -------------------------------------------------
+    def _public_items(self):
+        for f in dtc.fields(self):
+            if f.metadata.get(_RUNTIME_ONLY):
+                continue
+            yield f.name, getattr(self, f.name)
+
+    def to_plain(self):
+        def plain(v):
+            if isinstance(v, Config):
+                d = {k: plain(x) for k, x in v._public_items()}
+                d.setdefault("type", _qualified_name(type(v)))
+                return d
+            if isinstance(v, (tuple, list)):
+                return [plain(x) for x in v]
+            if isinstance(v, dict):
+                return {k: plain(x) for k, x in v.items()}
+            if callable(v) and not isinstance(v, type):
+                return None
+            return str(v) if hasattr(v, "value") and isinstance(v, str) else v
+
+        return plain(self)
+
+    def serialize(self) -> str:
+        import yaml
+
+        return yaml.safe_dump(self.to_plain(), sort_keys=False)
+
+    @staticmethod
+    def deserialize(raw_yaml: str, as_type=None):
+        import yaml
+
+        return Config.object(yaml.safe_load(raw_yaml), as_type)
+
+    @staticmethod
+    def object(plain, as_type=None):
+        if isinstance(plain, dict):
+            cls = as_type if as_type is not None else (_resolve(plain["type"]) if "type" in plain else None)
+            vals = {k: Config.object(v) for k, v in plain.items() if k != "type"}
+            if cls is None:
+                return vals
+            init_names = {f.name for f in dtc.fields(cls) if f.init}
+            return cls(**{k: (tuple(v) if isinstance(v, list) else v) for k, v in vals.items() if k in init_names})
+        if isinstance(plain, (list, tuple)):
+            return tuple(Config.object(v) for v in plain)
+        return plain
+
+    # -- conveniences --------------------------------------------------------
+    def dict(self):
+        return dtc.asdict(self)
+
+    def copy(self):
+        return copy.deepcopy(self)
+
+    def validate(self) -> Tuple[bool, str]:
+        return True, ""
+
+
+class Configurable(abc.ABC):
+    """Something that is built from a :class:`Config` and remembers it."""
+
+    @classmethod
+    @abc.abstractmethod
+    def from_config(cls, config: Config):
+        ...
+
+    @property
+    @abc.abstractmethod
+    def config(self) -> Config:
+        ...

@@ -1,0 +1,223 @@
+// Feature functionals of the generate path: mu-law quantise / expand and the
+// framed periodic-Hann STFT magnitude (MagSpec).  All HBM-bound streaming work:
+// coalesced 16 B/lane accesses, tables and frame tiles staged in LDS.
+#include "mmk_common.h"
+
+namespace mmk {
+
+// ---- mu-law -----------------------------------------------------------------------
+// The reference formula (features/functionals.py:330-338) is evaluated in fp32
+// with torch's CPU log1p; a 1-ulp different log1p flips codes at bin edges.  The
+// kernel therefore only uses the device log1pf to get a candidate code and then
+// settles it against the q-1 decision thresholds of the reference formula
+// (built once on the host, mimikit_amd/features/functionals.py), which makes
+// in-range codes exact by construction.
+__device__ __forceinline__ int64_t mulaw_code(float x, float mu, float C, float inv_log, const float* edges, int q) {
+  const float ax = fabsf(x);
+  const float sgn = (x > 0.f) ? 1.f : ((x < 0.f) ? -1.f : 0.f);
+  const float y = sgn * log1pf(mu * ax * C) * inv_log;
+  const float v = (y + 1.f) / 2.f * mu + 0.5f;
+  int64_t c = (int64_t)v;  // trunc toward zero, as tensor.to(int64)
+  if (edges != nullptr && ax <= 1.f) {
+    int ci = (int)c;
+    ci = ci < 0 ? 0 : (ci > q - 1 ? q - 1 : ci);
+    while (ci > 0 && x < edges[ci - 1]) --ci;
+    while (ci < q - 1 && x >= edges[ci]) ++ci;
+    c = ci;
+  }
+  return c;
+}
+
+__global__ __launch_bounds__(256) void mulaw_compress_kernel(const float* __restrict__ x, int64_t* __restrict__ codes,
+                                                            int64_t n, int q, float C, const float* __restrict__ edges) {
+  extern __shared__ float s_edges[];
+  const bool have = edges != nullptr;
+  if (have)
+    for (int i = threadIdx.x; i < q - 1; i += blockDim.x) s_edges[i] = edges[i];
+  __syncthreads();
+  const float mu = (float)(q - 1);
+  const float inv_log = 1.f / log1pf(mu * C);
+  const float* e = have ? s_edges : nullptr;
+  const int64_t n4 = n >> 2;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const bool aligned = ((reinterpret_cast<uintptr_t>(x) & 15) == 0) && ((reinterpret_cast<uintptr_t>(codes) & 15) == 0);
+  if (aligned) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += stride) {
+      const float4 v = reinterpret_cast<const float4*>(x)[i];
+      longlong2 o0, o1;
+      o0.x = mulaw_code(v.x, mu, C, inv_log, e, q);
+      o0.y = mulaw_code(v.y, mu, C, inv_log, e, q);
+      o1.x = mulaw_code(v.z, mu, C, inv_log, e, q);
+      o1.y = mulaw_code(v.w, mu, C, inv_log, e, q);
+      reinterpret_cast<longlong2*>(codes)[2 * i] = o0;
+      reinterpret_cast<longlong2*>(codes)[2 * i + 1] = o1;
+    }
+    for (int64_t i = (n4 << 2) + blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += stride)
+      codes[i] = mulaw_code(x[i], mu, C, inv_log, e, q);
+  } else {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += stride)
+      codes[i] = mulaw_code(x[i], mu, C, inv_log, e, q);
+  }
+}
+
+__device__ __forceinline__ float mulaw_value(int64_t code, float mu, float C, float logv, const float* table, int q) {
+  if (table != nullptr && code >= 0 && code < q) return table[code];
+  // x = code/mu*2-1 ; sign(x)*(exp(|x|*log1p(mu*C))-1)/(mu*C)     (functionals.py:361-369)
+  const float xx = ((float)code / mu) * 2.f - 1.0f;
+  const float sgn = (xx > 0.f) ? 1.f : ((xx < 0.f) ? -1.f : 0.f);
+  return sgn * (expf(fabsf(xx) * logv) - 1.0f) / (mu * C);
+}
+
+__global__ __launch_bounds__(256) void mulaw_expand_kernel(const int64_t* __restrict__ codes, float* __restrict__ x,
+                                                          int64_t n, int q, float C, const float* __restrict__ table) {
+  extern __shared__ float s_table[];
+  const bool have = table != nullptr;
+  if (have)
+    for (int i = threadIdx.x; i < q; i += blockDim.x) s_table[i] = table[i];
+  __syncthreads();
+  const float mu = (float)(q - 1);
+  const float logv = log1pf(mu * C);
+  const float* t = have ? s_table : nullptr;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const int64_t n2 = n >> 1;
+  const bool aligned = ((reinterpret_cast<uintptr_t>(x) & 7) == 0) && ((reinterpret_cast<uintptr_t>(codes) & 15) == 0);
+  if (aligned) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n2; i += stride) {
+      const longlong2 c = reinterpret_cast<const longlong2*>(codes)[i];
+      float2 o;
+      o.x = mulaw_value(c.x, mu, C, logv, t, q);
+      o.y = mulaw_value(c.y, mu, C, logv, t, q);
+      reinterpret_cast<float2*>(x)[i] = o;
+    }
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) x[n - 1] = mulaw_value(codes[n - 1], mu, C, logv, t, q);
+  } else {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += stride)
+      x[i] = mulaw_value(codes[i], mu, C, logv, t, q);
+  }
+}
+
+// ---- framed STFT magnitude ----------------------------------------------------------
+// One workgroup transforms TWO consecutive frames with one complex FFT of size
+// n_fft (frame A in the real lane, frame B in the imaginary lane), radix-2
+// Stockham autosort in LDS (ping-pong buffers, natural-order output), then splits
+//   A[k] = (Z[k] + conj(Z[N-k]))/2 ,  B[k] = (Z[k] - conj(Z[N-k]))/(2i)
+// and stores |A|, |B| for k = 0..N/2 with consecutive lanes on consecutive bins.
+__global__ __launch_bounds__(256) void stft_mag_kernel(const float* __restrict__ x, int64_t x_row_stride,
+                                                      int64_t n_samples, int n_fft, int log2n, int hop, int center,
+                                                      int64_t n_frames, float* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float2* buf0 = reinterpret_cast<float2*>(smem_raw);
+  float2* buf1 = buf0 + n_fft;
+  float2* tw = buf1 + n_fft;  // n_fft/2 twiddles exp(-2 pi i m / N)
+
+  const int N = n_fft, half = n_fft >> 1;
+  const int tid = threadIdx.x, nt = blockDim.x;
+  const int64_t pairs_per_row = (n_frames + 1) >> 1;
+  const int64_t b = blockIdx.x / pairs_per_row;
+  const int64_t f0 = (blockIdx.x % pairs_per_row) * 2;
+  const bool has_b = (f0 + 1) < n_frames;
+  const float* xr = x + b * x_row_stride;
+  const int64_t pad = center ? half : 0;
+
+  for (int m = tid; m < half; m += nt) {
+    float s, c;
+    sincospif(-2.0f * (float)m / (float)N, &s, &c);
+    tw[m] = make_float2(c, s);
+  }
+  for (int n = tid; n < N; n += nt) {
+    // periodic Hann, as torch.hann_window(n_fft)            (functionals.py:513)
+    const float w = 0.5f - 0.5f * cospif(2.0f * (float)n / (float)N);
+    const int64_t ia = f0 * hop + n - pad;
+    const int64_t ib = ia + hop;
+    const float a = (ia >= 0 && ia < n_samples) ? xr[ia] : 0.f;
+    const float bb = (has_b && ib >= 0 && ib < n_samples) ? xr[ib] : 0.f;
+    buf0[n] = make_float2(a * w, bb * w);
+  }
+  __syncthreads();
+
+  float2* src = buf0;
+  float2* dst = buf1;
+  for (int s = 0; s < log2n; ++s) {
+    const int p = 1 << s;
+    for (int i = tid; i < half; i += nt) {
+      const int k = i & (p - 1);
+      const int j = ((i - k) << 1) + k;
+      const float2 w = tw[k * (half >> s)];
+      const float2 u0 = src[i];
+      const float2 t1 = src[i + half];
+      const float2 u1 = make_float2(t1.x * w.x - t1.y * w.y, t1.x * w.y + t1.y * w.x);
+      dst[j] = make_float2(u0.x + u1.x, u0.y + u1.y);
+      dst[j + p] = make_float2(u0.x - u1.x, u0.y - u1.y);
+    }
+    __syncthreads();
+    float2* t = src; src = dst; dst = t;
+  }
+
+  const int bins = half + 1;
+  float* oa = out + (b * n_frames + f0) * bins;
+  float* ob = oa + bins;
+  for (int k = tid; k < bins; k += nt) {
+    const float2 z = src[k];
+    const float2 zc = src[(N - k) & (N - 1)];
+    // A = (z + conj(zc))/2 ; B = (z - conj(zc))/(2i)
+    const float ar = 0.5f * (z.x + zc.x), ai = 0.5f * (z.y - zc.y);
+    const float br = 0.5f * (z.y + zc.y), bi = -0.5f * (z.x - zc.x);
+    oa[k] = sqrtf(ar * ar + ai * ai);
+    if (has_b) ob[k] = sqrtf(br * br + bi * bi);
+  }
+}
+
+}  // namespace mmk
+
+extern "C" int mmk_mulaw_compress_f32_i64(const float* x, int64_t* codes, int64_t n, int32_t q_levels,
+                                          float compression, const float* edges, mmk_stream_t stream) {
+  using namespace mmk;
+  if (n == 0) return MMK_OK;
+  if (!x || !codes || n < 0 || q_levels < 2 || q_levels > 65536)
+    return fail(MMK_ERR_INVALID, "mulaw_compress: bad arguments (n=%lld, q_levels=%d)", (long long)n, q_levels);
+  int64_t blocks = (n / 4 + 255) / 256;
+  blocks = blocks < 1 ? 1 : (blocks > 4096 ? 4096 : blocks);
+  hipLaunchKernelGGL(mulaw_compress_kernel, dim3((unsigned)blocks), dim3(256), (size_t)q_levels * sizeof(float),
+                     (hipStream_t)stream, x, codes, n, q_levels, compression, edges);
+  MMK_HIP(hipGetLastError());
+  return MMK_OK;
+}
+
+extern "C" int mmk_mulaw_expand_i64_f32(const int64_t* codes, float* x, int64_t n, int32_t q_levels, float compression,
+                                        const float* table, mmk_stream_t stream) {
+  using namespace mmk;
+  if (n == 0) return MMK_OK;
+  if (!x || !codes || n < 0 || q_levels < 2 || q_levels > 65536)
+    return fail(MMK_ERR_INVALID, "mulaw_expand: bad arguments (n=%lld, q_levels=%d)", (long long)n, q_levels);
+  int64_t blocks = (n / 2 + 255) / 256;
+  blocks = blocks < 1 ? 1 : (blocks > 4096 ? 4096 : blocks);
+  hipLaunchKernelGGL(mulaw_expand_kernel, dim3((unsigned)blocks), dim3(256), (size_t)q_levels * sizeof(float),
+                     (hipStream_t)stream, codes, x, n, q_levels, compression, table);
+  MMK_HIP(hipGetLastError());
+  return MMK_OK;
+}
+
+extern "C" int64_t mmk_stft_n_frames(int64_t n_samples, int32_t n_fft, int32_t hop, int32_t center) {
+  if (hop <= 0 || n_fft <= 0) return 0;
+  const int64_t padded = n_samples + (center ? (int64_t)(n_fft / 2) * 2 : 0);
+  if (padded < n_fft) return 0;
+  return 1 + (padded - n_fft) / hop;
+}
+
+extern "C" int mmk_stft_mag_f32(const float* x, int64_t x_row_stride, int32_t batch, int64_t n_samples, int32_t n_fft,
+                                int32_t hop, int32_t center, float* out, mmk_stream_t stream) {
+  using namespace mmk;
+  if (!x || !out || batch <= 0 || hop <= 0) return fail(MMK_ERR_INVALID, "stft: bad arguments");
+  int log2n = 0;
+  while ((1 << log2n) < n_fft) ++log2n;
+  if ((1 << log2n) != n_fft || n_fft < 64 || n_fft > 4096)
+    return fail(MMK_ERR_UNSUPPORTED, "stft: n_fft must be a power of two in [64, 4096], got %d", n_fft);
+  const int64_t n_frames = mmk_stft_n_frames(n_samples, n_fft, hop, center);
+  if (n_frames <= 0) return fail(MMK_ERR_INVALID, "stft: input of %lld samples is shorter than one frame", (long long)n_samples);
+  const int64_t blocks = (int64_t)batch * ((n_frames + 1) / 2);
+  const size_t lds = (size_t)n_fft * sizeof(float2) * 2 + (size_t)(n_fft / 2) * sizeof(float2);
+  hipLaunchKernelGGL(stft_mag_kernel, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, x, x_row_stride,
+                     n_samples, n_fft, log2n, hop, center, n_frames, out);
+  MMK_HIP(hipGetLastError());
+  return MMK_OK;
+}

@@ -1,0 +1,312 @@
+// Skinny fp32 GEMM on the f32-input matrix cores + fused epilogues (gfx950).
+//
+// Y[M,N] = X[M,K] · W[N,K]^T for M = clips (1..64 per workgroup row-block),
+// the shape of every per-step op on the generate path: WaveNet dilated/1x1
+// convs at one time position (wavenet_v2.py:131-176), SampleRNN tier
+// projections / RNN gates / up-samplers (sample_rnn_v2.py:83-99), the MLP head
+// (mlp.py:58-63) and the Seq2Seq LSTM gates.
+//
+// Mapping: one workgroup = one 16-column output tile x (MT x 16) rows; its
+// waves split K between them (v_mfma_f32_16x16x4_f32, exact fp32 fmaf chains)
+// and reduce through LDS in a fixed wave order, so results are run-to-run
+// deterministic.  Weights are pre-packed once per commit into fragment order
+// (one coalesced 1 KiB dwordx4 load per 16x16 block).  The A operand can be the
+// concatenation of up to kMaxSeg row-major segments, each resolved through a
+// time-indexed Addr (dilation queues, cond rows, int64 sample windows).
+#include "mmk_common.h"
+
+namespace mmk {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float seg_load_scalar(const Seg& sg, int64_t base_off, int64_t row, int k) {
+  if (k >= sg.K) return 0.f;
+  if (sg.kind == SEG_I64_LINEARIZED) {
+    const int64_t* p = (const int64_t*)sg.x.base + base_off + row * sg.ld + k;
+    return (((float)(*p) / sg.class_size) - .5f) * 2.f;
+  }
+  const float* p = (const float*)sg.x.base + base_off + row * sg.ld + k;
+  return *p;
+}
+
+template <int MT, bool VEC>
+__global__ __launch_bounds__(1024) void linear_kernel(const LinearArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  f32x4* red = reinterpret_cast<f32x4*>(smem_raw);
+
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int nw = blockDim.x >> 6;
+  const int tile = blockIdx.x;
+  const int m0 = blockIdx.y * (MT * 16);
+  const int64_t tau = (a.tau_ptr ? *a.tau_ptr : 0) + a.tau_off;
+
+  const int c_begin = (int)(((int64_t)a.k_chunks * wave) / nw);
+  const int c_end = (int)(((int64_t)a.k_chunks * (wave + 1)) / nw);
+  const int r = lane & 15, q = lane >> 4;
+
+  int64_t row[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    int m = m0 + mt * 16 + r;
+    row[mt] = m < a.M ? m : a.M - 1;
+  }
+
+  f32x4 acc[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const f32x4* wp = reinterpret_cast<const f32x4*>(a.Wp) + ((int64_t)tile * a.k_chunks) * 64 + lane;
+
+  int s = 0;
+  while (s + 1 < a.nseg && c_begin >= a.seg_chunk0[s + 1]) ++s;
+  int64_t seg_off = addr_elems(a.seg[s].x, tau);
+
+  for (int c = c_begin; c < c_end; ++c) {
+    while (c >= a.seg_chunk0[s + 1]) {
+      ++s;
+      seg_off = addr_elems(a.seg[s].x, tau);
+    }
+    const Seg& sg = a.seg[s];
+    const int kk = (c - a.seg_chunk0[s]) * 16 + 4 * q;
+    const f32x4 w = wp[(int64_t)c * 64];
+    f32x4 x[MT];
+    if (VEC) {
+      const float* xb = (const float*)sg.x.base + seg_off + kk;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        if (kk < sg.K)
+          x[mt] = *reinterpret_cast<const f32x4*>(xb + row[mt] * sg.ld);
+        else
+          x[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    } else {
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) x[mt][i] = seg_load_scalar(sg, seg_off, row[mt], kk + i);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+        acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(x[mt][i], w[i], acc[mt], 0, 0, 0);
+    }
+  }
+
+  // ---- split-K reduction across the workgroup's waves (fixed order) ----------
+  f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+  int mt_out = 0;
+  bool active = true;
+  if (nw > 1) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) red[(wave * MT + mt) * 64 + lane] = acc[mt];
+    __syncthreads();
+    active = (int)threadIdx.x < MT * 64;
+    if (active) {
+      mt_out = threadIdx.x >> 6;
+      for (int w = 0; w < nw; ++w) {
+        f32x4 p = red[(w * MT + mt_out) * 64 + lane];
+        v[0] += p[0]; v[1] += p[1]; v[2] += p[2]; v[3] += p[3];
+      }
+    }
+  }
+
+  // ---- epilogue: lane holds column n, rows 4*(lane>>4)+j ----------------------
+  const int n = tile * 16 + (lane & 15);
+  const float b = (a.bias && n < a.N) ? a.bias[n] : 0.f;
+
+  auto run_epilogue = [&](const f32x4& val, int mt) {
+    const int mbase = m0 + mt * 16 + 4 * (lane >> 4);
+    if (a.epilogue == EPI_GATE) {
+      const int64_t ooff = addr_elems(a.out, tau);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float f = val[j] + b;
+        const float g = __shfl_down(f, 1);
+        const int m = mbase + j;
+        if (!(n & 1) && n < a.N && m < a.M) {
+          float* o = (float*)a.out.base + ooff + (int64_t)m * a.out_ld + (n >> 1);
+          *o = tanhf(f) * sigmoidf_(g);
+        }
+      }
+    } else if (a.epilogue == EPI_RES_SKIP) {
+      if (n < a.n_res) {
+        const int64_t ioff = addr_elems(a.res_in, tau), ooff = addr_elems(a.res_out, tau);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int m = mbase + j;
+          if (m < a.M) {
+            const float xin = ((const float*)a.res_in.base)[ioff + (int64_t)m * a.res_in_ld + n];
+            ((float*)a.res_out.base)[ooff + (int64_t)m * a.res_out_ld + n] = xin + (val[j] + b);
+          }
+        }
+      } else if (n >= a.n_res_pad && n - a.n_res_pad < a.n_skip) {
+        const int ns = n - a.n_res_pad;
+        const int64_t soff = addr_elems(a.skip, tau);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int m = mbase + j;
+          if (m < a.M) {
+            float* sp = (float*)a.skip.base + soff + (int64_t)m * a.skip_ld + ns;
+            const float cv = val[j] + b;
+            *sp = a.skip_first ? cv : cv + *sp;
+          }
+        }
+      }
+    } else {
+      if (n < a.N) {
+        const int64_t ooff = addr_elems(a.out, tau);
+        const int64_t aoff = a.has_add ? addr_elems(a.add, tau) : 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int m = mbase + j;
+          if (m < a.M) {
+            float t = val[j] + b;
+            if (a.has_add) t += ((const float*)a.add.base)[aoff + (int64_t)m * a.add_ld + n];
+            t = apply_act(t, a.act);
+            float* o = (float*)a.out.base + ooff + (int64_t)m * a.out_ld + n;
+            *o = a.accumulate ? (*o + t) : t;
+          }
+        }
+      }
+    }
+  };
+
+  if (nw > 1) {
+    if (active) run_epilogue(v, mt_out);
+  } else {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) run_epilogue(acc[mt], mt);
+  }
+}
+
+static bool seg_vec_ok(const Seg& s) {
+  return s.kind == SEG_F32 && (s.K % 4 == 0) && (s.ld % 4 == 0) && (s.x.slot_stride % 4 == 0) &&
+         ((reinterpret_cast<uintptr_t>(s.x.base) & 15) == 0);
+}
+
+int launch_linear(const LinearArgs& a, hipStream_t stream) {
+  if (a.M <= 0 || a.n_tiles <= 0) return MMK_OK;
+  if (a.nseg < 1 || a.nseg > kMaxSeg) return fail(MMK_ERR_INVALID, "linear: bad segment count %d", a.nseg);
+  bool vec = true;
+  for (int s = 0; s < a.nseg; ++s) vec = vec && seg_vec_ok(a.seg[s]);
+  int mt = a.M <= 16 ? 1 : (a.M <= 32 ? 2 : 4);
+  int nw = 1;
+  // aim for ~2 chunks (32 k-columns) per wave: the kernels are latency-, not issue-bound
+  while (nw < 16 && a.k_chunks >= nw * 4) nw *= 2;
+  dim3 grid(a.n_tiles, (a.M + mt * 16 - 1) / (mt * 16));
+  dim3 block(64 * nw);
+  size_t lds = nw > 1 ? (size_t)nw * mt * 64 * sizeof(f32x4) : 0;
+#define MMK_LAUNCH(MT_, VEC_) \
+  hipLaunchKernelGGL((linear_kernel<MT_, VEC_>), grid, block, lds, stream, a)
+  if (vec) {
+    if (mt == 1) MMK_LAUNCH(1, true);
+    else if (mt == 2) MMK_LAUNCH(2, true);
+    else MMK_LAUNCH(4, true);
+  } else {
+    if (mt == 1) MMK_LAUNCH(1, false);
+    else if (mt == 2) MMK_LAUNCH(2, false);
+    else MMK_LAUNCH(4, false);
+  }
+#undef MMK_LAUNCH
+  MMK_HIP(hipGetLastError());
+  return MMK_OK;
+}
+
+// ---- packing ----------------------------------------------------------------
+int64_t packed_floats(int n_rows, int k_cols) {
+  return round_up(n_rows, 16) * round_up(k_cols, 16);
+}
+
+__global__ void pack_rect_kernel(float* __restrict__ Wp, int k_chunks_total, int row0, int row_step, int n_rows,
+                                 int chunk0, int n_chunks, int K_real, const float* __restrict__ src,
+                                 int64_t rs, int64_t cs) {
+  const int64_t total = (int64_t)n_rows * n_chunks * 16;
+  for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const int rr = (int)(idx / (n_chunks * 16));
+    const int kk = (int)(idx % (n_chunks * 16));
+    const int prow = row0 + rr * row_step;
+    const int tile = prow >> 4, rin = prow & 15;
+    const int c = chunk0 + (kk >> 4);
+    const int k16 = kk & 15;
+    const int lane = (k16 >> 2) * 16 + rin;
+    const float val = kk < K_real ? src[rr * rs + kk * cs] : 0.f;
+    Wp[(((int64_t)tile * k_chunks_total + c) * 64 + lane) * 4 + (k16 & 3)] = val;
+  }
+}
+
+int pack_rect(float* Wp, int k_chunks_total, int row0, int row_step, int n_rows, int chunk0, int K_real,
+              const float* src, int64_t src_row_stride, int64_t src_col_stride, hipStream_t stream) {
+  const int n_chunks = (K_real + 15) / 16;
+  const int64_t total = (int64_t)n_rows * n_chunks * 16;
+  if (total <= 0) return MMK_OK;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(pack_rect_kernel, dim3(blocks), dim3(256), 0, stream, Wp, k_chunks_total, row0, row_step,
+                     n_rows, chunk0, n_chunks, K_real, src, src_row_stride, src_col_stride);
+  MMK_HIP(hipGetLastError());
+  return MMK_OK;
+}
+
+__global__ void pack_bias_kernel(float* dst, int row0, int row_step, int n_rows, const float* src, int accumulate) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n_rows) {
+    float* d = dst + row0 + i * row_step;
+    *d = accumulate ? (*d + src[i]) : src[i];
+  }
+}
+
+int pack_bias(float* dst, int row0, int row_step, int n_rows, const float* src, int accumulate, hipStream_t stream) {
+  if (n_rows <= 0) return MMK_OK;
+  hipLaunchKernelGGL(pack_bias_kernel, dim3((n_rows + 255) / 256), dim3(256), 0, stream, dst, row0, row_step,
+                     n_rows, src, accumulate);
+  MMK_HIP(hipGetLastError());
+  return MMK_OK;
+}
+
+}  // namespace mmk
+
+// ---- exported building blocks -------------------------------------------------
+extern "C" int64_t mmk_packed_weight_floats(int32_t n_rows, int32_t k_cols) {
+  return mmk::packed_floats(n_rows, k_cols);
+}
+
+extern "C" int mmk_pack_weight_f32(const float* w, int64_t ldw, int32_t n_rows, int32_t k_cols, float* packed,
+                                   mmk_stream_t stream) {
+  using namespace mmk;
+  if (!w || !packed || n_rows <= 0 || k_cols <= 0) return fail(MMK_ERR_INVALID, "pack_weight: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  MMK_HIP(hipMemsetAsync(packed, 0, packed_floats(n_rows, k_cols) * sizeof(float), st));
+  return pack_rect(packed, (k_cols + 15) / 16, 0, 1, n_rows, 0, k_cols, w, ldw, 1, st);
+}
+
+extern "C" int mmk_linear_f32(const float* x, int64_t ldx, int32_t m_rows, const float* packed_w, const float* bias,
+                              int32_t n_rows, int32_t k_cols, float* y, int64_t ldy, int32_t act,
+                              mmk_stream_t stream) {
+  using namespace mmk;
+  if (!x || !packed_w || !y || m_rows <= 0 || n_rows <= 0 || k_cols <= 0)
+    return fail(MMK_ERR_INVALID, "linear: bad arguments");
+  LinearArgs a = {};
+  a.nseg = 1;
+  a.seg[0].x = addr_static(x);
+  a.seg[0].ld = ldx;
+  a.seg[0].K = k_cols;
+  a.seg[0].kind = SEG_F32;
+  a.seg_chunk0[0] = 0;
+  a.seg_chunk0[1] = (k_cols + 15) / 16;
+  a.k_chunks = a.seg_chunk0[1];
+  a.M = m_rows;
+  a.N = n_rows;
+  a.n_tiles = (n_rows + 15) / 16;
+  a.Wp = packed_w;
+  a.bias = bias;
+  a.tau_ptr = nullptr;
+  a.epilogue = EPI_STORE;
+  a.act = act;
+  a.out = addr_static(y);
+  a.out_ld = ldy;
+  return launch_linear(a, (hipStream_t)stream);
+}

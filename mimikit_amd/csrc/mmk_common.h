@@ -1,0 +1,167 @@
+// Shared host/device declarations of libmmk_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+#include <vector>
+
+#include "../../include/mmk.h"
+
+namespace mmk {
+
+// ---- error plumbing ---------------------------------------------------------
+void set_error(const char* fmt, ...);
+int fail(int code, const char* fmt, ...);
+
+#define MMK_HIP(call)                                                                         \
+  do {                                                                                        \
+    hipError_t e__ = (call);                                                                  \
+    if (e__ != hipSuccess)                                                                    \
+      return ::mmk::fail(MMK_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e__), \
+                         __FILE__, __LINE__);                                                 \
+  } while (0)
+
+#define MMK_TRY(expr)            \
+  do {                           \
+    int rc__ = (expr);           \
+    if (rc__ != MMK_OK) return rc__; \
+  } while (0)
+
+static inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
+
+// ---- time-indexed addressing --------------------------------------------------
+// Every step kernel reads the current position `tau` from device memory, so a
+// captured hipGraph can be replayed for any step.  An Addr resolves to
+//   base + (((tau + offset) / div) % mod) * slot_stride        (mod == 0: no wrap)
+// in ELEMENTS of the pointed-to type; static buffers use slot_stride == 0.
+struct Addr {
+  const void* base;
+  int64_t slot_stride;
+  int32_t offset;
+  int32_t div;
+  int32_t mod;
+  int32_t pad_;
+};
+
+static inline Addr addr_static(const void* p) { return Addr{p, 0, 0, 1, 0, 0}; }
+static inline Addr addr_ring(const void* p, int64_t slot_stride, int32_t offset, int32_t mod) {
+  return Addr{p, slot_stride, offset, 1, mod, 0};
+}
+static inline Addr addr_time(const void* p, int64_t slot_stride, int32_t offset, int32_t div, int32_t mod) {
+  return Addr{p, slot_stride, offset, div, mod, 0};
+}
+
+__device__ __forceinline__ int64_t addr_elems(const Addr& a, int64_t tau) {
+  if (a.slot_stride == 0) return 0;
+  int64_t s = tau + a.offset;
+  if (a.div > 1) s /= a.div;
+  if (a.mod > 0) {
+    s %= a.mod;
+    if (s < 0) s += a.mod;  // positions before the start of a warm-up read (zeroed) slots
+  }
+  return s * a.slot_stride;
+}
+
+// ---- activations (match the torch CPU formulas the reference runs) ------------
+enum Act : int32_t { ACT_NONE = 0, ACT_TANH = 1, ACT_SIGMOID = 2, ACT_MISH = 3, ACT_ABS = 4, ACT_RELU = 5 };
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+__device__ __forceinline__ float mishf_(float x) { return x * tanhf(log1pf(expf(x))); }
+
+__device__ __forceinline__ float apply_act(float v, int act) {
+  switch (act) {
+    case ACT_TANH: return tanhf(v);
+    case ACT_SIGMOID: return sigmoidf_(v);
+    case ACT_MISH: return mishf_(v);
+    case ACT_ABS: return fabsf(v);
+    case ACT_RELU: return v > 0.f ? v : 0.f;
+    default: return v;
+  }
+}
+
+// ---- linear (skinny GEMM) kernel interface ------------------------------------
+constexpr int kMaxSeg = 4;
+
+enum SegKind : int32_t { SEG_F32 = 0, SEG_I64_LINEARIZED = 1 };
+
+// One K-segment of the A operand: rows m = 0..M-1 at x + m*ld (+ time slot).
+struct Seg {
+  Addr x;
+  int64_t ld;       // elements between consecutive rows (clips)
+  int32_t K;        // real columns
+  int32_t kind;     // SegKind
+  float class_size; // for SEG_I64_LINEARIZED: ((q / class_size) - .5) * 2   (modules/io.py:106-112)
+  int32_t pad_;
+};
+
+enum Epilogue : int32_t {
+  EPI_STORE = 0,     // y = act(v + bias (+ add))
+  EPI_GATE = 1,      // packed rows interleave (f, g): y[n/2] = tanh(f) * sigmoid(g)   (wavenet_v2.py:151)
+  EPI_RES_SKIP = 2,  // n < n_res: out = res_in + v ; n >= n_res_pad: skip (+)= v      (wavenet_v2.py:165-176)
+};
+
+struct LinearArgs {
+  Seg seg[kMaxSeg];
+  int32_t nseg;
+  int32_t M;            // real rows
+  int32_t N;            // real output columns (packed order)
+  int32_t n_tiles;      // ceil(N_pad / 16)
+  int32_t k_chunks;     // total 16-wide K chunks over all segments
+  int32_t seg_chunk0[kMaxSeg + 1];
+  const float* Wp;      // [n_tiles][k_chunks][64][4]
+  const float* bias;    // packed order, n_tiles*16 floats, or nullptr
+  const int64_t* tau_ptr;
+  int64_t tau_off;
+  int32_t epilogue;
+  int32_t act;
+  // EPI_STORE
+  Addr out; int64_t out_ld;
+  Addr add; int64_t add_ld; int32_t has_add; int32_t accumulate;
+  // EPI_GATE: out/out_ld receive N/2 columns
+  // EPI_RES_SKIP
+  int32_t n_res;        // real residual rows (0: none)
+  int32_t n_res_pad;    // packed row where the skip rows start
+  int32_t n_skip;       // real skip rows (0: none)
+  int32_t skip_first;   // overwrite instead of accumulate
+  Addr res_in; int64_t res_in_ld;
+  Addr res_out; int64_t res_out_ld;
+  Addr skip; int64_t skip_ld;
+};
+
+int launch_linear(const LinearArgs& a, hipStream_t stream);
+
+// packing helpers (device side, enqueue on stream)
+int64_t packed_floats(int n_rows, int k_cols);
+// writes rows [row0 + r*row_step) r<n_rows, k-chunks starting at chunk0 of a packed matrix with k_chunks total
+int pack_rect(float* Wp, int k_chunks_total, int row0, int row_step, int n_rows, int chunk0, int K_real,
+              const float* src, int64_t src_row_stride, int64_t src_col_stride, hipStream_t stream);
+int pack_bias(float* dst, int row0, int row_step, int n_rows, const float* src, int accumulate, hipStream_t stream);
+
+// small kernels
+int launch_embed(const int64_t* idx, int64_t idx_row_stride, int64_t idx_tau_off, const float* table, int C,
+                 int q_levels, Addr out, int64_t out_ld, int M, const int64_t* tau_ptr, int64_t tau_off,
+                 hipStream_t stream);
+int launch_bump(int64_t* tau_ptr, int64_t inc, hipStream_t stream);
+int launch_set_i64(int64_t* p, int64_t v, hipStream_t stream);
+int launch_copy_rows(Addr src, int64_t src_ld, Addr dst, int64_t dst_ld, int M, int C, const int64_t* tau_ptr,
+                     int64_t tau_off, hipStream_t stream);
+int launch_fill(float* p, float v, int64_t n, hipStream_t stream);
+
+struct SampleArgs {
+  const float* logits; int64_t ld; int32_t rows; int32_t n_classes; int32_t has_temp_col; float min_temp;
+  const float* temperature;     // nullptr: argmax
+  const float* uniforms;        // [rows][uniform_ld], column = (tau + uni_off)
+  int64_t uniform_ld; int64_t uni_off;
+  int64_t* out; int64_t out_row_stride; int64_t out_tau_off;  // out[r*stride + tau + out_tau_off]
+  const int64_t* tau_ptr; int64_t tau_off;
+};
+int launch_sample(const SampleArgs& a, hipStream_t stream);
+
+// recurrent cells (elementwise)
+int launch_gru_cell(const float* gi, const float* gh, float* h, int M, int H, hipStream_t stream);
+int launch_lstm_cell(const float* gates, int64_t gates_ld, const float* gadd, int64_t gadd_ld, float* h, int64_t h_ld,
+                     float* c, int64_t c_ld, float* y, int64_t y_ld, int M, int H, hipStream_t stream);
+int launch_rnn_tanh_cell(const float* g, float* h, int M, int H, hipStream_t stream);
+
+}  // namespace mmk

@@ -1,0 +1,286 @@
+// Seq2SeqLSTMNetwork generate plan (host side).
+//
+// Reference: Seq2SeqLSTMNetwork.forward/decode (s2s_lstm_v2.py:246-253),
+// EncoderLSTM.forward (:93-113, edge_sum down-sampling), DecoderLSTM.forward
+// (:155-179, linear_resample up-sampling).  One generate_step maps hop input
+// frames to hop output frames through two bidirectional LSTMs:
+//   - input projections of all hop frames are one GEMM (M = batch*hop),
+//   - the 2*hop recurrent steps are skinny GEMMs + a fused LSTM cell,
+//   - the "[fwd|bwd].view(.., D, 2).sum(-1)" of the reference pairs ADJACENT
+//     channels of the concatenation (:100, :174); reproduced literally.
+#include "plan_util.h"
+
+using namespace mmk;
+
+namespace {
+
+// gather a strided (batch, hop, dim) window into rows (b*hop + t) of a padded buffer
+__global__ void gather_frames_kernel(const float* __restrict__ x, int64_t bs, int64_t fs, int hop, int dim,
+                                     float* __restrict__ out, int out_ld) {
+  const int row = blockIdx.x;  // b*hop + t
+  const int b = row / hop, t = row % hop;
+  const float* src = x + b * bs + t * fs;
+  float* dst = out + (int64_t)row * out_ld;
+  for (int c = threadIdx.x; c < out_ld; c += blockDim.x) dst[c] = c < dim ? src[c] : 0.f;
+}
+
+// scatter rows (b*hop + t) to a strided (batch, n_out<=hop, dim) destination
+__global__ void scatter_frames_kernel(const float* __restrict__ in, int in_ld, int hop, int n_out, int dim,
+                                      float* __restrict__ y, int64_t bs, int64_t fs) {
+  const int row = blockIdx.x;
+  const int b = row / hop, t = row % hop;
+  if (t >= n_out) return;
+  const float* src = in + (int64_t)row * in_ld;
+  float* dst = y + b * bs + t * fs;
+  for (int c = threadIdx.x; c < dim; c += blockDim.x) dst[c] = src[c];
+}
+
+// y'[r][c] = cat(f, b)[r][2c] + cat(f, b)[r][2c+1]                (s2s_lstm_v2.py:100)
+__device__ __forceinline__ float cat_at(const float* f, const float* b, int D, int i) { return i < D ? f[i] : b[i - D]; }
+
+__global__ void pair_sum_kernel(const float* __restrict__ of, const float* __restrict__ ob, int D, int rows,
+                                float* __restrict__ out) {
+  const int r = blockIdx.x;
+  if (r >= rows) return;
+  const float* f = of + (int64_t)r * D;
+  const float* b = ob + (int64_t)r * D;
+  for (int c = threadIdx.x; c < D; c += blockDim.x) out[(int64_t)r * D + c] = cat_at(f, b, D, 2 * c) + cat_at(f, b, D, 2 * c + 1);
+}
+
+// edge_sum: unfold(1, hop, hop)[..., [0, -1]].sum(-1) of the pair-summed output   (:108-112)
+__global__ void edge_pair_sum_kernel(const float* __restrict__ of, const float* __restrict__ ob, int D, int hop,
+                                     float* __restrict__ out) {
+  const int bidx = blockIdx.x;
+  const float* f0 = of + (int64_t)(bidx * hop) * D;
+  const float* b0 = ob + (int64_t)(bidx * hop) * D;
+  const float* f1 = of + (int64_t)(bidx * hop + hop - 1) * D;
+  const float* b1 = ob + (int64_t)(bidx * hop + hop - 1) * D;
+  for (int c = threadIdx.x; c < D; c += blockDim.x) {
+    const float first = cat_at(f0, b0, D, 2 * c) + cat_at(f0, b0, D, 2 * c + 1);
+    const float last = cat_at(f1, b1, D, 2 * c) + cat_at(f1, b1, D, 2 * c + 1);
+    out[(int64_t)bidx * D + c] = first + last;
+  }
+}
+
+}  // namespace
+
+struct BiLstm {
+  PackedLinear ih[2], hh[2];  // [fwd, reverse]
+};
+
+struct mmk_s2s_plan {
+  mmk_s2s_config cfg;
+  Binder binder;
+  bool committed = false;
+  int D = 0, hop = 0, Bmax = 0, in_pad = 0, out_pad = 0;
+  BiLstm enc, dec;
+  PackedLinear fc_out, dec_fc, out_lin;
+  float *xin = nullptr, *gi[2] = {nullptr, nullptr}, *gates = nullptr;
+  float *h[2] = {nullptr, nullptr}, *c[2] = {nullptr, nullptr};
+  float *of = nullptr, *ob = nullptr, *es = nullptr, *coded = nullptr, *z = nullptr, *ysum = nullptr, *yout = nullptr;
+
+  void layout(Carver& cv) {
+    for (int d = 0; d < 2; ++d) { enc.ih[d].carve(cv, true); enc.hh[d].carve(cv, false); }
+    for (int d = 0; d < 2; ++d) { dec.ih[d].carve(cv, true); dec.hh[d].carve(cv, false); }
+    fc_out.carve(cv, false);
+    dec_fc.carve(cv, true);
+    out_lin.carve(cv, true);
+    const int64_t rows = (int64_t)Bmax * hop;
+    xin = cv.take<float>(rows * in_pad);
+    gi[0] = cv.take<float>(rows * 4 * D);
+    gi[1] = cv.take<float>(rows * 4 * D);
+    gates = cv.take<float>((int64_t)Bmax * 4 * D);
+    for (int d = 0; d < 2; ++d) { h[d] = cv.take<float>((int64_t)Bmax * D); c[d] = cv.take<float>((int64_t)Bmax * D); }
+    of = cv.take<float>(rows * D);
+    ob = cv.take<float>(rows * D);
+    es = cv.take<float>((int64_t)Bmax * D);
+    coded = cv.take<float>((int64_t)Bmax * D);
+    z = cv.take<float>(rows * D);
+    ysum = cv.take<float>(rows * D);
+    yout = cv.take<float>(rows * out_pad);
+  }
+};
+
+static int derive(mmk_s2s_plan* p) {
+  const mmk_s2s_config& c = p->cfg;
+  if (c.in_dim < 1 || c.out_dim < 1 || c.model_dim < 1 || c.hop < 1 || c.max_batch < 1) return fail(MMK_ERR_INVALID, "s2s: bad dimensions");
+  if (c.enc_n_lstm != 1 || c.dec_n_lstm != 1) return fail(MMK_ERR_UNSUPPORTED, "s2s: only enc_n_lstm = dec_n_lstm = 1 is covered");
+  if (c.model_dim % 2 != 0) return fail(MMK_ERR_UNSUPPORTED, "s2s: model_dim must be even");
+  p->D = c.model_dim;
+  p->hop = c.hop;
+  p->Bmax = c.max_batch;
+  p->in_pad = (int)round_up(c.in_dim, 4);
+  p->out_pad = (int)round_up(c.out_dim, 4);
+  for (int d = 0; d < 2; ++d) {
+    p->enc.ih[d].set_geometry(4 * p->D, {p->in_pad});
+    p->enc.hh[d].set_geometry(4 * p->D, {p->D});
+    p->dec.ih[d].set_geometry(4 * p->D, {p->D});
+    p->dec.hh[d].set_geometry(4 * p->D, {p->D});
+  }
+  p->fc_out.set_geometry(p->D, {p->D});
+  p->dec_fc.set_geometry(p->hop * p->D, {p->D});
+  p->out_lin.set_geometry(c.out_dim, {p->D});
+  return MMK_OK;
+}
+
+extern "C" int mmk_s2s_plan_create(const mmk_s2s_config* cfg, mmk_s2s_plan** out) {
+  if (!cfg || !out) return fail(MMK_ERR_INVALID, "s2s_plan_create: null argument");
+  mmk_s2s_plan* p = new mmk_s2s_plan();
+  p->cfg = *cfg;
+  int rc = derive(p);
+  if (rc != MMK_OK) {
+    delete p;
+    return rc;
+  }
+  *out = p;
+  return MMK_OK;
+}
+
+extern "C" void mmk_s2s_plan_destroy(mmk_s2s_plan* p) { delete p; }
+
+extern "C" int mmk_s2s_plan_bind(mmk_s2s_plan* p, const char* key, const float* dev_ptr, int64_t numel) {
+  if (!p || !key || !dev_ptr) return fail(MMK_ERR_INVALID, "s2s_plan_bind: null argument");
+  p->binder.bind(key, dev_ptr, numel);
+  p->committed = false;
+  return MMK_OK;
+}
+
+extern "C" size_t mmk_s2s_workspace_bytes(const mmk_s2s_plan* p) {
+  if (!p) return 0;
+  mmk_s2s_plan tmp = *p;
+  Carver c(nullptr);
+  tmp.layout(c);
+  return c.used();
+}
+
+static int pack_lstm(mmk_s2s_plan* p, BiLstm& l, const std::string& base, int in_dim, hipStream_t st) {
+  Binder& b = p->binder;
+  const int D = p->D;
+  const char* sfx[2] = {"", "_reverse"};
+  for (int d = 0; d < 2; ++d) {
+    const float* wih = b.need(base + "weight_ih_l0" + sfx[d], (int64_t)4 * D * in_dim);
+    const float* whh = b.need(base + "weight_hh_l0" + sfx[d], (int64_t)4 * D * D);
+    const float* bih = b.need(base + "bias_ih_l0" + sfx[d], 4 * D);
+    const float* bhh = b.need(base + "bias_hh_l0" + sfx[d], 4 * D);
+    if (wih) MMK_TRY(pack_rect(l.ih[d].Wp, l.ih[d].k_chunks, 0, 1, 4 * D, 0, in_dim, wih, in_dim, 1, st));
+    if (whh) MMK_TRY(pack_rect(l.hh[d].Wp, l.hh[d].k_chunks, 0, 1, 4 * D, 0, D, whh, D, 1, st));
+    if (bih) MMK_TRY(pack_bias(l.ih[d].bias, 0, 1, 4 * D, bih, 0, st));
+    if (bhh) MMK_TRY(pack_bias(l.ih[d].bias, 0, 1, 4 * D, bhh, 1, st));
+  }
+  return MMK_OK;
+}
+
+extern "C" int mmk_s2s_commit(mmk_s2s_plan* p, void* workspace, size_t workspace_bytes, mmk_stream_t stream) {
+  if (!p || !workspace) return fail(MMK_ERR_INVALID, "s2s_commit: null argument");
+  if ((reinterpret_cast<uintptr_t>(workspace) & 255) != 0) return fail(MMK_ERR_WORKSPACE, "s2s_commit: workspace must be 256-byte aligned");
+  hipStream_t st = (hipStream_t)stream;
+  const mmk_s2s_config& c = p->cfg;
+  Carver carve(workspace);
+  p->layout(carve);
+  if (carve.used() > workspace_bytes)
+    return fail(MMK_ERR_WORKSPACE, "s2s_commit: workspace of %zu bytes, %zu needed", workspace_bytes, carve.used());
+  MMK_HIP(hipMemsetAsync(workspace, 0, carve.used(), st));
+  Binder& b = p->binder;
+  b.clear_missing();
+  const int D = p->D;
+  MMK_TRY(pack_lstm(p, p->enc, "enc.lstm.0.", c.in_dim, st));
+  MMK_TRY(pack_lstm(p, p->dec, "dec.lstm.0.", D, st));
+  if (const float* w = b.need("enc.fc_out.weight", (int64_t)D * D))
+    MMK_TRY(pack_rect(p->fc_out.Wp, p->fc_out.k_chunks, 0, 1, D, 0, D, w, D, 1, st));
+  if (const float* w = b.need("dec.fc.fc.weight", (int64_t)p->hop * D * D))
+    MMK_TRY(pack_rect(p->dec_fc.Wp, p->dec_fc.k_chunks, 0, 1, p->hop * D, 0, D, w, D, 1, st));
+  if (const float* bb = b.need("dec.fc.fc.bias", (int64_t)p->hop * D)) MMK_TRY(pack_bias(p->dec_fc.bias, 0, 1, p->hop * D, bb, 0, st));
+  if (const float* w = b.need("output_module.heads.0.0.weight", (int64_t)c.out_dim * D))
+    MMK_TRY(pack_rect(p->out_lin.Wp, p->out_lin.k_chunks, 0, 1, c.out_dim, 0, D, w, D, 1, st));
+  if (const float* bb = b.need("output_module.heads.0.0.bias", c.out_dim)) MMK_TRY(pack_bias(p->out_lin.bias, 0, 1, c.out_dim, bb, 0, st));
+  if (!b.missing().empty()) return fail(MMK_ERR_KEY, "s2s_commit: state_dict tensor %s", b.missing().c_str());
+  p->committed = true;
+  return MMK_OK;
+}
+
+static int plain_linear(const PackedLinear& w, const float* x, int64_t ldx, int M, float* y, int64_t ldy, int act,
+                        hipStream_t st) {
+  LinearArgs a = {};
+  w.fill(a);
+  a.seg[0].x = addr_static(x);
+  a.seg[0].ld = ldx;
+  a.M = M;
+  a.tau_ptr = nullptr;
+  a.epilogue = EPI_STORE;
+  a.act = act;
+  a.out = addr_static(y);
+  a.out_ld = ldy;
+  return launch_linear(a, st);
+}
+
+// one bidirectional LSTM over hop frames; rows of x/of/ob are (b*hop + t)
+static int run_bilstm(mmk_s2s_plan* p, BiLstm& l, const float* x, int x_ld, int M, bool zero_state, hipStream_t st) {
+  const int D = p->D, hop = p->hop;
+  const int64_t rows = (int64_t)M * hop;
+  for (int d = 0; d < 2; ++d) {
+    MMK_TRY(plain_linear(l.ih[d], x, x_ld, (int)rows, p->gi[d], 4 * D, ACT_NONE, st));
+    if (zero_state) {
+      // `lstm(x,)` : fresh zero state on every call                    (s2s_lstm_v2.py:97)
+      MMK_HIP(hipMemsetAsync(p->h[d], 0, (size_t)p->Bmax * D * sizeof(float), st));
+      MMK_HIP(hipMemsetAsync(p->c[d], 0, (size_t)p->Bmax * D * sizeof(float), st));
+    }
+  }
+  for (int s = 0; s < hop; ++s) {
+    for (int d = 0; d < 2; ++d) {
+      const int t = d == 0 ? s : hop - 1 - s;
+      MMK_TRY(plain_linear(l.hh[d], p->h[d], D, M, p->gates, 4 * D, ACT_NONE, st));
+      float* y = (d == 0 ? p->of : p->ob) + (int64_t)t * D;
+      MMK_TRY(launch_lstm_cell(p->gates, 4 * D, p->gi[d] + (int64_t)t * 4 * D, (int64_t)hop * 4 * D, p->h[d], D,
+                               p->c[d], D, y, (int64_t)hop * D, M, D, st));
+    }
+  }
+  return MMK_OK;
+}
+
+static int s2s_step(mmk_s2s_plan* p, int M, const float* x, int64_t xbs, int64_t xfs, float* y, int64_t ybs, int64_t yfs,
+                    int n_out, hipStream_t st) {
+  const mmk_s2s_config& c = p->cfg;
+  const int D = p->D, hop = p->hop;
+  const int rows = M * hop;
+  hipLaunchKernelGGL(gather_frames_kernel, dim3(rows), dim3(256), 0, st, x, xbs, xfs, hop, c.in_dim, p->xin, p->in_pad);
+  MMK_HIP(hipGetLastError());
+  // encoder
+  MMK_TRY(run_bilstm(p, p->enc, p->xin, p->in_pad, M, true, st));
+  hipLaunchKernelGGL(edge_pair_sum_kernel, dim3(M), dim3(256), 0, st, p->of, p->ob, D, hop, p->es);
+  MMK_HIP(hipGetLastError());
+  MMK_TRY(plain_linear(p->fc_out, p->es, D, M, p->coded, D, ACT_NONE, st));
+  // decoder: LinearResampler to hop frames, bi-LSTM seeded with the encoder's (h_n, c_n)  (:158-171)
+  MMK_TRY(plain_linear(p->dec_fc, p->coded, D, M, p->z, (int64_t)hop * D, ACT_NONE, st));
+  MMK_TRY(run_bilstm(p, p->dec, p->z, D, M, false, st));
+  hipLaunchKernelGGL(pair_sum_kernel, dim3(rows), dim3(256), 0, st, p->of, p->ob, D, rows, p->ysum);
+  MMK_HIP(hipGetLastError());
+  MMK_TRY(plain_linear(p->out_lin, p->ysum, D, rows, p->yout, p->out_pad, c.out_abs ? ACT_ABS : ACT_NONE, st));
+  hipLaunchKernelGGL(scatter_frames_kernel, dim3(rows), dim3(256), 0, st, p->yout, p->out_pad, hop, n_out, c.out_dim, y,
+                     ybs, yfs);
+  MMK_HIP(hipGetLastError());
+  return MMK_OK;
+}
+
+extern "C" int mmk_s2s_step(mmk_s2s_plan* p, int32_t batch, const float* x, int64_t x_batch_stride, int64_t x_frame_stride,
+                            float* y, int64_t y_batch_stride, int64_t y_frame_stride, mmk_stream_t stream) {
+  if (!p || !x || !y) return fail(MMK_ERR_INVALID, "s2s_step: null argument");
+  if (!p->committed) return fail(MMK_ERR_STATE, "s2s_step: plan not committed");
+  if (batch < 1 || batch > p->Bmax) return fail(MMK_ERR_INVALID, "s2s_step: batch %d outside [1, %d]", batch, p->Bmax);
+  return s2s_step(p, batch, x, x_batch_stride, x_frame_stride, y, y_batch_stride, y_frame_stride, p->hop, (hipStream_t)stream);
+}
+
+extern "C" int mmk_s2s_generate(mmk_s2s_plan* p, int32_t batch, float* frames, int64_t batch_stride, int64_t frame_stride,
+                                int64_t t0, int64_t n_steps, int64_t t_total, mmk_stream_t stream) {
+  if (!p || !frames) return fail(MMK_ERR_INVALID, "s2s_generate: null argument");
+  if (!p->committed) return fail(MMK_ERR_STATE, "s2s_generate: plan not committed");
+  if (batch < 1 || batch > p->Bmax) return fail(MMK_ERR_INVALID, "s2s_generate: batch %d outside [1, %d]", batch, p->Bmax);
+  if (t0 < p->hop) return fail(MMK_ERR_INVALID, "s2s_generate: t0=%lld is shorter than hop=%d", (long long)t0, p->hop);
+  // loops/generate.py:207-219 : steps covered by the previous call's hop outputs are skipped
+  for (int64_t t = t0; t < t0 + n_steps && t < t_total; t += p->hop) {
+    const int64_t room = t_total - t;
+    const int n_out = (int)(room < p->hop ? room : p->hop);
+    MMK_TRY(s2s_step(p, batch, frames + (t - p->hop) * frame_stride, batch_stride, frame_stride,
+                     frames + t * frame_stride, batch_stride, frame_stride, n_out, (hipStream_t)stream));
+  }
+  return MMK_OK;
+}

@@ -1,0 +1,425 @@
+// SampleRNN generate plan (host side): tier schedule, recurrent state in HBM,
+// per-step launch sequences replayed as hipGraphs of frame_sizes[0] steps.
+//
+// Reference: SampleRNN.generate_step (sample_rnn_v2.py:236-260), the warm-up of
+// before_generate (:226-234) and SampleRNNTier.forward (:83-99).  The device
+// counter holds the step index t (the position being predicted); data windows
+// are idx[:, t+shift-fs : t+shift] with shift = prompt_len % rf during warm-up
+// (the reference slides its window by that offset, :229-234) and 0 afterwards.
+#include "plan_util.h"
+
+using namespace mmk;
+
+struct SrnnCall {
+  int M = 0;
+  const int64_t* idx = nullptr;
+  int64_t idx_rs = 0;
+  int64_t shift = 0;
+  const float* temperature = nullptr;
+  const float* uniforms = nullptr;
+  int64_t uni_ld = 0;
+  int64_t uni_off = 0;
+};
+
+struct SrnnTier {
+  int fs = 0, up = 0;
+  PackedLinear in_lin, gates, gates_hh, up_lin;
+  float *h = nullptr, *c = nullptr, *out = nullptr;
+};
+
+struct mmk_srnn_plan {
+  mmk_srnn_config cfg;
+  Binder binder;
+  bool committed = false;
+  int n_rnn_tiers = 0, H = 0, G = 0, Bmax = 0;
+  std::vector<SrnnTier> tiers;
+  PackedLinear bottom;
+  std::vector<PackedLinear> mlp;
+  float *xbuf = nullptr, *gi = nullptr, *gh = nullptr, *xbot = nullptr, *hid[2] = {nullptr, nullptr}, *logits = nullptr;
+  int logits_ld = 0;
+  int64_t* tau = nullptr;
+  hipStream_t cap_stream = nullptr;
+  GraphCache gc;
+
+  void layout(Carver& c) {
+    const bool bias = cfg.rnn_bias != 0;
+    for (auto& t : tiers) {
+      t.in_lin.carve(c, true);
+      t.gates.carve(c, bias);
+      if (cfg.rnn_kind == 1) t.gates_hh.carve(c, bias);
+      t.up_lin.carve(c, true);
+      t.h = c.take<float>((int64_t)Bmax * H);
+      t.c = c.take<float>((int64_t)Bmax * H);
+      t.out = c.take<float>((int64_t)Bmax * t.up * H);
+    }
+    bottom.carve(c, true);
+    for (auto& m : mlp) m.carve(c, true);
+    xbuf = c.take<float>((int64_t)Bmax * H);
+    gi = c.take<float>((int64_t)Bmax * G * H);
+    gh = c.take<float>((int64_t)Bmax * G * H);
+    xbot = c.take<float>((int64_t)Bmax * H);
+    hid[0] = c.take<float>((int64_t)Bmax * cfg.mlp_hidden);
+    hid[1] = c.take<float>((int64_t)Bmax * cfg.mlp_hidden);
+    logits_ld = (int)round_up(cfg.q_levels + (cfg.learn_temp ? 1 : 0), 4);
+    logits = c.take<float>((int64_t)Bmax * logits_ld);
+    tau = c.take<int64_t>(32);
+  }
+};
+
+static int derive(mmk_srnn_plan* p) {
+  const mmk_srnn_config& c = p->cfg;
+  if (c.n_tiers < 2 || c.n_tiers > MMK_MAX_TIERS) return fail(MMK_ERR_INVALID, "srnn: n_tiers=%d outside [2, %d]", c.n_tiers, MMK_MAX_TIERS);
+  if (c.hidden_dim < 1 || c.max_batch < 1 || c.q_levels < 2) return fail(MMK_ERR_INVALID, "srnn: bad hidden_dim / max_batch / q_levels");
+  if (c.rnn_kind < 0 || c.rnn_kind > 2) return fail(MMK_ERR_INVALID, "srnn: rnn_kind %d unknown", c.rnn_kind);
+  if (c.mlp_hidden < 1 || c.mlp_n_hidden < 0 || c.mlp_n_hidden > MMK_MAX_MLP_HIDDEN) return fail(MMK_ERR_INVALID, "srnn: bad MLP head geometry");
+  p->H = c.hidden_dim;
+  p->Bmax = c.max_batch;
+  p->G = c.rnn_kind == 0 ? 4 : (c.rnn_kind == 1 ? 3 : 1);
+  p->n_rnn_tiers = c.n_tiers - 1;
+  p->tiers.resize(p->n_rnn_tiers);
+  for (int i = 0; i < p->n_rnn_tiers; ++i) {
+    SrnnTier& t = p->tiers[i];
+    t.fs = c.frame_size[i];
+    const int next = (i < c.n_tiers - 2) ? c.frame_size[i + 1] : 1;  // from_config, sample_rnn_v2.py:155-158
+    if (t.fs < 1 || next < 1 || t.fs % next != 0)
+      return fail(MMK_ERR_INVALID, "srnn: frame_sizes[%d]=%d is not a multiple of the next tier's %d", i, t.fs, next);
+    if (c.frame_size[0] % t.fs != 0)
+      return fail(MMK_ERR_UNSUPPORTED, "srnn: frame_sizes[%d]=%d does not divide frame_sizes[0]=%d", i, t.fs, c.frame_size[0]);
+    t.up = t.fs / next;
+    t.in_lin.set_geometry(p->H, {t.fs});
+    if (c.rnn_kind == 1) {
+      t.gates.set_geometry(3 * p->H, {p->H});
+      t.gates_hh.set_geometry(3 * p->H, {p->H});
+    } else {
+      t.gates.set_geometry(p->G * p->H, {p->H, p->H});
+    }
+    t.up_lin.set_geometry(p->H * t.up, {p->H});
+  }
+  if (c.frame_size[c.n_tiers - 1] < 1) return fail(MMK_ERR_INVALID, "srnn: bad bottom frame size");
+  p->bottom.set_geometry(p->H, {c.frame_size[c.n_tiers - 1]});
+  p->mlp.clear();
+  PackedLinear first;
+  first.set_geometry(c.mlp_hidden, {p->H});
+  p->mlp.push_back(first);
+  for (int i = 0; i < c.mlp_n_hidden; ++i) {
+    PackedLinear h;
+    h.set_geometry(c.mlp_hidden, {c.mlp_hidden});
+    p->mlp.push_back(h);
+  }
+  PackedLinear last;
+  last.set_geometry(c.q_levels + (c.learn_temp ? 1 : 0), {c.mlp_hidden});
+  p->mlp.push_back(last);
+  return MMK_OK;
+}
+
+extern "C" int mmk_srnn_plan_create(const mmk_srnn_config* cfg, mmk_srnn_plan** out) {
+  if (!cfg || !out) return fail(MMK_ERR_INVALID, "srnn_plan_create: null argument");
+  mmk_srnn_plan* p = new mmk_srnn_plan();
+  p->cfg = *cfg;
+  int rc = derive(p);
+  if (rc != MMK_OK) {
+    delete p;
+    return rc;
+  }
+  *out = p;
+  return MMK_OK;
+}
+
+extern "C" void mmk_srnn_plan_destroy(mmk_srnn_plan* p) {
+  if (!p) return;
+  p->gc.reset();
+  if (p->cap_stream) (void)hipStreamDestroy(p->cap_stream);
+  delete p;
+}
+
+extern "C" int mmk_srnn_plan_bind(mmk_srnn_plan* p, const char* key, const float* dev_ptr, int64_t numel) {
+  if (!p || !key || !dev_ptr) return fail(MMK_ERR_INVALID, "srnn_plan_bind: null argument");
+  p->binder.bind(key, dev_ptr, numel);
+  p->committed = false;
+  return MMK_OK;
+}
+
+extern "C" size_t mmk_srnn_workspace_bytes(const mmk_srnn_plan* p) {
+  if (!p) return 0;
+  mmk_srnn_plan tmp = *p;
+  tmp.gc = GraphCache();
+  tmp.cap_stream = nullptr;
+  Carver c(nullptr);
+  tmp.layout(c);
+  return c.used();
+}
+
+extern "C" int mmk_srnn_reset(mmk_srnn_plan* p, mmk_stream_t stream) {
+  if (!p || !p->committed) return fail(MMK_ERR_STATE, "srnn_reset: plan not committed");
+  hipStream_t st = (hipStream_t)stream;
+  for (auto& t : p->tiers) {
+    // h0_init zeros / ones (SampleRNNTier._init_h0, sample_rnn_v2.py:118-119)
+    MMK_TRY(launch_fill(t.h, p->cfg.h0_ones ? 1.f : 0.f, (int64_t)p->Bmax * p->H, st));
+    MMK_TRY(launch_fill(t.c, p->cfg.h0_ones ? 1.f : 0.f, (int64_t)p->Bmax * p->H, st));
+    MMK_HIP(hipMemsetAsync(t.out, 0, (size_t)p->Bmax * t.up * p->H * sizeof(float), st));
+  }
+  return MMK_OK;
+}
+
+extern "C" int mmk_srnn_commit(mmk_srnn_plan* p, void* workspace, size_t workspace_bytes, mmk_stream_t stream) {
+  if (!p || !workspace) return fail(MMK_ERR_INVALID, "srnn_commit: null argument");
+  if ((reinterpret_cast<uintptr_t>(workspace) & 255) != 0) return fail(MMK_ERR_WORKSPACE, "srnn_commit: workspace must be 256-byte aligned");
+  hipStream_t st = (hipStream_t)stream;
+  const mmk_srnn_config& c = p->cfg;
+  Carver carve(workspace);
+  p->layout(carve);
+  if (carve.used() > workspace_bytes)
+    return fail(MMK_ERR_WORKSPACE, "srnn_commit: workspace of %zu bytes, %zu needed", workspace_bytes, carve.used());
+  p->gc.reset();
+  MMK_HIP(hipMemsetAsync(workspace, 0, carve.used(), st));
+  Binder& b = p->binder;
+  b.clear_missing();
+  const int H = p->H, G = p->G;
+  const bool bias = c.rnn_bias != 0;
+  for (int i = 0; i < p->n_rnn_tiers; ++i) {
+    SrnnTier& t = p->tiers[i];
+    const std::string tb = "tiers." + std::to_string(i) + ".";
+    // input_module = ZipReduceVariables([Sequential(Linearizer, Unfold, Linear)])  -> heads.0.2
+    const float* w = b.need(tb + "input_module.heads.0.2.weight", (int64_t)H * t.fs);
+    const float* bb = b.need(tb + "input_module.heads.0.2.bias", H);
+    if (w) MMK_TRY(pack_rect(t.in_lin.Wp, t.in_lin.k_chunks, 0, 1, H, 0, t.fs, w, t.fs, 1, st));
+    if (bb) MMK_TRY(pack_bias(t.in_lin.bias, 0, 1, H, bb, 0, st));
+    const float* wih = b.need(tb + "rnn.weight_ih_l0", (int64_t)G * H * H);
+    const float* whh = b.need(tb + "rnn.weight_hh_l0", (int64_t)G * H * H);
+    const float* bih = bias ? b.need(tb + "rnn.bias_ih_l0", (int64_t)G * H) : nullptr;
+    const float* bhh = bias ? b.need(tb + "rnn.bias_hh_l0", (int64_t)G * H) : nullptr;
+    if (c.rnn_kind == 1) {
+      if (wih) MMK_TRY(pack_rect(t.gates.Wp, t.gates.k_chunks, 0, 1, G * H, 0, H, wih, H, 1, st));
+      if (whh) MMK_TRY(pack_rect(t.gates_hh.Wp, t.gates_hh.k_chunks, 0, 1, G * H, 0, H, whh, H, 1, st));
+      if (bih) MMK_TRY(pack_bias(t.gates.bias, 0, 1, G * H, bih, 0, st));
+      if (bhh) MMK_TRY(pack_bias(t.gates_hh.bias, 0, 1, G * H, bhh, 0, st));
+    } else {
+      if (wih) MMK_TRY(pack_rect(t.gates.Wp, t.gates.k_chunks, 0, 1, G * H, t.gates.seg_chunk0[0], H, wih, H, 1, st));
+      if (whh) MMK_TRY(pack_rect(t.gates.Wp, t.gates.k_chunks, 0, 1, G * H, t.gates.seg_chunk0[1], H, whh, H, 1, st));
+      if (bih) MMK_TRY(pack_bias(t.gates.bias, 0, 1, G * H, bih, 0, st));
+      if (bhh) MMK_TRY(pack_bias(t.gates.bias, 0, 1, G * H, bhh, 1, st));
+    }
+    const float* wu = b.need(tb + "up_sampler.fc.weight", (int64_t)H * t.up * H);
+    const float* bu = b.need(tb + "up_sampler.fc.bias", (int64_t)H * t.up);
+    if (wu) MMK_TRY(pack_rect(t.up_lin.Wp, t.up_lin.k_chunks, 0, 1, H * t.up, 0, H, wu, H, 1, st));
+    if (bu) MMK_TRY(pack_bias(t.up_lin.bias, 0, 1, H * t.up, bu, 0, st));
+  }
+  {
+    // bottom tier: FramedConv1dIO -> heads.0 = Sequential(Linearizer, Unfold, Sequential(Flatten, Unsqueeze, Conv1dResampler))
+    const int fsl = c.frame_size[c.n_tiers - 1];
+    const std::string tb = "tiers." + std::to_string(c.n_tiers - 1) + ".input_module.heads.0.2.2.cv.";
+    const float* w = b.need(tb + "weight", (int64_t)H * fsl);
+    const float* bb = b.need(tb + "bias", H);
+    if (w) MMK_TRY(pack_rect(p->bottom.Wp, p->bottom.k_chunks, 0, 1, H, 0, fsl, w, fsl, 1, st));
+    if (bb) MMK_TRY(pack_bias(p->bottom.bias, 0, 1, H, bb, 0, st));
+  }
+  for (size_t i = 0; i < p->mlp.size(); ++i) {
+    PackedLinear& m = p->mlp[i];
+    const std::string kb = "output_modules.0.estimator.0.fc." + std::to_string(2 * i) + ".";
+    const float* w = b.need(kb + "weight", (int64_t)m.N * m.segK[0]);
+    const float* bb = b.need(kb + "bias", m.N);
+    if (w) MMK_TRY(pack_rect(m.Wp, m.k_chunks, 0, 1, m.N, 0, m.segK[0], w, m.segK[0], 1, st));
+    if (bb) MMK_TRY(pack_bias(m.bias, 0, 1, m.N, bb, 0, st));
+  }
+  if (!b.missing().empty()) return fail(MMK_ERR_KEY, "srnn_commit: state_dict tensor %s", b.missing().c_str());
+  if (!p->cap_stream) MMK_HIP(hipStreamCreateWithFlags(&p->cap_stream, hipStreamNonBlocking));
+  p->committed = true;
+  return mmk_srnn_reset(p, stream);
+}
+
+// enqueue step t = *tau + tau_off, whose residue modulo frame_sizes[0] is `phase`
+static int emit_step(mmk_srnn_plan* p, const SrnnCall& call, int64_t tau_off, int phase, bool with_bottom, hipStream_t st) {
+  const mmk_srnn_config& c = p->cfg;
+  const int H = p->H, G = p->G, M = call.M;
+  for (int i = 0; i < p->n_rnn_tiers; ++i) {
+    SrnnTier& t = p->tiers[i];
+    if (phase % t.fs != 0) continue;  // `if t % fs[i] == 0`, sample_rnn_v2.py:246
+    {
+      LinearArgs a = {};
+      t.in_lin.fill(a);
+      a.seg[0].x = addr_time(call.idx, 1, (int32_t)(call.shift - t.fs), 1, 0);
+      a.seg[0].ld = call.idx_rs;
+      a.seg[0].kind = SEG_I64_LINEARIZED;
+      a.seg[0].class_size = (float)c.q_levels;
+      a.M = M; a.tau_ptr = p->tau; a.tau_off = tau_off;
+      a.epilogue = EPI_STORE; a.act = ACT_NONE;
+      a.out = addr_static(p->xbuf); a.out_ld = H;
+      if (i > 0) {
+        // outputs[i-1][:, (t // fs[i]) % (fs[i-1] // fs[i])]      (:251)
+        SrnnTier& up = p->tiers[i - 1];
+        a.has_add = 1;
+        a.add = addr_time(up.out, H, 0, t.fs, up.fs / t.fs);
+        a.add_ld = (int64_t)up.up * H;
+      }
+      MMK_TRY(launch_linear(a, st));
+    }
+    if (c.rnn_kind == 1) {
+      LinearArgs a = {};
+      t.gates.fill(a);
+      a.seg[0].x = addr_static(p->xbuf); a.seg[0].ld = H;
+      a.M = M; a.tau_ptr = p->tau; a.tau_off = tau_off;
+      a.epilogue = EPI_STORE; a.act = ACT_NONE;
+      a.out = addr_static(p->gi); a.out_ld = 3 * H;
+      MMK_TRY(launch_linear(a, st));
+      LinearArgs hh = {};
+      t.gates_hh.fill(hh);
+      hh.seg[0].x = addr_static(t.h); hh.seg[0].ld = H;
+      hh.M = M; hh.tau_ptr = p->tau; hh.tau_off = tau_off;
+      hh.epilogue = EPI_STORE; hh.act = ACT_NONE;
+      hh.out = addr_static(p->gh); hh.out_ld = 3 * H;
+      MMK_TRY(launch_linear(hh, st));
+      MMK_TRY(launch_gru_cell(p->gi, p->gh, t.h, M, H, st));
+    } else {
+      LinearArgs a = {};
+      t.gates.fill(a);
+      a.seg[0].x = addr_static(p->xbuf); a.seg[0].ld = H;
+      a.seg[1].x = addr_static(t.h); a.seg[1].ld = H;
+      a.M = M; a.tau_ptr = p->tau; a.tau_off = tau_off;
+      a.epilogue = EPI_STORE; a.act = ACT_NONE;
+      a.out = addr_static(p->gi); a.out_ld = (int64_t)G * H;
+      MMK_TRY(launch_linear(a, st));
+      if (c.rnn_kind == 0)
+        MMK_TRY(launch_lstm_cell(p->gi, 4 * H, nullptr, 0, t.h, H, t.c, H, nullptr, 0, M, H, st));
+      else
+        MMK_TRY(launch_rnn_tanh_cell(p->gi, t.h, M, H, st));
+    }
+    {
+      LinearArgs a = {};
+      t.up_lin.fill(a);
+      a.seg[0].x = addr_static(t.h); a.seg[0].ld = H;
+      a.M = M; a.tau_ptr = p->tau; a.tau_off = tau_off;
+      a.epilogue = EPI_STORE; a.act = ACT_NONE;
+      a.out = addr_static(t.out); a.out_ld = (int64_t)t.up * H;
+      MMK_TRY(launch_linear(a, st));
+    }
+  }
+  if (!with_bottom) return MMK_OK;
+  {
+    const int fsl = c.frame_size[c.n_tiers - 1];
+    SrnnTier& up = p->tiers[p->n_rnn_tiers - 1];
+    LinearArgs a = {};
+    p->bottom.fill(a);
+    a.seg[0].x = addr_time(call.idx, 1, (int32_t)(call.shift - fsl), 1, 0);
+    a.seg[0].ld = call.idx_rs;
+    a.seg[0].kind = SEG_I64_LINEARIZED;
+    a.seg[0].class_size = (float)c.q_levels;
+    a.M = M; a.tau_ptr = p->tau; a.tau_off = tau_off;
+    a.epilogue = EPI_STORE; a.act = ACT_NONE;
+    a.out = addr_static(p->xbot); a.out_ld = H;
+    a.has_add = 1;  // outputs[-1][:, (t % fs[-2]) - fs[-2]]   (:257)
+    a.add = addr_time(up.out, H, 0, 1, up.fs);
+    a.add_ld = (int64_t)up.up * H;
+    MMK_TRY(launch_linear(a, st));
+  }
+  const float* x = p->xbot;
+  int x_ld = H;
+  for (size_t i = 0; i < p->mlp.size(); ++i) {
+    const bool last = (i + 1 == p->mlp.size());
+    LinearArgs a = {};
+    p->mlp[i].fill(a);
+    a.seg[0].x = addr_static(x); a.seg[0].ld = x_ld;
+    a.M = M; a.tau_ptr = p->tau; a.tau_off = tau_off;
+    a.epilogue = EPI_STORE; a.act = last ? ACT_NONE : ACT_MISH;
+    float* o = last ? p->logits : p->hid[i & 1];
+    a.out = addr_static(o);
+    a.out_ld = last ? p->logits_ld : c.mlp_hidden;
+    MMK_TRY(launch_linear(a, st));
+    x = o;
+    x_ld = (int)a.out_ld;
+  }
+  SampleArgs s = {};
+  s.logits = p->logits; s.ld = p->logits_ld; s.rows = M; s.n_classes = c.q_levels; s.has_temp_col = c.learn_temp;
+  s.min_temp = c.min_temp; s.temperature = call.temperature; s.uniforms = call.uniforms;
+  s.uniform_ld = call.uni_ld; s.uni_off = call.uni_off;
+  s.out = const_cast<int64_t*>(call.idx); s.out_row_stride = call.idx_rs; s.out_tau_off = 0;
+  s.tau_ptr = p->tau; s.tau_off = tau_off;
+  return launch_sample(s, st);
+}
+
+static int run_steps(mmk_srnn_plan* p, const SrnnCall& call, int64_t t_begin, int64_t n, bool with_bottom, hipStream_t st) {
+  if (n <= 0) return MMK_OK;
+  const int period = p->cfg.frame_size[0];
+  MMK_TRY(launch_set_i64(p->tau, t_begin, st));
+  int64_t done = 0;
+  const int phase0 = (int)(t_begin % period);
+  if (n >= 2 * period) {
+    std::vector<int64_t> key = {call.M, (int64_t)(uintptr_t)call.idx, call.idx_rs, call.shift, with_bottom ? 1 : 0,
+                                (int64_t)(uintptr_t)call.temperature, (int64_t)(uintptr_t)call.uniforms, call.uni_ld,
+                                call.uni_off, phase0};
+    if (!p->gc.exec || p->gc.key != key) {
+      MMK_HIP(hipStreamSynchronize(st));
+      p->gc.reset();
+      MMK_HIP(hipStreamBeginCapture(p->cap_stream, hipStreamCaptureModeThreadLocal));
+      int rc = MMK_OK;
+      for (int s = 0; s < period && rc == MMK_OK; ++s)
+        rc = emit_step(p, call, s, (phase0 + s) % period, with_bottom, p->cap_stream);
+      if (rc == MMK_OK) rc = launch_bump(p->tau, period, p->cap_stream);
+      hipGraph_t g = nullptr;
+      hipError_t e = hipStreamEndCapture(p->cap_stream, &g);
+      if (rc != MMK_OK) {
+        if (g) (void)hipGraphDestroy(g);
+        return rc;
+      }
+      if (e != hipSuccess) return fail(MMK_ERR_HIP, "hipStreamEndCapture failed: %s", hipGetErrorString(e));
+      p->gc.graph = g;
+      MMK_HIP(hipGraphInstantiate(&p->gc.exec, g, nullptr, nullptr, 0));
+      p->gc.key = key;
+      p->gc.steps = period;
+    }
+    const int64_t reps = n / period;
+    for (int64_t r = 0; r < reps; ++r) MMK_HIP(hipGraphLaunch(p->gc.exec, st));
+    done = reps * period;
+  }
+  for (int64_t s = done; s < n; ++s)
+    MMK_TRY(emit_step(p, call, s - done, (int)((t_begin + s) % period), with_bottom, st));
+  if (n > done) MMK_TRY(launch_bump(p->tau, n - done, st));
+  return MMK_OK;
+}
+
+static int check_call(mmk_srnn_plan* p, int32_t batch, const int64_t* idx, SrnnCall& call) {
+  if (!p) return fail(MMK_ERR_INVALID, "srnn: null plan");
+  if (!p->committed) return fail(MMK_ERR_STATE, "srnn: plan not committed (bind weights, then mmk_srnn_commit)");
+  if (batch < 1 || batch > p->Bmax) return fail(MMK_ERR_INVALID, "srnn: batch %d outside [1, %d]", batch, p->Bmax);
+  if (!idx) return fail(MMK_ERR_INVALID, "srnn: null input");
+  call.M = batch;
+  call.idx = idx;
+  return MMK_OK;
+}
+
+extern "C" int mmk_srnn_warmup(mmk_srnn_plan* p, int32_t batch, const int64_t* idx, int64_t idx_row_stride,
+                               int64_t prompt_len, mmk_stream_t stream) {
+  SrnnCall call;
+  MMK_TRY(check_call(p, batch, idx, call));
+  call.idx_rs = idx_row_stride;
+  const int64_t rf = p->cfg.frame_size[0];
+  if (prompt_len < rf) return fail(MMK_ERR_INVALID, "srnn_warmup: prompt of %lld steps is shorter than rf=%lld", (long long)prompt_len, (long long)rf);
+  const int64_t offset = prompt_len % rf;     // :230
+  const int64_t stop = prompt_len - offset;   // self.prompt_length, :231
+  call.shift = offset;
+  // for t in range(rf, prompt_length): generate_step(window shifted by offset, t=t)   (:233-234)
+  return run_steps(p, call, rf, stop - rf, false, (hipStream_t)stream);
+}
+
+extern "C" int mmk_srnn_generate(mmk_srnn_plan* p, int32_t batch, int64_t* idx, int64_t idx_row_stride, int64_t t0,
+                                 int64_t n_steps, const float* temperature, const float* uniforms, mmk_stream_t stream) {
+  SrnnCall call;
+  MMK_TRY(check_call(p, batch, idx, call));
+  call.idx_rs = idx_row_stride;
+  if (t0 < p->cfg.frame_size[0] || n_steps < 0) return fail(MMK_ERR_INVALID, "srnn_generate: t0 must be >= rf and n_steps >= 0");
+  if (temperature && !uniforms) return fail(MMK_ERR_INVALID, "srnn_generate: temperature given without uniforms");
+  call.shift = 0;
+  call.temperature = temperature;
+  call.uniforms = uniforms;
+  call.uni_ld = n_steps;
+  call.uni_off = -t0;
+  return run_steps(p, call, t0, n_steps, true, (hipStream_t)stream);
+}
+
+extern "C" int mmk_srnn_last_logits(mmk_srnn_plan* p, int32_t batch, float* out, int64_t ld, mmk_stream_t stream) {
+  if (!p || !out) return fail(MMK_ERR_INVALID, "srnn_last_logits: null argument");
+  if (!p->committed) return fail(MMK_ERR_STATE, "srnn_last_logits: plan not committed");
+  const int n = p->cfg.q_levels + (p->cfg.learn_temp ? 1 : 0);
+  MMK_HIP(hipMemcpy2DAsync(out, ld * sizeof(float), p->logits, p->logits_ld * sizeof(float), n * sizeof(float), batch,
+                           hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  return MMK_OK;
+}

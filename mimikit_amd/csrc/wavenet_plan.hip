@@ -1,0 +1,530 @@
+// WaveNet generate plan (host side): dilation-queue state in HBM, per-step launch
+// sequence built from the fused linear kernels, hipGraph replay of step blocks.
+//
+// Reference algorithm: WaveNet.generate_step == WaveNet.forward over the
+// rf-long window (wavenet_v2.py:276-293, :447-452) -- every step recomputes all
+// rf positions.  Here each layer keeps a queue of its own past inputs
+// (ring of (k-1)*d+1 slots), so a step touches every layer once:
+//   z   = sum_j W[:,:,j] . h_l[tau-(k-1-j)d] + sum_c W1x1_c . cond_c[tau] + b   (:141-150)
+//   y   = tanh(z_f) * sigmoid(z_g)                                               (:151)
+//   skp = Wskip . y + b (+ skp) ; h_{l+1}[tau] = h_l[tau] + Wres . y + b         (:165-176)
+// which is the same arithmetic on the same operands as the window form.
+#include "plan_util.h"
+
+using namespace mmk;
+
+struct WnCall {
+  int M = 0;
+  const void* in0 = nullptr;
+  int64_t in0_rs = 0;
+  const float* cond[MMK_MAX_COND] = {nullptr, nullptr, nullptr, nullptr};
+  int64_t cond_rs[MMK_MAX_COND] = {0, 0, 0, 0};
+  const float* temperature = nullptr;
+  const float* uniforms = nullptr;
+  int64_t uni_ld = 0;
+  int64_t uni_off = 0;
+};
+
+struct mmk_wavenet_plan {
+  mmk_wavenet_config cfg;
+  Binder binder;
+  bool committed = false;
+  int L = 0, C = 0, S = 0, Bmax = 0, n_cond = 0;
+  std::vector<int> ksz, dil, ring;
+  std::vector<char> has_res;
+  int64_t rf = 1;
+  int head_in = 0;
+
+  const float* emb = nullptr;
+  PackedLinear in0_lin;
+  std::vector<PackedLinear> cond_lin, A, Bm, mlp;
+
+  std::vector<float*> hist;
+  std::vector<float*> cbuf;
+  float* ybuf = nullptr;
+  float* skipbuf = nullptr;
+  float* hid[2] = {nullptr, nullptr};
+  float* logits = nullptr;
+  int logits_ld = 0;
+  int64_t* tau = nullptr;
+
+  hipStream_t cap_stream = nullptr;
+  GraphCache gc;
+
+  void layout(Carver& c) {
+    const bool bias = cfg.bias != 0;
+    if (cfg.q_levels == 0) in0_lin.carve(c, true);
+    for (auto& p : cond_lin) p.carve(c, true);
+    for (auto& p : A) p.carve(c, bias);
+    for (auto& p : Bm)
+      if (p.n_tiles > 0) p.carve(c, bias);
+    for (auto& p : mlp) p.carve(c, true);
+    hist.resize(L + 1);
+    for (int l = 0; l < L; ++l) hist[l] = c.take<float>((int64_t)ring[l] * Bmax * C);
+    hist[L] = c.take<float>((int64_t)Bmax * C);  // sink for the last layer's dilated output
+    cbuf.resize(n_cond);
+    for (int j = 0; j < n_cond; ++j) cbuf[j] = c.take<float>((int64_t)Bmax * cfg.cond_dim[j]);
+    ybuf = c.take<float>((int64_t)Bmax * C);
+    skipbuf = c.take<float>((int64_t)Bmax * (S > 0 ? S : 1));
+    const int hmax = cfg.mlp_hidden > 0 ? cfg.mlp_hidden : 1;
+    hid[0] = c.take<float>((int64_t)Bmax * hmax);
+    hid[1] = c.take<float>((int64_t)Bmax * hmax);
+    logits_ld = (int)round_up(cfg.out_dim + (cfg.learn_temp ? 1 : 0), 4);
+    logits = c.take<float>((int64_t)Bmax * logits_ld);
+    tau = c.take<int64_t>(32);
+  }
+
+  Addr hist_slot(int l, int offset) const {
+    if (l >= L) return addr_static(hist[L]);
+    return addr_ring(hist[l], (int64_t)Bmax * C, offset, ring[l]);
+  }
+  // where layer l's gated output y lives
+  Addr y_addr(int l) const {
+    if (has_res[l] || l + 1 >= L) return addr_static(ybuf);
+    return hist_slot(l + 1, 0);
+  }
+};
+
+static int derive(mmk_wavenet_plan* p) {
+  const mmk_wavenet_config& c = p->cfg;
+  if (c.n_layers < 1 || c.n_layers > MMK_MAX_LAYERS) return fail(MMK_ERR_INVALID, "wavenet: n_layers=%d out of range", c.n_layers);
+  if (c.dim_dilated < 1 || c.max_batch < 1) return fail(MMK_ERR_INVALID, "wavenet: dim_dilated / max_batch must be positive");
+  if (c.n_cond < 0 || c.n_cond > MMK_MAX_COND) return fail(MMK_ERR_INVALID, "wavenet: n_cond=%d out of range", c.n_cond);
+  if (c.q_levels == 0 && c.in_dim < 1) return fail(MMK_ERR_INVALID, "wavenet: in_dim required when q_levels == 0");
+  if (c.head_kind == 0 && (c.mlp_hidden < 1 || c.mlp_n_hidden < 0 || c.mlp_n_hidden > MMK_MAX_MLP_HIDDEN))
+    return fail(MMK_ERR_INVALID, "wavenet: bad MLP head geometry");
+  if (c.head_kind < 0 || c.head_kind > 2) return fail(MMK_ERR_INVALID, "wavenet: head_kind %d unknown", c.head_kind);
+  if (c.head_kind != 0 && c.q_levels != 0) return fail(MMK_ERR_UNSUPPORTED, "wavenet: linear head needs a continuous input 0");
+  if (c.head_kind != 0 && c.out_dim != c.in_dim) return fail(MMK_ERR_UNSUPPORTED, "wavenet: linear head out_dim must equal in_dim");
+  p->L = c.n_layers;
+  p->C = c.dim_dilated;
+  p->S = c.skips_dim;
+  p->Bmax = c.max_batch;
+  p->n_cond = c.n_cond;
+  p->ksz.assign(c.kernel_size, c.kernel_size + p->L);
+  p->dil.assign(c.dilation, c.dilation + p->L);
+  p->ring.resize(p->L);
+  p->has_res.resize(p->L);
+  p->rf = 1;
+  for (int l = 0; l < p->L; ++l) {
+    if (p->ksz[l] < 1 || p->dil[l] < 1) return fail(MMK_ERR_INVALID, "wavenet: layer %d has kernel %d dilation %d", l, p->ksz[l], p->dil[l]);
+    if (p->ksz[l] + p->n_cond > kMaxSeg)
+      return fail(MMK_ERR_UNSUPPORTED, "wavenet: kernel_size + n_cond = %d exceeds %d K-segments", p->ksz[l] + p->n_cond, kMaxSeg);
+    const int cause = (p->ksz[l] - 1) * p->dil[l];  // WNLayer.cause, wavenet_v2.py:74
+    p->ring[l] = cause + 1;
+    p->rf += cause;
+    // has_residuals (:78) with input_dim == dims_dilated[0]; last layer built with residuals_dim=None (:216)
+    p->has_res[l] = (l != p->L - 1) && c.residuals_dim != 0 && c.residuals_dim == p->C;
+  }
+  p->head_in = p->S > 0 ? p->S : p->C;
+
+  // geometry of the packed matrices
+  if (c.q_levels == 0) p->in0_lin.set_geometry(p->C, {c.in_dim});
+  p->cond_lin.resize(p->n_cond);
+  for (int j = 0; j < p->n_cond; ++j) p->cond_lin[j].set_geometry(c.cond_dim[j], {c.cond_in_dim[j]});
+  p->A.resize(p->L);
+  p->Bm.resize(p->L);
+  for (int l = 0; l < p->L; ++l) {
+    std::vector<int> ks;
+    for (int j = 0; j < p->ksz[l]; ++j) ks.push_back(p->C);
+    for (int j = 0; j < p->n_cond; ++j) ks.push_back(c.cond_dim[j]);
+    p->A[l].set_geometry(c.gated ? 2 * p->C : p->C, ks);
+    const int n_res_pad = p->has_res[l] ? (int)round_up(p->C, 16) : 0;
+    if (p->has_res[l] || p->S > 0)
+      p->Bm[l].set_geometry(n_res_pad + p->S, {p->C});
+    else
+      p->Bm[l] = PackedLinear();
+  }
+  p->mlp.clear();
+  if (c.head_kind == 0) {
+    PackedLinear first;
+    first.set_geometry(c.mlp_hidden, {p->head_in});
+    p->mlp.push_back(first);
+    for (int i = 0; i < c.mlp_n_hidden; ++i) {
+      PackedLinear h;
+      h.set_geometry(c.mlp_hidden, {c.mlp_hidden});
+      p->mlp.push_back(h);
+    }
+    PackedLinear last;
+    last.set_geometry(c.out_dim + (c.learn_temp ? 1 : 0), {c.mlp_hidden});
+    p->mlp.push_back(last);
+  } else {
+    PackedLinear only;
+    only.set_geometry(c.out_dim, {p->head_in});
+    p->mlp.push_back(only);
+  }
+  return MMK_OK;
+}
+
+extern "C" int mmk_wavenet_plan_create(const mmk_wavenet_config* cfg, mmk_wavenet_plan** out) {
+  if (!cfg || !out) return fail(MMK_ERR_INVALID, "wavenet_plan_create: null argument");
+  mmk_wavenet_plan* p = new mmk_wavenet_plan();
+  p->cfg = *cfg;
+  int rc = derive(p);
+  if (rc != MMK_OK) {
+    delete p;
+    return rc;
+  }
+  *out = p;
+  return MMK_OK;
+}
+
+extern "C" void mmk_wavenet_plan_destroy(mmk_wavenet_plan* p) {
+  if (!p) return;
+  p->gc.reset();
+  if (p->cap_stream) (void)hipStreamDestroy(p->cap_stream);
+  delete p;
+}
+
+extern "C" int mmk_wavenet_plan_bind(mmk_wavenet_plan* p, const char* key, const float* dev_ptr, int64_t numel) {
+  if (!p || !key || !dev_ptr) return fail(MMK_ERR_INVALID, "wavenet_plan_bind: null argument");
+  p->binder.bind(key, dev_ptr, numel);
+  p->committed = false;
+  return MMK_OK;
+}
+
+extern "C" int64_t mmk_wavenet_receptive_field(const mmk_wavenet_plan* p) { return p ? p->rf : 0; }
+
+extern "C" size_t mmk_wavenet_workspace_bytes(const mmk_wavenet_plan* p) {
+  if (!p) return 0;
+  mmk_wavenet_plan tmp = *p;  // layout() only writes pointers; run it on a copy
+  tmp.gc = GraphCache();
+  tmp.cap_stream = nullptr;
+  Carver c(nullptr);
+  tmp.layout(c);
+  return c.used();
+}
+
+extern "C" int mmk_wavenet_commit(mmk_wavenet_plan* p, void* workspace, size_t workspace_bytes, mmk_stream_t stream) {
+  if (!p || !workspace) return fail(MMK_ERR_INVALID, "wavenet_commit: null argument");
+  if ((reinterpret_cast<uintptr_t>(workspace) & 255) != 0) return fail(MMK_ERR_WORKSPACE, "wavenet_commit: workspace must be 256-byte aligned");
+  hipStream_t st = (hipStream_t)stream;
+  const mmk_wavenet_config& c = p->cfg;
+  Carver carve(workspace);
+  p->layout(carve);
+  if (carve.used() > workspace_bytes)
+    return fail(MMK_ERR_WORKSPACE, "wavenet_commit: workspace of %zu bytes, %zu needed", workspace_bytes, carve.used());
+  p->gc.reset();  // pointers inside a cached graph are stale now
+  MMK_HIP(hipMemsetAsync(workspace, 0, carve.used(), st));
+
+  Binder& b = p->binder;
+  b.clear_missing();
+  const int C = p->C, S = p->S, L = p->L;
+  const bool bias = c.bias != 0;
+  auto key = [](const std::string& s) { return s; };
+
+  // input 0
+  if (c.q_levels > 0) {
+    p->emb = b.need(key("input_modules.0.0.weight"), (int64_t)c.q_levels * C);
+  } else {
+    const float* w = b.need("input_modules.0.0.weight", (int64_t)C * c.in_dim);
+    const float* bb = b.need("input_modules.0.0.bias", C);
+    if (w && bb) {
+      MMK_TRY(pack_rect(p->in0_lin.Wp, p->in0_lin.k_chunks, 0, 1, C, 0, c.in_dim, w, c.in_dim, 1, st));
+      MMK_TRY(pack_bias(p->in0_lin.bias, 0, 1, C, bb, 0, st));
+    }
+  }
+  // conditioning inputs (LinearIO, modules/io.py:115-122)
+  for (int j = 0; j < p->n_cond; ++j) {
+    const std::string base = "input_modules." + std::to_string(j + 1) + ".0.";
+    const float* w = b.need(base + "weight", (int64_t)c.cond_dim[j] * c.cond_in_dim[j]);
+    const float* bb = b.need(base + "bias", c.cond_dim[j]);
+    if (w && bb) {
+      MMK_TRY(pack_rect(p->cond_lin[j].Wp, p->cond_lin[j].k_chunks, 0, 1, c.cond_dim[j], 0, c.cond_in_dim[j], w,
+                        c.cond_in_dim[j], 1, st));
+      MMK_TRY(pack_bias(p->cond_lin[j].bias, 0, 1, c.cond_dim[j], bb, 0, st));
+    }
+  }
+  // layers
+  for (int l = 0; l < L; ++l) {
+    const std::string ly = "layers." + std::to_string(l) + ".";
+    const int k = p->ksz[l];
+    const int rows_src = c.gated ? 2 * C : C;
+    const std::string dil_base = ly + (c.gated ? "conv_dil.0.0." : "conv_dil.0.");
+    const float* wd = b.need(dil_base + "weight", (int64_t)rows_src * C * k);
+    const float* bd = bias ? b.need(dil_base + "bias", rows_src) : nullptr;
+    PackedLinear& A = p->A[l];
+    if (wd) {
+      for (int j = 0; j < k; ++j) {
+        // tap j multiplies x[tau - (k-1-j)*d]  (cross-correlation, tap 0 = most delayed)
+        if (c.gated) {
+          MMK_TRY(pack_rect(A.Wp, A.k_chunks, 0, 2, C, A.seg_chunk0[j], C, wd + j, (int64_t)C * k, k, st));
+          MMK_TRY(pack_rect(A.Wp, A.k_chunks, 1, 2, C, A.seg_chunk0[j], C, wd + (int64_t)C * C * k + j, (int64_t)C * k, k, st));
+        } else {
+          MMK_TRY(pack_rect(A.Wp, A.k_chunks, 0, 1, C, A.seg_chunk0[j], C, wd + j, (int64_t)C * k, k, st));
+        }
+      }
+    }
+    if (bd) {
+      if (c.gated) {
+        MMK_TRY(pack_bias(A.bias, 0, 2, C, bd, 0, st));
+        MMK_TRY(pack_bias(A.bias, 1, 2, C, bd + C, 0, st));
+      } else {
+        MMK_TRY(pack_bias(A.bias, 0, 1, C, bd, 0, st));
+      }
+    }
+    for (int j = 0; j < p->n_cond; ++j) {
+      const std::string cb = ly + "conv_1x1." + std::to_string(j) + (c.gated ? ".0." : ".");
+      const int cd = c.cond_dim[j];
+      const float* w1 = b.need(cb + "weight", (int64_t)rows_src * cd);
+      const float* b1 = bias ? b.need(cb + "bias", rows_src) : nullptr;
+      if (w1) {
+        if (c.gated) {
+          MMK_TRY(pack_rect(A.Wp, A.k_chunks, 0, 2, C, A.seg_chunk0[k + j], cd, w1, cd, 1, st));
+          MMK_TRY(pack_rect(A.Wp, A.k_chunks, 1, 2, C, A.seg_chunk0[k + j], cd, w1 + (int64_t)C * cd, cd, 1, st));
+        } else {
+          MMK_TRY(pack_rect(A.Wp, A.k_chunks, 0, 1, C, A.seg_chunk0[k + j], cd, w1, cd, 1, st));
+        }
+      }
+      if (b1) {
+        if (c.gated) {
+          MMK_TRY(pack_bias(A.bias, 0, 2, C, b1, 1, st));
+          MMK_TRY(pack_bias(A.bias, 1, 2, C, b1 + C, 1, st));
+        } else {
+          MMK_TRY(pack_bias(A.bias, 0, 1, C, b1, 1, st));
+        }
+      }
+    }
+    PackedLinear& Bm = p->Bm[l];
+    if (Bm.n_tiles > 0) {
+      const int n_res_pad = p->has_res[l] ? (int)round_up(C, 16) : 0;
+      if (p->has_res[l]) {
+        const float* wr = b.need(ly + "conv_res.weight", (int64_t)C * C);
+        const float* br = bias ? b.need(ly + "conv_res.bias", C) : nullptr;
+        if (wr) MMK_TRY(pack_rect(Bm.Wp, Bm.k_chunks, 0, 1, C, 0, C, wr, C, 1, st));
+        if (br) MMK_TRY(pack_bias(Bm.bias, 0, 1, C, br, 0, st));
+      }
+      if (S > 0) {
+        const float* ws = b.need(ly + "conv_skip.weight", (int64_t)S * C);
+        const float* bs = bias ? b.need(ly + "conv_skip.bias", S) : nullptr;
+        if (ws) MMK_TRY(pack_rect(Bm.Wp, Bm.k_chunks, n_res_pad, 1, S, 0, C, ws, C, 1, st));
+        if (bs) MMK_TRY(pack_bias(Bm.bias, n_res_pad, 1, S, bs, 0, st));
+      }
+    }
+  }
+  // head
+  if (c.head_kind == 0) {
+    const std::string hb = "output_modules.0.estimator.0.fc.";
+    for (size_t i = 0; i < p->mlp.size(); ++i) {
+      PackedLinear& m = p->mlp[i];
+      const std::string kb = hb + std::to_string(2 * i) + ".";
+      const float* w = b.need(kb + "weight", (int64_t)m.N * m.segK[0]);
+      const float* bb = b.need(kb + "bias", m.N);
+      if (w) MMK_TRY(pack_rect(m.Wp, m.k_chunks, 0, 1, m.N, 0, m.segK[0], w, m.segK[0], 1, st));
+      if (bb) MMK_TRY(pack_bias(m.bias, 0, 1, m.N, bb, 0, st));
+    }
+  } else {
+    PackedLinear& m = p->mlp[0];
+    const float* w = b.need("output_modules.0.0.weight", (int64_t)m.N * m.segK[0]);
+    const float* bb = b.need("output_modules.0.0.bias", m.N);
+    if (w) MMK_TRY(pack_rect(m.Wp, m.k_chunks, 0, 1, m.N, 0, m.segK[0], w, m.segK[0], 1, st));
+    if (bb) MMK_TRY(pack_bias(m.bias, 0, 1, m.N, bb, 0, st));
+  }
+  if (!b.missing().empty()) return fail(MMK_ERR_KEY, "wavenet_commit: state_dict tensor %s", b.missing().c_str());
+  if (!p->cap_stream) MMK_HIP(hipStreamCreateWithFlags(&p->cap_stream, hipStreamNonBlocking));
+  p->committed = true;
+  return MMK_OK;
+}
+
+// enqueue one step at position tau = *plan->tau + tau_off
+static int emit_step(mmk_wavenet_plan* p, const WnCall& call, int64_t tau_off, bool with_head, hipStream_t st) {
+  const mmk_wavenet_config& c = p->cfg;
+  const int C = p->C, S = p->S, L = p->L, M = call.M;
+  // input module 0
+  if (c.q_levels > 0) {
+    MMK_TRY(launch_embed((const int64_t*)call.in0, call.in0_rs, 0, p->emb, C, c.q_levels, p->hist_slot(0, 0), C, M,
+                         p->tau, tau_off, st));
+  } else {
+    LinearArgs a = {};
+    p->in0_lin.fill(a);
+    a.seg[0].x = addr_time(call.in0, c.in_dim, 0, 1, 0);
+    a.seg[0].ld = call.in0_rs;
+    a.M = M; a.tau_ptr = p->tau; a.tau_off = tau_off;
+    a.epilogue = EPI_STORE; a.act = ACT_NONE;
+    a.out = p->hist_slot(0, 0); a.out_ld = C;
+    MMK_TRY(launch_linear(a, st));
+  }
+  for (int j = 0; j < p->n_cond; ++j) {
+    LinearArgs a = {};
+    p->cond_lin[j].fill(a);
+    a.seg[0].x = addr_time(call.cond[j], c.cond_in_dim[j], 0, 1, 0);
+    a.seg[0].ld = call.cond_rs[j];
+    a.M = M; a.tau_ptr = p->tau; a.tau_off = tau_off;
+    a.epilogue = EPI_STORE; a.act = ACT_NONE;
+    a.out = addr_static(p->cbuf[j]); a.out_ld = c.cond_dim[j];
+    MMK_TRY(launch_linear(a, st));
+  }
+  for (int l = 0; l < L; ++l) {
+    const int k = p->ksz[l], d = p->dil[l];
+    {
+      LinearArgs a = {};
+      p->A[l].fill(a);
+      for (int j = 0; j < k; ++j) {
+        a.seg[j].x = p->hist_slot(l, -(k - 1 - j) * d);
+        a.seg[j].ld = C;
+      }
+      for (int j = 0; j < p->n_cond; ++j) {
+        a.seg[k + j].x = addr_static(p->cbuf[j]);
+        a.seg[k + j].ld = c.cond_dim[j];
+      }
+      a.M = M; a.tau_ptr = p->tau; a.tau_off = tau_off;
+      a.epilogue = c.gated ? EPI_GATE : EPI_STORE;
+      a.act = c.gated ? ACT_NONE : ACT_TANH;
+      a.out = p->y_addr(l); a.out_ld = C;
+      MMK_TRY(launch_linear(a, st));
+    }
+    if (p->Bm[l].n_tiles > 0) {
+      LinearArgs a = {};
+      p->Bm[l].fill(a);
+      a.seg[0].x = p->y_addr(l);
+      a.seg[0].ld = C;
+      a.M = M; a.tau_ptr = p->tau; a.tau_off = tau_off;
+      a.epilogue = EPI_RES_SKIP;
+      a.n_res = p->has_res[l] ? C : 0;
+      a.n_res_pad = p->has_res[l] ? (int)round_up(C, 16) : 0;
+      a.n_skip = S;
+      a.skip_first = (l == 0);
+      a.res_in = p->hist_slot(l, 0); a.res_in_ld = C;
+      a.res_out = p->hist_slot(l + 1, 0); a.res_out_ld = C;
+      a.skip = addr_static(p->skipbuf); a.skip_ld = S > 0 ? S : 1;
+      MMK_TRY(launch_linear(a, st));
+    }
+  }
+  if (!with_head) return MMK_OK;
+  const float* x = S > 0 ? p->skipbuf : p->ybuf;
+  int x_ld = p->head_in;
+  if (c.head_kind == 0) {
+    for (size_t i = 0; i < p->mlp.size(); ++i) {
+      const bool last = (i + 1 == p->mlp.size());
+      LinearArgs a = {};
+      p->mlp[i].fill(a);
+      a.seg[0].x = addr_static(x);
+      a.seg[0].ld = x_ld;
+      a.M = M; a.tau_ptr = p->tau; a.tau_off = tau_off;
+      a.epilogue = EPI_STORE;
+      a.act = last ? ACT_NONE : ACT_MISH;  // MLPIO default activation (modules/io.py:205)
+      float* o = last ? p->logits : p->hid[i & 1];
+      a.out = addr_static(o);
+      a.out_ld = last ? p->logits_ld : c.mlp_hidden;
+      MMK_TRY(launch_linear(a, st));
+      x = o;
+      x_ld = (int)a.out_ld;
+    }
+    SampleArgs s = {};
+    s.logits = p->logits; s.ld = p->logits_ld; s.rows = M; s.n_classes = c.out_dim; s.has_temp_col = c.learn_temp;
+    s.min_temp = c.min_temp; s.temperature = call.temperature; s.uniforms = call.uniforms;
+    s.uniform_ld = call.uni_ld; s.uni_off = call.uni_off;
+    s.out = (int64_t*)call.in0; s.out_row_stride = call.in0_rs; s.out_tau_off = 1;
+    s.tau_ptr = p->tau; s.tau_off = tau_off;
+    MMK_TRY(launch_sample(s, st));
+  } else {
+    LinearArgs a = {};
+    p->mlp[0].fill(a);
+    a.seg[0].x = addr_static(x);
+    a.seg[0].ld = x_ld;
+    a.M = M; a.tau_ptr = p->tau; a.tau_off = tau_off;
+    a.epilogue = EPI_STORE; a.act = c.head_kind == 1 ? ACT_ABS : ACT_NONE;
+    a.out = addr_time(call.in0, c.in_dim, 1, 1, 0);
+    a.out_ld = call.in0_rs;
+    MMK_TRY(launch_linear(a, st));
+  }
+  return MMK_OK;
+}
+
+static constexpr int kGraphSteps = 8;
+
+// run n steps starting at position tau0 (device counter is set here)
+static int run_steps(mmk_wavenet_plan* p, const WnCall& call, int64_t tau0, int64_t n, bool with_head, hipStream_t st) {
+  if (n <= 0) return MMK_OK;
+  MMK_TRY(launch_set_i64(p->tau, tau0, st));
+  int64_t done = 0;
+  if (n >= 2 * kGraphSteps) {
+    std::vector<int64_t> key = {call.M, (int64_t)(uintptr_t)call.in0, call.in0_rs, with_head ? 1 : 0,
+                                (int64_t)(uintptr_t)call.temperature, (int64_t)(uintptr_t)call.uniforms, call.uni_ld,
+                                call.uni_off};
+    for (int j = 0; j < p->n_cond; ++j) {
+      key.push_back((int64_t)(uintptr_t)call.cond[j]);
+      key.push_back(call.cond_rs[j]);
+    }
+    if (!p->gc.exec || p->gc.key != key) {
+      MMK_HIP(hipStreamSynchronize(st));  // a cached graph may still be in flight
+      p->gc.reset();
+      MMK_HIP(hipStreamBeginCapture(p->cap_stream, hipStreamCaptureModeThreadLocal));
+      int rc = MMK_OK;
+      for (int s = 0; s < kGraphSteps && rc == MMK_OK; ++s) rc = emit_step(p, call, s, with_head, p->cap_stream);
+      if (rc == MMK_OK) rc = launch_bump(p->tau, kGraphSteps, p->cap_stream);
+      hipGraph_t g = nullptr;
+      hipError_t e = hipStreamEndCapture(p->cap_stream, &g);
+      if (rc != MMK_OK) {
+        if (g) (void)hipGraphDestroy(g);
+        return rc;
+      }
+      if (e != hipSuccess) return fail(MMK_ERR_HIP, "hipStreamEndCapture failed: %s", hipGetErrorString(e));
+      p->gc.graph = g;
+      MMK_HIP(hipGraphInstantiate(&p->gc.exec, g, nullptr, nullptr, 0));
+      p->gc.key = key;
+      p->gc.steps = kGraphSteps;
+    }
+    const int64_t reps = n / kGraphSteps;
+    for (int64_t r = 0; r < reps; ++r) MMK_HIP(hipGraphLaunch(p->gc.exec, st));
+    done = reps * kGraphSteps;
+  }
+  for (int64_t s = done; s < n; ++s) MMK_TRY(emit_step(p, call, s - done, with_head, st));
+  if (n > done) MMK_TRY(launch_bump(p->tau, n - done, st));
+  return MMK_OK;
+}
+
+static int check_call(mmk_wavenet_plan* p, int32_t batch, const void* in0, const float* const* cond,
+                      const int64_t* cond_rs, WnCall& call) {
+  if (!p) return fail(MMK_ERR_INVALID, "wavenet: null plan");
+  if (!p->committed) return fail(MMK_ERR_STATE, "wavenet: plan not committed (bind weights, then mmk_wavenet_commit)");
+  if (batch < 1 || batch > p->Bmax) return fail(MMK_ERR_INVALID, "wavenet: batch %d outside [1, %d]", batch, p->Bmax);
+  if (!in0) return fail(MMK_ERR_INVALID, "wavenet: null input");
+  if (p->n_cond > 0 && (!cond || !cond_rs)) return fail(MMK_ERR_INVALID, "wavenet: %d conditioning inputs expected", p->n_cond);
+  call.M = batch;
+  call.in0 = in0;
+  for (int j = 0; j < p->n_cond; ++j) {
+    if (!cond[j]) return fail(MMK_ERR_INVALID, "wavenet: conditioning input %d is null", j);
+    call.cond[j] = cond[j];
+    call.cond_rs[j] = cond_rs[j];
+  }
+  return MMK_OK;
+}
+
+extern "C" int mmk_wavenet_warmup(mmk_wavenet_plan* p, int32_t batch, const void* in0, int64_t in0_row_stride,
+                                  const float* const* cond, const int64_t* cond_row_stride, int64_t t_begin,
+                                  int64_t t_end, mmk_stream_t stream) {
+  WnCall call;
+  MMK_TRY(check_call(p, batch, in0, cond, cond_row_stride, call));
+  call.in0_rs = in0_row_stride;
+  if (t_begin < 0 || t_end < t_begin) return fail(MMK_ERR_INVALID, "wavenet_warmup: bad range [%lld, %lld)", (long long)t_begin, (long long)t_end);
+  return run_steps(p, call, t_begin, t_end - t_begin, false, (hipStream_t)stream);
+}
+
+extern "C" int mmk_wavenet_generate(mmk_wavenet_plan* p, int32_t batch, void* in0, int64_t in0_row_stride,
+                                    const float* const* cond, const int64_t* cond_row_stride, int64_t t0,
+                                    int64_t n_steps, const float* temperature, const float* uniforms,
+                                    mmk_stream_t stream) {
+  WnCall call;
+  MMK_TRY(check_call(p, batch, in0, cond, cond_row_stride, call));
+  call.in0_rs = in0_row_stride;
+  if (t0 < 1 || n_steps < 0) return fail(MMK_ERR_INVALID, "wavenet_generate: bad t0/n_steps");
+  if (temperature && !uniforms) return fail(MMK_ERR_INVALID, "wavenet_generate: temperature given without uniforms");
+  if (temperature && p->cfg.head_kind != 0) return fail(MMK_ERR_INVALID, "wavenet_generate: this head has no sampler");
+  call.temperature = temperature;
+  call.uniforms = uniforms;
+  call.uni_ld = n_steps;
+  call.uni_off = -(t0 - 1);
+  // the step that writes position t consumes position tau = t-1 as its newest input
+  return run_steps(p, call, t0 - 1, n_steps, true, (hipStream_t)stream);
+}
+
+extern "C" int mmk_wavenet_last_logits(mmk_wavenet_plan* p, int32_t batch, float* out, int64_t ld, mmk_stream_t stream) {
+  if (!p || !out) return fail(MMK_ERR_INVALID, "wavenet_last_logits: null argument");
+  if (!p->committed) return fail(MMK_ERR_STATE, "wavenet_last_logits: plan not committed");
+  if (p->cfg.head_kind != 0) return fail(MMK_ERR_UNSUPPORTED, "wavenet_last_logits: only for the MLP head");
+  const int n = p->cfg.out_dim + (p->cfg.learn_temp ? 1 : 0);
+  MMK_HIP(hipMemcpy2DAsync(out, ld * sizeof(float), p->logits, p->logits_ld * sizeof(float), n * sizeof(float), batch,
+                           hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  return MMK_OK;
+}

@@ -1,0 +1,395 @@
+"""ctypes binding of ``libmmk_hip.so`` (the C ABI declared in ``include/mmk.h``).
+
+The library is the only compute path of this package: there is no CPU or
+eager-PyTorch fallback.  Every wrapper takes torch tensors that already live on
+a HIP device, passes raw ``data_ptr()``s and enqueues on torch's current HIP
+stream.  A missing library, or a tensor that is not on a HIP device, raises.
+"""
+import ctypes as C
+import os
+from typing import Optional, Sequence
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmmk_hip.so")
+
+MAX_LAYERS, MAX_COND, MAX_TIERS = 128, 4, 8
+ACT = {"none": 0, None: 0, "Identity": 0, "Tanh": 1, "Sigmoid": 2, "Mish": 3, "Abs": 4, "ReLU": 5}
+
+i32, i64, f32, vp, cp = C.c_int32, C.c_int64, C.c_float, C.c_void_p, C.c_char_p
+
+
+class NativeError(RuntimeError):
+    pass
+
+
+class WaveNetConfig(C.Structure):
+    _fields_ = [
+        ("n_layers", i32), ("kernel_size", i32 * MAX_LAYERS), ("dilation", i32 * MAX_LAYERS),
+        ("q_levels", i32), ("in_dim", i32), ("dim_dilated", i32), ("residuals_dim", i32), ("skips_dim", i32),
+        ("n_cond", i32), ("cond_in_dim", i32 * MAX_COND), ("cond_dim", i32 * MAX_COND),
+        ("bias", i32), ("gated", i32), ("head_kind", i32), ("mlp_hidden", i32), ("mlp_n_hidden", i32),
+        ("out_dim", i32), ("learn_temp", i32), ("min_temp", f32), ("max_batch", i32),
+    ]
+
+
+class SrnnConfig(C.Structure):
+    _fields_ = [
+        ("n_tiers", i32), ("frame_size", i32 * MAX_TIERS), ("hidden_dim", i32), ("rnn_kind", i32),
+        ("rnn_bias", i32), ("h0_ones", i32), ("q_levels", i32), ("mlp_hidden", i32), ("mlp_n_hidden", i32),
+        ("learn_temp", i32), ("min_temp", f32), ("max_batch", i32),
+    ]
+
+
+class S2SConfig(C.Structure):
+    _fields_ = [
+        ("in_dim", i32), ("out_dim", i32), ("model_dim", i32), ("hop", i32), ("enc_n_lstm", i32),
+        ("dec_n_lstm", i32), ("out_abs", i32), ("max_batch", i32),
+    ]
+
+
+_SIGNATURES = {
+    "mmk_abi_version": (i32, []),
+    "mmk_last_error": (cp, []),
+    "mmk_mulaw_compress_f32_i64": (i32, [vp, vp, i64, i32, f32, vp, vp]),
+    "mmk_mulaw_expand_i64_f32": (i32, [vp, vp, i64, i32, f32, vp, vp]),
+    "mmk_stft_n_frames": (i64, [i64, i32, i32, i32]),
+    "mmk_stft_mag_f32": (i32, [vp, i64, i32, i64, i32, i32, i32, vp, vp]),
+    "mmk_packed_weight_floats": (i64, [i32, i32]),
+    "mmk_pack_weight_f32": (i32, [vp, i64, i32, i32, vp, vp]),
+    "mmk_linear_f32": (i32, [vp, i64, i32, vp, vp, i32, i32, vp, i64, i32, vp]),
+    "mmk_categorical_sample_f32_i64": (i32, [vp, i64, i32, i32, i32, f32, vp, vp, vp, i64, vp]),
+    "mmk_wavenet_plan_create": (i32, [C.POINTER(WaveNetConfig), C.POINTER(vp)]),
+    "mmk_wavenet_plan_destroy": (None, [vp]),
+    "mmk_wavenet_plan_bind": (i32, [vp, cp, vp, i64]),
+    "mmk_wavenet_receptive_field": (i64, [vp]),
+    "mmk_wavenet_workspace_bytes": (C.c_size_t, [vp]),
+    "mmk_wavenet_commit": (i32, [vp, vp, C.c_size_t, vp]),
+    "mmk_wavenet_warmup": (i32, [vp, i32, vp, i64, C.POINTER(vp), C.POINTER(i64), i64, i64, vp]),
+    "mmk_wavenet_generate": (i32, [vp, i32, vp, i64, C.POINTER(vp), C.POINTER(i64), i64, i64, vp, vp, vp]),
+    "mmk_wavenet_last_logits": (i32, [vp, i32, vp, i64, vp]),
+    "mmk_srnn_plan_create": (i32, [C.POINTER(SrnnConfig), C.POINTER(vp)]),
+    "mmk_srnn_plan_destroy": (None, [vp]),
+    "mmk_srnn_plan_bind": (i32, [vp, cp, vp, i64]),
+    "mmk_srnn_workspace_bytes": (C.c_size_t, [vp]),
+    "mmk_srnn_commit": (i32, [vp, vp, C.c_size_t, vp]),
+    "mmk_srnn_reset": (i32, [vp, vp]),
+    "mmk_srnn_warmup": (i32, [vp, i32, vp, i64, i64, vp]),
+    "mmk_srnn_generate": (i32, [vp, i32, vp, i64, i64, i64, vp, vp, vp]),
+    "mmk_srnn_last_logits": (i32, [vp, i32, vp, i64, vp]),
+    "mmk_s2s_plan_create": (i32, [C.POINTER(S2SConfig), C.POINTER(vp)]),
+    "mmk_s2s_plan_destroy": (None, [vp]),
+    "mmk_s2s_plan_bind": (i32, [vp, cp, vp, i64]),
+    "mmk_s2s_workspace_bytes": (C.c_size_t, [vp]),
+    "mmk_s2s_commit": (i32, [vp, vp, C.c_size_t, vp]),
+    "mmk_s2s_step": (i32, [vp, i32, vp, i64, i64, vp, i64, i64, vp]),
+    "mmk_s2s_generate": (i32, [vp, i32, vp, i64, i64, i64, i64, i64, vp]),
+}
+
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+_lib = None
+
+
+def load_library(path: Optional[str] = None):
+    """dlopen the HIP library and type its entry points (no GPU needed for this)."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    path = path or LIB_PATH
+    if not os.path.exists(path):
+        raise NativeError(
+            f"{path} is missing: build it with `python -m mimikit_amd.build` (hipcc, --offload-arch=gfx950). "
+            "There is no CPU fallback for the generate path.")
+    lib = C.CDLL(path)
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    if lib.mmk_abi_version() != 1:
+        raise NativeError(f"ABI version mismatch: library reports {lib.mmk_abi_version()}, binding expects 1")
+    _lib = lib
+    return lib
+
+
+def lib():
+    return load_library()
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        msg = lib().mmk_last_error().decode("utf-8", "replace")
+        kind = {-1: ValueError, -3: NotImplementedError, -6: KeyError}.get(rc, NativeError)
+        raise kind(f"{what or 'libmmk_hip'} failed (code {rc}): {msg}")
+
+
+def require_device(*tensors: torch.Tensor):
+    """The hot path only runs on a HIP device; anything else is an error, never a fallback."""
+    for t in tensors:
+        if t is None:
+            continue
+        if not isinstance(t, torch.Tensor):
+            raise TypeError(f"expected a torch.Tensor, got {type(t)}")
+        if t.device.type != "cuda":
+            raise RuntimeError(
+                f"mimikit_amd runs its generate path on the MI355X only: got a tensor on '{t.device}'. "
+                "Move the network and its inputs to the HIP device ('cuda'); there is no CPU implementation "
+                "in this package (the CPU restatement under oracle/ is test infrastructure).")
+
+
+def stream_ptr(device=None) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+# ---------------------------------------------------------------------------
+# feature functionals
+# ---------------------------------------------------------------------------
+def mulaw_compress(x: torch.Tensor, q_levels: int, compression: float, edges: torch.Tensor) -> torch.Tensor:
+    require_device(x, edges)
+    x = x.contiguous()
+    if x.dtype != torch.float32:
+        x = x.float()
+    out = torch.empty(x.shape, dtype=torch.int64, device=x.device)
+    check(lib().mmk_mulaw_compress_f32_i64(ptr(x), ptr(out), x.numel(), q_levels, compression, ptr(edges),
+                                           stream_ptr(x.device)), "mmk_mulaw_compress_f32_i64")
+    return out
+
+
+def mulaw_expand(codes: torch.Tensor, q_levels: int, compression: float, table: torch.Tensor) -> torch.Tensor:
+    require_device(codes, table)
+    codes = codes.contiguous()
+    if codes.dtype != torch.int64:
+        codes = codes.long()
+    out = torch.empty(codes.shape, dtype=torch.float32, device=codes.device)
+    check(lib().mmk_mulaw_expand_i64_f32(ptr(codes), ptr(out), codes.numel(), q_levels, compression, ptr(table),
+                                         stream_ptr(codes.device)), "mmk_mulaw_expand_i64_f32")
+    return out
+
+
+def stft_mag(x: torch.Tensor, n_fft: int, hop: int, center: bool) -> torch.Tensor:
+    """x: (..., n_samples) fp32 -> (..., n_frames, n_fft//2+1)"""
+    require_device(x)
+    if x.dtype != torch.float32:
+        x = x.float()
+    lead = x.shape[:-1]
+    x2 = x.reshape(-1, x.shape[-1]).contiguous()
+    n = x2.shape[-1]
+    n_frames = lib().mmk_stft_n_frames(n, n_fft, hop, int(center))
+    if n_frames <= 0:
+        raise RuntimeError(f"stft: input of {n} samples is shorter than one frame of {n_fft}")
+    out = torch.empty((x2.shape[0], n_frames, n_fft // 2 + 1), dtype=torch.float32, device=x.device)
+    check(lib().mmk_stft_mag_f32(ptr(x2), x2.stride(0), x2.shape[0], n, n_fft, hop, int(center), ptr(out),
+                                 stream_ptr(x.device)), "mmk_stft_mag_f32")
+    return out.reshape(*lead, n_frames, n_fft // 2 + 1)
+
+
+# ---------------------------------------------------------------------------
+# building blocks
+# ---------------------------------------------------------------------------
+def pack_weight(w: torch.Tensor) -> torch.Tensor:
+    require_device(w)
+    w = w.contiguous().float()
+    n, k = w.shape
+    out = torch.empty(lib().mmk_packed_weight_floats(n, k), dtype=torch.float32, device=w.device)
+    check(lib().mmk_pack_weight_f32(ptr(w), w.stride(0), n, k, ptr(out), stream_ptr(w.device)), "mmk_pack_weight_f32")
+    return out
+
+
+def linear(x: torch.Tensor, packed_w: torch.Tensor, bias: Optional[torch.Tensor], n: int, k: int,
+           act: str = "none") -> torch.Tensor:
+    require_device(x, packed_w, bias)
+    x2 = x.reshape(-1, x.shape[-1])
+    if x2.stride(-1) != 1:
+        x2 = x2.contiguous()
+    y = torch.empty((x2.shape[0], n), dtype=torch.float32, device=x.device)
+    check(lib().mmk_linear_f32(ptr(x2), x2.stride(0), x2.shape[0], ptr(packed_w), ptr(bias), n, k, ptr(y), y.stride(0),
+                               ACT[act], stream_ptr(x.device)), "mmk_linear_f32")
+    return y.reshape(*x.shape[:-1], n)
+
+
+def categorical_sample(logits: torch.Tensor, n_classes: int, has_temp_col: bool, min_temp: float,
+                       temperature: Optional[torch.Tensor], uniforms: Optional[torch.Tensor]) -> torch.Tensor:
+    require_device(logits, temperature, uniforms)
+    lg = logits.reshape(-1, logits.shape[-1])
+    if lg.stride(-1) != 1:
+        lg = lg.contiguous()
+    rows = lg.shape[0]
+    out = torch.empty(rows, dtype=torch.int64, device=logits.device)
+    check(lib().mmk_categorical_sample_f32_i64(ptr(lg), lg.stride(0), rows, n_classes, int(has_temp_col), min_temp,
+                                               ptr(temperature), ptr(uniforms), ptr(out), 1,
+                                               stream_ptr(logits.device)), "mmk_categorical_sample_f32_i64")
+    return out.reshape(logits.shape[:-1])
+
+
+# ---------------------------------------------------------------------------
+# plans
+# ---------------------------------------------------------------------------
+class _Plan:
+    """Owns one native plan handle and its torch-allocated workspace."""
+    _prefix = ""
+
+    def __init__(self, cfg_struct, device: torch.device):
+        self._lib = lib()
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError(f"plans live on the HIP device; got '{device}' (no CPU implementation in this package)")
+        self.cfg = cfg_struct
+        handle = vp()
+        check(getattr(self._lib, self._prefix + "_plan_create")(C.byref(cfg_struct), C.byref(handle)),
+              self._prefix + "_plan_create")
+        self.handle = handle
+        self.workspace = None
+        self._bound = {}
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                if torch.cuda.is_available():
+                    torch.cuda.synchronize(self.device)
+                getattr(self._lib, self._prefix + "_plan_destroy")(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+    def bind_state_dict(self, tensors):
+        for key, t in tensors.items():
+            if not torch.is_floating_point(t) or t.dim() == 0:
+                continue
+            require_device(t)
+            t = t.detach()
+            if t.dtype != torch.float32 or not t.is_contiguous():
+                t = t.float().contiguous()
+            self._bound[key] = t  # keep alive: the plan reads these pointers at commit
+            check(getattr(self._lib, self._prefix + "_plan_bind")(self.handle, key.encode(), ptr(t), t.numel()),
+                  self._prefix + "_plan_bind")
+
+    def commit(self):
+        need = getattr(self._lib, self._prefix + "_workspace_bytes")(self.handle)
+        if self.workspace is None or self.workspace.numel() < need:
+            self.workspace = torch.empty(need + 256, dtype=torch.uint8, device=self.device)
+        base = self.workspace.data_ptr()
+        aligned = (base + 255) // 256 * 256
+        check(getattr(self._lib, self._prefix + "_commit")(self.handle, aligned, need, stream_ptr(self.device)),
+              self._prefix + "_commit")
+        self.workspace_bytes = need
+
+
+def abs_ptr(view: torch.Tensor, t_first: int) -> int:
+    """address A such that A + t * stride(1) * itemsize is ``view[:, t - t_first]``: lets a window
+    view of a longer (batch, T, ...) tensor be addressed by absolute time on the device"""
+    return view.data_ptr() - t_first * view.stride(1) * view.element_size()
+
+
+def _cond_arrays(cond: Sequence[torch.Tensor], t_first: int):
+    n = len(cond)
+    ptrs = (vp * max(n, 1))(*[abs_ptr(c, t_first) for c in cond])
+    strides = (i64 * max(n, 1))(*[c.stride(0) for c in cond])
+    return ptrs, strides
+
+
+class WaveNetPlan(_Plan):
+    """``in0`` / ``cond`` arguments are (batch, T[, dim]) tensors (or views) whose column 0 is
+    absolute time ``t_first``; all ``t`` arguments are absolute times."""
+    _prefix = "mmk_wavenet"
+
+    @property
+    def rf(self) -> int:
+        return self._lib.mmk_wavenet_receptive_field(self.handle)
+
+    def _check_inputs(self, in0, cond):
+        require_device(in0, *cond)
+        if self.cfg.q_levels > 0:
+            if in0.dtype != torch.int64 or in0.dim() != 2 or in0.stride(1) != 1:
+                raise ValueError("input 0 must be int64 (batch, T) with unit stride along time")
+        else:
+            if in0.dtype != torch.float32 or in0.dim() != 3 or in0.stride(2) != 1 or in0.stride(1) != in0.shape[2]:
+                raise ValueError("input 0 must be fp32 (batch, T, dim), contiguous along time and dim")
+        if len(cond) != self.cfg.n_cond:
+            raise ValueError(f"expected {self.cfg.n_cond} conditioning inputs, got {len(cond)}")
+        for c in cond:
+            if c.dtype != torch.float32 or c.dim() != 3 or c.stride(2) != 1 or c.stride(1) != c.shape[2]:
+                raise ValueError("conditioning inputs must be fp32 (batch, T, dim), contiguous along time and dim")
+
+    def warmup(self, in0: torch.Tensor, cond: Sequence[torch.Tensor], t_begin: int, t_end: int, t_first: int = 0):
+        self._check_inputs(in0, cond)
+        ptrs, strides = _cond_arrays(cond, t_first)
+        check(self._lib.mmk_wavenet_warmup(self.handle, in0.shape[0], abs_ptr(in0, t_first), in0.stride(0), ptrs,
+                                           strides, t_begin, t_end, stream_ptr(self.device)), "mmk_wavenet_warmup")
+
+    def generate(self, in0: torch.Tensor, cond: Sequence[torch.Tensor], t0: int, n_steps: int,
+                 temperature: Optional[torch.Tensor] = None, uniforms: Optional[torch.Tensor] = None,
+                 t_first: int = 0):
+        self._check_inputs(in0, cond)
+        require_device(temperature, uniforms)
+        if uniforms is not None and (uniforms.dtype != torch.float32 or not uniforms.is_contiguous()
+                                     or uniforms.numel() != in0.shape[0] * n_steps):
+            raise ValueError("uniforms must be contiguous fp32 of shape (batch, n_steps)")
+        ptrs, strides = _cond_arrays(cond, t_first)
+        check(self._lib.mmk_wavenet_generate(self.handle, in0.shape[0], abs_ptr(in0, t_first), in0.stride(0), ptrs,
+                                             strides, t0, n_steps, ptr(temperature), ptr(uniforms),
+                                             stream_ptr(self.device)), "mmk_wavenet_generate")
+
+    def last_logits(self, batch: int) -> torch.Tensor:
+        n = self.cfg.out_dim + (1 if self.cfg.learn_temp else 0)
+        out = torch.empty((batch, n), dtype=torch.float32, device=self.device)
+        check(self._lib.mmk_wavenet_last_logits(self.handle, batch, ptr(out), out.stride(0), stream_ptr(self.device)),
+              "mmk_wavenet_last_logits")
+        return out
+
+
+class SrnnPlan(_Plan):
+    _prefix = "mmk_srnn"
+
+    def reset(self):
+        check(self._lib.mmk_srnn_reset(self.handle, stream_ptr(self.device)), "mmk_srnn_reset")
+
+    def warmup(self, idx: torch.Tensor, prompt_len: int):
+        """idx: (batch, >= prompt_len) prompt, column 0 = time 0"""
+        require_device(idx)
+        if idx.dtype != torch.int64 or idx.stride(1) != 1:
+            raise ValueError("SampleRNN input must be int64 (batch, T), contiguous along time")
+        if idx.shape[1] < prompt_len:
+            raise ValueError(f"prompt tensor holds {idx.shape[1]} steps, prompt_len={prompt_len}")
+        check(self._lib.mmk_srnn_warmup(self.handle, idx.shape[0], ptr(idx), idx.stride(0), prompt_len,
+                                        stream_ptr(self.device)), "mmk_srnn_warmup")
+
+    def generate(self, idx: torch.Tensor, t0: int, n_steps: int, temperature=None, uniforms=None, t_first: int = 0):
+        """idx: (batch, T) tensor or view whose column 0 is absolute time t_first"""
+        require_device(idx, temperature, uniforms)
+        if idx.dtype != torch.int64 or idx.stride(1) != 1:
+            raise ValueError("SampleRNN input must be int64 (batch, T), contiguous along time")
+        check(self._lib.mmk_srnn_generate(self.handle, idx.shape[0], abs_ptr(idx, t_first), idx.stride(0), t0, n_steps,
+                                          ptr(temperature), ptr(uniforms), stream_ptr(self.device)),
+              "mmk_srnn_generate")
+
+    def last_logits(self, batch: int) -> torch.Tensor:
+        n = self.cfg.q_levels + (1 if self.cfg.learn_temp else 0)
+        out = torch.empty((batch, n), dtype=torch.float32, device=self.device)
+        check(self._lib.mmk_srnn_last_logits(self.handle, batch, ptr(out), out.stride(0), stream_ptr(self.device)),
+              "mmk_srnn_last_logits")
+        return out
+
+
+class S2SPlan(_Plan):
+    _prefix = "mmk_s2s"
+
+    def step(self, x: torch.Tensor) -> torch.Tensor:
+        require_device(x)
+        if x.dtype != torch.float32 or x.stride(2) != 1:
+            raise ValueError("Seq2Seq input must be fp32 (batch, hop, n_bins) with unit stride on the last dim")
+        y = torch.empty((x.shape[0], self.cfg.hop, self.cfg.out_dim), dtype=torch.float32, device=x.device)
+        check(self._lib.mmk_s2s_step(self.handle, x.shape[0], ptr(x), x.stride(0), x.stride(1), ptr(y), y.stride(0),
+                                     y.stride(1), stream_ptr(self.device)), "mmk_s2s_step")
+        return y
+
+    def generate(self, frames: torch.Tensor, t0: int, n_steps: int):
+        require_device(frames)
+        if frames.dtype != torch.float32 or frames.stride(2) != 1:
+            raise ValueError("Seq2Seq frames must be fp32 (batch, T, n_bins) with unit stride on the last dim")
+        check(self._lib.mmk_s2s_generate(self.handle, frames.shape[0], ptr(frames), frames.stride(0), frames.stride(1),
+                                         t0, n_steps, frames.shape[1], stream_ptr(self.device)), "mmk_s2s_generate")

@@ -1,0 +1,281 @@
+"""Seq2Seq bi-LSTM frame predictor behind the ARM protocol, generating on the MI355X.
+
+Config, module wiring and ``state_dict`` layout follow the reference
+(``mimikit/networks/s2s_lstm_v2.py``: ``EncoderLSTM`` :53-116, ``DecoderLSTM``
+:119-182, ``Seq2SeqLSTMNetwork`` :185-303).  One ``generate_step`` maps the last
+``hop`` frames to the next ``hop`` frames; on the HIP device it runs as
+``csrc/s2s_plan.hip`` (GEMM-shaped: fp32 matrix cores).  Covered option space:
+continuous (magspec) input, ``enc_downsampling='edge_sum'``,
+``dec_upsampling='linear_resample'``, one LSTM each, no residuals / weight norm.
+"""
+import dataclasses as dtc
+from enum import auto
+from typing import Dict, Set, Tuple
+
+import torch
+import torch.nn as nn
+
+from .. import native
+from ..features.functionals import Continuous
+from ..features.item_spec import ItemSpec
+from ..io_spec import IOSpec
+from ..modules.io import ZipReduceVariables
+from ..modules.misc import Chunk
+from ..modules.resamplers import LinearResampler
+from ..utils import AutoStrEnum
+from .arm import ARMWithHidden, NetworkConfig
+
+__all__ = ["EncoderLSTM", "DecoderLSTM", "Seq2SeqLSTMNetwork"]
+
+
+class DownSampling(AutoStrEnum):
+    edge_sum = auto()
+    edge_mean = auto()
+    sum = auto()
+    mean = auto()
+    linear_resample = auto()
+
+
+class UpSampling(AutoStrEnum):
+    repeat = auto()
+    interp = auto()
+    linear_resample = auto()
+
+
+def _bi_lstms(in_dim, dim, n):
+    return nn.ModuleList([nn.LSTM(in_dim if i == 0 else dim, dim, batch_first=True, bidirectional=True)
+                          for i in range(n)])
+
+
+def _fold_directions(y, dim):
+    """the reference's ``y.view(..., dim, 2).sum(-1)`` (:100, :174): sums ADJACENT channel pairs of the
+    [forward | backward] concatenation"""
+    return y.view(*y.size()[:-1], dim, 2).sum(dim=-1)
+
+
+class EncoderLSTM(nn.Module):
+    def __init__(self, downsampling: str, input_dim: int = 512, output_dim: int = 512, num_layers: int = 1,
+                 hop: int = 4, apply_residuals: bool = False, weight_norm: bool = False):
+        super().__init__()
+        if weight_norm:
+            raise NotImplementedError("weight_norm is outside the covered option space")
+        self.downsampling, self.input_dim, self.output_dim = str(downsampling), input_dim, output_dim
+        self.num_layers, self.hop, self.apply_residuals = num_layers, hop, apply_residuals
+        self.lstm = _bi_lstms(input_dim, output_dim, num_layers)
+        if self.downsampling == "linear_resample":
+            self.fc = LinearResampler(output_dim, 1 / hop, 1)
+        self.fc_out = nn.Linear(output_dim, output_dim, bias=False)
+        self.hidden = [None] * num_layers
+
+    def forward(self, x):
+        assert x.size(1) == self.hop
+        for n, lstm in enumerate(self.lstm):
+            y, self.hidden[n] = lstm(x)   # fresh zero state on every call
+            y = _fold_directions(y, self.output_dim)
+            x = x + y if (n > 0 and self.apply_residuals) else y
+        if self.downsampling == "linear_resample":
+            return self.fc_out(self.fc(x)), self.hidden[-1]
+        x = x.unfold(1, self.hop, self.hop)
+        if "edge" in self.downsampling:
+            x = x[..., [0, -1]]
+        pooled = x.sum(dim=-1) if "sum" in self.downsampling else x.mean(dim=-1)
+        return self.fc_out(pooled), self.hidden[-1]
+
+
+class DecoderLSTM(nn.Module):
+    def __init__(self, upsampling: str, model_dim: int = 512, num_layers: int = 1, hop: int = 4,
+                 apply_residuals: bool = False, weight_norm: bool = False):
+        super().__init__()
+        if weight_norm:
+            raise NotImplementedError("weight_norm is outside the covered option space")
+        self.upsampling = str(upsampling)
+        self.output_dim = self.model_dim = model_dim
+        self.num_layers, self.hop, self.apply_residuals = num_layers, hop, apply_residuals
+        self.lstm = _bi_lstms(model_dim, model_dim, num_layers)
+        if self.upsampling == "linear_resample":
+            self.fc = LinearResampler(model_dim, hop, 1)
+        self.hidden = [None] * num_layers
+
+    def forward(self, x, hidden=None):
+        assert x.size(1) == 1
+        if self.upsampling == "linear_resample":
+            x = self.fc(x)
+        elif self.upsampling == "repeat":
+            x = x.repeat_interleave(self.hop, 1)
+        else:
+            raise NotImplementedError(f"dec_upsampling='{self.upsampling}' is outside the covered option space")
+        self.hidden[0] = hidden
+        for n, lstm in enumerate(self.lstm):
+            y, self.hidden[n] = lstm(x, hidden)   # every layer is seeded with the encoder state (:171)
+            y = _fold_directions(y, self.model_dim)
+            x = x + y if self.apply_residuals else y
+        return x
+
+
+class Seq2SeqLSTMNetwork(ARMWithHidden, nn.Module):
+    @dtc.dataclass
+    class Config(NetworkConfig):
+        io_spec: IOSpec = None
+        model_dim: int = 1024
+        enc_downsampling: DownSampling = "edge_sum"
+        enc_n_lstm: int = 1
+        enc_apply_residuals: bool = False
+        enc_weight_norm: bool = False
+        dec_upsampling: UpSampling = "linear_resample"
+        dec_n_lstm: int = 1
+        dec_apply_residuals: bool = False
+        dec_weight_norm: bool = False
+        hop: int = 8
+
+    @classmethod
+    def from_config(cls, cfg: "Seq2SeqLSTMNetwork.Config"):
+        first = cfg.io_spec.inputs[0]
+        if isinstance(first.elem_type, Continuous):
+            input_dim, input_module = first.elem_type.size, sum   # continuous inputs are just added up (:202-204)
+        else:
+            input_dim = cfg.model_dim
+            input_module = ZipReduceVariables(mode="sum", modules=[
+                spec.module.copy().set(out_dim=cfg.model_dim).module() for spec in cfg.io_spec.inputs])
+        enc = EncoderLSTM(downsampling=cfg.enc_downsampling, input_dim=input_dim, output_dim=cfg.model_dim,
+                          num_layers=cfg.enc_n_lstm, weight_norm=cfg.enc_weight_norm, hop=cfg.hop,
+                          apply_residuals=cfg.enc_apply_residuals)
+        # (the reference passes dec_apply_residuals as the decoder's weight_norm flag, :221)
+        dec = DecoderLSTM(upsampling=cfg.dec_upsampling, model_dim=cfg.model_dim, num_layers=cfg.dec_n_lstm,
+                          hop=cfg.hop, apply_residuals=cfg.dec_apply_residuals, weight_norm=cfg.dec_apply_residuals)
+        heads = [spec.module.copy().set(in_dim=cfg.model_dim).module() for spec in cfg.io_spec.targets]
+        return cls(cfg, input_module=input_module, output_module=ZipReduceVariables(mode="sum", modules=heads),
+                   encoder=enc, decoder=dec)
+
+    def __init__(self, config, input_module, output_module, encoder: EncoderLSTM, decoder: DecoderLSTM):
+        super().__init__()
+        self._config = config
+        self.input_module = input_module
+        self.enc = encoder
+        self.dec = decoder
+        self.output_module = output_module
+        self.output_length = lambda n: n
+        self._plan = None
+        self._plan_batch = 0
+        self._stale = True
+
+    # -- ARM properties -----------------------------------------------------------
+    @property
+    def config(self) -> NetworkConfig:
+        return self._config
+
+    @property
+    def rf(self):
+        return self._config.hop
+
+    @property
+    def generate_params(self) -> Set[str]:
+        return {p for m in getattr(self.output_module, "heads", []) for p in getattr(m, "sampling_params", {})}
+
+    def train_batch(self, item_spec: ItemSpec):
+        hop = self._config.hop
+        return tuple(
+            spec.to_batch_item(ItemSpec(shift=0, length=hop, unit=item_spec.unit)) for spec in self.config.io_spec.inputs
+        ), tuple(
+            spec.to_batch_item(ItemSpec(shift=hop, length=hop, unit=item_spec.unit)) for spec in self.config.io_spec.targets
+        )
+
+    def test_batch(self, item_spec: ItemSpec):
+        return tuple(spec.to_batch_item(item_spec) for spec in self.config.io_spec.inputs), ()
+
+    # -- forward ------------------------------------------------------------------------
+    def _forward_autograd(self, x: Tuple, temperature=None):
+        x = self.input_module(x)
+        coded, (h_enc, c_enc) = self.enc(x)
+        out = self.dec(coded, (h_enc, c_enc))
+        return self.output_module((out,), *((temperature,) if temperature is not None else ()))
+
+    def forward(self, x: Tuple, temperature=None):
+        if self.training:
+            return self._forward_autograd(x, temperature)
+        return self._device_step(tuple(x))
+
+    # -- HIP plan ---------------------------------------------------------------------
+    def _describe(self, max_batch: int) -> native.S2SConfig:
+        cfg = self._config
+        unsupported = []
+        if self.input_module is not sum:
+            unsupported.append("discrete inputs (input module other than a plain sum)")
+        if str(cfg.enc_downsampling) != "edge_sum":
+            unsupported.append(f"enc_downsampling='{cfg.enc_downsampling}'")
+        if str(cfg.dec_upsampling) != "linear_resample":
+            unsupported.append(f"dec_upsampling='{cfg.dec_upsampling}'")
+        if cfg.enc_n_lstm != 1 or cfg.dec_n_lstm != 1:
+            unsupported.append("more than one LSTM per side")
+        if cfg.enc_apply_residuals or cfg.dec_apply_residuals:
+            unsupported.append("residual LSTM stacks")
+        heads = list(self.output_module.heads)
+        c = native.S2SConfig()
+        if len(heads) != 1 or len(cfg.io_spec.inputs) != 1:
+            unsupported.append("more than one input / target")
+        else:
+            head = heads[0]
+            lin = head[0] if isinstance(head, nn.Sequential) else None
+            tail = [m for m in list(head)[1:] if not (isinstance(m, Chunk) and m.chunks == 1)] if lin is not None else []
+            kinds = [type(m).__name__ for m in tail]
+            if not isinstance(lin, nn.Linear) or lin.bias is None or kinds not in ([], ["Abs"]):
+                unsupported.append("output module other than (Chunked)LinearIO [+ Abs]")
+            else:
+                c.out_dim, c.out_abs = lin.out_features, int(kinds == ["Abs"])
+        if unsupported:
+            raise NotImplementedError("the HIP generate path does not cover: " + "; ".join(unsupported))
+        c.in_dim = self.enc.input_dim
+        c.model_dim, c.hop = cfg.model_dim, cfg.hop
+        c.enc_n_lstm, c.dec_n_lstm = cfg.enc_n_lstm, cfg.dec_n_lstm
+        c.max_batch = max_batch
+        return c
+
+    def _ensure_plan(self, batch: int, refresh_weights: bool):
+        device = self.device
+        if device.type != "cuda":
+            raise RuntimeError("Seq2SeqLSTMNetwork generates on the MI355X only: move the network to the HIP device "
+                               "('cuda'); there is no CPU implementation in this package")
+        rebuilt = False
+        if self._plan is None or self._plan_batch < batch or self._plan.device != device:
+            self._plan = native.S2SPlan(self._describe(max(batch, 1)), device)
+            self._plan_batch = max(batch, 1)
+            rebuilt = True
+        if rebuilt or refresh_weights or self._stale:
+            self._plan.bind_state_dict(self.state_dict())
+            self._plan.commit()
+            self._stale = False
+
+    def _device_step(self, inputs: Tuple[torch.Tensor, ...]):
+        native.require_device(*inputs)
+        x = inputs[0] if len(inputs) == 1 else sum(inputs)
+        if x.size(1) != self._config.hop:
+            raise AssertionError(f"expected {self._config.hop} input frames, got {x.size(1)}")
+        self._ensure_plan(x.size(0), refresh_weights=False)
+        x = x.float() if x.dtype != torch.float32 else x
+        return self._plan.step(x if x.stride(2) == 1 else x.contiguous())
+
+    # -- ARM generation protocol ------------------------------------------------------
+    def reset_hidden(self):
+        self.enc.hidden = [None] * self._config.enc_n_lstm
+        self.dec.hidden = [None] * self._config.dec_n_lstm
+
+    def before_generate(self, prompts: Tuple[torch.Tensor, ...], batch_index) -> None:
+        self.reset_hidden()
+        native.require_device(*tuple(prompts))
+        self._ensure_plan(prompts[0].size(0), refresh_weights=True)
+
+    def generate_step(self, inputs: Tuple[torch.Tensor, ...], *, t: int = 0, **parameters):
+        return self._device_step(tuple(inputs))
+
+    def generate_block(self, tensors: Tuple[torch.Tensor, ...], t0: int, n_steps: int, **parameters):
+        tensors = tuple(tensors)
+        native.require_device(*tensors)
+        if len(tensors) != 1 or tensors[0].dtype != torch.float32:
+            return None
+        frames = tensors[0]
+        self._ensure_plan(frames.size(0), refresh_weights=False)
+        self._plan.generate(frames, t0, n_steps)
+        return True
+
+    def after_generate(self, final_outputs: Tuple[torch.Tensor, ...], batch_index) -> None:
+        self.reset_hidden()
+        self._stale = True

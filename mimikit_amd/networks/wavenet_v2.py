@@ -1,0 +1,435 @@
+"""WaveNet behind the ARM protocol, generating on the MI355X.
+
+Config fields, layer wiring and ``state_dict`` layout follow the reference
+(``mimikit/networks/wavenet_v2.py``: ``WNLayer`` :32-182, ``WaveNet`` :185-469).
+
+Generation differs in HOW, not WHAT: the reference's ``generate_step`` is a full
+forward over the rf-long window (its "fast generate" hooks are dead code,
+SURVEY.md section 0), i.e. O(rf * L) layer evaluations per sample.  Here every layer keeps
+a dilation queue of its past inputs in HBM (``csrc/wavenet_plan.hip``) and a step
+costs L fused layer kernels; results are the same arithmetic on the same
+operands.  ``eval()`` forward / ``generate_step`` / ``generate_block`` run only on
+the HIP device through ``libmmk_hip.so``; training-mode ``forward`` is the stock
+differentiable torch graph (training is out of this package's scope and is
+kept only so the network still drops into the reference's trainer).
+"""
+import dataclasses as dtc
+import operator
+from itertools import accumulate, chain
+from typing import Dict, Iterable, List, Optional, Set, Tuple
+
+import torch
+import torch.nn as nn
+
+from .. import native
+from ..features.item_spec import ItemSpec, Step
+from ..io_spec import IOSpec
+from ..modules.activations import ActivationConfig, ActivationEnum
+from ..modules.misc import CausalPad, Chunk, Transpose
+from ..modules.mlp import MLP
+from ..modules.targets import OutputWrapper, per_row_temperature
+from .arm import ARM, NetworkConfig
+
+__all__ = ["WNLayer", "WaveNet"]
+
+
+class WNLayer(nn.Module):
+    """One dilated causal conv layer with gated units, 1x1 conditioning, skip and residual
+    connections.  Holds the parameters (reference names) and the differentiable forward."""
+
+    def __init__(self, input_dim: Optional[int] = None, dims_dilated: Tuple[int] = (128,),
+                 dims_1x1: Tuple[int] = tuple(), residuals_dim: Optional[int] = None,
+                 apply_residuals: bool = False, skips_dim: Optional[int] = None, kernel_size: int = 2,
+                 groups: int = 1, act_f: nn.Module = nn.Tanh(), act_g: Optional[nn.Module] = nn.Sigmoid(),
+                 pad_side: int = 1, stride: int = 1, bias: bool = True, dilation: int = 1,
+                 with_affine_residuals: bool = False):
+        super().__init__()
+        if with_affine_residuals:
+            raise NotImplementedError("with_affine_residuals is outside the covered option space (SURVEY 8(f) rank 4)")
+        self.input_dim, self.dims_dilated, self.dims_1x1 = input_dim, dims_dilated, dims_1x1
+        self.residuals_dim, self.apply_residuals, self.skips_dim = residuals_dim, apply_residuals, skips_dim
+        self.kernel_size, self.groups, self.act_f, self.act_g = kernel_size, groups, act_f, act_g
+        self.pad_side, self.stride, self.bias, self.dilation = pad_side, stride, bias, dilation
+
+        self.cause = (kernel_size - 1) * dilation
+        self.needs_padding = pad_side != 0
+        self.has_gated_units = act_g is not None
+        self.has_skips = skips_dim is not None
+        self.has_residuals = residuals_dim is not None and (input_dim is None or input_dim == residuals_dim)
+
+        inner = dims_dilated[0]
+        outer = inner if residuals_dim is None else residuals_dim
+        in_dim = outer if input_dim is None else input_dim
+        kw_dil = dict(kernel_size=(kernel_size,), dilation=dilation, stride=stride, bias=bias, groups=groups)
+        kw_1x1 = dict(kernel_size=(1,), stride=stride, bias=bias)
+        if self.needs_padding:
+            self.pad = CausalPad((0, 0, pad_side * self.cause))
+        if self.has_gated_units:
+            def gated(i, o, **kw):
+                return nn.Sequential(nn.Conv1d(i, o * 2, **kw), Chunk(2, dim=1, sum_outputs=False))
+
+            self.conv_dil = nn.ModuleList([gated(in_dim, d, **kw_dil) for d in dims_dilated])
+            self.conv_1x1 = nn.ModuleList([gated(d, inner, **kw_1x1) for d in dims_1x1])
+        else:
+            self.conv_dil = nn.ModuleList([nn.Conv1d(in_dim, d, **kw_dil) for d in dims_dilated])
+            self.conv_1x1 = nn.ModuleList([nn.Conv1d(d, inner, **kw_1x1) for d in dims_1x1])
+        if self.has_skips:
+            self.conv_skip = nn.Conv1d(inner, skips_dim, **kw_1x1)
+        if self.has_residuals:
+            self.conv_res = nn.Conv1d(inner, outer, **kw_1x1)
+
+    def trim_cause(self, x):
+        cs = self.cause
+        return x[:, :, cs:] if self.pad_side >= 0 else x[:, :, :-cs]
+
+    def forward(self, inputs_dilated, inputs_1x1, skips=None):
+        x = inputs_dilated[0]
+        if self.needs_padding:
+            x = self.pad(x)
+        conds = [c if self.needs_padding else self.trim_cause(c) for c in inputs_1x1]
+        if self.has_gated_units:
+            z_f, z_g = self.conv_dil[0](x)
+            for conv, c in zip(self.conv_1x1, conds):
+                c_f, c_g = conv(c)
+                z_f, z_g = z_f + c_f, z_g + c_g
+            y = self.act_f(z_f) * self.act_g(z_g)
+        else:
+            z = self.conv_dil[0](x)
+            for conv, c in zip(self.conv_1x1, conds):
+                z = z + conv(c)
+            y = self.act_f(z)
+        if self.has_skips:
+            if skips is not None and not self.needs_padding:
+                skips = self.trim_cause(skips)
+            skips = self.conv_skip(y) if skips is None else self.conv_skip(y) + skips
+        if self.has_residuals:
+            y = self.trim_cause(x) + self.conv_res(y)
+        return y, skips
+
+
+class WaveNet(ARM, nn.Module):
+    @dtc.dataclass
+    class Config(NetworkConfig):
+        io_spec: IOSpec = None
+        kernel_sizes: Tuple[int, ...] = (2,)
+        blocks: Tuple[int, ...] = (4,)
+        dims_dilated: Tuple[int, ...] = (128,)
+        dims_1x1: Tuple[int, ...] = ()
+        residuals_dim: Optional[int] = None
+        apply_residuals: bool = False
+        skips_dim: Optional[int] = None
+        with_affine_residuals: bool = False
+        groups: int = 1
+        act_f: ActivationEnum = "Tanh"
+        act_g: Optional[ActivationEnum] = "Sigmoid"
+        pad_side: int = 0
+        stride: int = 1
+        bias: bool = True
+        use_fast_generate: bool = False
+        tie_io_weights: bool = False
+        layerwise_inputs: bool = False
+        reverse_layer_order: bool = False
+
+    # -- construction -----------------------------------------------------------
+    @classmethod
+    def get_kernels_and_dilation(cls, kernel_sizes, blocks):
+        """(kernel size, dilation) per layer from the (kernel_sizes, blocks) shorthand
+        (reference :295-327): one kernel + n blocks, one block pattern repeated, or explicit."""
+        kernel_sizes, blocks = tuple(kernel_sizes), tuple(blocks)
+        if not blocks:
+            return list(kernel_sizes), list(accumulate([1, *kernel_sizes], operator.mul))
+        if len(set(blocks)) == 1 and blocks[0] == len(kernel_sizes):
+            one = list(accumulate([1, *kernel_sizes[:-1]], operator.mul))
+            return list(kernel_sizes) * len(blocks), one * len(blocks)
+        if len(kernel_sizes) == sum(blocks):
+            dil, start = [], 0
+            for b in blocks:
+                dil += list(accumulate([1, *kernel_sizes[start:start + b - 1]], operator.mul))
+                start += b
+            return list(kernel_sizes), dil
+        if len(kernel_sizes) == 1:
+            k = kernel_sizes[0]
+            return [k] * sum(blocks), [k ** i for b in blocks for i in range(b)]
+        raise ValueError("number of layers and number of kernel sizes not compatible."
+                         f" Got kernel_sizes={kernel_sizes} ; blocks={blocks}")
+
+    @classmethod
+    def get_layers(cls, config: "WaveNet.Config") -> List[WNLayer]:
+        ks, ds = cls.get_kernels_and_dilation(config.kernel_sizes, config.blocks)
+        ks, ds = list(ks), list(ds)
+        n_layers = sum(config.blocks) if config.blocks else len(ks)
+        layers = []
+        for n, (k, d) in enumerate(zip(ks, ds)):
+            layers.append(WNLayer(
+                input_dim=config.dims_dilated[0], dims_dilated=config.dims_dilated, dims_1x1=config.dims_1x1,
+                residuals_dim=config.residuals_dim if n != n_layers - 1 else None,  # no residuals for last layer
+                apply_residuals=config.apply_residuals and n != 0, skips_dim=config.skips_dim, kernel_size=k,
+                groups=config.groups, act_f=ActivationConfig(str(config.act_f)).get(),
+                act_g=ActivationConfig(str(config.act_g)).get() if config.act_g is not None else None,
+                pad_side=config.pad_side, stride=config.stride, bias=config.bias, dilation=d,
+                with_affine_residuals=config.with_affine_residuals))
+        return layers
+
+    @classmethod
+    def from_config(cls, config: "WaveNet.Config") -> "WaveNet":
+        layers = cls.get_layers(config)
+        hidden = [*config.dims_dilated, *config.dims_1x1]
+        input_modules = [spec.module.copy().set(out_dim=h).module() for spec, h in zip(config.io_spec.inputs, hidden)]
+        head_in = config.skips_dim if config.skips_dim is not None else hidden[0]
+        output_modules = [spec.module.copy().set(in_dim=head_in).module() for spec in config.io_spec.targets]
+        if config.tie_io_weights:
+            raise NotImplementedError("tie_io_weights is outside the covered option space (SURVEY 8(f) rank 4)")
+        return cls(config=config, layers=layers, input_modules=input_modules, output_modules=output_modules)
+
+    def __init__(self, config: "WaveNet.Config", layers: List[WNLayer], input_modules: List[nn.Module],
+                 output_modules: List[nn.Module]):
+        super().__init__()
+        self._config = config
+        self.input_modules = nn.ModuleList(input_modules)
+        self.transpose = Transpose(1, 2)
+        self.layers: Iterable[WNLayer] = nn.ModuleList(reversed(layers) if config.reverse_layer_order else layers)
+        self.has_skips = config.skips_dim is not None
+        self.output_modules = nn.ModuleList(output_modules)
+        self.eval_slice = slice(-1, None) if config.pad_side == 1 else slice(0, 1)
+        self._plan: Optional[native.WaveNetPlan] = None
+        self._plan_batch = 0
+        self._next_t: Optional[int] = None   # absolute time the queues are ready to produce
+        self._state_batch = 0
+
+    # -- ARM properties -----------------------------------------------------------
+    @property
+    def config(self) -> Config:
+        return self._config
+
+    @property
+    def shift(self) -> int:
+        return 1 if self.config.pad_side == 1 else self.rf
+
+    @property
+    def rf(self) -> int:
+        return sum(layer.cause for layer in self.layers) + 1
+
+    def output_length(self, n_input_steps: int) -> int:
+        return n_input_steps if self.config.pad_side != 0 else n_input_steps - self.shift + 1
+
+    @property
+    def use_fast_generate(self):
+        return self._config.use_fast_generate
+
+    def train_batch(self, item_spec: ItemSpec):
+        inputs = tuple(spec.to_batch_item(item_spec) for spec in self.config.io_spec.inputs)
+        shifted = item_spec + ItemSpec(self.shift, self.output_length(0), unit=Step())
+        return inputs, tuple(spec.to_batch_item(shifted) for spec in self.config.io_spec.targets)
+
+    def test_batch(self, item_spec: ItemSpec):
+        return self.train_batch(item_spec)
+
+    @property
+    def generate_params(self) -> Set[str]:
+        # Reproduced quirk: the reference asks the ModuleList itself (wavenet_v2.py:364-366), which
+        # has no `sampling_params`, so GenerateLoopV2 filters every parameter out and a WaveNet
+        # always decodes greedily inside the loop.  `generate_step` / `generate_block` called
+        # directly still honour `temperature=`, as in the reference's tests.
+        return set(getattr(self.output_modules, "sampling_params", {}))
+
+    # -- differentiable forward (training only) --------------------------------------
+    def _forward_autograd(self, inputs: Tuple, **parameters):
+        feats = tuple(self.transpose(mod(x)) for mod, x in zip(self.input_modules, inputs))
+        dilated, in_1x1, skips = feats[0], feats[1:], None
+        for layer in self.layers:
+            dilated, skips = layer(inputs_dilated=(dilated,), inputs_1x1=in_1x1, skips=skips)
+            if self._config.layerwise_inputs:
+                dilated = dilated + feats[0][..., -dilated.size(-1):]
+            if not layer.needs_padding:
+                in_1x1 = tuple(layer.trim_cause(x) for x in in_1x1)
+        y = self.transpose(skips if self.has_skips else dilated)
+        return tuple(mod(y, **parameters) for mod in self.output_modules)
+
+    def forward(self, inputs: Tuple, **parameters):
+        if self.training:
+            return self._forward_autograd(inputs, **parameters)
+        # eval: one output step computed from the first rf positions (eval_slice, reference :273, :291-292)
+        inputs = tuple(inputs)
+        native.require_device(*inputs)
+        rf = self.rf
+        if inputs[0].size(1) < rf:
+            raise RuntimeError(f"Calculated output size is too small: window of {inputs[0].size(1)} steps "
+                               f"for a receptive field of {rf}")
+        return self._window_step(tuple(x[:, :rf] for x in inputs), t=rf, **parameters)
+
+    # -- HIP plan ---------------------------------------------------------------------
+    def _describe(self, max_batch: int) -> native.WaveNetConfig:
+        cfg, io = self._config, self._config.io_spec
+        unsupported = []
+        if cfg.pad_side != 0:
+            unsupported.append("pad_side != 0")
+        if cfg.groups != 1:
+            unsupported.append("groups > 1")
+        if cfg.stride != 1:
+            unsupported.append("stride != 1")
+        if cfg.layerwise_inputs or cfg.reverse_layer_order or cfg.with_affine_residuals:
+            unsupported.append("layerwise_inputs / reverse_layer_order / with_affine_residuals")
+        if str(cfg.act_f) != "Tanh" or (cfg.act_g is not None and str(cfg.act_g) != "Sigmoid"):
+            unsupported.append("activations other than Tanh / Sigmoid")
+        if len(cfg.dims_dilated) != 1:
+            unsupported.append("more than one dilated path")
+        if len(io.targets) != 1:
+            unsupported.append("more than one target")
+        if len(cfg.dims_1x1) > native.MAX_COND or len(self.layers) > native.MAX_LAYERS:
+            unsupported.append("too many conditioning inputs / layers")
+        c = native.WaveNetConfig()
+        c.n_layers = len(self.layers)
+        for i, layer in enumerate(self.layers):
+            c.kernel_size[i], c.dilation[i] = layer.kernel_size, layer.dilation
+        first = self.input_modules[0][0]
+        if isinstance(first, nn.Embedding) and len(self.input_modules[0]) == 1:
+            c.q_levels, c.in_dim = first.num_embeddings, 0
+        elif isinstance(first, nn.Linear) and first.bias is not None and all(
+                isinstance(m, Chunk) and m.chunks == 1 for m in list(self.input_modules[0])[1:]):
+            c.q_levels, c.in_dim = 0, first.in_features
+        else:
+            unsupported.append(f"input module 0 of type {type(first).__name__}")
+        c.dim_dilated = cfg.dims_dilated[0]
+        c.residuals_dim = cfg.residuals_dim or 0
+        c.skips_dim = cfg.skips_dim or 0
+        c.n_cond = len(cfg.dims_1x1)
+        for j, mod in enumerate(self.input_modules[1:]):
+            lin = mod[0]
+            if not isinstance(lin, nn.Linear) or lin.bias is None or not all(
+                    isinstance(m, Chunk) and m.chunks == 1 for m in list(mod)[1:]):
+                unsupported.append(f"conditioning input module {j + 1} is not a plain (Chunked)LinearIO")
+                continue
+            c.cond_in_dim[j], c.cond_dim[j] = lin.in_features, lin.out_features
+        c.bias, c.gated = int(cfg.bias), int(cfg.act_g is not None)
+        head = self.output_modules[0]
+        if isinstance(head, OutputWrapper) and isinstance(head.estimator[0], MLP) and len(head.estimator) == 1:
+            mlp: MLP = head.estimator[0]
+            if not isinstance(mlp.activation, nn.Mish) or not mlp.bias or mlp.dropout or mlp.dropout1d:
+                unsupported.append("MLP head with a non-Mish activation, no bias or dropout")
+            c.head_kind, c.mlp_hidden, c.mlp_n_hidden = 0, mlp.hidden_dim, mlp.n_hidden_layers
+            c.learn_temp = int(mlp.learn_temperature)
+            c.out_dim = mlp.out_dim - c.learn_temp
+            c.min_temp = float(mlp.min_temp) if mlp.learn_temperature else 0.
+            if mlp.n_hidden_layers > 1:
+                unsupported.append("n_mlp_layers > 1")
+        elif isinstance(head, nn.Sequential) and isinstance(head[0], nn.Linear) and head[0].bias is not None:
+            tail = [m for m in list(head)[1:] if not (isinstance(m, Chunk) and m.chunks == 1)]
+            kinds = [type(m).__name__ for m in tail]
+            if kinds == ["Abs"]:
+                c.head_kind = 1
+            elif not kinds:
+                c.head_kind = 2
+            else:
+                unsupported.append(f"linear head followed by {kinds}")
+            c.out_dim = head[0].out_features
+        else:
+            unsupported.append(f"output module of type {type(head).__name__}")
+        c.max_batch = max_batch
+        if unsupported:
+            raise NotImplementedError("the HIP generate path does not cover: " + "; ".join(unsupported))
+        return c
+
+    def _ensure_plan(self, batch: int, refresh_weights: bool):
+        device = self.device
+        if device.type != "cuda":
+            raise RuntimeError("WaveNet generates on the MI355X only: move the network to the HIP device ('cuda'); "
+                               "there is no CPU implementation in this package")
+        rebuilt = False
+        if self._plan is None or self._plan_batch < batch or self._plan.device != device:
+            self._plan = native.WaveNetPlan(self._describe(max(batch, 1)), device)
+            self._plan_batch = max(batch, 1)
+            rebuilt = True
+        if rebuilt or refresh_weights:
+            self._plan.bind_state_dict(self.state_dict())
+            self._plan.commit()   # repacks the (possibly just trained) weights and clears the queues
+            self._next_t = None
+
+    def _sampling(self, batch: int, n_steps: int, parameters: Dict):
+        temperature = parameters.get("temperature", None)
+        if temperature is None:
+            return None, None
+        if self._plan.cfg.head_kind != 0:
+            return None, None
+        t = per_row_temperature(temperature, batch, self.device)
+        u = torch.rand((batch, n_steps), device=self.device, dtype=torch.float32)
+        return t, u
+
+    def _prepare(self, tensors: Tuple[torch.Tensor, ...]):
+        in0, cond = tensors[0], tuple(tensors[1:])
+        if self._plan.cfg.q_levels == 0 and in0.dtype != torch.float32:
+            in0 = in0.float()
+        return in0, tuple(c if c.dtype == torch.float32 else c.float() for c in cond)
+
+    def _window_step(self, window: Tuple[torch.Tensor, ...], t: int, **parameters):
+        """rebuild the queues from an rf-long window ending at absolute time t, then produce step t"""
+        batch, rf = window[0].size(0), self.rf
+        self._ensure_plan(batch, refresh_weights=True)
+        in0, cond = self._prepare(window)
+        # scratch copy of the window with one free column for the produced step
+        buf = torch.cat([in0, torch.zeros_like(in0[:, :1])], dim=1).contiguous()
+        cond = tuple(c.contiguous() for c in cond)
+        t_first = t - rf
+        self._plan.warmup(buf, cond, t_first, t - 1, t_first=t_first)
+        temp, uni = self._sampling(batch, 1, parameters)
+        self._plan.generate(buf, cond, t, 1, temp, uni, t_first=t_first)
+        self._next_t, self._state_batch = t + 1, batch
+        return (buf[:, rf:rf + 1],)
+
+    # -- ARM generation protocol ------------------------------------------------------
+    def before_generate(self, prompts: Tuple[torch.Tensor, ...], batch_index) -> None:
+        prompts = tuple(prompts)
+        native.require_device(*prompts)
+        batch, length, rf = prompts[0].size(0), prompts[0].size(1), self.rf
+        self._ensure_plan(batch, refresh_weights=True)
+        if length < rf:
+            # the reference fails at its first step on such a prompt (negative window start)
+            self._next_t = None
+            return
+        in0, cond = self._prepare(prompts)
+        in0 = in0 if in0.stride(-1) == 1 else in0.contiguous()
+        cond = tuple(c.contiguous() for c in cond)
+        # positions [P - rf, P - 1) fill the queues; position P - 1 is consumed by the first step
+        self._plan.warmup(in0, cond, length - rf, length - 1, t_first=0)
+        self._next_t, self._state_batch = length, batch
+
+    def generate_step(self, inputs: Tuple[torch.Tensor, ...], *, t: int = 0, **parameters):
+        inputs = tuple(inputs)
+        native.require_device(*inputs)
+        batch, rf = inputs[0].size(0), self.rf
+        if inputs[0].size(1) < rf:
+            raise RuntimeError(f"Calculated output size is too small: window of {inputs[0].size(1)} steps "
+                               f"for a receptive field of {rf}")
+        if self._plan is None or self._next_t != t or self._state_batch != batch:
+            return self._window_step(tuple(x[:, -rf:] for x in inputs), t=t, **parameters)
+        # queues are in sync: only the newest position (t - 1) is consumed
+        in0, cond = self._prepare(tuple(x[:, -1:] for x in inputs))
+        buf = torch.cat([in0, torch.zeros_like(in0)], dim=1).contiguous()
+        cond = tuple(c.contiguous() for c in cond)
+        temp, uni = self._sampling(batch, 1, parameters)
+        self._plan.generate(buf, cond, t, 1, temp, uni, t_first=t - 1)
+        self._next_t = t + 1
+        return (buf[:, 1:2],)
+
+    def generate_block(self, tensors: Tuple[torch.Tensor, ...], t0: int, n_steps: int, **parameters):
+        """all steps of one batch in one device call; ``tensors`` are the loop's (batch, prior+steps[, dim])
+        tensors, target 0 is written in place into ``tensors[0]``"""
+        tensors = tuple(tensors)
+        native.require_device(*tensors)
+        batch = tensors[0].size(0)
+        if self._plan is None or self._next_t != t0 or self._state_batch != batch:
+            self.before_generate(tuple(x[:, :t0] for x in tensors), None)
+            if self._next_t != t0:
+                raise RuntimeError(f"prompt of {t0} steps is shorter than the receptive field ({self.rf})")
+        in0, cond = self._prepare(tensors)
+        if in0.data_ptr() != tensors[0].data_ptr():
+            raise TypeError("generate_block writes in place: tensors[0] must already have the network's input dtype")
+        for c, orig in zip(cond, tensors[1:]):
+            if not c.is_contiguous():
+                raise ValueError("conditioning tensors must be contiguous for generate_block")
+        temp, uni = self._sampling(batch, n_steps, parameters)
+        self._plan.generate(in0, cond, t0, n_steps, temp, uni, t_first=0)
+        self._next_t = t0 + n_steps
+        return True
+
+    def after_generate(self, final_outputs: Tuple[torch.Tensor, ...], batch_index) -> None:
+        self._next_t = None

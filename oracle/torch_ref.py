@@ -1,0 +1,335 @@
+"""CPU restatement of the reference's generate-path algorithms (TEST INFRASTRUCTURE ONLY).
+
+This file is the ORACLE of the repo: plain fp32 PyTorch/numpy on the host, no
+dependence on the product package, each function citing the reference lines it
+restates (paths relative to the reference root, ``mimikit/...``).  It executes the
+reference's ALGORITHM literally -- in particular the naive WaveNet generation that
+re-runs the whole rf-long window for every sample (networks/wavenet_v2.py:276-293,
+:447-452) and the Python ``for t`` loop of loops/generate.py:207-219 -- so it is
+also what ``bench.py`` times as the reference-algorithm CPU baseline.
+
+Pinning: ``tests/test_oracle_golden.py`` checks every function here against golden
+vectors produced by the reference's own code (imported in the build container
+through ``oracle/ref_shim.py``; generator: ``tests/golden/make_golden.py``).
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s cpu_baseline leg may
+import this module.  All functions take a ``state_dict``-like mapping with the
+reference's parameter names.
+"""
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+SD = Dict[str, torch.Tensor]
+
+
+# ---------------------------------------------------------------------------
+# features
+# ---------------------------------------------------------------------------
+def mulaw_compress(x: torch.Tensor, q_levels: int = 256, compression: float = 1.) -> torch.Tensor:
+    """MuLawCompress.torch_func, features/functionals.py:330-338"""
+    mu = torch.tensor(q_levels - 1.0, dtype=torch.float32)
+    c = torch.tensor(compression, dtype=torch.float32)
+    x = x.to(torch.float32)
+    y = torch.sign(x) * torch.log1p(mu * torch.abs(x) * c) / torch.log1p(mu * c)
+    return ((y + 1) / 2 * mu + 0.5).to(torch.int64)
+
+
+def mulaw_expand(codes: torch.Tensor, q_levels: int = 256, compression: float = 1.) -> torch.Tensor:
+    """MuLawExpand.torch_func, features/functionals.py:361-369"""
+    mu = torch.tensor(q_levels - 1.0, dtype=torch.float32)
+    c = torch.tensor(compression, dtype=torch.float32)
+    x = (codes.to(torch.float32) / mu) * 2 - 1.0
+    return torch.sign(x) * (torch.exp(torch.abs(x) * torch.log1p(mu * c)) - 1.0) / (mu * c)
+
+
+def stft_fixed_length(n_samples: int, n_fft: int, hop: int, center: bool) -> int:
+    """STFT._fix_length target (features/functionals.py:468-486 with features/item_spec.py:58-112)"""
+    extra = 0 if center else n_fft - hop
+    n_frames = int((n_samples - extra) // hop) + int(center)
+    return int((n_frames - int(center)) * hop) + extra
+
+
+def magspec(x: torch.Tensor, n_fft: int, hop: int, center: bool = False, alignment: Optional[str] = "end") -> torch.Tensor:
+    """MagSpec.torch_func == STFT(coordinate='mag').torch_func, features/functionals.py:507-524:
+    length fix-up, torch.stft with a periodic Hann window, (.., frames, bins), abs"""
+    if alignment is not None:
+        keep = stft_fixed_length(x.shape[-1], n_fft, hop, center)
+        x = x[..., -keep:] if alignment == "end" else x[..., :keep]
+    s = torch.stft(x, n_fft, hop_length=hop, return_complex=True, center=center,
+                   window=torch.hann_window(n_fft, device=x.device), pad_mode="constant")
+    return s.transpose(-1, -2).contiguous().abs()
+
+
+# ---------------------------------------------------------------------------
+# head: MLP with learned temperature + categorical sampler
+# ---------------------------------------------------------------------------
+def mlp_raw(sd: SD, prefix: str, x: torch.Tensor, n_hidden: int = 0) -> torch.Tensor:
+    """MLP.fc (networks/mlp.py:42-53): Linear, Mish, [Linear, Mish]*n, Linear -> (.., q+1) raw outputs"""
+    h = F.mish(F.linear(x, sd[prefix + "fc.0.weight"], sd[prefix + "fc.0.bias"]))
+    for i in range(n_hidden):
+        k = prefix + f"fc.{2 * (i + 1)}."
+        h = F.mish(F.linear(h, sd[k + "weight"], sd[k + "bias"]))
+    k = prefix + f"fc.{2 * (n_hidden + 1)}."
+    return F.linear(h, sd[k + "weight"], sd[k + "bias"])
+
+
+def mlp_logits(raw: torch.Tensor, min_temp: Optional[float] = 1e-4) -> torch.Tensor:
+    """MLP.forward tail (networks/mlp.py:58-63)"""
+    if min_temp is None:
+        return raw
+    temp = torch.sigmoid(raw[..., -1:])
+    return raw[..., :-1] / torch.maximum(temp, torch.tensor(min_temp))
+
+
+def categorical(logits: torch.Tensor, temperature=None, uniforms: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """CategoricalSampler.forward (modules/targets.py:37-52).  argmax when temperature is None.
+    With a temperature the reference draws from torch.multinomial, whose RNG stream cannot be
+    reproduced elsewhere; the oracle instead inverts the CDF of the SAME distribution
+    (softmax(logits / T)) at caller-supplied uniforms, which is what the device kernel does."""
+    if temperature is None:
+        return logits.argmax(dim=-1)
+    t = torch.as_tensor(temperature, dtype=torch.float32).reshape(-1, *([1] * (logits.dim() - 1)))
+    l = logits / t
+    l = l - l.max(dim=-1, keepdim=True).values
+    e = torch.exp(l)
+    cdf = torch.cumsum(e, dim=-1)
+    target = uniforms.reshape(*logits.shape[:-1], 1).to(torch.float32) * cdf[..., -1:]
+    hit = (cdf > target) & (e > 0)
+    first = torch.where(hit.any(-1), hit.float().argmax(-1), (e > 0).float().cumsum(-1).argmax(-1))
+    return first
+
+
+# ---------------------------------------------------------------------------
+# WaveNet
+# ---------------------------------------------------------------------------
+def wavenet_dilations(kernel_sizes: Sequence[int], blocks: Sequence[int]) -> Tuple[List[int], List[int]]:
+    """WaveNet.get_kernels_and_dilation for the `one kernel size, n blocks` form (wavenet_v2.py:319-323)"""
+    assert len(kernel_sizes) == 1
+    k = kernel_sizes[0]
+    return [k] * sum(blocks), [k ** i for b in blocks for i in range(b)]
+
+
+def wavenet_rf(kernels: Sequence[int], dilations: Sequence[int]) -> int:
+    """WaveNet.rf, wavenet_v2.py:337-339"""
+    return sum((k - 1) * d for k, d in zip(kernels, dilations)) + 1
+
+
+def wavenet_window_forward(sd: SD, inputs: Tuple[torch.Tensor, ...], kernels: Sequence[int], dilations: Sequence[int],
+                           n_cond: int = 0, has_skips: bool = True, residuals: bool = True,
+                           n_mlp_hidden: int = 0, embedding: bool = True) -> torch.Tensor:
+    """Full-window eval forward (wavenet_v2.py:276-293 with WNLayer.forward :131-176, pad_side=0):
+    returns the RAW head outputs (B, 1, q+1) of the FIRST computable position (eval_slice, :273)."""
+    if embedding:
+        h = F.embedding(inputs[0], sd["input_modules.0.0.weight"])
+    else:
+        h = F.linear(inputs[0], sd["input_modules.0.0.weight"], sd["input_modules.0.0.bias"])
+    h = h.transpose(1, 2).contiguous()
+    conds = [F.linear(inputs[1 + j], sd[f"input_modules.{1 + j}.0.weight"], sd[f"input_modules.{1 + j}.0.bias"])
+             .transpose(1, 2).contiguous() for j in range(n_cond)]
+    skips = None
+    n_layers = len(kernels)
+    for l, (k, d) in enumerate(zip(kernels, dilations)):
+        p = f"layers.{l}."
+        cause = (k - 1) * d
+        z = F.conv1d(h, sd[p + "conv_dil.0.0.weight"], sd.get(p + "conv_dil.0.0.bias"), dilation=d)
+        z_f, z_g = torch.chunk(z, 2, dim=1)
+        c_f, c_g = 0, 0
+        for j in range(n_cond):
+            c = F.conv1d(conds[j][:, :, cause:], sd[p + f"conv_1x1.{j}.0.weight"], sd.get(p + f"conv_1x1.{j}.0.bias"))
+            a, b = torch.chunk(c, 2, dim=1)
+            c_f, c_g = c_f + a, c_g + b
+        y = torch.tanh(z_f + c_f) * torch.sigmoid(z_g + c_g)
+        if has_skips:
+            s = F.conv1d(y, sd[p + "conv_skip.weight"], sd.get(p + "conv_skip.bias"))
+            skips = s if skips is None else s + skips[:, :, cause:]
+        if residuals and l != n_layers - 1:   # last layer is built without residuals (:216)
+            h = h[:, :, cause:] + F.conv1d(y, sd[p + "conv_res.weight"], sd.get(p + "conv_res.bias"))
+        else:
+            h = y
+        conds = [c[:, :, cause:] for c in conds]
+    y = (skips if has_skips else h).transpose(1, 2).contiguous()[:, 0:1]
+    return mlp_raw(sd, "output_modules.0.estimator.0.", y, n_mlp_hidden)
+
+
+def wavenet_generate(sd: SD, prompt: torch.Tensor, cond: Sequence[torch.Tensor], n_steps: int, kernels, dilations,
+                     min_temp: Optional[float] = 1e-4, temperature=None, uniforms=None, keep_logits: bool = False,
+                     **arch):
+    """GenerateLoopV2.run's hot loop (loops/generate.py:195-219) around WaveNet.generate_step:
+    prompt + blanks, one full-window forward per step, in-place write."""
+    rf = wavenet_rf(kernels, dilations)
+    prior = prompt.size(1)
+    idx = torch.cat([prompt, torch.zeros(prompt.size(0), n_steps, dtype=prompt.dtype)], dim=1)
+    logits_log = []
+    for s, t in enumerate(range(prior, prior + n_steps)):
+        window = (idx[:, t - rf:t], *[c[:, t - rf:t] for c in cond])
+        raw = wavenet_window_forward(sd, window, kernels, dilations, n_cond=len(cond), **arch)
+        logits = mlp_logits(raw, min_temp)
+        u = None if uniforms is None else uniforms[:, s]
+        idx[:, t:t + 1] = categorical(logits, temperature, u)
+        if keep_logits:
+            logits_log.append(raw[:, 0])
+    return (idx, torch.stack(logits_log, 1)) if keep_logits else idx
+
+
+# ---------------------------------------------------------------------------
+# SampleRNN
+# ---------------------------------------------------------------------------
+def _linearize(q: torch.Tensor, class_size: int) -> torch.Tensor:
+    """Linearizer, modules/io.py:106-112"""
+    return ((q.float() / class_size) - .5) * 2
+
+
+def _rnn_cell(kind: str, sd: SD, p: str, x: torch.Tensor, state):
+    """one time step of nn.LSTM / nn.GRU / nn.RNN (gate orders i,f,g,o and r,z,n)"""
+    w_ih, w_hh = sd[p + "weight_ih_l0"], sd[p + "weight_hh_l0"]
+    b_ih, b_hh = sd.get(p + "bias_ih_l0"), sd.get(p + "bias_hh_l0")
+    if kind == "lstm":
+        h, c = state
+        g = F.linear(x, w_ih, b_ih) + F.linear(h, w_hh, b_hh)
+        i, f, gg, o = g.chunk(4, dim=-1)
+        c = torch.sigmoid(f) * c + torch.sigmoid(i) * torch.tanh(gg)
+        h = torch.sigmoid(o) * torch.tanh(c)
+        return h, (h, c)
+    if kind == "gru":
+        h = state
+        gi, gh = F.linear(x, w_ih, b_ih), F.linear(h, w_hh, b_hh)
+        i_r, i_z, i_n = gi.chunk(3, dim=-1)
+        h_r, h_z, h_n = gh.chunk(3, dim=-1)
+        r, z = torch.sigmoid(i_r + h_r), torch.sigmoid(i_z + h_z)
+        n = torch.tanh(i_n + r * h_n)
+        h = (h - n) * z + n
+        return h, h
+    h = torch.tanh(F.linear(x, w_ih, b_ih) + F.linear(state, w_hh, b_hh))
+    return h, h
+
+
+class SampleRNNOracle:
+    """SampleRNN.before_generate / generate_step / after_generate (sample_rnn_v2.py:226-268) with
+    SampleRNNTier.forward (:83-99) for n_rnn = 1, restated over a state_dict."""
+
+    def __init__(self, sd: SD, frame_sizes: Sequence[int], hidden_dim: int, rnn_class: str = "lstm",
+                 q_levels: int = 256, n_mlp_hidden: int = 0, min_temp: Optional[float] = 1e-4, h0: str = "zeros"):
+        self.sd, self.fs, self.H, self.kind = sd, tuple(frame_sizes), hidden_dim, rnn_class
+        self.q, self.n_mlp_hidden, self.min_temp, self.h0 = q_levels, n_mlp_hidden, min_temp, h0
+        self.hidden = [None] * (len(self.fs) - 1)
+        self.outputs = [None] * (len(self.fs) - 1)
+        self.prompt_length = 0
+        self.last_raw = None
+
+    @property
+    def rf(self):
+        return self.fs[0]
+
+    def reset_hidden(self):
+        self.hidden = [None] * (len(self.fs) - 1)
+
+    def _tier(self, i: int, frames: torch.Tensor, upper: Optional[torch.Tensor]) -> torch.Tensor:
+        sd, p = self.sd, f"tiers.{i}."
+        x = F.linear(_linearize(frames, self.q), sd[p + "input_module.heads.0.2.weight"], sd[p + "input_module.heads.0.2.bias"])
+        if upper is not None:
+            x = x + upper
+        if self.hidden[i] is None:
+            init = getattr(torch, self.h0)
+            z = init(x.size(0), self.H)
+            self.hidden[i] = (z, init(x.size(0), self.H)) if self.kind == "lstm" else z
+        x, self.hidden[i] = _rnn_cell(self.kind, sd, p + "rnn.", x, self.hidden[i])
+        up = self.fs[i] // (self.fs[i + 1] if i < len(self.fs) - 2 else 1)
+        out = F.linear(x, sd[p + "up_sampler.fc.weight"], sd[p + "up_sampler.fc.bias"])
+        return out.reshape(x.size(0), up, self.H)
+
+    def generate_step(self, window: torch.Tensor, t: int, temperature=None, uniforms=None):
+        fs, n = self.fs, len(self.fs)
+        for i in range(n - 1):
+            if t % fs[i] == 0:
+                upper = None if i == 0 else self.outputs[i - 1][:, (t // fs[i]) % (fs[i - 1] // fs[i])]
+                self.outputs[i] = self._tier(i, window[:, -fs[i]:], upper)
+        if t < self.prompt_length:
+            return None
+        sd, p = self.sd, f"tiers.{n - 1}.input_module.heads.0.2.2.cv."
+        frames = _linearize(window[:, -fs[-1]:], self.q)
+        x = F.linear(frames, sd[p + "weight"].reshape(self.H, fs[-1]), sd[p + "bias"])
+        x = x + self.outputs[-1][:, (t % fs[-2]) - fs[-2]]
+        raw = mlp_raw(sd, "output_modules.0.estimator.0.", x, self.n_mlp_hidden)
+        self.last_raw = raw
+        return categorical(mlp_logits(raw, self.min_temp), temperature, uniforms)
+
+    def before_generate(self, prompt: torch.Tensor):
+        self.outputs = [None] * (len(self.fs) - 1)
+        self.reset_hidden()
+        length = prompt.size(1)
+        offset = length % self.rf
+        self.prompt_length = length - offset
+        for t in range(self.rf, self.prompt_length):
+            self.generate_step(prompt[:, t + offset - self.rf:t + offset], t)
+
+    def generate(self, prompt: torch.Tensor, n_steps: int, temperature=None, uniforms=None, keep_logits=False):
+        self.before_generate(prompt)
+        prior = prompt.size(1)
+        idx = torch.cat([prompt, torch.zeros(prompt.size(0), n_steps, dtype=prompt.dtype)], dim=1)
+        logs = []
+        for s, t in enumerate(range(prior, prior + n_steps)):
+            u = None if uniforms is None else uniforms[:, s]
+            idx[:, t] = self.generate_step(idx[:, t - self.rf:t], t, temperature, u)
+            if keep_logits:
+                logs.append(self.last_raw)
+        self.reset_hidden()
+        return (idx, torch.stack(logs, 1)) if keep_logits else idx
+
+
+# ---------------------------------------------------------------------------
+# Seq2Seq
+# ---------------------------------------------------------------------------
+def _bilstm(sd: SD, p: str, x: torch.Tensor, state=None):
+    """bidirectional single-layer nn.LSTM, batch_first; returns (B, T, 2D), (h_n, c_n) each (2, B, D)"""
+    B, T, _ = x.shape
+    D = sd[p + "weight_hh_l0"].shape[1]
+    outs, hs, cs = [], [], []
+    for d, sfx in enumerate(("", "_reverse")):
+        h = torch.zeros(B, D) if state is None else state[0][d]
+        c = torch.zeros(B, D) if state is None else state[1][d]
+        seq = range(T) if d == 0 else range(T - 1, -1, -1)
+        ys = [None] * T
+        for t in seq:
+            g = F.linear(x[:, t], sd[p + "weight_ih_l0" + sfx], sd[p + "bias_ih_l0" + sfx]) + \
+                F.linear(h, sd[p + "weight_hh_l0" + sfx], sd[p + "bias_hh_l0" + sfx])
+            i, f, gg, o = g.chunk(4, dim=-1)
+            c = torch.sigmoid(f) * c + torch.sigmoid(i) * torch.tanh(gg)
+            h = torch.sigmoid(o) * torch.tanh(c)
+            ys[t] = h
+        outs.append(torch.stack(ys, 1))
+        hs.append(h)
+        cs.append(c)
+    return torch.cat(outs, -1), (torch.stack(hs), torch.stack(cs))
+
+
+def s2s_step(sd: SD, x: torch.Tensor, hop: int, out_abs: bool = True) -> torch.Tensor:
+    """Seq2SeqLSTMNetwork.forward (s2s_lstm_v2.py:246-253) for the class defaults:
+    EncoderLSTM.forward edge_sum (:93-113), DecoderLSTM.forward linear_resample (:155-179)"""
+    D = sd["enc.fc_out.weight"].shape[0]
+    y, hidden = _bilstm(sd, "enc.lstm.0.", x)
+    y = y.view(*y.shape[:-1], D, 2).sum(-1)
+    y = y.unfold(1, hop, hop)[..., [0, -1]].sum(-1)
+    coded = F.linear(y, sd["enc.fc_out.weight"])
+    z = F.linear(coded, sd["dec.fc.fc.weight"], sd["dec.fc.fc.bias"]).reshape(x.size(0), hop, D)
+    y, _ = _bilstm(sd, "dec.lstm.0.", z, hidden)
+    y = y.view(*y.shape[:-1], D, 2).sum(-1)
+    out = F.linear(y, sd["output_module.heads.0.0.weight"], sd["output_module.heads.0.0.bias"])
+    return out.abs() if out_abs else out
+
+
+def s2s_generate(sd: SD, prompt: torch.Tensor, n_steps: int, hop: int, out_abs: bool = True) -> torch.Tensor:
+    """the loop of loops/generate.py:207-219 for a net that returns hop frames per call"""
+    prior = prompt.size(1)
+    frames = torch.cat([prompt, torch.zeros(prompt.size(0), n_steps, prompt.size(2))], dim=1)
+    until = 0
+    for t in range(prior, prior + n_steps):
+        if t < until:
+            continue
+        out = s2s_step(sd, frames[:, t - hop:t], hop, out_abs)
+        n_out = min(out.size(1), frames.size(1) - t)
+        frames[:, t:t + n_out] = out[:, :n_out]
+        until = t + n_out
+    return frames

@@ -1,0 +1,269 @@
+"""Generates the golden vectors under tests/golden/ FROM THE REFERENCE'S OWN CODE.
+
+Run in the build container only (needs /root/reference):
+    python tests/golden/make_golden.py
+The reference is imported unmodified through oracle/ref_shim.py (third-party
+packages it needs but that are not installed are stubbed; see that file).  What is
+committed are inputs and expected outputs only (.npz / .json) -- never reference
+source.  Network weights come from the deterministic recipe in oracle/weights.py
+(loaded into the reference's modules with load_state_dict), so fixtures hold only
+prompts and outputs.
+"""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+
+from oracle.ref_shim import load_reference  # noqa: E402
+from oracle.weights import load_recipe  # noqa: E402
+
+OUT = os.path.dirname(os.path.abspath(__file__))
+ref = load_reference()
+torch.set_grad_enabled(False)
+META = {"torch": torch.__version__, "numpy": np.__version__}
+
+
+def save(name, **arrays):
+    path = os.path.join(OUT, name)
+    np.savez_compressed(path, **{k: (v.detach().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)) for k, v in arrays.items()})
+    print(f"{name}: {os.path.getsize(path) / 1024:.1f} KiB")
+
+
+def f32_neighbours(x: torch.Tensor, radius: int) -> torch.Tensor:
+    bits = x.view(torch.int32).to(torch.int64)
+    key = torch.where(bits >= 0, bits, -(bits & 0x7FFFFFFF))
+    out = []
+    for d in range(-radius, radius + 1):
+        k = key + d
+        b = torch.where(k >= 0, k, (-k) | 0x80000000)
+        b = torch.where(b >= 2 ** 31, b - 2 ** 32, b)
+        out.append(b.to(torch.int32).view(torch.float32))
+    return torch.cat(out)
+
+
+# ---------------------------------------------------------------------------
+def make_mulaw():
+    g = torch.Generator().manual_seed(1234)
+    for tag, comp in (("c1", 1.0), ("c05", 0.5)):
+        fwd = ref.functionals.MuLawCompress(256, comp)
+        inv = ref.functionals.MuLawExpand(256, comp)
+        # bin edges of the reference formula by bisection on the fp32 number line
+        lo = torch.full((255,), -1.0)
+        hi = torch.full((255,), 1.0)
+        targets = torch.arange(1, 256)
+        for _ in range(60):
+            mid = ((lo.double() + hi.double()) / 2).float()
+            ge = fwd(mid) >= targets
+            hi = torch.where(ge, mid, hi)
+            lo = torch.where(ge, lo, mid)
+        near = f32_neighbours(hi, 6)
+        near = near[(near >= -1) & (near <= 1)]
+        x = torch.cat([
+            torch.tensor([-1., 1., 0., -0., 1e-8, -1e-8, 1e-4, -1e-4, 0.5, -0.5, 0.999999, -0.999999]),
+            torch.linspace(-1, 1, 4097),
+            torch.rand(20000, generator=g) * 2 - 1,
+            near,
+            torch.tensor([1.5, -1.5, 3.0, -2.0]),        # out of range: no clamp in the reference
+        ]).float()
+        codes = fwd(x)
+        all_codes = torch.arange(-2, 259)
+        save(f"mulaw_{tag}.npz", x=x, codes=codes, n_near=np.int64(near.numel()),
+             all_codes=all_codes, expanded=inv(all_codes), compression=np.float32(comp))
+
+
+def make_stft():
+    g = torch.Generator().manual_seed(1234)
+    x = torch.randn(2, 8192, generator=g)
+    out = {"x": x}
+    for n_fft, hop, center in ((1024, 256, False), (2048, 512, False), (2048, 512, True), (256, 64, False)):
+        s = ref.functionals.MagSpec(n_fft, hop, center=center)(x)
+        out[f"mag_{n_fft}_{hop}_{int(center)}"] = s
+    # a length that is not a multiple of hop exercises _fix_length (alignment='end')
+    y = torch.randn(3, 5000, generator=g)
+    out["y"] = y
+    out["mag_y_512_128_0"] = ref.functionals.MagSpec(512, 128, center=False)(y)
+    save("stft.npz", **out)
+
+
+def capture_raw(net):
+    """records the raw (pre-temperature) outputs of the MLP head at every call"""
+    log = []
+    mlp = net.output_modules[0].estimator[0]
+    handle = mlp.fc.register_forward_hook(lambda m, i, o: log.append(o.detach().clone()))
+    return log, handle
+
+
+def run_loop(net, prompts, n_steps, parameters=None, inversed=False):
+    cfg = ref.GenerateLoopV2.Config(parameters=parameters, yield_inversed_outputs=inversed,
+                                    display_waveform=False, write_waveform=False)
+    loop = ref.GenerateLoopV2(cfg, net, n_steps, dataloader=[[np.arange(prompts[0].size(0)), *prompts]], logger=None)
+    outs = [o for o in loop.run()]
+    torch.set_grad_enabled(False)   # the reference loop re-enables grad globally in teardown
+    return outs[0]
+
+
+def make_wavenet():
+    g = torch.Generator().manual_seed(7)
+    arrays = {}
+    # (a) tiny unconditioned net, two blocks
+    io = ref.IOSpec.mulaw_io(ref.IOSpec.MuLawIOConfig(input_module_type="embedding", mlp_dim=32))
+    cfg = ref.WaveNet.Config(io_spec=io, blocks=(3, 2), dims_dilated=(16,), residuals_dim=16, skips_dim=16)
+    net = ref.WaveNet.from_config(cfg).eval()
+    load_recipe(net, seed=11, gain=2.0)
+    rf = net.rf
+    prompt = torch.randint(0, 256, (3, rf + 5), generator=g)
+    log, h = capture_raw(net)
+    out = run_loop(net, (prompt,), 24)
+    h.remove()
+    arrays.update(a_prompt=prompt, a_out=out[0], a_raw=torch.cat(log, 1), a_rf=np.int64(rf))
+    # loop with yield_inversed_outputs=True returns MuLawExpand(out)
+    arrays["a_inversed"] = run_loop(net, (prompt,), 24, inversed=True)[0]
+    # single generate_step after before_generate (tests/test_wavenet.py:140-165 path)
+    net.before_generate((prompt,), 0)
+    arrays["a_step"] = net.generate_step((prompt[:, -rf:],), t=prompt.size(1))[0]
+
+    # (b) conditioned net: one 1x1 input through LinearIO(12 -> 8), no skips, kernel size 3
+    mag = ref.functionals.MagSpec(22, 4, center=False)
+    ext = ref.extractor.Extractor("signal", ref.functionals.FileToSignal(16000))
+    io_b = ref.IOSpec(
+        inputs=(io.inputs[0], ref.io_spec.InputSpec("signal", mag, ref.io.LinearIO()).bind_to(ext)),
+        targets=io.targets)
+    cfg_b = ref.WaveNet.Config(io_spec=io_b, kernel_sizes=(3,), blocks=(3,), dims_dilated=(16,), dims_1x1=(8,),
+                               residuals_dim=16, skips_dim=None)
+    net_b = ref.WaveNet.from_config(cfg_b).eval()
+    load_recipe(net_b, seed=12, gain=2.0)
+    rf_b = net_b.rf
+    n = 10
+    idx = torch.randint(0, 256, (2, rf_b + n), generator=g)
+    cond = torch.rand(2, rf_b + n, 12, generator=g)
+    log, h = capture_raw(net_b)
+    # teacher forced: one step per position, inputs taken from idx (not fed back)
+    steps = [net_b.generate_step((idx[:, t - rf_b:t], cond[:, t - rf_b:t]), t=t)[0] for t in range(rf_b, rf_b + n)]
+    h.remove()
+    arrays.update(b_idx=idx, b_cond=cond, b_raw=torch.cat(log, 1), b_argmax=torch.cat(steps, 1), b_rf=np.int64(rf_b))
+
+    # (c) the shape of BASELINE config 2 (10 layers x 64 ch), 12 free-running steps
+    cfg_c = ref.WaveNet.Config(io_spec=ref.IOSpec.mulaw_io(ref.IOSpec.MuLawIOConfig(input_module_type="embedding")),
+                               blocks=(10,), dims_dilated=(64,), residuals_dim=64, skips_dim=64)
+    net_c = ref.WaveNet.from_config(cfg_c).eval()
+    load_recipe(net_c, seed=13, gain=2.0)
+    prompt_c = torch.randint(0, 256, (2, net_c.rf), generator=g)
+    log, h = capture_raw(net_c)
+    out_c = run_loop(net_c, (prompt_c,), 12)
+    h.remove()
+    arrays.update(c_prompt=prompt_c, c_out=out_c[0], c_raw=torch.cat(log, 1), c_rf=np.int64(net_c.rf))
+    save("wavenet.npz", **arrays)
+
+
+def make_srnn():
+    g = torch.Generator().manual_seed(21)
+    arrays = {}
+    for tag, fs, kind, plen in (("gru", (16, 4, 1), "gru", 40), ("lstm", (16, 8, 8), "lstm", 32), ("rnn", (8, 2, 2), "rnn", 21)):
+        io = ref.IOSpec.mulaw_io(ref.IOSpec.MuLawIOConfig(mlp_dim=32))
+        cfg = ref.SampleRNN.Config(io_spec=io, frame_sizes=fs, hidden_dim=32, rnn_class=kind)
+        net = ref.SampleRNN.from_config(cfg).eval()
+        load_recipe(net, seed=30 + len(tag), gain=2.0)
+        prompt = torch.randint(0, 256, (3, plen), generator=g)
+        log, h = capture_raw(net)
+        out = run_loop(net, (prompt,), 40)
+        h.remove()
+        arrays.update({f"{tag}_prompt": prompt, f"{tag}_out": out[0], f"{tag}_raw": torch.stack(log, 1)})
+    save("srnn.npz", **arrays)
+
+
+def make_s2s():
+    g = torch.Generator().manual_seed(31)
+    io = ref.IOSpec.magspec_io(ref.IOSpec.MagSpecIOConfig(n_fft=128, hop_length=32))
+    cfg = ref.Seq2SeqLSTMNetwork.Config(io_spec=io, model_dim=32, hop=4)
+    net = ref.Seq2SeqLSTMNetwork.from_config(cfg).eval()
+    load_recipe(net, seed=41, gain=1.5)
+    x = torch.rand(3, 4, 65, generator=g)
+    y = net.generate_step((x,), t=4)
+    prompt = torch.rand(2, 6, 65, generator=g)
+    out = run_loop(net, (prompt,), 10)
+    save("s2s.npz", x=x, y=y, prompt=prompt, out=out[0])
+
+
+def make_sampler():
+    g = torch.Generator().manual_seed(51)
+    logits = torch.randn(6, 1, 256, generator=g) * 3
+    arrays = {"logits": logits, "argmax": ref.targets.CategoricalSampler().eval()(logits)}
+    for tag, temp in (("t05", 0.5), ("t1", (1.,)), ("per_item", torch.tensor([0.5, 1., 2., 0.1, 1.5, 1.]))):
+        t = ref.targets.as_tensor(temp, logits)
+        l = logits / t
+        arrays[f"probs_{tag}"] = (l - l.logsumexp(-1, keepdim=True)).exp()
+        arrays[f"temp_{tag}"] = t.reshape(-1).expand(6) if t.numel() == 1 else t.reshape(-1)
+    # learned-temperature column of the MLP head
+    raw = torch.randn(5, 257, generator=g)
+    mlp = ref.io.MLP(in_dim=8, hidden_dim=8, out_dim=256)
+    temp = torch.sigmoid(raw[..., -1:])
+    arrays["raw"] = raw
+    arrays["raw_logits"] = raw[..., :-1] / torch.maximum(temp, mlp.min_temp)
+    save("sampler.npz", **arrays)
+
+
+def make_keys():
+    """state_dict names and shapes of the reference networks at the BASELINE configs"""
+    out = {}
+    mu_emb = lambda: ref.IOSpec.mulaw_io(ref.IOSpec.MuLawIOConfig(input_module_type="embedding"))
+    mu_lin = lambda: ref.IOSpec.mulaw_io(ref.IOSpec.MuLawIOConfig())
+
+    def keys(net):
+        return {k: list(v.shape) for k, v in net.state_dict().items()}
+
+    out["wavenet_default"] = keys(ref.WaveNet.from_config(ref.WaveNet.Config(io_spec=mu_emb())))
+    out["wavenet_cfg2"] = keys(ref.WaveNet.from_config(ref.WaveNet.Config(
+        io_spec=mu_emb(), blocks=(10,), dims_dilated=(64,), residuals_dim=64, skips_dim=64)))
+    mag = ref.functionals.MagSpec(1024, 256, center=False)
+    ext = ref.extractor.Extractor("signal", ref.functionals.FileToSignal(16000))
+    io4 = mu_emb()
+    io4 = ref.IOSpec(inputs=(io4.inputs[0], ref.io_spec.InputSpec("signal", mag, ref.io.LinearIO()).bind_to(ext)),
+                     targets=io4.targets)
+    out["wavenet_cfg4"] = keys(ref.WaveNet.from_config(ref.WaveNet.Config(
+        io_spec=io4, blocks=(10, 10, 10), dims_dilated=(256,), dims_1x1=(256,), residuals_dim=256, skips_dim=256)))
+    out["srnn_cfg1"] = keys(ref.SampleRNN.from_config(ref.SampleRNN.Config(io_spec=mu_lin())))
+    out["srnn_cfg3"] = keys(ref.SampleRNN.from_config(ref.SampleRNN.Config(
+        io_spec=mu_lin(), frame_sizes=(16, 4, 1), hidden_dim=512, rnn_class="gru")))
+    out["s2s_cfg5"] = keys(ref.Seq2SeqLSTMNetwork.from_config(ref.Seq2SeqLSTMNetwork.Config(
+        io_spec=ref.IOSpec.magspec_io(ref.IOSpec.MagSpecIOConfig(sr=22050, n_fft=1024, hop_length=256)))))
+    # host logic: rf / n_steps / unit conversions the loop relies on
+    host = {"rf": {}, "n_steps": {}, "convert": []}
+    for blocks, ks in (((3,), (2,)), ((10,), (2,)), ((10, 10, 10), (2,)), ((2, 2, 1), (2,)), ((3,), (3,))):
+        net = ref.WaveNet.from_config(ref.WaveNet.Config(io_spec=mu_emb(), blocks=blocks, kernel_sizes=ks, dims_dilated=(4,)))
+        host["rf"][f"{blocks}|{ks}"] = int(net.rf)
+    s2s = ref.Seq2SeqLSTMNetwork.from_config(ref.Seq2SeqLSTMNetwork.Config(
+        io_spec=ref.IOSpec.magspec_io(ref.IOSpec.MagSpecIOConfig(sr=22050, n_fft=1024, hop_length=256)), model_dim=8))
+    wn = ref.WaveNet.from_config(ref.WaveNet.Config(io_spec=mu_emb(), dims_dilated=(4,)))
+    for dur in (1.0, 0.5, 0.032):
+        c = ref.GenerateLoopV2.Config(output_duration_sec=dur)
+        host["n_steps"][f"s2s|{dur}"] = int(ref.GenerateLoopV2.get_n_steps(c, s2s))
+        host["n_steps"][f"wavenet|{dur}"] = int(ref.GenerateLoopV2.get_n_steps(c, wn))
+    I = ref.item_spec
+    for n in (22050, 8192, 5000, 1024, 2047):
+        for n_fft, hop, pad in ((1024, 256, False), (2048, 512, True), (2048, 512, False), (512, 128, False)):
+            fr = I.Frame(n_fft, hop, padding=pad)
+            host["convert"].append({
+                "n": n, "n_fft": n_fft, "hop": hop, "pad": pad,
+                "s2f_len": I.convert(n, I.Sample(1), fr, True), "s2f_pos": I.convert(n, I.Sample(1), fr, False),
+                "f2s_len": I.convert(n // hop, fr, I.Sample(1), True), "f2s_pos": I.convert(n // hop, fr, I.Sample(1), False),
+            })
+    out["host"] = host
+    out["meta"] = META
+    with open(os.path.join(OUT, "reference_facts.json"), "w") as f:
+        json.dump(out, f, indent=1, sort_keys=True)
+    print("reference_facts.json written")
+
+
+if __name__ == "__main__":
+    make_mulaw()
+    make_stft()
+    make_wavenet()
+    make_srnn()
+    make_s2s()
+    make_sampler()
+    make_keys()

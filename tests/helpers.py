@@ -1,0 +1,88 @@
+"""Shared test plumbing: golden fixtures, network builders (product package) and the matching
+oracle argument sets."""
+import json
+import os
+
+import numpy as np
+import torch
+
+import mimikit_amd as mmk
+from oracle.weights import load_recipe
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def golden(name):
+    return {k: v for k, v in np.load(os.path.join(GOLDEN, name)).items()}
+
+
+def facts():
+    with open(os.path.join(GOLDEN, "reference_facts.json")) as f:
+        return json.load(f)
+
+
+def T(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def mu_emb(**kw):
+    return mmk.IOSpec.mulaw_io(mmk.IOSpec.MuLawIOConfig(input_module_type="embedding", **kw))
+
+
+def mu_lin(**kw):
+    return mmk.IOSpec.mulaw_io(mmk.IOSpec.MuLawIOConfig(**kw))
+
+
+# ---- the networks the golden vectors were produced with (tests/golden/make_golden.py) -------------
+def wavenet_a():
+    net = mmk.WaveNet.from_config(mmk.WaveNet.Config(io_spec=mu_emb(mlp_dim=32), blocks=(3, 2), dims_dilated=(16,),
+                                                     residuals_dim=16, skips_dim=16))
+    sd = load_recipe(net, seed=11, gain=2.0)
+    arch = dict(kernels=[2] * 5, dilations=[1, 2, 4, 1, 2], has_skips=True, residuals=True)
+    return net.eval(), sd, arch
+
+
+def wavenet_b():
+    io = mu_emb(mlp_dim=32)
+    ext = mmk.Extractor("signal", mmk.FileToSignal(16000))
+    io_b = mmk.IOSpec(inputs=(io.inputs[0], mmk.InputSpec("signal", mmk.MagSpec(22, 4, center=False), mmk.LinearIO()).bind_to(ext)),
+                      targets=io.targets)
+    net = mmk.WaveNet.from_config(mmk.WaveNet.Config(io_spec=io_b, kernel_sizes=(3,), blocks=(3,), dims_dilated=(16,),
+                                                     dims_1x1=(8,), residuals_dim=16, skips_dim=None))
+    sd = load_recipe(net, seed=12, gain=2.0)
+    arch = dict(kernels=[3] * 3, dilations=[1, 3, 9], has_skips=False, residuals=True)
+    return net.eval(), sd, arch
+
+
+def wavenet_c():
+    net = mmk.WaveNet.from_config(mmk.WaveNet.Config(io_spec=mu_emb(), blocks=(10,), dims_dilated=(64,),
+                                                     residuals_dim=64, skips_dim=64))
+    sd = load_recipe(net, seed=13, gain=2.0)
+    arch = dict(kernels=[2] * 10, dilations=[2 ** i for i in range(10)], has_skips=True, residuals=True)
+    return net.eval(), sd, arch
+
+
+SRNN_CASES = {"gru": ((16, 4, 1), "gru", 40), "lstm": ((16, 8, 8), "lstm", 32), "rnn": ((8, 2, 2), "rnn", 21)}
+
+
+def srnn(tag, hidden=32, mlp_dim=32, seed=None, frame_sizes=None, kind=None):
+    fs, k, _ = SRNN_CASES.get(tag, (frame_sizes, kind, None))
+    fs, k = frame_sizes or fs, kind or k
+    net = mmk.SampleRNN.from_config(mmk.SampleRNN.Config(io_spec=mu_lin(mlp_dim=mlp_dim), frame_sizes=fs, hidden_dim=hidden,
+                                                         rnn_class=k))
+    sd = load_recipe(net, seed=(30 + len(tag)) if seed is None else seed, gain=2.0)
+    return net.eval(), sd, dict(frame_sizes=fs, hidden_dim=hidden, rnn_class=k)
+
+
+def s2s_tiny():
+    io = mmk.IOSpec.magspec_io(mmk.IOSpec.MagSpecIOConfig(n_fft=128, hop_length=32))
+    net = mmk.Seq2SeqLSTMNetwork.from_config(mmk.Seq2SeqLSTMNetwork.Config(io_spec=io, model_dim=32, hop=4))
+    sd = load_recipe(net, seed=41, gain=1.5)
+    return net.eval(), sd
+
+
+def margin_ok(raw, min_gap=1e-3):
+    """top-1 / top-2 gap of the class logits (temperature column excluded): greedy decode is only
+    comparable bit-exactly where no near-tie exists"""
+    top = torch.topk(T(raw)[..., :-1], 2, dim=-1).values
+    return (top[..., 0] - top[..., 1]) > min_gap
