@@ -1,0 +1,414 @@
+"""Headline benchmark: generated audio samples / second on MI355X.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json `metric`: "WaveNet 256-ch mu-law, 16 kHz" = configs[3]): WaveNet
+blocks=(10,10,10), 256 dilated/residual/skip channels, one STFT-magnitude conditioning input
+(513 bins -> LinearIO 256 -> per-layer 1x1), mu-law-256 MLP head, 32 clips per GPU (256 clips
+over 8 GPUs), prompt 3072 samples, 1 s = 16 000 generated samples per clip, greedy decode.
+One "step" = one full generate pass over the local batch: before_generate (queue warm-up over the
+prompt) + 16 000 auto-regressive steps + mu-law expansion of the result, inputs resident in HBM.
+Clips shard over ranks with one weight broadcast and no other collective (weak scaling).
+
+The JSON line also carries
+  roofline     : HBM roofline of the dominant kernel, from HIP start/stop events on its launches
+  cpu_baseline : the reference ALGORITHM (oracle/torch_ref.py: naive full-window forward per step,
+                 Python loop) timed on this box's host cores on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6.3 TB/s is the measured copy ceiling
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="wavenet_cfg4",
+                    choices=["wavenet_cfg4", "wavenet_cfg2", "srnn_cfg3", "s2s_cfg5", "mulaw", "stft"])
+    ap.add_argument("--clips", type=int, default=0, help="clips per GPU (0 = the workload's BASELINE value)")
+    ap.add_argument("--seconds", type=float, default=1.0, help="generated audio per clip")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline sample")
+    return ap.parse_args()
+
+
+# ----------------------------------------------------------------------------- workloads
+def build_wavenet(cfg_name):
+    import mimikit_amd as mmk
+    io = mmk.IOSpec.mulaw_io(mmk.IOSpec.MuLawIOConfig(sr=16000, q_levels=256, input_module_type="embedding"))
+    if cfg_name == "wavenet_cfg4":
+        ext = mmk.Extractor("signal", mmk.FileToSignal(16000))
+        cond = mmk.InputSpec("signal", mmk.MagSpec(1024, 256, center=False), mmk.LinearIO()).bind_to(ext)
+        io = mmk.IOSpec(inputs=(io.inputs[0], cond), targets=io.targets)
+        cfg = mmk.WaveNet.Config(io_spec=io, blocks=(10, 10, 10), dims_dilated=(256,), dims_1x1=(256,),
+                                 residuals_dim=256, skips_dim=256)
+        clips, cond_dim = 32, 513
+    else:
+        cfg = mmk.WaveNet.Config(io_spec=io, blocks=(10,), dims_dilated=(64,), residuals_dim=64, skips_dim=64)
+        clips, cond_dim = 8, 0
+    torch.manual_seed(1234)
+    return mmk.WaveNet.from_config(cfg).eval(), clips, cond_dim
+
+
+class WaveNetJob:
+    unit = "audio samples/s"
+
+    def __init__(self, args, device, rank):
+        import mimikit_amd as mmk
+        self.mmk = mmk
+        self.net, clips, cond_dim = build_wavenet(args.workload)
+        self.clips = args.clips or clips
+        self.device = device
+        self.rf = self.net.rf
+        self.prompt_len = -(-self.rf // 16) * 16          # rf rounded up (cfg2: 1024, cfg4: 3072)
+        self.n_steps = int(16000 * args.seconds)
+        gen = torch.Generator().manual_seed(1234 + rank)
+        audio = torch.rand(self.clips, self.prompt_len, generator=gen) * 2 - 1
+        total = self.prompt_len + self.n_steps
+        self.cond_cpu = torch.rand(self.clips, total, cond_dim, generator=gen) if cond_dim else None
+        self.audio_cpu = audio
+        self.expand = mmk.MuLawExpand(256)
+        self.name = args.workload
+        self.dtype = "f32"
+
+    def to_device(self):
+        self.net.to(self.device)
+        prompt = self.mmk.MuLawCompress(256)(self.audio_cpu.to(self.device))
+        self.idx = torch.cat([prompt, torch.zeros(self.clips, self.n_steps, dtype=torch.int64, device=self.device)], 1)
+        self.cond = (self.cond_cpu.to(self.device),) if self.cond_cpu is not None else ()
+        self.prompt_cpu = prompt.cpu()
+
+    def one_pass(self):
+        p = self.prompt_len
+        net = self.net
+        net.before_generate((self.idx[:, :p], *[c[:, :p] for c in self.cond]), None)
+        net.generate_block((self.idx, *self.cond), p, self.n_steps)
+        net.after_generate((self.idx,), None)
+        self.audio_out = self.expand(self.idx)
+
+    def units_per_pass(self):
+        return self.clips * self.n_steps
+
+    def config(self, world):
+        c = self.net.config
+        return {"workload": f"{self.name}: WaveNet blocks={tuple(c.blocks)} x {c.dims_dilated[0]} ch, "
+                            f"{len(c.dims_1x1)} cond input(s), mu-law-256, 16 kHz",
+                "clips_per_gpu": self.clips, "global_clips": self.clips * world, "prompt_samples": self.prompt_len,
+                "generated_samples_per_clip": self.n_steps, "decode": "greedy", "parallelism": f"clip-shard x{world}"}
+
+    # HBM roofline of the dominant kernel, measured with HIP events on its launches
+    def roofline(self):
+        p = self.prompt_len
+        net, plan = self.net, self.net._plan
+        net.before_generate((self.idx[:, :p], *[c[:, :p] for c in self.cond]), None)
+        stats = plan.profile_steps(self.idx, self.cond, p, 48)
+        net.after_generate((self.idx,), None)
+        c, B = plan.cfg, self.clips
+        C, k = c.dim_dilated, c.kernel_size[0]
+        k_a = k * C + sum(c.cond_dim[j] for j in range(c.n_cond))
+        n_a = 2 * C if c.gated else C
+        bytes_a = 4 * (n_a * k_a + n_a) + 4 * B * (k_a + C)
+        n_b = (C if c.residuals_dim else 0) + c.skips_dim
+        bytes_b = 4 * (n_b * C + n_b) + 4 * B * (C + 2 * n_b)
+        per = {"layer_a": bytes_a, "layer_b": bytes_b}
+        name = max(("layer_a", "layer_b"), key=lambda n: stats[n][0])
+        ms, launches = stats[name]
+        dur_us = 1e3 * ms / max(launches, 1)
+        achieved = per[name] / (dur_us * 1e-6) / 1e9
+        return {"bound": "hbm", "kernel": f"linear_kernel ({name}: " +
+                ("dilated taps + 1x1 cond + gate" if name == "layer_a" else "residual + skip 1x1") + ")",
+                "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                "algorithmic_bytes_per_launch": per[name], "avg_launch_us": round(dur_us, 3),
+                "launches_timed": int(launches),
+                "per_class_avg_us": {n: round(1e3 * stats[n][0] / max(stats[n][1], 1), 3) for n in stats}}
+
+    def step_bytes(self):
+        """algorithmic bytes of one auto-regressive step of the local batch (weights once + state)"""
+        c = self.net._plan.cfg
+        w = sum(p.numel() for n, p in self.net.named_parameters() if not n.startswith("input_modules.0."))
+        w += c.dim_dilated                    # one embedding row per clip is negligible; count one
+        state = self.clips * (2 * c.dim_dilated * 4 * c.n_layers + sum(c.cond_in_dim[j] for j in range(c.n_cond)) * 4)
+        return 4 * w + state
+
+    def cpu_baseline(self, budget_s):
+        from oracle import torch_ref as O
+        sd = {k: v.detach().cpu() for k, v in self.net.state_dict().items()}
+        c = self.net._plan.cfg
+        arch = dict(kernels=[c.kernel_size[i] for i in range(c.n_layers)],
+                    dilations=[c.dilation[i] for i in range(c.n_layers)], has_skips=bool(c.skips_dim), residuals=True)
+        b = min(self.clips, 2)
+        prompt = self.prompt_cpu[:b]
+        cond = [self.cond_cpu[:b]] if self.cond_cpu is not None else []
+        t0 = time.perf_counter()
+        O.wavenet_generate(sd, prompt, [x[:, :self.prompt_len + 1] for x in cond], 1, **arch)
+        one = time.perf_counter() - t0
+        n = max(2, min(64, int(budget_s / max(one, 1e-3))))
+        t0 = time.perf_counter()
+        out = O.wavenet_generate(sd, prompt, [x[:, :self.prompt_len + n] for x in cond], n, **arch)
+        dt = time.perf_counter() - t0
+        # the GPU run and the CPU run must agree on what they generated
+        agree = bool((out[:, self.prompt_len:] == self.idx[:b, self.prompt_len:self.prompt_len + n].cpu()).all())
+        return {"value": round(b * n / dt, 3), "unit": self.unit, "cores": torch.get_num_threads(), "kind": "port",
+                "sample": f"{b} clips x {n} steps of the same network/prompt, naive full-window forward per step "
+                          f"(reference algorithm), torch CPU fp32", "matches_gpu_output": agree}
+
+
+class SrnnJob:
+    unit = "audio samples/s"
+
+    def __init__(self, args, device, rank):
+        import mimikit_amd as mmk
+        self.mmk = mmk
+        torch.manual_seed(1234)
+        io = mmk.IOSpec.mulaw_io(mmk.IOSpec.MuLawIOConfig(sr=16000))
+        self.net = mmk.SampleRNN.from_config(mmk.SampleRNN.Config(io_spec=io, frame_sizes=(16, 4, 1), hidden_dim=512,
+                                                                  rnn_class="gru")).eval()
+        self.clips, self.device = args.clips or 64, device
+        self.prompt_len, self.n_steps = 512, int(16000 * args.seconds)
+        gen = torch.Generator().manual_seed(1234 + rank)
+        self.audio_cpu = torch.rand(self.clips, self.prompt_len, generator=gen) * 2 - 1
+        self.expand = mmk.MuLawExpand(256)
+        self.name, self.dtype = args.workload, "f32"
+
+    def to_device(self):
+        self.net.to(self.device)
+        prompt = self.mmk.MuLawCompress(256)(self.audio_cpu.to(self.device))
+        self.idx = torch.cat([prompt, torch.zeros(self.clips, self.n_steps, dtype=torch.int64, device=self.device)], 1)
+        self.prompt_cpu = prompt.cpu()
+
+    def one_pass(self):
+        self.net.before_generate((self.idx[:, :self.prompt_len],), None)
+        self.net.generate_block((self.idx,), self.prompt_len, self.n_steps)
+        self.net.after_generate((self.idx,), None)
+        self.audio_out = self.expand(self.idx)
+
+    def units_per_pass(self):
+        return self.clips * self.n_steps
+
+    def config(self, world):
+        return {"workload": "srnn_cfg3: SampleRNN frame_sizes=(16,4,1), GRU hidden 512, mu-law-256, 16 kHz",
+                "clips_per_gpu": self.clips, "global_clips": self.clips * world, "prompt_samples": self.prompt_len,
+                "generated_samples_per_clip": self.n_steps, "decode": "greedy", "parallelism": f"clip-shard x{world}"}
+
+    def roofline(self):
+        return None
+
+    def cpu_baseline(self, budget_s):
+        from oracle import torch_ref as O
+        sd = {k: v.detach().cpu() for k, v in self.net.state_dict().items()}
+        o = O.SampleRNNOracle(sd, (16, 4, 1), 512, "gru")
+        n = 400
+        t0 = time.perf_counter()
+        out = o.generate(self.prompt_cpu, n)
+        dt = time.perf_counter() - t0
+        agree = bool((out[:, self.prompt_len:] == self.idx[:, self.prompt_len:self.prompt_len + n].cpu()).all())
+        return {"value": round(self.clips * n / dt, 3), "unit": self.unit, "cores": torch.get_num_threads(),
+                "kind": "port", "sample": f"{self.clips} clips x {n} steps (+ prompt warm-up), reference algorithm, torch CPU fp32",
+                "matches_gpu_output": agree}
+
+
+class S2SJob:
+    unit = "audio samples/s"
+
+    def __init__(self, args, device, rank):
+        import mimikit_amd as mmk
+        self.mmk = mmk
+        torch.manual_seed(1234)
+        io = mmk.IOSpec.magspec_io(mmk.IOSpec.MagSpecIOConfig(sr=22050, n_fft=1024, hop_length=256))
+        self.net = mmk.Seq2SeqLSTMNetwork.from_config(mmk.Seq2SeqLSTMNetwork.Config(io_spec=io)).eval()
+        self.clips, self.device = args.clips or 64, device
+        self.n_steps = mmk.GenerateLoopV2.get_n_steps(mmk.GenerateLoopV2.Config(output_duration_sec=args.seconds), self.net)
+        self.prompt_frames = 16
+        gen = torch.Generator().manual_seed(1234 + rank)
+        self.audio_cpu = torch.rand(self.clips, 1024 + 256 * (self.prompt_frames - 1), generator=gen) * 2 - 1
+        self.name, self.dtype = args.workload, "f32"
+        self.samples_per_frame = 256
+
+    def to_device(self):
+        self.net.to(self.device)
+        prompt = self.mmk.MagSpec(1024, 256, center=False)(self.audio_cpu.to(self.device))
+        assert prompt.shape[1] == self.prompt_frames
+        self.frames = torch.cat([prompt, torch.zeros(self.clips, self.n_steps, 513, device=self.device)], 1).contiguous()
+
+    def one_pass(self):
+        self.net.before_generate((self.frames[:, :self.prompt_frames],), None)
+        self.net.generate_block((self.frames,), self.prompt_frames, self.n_steps)
+        self.net.after_generate((self.frames,), None)
+
+    def units_per_pass(self):
+        return self.clips * self.n_steps * self.samples_per_frame
+
+    def config(self, world):
+        return {"workload": "s2s_cfg5: Seq2Seq bi-LSTM D=1024 hop=8 on 1024-pt STFT magnitudes @22.05 kHz",
+                "clips_per_gpu": self.clips, "global_clips": self.clips * world, "prompt_frames": self.prompt_frames,
+                "generated_frames_per_clip": self.n_steps, "parallelism": f"clip-shard x{world}"}
+
+    def roofline(self):
+        return None
+
+    def cpu_baseline(self, budget_s):
+        from oracle import torch_ref as O
+        sd = {k: v.detach().cpu() for k, v in self.net.state_dict().items()}
+        b = 4
+        x = self.frames[:b, self.prompt_frames - 8:self.prompt_frames].cpu()
+        t0 = time.perf_counter()
+        n = 0
+        while time.perf_counter() - t0 < min(budget_s, 10.0):
+            O.s2s_step(sd, x, 8)
+            n += 1
+        dt = time.perf_counter() - t0
+        return {"value": round(b * n * 8 * 256 / dt, 3), "unit": self.unit, "cores": torch.get_num_threads(),
+                "kind": "port", "sample": f"{b} clips x {n} generate_steps (8 frames each), torch CPU fp32"}
+
+
+class FeatureJob:
+    def __init__(self, args, device, rank):
+        import mimikit_amd as mmk
+        self.mmk, self.device, self.name, self.dtype = mmk, device, args.workload, "f32"
+        gen = torch.Generator().manual_seed(1234 + rank)
+        if args.workload == "mulaw":
+            self.x_cpu = torch.rand(64, 16000 * 60, generator=gen) * 2 - 1
+            self.unit = "audio samples/s"
+        else:
+            self.x_cpu = torch.randn(64, 22050 * 10, generator=gen)
+            self.unit = "frames/s"
+
+    def to_device(self):
+        self.x = self.x_cpu.to(self.device)
+        self.f = self.mmk.MuLawCompress(256) if self.name == "mulaw" else self.mmk.MagSpec(1024, 256, center=False)
+
+    def one_pass(self):
+        self.out = self.f(self.x)
+
+    def units_per_pass(self):
+        return self.x.numel() if self.name == "mulaw" else self.out.shape[0] * self.out.shape[1]
+
+    def config(self, world):
+        return {"workload": f"{self.name}: " + ("MuLawCompress(256) on (64, 960000) fp32" if self.name == "mulaw"
+                                                else "MagSpec(1024, 256) on (64, 220500) fp32"),
+                "parallelism": f"replicas x{world}"}
+
+    def roofline(self):
+        start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        n = 20
+        start.record()
+        for _ in range(n):
+            self.one_pass()
+        stop.record()
+        torch.cuda.synchronize()
+        us = start.elapsed_time(stop) * 1e3 / n
+        if self.name == "mulaw":
+            nbytes = self.x.numel() * 12
+        else:
+            nbytes = self.out.shape[0] * self.out.shape[1] * (4 * 256 + 4 * 513)
+        achieved = nbytes / (us * 1e-6) / 1e9
+        return {"bound": "hbm", "kernel": "mulaw_compress_kernel" if self.name == "mulaw" else "stft_mag_kernel",
+                "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
+                "traffic": None, "algorithmic_bytes_per_launch": nbytes, "avg_launch_us": round(us, 2)}
+
+    def cpu_baseline(self, budget_s):
+        from oracle import torch_ref as O
+        x = self.x_cpu[:8]
+        t0 = time.perf_counter()
+        n = 0
+        while time.perf_counter() - t0 < min(budget_s, 5.0):
+            out = O.mulaw_compress(x) if self.name == "mulaw" else O.magspec(x, 1024, 256, False)
+            n += 1
+        dt = time.perf_counter() - t0
+        units = x.numel() if self.name == "mulaw" else out.shape[0] * out.shape[1]
+        return {"value": round(units * n / dt, 1), "unit": self.unit, "cores": torch.get_num_threads(), "kind": "port",
+                "sample": f"8 of the 64 rows, {n} repetitions, torch CPU fp32"}
+
+
+JOBS = {"wavenet_cfg4": WaveNetJob, "wavenet_cfg2": WaveNetJob, "srnn_cfg3": SrnnJob, "s2s_cfg5": S2SJob,
+        "mulaw": FeatureJob, "stft": FeatureJob}
+
+
+# ----------------------------------------------------------------------------- main
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs the MI355X: the generate path has no CPU implementation")
+    import torch.distributed as dist
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group(backend="nccl", device_id=device)     # RCCL over xGMI
+    torch.set_grad_enabled(False)
+
+    job = JOBS[args.workload](args, device, rank)
+    job.to_device()
+    if world > 1 and hasattr(job, "net"):
+        from mimikit_amd.shard import broadcast_weights
+        broadcast_weights(job.net, src=0)          # the path's only collective
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        job.one_pass()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        job.one_pass()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    units = job.units_per_pass() * args.steps * world
+    value = units / elapsed
+    line = {
+        "metric": "audio samples/sec generated (WaveNet 256-ch mu-law, 16kHz)" if args.workload == "wavenet_cfg4"
+        else f"{job.unit} ({args.workload})",
+        "value": round(value, 1), "unit": job.unit, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": job.dtype, "data": "synthetic", "config": job.config(world),
+    }
+    if rank == 0:
+        if hasattr(job, "step_bytes"):
+            steps_per_s = value / (job.clips * world)
+            roof = job.clips * HBM_PEAK_GBS * 1e9 / job.step_bytes()
+            line["ar_steps_per_s_per_gpu"] = round(steps_per_s, 1)
+            line["us_per_ar_step"] = round(1e6 / steps_per_s, 2)
+            line["whole_step_hbm_roofline"] = {"samples_per_s_per_gpu_at_peak": round(roof, 1),
+                                               "algorithmic_bytes_per_step": job.step_bytes(),
+                                               "frac": round(value / world / roof, 5)}
+        roof = job.roofline()
+        if roof is not None:
+            line["roofline"] = roof
+        if not args.no_cpu_baseline:
+            line["cpu_baseline"] = job.cpu_baseline(args.cpu_seconds)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -159,6 +159,13 @@ int mmk_wavenet_generate(mmk_wavenet_plan* plan, int32_t batch, void* in0, int64
                          mmk_stream_t stream);
 /* raw head outputs of the most recent step: (batch, out_dim + learn_temp) fp32 */
 int mmk_wavenet_last_logits(mmk_wavenet_plan* plan, int32_t batch, float* out, int64_t ld, mmk_stream_t stream);
+/* Measurement aid for bench.py: runs n_steps like mmk_wavenet_generate (greedy) but eagerly, with HIP
+ * start/stop events attached to every fused-linear launch on `stream`; waits for completion and returns
+ * summed device time (ms) and launch counts per kernel class: [0] dilated+cond+gate layer kernel,
+ * [1] residual+skip layer kernel, [2] input / conditioning / head linears. */
+int mmk_wavenet_profile_steps(mmk_wavenet_plan* plan, int32_t batch, void* in0, int64_t in0_row_stride,
+                              const float* const* cond, const int64_t* cond_row_stride, int64_t t0,
+                              int64_t n_steps, double* ms_total, int64_t* launches, mmk_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * SampleRNN (mimikit/networks/sample_rnn_v2.py)

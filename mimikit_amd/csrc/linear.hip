@@ -13,9 +13,14 @@
 // (one coalesced 1 KiB dwordx4 load per 16x16 block).  The A operand can be the
 // concatenation of up to kMaxSeg row-major segments, each resolved through a
 // time-indexed Addr (dilation queues, cond rows, int64 sample windows).
+#include <hip/hip_ext.h>
+
 #include "mmk_common.h"
 
 namespace mmk {
+
+thread_local std::vector<ProfRecord>* g_prof = nullptr;
+thread_local int g_prof_tag = 0;
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -199,8 +204,19 @@ int launch_linear(const LinearArgs& a, hipStream_t stream) {
   dim3 grid(a.n_tiles, (a.M + mt * 16 - 1) / (mt * 16));
   dim3 block(64 * nw);
   size_t lds = nw > 1 ? (size_t)nw * mt * 64 * sizeof(f32x4) : 0;
-#define MMK_LAUNCH(MT_, VEC_) \
-  hipLaunchKernelGGL((linear_kernel<MT_, VEC_>), grid, block, lds, stream, a)
+  hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+  if (g_prof) {  // measurement mode: exact kernel start/stop timestamps on this stream
+    MMK_HIP(hipEventCreate(&ev_start));
+    MMK_HIP(hipEventCreate(&ev_stop));
+    g_prof->push_back(ProfRecord{ev_start, ev_stop, g_prof_tag});
+  }
+#define MMK_LAUNCH(MT_, VEC_)                                                                              \
+  do {                                                                                                     \
+    if (g_prof)                                                                                            \
+      hipExtLaunchKernelGGL((linear_kernel<MT_, VEC_>), grid, block, lds, stream, ev_start, ev_stop, 0, a); \
+    else                                                                                                   \
+      hipLaunchKernelGGL((linear_kernel<MT_, VEC_>), grid, block, lds, stream, a);                          \
+  } while (0)
   if (vec) {
     if (mt == 1) MMK_LAUNCH(1, true);
     else if (mt == 2) MMK_LAUNCH(2, true);

@@ -131,6 +131,14 @@ struct LinearArgs {
 
 int launch_linear(const LinearArgs& a, hipStream_t stream);
 
+// measurement mode: when g_prof is set, every linear launch carries start/stop events tagged g_prof_tag
+struct ProfRecord {
+  hipEvent_t start, stop;
+  int tag;
+};
+extern thread_local std::vector<ProfRecord>* g_prof;
+extern thread_local int g_prof_tag;
+
 // packing helpers (device side, enqueue on stream)
 int64_t packed_floats(int n_rows, int k_cols);
 // writes rows [row0 + r*row_step) r<n_rows, k-chunks starting at chunk0 of a packed matrix with k_chunks total

@@ -330,6 +330,7 @@ extern "C" int mmk_wavenet_commit(mmk_wavenet_plan* p, void* workspace, size_t w
 static int emit_step(mmk_wavenet_plan* p, const WnCall& call, int64_t tau_off, bool with_head, hipStream_t st) {
   const mmk_wavenet_config& c = p->cfg;
   const int C = p->C, S = p->S, L = p->L, M = call.M;
+  g_prof_tag = 2;
   // input module 0
   if (c.q_levels > 0) {
     MMK_TRY(launch_embed((const int64_t*)call.in0, call.in0_rs, 0, p->emb, C, c.q_levels, p->hist_slot(0, 0), C, M,
@@ -371,6 +372,7 @@ static int emit_step(mmk_wavenet_plan* p, const WnCall& call, int64_t tau_off, b
       a.epilogue = c.gated ? EPI_GATE : EPI_STORE;
       a.act = c.gated ? ACT_NONE : ACT_TANH;
       a.out = p->y_addr(l); a.out_ld = C;
+      g_prof_tag = 0;
       MMK_TRY(launch_linear(a, st));
     }
     if (p->Bm[l].n_tiles > 0) {
@@ -387,9 +389,11 @@ static int emit_step(mmk_wavenet_plan* p, const WnCall& call, int64_t tau_off, b
       a.res_in = p->hist_slot(l, 0); a.res_in_ld = C;
       a.res_out = p->hist_slot(l + 1, 0); a.res_out_ld = C;
       a.skip = addr_static(p->skipbuf); a.skip_ld = S > 0 ? S : 1;
+      g_prof_tag = 1;
       MMK_TRY(launch_linear(a, st));
     }
   }
+  g_prof_tag = 2;
   if (!with_head) return MMK_OK;
   const float* x = S > 0 ? p->skipbuf : p->ybuf;
   int x_ld = p->head_in;
@@ -527,4 +531,35 @@ extern "C" int mmk_wavenet_last_logits(mmk_wavenet_plan* p, int32_t batch, float
   MMK_HIP(hipMemcpy2DAsync(out, ld * sizeof(float), p->logits, p->logits_ld * sizeof(float), n * sizeof(float), batch,
                            hipMemcpyDeviceToDevice, (hipStream_t)stream));
   return MMK_OK;
+}
+
+extern "C" int mmk_wavenet_profile_steps(mmk_wavenet_plan* p, int32_t batch, void* in0, int64_t in0_row_stride,
+                                         const float* const* cond, const int64_t* cond_row_stride, int64_t t0,
+                                         int64_t n_steps, double* ms_total, int64_t* launches, mmk_stream_t stream) {
+  WnCall call;
+  MMK_TRY(check_call(p, batch, in0, cond, cond_row_stride, call));
+  if (!ms_total || !launches || t0 < 1 || n_steps < 1) return fail(MMK_ERR_INVALID, "wavenet_profile_steps: bad arguments");
+  call.in0_rs = in0_row_stride;
+  hipStream_t st = (hipStream_t)stream;
+  std::vector<ProfRecord> records;
+  records.reserve((size_t)n_steps * (2 * p->L + 8));
+  MMK_TRY(launch_set_i64(p->tau, t0 - 1, st));
+  g_prof = &records;
+  int rc = MMK_OK;
+  for (int64_t s = 0; s < n_steps && rc == MMK_OK; ++s) rc = emit_step(p, call, s, true, st);
+  g_prof = nullptr;
+  if (rc == MMK_OK) rc = launch_bump(p->tau, n_steps, st);
+  hipError_t e = hipStreamSynchronize(st);
+  for (int k = 0; k < 3; ++k) { ms_total[k] = 0.0; launches[k] = 0; }
+  for (auto& r : records) {
+    float ms = 0.f;
+    if (e == hipSuccess && hipEventElapsedTime(&ms, r.start, r.stop) == hipSuccess && r.tag >= 0 && r.tag < 3) {
+      ms_total[r.tag] += ms;
+      launches[r.tag] += 1;
+    }
+    (void)hipEventDestroy(r.start);
+    (void)hipEventDestroy(r.stop);
+  }
+  if (e != hipSuccess) return fail(MMK_ERR_HIP, "wavenet_profile_steps: %s", hipGetErrorString(e));
+  return rc;
 }

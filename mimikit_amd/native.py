@@ -69,6 +69,8 @@ _SIGNATURES = {
     "mmk_wavenet_warmup": (i32, [vp, i32, vp, i64, C.POINTER(vp), C.POINTER(i64), i64, i64, vp]),
     "mmk_wavenet_generate": (i32, [vp, i32, vp, i64, C.POINTER(vp), C.POINTER(i64), i64, i64, vp, vp, vp]),
     "mmk_wavenet_last_logits": (i32, [vp, i32, vp, i64, vp]),
+    "mmk_wavenet_profile_steps": (i32, [vp, i32, vp, i64, C.POINTER(vp), C.POINTER(i64), i64, i64,
+                                        C.POINTER(C.c_double), C.POINTER(i64), vp]),
     "mmk_srnn_plan_create": (i32, [C.POINTER(SrnnConfig), C.POINTER(vp)]),
     "mmk_srnn_plan_destroy": (None, [vp]),
     "mmk_srnn_plan_bind": (i32, [vp, cp, vp, i64]),
@@ -333,6 +335,18 @@ class WaveNetPlan(_Plan):
         check(self._lib.mmk_wavenet_generate(self.handle, in0.shape[0], abs_ptr(in0, t_first), in0.stride(0), ptrs,
                                              strides, t0, n_steps, ptr(temperature), ptr(uniforms),
                                              stream_ptr(self.device)), "mmk_wavenet_generate")
+
+    def profile_steps(self, in0: torch.Tensor, cond: Sequence[torch.Tensor], t0: int, n_steps: int, t_first: int = 0):
+        """measurement aid: per-kernel-class device time from HIP events (see include/mmk.h);
+        returns {"layer_a": (ms_total, launches), "layer_b": ..., "other": ...}"""
+        self._check_inputs(in0, cond)
+        ptrs, strides = _cond_arrays(cond, t_first)
+        ms = (C.c_double * 3)()
+        cnt = (i64 * 3)()
+        check(self._lib.mmk_wavenet_profile_steps(self.handle, in0.shape[0], abs_ptr(in0, t_first), in0.stride(0), ptrs,
+                                                  strides, t0, n_steps, ms, cnt, stream_ptr(self.device)),
+              "mmk_wavenet_profile_steps")
+        return {name: (ms[i], cnt[i]) for i, name in enumerate(("layer_a", "layer_b", "other"))}
 
     def last_logits(self, batch: int) -> torch.Tensor:
         n = self.cfg.out_dim + (1 if self.cfg.learn_temp else 0)

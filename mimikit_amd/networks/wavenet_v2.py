@@ -354,11 +354,19 @@ class WaveNet(ARM, nn.Module):
         u = torch.rand((batch, n_steps), device=self.device, dtype=torch.float32)
         return t, u
 
+    @staticmethod
+    def _time_major(x: torch.Tensor) -> torch.Tensor:
+        """(batch, T[, dim]) with unit stride on dim and dim-stride on T; the batch stride is free,
+        so windows of a longer tensor are used in place"""
+        ok = x.stride(-1) == 1 and (x.dim() == 2 or x.stride(1) == x.shape[2])
+        return x if ok else x.contiguous()
+
     def _prepare(self, tensors: Tuple[torch.Tensor, ...]):
         in0, cond = tensors[0], tuple(tensors[1:])
         if self._plan.cfg.q_levels == 0 and in0.dtype != torch.float32:
             in0 = in0.float()
-        return in0, tuple(c if c.dtype == torch.float32 else c.float() for c in cond)
+        cond = tuple(self._time_major(c if c.dtype == torch.float32 else c.float()) for c in cond)
+        return self._time_major(in0), cond
 
     def _window_step(self, window: Tuple[torch.Tensor, ...], t: int, **parameters):
         """rebuild the queues from an rf-long window ending at absolute time t, then produce step t"""
@@ -367,7 +375,6 @@ class WaveNet(ARM, nn.Module):
         in0, cond = self._prepare(window)
         # scratch copy of the window with one free column for the produced step
         buf = torch.cat([in0, torch.zeros_like(in0[:, :1])], dim=1).contiguous()
-        cond = tuple(c.contiguous() for c in cond)
         t_first = t - rf
         self._plan.warmup(buf, cond, t_first, t - 1, t_first=t_first)
         temp, uni = self._sampling(batch, 1, parameters)
@@ -386,8 +393,6 @@ class WaveNet(ARM, nn.Module):
             self._next_t = None
             return
         in0, cond = self._prepare(prompts)
-        in0 = in0 if in0.stride(-1) == 1 else in0.contiguous()
-        cond = tuple(c.contiguous() for c in cond)
         # positions [P - rf, P - 1) fill the queues; position P - 1 is consumed by the first step
         self._plan.warmup(in0, cond, length - rf, length - 1, t_first=0)
         self._next_t, self._state_batch = length, batch
@@ -404,7 +409,6 @@ class WaveNet(ARM, nn.Module):
         # queues are in sync: only the newest position (t - 1) is consumed
         in0, cond = self._prepare(tuple(x[:, -1:] for x in inputs))
         buf = torch.cat([in0, torch.zeros_like(in0)], dim=1).contiguous()
-        cond = tuple(c.contiguous() for c in cond)
         temp, uni = self._sampling(batch, 1, parameters)
         self._plan.generate(buf, cond, t, 1, temp, uni, t_first=t - 1)
         self._next_t = t + 1
@@ -423,9 +427,6 @@ class WaveNet(ARM, nn.Module):
         in0, cond = self._prepare(tensors)
         if in0.data_ptr() != tensors[0].data_ptr():
             raise TypeError("generate_block writes in place: tensors[0] must already have the network's input dtype")
-        for c, orig in zip(cond, tensors[1:]):
-            if not c.is_contiguous():
-                raise ValueError("conditioning tensors must be contiguous for generate_block")
         temp, uni = self._sampling(batch, n_steps, parameters)
         self._plan.generate(in0, cond, t0, n_steps, temp, uni, t_first=0)
         self._next_t = t0 + n_steps

@@ -1,0 +1,203 @@
+"""GPU parity of the feature functionals and building-block kernels, through the C ABI.
+Bars: bit-exact for mu-law codes / class indices; fp32 tolerances (stated per test) for
+magnitudes, logits and linear layers."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import mimikit_amd as mmk
+from mimikit_amd import native
+from oracle import torch_ref as O
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+torch.set_grad_enabled(False)
+
+
+# ---------------------------------------------------------------------------- mu-law
+@pytest.mark.parametrize("tag", ["c1", "c05"])
+def test_mulaw_golden_bit_exact(device, tag):
+    g = H.golden(f"mulaw_{tag}.npz")
+    comp = float(g["compression"])
+    x = H.T(g["x"]).to(device)
+    n_in_range = x.numel() - 4   # the last four inputs are outside [-1, 1]
+    codes = mmk.MuLawCompress(256, comp)(x).cpu()
+    assert codes.dtype == torch.int64
+    assert torch.equal(codes[:n_in_range], H.T(g["codes"])[:n_in_range])
+    # out-of-range inputs are evaluated directly (no clamp, like the reference): same code +-1
+    assert (codes[n_in_range:] - H.T(g["codes"])[n_in_range:]).abs().max() <= 1
+    all_codes = H.T(g["all_codes"]).to(device)
+    exp = mmk.MuLawExpand(256, comp)(all_codes).cpu()
+    in_range = (H.T(g["all_codes"]) >= 0) & (H.T(g["all_codes"]) < 256)
+    assert torch.equal(exp[in_range], H.T(g["expanded"])[in_range])
+    assert torch.allclose(exp[~in_range], H.T(g["expanded"])[~in_range], rtol=1e-5, atol=1e-7)
+
+
+@pytest.mark.parametrize("shape", [(0,), (1,), (3,), (7, 13), (2, 16000), (64, 10007)])
+@pytest.mark.parametrize("q,comp", [(256, 1.0), (256, 0.5), (64, 1.0), (1024, 2.0)])
+def test_mulaw_vs_oracle_bit_exact(device, shape, q, comp):
+    gen = torch.Generator().manual_seed(hash((shape, q)) % 1000)
+    x = torch.rand(*shape, generator=gen) * 2 - 1
+    want = O.mulaw_compress(x, q, comp)
+    got = mmk.MuLawCompress(q, comp)(x.to(device))
+    assert got.shape == want.shape and torch.equal(got.cpu(), want)
+    back = mmk.MuLawExpand(q, comp)(got)
+    assert torch.equal(back.cpu(), O.mulaw_expand(want, q, comp))
+
+
+def test_mulaw_unaligned_views(device):
+    x = (torch.rand(4099) * 2 - 1)
+    xd = x.to(device)
+    for off in (1, 2, 3):
+        got = mmk.MuLawCompress()(xd[off:])
+        assert torch.equal(got.cpu(), O.mulaw_compress(x[off:]))
+        assert torch.equal(mmk.MuLawExpand()(got[off:]).cpu(), O.mulaw_expand(O.mulaw_compress(x[off:])[off:]))
+
+
+def test_mulaw_full_size_round_trip(device):
+    """BASELINE feature size (64 x 60 s @ 16 kHz): quantise -> expand -> quantise is idempotent,
+    codes stay in range and are monotone in the input"""
+    x = torch.rand(64, 16000 * 60, device=device) * 2 - 1
+    f, inv = mmk.MuLawCompress(), mmk.MuLawExpand()
+    codes = f(x)
+    assert int(codes.min()) >= 0 and int(codes.max()) <= 255
+    assert torch.equal(f(inv(codes)), codes)
+    xs, order = torch.sort(x.flatten()[:1 << 20])
+    cs = f(xs)
+    assert bool((cs[1:] >= cs[:-1]).all())
+
+
+def test_mulaw_requires_device():
+    with pytest.raises(RuntimeError):
+        mmk.MuLawCompress()(torch.zeros(4))
+
+
+# ---------------------------------------------------------------------------- STFT
+def test_magspec_golden(device):
+    g = H.golden("stft.npz")
+    for key, want in g.items():
+        if not key.startswith("mag_"):
+            continue
+        parts = key.split("_")
+        src = "y" if parts[1] == "y" else "x"
+        n_fft, hop, center = (int(p) for p in parts[-3:])
+        got = mmk.MagSpec(n_fft, hop, center=bool(center))(H.T(g[src]).to(device)).cpu()
+        assert got.shape == want.shape, key
+        # fp32 tolerance: 2e-5 of the largest magnitude of the spectrogram
+        assert float((got - H.T(want)).abs().max()) <= 2e-5 * float(np.abs(want).max()), key
+
+
+@pytest.mark.parametrize("n_fft,hop", [(64, 16), (256, 64), (512, 128), (1024, 256), (2048, 512), (4096, 1024), (1024, 100)])
+@pytest.mark.parametrize("center", [False, True])
+def test_magspec_vs_oracle(device, n_fft, hop, center):
+    gen = torch.Generator().manual_seed(n_fft + hop)
+    for shape in [(1, n_fft), (3, n_fft * 3 + 17), (2, 22050)]:
+        x = torch.randn(*shape, generator=gen)
+        want = O.magspec(x, n_fft, hop, center)
+        got = mmk.MagSpec(n_fft, hop, center=center)(x.to(device)).cpu()
+        assert got.shape == want.shape
+        assert float((got - want).abs().max()) <= 2e-5 * float(want.abs().max())
+    one = torch.randn(n_fft * 2, generator=gen)   # 1-D input
+    assert mmk.MagSpec(n_fft, hop, center=center)(one.to(device)).shape == O.magspec(one, n_fft, hop, center).shape
+
+
+def test_magspec_linearity_and_pure_tone(device):
+    n_fft, hop = 1024, 256
+    f = mmk.MagSpec(n_fft, hop, center=False)
+    t = torch.arange(22050, dtype=torch.float32)
+    k = 37
+    tone = torch.cos(2 * np.pi * k * t / n_fft).to(device)
+    mag = f(tone)
+    assert int(mag[5].argmax()) == k
+    assert abs(float(mag[5, k]) - n_fft / 4) < 1e-2 * n_fft     # Hann: amplitude N/4 at the bin centre
+    x = torch.randn(2, 22050, device=device)
+    assert torch.allclose(f(3.0 * x), 3.0 * f(x), rtol=1e-5, atol=1e-4)
+
+
+def test_magspec_too_short_raises(device):
+    with pytest.raises((RuntimeError, ValueError)):
+        mmk.MagSpec(1024, 256, center=False)(torch.zeros(2, 100, device=device))
+
+
+# ---------------------------------------------------------------------------- linear
+@pytest.mark.parametrize("m,n,k", [(1, 16, 16), (2, 257, 128), (8, 128, 64), (32, 512, 768), (64, 1536, 512),
+                                   (3, 33, 513), (64, 65, 17), (130, 48, 100), (512, 96, 260)])
+@pytest.mark.parametrize("act", ["none", "Mish", "Abs", "Tanh"])
+def test_linear_vs_torch(device, m, n, k, act):
+    gen = torch.Generator().manual_seed(m * 1000 + n)
+    x = torch.randn(m, k, generator=gen)
+    w = torch.randn(n, k, generator=gen) / np.sqrt(k)
+    b = torch.randn(n, generator=gen)
+    want = F.linear(x, w, b)
+    want = {"none": want, "Mish": F.mish(want), "Abs": want.abs(), "Tanh": torch.tanh(want)}[act]
+    wp = native.pack_weight(w.to(device))
+    got = native.linear(x.to(device), wp, b.to(device), n, k, act).cpu()
+    # fp32 accumulation in a different order: 1e-5 relative to the row scale
+    assert float((got - want).abs().max()) <= 2e-5 * max(1.0, float(want.abs().max()))
+
+
+def test_linear_strided_input(device):
+    x = torch.randn(8, 40, device=device)[:, 4:36]       # ld 40, K 32
+    w = torch.randn(24, 32, device=device)
+    got = native.linear(x, native.pack_weight(w), None, 24, 32)
+    assert torch.allclose(got, x @ w.t(), rtol=1e-5, atol=1e-5)
+
+
+# ---------------------------------------------------------------------------- sampler
+def test_sampler_golden(device):
+    g = H.golden("sampler.npz")
+    logits = H.T(g["logits"]).to(device)
+    got = mmk.CategoricalSampler().eval()(logits)
+    assert got.shape == (6, 1) and torch.equal(got.cpu(), H.T(g["argmax"]))
+    raw = H.T(g["raw"]).to(device)
+    amax = native.categorical_sample(raw, 256, True, 1e-4, None, None)
+    assert torch.equal(amax.cpu(), H.T(g["raw_logits"]).argmax(-1))
+
+
+def test_sampler_argmax_ties_take_first(device):
+    logits = torch.zeros(5, 256)
+    logits[1, [7, 200]] = 3.0
+    logits[2, 255] = 1.0
+    logits[3, [0, 1]] = -0.0
+    logits[4] = -1.0
+    got = native.categorical_sample(logits.to(device), 256, False, 0., None, None).cpu()
+    assert torch.equal(got, logits.argmax(-1))
+
+
+@pytest.mark.parametrize("n_classes", [256, 64, 100, 1000])
+def test_sampler_inverse_cdf_matches_oracle(device, n_classes):
+    gen = torch.Generator().manual_seed(n_classes)
+    rows = 4096
+    logits = torch.randn(rows, n_classes, generator=gen) * 2
+    temp = torch.rand(rows, generator=gen) * 1.5 + 0.25
+    u = torch.rand(rows, generator=gen)
+    want = O.categorical(logits, temp, u)
+    got = native.categorical_sample(logits.to(device), n_classes, False, 0., temp.to(device), u.to(device)).cpu()
+    same = got == want
+    # a draw may legitimately differ only when u sits within fp32 rounding of a CDF step
+    l = logits / temp[:, None]
+    p = torch.softmax(l.double(), -1)
+    cdf = p.cumsum(-1)
+    lo = torch.minimum(got, want)
+    gap = (cdf[torch.arange(rows), lo] - u.double()).abs()
+    assert bool((same | (gap < 1e-5)).all())
+    assert float(same.float().mean()) > 0.999
+    # distribution check against the reference's probabilities for one row
+    g = H.golden("sampler.npz")
+    row = H.T(g["logits"])[0, 0]
+    n = 200000
+    draws = native.categorical_sample(row.to(device).expand(n, 256).contiguous(), 256, False, 0.,
+                                      torch.full((n,), 0.5, device=device), torch.rand(n, device=device)).cpu()
+    hist = torch.bincount(draws, minlength=256).float() / n
+    assert float((hist - H.T(g["probs_t05"])[0, 0]).abs().max()) < 5e-3
+
+
+def test_sampler_module_shapes(device):
+    s = mmk.CategoricalSampler().eval()
+    logits = torch.randn(3, 1, 256, device=device)
+    for temp in (None, 0.5, (1.,), torch.tensor([0.5, 1., 2.])):
+        out = s(logits, temperature=temp)
+        assert out.shape == (3, 1) and out.dtype == torch.int64
+    s.train()
+    assert s(logits) is logits

@@ -1,0 +1,228 @@
+"""CPU-side tests: host logic mirrors the reference (facts captured from the reference's own code in
+tests/golden/reference_facts.json), the C-ABI library loads and exports what include/mmk.h declares,
+and the product path refuses to run anywhere but on the HIP device."""
+import dataclasses as dtc
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import mimikit_amd as mmk
+from mimikit_amd import native
+from mimikit_amd.features.functionals import mulaw_edges, mulaw_table
+from oracle import torch_ref as O
+from tests import helpers as H
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def shapes(net):
+    return {k: list(v.shape) for k, v in net.state_dict().items()}
+
+
+def cfg4_io():
+    io = H.mu_emb()
+    ext = mmk.Extractor("signal", mmk.FileToSignal(16000))
+    return mmk.IOSpec(inputs=(io.inputs[0], mmk.InputSpec("signal", mmk.MagSpec(1024, 256, center=False), mmk.LinearIO()).bind_to(ext)),
+                      targets=io.targets)
+
+
+# ------------------------------------------------------------------ state_dict layout == reference
+def test_state_dict_layout_matches_reference():
+    f = H.facts()
+    assert shapes(mmk.WaveNet.from_config(mmk.WaveNet.Config(io_spec=H.mu_emb()))) == f["wavenet_default"]
+    assert shapes(mmk.WaveNet.from_config(mmk.WaveNet.Config(
+        io_spec=H.mu_emb(), blocks=(10,), dims_dilated=(64,), residuals_dim=64, skips_dim=64))) == f["wavenet_cfg2"]
+    assert shapes(mmk.WaveNet.from_config(mmk.WaveNet.Config(
+        io_spec=cfg4_io(), blocks=(10, 10, 10), dims_dilated=(256,), dims_1x1=(256,), residuals_dim=256,
+        skips_dim=256))) == f["wavenet_cfg4"]
+    assert shapes(mmk.SampleRNN.from_config(mmk.SampleRNN.Config(io_spec=H.mu_lin()))) == f["srnn_cfg1"]
+    assert shapes(mmk.SampleRNN.from_config(mmk.SampleRNN.Config(
+        io_spec=H.mu_lin(), frame_sizes=(16, 4, 1), hidden_dim=512, rnn_class="gru"))) == f["srnn_cfg3"]
+    assert shapes(mmk.Seq2SeqLSTMNetwork.from_config(mmk.Seq2SeqLSTMNetwork.Config(
+        io_spec=mmk.IOSpec.magspec_io(mmk.IOSpec.MagSpecIOConfig(sr=22050, n_fft=1024, hop_length=256))))) == f["s2s_cfg5"]
+
+
+def test_rf_n_steps_and_unit_conversions_match_reference():
+    host = H.facts()["host"]
+    for key, rf in host["rf"].items():
+        blocks, ks = (eval(p) for p in key.split("|"))
+        net = mmk.WaveNet.from_config(mmk.WaveNet.Config(io_spec=H.mu_emb(), blocks=blocks, kernel_sizes=ks, dims_dilated=(4,)))
+        assert net.rf == rf, key
+        assert O.wavenet_rf(*mmk.WaveNet.get_kernels_and_dilation(ks, blocks)) == rf
+    s2s = mmk.Seq2SeqLSTMNetwork.from_config(mmk.Seq2SeqLSTMNetwork.Config(
+        io_spec=mmk.IOSpec.magspec_io(mmk.IOSpec.MagSpecIOConfig(sr=22050, n_fft=1024, hop_length=256)), model_dim=8))
+    wn = mmk.WaveNet.from_config(mmk.WaveNet.Config(io_spec=H.mu_emb(), dims_dilated=(4,)))
+    for key, n in host["n_steps"].items():
+        name, dur = key.split("|")
+        net = s2s if name == "s2s" else wn
+        assert mmk.GenerateLoopV2.get_n_steps(mmk.GenerateLoopV2.Config(output_duration_sec=float(dur)), net) == n, key
+    for c in host["convert"]:
+        fr = mmk.Frame(c["n_fft"], c["hop"], padding=c["pad"])
+        assert mmk.convert(c["n"], mmk.Sample(1), fr, True) == c["s2f_len"]
+        assert mmk.convert(c["n"], mmk.Sample(1), fr, False) == c["s2f_pos"]
+        assert mmk.convert(c["n"] // c["hop"], fr, mmk.Sample(1), True) == c["f2s_len"]
+        assert mmk.convert(c["n"] // c["hop"], fr, mmk.Sample(1), False) == c["f2s_pos"]
+        if not c["pad"] and c["n"] >= c["n_fft"]:
+            keep = mmk.STFT(c["n_fft"], c["hop"], "mag", center=False).fixed_length(c["n"])
+            assert keep == O.stft_fixed_length(c["n"], c["n_fft"], c["hop"], False)
+            assert native.load_library().mmk_stft_n_frames(keep, c["n_fft"], c["hop"], 0) == c["s2f_len"]
+
+
+def test_wavenet_rf_examples_of_the_reference_tests():
+    """tests/test_wavenet.py:251-262 of the reference: all these block layouts have rf == 8"""
+    io = mmk.IOSpec.magspec_io(mmk.IOSpec.MagSpecIOConfig())
+    for blocks in [(3,), (1, 1, 1, 1, 1, 1, 1), (2, 2, 1), (1, 2, 2), (1, 1, 1, 1, 2)]:
+        assert mmk.WaveNet.from_config(mmk.WaveNet.Config(io_spec=io, blocks=blocks)).rf == 8
+    with pytest.raises(ValueError):
+        mmk.WaveNet.get_kernels_and_dilation((2, 3), (3,))
+
+
+# ------------------------------------------------------------------ training-mode graphs (shapes)
+def test_training_forward_shapes():
+    wn = mmk.WaveNet.from_config(mmk.WaveNet.Config(io_spec=mmk.IOSpec.magspec_io(mmk.IOSpec.MagSpecIOConfig()), blocks=(3,)))
+    x = torch.randn(2, 9, 1025)
+    assert wn((x,))[0].shape == (2, 2, 1025)          # T = rf + 1 -> 2 outputs
+    with pytest.raises(RuntimeError):
+        wn((x[:, :7],))                                  # shorter than rf
+    srnn = mmk.SampleRNN.from_config(mmk.SampleRNN.Config(frame_sizes=(16, 4, 2), io_spec=H.mu_lin()))
+    out = srnn((torch.arange(128).reshape(2, 64),))
+    assert type(out) is tuple and out[0].shape == (2, 48, 256)
+    s2s = mmk.Seq2SeqLSTMNetwork.from_config(mmk.Seq2SeqLSTMNetwork.Config(
+        io_spec=mmk.IOSpec.magspec_io(mmk.IOSpec.MagSpecIOConfig(n_fft=128, hop_length=32)), model_dim=16, hop=4))
+    y = s2s((torch.randn(4, 4, 65),))
+    assert isinstance(y, torch.Tensor) and y.shape == (4, 4, 65)
+    assert isinstance(wn, mmk.ARM) and isinstance(srnn, mmk.ARMWithHidden) and isinstance(s2s, mmk.ARM)
+    assert len(mmk.SampleRNN.from_config(mmk.SampleRNN.Config(io_spec=H.mu_lin())).tiers) == 3
+    assert len(mmk.WaveNet.from_config(mmk.WaveNet.Config(io_spec=H.mu_emb())).layers) == 4
+
+
+def test_generate_params():
+    assert mmk.SampleRNN.from_config(mmk.SampleRNN.Config(io_spec=H.mu_lin())).generate_params == {"temperature"}
+    # reproduced reference quirk: WaveNet exposes no sampling parameter to the loop
+    assert mmk.WaveNet.from_config(mmk.WaveNet.Config(io_spec=H.mu_emb())).generate_params == set()
+
+
+# ------------------------------------------------------------------ error behaviour of the config layer
+def test_io_module_wiring_errors():
+    m = mmk.LinearIO()
+    with pytest.raises(AttributeError):
+        m.set(nope=1)
+    m.set(in_dim=3)
+    with pytest.raises(RuntimeError):
+        m.set(in_dim=4)
+    with pytest.raises(ValueError):
+        m.module()                                       # out_dim missing
+    with pytest.raises(ValueError):
+        mmk.IOSpec.mulaw_io(mmk.IOSpec.MuLawIOConfig(input_module_type="nope"))
+    with pytest.raises(ValueError):
+        # WaveNet needs the embedding input; framed_linear lacks a frame size there
+        mmk.WaveNet.from_config(mmk.WaveNet.Config(io_spec=H.mu_lin()))
+    io = cfg4_io()
+    with pytest.raises(RuntimeError):
+        io.unit                                          # Sample and Frame units mixed
+    assert io.sr == 16000
+
+
+def test_config_round_trip_and_type_tags():
+    cfg = mmk.GenerateLoopV2.Config(output_duration_sec=2., batch_size=3, parameters={"temperature": 0.5})
+    again = mmk.Config.deserialize(cfg.serialize())
+    assert isinstance(again, mmk.GenerateLoopV2.Config)
+    assert again.output_duration_sec == 2. and again.batch_size == 3 and again.parameters == {"temperature": 0.5}
+    assert mmk.WaveNet.Config().type == "WaveNet.Config"
+    assert "in_dim" not in mmk.LinearIO().serialize()     # runtime wiring is not serialised
+
+
+def test_fill_and_prepare_prompt():
+    x = torch.arange(6).reshape(2, 3)
+    y = mmk.fill(x, ("data", 3), ("blank", 2))
+    assert y.shape == (2, 5) and y.dtype == x.dtype and bool((y[:, 3:] == 0).all())
+    z = mmk.fill(torch.ones(2, 3, 4), ("data", 3), ("blank", 5))
+    assert z.shape == (2, 8, 4)
+    with pytest.raises(AssertionError):
+        mmk.fill(x, (torch.zeros(3), 1), ("blank", 1))
+    p = mmk.prepare_prompt("cpu", (np.zeros(4, dtype=np.float32), torch.ones(1, 4)), 2)
+    assert p[0].shape == (1, 6) and p[1].shape == (1, 6)
+
+
+# ------------------------------------------------------------------ mu-law tables (host side of the kernel)
+@pytest.mark.parametrize("q,comp", [(256, 1.0), (256, 0.5), (64, 1.0)])
+def test_mulaw_edge_table_reproduces_the_formula(q, comp):
+    e = mulaw_edges(q, comp)
+    assert e.shape == (q - 1,) and bool((e[1:] > e[:-1]).all())
+    x = torch.rand(500000, generator=torch.Generator().manual_seed(0)) * 2 - 1
+    assert torch.equal(torch.searchsorted(e, x, right=True), O.mulaw_compress(x, q, comp))
+    assert torch.equal(mulaw_table(q, comp), O.mulaw_expand(torch.arange(q), q, comp))
+    g = H.golden("mulaw_c1.npz")
+    if (q, comp) == (256, 1.0):
+        xin = H.T(g["x"])[:-4]
+        assert torch.equal(torch.searchsorted(e, xin, right=True), H.T(g["codes"])[:-4])
+
+
+def test_numpy_twins():
+    x = np.linspace(-1, 1, 1001).astype(np.float32)
+    codes = mmk.MuLawCompress()(x)
+    assert codes.dtype == np.int64 and codes.min() == 0 and codes.max() == 255
+    assert np.abs(mmk.MuLawExpand()(codes) - x).max() < 0.05
+    assert isinstance(mmk.MuLawCompress().inv, mmk.MuLawExpand) and isinstance(mmk.MagSpec().inv, mmk.GLA)
+
+
+# ------------------------------------------------------------------ C ABI
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, "include", "mmk.h")).read()
+    declared = set(re.findall(r"\b(mmk_[a-z0-9_]+)\s*\(", header))
+    declared -= {"mmk_stream_t"}
+    lib = native.load_library()
+    assert lib.mmk_abi_version() == 1
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} is declared in include/mmk.h but not exported"
+    assert declared == set(native.EXPORTED_SYMBOLS), declared ^ set(native.EXPORTED_SYMBOLS)
+
+
+def test_abi_argument_validation_needs_no_gpu():
+    lib = native.load_library()
+    cfg = native.WaveNetConfig()
+    handle = native.vp()
+    assert lib.mmk_wavenet_plan_create(native.C.byref(cfg), native.C.byref(handle)) == -1   # n_layers = 0
+    assert b"n_layers" in lib.mmk_last_error()
+    cfg.n_layers, cfg.dim_dilated, cfg.max_batch, cfg.q_levels = 2, 16, 2, 256
+    cfg.kernel_size[0] = cfg.kernel_size[1] = 2
+    cfg.dilation[0], cfg.dilation[1] = 1, 2
+    cfg.mlp_hidden, cfg.out_dim, cfg.learn_temp, cfg.gated, cfg.bias = 8, 256, 1, 1, 1
+    assert lib.mmk_wavenet_plan_create(native.C.byref(cfg), native.C.byref(handle)) == 0
+    assert lib.mmk_wavenet_receptive_field(handle) == 4
+    assert lib.mmk_wavenet_workspace_bytes(handle) > 0
+    # generate before commit is a state error, not a crash
+    assert lib.mmk_wavenet_generate(handle, 1, 1, 8, None, None, 4, 1, None, None, None) == -5
+    lib.mmk_wavenet_plan_destroy(handle)
+    assert lib.mmk_stft_n_frames(22050, 1024, 256, 0) == 83
+    assert lib.mmk_packed_weight_floats(17, 33) == 32 * 48
+
+
+# ------------------------------------------------------------------ no CPU fallback
+def test_generate_path_refuses_cpu():
+    wn = mmk.WaveNet.from_config(mmk.WaveNet.Config(io_spec=H.mu_emb(), blocks=(2,), dims_dilated=(8,))).eval()
+    x = torch.zeros(1, 8, dtype=torch.int64)
+    for call in (lambda: wn((x,)), lambda: wn.generate_step((x,), t=8), lambda: wn.before_generate((x,), 0),
+                 lambda: mmk.MuLawCompress()(torch.zeros(4)), lambda: mmk.MagSpec()(torch.zeros(4096)),
+                 lambda: mmk.CategoricalSampler().eval()(torch.zeros(2, 256))):
+        with pytest.raises(RuntimeError, match="HIP device|MI355X"):
+            call()
+    srnn = mmk.SampleRNN.from_config(mmk.SampleRNN.Config(io_spec=H.mu_lin())).eval()
+    with pytest.raises(RuntimeError):
+        srnn.before_generate((torch.zeros(1, 32, dtype=torch.int64),), 0)
+    with pytest.raises(RuntimeError):
+        srnn((torch.zeros(1, 64, dtype=torch.int64),))    # eval forward is not the training graph
+    with pytest.raises(native.NativeError, match="no CPU fallback"):
+        native.load_library("/nonexistent/libmmk_hip.so")
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "mimikit_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for name in files:
+            if name.endswith(".py"):
+                src = open(os.path.join(dirpath, name)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle", src, re.M), f"{name} imports the oracle"
