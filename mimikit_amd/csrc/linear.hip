@@ -101,21 +101,10 @@ __global__ __launch_bounds__(1024) void linear_kernel(const LinearArgs a) {
   }
 
   // ---- split-K reduction across the workgroup's waves (fixed order) ----------
-  f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
-  int mt_out = 0;
-  bool active = true;
   if (nw > 1) {
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) red[(wave * MT + mt) * 64 + lane] = acc[mt];
     __syncthreads();
-    active = (int)threadIdx.x < MT * 64;
-    if (active) {
-      mt_out = threadIdx.x >> 6;
-      for (int w = 0; w < nw; ++w) {
-        f32x4 p = red[(w * MT + mt_out) * 64 + lane];
-        v[0] += p[0]; v[1] += p[1]; v[2] += p[2]; v[3] += p[3];
-      }
-    }
   }
 
   // ---- epilogue: lane holds column n, rows 4*(lane>>4)+j ----------------------
@@ -180,7 +169,15 @@ __global__ __launch_bounds__(1024) void linear_kernel(const LinearArgs a) {
   };
 
   if (nw > 1) {
-    if (active) run_epilogue(v, mt_out);
+    // wave w' finishes row tiles w', w'+nw, ...: sums the partials in wave order, then the epilogue
+    for (int mt = wave; mt < MT; mt += nw) {
+      f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int w = 0; w < nw; ++w) {
+        const f32x4 p = red[(w * MT + mt) * 64 + lane];
+        v[0] += p[0]; v[1] += p[1]; v[2] += p[2]; v[3] += p[3];
+      }
+      run_epilogue(v, mt);
+    }
   } else {
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) run_epilogue(acc[mt], mt);

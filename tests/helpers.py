@@ -81,8 +81,9 @@ def s2s_tiny():
     return net.eval(), sd
 
 
-def margin_ok(raw, min_gap=1e-3):
+def margin_ok(raw, min_gap=5e-5):
     """top-1 / top-2 gap of the class logits (temperature column excluded): greedy decode is only
-    comparable bit-exactly where no near-tie exists"""
+    comparable bit-exactly where no near-tie exists (fp32 re-association noise on these logits is
+    ~1e-6; the committed fixtures have a smallest gap of 1.8e-4)"""
     top = torch.topk(T(raw)[..., :-1], 2, dim=-1).values
     return (top[..., 0] - top[..., 1]) > min_gap

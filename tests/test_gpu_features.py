@@ -29,9 +29,13 @@ def test_mulaw_golden_bit_exact(device, tag):
     assert (codes[n_in_range:] - H.T(g["codes"])[n_in_range:]).abs().max() <= 1
     all_codes = H.T(g["all_codes"]).to(device)
     exp = mmk.MuLawExpand(256, comp)(all_codes).cpu()
-    in_range = (H.T(g["all_codes"]) >= 0) & (H.T(g["all_codes"]) < 256)
-    assert torch.equal(exp[in_range], H.T(g["expanded"])[in_range])
-    assert torch.allclose(exp[~in_range], H.T(g["expanded"])[~in_range], rtol=1e-5, atol=1e-7)
+    # expanded VALUES are fp32: bit-exact against the oracle evaluated on this host (the kernel's
+    # table is built with the same torch CPU ops), 2 ulp against the fixture made on another CPU
+    # (torch's vectorised exp/log1p differ in the last bit between CPU ISAs)
+    assert torch.equal(exp[2:-3], O.mulaw_expand(H.T(g["all_codes"])[2:-3], 256, comp))
+    assert torch.allclose(exp[2:-3], H.T(g["expanded"])[2:-3], rtol=3e-7, atol=1e-9)
+    out_of_range = torch.tensor([0, 1, 258, 259, 260])      # codes -2, -1, 256, 257, 258: direct evaluation
+    assert torch.allclose(exp[out_of_range], H.T(g["expanded"])[out_of_range], rtol=1e-5, atol=1e-7)
 
 
 @pytest.mark.parametrize("shape", [(0,), (1,), (3,), (7, 13), (2, 16000), (64, 10007)])

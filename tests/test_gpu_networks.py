@@ -42,7 +42,10 @@ def test_wavenet_loop_matches_reference_golden(device):
     raw_last = net._plan.last_logits(prompt.size(0)).cpu()
     assert torch.allclose(raw_last, H.T(g["a_raw"])[:, -1], **LOGIT_TOL)
     inv = run_loop(net, (prompt,), 24, yield_inversed_outputs=True)
-    assert torch.equal(inv[0].cpu(), H.T(g["a_inversed"]))
+    # expanded audio is fp32: exact against the oracle on this host, 2 ulp against the fixture
+    # (made on another CPU; torch's vectorised exp differs in the last bit between CPU ISAs)
+    assert torch.equal(inv[0].cpu(), O.mulaw_expand(H.T(g["a_out"])))
+    assert torch.allclose(inv[0].cpu(), H.T(g["a_inversed"]), rtol=3e-7, atol=1e-9)
 
 
 def test_wavenet_generate_step_protocol(device):
