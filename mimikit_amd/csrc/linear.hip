@@ -24,36 +24,52 @@ thread_local int g_prof_tag = 0;
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ float seg_load_scalar(const Seg& sg, int64_t base_off, int64_t row, int k) {
-  if (k >= sg.K) return 0.f;
-  if (sg.kind == SEG_I64_LINEARIZED) {
-    const int64_t* p = (const int64_t*)sg.x.base + base_off + row * sg.ld + k;
-    return (((float)(*p) / sg.class_size) - .5f) * 2.f;
-  }
-  const float* p = (const float*)sg.x.base + base_off + row * sg.ld + k;
-  return *p;
-}
+// per-chunk view of the A operand: which segment a K-chunk belongs to is resolved with selects on
+// wave-uniform scalars (no dynamic indexing of the kernel-argument struct)
+struct SegView {
+  const char* base;  // segment base at the current time slot (bytes)
+  int64_t ld;        // row stride in elements
+  int K;
+  int kind;
+  float class_size;
+  int chunk0;
+};
 
 template <int MT, bool VEC>
 __global__ __launch_bounds__(1024) void linear_kernel(const LinearArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   f32x4* red = reinterpret_cast<f32x4*>(smem_raw);
+  constexpr int UNR = MT <= 2 ? 4 : 2;  // K-chunks whose loads are in flight together
 
   const int lane = threadIdx.x & 63;
-  const int wave = threadIdx.x >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int nw = blockDim.x >> 6;
   const int tile = blockIdx.x;
   const int m0 = blockIdx.y * (MT * 16);
-  const int64_t tau = (a.tau_ptr ? *a.tau_ptr : 0) + a.tau_off;
+  const int tau = (int)((a.tau_ptr ? *a.tau_ptr : 0) + a.tau_off);
 
-  const int c_begin = (int)(((int64_t)a.k_chunks * wave) / nw);
-  const int c_end = (int)(((int64_t)a.k_chunks * (wave + 1)) / nw);
+  // ---- resolve the (<= 4) segments once, with compile-time indices ----------------
+  SegView sv[kMaxSeg];
+#pragma unroll
+  for (int s = 0; s < kMaxSeg; ++s) {
+    const int esz = a.seg[s].kind == SEG_I64_LINEARIZED ? 8 : 4;
+    sv[s].base = (const char*)a.seg[s].x.base + addr_elems(a.seg[s].x, tau) * esz;
+    sv[s].ld = a.seg[s].ld;
+    sv[s].K = a.seg[s].K;
+    sv[s].kind = a.seg[s].kind;
+    sv[s].class_size = a.seg[s].class_size;
+    sv[s].chunk0 = a.seg_chunk0[s];
+  }
+  const int c1 = a.seg_chunk0[1], c2 = a.seg_chunk0[2], c3 = a.seg_chunk0[3];
+
+  const int c_begin = (int)(((long)a.k_chunks * wave) / nw);
+  const int c_end = (int)(((long)a.k_chunks * (wave + 1)) / nw);
   const int r = lane & 15, q = lane >> 4;
 
   int64_t row[MT];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
-    int m = m0 + mt * 16 + r;
+    const int m = m0 + mt * 16 + r;
     row[mt] = m < a.M ? m : a.M - 1;
   }
 
@@ -63,40 +79,60 @@ __global__ __launch_bounds__(1024) void linear_kernel(const LinearArgs a) {
 
   const f32x4* wp = reinterpret_cast<const f32x4*>(a.Wp) + ((int64_t)tile * a.k_chunks) * 64 + lane;
 
-  int s = 0;
-  while (s + 1 < a.nseg && c_begin >= a.seg_chunk0[s + 1]) ++s;
-  int64_t seg_off = addr_elems(a.seg[s].x, tau);
-
-  for (int c = c_begin; c < c_end; ++c) {
-    while (c >= a.seg_chunk0[s + 1]) {
-      ++s;
-      seg_off = addr_elems(a.seg[s].x, tau);
-    }
-    const Seg& sg = a.seg[s];
-    const int kk = (c - a.seg_chunk0[s]) * 16 + 4 * q;
-    const f32x4 w = wp[(int64_t)c * 64];
-    f32x4 x[MT];
-    if (VEC) {
-      const float* xb = (const float*)sg.x.base + seg_off + kk;
+  for (int cb = c_begin; cb < c_end; cb += UNR) {
+    f32x4 w[UNR];
+    f32x4 x[UNR][MT];
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) {
-        if (kk < sg.K)
-          x[mt] = *reinterpret_cast<const f32x4*>(xb + row[mt] * sg.ld);
-        else
-          x[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int u = 0; u < UNR; ++u) {
+      const int c = cb + u;
+      const bool live = c < c_end;
+      const int cc = live ? c : c_begin;
+      // segment of this chunk (wave-uniform selects)
+      const int si = (cc >= c1) + (cc >= c2) + (cc >= c3);
+      const char* base = si == 0 ? sv[0].base : (si == 1 ? sv[1].base : (si == 2 ? sv[2].base : sv[3].base));
+      const int64_t ld = si == 0 ? sv[0].ld : (si == 1 ? sv[1].ld : (si == 2 ? sv[2].ld : sv[3].ld));
+      const int K = si == 0 ? sv[0].K : (si == 1 ? sv[1].K : (si == 2 ? sv[2].K : sv[3].K));
+      const int ch0 = si == 0 ? 0 : (si == 1 ? c1 : (si == 2 ? c2 : c3));
+      const int kk = (cc - ch0) * 16 + 4 * q;
+      w[u] = live ? wp[(int64_t)cc * 64] : f32x4{0.f, 0.f, 0.f, 0.f};
+      if (VEC) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          if (live && kk < K)
+            x[u][mt] = *reinterpret_cast<const f32x4*>(base + (row[mt] * ld + kk) * 4);
+          else
+            x[u][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+      } else {
+        const int kind = si == 0 ? sv[0].kind : (si == 1 ? sv[1].kind : (si == 2 ? sv[2].kind : sv[3].kind));
+        const float cs = si == 0 ? sv[0].class_size
+                                 : (si == 1 ? sv[1].class_size : (si == 2 ? sv[2].class_size : sv[3].class_size));
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            float v = 0.f;
+            if (live && kk + i < K) {
+              if (kind == SEG_I64_LINEARIZED) {
+                const int64_t cls = *reinterpret_cast<const int64_t*>(base + (row[mt] * ld + kk + i) * 8);
+                v = (((float)cls / cs) - .5f) * 2.f;  // Linearizer, modules/io.py:106-112
+              } else {
+                v = *reinterpret_cast<const float*>(base + (row[mt] * ld + kk + i) * 4);
+              }
+            }
+            x[u][mt][i] = v;
+          }
+        }
       }
-    } else {
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) x[mt][i] = seg_load_scalar(sg, seg_off, row[mt], kk + i);
-      }
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int u = 0; u < UNR; ++u) {
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
-        acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(x[mt][i], w[i], acc[mt], 0, 0, 0);
+      for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+          acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(x[u][mt][i], w[u][i], acc[mt], 0, 0, 0);
+      }
     }
   }
 
@@ -189,15 +225,24 @@ static bool seg_vec_ok(const Seg& s) {
          ((reinterpret_cast<uintptr_t>(s.x.base) & 15) == 0);
 }
 
-int launch_linear(const LinearArgs& a, hipStream_t stream) {
-  if (a.M <= 0 || a.n_tiles <= 0) return MMK_OK;
-  if (a.nseg < 1 || a.nseg > kMaxSeg) return fail(MMK_ERR_INVALID, "linear: bad segment count %d", a.nseg);
+int launch_linear(const LinearArgs& a_in, hipStream_t stream) {
+  if (a_in.M <= 0 || a_in.n_tiles <= 0) return MMK_OK;
+  if (a_in.nseg < 1 || a_in.nseg > kMaxSeg) return fail(MMK_ERR_INVALID, "linear: bad segment count %d", a_in.nseg);
+  LinearArgs a = a_in;
+  for (int s = a.nseg; s < kMaxSeg; ++s) {  // unused segments alias segment 0 (never selected: chunk0 == k_chunks)
+    a.seg[s] = a.seg[0];
+    a.seg[s].K = 0;
+  }
+  for (int s = a.nseg; s <= kMaxSeg; ++s) a.seg_chunk0[s] = a.k_chunks;
   bool vec = true;
   for (int s = 0; s < a.nseg; ++s) vec = vec && seg_vec_ok(a.seg[s]);
-  int mt = a.M <= 16 ? 1 : (a.M <= 32 ? 2 : 4);
+  // latency-bound shapes (few tiles): one 16-row tile per workgroup to spread over more CUs;
+  // GEMM-like shapes: up to 64 rows per workgroup so a weight fragment is reused from registers
+  const int m_tiles = (a.M + 15) / 16;
+  int mt = 1;
+  if ((long)a.n_tiles * m_tiles > 512) mt = m_tiles >= 4 ? 4 : (m_tiles >= 2 ? 2 : 1);
   int nw = 1;
-  // aim for ~2 chunks (32 k-columns) per wave: the kernels are latency-, not issue-bound
-  while (nw < 16 && a.k_chunks >= nw * 4) nw *= 2;
+  while (nw < 16 && a.k_chunks > nw * 3) nw *= 2;  // <= 3 K-chunks (48 columns) per wave where possible
   dim3 grid(a.n_tiles, (a.M + mt * 16 - 1) / (mt * 16));
   dim3 block(64 * nw);
   size_t lds = nw > 1 ? (size_t)nw * mt * 64 * sizeof(f32x4) : 0;

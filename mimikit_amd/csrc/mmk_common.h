@@ -39,28 +39,46 @@ struct Addr {
   const void* base;
   int64_t slot_stride;
   int32_t offset;
-  int32_t div;
-  int32_t mod;
+  int32_t div;    // >= 1
+  int32_t mod;    // 0: no wrap
+  int32_t shift;  // log2(div) when div is a power of two, else -1
+  int32_t mask;   // mod - 1 when mod is a power of two, else -1
   int32_t pad_;
 };
 
-static inline Addr addr_static(const void* p) { return Addr{p, 0, 0, 1, 0, 0}; }
-static inline Addr addr_ring(const void* p, int64_t slot_stride, int32_t offset, int32_t mod) {
-  return Addr{p, slot_stride, offset, 1, mod, 0};
+static inline int32_t log2_exact(int32_t v) {
+  if (v <= 0 || (v & (v - 1))) return -1;
+  int32_t l = 0;
+  while ((1 << l) < v) ++l;
+  return l;
 }
 static inline Addr addr_time(const void* p, int64_t slot_stride, int32_t offset, int32_t div, int32_t mod) {
-  return Addr{p, slot_stride, offset, div, mod, 0};
+  Addr a;
+  a.base = p; a.slot_stride = slot_stride; a.offset = offset; a.div = div < 1 ? 1 : div; a.mod = mod;
+  a.shift = log2_exact(a.div);
+  a.mask = (mod > 0 && log2_exact(mod) >= 0) ? mod - 1 : -1;
+  a.pad_ = 0;
+  return a;
+}
+static inline Addr addr_static(const void* p) { return addr_time(p, 0, 0, 1, 0); }
+static inline Addr addr_ring(const void* p, int64_t slot_stride, int32_t offset, int32_t mod) {
+  return addr_time(p, slot_stride, offset, 1, mod);
 }
 
-__device__ __forceinline__ int64_t addr_elems(const Addr& a, int64_t tau) {
+// positions are < 2^31; everything here is 32-bit and, for power-of-two rings, shift/mask only
+__device__ __forceinline__ int64_t addr_elems(const Addr& a, int tau) {
   if (a.slot_stride == 0) return 0;
-  int64_t s = tau + a.offset;
-  if (a.div > 1) s /= a.div;
+  int s = tau + a.offset;
+  if (a.div > 1) s = a.shift >= 0 ? (s >> a.shift) : (int)((unsigned)(s < 0 ? 0 : s) / (unsigned)a.div);
   if (a.mod > 0) {
-    s %= a.mod;
-    if (s < 0) s += a.mod;  // positions before the start of a warm-up read (zeroed) slots
+    if (a.mask >= 0) {
+      s &= a.mask;  // two's complement: also right for positions before the start of a warm-up
+    } else {
+      s %= a.mod;
+      if (s < 0) s += a.mod;
+    }
   }
-  return s * a.slot_stride;
+  return (int64_t)s * a.slot_stride;
 }
 
 // ---- activations (match the torch CPU formulas the reference runs) ------------

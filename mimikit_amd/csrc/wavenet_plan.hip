@@ -111,7 +111,9 @@ static int derive(mmk_wavenet_plan* p) {
     if (p->ksz[l] + p->n_cond > kMaxSeg)
       return fail(MMK_ERR_UNSUPPORTED, "wavenet: kernel_size + n_cond = %d exceeds %d K-segments", p->ksz[l] + p->n_cond, kMaxSeg);
     const int cause = (p->ksz[l] - 1) * p->dil[l];  // WNLayer.cause, wavenet_v2.py:74
-    p->ring[l] = cause + 1;
+    int ring = 1;
+    while (ring < cause + 1) ring <<= 1;  // power-of-two queue: slot = position & (ring - 1)
+    p->ring[l] = ring;
     p->rf += cause;
     // has_residuals (:78) with input_dim == dims_dilated[0]; last layer built with residuals_dim=None (:216)
     p->has_res[l] = (l != p->L - 1) && c.residuals_dim != 0 && c.residuals_dim == p->C;
