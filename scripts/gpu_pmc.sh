@@ -1,13 +1,12 @@
 #!/bin/bash
-# separate PMC passes (no trace domains besides kernel-trace), short clip
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 WL=${WORKLOAD:-wavenet_cfg4}
 cd /tmp
 for C in FETCH_SIZE WRITE_SIZE; do
-  timeout 600 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $R/gpurun_out/pmc_${WL}_$C -- python3 $R/bench.py --workload $WL --steps 1 --warmup 0 --seconds ${PMC_SECONDS:-0.004} --no-cpu-baseline > $R/gpurun_out/pmc_${WL}_$C.log 2>&1
-  echo "pmc $C exit: $?"
+  timeout 600 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $R/gpurun_out/pmc_${WL}_$C -- python3 $R/scripts/pmc_target.py > $R/gpurun_out/pmc_${WL}_$C.log 2>&1
+  echo "pmc $C exit: $?"; tail -2 $R/gpurun_out/pmc_${WL}_$C.log
 done
 cd $R
 python scripts/pmc_summary.py gpurun_out/pmc_${WL}_FETCH_SIZE gpurun_out/pmc_${WL}_fetch_summary.csv | head -12

@@ -1,0 +1,28 @@
+"""Small eager (no hipGraph) run of the cfg4 step kernels, as a target for rocprofv3 --pmc."""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402
+
+torch.set_grad_enabled(False)
+
+
+class A:
+    workload = os.environ.get("WORKLOAD", "wavenet_cfg4")
+    clips = 0
+    seconds = 0.001
+
+
+job = bench.WaveNetJob(A, torch.device("cuda", 0), 0)
+job.to_device()
+p = job.prompt_len
+net = job.net
+net._ensure_plan(job.clips, refresh_weights=True)
+net._plan.warmup(job.idx, job.cond, p - 13, p - 1)          # 12 eager steps
+net._next_t, net._state_batch = p, job.clips
+net._plan.generate(job.idx, job.cond, p, 12)                # 12 eager steps with head
+torch.cuda.synchronize()
+print("done")
