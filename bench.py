@@ -115,6 +115,24 @@ class WaveNetJob:
         p = self.prompt_len
         net, plan = self.net, self.net._plan
         net.before_generate((self.idx[:, :p], *[c[:, :p] for c in self.cond]), None)
+        if plan.persistent:
+            # ONE kernel runs every step of a block: HIP events around its launches on the launch stream
+            n = min(self.n_steps, 1024)
+            torch.cuda.synchronize()
+            start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            start.record()
+            net.generate_block((self.idx, *self.cond), p, n)
+            stop.record()
+            torch.cuda.synchronize()
+            net.after_generate((self.idx,), None)
+            us = start.elapsed_time(stop) * 1e3
+            nbytes = self.step_bytes() * n
+            achieved = nbytes / (us * 1e-6) / 1e9
+            return {"bound": "hbm", "kernel": "wavenet_persist_kernel (all layers + head of every step of a block)",
+                    "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                    "algorithmic_bytes_per_launch": nbytes, "avg_launch_us": round(us, 1), "launches_timed": 1,
+                    "steps_per_launch": n, "us_per_step_in_kernel": round(us / n, 2)}
         stats = plan.profile_steps(self.idx, self.cond, p, 48)
         net.after_generate((self.idx,), None)
         c, B = plan.cfg, self.clips
@@ -129,10 +147,16 @@ class WaveNetJob:
         ms, launches = stats[name]
         dur_us = 1e3 * ms / max(launches, 1)
         achieved = per[name] / (dur_us * 1e-6) / 1e9
+        traffic = None
+        try:  # PMC-derived HBM bytes per launch, collected in separate rocprofv3 --pmc passes (profiles/)
+            with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+                traffic = json.load(f).get(self.name, {}).get(name, {}).get("bytes")
+        except (OSError, ValueError):
+            pass
         return {"bound": "hbm", "kernel": f"linear_kernel ({name}: " +
                 ("dilated taps + 1x1 cond + gate" if name == "layer_a" else "residual + skip 1x1") + ")",
                 "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                 "algorithmic_bytes_per_launch": per[name], "avg_launch_us": round(dur_us, 3),
                 "launches_timed": int(launches),
                 "per_class_avg_us": {n: round(1e3 * stats[n][0] / max(stats[n][1], 1), 3) for n in stats}}

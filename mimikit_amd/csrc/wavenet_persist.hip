@@ -1,0 +1,617 @@
+// Persistent WaveNet step kernel (gfx950): the whole `for t` loop of one generate call runs in ONE
+// launch.  Per-step work is a chain of 2*L + 4 tiny dependent GEMMs; as separate launches each
+// link costs >= 4-5 us of dispatch/drain on this chip (profiles/r01_v1_*), so the chain is kept
+// on-chip and the links become data-tagged hand-offs through L2:
+//
+//   * clips are split in Gc independent groups (<= 16 clips each = one MFMA row tile); groups never
+//     talk to each other;
+//   * inside a group, workgroup j of Gn owns ONE 16-row tile of every layer's packed weight
+//     matrices: tile j of A = [tap0 | tap1 | cond] (8 gated channels) and one tile of B = [res ; skip];
+//   * a layer is:  wait h_l -> z = W1.h_l + P0 + Wc.c + b -> gate -> publish y slice
+//                  (shadow work: P0' = W0.h_l stored for step tau+d)
+//                  wait y -> [res|skip] tile -> publish h_{l+1} slice / accumulate skip
+//                  (shadow work: Wc.c of the NEXT position for this layer)
+//     "publish" = 8-byte {epoch, value} granules written with agent-scope relaxed atomic stores
+//     (sc1), "wait" = every thread polls its own granules with agent-scope relaxed atomic loads
+//     until all tags match (cdna_hip_programming.md guideline 16, form R2: the data is the flag);
+//   * the dilated tap is kept as a per-workgroup ring of tap-0 PRODUCTS (16x16 floats per
+//     position) instead of a queue of full activations, so it is private, 16x smaller and its
+//     read is off the critical path;
+//   * head: skip sums -> fc0+Mish -> fc2 -> temperature/argmax|sample, three more hand-offs,
+//     the sampled class is written to the caller's int64 tensor and handed to every workgroup
+//     for the next step's embedding row.
+//
+// Same arithmetic as the launch path / the reference: fp32 MFMA fmaf chains, fixed reduction
+// order, so results are run-to-run deterministic.  Every spin is bounded; a timeout raises
+// err_flag and every workgroup leaves at its next hand-off.
+#include "wavenet_persist.h"
+
+namespace mmk {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned long long u64;
+
+constexpr int kPersistThreads = 512;   // upper bound; actual = 64 * nw
+constexpr unsigned kSpinLimit = 1u << 22;
+
+// XCD == false: agent-scope store (sc1, write-through to memory; readable from every XCD).
+// XCD == true : plain 8-byte store that stays in the producer's XCD L2; only used when every consumer
+//               of the granule was VERIFIED (at kernel start, from HW_REG_XCC_ID) to run on the same XCD,
+//               whose L2 is the coherence point for its CUs.  Consumers always load with sc1 (L1 bypass).
+template <bool XCD>
+__device__ __forceinline__ void gran_store(u64* p, unsigned epoch, float v) {
+  const u64 x = ((u64)epoch << 32) | (u64)__float_as_uint(v);
+  if (XCD)
+    __hip_atomic_store(p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  else
+    __hip_atomic_store(p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <bool XCD>
+__device__ __forceinline__ void gran_store_u32(u64* p, unsigned epoch, unsigned v) {
+  const u64 x = ((u64)epoch << 32) | (u64)v;
+  if (XCD)
+    __hip_atomic_store(p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  else
+    __hip_atomic_store(p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ u64 gran_load(const u64* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Poll `count` granules until every tag == epoch and write the values as floats into an LDS matrix
+// (`cols` values per row, leading dimension ld).  Each thread keeps up to four 8-byte loads in flight
+// per round, so a sweep whose data is already there costs ONE memory round trip.
+// Returns a workgroup-uniform success flag.
+__device__ __forceinline__ bool sweep(const u64* gran, int count, int cols, unsigned epoch, float* dst, int ld,
+                                      int* err_flag, int* s_fail) {
+  const int tid = threadIdx.x, nt = blockDim.x;
+  for (int base = 0; base < count; base += nt * 4) {
+    const int i0 = base + tid * 4;
+    if (i0 < count) {
+      const int n = min(4, count - i0);
+      u64 v[4];
+      unsigned spins = 0;
+      bool ok = true;
+      for (;;) {
+        bool all = true;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = k < n ? gran_load(gran + i0 + k) : ((u64)epoch << 32);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) all = all && ((unsigned)(v[k] >> 32) == epoch);
+        if (all) break;
+        ++spins;
+        if (spins > kSpinLimit || ((spins & 255u) == 0 && __hip_atomic_load(err_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+          ok = false;
+          break;
+        }
+        __builtin_amdgcn_s_sleep(1);
+      }
+      if (!ok) {
+        *s_fail = 1;
+        atomicExch(err_flag, 1);
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        if (k < n) {
+          const int m = (i0 + k) / cols, c = (i0 + k) - m * cols;
+          dst[m * ld + c] = __uint_as_float((unsigned)v[k]);
+        }
+      }
+    }
+  }
+  __syncthreads();
+  return *s_fail == 0;
+}
+
+// gate of the gated units with hardware exp/rcp: tanh(f) * sigmoid(g)   (wavenet_v2.py:151)
+// |error| ~1e-7 absolute, far inside the logit tolerance; keeps the critical-path epilogue short
+__device__ __forceinline__ float fast_sigmoid(float x) { return __frcp_rn(1.0f + __expf(-x)); }
+__device__ __forceinline__ float fast_tanh(float x) { return 1.0f - 2.0f * __frcp_rn(1.0f + __expf(2.0f * x)); }
+
+// one wave's share of  X[16 x K] (LDS, ld) . W^T  for a 16-column tile: chunks [c0, c1) after chunk_base
+__device__ __forceinline__ f32x4 tile_mma(const float* x, int ld, const f32x4* wp, int chunk_base, int c0, int c1,
+                                          int lane) {
+  f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int r = lane & 15, q = lane >> 4;
+  for (int c = c0; c < c1; ++c) {
+    const f32x4 w = wp[(int64_t)(chunk_base + c) * 64 + lane];
+    const f32x4 xv = *reinterpret_cast<const f32x4*>(x + r * ld + c * 16 + 4 * q);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[i], w[i], acc, 0, 0, 0);
+  }
+  return acc;
+}
+
+// same with the weight fragments already in registers (CPW chunks per wave, starting at chunk c0)
+template <int CPW>
+__device__ __forceinline__ f32x4 tile_mma_reg(const float* x, int ld, const f32x4 (&w)[CPW], int c0, int lane) {
+  f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int r = lane & 15, q = lane >> 4;
+#pragma unroll
+  for (int u = 0; u < CPW; ++u) {
+    const f32x4 xv = *reinterpret_cast<const f32x4*>(x + r * ld + (c0 + u) * 16 + 4 * q);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[i], w[u][i], acc, 0, 0, 0);
+  }
+  return acc;
+}
+
+// cross-wave reduction in fixed order; result valid in wave 0 only
+__device__ __forceinline__ f32x4 reduce_waves(f32x4 acc, f32x4* red, int wave, int lane, int nw) {
+  red[wave * 64 + lane] = acc;
+  __syncthreads();
+  f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (wave == 0) {
+    for (int w = 0; w < nw; ++w) {
+      const f32x4 p = red[w * 64 + lane];
+      v[0] += p[0]; v[1] += p[1]; v[2] += p[2]; v[3] += p[3];
+    }
+  }
+  __syncthreads();
+  return v;
+}
+
+template <int CPW, int NW, bool STAMPS, bool XCD>
+__global__ __launch_bounds__(kPersistThreads) void wavenet_persist_kernel(const WnPersistArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  constexpr int nw = NW;
+  int g = blockIdx.x / a.Gn;          // clip group
+  int j = blockIdx.x % a.Gn;          // tile owner inside the group
+  if (XCD) {
+    // Roles follow the hardware: group = the XCD this workgroup actually runs on, owner index = arrival
+    // order on that XCD.  Every workgroup registers, waits for all registrations, and the launch only
+    // proceeds if each of the 8 XCDs hosts exactly Gn workgroups; otherwise err_flag = 2 and everyone
+    // leaves (the host then falls back to agent-scope hand-offs).  Placement is verified, never assumed.
+    int* role = reinterpret_cast<int*>(smem_raw);
+    if (tid == 0) {
+      unsigned xcc;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+      xcc &= 0xfu;
+      const unsigned mine = atomicAdd(&a.xcd_count[xcc & 7u], 1u);
+      atomicAdd(&a.xcd_count[8], 1u);
+      unsigned spins = 0;
+      bool ok = xcc < 8u;
+      while (__hip_atomic_load(&a.xcd_count[8], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gridDim.x) {
+        if (++spins > kSpinLimit) { ok = false; break; }
+        __builtin_amdgcn_s_sleep(2);
+      }
+      for (int x = 0; x < 8 && ok; ++x)
+        ok = __hip_atomic_load(&a.xcd_count[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)a.Gn;
+      if (!ok) atomicExch(a.err_flag, 2);
+      role[0] = ok ? (int)xcc : -1;
+      role[1] = (int)mine;
+    }
+    __syncthreads();
+    g = role[0];
+    j = role[1];
+    __syncthreads();
+    if (g < 0) return;
+  }
+  const int C = a.C, L = a.L;
+  const int m_first = g * a.Mg;
+  const int mg = min(a.Mg, a.B - m_first);   // clips of this group
+  if (mg <= 0) return;
+
+  // ---- LDS carve (all dynamic, 16-byte aligned pieces) -----------------------------------
+  const int wide = max(max(C, a.S), a.H1);
+  const int ldh = C + 4, ldy = wide + 4, ldc = a.C1 + 4, ldl = a.n_logits_pad + 4;
+  char* sp = smem_raw;
+  float* hbuf = (float*)sp;  sp += 16 * ldh * 4;                          // layer input, rows = clips
+  float* ybuf = (float*)sp;  sp += 16 * ldy * 4;                          // gated output / skip sums / hidden
+  float* cbuf = (float*)sp;  sp += 16 * (a.C1 > 0 ? ldc : 4) * 4;         // projected cond row of the NEXT position
+  f32x4* red = (f32x4*)sp;   sp += 4 * nw * 64 * 16;                      // split-K partials: [A | P0 | B | cond][nw][64]
+  f32x4* condp = (f32x4*)sp; sp += (a.C1 > 0 ? L : 1) * 64 * 16;          // Wc.c per layer (D-fragment layout)
+  const float** lt_A = (const float**)sp; sp += L * 8;                    // per-layer table, copied once
+  const float** lt_B = (const float**)sp; sp += L * 8;
+  int64_t* lt_off = (int64_t*)sp;         sp += L * 8;
+  int* lt_i = (int*)sp;                   sp += ((L * 4 * 4 + 15) / 16) * 16;   // dil, mask, has_res, btile
+  float* biasA = (float*)sp;              sp += L * 16 * 4;
+  float* biasB = (float*)sp;              sp += L * 16 * 4;
+  int* s_idx = (int*)sp;     sp += 16 * 4;
+  int* s_fail = (int*)sp;    sp += 16;
+  float* lbuf = (float*)sp;                                               // logits for the sampler (owner 0 only)
+  f32x4* redA = red, *redP = red + nw * 64, *redB = red + 2 * nw * 64, *redC = red + 3 * nw * 64;
+
+  const int kcC = C / 16;                 // K-chunks of one tap / of B
+  const int kcC1 = a.C1 / 16;
+  const int kcA = a.kcA;                  // chunks per A tile: 2*kcC + kcC1
+  const int c0 = wave * CPW;              // this wave's chunk range inside a K = C product
+  const int D_q = lane >> 4, D_n = lane & 15;
+  const bool owns_res = j < kcC;          // owners [0, C/16) hold residual rows of B, the others skip rows
+  const int cond_per = kcC1 > 0 ? (kcC1 + nw - 1) / nw : 0;
+  const int cc0 = min(wave * cond_per, kcC1), cc1 = min(cc0 + cond_per, kcC1);
+  const bool cond_reg = kcC1 == kcC;      // conditioning width == C: its fragments ride in registers like the taps
+
+  for (int i = tid; i < 16 * ldh; i += blockDim.x) hbuf[i] = 0.f;
+  for (int i = tid; i < 16 * ldy; i += blockDim.x) ybuf[i] = 0.f;
+  if (a.C1 > 0)
+    for (int i = tid; i < 16 * ldc; i += blockDim.x) cbuf[i] = 0.f;
+  if (j == 0)
+    for (int i = tid; i < 16 * ldl; i += blockDim.x) lbuf[i] = 0.f;
+  for (int l = tid; l < L; l += blockDim.x) {
+    const WnLayerTab t = a.layers[l];
+    const int btile = owns_res ? j : (j - kcC + (t.has_res ? kcC : 0));
+    lt_A[l] = t.A_wp;
+    lt_B[l] = t.B_wp;
+    lt_off[l] = t.p0_offset;
+    lt_i[4 * l + 0] = t.dil;
+    lt_i[4 * l + 1] = t.p0_mask;
+    lt_i[4 * l + 2] = t.has_res;
+    lt_i[4 * l + 3] = btile;
+  }
+  for (int i = tid; i < L * 16; i += blockDim.x) {
+    const int l = i >> 4, n = i & 15;
+    const WnLayerTab t = a.layers[l];
+    const int btile = owns_res ? j : (j - kcC + (t.has_res ? kcC : 0));
+    biasA[i] = t.A_bias ? t.A_bias[j * 16 + n] : 0.f;
+    biasB[i] = (t.B_bias && (!owns_res || t.has_res)) ? t.B_bias[btile * 16 + n] : 0.f;
+  }
+  if (tid == 0) *s_fail = 0;
+  __syncthreads();
+
+  // ---- per-group exchange buffers, per-workgroup private ring ---------------------------------
+  u64* gran_h = a.gran_h + (int64_t)g * 16 * C;
+  u64* gran_y0 = a.gran_y + (int64_t)g * 2 * 16 * C;
+  u64* gran_skip = a.gran_skip + (int64_t)g * 16 * a.S;
+  u64* gran_hid = a.gran_hid + (int64_t)g * 16 * a.H1;
+  u64* gran_logit = a.gran_logit + (int64_t)g * 16 * a.n_logits_pad;
+  u64* gran_idx = a.gran_idx + (int64_t)g * 16;
+  float* p0_ring = a.p0_rings + (int64_t)(g * a.Gn + j) * a.p0_floats_per_wg;   // follows the ROLE, not the block id
+  int* err = a.err_flag;
+
+  // weight fragments: current layer and (prefetched one layer ahead) next layer
+  f32x4 w_t1[CPW], w_t0[CPW], w_b[CPW], w_c[CPW];
+  f32x4 n_t1[CPW], n_t0[CPW], n_b[CPW], n_c[CPW];
+  auto load_A = [&](int l, f32x4 (&t1)[CPW], f32x4 (&t0)[CPW]) {
+    const f32x4* A = reinterpret_cast<const f32x4*>(lt_A[l]) + (int64_t)j * kcA * 64 + lane;
+#pragma unroll
+    for (int u = 0; u < CPW; ++u) {
+      t0[u] = A[(int64_t)(c0 + u) * 64];
+      t1[u] = A[(int64_t)(kcC + c0 + u) * 64];
+    }
+  };
+  auto load_B = [&](int l, f32x4 (&b)[CPW], f32x4 (&c)[CPW]) {
+    if (!owns_res || lt_i[4 * l + 2]) {   // B of layer l: [res rows (if the layer has a residual conv) ; skip rows]
+      const f32x4* Bm = reinterpret_cast<const f32x4*>(lt_B[l]) + (int64_t)lt_i[4 * l + 3] * kcC * 64 + lane;
+#pragma unroll
+      for (int u = 0; u < CPW; ++u) b[u] = Bm[(int64_t)(c0 + u) * 64];
+    }
+    if (cond_reg) {
+      const f32x4* A = reinterpret_cast<const f32x4*>(lt_A[l]) + (int64_t)j * kcA * 64 + lane;
+#pragma unroll
+      for (int u = 0; u < CPW; ++u) c[u] = A[(int64_t)(2 * kcC + c0 + u) * 64];
+    }
+  };
+  // Epilogues run one output ELEMENT per thread: element e = (clip m, column n) of the 16x16 tile for
+  // e < mg*16, so only real clips cost transcendental work and it is spread over mg/4 waves.  `frag` is
+  // the element's float index inside a 64-lane x 4-register MFMA accumulator image.
+  const bool elem = tid < mg * 16;
+  const int e_m = tid >> 4, e_n = tid & 15;
+  const int frag = ((e_m >> 2) * 16 + e_n) * 4 + (e_m & 3);
+  auto sum_partials = [&](const f32x4* part) -> float {
+    const float* f = reinterpret_cast<const float*>(part) + frag;
+    float v = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) v += f[w * 256];
+    return v;
+  };
+  auto load_p0 = [&](int l, int64_t tau) -> float {   // tap-0 product of position tau - d (zeros before the warm-up start)
+    const float* ring = p0_ring + lt_off[l];
+    return ring[(int64_t)((tau - lt_i[4 * l]) & lt_i[4 * l + 1]) * 256 + frag];
+  };
+  auto load_cond_row = [&](int64_t pos) {     // cbuf <- c[:, pos, :]
+    for (int i = tid; i < mg * a.C1; i += blockDim.x) {
+      const int m = i / a.C1, c = i - m * a.C1;
+      cbuf[m * ldc + c] = a.cproj[((int64_t)(m_first + m) * a.cproj_steps + (pos - a.cproj_t0)) * a.C1 + c];
+    }
+    __syncthreads();
+  };
+  auto cond_product = [&](int l) {            // condp[l] <- Wc_l[tile j] . cbuf   (prologue only)
+    const f32x4* A = reinterpret_cast<const f32x4*>(lt_A[l]) + (int64_t)j * kcA * 64;
+    f32x4 v = reduce_waves(tile_mma(cbuf, ldc, A, 2 * kcC, cc0, cc1, lane), redA, wave, lane, nw);
+    if (wave == 0) condp[l * 64 + lane] = v;
+  };
+
+  // diagnostic build only: 100 MHz wall-clock stamps of the phases of owner 1 of group 0, summed over steps and layers
+  unsigned long long st_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long st_prev = 0;
+  auto stamp = [&](int slot) {
+    if (STAMPS) {
+      const unsigned long long now = wall_clock64();
+      st_acc[slot] += now - st_prev;
+      st_prev = now;
+    }
+  };
+  const unsigned long long clk_start = STAMPS ? clock64() : 0, wall_start = STAMPS ? wall_clock64() : 0;
+  float skipacc = 0.f;                           // element threads of skip-row owners
+  const int64_t tau0 = a.t0 - 1;
+  float* condp_f = reinterpret_cast<float*>(condp);
+
+  if (a.C1 > 0) {   // prologue: conditioning products of the first position, all layers
+    load_cond_row(tau0);
+    for (int l = 0; l < L; ++l) cond_product(l);
+    __syncthreads();
+  }
+
+  for (int64_t s = 0; s < a.n_steps; ++s) {
+    const int64_t tau = tau0 + s;
+    const bool more = (s + 1) < a.n_steps;
+    // ---- input 0: embedding row of the newest sample ---------------------------------------
+    if (s > 0 && !a.teacher_forced) {
+      // classes sampled by the previous step arrive as granules (epoch = s)
+      if (tid < mg) {
+        unsigned spins = 0;
+        u64 v;
+        for (;;) {
+          v = gran_load(gran_idx + tid);
+          if ((unsigned)(v >> 32) == (unsigned)s) break;
+          ++spins;
+          if (spins > kSpinLimit || ((spins & 255u) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+            *s_fail = 1;
+            atomicExch(err, 1);
+            break;
+          }
+          __builtin_amdgcn_s_sleep(1);
+        }
+        s_idx[tid] = (int)(unsigned)v;
+      }
+    } else {
+      if (tid < mg) s_idx[tid] = (int)a.idx[(int64_t)(m_first + tid) * a.idx_rs + tau];
+    }
+    __syncthreads();
+    if (*s_fail) return;
+    // weights and tap-0 product of layer 0 go in flight under the embedding gather
+    load_A(0, w_t1, w_t0);
+    load_B(0, w_b, w_c);
+    float p0 = 0.f, p0n = 0.f;
+    if (elem) p0 = load_p0(0, tau);
+    for (int i = tid; i < mg * C; i += blockDim.x) {
+      const int m = i / C, c = i - m * C;
+      const int cls = s_idx[m];
+      // torch raises on an out-of-range class; keep memory safe and make it visible (NaN row)
+      hbuf[m * ldh + c] = (cls >= 0 && cls < a.q_levels) ? a.emb[(int64_t)cls * C + c] : __builtin_nanf("");
+    }
+    if (a.C1 > 0 && more) load_cond_row(tau + 1); else __syncthreads();
+    if (STAMPS) st_prev = wall_clock64();
+
+    for (int l = 0; l < L; ++l) {
+      const unsigned epoch = (unsigned)(s * L + l + 1);
+      const bool last = (l + 1 == L);
+      const bool has_b = !owns_res || lt_i[4 * l + 2];
+      const bool do_cond = a.C1 > 0 && more;
+      // ---- phase A (critical): z = W1.h + P0 + cond + b ; gate ; publish y ---------------------
+      redA[wave * 64 + lane] = tile_mma_reg<CPW>(hbuf, ldh, w_t1, c0, lane);
+      __syncthreads();
+      u64* gran_y = gran_y0 + (int64_t)(l & 1) * 16 * C;
+      if (elem) {
+        const float f = sum_partials(redA) + p0 + (a.C1 > 0 ? condp_f[l * 256 + frag] : 0.f) + biasA[l * 16 + e_n];
+        // even columns hold f, odd columns g of the same channel: one transcendental per thread
+        const float act = (e_n & 1) ? fast_sigmoid(f) : fast_tanh(f);
+        const float other = __shfl_down(act, 1);
+        if (!(e_n & 1)) gran_store<XCD>(gran_y + e_m * C + j * 8 + (e_n >> 1), epoch, act * other);
+      }
+      stamp(0);   // phase A
+      // ---- shadow of the wait for y: tap-0 product of THIS position, consumed at step tau + d ----
+      redP[wave * 64 + lane] = tile_mma_reg<CPW>(hbuf, ldh, w_t0, c0, lane);
+      // next layer's tap weights go in flight only now (hipcc waits vmcnt(0) in front of MFMAs, so
+      // an earlier prefetch would put a memory round trip on the critical path)
+      if (!last) load_A(l + 1, n_t1, n_t0);
+      __syncthreads();
+      if (elem) {
+        float* ring = p0_ring + lt_off[l];
+        ring[(int64_t)(tau & lt_i[4 * l + 1]) * 256 + frag] = sum_partials(redP);
+      }
+      stamp(1);   // shadow tap-0
+      // ---- phase B (critical): wait y ; [res | skip] tile ----------------------------------------
+      if (has_b) {
+        if (!sweep(gran_y, mg * C, C, epoch, ybuf, ldy, err, s_fail)) return;
+        stamp(2);   // wait y
+        redB[wave * 64 + lane] = tile_mma_reg<CPW>(ybuf, ldy, w_b, c0, lane);
+        __syncthreads();
+        if (elem) {
+          const float vb = sum_partials(redB) + biasB[l * 16 + e_n];
+          if (owns_res)
+            gran_store<XCD>(gran_h + e_m * C + j * 16 + e_n, epoch, hbuf[e_m * ldh + j * 16 + e_n] + vb);
+          else
+            skipacc = (l == 0) ? vb : vb + skipacc;
+        }
+      }
+      stamp(3);   // phase B
+      // ---- shadow of the wait for h': Wc.c of the NEXT position for this layer -------------------
+      if (do_cond) {
+        if (cond_reg) {
+          redC[wave * 64 + lane] = tile_mma_reg<CPW>(cbuf, ldc, w_c, c0, lane);
+        } else {
+          const f32x4* A = reinterpret_cast<const f32x4*>(lt_A[l]) + (int64_t)j * kcA * 64;
+          redC[wave * 64 + lane] = tile_mma(cbuf, ldc, A, 2 * kcC, cc0, cc1, lane);
+        }
+      }
+      // next layer's B / cond fragments and tap-0 product go in flight now (absorbed by the wait for h')
+      if (!last) {
+        load_B(l + 1, n_b, n_c);
+        if (elem) p0n = load_p0(l + 1, tau);
+      }
+      __syncthreads();
+      if (elem && do_cond) condp_f[l * 256 + frag] = sum_partials(redC);   // this layer's current product was consumed in phase A
+      stamp(4);   // shadow cond
+      // ---- wait for the next layer's input -----------------------------------------------------
+      if (!last) {
+        if (!sweep(gran_h, mg * C, C, epoch, hbuf, ldh, err, s_fail)) return;
+#pragma unroll
+        for (int u = 0; u < CPW; ++u) { w_t1[u] = n_t1[u]; w_t0[u] = n_t0[u]; w_b[u] = n_b[u]; w_c[u] = n_c[u]; }
+        p0 = p0n;
+      }
+      stamp(5);   // wait h'
+    }
+    if (a.teacher_forced) { __syncthreads(); continue; }
+
+    // ---- head -----------------------------------------------------------------------------------
+    const unsigned he = (unsigned)(s + 1);
+    if (elem && !owns_res) gran_store<XCD>(gran_skip + e_m * a.S + (j - kcC) * 16 + e_n, he, skipacc);
+    // fc0 + Mish : tiles j, j+Gn, ... of H1/16
+    const int t_fc0 = a.H1 / 16, kc_fc0 = a.S / 16;
+    if (j < t_fc0) {
+      if (!sweep(gran_skip, mg * a.S, a.S, he, ybuf, ldy, err, s_fail)) return;
+      const int per = (kc_fc0 + nw - 1) / nw;
+      const int k0 = min(wave * per, kc_fc0), k1 = min(k0 + per, kc_fc0);
+      for (int t = j; t < t_fc0; t += a.Gn) {
+        const f32x4* W = reinterpret_cast<const f32x4*>(a.fc0_wp) + (int64_t)t * kc_fc0 * 64;
+        f32x4 v = reduce_waves(tile_mma(ybuf, ldy, W, 0, k0, k1, lane), redA, wave, lane, nw);
+        if (wave == 0) {
+          const float bias = a.fc0_bias[t * 16 + D_n];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int m = 4 * D_q + r;
+            if (m < mg) gran_store<XCD>(gran_hid + m * a.H1 + t * 16 + D_n, he, mishf_(v[r] + bias));
+          }
+        }
+      }
+    }
+    // fc2 : tiles of the (n_classes + temperature column) outputs
+    const int t_fc2 = a.n_logits_pad / 16, kc_fc2 = a.H1 / 16;
+    if (j < t_fc2) {
+      if (!sweep(gran_hid, mg * a.H1, a.H1, he, ybuf, ldy, err, s_fail)) return;
+      const int per = (kc_fc2 + nw - 1) / nw;
+      const int k0 = min(wave * per, kc_fc2), k1 = min(k0 + per, kc_fc2);
+      for (int t = j; t < t_fc2; t += a.Gn) {
+        const f32x4* W = reinterpret_cast<const f32x4*>(a.fc2_wp) + (int64_t)t * kc_fc2 * 64;
+        f32x4 v = reduce_waves(tile_mma(ybuf, ldy, W, 0, k0, k1, lane), redA, wave, lane, nw);
+        if (wave == 0) {
+          const float bias = a.fc2_bias[t * 16 + D_n];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int m = 4 * D_q + r;
+            if (m < mg) gran_store<XCD>(gran_logit + m * a.n_logits_pad + t * 16 + D_n, he, v[r] + bias);
+          }
+        }
+      }
+    }
+    // temperature column + argmax / inverse-CDF sample : owner 0 of the group, one clip per wave
+    if (j == 0) {
+      if (!sweep(gran_logit, mg * a.n_logits_pad, a.n_logits_pad, he, lbuf, ldl, err, s_fail)) return;
+      const int nc = a.n_classes;
+      const int per = (nc + 63) / 64;
+      for (int m = wave; m < mg; m += nw) {
+        const float* lg = lbuf + m * ldl;
+        const int clip = m_first + m;
+        if (a.logits_out)
+          for (int c = lane; c < nc + a.learn_temp; c += 64) a.logits_out[(int64_t)clip * a.logits_ld + c] = lg[c];
+        float denom = 1.f;
+        if (a.learn_temp) denom = fmaxf(sigmoidf_(lg[nc]), a.min_temp);   // mlp.py:60-62
+        int result;
+        if (a.temperature == nullptr) {
+          float best = -INFINITY;
+          int bi = 0x7fffffff;
+          for (int q = 0; q < per; ++q) {
+            const int c = lane * per + q;
+            if (c < nc) {
+              const float v = a.learn_temp ? lg[c] / denom : lg[c];
+              if (v > best || bi == 0x7fffffff) { best = v; bi = c; }
+            }
+          }
+#pragma unroll
+          for (int o = 32; o > 0; o >>= 1) {
+            const float ob = __shfl_xor(best, o);
+            const int oi = __shfl_xor(bi, o);
+            if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+          }
+          result = bi;
+        } else {
+          const float T = a.temperature[clip];
+          float mx = -INFINITY;
+          for (int q = 0; q < per; ++q) {
+            const int c = lane * per + q;
+            if (c < nc) mx = fmaxf(mx, (a.learn_temp ? lg[c] / denom : lg[c]) / T);
+          }
+#pragma unroll
+          for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+          float local = 0.f;
+          for (int q = 0; q < per; ++q) {
+            const int c = lane * per + q;
+            if (c < nc) local += expf((a.learn_temp ? lg[c] / denom : lg[c]) / T - mx);
+          }
+          float incl = local;
+#pragma unroll
+          for (int o = 1; o < 64; o <<= 1) {
+            const float up = __shfl_up(incl, o);
+            if (lane >= o) incl += up;
+          }
+          const float total = __shfl(incl, 63);
+          const float target = a.uniforms[(int64_t)clip * a.uni_ld + s] * total;
+          float run = incl - local;
+          int pick = 0x7fffffff, last_c = -1;
+          for (int q = 0; q < per; ++q) {
+            const int c = lane * per + q;
+            if (c < nc) {
+              const float e = expf((a.learn_temp ? lg[c] / denom : lg[c]) / T - mx);
+              run += e;
+              if (e > 0.f) last_c = c;
+              if (pick == 0x7fffffff && run > target && e > 0.f) pick = c;
+            }
+          }
+#pragma unroll
+          for (int o = 32; o > 0; o >>= 1) {
+            const int op = __shfl_xor(pick, o), ol = __shfl_xor(last_c, o);
+            pick = op < pick ? op : pick;
+            last_c = ol > last_c ? ol : last_c;
+          }
+          result = pick != 0x7fffffff ? pick : (last_c < 0 ? 0 : last_c);
+        }
+        if (lane == 0) {
+          a.idx[(int64_t)clip * a.idx_rs + tau + 1] = result;
+          gran_store_u32<XCD>(gran_idx + m, he, (unsigned)result);
+        }
+      }
+    }
+    __syncthreads();
+    stamp(6);     // head (as seen by this workgroup)
+  }
+  if (STAMPS && a.stamps && g == 0 && j == 1 && tid == 0) {
+    st_acc[12] = clock64() - clk_start;        // shader cycles
+    st_acc[13] = wall_clock64() - wall_start;  // 100 MHz ticks
+    for (int i = 0; i < 16; ++i) a.stamps[i] = st_acc[i];
+  }
+}
+
+size_t wn_persist_lds_bytes(const WnPersistArgs& a, int nw) {
+  const int wide = a.C > a.S ? (a.C > a.H1 ? a.C : a.H1) : (a.S > a.H1 ? a.S : a.H1);
+  const int ldh = a.C + 4, ldy = wide + 4, ldc = a.C1 + 4, ldl = a.n_logits_pad + 4;
+  return (size_t)16 * ldh * 4 + (size_t)16 * ldy * 4 + (size_t)16 * (a.C1 > 0 ? ldc : 4) * 4 + (size_t)4 * nw * 64 * 16 +
+         (size_t)(a.C1 > 0 ? a.L : 1) * 64 * 16 + (size_t)a.L * 24 + (size_t)((a.L * 16 + 15) / 16) * 16 +
+         (size_t)a.L * 128 + 16 * 4 + 16 + (size_t)16 * ldl * 4;
+}
+
+int launch_wavenet_persist(const WnPersistArgs& a, hipStream_t stream) {
+  const int nw = a.C / 32;  // two K-chunks of a K = C product per wave
+  if (nw < 1 || nw > 8 || a.C % 32) return fail(MMK_ERR_UNSUPPORTED, "persistent WaveNet: C=%d not in {32..256 step 32}", a.C);
+  const size_t lds = wn_persist_lds_bytes(a, nw);
+  if (lds > 160 * 1024) return fail(MMK_ERR_UNSUPPORTED, "persistent WaveNet: %zu bytes of LDS needed", lds);
+  dim3 grid(a.Gc * a.Gn), block(64 * nw);
+#define MMK_WNP(NW_)                                                                                        \
+  do {                                                                                                    \
+    if (a.stamps) {                                                                                       \
+      if (a.xcd_local) hipLaunchKernelGGL((wavenet_persist_kernel<2, NW_, true, true>), grid, block, lds, stream, a);   \
+      else hipLaunchKernelGGL((wavenet_persist_kernel<2, NW_, true, false>), grid, block, lds, stream, a);              \
+    } else {                                                                                              \
+      if (a.xcd_local) hipLaunchKernelGGL((wavenet_persist_kernel<2, NW_, false, true>), grid, block, lds, stream, a);  \
+      else hipLaunchKernelGGL((wavenet_persist_kernel<2, NW_, false, false>), grid, block, lds, stream, a);             \
+    }                                                                                                     \
+  } while (0)
+  switch (nw) {
+    case 1: MMK_WNP(1); break;
+    case 2: MMK_WNP(2); break;
+    case 3: MMK_WNP(3); break;
+    case 4: MMK_WNP(4); break;
+    case 5: MMK_WNP(5); break;
+    case 6: MMK_WNP(6); break;
+    case 7: MMK_WNP(7); break;
+    default: MMK_WNP(8); break;
+  }
+#undef MMK_WNP
+  MMK_HIP(hipGetLastError());
+  return MMK_OK;
+}
+
+}  // namespace mmk

@@ -9,7 +9,10 @@
 //   y   = tanh(z_f) * sigmoid(z_g)                                               (:151)
 //   skp = Wskip . y + b (+ skp) ; h_{l+1}[tau] = h_l[tau] + Wres . y + b         (:165-176)
 // which is the same arithmetic on the same operands as the window form.
+#include <stdlib.h>
+
 #include "plan_util.h"
+#include "wavenet_persist.h"
 
 using namespace mmk;
 
@@ -51,6 +54,41 @@ struct mmk_wavenet_plan {
   hipStream_t cap_stream = nullptr;
   GraphCache gc;
 
+  // persistent-kernel mode (wavenet_persist.hip): chosen at create time when the geometry allows it
+  bool persistent = false;
+  int Gc = 0, Gn = 0, Mg = 0, C1 = 0, n_logits_pad = 0;
+  static constexpr int kCondBlock = 1024;       // positions whose conditioning is projected per launch
+  std::vector<int64_t> p0_offset;
+  std::vector<int> p0_mask;
+  int64_t p0_floats_per_wg = 0;
+  WnLayerTab* layer_tab = nullptr;
+  unsigned long long *gran_h = nullptr, *gran_y = nullptr, *gran_skip = nullptr, *gran_hid = nullptr,
+                     *gran_logit = nullptr, *gran_idx = nullptr;
+  int64_t gran_words = 0;       // contiguous block [gran_h .. gran_idx] + err word, zeroed before every launch
+  float* p0_rings = nullptr;
+  float* cproj = nullptr;
+  int32_t* err_flag = nullptr;
+  unsigned* xcd_count = nullptr;
+  bool xcd_local = false;       // one clip group per XCD, hand-offs through the XCD's L2 (verified in-kernel)
+
+  void layout_persistent(Carver& c) {
+    layer_tab = c.take<WnLayerTab>(L);
+    const int64_t n_h = (int64_t)Gc * 16 * C, n_y = 2 * n_h, n_s = (int64_t)Gc * 16 * S,
+                  n_hid = (int64_t)Gc * 16 * cfg.mlp_hidden, n_l = (int64_t)Gc * 16 * n_logits_pad, n_i = (int64_t)Gc * 16;
+    gran_words = n_h + n_y + n_s + n_hid + n_l + n_i + 8 + 2;   // + XCD registration counters + sticky error word
+    unsigned long long* base = c.take<unsigned long long>(gran_words);
+    gran_h = base;
+    gran_y = gran_h + (base ? n_h : 0);
+    gran_skip = gran_y + (base ? n_y : 0);
+    gran_hid = gran_skip + (base ? n_s : 0);
+    gran_logit = gran_hid + (base ? n_hid : 0);
+    gran_idx = gran_logit + (base ? n_l : 0);
+    xcd_count = reinterpret_cast<unsigned*>(gran_idx + (base ? n_i : 0));
+    err_flag = reinterpret_cast<int32_t*>(gran_idx + (base ? n_i + 8 : 0));
+    p0_rings = c.take<float>((int64_t)Gc * Gn * p0_floats_per_wg);
+    cproj = C1 > 0 ? c.take<float>((int64_t)Bmax * kCondBlock * C1) : nullptr;
+  }
+
   void layout(Carver& c) {
     const bool bias = cfg.bias != 0;
     if (cfg.q_levels == 0) in0_lin.carve(c, true);
@@ -72,6 +110,7 @@ struct mmk_wavenet_plan {
     logits_ld = (int)round_up(cfg.out_dim + (cfg.learn_temp ? 1 : 0), 4);
     logits = c.take<float>((int64_t)Bmax * logits_ld);
     tau = c.take<int64_t>(32);
+    if (persistent) layout_persistent(c);
   }
 
   Addr hist_slot(int l, int offset) const {
@@ -154,6 +193,58 @@ static int derive(mmk_wavenet_plan* p) {
     PackedLinear only;
     only.set_geometry(c.out_dim, {p->head_in});
     p->mlp.push_back(only);
+  }
+
+  // ---- persistent-kernel mode: one launch for all steps (wavenet_persist.hip) -------------------
+  // Geometry it covers: gated k=2 layers, embedding input, MLP head without extra hidden layers,
+  // C = skips = residuals in {32..256 step 32}, at most one conditioning input of a multiple of 16
+  // channels.  Anything else stays on the per-layer launch path.
+  const char* env = getenv("MMK_WN_PERSISTENT");
+  bool ok = !(env && env[0] == '0');
+  ok = ok && c.gated && c.q_levels > 0 && c.head_kind == 0 && c.mlp_n_hidden == 0 && c.n_cond <= 1;
+  ok = ok && p->C % 32 == 0 && p->C <= 256 && p->S == p->C && c.residuals_dim == p->C;
+  ok = ok && c.mlp_hidden % 16 == 0 && c.mlp_hidden >= 16;
+  if (c.n_cond == 1) ok = ok && c.cond_dim[0] % 16 == 0;
+  for (int l = 0; l < p->L; ++l) ok = ok && p->ksz[l] == 2;
+  p->persistent = false;
+  if (ok) {
+    p->Gn = 2 * p->C / 16;
+    int gc_max = 256 / p->Gn;
+    if (gc_max < 1) gc_max = 1;
+    // clips per group: one MFMA row tile (16) at most, and one epilogue element per thread
+    // (16 columns x Mg clips <= 64 * C/32 threads)
+    const int mg_cap = 16 < 4 * (p->C / 32) ? 16 : 4 * (p->C / 32);
+    int gc = (p->Bmax + 7) / 8;                      // aim at 8 clips per group
+    const char* genv = getenv("MMK_WN_GROUPS");
+    if (genv && atoi(genv) > 0) gc = atoi(genv);
+    if (gc < (p->Bmax + mg_cap - 1) / mg_cap) gc = (p->Bmax + mg_cap - 1) / mg_cap;
+    if (gc > gc_max) gc = gc_max;
+    if (gc > p->Bmax) gc = p->Bmax;
+    p->Mg = (p->Bmax + gc - 1) / gc;
+    p->Gc = (p->Bmax + p->Mg - 1) / p->Mg;
+    // XCD-local mode: always 8 groups (one per XCD, some possibly without clips), 8 * Gn workgroups
+    const char* xenv = getenv("MMK_WN_XCD_LOCAL");
+    p->xcd_local = !(xenv && xenv[0] == '0') && 8 * p->Gn <= 256 && (p->Bmax + 7) / 8 <= mg_cap;
+    if (p->xcd_local) {
+      p->Gc = 8;
+      p->Mg = (p->Bmax + 7) / 8;
+    }
+    p->C1 = c.n_cond == 1 ? c.cond_dim[0] : 0;
+    p->n_logits_pad = (int)round_up(c.out_dim + (c.learn_temp ? 1 : 0), 16);
+    if (p->Mg <= mg_cap) {
+      p->persistent = true;
+      p->p0_offset.assign(p->L, 0);
+      p->p0_mask.assign(p->L, 0);
+      int64_t off = 0;
+      for (int l = 0; l < p->L; ++l) {
+        int ring = 1;
+        while (ring < p->dil[l] + 1) ring <<= 1;
+        p->p0_offset[l] = off;
+        p->p0_mask[l] = ring - 1;
+        off += (int64_t)ring * 256;               // 16 x 16 floats per position
+      }
+      p->p0_floats_per_wg = off;
+    }
   }
   return MMK_OK;
 }
@@ -323,6 +414,22 @@ extern "C" int mmk_wavenet_commit(mmk_wavenet_plan* p, void* workspace, size_t w
     if (bb) MMK_TRY(pack_bias(m.bias, 0, 1, m.N, bb, 0, st));
   }
   if (!b.missing().empty()) return fail(MMK_ERR_KEY, "wavenet_commit: state_dict tensor %s", b.missing().c_str());
+  if (p->persistent) {
+    std::vector<WnLayerTab> tab(L);
+    for (int l = 0; l < L; ++l) {
+      tab[l].dil = p->dil[l];
+      tab[l].has_res = p->has_res[l] ? 1 : 0;
+      tab[l].p0_mask = p->p0_mask[l];
+      tab[l].pad_ = 0;
+      tab[l].p0_offset = p->p0_offset[l];
+      tab[l].A_wp = p->A[l].Wp;
+      tab[l].A_bias = p->A[l].bias;
+      tab[l].B_wp = p->Bm[l].Wp;
+      tab[l].B_bias = p->Bm[l].bias;
+    }
+    MMK_HIP(hipMemcpyAsync(p->layer_tab, tab.data(), sizeof(WnLayerTab) * L, hipMemcpyHostToDevice, st));
+    MMK_HIP(hipStreamSynchronize(st));   // `tab` is host-local
+  }
   if (!p->cap_stream) MMK_HIP(hipStreamCreateWithFlags(&p->cap_stream, hipStreamNonBlocking));
   p->committed = true;
   return MMK_OK;
@@ -439,9 +546,65 @@ static int emit_step(mmk_wavenet_plan* p, const WnCall& call, int64_t tau_off, b
 
 static constexpr int kGraphSteps = 8;
 
+// persistent mode: blocks of up to kCondBlock positions, each = (conditioning projection GEMMs) +
+// (clear of the hand-off words) + ONE kernel that runs every step of the block
+static int run_persistent(mmk_wavenet_plan* p, const WnCall& call, int64_t tau0, int64_t n, bool with_head, hipStream_t st) {
+  const mmk_wavenet_config& c = p->cfg;
+  for (int64_t done = 0; done < n;) {
+    const int64_t nb = (n - done) < p->kCondBlock ? (n - done) : p->kCondBlock;
+    const int64_t tau_b = tau0 + done;
+    if (p->C1 > 0) {
+      // c[b, tau, :] = LinearIO(cond[b, tau, :]) for the block's positions (modules/io.py:115-122)
+      g_prof_tag = 2;
+      for (int b = 0; b < call.M; ++b) {
+        LinearArgs a = {};
+        p->cond_lin[0].fill(a);
+        a.seg[0].x = addr_static(call.cond[0] + (int64_t)b * call.cond_rs[0] + tau_b * c.cond_in_dim[0]);
+        a.seg[0].ld = c.cond_in_dim[0];
+        a.M = (int)nb; a.tau_ptr = nullptr; a.tau_off = 0;
+        a.epilogue = EPI_STORE; a.act = ACT_NONE;
+        a.out = addr_static(p->cproj + (int64_t)b * p->kCondBlock * p->C1);
+        a.out_ld = p->C1;
+        MMK_TRY(launch_linear(a, st));
+      }
+    }
+    // hand-off words are zeroed before EVERY launch (epochs restart at 1); the error word after them is sticky
+    MMK_HIP(hipMemsetAsync(p->gran_h, 0, (size_t)(p->gran_words - 2) * sizeof(unsigned long long), st));
+    WnPersistArgs a = {};
+    a.B = call.M; a.Gc = p->Gc; a.Gn = p->Gn; a.Mg = p->Mg;
+    a.L = p->L; a.C = p->C; a.S = p->S; a.C1 = p->C1;
+    a.kcA = 2 * (p->C / 16) + p->C1 / 16;
+    a.q_levels = c.q_levels; a.H1 = c.mlp_hidden; a.n_classes = c.out_dim; a.n_logits_pad = p->n_logits_pad;
+    a.learn_temp = c.learn_temp; a.min_temp = c.min_temp;
+    a.teacher_forced = with_head ? 0 : 1;
+    a.xcd_local = p->xcd_local ? 1 : 0;
+    a.xcd_count = p->xcd_count;
+    a.t0 = tau_b + 1; a.n_steps = nb;
+    a.layers = p->layer_tab; a.p0_floats_per_wg = p->p0_floats_per_wg;
+    a.emb = p->emb; a.idx = (int64_t*)call.in0; a.idx_rs = call.in0_rs;
+    a.cproj = p->cproj; a.cproj_t0 = tau_b; a.cproj_steps = p->kCondBlock;
+    a.fc0_wp = p->mlp[0].Wp; a.fc0_bias = p->mlp[0].bias; a.fc2_wp = p->mlp[1].Wp; a.fc2_bias = p->mlp[1].bias;
+    a.temperature = call.temperature;
+    a.uniforms = call.uniforms ? call.uniforms + done : nullptr;   // column s of this block = done + s
+    a.uni_ld = call.uni_ld;
+    a.logits_out = p->logits; a.logits_ld = p->logits_ld;
+    a.gran_h = p->gran_h; a.gran_y = p->gran_y; a.gran_skip = p->gran_skip; a.gran_hid = p->gran_hid;
+    a.gran_logit = p->gran_logit; a.gran_idx = p->gran_idx;
+    a.p0_rings = p->p0_rings; a.err_flag = p->err_flag;
+    {
+      const char* senv = getenv("MMK_WN_STAMPS");
+      a.stamps = (senv && senv[0] == '1') ? reinterpret_cast<unsigned long long*>(p->tau + 8) : nullptr;
+    }
+    MMK_TRY(launch_wavenet_persist(a, st));
+    done += nb;
+  }
+  return MMK_OK;
+}
+
 // run n steps starting at position tau0 (device counter is set here)
 static int run_steps(mmk_wavenet_plan* p, const WnCall& call, int64_t tau0, int64_t n, bool with_head, hipStream_t st) {
   if (n <= 0) return MMK_OK;
+  if (p->persistent) return run_persistent(p, call, tau0, n, with_head, st);
   MMK_TRY(launch_set_i64(p->tau, tau0, st));
   int64_t done = 0;
   if (n >= 2 * kGraphSteps) {
@@ -541,6 +704,7 @@ extern "C" int mmk_wavenet_profile_steps(mmk_wavenet_plan* p, int32_t batch, voi
   WnCall call;
   MMK_TRY(check_call(p, batch, in0, cond, cond_row_stride, call));
   if (!ms_total || !launches || t0 < 1 || n_steps < 1) return fail(MMK_ERR_INVALID, "wavenet_profile_steps: bad arguments");
+  if (p->persistent) return fail(MMK_ERR_UNSUPPORTED, "wavenet_profile_steps: the plan runs one persistent kernel per call; time mmk_wavenet_generate instead");
   call.in0_rs = in0_row_stride;
   hipStream_t st = (hipStream_t)stream;
   std::vector<ProfRecord> records;
@@ -564,4 +728,30 @@ extern "C" int mmk_wavenet_profile_steps(mmk_wavenet_plan* p, int32_t batch, voi
   }
   if (e != hipSuccess) return fail(MMK_ERR_HIP, "wavenet_profile_steps: %s", hipGetErrorString(e));
   return rc;
+}
+
+extern "C" int mmk_wavenet_mode(const mmk_wavenet_plan* p) { return (p && p->persistent) ? 1 : 0; }
+
+extern "C" int mmk_wavenet_sync_status(mmk_wavenet_plan* p, mmk_stream_t stream) {
+  if (!p) return fail(MMK_ERR_INVALID, "wavenet_sync_status: null plan");
+  MMK_HIP(hipStreamSynchronize((hipStream_t)stream));
+  if (!p->committed || !p->persistent) return MMK_OK;
+  int32_t flag = 0;
+  MMK_HIP(hipMemcpy(&flag, p->err_flag, sizeof(flag), hipMemcpyDeviceToHost));
+  if (flag == 2)
+    return fail(MMK_ERR_STATE, "wavenet: the persistent kernel's workgroups were not spread 8 x %d over the XCDs; rerun with MMK_WN_XCD_LOCAL=0 (agent-scope hand-offs)", p->Gn);
+  if (flag != 0) return fail(MMK_ERR_STATE, "wavenet: a hand-off inside the persistent kernel timed out (not all workgroups resident?)");
+  {
+    const char* senv = getenv("MMK_WN_STAMPS");
+    if (senv && senv[0] == '1') {
+      unsigned long long st[16];
+      MMK_HIP(hipMemcpy(st, p->tau + 8, sizeof(st), hipMemcpyDeviceToHost));
+      const char* names[8] = {"A", "tap0 shadow", "wait y", "B", "cond shadow", "wait h'", "head", "-"};
+      fprintf(stderr, "[mmk stamps] last persistent launch, workgroup 1, totals in ms:");
+      for (int i = 0; i < 7; ++i) fprintf(stderr, " %s=%.3f;", names[i], st[i] * 1e-5);
+      fprintf(stderr, " shader clock=%.0f MHz;", st[13] ? 100.0 * (double)st[12] / (double)st[13] : 0.0);
+      fprintf(stderr, "\n");
+    }
+  }
+  return MMK_OK;
 }

@@ -71,6 +71,8 @@ _SIGNATURES = {
     "mmk_wavenet_last_logits": (i32, [vp, i32, vp, i64, vp]),
     "mmk_wavenet_profile_steps": (i32, [vp, i32, vp, i64, C.POINTER(vp), C.POINTER(i64), i64, i64,
                                         C.POINTER(C.c_double), C.POINTER(i64), vp]),
+    "mmk_wavenet_mode": (i32, [vp]),
+    "mmk_wavenet_sync_status": (i32, [vp, vp]),
     "mmk_srnn_plan_create": (i32, [C.POINTER(SrnnConfig), C.POINTER(vp)]),
     "mmk_srnn_plan_destroy": (None, [vp]),
     "mmk_srnn_plan_bind": (i32, [vp, cp, vp, i64]),
@@ -335,6 +337,14 @@ class WaveNetPlan(_Plan):
         check(self._lib.mmk_wavenet_generate(self.handle, in0.shape[0], abs_ptr(in0, t_first), in0.stride(0), ptrs,
                                              strides, t0, n_steps, ptr(temperature), ptr(uniforms),
                                              stream_ptr(self.device)), "mmk_wavenet_generate")
+
+    @property
+    def persistent(self) -> bool:
+        return bool(self._lib.mmk_wavenet_mode(self.handle))
+
+    def sync_status(self):
+        """wait for the stream and raise if a hand-off inside the persistent kernel timed out"""
+        check(self._lib.mmk_wavenet_sync_status(self.handle, stream_ptr(self.device)), "mmk_wavenet_sync_status")
 
     def profile_steps(self, in0: torch.Tensor, cond: Sequence[torch.Tensor], t0: int, n_steps: int, t_first: int = 0):
         """measurement aid: per-kernel-class device time from HIP events (see include/mmk.h);

@@ -434,3 +434,7 @@ class WaveNet(ARM, nn.Module):
 
     def after_generate(self, final_outputs: Tuple[torch.Tensor, ...], batch_index) -> None:
         self._next_t = None
+        if self._plan is not None and self._plan.persistent:
+            # the loop reads the outputs right after this call anyway; surface a hand-off timeout
+            # of the persistent kernel as an exception instead of silently returning blanks
+            self._plan.sync_status()
