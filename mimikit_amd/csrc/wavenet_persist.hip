@@ -63,7 +63,7 @@ __device__ __forceinline__ u64 gran_load(const u64* p) {
 // per round, so a sweep whose data is already there costs ONE memory round trip.
 // Returns a workgroup-uniform success flag.
 __device__ __forceinline__ bool sweep(const u64* gran, int count, int cols, unsigned epoch, float* dst, int ld,
-                                      int* err_flag, int* s_fail) {
+                                      int* err_flag, int* s_fail, bool nap = true) {
   const int tid = threadIdx.x, nt = blockDim.x;
   for (int base = 0; base < count; base += nt * 4) {
     const int i0 = base + tid * 4;
@@ -84,7 +84,7 @@ __device__ __forceinline__ bool sweep(const u64* gran, int count, int cols, unsi
           ok = false;
           break;
         }
-        __builtin_amdgcn_s_sleep(1);
+        if (nap) __builtin_amdgcn_s_sleep(1);
       }
       if (!ok) {
         *s_fail = 1;
@@ -383,7 +383,9 @@ __global__ __launch_bounds__(kPersistThreads) void wavenet_persist_kernel(const 
       const bool do_cond = a.C1 > 0 && more;
       // ---- phase A (critical): z = W1.h + P0 + cond + b ; gate ; publish y ---------------------
       redA[wave * 64 + lane] = tile_mma_reg<CPW>(hbuf, ldh, w_t1, c0, lane);
+      stamp(8);    // A: mfma + LDS write
       __syncthreads();
+      stamp(9);    // A: barrier
       u64* gran_y = gran_y0 + (int64_t)(l & 1) * 16 * C;
       if (elem) {
         const float f = sum_partials(redA) + p0 + (a.C1 > 0 ? condp_f[l * 256 + frag] : 0.f) + biasA[l * 16 + e_n];
@@ -395,10 +397,12 @@ __global__ __launch_bounds__(kPersistThreads) void wavenet_persist_kernel(const 
       stamp(0);   // phase A
       // ---- shadow of the wait for y: tap-0 product of THIS position, consumed at step tau + d ----
       redP[wave * 64 + lane] = tile_mma_reg<CPW>(hbuf, ldh, w_t0, c0, lane);
+      stamp(10);   // tap0 shadow: mfma + LDS write
       // next layer's tap weights go in flight only now (hipcc waits vmcnt(0) in front of MFMAs, so
       // an earlier prefetch would put a memory round trip on the critical path)
       if (!last) load_A(l + 1, n_t1, n_t0);
       __syncthreads();
+      stamp(11);   // tap0 shadow: prefetch issue + barrier
       if (elem) {
         float* ring = p0_ring + lt_off[l];
         ring[(int64_t)(tau & lt_i[4 * l + 1]) * 256 + frag] = sum_partials(redP);
@@ -406,7 +410,7 @@ __global__ __launch_bounds__(kPersistThreads) void wavenet_persist_kernel(const 
       stamp(1);   // shadow tap-0
       // ---- phase B (critical): wait y ; [res | skip] tile ----------------------------------------
       if (has_b) {
-        if (!sweep(gran_y, mg * C, C, epoch, ybuf, ldy, err, s_fail)) return;
+        if (!sweep(gran_y, mg * C, C, epoch, ybuf, ldy, err, s_fail, a.poll_sleep != 0)) return;
         stamp(2);   // wait y
         redB[wave * 64 + lane] = tile_mma_reg<CPW>(ybuf, ldy, w_b, c0, lane);
         __syncthreads();
@@ -438,7 +442,7 @@ __global__ __launch_bounds__(kPersistThreads) void wavenet_persist_kernel(const 
       stamp(4);   // shadow cond
       // ---- wait for the next layer's input -----------------------------------------------------
       if (!last) {
-        if (!sweep(gran_h, mg * C, C, epoch, hbuf, ldh, err, s_fail)) return;
+        if (!sweep(gran_h, mg * C, C, epoch, hbuf, ldh, err, s_fail, a.poll_sleep != 0)) return;
 #pragma unroll
         for (int u = 0; u < CPW; ++u) { w_t1[u] = n_t1[u]; w_t0[u] = n_t0[u]; w_b[u] = n_b[u]; w_c[u] = n_c[u]; }
         p0 = p0n;
@@ -584,20 +588,26 @@ size_t wn_persist_lds_bytes(const WnPersistArgs& a, int nw) {
 }
 
 int launch_wavenet_persist(const WnPersistArgs& a, hipStream_t stream) {
-  const int nw = a.C / 32;  // two K-chunks of a K = C product per wave
+  const int cpw = (a.cpw == 4 && a.C % 64 == 0) ? 4 : 2;   // K-chunks of a K = C product per wave
+  const int nw = a.C / (16 * cpw);
   if (nw < 1 || nw > 8 || a.C % 32) return fail(MMK_ERR_UNSUPPORTED, "persistent WaveNet: C=%d not in {32..256 step 32}", a.C);
   const size_t lds = wn_persist_lds_bytes(a, nw);
   if (lds > 160 * 1024) return fail(MMK_ERR_UNSUPPORTED, "persistent WaveNet: %zu bytes of LDS needed", lds);
   dim3 grid(a.Gc * a.Gn), block(64 * nw);
-#define MMK_WNP(NW_)                                                                                        \
+#define MMK_WNP2(CPW_, NW_)                                                                                     \
   do {                                                                                                    \
     if (a.stamps) {                                                                                       \
-      if (a.xcd_local) hipLaunchKernelGGL((wavenet_persist_kernel<2, NW_, true, true>), grid, block, lds, stream, a);   \
-      else hipLaunchKernelGGL((wavenet_persist_kernel<2, NW_, true, false>), grid, block, lds, stream, a);              \
+      if (a.xcd_local) hipLaunchKernelGGL((wavenet_persist_kernel<CPW_, NW_, true, true>), grid, block, lds, stream, a);   \
+      else hipLaunchKernelGGL((wavenet_persist_kernel<CPW_, NW_, true, false>), grid, block, lds, stream, a);              \
     } else {                                                                                              \
-      if (a.xcd_local) hipLaunchKernelGGL((wavenet_persist_kernel<2, NW_, false, true>), grid, block, lds, stream, a);  \
-      else hipLaunchKernelGGL((wavenet_persist_kernel<2, NW_, false, false>), grid, block, lds, stream, a);             \
+      if (a.xcd_local) hipLaunchKernelGGL((wavenet_persist_kernel<CPW_, NW_, false, true>), grid, block, lds, stream, a);  \
+      else hipLaunchKernelGGL((wavenet_persist_kernel<CPW_, NW_, false, false>), grid, block, lds, stream, a);             \
     }                                                                                                     \
+  } while (0)
+#define MMK_WNP(NW_)                 \
+  do {                               \
+    if (cpw == 4) MMK_WNP2(4, NW_);  \
+    else MMK_WNP2(2, NW_);           \
   } while (0)
   switch (nw) {
     case 1: MMK_WNP(1); break;
@@ -610,6 +620,7 @@ int launch_wavenet_persist(const WnPersistArgs& a, hipStream_t stream) {
     default: MMK_WNP(8); break;
   }
 #undef MMK_WNP
+#undef MMK_WNP2
   MMK_HIP(hipGetLastError());
   return MMK_OK;
 }

@@ -213,7 +213,10 @@ static int derive(mmk_wavenet_plan* p) {
     if (gc_max < 1) gc_max = 1;
     // clips per group: one MFMA row tile (16) at most, and one epilogue element per thread
     // (16 columns x Mg clips <= 64 * C/32 threads)
-    const int mg_cap = 16 < 4 * (p->C / 32) ? 16 : 4 * (p->C / 32);
+    const char* cpw_env = getenv("MMK_WN_CPW");
+    const int cpw_sel = (cpw_env && atoi(cpw_env) == 4 && p->C % 64 == 0) ? 4 : 2;
+    const int nw_sel = p->C / (16 * cpw_sel);
+    const int mg_cap = 16 < 4 * nw_sel ? 16 : 4 * nw_sel;
     int gc = (p->Bmax + 7) / 8;                      // aim at 8 clips per group
     const char* genv = getenv("MMK_WN_GROUPS");
     if (genv && atoi(genv) > 0) gc = atoi(genv);
@@ -579,6 +582,12 @@ static int run_persistent(mmk_wavenet_plan* p, const WnCall& call, int64_t tau0,
     a.teacher_forced = with_head ? 0 : 1;
     a.xcd_local = p->xcd_local ? 1 : 0;
     a.xcd_count = p->xcd_count;
+    {
+      const char* cenv = getenv("MMK_WN_CPW");
+      a.cpw = (cenv && atoi(cenv) == 4) ? 4 : 2;
+      const char* pe = getenv("MMK_WN_POLL_SLEEP");
+      a.poll_sleep = (pe && pe[0] == '0') ? 0 : 1;
+    }
     a.t0 = tau_b + 1; a.n_steps = nb;
     a.layers = p->layer_tab; a.p0_floats_per_wg = p->p0_floats_per_wg;
     a.emb = p->emb; a.idx = (int64_t*)call.in0; a.idx_rs = call.in0_rs;
@@ -749,6 +758,7 @@ extern "C" int mmk_wavenet_sync_status(mmk_wavenet_plan* p, mmk_stream_t stream)
       const char* names[8] = {"A", "tap0 shadow", "wait y", "B", "cond shadow", "wait h'", "head", "-"};
       fprintf(stderr, "[mmk stamps] last persistent launch, workgroup 1, totals in ms:");
       for (int i = 0; i < 7; ++i) fprintf(stderr, " %s=%.3f;", names[i], st[i] * 1e-5);
+      fprintf(stderr, " [A: mfma+lds=%.3f barrier=%.3f epilogue=%.3f | tap0: mfma+lds=%.3f issue+barrier=%.3f reduce+store=%.3f];", st[8] * 1e-5, st[9] * 1e-5, st[0] * 1e-5, st[10] * 1e-5, st[11] * 1e-5, st[1] * 1e-5);
       fprintf(stderr, " shader clock=%.0f MHz;", st[13] ? 100.0 * (double)st[12] / (double)st[13] : 0.0);
       fprintf(stderr, "\n");
     }

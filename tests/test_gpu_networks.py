@@ -243,3 +243,82 @@ def test_seq2seq_cfg5_geometry_vs_oracle(device):
     assert float((got - want).abs().max()) <= 1e-4 * float(want.abs().max())
     loop_cfg = mmk.GenerateLoopV2.Config(output_duration_sec=1.0)
     assert mmk.GenerateLoopV2.get_n_steps(loop_cfg, net) == 84
+
+
+# ---------------------------------------------------------------------------- WaveNet execution modes
+def _cond_net(seed=21):
+    """persistent-kernel eligible net with one conditioning input: C = S = R = 32, cond 12 -> 16, blocks (3, 2)"""
+    from oracle.weights import load_recipe
+    io = H.mu_emb(mlp_dim=32)
+    ext = mmk.Extractor("signal", mmk.FileToSignal(16000))
+    io = mmk.IOSpec(inputs=(io.inputs[0], mmk.InputSpec("signal", mmk.MagSpec(22, 4, center=False), mmk.LinearIO()).bind_to(ext)),
+                    targets=io.targets)
+    net = mmk.WaveNet.from_config(mmk.WaveNet.Config(io_spec=io, blocks=(3, 2), dims_dilated=(32,), dims_1x1=(16,),
+                                                     residuals_dim=32, skips_dim=32)).eval()
+    sd = load_recipe(net, seed=seed, gain=2.0)
+    arch = dict(kernels=[2] * 5, dilations=[1, 2, 4, 1, 2], has_skips=True, residuals=True)
+    return net, sd, arch
+
+
+MODES = {"persistent_xcd": {}, "persistent_agent": {"MMK_WN_XCD_LOCAL": "0"}, "launches": {"MMK_WN_PERSISTENT": "0"}}
+
+
+@pytest.mark.parametrize("mode", list(MODES))
+def test_wavenet_modes_agree_with_oracle(device, mode, monkeypatch):
+    """the persistent kernel (XCD-local and agent-scope hand-offs) and the per-layer launch path all reproduce
+    the oracle: conditioned net, batch 5 (ragged clip groups), prompt longer than rf, 70 steps, greedy + sampled"""
+    for k in ("MMK_WN_XCD_LOCAL", "MMK_WN_PERSISTENT", "MMK_WN_GROUPS"):
+        monkeypatch.delenv(k, raising=False)
+    for k, v in MODES[mode].items():
+        monkeypatch.setenv(k, v)
+    net, sd, arch = _cond_net()
+    net = net.to(device)
+    gen = torch.Generator().manual_seed(17)
+    rf, n, B = net.rf, 70, 5
+    prompt = torch.randint(0, 256, (B, rf + 9), generator=gen)
+    cond = torch.rand(B, rf + 9 + n, 12, generator=gen)
+    want, raw = O.wavenet_generate(sd, prompt, (cond,), n, keep_logits=True, **arch)
+    idx = torch.cat([prompt, torch.zeros(B, n, dtype=torch.int64)], 1).to(device)
+    net.generate_block((idx, cond.to(device)), prompt.size(1), n)
+    net.after_generate((idx,), None)
+    assert net._plan.persistent == (mode != "launches")
+    ok = H.margin_ok(raw.numpy())
+    first_bad = (~ok).float().cumsum(1) > 0
+    same = idx.cpu()[:, prompt.size(1):] == want[:, prompt.size(1):]
+    assert bool((same | first_bad).all())
+    assert float(ok.float().mean()) > 0.9
+    assert torch.allclose(net._plan.last_logits(B).cpu()[ok[:, -1]], raw[:, -1][ok[:, -1]], **LOGIT_TOL)
+    # sampled decode with the uniforms generate_block will draw
+    temp = torch.tensor([0.6, 1.0, 1.4, 0.8, 1.1])
+    torch.manual_seed(5)
+    u = torch.rand((B, n), device=device)
+    torch.manual_seed(5)
+    idx2 = torch.cat([prompt, torch.zeros(B, n, dtype=torch.int64)], 1).to(device)
+    net.generate_block((idx2, cond.to(device)), prompt.size(1), n, temperature=temp)
+    net.after_generate((idx2,), None)
+    want2 = O.wavenet_generate(sd, prompt, (cond,), n, temperature=temp, uniforms=u.cpu(), **arch)
+    agree = (idx2.cpu() == want2)[:, prompt.size(1):]
+    assert float(agree.float().cumprod(1).sum(1).mean()) >= 0.7 * n
+
+
+def test_wavenet_persistent_long_block_crosses_cond_blocks(device, monkeypatch):
+    """more steps than one conditioning block (1024): two persistent launches chained through the product rings"""
+    for k in ("MMK_WN_XCD_LOCAL", "MMK_WN_PERSISTENT", "MMK_WN_GROUPS"):
+        monkeypatch.delenv(k, raising=False)
+    net, sd, arch = _cond_net(seed=22)
+    net = net.to(device)
+    gen = torch.Generator().manual_seed(3)
+    rf, n, B = net.rf, 1030, 2
+    prompt = torch.randint(0, 256, (B, rf), generator=gen)
+    cond = torch.rand(B, rf + n, 12, generator=gen)
+    idx = torch.cat([prompt, torch.zeros(B, n, dtype=torch.int64)], 1).to(device)
+    net.generate_block((idx, cond.to(device)), rf, n)
+    net.after_generate((idx,), None)
+    assert net._plan.persistent
+    # teacher-forced oracle check of the LAST few steps: feed the GPU's own history to the naive window forward
+    hist = idx.cpu()
+    for t in range(rf + n - 4, rf + n):
+        raw = O.wavenet_window_forward(sd, (hist[:, t - rf:t], cond[:, t - rf:t]), n_cond=1, **arch)
+        pick = O.categorical(O.mlp_logits(raw))
+        gap_ok = H.margin_ok(raw.numpy())[:, 0]
+        assert bool(((pick[:, 0] == hist[:, t]) | ~gap_ok).all())
