@@ -10,6 +10,10 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `-m gpu` through gpurun)")
+    # the oracle runs thousands of tiny torch ops; on a 128-core host the default intra-op pool makes
+    # each of them ~ms slow
+    import torch
+    torch.set_num_threads(min(8, torch.get_num_threads()))
 
 
 @pytest.fixture(scope="session")
