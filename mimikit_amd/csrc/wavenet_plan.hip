@@ -58,15 +58,17 @@ struct mmk_wavenet_plan {
   bool persistent = false;
   int Gc = 0, Gn = 0, Mg = 0, C1 = 0, n_logits_pad = 0;
   static constexpr int kCondBlock = 1024;       // positions whose conditioning is projected per launch
-  std::vector<int64_t> p0_offset;
-  std::vector<int> p0_mask;
-  int64_t p0_floats_per_wg = 0;
+  std::vector<int64_t> ring_offset;  // per layer: float offset of its history ring inside a workgroup's block
+  std::vector<int> ring_mask;
+  int64_t ring_floats_per_wg = 0;
+  PackedLinear cond_all;             // rows = L x 2C gate rows of every layer's conditioning 1x1 conv, K = C1
   WnLayerTab* layer_tab = nullptr;
   unsigned long long *gran_h = nullptr, *gran_y = nullptr, *gran_skip = nullptr, *gran_hid = nullptr,
                      *gran_logit = nullptr, *gran_idx = nullptr;
   int64_t gran_words = 0;       // contiguous block [gran_h .. gran_idx] + err word, zeroed before every launch
-  float* p0_rings = nullptr;
-  float* cproj = nullptr;
+  float* h_rings = nullptr;     // per workgroup: past inputs of every layer (the delayed tap reads them)
+  float* cproj = nullptr;       // (Bmax, kCondBlock, C1) conditioning after its LinearIO
+  float* condall = nullptr;     // (Bmax, kCondBlock, L, 2C) every layer's conditioning product, packed gate order
   int32_t* err_flag = nullptr;
   unsigned* xcd_count = nullptr;
   bool xcd_local = false;       // one clip group per XCD, hand-offs through the XCD's L2 (verified in-kernel)
@@ -85,8 +87,10 @@ struct mmk_wavenet_plan {
     gran_idx = gran_logit + (base ? n_l : 0);
     xcd_count = reinterpret_cast<unsigned*>(gran_idx + (base ? n_i : 0));
     err_flag = reinterpret_cast<int32_t*>(gran_idx + (base ? n_i + 8 : 0));
-    p0_rings = c.take<float>((int64_t)Gc * Gn * p0_floats_per_wg);
+    h_rings = c.take<float>((int64_t)Gc * Gn * ring_floats_per_wg);
     cproj = C1 > 0 ? c.take<float>((int64_t)Bmax * kCondBlock * C1) : nullptr;
+    condall = C1 > 0 ? c.take<float>((int64_t)Bmax * kCondBlock * L * 2 * C) : nullptr;
+    if (C1 > 0) cond_all.carve(c, false);
   }
 
   void layout(Carver& c) {
@@ -236,17 +240,18 @@ static int derive(mmk_wavenet_plan* p) {
     p->n_logits_pad = (int)round_up(c.out_dim + (c.learn_temp ? 1 : 0), 16);
     if (p->Mg <= mg_cap) {
       p->persistent = true;
-      p->p0_offset.assign(p->L, 0);
-      p->p0_mask.assign(p->L, 0);
+      p->ring_offset.assign(p->L, 0);
+      p->ring_mask.assign(p->L, 0);
       int64_t off = 0;
       for (int l = 0; l < p->L; ++l) {
         int ring = 1;
         while (ring < p->dil[l] + 1) ring <<= 1;
-        p->p0_offset[l] = off;
-        p->p0_mask[l] = ring - 1;
-        off += (int64_t)ring * 256;               // 16 x 16 floats per position
+        p->ring_offset[l] = off;
+        p->ring_mask[l] = ring - 1;
+        off += (int64_t)ring * p->Mg * p->C;      // one slot = the group's clips x C
       }
-      p->p0_floats_per_wg = off;
+      p->ring_floats_per_wg = off;
+      if (p->C1 > 0) p->cond_all.set_geometry(p->L * 2 * p->C, {p->C1});
     }
   }
   return MMK_OK;
@@ -368,6 +373,10 @@ extern "C" int mmk_wavenet_commit(mmk_wavenet_plan* p, void* workspace, size_t w
         if (c.gated) {
           MMK_TRY(pack_rect(A.Wp, A.k_chunks, 0, 2, C, A.seg_chunk0[k + j], cd, w1, cd, 1, st));
           MMK_TRY(pack_rect(A.Wp, A.k_chunks, 1, 2, C, A.seg_chunk0[k + j], cd, w1 + (int64_t)C * cd, cd, 1, st));
+          if (p->persistent && p->C1 > 0) {   // same gate-interleaved rows, all layers stacked (bias stays in A.bias)
+            MMK_TRY(pack_rect(p->cond_all.Wp, p->cond_all.k_chunks, l * 2 * C, 2, C, 0, cd, w1, cd, 1, st));
+            MMK_TRY(pack_rect(p->cond_all.Wp, p->cond_all.k_chunks, l * 2 * C + 1, 2, C, 0, cd, w1 + (int64_t)C * cd, cd, 1, st));
+          }
         } else {
           MMK_TRY(pack_rect(A.Wp, A.k_chunks, 0, 1, C, A.seg_chunk0[k + j], cd, w1, cd, 1, st));
         }
@@ -422,9 +431,9 @@ extern "C" int mmk_wavenet_commit(mmk_wavenet_plan* p, void* workspace, size_t w
     for (int l = 0; l < L; ++l) {
       tab[l].dil = p->dil[l];
       tab[l].has_res = p->has_res[l] ? 1 : 0;
-      tab[l].p0_mask = p->p0_mask[l];
+      tab[l].ring_mask = p->ring_mask[l];
       tab[l].pad_ = 0;
-      tab[l].p0_offset = p->p0_offset[l];
+      tab[l].ring_offset = p->ring_offset[l];
       tab[l].A_wp = p->A[l].Wp;
       tab[l].A_bias = p->A[l].bias;
       tab[l].B_wp = p->Bm[l].Wp;
@@ -569,6 +578,16 @@ static int run_persistent(mmk_wavenet_plan* p, const WnCall& call, int64_t tau0,
         a.out = addr_static(p->cproj + (int64_t)b * p->kCondBlock * p->C1);
         a.out_ld = p->C1;
         MMK_TRY(launch_linear(a, st));
+        // every layer's conv_1x1(c) for the same positions (wavenet_v2.py:140-150): off the per-sample chain
+        LinearArgs w = {};
+        p->cond_all.fill(w);
+        w.seg[0].x = addr_static(p->cproj + (int64_t)b * p->kCondBlock * p->C1);
+        w.seg[0].ld = p->C1;
+        w.M = (int)nb; w.tau_ptr = nullptr; w.tau_off = 0;
+        w.epilogue = EPI_STORE; w.act = ACT_NONE;
+        w.out = addr_static(p->condall + (int64_t)b * p->kCondBlock * p->L * 2 * p->C);
+        w.out_ld = (int64_t)p->L * 2 * p->C;
+        MMK_TRY(launch_linear(w, st));
       }
     }
     // hand-off words are zeroed before EVERY launch (epochs restart at 1); the error word after them is sticky
@@ -589,9 +608,9 @@ static int run_persistent(mmk_wavenet_plan* p, const WnCall& call, int64_t tau0,
       a.poll_sleep = (pe && pe[0] == '0') ? 0 : 1;
     }
     a.t0 = tau_b + 1; a.n_steps = nb;
-    a.layers = p->layer_tab; a.p0_floats_per_wg = p->p0_floats_per_wg;
+    a.layers = p->layer_tab; a.ring_floats_per_wg = p->ring_floats_per_wg;
     a.emb = p->emb; a.idx = (int64_t*)call.in0; a.idx_rs = call.in0_rs;
-    a.cproj = p->cproj; a.cproj_t0 = tau_b; a.cproj_steps = p->kCondBlock;
+    a.condall = p->condall; a.cond_steps = p->kCondBlock;
     a.fc0_wp = p->mlp[0].Wp; a.fc0_bias = p->mlp[0].bias; a.fc2_wp = p->mlp[1].Wp; a.fc2_bias = p->mlp[1].bias;
     a.temperature = call.temperature;
     a.uniforms = call.uniforms ? call.uniforms + done : nullptr;   // column s of this block = done + s
@@ -599,7 +618,7 @@ static int run_persistent(mmk_wavenet_plan* p, const WnCall& call, int64_t tau0,
     a.logits_out = p->logits; a.logits_ld = p->logits_ld;
     a.gran_h = p->gran_h; a.gran_y = p->gran_y; a.gran_skip = p->gran_skip; a.gran_hid = p->gran_hid;
     a.gran_logit = p->gran_logit; a.gran_idx = p->gran_idx;
-    a.p0_rings = p->p0_rings; a.err_flag = p->err_flag;
+    a.h_rings = p->h_rings; a.err_flag = p->err_flag;
     {
       const char* senv = getenv("MMK_WN_STAMPS");
       a.stamps = (senv && senv[0] == '1') ? reinterpret_cast<unsigned long long*>(p->tau + 8) : nullptr;
@@ -755,10 +774,10 @@ extern "C" int mmk_wavenet_sync_status(mmk_wavenet_plan* p, mmk_stream_t stream)
     if (senv && senv[0] == '1') {
       unsigned long long st[16];
       MMK_HIP(hipMemcpy(st, p->tau + 8, sizeof(st), hipMemcpyDeviceToHost));
-      const char* names[8] = {"A", "tap0 shadow", "wait y", "B", "cond shadow", "wait h'", "head", "-"};
+      const char* names[7] = {"requests", "A mfma+barrier", "A epilogue+publish", "wait y", "B", "wait h'", "head"};
+      const int slot[7] = {8, 9, 0, 1, 2, 3, 6};
       fprintf(stderr, "[mmk stamps] last persistent launch, workgroup 1, totals in ms:");
-      for (int i = 0; i < 7; ++i) fprintf(stderr, " %s=%.3f;", names[i], st[i] * 1e-5);
-      fprintf(stderr, " [A: mfma+lds=%.3f barrier=%.3f epilogue=%.3f | tap0: mfma+lds=%.3f issue+barrier=%.3f reduce+store=%.3f];", st[8] * 1e-5, st[9] * 1e-5, st[0] * 1e-5, st[10] * 1e-5, st[11] * 1e-5, st[1] * 1e-5);
+      for (int i = 0; i < 7; ++i) fprintf(stderr, " %s=%.3f;", names[i], st[slot[i]] * 1e-5);
       fprintf(stderr, " shader clock=%.0f MHz;", st[13] ? 100.0 * (double)st[12] / (double)st[13] : 0.0);
       fprintf(stderr, "\n");
     }
