@@ -48,7 +48,7 @@ struct WnPersistArgs {
   unsigned long long* stamps;     // diagnostic build (MMK_WN_STAMPS=1): 8 phase totals of workgroup 1, 100 MHz ticks
 };
 
-size_t wn_persist_lds_bytes(const WnPersistArgs& a, int nw);
+size_t wn_persist_lds_bytes(const WnPersistArgs& a);
 int launch_wavenet_persist(const WnPersistArgs& a, hipStream_t stream);
 
 }  // namespace mmk

@@ -35,7 +35,6 @@ typedef unsigned long long u64;
 typedef const __attribute__((address_space(1))) f32x4* gf32x4_ptr;
 __device__ __forceinline__ gf32x4_ptr as_global(const void* p) { return (gf32x4_ptr)(uintptr_t)p; }
 
-constexpr int kPersistThreads = 512;   // upper bound; actual = 64 * nw
 constexpr unsigned kSpinLimit = 1u << 22;
 
 // XCD == false: agent-scope store (sc1, write-through to memory; readable from every XCD).
@@ -64,15 +63,14 @@ __device__ __forceinline__ u64 gran_load(const u64* p) {
 
 // Poll `count` granules until every tag == epoch and write the values as floats into an LDS matrix
 // (`cols` values per row, leading dimension ld; cols and ld are multiples of 4).  Each thread keeps four 8-byte
-// loads in flight per round, so a sweep whose data is already there costs ONE round trip; the thread's first
-// four granules sit at (row0, col0) when cols == cols0 (precomputed by the caller: no division on the path).
+// loads in flight per round, so a sweep whose data is already there costs ONE round trip.  dst0 (optional) is
+// the LDS address of the thread's first four values, computed once by the caller: no division on the path.
 // Returns a workgroup-uniform success flag.
 template <int NT>
-__device__ __forceinline__ bool sweep(const u64* gran, int count, int cols, unsigned epoch, float* dst, int ld,
-                                      int cols0, int row0, int col0, int* err_flag, int* s_fail) {
+__device__ __forceinline__ bool sweep(const u64* gran, int count, unsigned epoch, float* dst0, float* dst, int cols,
+                                      int ld, int* err_flag, int* s_fail) {
   const int tid = threadIdx.x;
-  constexpr int nt = NT;   // blockDim.x, as a constant: reading it costs a global load from the dispatch packet
-  for (int base = 0; base < count; base += nt * 4) {
+  for (int base = 0; base < count; base += NT * 4) {
     const int i0 = base + tid * 4;
     if (i0 < count) {      // count is a multiple of 16, i0 of 4: all four granules exist and share a row
       u64 v[4];
@@ -96,21 +94,19 @@ __device__ __forceinline__ bool sweep(const u64* gran, int count, int cols, unsi
         *s_fail = 1;
         atomicExch(err_flag, 1);
       }
-      int m, c;
-      if (base == 0 && cols == cols0) {
-        m = row0;
-        c = col0;
+      float* d;
+      if (base == 0 && dst0) {
+        d = dst0;
       } else {
-        m = i0 / cols;
-        c = i0 - m * cols;
+        const int m = i0 / cols;
+        d = dst + m * ld + (i0 - m * cols);
       }
-      *reinterpret_cast<f32x4*>(dst + m * ld + c) =
-          f32x4{__uint_as_float((unsigned)v[0]), __uint_as_float((unsigned)v[1]), __uint_as_float((unsigned)v[2]),
-                __uint_as_float((unsigned)v[3])};
+      *reinterpret_cast<f32x4*>(d) = f32x4{__uint_as_float((unsigned)v[0]), __uint_as_float((unsigned)v[1]),
+                                           __uint_as_float((unsigned)v[2]), __uint_as_float((unsigned)v[3])};
     }
   }
   // vmcnt(0) on EVERY path: waves without granules skip the polls, and without this the compiler has to assume
-  // that older requests are still pending and waits for them in front of the next batch of requests instead
+  // that older requests are still pending and guards recycled registers with waits between the next requests
   __builtin_amdgcn_s_waitcnt(0x0F70);
   __syncthreads();
   return *s_fail == 0;
@@ -135,15 +131,15 @@ __device__ __forceinline__ f32x4 tile_mma(const float* x, int ld, const f32x4* w
   return acc;
 }
 
-// same with the weight fragments already in registers (CPW chunks per wave, starting at chunk c0); all LDS
-// reads are issued before the first MFMA so their latencies overlap
+// X[16 x 16 CPW] (LDS; x points at this lane's first operand: row lane & 15, K offset 4 (lane >> 4) of the wave's
+// first chunk) times CPW weight fragments held in registers; all LDS reads are issued before the first MFMA
 template <int CPW>
-__device__ __forceinline__ f32x4 tile_mma_reg(const float* x, int ld, const f32x4 (&w)[CPW], int c0, int lane, f32x4 acc) {
-  const int r = lane & 15, q = lane >> 4;
+__device__ __forceinline__ f32x4 tile_mma_reg(const float* x, const f32x4 (&w)[CPW]) {
   f32x4 xv[CPW];
 #pragma unroll
-  for (int u = 0; u < CPW; ++u) xv[u] = *reinterpret_cast<const f32x4*>(x + r * ld + (c0 + u) * 16 + 4 * q);
-  __builtin_amdgcn_sched_barrier(0);
+  for (int u = 0; u < CPW; ++u) xv[u] = *reinterpret_cast<const f32x4*>(x + u * 16);
+  __builtin_amdgcn_sched_barrier(0);   // keep the reads ahead of the MFMA chain (the scheduler sinks them otherwise)
+  f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int u = 0; u < CPW; ++u) {
 #pragma unroll
@@ -154,15 +150,14 @@ __device__ __forceinline__ f32x4 tile_mma_reg(const float* x, int ld, const f32x
 // two products into one accumulator chain: x0 . w0 + x1 . w1
 template <int CPW>
 __device__ __forceinline__ f32x4 tile_mma_reg2(const float* x0, const f32x4 (&w0)[CPW], const float* x1,
-                                               const f32x4 (&w1)[CPW], int ld, int c0, int lane) {
-  const int r = lane & 15, q = lane >> 4;
+                                               const f32x4 (&w1)[CPW]) {
   f32x4 xa[CPW], xb[CPW];
 #pragma unroll
   for (int u = 0; u < CPW; ++u) {
-    xa[u] = *reinterpret_cast<const f32x4*>(x0 + r * ld + (c0 + u) * 16 + 4 * q);
-    xb[u] = *reinterpret_cast<const f32x4*>(x1 + r * ld + (c0 + u) * 16 + 4 * q);
+    xa[u] = *reinterpret_cast<const f32x4*>(x0 + u * 16);
+    xb[u] = *reinterpret_cast<const f32x4*>(x1 + u * 16);
   }
-  __builtin_amdgcn_sched_barrier(0);   // keep the reads ahead of the MFMA chain (the scheduler sinks them otherwise)
+  __builtin_amdgcn_sched_barrier(0);
   f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int u = 0; u < CPW; ++u) {
@@ -192,13 +187,49 @@ __device__ __forceinline__ f32x4 reduce_waves(f32x4 acc, f32x4* red, int wave, i
   return v;
 }
 
-template <int CPW, int NW, bool STAMPS, bool XCD>
-__global__ __launch_bounds__(kPersistThreads) void wavenet_persist_kernel(const WnPersistArgs a) {
+// A workgroup's per-layer facts, built once in LDS; one layer's entry is two 16-byte reads
+struct __attribute__((aligned(16))) LtEntry {
+  unsigned A_lo, A_hi;     // this workgroup's tile of the layer's packed A (byte address)
+  unsigned B_lo, B_hi;     // its tile of packed B (the A tile again when it has none in this layer: fetched, unused)
+  unsigned ring_off;       // byte offset of the layer's input-history ring inside the workgroup's block
+  unsigned dil, mask;      // dilation, ring slots - 1
+  unsigned has_b;
+};
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(1))) const float* gcfloat_ptr;
+typedef __attribute__((address_space(1))) f32x4* gf32x4_wptr;
+
+__device__ __forceinline__ unsigned sgpr(unsigned v) { return (unsigned)__builtin_amdgcn_readfirstlane((int)v); }
+
+constexpr int kIoWaves = 4;                       // waves 0..3: hand-offs, epilogues, ring stores
+constexpr int wn_cpw(int kc) { return kc % 4 == 0 ? 4 : 2; }          // K-chunks per matrix wave
+constexpr int wn_threads(int kc) { return 64 * (kIoWaves + kc / wn_cpw(kc)); }
+
+// Two kinds of waves.  vmcnt retires in order, so a poll issued behind a long-latency load only returns after
+// it - and the weight stream of a layer (48 KiB per workgroup at C = 256, mostly from the memory-side cache)
+// takes longer than the gap between two polls.  Therefore:
+//   * I/O waves (0..3) never load anything but granules: they poll, move the arrived values into LDS, run the
+//     per-element epilogues, publish, and store the layer inputs into the history ring;
+//   * matrix waves (4..) never poll: they request the next layer's weight fragments, delayed input and
+//     conditioning terms (one layer ahead, the fragment loads interleaved with the MFMA chain whose dependent
+//     issue leaves the slots free), run the MFMAs, and pass the small operands on through LDS.
+// Both kinds meet at the same four workgroup barriers per layer:
+//   B1 phase-A partials in LDS | B2 y in LDS | B3 phase-B partials in LDS | B4 next input (+ delayed input) in LDS
+template <int KC, bool STAMPS, bool XCD>
+__global__ __launch_bounds__(wn_threads(KC)) void wavenet_persist_kernel(const WnPersistArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  constexpr int CPW = wn_cpw(KC);      // K-chunks of a K = C product per matrix wave
+  constexpr int NWM = KC / CPW;        // matrix waves
+  constexpr int NMT = NWM * 64;        // matrix threads
+  constexpr int NIO = kIoWaves * 64;   // I/O threads
+  constexpr int nw = kIoWaves + NWM;
+  constexpr int NT = nw * 64;          // == blockDim.x (reading the builtin costs a load from the dispatch packet)
+  constexpr int C = 16 * KC;           // channels
+  constexpr int kcC = KC;              // K-chunks of one tap / of B
+  constexpr int ldh = C + 4;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  constexpr int nw = NW;
-  constexpr int NT = NW * 64;          // == NT
+  const bool is_io = wave < kIoWaves;
   int g = blockIdx.x / a.Gn;          // clip group
   int j = blockIdx.x % a.Gn;          // tile owner inside the group
   if (XCD) {
@@ -226,56 +257,55 @@ __global__ __launch_bounds__(kPersistThreads) void wavenet_persist_kernel(const 
       role[1] = (int)mine;
     }
     __syncthreads();
-    g = role[0];
-    j = role[1];
+    g = __builtin_amdgcn_readfirstlane(role[0]);
+    j = __builtin_amdgcn_readfirstlane(role[1]);
     __syncthreads();
     if (g < 0) return;
   }
-  const int C = a.C, L = a.L;
+  const int L = a.L;
   const int m_first = g * a.Mg;
   const int mg = min(a.Mg, a.B - m_first);   // clips of this group
   if (mg <= 0) return;
 
   // ---- LDS carve (all dynamic, 16-byte aligned pieces) -----------------------------------
-  const int wide = max(max(C, a.S), a.H1);
-  const int ldh = C + 4, ldy = wide + 4, ldl = a.n_logits_pad + 4;
+  const int wide = max(C, a.H1);
+  const int ldy = wide + 4, ldl = a.n_logits_pad + 4;
+  constexpr int kRed = (2 * NWM > nw ? 2 * NWM : nw) * 64;                // f32x4 slots: [A | B][NWM][64], head: [nw][64]
   char* sp = smem_raw;
   float* hbuf = (float*)sp;   sp += 16 * ldh * 4;                         // layer input h_l[tau], rows = clips
-  float* hprev0 = (float*)sp; sp += 2 * 16 * ldh * 4;                     // h_l[tau - d_l], double buffered by layer parity
+  float* hprev = (float*)sp;  sp += 16 * ldh * 4;                         // h_l[tau - d_l]
   float* ybuf = (float*)sp;   sp += 16 * ldy * 4;                         // gated output / skip sums / hidden
-  f32x4* red = (f32x4*)sp;    sp += 2 * nw * 64 * 16;                     // split-K partials: [A | B][nw][64]
-  const float** lt_A = (const float**)sp; sp += L * 8;                    // per-layer table, copied once
-  const float** lt_B = (const float**)sp; sp += L * 8;
-  int64_t* lt_off = (int64_t*)sp;         sp += L * 8;
-  int* lt_i = (int*)sp;                   sp += ((L * 4 * 4 + 15) / 16) * 16;   // dil, ring mask, has_res, btile
+  f32x4* red = (f32x4*)sp;    sp += kRed * 16;                            // split-K partials
+  LtEntry* ltab = (LtEntry*)sp;           sp += L * 32;                   // per-layer table, built once
   float* biasA = (float*)sp;              sp += L * 16 * 4;
   float* biasB = (float*)sp;              sp += L * 16 * 4;
+  float* cndbuf = (float*)sp;             sp += 256 * 4;                  // conditioning term per output element
   int* s_idx = (int*)sp;      sp += 16 * 4;
   int* s_fail = (int*)sp;     sp += 16;
   float* lbuf = (float*)sp;                                               // logits for the sampler (owner 0 only)
-  f32x4* redA = red, *redB = red + nw * 64;
+  f32x4* redA = red, *redB = red + NWM * 64;
 
-  const int kcC = C / 16;                 // K-chunks of one tap / of B
-  const int kcA = a.kcA;                  // chunks per A tile: 2*kcC (+ cond chunks, unused here)
-  const int c0 = wave * CPW;              // this wave's chunk range inside a K = C product
   const int D_q = lane >> 4, D_n = lane & 15;
   const bool owns_res = j < kcC;          // owners [0, C/16) hold residual rows of B, the others skip rows
   const bool has_cond = a.C1 > 0;
 
-  for (int i = tid; i < 3 * 16 * ldh; i += NT) hbuf[i] = 0.f;      // hbuf + both hprev buffers
+  for (int i = tid; i < 2 * 16 * ldh; i += NT) hbuf[i] = 0.f;      // hbuf + hprev
   for (int i = tid; i < 16 * ldy; i += NT) ybuf[i] = 0.f;
+  for (int i = tid; i < 256; i += NT) cndbuf[i] = 0.f;
   if (j == 0)
     for (int i = tid; i < 16 * ldl; i += NT) lbuf[i] = 0.f;
   for (int l = tid; l < L; l += NT) {
     const WnLayerTab t = a.layers[l];
+    const bool hb = !owns_res || t.has_res;   // B of layer l: [res rows (if the layer has a residual conv) ; skip rows]
     const int btile = owns_res ? j : (j - kcC + (t.has_res ? kcC : 0));
-    lt_A[l] = t.A_wp;
-    lt_B[l] = t.B_wp;
-    lt_off[l] = t.ring_offset;
-    lt_i[4 * l + 0] = t.dil;
-    lt_i[4 * l + 1] = t.ring_mask;
-    lt_i[4 * l + 2] = t.has_res;
-    lt_i[4 * l + 3] = btile;
+    const uintptr_t Ap = (uintptr_t)(t.A_wp + (int64_t)j * a.kcA * 256);
+    const uintptr_t Bp = hb ? (uintptr_t)(t.B_wp + (int64_t)btile * kcC * 256) : Ap;   // no B rows: any valid tile
+    LtEntry e;
+    e.A_lo = (unsigned)Ap; e.A_hi = (unsigned)(Ap >> 32);
+    e.B_lo = (unsigned)Bp; e.B_hi = (unsigned)(Bp >> 32);
+    e.ring_off = (unsigned)(t.ring_offset * 4);
+    e.dil = (unsigned)t.dil; e.mask = (unsigned)t.ring_mask; e.has_b = hb ? 1u : 0u;
+    ltab[l] = e;
   }
   for (int i = tid; i < L * 16; i += NT) {
     const int l = i >> 4, n = i & 15;
@@ -290,33 +320,16 @@ __global__ __launch_bounds__(kPersistThreads) void wavenet_persist_kernel(const 
   // ---- per-group exchange buffers, per-workgroup private history ring ---------------------------
   u64* gran_h = a.gran_h + (int64_t)g * 16 * C;
   u64* gran_y0 = a.gran_y + (int64_t)g * 2 * 16 * C;
-  u64* gran_skip = a.gran_skip + (int64_t)g * 16 * a.S;
+  u64* gran_skip = a.gran_skip + (int64_t)g * 16 * C;
   u64* gran_hid = a.gran_hid + (int64_t)g * 16 * a.H1;
   u64* gran_logit = a.gran_logit + (int64_t)g * 16 * a.n_logits_pad;
   u64* gran_idx = a.gran_idx + (int64_t)g * 16;
-  float* h_ring = a.h_rings + (int64_t)(g * a.Gn + j) * a.ring_floats_per_wg;   // follows the ROLE, not the block id
-  const int slot_floats = a.Mg * C;       // one ring slot = the group's clips x C
+  char* h_ring = (char*)(a.h_rings + (int64_t)(g * a.Gn + j) * a.ring_floats_per_wg);   // follows the ROLE, not the block id
+  const unsigned slot_bytes = (unsigned)a.Mg * C * 4;       // one ring slot = the group's clips x C
+  const int slot_f4 = mg * (C / 4);                          // 16-byte pieces of a slot that hold real clips
   int* err = a.err_flag;
 
-  // weight fragments: current layer and (prefetched one layer ahead) next layer
-  f32x4 w_t1[CPW], w_t0[CPW], w_b[CPW];
-  f32x4 n_t1[CPW], n_t0[CPW], n_b[CPW];
-  auto load_A = [&](int l, f32x4 (&t1)[CPW], f32x4 (&t0)[CPW]) {
-    gf32x4_ptr A = as_global(lt_A[l]) + (int64_t)j * kcA * 64 + lane;
-#pragma unroll
-    for (int u = 0; u < CPW; ++u) {
-      t0[u] = A[(int64_t)(c0 + u) * 64];
-      t1[u] = A[(int64_t)(kcC + c0 + u) * 64];
-    }
-  };
-  auto load_B = [&](int l, f32x4 (&b)[CPW]) {
-    if (!owns_res || lt_i[4 * l + 2]) {   // B of layer l: [res rows (if the layer has a residual conv) ; skip rows]
-      gf32x4_ptr Bm = as_global(lt_B[l]) + (int64_t)lt_i[4 * l + 3] * kcC * 64 + lane;
-#pragma unroll
-      for (int u = 0; u < CPW; ++u) b[u] = Bm[(int64_t)(c0 + u) * 64];
-    }
-  };
-  // Epilogues run one output ELEMENT per thread: element e = (clip m, column n) of the 16x16 tile for
+  // Epilogues run one output ELEMENT per I/O thread: element e = (clip m, column n) of the 16x16 tile for
   // e < mg*16, so only real clips cost transcendental work.  `frag` is the element's float index inside a
   // 64-lane x 4-register MFMA accumulator image.
   const bool elem = tid < mg * 16;
@@ -324,59 +337,108 @@ __global__ __launch_bounds__(kPersistThreads) void wavenet_persist_kernel(const 
   const int frag = ((e_m >> 2) * 16 + e_n) * 4 + (e_m & 3);
   auto sum_partials = [&](const f32x4* part) -> float {
     const float* f = reinterpret_cast<const float*>(part) + frag;
-    float pv[NW];
+    float pv[NWM];
 #pragma unroll
-    for (int w = 0; w < NW; ++w) pv[w] = f[w * 256];   // all reads in flight before the first add
+    for (int w = 0; w < NWM; ++w) pv[w] = f[w * 256];   // all reads in flight before the first add
     __builtin_amdgcn_sched_barrier(0);
     float v = 0.f;
 #pragma unroll
-    for (int w = 0; w < NW; ++w) v += pv[w];
+    for (int w = 0; w < NWM; ++w) v += pv[w];
     return v;
   };
-  // history: float i = tid + k NT of a ring slot is (clip m0 + 2k, channel hc)   [NT == 2C]
-  // the workgroup's h_l[tau - d_l] (mg x C floats) rides in up to 8 registers per thread while in flight
-  constexpr int kHP = 8;
-  const int mgC = mg * C;                         // <= kHP * NT by construction (launch check)
-  const int hm0 = tid >= C ? 1 : 0, hc = tid - hm0 * C;
-  float hp[kHP];
-  auto ring_slot = [&](int l, int64_t pos) -> float* {
-    return h_ring + lt_off[l] + (int64_t)(pos & lt_i[4 * l + 1]) * slot_floats;
-  };
-  auto hist_load = [&](int l, int64_t tau) {
-    const float* src = ring_slot(l, tau - lt_i[4 * l]);
-#pragma unroll
-    for (int k = 0; k < kHP; ++k) {
-      if (k * NT >= mgC) break;                   // uniform
-      const int i = tid + k * NT;
-      hp[k] = i < mgC ? src[i] : 0.f;
-    }
-  };
-  auto hist_to_lds = [&](int l) {
-    float* dst = hprev0 + (l & 1) * 16 * ldh;
-#pragma unroll
-    for (int k = 0; k < kHP; ++k) {
-      if (k * NT >= mgC) break;
-      if (tid + k * NT < mgC) dst[(hm0 + 2 * k) * ldh + hc] = hp[k];
-    }
-  };
-  // h_l[tau] (LDS hbuf) -> ring of layer l; same thread <-> float mapping as hist_load, so a thread only ever
-  // reads back its own stores
-  auto ring_store = [&](int l, int64_t tau) {
-    float* dst = ring_slot(l, tau);
-#pragma unroll
-    for (int k = 0; k < kHP; ++k) {
-      if (k * NT >= mgC) break;
-      if (tid + k * NT < mgC) dst[tid + k * NT] = hbuf[(hm0 + 2 * k) * ldh + hc];
-    }
-  };
-  // conditioning product of (clip e_m, position, layer l, packed column 16 j + e_n), computed before the launch
-  auto cond_at = [&](int l, int64_t s) -> float {
-    return a.condall[(((int64_t)(m_first + e_m) * a.cond_steps + s) * L + l) * (2 * C) + j * 16 + e_n];
-  };
+  // gate: even packed columns hold f (tanh), odd columns g (sigmoid) of the same channel.  One code path for
+  // both: tanh(x) = 2 sigmoid(2x) - 1, so act = k / (1 + exp(-k x)) - (k - 1) with k = 2 | 1   (wavenet_v2.py:151)
+  const float gate_k = (e_n & 1) ? 1.f : 2.f;
+  const float gate_scale = -gate_k * 1.4426950408889634f;
+  const float gate_shift = 1.f - gate_k;
+  // where this thread's results go (granule indices inside the group's exchange buffers)
+  const unsigned y_slot = (unsigned)(e_m * C + j * 8 + (e_n >> 1));
+  const unsigned h_slot = (unsigned)(e_m * C + j * 16 + e_n);
+  const int res_off = e_m * ldh + j * 16 + e_n;          // residual input of the element (owners of residual rows)
   // first-round position of this thread's four granules in a sweep over mg x C values
   const int sw_row = (tid * 4) / C, sw_col = tid * 4 - sw_row * C;
+  float* const sw_h = hbuf + sw_row * ldh + sw_col;
+  float* const sw_y = ybuf + sw_row * ldy + sw_col;
 
-  // diagnostic build only: 100 MHz wall-clock stamps of the phases of owner 1 of group 0, summed over steps and layers
+  // ---- matrix-wave state ------------------------------------------------------------------------------
+  const int mt = tid - NIO;                               // matrix thread index (negative on I/O waves)
+  const int mwave = __builtin_amdgcn_readfirstlane(mt >> 6);
+  const int c0 = mwave * CPW;                             // this wave's chunk range inside a K = C product
+  // history: 16-byte piece q = mt + k NMT of a ring slot is (clip q / (C/4), channels 4 (q % (C/4)) ..)
+  constexpr int kHP = (16 * (C / 4) + NMT - 1) / NMT;     // pieces per thread for 16 clips
+  f32x4 hp[kHP];
+  // conditioning product of (clip, position, layer, packed column 16 j + e_n), computed before the launch:
+  // consecutive requests (layer l+1 of this step ... layer 0 of the next) are 2C floats apart; element
+  // e = mt + k NMT sits 4 NWM k clips further
+  constexpr int kCP = (256 + NMT - 1) / NMT;              // elements per matrix thread for 16 clips
+  const int64_t cond_clip = (int64_t)a.cond_steps * L * (2 * C);
+  gcfloat_ptr cptr = (gcfloat_ptr)(uintptr_t)(a.condall + (int64_t)(m_first + (mt >> 4)) * cond_clip + j * 16 + (mt & 15));
+  float cnd_n[kCP];
+  // weight fragments: byte offset of this lane inside a tile; chunk c0 + u is u KiB further
+  const unsigned w_voff = (unsigned)(c0 * 64 + lane) * 16u;
+  f32x4 w_t1[CPW], w_t0[CPW], w_b[CPW];
+  // MFMA A-operand addresses (LDS floats): row = lane & 15, this wave's K range
+  const int x_off = (lane & 15) * ldh + c0 * 16 + 4 * (lane >> 4);
+  const int xy_off = (lane & 15) * ldy + c0 * 16 + 4 * (lane >> 4);
+  unsigned cur_hasb = 0, nx_hasb = 0;                      // uniform: does this workgroup have B rows in the layer
+  u64 rq_A = 0, rq_B = 0;
+  // a request in two parts: `prepare` reads the layer's table entry into SGPRs and asks for the small pieces
+  // (delayed input, conditioning terms); the weight fragments of the NEXT layer are loaded straight into the
+  // registers of the fragment that the MFMA chain has just consumed (no second register set, no copies): one
+  // 1-KiB load per four MFMAs in phase A, the B fragments right after phase B.  The texture path moves the
+  // workgroup's 48 KiB of weights per layer (~0.3 us at 64 B/clk) under the matrix pipe's shadow, and the
+  // compiler's own vmcnt bookkeeping makes each MFMA group wait for exactly its fragment.
+  auto prepare = [&](int nl, unsigned ntau, bool with_cond) {
+    const u32x4 e0 = reinterpret_cast<const u32x4*>(ltab)[2 * nl];
+    const u32x4 e1 = reinterpret_cast<const u32x4*>(ltab)[2 * nl + 1];
+    rq_A = ((u64)sgpr(e0[1]) << 32) | sgpr(e0[0]);
+    rq_B = ((u64)sgpr(e0[3]) << 32) | sgpr(e0[2]);
+    const unsigned ring_off = sgpr(e1[0]), dil = sgpr(e1[1]), mask = sgpr(e1[2]);
+    nx_hasb = sgpr(e1[3]);
+    gf32x4_ptr src = (gf32x4_ptr)(uintptr_t)(h_ring + ring_off + (u64)((ntau - dil) & mask) * slot_bytes);
+#pragma unroll
+    for (int k = 0; k < kHP; ++k) {
+      if (k * NMT >= slot_f4) break;                        // uniform
+      if (mt + k * NMT < slot_f4) hp[k] = src[mt + k * NMT];
+    }
+    if (has_cond) {
+      if (with_cond) {
+#pragma unroll
+        for (int k = 0; k < kCP; ++k) {
+          if (k * NMT >= mg * 16) break;
+          if (mt + k * NMT < mg * 16) cnd_n[k] = cptr[(int64_t)k * (4 * NWM) * cond_clip];
+        }
+      }
+      cptr += 2 * C;
+    }
+  };
+  auto frag_A = [&](int i) -> f32x4 {   // fragment i of the requested layer: tap 0 chunks, then tap 1 chunks
+    gf32x4_ptr A0 = (gf32x4_ptr)(uintptr_t)(rq_A + w_voff);
+    gf32x4_ptr A1 = (gf32x4_ptr)(uintptr_t)(rq_A + (u64)kcC * 1024 + w_voff);
+    return i < CPW ? A0[i * 64] : A1[(i - CPW) * 64];
+  };
+  auto frag_B = [&](int i) -> f32x4 {
+    gf32x4_ptr B0 = (gf32x4_ptr)(uintptr_t)(rq_B + w_voff);
+    return B0[i * 64];
+  };
+  // the requested layer's small operands -> LDS (their loads were issued before the weight loads, so the
+  // compiler's wait leaves the weights in flight)
+  auto small_to_lds = [&]() {
+#pragma unroll
+    for (int k = 0; k < kHP; ++k) {
+      if (k * NMT >= slot_f4) break;
+      const int q = mt + k * NMT;
+      if (q < slot_f4) *reinterpret_cast<f32x4*>(hprev + (q / (C / 4)) * ldh + (q % (C / 4)) * 4) = hp[k];
+    }
+    if (has_cond) {
+#pragma unroll
+      for (int k = 0; k < kCP; ++k) {
+        if (k * NMT >= mg * 16) break;
+        if (mt + k * NMT < mg * 16) cndbuf[mt + k * NMT] = cnd_n[k];
+      }
+    }
+  };
+  // diagnostic build only: 100 MHz wall-clock stamps of thread 0 (an I/O wave) of owner 1 of group 0, summed
   unsigned long long st_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long st_prev = 0;
   auto stamp = [&](int slot) {
@@ -390,19 +452,17 @@ __global__ __launch_bounds__(kPersistThreads) void wavenet_persist_kernel(const 
   float skipacc = 0.f;                           // element threads of skip-row owners
   const int64_t tau0 = a.t0 - 1;
 
-  // Memory prefetch discipline.  vmcnt retires in order, so a poll issued behind a long-latency load only
-  // returns after it.  Everything a layer needs from memory (its weight fragments, its delayed input, its
-  // conditioning term) is therefore requested ONE LAYER AHEAD, at the top of the previous layer: right after a
-  // sweep (whose last poll drained every older request) and right before that layer's MFMAs and epilogue, which
-  // do not touch memory - the latency hides under compute and under the wait for the other workgroups.
-  float cnd = 0.f, cnd_n = 0.f;
-  hist_load(0, tau0);
-  load_A(0, n_t1, n_t0);
-  load_B(0, n_b);
-  if (elem && has_cond) cnd_n = cond_at(0, 0);
+  if (!is_io) {   // layer 0 of the first step: requested and put in place right away (once per launch)
+    prepare(0, (unsigned)tau0, true);
+#pragma unroll
+    for (int u = 0; u < CPW; ++u) { w_t0[u] = frag_A(u); w_t1[u] = frag_A(CPW + u); w_b[u] = frag_B(u); }
+    small_to_lds();
+    cur_hasb = nx_hasb;
+  }
 
   for (int64_t s = 0; s < a.n_steps; ++s) {
     const int64_t tau = tau0 + s;
+    const unsigned tau_u = (unsigned)tau;
     // ---- input 0: embedding row of the newest sample ---------------------------------------
     if (s > 0 && !a.teacher_forced) {
       // classes sampled by the previous step arrive as granules (epoch = s)
@@ -427,96 +487,131 @@ __global__ __launch_bounds__(kPersistThreads) void wavenet_persist_kernel(const 
     }
     __syncthreads();
     if (*s_fail) return;
-    {
-      float* ring0 = ring_slot(0, tau);
-#pragma unroll
-      for (int k = 0; k < kHP; ++k) {
-        if (k * NT >= mgC) break;
-        if (tid + k * NT < mgC) {
-          const int cls = s_idx[hm0 + 2 * k];
-          // torch raises on an out-of-range class; keep memory safe and make it visible (NaN row)
-          const float v = (cls >= 0 && cls < a.q_levels) ? a.emb[(int64_t)cls * C + hc] : __builtin_nanf("");
-          hbuf[(hm0 + 2 * k) * ldh + hc] = v;
-          ring0[tid + k * NT] = v;
-        }
+    if (is_io) {
+      const u32x4 e1 = reinterpret_cast<const u32x4*>(ltab)[1];
+      gf32x4_wptr ring0 = (gf32x4_wptr)(uintptr_t)(h_ring + sgpr(e1[0]) + (u64)(tau_u & sgpr(e1[2])) * slot_bytes);
+      for (int q = tid; q < slot_f4; q += NIO) {
+        const int m = q / (C / 4), c = (q % (C / 4)) * 4;
+        const int cls = s_idx[m];
+        // torch raises on an out-of-range class; keep memory safe and make it visible (NaN row)
+        const float nanv = __builtin_nanf("");
+        const f32x4 v = (cls >= 0 && cls < a.q_levels) ? *reinterpret_cast<const f32x4*>(a.emb + (int64_t)cls * C + c)
+                                                       : f32x4{nanv, nanv, nanv, nanv};
+        *reinterpret_cast<f32x4*>(hbuf + m * ldh + c) = v;
+        ring0[q] = v;
       }
     }
-    hist_to_lds(0);
-#pragma unroll
-    for (int u = 0; u < CPW; ++u) { w_t1[u] = n_t1[u]; w_t0[u] = n_t0[u]; w_b[u] = n_b[u]; }
-    cnd = cnd_n;
     __syncthreads();
     if (STAMPS) st_prev = wall_clock64();
 
-    for (int l = 0;; ++l) {   // leaves through the `last` branch at the bottom (keeps that path off the back edge)
-      const unsigned epoch = (unsigned)(s * L + l + 1);
-      const bool last = (l + 1 == L);
-      const bool has_b = !owns_res || lt_i[4 * l + 2];
-      // requests for the next layer (after the last layer: layer 0 of the next step).  Nothing is outstanding
-      // here (a sweep or the step prologue just drained vmcnt); saying so keeps the compiler from guarding the
-      // registers it recycles for the address arithmetic below with partial waits between the requests.
-      __builtin_amdgcn_s_waitcnt(0x0F70);
-      if (!last || s + 1 < a.n_steps) {
-        const int nl = last ? 0 : l + 1;
-        hist_load(nl, last ? tau + 1 : tau);
-        if (elem && has_cond) cnd_n = cond_at(nl, last ? s + 1 : s);
-        load_A(nl, n_t1, n_t0);
-        load_B(nl, n_b);
-      }
-      stamp(8);   // requests issued
-      // ---- phase A (critical): z = W0.h[tau-d] + W1.h[tau] + cond + b ; gate ; publish y -------------
-      redA[wave * 64 + lane] = tile_mma_reg2<CPW>(hprev0 + (l & 1) * 16 * ldh, w_t0, hbuf, w_t1, ldh, c0, lane);
-      __syncthreads();
-      stamp(9);   // A: LDS reads + MFMA + barrier
-      u64* gran_y = gran_y0 + (int64_t)(l & 1) * 16 * C;
-      if (elem) {
-        const float f = sum_partials(redA) + cnd + biasA[l * 16 + e_n];
-        // even columns hold f, odd columns g of the same channel: one transcendental per thread
-        const float act = (e_n & 1) ? fast_sigmoid(f) : fast_tanh(f);
-        const float other = __shfl_down(act, 1);
-        if (!(e_n & 1)) gran_store<XCD>(gran_y + e_m * C + j * 8 + (e_n >> 1), epoch, act * other);
-      }
-      // this layer's input joins its history ring while the other workgroups' y slices are on their way
-      if (l > 0) ring_store(l, tau);
-      stamp(0);   // A: epilogue + publish + ring store
-      // ---- phase B (critical): wait y ; [res | skip] tile ----------------------------------------
-      if (has_b) {
-        if (!sweep<NT>(gran_y, mg * C, C, epoch, ybuf, ldy, C, sw_row, sw_col, err, s_fail)) return;
-        stamp(1);   // wait y
-        redB[wave * 64 + lane] = tile_mma_reg<CPW>(ybuf, ldy, w_b, c0, lane, f32x4{0.f, 0.f, 0.f, 0.f});
-        __syncthreads();
+    if (is_io) {
+      // ================================ I/O waves ================================
+      for (int l = 0;; ++l) {
+        const unsigned epoch = (unsigned)(s * L + l + 1);
+        const bool last = (l + 1 == L);
+        const u32x4 e1 = reinterpret_cast<const u32x4*>(ltab)[2 * l + 1];
+        const unsigned ring_off = sgpr(e1[0]), ring_mask = sgpr(e1[2]), hasb = sgpr(e1[3]);
+        __syncthreads();                                   // B1: phase-A partials are in LDS
+        stamp(0);   // wait for phase A
+        u64* gran_y = gran_y0 + (l & 1) * 16 * C;
         if (elem) {
-          const float vb = sum_partials(redB) + biasB[l * 16 + e_n];
-          if (owns_res)
-            gran_store<XCD>(gran_h + e_m * C + j * 16 + e_n, epoch, hbuf[e_m * ldh + j * 16 + e_n] + vb);
-          else
-            skipacc = (l == 0) ? vb : vb + skipacc;
+          const float f = sum_partials(redA) + cndbuf[tid] + biasA[l * 16 + e_n];
+          const float act = fmaf(__frcp_rn(1.0f + __builtin_amdgcn_exp2f(f * gate_scale)), gate_k, gate_shift);
+          // lane i takes lane i+1's value (row_shl:1): the even lane multiplies tanh(f) by its neighbour's sigmoid(g)
+          const float other = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(act), 0x101, 0xf, 0xf, false));
+          if (!(e_n & 1)) gran_store<XCD>(gran_y + y_slot, epoch, act * other);
+        }
+        // this layer's input joins its history ring while the other workgroups' y slices are on their way
+        if (l > 0) {
+          gf32x4_wptr dst = (gf32x4_wptr)(uintptr_t)(h_ring + ring_off + (u64)(tau_u & ring_mask) * slot_bytes);
+          for (int q = tid; q < slot_f4; q += NIO)
+            dst[q] = *reinterpret_cast<const f32x4*>(hbuf + (q / (C / 4)) * ldh + (q % (C / 4)) * 4);
+        }
+        stamp(1);   // epilogue A + publish + ring store
+        if (hasb) {
+          if (!sweep<NIO>(gran_y, mg * C, epoch, sw_y, ybuf, C, ldy, err, s_fail)) return;   // ... B2
+          stamp(2);   // wait y
+          __syncthreads();                                 // B3: phase-B partials are in LDS
+          stamp(3);   // wait for phase B
+          if (elem) {
+            const float vb = sum_partials(redB) + biasB[l * 16 + e_n];
+            if (owns_res)
+              gran_store<XCD>(gran_h + h_slot, epoch, hbuf[res_off] + vb);
+            else
+              skipacc = (l == 0) ? vb : vb + skipacc;
+          }
+          stamp(4);   // epilogue B + publish
+        }
+        if (!last) {
+          if (!sweep<NIO>(gran_h, mg * C, epoch, sw_h, hbuf, C, ldh, err, s_fail)) return;   // ... B4
+          stamp(5);   // wait h'
+        } else {
+          __syncthreads();                                 // B4
+          break;
         }
       }
-      stamp(2);   // phase B
-      // ---- wait for the next layer's input; its delayed input moves from registers to LDS first ----
-      if (!last) {
-        hist_to_lds(l + 1);
-        if (!sweep<NT>(gran_h, mg * C, C, epoch, hbuf, ldh, C, sw_row, sw_col, err, s_fail)) return;
+    } else {
+      // =============================== matrix waves ===============================
+      for (int l = 0;; ++l) {
+        const bool last = (l + 1 == L);
+        // The very last layer of a launch re-requests layer 0 (unused) so that the sequence stays branch-free.
+        prepare(last ? 0 : l + 1, last ? tau_u + 1 : tau_u, !last || s + 1 < a.n_steps);
+        // ---- phase A: z = W0.h[tau-d] + W1.h[tau]  (K = 2C, this wave's chunks) ----
+        {
+          const float* x0 = hprev + x_off;
+          const float* x1 = hbuf + x_off;
+          f32x4 xa[CPW], xb[CPW];
 #pragma unroll
-        for (int u = 0; u < CPW; ++u) { w_t1[u] = n_t1[u]; w_t0[u] = n_t0[u]; w_b[u] = n_b[u]; }
-        cnd = cnd_n;
-        stamp(3);   // wait h'
-      } else {
-        __syncthreads();
-        stamp(3);
-        break;
+          for (int u = 0; u < CPW; ++u) {
+            xa[u] = *reinterpret_cast<const f32x4*>(x0 + u * 16);
+            xb[u] = *reinterpret_cast<const f32x4*>(x1 + u * 16);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int u = 0; u < CPW; ++u) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[u][i], w_t0[u][i], acc, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            w_t0[u] = frag_A(u);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+#pragma unroll
+          for (int u = 0; u < CPW; ++u) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xb[u][i], w_t1[u][i], acc, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            w_t1[u] = frag_A(CPW + u);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+          redA[mwave * 64 + lane] = acc;
+        }
+        __syncthreads();                                   // B1
+        if (cur_hasb) {
+          __syncthreads();                                 // B2: y is in LDS
+          if (*s_fail) return;
+          redB[mwave * 64 + lane] = tile_mma_reg<CPW>(ybuf + xy_off, w_b);
+          __syncthreads();                                 // B3
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < CPW; ++u) w_b[u] = frag_B(u);
+        small_to_lds();
+        __syncthreads();                                   // B4
+        if (*s_fail) return;
+        cur_hasb = nx_hasb;
+        if (last) break;
       }
     }
     if (a.teacher_forced) continue;
 
     // ---- head -----------------------------------------------------------------------------------
     const unsigned he = (unsigned)(s + 1);
-    if (elem && !owns_res) gran_store<XCD>(gran_skip + e_m * a.S + (j - kcC) * 16 + e_n, he, skipacc);
+    if (elem && !owns_res) gran_store<XCD>(gran_skip + e_m * C + (j - kcC) * 16 + e_n, he, skipacc);
     // fc0 + Mish : tiles j, j+Gn, ... of H1/16
-    const int t_fc0 = a.H1 / 16, kc_fc0 = a.S / 16;
+    const int t_fc0 = a.H1 / 16, kc_fc0 = C / 16;
     if (j < t_fc0) {
-      if (!sweep<NT>(gran_skip, mg * a.S, a.S, he, ybuf, ldy, C, sw_row, sw_col, err, s_fail)) return;
+      if (!sweep<NT>(gran_skip, mg * C, he, sw_y, ybuf, C, ldy, err, s_fail)) return;
       const int per = (kc_fc0 + nw - 1) / nw;
       const int k0 = min(wave * per, kc_fc0), k1 = min(k0 + per, kc_fc0);
       for (int t = j; t < t_fc0; t += a.Gn) {
@@ -535,7 +630,7 @@ __global__ __launch_bounds__(kPersistThreads) void wavenet_persist_kernel(const 
     // fc2 : tiles of the (n_classes + temperature column) outputs
     const int t_fc2 = a.n_logits_pad / 16, kc_fc2 = a.H1 / 16;
     if (j < t_fc2) {
-      if (!sweep<NT>(gran_hid, mg * a.H1, a.H1, he, ybuf, ldy, C, sw_row, sw_col, err, s_fail)) return;
+      if (!sweep<NT>(gran_hid, mg * a.H1, he, nullptr, ybuf, a.H1, ldy, err, s_fail)) return;
       const int per = (kc_fc2 + nw - 1) / nw;
       const int k0 = min(wave * per, kc_fc2), k1 = min(k0 + per, kc_fc2);
       for (int t = j; t < t_fc2; t += a.Gn) {
@@ -553,7 +648,7 @@ __global__ __launch_bounds__(kPersistThreads) void wavenet_persist_kernel(const 
     }
     // temperature column + argmax / inverse-CDF sample : owner 0 of the group, one clip per wave
     if (j == 0) {
-      if (!sweep<NT>(gran_logit, mg * a.n_logits_pad, a.n_logits_pad, he, lbuf, ldl, C, sw_row, sw_col, err, s_fail)) return;
+      if (!sweep<NT>(gran_logit, mg * a.n_logits_pad, he, nullptr, lbuf, a.n_logits_pad, ldl, err, s_fail)) return;
       const int nc = a.n_classes;
       const int per = (nc + 63) / 64;
       for (int m = wave; m < mg; m += nw) {
@@ -638,40 +733,41 @@ __global__ __launch_bounds__(kPersistThreads) void wavenet_persist_kernel(const 
   }
 }
 
-size_t wn_persist_lds_bytes(const WnPersistArgs& a, int nw) {
-  const int wide = a.C > a.S ? (a.C > a.H1 ? a.C : a.H1) : (a.S > a.H1 ? a.S : a.H1);
+size_t wn_persist_lds_bytes(const WnPersistArgs& a) {
+  const int kc = a.C / 16, nwm = kc / wn_cpw(kc), nw = kIoWaves + nwm;
+  const int wide = a.C > a.H1 ? a.C : a.H1;
   const int ldh = a.C + 4, ldy = wide + 4, ldl = a.n_logits_pad + 4;
-  return (size_t)3 * 16 * ldh * 4 + (size_t)16 * ldy * 4 + (size_t)2 * nw * 64 * 16 + (size_t)a.L * 24 +
-         (size_t)((a.L * 16 + 15) / 16) * 16 + (size_t)a.L * 128 + 16 * 4 + 16 + (size_t)16 * ldl * 4;
+  const int red = (2 * nwm > nw ? 2 * nwm : nw) * 64;
+  return (size_t)2 * 16 * ldh * 4 + (size_t)16 * ldy * 4 + (size_t)red * 16 + (size_t)a.L * 32 + (size_t)a.L * 128 +
+         256 * 4 + 16 * 4 + 16 + (size_t)16 * ldl * 4;
 }
 
 int launch_wavenet_persist(const WnPersistArgs& a, hipStream_t stream) {
-  const int cpw = 2;                         // K-chunks of a K = C product per wave
-  const int nw = a.C / (16 * cpw);
-  if (nw < 1 || nw > 8 || a.C % 32) return fail(MMK_ERR_UNSUPPORTED, "persistent WaveNet: C=%d not in {32..256 step 32}", a.C);
-  if ((int64_t)a.Mg * a.C > 8 * 64 * nw) return fail(MMK_ERR_UNSUPPORTED, "persistent WaveNet: %d clips per group do not fit the history prefetch", a.Mg);
-  const size_t lds = wn_persist_lds_bytes(a, nw);
+  const int kc = a.C / 16;
+  if (kc < 2 || kc > 16 || a.C % 32 || a.S != a.C) return fail(MMK_ERR_UNSUPPORTED, "persistent WaveNet: C=%d not in {32..256 step 32}", a.C);
+  if (a.Mg > 16) return fail(MMK_ERR_UNSUPPORTED, "persistent WaveNet: %d clips per group", a.Mg);
+  const size_t lds = wn_persist_lds_bytes(a);
   if (lds > 160 * 1024) return fail(MMK_ERR_UNSUPPORTED, "persistent WaveNet: %zu bytes of LDS needed", lds);
-  dim3 grid(a.Gc * a.Gn), block(64 * nw);
-#define MMK_WNP(NW_)                                                                                               \
-  do {                                                                                                             \
-    if (a.stamps) {                                                                                                \
-      if (a.xcd_local) hipLaunchKernelGGL((wavenet_persist_kernel<2, NW_, true, true>), grid, block, lds, stream, a);   \
-      else hipLaunchKernelGGL((wavenet_persist_kernel<2, NW_, true, false>), grid, block, lds, stream, a);              \
-    } else {                                                                                                       \
-      if (a.xcd_local) hipLaunchKernelGGL((wavenet_persist_kernel<2, NW_, false, true>), grid, block, lds, stream, a);  \
-      else hipLaunchKernelGGL((wavenet_persist_kernel<2, NW_, false, false>), grid, block, lds, stream, a);             \
-    }                                                                                                              \
+  dim3 grid(a.Gc * a.Gn), block(wn_threads(kc));
+#define MMK_WNP(KC_)                                                                                            \
+  do {                                                                                                          \
+    if (a.stamps) {                                                                                             \
+      if (a.xcd_local) hipLaunchKernelGGL((wavenet_persist_kernel<KC_, true, true>), grid, block, lds, stream, a);   \
+      else hipLaunchKernelGGL((wavenet_persist_kernel<KC_, true, false>), grid, block, lds, stream, a);              \
+    } else {                                                                                                    \
+      if (a.xcd_local) hipLaunchKernelGGL((wavenet_persist_kernel<KC_, false, true>), grid, block, lds, stream, a);  \
+      else hipLaunchKernelGGL((wavenet_persist_kernel<KC_, false, false>), grid, block, lds, stream, a);             \
+    }                                                                                                           \
   } while (0)
-  switch (nw) {
-    case 1: MMK_WNP(1); break;
+  switch (kc) {
     case 2: MMK_WNP(2); break;
-    case 3: MMK_WNP(3); break;
     case 4: MMK_WNP(4); break;
-    case 5: MMK_WNP(5); break;
     case 6: MMK_WNP(6); break;
-    case 7: MMK_WNP(7); break;
-    default: MMK_WNP(8); break;
+    case 8: MMK_WNP(8); break;
+    case 10: MMK_WNP(10); break;
+    case 12: MMK_WNP(12); break;
+    case 14: MMK_WNP(14); break;
+    default: MMK_WNP(16); break;
   }
 #undef MMK_WNP
   MMK_HIP(hipGetLastError());

@@ -217,10 +217,7 @@ static int derive(mmk_wavenet_plan* p) {
     if (gc_max < 1) gc_max = 1;
     // clips per group: one MFMA row tile (16) at most, and one epilogue element per thread
     // (16 columns x Mg clips <= 64 * C/32 threads)
-    const char* cpw_env = getenv("MMK_WN_CPW");
-    const int cpw_sel = (cpw_env && atoi(cpw_env) == 4 && p->C % 64 == 0) ? 4 : 2;
-    const int nw_sel = p->C / (16 * cpw_sel);
-    const int mg_cap = 16 < 4 * nw_sel ? 16 : 4 * nw_sel;
+    const int mg_cap = 16;                           // one MFMA row tile; one epilogue element per I/O thread
     int gc = (p->Bmax + 7) / 8;                      // aim at 8 clips per group
     const char* genv = getenv("MMK_WN_GROUPS");
     if (genv && atoi(genv) > 0) gc = atoi(genv);
@@ -251,6 +248,7 @@ static int derive(mmk_wavenet_plan* p) {
         off += (int64_t)ring * p->Mg * p->C;      // one slot = the group's clips x C
       }
       p->ring_floats_per_wg = off;
+      if (off * 4 >= ((int64_t)1 << 32)) p->persistent = false;   // ring offsets are 32-bit byte offsets in the kernel
       if (p->C1 > 0) p->cond_all.set_geometry(p->L * 2 * p->C, {p->C1});
     }
   }
@@ -438,6 +436,10 @@ extern "C" int mmk_wavenet_commit(mmk_wavenet_plan* p, void* workspace, size_t w
       tab[l].A_bias = p->A[l].bias;
       tab[l].B_wp = p->Bm[l].Wp;
       tab[l].B_bias = p->Bm[l].bias;
+    }
+    if (const char* x = getenv("MMK_WN_EXPERIMENT_SAME_WEIGHTS"); x && x[0] == '1') {
+      // timing experiment only (results are wrong): every layer reads layer 0's weights, which then stay in L2
+      for (int l = 1; l < L; ++l) { tab[l].A_wp = tab[0].A_wp; tab[l].B_wp = tab[0].B_wp; }
     }
     MMK_HIP(hipMemcpyAsync(p->layer_tab, tab.data(), sizeof(WnLayerTab) * L, hipMemcpyHostToDevice, st));
     MMK_HIP(hipStreamSynchronize(st));   // `tab` is host-local
@@ -774,9 +776,9 @@ extern "C" int mmk_wavenet_sync_status(mmk_wavenet_plan* p, mmk_stream_t stream)
     if (senv && senv[0] == '1') {
       unsigned long long st[16];
       MMK_HIP(hipMemcpy(st, p->tau + 8, sizeof(st), hipMemcpyDeviceToHost));
-      const char* names[7] = {"requests", "A mfma+barrier", "A epilogue+publish", "wait y", "B", "wait h'", "head"};
-      const int slot[7] = {8, 9, 0, 1, 2, 3, 6};
-      fprintf(stderr, "[mmk stamps] last persistent launch, workgroup 1, totals in ms:");
+      const char* names[7] = {"wait phase A", "epilogue A + publish", "wait y", "wait phase B", "epilogue B + publish", "wait h'", "head"};
+      const int slot[7] = {0, 1, 2, 3, 4, 5, 6};
+      fprintf(stderr, "[mmk stamps] last persistent launch, I/O wave 0 of workgroup 1, totals in ms:");
       for (int i = 0; i < 7; ++i) fprintf(stderr, " %s=%.3f;", names[i], st[slot[i]] * 1e-5);
       fprintf(stderr, " shader clock=%.0f MHz;", st[13] ? 100.0 * (double)st[12] / (double)st[13] : 0.0);
       fprintf(stderr, "\n");
