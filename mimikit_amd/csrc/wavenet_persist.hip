@@ -172,6 +172,19 @@ __device__ __forceinline__ f32x4 tile_mma_reg2(const float* x0, const f32x4 (&w0
   return acc;
 }
 
+// One step of the K loop of the per-layer products.
+//   SMALL == false: v_mfma_f32_16x16x4_f32 - rows = 16 clips (lane & 15), K = 4 per instruction.
+//   SMALL == true : v_mfma_f32_4x4x1_16b_f32 - 16 independent 4x4 blocks, K = 1 per instruction.  Block b = lane / 4
+//     handles output columns 4 (b % 4) .. +3 for k sub-slice b / 4; A operand = x[clip lane % 4][k], B operand =
+//     W[column lane % 16][k], D register i of lane = (clip i, column lane % 16).  With at most 4 clips per group
+//     a 16-row tile would be 3/4 padding; this form does the same arithmetic in a quarter of the matrix-pipe time
+//     (layout measured with scripts/probes/mfma4x4.hip).
+template <bool SMALL>
+__device__ __forceinline__ f32x4 mma_step(float x, float w, f32x4 acc) {
+  if (SMALL) return __builtin_amdgcn_mfma_f32_4x4x1f32(x, w, acc, 0, 0, 0);
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(x, w, acc, 0, 0, 0);
+}
+
 // cross-wave reduction in fixed order; result valid in wave 0 only (head phases)
 __device__ __forceinline__ f32x4 reduce_waves(f32x4 acc, f32x4* red, int wave, int lane, int nw) {
   red[wave * 64 + lane] = acc;
@@ -213,9 +226,10 @@ constexpr int wn_threads(int kc) { return 64 * (kIoWaves + kc / wn_cpw(kc)); }
 //   * matrix waves (4..) never poll: they request the next layer's weight fragments, delayed input and
 //     conditioning terms (one layer ahead, the fragment loads interleaved with the MFMA chain whose dependent
 //     issue leaves the slots free), run the MFMAs, and pass the small operands on through LDS.
-// Both kinds meet at the same four workgroup barriers per layer:
-//   B1 phase-A partials in LDS | B2 y in LDS | B3 phase-B partials in LDS | B4 next input (+ delayed input) in LDS
-template <int KC, bool STAMPS, bool XCD>
+// Both kinds meet at the same six workgroup barriers per layer:
+//   B1 phase-A partials in LDS | B1b y published | B2 y in LDS | B3 phase-B partials in LDS | B3b h' published |
+//   B4 next input (+ delayed input) in LDS
+template <int KC, bool SMALL, bool STAMPS, bool XCD>
 __global__ __launch_bounds__(wn_threads(KC)) void wavenet_persist_kernel(const WnPersistArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   constexpr int CPW = wn_cpw(KC);      // K-chunks of a K = C product per matrix wave
@@ -334,16 +348,19 @@ __global__ __launch_bounds__(wn_threads(KC)) void wavenet_persist_kernel(const W
   // 64-lane x 4-register MFMA accumulator image.
   const bool elem = tid < mg * 16;
   const int e_m = tid >> 4, e_n = tid & 15;
-  const int frag = ((e_m >> 2) * 16 + e_n) * 4 + (e_m & 3);
+  // 16x16 tiles: (row m, col n) sits in lane 16 (m / 4) + n, register m % 4; one partial per matrix wave.
+  // 4x4 blocks  : (clip m, col n) sits in lane 16 ks + n, register m, for each of the 4 k sub-slices ks.
+  const int frag = SMALL ? e_n * 4 + e_m : ((e_m >> 2) * 16 + e_n) * 4 + (e_m & 3);
+  constexpr int kParts = SMALL ? 4 * NWM : NWM;
   auto sum_partials = [&](const f32x4* part) -> float {
     const float* f = reinterpret_cast<const float*>(part) + frag;
-    float pv[NWM];
+    float pv[kParts];
 #pragma unroll
-    for (int w = 0; w < NWM; ++w) pv[w] = f[w * 256];   // all reads in flight before the first add
+    for (int w = 0; w < kParts; ++w) pv[w] = f[w * (SMALL ? 64 : 256)];   // all reads in flight before the first add
     __builtin_amdgcn_sched_barrier(0);
     float v = 0.f;
 #pragma unroll
-    for (int w = 0; w < NWM; ++w) v += pv[w];
+    for (int w = 0; w < kParts; ++w) v += pv[w];
     return v;
   };
   // gate: even packed columns hold f (tanh), odd columns g (sigmoid) of the same channel.  One code path for
@@ -375,11 +392,18 @@ __global__ __launch_bounds__(wn_threads(KC)) void wavenet_persist_kernel(const W
   gcfloat_ptr cptr = (gcfloat_ptr)(uintptr_t)(a.condall + (int64_t)(m_first + (mt >> 4)) * cond_clip + j * 16 + (mt & 15));
   float cnd_n[kCP];
   // weight fragments: byte offset of this lane inside a tile; chunk c0 + u is u KiB further
-  const unsigned w_voff = (unsigned)(c0 * 64 + lane) * 16u;
+  // (4x4 blocks: the lane's k sub-slice ks = lane / 16 starts 4 CPW ks floats into the wave's slice; its fragment u
+  //  holds W[column lane % 16][4 consecutive k], which is element (q, n) of a chunk of the SAME packed matrix)
+  constexpr int kFragStride = SMALL ? 16 : 64;               // f32x4 elements between a lane's consecutive fragments
+  const int sm_k0 = (lane >> 4) * 4 * CPW;                   // first k of the lane's sub-slice inside the wave's slice
+  const unsigned w_voff = SMALL ? (unsigned)((c0 + sm_k0 / 16) * 64 + ((sm_k0 % 16) / 4) * 16 + (lane & 15)) * 16u
+                                : (unsigned)(c0 * 64 + lane) * 16u;
   f32x4 w_t1[CPW], w_t0[CPW], w_b[CPW];
   // MFMA A-operand addresses (LDS floats): row = lane & 15, this wave's K range
-  const int x_off = (lane & 15) * ldh + c0 * 16 + 4 * (lane >> 4);
-  const int xy_off = (lane & 15) * ldy + c0 * 16 + 4 * (lane >> 4);
+  // (4x4 blocks: row = clip lane % 4, the lane's own 4 CPW consecutive k)
+  constexpr int kXStride = SMALL ? 4 : 16;                   // floats between a lane's consecutive A-operand reads
+  const int x_off = SMALL ? (lane & 3) * ldh + c0 * 16 + sm_k0 : (lane & 15) * ldh + c0 * 16 + 4 * (lane >> 4);
+  const int xy_off = SMALL ? (lane & 3) * ldy + c0 * 16 + sm_k0 : (lane & 15) * ldy + c0 * 16 + 4 * (lane >> 4);
   unsigned cur_hasb = 0, nx_hasb = 0;                      // uniform: does this workgroup have B rows in the layer
   u64 rq_A = 0, rq_B = 0;
   // a request in two parts: `prepare` reads the layer's table entry into SGPRs and asks for the small pieces
@@ -415,11 +439,11 @@ __global__ __launch_bounds__(wn_threads(KC)) void wavenet_persist_kernel(const W
   auto frag_A = [&](int i) -> f32x4 {   // fragment i of the requested layer: tap 0 chunks, then tap 1 chunks
     gf32x4_ptr A0 = (gf32x4_ptr)(uintptr_t)(rq_A + w_voff);
     gf32x4_ptr A1 = (gf32x4_ptr)(uintptr_t)(rq_A + (u64)kcC * 1024 + w_voff);
-    return i < CPW ? A0[i * 64] : A1[(i - CPW) * 64];
+    return i < CPW ? A0[i * kFragStride] : A1[(i - CPW) * kFragStride];
   };
   auto frag_B = [&](int i) -> f32x4 {
     gf32x4_ptr B0 = (gf32x4_ptr)(uintptr_t)(rq_B + w_voff);
-    return B0[i * 64];
+    return B0[i * kFragStride];
   };
   // the requested layer's small operands -> LDS (their loads were issued before the weight loads, so the
   // compiler's wait leaves the weights in flight)
@@ -521,6 +545,7 @@ __global__ __launch_bounds__(wn_threads(KC)) void wavenet_persist_kernel(const W
           const float other = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(act), 0x101, 0xf, 0xf, false));
           if (!(e_n & 1)) gran_store<XCD>(gran_y + y_slot, epoch, act * other);
         }
+        __syncthreads();                                   // B1b: y is on its way - the matrix waves may use the memory pipe
         // this layer's input joins its history ring while the other workgroups' y slices are on their way
         if (l > 0) {
           gf32x4_wptr dst = (gf32x4_wptr)(uintptr_t)(h_ring + ring_off + (u64)(tau_u & ring_mask) * slot_bytes);
@@ -540,6 +565,7 @@ __global__ __launch_bounds__(wn_threads(KC)) void wavenet_persist_kernel(const W
             else
               skipacc = (l == 0) ? vb : vb + skipacc;
           }
+          __syncthreads();                                 // B3b: h' is on its way
           stamp(4);   // epilogue B + publish
         }
         if (!last) {
@@ -552,10 +578,15 @@ __global__ __launch_bounds__(wn_threads(KC)) void wavenet_persist_kernel(const W
       }
     } else {
       // =============================== matrix waves ===============================
-      for (int l = 0;; ++l) {
+      // A counted loop without exits: every iteration issues the same loads in the same order, so the compiler's
+      // vmcnt bookkeeping is exact and an MFMA group waits for its own fragment only (with an exit or a skipped
+      // load on some path it has to assume the shortest one, and phase A ends up waiting for the delayed-input
+      // load issued just before it).  A hand-off timeout is noticed after the loop.
+      for (int l = 0; l < L; ++l) {
         const bool last = (l + 1 == L);
         // The very last layer of a launch re-requests layer 0 (unused) so that the sequence stays branch-free.
         prepare(last ? 0 : l + 1, last ? tau_u + 1 : tau_u, !last || s + 1 < a.n_steps);
+        stamp(8);    // small requests issued
         // ---- phase A: z = W0.h[tau-d] + W1.h[tau]  (K = 2C, this wave's chunks) ----
         {
           const float* x0 = hprev + x_off;
@@ -563,45 +594,65 @@ __global__ __launch_bounds__(wn_threads(KC)) void wavenet_persist_kernel(const W
           f32x4 xa[CPW], xb[CPW];
 #pragma unroll
           for (int u = 0; u < CPW; ++u) {
-            xa[u] = *reinterpret_cast<const f32x4*>(x0 + u * 16);
-            xb[u] = *reinterpret_cast<const f32x4*>(x1 + u * 16);
+            xa[u] = *reinterpret_cast<const f32x4*>(x0 + u * kXStride);
+            xb[u] = *reinterpret_cast<const f32x4*>(x1 + u * kXStride);
           }
           __builtin_amdgcn_sched_barrier(0);
           f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
           for (int u = 0; u < CPW; ++u) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[u][i], w_t0[u][i], acc, 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            w_t0[u] = frag_A(u);
-            __builtin_amdgcn_sched_barrier(0);
+            for (int i = 0; i < 4; ++i) acc = mma_step<SMALL>(xa[u][i], w_t0[u][i], acc);
           }
 #pragma unroll
           for (int u = 0; u < CPW; ++u) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xb[u][i], w_t1[u][i], acc, 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            w_t1[u] = frag_A(CPW + u);
-            __builtin_amdgcn_sched_barrier(0);
+            for (int i = 0; i < 4; ++i) acc = mma_step<SMALL>(xb[u][i], w_t1[u][i], acc);
           }
           redA[mwave * 64 + lane] = acc;
         }
+        stamp(9);    // phase A: operand reads, (wait for the fragments), MFMAs with the next fragments' loads
         __syncthreads();                                   // B1
+        __syncthreads();                                   // B1b: the I/O waves have published y
+        // The workgroup shares one memory pipe, in order (requests AND returns): a burst of fragment loads in
+        // front of a publish delays the publish, and a poll behind a slow load returns after it.  So the next
+        // layer's fragments are requested right AFTER each publish, while its echo cannot be back yet anyway
+        // (measured: requesting them under the MFMA chain instead costs 10 us per step on cfg4).
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < CPW; ++u) { w_t0[u] = frag_A(u); w_t1[u] = frag_A(CPW + u); }
+        __builtin_amdgcn_sched_barrier(0);
+        stamp(10);   // epilogue A of the I/O waves
         if (cur_hasb) {
           __syncthreads();                                 // B2: y is in LDS
-          if (*s_fail) return;
-          redB[mwave * 64 + lane] = tile_mma_reg<CPW>(ybuf + xy_off, w_b);
+          stamp(11);   // wait for y
+          {
+            f32x4 xv[CPW];
+#pragma unroll
+            for (int u = 0; u < CPW; ++u) xv[u] = *reinterpret_cast<const f32x4*>(ybuf + xy_off + u * kXStride);
+            __builtin_amdgcn_sched_barrier(0);
+            f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int u = 0; u < CPW; ++u) {
+#pragma unroll
+              for (int i = 0; i < 4; ++i) acc = mma_step<SMALL>(xv[u][i], w_b[u][i], acc);
+            }
+            redB[mwave * 64 + lane] = acc;
+          }
           __syncthreads();                                 // B3
+          __syncthreads();                                 // B3b: the I/O waves have published h'
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int u = 0; u < CPW; ++u) w_b[u] = frag_B(u);
+        __builtin_amdgcn_sched_barrier(0);
         small_to_lds();
+        stamp(12);   // phase B + B3 + small operands to LDS
         __syncthreads();                                   // B4
-        if (*s_fail) return;
+        stamp(13);   // wait for h'
         cur_hasb = nx_hasb;
-        if (last) break;
       }
+      if (*s_fail) return;
     }
     if (a.teacher_forced) continue;
 
@@ -726,10 +777,16 @@ __global__ __launch_bounds__(wn_threads(KC)) void wavenet_persist_kernel(const W
     __syncthreads();
     stamp(6);     // head (as seen by this workgroup)
   }
-  if (STAMPS && a.stamps && g == 0 && j == 1 && tid == 0) {
-    st_acc[12] = clock64() - clk_start;        // shader cycles
-    st_acc[13] = wall_clock64() - wall_start;  // 100 MHz ticks
-    for (int i = 0; i < 16; ++i) a.stamps[i] = st_acc[i];
+  if (STAMPS && a.stamps && g == 0 && j == 1) {
+    if (tid == 0) {
+      st_acc[14] = clock64() - clk_start;        // shader cycles
+      st_acc[15] = wall_clock64() - wall_start;  // 100 MHz ticks
+      for (int i = 0; i < 8; ++i) a.stamps[i] = st_acc[i];
+      a.stamps[14] = st_acc[14];
+      a.stamps[15] = st_acc[15];
+    }
+    if (tid == NIO)
+      for (int i = 8; i < 14; ++i) a.stamps[i] = st_acc[i];
   }
 }
 
@@ -749,16 +806,24 @@ int launch_wavenet_persist(const WnPersistArgs& a, hipStream_t stream) {
   const size_t lds = wn_persist_lds_bytes(a);
   if (lds > 160 * 1024) return fail(MMK_ERR_UNSUPPORTED, "persistent WaveNet: %zu bytes of LDS needed", lds);
   dim3 grid(a.Gc * a.Gn), block(wn_threads(kc));
-#define MMK_WNP(KC_)                                                                                            \
-  do {                                                                                                          \
-    if (a.stamps) {                                                                                             \
-      if (a.xcd_local) hipLaunchKernelGGL((wavenet_persist_kernel<KC_, true, true>), grid, block, lds, stream, a);   \
-      else hipLaunchKernelGGL((wavenet_persist_kernel<KC_, true, false>), grid, block, lds, stream, a);              \
-    } else {                                                                                                    \
-      if (a.xcd_local) hipLaunchKernelGGL((wavenet_persist_kernel<KC_, false, true>), grid, block, lds, stream, a);  \
-      else hipLaunchKernelGGL((wavenet_persist_kernel<KC_, false, false>), grid, block, lds, stream, a);             \
-    }                                                                                                           \
+#define MMK_WNP2(KC_, SM_)                                                                                             \
+  do {                                                                                                                 \
+    if (a.stamps) {                                                                                                    \
+      if (a.xcd_local) hipLaunchKernelGGL((wavenet_persist_kernel<KC_, SM_, true, true>), grid, block, lds, stream, a);     \
+      else hipLaunchKernelGGL((wavenet_persist_kernel<KC_, SM_, true, false>), grid, block, lds, stream, a);                \
+    } else {                                                                                                           \
+      if (a.xcd_local) hipLaunchKernelGGL((wavenet_persist_kernel<KC_, SM_, false, true>), grid, block, lds, stream, a);    \
+      else hipLaunchKernelGGL((wavenet_persist_kernel<KC_, SM_, false, false>), grid, block, lds, stream, a);               \
+    }                                                                                                                  \
   } while (0)
+#define MMK_WNP(KC_)                   \
+  do {                                 \
+    if (small) MMK_WNP2(KC_, true);    \
+    else MMK_WNP2(KC_, false);         \
+  } while (0)
+  // groups of at most 4 clips use 4x4 MFMA blocks instead of 16-row tiles (MMK_WN_SMALL=0 forces the tiles)
+  const char* senv = getenv("MMK_WN_SMALL");
+  const bool small = a.Mg <= 4 && !(senv && senv[0] == '0');
   switch (kc) {
     case 2: MMK_WNP(2); break;
     case 4: MMK_WNP(4); break;
@@ -770,6 +835,7 @@ int launch_wavenet_persist(const WnPersistArgs& a, hipStream_t stream) {
     default: MMK_WNP(16); break;
   }
 #undef MMK_WNP
+#undef MMK_WNP2
   MMK_HIP(hipGetLastError());
   return MMK_OK;
 }

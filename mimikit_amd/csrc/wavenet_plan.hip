@@ -606,8 +606,8 @@ static int run_persistent(mmk_wavenet_plan* p, const WnCall& call, int64_t tau0,
     {
       const char* cenv = getenv("MMK_WN_CPW");
       a.cpw = (cenv && atoi(cenv) == 4) ? 4 : 2;
-      const char* pe = getenv("MMK_WN_POLL_SLEEP");
-      a.poll_sleep = (pe && pe[0] == '0') ? 0 : 1;
+      const char* pe = getenv("MMK_WN_SCHED");
+      a.poll_sleep = pe ? atoi(pe) : 0;
     }
     a.t0 = tau_b + 1; a.n_steps = nb;
     a.layers = p->layer_tab; a.ring_floats_per_wg = p->ring_floats_per_wg;
@@ -780,7 +780,10 @@ extern "C" int mmk_wavenet_sync_status(mmk_wavenet_plan* p, mmk_stream_t stream)
       const int slot[7] = {0, 1, 2, 3, 4, 5, 6};
       fprintf(stderr, "[mmk stamps] last persistent launch, I/O wave 0 of workgroup 1, totals in ms:");
       for (int i = 0; i < 7; ++i) fprintf(stderr, " %s=%.3f;", names[i], st[slot[i]] * 1e-5);
-      fprintf(stderr, " shader clock=%.0f MHz;", st[13] ? 100.0 * (double)st[12] / (double)st[13] : 0.0);
+      const char* mnames[6] = {"requests", "phase A", "B1", "wait y", "phase B + small operands", "wait h'"};
+      fprintf(stderr, " | matrix wave 0:");
+      for (int i = 0; i < 6; ++i) fprintf(stderr, " %s=%.3f;", mnames[i], st[8 + i] * 1e-5);
+      fprintf(stderr, " shader clock=%.0f MHz;", st[15] ? 100.0 * (double)st[14] / (double)st[15] : 0.0);
       fprintf(stderr, "\n");
     }
   }

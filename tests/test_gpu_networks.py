@@ -260,14 +260,15 @@ def _cond_net(seed=21):
     return net, sd, arch
 
 
-MODES = {"persistent_xcd": {}, "persistent_agent": {"MMK_WN_XCD_LOCAL": "0"}, "launches": {"MMK_WN_PERSISTENT": "0"}}
+MODES = {"persistent_xcd": {}, "persistent_agent": {"MMK_WN_XCD_LOCAL": "0"}, "persistent_tiles": {"MMK_WN_SMALL": "0"},
+         "launches": {"MMK_WN_PERSISTENT": "0"}}
 
 
 @pytest.mark.parametrize("mode", list(MODES))
 def test_wavenet_modes_agree_with_oracle(device, mode, monkeypatch):
-    """the persistent kernel (XCD-local and agent-scope hand-offs) and the per-layer launch path all reproduce
-    the oracle: conditioned net, batch 5 (ragged clip groups), prompt longer than rf, 70 steps, greedy + sampled"""
-    for k in ("MMK_WN_XCD_LOCAL", "MMK_WN_PERSISTENT", "MMK_WN_GROUPS"):
+    """the persistent kernel (XCD-local and agent-scope hand-offs, 4x4 MFMA blocks and 16-row tiles) and the
+    per-layer launch path all reproduce the oracle: conditioned net, batch 5 (ragged clip groups), prompt longer than rf, 70 steps, greedy + sampled"""
+    for k in ("MMK_WN_XCD_LOCAL", "MMK_WN_PERSISTENT", "MMK_WN_GROUPS", "MMK_WN_SMALL"):
         monkeypatch.delenv(k, raising=False)
     for k, v in MODES[mode].items():
         monkeypatch.setenv(k, v)
@@ -303,7 +304,7 @@ def test_wavenet_modes_agree_with_oracle(device, mode, monkeypatch):
 
 def test_wavenet_persistent_long_block_crosses_cond_blocks(device, monkeypatch):
     """more steps than one conditioning block (1024): two persistent launches chained through the product rings"""
-    for k in ("MMK_WN_XCD_LOCAL", "MMK_WN_PERSISTENT", "MMK_WN_GROUPS"):
+    for k in ("MMK_WN_XCD_LOCAL", "MMK_WN_PERSISTENT", "MMK_WN_GROUPS", "MMK_WN_SMALL"):
         monkeypatch.delenv(k, raising=False)
     net, sd, arch = _cond_net(seed=22)
     net = net.to(device)
