@@ -36,6 +36,7 @@ struct WnPersistArgs {
   int64_t idx_rs;
   const float* condall;           // (B, cond_steps, L, 2C): conv_1x1_l(c[tau0 + s]) in packed gate order, no bias; C1 == 0: unused
   int64_t cond_steps;
+  const float* zeros;             // a few words of zeros (address of every load that has nothing to fetch)
   // head
   const float* fc0_wp; const float* fc0_bias; const float* fc2_wp; const float* fc2_bias;
   const float* temperature; const float* uniforms; int64_t uni_ld;

@@ -382,14 +382,28 @@ __global__ __launch_bounds__(wn_threads(KC)) void wavenet_persist_kernel(const W
   const int mwave = __builtin_amdgcn_readfirstlane(mt >> 6);
   const int c0 = mwave * CPW;                             // this wave's chunk range inside a K = C product
   // history: 16-byte piece q = mt + k NMT of a ring slot is (clip q / (C/4), channels 4 (q % (C/4)) ..)
-  constexpr int kHP = (16 * (C / 4) + NMT - 1) / NMT;     // pieces per thread for 16 clips
+  // Every matrix thread issues the SAME number of loads in every layer (addresses are clamped, never predicated):
+  // with a conditional load on some path the compiler has to assume the shortest path when it counts vmcnt, and
+  // the MFMAs end up waiting for requests issued just before them.
+  constexpr int kClipsMax = SMALL ? 4 : 16;
+  constexpr int kHP = (kClipsMax * (C / 4) + NMT - 1) / NMT;     // pieces per thread
   f32x4 hp[kHP];
   // conditioning product of (clip, position, layer, packed column 16 j + e_n), computed before the launch:
   // consecutive requests (layer l+1 of this step ... layer 0 of the next) are 2C floats apart; element
-  // e = mt + k NMT sits 4 NWM k clips further
-  constexpr int kCP = (256 + NMT - 1) / NMT;              // elements per matrix thread for 16 clips
+  // e = mt + k NMT sits 4 NWM k clips further.  Without conditioning (or for a lane without an element) the
+  // address is a word of zeros.
+  constexpr int kCP = (kClipsMax * 16 + NMT - 1) / NMT;          // elements per matrix thread
   const int64_t cond_clip = (int64_t)a.cond_steps * L * (2 * C);
-  gcfloat_ptr cptr = (gcfloat_ptr)(uintptr_t)(a.condall + (int64_t)(m_first + (mt >> 4)) * cond_clip + j * 16 + (mt & 15));
+  gcfloat_ptr cptr[kCP];
+  int cstep[kCP];                                                // per lane: only real elements walk through condall
+#pragma unroll
+  for (int k = 0; k < kCP; ++k) {
+    const int e = mt + k * NMT;
+    const bool real = has_cond && e >= 0 && e < mg * 16;
+    cptr[k] = real ? (gcfloat_ptr)(uintptr_t)(a.condall + (int64_t)(m_first + (e >> 4)) * cond_clip + j * 16 + (e & 15))
+                   : (gcfloat_ptr)(uintptr_t)a.zeros;
+    cstep[k] = real ? 2 * C : 0;
+  }
   float cnd_n[kCP];
   // weight fragments: byte offset of this lane inside a tile; chunk c0 + u is u KiB further
   // (4x4 blocks: the lane's k sub-slice ks = lane / 16 starts 4 CPW ks floats into the wave's slice; its fragment u
@@ -405,7 +419,7 @@ __global__ __launch_bounds__(wn_threads(KC)) void wavenet_persist_kernel(const W
   const int x_off = SMALL ? (lane & 3) * ldh + c0 * 16 + sm_k0 : (lane & 15) * ldh + c0 * 16 + 4 * (lane >> 4);
   const int xy_off = SMALL ? (lane & 3) * ldy + c0 * 16 + sm_k0 : (lane & 15) * ldy + c0 * 16 + 4 * (lane >> 4);
   unsigned cur_hasb = 0, nx_hasb = 0;                      // uniform: does this workgroup have B rows in the layer
-  u64 rq_A = 0, rq_B = 0;
+  u64 rq_A = 0, rq_B = 0, rq_Bn = 0;
   // a request in two parts: `prepare` reads the layer's table entry into SGPRs and asks for the small pieces
   // (delayed input, conditioning terms); the weight fragments of the NEXT layer are loaded straight into the
   // registers of the fragment that the MFMA chain has just consumed (no second register set, no copies): one
@@ -415,25 +429,18 @@ __global__ __launch_bounds__(wn_threads(KC)) void wavenet_persist_kernel(const W
   auto prepare = [&](int nl, unsigned ntau, bool with_cond) {
     const u32x4 e0 = reinterpret_cast<const u32x4*>(ltab)[2 * nl];
     const u32x4 e1 = reinterpret_cast<const u32x4*>(ltab)[2 * nl + 1];
-    rq_A = ((u64)sgpr(e0[1]) << 32) | sgpr(e0[0]);
-    rq_B = ((u64)sgpr(e0[3]) << 32) | sgpr(e0[2]);
+    rq_B = rq_Bn;                                             // B tile of the layer that starts now
+    rq_A = ((u64)sgpr(e0[1]) << 32) | sgpr(e0[0]);           // A and B tiles of the next one
+    rq_Bn = ((u64)sgpr(e0[3]) << 32) | sgpr(e0[2]);
     const unsigned ring_off = sgpr(e1[0]), dil = sgpr(e1[1]), mask = sgpr(e1[2]);
     nx_hasb = sgpr(e1[3]);
     gf32x4_ptr src = (gf32x4_ptr)(uintptr_t)(h_ring + ring_off + (u64)((ntau - dil) & mask) * slot_bytes);
 #pragma unroll
-    for (int k = 0; k < kHP; ++k) {
-      if (k * NMT >= slot_f4) break;                        // uniform
-      if (mt + k * NMT < slot_f4) hp[k] = src[mt + k * NMT];
-    }
-    if (has_cond) {
-      if (with_cond) {
+    for (int k = 0; k < kHP; ++k) hp[k] = src[min(mt + k * NMT, slot_f4 - 1)];
 #pragma unroll
-        for (int k = 0; k < kCP; ++k) {
-          if (k * NMT >= mg * 16) break;
-          if (mt + k * NMT < mg * 16) cnd_n[k] = cptr[(int64_t)k * (4 * NWM) * cond_clip];
-        }
-      }
-      cptr += 2 * C;
+    for (int k = 0; k < kCP; ++k) {
+      cnd_n[k] = *(with_cond ? cptr[k] : (gcfloat_ptr)(uintptr_t)a.zeros);
+      cptr[k] += cstep[k];
     }
   };
   auto frag_A = [&](int i) -> f32x4 {   // fragment i of the requested layer: tap 0 chunks, then tap 1 chunks
@@ -450,17 +457,12 @@ __global__ __launch_bounds__(wn_threads(KC)) void wavenet_persist_kernel(const W
   auto small_to_lds = [&]() {
 #pragma unroll
     for (int k = 0; k < kHP; ++k) {
-      if (k * NMT >= slot_f4) break;
       const int q = mt + k * NMT;
       if (q < slot_f4) *reinterpret_cast<f32x4*>(hprev + (q / (C / 4)) * ldh + (q % (C / 4)) * 4) = hp[k];
     }
-    if (has_cond) {
 #pragma unroll
-      for (int k = 0; k < kCP; ++k) {
-        if (k * NMT >= mg * 16) break;
-        if (mt + k * NMT < mg * 16) cndbuf[mt + k * NMT] = cnd_n[k];
-      }
-    }
+    for (int k = 0; k < kCP; ++k)
+      if (mt + k * NMT < mg * 16) cndbuf[mt + k * NMT] = cnd_n[k];
   };
   // diagnostic build only: 100 MHz wall-clock stamps of thread 0 (an I/O wave) of owner 1 of group 0, summed
   unsigned long long st_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -479,7 +481,7 @@ __global__ __launch_bounds__(wn_threads(KC)) void wavenet_persist_kernel(const W
   if (!is_io) {   // layer 0 of the first step: requested and put in place right away (once per launch)
     prepare(0, (unsigned)tau0, true);
 #pragma unroll
-    for (int u = 0; u < CPW; ++u) { w_t0[u] = frag_A(u); w_t1[u] = frag_A(CPW + u); w_b[u] = frag_B(u); }
+    for (int u = 0; u < CPW; ++u) { w_t0[u] = frag_A(u); w_t1[u] = frag_A(CPW + u); }
     small_to_lds();
     cur_hasb = nx_hasb;
   }
@@ -586,7 +588,10 @@ __global__ __launch_bounds__(wn_threads(KC)) void wavenet_persist_kernel(const W
         const bool last = (l + 1 == L);
         // The very last layer of a launch re-requests layer 0 (unused) so that the sequence stays branch-free.
         prepare(last ? 0 : l + 1, last ? tau_u + 1 : tau_u, !last || s + 1 < a.n_steps);
-        stamp(8);    // small requests issued
+#pragma unroll
+        for (int u = 0; u < CPW; ++u) w_b[u] = frag_B(u);   // this layer's B fragments: needed at B2, 1.5 us from here
+        __builtin_amdgcn_sched_barrier(0);
+        stamp(8);    // requests issued
         // ---- phase A: z = W0.h[tau-d] + W1.h[tau]  (K = 2C, this wave's chunks) ----
         {
           const float* x0 = hprev + x_off;
@@ -615,12 +620,14 @@ __global__ __launch_bounds__(wn_threads(KC)) void wavenet_persist_kernel(const W
         __syncthreads();                                   // B1
         __syncthreads();                                   // B1b: the I/O waves have published y
         // The workgroup shares one memory pipe, in order (requests AND returns): a burst of fragment loads in
-        // front of a publish delays the publish, and a poll behind a slow load returns after it.  So the next
-        // layer's fragments are requested right AFTER each publish, while its echo cannot be back yet anyway
-        // (measured: requesting them under the MFMA chain instead costs 10 us per step on cfg4).
+        // front of a publish delays the publish, and a poll behind a slow load returns after it; and a layer's
+        // 1.5 MB per XCD need about a microsecond of the XCD's fabric link.  So the stream is cut in three
+        // 16-KiB pieces per workgroup, each issued right after a hand-off completed or a publish left:
+        // this layer's B fragments at the layer's top, the next layer's tap-0 fragments behind publish y,
+        // its tap-1 fragments behind phase B.
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int u = 0; u < CPW; ++u) { w_t0[u] = frag_A(u); w_t1[u] = frag_A(CPW + u); }
+        for (int u = 0; u < CPW; ++u) w_t0[u] = frag_A(u);
         __builtin_amdgcn_sched_barrier(0);
         stamp(10);   // epilogue A of the I/O waves
         if (cur_hasb) {
@@ -639,13 +646,15 @@ __global__ __launch_bounds__(wn_threads(KC)) void wavenet_persist_kernel(const W
             }
             redB[mwave * 64 + lane] = acc;
           }
-          __syncthreads();                                 // B3
-          __syncthreads();                                 // B3b: the I/O waves have published h'
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int u = 0; u < CPW; ++u) w_b[u] = frag_B(u);
+        for (int u = 0; u < CPW; ++u) w_t1[u] = frag_A(CPW + u);
         __builtin_amdgcn_sched_barrier(0);
+        if (cur_hasb) {
+          __syncthreads();                                 // B3
+          __syncthreads();                                 // B3b: the I/O waves have published h'
+        }
         small_to_lds();
         stamp(12);   // phase B + B3 + small operands to LDS
         __syncthreads();                                   // B4

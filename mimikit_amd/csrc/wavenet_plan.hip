@@ -69,6 +69,7 @@ struct mmk_wavenet_plan {
   float* h_rings = nullptr;     // per workgroup: past inputs of every layer (the delayed tap reads them)
   float* cproj = nullptr;       // (Bmax, kCondBlock, C1) conditioning after its LinearIO
   float* condall = nullptr;     // (Bmax, kCondBlock, L, 2C) every layer's conditioning product, packed gate order
+  float* zero_pad = nullptr;    // 64 floats that stay zero
   int32_t* err_flag = nullptr;
   unsigned* xcd_count = nullptr;
   bool xcd_local = false;       // one clip group per XCD, hand-offs through the XCD's L2 (verified in-kernel)
@@ -91,6 +92,7 @@ struct mmk_wavenet_plan {
     cproj = C1 > 0 ? c.take<float>((int64_t)Bmax * kCondBlock * C1) : nullptr;
     condall = C1 > 0 ? c.take<float>((int64_t)Bmax * kCondBlock * L * 2 * C) : nullptr;
     if (C1 > 0) cond_all.carve(c, false);
+    zero_pad = c.take<float>(64);
   }
 
   void layout(Carver& c) {
@@ -612,7 +614,7 @@ static int run_persistent(mmk_wavenet_plan* p, const WnCall& call, int64_t tau0,
     a.t0 = tau_b + 1; a.n_steps = nb;
     a.layers = p->layer_tab; a.ring_floats_per_wg = p->ring_floats_per_wg;
     a.emb = p->emb; a.idx = (int64_t*)call.in0; a.idx_rs = call.in0_rs;
-    a.condall = p->condall; a.cond_steps = p->kCondBlock;
+    a.condall = p->condall; a.cond_steps = p->kCondBlock; a.zeros = p->zero_pad;
     a.fc0_wp = p->mlp[0].Wp; a.fc0_bias = p->mlp[0].bias; a.fc2_wp = p->mlp[1].Wp; a.fc2_bias = p->mlp[1].bias;
     a.temperature = call.temperature;
     a.uniforms = call.uniforms ? call.uniforms + done : nullptr;   // column s of this block = done + s
