@@ -294,6 +294,7 @@ __global__ __launch_bounds__(wn_threads(KC)) void wavenet_persist_kernel(const W
   float* biasA = (float*)sp;              sp += L * 16 * 4;
   float* biasB = (float*)sp;              sp += L * 16 * 4;
   float* cndbuf = (float*)sp;             sp += 256 * 4;                  // conditioning term per output element
+  int* sfx = (int*)sp;                    sp += ((L * 4 + 15) / 16) * 16;   // sfx[l] = sum of the dilations above layer l
   int* s_idx = (int*)sp;      sp += 16 * 4;
   int* s_fail = (int*)sp;     sp += 16;
   float* lbuf = (float*)sp;                                               // logits for the sampler (owner 0 only)
@@ -329,6 +330,14 @@ __global__ __launch_bounds__(wn_threads(KC)) void wavenet_persist_kernel(const W
     biasB[i] = (t.B_bias && (!owns_res || t.has_res)) ? t.B_bias[btile * 16 + n] : 0.f;
   }
   if (tid == 0) *s_fail = 0;
+  __syncthreads();
+  if (tid == 0) {
+    int acc = 0;
+    for (int l = L - 1; l >= 0; --l) {
+      sfx[l] = acc;
+      acc += (int)ltab[l].dil;
+    }
+  }
   __syncthreads();
 
   // ---- per-group exchange buffers, per-workgroup private history ring ---------------------------
@@ -389,9 +398,8 @@ __global__ __launch_bounds__(wn_threads(KC)) void wavenet_persist_kernel(const W
   constexpr int kHP = (kClipsMax * (C / 4) + NMT - 1) / NMT;     // pieces per thread
   f32x4 hp[kHP];
   // conditioning product of (clip, position, layer, packed column 16 j + e_n), computed before the launch:
-  // consecutive requests (layer l+1 of this step ... layer 0 of the next) are 2C floats apart; element
-  // e = mt + k NMT sits 4 NWM k clips further.  Without conditioning (or for a lane without an element) the
-  // address is a word of zeros.
+  // entry (step, layer) sits (step L + layer) 2C floats into the clip's block; element e = mt + k NMT belongs to
+  // clip e / 16.  Without conditioning (or for a lane without an element) the address is a word of zeros.
   constexpr int kCP = (kClipsMax * 16 + NMT - 1) / NMT;          // elements per matrix thread
   const int64_t cond_clip = (int64_t)a.cond_steps * L * (2 * C);
   gcfloat_ptr cptr[kCP];
@@ -426,7 +434,7 @@ __global__ __launch_bounds__(wn_threads(KC)) void wavenet_persist_kernel(const W
   // 1-KiB load per four MFMAs in phase A, the B fragments right after phase B.  The texture path moves the
   // workgroup's 48 KiB of weights per layer (~0.3 us at 64 B/clk) under the matrix pipe's shadow, and the
   // compiler's own vmcnt bookkeeping makes each MFMA group wait for exactly its fragment.
-  auto prepare = [&](int nl, unsigned ntau, bool with_cond) {
+  auto prepare = [&](int nl, unsigned ntau, int64_t cidx, bool with_cond) {   // cidx = step * L + layer of the request
     const u32x4 e0 = reinterpret_cast<const u32x4*>(ltab)[2 * nl];
     const u32x4 e1 = reinterpret_cast<const u32x4*>(ltab)[2 * nl + 1];
     rq_B = rq_Bn;                                             // B tile of the layer that starts now
@@ -439,8 +447,7 @@ __global__ __launch_bounds__(wn_threads(KC)) void wavenet_persist_kernel(const W
     for (int k = 0; k < kHP; ++k) hp[k] = src[min(mt + k * NMT, slot_f4 - 1)];
 #pragma unroll
     for (int k = 0; k < kCP; ++k) {
-      cnd_n[k] = *(with_cond ? cptr[k] : (gcfloat_ptr)(uintptr_t)a.zeros);
-      cptr[k] += cstep[k];
+      cnd_n[k] = *(with_cond ? cptr[k] + (int64_t)cstep[k] * cidx : (gcfloat_ptr)(uintptr_t)a.zeros);
     }
   };
   auto frag_A = [&](int i) -> f32x4 {   // fragment i of the requested layer: tap 0 chunks, then tap 1 chunks
@@ -479,16 +486,23 @@ __global__ __launch_bounds__(wn_threads(KC)) void wavenet_persist_kernel(const W
   const int64_t tau0 = a.t0 - 1;
 
   if (!is_io) {   // layer 0 of the first step: requested and put in place right away (once per launch)
-    prepare(0, (unsigned)tau0, true);
+    prepare(0, (unsigned)tau0, 0, true);
 #pragma unroll
     for (int u = 0; u < CPW; ++u) { w_t0[u] = frag_A(u); w_t1[u] = frag_A(CPW + u); }
     small_to_lds();
     cur_hasb = nx_hasb;
   }
 
+  // Teacher-forced warm-up (filling the history rings from a prompt): position tau only has to go through the
+  // layers whose output is still needed when generation starts at tf_end - the output of layer l at tau matters iff
+  // tf_end - tau <= (sum of the dilations above l).  The top layer never runs, the bottom block sees the whole
+  // prompt: 2/3 of the layer-positions for three equal blocks.  Lrun is uniform and never decreases.
+  int Lrun = a.teacher_forced ? 1 : L;
   for (int64_t s = 0; s < a.n_steps; ++s) {
     const int64_t tau = tau0 + s;
     const unsigned tau_u = (unsigned)tau;
+    if (a.teacher_forced)
+      while (Lrun < L && (int64_t)sfx[Lrun] >= a.tf_end - tau) ++Lrun;
     // ---- input 0: embedding row of the newest sample ---------------------------------------
     if (s > 0 && !a.teacher_forced) {
       // classes sampled by the previous step arrive as granules (epoch = s)
@@ -535,6 +549,7 @@ __global__ __launch_bounds__(wn_threads(KC)) void wavenet_persist_kernel(const W
       for (int l = 0;; ++l) {
         const unsigned epoch = (unsigned)(s * L + l + 1);
         const bool last = (l + 1 == L);
+        const bool last_run = (l + 1 == Lrun);
         const u32x4 e1 = reinterpret_cast<const u32x4*>(ltab)[2 * l + 1];
         const unsigned ring_off = sgpr(e1[0]), ring_mask = sgpr(e1[2]), hasb = sgpr(e1[3]);
         __syncthreads();                                   // B1: phase-A partials are in LDS
@@ -573,6 +588,13 @@ __global__ __launch_bounds__(wn_threads(KC)) void wavenet_persist_kernel(const W
         if (!last) {
           if (!sweep<NIO>(gran_h, mg * C, epoch, sw_h, hbuf, C, ldh, err, s_fail)) return;   // ... B4
           stamp(5);   // wait h'
+          if (last_run) {   // warm-up stops here: the input of the first layer that does not run still joins its ring
+            const u32x4 en = reinterpret_cast<const u32x4*>(ltab)[2 * (l + 1) + 1];
+            gf32x4_wptr dst = (gf32x4_wptr)(uintptr_t)(h_ring + sgpr(en[0]) + (u64)(tau_u & sgpr(en[2])) * slot_bytes);
+            for (int q = tid; q < slot_f4; q += NIO)
+              dst[q] = *reinterpret_cast<const f32x4*>(hbuf + (q / (C / 4)) * ldh + (q % (C / 4)) * 4);
+            break;
+          }
         } else {
           __syncthreads();                                 // B4
           break;
@@ -584,10 +606,10 @@ __global__ __launch_bounds__(wn_threads(KC)) void wavenet_persist_kernel(const W
       // vmcnt bookkeeping is exact and an MFMA group waits for its own fragment only (with an exit or a skipped
       // load on some path it has to assume the shortest one, and phase A ends up waiting for the delayed-input
       // load issued just before it).  A hand-off timeout is noticed after the loop.
-      for (int l = 0; l < L; ++l) {
-        const bool last = (l + 1 == L);
+      for (int l = 0; l < Lrun; ++l) {
+        const bool last = (l + 1 == Lrun);
         // The very last layer of a launch re-requests layer 0 (unused) so that the sequence stays branch-free.
-        prepare(last ? 0 : l + 1, last ? tau_u + 1 : tau_u, !last || s + 1 < a.n_steps);
+        prepare(last ? 0 : l + 1, last ? tau_u + 1 : tau_u, last ? (s + 1) * L : s * L + l + 1, !last || s + 1 < a.n_steps);
 #pragma unroll
         for (int u = 0; u < CPW; ++u) w_b[u] = frag_B(u);   // this layer's B fragments: needed at B2, 1.5 us from here
         __builtin_amdgcn_sched_barrier(0);
@@ -805,7 +827,7 @@ size_t wn_persist_lds_bytes(const WnPersistArgs& a) {
   const int ldh = a.C + 4, ldy = wide + 4, ldl = a.n_logits_pad + 4;
   const int red = (2 * nwm > nw ? 2 * nwm : nw) * 64;
   return (size_t)2 * 16 * ldh * 4 + (size_t)16 * ldy * 4 + (size_t)red * 16 + (size_t)a.L * 32 + (size_t)a.L * 128 +
-         256 * 4 + 16 * 4 + 16 + (size_t)16 * ldl * 4;
+         256 * 4 + (size_t)((a.L * 4 + 15) / 16) * 16 + 16 * 4 + 16 + (size_t)16 * ldl * 4;
 }
 
 int launch_wavenet_persist(const WnPersistArgs& a, hipStream_t stream) {

@@ -603,6 +603,7 @@ static int run_persistent(mmk_wavenet_plan* p, const WnCall& call, int64_t tau0,
     a.q_levels = c.q_levels; a.H1 = c.mlp_hidden; a.n_classes = c.out_dim; a.n_logits_pad = p->n_logits_pad;
     a.learn_temp = c.learn_temp; a.min_temp = c.min_temp;
     a.teacher_forced = with_head ? 0 : 1;
+    a.tf_end = tau0 + n;   // warm-up: generation starts consuming here
     a.xcd_local = p->xcd_local ? 1 : 0;
     a.xcd_count = p->xcd_count;
     {
