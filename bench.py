@@ -128,9 +128,16 @@ class WaveNetJob:
             us = start.elapsed_time(stop) * 1e3
             nbytes = self.step_bytes() * n
             achieved = nbytes / (us * 1e-6) / 1e9
+            traffic = None
+            try:  # PMC-derived HBM bytes of one 1024-step launch (separate rocprofv3 --pmc passes, profiles/)
+                with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+                    per_step = json.load(f).get(self.name, {}).get("persistent", {}).get("bytes_per_step")
+                traffic = int(per_step * n) if per_step else None
+            except (OSError, ValueError):
+                pass
             return {"bound": "hbm", "kernel": "wavenet_persist_kernel (all layers + head of every step of a block)",
                     "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                     "algorithmic_bytes_per_launch": nbytes, "avg_launch_us": round(us, 1), "launches_timed": 1,
                     "steps_per_launch": n, "us_per_step_in_kernel": round(us / n, 2)}
         stats = plan.profile_steps(self.idx, self.cond, p, 48)

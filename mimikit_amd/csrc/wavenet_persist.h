@@ -25,7 +25,6 @@ struct WnPersistArgs {
   float min_temp;
   int32_t teacher_forced;         // warm-up: inputs come from idx[], no head
   int64_t tf_end;                 // warm-up: first position that generation will consume (layers above the need line are skipped)
-  int32_t cpw, poll_sleep;        // tuning: K-chunks per wave (2 | 4), s_sleep between polls
   int32_t xcd_local;              // 1: one clip group per XCD, hand-offs through that XCD's L2 (see .hip)
   int64_t t0, n_steps;            // positions t0 .. t0+n_steps-1 are produced (newest input = t0-1+s)
   // layers (table in device memory: too large for the 4 KiB kernel-argument segment)
@@ -47,7 +46,7 @@ struct WnPersistArgs {
   float* h_rings;                 // [Gc*Gn][ring_floats_per_wg]: each workgroup's copy of past layer inputs
   int32_t* err_flag;              // 1: hand-off timeout, 2: workgroups were not spread 8 x Gn over the XCDs
   unsigned* xcd_count;            // [8] arrivals per XCD + [1] total, zeroed before every launch
-  unsigned long long* stamps;     // diagnostic build (MMK_WN_STAMPS=1): 8 phase totals of workgroup 1, 100 MHz ticks
+  unsigned long long* stamps;     // diagnostic build (MMK_WN_STAMPS=1): 16 phase totals of workgroup 1, 100 MHz ticks
 };
 
 size_t wn_persist_lds_bytes(const WnPersistArgs& a);

@@ -3,20 +3,24 @@
 // link costs >= 4-5 us of dispatch/drain on this chip (profiles/r01_v1_*), so the chain is kept
 // on-chip and the links become data-tagged hand-offs through L2:
 //
-//   * clips are split in Gc independent groups (<= 16 clips each = one MFMA row tile); groups never
-//     talk to each other;
-//   * inside a group, workgroup j of Gn owns ONE 16-row tile of every layer's packed weight
+//   * clips are split in Gc independent groups (<= 16 clips each); groups never talk to each other;
+//   * inside a group, workgroup j of Gn owns ONE 16-column tile of every layer's packed weight
 //     matrices: tile j of A = [tap0 | tap1] (8 gated channels) and one tile of B = [res ; skip];
 //   * a layer is:  phase A  z = W0.h_l[tau-d] + W1.h_l[tau] + (Wc.c)[tau] + b -> gate -> publish y slice
 //                  phase B  wait y -> [res|skip] tile -> publish h_{l+1} slice / accumulate skip
 //                           wait h_{l+1}
 //     nothing else sits between the hand-offs: the delayed tap comes from a private per-workgroup ring
-//     of past layer inputs (prefetched into LDS a layer ahead), and the conditioning products Wc.c of
-//     all layers are computed for a whole block of positions by one GEMM BEFORE the launch (the
-//     conditioning is known up front), so the chain carries only what depends on the previous sample;
-//   * "publish" = 8-byte {epoch, value} granules, "wait" = every thread polls its own granules with
+//     of past layer inputs (requested a layer ahead), and the conditioning products Wc.c of all layers are
+//     computed for a whole block of positions by one GEMM BEFORE the launch (the conditioning is known up
+//     front), so the chain carries only what depends on the previous sample;
+//   * "publish" = 8-byte {epoch, value} granules, "wait" = I/O threads poll their own granules with
 //     agent-scope relaxed atomic loads (sc1, L1 bypass) until all tags match
-//     (cdna_hip_programming.md guideline 16, form R2: the data is the flag);
+//     (cdna_hip_programming.md guideline 16, form R2: the data is the flag).  One poll set in flight per
+//     thread, with a short sleep between rounds: back-to-back polling floods the memory pipe and costs
+//     18 us per step on cfg4 (measured);
+//   * a workgroup's waves are specialised (I/O waves / matrix waves, see the kernel) because the CU's memory
+//     pipe is in order: polls must never queue behind the weight stream;
+//   * groups of <= 4 clips use v_mfma_f32_4x4x1_16b_f32 blocks instead of 16-row tiles (no padding rows);
 //   * head: skip sums -> fc0+Mish -> fc2 -> temperature/argmax|sample, three more hand-offs,
 //     the sampled class is written to the caller's int64 tensor and handed to every workgroup
 //     for the next step's embedding row.
@@ -31,9 +35,8 @@ namespace mmk {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned long long u64;
 // Pointers that come out of LDS tables lose their address space and compile to FLAT loads, which count against
-// lgkmcnt as well: every later LDS wait would then also wait for the weight prefetch.  Force global loads.
+// lgkmcnt as well: every later LDS wait would then also wait for the weight stream.  Force global loads.
 typedef const __attribute__((address_space(1))) f32x4* gf32x4_ptr;
-__device__ __forceinline__ gf32x4_ptr as_global(const void* p) { return (gf32x4_ptr)(uintptr_t)p; }
 
 constexpr unsigned kSpinLimit = 1u << 22;
 
@@ -112,11 +115,6 @@ __device__ __forceinline__ bool sweep(const u64* gran, int count, unsigned epoch
   return *s_fail == 0;
 }
 
-// gate of the gated units with hardware exp/rcp: tanh(f) * sigmoid(g)   (wavenet_v2.py:151)
-// |error| ~1e-7 absolute, far inside the logit tolerance; keeps the critical-path epilogue short
-__device__ __forceinline__ float fast_sigmoid(float x) { return __frcp_rn(1.0f + __expf(-x)); }
-__device__ __forceinline__ float fast_tanh(float x) { return 1.0f - 2.0f * __frcp_rn(1.0f + __expf(2.0f * x)); }
-
 // one wave's share of  X[16 x K] (LDS, ld) . W^T  for a 16-column tile: chunks [c0, c1) after chunk_base
 __device__ __forceinline__ f32x4 tile_mma(const float* x, int ld, const f32x4* wp, int chunk_base, int c0, int c1,
                                           int lane) {
@@ -127,47 +125,6 @@ __device__ __forceinline__ f32x4 tile_mma(const float* x, int ld, const f32x4* w
     const f32x4 xv = *reinterpret_cast<const f32x4*>(x + r * ld + c * 16 + 4 * q);
 #pragma unroll
     for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[i], w[i], acc, 0, 0, 0);
-  }
-  return acc;
-}
-
-// X[16 x 16 CPW] (LDS; x points at this lane's first operand: row lane & 15, K offset 4 (lane >> 4) of the wave's
-// first chunk) times CPW weight fragments held in registers; all LDS reads are issued before the first MFMA
-template <int CPW>
-__device__ __forceinline__ f32x4 tile_mma_reg(const float* x, const f32x4 (&w)[CPW]) {
-  f32x4 xv[CPW];
-#pragma unroll
-  for (int u = 0; u < CPW; ++u) xv[u] = *reinterpret_cast<const f32x4*>(x + u * 16);
-  __builtin_amdgcn_sched_barrier(0);   // keep the reads ahead of the MFMA chain (the scheduler sinks them otherwise)
-  f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int u = 0; u < CPW; ++u) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[u][i], w[u][i], acc, 0, 0, 0);
-  }
-  return acc;
-}
-// two products into one accumulator chain: x0 . w0 + x1 . w1
-template <int CPW>
-__device__ __forceinline__ f32x4 tile_mma_reg2(const float* x0, const f32x4 (&w0)[CPW], const float* x1,
-                                               const f32x4 (&w1)[CPW]) {
-  f32x4 xa[CPW], xb[CPW];
-#pragma unroll
-  for (int u = 0; u < CPW; ++u) {
-    xa[u] = *reinterpret_cast<const f32x4*>(x0 + u * 16);
-    xb[u] = *reinterpret_cast<const f32x4*>(x1 + u * 16);
-  }
-  __builtin_amdgcn_sched_barrier(0);
-  f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int u = 0; u < CPW; ++u) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[u][i], w0[u][i], acc, 0, 0, 0);
-  }
-#pragma unroll
-  for (int u = 0; u < CPW; ++u) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xb[u][i], w1[u][i], acc, 0, 0, 0);
   }
   return acc;
 }

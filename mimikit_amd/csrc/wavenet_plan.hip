@@ -606,12 +606,6 @@ static int run_persistent(mmk_wavenet_plan* p, const WnCall& call, int64_t tau0,
     a.tf_end = tau0 + n;   // warm-up: generation starts consuming here
     a.xcd_local = p->xcd_local ? 1 : 0;
     a.xcd_count = p->xcd_count;
-    {
-      const char* cenv = getenv("MMK_WN_CPW");
-      a.cpw = (cenv && atoi(cenv) == 4) ? 4 : 2;
-      const char* pe = getenv("MMK_WN_SCHED");
-      a.poll_sleep = pe ? atoi(pe) : 0;
-    }
     a.t0 = tau_b + 1; a.n_steps = nb;
     a.layers = p->layer_tab; a.ring_floats_per_wg = p->ring_floats_per_wg;
     a.emb = p->emb; a.idx = (int64_t*)call.in0; a.idx_rs = call.in0_rs;
