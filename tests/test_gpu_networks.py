@@ -302,6 +302,47 @@ def test_wavenet_modes_agree_with_oracle(device, mode, monkeypatch):
     assert float(agree.float().cumprod(1).sum(1).mean()) >= 0.7 * n
 
 
+def _wide_net(C, cond_dim, seed):
+    from oracle.weights import load_recipe
+    io = H.mu_emb(mlp_dim=32)
+    ext = mmk.Extractor("signal", mmk.FileToSignal(16000))
+    io = mmk.IOSpec(inputs=(io.inputs[0], mmk.InputSpec("signal", mmk.MagSpec(22, 4, center=False), mmk.LinearIO()).bind_to(ext)),
+                    targets=io.targets)
+    net = mmk.WaveNet.from_config(mmk.WaveNet.Config(io_spec=io, blocks=(3,), dims_dilated=(C,), dims_1x1=(cond_dim,),
+                                                     residuals_dim=C, skips_dim=C)).eval()
+    sd = load_recipe(net, seed=seed, gain=2.0)
+    arch = dict(kernels=[2] * 3, dilations=[1, 2, 4], has_skips=True, residuals=True)
+    return net, sd, arch
+
+
+@pytest.mark.parametrize("C,B,env", [(96, 3, {}), (128, 72, {}), (128, 37, {"MMK_WN_XCD_LOCAL": "0"}), (256, 40, {})])
+def test_wavenet_persistent_kernel_shapes(device, monkeypatch, C, B, env):
+    """other instantiations of the persistent kernel against the oracle: 96 channels (2 K-chunks per matrix wave,
+    3 matrix waves), 128 channels with 9 clips per group (16-row MFMA tiles, two poll rounds per hand-off),
+    agent-scope groups with a ragged last group, 256 channels with 5 clips per group"""
+    for k in ("MMK_WN_XCD_LOCAL", "MMK_WN_PERSISTENT", "MMK_WN_GROUPS", "MMK_WN_SMALL"):
+        monkeypatch.delenv(k, raising=False)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    net, sd, arch = _wide_net(C, 16, seed=40 + C)
+    net = net.to(device)
+    gen = torch.Generator().manual_seed(C + B)
+    rf, n = net.rf, 12
+    prompt = torch.randint(0, 256, (B, rf + 3), generator=gen)
+    cond = torch.rand(B, rf + 3 + n, 12, generator=gen)
+    want, raw = O.wavenet_generate(sd, prompt, (cond,), n, keep_logits=True, **arch)
+    idx = torch.cat([prompt, torch.zeros(B, n, dtype=torch.int64)], 1).to(device)
+    net.generate_block((idx, cond.to(device)), prompt.size(1), n)
+    net.after_generate((idx,), None)
+    assert net._plan.persistent
+    ok = H.margin_ok(raw.numpy())
+    first_bad = (~ok).float().cumsum(1) > 0
+    same = idx.cpu()[:, prompt.size(1):] == want[:, prompt.size(1):]
+    assert bool((same | first_bad).all())
+    assert float(ok.float().mean()) > 0.9
+    assert torch.allclose(net._plan.last_logits(B).cpu()[ok[:, -1]], raw[:, -1][ok[:, -1]], **LOGIT_TOL)
+
+
 def test_wavenet_persistent_long_block_crosses_cond_blocks(device, monkeypatch):
     """more steps than one conditioning block (1024): two persistent launches chained through the product rings"""
     for k in ("MMK_WN_XCD_LOCAL", "MMK_WN_PERSISTENT", "MMK_WN_GROUPS", "MMK_WN_SMALL"):
