@@ -86,6 +86,14 @@ enum Act : int32_t { ACT_NONE = 0, ACT_TANH = 1, ACT_SIGMOID = 2, ACT_MISH = 3, 
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 __device__ __forceinline__ float mishf_(float x) { return x * tanhf(log1pf(expf(x))); }
+// Mish with the hardware exp/rcp: tanh(log(1 + e)) = n / (n + 2) with n = e (e + 2), e = exp(x); for x > 20 the
+// factor is 1 to fp32 precision (and e*e would overflow).  ~1e-6 relative, a dozen instructions instead of three
+// libm calls - for the kernels where the activation sits on the per-sample chain.
+__device__ __forceinline__ float mish_fast(float x) {
+  const float e = __expf(fminf(x, 20.f));
+  const float n = e * (e + 2.f);
+  return x > 20.f ? x : x * (n * __frcp_rn(n + 2.f));
+}
 
 __device__ __forceinline__ float apply_act(float v, int act) {
   switch (act) {

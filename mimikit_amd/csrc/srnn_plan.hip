@@ -7,6 +7,7 @@
 // are idx[:, t+shift-fs : t+shift] with shift = prompt_len % rf during warm-up
 // (the reference slides its window by that offset, :229-234) and 0 afterwards.
 #include "plan_util.h"
+#include "srnn_bottom.h"
 
 using namespace mmk;
 
@@ -40,6 +41,9 @@ struct mmk_srnn_plan {
   int64_t* tau = nullptr;
   hipStream_t cap_stream = nullptr;
   GraphCache gc;
+  // fused bottom tier (srnn_bottom.hip): chosen at create time when the geometry allows it
+  bool fused_bottom = false;
+  float *wb_raw = nullptr, *bb_raw = nullptr;   // framed conv weight / bias in their state_dict layout
 
   void layout(Carver& c) {
     const bool bias = cfg.rnn_bias != 0;
@@ -63,6 +67,8 @@ struct mmk_srnn_plan {
     logits_ld = (int)round_up(cfg.q_levels + (cfg.learn_temp ? 1 : 0), 4);
     logits = c.take<float>((int64_t)Bmax * logits_ld);
     tau = c.take<int64_t>(32);
+    wb_raw = c.take<float>((int64_t)H * cfg.frame_size[cfg.n_tiers - 1]);
+    bb_raw = c.take<float>(H);
   }
 };
 
@@ -109,6 +115,9 @@ static int derive(mmk_srnn_plan* p) {
   PackedLinear last;
   last.set_geometry(c.q_levels + (c.learn_temp ? 1 : 0), {c.mlp_hidden});
   p->mlp.push_back(last);
+  const char* fenv = getenv("MMK_SRNN_FUSED");
+  p->fused_bottom = !(fenv && fenv[0] == '0') && c.mlp_n_hidden == 0 &&
+                    srnn_bottom_supported(p->H, c.mlp_hidden, c.q_levels + (c.learn_temp ? 1 : 0), c.frame_size[c.n_tiers - 1]);
   return MMK_OK;
 }
 
@@ -212,6 +221,8 @@ extern "C" int mmk_srnn_commit(mmk_srnn_plan* p, void* workspace, size_t workspa
     const float* bb = b.need(tb + "bias", H);
     if (w) MMK_TRY(pack_rect(p->bottom.Wp, p->bottom.k_chunks, 0, 1, H, 0, fsl, w, fsl, 1, st));
     if (bb) MMK_TRY(pack_bias(p->bottom.bias, 0, 1, H, bb, 0, st));
+    if (w) MMK_HIP(hipMemcpyAsync(p->wb_raw, w, (size_t)H * fsl * sizeof(float), hipMemcpyDeviceToDevice, st));
+    if (bb) MMK_HIP(hipMemcpyAsync(p->bb_raw, bb, (size_t)H * sizeof(float), hipMemcpyDeviceToDevice, st));
   }
   for (size_t i = 0; i < p->mlp.size(); ++i) {
     PackedLinear& m = p->mlp[i];
@@ -228,7 +239,9 @@ extern "C" int mmk_srnn_commit(mmk_srnn_plan* p, void* workspace, size_t workspa
 }
 
 // enqueue step t = *tau + tau_off, whose residue modulo frame_sizes[0] is `phase`
-static int emit_step(mmk_srnn_plan* p, const SrnnCall& call, int64_t tau_off, int phase, bool with_bottom, hipStream_t st) {
+// bottom_steps: 0 = no bottom tier here (warm-up, or covered by an earlier fused launch), 1 = this step,
+// > 1 = this and the following steps in one fused launch (no tier above fires inside the range)
+static int emit_step(mmk_srnn_plan* p, const SrnnCall& call, int64_t tau_off, int phase, int bottom_steps, hipStream_t st) {
   const mmk_srnn_config& c = p->cfg;
   const int H = p->H, G = p->G, M = call.M;
   for (int i = 0; i < p->n_rnn_tiers; ++i) {
@@ -293,7 +306,26 @@ static int emit_step(mmk_srnn_plan* p, const SrnnCall& call, int64_t tau_off, in
       MMK_TRY(launch_linear(a, st));
     }
   }
-  if (!with_bottom) return MMK_OK;
+  if (bottom_steps <= 0) return MMK_OK;
+  if (p->fused_bottom) {
+    SrnnTier& up = p->tiers[p->n_rnn_tiers - 1];
+    SrnnBottomArgs a = {};
+    a.B = M; a.H = H; a.Hm = c.mlp_hidden; a.Q = c.q_levels; a.n_out = c.q_levels + (c.learn_temp ? 1 : 0);
+    a.learn_temp = c.learn_temp; a.min_temp = c.min_temp; a.class_size = (float)c.q_levels;
+    a.fs = c.frame_size[c.n_tiers - 1]; a.up_slots = up.up;
+    a.n_steps = bottom_steps;
+    a.tau_ptr = p->tau; a.tau_off = tau_off;
+    a.idx = const_cast<int64_t*>(call.idx); a.idx_rs = call.idx_rs;
+    a.wb = p->wb_raw; a.bb = p->bb_raw; a.upper = up.out;
+    a.fc0_wp = p->mlp[0].Wp; a.fc0_bias = p->mlp[0].bias; a.fc2_wp = p->mlp[1].Wp; a.fc2_bias = p->mlp[1].bias;
+    a.temperature = call.temperature; a.uniforms = call.uniforms; a.uni_ld = call.uni_ld; a.uni_off = call.uni_off;
+    a.logits_out = p->logits; a.logits_ld = p->logits_ld;
+    {
+      const char* senv = getenv("MMK_SRNN_STAMPS");
+      a.stamps = (senv && senv[0] == '1') ? reinterpret_cast<unsigned long long*>(p->tau + 8) : nullptr;
+    }
+    return launch_srnn_bottom(a, st);
+  }
   {
     const int fsl = c.frame_size[c.n_tiers - 1];
     SrnnTier& up = p->tiers[p->n_rnn_tiers - 1];
@@ -336,6 +368,31 @@ static int emit_step(mmk_srnn_plan* p, const SrnnCall& call, int64_t tau_off, in
   return launch_sample(s, st);
 }
 
+// steps [first, first + count) relative to *tau; `phase` = residue of the first step modulo frame_sizes[0].
+// With the fused bottom kernel the steps up to the next update of the tier above go into one launch.
+static int emit_range(mmk_srnn_plan* p, const SrnnCall& call, int64_t first, int64_t count, int phase, bool with_bottom,
+                      hipStream_t st) {
+  const int period = p->cfg.frame_size[0];
+  const int slots = p->tiers[p->n_rnn_tiers - 1].up;          // frame_sizes[-2]
+  int64_t covered = 0;                                        // bottom steps already inside a fused launch
+  for (int64_t s = 0; s < count; ++s) {
+    const int ph = (int)((phase + s) % period);
+    int bottom = 0;
+    if (with_bottom) {
+      if (!p->fused_bottom) {
+        bottom = 1;
+      } else if (covered == 0) {
+        const int64_t until_update = slots - (ph % slots);
+        bottom = (int)(until_update < count - s ? until_update : count - s);
+        covered = bottom;
+      }
+    }
+    MMK_TRY(emit_step(p, call, first + s, ph, bottom, st));
+    if (covered > 0) --covered;
+  }
+  return MMK_OK;
+}
+
 static int run_steps(mmk_srnn_plan* p, const SrnnCall& call, int64_t t_begin, int64_t n, bool with_bottom, hipStream_t st) {
   if (n <= 0) return MMK_OK;
   const int period = p->cfg.frame_size[0];
@@ -350,9 +407,7 @@ static int run_steps(mmk_srnn_plan* p, const SrnnCall& call, int64_t t_begin, in
       MMK_HIP(hipStreamSynchronize(st));
       p->gc.reset();
       MMK_HIP(hipStreamBeginCapture(p->cap_stream, hipStreamCaptureModeThreadLocal));
-      int rc = MMK_OK;
-      for (int s = 0; s < period && rc == MMK_OK; ++s)
-        rc = emit_step(p, call, s, (phase0 + s) % period, with_bottom, p->cap_stream);
+      int rc = emit_range(p, call, 0, period, phase0, with_bottom, p->cap_stream);
       if (rc == MMK_OK) rc = launch_bump(p->tau, period, p->cap_stream);
       hipGraph_t g = nullptr;
       hipError_t e = hipStreamEndCapture(p->cap_stream, &g);
@@ -370,9 +425,10 @@ static int run_steps(mmk_srnn_plan* p, const SrnnCall& call, int64_t t_begin, in
     for (int64_t r = 0; r < reps; ++r) MMK_HIP(hipGraphLaunch(p->gc.exec, st));
     done = reps * period;
   }
-  for (int64_t s = done; s < n; ++s)
-    MMK_TRY(emit_step(p, call, s - done, (int)((t_begin + s) % period), with_bottom, st));
-  if (n > done) MMK_TRY(launch_bump(p->tau, n - done, st));
+  if (n > done) {
+    MMK_TRY(emit_range(p, call, 0, n - done, (int)((t_begin + done) % period), with_bottom, st));
+    MMK_TRY(launch_bump(p->tau, n - done, st));
+  }
   return MMK_OK;
 }
 
@@ -418,6 +474,15 @@ extern "C" int mmk_srnn_generate(mmk_srnn_plan* p, int32_t batch, int64_t* idx, 
 extern "C" int mmk_srnn_last_logits(mmk_srnn_plan* p, int32_t batch, float* out, int64_t ld, mmk_stream_t stream) {
   if (!p || !out) return fail(MMK_ERR_INVALID, "srnn_last_logits: null argument");
   if (!p->committed) return fail(MMK_ERR_STATE, "srnn_last_logits: plan not committed");
+  if (const char* senv = getenv("MMK_SRNN_STAMPS"); senv && senv[0] == '1') {
+    unsigned long long st[8];
+    MMK_HIP(hipStreamSynchronize((hipStream_t)stream));
+    MMK_HIP(hipMemcpy(st, p->tau + 8, sizeof(st), hipMemcpyDeviceToHost));
+    const double n = st[7] ? (double)st[7] : 1.0;
+    fprintf(stderr, "[mmk stamps] srnn bottom kernel, workgroup 0, us per launch over %llu launches: prologue=%.2f x=%.2f fc0=%.2f fc2=%.2f sampler=%.2f; shader clock %.0f MHz\n",
+            st[7], st[0] * 1e-2 / n, st[1] * 1e-2 / n, st[2] * 1e-2 / n, st[3] * 1e-2 / n, st[4] * 1e-2 / n,
+            st[6] ? 100.0 * (double)st[5] / (double)st[6] : 0.0);
+  }
   const int n = p->cfg.q_levels + (p->cfg.learn_temp ? 1 : 0);
   MMK_HIP(hipMemcpy2DAsync(out, ld * sizeof(float), p->logits, p->logits_ld * sizeof(float), n * sizeof(float), batch,
                            hipMemcpyDeviceToDevice, (hipStream_t)stream));

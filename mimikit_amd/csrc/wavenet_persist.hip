@@ -661,7 +661,7 @@ __global__ __launch_bounds__(wn_threads(KC)) void wavenet_persist_kernel(const W
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int m = 4 * D_q + r;
-            if (m < mg) gran_store<XCD>(gran_hid + m * a.H1 + t * 16 + D_n, he, mishf_(v[r] + bias));
+            if (m < mg) gran_store<XCD>(gran_hid + m * a.H1 + t * 16 + D_n, he, mish_fast(v[r] + bias));
           }
         }
       }

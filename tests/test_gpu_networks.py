@@ -199,11 +199,15 @@ def test_sample_rnn_loop_with_temperature(device):
     assert float(out[0].abs().max()) <= 1.0
 
 
-def test_sample_rnn_cfg3_shape_vs_oracle(device):
-    """BASELINE config 3 geometry (frame sizes 16/4/1, GRU) at hidden 128, batch 64, prompt with P % rf != 0"""
-    net, sd, arch = H.srnn("big", hidden=128, mlp_dim=128, seed=77, frame_sizes=(16, 4, 1), kind="gru")
+@pytest.mark.parametrize("fused,frame_sizes,batch", [("1", (16, 4, 1), 64), ("0", (16, 4, 1), 64), ("1", (8, 4, 2), 6)])
+def test_sample_rnn_cfg3_shape_vs_oracle(device, monkeypatch, fused, frame_sizes, batch):
+    """BASELINE config 3 geometry (frame sizes 16/4/1, GRU) at hidden 128, batch 64, prompt with P % rf != 0; with the
+    fused bottom-tier kernel (several steps per launch) and with one launch per op; bottom frames of 2 samples, ragged
+    last workgroup"""
+    monkeypatch.setenv("MMK_SRNN_FUSED", fused)
+    net, sd, arch = H.srnn("big", hidden=128, mlp_dim=128, seed=77, frame_sizes=frame_sizes, kind="gru")
     gen = torch.Generator().manual_seed(8)
-    prompt = torch.randint(0, 256, (64, 16 * 5 + 7), generator=gen)
+    prompt = torch.randint(0, 256, (batch, frame_sizes[0] * 5 + 7), generator=gen)
     n = 100
     o = O.SampleRNNOracle(sd, **arch)
     want, raw = o.generate(prompt, n, keep_logits=True)
@@ -213,6 +217,28 @@ def test_sample_rnn_cfg3_shape_vs_oracle(device):
     same = got[:, prompt.size(1):] == want[:, prompt.size(1):]
     assert bool((same | first_bad).all())
     assert float(ok.float().mean()) > 0.9
+
+
+def test_sample_rnn_fused_bottom_sampled_decode(device, monkeypatch):
+    """temperature sampling through the fused bottom kernel against the oracle's inverse-CDF draw for the same uniforms"""
+    monkeypatch.setenv("MMK_SRNN_FUSED", "1")
+    net, sd, arch = H.srnn("big", hidden=128, mlp_dim=128, seed=78, frame_sizes=(16, 4, 1), kind="gru")
+    net = net.to(device)
+    gen = torch.Generator().manual_seed(9)
+    B, P, n = 5, 48, 60
+    prompt = torch.randint(0, 256, (B, P), generator=gen)
+    temp = torch.tensor([0.6, 1.0, 1.4, 0.8, 1.1])
+    torch.manual_seed(5)
+    u = torch.rand((B, n), device=device)
+    torch.manual_seed(5)
+    idx = torch.cat([prompt, torch.zeros(B, n, dtype=torch.int64)], 1).to(device)
+    net.before_generate((idx[:, :P],), None)
+    net.generate_block((idx,), P, n, temperature=temp)
+    net.after_generate((idx,), None)
+    o = O.SampleRNNOracle(sd, **arch)
+    want = o.generate(prompt, n, temperature=temp, uniforms=u.cpu())
+    agree = (idx.cpu() == want)[:, P:]
+    assert float(agree.float().cumprod(1).sum(1).mean()) >= 0.7 * n
 
 
 # ---------------------------------------------------------------------------- Seq2Seq
