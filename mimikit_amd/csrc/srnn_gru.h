@@ -1,0 +1,24 @@
+// Arguments of the fused SampleRNN GRU-tier kernel (see srnn_gru.hip).
+#pragma once
+#include "mmk_common.h"
+
+namespace mmk {
+
+struct SrnnGruArgs {
+  int32_t B, H, fs;                         // clips, hidden, frame size of this tier
+  int32_t up_mod, div;                      // slots of the tier above per own step (0: top tier), own frame size
+  float class_size;
+  const int64_t* tau_ptr; int64_t tau_off;  // t = *tau_ptr + tau_off
+  const int64_t* idx; int64_t idx_rs; int64_t shift;   // window idx[:, t + shift - fs : t + shift]
+  const float* win_wp; const float* win_bias;   // input Linear (H x fs), packed (linear.hip), bias in row order
+  const float* upper;                       // (B, up_mod, H) output of the tier above, or nullptr
+  const float* wih_wp; const float* wih_bias; const float* whh_wp; const float* whh_bias;   // packed (linear.hip)
+  float* h_ring; int64_t h_slot_stride;     // [2][B][H]: slot (cnt & 1) is read, slot ((cnt + 1) & 1) written
+  int64_t* cnt; unsigned* done;             // update counter of the tier, finish ticket
+  unsigned long long* stamps;               // diagnostic: phase totals (100 MHz ticks) + launch count, or nullptr
+};
+
+bool srnn_gru_supported(int H, int fs);
+int launch_srnn_gru(const SrnnGruArgs& a, hipStream_t stream);
+
+}  // namespace mmk

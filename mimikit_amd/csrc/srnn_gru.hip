@@ -1,0 +1,223 @@
+// One SampleRNN GRU tier update in ONE launch (gfx950).
+//
+// Reference: SampleRNNTier.forward (sample_rnn_v2.py:83-99) for a GRU tier with one layer:
+//     x  = Linear(linearize(idx[t-fs:t])) (+ upper tier output slice)         input_module, K = fs (tiny)
+//     gi = W_ih x + b_ih ; gh = W_hh h + b_hh                                   two (3H x H) products
+//     r = s(gi_r + gh_r), z = s(gi_z + gh_z), n = tanh(gi_n + r gh_n), h' = (h - n) z + n      (ATen GRUCell)
+// As separate launches this was four kernels (input linear, two gate GEMMs, cell) at 5-10 us each, each far
+// below 1 us of work.  Here a workgroup owns 16 hidden units x 16 clips: it builds its 16 rows of x in LDS,
+// streams the six 16-row weight tiles of its units (r, z, n of W_ih and W_hh; K split over 8 waves,
+// v_mfma_f32_16x16x4_f32), reduces in LDS and runs the cell for its 256 (clip, unit) pairs - no exchange with
+// other workgroups.  The hidden state is double buffered ([2][B][H], slot = update counter & 1): every
+// workgroup reads the old slot, writes the new one, and the last workgroup to finish bumps the counter, which
+// the up-sampling launch that follows uses as its position counter.
+#include "mmk_common.h"
+#include "srnn_gru.h"
+
+namespace mmk {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(1))) f32x4* gf32x4_ptr;
+
+constexpr int kGruThreads = 512;
+constexpr int kGruWaves = kGruThreads / 64;
+
+template <int KC>   // KC = H / 16 K-chunks; each of the 8 waves takes KC / 8 of them
+__global__ __launch_bounds__(kGruThreads) void srnn_gru_kernel(const SrnnGruArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  constexpr int H = KC * 16;
+  constexpr int CPW = KC / kGruWaves;              // chunks per wave
+  constexpr int ldx = H + 4;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ub = blockIdx.x % KC;                  // block of 16 hidden units
+  const int m_first = (blockIdx.x / KC) * 16;      // first clip of this workgroup's row tile
+  const int mg = min(16, a.B - m_first);
+  const int64_t t = *a.tau_ptr + a.tau_off;
+  const int64_t cnt = *a.cnt;
+  const float* h_old = a.h_ring + (cnt & 1) * a.h_slot_stride;
+  float* h_new = a.h_ring + ((cnt + 1) & 1) * a.h_slot_stride;
+
+  // diagnostic (MMK_SRNN_STAMPS=1): 100 MHz wall-clock totals per phase of thread 0 of workgroup 0
+  const bool stamping = a.stamps != nullptr && blockIdx.x == 0 && tid == 0;
+  unsigned long long st_prev = stamping ? wall_clock64() : 0, st_acc[6] = {0, 0, 0, 0, 0, 0};
+  auto stamp = [&](int slot) {
+    if (stamping) {
+      const unsigned long long now = wall_clock64();
+      st_acc[slot] += now - st_prev;
+      st_prev = now;
+    }
+  };
+
+  char* sp = smem_raw;
+  float* xs = (float*)sp;    sp += 16 * ldx * 4;                  // x rows of the 16 clips
+  float* hs = (float*)sp;    sp += 16 * ldx * 4;                  // h rows (old state)
+  f32x4* red = (f32x4*)sp;   sp += 6 * kGruWaves * 64 * 16;       // split-K partials: [tile][wave][lane]
+  float* s_lin = (float*)sp;                                      // linearized window [16][fs]
+
+  // ---- weights first: 6 tiles x CPW chunks of this wave (nothing depends on them for a while) ---------------
+  f32x4 w[6][CPW];
+  {
+    const int c0 = wave * CPW;
+#pragma unroll
+    for (int g = 0; g < 3; ++g) {
+      gf32x4_ptr wi = (gf32x4_ptr)(uintptr_t)a.wih_wp + ((int64_t)(g * KC + ub) * KC + c0) * 64 + lane;
+      gf32x4_ptr wh = (gf32x4_ptr)(uintptr_t)a.whh_wp + ((int64_t)(g * KC + ub) * KC + c0) * 64 + lane;
+#pragma unroll
+      for (int u = 0; u < CPW; ++u) {
+        w[g][u] = wi[u * 64];
+        w[3 + g][u] = wh[u * 64];
+      }
+    }
+  }
+  // ---- the window, linearized (modules/io.py:106-112), zero padded to whole K-chunks ----------------------------
+  const int kci = (a.fs + 15) / 16, ldl = kci * 16 + 4;
+  for (int e = tid; e < 16 * kci * 16; e += kGruThreads) {
+    const int m = e / (kci * 16), i = e - m * (kci * 16);
+    float v = 0.f;
+    if (m < mg && i < a.fs) {
+      const int64_t cls = a.idx[(int64_t)(m_first + m) * a.idx_rs + t + a.shift - a.fs + i];
+      v = (((float)cls / a.class_size) - .5f) * 2.f;
+    }
+    s_lin[m * ldl + i] = v;
+  }
+  // ---- old state rows -> LDS --------------------------------------------------------------------------------
+  for (int q = tid; q < 16 * (H / 4); q += kGruThreads) {
+    const int m = q / (H / 4), c = (q - m * (H / 4)) * 4;
+    f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (m < mg) v = *reinterpret_cast<const f32x4*>(h_old + (int64_t)(m_first + m) * H + c);
+    *reinterpret_cast<f32x4*>(hs + m * ldx + c) = v;
+  }
+  __syncthreads();
+  stamp(0);   // weights requested, window + old state in LDS
+  // ---- x = W_in lin + b_in (+ upper): 16 x 16 tiles over the waves, K = fs (same MFMA order as the launch path) ----
+  {
+    const int slot = a.up_mod > 0 ? (int)((t / a.div) % a.up_mod) : 0;     // outputs[i-1][:, (t // fs) % ...]   (:251)
+    const int q = lane >> 4, n = lane & 15;
+    for (int tile = wave; tile < KC; tile += kGruWaves) {
+      const int col = tile * 16 + n;
+      float upv[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {   // unconditional loads from clamped addresses
+        const int m = min(4 * q + r, mg - 1);
+        const float* src = a.upper ? a.upper + ((int64_t)(m_first + m) * a.up_mod + slot) * H + col : a.win_bias + col;
+        upv[r] = *src;
+      }
+      const float bias = a.win_bias[col];
+      f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int c = 0; c < kci; ++c) {
+        const f32x4 xv = *reinterpret_cast<const f32x4*>(s_lin + n * ldl + c * 16 + 4 * q);
+        const f32x4 wv = ((gf32x4_ptr)(uintptr_t)a.win_wp)[((int64_t)tile * kci + c) * 64 + lane];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[i], wv[i], acc, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = 4 * q + r;
+        float v = acc[r] + bias;
+        if (a.upper) v += upv[r];
+        xs[m * ldx + col] = m < mg ? v : 0.f;
+      }
+    }
+  }
+  __syncthreads();
+  stamp(1);   // x
+  // ---- six 16 x 16 tiles, this wave's K range ----------------------------------------------------------------
+  {
+    const int c0 = wave * CPW;
+    const float* xr = xs + (lane & 15) * ldx + c0 * 16 + 4 * (lane >> 4);
+    const float* hr = hs + (lane & 15) * ldx + c0 * 16 + 4 * (lane >> 4);
+    f32x4 xv[CPW], hv[CPW];
+#pragma unroll
+    for (int u = 0; u < CPW; ++u) {
+      xv[u] = *reinterpret_cast<const f32x4*>(xr + u * 16);
+      hv[u] = *reinterpret_cast<const f32x4*>(hr + u * 16);
+    }
+    f32x4 acc[6];
+#pragma unroll
+    for (int g = 0; g < 6; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < CPW; ++u) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int g = 0; g < 3; ++g) {     // six independent accumulator chains
+          acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[u][i], w[g][u][i], acc[g], 0, 0, 0);
+          acc[3 + g] = __builtin_amdgcn_mfma_f32_16x16x4f32(hv[u][i], w[3 + g][u][i], acc[3 + g], 0, 0, 0);
+        }
+      }
+    }
+#pragma unroll
+    for (int g = 0; g < 6; ++g) red[(g * kGruWaves + wave) * 64 + lane] = acc[g];
+  }
+  __syncthreads();
+  stamp(2);   // MFMAs (incl. the wait for the weights)
+  // ---- cell: one (clip, unit) pair per thread -----------------------------------------------------------------
+  if (tid < 256) {
+    const int m = tid >> 4, n = tid & 15;
+    const int frag = ((m >> 2) * 16 + n) * 4 + (m & 3);      // (row m, col n) of a 16x16 accumulator image
+    float s[6];
+#pragma unroll
+    for (int g = 0; g < 6; ++g) {
+      const float* f = reinterpret_cast<const float*>(red + g * kGruWaves * 64) + frag;
+      float v = 0.f;
+#pragma unroll
+      for (int wv = 0; wv < kGruWaves; ++wv) v += f[wv * 256];
+      s[g] = v;
+    }
+    if (m < mg) {
+      const int unit = ub * 16 + n;
+      const float gi_r = s[0] + (a.wih_bias ? a.wih_bias[unit] : 0.f);
+      const float gi_z = s[1] + (a.wih_bias ? a.wih_bias[H + unit] : 0.f);
+      const float gi_n = s[2] + (a.wih_bias ? a.wih_bias[2 * H + unit] : 0.f);
+      const float gh_r = s[3] + (a.whh_bias ? a.whh_bias[unit] : 0.f);
+      const float gh_z = s[4] + (a.whh_bias ? a.whh_bias[H + unit] : 0.f);
+      const float gh_n = s[5] + (a.whh_bias ? a.whh_bias[2 * H + unit] : 0.f);
+      const float r = sigmoidf_(gh_r + gi_r);
+      const float z = sigmoidf_(gh_z + gi_z);
+      const float nn = tanhf(gi_n + gh_n * r);
+      const float hp = hs[m * ldx + unit];
+      h_new[(int64_t)(m_first + m) * H + unit] = (hp - nn) * z + nn;
+    }
+  }
+  // ---- the last workgroup to finish publishes the new slot -----------------------------------------------------
+  __syncthreads();
+  stamp(3);   // cell
+  if (stamping) {
+    for (int i = 0; i < 4; ++i) a.stamps[i] += st_acc[i];
+    a.stamps[7] += 1;
+  }
+  if (tid == 0) {
+    __threadfence();
+    const unsigned ticket = atomicAdd(a.done, 1u);
+    if (ticket == gridDim.x - 1) {
+      *a.done = 0;
+      __threadfence();
+      *a.cnt = cnt + 1;
+    }
+  }
+}
+
+size_t srnn_gru_lds_bytes(int H, int fs) {
+  return (size_t)2 * 16 * (H + 4) * 4 + (size_t)6 * kGruWaves * 64 * 16 + (size_t)16 * (((fs + 15) / 16) * 16 + 4) * 4;
+}
+
+bool srnn_gru_supported(int H, int fs) {
+  if (!(H == 128 || H == 256 || H == 512)) return false;
+  return fs >= 1 && fs <= 256 && srnn_gru_lds_bytes(H, fs) <= 160 * 1024;
+}
+
+int launch_srnn_gru(const SrnnGruArgs& a, hipStream_t stream) {
+  if (!srnn_gru_supported(a.H, a.fs)) return fail(MMK_ERR_UNSUPPORTED, "srnn gru kernel: geometry H=%d fs=%d", a.H, a.fs);
+  const size_t lds = srnn_gru_lds_bytes(a.H, a.fs);
+  dim3 grid((a.H / 16) * ((a.B + 15) / 16)), block(kGruThreads);
+  switch (a.H) {
+    case 128: hipLaunchKernelGGL((srnn_gru_kernel<8>), grid, block, lds, stream, a); break;
+    case 256: hipLaunchKernelGGL((srnn_gru_kernel<16>), grid, block, lds, stream, a); break;
+    default: hipLaunchKernelGGL((srnn_gru_kernel<32>), grid, block, lds, stream, a); break;
+  }
+  MMK_HIP(hipGetLastError());
+  return MMK_OK;
+}
+
+}  // namespace mmk

@@ -8,6 +8,7 @@
 // (the reference slides its window by that offset, :229-234) and 0 afterwards.
 #include "plan_util.h"
 #include "srnn_bottom.h"
+#include "srnn_gru.h"
 
 using namespace mmk;
 
@@ -25,7 +26,10 @@ struct SrnnCall {
 struct SrnnTier {
   int fs = 0, up = 0;
   PackedLinear in_lin, gates, gates_hh, up_lin;
-  float *h = nullptr, *c = nullptr, *out = nullptr;
+  float *h = nullptr, *c = nullptr, *out = nullptr;   // h: [2][Bmax][H] (the fused GRU kernel alternates the slots)
+  float *win_raw = nullptr, *bin_raw = nullptr;       // input Linear in its state_dict layout
+  int64_t* cnt = nullptr;                             // update counter (slot of the current state = cnt & 1)
+  unsigned* done = nullptr;
 };
 
 struct mmk_srnn_plan {
@@ -43,6 +47,7 @@ struct mmk_srnn_plan {
   GraphCache gc;
   // fused bottom tier (srnn_bottom.hip): chosen at create time when the geometry allows it
   bool fused_bottom = false;
+  bool fused_gru = false;                       // srnn_gru.hip: input linear + both gate products + cell in one launch
   float *wb_raw = nullptr, *bb_raw = nullptr;   // framed conv weight / bias in their state_dict layout
 
   void layout(Carver& c) {
@@ -52,8 +57,12 @@ struct mmk_srnn_plan {
       t.gates.carve(c, bias);
       if (cfg.rnn_kind == 1) t.gates_hh.carve(c, bias);
       t.up_lin.carve(c, true);
-      t.h = c.take<float>((int64_t)Bmax * H);
+      t.h = c.take<float>((int64_t)2 * Bmax * H);
       t.c = c.take<float>((int64_t)Bmax * H);
+      t.win_raw = c.take<float>((int64_t)H * t.fs);
+      t.bin_raw = c.take<float>(H);
+      t.cnt = c.take<int64_t>(4);
+      t.done = c.take<unsigned>(4);
       t.out = c.take<float>((int64_t)Bmax * t.up * H);
     }
     bottom.carve(c, true);
@@ -118,6 +127,8 @@ static int derive(mmk_srnn_plan* p) {
   const char* fenv = getenv("MMK_SRNN_FUSED");
   p->fused_bottom = !(fenv && fenv[0] == '0') && c.mlp_n_hidden == 0 &&
                     srnn_bottom_supported(p->H, c.mlp_hidden, c.q_levels + (c.learn_temp ? 1 : 0), c.frame_size[c.n_tiers - 1]);
+  p->fused_gru = !(fenv && fenv[0] == '0') && c.rnn_kind == 1;
+  for (auto& t : p->tiers) p->fused_gru = p->fused_gru && srnn_gru_supported(p->H, t.fs);
   return MMK_OK;
 }
 
@@ -163,7 +174,9 @@ extern "C" int mmk_srnn_reset(mmk_srnn_plan* p, mmk_stream_t stream) {
   hipStream_t st = (hipStream_t)stream;
   for (auto& t : p->tiers) {
     // h0_init zeros / ones (SampleRNNTier._init_h0, sample_rnn_v2.py:118-119)
-    MMK_TRY(launch_fill(t.h, p->cfg.h0_ones ? 1.f : 0.f, (int64_t)p->Bmax * p->H, st));
+    MMK_TRY(launch_fill(t.h, p->cfg.h0_ones ? 1.f : 0.f, (int64_t)2 * p->Bmax * p->H, st));
+    MMK_HIP(hipMemsetAsync(t.cnt, 0, 4 * sizeof(int64_t), st));
+    MMK_HIP(hipMemsetAsync(t.done, 0, 4 * sizeof(unsigned), st));
     MMK_TRY(launch_fill(t.c, p->cfg.h0_ones ? 1.f : 0.f, (int64_t)p->Bmax * p->H, st));
     MMK_HIP(hipMemsetAsync(t.out, 0, (size_t)p->Bmax * t.up * p->H * sizeof(float), st));
   }
@@ -193,6 +206,8 @@ extern "C" int mmk_srnn_commit(mmk_srnn_plan* p, void* workspace, size_t workspa
     const float* bb = b.need(tb + "input_module.heads.0.2.bias", H);
     if (w) MMK_TRY(pack_rect(t.in_lin.Wp, t.in_lin.k_chunks, 0, 1, H, 0, t.fs, w, t.fs, 1, st));
     if (bb) MMK_TRY(pack_bias(t.in_lin.bias, 0, 1, H, bb, 0, st));
+    if (w) MMK_HIP(hipMemcpyAsync(t.win_raw, w, (size_t)H * t.fs * sizeof(float), hipMemcpyDeviceToDevice, st));
+    if (bb) MMK_HIP(hipMemcpyAsync(t.bin_raw, bb, (size_t)H * sizeof(float), hipMemcpyDeviceToDevice, st));
     const float* wih = b.need(tb + "rnn.weight_ih_l0", (int64_t)G * H * H);
     const float* whh = b.need(tb + "rnn.weight_hh_l0", (int64_t)G * H * H);
     const float* bih = bias ? b.need(tb + "rnn.bias_ih_l0", (int64_t)G * H) : nullptr;
@@ -247,6 +262,34 @@ static int emit_step(mmk_srnn_plan* p, const SrnnCall& call, int64_t tau_off, in
   for (int i = 0; i < p->n_rnn_tiers; ++i) {
     SrnnTier& t = p->tiers[i];
     if (phase % t.fs != 0) continue;  // `if t % fs[i] == 0`, sample_rnn_v2.py:246
+    if (p->fused_gru) {
+      SrnnGruArgs g = {};
+      g.B = M; g.H = H; g.fs = t.fs; g.div = t.fs; g.class_size = (float)c.q_levels;
+      g.tau_ptr = p->tau; g.tau_off = tau_off;
+      g.idx = call.idx; g.idx_rs = call.idx_rs; g.shift = call.shift;
+      g.win_wp = t.in_lin.Wp; g.win_bias = t.in_lin.bias;
+      if (i > 0) {   // outputs[i-1][:, (t // fs[i]) % (fs[i-1] // fs[i])]      (:251)
+        g.upper = p->tiers[i - 1].out;
+        g.up_mod = p->tiers[i - 1].up;
+      }
+      g.wih_wp = t.gates.Wp; g.wih_bias = t.gates.bias; g.whh_wp = t.gates_hh.Wp; g.whh_bias = t.gates_hh.bias;
+      g.h_ring = t.h; g.h_slot_stride = (int64_t)p->Bmax * H;
+      g.cnt = t.cnt; g.done = t.done;
+      {
+        const char* senv = getenv("MMK_SRNN_STAMPS");
+        g.stamps = (senv && senv[0] == '1') ? reinterpret_cast<unsigned long long*>(p->tau + 16) : nullptr;
+      }
+      MMK_TRY(launch_srnn_gru(g, st));
+      // up-sampler on the slot the kernel has just published: its position counter is the tier's update counter
+      LinearArgs a = {};
+      t.up_lin.fill(a);
+      a.seg[0].x = addr_time(t.h, (int64_t)p->Bmax * H, 0, 1, 2); a.seg[0].ld = H;
+      a.M = M; a.tau_ptr = t.cnt; a.tau_off = 0;
+      a.epilogue = EPI_STORE; a.act = ACT_NONE;
+      a.out = addr_static(t.out); a.out_ld = (int64_t)t.up * H;
+      MMK_TRY(launch_linear(a, st));
+      continue;
+    }
     {
       LinearArgs a = {};
       t.in_lin.fill(a);
@@ -482,6 +525,10 @@ extern "C" int mmk_srnn_last_logits(mmk_srnn_plan* p, int32_t batch, float* out,
     fprintf(stderr, "[mmk stamps] srnn bottom kernel, workgroup 0, us per launch over %llu launches: prologue=%.2f x=%.2f fc0=%.2f fc2=%.2f sampler=%.2f; shader clock %.0f MHz\n",
             st[7], st[0] * 1e-2 / n, st[1] * 1e-2 / n, st[2] * 1e-2 / n, st[3] * 1e-2 / n, st[4] * 1e-2 / n,
             st[6] ? 100.0 * (double)st[5] / (double)st[6] : 0.0);
+    MMK_HIP(hipMemcpy(st, p->tau + 16, sizeof(st), hipMemcpyDeviceToHost));
+    const double ng = st[7] ? (double)st[7] : 1.0;
+    fprintf(stderr, "[mmk stamps] srnn gru kernel, workgroup 0, us per launch over %llu launches: loads=%.2f x=%.2f mfma=%.2f cell=%.2f\n",
+            st[7], st[0] * 1e-2 / ng, st[1] * 1e-2 / ng, st[2] * 1e-2 / ng, st[3] * 1e-2 / ng);
   }
   const int n = p->cfg.q_levels + (p->cfg.learn_temp ? 1 : 0);
   MMK_HIP(hipMemcpy2DAsync(out, ld * sizeof(float), p->logits, p->logits_ld * sizeof(float), n * sizeof(float), batch,
