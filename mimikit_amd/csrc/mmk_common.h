@@ -192,6 +192,10 @@ struct SampleArgs {
 };
 int launch_sample(const SampleArgs& a, hipStream_t stream);
 
+// plain tiled GEMM on a packed weight matrix (gemm.hip): C[b][M, N] = A[b][M, K] . W^T, b < batch
+int launch_gemm_f32(const float* A, int64_t lda, int64_t a_batch, const float* Wp, int n_tiles, int k_chunks, int N, int K,
+                    float* C, int64_t ldc, int64_t c_batch, int M, int batch, hipStream_t stream);
+
 // recurrent cells (elementwise)
 int launch_gru_cell(const float* gi, const float* gh, float* h, int M, int H, hipStream_t stream);
 int launch_lstm_cell(const float* gates, int64_t gates_ld, const float* gadd, int64_t gadd_ld, float* h, int64_t h_ld,

@@ -582,17 +582,12 @@ static int run_persistent(mmk_wavenet_plan* p, const WnCall& call, int64_t tau0,
         a.out = addr_static(p->cproj + (int64_t)b * p->kCondBlock * p->C1);
         a.out_ld = p->C1;
         MMK_TRY(launch_linear(a, st));
-        // every layer's conv_1x1(c) for the same positions (wavenet_v2.py:140-150): off the per-sample chain
-        LinearArgs w = {};
-        p->cond_all.fill(w);
-        w.seg[0].x = addr_static(p->cproj + (int64_t)b * p->kCondBlock * p->C1);
-        w.seg[0].ld = p->C1;
-        w.M = (int)nb; w.tau_ptr = nullptr; w.tau_off = 0;
-        w.epilogue = EPI_STORE; w.act = ACT_NONE;
-        w.out = addr_static(p->condall + (int64_t)b * p->kCondBlock * p->L * 2 * p->C);
-        w.out_ld = (int64_t)p->L * 2 * p->C;
-        MMK_TRY(launch_linear(w, st));
       }
+      // every layer's conv_1x1(c) for the same positions (wavenet_v2.py:140-150): off the per-sample chain; one
+      // GEMM over all clips (M = positions, N = L x 2C, K = C1)
+      MMK_TRY(launch_gemm_f32(p->cproj, p->C1, (int64_t)p->kCondBlock * p->C1, p->cond_all.Wp, p->cond_all.n_tiles,
+                              p->cond_all.k_chunks, p->cond_all.N, p->C1, p->condall, (int64_t)p->L * 2 * p->C,
+                              (int64_t)p->kCondBlock * p->L * 2 * p->C, (int)nb, call.M, st));
     }
     // hand-off words are zeroed before EVERY launch (epochs restart at 1); the error word after them is sticky
     MMK_HIP(hipMemsetAsync(p->gran_h, 0, (size_t)(p->gran_words - 2) * sizeof(unsigned long long), st));
