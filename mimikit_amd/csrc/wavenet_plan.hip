@@ -13,6 +13,7 @@
 
 #include "plan_util.h"
 #include "wavenet_persist.h"
+#include "wavenet_prefill.h"
 
 using namespace mmk;
 
@@ -70,6 +71,10 @@ struct mmk_wavenet_plan {
   float* cproj = nullptr;       // (Bmax, kCondBlock, C1) conditioning after its LinearIO
   float* condall = nullptr;     // (Bmax, kCondBlock, L, 2C) every layer's conditioning product, packed gate order
   float* zero_pad = nullptr;    // 64 floats that stay zero
+  // warm-up as a prefill (wavenet_prefill.hip): two ping-pong layer inputs, the gated output, the projected
+  // conditioning, each (Bmax, pf_P, .) for a prompt window of up to pf_P positions
+  int64_t pf_P = 0;
+  float *pf_h[2] = {nullptr, nullptr}, *pf_y = nullptr, *pf_c = nullptr;
   int32_t* err_flag = nullptr;
   unsigned* xcd_count = nullptr;
   bool xcd_local = false;       // one clip group per XCD, hand-offs through the XCD's L2 (verified in-kernel)
@@ -93,6 +98,11 @@ struct mmk_wavenet_plan {
     condall = C1 > 0 ? c.take<float>((int64_t)Bmax * kCondBlock * L * 2 * C) : nullptr;
     if (C1 > 0) cond_all.carve(c, false);
     zero_pad = c.take<float>(64);
+    pf_P = round_up(rf, 32);
+    pf_h[0] = c.take<float>((int64_t)Bmax * pf_P * C);
+    pf_h[1] = c.take<float>((int64_t)Bmax * pf_P * C);
+    pf_y = c.take<float>((int64_t)Bmax * pf_P * C);
+    pf_c = C1 > 0 ? c.take<float>((int64_t)Bmax * pf_P * C1) : nullptr;
   }
 
   void layout(Carver& c) {
@@ -623,6 +633,70 @@ static int run_persistent(mmk_wavenet_plan* p, const WnCall& call, int64_t tau0,
   return MMK_OK;
 }
 
+// Warm-up of the persistent path as a prefill: all positions of [t_begin, t_end) go through a layer at once (GEMMs
+// with the gate / residual epilogues), then the tail of every layer input is copied into the step kernel's rings.
+// The same staircase as the step path: layer l only runs where its output is still needed at t_end.
+static int prefill(mmk_wavenet_plan* p, const WnCall& call, int64_t t_begin, int64_t t_end, hipStream_t st) {
+  const mmk_wavenet_config& c = p->cfg;
+  const int C = p->C, L = p->L, C1 = p->C1, B = call.M;
+  const int64_t n = t_end - t_begin, P = p->pf_P;
+  MMK_TRY(launch_wn_prefill_embed((const int64_t*)call.in0, call.in0_rs, t_begin, p->emb, c.q_levels, C, (int)n, p->pf_h[0],
+                                  P * C, B, st));
+  if (C1 > 0) {
+    for (int b = 0; b < B; ++b) {   // c[b, t, :] = LinearIO(cond[b, t, :])   (modules/io.py:115-122)
+      LinearArgs a = {};
+      p->cond_lin[0].fill(a);
+      a.seg[0].x = addr_static(call.cond[0] + (int64_t)b * call.cond_rs[0] + t_begin * c.cond_in_dim[0]);
+      a.seg[0].ld = c.cond_in_dim[0];
+      a.M = (int)n; a.tau_ptr = nullptr; a.tau_off = 0;
+      a.epilogue = EPI_STORE; a.act = ACT_NONE;
+      a.out = addr_static(p->pf_c + (int64_t)b * P * C1);
+      a.out_ld = C1;
+      MMK_TRY(launch_linear(a, st));
+    }
+  }
+  std::vector<int64_t> sfx(L, 0);   // sfx[l] = sum of the dilations above layer l
+  for (int l = L - 2; l >= 0; --l) sfx[l] = sfx[l + 1] + p->dil[l + 1];
+  int cur = 0;
+  for (int l = 0; l < L; ++l) {
+    const int d = p->dil[l];
+    // the ring of layer l holds its input at the last d positions
+    const int64_t t_lo = t_end - d > t_begin ? t_end - d : t_begin;
+    MMK_TRY(launch_wn_prefill_scatter(p->pf_h[cur], P * C, t_begin, t_lo, (int)(t_end - t_lo), C, B, p->Mg, p->Gc, p->Gn, p->h_rings,
+                                      p->ring_floats_per_wg, p->ring_offset[l], p->ring_mask[l], st));
+    if (l == L - 1) break;
+    int64_t r_lo = t_end - sfx[l];                       // first position whose output is still needed
+    if (r_lo < t_begin + d) r_lo = t_begin + d;          // the delayed input must exist
+    if (r_lo >= t_end) break;
+    const int64_t p0 = r_lo - t_begin;
+    const int M = (int)(t_end - r_lo);
+    const float* h = p->pf_h[cur];
+    {
+      WnPrefillArgs a = {};
+      a.M = M; a.N = 2 * C; a.n_tiles = p->A[l].n_tiles; a.k_chunks = p->A[l].k_chunks;
+      a.nseg = C1 > 0 ? 3 : 2;
+      a.seg_k[0] = C; a.seg[0] = h + (p0 - d) * C; a.seg_ld[0] = C; a.seg_batch[0] = P * C;
+      a.seg_k[1] = C; a.seg[1] = h + p0 * C; a.seg_ld[1] = C; a.seg_batch[1] = P * C;
+      if (C1 > 0) { a.seg_k[2] = C1; a.seg[2] = p->pf_c + p0 * C1; a.seg_ld[2] = C1; a.seg_batch[2] = P * C1; }
+      a.wp = p->A[l].Wp; a.bias = p->A[l].bias;
+      a.out = p->pf_y + p0 * C; a.out_ld = C; a.out_batch = P * C;
+      MMK_TRY(launch_wn_prefill(a, 0, B, st));
+    }
+    {
+      WnPrefillArgs a = {};
+      a.M = M; a.N = C; a.n_tiles = C / 16; a.k_chunks = p->Bm[l].k_chunks;
+      a.nseg = 1;
+      a.seg_k[0] = C; a.seg[0] = p->pf_y + p0 * C; a.seg_ld[0] = C; a.seg_batch[0] = P * C;
+      a.wp = p->Bm[l].Wp; a.bias = p->Bm[l].bias;     // rows [res ; skip]: the first C packed rows
+      a.res_in = h + p0 * C; a.res_ld = C; a.res_batch = P * C;
+      a.out = p->pf_h[cur ^ 1] + p0 * C; a.out_ld = C; a.out_batch = P * C;
+      MMK_TRY(launch_wn_prefill(a, 1, B, st));
+    }
+    cur ^= 1;
+  }
+  return MMK_OK;
+}
+
 // run n steps starting at position tau0 (device counter is set here)
 static int run_steps(mmk_wavenet_plan* p, const WnCall& call, int64_t tau0, int64_t n, bool with_head, hipStream_t st) {
   if (n <= 0) return MMK_OK;
@@ -689,6 +763,9 @@ extern "C" int mmk_wavenet_warmup(mmk_wavenet_plan* p, int32_t batch, const void
   MMK_TRY(check_call(p, batch, in0, cond, cond_row_stride, call));
   call.in0_rs = in0_row_stride;
   if (t_begin < 0 || t_end < t_begin) return fail(MMK_ERR_INVALID, "wavenet_warmup: bad range [%lld, %lld)", (long long)t_begin, (long long)t_end);
+  const char* penv = getenv("MMK_WN_PREFILL");
+  if (p->persistent && t_end > t_begin && t_end - t_begin <= p->pf_P && !(penv && penv[0] == '0'))
+    return prefill(p, call, t_begin, t_end, (hipStream_t)stream);
   return run_steps(p, call, t_begin, t_end - t_begin, false, (hipStream_t)stream);
 }
 

@@ -287,14 +287,14 @@ def _cond_net(seed=21):
 
 
 MODES = {"persistent_xcd": {}, "persistent_agent": {"MMK_WN_XCD_LOCAL": "0"}, "persistent_tiles": {"MMK_WN_SMALL": "0"},
-         "launches": {"MMK_WN_PERSISTENT": "0"}}
+         "persistent_step_warmup": {"MMK_WN_PREFILL": "0"}, "launches": {"MMK_WN_PERSISTENT": "0"}}
 
 
 @pytest.mark.parametrize("mode", list(MODES))
 def test_wavenet_modes_agree_with_oracle(device, mode, monkeypatch):
-    """the persistent kernel (XCD-local and agent-scope hand-offs, 4x4 MFMA blocks and 16-row tiles) and the
-    per-layer launch path all reproduce the oracle: conditioned net, batch 5 (ragged clip groups), prompt longer than rf, 70 steps, greedy + sampled"""
-    for k in ("MMK_WN_XCD_LOCAL", "MMK_WN_PERSISTENT", "MMK_WN_GROUPS", "MMK_WN_SMALL"):
+    """the persistent kernel (XCD-local and agent-scope hand-offs, 4x4 MFMA blocks and 16-row tiles, warm-up as a
+    prefill and step by step) and the per-layer launch path all reproduce the oracle: conditioned net, batch 5 (ragged clip groups), prompt longer than rf, 70 steps, greedy + sampled"""
+    for k in ("MMK_WN_XCD_LOCAL", "MMK_WN_PERSISTENT", "MMK_WN_GROUPS", "MMK_WN_SMALL", "MMK_WN_PREFILL"):
         monkeypatch.delenv(k, raising=False)
     for k, v in MODES[mode].items():
         monkeypatch.setenv(k, v)
@@ -346,7 +346,7 @@ def test_wavenet_persistent_kernel_shapes(device, monkeypatch, C, B, env):
     """other instantiations of the persistent kernel against the oracle: 96 channels (2 K-chunks per matrix wave,
     3 matrix waves), 128 channels with 9 clips per group (16-row MFMA tiles, two poll rounds per hand-off),
     agent-scope groups with a ragged last group, 256 channels with 5 clips per group"""
-    for k in ("MMK_WN_XCD_LOCAL", "MMK_WN_PERSISTENT", "MMK_WN_GROUPS", "MMK_WN_SMALL"):
+    for k in ("MMK_WN_XCD_LOCAL", "MMK_WN_PERSISTENT", "MMK_WN_GROUPS", "MMK_WN_SMALL", "MMK_WN_PREFILL"):
         monkeypatch.delenv(k, raising=False)
     for k, v in env.items():
         monkeypatch.setenv(k, v)
@@ -371,7 +371,7 @@ def test_wavenet_persistent_kernel_shapes(device, monkeypatch, C, B, env):
 
 def test_wavenet_persistent_long_block_crosses_cond_blocks(device, monkeypatch):
     """more steps than one conditioning block (1024): two persistent launches chained through the product rings"""
-    for k in ("MMK_WN_XCD_LOCAL", "MMK_WN_PERSISTENT", "MMK_WN_GROUPS", "MMK_WN_SMALL"):
+    for k in ("MMK_WN_XCD_LOCAL", "MMK_WN_PERSISTENT", "MMK_WN_GROUPS", "MMK_WN_SMALL", "MMK_WN_PREFILL"):
         monkeypatch.delenv(k, raising=False)
     net, sd, arch = _cond_net(seed=22)
     net = net.to(device)
