@@ -603,7 +603,7 @@ __global__ __launch_bounds__(wn_threads(KC)) void wavenet_persist_kernel(const W
         // 1.5 MB per XCD need about a microsecond of the XCD's fabric link.  So the stream is cut in three
         // 16-KiB pieces per workgroup, each issued right after a hand-off completed or a publish left:
         // this layer's B fragments at the layer's top, the next layer's tap-0 fragments behind publish y,
-        // its tap-1 fragments behind phase B.
+        // its tap-1 fragments behind publish h'.
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int u = 0; u < CPW; ++u) w_t0[u] = frag_A(u);
@@ -626,14 +626,14 @@ __global__ __launch_bounds__(wn_threads(KC)) void wavenet_persist_kernel(const W
             redB[mwave * 64 + lane] = acc;
           }
         }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int u = 0; u < CPW; ++u) w_t1[u] = frag_A(CPW + u);
-        __builtin_amdgcn_sched_barrier(0);
         if (cur_hasb) {
           __syncthreads();                                 // B3
           __syncthreads();                                 // B3b: the I/O waves have published h'
         }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < CPW; ++u) w_t1[u] = frag_A(CPW + u);
+        __builtin_amdgcn_sched_barrier(0);
         small_to_lds();
         stamp(12);   // phase B + B3 + small operands to LDS
         __syncthreads();                                   // B4
