@@ -44,8 +44,8 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_f32_kernel(const float* __r
     *reinterpret_cast<f32x4*>(as + m * ldk + c) = v;
   }
   __syncthreads();
-  if (tile >= n_tiles) return;
-  gf32x4_ptr w = (gf32x4_ptr)(uintptr_t)Wp + (int64_t)tile * k_chunks * 64 + lane;
+  const int wtile = tile < n_tiles ? tile : n_tiles - 1;       // surplus waves recompute the last tile (never stored)
+  gf32x4_ptr w = (gf32x4_ptr)(uintptr_t)Wp + (int64_t)wtile * k_chunks * 64 + lane;
   const float* x = as + (lane & 15) * ldk + 4 * (lane >> 4);
   f32x4 acc[4];
 #pragma unroll
@@ -63,17 +63,24 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_f32_kernel(const float* __r
     }
     wv = wn;
   }
-  // ---- D: column lane & 15, rows 4 (lane >> 4) + r of each 16-row tile -------------------------------------------
-  const int col = tile * 16 + (lane & 15);
-  if (col < N) {
+  // ---- D (column lane & 15, rows 4 (lane >> 4) + r) -> LDS -> rows of 512 contiguous bytes ------------------------
+  __syncthreads();                                              // every wave is done with the A block
+  constexpr int ldo = kGemmBN + 4;
+  float* os = as;                                               // 64 x 132 floats <= the A stage (K >= 128) or its own 33 KiB
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
+  for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int m = m_first + mt * 16 + 4 * (lane >> 4) + r;
-        if (m < M) C[(int64_t)m * ldc + col] = acc[mt][r];
-      }
-    }
+    for (int r = 0; r < 4; ++r) os[(mt * 16 + 4 * (lane >> 4) + r) * ldo + wave * 16 + (lane & 15)] = acc[mt][r];
+  __syncthreads();
+  const int col0 = blockIdx.x * kGemmBN;
+  for (int q = tid; q < kGemmBM * (kGemmBN / 4); q += kGemmThreads) {
+    const int m = q / (kGemmBN / 4), c = (q - m * (kGemmBN / 4)) * 4;
+    if (m_first + m >= M) continue;
+    float* dst = C + (int64_t)(m_first + m) * ldc + col0 + c;
+    const f32x4 v = *reinterpret_cast<const f32x4*>(os + m * ldo + c);
+    if (col0 + c + 3 < N && (ldc & 3) == 0) *reinterpret_cast<f32x4*>(dst) = v;
+    else
+      for (int i = 0; i < 4; ++i) if (col0 + c + i < N) dst[i] = v[i];
   }
 }
 
@@ -81,7 +88,9 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_f32_kernel(const float* __r
 int launch_gemm_f32(const float* A, int64_t lda, int64_t a_batch, const float* Wp, int n_tiles, int k_chunks, int N, int K,
                     float* C, int64_t ldc, int64_t c_batch, int M, int batch, hipStream_t stream) {
   if (M <= 0 || batch <= 0 || n_tiles <= 0) return MMK_OK;
-  const size_t lds = (size_t)kGemmBM * (k_chunks * 16 + 4) * sizeof(float);
+  size_t lds = (size_t)kGemmBM * (k_chunks * 16 + 4) * sizeof(float);
+  const size_t lds_out = (size_t)kGemmBM * (kGemmBN + 4) * sizeof(float);
+  if (lds < lds_out) lds = lds_out;
   if (lds > 160 * 1024) return fail(MMK_ERR_UNSUPPORTED, "gemm: K=%d does not fit the LDS stage", K);
   if ((lda % 4) != 0 || (reinterpret_cast<uintptr_t>(A) & 15) != 0) return fail(MMK_ERR_UNSUPPORTED, "gemm: A must be 16-byte aligned with lda %% 4 == 0");
   dim3 grid((n_tiles + kGemmBN / 16 - 1) / (kGemmBN / 16), (M + kGemmBM - 1) / kGemmBM, batch), block(kGemmThreads);
