@@ -236,8 +236,40 @@ class SrnnJob:
                 "clips_per_gpu": self.clips, "global_clips": self.clips * world, "prompt_samples": self.prompt_len,
                 "generated_samples_per_clip": self.n_steps, "decode": "greedy", "parallelism": f"clip-shard x{world}"}
 
+    def step_bytes(self):
+        """algorithmic bytes of one auto-regressive step of the local batch, amortised over the tier clocks: every
+        tier's weights once per update (tier i fires every frame_sizes[i] steps, the bottom tier and the MLP every
+        step) + the per-clip state it touches"""
+        fs = (16, 4, 1)
+        total = 0.0
+        for n, p in self.net.named_parameters():
+            if n.startswith("tiers."):
+                i = int(n.split(".")[1])
+                total += 4 * p.numel() / fs[i]
+            else:
+                total += 4 * p.numel()
+        H = 512
+        state = self.clips * 4 * (2 * H / 16 + 2 * H / 4 + 4 * H / 16 + 4 * H / 4 + H + 8)   # h in/out, up-sampled outputs, x
+        return int(total + state)
+
     def roofline(self):
-        return None
+        """the step is a chain of small launches: HIP events around one whole generate block on the launch stream"""
+        n = min(self.n_steps, 1600)
+        self.net.before_generate((self.idx[:, :self.prompt_len],), None)
+        torch.cuda.synchronize()
+        start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        start.record()
+        self.net.generate_block((self.idx,), self.prompt_len, n)
+        stop.record()
+        torch.cuda.synchronize()
+        self.net.after_generate((self.idx,), None)
+        us = start.elapsed_time(stop) * 1e3
+        nbytes = self.step_bytes() * n
+        achieved = nbytes / (us * 1e-6) / 1e9
+        return {"bound": "hbm", "kernel": "SampleRNN step chain (srnn_bottom_kernel + srnn_gru_kernel + up-sampler GEMM), one generate block",
+                "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
+                "traffic": None, "algorithmic_bytes_per_launch": nbytes, "avg_launch_us": round(us, 1), "launches_timed": 1,
+                "steps_per_launch": n, "us_per_step": round(us / n, 2)}
 
     def cpu_baseline(self, budget_s):
         from oracle import torch_ref as O

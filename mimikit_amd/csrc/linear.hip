@@ -240,7 +240,7 @@ int launch_linear(const LinearArgs& a_in, hipStream_t stream) {
   // GEMM-like shapes: up to 64 rows per workgroup so a weight fragment is reused from registers
   const int m_tiles = (a.M + 15) / 16;
   int mt = 1;
-  if ((long)a.n_tiles * m_tiles > 512) mt = m_tiles >= 4 ? 4 : (m_tiles >= 2 ? 2 : 1);
+  if ((long)a.n_tiles * m_tiles >= 512) mt = m_tiles >= 4 ? 4 : (m_tiles >= 2 ? 2 : 1);
   int nw = 1;
   while (nw < 16 && a.k_chunks > nw * 3) nw *= 2;  // <= 3 K-chunks (48 columns) per wave where possible
   dim3 grid(a.n_tiles, (a.M + mt * 16 - 1) / (mt * 16));
