@@ -81,8 +81,22 @@ __device__ __forceinline__ bool sweep(const u64* gran, int count, unsigned epoch
       bool ok = true;
       for (;;) {
         bool all = true;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) v[k] = gran_load(gran + i0 + k);
+        {
+          // two 16-byte agent-scope loads (sc1: L1 bypass) for the four 8-byte granules.  A granule is written by ONE
+          // aligned 8-byte store and lies inside one aligned 16-byte read: both are single transactions on a cache
+          // line, so a granule is seen entirely old or entirely new; its tag is checked either way.
+          typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
+          u32x4v lo, hi;
+          const u64* gp = gran + i0;
+          asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dwordx4 %1, %2, off offset:16 sc1\n\ts_waitcnt vmcnt(0)"
+                       : "=&v"(lo), "=&v"(hi)
+                       : "v"(gp)
+                       : "memory");
+          v[0] = ((u64)lo[1] << 32) | lo[0];
+          v[1] = ((u64)lo[3] << 32) | lo[2];
+          v[2] = ((u64)hi[1] << 32) | hi[0];
+          v[3] = ((u64)hi[3] << 32) | hi[2];
+        }
 #pragma unroll
         for (int k = 0; k < 4; ++k) all = all && ((unsigned)(v[k] >> 32) == epoch);
         if (all) break;
