@@ -268,7 +268,16 @@ __global__ __launch_bounds__(wn_threads(KC)) void wavenet_persist_kernel(const W
   int* sfx = (int*)sp;                    sp += ((L * 4 + 15) / 16) * 16;   // sfx[l] = sum of the dilations above layer l
   int* s_idx = (int*)sp;      sp += 16 * 4;
   int* s_fail = (int*)sp;     sp += 16;
-  float* lbuf = (float*)sp;                                               // logits for the sampler (owner 0 only)
+  float* lbuf = (float*)sp;   sp += 16 * ldl * 4;                         // logits for the sampler (owner 0 only)
+  // the head's weight tiles of this workgroup (fc0: tiles j, j + Gn, ..; fc2 likewise) and their biases, staged once
+  // per launch: the layers' weight stream evicts them from L2 every step, and a miss costs ~1 us on the chain
+  const int t_fc0 = a.H1 / 16, kc_fc0 = C / 16;
+  const int t_fc2 = a.n_logits_pad / 16, kc_fc2 = a.H1 / 16;
+  const int nt0 = j < t_fc0 ? (t_fc0 - j + a.Gn - 1) / a.Gn : 0, nt2 = j < t_fc2 ? (t_fc2 - j + a.Gn - 1) / a.Gn : 0;
+  f32x4* hw0 = (f32x4*)sp;    sp += (size_t)((t_fc0 + a.Gn - 1) / a.Gn) * kc_fc0 * 1024;
+  f32x4* hw2 = (f32x4*)sp;    sp += (size_t)((t_fc2 + a.Gn - 1) / a.Gn) * kc_fc2 * 1024;
+  float* hb0 = (float*)sp;    sp += (size_t)((t_fc0 + a.Gn - 1) / a.Gn) * 64;
+  float* hb2 = (float*)sp;
   f32x4* redA = red, *redB = red + NWM * 64;
 
   const int D_q = lane >> 4, D_n = lane & 15;
@@ -299,6 +308,16 @@ __global__ __launch_bounds__(wn_threads(KC)) void wavenet_persist_kernel(const W
     const int btile = owns_res ? j : (j - kcC + (t.has_res ? kcC : 0));
     biasA[i] = t.A_bias ? t.A_bias[j * 16 + n] : 0.f;
     biasB[i] = (t.B_bias && (!owns_res || t.has_res)) ? t.B_bias[btile * 16 + n] : 0.f;
+  }
+  for (int i = 0; i < nt0; ++i) {
+    const f32x4* src = reinterpret_cast<const f32x4*>(a.fc0_wp) + (int64_t)(j + i * a.Gn) * kc_fc0 * 64;
+    for (int q = tid; q < kc_fc0 * 64; q += NT) hw0[i * kc_fc0 * 64 + q] = src[q];
+    if (tid < 16) hb0[i * 16 + tid] = a.fc0_bias[(j + i * a.Gn) * 16 + tid];
+  }
+  for (int i = 0; i < nt2; ++i) {
+    const f32x4* src = reinterpret_cast<const f32x4*>(a.fc2_wp) + (int64_t)(j + i * a.Gn) * kc_fc2 * 64;
+    for (int q = tid; q < kc_fc2 * 64; q += NT) hw2[i * kc_fc2 * 64 + q] = src[q];
+    if (tid < 16) hb2[i * 16 + tid] = a.fc2_bias[(j + i * a.Gn) * 16 + tid];
   }
   if (tid == 0) *s_fail = 0;
   __syncthreads();
@@ -443,7 +462,7 @@ __global__ __launch_bounds__(wn_threads(KC)) void wavenet_persist_kernel(const W
       if (mt + k * NMT < mg * 16) cndbuf[mt + k * NMT] = cnd_n[k];
   };
   // diagnostic build only: 100 MHz wall-clock stamps of thread 0 (an I/O wave) of owner 1 of group 0, summed
-  unsigned long long st_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long st_acc[18] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long st_prev = 0;
   auto stamp = [&](int slot) {
     if (STAMPS) {
@@ -513,6 +532,7 @@ __global__ __launch_bounds__(wn_threads(KC)) void wavenet_persist_kernel(const W
       }
     }
     __syncthreads();
+    if (STAMPS && s > 0) stamp(7);   // wait for the sampled classes + embedding rows
     if (STAMPS) st_prev = wall_clock64();
 
     if (is_io) {
@@ -662,16 +682,14 @@ __global__ __launch_bounds__(wn_threads(KC)) void wavenet_persist_kernel(const W
     const unsigned he = (unsigned)(s + 1);
     if (elem && !owns_res) gran_store<XCD>(gran_skip + e_m * C + (j - kcC) * 16 + e_n, he, skipacc);
     // fc0 + Mish : tiles j, j+Gn, ... of H1/16
-    const int t_fc0 = a.H1 / 16, kc_fc0 = C / 16;
     if (j < t_fc0) {
       if (!sweep<NT>(gran_skip, mg * C, he, sw_y, ybuf, C, ldy, err, s_fail)) return;
       const int per = (kc_fc0 + nw - 1) / nw;
       const int k0 = min(wave * per, kc_fc0), k1 = min(k0 + per, kc_fc0);
-      for (int t = j; t < t_fc0; t += a.Gn) {
-        const f32x4* W = reinterpret_cast<const f32x4*>(a.fc0_wp) + (int64_t)t * kc_fc0 * 64;
-        f32x4 v = reduce_waves(tile_mma(ybuf, ldy, W, 0, k0, k1, lane), redA, wave, lane, nw);
+      for (int t = j, ti = 0; t < t_fc0; t += a.Gn, ++ti) {
+        f32x4 v = reduce_waves(tile_mma(ybuf, ldy, hw0 + ti * kc_fc0 * 64, 0, k0, k1, lane), redA, wave, lane, nw);
         if (wave == 0) {
-          const float bias = a.fc0_bias[t * 16 + D_n];
+          const float bias = hb0[ti * 16 + D_n];
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int m = 4 * D_q + r;
@@ -680,17 +698,16 @@ __global__ __launch_bounds__(wn_threads(KC)) void wavenet_persist_kernel(const W
         }
       }
     }
+    stamp(16);    // head: wait for the skip sums + fc0
     // fc2 : tiles of the (n_classes + temperature column) outputs
-    const int t_fc2 = a.n_logits_pad / 16, kc_fc2 = a.H1 / 16;
     if (j < t_fc2) {
       if (!sweep<NT>(gran_hid, mg * a.H1, he, nullptr, ybuf, a.H1, ldy, err, s_fail)) return;
       const int per = (kc_fc2 + nw - 1) / nw;
       const int k0 = min(wave * per, kc_fc2), k1 = min(k0 + per, kc_fc2);
-      for (int t = j; t < t_fc2; t += a.Gn) {
-        const f32x4* W = reinterpret_cast<const f32x4*>(a.fc2_wp) + (int64_t)t * kc_fc2 * 64;
-        f32x4 v = reduce_waves(tile_mma(ybuf, ldy, W, 0, k0, k1, lane), redA, wave, lane, nw);
+      for (int t = j, ti = 0; t < t_fc2; t += a.Gn, ++ti) {
+        f32x4 v = reduce_waves(tile_mma(ybuf, ldy, hw2 + ti * kc_fc2 * 64, 0, k0, k1, lane), redA, wave, lane, nw);
         if (wave == 0) {
-          const float bias = a.fc2_bias[t * 16 + D_n];
+          const float bias = hb2[ti * 16 + D_n];
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int m = 4 * D_q + r;
@@ -786,6 +803,7 @@ __global__ __launch_bounds__(wn_threads(KC)) void wavenet_persist_kernel(const W
       for (int i = 0; i < 8; ++i) a.stamps[i] = st_acc[i];
       a.stamps[14] = st_acc[14];
       a.stamps[15] = st_acc[15];
+      a.stamps[16] = st_acc[16];
     }
     if (tid == NIO)
       for (int i = 8; i < 14; ++i) a.stamps[i] = st_acc[i];
@@ -798,7 +816,8 @@ size_t wn_persist_lds_bytes(const WnPersistArgs& a) {
   const int ldh = a.C + 4, ldy = wide + 4, ldl = a.n_logits_pad + 4;
   const int red = (2 * nwm > nw ? 2 * nwm : nw) * 64;
   return (size_t)2 * 16 * ldh * 4 + (size_t)16 * ldy * 4 + (size_t)red * 16 + (size_t)a.L * 32 + (size_t)a.L * 128 +
-         256 * 4 + (size_t)((a.L * 4 + 15) / 16) * 16 + 16 * 4 + 16 + (size_t)16 * ldl * 4;
+         256 * 4 + (size_t)((a.L * 4 + 15) / 16) * 16 + 16 * 4 + 16 + (size_t)16 * ldl * 4 +
+         (size_t)((a.H1 / 16 + a.Gn - 1) / a.Gn) * (kc * 1024 + 64) + (size_t)((a.n_logits_pad / 16 + a.Gn - 1) / a.Gn) * ((a.H1 / 16) * 1024 + 64);
 }
 
 int launch_wavenet_persist(const WnPersistArgs& a, hipStream_t stream) {

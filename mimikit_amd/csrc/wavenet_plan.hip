@@ -261,6 +261,12 @@ static int derive(mmk_wavenet_plan* p) {
       }
       p->ring_floats_per_wg = off;
       if (off * 4 >= ((int64_t)1 << 32)) p->persistent = false;   // ring offsets are 32-bit byte offsets in the kernel
+      {
+        WnPersistArgs probe = {};   // the kernel's LDS carve must fit (wide MLP heads may not)
+        probe.C = p->C; probe.S = p->S; probe.H1 = c.mlp_hidden; probe.n_logits_pad = p->n_logits_pad; probe.L = p->L;
+        probe.Gn = p->Gn;
+        if (wn_persist_lds_bytes(probe) > 160 * 1024) p->persistent = false;
+      }
       if (p->C1 > 0) p->cond_all.set_geometry(p->L * 2 * p->C, {p->C1});
     }
   }
@@ -843,12 +849,13 @@ extern "C" int mmk_wavenet_sync_status(mmk_wavenet_plan* p, mmk_stream_t stream)
   {
     const char* senv = getenv("MMK_WN_STAMPS");
     if (senv && senv[0] == '1') {
-      unsigned long long st[16];
+      unsigned long long st[24];
       MMK_HIP(hipMemcpy(st, p->tau + 8, sizeof(st), hipMemcpyDeviceToHost));
       const char* names[7] = {"wait phase A", "epilogue A + publish", "wait y", "wait phase B", "epilogue B + publish", "wait h'", "head"};
       const int slot[7] = {0, 1, 2, 3, 4, 5, 6};
       fprintf(stderr, "[mmk stamps] last persistent launch, I/O wave 0 of workgroup 1, totals in ms:");
       for (int i = 0; i < 7; ++i) fprintf(stderr, " %s=%.3f;", names[i], st[slot[i]] * 1e-5);
+      fprintf(stderr, " [step start=%.3f; head: skip wait + fc0=%.3f, rest=%.3f]", st[7] * 1e-5, st[16] * 1e-5, st[6] * 1e-5);
       const char* mnames[6] = {"requests", "phase A", "B1", "wait y", "phase B + small operands", "wait h'"};
       fprintf(stderr, " | matrix wave 0:");
       for (int i = 0; i < 6; ++i) fprintf(stderr, " %s=%.3f;", mnames[i], st[8 + i] * 1e-5);
