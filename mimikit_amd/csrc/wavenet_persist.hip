@@ -146,14 +146,25 @@ __device__ __forceinline__ f32x4 tile_mma(const float* x, int ld, const f32x4* w
 // One step of the K loop of the per-layer products.
 //   SMALL == false: v_mfma_f32_16x16x4_f32 - rows = 16 clips (lane & 15), K = 4 per instruction.
 //   SMALL == true : v_mfma_f32_4x4x1_16b_f32 - 16 independent 4x4 blocks, K = 1 per instruction.  Block b = lane / 4
-//     handles output columns 4 (b % 4) .. +3 for k sub-slice b / 4; A operand = x[clip lane % 4][k], B operand =
-//     W[column lane % 16][k], D register i of lane = (clip i, column lane % 16).  With at most 4 clips per group
+//     handles output columns 4 (b / 4) .. +3 for k sub-slice b % 4; A operand = x[clip lane % 4][k], B operand =
+//     W[column 4 (lane / 16) + lane % 4][k], D register i of lane = (clip i, that column).  With at most 4 clips per group
 //     a 16-row tile would be 3/4 padding; this form does the same arithmetic in a quarter of the matrix-pipe time
 //     (layout measured with scripts/probes/mfma4x4.hip).
 template <bool SMALL>
 __device__ __forceinline__ f32x4 mma_step(float x, float w, f32x4 acc) {
   if (SMALL) return __builtin_amdgcn_mfma_f32_4x4x1f32(x, w, acc, 0, 0, 0);
   return __builtin_amdgcn_mfma_f32_16x16x4f32(x, w, acc, 0, 0, 0);
+}
+
+// 4x4-block mode: add the partial sums of the four K sub-slices of a column group (lanes 4 apart inside a row of 16):
+// after two row shifts the lane of sub-slice 3 holds ((s3 + s2) + (s1 + s0)); shifted-in lanes read zero
+__device__ __forceinline__ f32x4 reduce_subslices(f32x4 v) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    v[i] += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v[i]), 0x114, 0xf, 0xf, true));   // row_shr:4
+    v[i] += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v[i]), 0x118, 0xf, 0xf, true));   // row_shr:8
+  }
+  return v;
 }
 
 // cross-wave reduction in fixed order; result valid in wave 0 only (head phases)
@@ -348,14 +359,15 @@ __global__ __launch_bounds__(wn_threads(KC)) void wavenet_persist_kernel(const W
   const bool elem = tid < mg * 16;
   const int e_m = tid >> 4, e_n = tid & 15;
   // 16x16 tiles: (row m, col n) sits in lane 16 (m / 4) + n, register m % 4; one partial per matrix wave.
-  // 4x4 blocks  : (clip m, col n) sits in lane 16 ks + n, register m, for each of the 4 k sub-slices ks.
-  const int frag = SMALL ? e_n * 4 + e_m : ((e_m >> 2) * 16 + e_n) * 4 + (e_m & 3);
-  constexpr int kParts = SMALL ? 4 * NWM : NWM;
+  // 4x4 blocks  : (clip m, col n) sits in lane 16 (n / 4) + 12 + n % 4 (the lane of sub-slice 3, which holds the sum
+  //               over the four sub-slices), register m; one partial per matrix wave.
+  const int frag = SMALL ? ((e_n >> 2) * 16 + 12 + (e_n & 3)) * 4 + e_m : ((e_m >> 2) * 16 + e_n) * 4 + (e_m & 3);
+  constexpr int kParts = NWM;
   auto sum_partials = [&](const f32x4* part) -> float {
     const float* f = reinterpret_cast<const float*>(part) + frag;
     float pv[kParts];
 #pragma unroll
-    for (int w = 0; w < kParts; ++w) pv[w] = f[w * (SMALL ? 64 : 256)];   // all reads in flight before the first add
+    for (int w = 0; w < kParts; ++w) pv[w] = f[w * 256];   // all reads in flight before the first add
     __builtin_amdgcn_sched_barrier(0);
     float v = 0.f;
 #pragma unroll
@@ -407,8 +419,11 @@ __global__ __launch_bounds__(wn_threads(KC)) void wavenet_persist_kernel(const W
   // (4x4 blocks: the lane's k sub-slice ks = lane / 16 starts 4 CPW ks floats into the wave's slice; its fragment u
   //  holds W[column lane % 16][4 consecutive k], which is element (q, n) of a chunk of the SAME packed matrix)
   constexpr int kFragStride = SMALL ? 16 : 64;               // f32x4 elements between a lane's consecutive fragments
-  const int sm_k0 = (lane >> 4) * 4 * CPW;                   // first k of the lane's sub-slice inside the wave's slice
-  const unsigned w_voff = SMALL ? (unsigned)((c0 + sm_k0 / 16) * 64 + ((sm_k0 % 16) / 4) * 16 + (lane & 15)) * 16u
+  // lane = 16 cg + 4 ks + j: block lane / 4 = (column group cg, K sub-slice ks); the four sub-slices of a column group
+  // share a row of 16 lanes, so their partial sums are added with two DPP row shifts instead of through LDS
+  const int sm_k0 = ((lane >> 2) & 3) * 4 * CPW;             // first k of the lane's sub-slice inside the wave's slice
+  const int sm_n = (lane >> 4) * 4 + (lane & 3);             // its column inside the 16-column tile
+  const unsigned w_voff = SMALL ? (unsigned)((c0 + sm_k0 / 16) * 64 + ((sm_k0 % 16) / 4) * 16 + sm_n) * 16u
                                 : (unsigned)(c0 * 64 + lane) * 16u;
   f32x4 w_t1[CPW], w_t0[CPW], w_b[CPW];
   // MFMA A-operand addresses (LDS floats): row = lane & 15, this wave's K range
@@ -627,7 +642,7 @@ __global__ __launch_bounds__(wn_threads(KC)) void wavenet_persist_kernel(const W
 #pragma unroll
             for (int i = 0; i < 4; ++i) acc = mma_step<SMALL>(xb[u][i], w_t1[u][i], acc);
           }
-          redA[mwave * 64 + lane] = acc;
+          redA[mwave * 64 + lane] = SMALL ? reduce_subslices(acc) : acc;
         }
         stamp(9);    // phase A: operand reads, (wait for the fragments), MFMAs with the next fragments' loads
         __syncthreads();                                   // B1
@@ -657,7 +672,7 @@ __global__ __launch_bounds__(wn_threads(KC)) void wavenet_persist_kernel(const W
 #pragma unroll
               for (int i = 0; i < 4; ++i) acc = mma_step<SMALL>(xv[u][i], w_b[u][i], acc);
             }
-            redB[mwave * 64 + lane] = acc;
+            redB[mwave * 64 + lane] = SMALL ? reduce_subslices(acc) : acc;
           }
         }
         if (cur_hasb) {
