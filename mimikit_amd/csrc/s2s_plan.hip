@@ -9,6 +9,7 @@
 //   - the "[fwd|bwd].view(.., D, 2).sum(-1)" of the reference pairs ADJACENT
 //     channels of the concatenation (:100, :174); reproduced literally.
 #include "plan_util.h"
+#include "lstm_step.h"
 
 using namespace mmk;
 
@@ -77,6 +78,8 @@ struct mmk_s2s_plan {
   PackedLinear fc_out, dec_fc, out_lin;
   float *xin = nullptr, *gi[2] = {nullptr, nullptr}, *gates = nullptr;
   float *h[2] = {nullptr, nullptr}, *c[2] = {nullptr, nullptr};
+  float* h2[2] = {nullptr, nullptr};   // second state buffer of each direction (the fused step kernel ping-pongs)
+  bool fused_lstm = false;
   float *of = nullptr, *ob = nullptr, *es = nullptr, *coded = nullptr, *z = nullptr, *ysum = nullptr, *yout = nullptr;
 
   void layout(Carver& cv) {
@@ -91,6 +94,7 @@ struct mmk_s2s_plan {
     gi[1] = cv.take<float>(rows * 4 * D);
     gates = cv.take<float>((int64_t)Bmax * 4 * D);
     for (int d = 0; d < 2; ++d) { h[d] = cv.take<float>((int64_t)Bmax * D); c[d] = cv.take<float>((int64_t)Bmax * D); }
+    for (int d = 0; d < 2; ++d) h2[d] = cv.take<float>((int64_t)Bmax * D);
     of = cv.take<float>(rows * D);
     ob = cv.take<float>(rows * D);
     es = cv.take<float>((int64_t)Bmax * D);
@@ -120,6 +124,8 @@ static int derive(mmk_s2s_plan* p) {
   p->fc_out.set_geometry(p->D, {p->D});
   p->dec_fc.set_geometry(p->hop * p->D, {p->D});
   p->out_lin.set_geometry(c.out_dim, {p->D});
+  const char* fenv = getenv("MMK_S2S_FUSED");
+  p->fused_lstm = !(fenv && fenv[0] == '0') && lstm_step_supported(p->D);
   return MMK_OK;
 }
 
@@ -224,6 +230,29 @@ static int run_bilstm(mmk_s2s_plan* p, BiLstm& l, const float* x, int x_ld, int 
       MMK_HIP(hipMemsetAsync(p->h[d], 0, (size_t)p->Bmax * D * sizeof(float), st));
       MMK_HIP(hipMemsetAsync(p->c[d], 0, (size_t)p->Bmax * D * sizeof(float), st));
     }
+  }
+  if (p->fused_lstm) {
+    // both directions of a time step in one launch; the state ping-pongs between h and h2 (an even number of steps
+    // leaves it in h, an odd one is copied back)
+    float* cur[2] = {p->h[0], p->h[1]};
+    float* nxt[2] = {p->h2[0], p->h2[1]};
+    for (int s = 0; s < hop; ++s) {
+      LstmStepArgs a = {};
+      a.M = M; a.H = D; a.n_dir = 2; a.gadd_ld = (int64_t)hop * 4 * D; a.y_ld = (int64_t)hop * D;
+      for (int d = 0; d < 2; ++d) {
+        const int t = d == 0 ? s : hop - 1 - s;
+        a.dir[d].whh_wp = l.hh[d].Wp;
+        a.dir[d].gadd = p->gi[d] + (int64_t)t * 4 * D;
+        a.dir[d].h_in = cur[d]; a.dir[d].h_out = nxt[d]; a.dir[d].c = p->c[d];
+        a.dir[d].y = (d == 0 ? p->of : p->ob) + (int64_t)t * D;
+      }
+      MMK_TRY(launch_lstm_step(a, st));
+      for (int d = 0; d < 2; ++d) { float* tmp = cur[d]; cur[d] = nxt[d]; nxt[d] = tmp; }
+    }
+    if (cur[0] != p->h[0])
+      for (int d = 0; d < 2; ++d)
+        MMK_HIP(hipMemcpyAsync(p->h[d], cur[d], (size_t)M * D * sizeof(float), hipMemcpyDeviceToDevice, st));
+    return MMK_OK;
   }
   for (int s = 0; s < hop; ++s) {
     for (int d = 0; d < 2; ++d) {

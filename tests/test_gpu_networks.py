@@ -257,18 +257,23 @@ def test_seq2seq_matches_reference_golden(device):
     assert bool((out[0][:, -10:] != 0).all())                 # tests/test_seq2seq.py:146
 
 
-def test_seq2seq_cfg5_geometry_vs_oracle(device):
-    """magspec_io(22050, 1024, 256) -> 513 bins, hop 8, model_dim 128 (cfg 5 at reduced width), batch 6"""
+@pytest.mark.parametrize("fused,hop,batch", [("1", 8, 6), ("0", 8, 6), ("1", 5, 19)])
+def test_seq2seq_cfg5_geometry_vs_oracle(device, monkeypatch, fused, hop, batch):
+    """magspec_io(22050, 1024, 256) -> 513 bins, hop 8, model_dim 128 (cfg 5 at reduced width), batch 6; with the fused
+    LSTM time-step kernel (both directions per launch) and with one launch per op; an odd hop (state ends in the
+    second buffer) with a ragged row tile"""
+    monkeypatch.setenv("MMK_S2S_FUSED", fused)
     io = mmk.IOSpec.magspec_io(mmk.IOSpec.MagSpecIOConfig(sr=22050, n_fft=1024, hop_length=256))
-    net = mmk.Seq2SeqLSTMNetwork.from_config(mmk.Seq2SeqLSTMNetwork.Config(io_spec=io, model_dim=128, hop=8)).eval()
+    net = mmk.Seq2SeqLSTMNetwork.from_config(mmk.Seq2SeqLSTMNetwork.Config(io_spec=io, model_dim=128, hop=hop)).eval()
     from oracle.weights import load_recipe
     sd = load_recipe(net, seed=99, gain=1.5)
-    x = torch.rand(6, 8, 513, generator=torch.Generator().manual_seed(4))
-    want = O.s2s_step(sd, x, hop=8)
-    got = net.to(device).generate_step((x.to(device),), t=8).cpu()
+    x = torch.rand(batch, hop, 513, generator=torch.Generator().manual_seed(4))
+    want = O.s2s_step(sd, x, hop=hop)
+    got = net.to(device).generate_step((x.to(device),), t=hop).cpu()
     assert float((got - want).abs().max()) <= 1e-4 * float(want.abs().max())
-    loop_cfg = mmk.GenerateLoopV2.Config(output_duration_sec=1.0)
-    assert mmk.GenerateLoopV2.get_n_steps(loop_cfg, net) == 84
+    if hop == 8:
+        loop_cfg = mmk.GenerateLoopV2.Config(output_duration_sec=1.0)
+        assert mmk.GenerateLoopV2.get_n_steps(loop_cfg, net) == 84
 
 
 # ---------------------------------------------------------------------------- WaveNet execution modes
