@@ -13,12 +13,15 @@ struct SrnnGruArgs {
   const float* win_wp; const float* win_bias;   // input Linear (H x fs), packed (linear.hip), bias in row order
   const float* upper;                       // (B, up_mod, H) output of the tier above, or nullptr
   const float* wih_wp; const float* wih_bias; const float* whh_wp; const float* whh_bias;   // packed (linear.hip)
+  int32_t w_tile_chunks;                    // K-chunks per packed tile (H/16 for separate matrices, 2 H/16 for [x | h])
+  int32_t lstm;                             // 0: GRU (3 gates, separate biases) ; 1: LSTM (4 gates, summed bias in wih_bias)
+  float* c;                                 // LSTM cell state (B, H), in place
   float* h_ring; int64_t h_slot_stride;     // [2][B][H]: slot (cnt & 1) is read, slot ((cnt + 1) & 1) written
   int64_t* cnt; unsigned* done;             // update counter of the tier, finish ticket
   unsigned long long* stamps;               // diagnostic: phase totals (100 MHz ticks) + launch count, or nullptr
 };
 
-bool srnn_gru_supported(int H, int fs);
+bool srnn_gru_supported(int H, int fs, bool lstm);
 int launch_srnn_gru(const SrnnGruArgs& a, hipStream_t stream);
 
 }  // namespace mmk

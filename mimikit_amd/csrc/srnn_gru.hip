@@ -1,4 +1,4 @@
-// One SampleRNN GRU tier update in ONE launch (gfx950).
+// One SampleRNN GRU or LSTM tier update in ONE launch (gfx950).
 //
 // Reference: SampleRNNTier.forward (sample_rnn_v2.py:83-99) for a GRU tier with one layer:
 //     x  = Linear(linearize(idx[t-fs:t])) (+ upper tier output slice)         input_module, K = fs (tiny)
@@ -11,6 +11,8 @@
 // other workgroups.  The hidden state is double buffered ([2][B][H], slot = update counter & 1): every
 // workgroup reads the old slot, writes the new one, and the last workgroup to finish bumps the counter, which
 // the up-sampling launch that follows uses as its position counter.
+// LSTM tiers (the reference's default rnn_class) run through the same kernel: eight tiles (i, f, g, o of W_ih and W_hh,
+// which the plan packs side by side along K), the ATen LSTMCell, and a cell state updated in place.
 #include "mmk_common.h"
 #include "srnn_gru.h"
 
@@ -22,12 +24,13 @@ typedef const __attribute__((address_space(1))) f32x4* gf32x4_ptr;
 constexpr int kGruThreads = 512;
 constexpr int kGruWaves = kGruThreads / 64;
 
-template <int KC>   // KC = H / 16 K-chunks; each of the 8 waves takes KC / 8 of them
+template <int KC, bool LSTM>   // KC = H / 16 K-chunks; each of the 8 waves takes KC / 8 of them
 __global__ __launch_bounds__(kGruThreads) void srnn_gru_kernel(const SrnnGruArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   constexpr int H = KC * 16;
   constexpr int CPW = KC / kGruWaves;              // chunks per wave
   constexpr int ldx = H + 4;
+  constexpr int NG = LSTM ? 4 : 3;                 // gates; 2 NG weight tiles per workgroup
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int ub = blockIdx.x % KC;                  // block of 16 hidden units
@@ -52,21 +55,21 @@ __global__ __launch_bounds__(kGruThreads) void srnn_gru_kernel(const SrnnGruArgs
   char* sp = smem_raw;
   float* xs = (float*)sp;    sp += 16 * ldx * 4;                  // x rows of the 16 clips
   float* hs = (float*)sp;    sp += 16 * ldx * 4;                  // h rows (old state)
-  f32x4* red = (f32x4*)sp;   sp += 6 * kGruWaves * 64 * 16;       // split-K partials: [tile][wave][lane]
+  f32x4* red = (f32x4*)sp;   sp += 2 * NG * kGruWaves * 64 * 16;  // split-K partials: [tile][wave][lane]
   float* s_lin = (float*)sp;                                      // linearized window [16][fs]
 
-  // ---- weights first: 6 tiles x CPW chunks of this wave (nothing depends on them for a while) ---------------
-  f32x4 w[6][CPW];
+  // ---- weights first: 2 NG tiles x CPW chunks of this wave (nothing depends on them for a while) -----------------
+  f32x4 w[2 * NG][CPW];
   {
     const int c0 = wave * CPW;
 #pragma unroll
-    for (int g = 0; g < 3; ++g) {
-      gf32x4_ptr wi = (gf32x4_ptr)(uintptr_t)a.wih_wp + ((int64_t)(g * KC + ub) * KC + c0) * 64 + lane;
-      gf32x4_ptr wh = (gf32x4_ptr)(uintptr_t)a.whh_wp + ((int64_t)(g * KC + ub) * KC + c0) * 64 + lane;
+    for (int g = 0; g < NG; ++g) {
+      gf32x4_ptr wi = (gf32x4_ptr)(uintptr_t)a.wih_wp + ((int64_t)(g * KC + ub) * a.w_tile_chunks + c0) * 64 + lane;
+      gf32x4_ptr wh = (gf32x4_ptr)(uintptr_t)a.whh_wp + ((int64_t)(g * KC + ub) * a.w_tile_chunks + c0) * 64 + lane;
 #pragma unroll
       for (int u = 0; u < CPW; ++u) {
         w[g][u] = wi[u * 64];
-        w[3 + g][u] = wh[u * 64];
+        w[NG + g][u] = wh[u * 64];
       }
     }
   }
@@ -133,22 +136,22 @@ __global__ __launch_bounds__(kGruThreads) void srnn_gru_kernel(const SrnnGruArgs
       xv[u] = *reinterpret_cast<const f32x4*>(xr + u * 16);
       hv[u] = *reinterpret_cast<const f32x4*>(hr + u * 16);
     }
-    f32x4 acc[6];
+    f32x4 acc[2 * NG];
 #pragma unroll
-    for (int g = 0; g < 6; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int g = 0; g < 2 * NG; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int u = 0; u < CPW; ++u) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
 #pragma unroll
-        for (int g = 0; g < 3; ++g) {     // six independent accumulator chains
+        for (int g = 0; g < NG; ++g) {     // 2 NG independent accumulator chains
           acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[u][i], w[g][u][i], acc[g], 0, 0, 0);
-          acc[3 + g] = __builtin_amdgcn_mfma_f32_16x16x4f32(hv[u][i], w[3 + g][u][i], acc[3 + g], 0, 0, 0);
+          acc[NG + g] = __builtin_amdgcn_mfma_f32_16x16x4f32(hv[u][i], w[NG + g][u][i], acc[NG + g], 0, 0, 0);
         }
       }
     }
 #pragma unroll
-    for (int g = 0; g < 6; ++g) red[(g * kGruWaves + wave) * 64 + lane] = acc[g];
+    for (int g = 0; g < 2 * NG; ++g) red[(g * kGruWaves + wave) * 64 + lane] = acc[g];
   }
   __syncthreads();
   stamp(2);   // MFMAs (incl. the wait for the weights)
@@ -156,9 +159,9 @@ __global__ __launch_bounds__(kGruThreads) void srnn_gru_kernel(const SrnnGruArgs
   if (tid < 256) {
     const int m = tid >> 4, n = tid & 15;
     const int frag = ((m >> 2) * 16 + n) * 4 + (m & 3);      // (row m, col n) of a 16x16 accumulator image
-    float s[6];
+    float s[2 * NG];
 #pragma unroll
-    for (int g = 0; g < 6; ++g) {
+    for (int g = 0; g < 2 * NG; ++g) {
       const float* f = reinterpret_cast<const float*>(red + g * kGruWaves * 64) + frag;
       float v = 0.f;
 #pragma unroll
@@ -167,17 +170,29 @@ __global__ __launch_bounds__(kGruThreads) void srnn_gru_kernel(const SrnnGruArgs
     }
     if (m < mg) {
       const int unit = ub * 16 + n;
-      const float gi_r = s[0] + (a.wih_bias ? a.wih_bias[unit] : 0.f);
-      const float gi_z = s[1] + (a.wih_bias ? a.wih_bias[H + unit] : 0.f);
-      const float gi_n = s[2] + (a.wih_bias ? a.wih_bias[2 * H + unit] : 0.f);
-      const float gh_r = s[3] + (a.whh_bias ? a.whh_bias[unit] : 0.f);
-      const float gh_z = s[4] + (a.whh_bias ? a.whh_bias[H + unit] : 0.f);
-      const float gh_n = s[5] + (a.whh_bias ? a.whh_bias[2 * H + unit] : 0.f);
-      const float r = sigmoidf_(gh_r + gi_r);
-      const float z = sigmoidf_(gh_z + gi_z);
-      const float nn = tanhf(gi_n + gh_n * r);
-      const float hp = hs[m * ldx + unit];
-      h_new[(int64_t)(m_first + m) * H + unit] = (hp - nn) * z + nn;
+      const int64_t o = (int64_t)(m_first + m) * H + unit;
+      if (LSTM) {
+        // gates = (W_ih x + W_hh h) + (b_ih + b_hh); i, f, o = s(.), g = tanh(.); c' = f c + i g; h' = o tanh(c')
+        float gt[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) gt[g] = (s[g] + s[NG + g]) + (a.wih_bias ? a.wih_bias[g * H + unit] : 0.f);
+        const float ig = sigmoidf_(gt[0]), fg = sigmoidf_(gt[1]), cg = tanhf(gt[2]), og = sigmoidf_(gt[3]);
+        const float cn = fg * a.c[o] + ig * cg;
+        a.c[o] = cn;
+        h_new[o] = og * tanhf(cn);
+      } else {
+        const float gi_r = s[0] + (a.wih_bias ? a.wih_bias[unit] : 0.f);
+        const float gi_z = s[1] + (a.wih_bias ? a.wih_bias[H + unit] : 0.f);
+        const float gi_n = s[2] + (a.wih_bias ? a.wih_bias[2 * H + unit] : 0.f);
+        const float gh_r = s[3] + (a.whh_bias ? a.whh_bias[unit] : 0.f);
+        const float gh_z = s[4] + (a.whh_bias ? a.whh_bias[H + unit] : 0.f);
+        const float gh_n = s[5] + (a.whh_bias ? a.whh_bias[2 * H + unit] : 0.f);
+        const float r = sigmoidf_(gh_r + gi_r);
+        const float z = sigmoidf_(gh_z + gi_z);
+        const float nn = tanhf(gi_n + gh_n * r);
+        const float hp = hs[m * ldx + unit];
+        h_new[o] = (hp - nn) * z + nn;
+      }
     }
   }
   // ---- the last workgroup to finish publishes the new slot -----------------------------------------------------
@@ -198,24 +213,31 @@ __global__ __launch_bounds__(kGruThreads) void srnn_gru_kernel(const SrnnGruArgs
   }
 }
 
-size_t srnn_gru_lds_bytes(int H, int fs) {
-  return (size_t)2 * 16 * (H + 4) * 4 + (size_t)6 * kGruWaves * 64 * 16 + (size_t)16 * (((fs + 15) / 16) * 16 + 4) * 4;
+size_t srnn_gru_lds_bytes(int H, int fs, bool lstm) {
+  return (size_t)2 * 16 * (H + 4) * 4 + (size_t)(lstm ? 8 : 6) * kGruWaves * 64 * 16 + (size_t)16 * (((fs + 15) / 16) * 16 + 4) * 4;
 }
 
-bool srnn_gru_supported(int H, int fs) {
+bool srnn_gru_supported(int H, int fs, bool lstm) {
   if (!(H == 128 || H == 256 || H == 512)) return false;
-  return fs >= 1 && fs <= 256 && srnn_gru_lds_bytes(H, fs) <= 160 * 1024;
+  return fs >= 1 && fs <= 256 && srnn_gru_lds_bytes(H, fs, lstm) <= 160 * 1024;
 }
 
 int launch_srnn_gru(const SrnnGruArgs& a, hipStream_t stream) {
-  if (!srnn_gru_supported(a.H, a.fs)) return fail(MMK_ERR_UNSUPPORTED, "srnn gru kernel: geometry H=%d fs=%d", a.H, a.fs);
-  const size_t lds = srnn_gru_lds_bytes(a.H, a.fs);
+  const bool lstm = a.lstm != 0;
+  if (!srnn_gru_supported(a.H, a.fs, lstm)) return fail(MMK_ERR_UNSUPPORTED, "srnn tier kernel: geometry H=%d fs=%d", a.H, a.fs);
+  const size_t lds = srnn_gru_lds_bytes(a.H, a.fs, lstm);
   dim3 grid((a.H / 16) * ((a.B + 15) / 16)), block(kGruThreads);
+#define MMK_GRU(KC_)                                                                                    \
+  do {                                                                                                  \
+    if (lstm) hipLaunchKernelGGL((srnn_gru_kernel<KC_, true>), grid, block, lds, stream, a);            \
+    else hipLaunchKernelGGL((srnn_gru_kernel<KC_, false>), grid, block, lds, stream, a);                \
+  } while (0)
   switch (a.H) {
-    case 128: hipLaunchKernelGGL((srnn_gru_kernel<8>), grid, block, lds, stream, a); break;
-    case 256: hipLaunchKernelGGL((srnn_gru_kernel<16>), grid, block, lds, stream, a); break;
-    default: hipLaunchKernelGGL((srnn_gru_kernel<32>), grid, block, lds, stream, a); break;
+    case 128: MMK_GRU(8); break;
+    case 256: MMK_GRU(16); break;
+    default: MMK_GRU(32); break;
   }
+#undef MMK_GRU
   MMK_HIP(hipGetLastError());
   return MMK_OK;
 }

@@ -127,8 +127,8 @@ static int derive(mmk_srnn_plan* p) {
   const char* fenv = getenv("MMK_SRNN_FUSED");
   p->fused_bottom = !(fenv && fenv[0] == '0') && c.mlp_n_hidden == 0 &&
                     srnn_bottom_supported(p->H, c.mlp_hidden, c.q_levels + (c.learn_temp ? 1 : 0), c.frame_size[c.n_tiers - 1]);
-  p->fused_gru = !(fenv && fenv[0] == '0') && c.rnn_kind == 1;
-  for (auto& t : p->tiers) p->fused_gru = p->fused_gru && srnn_gru_supported(p->H, t.fs);
+  p->fused_gru = !(fenv && fenv[0] == '0') && (c.rnn_kind == 1 || c.rnn_kind == 0);   // GRU or LSTM tiers
+  for (auto& t : p->tiers) p->fused_gru = p->fused_gru && srnn_gru_supported(p->H, t.fs, c.rnn_kind == 0);
   return MMK_OK;
 }
 
@@ -272,7 +272,14 @@ static int emit_step(mmk_srnn_plan* p, const SrnnCall& call, int64_t tau_off, in
         g.upper = p->tiers[i - 1].out;
         g.up_mod = p->tiers[i - 1].up;
       }
-      g.wih_wp = t.gates.Wp; g.wih_bias = t.gates.bias; g.whh_wp = t.gates_hh.Wp; g.whh_bias = t.gates_hh.bias;
+      if (c.rnn_kind == 1) {
+        g.wih_wp = t.gates.Wp; g.wih_bias = t.gates.bias; g.whh_wp = t.gates_hh.Wp; g.whh_bias = t.gates_hh.bias;
+        g.w_tile_chunks = t.gates.k_chunks;
+      } else {   // LSTM: one packed matrix, K = [x | h]; the summed bias
+        g.lstm = 1;
+        g.wih_wp = t.gates.Wp; g.whh_wp = t.gates.Wp + (int64_t)t.gates.seg_chunk0[1] * 256; g.wih_bias = t.gates.bias;
+        g.w_tile_chunks = t.gates.k_chunks; g.c = t.c;
+      }
       g.h_ring = t.h; g.h_slot_stride = (int64_t)p->Bmax * H;
       g.cnt = t.cnt; g.done = t.done;
       {

@@ -199,13 +199,14 @@ def test_sample_rnn_loop_with_temperature(device):
     assert float(out[0].abs().max()) <= 1.0
 
 
-@pytest.mark.parametrize("fused,frame_sizes,batch", [("1", (16, 4, 1), 64), ("0", (16, 4, 1), 64), ("1", (8, 4, 2), 6)])
-def test_sample_rnn_cfg3_shape_vs_oracle(device, monkeypatch, fused, frame_sizes, batch):
+@pytest.mark.parametrize("fused,frame_sizes,batch,kind", [("1", (16, 4, 1), 64, "gru"), ("0", (16, 4, 1), 64, "gru"),
+                                                          ("1", (8, 4, 2), 6, "gru"), ("1", (16, 4, 1), 21, "lstm")])
+def test_sample_rnn_cfg3_shape_vs_oracle(device, monkeypatch, fused, frame_sizes, batch, kind):
     """BASELINE config 3 geometry (frame sizes 16/4/1, GRU) at hidden 128, batch 64, prompt with P % rf != 0; with the
     fused bottom-tier kernel (several steps per launch) and with one launch per op; bottom frames of 2 samples, ragged
-    last workgroup"""
+    last workgroup; LSTM tiers (the reference's default) through the fused tier kernel"""
     monkeypatch.setenv("MMK_SRNN_FUSED", fused)
-    net, sd, arch = H.srnn("big", hidden=128, mlp_dim=128, seed=77, frame_sizes=frame_sizes, kind="gru")
+    net, sd, arch = H.srnn("big", hidden=128, mlp_dim=128, seed=77, frame_sizes=frame_sizes, kind=kind)
     gen = torch.Generator().manual_seed(8)
     prompt = torch.randint(0, 256, (batch, frame_sizes[0] * 5 + 7), generator=gen)
     n = 100
