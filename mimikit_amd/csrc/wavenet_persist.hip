@@ -739,8 +739,8 @@ __global__ __launch_bounds__(wn_threads(KC)) void wavenet_persist_kernel(const W
       for (int m = wave; m < mg; m += nw) {
         const float* lg = lbuf + m * ldl;
         const int clip = m_first + m;
-        if (a.logits_out)
-          for (int c = lane; c < nc + a.learn_temp; c += 64) a.logits_out[(int64_t)clip * a.logits_ld + c] = lg[c];
+        // the caller can ask for the logits of the LAST step (mmk_wavenet_last_logits): stored after the class is out
+        const bool keep_logits = a.logits_out && s + 1 == a.n_steps;
         float denom = 1.f;
         if (a.learn_temp) denom = fmaxf(sigmoidf_(lg[nc]), a.min_temp);   // mlp.py:60-62
         int result;
@@ -754,11 +754,23 @@ __global__ __launch_bounds__(wn_threads(KC)) void wavenet_persist_kernel(const W
               if (v > best || bi == 0x7fffffff) { best = v; bi = c; }
             }
           }
+          // first maximum wins (torch.argmax): inside a row of 16 lanes through DPP (VALU), across rows through LDS permutes
+          auto take = [&](float ob, int oi) {
+            if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+          };
+#define MMK_DPP_STEP(CTRL)                                                                                           \
+          take(__int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(best), CTRL, 0xf, 0xf, false)),            \
+               __builtin_amdgcn_update_dpp(0, bi, CTRL, 0xf, 0xf, false))
+          MMK_DPP_STEP(0xB1);    // quad_perm [1,0,3,2]
+          MMK_DPP_STEP(0x4E);    // quad_perm [2,3,0,1]
+          MMK_DPP_STEP(0x141);   // row_half_mirror
+          MMK_DPP_STEP(0x140);   // row_mirror
+#undef MMK_DPP_STEP
 #pragma unroll
-          for (int o = 32; o > 0; o >>= 1) {
+          for (int o = 16; o <= 32; o <<= 1) {
             const float ob = __shfl_xor(best, o);
             const int oi = __shfl_xor(bi, o);
-            if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+            take(ob, oi);
           }
           result = bi;
         } else {
@@ -803,9 +815,11 @@ __global__ __launch_bounds__(wn_threads(KC)) void wavenet_persist_kernel(const W
           result = pick != 0x7fffffff ? pick : (last_c < 0 ? 0 : last_c);
         }
         if (lane == 0) {
+          gran_store_u32<XCD>(gran_idx + m, he, (unsigned)result);   // first: every workgroup of the group waits for it
           a.idx[(int64_t)clip * a.idx_rs + tau + 1] = result;
-          gran_store_u32<XCD>(gran_idx + m, he, (unsigned)result);
         }
+        if (keep_logits)
+          for (int c = lane; c < nc + a.learn_temp; c += 64) a.logits_out[(int64_t)clip * a.logits_ld + c] = lg[c];
       }
     }
     __syncthreads();
