@@ -380,7 +380,7 @@ class FeatureJob:
         else:
             nbytes = self.out.shape[0] * self.out.shape[1] * (4 * 256 + 4 * 513)
         achieved = nbytes / (us * 1e-6) / 1e9
-        return {"bound": "hbm", "kernel": "mulaw_compress_kernel" if self.name == "mulaw" else "stft_mag_kernel",
+        return {"bound": "hbm", "kernel": "mulaw_compress_kernel" if self.name == "mulaw" else "stft1024_mag_kernel",
                 "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
                 "traffic": None, "algorithmic_bytes_per_launch": nbytes, "avg_launch_us": round(us, 2)}
 
