@@ -79,6 +79,50 @@ int64_t mmk_stft_n_frames(int64_t n_samples, int32_t n_fft, int32_t hop, int32_t
 int mmk_stft_mag_f32(const float* x, int64_t x_row_stride, int32_t batch, int64_t n_samples,
                      int32_t n_fft, int32_t hop, int32_t center, float* out, mmk_stream_t stream);
 
+/* STFT.torch_func with a complex coordinate (mimikit/features/functionals.py:506-523):
+ * torch.stft(x, n_fft, hop, window=hann_window(n_fft), center, pad_mode, return_complex=True)
+ * transposed to (batch, n_frames, n_fft/2+1), then
+ *   coordinate 0 'car'   -> (..., 2) = (real, imag)
+ *   coordinate 1 'pol'   -> (..., 2) = (abs, angle)
+ *   coordinate 2 'angle' -> angle only, no trailing dimension.
+ * reflect != 0 selects pad_mode="reflect" (needs n_samples > n_fft/2), else zeros.
+ * n_fft must be 1024 (MMK_ERR_UNSUPPORTED otherwise). */
+#define MMK_STFT_CAR 0
+#define MMK_STFT_POL 1
+#define MMK_STFT_ANGLE 2
+int mmk_stft_f32(const float* x, int64_t x_row_stride, int32_t batch, int64_t n_samples, int32_t n_fft,
+                 int32_t hop, int32_t center, int32_t reflect, int32_t coordinate, float* out,
+                 mmk_stream_t stream);
+
+/* ISTFT.torch_func (mimikit/features/functionals.py:553-564):
+ * torch.istft(spec^T, n_fft, hop, window=hann_window(n_fft)) with torch's defaults (center=True,
+ * length=None): inverse real FFT of every frame, periodic-Hann window, overlap-add, division by the
+ * overlap-added squared window, n_fft/2 samples trimmed on both sides.
+ * spec: (batch, n_frames, n_fft/2+1, 2) contiguous; coordinate 0: (real, imag), 1: (abs, angle)
+ * [the reference's 'pol': abs * exp(1j * angle)].  out: (batch, hop * (n_frames - 1)).
+ * work: mmk_istft_workspace_floats() floats of device scratch (the windowed frames).
+ * n_fft must be 1024; 1 <= hop < n_fft; n_frames >= 2. */
+int64_t mmk_istft_n_samples(int64_t n_frames, int32_t n_fft, int32_t hop);
+size_t mmk_istft_workspace_floats(int32_t batch, int64_t n_frames, int32_t n_fft);
+int mmk_istft_f32(const float* spec, int32_t coordinate, int32_t batch, int64_t n_frames, int32_t n_fft,
+                  int32_t hop, float* work, float* out, mmk_stream_t stream);
+
+/* GLA.torch_func (mimikit/features/functionals.py:634-642) = torchaudio.transforms.GriffinLim(
+ * n_fft, hop_length, power=1.) as published in torchaudio 2.0.1 (functional.griffinlim; the
+ * reference pins that version in pyproject.toml:63-68):
+ *   angles <- init;  tprev <- 0;  m = momentum / (1 + momentum)
+ *   n_iter times:  inverse = istft(mag * angles);  rebuilt = stft(inverse, center, reflect)
+ *                  angles = rebuilt - m * tprev;  angles /= |angles| + 1e-16;  tprev = rebuilt
+ *   out = istft(mag * angles)
+ * mag: (batch, n_frames, n_fft/2+1) magnitudes (time x freq, as the functional receives them).
+ * init: (batch, n_frames, n_fft/2+1, 2) initial complex "angles" (torchaudio draws torch.rand of a
+ * complex dtype: both parts uniform in [0, 1)), or NULL for rand_init=False (all 1 + 0i).
+ * out: (batch, hop * (n_frames - 1)), which must exceed n_fft/2 (reflect padding).
+ * work: mmk_gla_workspace_floats() floats of device scratch. */
+size_t mmk_gla_workspace_floats(int32_t batch, int64_t n_frames, int32_t n_fft, int32_t hop);
+int mmk_gla_f32(const float* mag, const float* init, int32_t batch, int64_t n_frames, int32_t n_fft,
+                int32_t hop, int32_t n_iter, float momentum, float* work, float* out, mmk_stream_t stream);
+
 /* ------------------------------------------------------------------------
  * Building blocks (exported for unit parity tests and for host-side reuse)
  * ---------------------------------------------------------------------- */

@@ -2,6 +2,7 @@
 // framed periodic-Hann STFT magnitude (MagSpec).  All HBM-bound streaming work:
 // coalesced 16 B/lane accesses, tables and frame tiles staged in LDS.
 #include "mmk_common.h"
+#include "fft1024.h"
 
 namespace mmk {
 
@@ -199,46 +200,8 @@ __global__ __launch_bounds__(256) void stft_mag_kernel(const float* __restrict__
 }
 
 
-// ---- n_fft = 1024: one frame pair per WAVE, 16 points per lane in registers ----------------------------------------
-// 1024 = 16 x 16 x 4.  With n = 64 n1 + n' and k = k1 + 16 k':   W^{nk} = W16^{n1 k1} W1024^{n' k1} W64^{n' k'},
-// and with n' = 4a + b, k' = c + 16 d:                            W64^{n'k'} = W16^{ac} W64^{bc} W4^{bd}.
-//   pass 1  lane n' holds x[64 n1 + n'] (the load pattern)  -> 16-point DFT over n1 in registers, twiddle W1024^{n' k1}
-//   (LDS)   lane (k1, b) collects a = 0..15                 -> 16-point DFT over a, twiddle W64^{bc}
-//   (LDS)   lane (k1, c mod 4) collects b for 4 values of c -> four 4-point DFTs over b:  X[k1 + 16 c + 256 d]
-//   (LDS)   natural order -> |A[k]|, |B[k]| of the two real frames packed as re/im, consecutive lanes on consecutive bins
-// The LDS buffer is private to the wave (wave-synchronous, no workgroup barrier in the loop); row strides of 68 and
-// 17 complex keep the transposes bank-conflict free.  The generic kernel above runs five radix-4 passes through LDS
-// with a workgroup barrier each; this one is bound by vector ALU work instead.
-struct cf32 { float x, y; };
-__device__ __forceinline__ cf32 cadd(cf32 a, cf32 b) { return cf32{a.x + b.x, a.y + b.y}; }
-__device__ __forceinline__ cf32 csub(cf32 a, cf32 b) { return cf32{a.x - b.x, a.y - b.y}; }
-__device__ __forceinline__ cf32 cmul(cf32 a, cf32 b) { return cf32{a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x}; }
-__device__ __forceinline__ void radix4(cf32& a0, cf32& a1, cf32& a2, cf32& a3) {   // out_k = sum_j a_j (-i)^{jk}
-  const cf32 t0 = cadd(a0, a2), t1 = csub(a0, a2), t2 = cadd(a1, a3), u = csub(a1, a3);
-  const cf32 t3 = cf32{u.y, -u.x};
-  a0 = cadd(t0, t2); a1 = cadd(t1, t3); a2 = csub(t0, t2); a3 = csub(t1, t3);
-}
-// 16-point DFT in place.  Input v[n1]; output X[k1] lands in v[i] with k1 = (i >> 2) + 4 (i & 3).
-__device__ __forceinline__ void dft16(cf32 (&v)[16]) {
-  constexpr float c1 = 0.92387953251128674f, s1 = 0.38268343236508977f, h = 0.70710678118654752f;
-#pragma unroll
-  for (int q = 0; q < 4; ++q) radix4(v[q], v[4 + q], v[8 + q], v[12 + q]);      // v[4r + q] = T[q][r]
-  // T[q][r] *= W16^{qr}:  W16^1 = (c1,-s1), ^2 = (h,-h), ^3 = (s1,-c1), ^4 = (0,-1), ^6 = (-h,-h), ^9 = (-c1, s1)
-  v[4 * 1 + 1] = cmul(v[4 * 1 + 1], cf32{c1, -s1});
-  v[4 * 1 + 2] = cmul(v[4 * 1 + 2], cf32{h, -h});
-  v[4 * 1 + 3] = cmul(v[4 * 1 + 3], cf32{s1, -c1});
-  v[4 * 2 + 1] = cmul(v[4 * 2 + 1], cf32{h, -h});
-  v[4 * 2 + 2] = cf32{v[4 * 2 + 2].y, -v[4 * 2 + 2].x};
-  v[4 * 2 + 3] = cmul(v[4 * 2 + 3], cf32{-h, -h});
-  v[4 * 3 + 1] = cmul(v[4 * 3 + 1], cf32{s1, -c1});
-  v[4 * 3 + 2] = cmul(v[4 * 3 + 2], cf32{-h, -h});
-  v[4 * 3 + 3] = cmul(v[4 * 3 + 3], cf32{-c1, s1});
-#pragma unroll
-  for (int r = 0; r < 4; ++r) radix4(v[4 * r], v[4 * r + 1], v[4 * r + 2], v[4 * r + 3]);   // v[4r + s] = X[r + 4s]
-}
-
 constexpr int kStftWaves = 4;
-constexpr int kStftWaveLds = 16 * 68;     // complex elements of a wave's private buffer (>= 64 x 17 and >= 1024)
+constexpr int kStftWaveLds = kFftWaveLds;
 
 __global__ __launch_bounds__(64 * kStftWaves) __attribute__((amdgpu_waves_per_eu(3, 3))) void stft1024_mag_kernel(const float* __restrict__ x, int64_t x_row_stride,
                                                                         int64_t n_samples, int hop, int center,
@@ -261,7 +224,6 @@ __global__ __launch_bounds__(64 * kStftWaves) __attribute__((amdgpu_waves_per_eu
   cf32* buf = bufs + wave * kStftWaveLds;
   const int64_t pairs_per_row = (n_frames + 1) >> 1;
   const int64_t pad = center ? N / 2 : 0;
-  const int k1b = lane >> 2, lo2 = lane & 3;                  // (k1, b) of pass 2 = (k1, c mod 4) of pass 3
 
   for (int64_t pair = (int64_t)blockIdx.x * kStftWaves + wave; pair < total_pairs; pair += (int64_t)gridDim.x * kStftWaves) {
     const int64_t b = pair / pairs_per_row;
@@ -290,40 +252,7 @@ __global__ __launch_bounds__(64 * kStftWaves) __attribute__((amdgpu_waves_per_eu
         v[r].y = (has_b && ib >= 0 && ib < n_samples) ? bb * win[r] : 0.f;
       }
     }
-    // ---- pass 1: DFT over n1, twiddle W1024^{n' k1}, transpose ---------------------------------------------------------
-    dft16(v);
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int k1 = (i >> 2) + 4 * (i & 3);
-      if (k1 != 0) v[i] = cmul(v[i], tw[(lane * k1) & (N - 1)]);
-      buf[k1 * 68 + lane] = v[i];
-    }
-    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int a2 = 0; a2 < 16; ++a2) v[a2] = buf[k1b * 68 + 4 * a2 + lo2];
-    __builtin_amdgcn_wave_barrier();
-    // ---- pass 2: DFT over a, twiddle W64^{b c}, transpose -----------------------------------------------------------------
-    dft16(v);
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int c = (i >> 2) + 4 * (i & 3);
-      if (c != 0) v[i] = cmul(v[i], tw[(16 * lo2 * c) & (N - 1)]);
-      buf[lane * 17 + c] = v[i];                              // row (k1, b)
-    }
-    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int g = 0; g < 4; ++g)
-#pragma unroll
-      for (int bq = 0; bq < 4; ++bq) v[4 * g + bq] = buf[(k1b * 4 + bq) * 17 + lo2 + 4 * g];   // c = (c mod 4) + 4 g
-    __builtin_amdgcn_wave_barrier();
-    // ---- pass 3: DFT over b -> X[k1 + 16 c + 256 d], natural order in LDS --------------------------------------------------
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      radix4(v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]);
-#pragma unroll
-      for (int d = 0; d < 4; ++d) buf[k1b + 16 * (lo2 + 4 * g) + 256 * d] = v[4 * g + d];
-    }
-    __builtin_amdgcn_wave_barrier();
+    fft1024_wave(v, buf, tw, lane);
     // ---- the two real spectra:  A[k] = (Z[k] + conj(Z[N-k])) / 2 ,  B[k] = (Z[k] - conj(Z[N-k])) / (2i) ------------------
     float* oa = out + (b * n_frames + f0) * bins;
     float* ob = oa + bins;

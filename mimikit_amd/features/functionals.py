@@ -361,13 +361,15 @@ class STFT(Functional):
     def torch_func(self, inputs):
         from .. import native
         native.require_device(inputs)
-        if self.coordinate != "mag":
-            raise NotImplementedError(f"HIP STFT covers coordinate='mag' (MagSpec); got '{self.coordinate}'")
-        if self.pad_mode != "constant":
-            raise NotImplementedError("HIP STFT covers pad_mode='constant'")
         # the reference ignores self.window on the torch path and always applies a periodic Hann (:513)
         inputs = self._fix_length(inputs)
-        return native.stft_mag(inputs, self.n_fft, self.hop_length, bool(self.center))
+        if self.coordinate == "mag" and self.pad_mode == "constant":
+            return native.stft_mag(inputs, self.n_fft, self.hop_length, bool(self.center))
+        if self.coordinate in native.STFT_COORDINATES:
+            return native.stft(inputs, self.n_fft, self.hop_length, bool(self.center), self.pad_mode, self.coordinate)
+        if self.coordinate == "mag":
+            return native.stft(inputs, self.n_fft, self.hop_length, bool(self.center), self.pad_mode, "pol")[..., 0]
+        raise ValueError(f"unknown STFT coordinate '{self.coordinate}'")
 
     @property
     def inv(self) -> Functional:
@@ -392,10 +394,22 @@ class ISTFT(Functional):
         return Continuous(-1., 1., 1)
 
     def np_func(self, inputs):
-        raise NotImplementedError("ISTFT is not on the generate path yet (SURVEY.md section 8(f) rank 1)")
+        raise NotImplementedError("the numpy (librosa) ISTFT belongs to dataset extraction; use the torch path on the HIP device")
 
     def torch_func(self, inputs):
-        raise NotImplementedError("ISTFT is not on the generate path yet (SURVEY.md section 8(f) rank 1)")
+        """reference :553-564: torch.istft with torch's defaults -- ``self.center`` and ``self.window`` are ignored
+        there (centre trimming always on, periodic Hann always applied), and so they are here."""
+        from .. import native
+        native.require_device(inputs)
+        if self.coordinate == "pol":
+            return native.istft(inputs, self.n_fft, self.hop_length, polar=True)
+        if self.coordinate == "car":
+            # the reference forms ``inputs[..., 0] * (1j * inputs[..., 1])`` (:558): a purely imaginary spectrum
+            # whose imaginary part is the PRODUCT of the two planes.  Kept as is.
+            prod = inputs[..., 0] * inputs[..., 1]
+            return native.istft(torch.stack((torch.zeros_like(prod), prod), dim=-1), self.n_fft, self.hop_length, polar=False)
+        raise RuntimeError(f"ISTFT: coordinate '{self.coordinate}' leaves a real tensor, torch.istft (and this path) "
+                           "needs a complex spectrum ('pol' or 'car')")
 
     @property
     def inv(self) -> Functional:
@@ -452,10 +466,21 @@ class GLA(Functional):
         return Continuous(-1., 1., 1)
 
     def np_func(self, inputs):
-        raise NotImplementedError("Griffin-Lim is not on the generate path yet (SURVEY.md section 8(f) rank 1)")
+        raise NotImplementedError("the numpy (librosa) Griffin-Lim belongs to dataset extraction; use the torch path on the HIP device")
 
-    def torch_func(self, inputs):
-        raise NotImplementedError("Griffin-Lim is not on the generate path yet (SURVEY.md section 8(f) rank 1)")
+    # torchaudio.transforms.GriffinLim defaults; the reference does not forward ``self.n_iter`` on the torch path (:637)
+    TORCH_N_ITER = 32
+    TORCH_MOMENTUM = 0.99
+
+    def torch_func(self, inputs, init=None):
+        """reference :634-642: torchaudio's GriffinLim(n_fft, hop_length, power=1.) over (time x freq) magnitudes with
+        its defaults: 32 iterations, momentum 0.99, random initial phases (``torch.rand`` of a complex dtype).  ``init``
+        lets a caller (the parity tests) supply those initial estimates instead of drawing them."""
+        from .. import native
+        native.require_device(inputs)
+        if init is None:
+            init = torch.rand(inputs.shape, dtype=torch.complex64, device=inputs.device)
+        return native.griffin_lim(inputs, self.n_fft, self.hop_length, self.TORCH_N_ITER, self.TORCH_MOMENTUM, init)
 
     @property
     def inv(self) -> Functional:

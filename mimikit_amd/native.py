@@ -56,6 +56,12 @@ _SIGNATURES = {
     "mmk_mulaw_expand_i64_f32": (i32, [vp, vp, i64, i32, f32, vp, vp]),
     "mmk_stft_n_frames": (i64, [i64, i32, i32, i32]),
     "mmk_stft_mag_f32": (i32, [vp, i64, i32, i64, i32, i32, i32, vp, vp]),
+    "mmk_stft_f32": (i32, [vp, i64, i32, i64, i32, i32, i32, i32, i32, vp, vp]),
+    "mmk_istft_n_samples": (i64, [i64, i32, i32]),
+    "mmk_istft_workspace_floats": (C.c_size_t, [i32, i64, i32]),
+    "mmk_istft_f32": (i32, [vp, i32, i32, i64, i32, i32, vp, vp, vp]),
+    "mmk_gla_workspace_floats": (C.c_size_t, [i32, i64, i32, i32]),
+    "mmk_gla_f32": (i32, [vp, vp, i32, i64, i32, i32, i32, f32, vp, vp, vp]),
     "mmk_packed_weight_floats": (i64, [i32, i32]),
     "mmk_pack_weight_f32": (i32, [vp, i64, i32, i32, vp, vp]),
     "mmk_linear_f32": (i32, [vp, i64, i32, vp, vp, i32, i32, vp, i64, i32, vp]),
@@ -190,6 +196,65 @@ def stft_mag(x: torch.Tensor, n_fft: int, hop: int, center: bool) -> torch.Tenso
     check(lib().mmk_stft_mag_f32(ptr(x2), x2.stride(0), x2.shape[0], n, n_fft, hop, int(center), ptr(out),
                                  stream_ptr(x.device)), "mmk_stft_mag_f32")
     return out.reshape(*lead, n_frames, n_fft // 2 + 1)
+
+
+STFT_COORDINATES = {"car": 0, "pol": 1, "angle": 2}
+
+
+def stft(x: torch.Tensor, n_fft: int, hop: int, center: bool, pad_mode: str, coordinate: str) -> torch.Tensor:
+    """x: (..., n_samples) fp32 -> (..., n_frames, n_fft//2+1[, 2]) in the 'car' / 'pol' / 'angle' coordinate"""
+    require_device(x)
+    if pad_mode not in ("constant", "reflect"):
+        raise NotImplementedError(f"HIP STFT covers pad_mode 'constant' and 'reflect', got '{pad_mode}'")
+    if x.dtype != torch.float32:
+        x = x.float()
+    lead = x.shape[:-1]
+    x2 = x.reshape(-1, x.shape[-1]).contiguous()
+    n = x2.shape[-1]
+    n_frames = lib().mmk_stft_n_frames(n, n_fft, hop, int(center))
+    if n_frames <= 0:
+        raise RuntimeError(f"stft: input of {n} samples is shorter than one frame of {n_fft}")
+    tail = (n_frames, n_fft // 2 + 1) + (() if coordinate == "angle" else (2,))
+    out = torch.empty((x2.shape[0],) + tail, dtype=torch.float32, device=x.device)
+    check(lib().mmk_stft_f32(ptr(x2), x2.stride(0), x2.shape[0], n, n_fft, hop, int(center), int(pad_mode == "reflect"),
+                             STFT_COORDINATES[coordinate], ptr(out), stream_ptr(x.device)), "mmk_stft_f32")
+    return out.reshape(*lead, *tail)
+
+
+def istft(spec: torch.Tensor, n_fft: int, hop: int, polar: bool) -> torch.Tensor:
+    """spec: (..., n_frames, n_fft//2+1, 2) fp32, (re, im) or (abs, angle) -> (..., hop * (n_frames - 1))"""
+    require_device(spec)
+    if spec.shape[-1] != 2 or spec.shape[-2] != n_fft // 2 + 1:
+        raise RuntimeError(f"istft: expected (..., n_frames, {n_fft // 2 + 1}, 2), got {tuple(spec.shape)}")
+    lead = spec.shape[:-3]
+    s3 = spec.reshape(-1, *spec.shape[-3:]).contiguous().float()
+    batch, n_frames = s3.shape[0], s3.shape[1]
+    n_out = lib().mmk_istft_n_samples(n_frames, n_fft, hop)
+    work = torch.empty(lib().mmk_istft_workspace_floats(batch, n_frames, n_fft), dtype=torch.float32, device=spec.device)
+    out = torch.empty((batch, n_out), dtype=torch.float32, device=spec.device)
+    check(lib().mmk_istft_f32(ptr(s3), int(polar), batch, n_frames, n_fft, hop, ptr(work), ptr(out), stream_ptr(spec.device)),
+          "mmk_istft_f32")
+    return out.reshape(*lead, n_out)
+
+
+def griffin_lim(mag: torch.Tensor, n_fft: int, hop: int, n_iter: int = 32, momentum: float = 0.99,
+                init: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """mag: (..., n_frames, n_fft//2+1) fp32; init: complex64 of the same shape (initial phase estimates) or None (ones)"""
+    require_device(mag)
+    lead = mag.shape[:-2]
+    m3 = mag.reshape(-1, *mag.shape[-2:]).contiguous().float()
+    batch, n_frames = m3.shape[0], m3.shape[1]
+    init_ri = None
+    if init is not None:
+        if tuple(init.shape) != tuple(mag.shape) or not init.is_complex():
+            raise RuntimeError("griffin_lim: init must be a complex tensor shaped like mag")
+        init_ri = torch.view_as_real(init.to(torch.complex64).reshape(m3.shape).contiguous())
+    n_out = lib().mmk_istft_n_samples(n_frames, n_fft, hop)
+    work = torch.empty(lib().mmk_gla_workspace_floats(batch, n_frames, n_fft, hop), dtype=torch.float32, device=mag.device)
+    out = torch.empty((batch, n_out), dtype=torch.float32, device=mag.device)
+    check(lib().mmk_gla_f32(ptr(m3), ptr(init_ri) if init_ri is not None else None, batch, n_frames, n_fft, hop, n_iter,
+                            momentum, ptr(work), ptr(out), stream_ptr(mag.device)), "mmk_gla_f32")
+    return out.reshape(*lead, n_out)
 
 
 # ---------------------------------------------------------------------------

@@ -12,6 +12,9 @@ Pinning: ``tests/test_oracle_golden.py`` checks every function here against gold
 vectors produced by the reference's own code (imported in the build container
 through ``oracle/ref_shim.py``; generator: ``tests/golden/make_golden.py``).
 
+Exception: ``griffin_lim`` is PARITY UNPINNED (torchaudio, which the reference calls, is not installed here; see its
+docstring) -- it restates torchaudio 2.0.1's published algorithm over torch.stft / torch.istft.
+
 Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s cpu_baseline leg may
 import this module.  All functions take a ``state_dict``-like mapping with the
 reference's parameter names.
@@ -61,6 +64,69 @@ def magspec(x: torch.Tensor, n_fft: int, hop: int, center: bool = False, alignme
     s = torch.stft(x, n_fft, hop_length=hop, return_complex=True, center=center,
                    window=torch.hann_window(n_fft, device=x.device), pad_mode="constant")
     return s.transpose(-1, -2).contiguous().abs()
+
+
+def stft_coord(x: torch.Tensor, n_fft: int, hop: int, coordinate: str = "pol", center: bool = True,
+               pad_mode: str = "constant", alignment: Optional[str] = "end") -> torch.Tensor:
+    """STFT.torch_func, features/functionals.py:506-523, for every coordinate it knows"""
+    if alignment is not None:
+        keep = stft_fixed_length(x.shape[-1], n_fft, hop, center)
+        x = x[..., -keep:] if alignment == "end" else x[..., :keep]
+    s = torch.stft(x, n_fft, hop_length=hop, return_complex=True, center=center,
+                   window=torch.hann_window(n_fft, device=x.device), pad_mode=pad_mode)
+    s = s.transpose(-1, -2).contiguous()
+    if coordinate == "pol":
+        return torch.stack((s.abs(), torch.angle(s)), dim=-1)
+    if coordinate == "car":
+        return torch.stack((s.real, s.imag), dim=-1)
+    if coordinate == "mag":
+        return s.abs()
+    if coordinate == "angle":
+        return torch.angle(s)
+    return s
+
+
+def istft(spec: torch.Tensor, n_fft: int, hop: int, coordinate: str = "pol") -> torch.Tensor:
+    """ISTFT.torch_func, features/functionals.py:553-564 (spec: (.., frames, bins, 2)); the 'car' branch multiplies
+    the two planes exactly as the reference does (:558)"""
+    if coordinate == "pol":
+        z = spec[..., 0] * torch.exp(1j * spec[..., 1])
+    elif coordinate == "car":
+        z = spec[..., 0] * (1j * spec[..., 1])
+    else:
+        z = spec
+    return torch.istft(z.transpose(1, 2).contiguous(), n_fft=n_fft, hop_length=hop,
+                       window=torch.hann_window(n_fft, device=spec.device))
+
+
+def griffin_lim(mag: torch.Tensor, n_fft: int, hop: int, n_iter: int = 32, momentum: float = 0.99,
+                init: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """GLA.torch_func, features/functionals.py:634-642 = torchaudio.transforms.GriffinLim(n_fft, hop_length, power=1.)
+
+    PARITY UNPINNED: torchaudio (pinned to 2.0.1 by the reference's pyproject.toml:63-68) is not installed in the build
+    container, so no golden vector of the reference's own GLA exists.  This restates torchaudio 2.0.1's published
+    ``functional.griffinlim`` on top of torch.stft / torch.istft (which ARE the reference's kernels): power = 1,
+    window = periodic Hann, win_length = n_fft, length = None; ``init`` replaces its ``torch.rand`` draw (complex dtype,
+    both parts uniform in [0, 1)), ``None`` is rand_init=False.  mag: (batch, frames, bins), as the functional gets it."""
+    assert 0 <= momentum < 1
+    m = momentum / (1 + momentum)
+    spec = mag.transpose(-1, -2).contiguous()                        # torchaudio layout (batch, freq, time)
+    window = torch.hann_window(n_fft, device=mag.device)
+    if init is None:
+        angles = torch.full(spec.shape, 1, dtype=torch.complex64, device=mag.device)
+    else:
+        angles = init.transpose(-1, -2).contiguous().to(torch.complex64)
+    tprev = torch.tensor(0., dtype=spec.dtype, device=mag.device)
+    for _ in range(n_iter):
+        inverse = torch.istft(spec * angles, n_fft=n_fft, hop_length=hop, win_length=n_fft, window=window, length=None)
+        rebuilt = torch.stft(inverse, n_fft=n_fft, hop_length=hop, win_length=n_fft, window=window, center=True,
+                             pad_mode="reflect", normalized=False, onesided=True, return_complex=True)
+        angles = rebuilt
+        if m:
+            angles = angles - tprev * m
+        angles = angles / (angles.abs() + 1e-16)
+        tprev = rebuilt
+    return torch.istft(spec * angles, n_fft=n_fft, hop_length=hop, win_length=n_fft, window=window, length=None)
 
 
 # ---------------------------------------------------------------------------

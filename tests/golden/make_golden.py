@@ -90,6 +90,27 @@ def make_stft():
     save("stft.npz", **out)
 
 
+def make_istft():
+    """complex STFT coordinates and the ISTFT functional; GLA needs torchaudio, which is
+    not installed here: no reference vector exists for it (oracle/torch_ref.py:griffin_lim is parity-unpinned)"""
+    g = torch.Generator().manual_seed(4321)
+    x = torch.randn(2, 4096, generator=g) * 0.3
+    out = {"x": x}
+    for coord in ("pol", "car", "angle"):
+        out[f"stft_{coord}_1024_256"] = ref.functionals.STFT(1024, 256, coord, center=True)(x)
+    out["stft_car_1024_256_reflect"] = ref.functionals.STFT(1024, 256, "car", center=True, pad_mode="reflect")(x)
+    out["stft_pol_1024_200_nc"] = ref.functionals.STFT(1024, 200, "pol", center=False)(x)
+    # a random polar spectrum (not the STFT of any signal) through the reference's ISTFT
+    spec = torch.stack((torch.rand(3, 11, 513, generator=g), (torch.rand(3, 11, 513, generator=g) * 2 - 1) * np.pi), dim=-1)
+    out["spec_pol"] = spec
+    out["istft_pol_1024_256"] = ref.functionals.ISTFT(1024, 256, "pol")(spec)
+    out["istft_pol_1024_100"] = ref.functionals.ISTFT(1024, 100, "pol")(spec)
+    out["istft_car_1024_256"] = ref.functionals.ISTFT(1024, 256, "car")(spec)
+    # the round trip the reference's own tests lean on: STFT -> ISTFT
+    out["roundtrip_1024_256"] = ref.functionals.ISTFT(1024, 256, "pol")(out["stft_pol_1024_256"])
+    save("istft.npz", **out)
+
+
 def capture_raw(net):
     """records the raw (pre-temperature) outputs of the MLP head at every call"""
     log = []
@@ -262,6 +283,7 @@ def make_keys():
 if __name__ == "__main__":
     make_mulaw()
     make_stft()
+    make_istft()
     make_wavenet()
     make_srnn()
     make_s2s()

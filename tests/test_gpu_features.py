@@ -119,6 +119,162 @@ def test_magspec_linearity_and_pure_tone(device):
     assert torch.allclose(f(3.0 * x), 3.0 * f(x), rtol=1e-5, atol=1e-4)
 
 
+# ---------------------------------------------------------------------------- complex STFT / ISTFT / Griffin-Lim
+def _angle_diff(a, b):
+    d = (a - b).abs()
+    return torch.minimum(d, (2 * np.pi - d).abs())
+
+
+def _check_stft(got, want, coord, tag):
+    assert got.shape == want.shape, tag
+    if coord == "angle":
+        return                                           # phases are compared by the caller, gated by the magnitudes
+    scale = float(want[..., 0].abs().max())
+    if coord == "car":
+        assert float((got - want).abs().max()) <= 2e-5 * float(want.abs().max()), tag      # fp32: 2e-5 of the largest bin
+    else:
+        assert float((got[..., 0] - want[..., 0]).abs().max()) <= 2e-5 * scale, tag
+        big = want[..., 0] > 1e-2 * scale                                                     # the phase of a tiny bin is noise
+        assert float(_angle_diff(got[..., 1], want[..., 1])[big].max()) <= 2e-3, tag
+
+
+def test_stft_coordinates_golden(device):
+    g = H.golden("istft.npz")
+    x = H.T(g["x"]).to(device)
+    for coord in ("pol", "car", "angle"):
+        got = mmk.STFT(1024, 256, coord, center=True)(x).cpu()
+        _check_stft(got, H.T(g[f"stft_{coord}_1024_256"]), coord, coord)
+    ang = mmk.STFT(1024, 256, "angle", center=True)(x).cpu()
+    pol = H.T(g["stft_pol_1024_256"])
+    big = pol[..., 0] > 1e-2 * float(pol[..., 0].max())
+    assert float(_angle_diff(ang, pol[..., 1])[big].max()) <= 2e-3
+    _check_stft(mmk.STFT(1024, 256, "car", center=True, pad_mode="reflect")(x).cpu(), H.T(g["stft_car_1024_256_reflect"]), "car", "reflect")
+    _check_stft(mmk.STFT(1024, 200, "pol", center=False)(x).cpu(), H.T(g["stft_pol_1024_200_nc"]), "pol", "hop200")
+
+
+@pytest.mark.parametrize("hop", [256, 100, 512, 37])
+@pytest.mark.parametrize("pad_mode", ["constant", "reflect"])
+def test_stft_complex_vs_oracle(device, hop, pad_mode):
+    gen = torch.Generator().manual_seed(hop)
+    for shape in [(1, 1024), (3, 3 * 1024 + 17), (2, 22050)]:
+        x = torch.randn(*shape, generator=gen)
+        for center in (True, False):
+            want = O.stft_coord(x, 1024, hop, "car", center=center, pad_mode=pad_mode)
+            got = mmk.STFT(1024, hop, "car", center=center, pad_mode=pad_mode)(x.to(device)).cpu()
+            _check_stft(got, want, "car", (shape, center))
+            # 'mag' with a non-constant padding goes through the same kernel
+            if pad_mode == "reflect":
+                m = mmk.STFT(1024, hop, "mag", center=center, pad_mode=pad_mode)(x.to(device)).cpu()
+                assert float((m - want.norm(dim=-1)).abs().max()) <= 2e-5 * float(want.abs().max())
+
+
+def test_istft_golden(device):
+    g = H.golden("istft.npz")
+    spec = H.T(g["spec_pol"]).to(device)
+    for key, hop, coord in (("istft_pol_1024_256", 256, "pol"), ("istft_pol_1024_100", 100, "pol"), ("istft_car_1024_256", 256, "car")):
+        got = mmk.ISTFT(1024, hop, coord)(spec).cpu()
+        want = H.T(g[key])
+        assert got.shape == want.shape, key
+        # fp32: 1e-5 of the largest output sample
+        assert float((got - want).abs().max()) <= 1e-5 * float(want.abs().max()), key
+    x = H.T(g["x"]).to(device)
+    rt = mmk.ISTFT(1024, 256, "pol")(mmk.STFT(1024, 256, "pol", center=True)(x)).cpu()
+    assert float((rt - H.T(g["roundtrip_1024_256"])).abs().max()) <= 2e-5
+    assert float((rt - x.cpu()[:, :rt.shape[1]]).abs().max()) <= 2e-5      # STFT -> ISTFT is the identity on the kept samples
+
+
+@pytest.mark.parametrize("hop", [256, 128, 100, 512, 37, 1000])
+@pytest.mark.parametrize("frames", [2, 3, 9, 40])
+def test_istft_vs_oracle(device, hop, frames):
+    gen = torch.Generator().manual_seed(hop * 100 + frames)
+    tol = 1e-5 if hop <= 512 else 5e-5     # hop 1000: samples divided by a window envelope of ~1e-5 carry amplified rounding
+    for batch in (1, 3):
+        spec = torch.stack((torch.rand(batch, frames, 513, generator=gen), (torch.rand(batch, frames, 513, generator=gen) * 2 - 1) * np.pi), -1)
+        want = O.istft(spec, 1024, hop, "pol")
+        got = mmk.ISTFT(1024, hop, "pol")(spec.to(device)).cpu()
+        assert got.shape == want.shape
+        assert float((got - want).abs().max()) <= tol * float(want.abs().max())
+    # complex (re, im) planes through the C ABI wrapper directly
+    z = torch.randn(2, frames, 513, 2, generator=gen)
+    want = O.istft(torch.view_as_complex(z), 1024, hop, "complex")
+    got = native.istft(z.to(device), 1024, hop, polar=False).cpu()
+    assert float((got - want).abs().max()) <= tol * float(want.abs().max())
+
+
+def test_istft_full_size_round_trip(device):
+    """cfg-5 sized: 64 clips x 30 s at 22.05 kHz, n_fft 1024 / hop 256; STFT -> ISTFT is the identity"""
+    gen = torch.Generator(device=device).manual_seed(3)
+    x = torch.rand(64, 661504, generator=gen, device=device) * 2 - 1
+    s = mmk.STFT(1024, 256, "car", center=True)(x)
+    y = native.istft(s, 1024, 256, polar=False)
+    assert y.shape == (64, 661504 - 661504 % 256)
+    assert float((y - x[:, :y.shape[1]]).abs().max()) <= 2e-5
+
+
+def test_istft_errors(device):
+    with pytest.raises(NotImplementedError):
+        mmk.ISTFT(2048, 512, "pol")(torch.zeros(1, 4, 1025, 2, device=device))     # n_fft 1024 only in this build
+    with pytest.raises(ValueError):
+        mmk.ISTFT(1024, 256, "pol")(torch.zeros(1, 1, 513, 2, device=device))      # one frame: nothing left after the trim
+    with pytest.raises(ValueError):
+        mmk.ISTFT(1024, 1024, "pol")(torch.zeros(1, 4, 513, 2, device=device))     # torch: window overlap-add is zero
+    with pytest.raises(RuntimeError):
+        mmk.ISTFT(1024, 256, "mag")(torch.zeros(1, 4, 513, device=device))
+    with pytest.raises(RuntimeError):
+        mmk.ISTFT(1024, 256, "pol")(torch.zeros(1, 4, 513, 2))                     # host tensor
+
+
+def _gla_signal(n=16384, batch=2, seed=5):
+    gen = torch.Generator().manual_seed(seed)
+    t = torch.arange(n) / 22050.
+    x = torch.stack([0.5 * torch.sin(2 * np.pi * 220 * (b + 2) * t) + 0.2 * torch.sin(2 * np.pi * 1870 * t + b) for b in range(batch)])
+    return x + 0.01 * torch.randn(batch, n, generator=gen), gen
+
+
+@pytest.mark.parametrize("n_iter", [0, 1, 3])
+@pytest.mark.parametrize("hop", [256, 128])
+def test_griffin_lim_few_iterations_vs_oracle(device, n_iter, hop):
+    """same initial phases, same iteration count: the waveform of the HIP loop against the restated torchaudio loop.
+    fp32 tolerances.  Drawn initial phases (the functional's case): relative L2 error 2e-5, worst sample 1e-4 of the
+    peak.  rand_init=False starts from a zero-phase (real, symmetric) spectrum whose rebuilt bins cancel almost
+    exactly, so the phase normalisation turns 1e-7 of rounding into a different phase: relative L2 2e-3 there."""
+    x, gen = _gla_signal()
+    mag = O.stft_coord(x, 1024, hop, "mag", center=True)
+    init = torch.rand(mag.shape, dtype=torch.complex64, generator=gen)
+    want = O.griffin_lim(mag, 1024, hop, n_iter, 0.99, init)
+    got = native.griffin_lim(mag.to(device), 1024, hop, n_iter, 0.99, init.to(device)).cpu()
+    assert got.shape == want.shape
+    assert float((got - want).norm() / want.norm()) <= 2e-5
+    assert float((got - want).abs().max()) <= 1e-4 * float(want.abs().max())
+    want1 = O.griffin_lim(mag, 1024, hop, n_iter, 0.99, None)
+    got1 = native.griffin_lim(mag.to(device), 1024, hop, n_iter, 0.99, None).cpu()
+    assert float((got1 - want1).norm() / want1.norm()) <= (2e-3 if n_iter else 2e-6)
+
+
+def test_griffin_lim_32_iterations(device):
+    """the functional as the reference configures it (32 iterations, momentum 0.99).  The iteration amplifies fp32
+    rounding through the phase normalisation of weak bins, so sample-wise agreement is looser (relative L2 error
+    2e-3, worst sample 1e-2 of the peak) and the quantity the algorithm minimises is compared as well."""
+    x, gen = _gla_signal()
+    mag = O.stft_coord(x, 1024, 256, "mag", center=True)
+    init = torch.rand(mag.shape, dtype=torch.complex64, generator=gen)
+    want = O.griffin_lim(mag, 1024, 256, 32, 0.99, init)
+    got = mmk.GLA(1024, 256).torch_func(mag.to(device), init=init.to(device)).cpu()
+    assert got.shape == want.shape
+
+    def err(y):
+        return float((O.stft_coord(y, 1024, 256, "mag", center=True, pad_mode="reflect") - mag).norm() / mag.norm())
+
+    e_got, e_want, e_0 = err(got), err(want), err(O.griffin_lim(mag, 1024, 256, 0, 0.99, init))
+    assert e_got < 0.5 * e_0 and abs(e_got - e_want) <= 0.05 * e_want + 1e-4
+    assert float((got - want).norm() / want.norm()) <= 2e-3
+    assert float((got - want).abs().max()) <= 1e-2 * float(want.abs().max())
+    # drawn phases: same shape, finite, and as consistent as the oracle's run
+    y = mmk.GLA(1024, 256)(mag.to(device)).cpu()
+    assert y.shape == want.shape and bool(torch.isfinite(y).all()) and err(y) < 0.5 * e_0
+    assert isinstance(mmk.MagSpec(1024, 256).inv, mmk.GLA)
+
+
 def test_magspec_too_short_raises(device):
     with pytest.raises((RuntimeError, ValueError)):
         mmk.MagSpec(1024, 256, center=False)(torch.zeros(2, 100, device=device))

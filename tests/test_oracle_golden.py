@@ -33,6 +33,56 @@ def test_magspec_matches_reference():
         assert torch.allclose(got, H.T(g[key]), rtol=0, atol=1e-6 * float(np.abs(g[key]).max()))
 
 
+def _angle_diff(a, b):
+    d = (a - b).abs()
+    return torch.minimum(d, (2 * np.pi - d).abs())
+
+
+def test_stft_coordinates_and_istft_match_reference():
+    g = H.golden("istft.npz")
+    x = H.T(g["x"])
+    for coord in ("pol", "car", "angle"):
+        want = H.T(g[f"stft_{coord}_1024_256"])
+        got = O.stft_coord(x, 1024, 256, coord, center=True)
+        assert got.shape == want.shape
+        if coord == "car":
+            assert torch.allclose(got, want, rtol=1e-5, atol=1e-4)
+    assert torch.allclose(O.stft_coord(x, 1024, 256, "car", center=True, pad_mode="reflect"), H.T(g["stft_car_1024_256_reflect"]),
+                          rtol=1e-5, atol=1e-4)
+    pol = O.stft_coord(x, 1024, 200, "pol", center=False)
+    want = H.T(g["stft_pol_1024_200_nc"])
+    assert torch.allclose(pol[..., 0], want[..., 0], rtol=1e-5, atol=1e-4)
+    big = want[..., 0] > 1e-2                                    # the phase of a tiny bin is noise
+    assert float(_angle_diff(pol[..., 1], want[..., 1])[big].max()) < 1e-3
+    spec = H.T(g["spec_pol"])
+    for key, hop, coord in (("istft_pol_1024_256", 256, "pol"), ("istft_pol_1024_100", 100, "pol"), ("istft_car_1024_256", 256, "car")):
+        got = O.istft(spec, 1024, hop, coord)
+        assert got.shape == g[key].shape, key
+        assert torch.allclose(got, H.T(g[key]), rtol=1e-5, atol=1e-6), key
+    rt = O.istft(O.stft_coord(x, 1024, 256, "pol", center=True), 1024, 256, "pol")
+    assert torch.allclose(rt, H.T(g["roundtrip_1024_256"]), rtol=1e-5, atol=1e-5)
+    assert torch.allclose(rt, x[:, :rt.shape[1]], atol=1e-5)
+
+
+def test_griffin_lim_restatement_properties():
+    """parity unpinned (no torchaudio here): what can be checked of the restatement without it -- shapes, the
+    rand_init=False branch, and that the iteration reduces the spectral inconsistency it is built to reduce."""
+    gen = torch.Generator().manual_seed(9)
+    t = torch.arange(8192) / 22050.
+    x = (0.5 * torch.sin(2 * np.pi * 440 * t) + 0.25 * torch.sin(2 * np.pi * 1320 * t))[None] + 0.01 * torch.randn(1, 8192, generator=gen)
+    mag = O.stft_coord(x, 1024, 256, "mag", center=True)
+    init = torch.rand(mag.shape, dtype=torch.complex64, generator=gen)
+
+    def err(y):
+        return float((O.stft_coord(y, 1024, 256, "mag", center=True, pad_mode="reflect") - mag).norm() / mag.norm())
+
+    y0 = O.griffin_lim(mag, 1024, 256, 0, 0.99, init)
+    y32 = O.griffin_lim(mag, 1024, 256, 32, 0.99, init)
+    assert y32.shape == (1, 256 * (mag.shape[1] - 1))
+    assert err(y32) < 0.5 * err(y0)
+    assert O.griffin_lim(mag, 1024, 256, 2, 0.99, None).shape == y32.shape
+
+
 def test_sampler_matches_reference():
     g = H.golden("sampler.npz")
     logits = H.T(g["logits"])
