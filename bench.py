@@ -19,6 +19,7 @@ The JSON line also carries
 """
 import argparse
 import json
+import math
 import os
 import sys
 import time
@@ -38,7 +39,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="wavenet_cfg4",
-                    choices=["wavenet_cfg4", "wavenet_cfg2", "srnn_cfg3", "s2s_cfg5", "mulaw", "stft"])
+                    choices=["wavenet_cfg4", "wavenet_cfg2", "srnn_cfg3", "s2s_cfg5", "mulaw", "stft", "istft", "gla"])
     ap.add_argument("--clips", type=int, default=0, help="clips per GPU (0 = the workload's BASELINE value)")
     ap.add_argument("--seconds", type=float, default=1.0, help="generated audio per clip")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -340,66 +341,90 @@ class S2SJob:
 
 
 class FeatureJob:
+    """the feature functionals either side of the networks: mu-law, MagSpec, ISTFT, Griffin-Lim"""
+
     def __init__(self, args, device, rank):
         import mimikit_amd as mmk
         self.mmk, self.device, self.name, self.dtype = mmk, device, args.workload, "f32"
         gen = torch.Generator().manual_seed(1234 + rank)
-        if args.workload == "mulaw":
+        w = args.workload
+        if w == "mulaw":
             self.x_cpu = torch.rand(64, 16000 * 60, generator=gen) * 2 - 1
-            self.unit = "audio samples/s"
-        else:
+            self.unit, self.what = "audio samples/s", "MuLawCompress(256) on (64, 960000) fp32"
+        elif w == "stft":
             self.x_cpu = torch.randn(64, 22050 * 10, generator=gen)
-            self.unit = "frames/s"
+            self.unit, self.what = "frames/s", "MagSpec(1024, 256) on (64, 220500) fp32"
+        elif w == "istft":      # 10 s of 22.05 kHz audio per clip as (abs, angle) frames
+            self.x_cpu = torch.stack((torch.rand(64, 862, 513, generator=gen), (torch.rand(64, 862, 513, generator=gen) * 2 - 1) * math.pi), -1)
+            self.unit, self.what = "frames/s", "ISTFT(1024, 256, 'pol') on (64, 862, 513, 2) fp32"
+        else:                   # gla: magnitudes of 10 s clips, torchaudio defaults (32 iterations, momentum 0.99)
+            self.x_cpu = torch.rand(64, 862, 513, generator=gen)
+            self.unit, self.what = "frames/s", "GLA(1024, 256): 32 Griffin-Lim iterations on (64, 862, 513) fp32 magnitudes"
 
     def to_device(self):
+        mmk = self.mmk
         self.x = self.x_cpu.to(self.device)
-        self.f = self.mmk.MuLawCompress(256) if self.name == "mulaw" else self.mmk.MagSpec(1024, 256, center=False)
+        self.f = {"mulaw": mmk.MuLawCompress(256), "stft": mmk.MagSpec(1024, 256, center=False), "istft": mmk.ISTFT(1024, 256, "pol"),
+                  "gla": mmk.GLA(1024, 256)}[self.name]
 
     def one_pass(self):
         self.out = self.f(self.x)
 
     def units_per_pass(self):
-        return self.x.numel() if self.name == "mulaw" else self.out.shape[0] * self.out.shape[1]
+        if self.name == "mulaw":
+            return self.x.numel()
+        if self.name == "stft":
+            return self.out.shape[0] * self.out.shape[1]
+        return self.x.shape[0] * self.x.shape[1]
 
     def config(self, world):
-        return {"workload": f"{self.name}: " + ("MuLawCompress(256) on (64, 960000) fp32" if self.name == "mulaw"
-                                                else "MagSpec(1024, 256) on (64, 220500) fp32"),
-                "parallelism": f"replicas x{world}"}
+        return {"workload": f"{self.name}: {self.what}", "parallelism": f"replicas x{world}"}
 
     def roofline(self):
         start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        n = 20
+        n = 20 if self.name != "gla" else 3
         start.record()
         for _ in range(n):
             self.one_pass()
         stop.record()
         torch.cuda.synchronize()
         us = start.elapsed_time(stop) * 1e3 / n
+        frames = self.units_per_pass()
+        # algorithmic bytes: what any implementation must read and write (DESIGN.md section 4)
         if self.name == "mulaw":
-            nbytes = self.x.numel() * 12
-        else:
-            nbytes = self.out.shape[0] * self.out.shape[1] * (4 * 256 + 4 * 513)
+            nbytes, kernel = self.x.numel() * 12, "mulaw_compress_kernel"
+        elif self.name == "stft":
+            nbytes, kernel = frames * (4 * 256 + 4 * 513), "stft1024_mag_kernel"
+        elif self.name == "istft":      # a frame's complex bins in, hop samples out
+            nbytes, kernel = frames * (8 * 513 + 4 * 256), "istft1024_frames_kernel + istft_ola_kernel"
+        else:   # per iteration: magnitudes, phase estimates, previous spectrum in; waveform out and in; estimates, spectrum out
+            it = 32
+            nbytes = frames * (it * (36 * 513 + 2 * 4 * 256) + 12 * 513 + 4 * 256)
+            kernel = "Griffin-Lim chain: 33 x (istft1024_frames_kernel + istft_ola_kernel) + 32 x stft1024_complex_kernel"
         achieved = nbytes / (us * 1e-6) / 1e9
-        return {"bound": "hbm", "kernel": "mulaw_compress_kernel" if self.name == "mulaw" else "stft1024_mag_kernel",
+        return {"bound": "hbm", "kernel": kernel,
                 "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
                 "traffic": None, "algorithmic_bytes_per_launch": nbytes, "avg_launch_us": round(us, 2)}
 
     def cpu_baseline(self, budget_s):
         from oracle import torch_ref as O
         x = self.x_cpu[:8]
+        fn = {"mulaw": lambda: O.mulaw_compress(x), "stft": lambda: O.magspec(x, 1024, 256, False),
+              "istft": lambda: O.istft(x, 1024, 256, "pol"),
+              "gla": lambda: O.griffin_lim(x, 1024, 256, 32, 0.99, torch.rand(x.shape, dtype=torch.complex64))}[self.name]
         t0 = time.perf_counter()
         n = 0
         while time.perf_counter() - t0 < min(budget_s, 5.0):
-            out = O.mulaw_compress(x) if self.name == "mulaw" else O.magspec(x, 1024, 256, False)
+            out = fn()
             n += 1
         dt = time.perf_counter() - t0
-        units = x.numel() if self.name == "mulaw" else out.shape[0] * out.shape[1]
+        units = x.numel() if self.name == "mulaw" else (out.shape[0] * out.shape[1] if self.name == "stft" else x.shape[0] * x.shape[1])
         return {"value": round(units * n / dt, 1), "unit": self.unit, "cores": torch.get_num_threads(), "kind": "port",
                 "sample": f"8 of the 64 rows, {n} repetitions, torch CPU fp32"}
 
 
 JOBS = {"wavenet_cfg4": WaveNetJob, "wavenet_cfg2": WaveNetJob, "srnn_cfg3": SrnnJob, "s2s_cfg5": S2SJob,
-        "mulaw": FeatureJob, "stft": FeatureJob}
+        "mulaw": FeatureJob, "stft": FeatureJob, "istft": FeatureJob, "gla": FeatureJob}
 
 
 # ----------------------------------------------------------------------------- main

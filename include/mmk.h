@@ -100,12 +100,10 @@ int mmk_stft_f32(const float* x, int64_t x_row_stride, int32_t batch, int64_t n_
  * overlap-added squared window, n_fft/2 samples trimmed on both sides.
  * spec: (batch, n_frames, n_fft/2+1, 2) contiguous; coordinate 0: (real, imag), 1: (abs, angle)
  * [the reference's 'pol': abs * exp(1j * angle)].  out: (batch, hop * (n_frames - 1)).
- * work: mmk_istft_workspace_floats() floats of device scratch (the windowed frames).
  * n_fft must be 1024; 1 <= hop < n_fft; n_frames >= 2. */
 int64_t mmk_istft_n_samples(int64_t n_frames, int32_t n_fft, int32_t hop);
-size_t mmk_istft_workspace_floats(int32_t batch, int64_t n_frames, int32_t n_fft);
 int mmk_istft_f32(const float* spec, int32_t coordinate, int32_t batch, int64_t n_frames, int32_t n_fft,
-                  int32_t hop, float* work, float* out, mmk_stream_t stream);
+                  int32_t hop, float* out, mmk_stream_t stream);
 
 /* GLA.torch_func (mimikit/features/functionals.py:634-642) = torchaudio.transforms.GriffinLim(
  * n_fft, hop_length, power=1.) as published in torchaudio 2.0.1 (functional.griffinlim; the

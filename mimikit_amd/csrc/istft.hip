@@ -24,117 +24,171 @@ __device__ __forceinline__ void make_twiddles(cf32* tw, int tid, int nthreads) {
   }
 }
 
-// ---- spectrum -> windowed frames ------------------------------------------------------------------------------------------
-// MODE 0: spec = (batch, frames, 513) complex (re, im);  MODE 1: (mag, angle) pairs;  MODE 2: mag plane x complex plane.
-template <int MODE>
-__device__ __forceinline__ cf32 load_bin(const float* __restrict__ spec, const float* __restrict__ mag, int64_t frame, int k) {
-  const int64_t e = frame * 513 + k;
-  const cf32 c = *reinterpret_cast<const cf32*>(spec + 2 * e);
-  cf32 z;
-  if (MODE == 0) z = c;
-  if (MODE == 1) {                                          // mag * exp(i angle)   (functionals.py:556)
-    float sn, cs;
-    sincosf(c.y, &sn, &cs);
-    z = cf32{c.x * cs, c.x * sn};
-  }
-  if (MODE == 2) {
-    const float m = mag[e];
-    z = cf32{m * c.x, m * c.y};
-  }
-  if (k == 0 || k == 512) z.y = 0.f;                        // a real signal's DC / Nyquist bins: the C2R transform ignores them
-  return z;
+// ---- spectrum -> waveform, overlap-add fused ----------------------------------------------------------------------------
+// MODE 0: spec = (batch, frames, 513) complex (re, im);  MODE 1: (abs, angle) pairs;  MODE 2: mag plane x complex plane.
+//
+// A wave owns a SEGMENT of one clip's output (seg_hops hops) and walks the frames that cover it in order, a pair per
+// FFT.  The windowed frames are summed into a wave-private ring of 2048 samples in LDS (the live window of a pair is
+// n_fft + hop wide); whatever lies below the next pair's first sample is final: divided by the window envelope, written
+// once, zeroed.  Frames are never written to HBM; the first ceil(n_fft / hop) - 1 frames of a segment are recomputed by
+// its left neighbour (11 % more transforms at hop = n_fft / 4 with 27-hop segments).  Summation order = frame order, so
+// the result does not depend on the launch geometry.
+
+// sin / cos of an angle in radians: three-constant Cody-Waite reduction to |r| <= pi/4 and the cephes single-precision
+// kernels (abs error ~1e-7 for |x| < 1e4; no Payne-Hanek path, which costs the library sincosf 300 B of scratch here).
+__device__ __forceinline__ void sincos_cw(float x, float* sn, float* cs) {
+  const float q = rintf(x * 0.636619772367581343f);
+  float r = fmaf(q, -1.5703125f, x);
+  r = fmaf(q, -4.837512969970703125e-4f, r);
+  r = fmaf(q, -7.54978995489188216e-8f, r);
+  const float z = r * r;
+  const float sp = fmaf(fmaf(fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f), z, -1.6666654611e-1f) * z, r, r);
+  const float cp = fmaf(fmaf(fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f), z, 4.166664568298827e-2f), z * z, fmaf(-0.5f, z, 1.0f));
+  const int qi = (int)q;
+  const float s0 = (qi & 1) ? cp : sp, c0 = (qi & 1) ? sp : cp;
+  *sn = (qi & 2) ? -s0 : s0;
+  *cs = ((qi + 1) & 2) ? -c0 : c0;
 }
 
 template <int MODE>
-__global__ __launch_bounds__(64 * kIstftWaves) __attribute__((amdgpu_waves_per_eu(3, 3)))
-void istft1024_frames_kernel(const float* __restrict__ spec, const float* __restrict__ mag, int64_t n_frames, int64_t total_pairs,
-                             float* __restrict__ frames) {
+struct IstftRaw {
+  cf32 a[16], b[16];
+  float ma[16], mb[16];                                      // MODE 2 only (dead otherwise)
+};
+
+// bins of frames fa, fb for the FFT input slots n = lane + 64 r: bin n for r < 8, bin N - n (to be conjugated) for r >= 8
+template <int MODE>
+__device__ __forceinline__ void istft_load(IstftRaw<MODE>& raw, const float* __restrict__ spec, const float* __restrict__ mag, int64_t fa,
+                                           int64_t fb, int lane) {
+  const cf32* sa_lo = reinterpret_cast<const cf32*>(spec) + fa * 513 + lane;
+  const cf32* sb_lo = reinterpret_cast<const cf32*>(spec) + fb * 513 + lane;
+  const cf32* sa_hi = reinterpret_cast<const cf32*>(spec) + fa * 513 + (1024 - lane);
+  const cf32* sb_hi = reinterpret_cast<const cf32*>(spec) + fb * 513 + (1024 - lane);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    raw.a[r] = (r < 8) ? sa_lo[64 * r] : sa_hi[-64 * r];
+    raw.b[r] = (r < 8) ? sb_lo[64 * r] : sb_hi[-64 * r];
+  }
+  if (MODE == 2) {
+    const float* ma_lo = mag + fa * 513 + lane;
+    const float* mb_lo = mag + fb * 513 + lane;
+    const float* ma_hi = mag + fa * 513 + (1024 - lane);
+    const float* mb_hi = mag + fb * 513 + (1024 - lane);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      raw.ma[r] = (r < 8) ? ma_lo[64 * r] : ma_hi[-64 * r];
+      raw.mb[r] = (r < 8) ? mb_lo[64 * r] : mb_hi[-64 * r];
+    }
+  }
+}
+
+template <int MODE>
+__device__ __forceinline__ cf32 istft_bin(cf32 c, float m) {
+  if (MODE == 1) {                                          // abs * exp(i angle)   (functionals.py:556)
+    float sn, cs;
+    sincos_cw(c.y, &sn, &cs);
+    return cf32{c.x * cs, c.x * sn};
+  }
+  if (MODE == 2) return cf32{m * c.x, m * c.y};
+  return c;
+}
+
+constexpr int kRing = 2048;
+
+template <int MODE>
+__global__ __launch_bounds__(64 * kIstftWaves) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void istft1024_kernel(const float* __restrict__ spec, const float* __restrict__ mag, int64_t n_frames, int hop, int seg_hops,
+                      int segs_per_clip, int64_t total_tasks, int64_t n_out, float* __restrict__ out) {
   constexpr int N = 1024;
   __shared__ cf32 tw[N];
+  __shared__ float w2[N];
   __shared__ cf32 bufs[kIstftWaves * kFftWaveLds];
+  __shared__ float rings[kIstftWaves * kRing];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   make_twiddles(tw, tid, 64 * kIstftWaves);
+  for (int m = tid; m < N; m += 64 * kIstftWaves) {
+    const float w = 0.5f - 0.5f * cospif(2.0f * (float)m / (float)N);
+    w2[m] = w * w;
+  }
   float win[16];                                            // periodic Hann / N at n = lane + 64 r
 #pragma unroll
   for (int r = 0; r < 16; ++r) win[r] = (0.5f - 0.5f * cospif(2.0f * (float)(lane + 64 * r) / (float)N)) * (1.0f / (float)N);
   __syncthreads();
   cf32* buf = bufs + wave * kFftWaveLds;
-  const int64_t pairs_per_row = (n_frames + 1) >> 1;
+  float* ring = rings + wave * kRing;
+  const int64_t t_end = N / 2 + n_out;                      // positions t are in the untrimmed overlap-add signal
 
-  for (int64_t pair = (int64_t)blockIdx.x * kIstftWaves + wave; pair < total_pairs; pair += (int64_t)gridDim.x * kIstftWaves) {
-    const int64_t b = pair / pairs_per_row;
-    const int64_t f0 = (pair - b * pairs_per_row) * 2;
-    const bool has_b = (f0 + 1) < n_frames;
-    const int64_t fa = b * n_frames + f0;
-    const int64_t fb = has_b ? fa + 1 : fa;                 // clamped: loads stay unconditional
-    cf32 v[16];
+  for (int64_t task = (int64_t)blockIdx.x * kIstftWaves + wave; task < total_tasks; task += (int64_t)gridDim.x * kIstftWaves) {
+    const int64_t b = task / segs_per_clip;
+    const int64_t sgm = task - b * segs_per_clip;
+    const int64_t t0 = N / 2 + sgm * seg_hops * hop;
+    int64_t t1 = t0 + (int64_t)seg_hops * hop;
+    t1 = t1 < t_end ? t1 : t_end;
+    if (t0 >= t1) continue;
+    const int64_t f_lo = (t0 - N + 1 <= 0) ? 0 : (t0 - N + hop) / hop;          // first frame that covers t0
+    int64_t f_hi = (t1 - 1) / hop;                                             // last frame that covers t1 - 1
+    f_hi = f_hi < n_frames - 1 ? f_hi : n_frames - 1;
+    const int64_t fbase = b * n_frames;
+    float* orow = out + b * n_out - N / 2;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      // n = lane + 64 r.  n <= 512 reads bin n, n > 512 the conjugate of bin N - n  (lane 0 of r = 8 is bin 512 either way)
-      const int k = (r < 8) ? lane + 64 * r : N - (lane + 64 * r);
-      const cf32 A = load_bin<MODE>(spec, mag, fa, k);
-      cf32 B = load_bin<MODE>(spec, mag, fb, k);
-      if (!has_b) B = cf32{0.f, 0.f};
-      // Z = A + i B (n <= 512) or conj(A) + i conj(B); the FFT input is conj(Z)
-      if (r < 8) v[r] = cf32{A.x - B.y, -(A.y + B.x)};
-      else v[r] = cf32{A.x + B.y, -(B.x - A.y)};
-    }
-    fft1024_wave(v, buf, tw, lane);
-    // a[m] = Re(Y[m]) / N , b[m] = -Im(Y[m]) / N ; windowed
-    float* oa = frames + fa * N;
+    for (int j = 0; j < kRing / 64; ++j) ring[lane + 64 * j] = 0.f;
+    int64_t frontier = f_lo * hop;
+    IstftRaw<MODE> raw;
+    istft_load<MODE>(raw, spec, mag, fbase + f_lo, fbase + (f_lo + 1 <= f_hi ? f_lo + 1 : f_lo), lane);
+    for (int64_t f = f_lo; f <= f_hi; f += 2) {
+      const bool has_b = f + 1 <= f_hi;
+      cf32 v[16];
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {
-      const cf32 y = buf[lane + 64 * j];
-      oa[lane + 64 * j] = y.x * win[j];
-      if (has_b) oa[N + lane + 64 * j] = -y.y * win[j];
-    }
-    __builtin_amdgcn_wave_barrier();
-  }
-}
-
-// ---- overlap-add / window envelope (torch.istft: fold, divide by the folded window^2, trim n_fft/2 on both sides) -------
-// out[b][n] = sum_f wf[b][f][t - f hop] / sum_f w^2[t - f hop],  t = n + N/2, over the frames that cover t, in frame order.
-template <int V>
-__global__ __launch_bounds__(256) void istft_ola_kernel(const float* __restrict__ frames, int64_t n_frames, int hop, int64_t n_out,
-                                                        int64_t total, float* __restrict__ out) {
-  constexpr int N = 1024;
-  __shared__ float w2[N];
-  for (int m = threadIdx.x; m < N; m += 256) {
-    const float w = 0.5f - 0.5f * cospif(2.0f * (float)m / (float)N);
-    w2[m] = w * w;
-  }
-  __syncthreads();
-  const int64_t row_v = n_out / V;
-  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
-    const int64_t b = e / row_v;
-    const int64_t n = (e - b * row_v) * V;
-    const int64_t t = n + N / 2;
-    int64_t f_hi = (t + V - 1) / hop;
-    if (f_hi > n_frames - 1) f_hi = n_frames - 1;
-    int64_t f_lo = (t - N + hop) / hop;                     // ceil((t - N + 1) / hop) for t >= N/2 > 0
-    if (t - N + 1 <= 0) f_lo = 0;
-    float acc[V], env[V];
-#pragma unroll
-    for (int i = 0; i < V; ++i) acc[i] = 0.f, env[i] = 0.f;
-    const float* fr = frames + b * n_frames * N;
-    for (int64_t f = f_lo; f <= f_hi; ++f) {
-      const int64_t o = t - f * hop;                        // offset of sample n in frame f
-      if (V == 4) {                                         // hop % 4 == 0: the four samples share their frames
-        if (o < 0 || o >= N) continue;
-        const float4 x = *reinterpret_cast<const float4*>(fr + f * N + o);
-        acc[0] += x.x, acc[1] += x.y, acc[2] += x.z, acc[3] += x.w;
-        env[0] += w2[o], env[1] += w2[o + 1], env[2] += w2[o + 2], env[3] += w2[o + 3];
-      } else {
-        if (o < 0 || o >= N) continue;
-        acc[0] += fr[f * N + o];
-        env[0] += w2[o];
+      for (int r = 0; r < 16; ++r) {
+        cf32 A = istft_bin<MODE>(raw.a[r], raw.ma[r]);
+        cf32 B = istft_bin<MODE>(raw.b[r], raw.mb[r]);
+        if ((r == 0 || r == 8) && lane == 0) A.y = 0.f, B.y = 0.f;   // DC / Nyquist of a real signal: the C2R transform ignores them
+        if (!has_b) B = cf32{0.f, 0.f};
+        // Z = A + i B (n <= 512) or conj(A) + i conj(B); the FFT input is conj(Z)
+        if (r < 8) v[r] = cf32{A.x - B.y, -(A.y + B.x)};
+        else v[r] = cf32{A.x + B.y, -(B.x - A.y)};
       }
-    }
-    if (V == 4) {
-      *reinterpret_cast<float4*>(out + b * n_out + n) = make_float4(acc[0] / env[0], acc[1] / env[1], acc[2] / env[2], acc[3] / env[3]);
-    } else {
-      out[b * n_out + n] = acc[0] / env[0];
+      {   // next pair's bins: in flight under this pair's transform (clamped, so unconditional)
+        const int64_t na = f + 2 <= f_hi ? f + 2 : f_hi;
+        const int64_t nb = f + 3 <= f_hi ? f + 3 : f_hi;
+        istft_load<MODE>(raw, spec, mag, fbase + na, fbase + nb, lane);
+      }
+      fft1024_wave(v, buf, tw, lane);
+      // a[m] = Re(Y[m]) / N , b[m] = -Im(Y[m]) / N ; windowed, summed at their positions
+      const int pa = (int)((f * hop) & (kRing - 1));
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const int q = (pa + lane + 64 * j) & (kRing - 1);
+        ring[q] += buf[lane + 64 * j].x * win[j];
+      }
+      if (has_b) {
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+          const int q = (pa + hop + lane + 64 * j) & (kRing - 1);
+          ring[q] -= buf[lane + 64 * j].y * win[j];
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+      // everything below the next pair's first sample is final
+      const bool more = f + 2 <= f_hi;
+      const int64_t upto = more ? (f + 2) * hop : t1;             // the ring is cleared again by the next segment
+      for (int64_t t = frontier + lane; t < upto; t += 64) {
+        const int q = (int)(t & (kRing - 1));
+        const float acc = ring[q];
+        ring[q] = 0.f;
+        if (t >= t0 && t < t1) {
+          int64_t g_hi = t / hop;
+          g_hi = g_hi < n_frames - 1 ? g_hi : n_frames - 1;
+          const int64_t g_lo = (t - N + 1 <= 0) ? 0 : (t - N + hop) / hop;
+          float env = 0.f;
+          for (int64_t g = g_lo; g <= g_hi; ++g) env += w2[t - g * hop];
+          orow[t] = acc / env;
+        }
+      }
+      frontier = upto;
+      __builtin_amdgcn_wave_barrier();
     }
   }
 }
@@ -241,22 +295,34 @@ static unsigned pair_grid(int64_t total_pairs) {
   return (unsigned)(wgs < 768 ? wgs : 768);                 // 3 workgroups of 4 waves per CU, all resident
 }
 
-static int launch_istft(const float* spec, const float* mag, int mode, int batch, int64_t n_frames, int hop, float* work, float* out,
-                        hipStream_t stream) {
-  const int64_t total_pairs = (int64_t)batch * ((n_frames + 1) / 2);
-  const dim3 grid(pair_grid(total_pairs)), block(64 * kIstftWaves);
-  if (mode == 0) hipLaunchKernelGGL((istft1024_frames_kernel<0>), grid, block, 0, stream, spec, mag, n_frames, total_pairs, work);
-  else if (mode == 1) hipLaunchKernelGGL((istft1024_frames_kernel<1>), grid, block, 0, stream, spec, mag, n_frames, total_pairs, work);
-  else hipLaunchKernelGGL((istft1024_frames_kernel<2>), grid, block, 0, stream, spec, mag, n_frames, total_pairs, work);
-  MMK_HIP(hipGetLastError());
+// segment length: one wave per segment, about two waves' worth of segments per SIMD pair (2 workgroups of 4 waves per CU)
+static void istft_geometry(int batch, int64_t n_frames, int* seg_hops, int* segs_per_clip) {
+  const int64_t hops = n_frames - 1;                        // output hops per clip
+  const int64_t slots = 2048;
+  const int64_t rounds = ((int64_t)batch * hops + slots * 48 - 1) / (slots * 48);
+  int64_t per_clip = (slots * rounds + batch - 1) / batch;
+  per_clip = per_clip < 1 ? 1 : per_clip;
+  int64_t sh = (hops + per_clip - 1) / per_clip;
+  sh = sh < 4 ? 4 : sh;
+  sh = sh > hops ? hops : sh;
+  *seg_hops = (int)sh;
+  *segs_per_clip = (int)((hops + sh - 1) / sh);
+}
+
+static int launch_istft(const float* spec, const float* mag, int mode, int batch, int64_t n_frames, int hop, float* out, hipStream_t stream) {
   const int64_t n_out = (int64_t)hop * (n_frames - 1);
   if (n_out <= 0) return MMK_OK;
-  const bool v4 = (hop % 4) == 0;
-  const int64_t total = (int64_t)batch * (v4 ? n_out / 4 : n_out);
-  int64_t blocks = (total + 255) / 256;
-  blocks = blocks > 4096 ? 4096 : blocks;
-  if (v4) hipLaunchKernelGGL((istft_ola_kernel<4>), dim3((unsigned)blocks), dim3(256), 0, stream, work, n_frames, hop, n_out, total, out);
-  else hipLaunchKernelGGL((istft_ola_kernel<1>), dim3((unsigned)blocks), dim3(256), 0, stream, work, n_frames, hop, n_out, total, out);
+  int seg_hops, segs_per_clip;
+  istft_geometry(batch, n_frames, &seg_hops, &segs_per_clip);
+  const int64_t total_tasks = (int64_t)batch * segs_per_clip;
+  const int64_t wgs = (total_tasks + kIstftWaves - 1) / kIstftWaves;
+  const dim3 grid((unsigned)(wgs < 512 ? wgs : 512)), block(64 * kIstftWaves);   // 2 workgroups per CU, all resident
+#define MMK_ISTFT_LAUNCH(M) \
+  hipLaunchKernelGGL((istft1024_kernel<M>), grid, block, 0, stream, spec, mag, n_frames, hop, seg_hops, segs_per_clip, total_tasks, n_out, out)
+  if (mode == 0) MMK_ISTFT_LAUNCH(0);
+  else if (mode == 1) MMK_ISTFT_LAUNCH(1);
+  else MMK_ISTFT_LAUNCH(2);
+#undef MMK_ISTFT_LAUNCH
   MMK_HIP(hipGetLastError());
   return MMK_OK;
 }
@@ -300,24 +366,19 @@ extern "C" int64_t mmk_istft_n_samples(int64_t n_frames, int32_t n_fft, int32_t 
   return n_frames > 0 ? (int64_t)hop * (n_frames - 1) : 0;
 }
 
-extern "C" size_t mmk_istft_workspace_floats(int32_t batch, int64_t n_frames, int32_t n_fft) {
-  return (size_t)batch * (size_t)n_frames * (size_t)n_fft;
-}
-
 extern "C" int mmk_istft_f32(const float* spec, int32_t coordinate, int32_t batch, int64_t n_frames, int32_t n_fft, int32_t hop,
-                             float* work, float* out, mmk_stream_t stream) {
+                             float* out, mmk_stream_t stream) {
   using namespace mmk;
-  if (!spec || !work || !out || batch <= 0 || n_frames <= 0) return fail(MMK_ERR_INVALID, "istft: bad arguments");
+  if (!spec || !out || batch <= 0 || n_frames <= 0) return fail(MMK_ERR_INVALID, "istft: bad arguments");
   if (int rc = check_1024("istft", n_fft, hop)) return rc;
   if (coordinate != 0 && coordinate != 1) return fail(MMK_ERR_INVALID, "istft: coordinate must be 0 (re, im) or 1 (mag, angle)");
   if (n_frames < 2) return fail(MMK_ERR_INVALID, "istft: one frame leaves no samples after the centre trim");
-  return launch_istft(spec, nullptr, coordinate, batch, n_frames, hop, work, out, (hipStream_t)stream);
+  return launch_istft(spec, nullptr, coordinate, batch, n_frames, hop, out, (hipStream_t)stream);
 }
 
 extern "C" size_t mmk_gla_workspace_floats(int32_t batch, int64_t n_frames, int32_t n_fft, int32_t hop) {
   const size_t bins = (size_t)n_fft / 2 + 1;
-  return (size_t)batch * ((size_t)n_frames * n_fft                      // windowed frames
-                          + (size_t)hop * (size_t)(n_frames > 0 ? n_frames - 1 : 0)   // the current waveform
+  return (size_t)batch * ((size_t)hop * (size_t)(n_frames > 0 ? n_frames - 1 : 0)   // the current waveform
                           + 4 * (size_t)n_frames * bins);               // angles, previous rebuilt spectrum (complex)
 }
 
@@ -332,8 +393,7 @@ extern "C" int mmk_gla_f32(const float* mag, const float* init, int32_t batch, i
                                       (long long)n_frames, (long long)n_out, n_fft / 2);
   hipStream_t s = (hipStream_t)stream;
   const size_t bins = 513;
-  float* frames = work;
-  float* wave = frames + (size_t)batch * n_frames * n_fft;
+  float* wave = work;
   float* angles = wave + (size_t)batch * n_out;
   float* tprev = angles + 2 * (size_t)batch * n_frames * bins;
   const size_t spec_bytes = 2 * (size_t)batch * n_frames * bins * sizeof(float);
@@ -347,8 +407,8 @@ extern "C" int mmk_gla_f32(const float* mag, const float* init, int32_t batch, i
   MMK_HIP(hipMemsetAsync(tprev, 0, spec_bytes, s));
   const float m = momentum / (1.f + momentum);
   for (int it = 0; it < n_iter; ++it) {
-    if (int rc = launch_istft(angles, mag, 2, batch, n_frames, hop, frames, wave, s)) return rc;
+    if (int rc = launch_istft(angles, mag, 2, batch, n_frames, hop, wave, s)) return rc;
     if (int rc = launch_stft_complex(wave, n_out, batch, n_out, hop, 1, 1, 3, angles, tprev, m, s)) return rc;
   }
-  return launch_istft(angles, mag, 2, batch, n_frames, hop, frames, out, s);
+  return launch_istft(angles, mag, 2, batch, n_frames, hop, out, s);
 }
