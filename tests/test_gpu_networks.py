@@ -277,6 +277,26 @@ def test_seq2seq_cfg5_geometry_vs_oracle(device, monkeypatch, fused, hop, batch)
         assert mmk.GenerateLoopV2.get_n_steps(loop_cfg, net) == 84
 
 
+def test_seq2seq_loop_ends_in_griffin_lim(device):
+    """a MagSpec-target network's loop inverts its frames with GLA inside process_outputs (loops/generate.py:242-245):
+    the waveform the loop yields is Griffin-Lim of the frames it generated, phases drawn from torch's device RNG"""
+    io = mmk.IOSpec.magspec_io(mmk.IOSpec.MagSpecIOConfig(sr=22050, n_fft=1024, hop_length=256))
+    net = mmk.Seq2SeqLSTMNetwork.from_config(mmk.Seq2SeqLSTMNetwork.Config(io_spec=io, model_dim=64, hop=4)).eval()
+    from oracle.weights import load_recipe
+    load_recipe(net, seed=5, gain=1.5)
+    net.to(device)
+    prompt = mmk.MagSpec(1024, 256, center=False)((torch.rand(3, 1024 + 256 * 7, generator=torch.Generator().manual_seed(8)) * 2 - 1).to(device))
+    frames = run_loop(net, (prompt,), 8)[0]
+    assert frames.shape == (3, 16, 513)
+    torch.manual_seed(77)
+    wave = run_loop(net, (prompt,), 8, yield_inversed_outputs=True)[0]
+    assert wave.shape == (3, 256 * 15)
+    torch.manual_seed(77)
+    init = torch.rand(frames.shape, dtype=torch.complex64, device=device)
+    want = O.griffin_lim(frames.cpu(), 1024, 256, 32, 0.99, init.cpu())
+    assert float((wave.cpu() - want).norm() / want.norm()) <= 2e-3          # fp32 through 32 iterations (test_gpu_features)
+
+
 # ---------------------------------------------------------------------------- WaveNet execution modes
 def _cond_net(seed=21):
     """persistent-kernel eligible net with one conditioning input: C = S = R = 32, cond 12 -> 16, blocks (3, 2)"""
