@@ -2,7 +2,6 @@
 // framed periodic-Hann STFT magnitude (MagSpec).  All HBM-bound streaming work:
 // coalesced 16 B/lane accesses, tables and frame tiles staged in LDS.
 #include "mmk_common.h"
-#include "fft1024.h"
 
 namespace mmk {
 
@@ -200,78 +199,6 @@ __global__ __launch_bounds__(256) void stft_mag_kernel(const float* __restrict__
 }
 
 
-constexpr int kStftWaves = 4;
-constexpr int kStftWaveLds = kFftWaveLds;
-
-__global__ __launch_bounds__(64 * kStftWaves) __attribute__((amdgpu_waves_per_eu(3, 3))) void stft1024_mag_kernel(const float* __restrict__ x, int64_t x_row_stride,
-                                                                        int64_t n_samples, int hop, int center,
-                                                                        int64_t n_frames, int64_t total_pairs,
-                                                                        float* __restrict__ out) {
-  constexpr int N = 1024, bins = 513;
-  __shared__ cf32 tw[N];                                      // exp(-2 pi i m / N)
-  __shared__ cf32 bufs[kStftWaves * kStftWaveLds];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  for (int m = tid; m < N; m += 64 * kStftWaves) {
-    float sn, cs;
-    sincospif(-2.0f * (float)m / (float)N, &sn, &cs);
-    tw[m] = cf32{cs, sn};
-  }
-  float win[16];                                              // periodic Hann at n = lane + 64 r (functionals.py:513)
-#pragma unroll
-  for (int r = 0; r < 16; ++r) win[r] = 0.5f - 0.5f * cospif(2.0f * (float)(lane + 64 * r) / (float)N);
-  __syncthreads();
-  cf32* buf = bufs + wave * kStftWaveLds;
-  const int64_t pairs_per_row = (n_frames + 1) >> 1;
-  const int64_t pad = center ? N / 2 : 0;
-
-  for (int64_t pair = (int64_t)blockIdx.x * kStftWaves + wave; pair < total_pairs; pair += (int64_t)gridDim.x * kStftWaves) {
-    const int64_t b = pair / pairs_per_row;
-    const int64_t f0 = (pair - b * pairs_per_row) * 2;
-    const bool has_b = (f0 + 1) < n_frames;
-    const float* xr = x + b * x_row_stride;
-    // ---- load + window: frame f0 -> re, frame f0 + 1 -> im; unconditional loads from clamped addresses -------------
-    cf32 v[16];
-    const int64_t start = f0 * hop - pad;                     // first sample of frame f0
-    if (start >= 0 && start + hop + N <= n_samples && has_b) {
-      // interior pair (all but the first / last few): one base address per frame, compile-time offsets
-      const float* pa = xr + start + lane;
-      const float* pb = pa + hop;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        v[r].x = pa[64 * r] * win[r];
-        v[r].y = pb[64 * r] * win[r];
-      }
-    } else {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int64_t ia = start + lane + 64 * r, ib = ia + hop;
-        const float a = xr[ia < 0 ? 0 : (ia >= n_samples ? n_samples - 1 : ia)];
-        const float bb = xr[ib < 0 ? 0 : (ib >= n_samples ? n_samples - 1 : ib)];
-        v[r].x = (ia >= 0 && ia < n_samples) ? a * win[r] : 0.f;                  // pad_mode="constant"
-        v[r].y = (has_b && ib >= 0 && ib < n_samples) ? bb * win[r] : 0.f;
-      }
-    }
-    fft1024_wave(v, buf, tw, lane);
-    // ---- the two real spectra:  A[k] = (Z[k] + conj(Z[N-k])) / 2 ,  B[k] = (Z[k] - conj(Z[N-k])) / (2i) ------------------
-    float* oa = out + (b * n_frames + f0) * bins;
-    float* ob = oa + bins;
-#pragma unroll
-    for (int jj = 0; jj < 9; ++jj) {
-      const int k = lane + 64 * jj;
-      if (k < bins) {
-        const cf32 z = buf[k];
-        const cf32 zc = buf[(N - k) & (N - 1)];
-        const float ar = 0.5f * (z.x + zc.x), ai = 0.5f * (z.y - zc.y);
-        const float br = 0.5f * (z.y + zc.y), bi = -0.5f * (z.x - zc.x);
-        oa[k] = sqrtf(ar * ar + ai * ai);
-        if (has_b) ob[k] = sqrtf(br * br + bi * bi);
-      }
-    }
-    __builtin_amdgcn_wave_barrier();                          // buf is rewritten by the next pair
-  }
-}
-
 }  // namespace mmk
 
 extern "C" int mmk_mulaw_compress_f32_i64(const float* x, int64_t* codes, int64_t n, int32_t q_levels,
@@ -320,14 +247,8 @@ extern "C" int mmk_stft_mag_f32(const float* x, int64_t x_row_stride, int32_t ba
   const int64_t n_frames = mmk_stft_n_frames(n_samples, n_fft, hop, center);
   if (n_frames <= 0) return fail(MMK_ERR_INVALID, "stft: input of %lld samples is shorter than one frame", (long long)n_samples);
   const int64_t total_pairs = (int64_t)batch * ((n_frames + 1) / 2);
-  if (n_fft == 1024) {   // register-resident variant, one pair per wave
-    const int64_t wgs = (total_pairs + kStftWaves - 1) / kStftWaves;
-    const int64_t blocks4 = wgs < 768 ? wgs : 768;                   // 3 workgroups of 4 waves per CU, all resident
-    hipLaunchKernelGGL(stft1024_mag_kernel, dim3((unsigned)blocks4), dim3(64 * kStftWaves), 0, (hipStream_t)stream, x, x_row_stride,
-                       n_samples, hop, center, n_frames, total_pairs, out);
-    MMK_HIP(hipGetLastError());
-    return MMK_OK;
-  }
+  if (n_fft == 1024)     // register-resident variant, one pair per wave (istft.hip)
+    return launch_stft1024(x, x_row_stride, batch, n_samples, hop, center, 0, 4, out, nullptr, 0.f, (hipStream_t)stream);
   const int64_t blocks = total_pairs < 2048 ? total_pairs : 2048;   // ~8 workgroups per CU, each walks several pairs
   const size_t lds = (size_t)n_fft * sizeof(float2) * 3 + (size_t)n_fft * sizeof(float);
   hipLaunchKernelGGL(stft_mag_kernel, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, x, x_row_stride,

@@ -193,62 +193,75 @@ void istft1024_kernel(const float* __restrict__ spec, const float* __restrict__ 
   }
 }
 
-// ---- complex STFT (center, constant or reflect padding) with four epilogues ------------------------------------------------
-// OUT 0: (re, im)   OUT 1: (|S|, angle S)   OUT 2: angle S   OUT 3: the Griffin-Lim phase update
+// ---- STFT (center or not, constant or reflect padding) with five epilogues --------------------------------------------------
+// OUT 0: (re, im)   OUT 1: (|S|, angle S)   OUT 2: angle S   OUT 4: |S|  (MagSpec)   OUT 3: the Griffin-Lim phase update
 //   angles = S - m tprev ; angles /= |angles| + 1e-16 ; tprev = S          (torchaudio functional.griffinlim, 2.0.1)
+// Two real frames per complex FFT, one pair per wave.
+struct StftRaw { float a[16], b[16]; };
+
+__device__ __forceinline__ void stft_load(StftRaw& raw, const float* __restrict__ xr, int64_t start, int hop, int64_t n_samples,
+                                          int reflect, int lane) {
+  constexpr int N = 1024;
+  if (start >= 0 && start + hop + N <= n_samples) {
+    // interior pair (all but the first / last few): one base address per frame, compile-time offsets
+    const float* pa = xr + start + lane;
+    const float* pb = pa + hop;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      raw.a[r] = pa[64 * r];
+      raw.b[r] = pb[64 * r];
+    }
+  } else {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int64_t ia = start + lane + 64 * r, ib = ia + hop;
+      const bool ina = ia >= 0 && ia < n_samples, inb = ib >= 0 && ib < n_samples;
+      int64_t ja = ia, jb = ib;
+      if (reflect) {                                        // torch 'reflect': no repeat of the edge sample
+        ja = ia < 0 ? -ia : (ia >= n_samples ? 2 * (n_samples - 1) - ia : ia);
+        jb = ib < 0 ? -ib : (ib >= n_samples ? 2 * (n_samples - 1) - ib : ib);
+      }
+      ja = ja < 0 ? 0 : (ja >= n_samples ? n_samples - 1 : ja);   // unconditional loads from clamped addresses
+      jb = jb < 0 ? 0 : (jb >= n_samples ? n_samples - 1 : jb);
+      const float a = xr[ja], bb = xr[jb];
+      raw.a[r] = (reflect || ina) ? a : 0.f;                // pad_mode="constant": zeros
+      raw.b[r] = (reflect || inb) ? bb : 0.f;
+    }
+  }
+}
+
 template <int OUT>
 __global__ __launch_bounds__(64 * kIstftWaves) __attribute__((amdgpu_waves_per_eu(3, 3)))
-void stft1024_complex_kernel(const float* __restrict__ x, int64_t x_row_stride, int64_t n_samples, int hop, int center, int reflect,
-                             int64_t n_frames, int64_t total_pairs, float* __restrict__ out, float* __restrict__ tprev, float momentum) {
+void stft1024_kernel(const float* __restrict__ x, int64_t x_row_stride, int64_t n_samples, int hop, int center, int reflect,
+                     int64_t n_frames, int64_t total_pairs, float* __restrict__ out, float* __restrict__ tprev, float momentum) {
   constexpr int N = 1024, bins = 513;
   __shared__ cf32 tw[N];
   __shared__ cf32 bufs[kIstftWaves * kFftWaveLds];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   make_twiddles(tw, tid, 64 * kIstftWaves);
-  float win[16];
+  float win[16];                                            // periodic Hann at n = lane + 64 r (functionals.py:513)
 #pragma unroll
   for (int r = 0; r < 16; ++r) win[r] = 0.5f - 0.5f * cospif(2.0f * (float)(lane + 64 * r) / (float)N);
   __syncthreads();
   cf32* buf = bufs + wave * kFftWaveLds;
   const int64_t pairs_per_row = (n_frames + 1) >> 1;
   const int64_t pad = center ? N / 2 : 0;
+  const int64_t stride = (int64_t)gridDim.x * kIstftWaves;
 
-  for (int64_t pair = (int64_t)blockIdx.x * kIstftWaves + wave; pair < total_pairs; pair += (int64_t)gridDim.x * kIstftWaves) {
+  for (int64_t pair = (int64_t)blockIdx.x * kIstftWaves + wave; pair < total_pairs; pair += stride) {
     const int64_t b = pair / pairs_per_row;
     const int64_t f0 = (pair - b * pairs_per_row) * 2;
     const bool has_b = (f0 + 1) < n_frames;
-    const float* xr = x + b * x_row_stride;
+    // (loading the next pair before this transform was measured: slower, the kernel is bound by vector-ALU issue)
+    StftRaw raw;
+    stft_load(raw, x + b * x_row_stride, f0 * hop - pad, hop, n_samples, reflect, lane);
     cf32 v[16];
-    const int64_t start = f0 * hop - pad;
-    if (start >= 0 && start + hop + N <= n_samples && has_b) {
-      const float* pa = xr + start + lane;
-      const float* pb = pa + hop;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        v[r].x = pa[64 * r] * win[r];
-        v[r].y = pb[64 * r] * win[r];
-      }
-    } else {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int64_t ia = start + lane + 64 * r, ib = ia + hop;
-        const bool ina = ia >= 0 && ia < n_samples, inb = ib >= 0 && ib < n_samples;
-        int64_t ja = ia, jb = ib;
-        if (reflect) {                                      // torch 'reflect': no repeat of the edge sample
-          ja = ia < 0 ? -ia : (ia >= n_samples ? 2 * (n_samples - 1) - ia : ia);
-          jb = ib < 0 ? -ib : (ib >= n_samples ? 2 * (n_samples - 1) - ib : ib);
-        }
-        ja = ja < 0 ? 0 : (ja >= n_samples ? n_samples - 1 : ja);
-        jb = jb < 0 ? 0 : (jb >= n_samples ? n_samples - 1 : jb);
-        const float a = xr[ja], bb = xr[jb];
-        v[r].x = (reflect || ina) ? a * win[r] : 0.f;
-        v[r].y = (has_b && (reflect || inb)) ? bb * win[r] : 0.f;
-      }
-    }
-    fft1024_wave(v, buf, tw, lane);
-    // A[k] = (Z[k] + conj(Z[N-k])) / 2 ,  B[k] = (Z[k] - conj(Z[N-k])) / (2i)
+    for (int r = 0; r < 16; ++r) v[r] = cf32{raw.a[r] * win[r], has_b ? raw.b[r] * win[r] : 0.f};   // frame f0 -> re, f0 + 1 -> im
     const int64_t ea = (b * n_frames + f0) * bins;
+    fft1024_wave(v, buf, tw, lane);
+    // the two real spectra:  A[k] = (Z[k] + conj(Z[N-k])) / 2 ,  B[k] = (Z[k] - conj(Z[N-k])) / (2i)
 #pragma unroll
     for (int jj = 0; jj < 9; ++jj) {
       const int k = lane + 64 * jj;
@@ -265,6 +278,7 @@ void stft1024_complex_kernel(const float* __restrict__ x, int64_t x_row_stride, 
           if (OUT == 0) *reinterpret_cast<cf32*>(out + 2 * e) = s[q];
           if (OUT == 1) *reinterpret_cast<cf32*>(out + 2 * e) = cf32{sqrtf(s[q].x * s[q].x + s[q].y * s[q].y), atan2f(s[q].y, s[q].x)};
           if (OUT == 2) out[e] = atan2f(s[q].y, s[q].x);
+          if (OUT == 4) out[e] = sqrtf(s[q].x * s[q].x + s[q].y * s[q].y);
           if (OUT == 3) {
             const cf32 tp = *reinterpret_cast<const cf32*>(tprev + 2 * e);
             const cf32 g = cf32{s[q].x - momentum * tp.x, s[q].y - momentum * tp.y};
@@ -275,7 +289,7 @@ void stft1024_complex_kernel(const float* __restrict__ x, int64_t x_row_stride, 
         }
       }
     }
-    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_wave_barrier();                        // buf is rewritten by the next pair
   }
 }
 
@@ -327,19 +341,20 @@ static int launch_istft(const float* spec, const float* mag, int mode, int batch
   return MMK_OK;
 }
 
-static int launch_stft_complex(const float* x, int64_t x_row_stride, int batch, int64_t n_samples, int hop, int center, int reflect,
-                               int out_mode, float* out, float* tprev, float momentum, hipStream_t stream) {
+int launch_stft1024(const float* x, int64_t x_row_stride, int batch, int64_t n_samples, int hop, int center, int reflect, int out_mode,
+                    float* out, float* tprev, float momentum, hipStream_t stream) {
   const int64_t n_frames = mmk_stft_n_frames(n_samples, 1024, hop, center);
   const int64_t total_pairs = (int64_t)batch * ((n_frames + 1) / 2);
   const dim3 grid(pair_grid(total_pairs)), block(64 * kIstftWaves);
 #define MMK_STFT_LAUNCH(O) \
-  hipLaunchKernelGGL((stft1024_complex_kernel<O>), grid, block, 0, stream, x, x_row_stride, n_samples, hop, center, reflect, n_frames, \
+  hipLaunchKernelGGL((stft1024_kernel<O>), grid, block, 0, stream, x, x_row_stride, n_samples, hop, center, reflect, n_frames, \
                      total_pairs, out, tprev, momentum)
   switch (out_mode) {
     case 0: MMK_STFT_LAUNCH(0); break;
     case 1: MMK_STFT_LAUNCH(1); break;
     case 2: MMK_STFT_LAUNCH(2); break;
-    default: MMK_STFT_LAUNCH(3); break;
+    case 3: MMK_STFT_LAUNCH(3); break;
+    default: MMK_STFT_LAUNCH(4); break;
   }
 #undef MMK_STFT_LAUNCH
   MMK_HIP(hipGetLastError());
@@ -358,7 +373,7 @@ extern "C" int mmk_stft_f32(const float* x, int64_t x_row_stride, int32_t batch,
     return fail(MMK_ERR_INVALID, "stft: input of %lld samples is shorter than one frame", (long long)n_samples);
   if (reflect && center && n_samples <= n_fft / 2)
     return fail(MMK_ERR_INVALID, "stft: reflect padding of %d needs more than %d samples, got %lld", n_fft / 2, n_fft / 2, (long long)n_samples);
-  return launch_stft_complex(x, x_row_stride, batch, n_samples, hop, center, reflect, coordinate, out, nullptr, 0.f, (hipStream_t)stream);
+  return launch_stft1024(x, x_row_stride, batch, n_samples, hop, center, reflect, coordinate, out, nullptr, 0.f, (hipStream_t)stream);
 }
 
 extern "C" int64_t mmk_istft_n_samples(int64_t n_frames, int32_t n_fft, int32_t hop) {
@@ -408,7 +423,7 @@ extern "C" int mmk_gla_f32(const float* mag, const float* init, int32_t batch, i
   const float m = momentum / (1.f + momentum);
   for (int it = 0; it < n_iter; ++it) {
     if (int rc = launch_istft(angles, mag, 2, batch, n_frames, hop, wave, s)) return rc;
-    if (int rc = launch_stft_complex(wave, n_out, batch, n_out, hop, 1, 1, 3, angles, tprev, m, s)) return rc;
+    if (int rc = launch_stft1024(wave, n_out, batch, n_out, hop, 1, 1, 3, angles, tprev, m, s)) return rc;
   }
   return launch_istft(angles, mag, 2, batch, n_frames, hop, out, s);
 }
