@@ -86,7 +86,7 @@ int mmk_stft_mag_f32(const float* x, int64_t x_row_stride, int32_t batch, int64_
  *   coordinate 1 'pol'   -> (..., 2) = (abs, angle)
  *   coordinate 2 'angle' -> angle only, no trailing dimension.
  * reflect != 0 selects pad_mode="reflect" (needs n_samples > n_fft/2), else zeros.
- * n_fft must be 1024 (MMK_ERR_UNSUPPORTED otherwise). */
+ * n_fft: a power of two in [64, 4096] (MMK_ERR_UNSUPPORTED otherwise). */
 #define MMK_STFT_CAR 0
 #define MMK_STFT_POL 1
 #define MMK_STFT_ANGLE 2
@@ -100,10 +100,12 @@ int mmk_stft_f32(const float* x, int64_t x_row_stride, int32_t batch, int64_t n_
  * overlap-added squared window, n_fft/2 samples trimmed on both sides.
  * spec: (batch, n_frames, n_fft/2+1, 2) contiguous; coordinate 0: (real, imag), 1: (abs, angle)
  * [the reference's 'pol': abs * exp(1j * angle)].  out: (batch, hop * (n_frames - 1)).
- * n_fft must be 1024; 1 <= hop < n_fft; n_frames >= 2. */
+ * work: mmk_istft_workspace_floats() floats of device scratch (0 for n_fft = 1024, where it may be NULL).
+ * n_fft: a power of two in [64, 4096]; 1 <= hop < n_fft; n_frames >= 2. */
 int64_t mmk_istft_n_samples(int64_t n_frames, int32_t n_fft, int32_t hop);
+size_t mmk_istft_workspace_floats(int32_t batch, int64_t n_frames, int32_t n_fft);
 int mmk_istft_f32(const float* spec, int32_t coordinate, int32_t batch, int64_t n_frames, int32_t n_fft,
-                  int32_t hop, float* out, mmk_stream_t stream);
+                  int32_t hop, float* work, float* out, mmk_stream_t stream);
 
 /* GLA.torch_func (mimikit/features/functionals.py:634-642) = torchaudio.transforms.GriffinLim(
  * n_fft, hop_length, power=1.) as published in torchaudio 2.0.1 (functional.griffinlim; the

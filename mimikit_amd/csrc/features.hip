@@ -99,105 +99,7 @@ __global__ __launch_bounds__(256) void mulaw_expand_kernel(const int64_t* __rest
   }
 }
 
-// ---- framed STFT magnitude ----------------------------------------------------------
-// A workgroup walks over frame PAIRS: two consecutive frames go through ONE complex FFT of size
-// n_fft (frame A in the real lane, frame B in the imaginary lane), radix-4 Stockham autosort passes
-// (+ one radix-2 pass when log2 n_fft is odd) between two LDS buffers, natural-order output, then
-//   A[k] = (Z[k] + conj(Z[N-k]))/2 ,  B[k] = (Z[k] - conj(Z[N-k]))/(2i)
-// and |A|, |B| are stored for k = 0..N/2 with consecutive lanes on consecutive bins.  The twiddle
-// table exp(-2 pi i m / N) and the periodic Hann window live in LDS and are built once per
-// workgroup (sincospif), amortised over all the pairs it processes.
-__global__ __launch_bounds__(256) void stft_mag_kernel(const float* __restrict__ x, int64_t x_row_stride,
-                                                      int64_t n_samples, int n_fft, int log2n, int hop, int center,
-                                                      int64_t n_frames, int64_t total_pairs, float* __restrict__ out) {
-  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  const int N = n_fft, half = n_fft >> 1, quarter = n_fft >> 2;
-  float2* buf0 = reinterpret_cast<float2*>(smem_raw);
-  float2* buf1 = buf0 + N;
-  float2* tw = buf1 + N;                                // N twiddles exp(-2 pi i m / N)
-  float* win = reinterpret_cast<float*>(tw + N);        // periodic Hann, as torch.hann_window(n_fft)  (functionals.py:513)
-  const int tid = threadIdx.x, nt = blockDim.x;
-  for (int m = tid; m < N; m += nt) {
-    float sn, cs;
-    sincospif(-2.0f * (float)m / (float)N, &sn, &cs);
-    tw[m] = make_float2(cs, sn);
-    win[m] = 0.5f - 0.5f * cospif(2.0f * (float)m / (float)N);
-  }
-  __syncthreads();
-
-  const int64_t pairs_per_row = (n_frames + 1) >> 1;
-  const int64_t pad = center ? half : 0;
-  const int bins = half + 1;
-
-  for (int64_t pair = blockIdx.x; pair < total_pairs; pair += gridDim.x) {
-    const int64_t b = pair / pairs_per_row;
-    const int64_t f0 = (pair - b * pairs_per_row) * 2;
-    const bool has_b = (f0 + 1) < n_frames;
-    const float* xr = x + b * x_row_stride;
-    for (int n = tid; n < N; n += nt) {
-      const float w = win[n];
-      const int64_t ia = f0 * hop + n - pad;
-      const int64_t ib = ia + hop;
-      const float a = (ia >= 0 && ia < n_samples) ? xr[ia] : 0.f;          // pad_mode="constant"
-      const float bb = (has_b && ib >= 0 && ib < n_samples) ? xr[ib] : 0.f;
-      buf0[n] = make_float2(a * w, bb * w);
-    }
-    __syncthreads();
-
-    float2* src = buf0;
-    float2* dst = buf1;
-    int p = 1;
-    for (; p * 4 <= N; p *= 4) {
-      const int tstep = N / (4 * p);
-      for (int i = tid; i < quarter; i += nt) {
-        const int k = i & (p - 1);
-        const int j = ((i - k) << 2) + k;
-        const int m = k * tstep;
-        const float2 w1 = tw[m], w2 = tw[2 * m], w3 = tw[3 * m];
-        const float2 u0 = src[i];
-        const float2 a1 = src[i + quarter], a2 = src[i + 2 * quarter], a3 = src[i + 3 * quarter];
-        const float2 u1 = make_float2(a1.x * w1.x - a1.y * w1.y, a1.x * w1.y + a1.y * w1.x);
-        const float2 u2 = make_float2(a2.x * w2.x - a2.y * w2.y, a2.x * w2.y + a2.y * w2.x);
-        const float2 u3 = make_float2(a3.x * w3.x - a3.y * w3.y, a3.x * w3.y + a3.y * w3.x);
-        const float2 v0 = make_float2(u0.x + u2.x, u0.y + u2.y), v1 = make_float2(u0.x - u2.x, u0.y - u2.y);
-        const float2 v2 = make_float2(u1.x + u3.x, u1.y + u3.y);
-        const float2 v3 = make_float2(u1.y - u3.y, -(u1.x - u3.x));       // (u1 - u3) * (-i)
-        dst[j] = make_float2(v0.x + v2.x, v0.y + v2.y);
-        dst[j + p] = make_float2(v1.x + v3.x, v1.y + v3.y);
-        dst[j + 2 * p] = make_float2(v0.x - v2.x, v0.y - v2.y);
-        dst[j + 3 * p] = make_float2(v1.x - v3.x, v1.y - v3.y);
-      }
-      __syncthreads();
-      float2* t = src; src = dst; dst = t;
-    }
-    if (p < N) {   // log2 n_fft odd: one radix-2 pass with p = N/2
-      for (int i = tid; i < half; i += nt) {
-        const int k = i & (p - 1);
-        const int j = ((i - k) << 1) + k;
-        const float2 w = tw[k * (N / (2 * p))];
-        const float2 u0 = src[i], a1 = src[i + half];
-        const float2 u1 = make_float2(a1.x * w.x - a1.y * w.y, a1.x * w.y + a1.y * w.x);
-        dst[j] = make_float2(u0.x + u1.x, u0.y + u1.y);
-        dst[j + p] = make_float2(u0.x - u1.x, u0.y - u1.y);
-      }
-      __syncthreads();
-      float2* t = src; src = dst; dst = t;
-    }
-
-    float* oa = out + (b * n_frames + f0) * bins;
-    float* ob = oa + bins;
-    for (int k = tid; k < bins; k += nt) {
-      const float2 z = src[k];
-      const float2 zc = src[(N - k) & (N - 1)];
-      const float ar = 0.5f * (z.x + zc.x), ai = 0.5f * (z.y - zc.y);
-      const float br = 0.5f * (z.y + zc.y), bi = -0.5f * (z.x - zc.x);
-      oa[k] = sqrtf(ar * ar + ai * ai);
-      if (has_b) ob[k] = sqrtf(br * br + bi * bi);
-    }
-    __syncthreads();   // src/dst are rewritten by the next pair
-  }
-}
-
+// (the framed STFT kernels live in istft.hip)
 
 }  // namespace mmk
 
@@ -246,13 +148,7 @@ extern "C" int mmk_stft_mag_f32(const float* x, int64_t x_row_stride, int32_t ba
     return fail(MMK_ERR_UNSUPPORTED, "stft: n_fft must be a power of two in [64, 4096], got %d", n_fft);
   const int64_t n_frames = mmk_stft_n_frames(n_samples, n_fft, hop, center);
   if (n_frames <= 0) return fail(MMK_ERR_INVALID, "stft: input of %lld samples is shorter than one frame", (long long)n_samples);
-  const int64_t total_pairs = (int64_t)batch * ((n_frames + 1) / 2);
   if (n_fft == 1024)     // register-resident variant, one pair per wave (istft.hip)
     return launch_stft1024(x, x_row_stride, batch, n_samples, hop, center, 0, 4, out, nullptr, 0.f, (hipStream_t)stream);
-  const int64_t blocks = total_pairs < 2048 ? total_pairs : 2048;   // ~8 workgroups per CU, each walks several pairs
-  const size_t lds = (size_t)n_fft * sizeof(float2) * 3 + (size_t)n_fft * sizeof(float);
-  hipLaunchKernelGGL(stft_mag_kernel, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, x, x_row_stride,
-                     n_samples, n_fft, log2n, hop, center, n_frames, total_pairs, out);
-  MMK_HIP(hipGetLastError());
-  return MMK_OK;
+  return launch_stft_generic(x, x_row_stride, batch, n_samples, n_fft, hop, center, 0, 4, out, nullptr, 0.f, (hipStream_t)stream);
 }

@@ -1,5 +1,6 @@
-// Inverse STFT, complex STFT and Griffin-Lim (the output side of the Seq2Seq / spectral
-// generate path).  n_fft = 1024, periodic Hann, one frame PAIR per wave through the register-resident FFT of fft1024.h.
+// STFT, inverse STFT and Griffin-Lim (the output side of the Seq2Seq / spectral generate
+// path).  Periodic Hann.  n_fft = 1024: one frame PAIR per wave through the register-resident FFT of fft1024.h; any other
+// power of two in [64, 4096]: one pair per workgroup, Stockham passes through LDS.
 //
 //   ISTFT.torch_func (features/functionals.py:553-564)  = torch.istft(spec^T, n_fft, hop, window=hann)   (center=True)
 //   STFT.torch_func  (features/functionals.py:506-523)  = torch.stft(..., return_complex=True) in 'car' / 'pol' / 'angle'
@@ -293,13 +294,223 @@ void stft1024_kernel(const float* __restrict__ x, int64_t x_row_stride, int64_t 
   }
 }
 
+// ---- any power-of-two n_fft in [64, 4096] -------------------------------------------------------------------------------------
+// A workgroup walks over frame PAIRS: two real frames go through ONE complex FFT of size n_fft (frame A in the real lane,
+// frame B in the imaginary lane), radix-4 Stockham autosort passes (+ one radix-2 pass when log2 n_fft is odd) between two
+// LDS buffers, natural-order output.  The twiddle table exp(-2 pi i m / N) and the periodic Hann window live in LDS and
+// are built once per workgroup (sincospif), amortised over all the pairs it processes.
+
+// src -> natural-order DFT; returns the buffer that holds it (src or dst).  All threads of the workgroup call it.
+__device__ __forceinline__ float2* stockham_fft(float2* src, float2* dst, const float2* __restrict__ tw, int N, int tid, int nt) {
+  const int half = N >> 1, quarter = N >> 2;
+  int p = 1;
+  for (; p * 4 <= N; p *= 4) {
+    const int tstep = N / (4 * p);
+    for (int i = tid; i < quarter; i += nt) {
+      const int k = i & (p - 1);
+      const int j = ((i - k) << 2) + k;
+      const int m = k * tstep;
+      const float2 w1 = tw[m], w2 = tw[2 * m], w3 = tw[3 * m];
+      const float2 u0 = src[i];
+      const float2 a1 = src[i + quarter], a2 = src[i + 2 * quarter], a3 = src[i + 3 * quarter];
+      const float2 u1 = make_float2(a1.x * w1.x - a1.y * w1.y, a1.x * w1.y + a1.y * w1.x);
+      const float2 u2 = make_float2(a2.x * w2.x - a2.y * w2.y, a2.x * w2.y + a2.y * w2.x);
+      const float2 u3 = make_float2(a3.x * w3.x - a3.y * w3.y, a3.x * w3.y + a3.y * w3.x);
+      const float2 v0 = make_float2(u0.x + u2.x, u0.y + u2.y), v1 = make_float2(u0.x - u2.x, u0.y - u2.y);
+      const float2 v2 = make_float2(u1.x + u3.x, u1.y + u3.y);
+      const float2 v3 = make_float2(u1.y - u3.y, -(u1.x - u3.x));       // (u1 - u3) * (-i)
+      dst[j] = make_float2(v0.x + v2.x, v0.y + v2.y);
+      dst[j + p] = make_float2(v1.x + v3.x, v1.y + v3.y);
+      dst[j + 2 * p] = make_float2(v0.x - v2.x, v0.y - v2.y);
+      dst[j + 3 * p] = make_float2(v1.x - v3.x, v1.y - v3.y);
+    }
+    __syncthreads();
+    float2* t = src; src = dst; dst = t;
+  }
+  if (p < N) {   // log2 n_fft odd: one radix-2 pass with p = N/2
+    for (int i = tid; i < half; i += nt) {
+      const int k = i & (p - 1);
+      const int j = ((i - k) << 1) + k;
+      const float2 w = tw[k * (N / (2 * p))];
+      const float2 u0 = src[i], a1 = src[i + half];
+      const float2 u1 = make_float2(a1.x * w.x - a1.y * w.y, a1.x * w.y + a1.y * w.x);
+      dst[j] = make_float2(u0.x + u1.x, u0.y + u1.y);
+      dst[j + p] = make_float2(u0.x - u1.x, u0.y - u1.y);
+    }
+    __syncthreads();
+    float2* t = src; src = dst; dst = t;
+  }
+  return src;
+}
+
+__device__ __forceinline__ void generic_tables(float2* tw, float* win, int N, float win_scale, int tid, int nt) {
+  for (int m = tid; m < N; m += nt) {
+    float sn, cs;
+    sincospif(-2.0f * (float)m / (float)N, &sn, &cs);
+    tw[m] = make_float2(cs, sn);
+    win[m] = (0.5f - 0.5f * cospif(2.0f * (float)m / (float)N)) * win_scale;   // periodic Hann, as torch.hann_window(n_fft)
+  }
+}
+
+template <int OUT>   // the epilogues of stft1024_kernel
+__global__ __launch_bounds__(256) void stft_generic_kernel(const float* __restrict__ x, int64_t x_row_stride, int64_t n_samples, int n_fft,
+                                                          int hop, int center, int reflect, int64_t n_frames, int64_t total_pairs,
+                                                          float* __restrict__ out, float* __restrict__ tprev, float momentum) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  const int N = n_fft, half = n_fft >> 1;
+  float2* buf0 = reinterpret_cast<float2*>(smem_raw);
+  float2* buf1 = buf0 + N;
+  float2* tw = buf1 + N;
+  float* win = reinterpret_cast<float*>(tw + N);
+  const int tid = threadIdx.x, nt = blockDim.x;
+  generic_tables(tw, win, N, 1.0f, tid, nt);
+  __syncthreads();
+  const int64_t pairs_per_row = (n_frames + 1) >> 1;
+  const int64_t pad = center ? half : 0;
+  const int bins = half + 1;
+
+  for (int64_t pair = blockIdx.x; pair < total_pairs; pair += gridDim.x) {
+    const int64_t b = pair / pairs_per_row;
+    const int64_t f0 = (pair - b * pairs_per_row) * 2;
+    const bool has_b = (f0 + 1) < n_frames;
+    const float* xr = x + b * x_row_stride;
+    for (int n = tid; n < N; n += nt) {
+      const float w = win[n];
+      int64_t ia = f0 * hop + n - pad, ib = ia + hop;
+      bool ina = ia >= 0 && ia < n_samples, inb = ib >= 0 && ib < n_samples;
+      if (reflect) {                                        // torch 'reflect': no repeat of the edge sample
+        ia = ia < 0 ? -ia : (ia >= n_samples ? 2 * (n_samples - 1) - ia : ia);
+        ib = ib < 0 ? -ib : (ib >= n_samples ? 2 * (n_samples - 1) - ib : ib);
+        ina = ia >= 0 && ia < n_samples, inb = ib >= 0 && ib < n_samples;
+      }
+      const float a = ina ? xr[ia] : 0.f;                   // pad_mode="constant": zeros
+      const float bb = (has_b && inb) ? xr[ib] : 0.f;
+      buf0[n] = make_float2(a * w, bb * w);
+    }
+    __syncthreads();
+    const float2* src = stockham_fft(buf0, buf1, tw, N, tid, nt);
+    const int64_t ea = (b * n_frames + f0) * bins;
+    for (int k = tid; k < bins; k += nt) {
+      const float2 z = src[k];
+      const float2 zc = src[(N - k) & (N - 1)];
+      float2 s2[2];
+      s2[0] = make_float2(0.5f * (z.x + zc.x), 0.5f * (z.y - zc.y));
+      s2[1] = make_float2(0.5f * (z.y + zc.y), -0.5f * (z.x - zc.x));
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        if (q == 1 && !has_b) break;
+        const int64_t e = ea + (int64_t)q * bins + k;
+        const float2 v = s2[q];
+        if (OUT == 0) *reinterpret_cast<float2*>(out + 2 * e) = v;
+        if (OUT == 1) *reinterpret_cast<float2*>(out + 2 * e) = make_float2(sqrtf(v.x * v.x + v.y * v.y), atan2f(v.y, v.x));
+        if (OUT == 2) out[e] = atan2f(v.y, v.x);
+        if (OUT == 4) out[e] = sqrtf(v.x * v.x + v.y * v.y);
+        if (OUT == 3) {
+          const float2 tp = *reinterpret_cast<const float2*>(tprev + 2 * e);
+          const float2 g = make_float2(v.x - momentum * tp.x, v.y - momentum * tp.y);
+          const float d = sqrtf(g.x * g.x + g.y * g.y) + 1e-16f;
+          *reinterpret_cast<float2*>(out + 2 * e) = make_float2(g.x / d, g.y / d);
+          *reinterpret_cast<float2*>(tprev + 2 * e) = v;
+        }
+      }
+    }
+    __syncthreads();   // the buffers are rewritten by the next pair
+  }
+}
+
+// spectrum -> windowed frames (batch, frames, n_fft) in `frames`; the inputs of istft1024_kernel's three modes
+template <int MODE>
+__global__ __launch_bounds__(256) void istft_frames_generic_kernel(const float* __restrict__ spec, const float* __restrict__ mag, int n_fft,
+                                                                  int64_t n_frames, int64_t total_pairs, float* __restrict__ frames) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  const int N = n_fft, half = n_fft >> 1, bins = half + 1;
+  float2* buf0 = reinterpret_cast<float2*>(smem_raw);
+  float2* buf1 = buf0 + N;
+  float2* tw = buf1 + N;
+  float* win = reinterpret_cast<float*>(tw + N);
+  const int tid = threadIdx.x, nt = blockDim.x;
+  generic_tables(tw, win, N, 1.0f / (float)N, tid, nt);
+  __syncthreads();
+  const int64_t pairs_per_row = (n_frames + 1) >> 1;
+  for (int64_t pair = blockIdx.x; pair < total_pairs; pair += gridDim.x) {
+    const int64_t b = pair / pairs_per_row;
+    const int64_t f0 = (pair - b * pairs_per_row) * 2;
+    const bool has_b = (f0 + 1) < n_frames;
+    const int64_t fa = b * n_frames + f0, fb = has_b ? fa + 1 : fa;
+    for (int n = tid; n < N; n += nt) {
+      const int k = n <= half ? n : N - n;
+      const int64_t e_a = fa * bins + k, e_b = fb * bins + k;
+      const cf32 ca = *reinterpret_cast<const cf32*>(spec + 2 * e_a), cb = *reinterpret_cast<const cf32*>(spec + 2 * e_b);
+      cf32 A = istft_bin<MODE>(ca, MODE == 2 ? mag[e_a] : 0.f);
+      cf32 B = istft_bin<MODE>(cb, MODE == 2 ? mag[e_b] : 0.f);
+      if (k == 0 || k == half) A.y = 0.f, B.y = 0.f;        // DC / Nyquist of a real signal
+      if (!has_b) B = cf32{0.f, 0.f};
+      // Z = A + i B (n <= N/2) or conj(A) + i conj(B); the FFT input is conj(Z)
+      buf0[n] = n <= half ? make_float2(A.x - B.y, -(A.y + B.x)) : make_float2(A.x + B.y, -(B.x - A.y));
+    }
+    __syncthreads();
+    const float2* y = stockham_fft(buf0, buf1, tw, N, tid, nt);
+    float* oa = frames + fa * N;                            // a[m] = Re(Y[m]) / N , b[m] = -Im(Y[m]) / N ; windowed
+    for (int m = tid; m < N; m += nt) {
+      oa[m] = y[m].x * win[m];
+      if (has_b) oa[N + m] = -y[m].y * win[m];
+    }
+    __syncthreads();
+  }
+}
+
+// out[b][n] = sum_f wf[b][f][t - f hop] / sum_f w^2[t - f hop],  t = n + N/2, over the frames that cover t, in frame order
+// (torch.istft: fold, divide by the folded window^2, trim n_fft/2 on both sides)
+template <int V>
+__global__ __launch_bounds__(256) void istft_ola_generic_kernel(const float* __restrict__ frames, int n_fft, int64_t n_frames, int hop,
+                                                               int64_t n_out, int64_t total, float* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float* w2 = reinterpret_cast<float*>(smem_raw);
+  const int N = n_fft;
+  for (int m = threadIdx.x; m < N; m += 256) {
+    const float w = 0.5f - 0.5f * cospif(2.0f * (float)m / (float)N);
+    w2[m] = w * w;
+  }
+  __syncthreads();
+  const int64_t row_v = n_out / V;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const int64_t b = e / row_v;
+    const int64_t n = (e - b * row_v) * V;
+    const int64_t t = n + N / 2;
+    int64_t f_hi = t / hop;
+    if (f_hi > n_frames - 1) f_hi = n_frames - 1;
+    const int64_t f_lo = (t - N + 1 <= 0) ? 0 : (t - N + hop) / hop;           // ceil((t - N + 1) / hop)
+    float acc[V], env[V];
+#pragma unroll
+    for (int i = 0; i < V; ++i) acc[i] = 0.f, env[i] = 0.f;
+    const float* fr = frames + b * n_frames * N;
+    for (int64_t f = f_lo; f <= f_hi; ++f) {
+      const int64_t o = t - f * hop;                        // offset of sample n in frame f; hop % 4 == 0: four samples share it
+      if (o < 0 || o >= N) continue;
+      if (V == 4) {
+        const float4 xv = *reinterpret_cast<const float4*>(fr + f * N + o);
+        acc[0] += xv.x, acc[1] += xv.y, acc[2] += xv.z, acc[3] += xv.w;
+        env[0] += w2[o], env[1] += w2[o + 1], env[2] += w2[o + 2], env[3] += w2[o + 3];
+      } else {
+        acc[0] += fr[f * N + o];
+        env[0] += w2[o];
+      }
+    }
+    if (V == 4) *reinterpret_cast<float4*>(out + b * n_out + n) = make_float4(acc[0] / env[0], acc[1] / env[1], acc[2] / env[2], acc[3] / env[3]);
+    else out[b * n_out + n] = acc[0] / env[0];
+  }
+}
+
 __global__ void fill_complex_kernel(float* __restrict__ dst, int64_t n, cf32 v) {
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x)
     *reinterpret_cast<cf32*>(dst + 2 * e) = v;
 }
 
-static int check_1024(const char* what, int n_fft, int hop) {
-  if (n_fft != 1024) return fail(MMK_ERR_UNSUPPORTED, "%s: n_fft must be 1024 in this build, got %d", what, n_fft);
+static int check_fft(const char* what, int n_fft, int hop) {
+  int log2n = 0;
+  while ((1 << log2n) < n_fft) ++log2n;
+  if ((1 << log2n) != n_fft || n_fft < 64 || n_fft > 4096)
+    return fail(MMK_ERR_UNSUPPORTED, "%s: n_fft must be a power of two in [64, 4096], got %d", what, n_fft);
   if (hop <= 0 || hop >= n_fft) return fail(MMK_ERR_INVALID, "%s: hop must be in [1, n_fft), got %d", what, hop);
   return MMK_OK;
 }
@@ -361,19 +572,75 @@ int launch_stft1024(const float* x, int64_t x_row_stride, int batch, int64_t n_s
   return MMK_OK;
 }
 
+int launch_stft_generic(const float* x, int64_t x_row_stride, int batch, int64_t n_samples, int n_fft, int hop, int center, int reflect,
+                        int out_mode, float* out, float* tprev, float momentum, hipStream_t stream) {
+  const int64_t n_frames = mmk_stft_n_frames(n_samples, n_fft, hop, center);
+  const int64_t total_pairs = (int64_t)batch * ((n_frames + 1) / 2);
+  const size_t lds = (size_t)n_fft * (3 * sizeof(float2) + sizeof(float));
+  const dim3 grid((unsigned)(total_pairs < 2048 ? total_pairs : 2048)), block(n_fft >= 1024 ? 256 : (n_fft / 4 < 64 ? 64 : n_fft / 4));
+#define MMK_STFT_LAUNCH(O) \
+  hipLaunchKernelGGL((stft_generic_kernel<O>), grid, block, lds, stream, x, x_row_stride, n_samples, n_fft, hop, center, reflect, n_frames, \
+                     total_pairs, out, tprev, momentum)
+  switch (out_mode) {
+    case 0: MMK_STFT_LAUNCH(0); break;
+    case 1: MMK_STFT_LAUNCH(1); break;
+    case 2: MMK_STFT_LAUNCH(2); break;
+    case 3: MMK_STFT_LAUNCH(3); break;
+    default: MMK_STFT_LAUNCH(4); break;
+  }
+#undef MMK_STFT_LAUNCH
+  MMK_HIP(hipGetLastError());
+  return MMK_OK;
+}
+
+static int launch_istft_generic(const float* spec, const float* mag, int mode, int batch, int64_t n_frames, int n_fft, int hop, float* work,
+                                float* out, hipStream_t stream) {
+  if (!work) return fail(MMK_ERR_INVALID, "istft: n_fft = %d needs the frame workspace (mmk_istft_workspace_floats)", n_fft);
+  const int64_t total_pairs = (int64_t)batch * ((n_frames + 1) / 2);
+  const size_t lds = (size_t)n_fft * (3 * sizeof(float2) + sizeof(float));
+  const dim3 grid((unsigned)(total_pairs < 2048 ? total_pairs : 2048)), block(n_fft >= 1024 ? 256 : (n_fft / 4 < 64 ? 64 : n_fft / 4));
+  if (mode == 0) hipLaunchKernelGGL((istft_frames_generic_kernel<0>), grid, block, lds, stream, spec, mag, n_fft, n_frames, total_pairs, work);
+  else if (mode == 1) hipLaunchKernelGGL((istft_frames_generic_kernel<1>), grid, block, lds, stream, spec, mag, n_fft, n_frames, total_pairs, work);
+  else hipLaunchKernelGGL((istft_frames_generic_kernel<2>), grid, block, lds, stream, spec, mag, n_fft, n_frames, total_pairs, work);
+  MMK_HIP(hipGetLastError());
+  const int64_t n_out = (int64_t)hop * (n_frames - 1);
+  if (n_out <= 0) return MMK_OK;
+  const bool v4 = (hop % 4) == 0;
+  const int64_t total = (int64_t)batch * (v4 ? n_out / 4 : n_out);
+  int64_t blocks = (total + 255) / 256;
+  blocks = blocks > 4096 ? 4096 : blocks;
+  const size_t lds2 = (size_t)n_fft * sizeof(float);
+  if (v4) hipLaunchKernelGGL((istft_ola_generic_kernel<4>), dim3((unsigned)blocks), dim3(256), lds2, stream, work, n_fft, n_frames, hop, n_out, total, out);
+  else hipLaunchKernelGGL((istft_ola_generic_kernel<1>), dim3((unsigned)blocks), dim3(256), lds2, stream, work, n_fft, n_frames, hop, n_out, total, out);
+  MMK_HIP(hipGetLastError());
+  return MMK_OK;
+}
+
+// n_fft = 1024 takes the fused register-FFT kernel, every other size the workgroup-FFT kernels and the frame workspace
+static int istft_any(const float* spec, const float* mag, int mode, int batch, int64_t n_frames, int n_fft, int hop, float* work, float* out,
+                     hipStream_t stream) {
+  if (n_fft == 1024) return launch_istft(spec, mag, mode, batch, n_frames, hop, out, stream);
+  return launch_istft_generic(spec, mag, mode, batch, n_frames, n_fft, hop, work, out, stream);
+}
+static int stft_any(const float* x, int64_t x_row_stride, int batch, int64_t n_samples, int n_fft, int hop, int center, int reflect, int out_mode,
+                    float* out, float* tprev, float momentum, hipStream_t stream) {
+  if (n_fft == 1024) return launch_stft1024(x, x_row_stride, batch, n_samples, hop, center, reflect, out_mode, out, tprev, momentum, stream);
+  return launch_stft_generic(x, x_row_stride, batch, n_samples, n_fft, hop, center, reflect, out_mode, out, tprev, momentum, stream);
+}
+
 }  // namespace mmk
 
 extern "C" int mmk_stft_f32(const float* x, int64_t x_row_stride, int32_t batch, int64_t n_samples, int32_t n_fft, int32_t hop,
                             int32_t center, int32_t reflect, int32_t coordinate, float* out, mmk_stream_t stream) {
   using namespace mmk;
   if (!x || !out || batch <= 0) return fail(MMK_ERR_INVALID, "stft: bad arguments");
-  if (int rc = check_1024("stft", n_fft, hop)) return rc;
+  if (int rc = check_fft("stft", n_fft, hop)) return rc;
   if (coordinate < 0 || coordinate > 2) return fail(MMK_ERR_INVALID, "stft: coordinate must be 0 (car), 1 (pol) or 2 (angle)");
   if (mmk_stft_n_frames(n_samples, n_fft, hop, center) <= 0)
     return fail(MMK_ERR_INVALID, "stft: input of %lld samples is shorter than one frame", (long long)n_samples);
   if (reflect && center && n_samples <= n_fft / 2)
     return fail(MMK_ERR_INVALID, "stft: reflect padding of %d needs more than %d samples, got %lld", n_fft / 2, n_fft / 2, (long long)n_samples);
-  return launch_stft1024(x, x_row_stride, batch, n_samples, hop, center, reflect, coordinate, out, nullptr, 0.f, (hipStream_t)stream);
+  return stft_any(x, x_row_stride, batch, n_samples, n_fft, hop, center, reflect, coordinate, out, nullptr, 0.f, (hipStream_t)stream);
 }
 
 extern "C" int64_t mmk_istft_n_samples(int64_t n_frames, int32_t n_fft, int32_t hop) {
@@ -381,36 +648,43 @@ extern "C" int64_t mmk_istft_n_samples(int64_t n_frames, int32_t n_fft, int32_t 
   return n_frames > 0 ? (int64_t)hop * (n_frames - 1) : 0;
 }
 
+// windowed frames of the two-kernel path; the n_fft = 1024 kernel overlap-adds in LDS and needs none
+extern "C" size_t mmk_istft_workspace_floats(int32_t batch, int64_t n_frames, int32_t n_fft) {
+  return n_fft == 1024 ? 0 : (size_t)batch * (size_t)n_frames * (size_t)n_fft;
+}
+
 extern "C" int mmk_istft_f32(const float* spec, int32_t coordinate, int32_t batch, int64_t n_frames, int32_t n_fft, int32_t hop,
-                             float* out, mmk_stream_t stream) {
+                             float* work, float* out, mmk_stream_t stream) {
   using namespace mmk;
   if (!spec || !out || batch <= 0 || n_frames <= 0) return fail(MMK_ERR_INVALID, "istft: bad arguments");
-  if (int rc = check_1024("istft", n_fft, hop)) return rc;
+  if (int rc = check_fft("istft", n_fft, hop)) return rc;
   if (coordinate != 0 && coordinate != 1) return fail(MMK_ERR_INVALID, "istft: coordinate must be 0 (re, im) or 1 (mag, angle)");
   if (n_frames < 2) return fail(MMK_ERR_INVALID, "istft: one frame leaves no samples after the centre trim");
-  return launch_istft(spec, nullptr, coordinate, batch, n_frames, hop, out, (hipStream_t)stream);
+  return istft_any(spec, nullptr, coordinate, batch, n_frames, n_fft, hop, work, out, (hipStream_t)stream);
 }
 
 extern "C" size_t mmk_gla_workspace_floats(int32_t batch, int64_t n_frames, int32_t n_fft, int32_t hop) {
   const size_t bins = (size_t)n_fft / 2 + 1;
   return (size_t)batch * ((size_t)hop * (size_t)(n_frames > 0 ? n_frames - 1 : 0)   // the current waveform
-                          + 4 * (size_t)n_frames * bins);               // angles, previous rebuilt spectrum (complex)
+                          + 4 * (size_t)n_frames * bins)                // angles, previous rebuilt spectrum (complex)
+         + mmk_istft_workspace_floats(batch, n_frames, n_fft);          // windowed frames (n_fft != 1024)
 }
 
 extern "C" int mmk_gla_f32(const float* mag, const float* init, int32_t batch, int64_t n_frames, int32_t n_fft, int32_t hop, int32_t n_iter,
                            float momentum, float* work, float* out, mmk_stream_t stream) {
   using namespace mmk;
   if (!mag || !work || !out || batch <= 0 || n_frames <= 0 || n_iter < 0) return fail(MMK_ERR_INVALID, "gla: bad arguments");
-  if (int rc = check_1024("gla", n_fft, hop)) return rc;
+  if (int rc = check_fft("gla", n_fft, hop)) return rc;
   if (!(momentum >= 0.f && momentum < 1.f)) return fail(MMK_ERR_INVALID, "gla: momentum must be in [0, 1), got %g", (double)momentum);
   const int64_t n_out = (int64_t)hop * (n_frames - 1);
   if (n_out <= n_fft / 2) return fail(MMK_ERR_INVALID, "gla: %lld frames give %lld samples, reflect padding needs more than %d",
                                       (long long)n_frames, (long long)n_out, n_fft / 2);
   hipStream_t s = (hipStream_t)stream;
-  const size_t bins = 513;
+  const size_t bins = (size_t)n_fft / 2 + 1;
   float* wave = work;
   float* angles = wave + (size_t)batch * n_out;
   float* tprev = angles + 2 * (size_t)batch * n_frames * bins;
+  float* frames = tprev + 2 * (size_t)batch * n_frames * bins;
   const size_t spec_bytes = 2 * (size_t)batch * n_frames * bins * sizeof(float);
   if (init) MMK_HIP(hipMemcpyAsync(angles, init, spec_bytes, hipMemcpyDeviceToDevice, s));
   else {                                                     // rand_init=False: every phase estimate starts at 1 + 0i
@@ -422,8 +696,8 @@ extern "C" int mmk_gla_f32(const float* mag, const float* init, int32_t batch, i
   MMK_HIP(hipMemsetAsync(tprev, 0, spec_bytes, s));
   const float m = momentum / (1.f + momentum);
   for (int it = 0; it < n_iter; ++it) {
-    if (int rc = launch_istft(angles, mag, 2, batch, n_frames, hop, wave, s)) return rc;
-    if (int rc = launch_stft1024(wave, n_out, batch, n_out, hop, 1, 1, 3, angles, tprev, m, s)) return rc;
+    if (int rc = istft_any(angles, mag, 2, batch, n_frames, n_fft, hop, frames, wave, s)) return rc;
+    if (int rc = stft_any(wave, n_out, batch, n_out, n_fft, hop, 1, 1, 3, angles, tprev, m, s)) return rc;
   }
-  return launch_istft(angles, mag, 2, batch, n_frames, hop, out, s);
+  return istft_any(angles, mag, 2, batch, n_frames, n_fft, hop, frames, out, s);
 }

@@ -195,6 +195,9 @@ int launch_sample(const SampleArgs& a, hipStream_t stream);
 // n_fft = 1024 STFT (istft.hip); out_mode 0 (re, im), 1 (abs, angle), 2 angle, 3 Griffin-Lim update, 4 abs
 int launch_stft1024(const float* x, int64_t x_row_stride, int batch, int64_t n_samples, int hop, int center, int reflect, int out_mode,
                     float* out, float* tprev, float momentum, hipStream_t stream);
+// any power-of-two n_fft in [64, 4096]: one pair per workgroup, Stockham passes through LDS (istft.hip); same out modes
+int launch_stft_generic(const float* x, int64_t x_row_stride, int batch, int64_t n_samples, int n_fft, int hop, int center, int reflect,
+                        int out_mode, float* out, float* tprev, float momentum, hipStream_t stream);
 // plain tiled GEMM on a packed weight matrix (gemm.hip): C[b][M, N] = A[b][M, K] . W^T, b < batch
 int launch_gemm_f32(const float* A, int64_t lda, int64_t a_batch, const float* Wp, int n_tiles, int k_chunks, int N, int K,
                     float* C, int64_t ldc, int64_t c_batch, int M, int batch, hipStream_t stream);

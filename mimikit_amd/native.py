@@ -58,7 +58,8 @@ _SIGNATURES = {
     "mmk_stft_mag_f32": (i32, [vp, i64, i32, i64, i32, i32, i32, vp, vp]),
     "mmk_stft_f32": (i32, [vp, i64, i32, i64, i32, i32, i32, i32, i32, vp, vp]),
     "mmk_istft_n_samples": (i64, [i64, i32, i32]),
-    "mmk_istft_f32": (i32, [vp, i32, i32, i64, i32, i32, vp, vp]),
+    "mmk_istft_workspace_floats": (C.c_size_t, [i32, i64, i32]),
+    "mmk_istft_f32": (i32, [vp, i32, i32, i64, i32, i32, vp, vp, vp]),
     "mmk_gla_workspace_floats": (C.c_size_t, [i32, i64, i32, i32]),
     "mmk_gla_f32": (i32, [vp, vp, i32, i64, i32, i32, i32, f32, vp, vp, vp]),
     "mmk_packed_weight_floats": (i64, [i32, i32]),
@@ -229,8 +230,10 @@ def istft(spec: torch.Tensor, n_fft: int, hop: int, polar: bool) -> torch.Tensor
     s3 = spec.reshape(-1, *spec.shape[-3:]).contiguous().float()
     batch, n_frames = s3.shape[0], s3.shape[1]
     n_out = lib().mmk_istft_n_samples(n_frames, n_fft, hop)
+    n_work = lib().mmk_istft_workspace_floats(batch, n_frames, n_fft)
+    work = torch.empty(n_work, dtype=torch.float32, device=spec.device) if n_work else None
     out = torch.empty((batch, n_out), dtype=torch.float32, device=spec.device)
-    check(lib().mmk_istft_f32(ptr(s3), int(polar), batch, n_frames, n_fft, hop, ptr(out), stream_ptr(spec.device)),
+    check(lib().mmk_istft_f32(ptr(s3), int(polar), batch, n_frames, n_fft, hop, ptr(work), ptr(out), stream_ptr(spec.device)),
           "mmk_istft_f32")
     return out.reshape(*lead, n_out)
 
