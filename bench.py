@@ -394,13 +394,13 @@ class FeatureJob:
         if self.name == "mulaw":
             nbytes, kernel = self.x.numel() * 12, "mulaw_compress_kernel"
         elif self.name == "stft":
-            nbytes, kernel = frames * (4 * 256 + 4 * 513), "stft1024_mag_kernel"
+            nbytes, kernel = frames * (4 * 256 + 4 * 513), "stft1024_kernel"
         elif self.name == "istft":      # a frame's complex bins in, hop samples out
-            nbytes, kernel = frames * (8 * 513 + 4 * 256), "istft1024_frames_kernel + istft_ola_kernel"
+            nbytes, kernel = frames * (8 * 513 + 4 * 256), "istft1024_kernel"
         else:   # per iteration: magnitudes, phase estimates, previous spectrum in; waveform out and in; estimates, spectrum out
             it = 32
             nbytes = frames * (it * (36 * 513 + 2 * 4 * 256) + 12 * 513 + 4 * 256)
-            kernel = "Griffin-Lim chain: 33 x (istft1024_frames_kernel + istft_ola_kernel) + 32 x stft1024_complex_kernel"
+            kernel = "Griffin-Lim chain: 33 x istft1024_kernel + 32 x stft1024_kernel (phase-update epilogue)"
         achieved = nbytes / (us * 1e-6) / 1e9
         return {"bound": "hbm", "kernel": kernel,
                 "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
