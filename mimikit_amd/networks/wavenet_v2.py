@@ -263,8 +263,8 @@ class WaveNet(ARM, nn.Module):
         unsupported = []
         if cfg.pad_side != 0:
             unsupported.append("pad_side != 0")
-        if cfg.groups != 1:
-            unsupported.append("groups > 1")
+        if cfg.groups < 1 or cfg.dims_dilated[0] % cfg.groups:
+            unsupported.append(f"groups={cfg.groups} does not divide the dilated width")
         if cfg.stride != 1:
             unsupported.append("stride != 1")
         if cfg.layerwise_inputs or cfg.reverse_layer_order or cfg.with_affine_residuals:
@@ -340,9 +340,29 @@ class WaveNet(ARM, nn.Module):
             self._plan_batch = max(batch, 1)
             rebuilt = True
         if rebuilt or refresh_weights:
-            self._plan.bind_state_dict(self.state_dict())
+            self._plan.bind_state_dict(self._plan_tensors())
             self._plan.commit()   # repacks the (possibly just trained) weights and clears the queues
             self._next_t = None
+
+    def _plan_tensors(self):
+        """``state_dict`` as the plan binds it.  A grouped dilated convolution (``groups`` > 1, :93 of the reference) is
+        handed over as the block-diagonal dense matrix it is: the kernels multiply whole channel tiles, and a zero
+        weight adds exactly 0 to a sum, so the result is that of the grouped convolution."""
+        sd = self.state_dict()
+        groups = self._config.groups
+        if groups == 1:
+            return sd
+        out = {}
+        for key, w in sd.items():
+            if ".conv_dil." in key and key.endswith("weight"):
+                n_out, in_g, k = w.shape
+                dense = w.new_zeros(n_out, in_g * groups, k)
+                og = n_out // groups
+                for gi in range(groups):
+                    dense[gi * og:(gi + 1) * og, gi * in_g:(gi + 1) * in_g] = w[gi * og:(gi + 1) * og]
+                w = dense
+            out[key] = w
+        return out
 
     def _sampling(self, batch: int, n_steps: int, parameters: Dict):
         temperature = parameters.get("temperature", None)

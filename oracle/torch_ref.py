@@ -185,9 +185,11 @@ def wavenet_rf(kernels: Sequence[int], dilations: Sequence[int]) -> int:
 
 def wavenet_window_forward(sd: SD, inputs: Tuple[torch.Tensor, ...], kernels: Sequence[int], dilations: Sequence[int],
                            n_cond: int = 0, has_skips: bool = True, residuals: bool = True,
-                           n_mlp_hidden: int = 0, embedding: bool = True) -> torch.Tensor:
+                           n_mlp_hidden: int = 0, embedding: bool = True, groups: int = 1, head: str = "mlp") -> torch.Tensor:
     """Full-window eval forward (wavenet_v2.py:276-293 with WNLayer.forward :131-176, pad_side=0):
-    returns the RAW head outputs (B, 1, q+1) of the FIRST computable position (eval_slice, :273)."""
+    returns the RAW head outputs (B, 1, q+1) of the FIRST computable position (eval_slice, :273).
+    ``groups`` applies to the dilated convolutions only (:93); ``head`` "linear" / "linear_abs" is the
+    (Chunked)LinearIO output module of a magnitude-frame target (io_spec.py:238-243) instead of the MLP."""
     if embedding:
         h = F.embedding(inputs[0], sd["input_modules.0.0.weight"])
     else:
@@ -200,7 +202,7 @@ def wavenet_window_forward(sd: SD, inputs: Tuple[torch.Tensor, ...], kernels: Se
     for l, (k, d) in enumerate(zip(kernels, dilations)):
         p = f"layers.{l}."
         cause = (k - 1) * d
-        z = F.conv1d(h, sd[p + "conv_dil.0.0.weight"], sd.get(p + "conv_dil.0.0.bias"), dilation=d)
+        z = F.conv1d(h, sd[p + "conv_dil.0.0.weight"], sd.get(p + "conv_dil.0.0.bias"), dilation=d, groups=groups)
         z_f, z_g = torch.chunk(z, 2, dim=1)
         c_f, c_g = 0, 0
         for j in range(n_cond):
@@ -217,7 +219,21 @@ def wavenet_window_forward(sd: SD, inputs: Tuple[torch.Tensor, ...], kernels: Se
             h = y
         conds = [c[:, :, cause:] for c in conds]
     y = (skips if has_skips else h).transpose(1, 2).contiguous()[:, 0:1]
-    return mlp_raw(sd, "output_modules.0.estimator.0.", y, n_mlp_hidden)
+    if head == "mlp":
+        return mlp_raw(sd, "output_modules.0.estimator.0.", y, n_mlp_hidden)
+    out = F.linear(y, sd["output_modules.0.0.weight"], sd["output_modules.0.0.bias"])
+    return out.abs() if head == "linear_abs" else out
+
+
+def wavenet_generate_frames(sd: SD, prompt: torch.Tensor, n_steps: int, kernels, dilations, **arch) -> torch.Tensor:
+    """the same loop (loops/generate.py:195-219) for a network whose input and target are real-valued frames
+    (magspec_io): every step's (B, 1, bins) output is written back as the next input frame"""
+    rf = wavenet_rf(kernels, dilations)
+    prior = prompt.size(1)
+    x = torch.cat([prompt, torch.zeros(prompt.size(0), n_steps, prompt.size(2))], dim=1)
+    for t in range(prior, prior + n_steps):
+        x[:, t:t + 1] = wavenet_window_forward(sd, (x[:, t - rf:t],), kernels, dilations, embedding=False, **arch)
+    return x
 
 
 def wavenet_generate(sd: SD, prompt: torch.Tensor, cond: Sequence[torch.Tensor], n_steps: int, kernels, dilations,

@@ -181,6 +181,24 @@ def make_wavenet():
     save("wavenet.npz", **arrays)
 
 
+def make_freqnet():
+    """WaveNet over magnitude frames (demos/freqnet.py:34-63 at reduced size): linear frame input and output, no residual
+    and no skip path, grouped dilated convolutions"""
+    g = torch.Generator().manual_seed(17)
+    arrays = {}
+    for tag, groups, act in (("g1", 1, "Identity"), ("g4", 4, "Identity"), ("g2abs", 2, "Abs")):
+        io = ref.IOSpec.magspec_io(ref.IOSpec.MagSpecIOConfig(sr=16000, n_fft=64, hop_length=16, activation=act))
+        cfg = ref.WaveNet.Config(io_spec=io, kernel_sizes=(2,), blocks=(3,), dims_dilated=(32,), apply_residuals=False,
+                                 residuals_dim=None, skips_dim=None, groups=groups)
+        net = ref.WaveNet.from_config(cfg).eval()
+        load_recipe(net, seed=50 + groups, gain=1.5)
+        rf = net.rf
+        prompt = torch.rand(2, rf + 3, 33, generator=g)
+        out = run_loop(net, (prompt,), 6)
+        arrays.update({f"{tag}_prompt": prompt, f"{tag}_out": out[0], f"{tag}_rf": np.int64(rf)})
+    save("freqnet.npz", **arrays)
+
+
 def make_srnn():
     g = torch.Generator().manual_seed(21)
     arrays = {}
@@ -285,6 +303,7 @@ if __name__ == "__main__":
     make_stft()
     make_istft()
     make_wavenet()
+    make_freqnet()
     make_srnn()
     make_s2s()
     make_sampler()

@@ -62,6 +62,21 @@ def wavenet_c():
     return net.eval(), sd, arch
 
 
+FREQNET_CASES = {"g1": (1, "Identity"), "g4": (4, "Identity"), "g2abs": (2, "Abs")}
+
+
+def freqnet(tag):
+    """demos/freqnet.py at reduced size: magnitude frames in and out, no residual / skip path, grouped dilated convolutions"""
+    groups, act = FREQNET_CASES[tag]
+    io = mmk.IOSpec.magspec_io(mmk.IOSpec.MagSpecIOConfig(sr=16000, n_fft=64, hop_length=16, activation=act))
+    net = mmk.WaveNet.from_config(mmk.WaveNet.Config(io_spec=io, kernel_sizes=(2,), blocks=(3,), dims_dilated=(32,),
+                                                     apply_residuals=False, residuals_dim=None, skips_dim=None, groups=groups))
+    sd = load_recipe(net, seed=50 + groups, gain=1.5)
+    arch = dict(kernels=[2] * 3, dilations=[1, 2, 4], has_skips=False, residuals=False, groups=groups,
+                head="linear_abs" if act == "Abs" else "linear")
+    return net.eval(), sd, arch
+
+
 SRNN_CASES = {"gru": ((16, 4, 1), "gru", 40), "lstm": ((16, 8, 8), "lstm", 32), "rnn": ((8, 2, 2), "rnn", 21)}
 
 

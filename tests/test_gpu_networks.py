@@ -277,6 +277,29 @@ def test_seq2seq_cfg5_geometry_vs_oracle(device, monkeypatch, fused, hop, batch)
         assert mmk.GenerateLoopV2.get_n_steps(loop_cfg, net) == 84
 
 
+@pytest.mark.parametrize("tag", list(H.FREQNET_CASES))
+def test_wavenet_on_magnitude_frames(device, tag):
+    """FreqNet (demos/freqnet.py:34-63) at reduced size: frames in, frames out, no residual / skip path, groups 1 / 4 / 2
+    + Abs.  Golden from the reference's loop; fp32 tolerance 1e-4 of the largest output."""
+    g = H.golden("freqnet.npz")
+    net, sd, arch = H.freqnet(tag)
+    net.to(device)
+    prompt = H.T(g[f"{tag}_prompt"])
+    out = run_loop(net, (prompt.to(device),), 6)[0].cpu()
+    want = H.T(g[f"{tag}_out"])
+    assert out.shape == want.shape
+    assert float((out - want).abs().max()) <= 1e-4 * float(want.abs().max())
+    # a longer free run against the oracle, batch 5
+    gen = torch.Generator().manual_seed(3)
+    p2 = torch.rand(5, net.rf + 9, 33, generator=gen)
+    want2 = O.wavenet_generate_frames(sd, p2, 20, **arch)
+    out2 = run_loop(net, (p2.to(device),), 20)[0].cpu()
+    assert float((out2 - want2).abs().max()) <= 1e-4 * float(want2.abs().max())
+    # the loop's waveform for these targets is Griffin-Lim of the frames (n_fft 64, hop 16)
+    wave = run_loop(net, (p2.to(device),), 20, yield_inversed_outputs=True)[0]
+    assert wave.shape == (5, 16 * (out2.shape[1] - 1)) and bool(torch.isfinite(wave).all())
+
+
 def test_seq2seq_loop_ends_in_griffin_lim(device):
     """a MagSpec-target network's loop inverts its frames with GLA inside process_outputs (loops/generate.py:242-245):
     the waveform the loop yields is Griffin-Lim of the frames it generated, phases drawn from torch's device RNG"""

@@ -125,6 +125,15 @@ def test_wavenet_conditioned_kernel3_matches_reference():
     assert torch.equal(O.categorical(O.mlp_logits(raw)), H.T(g["b_argmax"]))
 
 
+@pytest.mark.parametrize("tag", list(H.FREQNET_CASES))
+def test_wavenet_on_magnitude_frames_matches_reference(tag):
+    g = H.golden("freqnet.npz")
+    _, sd, arch = H.freqnet(tag)
+    assert int(g[f"{tag}_rf"]) == O.wavenet_rf(arch["kernels"], arch["dilations"])
+    out = O.wavenet_generate_frames(sd, H.T(g[f"{tag}_prompt"]), 6, **arch)
+    assert torch.allclose(out, H.T(g[f"{tag}_out"]), rtol=1e-5, atol=1e-6)
+
+
 def test_wavenet_cfg2_shape_matches_reference():
     g = H.golden("wavenet.npz")
     _, sd, arch = H.wavenet_c()
