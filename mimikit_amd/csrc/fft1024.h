@@ -15,14 +15,39 @@ namespace mmk {
 // The LDS buffer is private to the wave (wave-synchronous, no workgroup barrier in the loop); row strides of 68 and
 // 17 complex keep the transposes bank-conflict free.  The generic kernel above runs five radix-4 passes through LDS
 // with a workgroup barrier each; this one is bound by vector ALU work instead.
-struct cf32 { float x, y; };
-__device__ __forceinline__ cf32 cadd(cf32 a, cf32 b) { return cf32{a.x + b.x, a.y + b.y}; }
-__device__ __forceinline__ cf32 csub(cf32 a, cf32 b) { return cf32{a.x - b.x, a.y - b.y}; }
-__device__ __forceinline__ cf32 cmul(cf32 a, cf32 b) { return cf32{a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x}; }
+// a complex number is a native 2-vector: the compiler keeps (re, im) in an aligned register pair and emits packed fp32
+// instructions (v_pk_add / v_pk_mul / v_pk_fma) for it instead of pairing unrelated scalars and shuffling them back
+typedef float cf32 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ cf32 cadd(cf32 a, cf32 b) { return a + b; }
+__device__ __forceinline__ cf32 csub(cf32 a, cf32 b) { return a - b; }
+// The packed instructions pick either half of each 64-bit source for either half of the result (op_sel / op_sel_hi)
+// and negate per half (neg_lo / neg_hi), so a complex product is two of them and a rotation by -i costs nothing; the
+// compiler does not find these forms by itself (it scalarises the product and builds rotated copies with v_mov).
+__device__ __forceinline__ cf32 cmul(cf32 a, cf32 b) {   // (a.x b.x - a.y b.y, a.x b.y + a.y b.x)
+  cf32 t, d;
+  asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]" : "=v"(t) : "v"(a), "v"(b));
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]" : "=v"(d) : "v"(a), "v"(b), "v"(t));
+  return d;
+}
+__device__ __forceinline__ cf32 cmul_k(cf32 a, cf32 k) {   // the same with a wave-uniform constant (scalar register pair)
+  cf32 t, d;
+  asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]" : "=v"(t) : "v"(a), "s"(k));
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]" : "=v"(d) : "v"(a), "s"(k), "v"(t));
+  return d;
+}
+__device__ __forceinline__ cf32 add_mi(cf32 a, cf32 u) {   // a + (-i) u = (a.x + u.y, a.y - u.x)
+  cf32 d;
+  asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(u));
+  return d;
+}
+__device__ __forceinline__ cf32 sub_mi(cf32 a, cf32 u) {   // a - (-i) u = (a.x - u.y, a.y + u.x)
+  cf32 d;
+  asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(d) : "v"(a), "v"(u));
+  return d;
+}
 __device__ __forceinline__ void radix4(cf32& a0, cf32& a1, cf32& a2, cf32& a3) {   // out_k = sum_j a_j (-i)^{jk}
   const cf32 t0 = cadd(a0, a2), t1 = csub(a0, a2), t2 = cadd(a1, a3), u = csub(a1, a3);
-  const cf32 t3 = cf32{u.y, -u.x};
-  a0 = cadd(t0, t2); a1 = cadd(t1, t3); a2 = csub(t0, t2); a3 = csub(t1, t3);
+  a0 = cadd(t0, t2); a1 = add_mi(t1, u); a2 = csub(t0, t2); a3 = sub_mi(t1, u);
 }
 // 16-point DFT in place.  Input v[n1]; output X[k1] lands in v[i] with k1 = (i >> 2) + 4 (i & 3).
 __device__ __forceinline__ void dft16(cf32 (&v)[16]) {
@@ -30,15 +55,15 @@ __device__ __forceinline__ void dft16(cf32 (&v)[16]) {
 #pragma unroll
   for (int q = 0; q < 4; ++q) radix4(v[q], v[4 + q], v[8 + q], v[12 + q]);      // v[4r + q] = T[q][r]
   // T[q][r] *= W16^{qr}:  W16^1 = (c1,-s1), ^2 = (h,-h), ^3 = (s1,-c1), ^4 = (0,-1), ^6 = (-h,-h), ^9 = (-c1, s1)
-  v[4 * 1 + 1] = cmul(v[4 * 1 + 1], cf32{c1, -s1});
-  v[4 * 1 + 2] = cmul(v[4 * 1 + 2], cf32{h, -h});
-  v[4 * 1 + 3] = cmul(v[4 * 1 + 3], cf32{s1, -c1});
-  v[4 * 2 + 1] = cmul(v[4 * 2 + 1], cf32{h, -h});
+  v[4 * 1 + 1] = cmul_k(v[4 * 1 + 1], cf32{c1, -s1});
+  v[4 * 1 + 2] = cmul_k(v[4 * 1 + 2], cf32{h, -h});
+  v[4 * 1 + 3] = cmul_k(v[4 * 1 + 3], cf32{s1, -c1});
+  v[4 * 2 + 1] = cmul_k(v[4 * 2 + 1], cf32{h, -h});
   v[4 * 2 + 2] = cf32{v[4 * 2 + 2].y, -v[4 * 2 + 2].x};
-  v[4 * 2 + 3] = cmul(v[4 * 2 + 3], cf32{-h, -h});
-  v[4 * 3 + 1] = cmul(v[4 * 3 + 1], cf32{s1, -c1});
-  v[4 * 3 + 2] = cmul(v[4 * 3 + 2], cf32{-h, -h});
-  v[4 * 3 + 3] = cmul(v[4 * 3 + 3], cf32{-c1, s1});
+  v[4 * 2 + 3] = cmul_k(v[4 * 2 + 3], cf32{-h, -h});
+  v[4 * 3 + 1] = cmul_k(v[4 * 3 + 1], cf32{s1, -c1});
+  v[4 * 3 + 2] = cmul_k(v[4 * 3 + 2], cf32{-h, -h});
+  v[4 * 3 + 3] = cmul_k(v[4 * 3 + 3], cf32{-c1, s1});
 #pragma unroll
   for (int r = 0; r < 4; ++r) radix4(v[4 * r], v[4 * r + 1], v[4 * r + 2], v[4 * r + 3]);   // v[4r + s] = X[r + 4s]
 }

@@ -96,21 +96,27 @@ __device__ __forceinline__ cf32 istft_bin(cf32 c, float m) {
 
 constexpr int kRing = 2048;
 
+__device__ __forceinline__ float hann2(int m) {             // squared periodic Hann of length 1024
+  const float w = 0.5f - 0.5f * cospif(2.0f * (float)m / 1024.0f);
+  return w * w;
+}
+
 template <int MODE>
 __global__ __launch_bounds__(64 * kIstftWaves) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void istft1024_kernel(const float* __restrict__ spec, const float* __restrict__ mag, int64_t n_frames, int hop, int seg_hops,
                       int segs_per_clip, int64_t total_tasks, int64_t n_out, float* __restrict__ out) {
   constexpr int N = 1024;
   __shared__ cf32 tw[N];
-  __shared__ float w2[N];
+  __shared__ float envt[N];                                 // window envelope where every covering frame exists, by t mod hop
   __shared__ cf32 bufs[kIstftWaves * kFftWaveLds];
   __shared__ float rings[kIstftWaves * kRing];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   make_twiddles(tw, tid, 64 * kIstftWaves);
-  for (int m = tid; m < N; m += 64 * kIstftWaves) {
-    const float w = 0.5f - 0.5f * cospif(2.0f * (float)m / (float)N);
-    w2[m] = w * w;
+  for (int r = tid; r < hop; r += 64 * kIstftWaves) {       // (two workgroups per CU: no room for a separate w^2 table)
+    float e = 0.f;
+    for (int o = r; o < N; o += hop) e += hann2(o);
+    envt[r] = e;
   }
   float win[16];                                            // periodic Hann / N at n = lane + 64 r
 #pragma unroll
@@ -175,16 +181,27 @@ void istft1024_kernel(const float* __restrict__ spec, const float* __restrict__ 
       // everything below the next pair's first sample is final
       const bool more = f + 2 <= f_hi;
       const int64_t upto = more ? (f + 2) * hop : t1;             // the ring is cleared again by the next segment
-      for (int64_t t = frontier + lane; t < upto; t += 64) {
+      // frontier is a multiple of hop and upto - frontier <= 2 hop: t mod hop without a division
+      const int64_t t_int_lo = N - 1, t_int_hi = n_frames * hop;              // inside: every frame that covers t exists
+      for (int x = lane; frontier + x < upto; x += 64) {
+        const int64_t t = frontier + x;
         const int q = (int)(t & (kRing - 1));
         const float acc = ring[q];
         ring[q] = 0.f;
         if (t >= t0 && t < t1) {
-          int64_t g_hi = t / hop;
-          g_hi = g_hi < n_frames - 1 ? g_hi : n_frames - 1;
-          const int64_t g_lo = (t - N + 1 <= 0) ? 0 : (t - N + hop) / hop;
-          float env = 0.f;
-          for (int64_t g = g_lo; g <= g_hi; ++g) env += w2[t - g * hop];
+          float env;
+          if (t >= t_int_lo && t < t_int_hi) {
+            int r = x;
+            r = r >= hop ? r - hop : r;
+            r = r >= hop ? r - hop : r;
+            env = envt[r];
+          } else {                                          // the first / last n_fft samples of a clip
+            int64_t g_hi = t / hop;
+            g_hi = g_hi < n_frames - 1 ? g_hi : n_frames - 1;
+            const int64_t g_lo = (t - N + 1 <= 0) ? 0 : (t - N + hop) / hop;
+            env = 0.f;
+            for (int64_t g = g_lo; g <= g_hi; ++g) env += hann2((int)(t - g * hop));
+          }
           orow[t] = acc / env;
         }
       }
