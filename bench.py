@@ -397,10 +397,11 @@ class FeatureJob:
             nbytes, kernel = frames * (4 * 256 + 4 * 513), "stft1024_kernel"
         elif self.name == "istft":      # a frame's complex bins in, hop samples out
             nbytes, kernel = frames * (8 * 513 + 4 * 256), "istft1024_kernel"
-        else:   # per iteration: magnitudes, phase estimates, previous spectrum in; waveform out and in; estimates, spectrum out
+        else:   # per iteration: magnitudes, previous spectrum and waveform in; spectrum and waveform out (the phase estimates
+            # themselves never need to exist in HBM); plus the first inverse transform of mag x initial phases
             it = 32
-            nbytes = frames * (it * (36 * 513 + 2 * 4 * 256) + 12 * 513 + 4 * 256)
-            kernel = "Griffin-Lim chain: 33 x istft1024_kernel + 32 x stft1024_kernel (phase-update epilogue)"
+            nbytes = frames * (it * (20 * 513 + 2 * 4 * 256) + 12 * 513 + 4 * 256)
+            kernel = "Griffin-Lim chain: istft1024_kernel + 32 x gla1024_iter_kernel (stft -> phase update -> istft per launch)"
         achieved = nbytes / (us * 1e-6) / 1e9
         return {"bound": "hbm", "kernel": kernel,
                 "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),

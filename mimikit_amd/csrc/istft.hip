@@ -32,8 +32,8 @@ __device__ __forceinline__ void make_twiddles(cf32* tw, int tid, int nthreads) {
 // FFT.  The windowed frames are summed into a wave-private ring of 2048 samples in LDS (the live window of a pair is
 // n_fft + hop wide); whatever lies below the next pair's first sample is final: divided by the window envelope, written
 // once, zeroed.  Frames are never written to HBM; the first ceil(n_fft / hop) - 1 frames of a segment are recomputed by
-// its left neighbour (11 % more transforms at hop = n_fft / 4 with 27-hop segments).  Summation order = frame order, so
-// the result does not depend on the launch geometry.
+// its left neighbour (11 % more transforms at hop = n_fft / 4 with 27-hop segments).  Summation order = frame order and
+// the pairing of frames is fixed, so the result does not depend on the launch geometry.
 
 // sin / cos of an angle in radians: three-constant Cody-Waite reduction to |r| <= pi/4 and the cephes single-precision
 // kernels (abs error ~1e-7 for |x| < 1e4; no Payne-Hanek path, which costs the library sincosf 300 B of scratch here).
@@ -101,6 +101,53 @@ __device__ __forceinline__ float hann2(int m) {             // squared periodic 
   return w * w;
 }
 
+// One transformed pair (a[m] = Re(Y[m]) / N, b[m] = -Im(Y[m]) / N in buf) into the ring at its positions, then
+// everything below `upto` (the next pair's first sample) is final: divided by the window envelope, written, zeroed.
+__device__ __forceinline__ void ola_pair(float* ring, const cf32* buf, const float (&win)[16], const float* envt, int64_t f, int hop,
+                                         bool has_b, int64_t frontier, int64_t upto, int64_t t0, int64_t t1, int64_t n_frames,
+                                         float* __restrict__ orow, int lane) {
+  constexpr int N = 1024;
+  const int pa = (int)((f * hop) & (kRing - 1));
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const int q = (pa + lane + 64 * j) & (kRing - 1);
+    ring[q] += buf[lane + 64 * j].x * win[j];
+  }
+  if (has_b) {
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int q = (pa + hop + lane + 64 * j) & (kRing - 1);
+      ring[q] -= buf[lane + 64 * j].y * win[j];
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+  // frontier is a multiple of hop and upto - frontier <= 2 hop: t mod hop without a division
+  const int64_t t_int_lo = N - 1, t_int_hi = n_frames * hop;                  // inside: every frame that covers t exists
+  for (int x = lane; frontier + x < upto; x += 64) {
+    const int64_t t = frontier + x;
+    const int q = (int)(t & (kRing - 1));
+    const float acc = ring[q];
+    ring[q] = 0.f;
+    if (t >= t0 && t < t1) {
+      float env;
+      if (t >= t_int_lo && t < t_int_hi) {
+        int r = x;
+        r = r >= hop ? r - hop : r;
+        r = r >= hop ? r - hop : r;
+        env = envt[r];
+      } else {                                              // the first / last n_fft samples of a clip
+        int64_t g_hi = t / hop;
+        g_hi = g_hi < n_frames - 1 ? g_hi : n_frames - 1;
+        const int64_t g_lo = (t - N + 1 <= 0) ? 0 : (t - N + hop) / hop;
+        env = 0.f;
+        for (int64_t g = g_lo; g <= g_hi; ++g) env += hann2((int)(t - g * hop));
+      }
+      orow[t] = acc / env;
+    }
+  }
+}
+
 template <int MODE>
 __global__ __launch_bounds__(64 * kIstftWaves) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void istft1024_kernel(const float* __restrict__ spec, const float* __restrict__ mag, int64_t n_frames, int hop, int seg_hops,
@@ -140,11 +187,14 @@ void istft1024_kernel(const float* __restrict__ spec, const float* __restrict__ 
     float* orow = out + b * n_out - N / 2;
 #pragma unroll
     for (int j = 0; j < kRing / 64; ++j) ring[lane + 64 * j] = 0.f;
-    int64_t frontier = f_lo * hop;
+    // pairs are always (even, odd) frames, whatever the segment: two real transforms that share a complex one pick up
+    // each other's rounding, so a fixed pairing makes every frame's samples independent of the launch geometry
+    const int64_t f_first = f_lo & ~(int64_t)1, f_last = n_frames - 1;
+    int64_t frontier = f_first * hop;
     IstftRaw<MODE> raw;
-    istft_load<MODE>(raw, spec, mag, fbase + f_lo, fbase + (f_lo + 1 <= f_hi ? f_lo + 1 : f_lo), lane);
-    for (int64_t f = f_lo; f <= f_hi; f += 2) {
-      const bool has_b = f + 1 <= f_hi;
+    istft_load<MODE>(raw, spec, mag, fbase + f_first, fbase + (f_first + 1 <= f_last ? f_first + 1 : f_first), lane);
+    for (int64_t f = f_first; f <= f_hi; f += 2) {
+      const bool has_b = f + 1 <= f_last;
       cf32 v[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -157,54 +207,14 @@ void istft1024_kernel(const float* __restrict__ spec, const float* __restrict__ 
         else v[r] = cf32{A.x + B.y, -(B.x - A.y)};
       }
       {   // next pair's bins: in flight under this pair's transform (clamped, so unconditional)
-        const int64_t na = f + 2 <= f_hi ? f + 2 : f_hi;
-        const int64_t nb = f + 3 <= f_hi ? f + 3 : f_hi;
+        const int64_t na = f + 2 <= f_last ? f + 2 : f_last;
+        const int64_t nb = f + 3 <= f_last ? f + 3 : f_last;
         istft_load<MODE>(raw, spec, mag, fbase + na, fbase + nb, lane);
       }
       fft1024_wave(v, buf, tw, lane);
-      // a[m] = Re(Y[m]) / N , b[m] = -Im(Y[m]) / N ; windowed, summed at their positions
-      const int pa = (int)((f * hop) & (kRing - 1));
-#pragma unroll
-      for (int j = 0; j < 16; ++j) {
-        const int q = (pa + lane + 64 * j) & (kRing - 1);
-        ring[q] += buf[lane + 64 * j].x * win[j];
-      }
-      if (has_b) {
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-          const int q = (pa + hop + lane + 64 * j) & (kRing - 1);
-          ring[q] -= buf[lane + 64 * j].y * win[j];
-        }
-      }
-      __builtin_amdgcn_wave_barrier();
-      // everything below the next pair's first sample is final
       const bool more = f + 2 <= f_hi;
       const int64_t upto = more ? (f + 2) * hop : t1;             // the ring is cleared again by the next segment
-      // frontier is a multiple of hop and upto - frontier <= 2 hop: t mod hop without a division
-      const int64_t t_int_lo = N - 1, t_int_hi = n_frames * hop;              // inside: every frame that covers t exists
-      for (int x = lane; frontier + x < upto; x += 64) {
-        const int64_t t = frontier + x;
-        const int q = (int)(t & (kRing - 1));
-        const float acc = ring[q];
-        ring[q] = 0.f;
-        if (t >= t0 && t < t1) {
-          float env;
-          if (t >= t_int_lo && t < t_int_hi) {
-            int r = x;
-            r = r >= hop ? r - hop : r;
-            r = r >= hop ? r - hop : r;
-            env = envt[r];
-          } else {                                          // the first / last n_fft samples of a clip
-            int64_t g_hi = t / hop;
-            g_hi = g_hi < n_frames - 1 ? g_hi : n_frames - 1;
-            const int64_t g_lo = (t - N + 1 <= 0) ? 0 : (t - N + hop) / hop;
-            env = 0.f;
-            for (int64_t g = g_lo; g <= g_hi; ++g) env += hann2((int)(t - g * hop));
-          }
-          orow[t] = acc / env;
-        }
-      }
+      ola_pair(ring, buf, win, envt, f, hop, has_b, frontier, upto, t0, t1, n_frames, orow, lane);
       frontier = upto;
       __builtin_amdgcn_wave_barrier();
     }
@@ -244,6 +254,127 @@ __device__ __forceinline__ void stft_load(StftRaw& raw, const float* __restrict_
       const float a = xr[ja], bb = xr[jb];
       raw.a[r] = (reflect || ina) ? a : 0.f;                // pad_mode="constant": zeros
       raw.b[r] = (reflect || inb) ? bb : 0.f;
+    }
+  }
+}
+
+// ---- one whole Griffin-Lim iteration: stft -> phase update -> istft, per output segment ---------------------------------------
+//   rebuilt = stft(wave_in) ; angles = normalise(rebuilt - m tprev_in) ; tprev_out = rebuilt ; wave_out = istft(mag angles)
+// The segment walk of istft1024_kernel with a forward transform in front of each inverse one: the phase estimates never
+// exist in HBM (12 KB per frame-iteration instead of 20.5).  wave and tprev are ping-pong buffers, so the frames a segment
+// recomputes for its left edge read the same inputs as their owner and write the same values.
+__global__ __launch_bounds__(64 * kIstftWaves) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void gla1024_iter_kernel(const float* __restrict__ wave_in, const float* __restrict__ mag, const float* __restrict__ tprev_in,
+                         float* __restrict__ tprev_out, float momentum, int64_t n_frames, int hop, int seg_hops, int segs_per_clip,
+                         int64_t total_tasks, int64_t n_out, float* __restrict__ wave_out) {
+  constexpr int N = 1024, bins = 513;
+  __shared__ cf32 tw[N];
+  __shared__ float envt[N];
+  __shared__ cf32 bufs[kIstftWaves * kFftWaveLds];
+  __shared__ float rings[kIstftWaves * kRing];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  make_twiddles(tw, tid, 64 * kIstftWaves);
+  for (int r = tid; r < hop; r += 64 * kIstftWaves) {
+    float e = 0.f;
+    for (int o = r; o < N; o += hop) e += hann2(o);
+    envt[r] = e;
+  }
+  float win[16], win_n[16];                                 // periodic Hann at n = lane + 64 r, and the same / N
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    win[r] = 0.5f - 0.5f * cospif(2.0f * (float)(lane + 64 * r) / (float)N);
+    win_n[r] = win[r] * (1.0f / (float)N);
+  }
+  __syncthreads();
+  cf32* buf = bufs + wave * kFftWaveLds;
+  float* ring = rings + wave * kRing;
+  const int64_t t_end = N / 2 + n_out;
+
+  for (int64_t task = (int64_t)blockIdx.x * kIstftWaves + wave; task < total_tasks; task += (int64_t)gridDim.x * kIstftWaves) {
+    const int64_t b = task / segs_per_clip;
+    const int64_t sgm = task - b * segs_per_clip;
+    const int64_t t0 = N / 2 + sgm * seg_hops * hop;
+    int64_t t1 = t0 + (int64_t)seg_hops * hop;
+    t1 = t1 < t_end ? t1 : t_end;
+    if (t0 >= t1) continue;
+    const int64_t f_lo = (t0 - N + 1 <= 0) ? 0 : (t0 - N + hop) / hop;
+    int64_t f_hi = (t1 - 1) / hop;
+    f_hi = f_hi < n_frames - 1 ? f_hi : n_frames - 1;
+    const float* xr = wave_in + b * n_out;
+    float* orow = wave_out + b * n_out - N / 2;
+#pragma unroll
+    for (int j = 0; j < kRing / 64; ++j) ring[lane + 64 * j] = 0.f;
+    // (even, odd) pairs whatever the segment: a frame that two segments compute gets bit-identical values in both
+    const int64_t f_first = f_lo & ~(int64_t)1;
+    int64_t frontier = f_first * hop;
+    for (int64_t f = f_first; f <= f_hi; f += 2) {
+      const bool has_b = f + 1 < n_frames;
+      const int64_t ea = (b * n_frames + f) * bins;
+      // ---- forward: frames f, f + 1 of the current waveform (center, reflect) -------------------------------------------------
+      StftRaw raw;
+      stft_load(raw, xr, f * hop - N / 2, hop, n_out, 1, lane);
+      cf32 v[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) v[r] = cf32{raw.a[r] * win[r], has_b ? raw.b[r] * win[r] : 0.f};
+      // previous spectra and magnitudes of the bins this lane updates: in flight under the transform
+      cf32 tpa[9], tpb[9];
+      float mga[9], mgb[9];
+#pragma unroll
+      for (int jj = 0; jj < 9; ++jj) {
+        const int k = lane + 64 * jj;
+        const int kc = k < bins ? k : 0;                    // clamped: unconditional loads
+        const int64_t eb = has_b ? ea + bins : ea;
+        tpa[jj] = *reinterpret_cast<const cf32*>(tprev_in + 2 * (ea + kc));
+        tpb[jj] = *reinterpret_cast<const cf32*>(tprev_in + 2 * (eb + kc));
+        mga[jj] = mag[ea + kc];
+        mgb[jj] = mag[eb + kc];
+      }
+      fft1024_wave(v, buf, tw, lane);
+      // ---- phase update on the two real spectra; the new spectra mag * angles go back to LDS as A (0..512), B (513..1025) ---
+      cf32 za[9], zb[9];
+#pragma unroll
+      for (int jj = 0; jj < 9; ++jj) {
+        const int k = lane + 64 * jj;
+        if (k < bins) {
+          const cf32 z = buf[k];
+          const cf32 zc = buf[(N - k) & (N - 1)];
+          const cf32 sa = cf32{0.5f * (z.x + zc.x), 0.5f * (z.y - zc.y)};
+          const cf32 sb = cf32{0.5f * (z.y + zc.y), -0.5f * (z.x - zc.x)};
+          const cf32 ga = cf32{sa.x - momentum * tpa[jj].x, sa.y - momentum * tpa[jj].y};
+          const cf32 gb = cf32{sb.x - momentum * tpb[jj].x, sb.y - momentum * tpb[jj].y};
+          const float da = sqrtf(ga.x * ga.x + ga.y * ga.y) + 1e-16f, db = sqrtf(gb.x * gb.x + gb.y * gb.y) + 1e-16f;
+          za[jj] = cf32{mga[jj] * (ga.x / da), mga[jj] * (ga.y / da)};
+          zb[jj] = cf32{mgb[jj] * (gb.x / db), mgb[jj] * (gb.y / db)};
+          if (k == 0 || k == 512) za[jj].y = 0.f, zb[jj].y = 0.f;    // DC / Nyquist: the C2R transform ignores them
+          *reinterpret_cast<cf32*>(tprev_out + 2 * (ea + k)) = sa;
+          if (has_b) *reinterpret_cast<cf32*>(tprev_out + 2 * (ea + bins + k)) = sb;
+          else zb[jj] = cf32{0.f, 0.f};
+        }
+      }
+      __builtin_amdgcn_wave_barrier();                      // every lane has read its bins of the forward transform
+#pragma unroll
+      for (int jj = 0; jj < 9; ++jj) {
+        const int k = lane + 64 * jj;
+        if (k < bins) buf[k] = za[jj], buf[bins + k] = zb[jj];
+      }
+      __builtin_amdgcn_wave_barrier();
+      // ---- inverse: Z = A + i B (n <= 512) or conj(A) + i conj(B); the FFT input is conj(Z) ------------------------------------
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int n = lane + 64 * r;
+        const int k = (r < 8) ? n : N - n;
+        const cf32 A = buf[k], B = buf[bins + k];
+        if (r < 8) v[r] = cf32{A.x - B.y, -(A.y + B.x)};
+        else v[r] = cf32{A.x + B.y, -(B.x - A.y)};
+      }
+      __builtin_amdgcn_wave_barrier();
+      fft1024_wave(v, buf, tw, lane);
+      const bool more = f + 2 <= f_hi;
+      const int64_t upto = more ? (f + 2) * hop : t1;
+      ola_pair(ring, buf, win_n, envt, f, hop, has_b, frontier, upto, t0, t1, n_frames, orow, lane);
+      frontier = upto;
+      __builtin_amdgcn_wave_barrier();
     }
   }
 }
@@ -682,9 +813,10 @@ extern "C" int mmk_istft_f32(const float* spec, int32_t coordinate, int32_t batc
 
 extern "C" size_t mmk_gla_workspace_floats(int32_t batch, int64_t n_frames, int32_t n_fft, int32_t hop) {
   const size_t bins = (size_t)n_fft / 2 + 1;
-  return (size_t)batch * ((size_t)hop * (size_t)(n_frames > 0 ? n_frames - 1 : 0)   // the current waveform
-                          + 4 * (size_t)n_frames * bins)                // angles, previous rebuilt spectrum (complex)
-         + mmk_istft_workspace_floats(batch, n_frames, n_fft);          // windowed frames (n_fft != 1024)
+  const size_t wave = (size_t)hop * (size_t)(n_frames > 0 ? n_frames - 1 : 0);
+  // n_fft = 1024: two waveforms and two previous spectra (ping-pong of the fused iteration kernel);
+  // other sizes: the waveform, phase estimates, previous spectrum and the windowed frames
+  return (size_t)batch * ((n_fft == 1024 ? 2 : 1) * wave + 4 * (size_t)n_frames * bins) + mmk_istft_workspace_floats(batch, n_frames, n_fft);
 }
 
 extern "C" int mmk_gla_f32(const float* mag, const float* init, int32_t batch, int64_t n_frames, int32_t n_fft, int32_t hop, int32_t n_iter,
@@ -698,20 +830,58 @@ extern "C" int mmk_gla_f32(const float* mag, const float* init, int32_t batch, i
                                       (long long)n_frames, (long long)n_out, n_fft / 2);
   hipStream_t s = (hipStream_t)stream;
   const size_t bins = (size_t)n_fft / 2 + 1;
-  float* wave = work;
-  float* angles = wave + (size_t)batch * n_out;
-  float* tprev = angles + 2 * (size_t)batch * n_frames * bins;
-  float* frames = tprev + 2 * (size_t)batch * n_frames * bins;
-  const size_t spec_bytes = 2 * (size_t)batch * n_frames * bins * sizeof(float);
-  if (init) MMK_HIP(hipMemcpyAsync(angles, init, spec_bytes, hipMemcpyDeviceToDevice, s));
-  else {                                                     // rand_init=False: every phase estimate starts at 1 + 0i
+  const size_t spec_floats = 2 * (size_t)batch * n_frames * bins;
+  const float m = momentum / (1.f + momentum);
+  auto fill_ones = [&](float* dst) -> int {                  // rand_init=False: every phase estimate starts at 1 + 0i
     const int64_t n = (int64_t)batch * n_frames * (int64_t)bins;
-    hipLaunchKernelGGL(fill_complex_kernel, dim3((unsigned)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256)), dim3(256), 0, s, angles, n,
+    hipLaunchKernelGGL(fill_complex_kernel, dim3((unsigned)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256)), dim3(256), 0, s, dst, n,
                        cf32{1.f, 0.f});
     MMK_HIP(hipGetLastError());
+    return MMK_OK;
+  };
+  if (n_fft == 1024) {
+    // one launch per iteration: stft -> phase update -> istft fused per output segment (gla1024_iter_kernel)
+    float* wave_a = work;
+    float* wave_b = wave_a + (size_t)batch * n_out;
+    float* tprev_a = wave_b + (size_t)batch * n_out;
+    float* tprev_b = tprev_a + spec_floats;
+    const float* angles0 = init;
+    if (!init) {                                             // tprev_b holds the initial estimates until iteration 0 overwrites it
+      if (int rc = fill_ones(tprev_b)) return rc;
+      angles0 = tprev_b;
+    }
+    if (int rc = launch_istft(angles0, mag, 2, batch, n_frames, hop, n_iter ? wave_a : out, s)) return rc;
+    if (!n_iter) return MMK_OK;
+    MMK_HIP(hipMemsetAsync(tprev_a, 0, spec_floats * sizeof(float), s));
+    int seg_hops, segs_per_clip;
+    istft_geometry(batch, n_frames, &seg_hops, &segs_per_clip);
+    const int64_t total_tasks = (int64_t)batch * segs_per_clip;
+    const int64_t wgs = (total_tasks + kIstftWaves - 1) / kIstftWaves;
+    const dim3 grid((unsigned)(wgs < 512 ? wgs : 512)), block(64 * kIstftWaves);
+    const float* wave_in = wave_a;
+    float* wave_other = wave_b;
+    const float* tin = tprev_a;
+    float* tout = tprev_b;
+    for (int it = 0; it < n_iter; ++it) {
+      float* dst = it == n_iter - 1 ? out : wave_other;
+      hipLaunchKernelGGL(gla1024_iter_kernel, grid, block, 0, s, wave_in, mag, tin, tout, m, n_frames, hop, seg_hops, segs_per_clip,
+                         total_tasks, n_out, dst);
+      MMK_HIP(hipGetLastError());
+      wave_other = const_cast<float*>(wave_in);
+      wave_in = dst;
+      float* t = const_cast<float*>(tin);
+      tin = tout;
+      tout = t;
+    }
+    return MMK_OK;
   }
-  MMK_HIP(hipMemsetAsync(tprev, 0, spec_bytes, s));
-  const float m = momentum / (1.f + momentum);
+  float* wave = work;
+  float* angles = wave + (size_t)batch * n_out;
+  float* tprev = angles + spec_floats;
+  float* frames = tprev + spec_floats;
+  if (init) MMK_HIP(hipMemcpyAsync(angles, init, spec_floats * sizeof(float), hipMemcpyDeviceToDevice, s));
+  else if (int rc = fill_ones(angles)) return rc;
+  MMK_HIP(hipMemsetAsync(tprev, 0, spec_floats * sizeof(float), s));
   for (int it = 0; it < n_iter; ++it) {
     if (int rc = istft_any(angles, mag, 2, batch, n_frames, n_fft, hop, frames, wave, s)) return rc;
     if (int rc = stft_any(wave, n_out, batch, n_out, n_fft, hop, 1, 1, 3, angles, tprev, m, s)) return rc;
