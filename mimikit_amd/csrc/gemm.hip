@@ -99,4 +99,136 @@ int launch_gemm_f32(const float* A, int64_t lda, int64_t a_batch, const float* W
   return MMK_OK;
 }
 
+// ---- K-pipelined variant with an epilogue:  C[M, N] = act(A[M, K] . W^T + bias) ----------------------------------------------
+// For the GEMM-shaped ops of the Seq2Seq step (W_ih x over all hop frames of all clips: 512 x 4096 x 1024, and the
+// output projection), which the row-tile kernel of linear.hip (built for M <= 64) ran at 42 TFLOP/s.
+//   * 128 rows x 64 columns per workgroup, 8 waves as 4 x 2, a wave owns 32 x 32 = 2 x 2 MFMA tiles; 512 x 4096 gives
+//     256 workgroups: one per CU, two waves per SIMD
+//   * A goes through LDS in 64-k slabs, double buffered; the next slab travels global -> registers while the current
+//     one is multiplied (2 x 64 MFMAs per SIMD and stage = 1.7 us, longer than the loads take)
+//   * W fragments (1 KiB, packed order) come straight from global / L2 into registers, one stage ahead
+//   * per K-chunk a wave issues 2 LDS reads and 16 MFMAs: the matrix pipe is the bound
+constexpr int kTgThreads = 512;             // 8 waves as 4 x 2: two waves per SIMD keep the matrix pipe fed across LDS / barrier waits
+constexpr int kTgBM = 128, kTgBN = 64;
+constexpr int kTgCh = 4;                       // K-chunks (of 16) per pipeline stage: 1.7 us of MFMAs hide the next stage's loads
+constexpr int kTgLd = kTgCh * 16 + 4;          // LDS row stride: the 16 lanes of a quarter wave hit 64 different banks
+
+__global__ __launch_bounds__(kTgThreads) void gemm_bias_act_kernel(const float* __restrict__ A, int64_t lda, const float* __restrict__ Wp,
+                                                                 const float* __restrict__ bias, float* __restrict__ C, int64_t ldc,
+                                                                 int M, int n_tiles, int N, int K, int k_chunks, int act) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float* as = reinterpret_cast<float*>(smem_raw);              // [2][kTgBM][kTgLd]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;                       // 32 rows x 32 columns per wave
+  const int m_first = blockIdx.y * kTgBM;
+  const int tile0 = blockIdx.x * (kTgBN / 16) + wn * 2;         // this wave's two column tiles
+  // A slab loader: thread t moves row t / 4, floats 4 (t % 4) .. + 3 of each of the stage's chunks
+  const int a_row = tid >> 2, a_col = (tid & 3) * 4;
+  const int r0 = m_first + a_row;
+  const float* a0 = A + (int64_t)(r0 < M ? r0 : M - 1) * lda + a_col;     // clamped rows are never stored
+  f32x4 va[kTgCh];
+  auto load_a = [&](int stage) {
+#pragma unroll
+    for (int cc = 0; cc < kTgCh; ++cc) {
+      const int c = stage * kTgCh + cc;
+      const int k = c * 16 + a_col;
+      if (k + 3 < K) {
+        va[cc] = *reinterpret_cast<const f32x4*>(a0 + c * 16);
+      } else {                                                 // the ragged end of K (and chunks beyond it): zeros
+        for (int i = 0; i < 4; ++i) va[cc][i] = k + i < K ? a0[c * 16 + i] : 0.f;
+      }
+    }
+  };
+  auto store_a = [&](int buf) {
+    float* dst = as + buf * (kTgBM * kTgLd);
+#pragma unroll
+    for (int cc = 0; cc < kTgCh; ++cc) {
+      *reinterpret_cast<f32x4*>(dst + a_row * kTgLd + cc * 16 + a_col) = va[cc];
+    }
+  };
+  const int t0 = tile0 < n_tiles ? tile0 : n_tiles - 1, t1 = tile0 + 1 < n_tiles ? tile0 + 1 : n_tiles - 1;
+  gf32x4_ptr w0 = (gf32x4_ptr)(uintptr_t)Wp + (int64_t)t0 * k_chunks * 64 + lane;
+  gf32x4_ptr w1 = (gf32x4_ptr)(uintptr_t)Wp + (int64_t)t1 * k_chunks * 64 + lane;
+  f32x4 wc[kTgCh][2], wx[kTgCh][2];
+  auto load_w = [&](int stage, f32x4 (&w)[kTgCh][2]) {
+#pragma unroll
+    for (int cc = 0; cc < kTgCh; ++cc) {
+      const int c = stage * kTgCh + cc;
+      const int cl = c < k_chunks ? c : k_chunks - 1;           // beyond K the A slab is zero: any fragment will do
+      w[cc][0] = w0[(int64_t)cl * 64];
+      w[cc][1] = w1[(int64_t)cl * 64];
+    }
+  };
+  f32x4 acc[2][2];
+#pragma unroll
+  for (int r = 0; r < 2; ++r) acc[r][0] = acc[r][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int n_stages = (k_chunks + kTgCh - 1) / kTgCh;
+  load_a(0);
+  load_w(0, wc);
+  store_a(0);
+  __syncthreads();
+  const int x_off = (wm * 32 + (lane & 15)) * kTgLd + 4 * (lane >> 4);
+  for (int st = 0; st < n_stages; ++st) {
+    const bool more = st + 1 < n_stages;
+    if (more) {                                                // next stage's slab and fragments in flight
+      load_a(st + 1);
+      load_w(st + 1, wx);
+    }
+    const float* x = as + (st & 1) * (kTgBM * kTgLd) + x_off;
+#pragma unroll
+    for (int cc = 0; cc < kTgCh; ++cc) {
+      f32x4 xv[2];
+#pragma unroll
+      for (int r = 0; r < 2; ++r) xv[r] = *reinterpret_cast<const f32x4*>(x + r * 16 * kTgLd + cc * 16);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+          acc[r][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[r][i], wc[cc][0][i], acc[r][0], 0, 0, 0);
+          acc[r][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[r][i], wc[cc][1][i], acc[r][1], 0, 0, 0);
+        }
+      }
+    }
+    if (more) {
+      // the other buffer was last read in stage st - 1, which every wave left through the barrier below
+      store_a((st + 1) & 1);
+#pragma unroll
+      for (int cc = 0; cc < kTgCh; ++cc) wc[cc][0] = wx[cc][0], wc[cc][1] = wx[cc][1];
+    }
+    __syncthreads();
+  }
+  // ---- D: column lane & 15, rows 4 (lane >> 4) + j of each 16-row block ------------------------------------------------------
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int tile = tile0 + t;
+    const int col = tile * 16 + (lane & 15);
+    if (tile >= n_tiles || col >= N) continue;
+    const float b = bias ? bias[col] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int m = m_first + wm * 32 + r * 16 + 4 * (lane >> 4) + j;
+        if (m < M) C[(int64_t)m * ldc + col] = apply_act(acc[r][t][j] + b, act);
+      }
+    }
+  }
+}
+
+bool gemm_bias_act_supported(const float* A, int64_t lda, int M, int K) {
+  return M >= 128 && K >= 16 && (lda % 4) == 0 && (reinterpret_cast<uintptr_t>(A) & 15) == 0;
+}
+
+int launch_gemm_bias_act(const float* A, int64_t lda, const float* Wp, const float* bias, int n_tiles, int k_chunks, int N, int K, float* C,
+                         int64_t ldc, int M, int act, hipStream_t stream) {
+  if (M <= 0 || n_tiles <= 0) return MMK_OK;
+  if (!gemm_bias_act_supported(A, lda, M, K)) return fail(MMK_ERR_UNSUPPORTED, "gemm_bias_act: needs M >= 128 and a 16-byte aligned A");
+  dim3 grid((n_tiles + kTgBN / 16 - 1) / (kTgBN / 16), (M + kTgBM - 1) / kTgBM), block(kTgThreads);
+  const size_t lds = (size_t)2 * kTgBM * kTgLd * sizeof(float);
+  hipLaunchKernelGGL(gemm_bias_act_kernel, grid, block, lds, stream, A, lda, Wp, bias, C, ldc, M, n_tiles, N, K, k_chunks, act);
+  MMK_HIP(hipGetLastError());
+  return MMK_OK;
+}
+
 }  // namespace mmk

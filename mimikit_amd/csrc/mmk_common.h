@@ -201,6 +201,10 @@ int launch_stft_generic(const float* x, int64_t x_row_stride, int batch, int64_t
 // plain tiled GEMM on a packed weight matrix (gemm.hip): C[b][M, N] = A[b][M, K] . W^T, b < batch
 int launch_gemm_f32(const float* A, int64_t lda, int64_t a_batch, const float* Wp, int n_tiles, int k_chunks, int N, int K,
                     float* C, int64_t ldc, int64_t c_batch, int M, int batch, hipStream_t stream);
+// C[M, N] = act(A[M, K] . W^T + bias) on a packed weight matrix, 128 x 64 tiles with a pipelined K loop (gemm.hip); M >= 128
+bool gemm_bias_act_supported(const float* A, int64_t lda, int M, int K);
+int launch_gemm_bias_act(const float* A, int64_t lda, const float* Wp, const float* bias, int n_tiles, int k_chunks, int N, int K, float* C,
+                         int64_t ldc, int M, int act, hipStream_t stream);
 
 // recurrent cells (elementwise)
 int launch_gru_cell(const float* gi, const float* gh, float* h, int M, int H, hipStream_t stream);

@@ -206,6 +206,10 @@ extern "C" int mmk_s2s_commit(mmk_s2s_plan* p, void* workspace, size_t workspace
 
 static int plain_linear(const PackedLinear& w, const float* x, int64_t ldx, int M, float* y, int64_t ldy, int act,
                         hipStream_t st) {
+  // GEMM-shaped calls (all hop frames of all clips at once) take the tiled kernel; MMK_S2S_GEMM=0 keeps the row-tile one
+  static const bool tiled = [] { const char* e = getenv("MMK_S2S_GEMM"); return !(e && e[0] == '0'); }();
+  if (tiled && w.nseg == 1 && gemm_bias_act_supported(x, ldx, M, w.segK[0]))
+    return launch_gemm_bias_act(x, ldx, w.Wp, w.bias, w.n_tiles, w.k_chunks, w.N, w.segK[0], y, ldy, M, act, st);
   LinearArgs a = {};
   w.fill(a);
   a.seg[0].x = addr_static(x);

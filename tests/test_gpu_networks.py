@@ -258,11 +258,12 @@ def test_seq2seq_matches_reference_golden(device):
     assert bool((out[0][:, -10:] != 0).all())                 # tests/test_seq2seq.py:146
 
 
-@pytest.mark.parametrize("fused,hop,batch", [("1", 8, 6), ("0", 8, 6), ("1", 5, 19)])
+@pytest.mark.parametrize("fused,hop,batch", [("1", 8, 6), ("0", 8, 6), ("1", 5, 19), ("1", 8, 33), ("0", 3, 45)])
 def test_seq2seq_cfg5_geometry_vs_oracle(device, monkeypatch, fused, hop, batch):
     """magspec_io(22050, 1024, 256) -> 513 bins, hop 8, model_dim 128 (cfg 5 at reduced width), batch 6; with the fused
     LSTM time-step kernel (both directions per launch) and with one launch per op; an odd hop (state ends in the
-    second buffer) with a ragged row tile"""
+    second buffer) with a ragged row tile; 264 and 135 rows (batch x hop >= 128) take the tiled GEMM for the
+    input-to-hidden and output projections, with a ragged last row tile and K = 513"""
     monkeypatch.setenv("MMK_S2S_FUSED", fused)
     io = mmk.IOSpec.magspec_io(mmk.IOSpec.MagSpecIOConfig(sr=22050, n_fft=1024, hop_length=256))
     net = mmk.Seq2SeqLSTMNetwork.from_config(mmk.Seq2SeqLSTMNetwork.Config(io_spec=io, model_dim=128, hop=hop)).eval()
