@@ -42,6 +42,8 @@ def parse():
                     choices=["wavenet_cfg4", "wavenet_cfg2", "srnn_cfg3", "s2s_cfg5", "mulaw", "stft", "istft", "gla"])
     ap.add_argument("--clips", type=int, default=0, help="clips per GPU (0 = the workload's BASELINE value)")
     ap.add_argument("--seconds", type=float, default=1.0, help="generated audio per clip")
+    ap.add_argument("--temperature", type=float, default=0.0,
+                    help="> 0: sampled decode at this temperature (throughput only: the CPU check needs greedy decode)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline sample")
     return ap.parse_args()
@@ -85,6 +87,8 @@ class WaveNetJob:
         self.expand = mmk.MuLawExpand(256)
         self.name = args.workload
         self.dtype = "f32"
+        self.params = dict(temperature=(args.temperature,)) if getattr(args, "temperature", 0) > 0 else {}
+        self.decode = f"sampled, temperature {args.temperature}" if self.params else "greedy"
 
     def to_device(self):
         self.net.to(self.device)
@@ -97,7 +101,7 @@ class WaveNetJob:
         p = self.prompt_len
         net = self.net
         net.before_generate((self.idx[:, :p], *[c[:, :p] for c in self.cond]), None)
-        net.generate_block((self.idx, *self.cond), p, self.n_steps)
+        net.generate_block((self.idx, *self.cond), p, self.n_steps, **self.params)
         net.after_generate((self.idx,), None)
         self.audio_out = self.expand(self.idx)
 
@@ -109,7 +113,7 @@ class WaveNetJob:
         return {"workload": f"{self.name}: WaveNet blocks={tuple(c.blocks)} x {c.dims_dilated[0]} ch, "
                             f"{len(c.dims_1x1)} cond input(s), mu-law-256, 16 kHz",
                 "clips_per_gpu": self.clips, "global_clips": self.clips * world, "prompt_samples": self.prompt_len,
-                "generated_samples_per_clip": self.n_steps, "decode": "greedy", "parallelism": f"clip-shard x{world}"}
+                "generated_samples_per_clip": self.n_steps, "decode": self.decode, "parallelism": f"clip-shard x{world}"}
 
     # HBM roofline of the dominant kernel, measured with HIP events on its launches
     def roofline(self):
@@ -216,6 +220,8 @@ class SrnnJob:
         self.audio_cpu = torch.rand(self.clips, self.prompt_len, generator=gen) * 2 - 1
         self.expand = mmk.MuLawExpand(256)
         self.name, self.dtype = args.workload, "f32"
+        self.params = dict(temperature=(args.temperature,)) if getattr(args, "temperature", 0) > 0 else {}
+        self.decode = f"sampled, temperature {args.temperature}" if self.params else "greedy"
 
     def to_device(self):
         self.net.to(self.device)
@@ -225,7 +231,7 @@ class SrnnJob:
 
     def one_pass(self):
         self.net.before_generate((self.idx[:, :self.prompt_len],), None)
-        self.net.generate_block((self.idx,), self.prompt_len, self.n_steps)
+        self.net.generate_block((self.idx,), self.prompt_len, self.n_steps, **self.params)
         self.net.after_generate((self.idx,), None)
         self.audio_out = self.expand(self.idx)
 
@@ -235,7 +241,7 @@ class SrnnJob:
     def config(self, world):
         return {"workload": "srnn_cfg3: SampleRNN frame_sizes=(16,4,1), GRU hidden 512, mu-law-256, 16 kHz",
                 "clips_per_gpu": self.clips, "global_clips": self.clips * world, "prompt_samples": self.prompt_len,
-                "generated_samples_per_clip": self.n_steps, "decode": "greedy", "parallelism": f"clip-shard x{world}"}
+                "generated_samples_per_clip": self.n_steps, "decode": self.decode, "parallelism": f"clip-shard x{world}"}
 
     def step_bytes(self):
         """algorithmic bytes of one auto-regressive step of the local batch, amortised over the tier clocks: every
@@ -491,7 +497,7 @@ def main():
         roof = job.roofline()
         if roof is not None:
             line["roofline"] = roof
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and not args.temperature > 0:    # the CPU leg re-checks the GREEDY samples
             line["cpu_baseline"] = job.cpu_baseline(args.cpu_seconds)
         print(json.dumps(line), flush=True)
     if world > 1:
