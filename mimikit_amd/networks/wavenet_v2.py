@@ -252,6 +252,13 @@ class WaveNet(ARM, nn.Module):
         inputs = tuple(inputs)
         native.require_device(*inputs)
         rf = self.rf
+        if self._config.pad_side == 1:
+            # every layer pads its cause on the left and eval keeps the LAST position (reference :87-88, :273): with at
+            # least rf steps the padding is never reached and that is the step computed from the last rf positions
+            if inputs[0].size(1) < rf:
+                raise NotImplementedError("pad_side=1 on a window shorter than the receptive field (zero-padded hidden "
+                                          "states) is outside the HIP generate path")
+            return self._window_step(tuple(x[:, -rf:] for x in inputs), t=inputs[0].size(1), **parameters)
         if inputs[0].size(1) < rf:
             raise RuntimeError(f"Calculated output size is too small: window of {inputs[0].size(1)} steps "
                                f"for a receptive field of {rf}")
@@ -261,8 +268,8 @@ class WaveNet(ARM, nn.Module):
     def _describe(self, max_batch: int) -> native.WaveNetConfig:
         cfg, io = self._config, self._config.io_spec
         unsupported = []
-        if cfg.pad_side != 0:
-            unsupported.append("pad_side != 0")
+        if cfg.pad_side not in (0, 1):
+            unsupported.append("pad_side other than 0 / 1")
         if cfg.groups < 1 or cfg.dims_dilated[0] % cfg.groups:
             unsupported.append(f"groups={cfg.groups} does not divide the dilated width")
         if cfg.stride != 1:

@@ -199,6 +199,25 @@ def make_freqnet():
     save("freqnet.npz", **arrays)
 
 
+def make_wavenet_padded():
+    """pad_side=1 (every layer pads its cause on the left, eval returns the LAST position, wavenet_v2.py:87-88, :273):
+    the generate loop hands rf-long windows over, so the padding is never reached and the samples are those of
+    pad_side=0 -- pinned here rather than assumed"""
+    g = torch.Generator().manual_seed(23)
+    io = ref.IOSpec.mulaw_io(ref.IOSpec.MuLawIOConfig(input_module_type="embedding", mlp_dim=32))
+    cfg = ref.WaveNet.Config(io_spec=io, blocks=(3, 2), dims_dilated=(16,), residuals_dim=16, skips_dim=16, pad_side=1)
+    net = ref.WaveNet.from_config(cfg).eval()
+    load_recipe(net, seed=11, gain=2.0)            # the weights of case (a) of wavenet.npz
+    rf = net.rf
+    prompt = torch.randint(0, 256, (3, rf + 5), generator=g)
+    log, h = capture_raw(net)
+    out = run_loop(net, (prompt,), 24)
+    h.remove()
+    # eval forward on a longer window: the class of its last position
+    fwd = net((prompt,))[0]
+    save("wavenet_pad1.npz", prompt=prompt, out=out[0], raw=torch.cat(log[:24], 1), rf=np.int64(rf), forward_last=fwd)
+
+
 def make_srnn():
     g = torch.Generator().manual_seed(21)
     arrays = {}
@@ -304,6 +323,7 @@ if __name__ == "__main__":
     make_istft()
     make_wavenet()
     make_freqnet()
+    make_wavenet_padded()
     make_srnn()
     make_s2s()
     make_sampler()

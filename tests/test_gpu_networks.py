@@ -278,6 +278,22 @@ def test_seq2seq_cfg5_geometry_vs_oracle(device, monkeypatch, fused, hop, batch)
         assert mmk.GenerateLoopV2.get_n_steps(loop_cfg, net) == 84
 
 
+def test_wavenet_pad_side_1(device):
+    """pad_side=1: golden from the reference's loop and eval forward (classes bit-exact, as for pad_side=0)"""
+    g = H.golden("wavenet_pad1.npz")
+    net = mmk.WaveNet.from_config(mmk.WaveNet.Config(io_spec=H.mu_emb(mlp_dim=32), blocks=(3, 2), dims_dilated=(16,),
+                                                     residuals_dim=16, skips_dim=16, pad_side=1)).eval()
+    from oracle.weights import load_recipe
+    load_recipe(net, seed=11, gain=2.0)
+    net.to(device)
+    prompt = H.T(g["prompt"]).to(device)
+    out = run_loop(net, (prompt,), 24)[0].cpu()
+    assert torch.equal(out, H.T(g["out"]))
+    assert torch.equal(net((prompt,))[0].cpu(), H.T(g["forward_last"]))
+    with pytest.raises(NotImplementedError):
+        net((prompt[:, :5],))
+
+
 @pytest.mark.parametrize("tag", list(H.FREQNET_CASES))
 def test_wavenet_on_magnitude_frames(device, tag):
     """FreqNet (demos/freqnet.py:34-63) at reduced size: frames in, frames out, no residual / skip path, groups 1 / 4 / 2

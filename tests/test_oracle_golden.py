@@ -134,6 +134,21 @@ def test_wavenet_on_magnitude_frames_matches_reference(tag):
     assert torch.allclose(out, H.T(g[f"{tag}_out"]), rtol=1e-5, atol=1e-6)
 
 
+def test_wavenet_pad_side_1_generates_like_pad_side_0():
+    """the reference's loop on a pad_side=1 network: rf-long windows never reach the padding, so the oracle's
+    pad_side=0 algorithm reproduces its samples and the class of an eval forward's last position"""
+    g = H.golden("wavenet_pad1.npz")
+    _, sd, arch = H.wavenet_a()
+    rf = int(g["rf"])
+    assert rf == O.wavenet_rf(arch["kernels"], arch["dilations"])
+    prompt = H.T(g["prompt"])
+    idx, raw = O.wavenet_generate(sd, prompt, (), 24, keep_logits=True, **arch)
+    assert torch.allclose(raw, H.T(g["raw"]), rtol=1e-5, atol=1e-5)
+    assert torch.equal(idx, H.T(g["out"]))
+    last = O.categorical(O.mlp_logits(O.wavenet_window_forward(sd, (prompt[:, -rf:],), **arch)))
+    assert torch.equal(last, H.T(g["forward_last"]))
+
+
 def test_wavenet_cfg2_shape_matches_reference():
     g = H.golden("wavenet.npz")
     _, sd, arch = H.wavenet_c()
