@@ -44,6 +44,29 @@ class H0Init(AutoStrEnum):
     randn = auto()
 
 
+def weight_norm_leaves(root: nn.Module) -> None:
+    """``nn.utils.weight_norm`` on every parameter of every leaf module (reference :76-81 and SampleRNN.__init__)"""
+    for module in root.modules():
+        if isinstance(module, nn.ModuleList) or list(module.children()) != []:
+            continue
+        for name in dict(module.named_parameters()):
+            nn.utils.weight_norm(module, name)
+
+
+def fold_weight_norm(sd: Dict[str, T]) -> Dict[str, T]:
+    """state_dict as the HIP plan binds it: ``name_g`` / ``name_v`` pairs folded into ``name`` = g v / |v| (norm over
+    every dimension but the first, as ``torch._weight_norm(v, g, 0)``), which is what the module's pre-forward hook does"""
+    out = {}
+    for key, value in sd.items():
+        if key.endswith("_v") and key[:-2] + "_g" in sd:
+            out[key[:-2]] = torch._weight_norm(value, sd[key[:-2] + "_g"], 0)
+        elif key.endswith("_g") and key[:-2] + "_v" in sd:
+            continue
+        else:
+            out[key] = value
+    return out
+
+
 class SampleRNNTier(nn.Module):
     """input projection (+ upper tier vector) -> RNN -> linear up-sampler; parameters under the
     reference's names, differentiable forward for training"""
@@ -52,8 +75,6 @@ class SampleRNNTier(nn.Module):
                  rnn_class: RNNType = "lstm", n_rnn: int = 1, rnn_dropout: float = 0., rnn_bias: bool = True,
                  h0_init: H0Init = "zeros", weight_norm: bool = False, up_sampling: Optional[int] = None):
         super().__init__()
-        if weight_norm:
-            raise NotImplementedError("weight_norm is outside the covered option space (SURVEY 8(f) rank 2)")
         self.input_module = input_module
         self.hidden_dim, self.rnn_class, self.n_rnn = hidden_dim, str(rnn_class), n_rnn
         self.rnn_dropout, self.rnn_bias, self.h0_init = rnn_dropout, rnn_bias, str(h0_init)
@@ -67,6 +88,17 @@ class SampleRNNTier(nn.Module):
                             bias=rnn_bias)
         if self.has_up_sampling:
             self.up_sampler = LinearResampler(hidden_dim, t_factor=up_sampling, d_factor=1)
+        if weight_norm:
+            # the reference re-parametrises EVERY parameter of the RNN, the up-sampler and the leaves of the input module,
+            # biases included (:67-81): ``name`` becomes ``name_g`` / ``name_v`` in the state_dict
+            if self.has_rnn:
+                for name in dict(self.rnn.named_parameters()):
+                    nn.utils.weight_norm(self.rnn, name)
+            if self.has_up_sampling:
+                for module in self.up_sampler.children():
+                    for name in dict(module.named_parameters()):
+                        nn.utils.weight_norm(module, name)
+            weight_norm_leaves(self.input_module)
 
     def _fresh(self, batch: int, device):
         return getattr(torch, self.h0_init)(self.n_rnn, batch, self.hidden_dim).to(device)
@@ -137,6 +169,8 @@ class SampleRNN(ARMWithHidden, nn.Module):
         self.frame_sizes = config.frame_sizes
         self.tiers: List[SampleRNNTier] = nn.ModuleList(tiers)
         self.output_modules = nn.ModuleList(output_module)
+        if config.weight_norm:
+            weight_norm_leaves(self.output_modules)
         self.outputs = []
         self.prompt_length = 0
         self._plan: Optional[native.SrnnPlan] = None
@@ -242,7 +276,8 @@ class SampleRNN(ARMWithHidden, nn.Module):
             self._plan_batch = max(batch, 1)
             rebuilt = True
         if rebuilt or refresh_weights:
-            self._plan.bind_state_dict(self.state_dict())
+            sd = self.state_dict()
+            self._plan.bind_state_dict(fold_weight_norm(sd) if self._config.weight_norm else sd)
             self._plan.commit()
             self._next_t = None
 

@@ -288,6 +288,20 @@ def _rnn_cell(kind: str, sd: SD, p: str, x: torch.Tensor, state):
     return h, h
 
 
+def fold_weight_norm(sd: SD) -> SD:
+    """state_dict of a network built with weight_norm=True (sample_rnn_v2.py:67-81): every ``name_g`` / ``name_v`` pair
+    becomes ``name`` = g v / |v| with the norm over all dimensions but the first (torch.nn.utils.weight_norm, dim=0)"""
+    out = {}
+    for key, value in sd.items():
+        if key.endswith("_v") and key[:-2] + "_g" in sd:
+            g = sd[key[:-2] + "_g"]
+            norm = value.reshape(value.shape[0], -1).norm(dim=1).reshape(g.shape) if value.dim() > 1 else value.abs()
+            out[key[:-2]] = value * (g / norm)
+        elif not (key.endswith("_g") and key[:-2] + "_v" in sd):
+            out[key] = value
+    return out
+
+
 class SampleRNNOracle:
     """SampleRNN.before_generate / generate_step / after_generate (sample_rnn_v2.py:226-268) with
     SampleRNNTier.forward (:83-99) for n_rnn = 1, restated over a state_dict."""

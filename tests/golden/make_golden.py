@@ -234,6 +234,26 @@ def make_srnn():
     save("srnn.npz", **arrays)
 
 
+def make_srnn_weight_norm():
+    """weight_norm=True (sample_rnn_v2.py:67-81 and SampleRNN.__init__): every parameter of the RNNs, up-samplers, tier input
+    linears and of the MLP head is stored as a (g, v) pair; the recipe fills g and v, the network computes g v / |v|"""
+    import warnings
+    warnings.filterwarnings("ignore")
+    g = torch.Generator().manual_seed(27)
+    arrays = {}
+    for tag, fs, kind, plen in (("gru", (16, 4, 1), "gru", 40), ("lstm", (16, 8, 8), "lstm", 32)):
+        io = ref.IOSpec.mulaw_io(ref.IOSpec.MuLawIOConfig(mlp_dim=32))
+        cfg = ref.SampleRNN.Config(io_spec=io, frame_sizes=fs, hidden_dim=32, rnn_class=kind, weight_norm=True)
+        net = ref.SampleRNN.from_config(cfg).eval()
+        load_recipe(net, seed=60 + len(tag), gain=2.0)
+        prompt = torch.randint(0, 256, (3, plen), generator=g)
+        log, h = capture_raw(net)
+        out = run_loop(net, (prompt,), 40)
+        h.remove()
+        arrays.update({f"{tag}_prompt": prompt, f"{tag}_out": out[0], f"{tag}_raw": torch.stack(log, 1)})
+    save("srnn_wn.npz", **arrays)
+
+
 def make_s2s():
     g = torch.Generator().manual_seed(31)
     io = ref.IOSpec.magspec_io(ref.IOSpec.MagSpecIOConfig(n_fft=128, hop_length=32))
@@ -325,6 +345,7 @@ if __name__ == "__main__":
     make_freqnet()
     make_wavenet_padded()
     make_srnn()
+    make_srnn_weight_norm()
     make_s2s()
     make_sampler()
     make_keys()

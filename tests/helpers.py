@@ -80,12 +80,12 @@ def freqnet(tag):
 SRNN_CASES = {"gru": ((16, 4, 1), "gru", 40), "lstm": ((16, 8, 8), "lstm", 32), "rnn": ((8, 2, 2), "rnn", 21)}
 
 
-def srnn(tag, hidden=32, mlp_dim=32, seed=None, frame_sizes=None, kind=None):
+def srnn(tag, hidden=32, mlp_dim=32, seed=None, frame_sizes=None, kind=None, weight_norm=False):
     fs, k, _ = SRNN_CASES.get(tag, (frame_sizes, kind, None))
     fs, k = frame_sizes or fs, kind or k
     net = mmk.SampleRNN.from_config(mmk.SampleRNN.Config(io_spec=mu_lin(mlp_dim=mlp_dim), frame_sizes=fs, hidden_dim=hidden,
-                                                         rnn_class=k))
-    sd = load_recipe(net, seed=(30 + len(tag)) if seed is None else seed, gain=2.0)
+                                                         rnn_class=k, weight_norm=weight_norm))
+    sd = load_recipe(net, seed=((60 if weight_norm else 30) + len(tag)) if seed is None else seed, gain=2.0)
     return net.eval(), sd, dict(frame_sizes=fs, hidden_dim=hidden, rnn_class=k)
 
 

@@ -170,6 +170,21 @@ def test_sample_rnn_loop_matches_reference_golden(device, tag):
     assert inv[0].dtype == torch.float32 and inv[0].shape == (3, g[f"{tag}_prompt"].shape[1] + 40)
 
 
+@pytest.mark.parametrize("tag,fused", [("gru", "1"), ("gru", "0"), ("lstm", "1")])
+def test_sample_rnn_weight_norm_matches_reference_golden(device, monkeypatch, tag, fused):
+    """weight_norm=True: (g, v) pairs in the state_dict, folded to g v / |v| when the plan binds them (fused tier kernels
+    and one launch per op); classes bit-exact against the reference's loop"""
+    import warnings
+    warnings.filterwarnings("ignore")
+    monkeypatch.setenv("MMK_SRNN_FUSED", fused)
+    g = H.golden("srnn_wn.npz")
+    assert bool(H.margin_ok(g[f"{tag}_raw"].reshape(3, 40, 257)).all())
+    net, sd, _ = H.srnn(tag, weight_norm=True)
+    assert "tiers.0.rnn.weight_hh_l0_g" in sd and "output_modules.0.estimator.0.fc.0.bias_v" in sd
+    out = run_loop(net, (H.T(g[f"{tag}_prompt"]),), 40, parameters=None)
+    assert torch.equal(out[0].cpu(), H.T(g[f"{tag}_out"]))
+
+
 def test_sample_rnn_generate_step_protocol(device):
     """tests/test_sample_rnn.py:62-87 of the reference"""
     net, sd, arch = H.srnn("lstm")

@@ -168,6 +168,19 @@ def test_sample_rnn_matches_reference(tag):
     assert torch.equal(idx, H.T(g[f"{tag}_out"]))
 
 
+@pytest.mark.parametrize("tag", ["gru", "lstm"])
+def test_sample_rnn_weight_norm_matches_reference(tag):
+    import warnings
+    warnings.filterwarnings("ignore")
+    g = H.golden("srnn_wn.npz")
+    _, sd, arch = H.srnn(tag, weight_norm=True)
+    assert any(k.endswith("_g") for k in sd)
+    o = O.SampleRNNOracle(O.fold_weight_norm(sd), **arch)
+    idx, raw = o.generate(H.T(g[f"{tag}_prompt"]), 40, keep_logits=True)
+    assert torch.allclose(raw, H.T(g[f"{tag}_raw"]).reshape(raw.shape), rtol=1e-5, atol=1e-5)
+    assert torch.equal(idx, H.T(g[f"{tag}_out"]))
+
+
 def test_seq2seq_matches_reference():
     g = H.golden("s2s.npz")
     _, sd = H.s2s_tiny()
