@@ -150,5 +150,7 @@ extern "C" int mmk_stft_mag_f32(const float* x, int64_t x_row_stride, int32_t ba
   if (n_frames <= 0) return fail(MMK_ERR_INVALID, "stft: input of %lld samples is shorter than one frame", (long long)n_samples);
   if (n_fft == 1024)     // register-resident variant, one pair per wave (istft.hip)
     return launch_stft1024(x, x_row_stride, batch, n_samples, hop, center, 0, 4, out, nullptr, 0.f, (hipStream_t)stream);
+  if (n_fft == 2048)     // one frame per wave through the same 1024-point transform (spectral2048.hip)
+    return launch_stft2048(x, x_row_stride, batch, n_samples, hop, center, 0, 4, out, (hipStream_t)stream);
   return launch_stft_generic(x, x_row_stride, batch, n_samples, n_fft, hop, center, 0, 4, out, nullptr, 0.f, (hipStream_t)stream);
 }

@@ -10,20 +10,13 @@
 // All three are HBM-bound: a frame pair is 8 KiB of spectrum in, 8 KiB of windowed frames out (ISTFT), then the overlap-add
 // reads every windowed sample once.  Two real inverse transforms share one complex FFT:
 //       Z = A + i B  (A, B Hermitian-extended half spectra)   =>   ifft(Z) = a + i b ,   ifft(Z) = conj(fft(conj Z)) / N.
+#include <vector>
+
 #include "mmk_common.h"
 #include "fft1024.h"
+#include "spectral_util.h"
 
 namespace mmk {
-
-constexpr int kIstftWaves = 4;
-
-__device__ __forceinline__ void make_twiddles(cf32* tw, int tid, int nthreads) {
-  for (int m = tid; m < 1024; m += nthreads) {
-    float sn, cs;
-    sincospif(-2.0f * (float)m / 1024.0f, &sn, &cs);
-    tw[m] = cf32{cs, sn};
-  }
-}
 
 // ---- spectrum -> waveform, overlap-add fused ----------------------------------------------------------------------------
 // MODE 0: spec = (batch, frames, 513) complex (re, im);  MODE 1: (abs, angle) pairs;  MODE 2: mag plane x complex plane.
@@ -34,22 +27,6 @@ __device__ __forceinline__ void make_twiddles(cf32* tw, int tid, int nthreads) {
 // once, zeroed.  Frames are never written to HBM; the first ceil(n_fft / hop) - 1 frames of a segment are recomputed by
 // its left neighbour (11 % more transforms at hop = n_fft / 4 with 27-hop segments).  Summation order = frame order and
 // the pairing of frames is fixed, so the result does not depend on the launch geometry.
-
-// sin / cos of an angle in radians: three-constant Cody-Waite reduction to |r| <= pi/4 and the cephes single-precision
-// kernels (abs error ~1e-7 for |x| < 1e4; no Payne-Hanek path, which costs the library sincosf 300 B of scratch here).
-__device__ __forceinline__ void sincos_cw(float x, float* sn, float* cs) {
-  const float q = rintf(x * 0.636619772367581343f);
-  float r = fmaf(q, -1.5703125f, x);
-  r = fmaf(q, -4.837512969970703125e-4f, r);
-  r = fmaf(q, -7.54978995489188216e-8f, r);
-  const float z = r * r;
-  const float sp = fmaf(fmaf(fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f), z, -1.6666654611e-1f) * z, r, r);
-  const float cp = fmaf(fmaf(fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f), z, 4.166664568298827e-2f), z * z, fmaf(-0.5f, z, 1.0f));
-  const int qi = (int)q;
-  const float s0 = (qi & 1) ? cp : sp, c0 = (qi & 1) ? sp : cp;
-  *sn = (qi & 2) ? -s0 : s0;
-  *cs = ((qi + 1) & 2) ? -c0 : c0;
-}
 
 template <int MODE>
 struct IstftRaw {
@@ -81,17 +58,6 @@ __device__ __forceinline__ void istft_load(IstftRaw<MODE>& raw, const float* __r
       raw.mb[r] = (r < 8) ? mb_lo[64 * r] : mb_hi[-64 * r];
     }
   }
-}
-
-template <int MODE>
-__device__ __forceinline__ cf32 istft_bin(cf32 c, float m) {
-  if (MODE == 1) {                                          // abs * exp(i angle)   (functionals.py:556)
-    float sn, cs;
-    sincos_cw(c.y, &sn, &cs);
-    return cf32{c.x * cs, c.x * sn};
-  }
-  if (MODE == 2) return cf32{m * c.x, m * c.y};
-  return c;
 }
 
 constexpr int kRing = 2048;
@@ -663,6 +629,38 @@ static int check_fft(const char* what, int n_fft, int hop) {
   return MMK_OK;
 }
 
+// torch.istft refuses a window whose overlap-added square vanishes somewhere in the kept range ("window overlap add
+// min: 1", e.g. hop = n_fft - 1).  Same test on the host: the envelope is periodic in hop away from the clip's ends, so
+// the first and last n_fft kept positions and one period in between are all the distinct values.
+static int check_envelope(const char* what, int n_fft, int hop, int64_t n_frames) {
+  std::vector<float> w2((size_t)n_fft);
+  for (int m = 0; m < n_fft; ++m) {
+    const float w = 0.5f - 0.5f * cosf(6.283185307179586f * (float)m / (float)n_fft);
+    w2[(size_t)m] = w * w;
+  }
+  const int64_t t_lo = n_fft / 2, t_hi = n_fft / 2 + (int64_t)hop * (n_frames - 1);   // kept positions [t_lo, t_hi)
+  auto env = [&](int64_t t) {
+    int64_t g_hi = t / hop;
+    g_hi = g_hi < n_frames - 1 ? g_hi : n_frames - 1;
+    const int64_t g_lo = (t - n_fft + 1 <= 0) ? 0 : (t - n_fft + hop) / hop;
+    float e = 0.f;
+    for (int64_t g = g_lo; g <= g_hi; ++g) e += w2[(size_t)(t - g * hop)];
+    return e;
+  };
+  float mn = 1e30f;
+  const int64_t span = 2 * (int64_t)n_fft + hop;
+  if (t_hi - t_lo <= 2 * span) {
+    for (int64_t t = t_lo; t < t_hi; ++t) mn = fminf(mn, env(t));
+  } else {
+    for (int64_t t = t_lo; t < t_lo + span; ++t) mn = fminf(mn, env(t));
+    for (int64_t t = t_hi - span; t < t_hi; ++t) mn = fminf(mn, env(t));
+  }
+  if (!(mn >= 1e-11f))
+    return fail(MMK_ERR_INVALID, "%s: the overlap-added squared window vanishes (min %g) for n_fft=%d, hop=%d: torch.istft raises here too",
+                what, (double)mn, n_fft, hop);
+  return MMK_OK;
+}
+
 static unsigned pair_grid(int64_t total_pairs) {
   const int64_t wgs = (total_pairs + kIstftWaves - 1) / kIstftWaves;
   return (unsigned)(wgs < 768 ? wgs : 768);                 // 3 workgroups of 4 waves per CU, all resident
@@ -768,11 +766,13 @@ static int launch_istft_generic(const float* spec, const float* mag, int mode, i
 static int istft_any(const float* spec, const float* mag, int mode, int batch, int64_t n_frames, int n_fft, int hop, float* work, float* out,
                      hipStream_t stream) {
   if (n_fft == 1024) return launch_istft(spec, mag, mode, batch, n_frames, hop, out, stream);
+  if (n_fft == 2048) return launch_istft2048(spec, mag, mode, batch, n_frames, hop, out, stream);
   return launch_istft_generic(spec, mag, mode, batch, n_frames, n_fft, hop, work, out, stream);
 }
 static int stft_any(const float* x, int64_t x_row_stride, int batch, int64_t n_samples, int n_fft, int hop, int center, int reflect, int out_mode,
                     float* out, float* tprev, float momentum, hipStream_t stream) {
   if (n_fft == 1024) return launch_stft1024(x, x_row_stride, batch, n_samples, hop, center, reflect, out_mode, out, tprev, momentum, stream);
+  if (n_fft == 2048 && out_mode != 3) return launch_stft2048(x, x_row_stride, batch, n_samples, hop, center, reflect, out_mode, out, stream);
   return launch_stft_generic(x, x_row_stride, batch, n_samples, n_fft, hop, center, reflect, out_mode, out, tprev, momentum, stream);
 }
 
@@ -798,7 +798,7 @@ extern "C" int64_t mmk_istft_n_samples(int64_t n_frames, int32_t n_fft, int32_t 
 
 // windowed frames of the two-kernel path; the n_fft = 1024 kernel overlap-adds in LDS and needs none
 extern "C" size_t mmk_istft_workspace_floats(int32_t batch, int64_t n_frames, int32_t n_fft) {
-  return n_fft == 1024 ? 0 : (size_t)batch * (size_t)n_frames * (size_t)n_fft;
+  return (n_fft == 1024 || n_fft == 2048) ? 0 : (size_t)batch * (size_t)n_frames * (size_t)n_fft;
 }
 
 extern "C" int mmk_istft_f32(const float* spec, int32_t coordinate, int32_t batch, int64_t n_frames, int32_t n_fft, int32_t hop,
@@ -808,15 +808,17 @@ extern "C" int mmk_istft_f32(const float* spec, int32_t coordinate, int32_t batc
   if (int rc = check_fft("istft", n_fft, hop)) return rc;
   if (coordinate != 0 && coordinate != 1) return fail(MMK_ERR_INVALID, "istft: coordinate must be 0 (re, im) or 1 (mag, angle)");
   if (n_frames < 2) return fail(MMK_ERR_INVALID, "istft: one frame leaves no samples after the centre trim");
+  if (int rc = check_envelope("istft", n_fft, hop, n_frames)) return rc;
   return istft_any(spec, nullptr, coordinate, batch, n_frames, n_fft, hop, work, out, (hipStream_t)stream);
 }
 
 extern "C" size_t mmk_gla_workspace_floats(int32_t batch, int64_t n_frames, int32_t n_fft, int32_t hop) {
   const size_t bins = (size_t)n_fft / 2 + 1;
   const size_t wave = (size_t)hop * (size_t)(n_frames > 0 ? n_frames - 1 : 0);
-  // n_fft = 1024: two waveforms and two previous spectra (ping-pong of the fused iteration kernel);
+  // n_fft = 1024 / 2048: two waveforms and two previous spectra (ping-pong of the fused iteration kernels);
   // other sizes: the waveform, phase estimates, previous spectrum and the windowed frames
-  return (size_t)batch * ((n_fft == 1024 ? 2 : 1) * wave + 4 * (size_t)n_frames * bins) + mmk_istft_workspace_floats(batch, n_frames, n_fft);
+  return (size_t)batch * (((n_fft == 1024 || n_fft == 2048) ? 2 : 1) * wave + 4 * (size_t)n_frames * bins) +
+         mmk_istft_workspace_floats(batch, n_frames, n_fft);
 }
 
 extern "C" int mmk_gla_f32(const float* mag, const float* init, int32_t batch, int64_t n_frames, int32_t n_fft, int32_t hop, int32_t n_iter,
@@ -828,6 +830,7 @@ extern "C" int mmk_gla_f32(const float* mag, const float* init, int32_t batch, i
   const int64_t n_out = (int64_t)hop * (n_frames - 1);
   if (n_out <= n_fft / 2) return fail(MMK_ERR_INVALID, "gla: %lld frames give %lld samples, reflect padding needs more than %d",
                                       (long long)n_frames, (long long)n_out, n_fft / 2);
+  if (int rc = check_envelope("gla", n_fft, hop, n_frames)) return rc;
   hipStream_t s = (hipStream_t)stream;
   const size_t bins = (size_t)n_fft / 2 + 1;
   const size_t spec_floats = 2 * (size_t)batch * n_frames * bins;
@@ -839,8 +842,8 @@ extern "C" int mmk_gla_f32(const float* mag, const float* init, int32_t batch, i
     MMK_HIP(hipGetLastError());
     return MMK_OK;
   };
-  if (n_fft == 1024) {
-    // one launch per iteration: stft -> phase update -> istft fused per output segment (gla1024_iter_kernel)
+  if (n_fft == 1024 || n_fft == 2048) {
+    // one launch per iteration: stft -> phase update -> istft fused per output segment (gla1024_iter_kernel / gla2048_iter_kernel)
     float* wave_a = work;
     float* wave_b = wave_a + (size_t)batch * n_out;
     float* tprev_a = wave_b + (size_t)batch * n_out;
@@ -850,23 +853,31 @@ extern "C" int mmk_gla_f32(const float* mag, const float* init, int32_t batch, i
       if (int rc = fill_ones(tprev_b)) return rc;
       angles0 = tprev_b;
     }
-    if (int rc = launch_istft(angles0, mag, 2, batch, n_frames, hop, n_iter ? wave_a : out, s)) return rc;
+    if (int rc = istft_any(angles0, mag, 2, batch, n_frames, n_fft, hop, nullptr, n_iter ? wave_a : out, s)) return rc;
     if (!n_iter) return MMK_OK;
     MMK_HIP(hipMemsetAsync(tprev_a, 0, spec_floats * sizeof(float), s));
-    int seg_hops, segs_per_clip;
-    istft_geometry(batch, n_frames, &seg_hops, &segs_per_clip);
-    const int64_t total_tasks = (int64_t)batch * segs_per_clip;
-    const int64_t wgs = (total_tasks + kIstftWaves - 1) / kIstftWaves;
-    const dim3 grid((unsigned)(wgs < 512 ? wgs : 512)), block(64 * kIstftWaves);
+    int seg_hops = 0, segs_per_clip = 0;
+    int64_t total_tasks = 0;
+    dim3 grid(1), block(64 * kIstftWaves);
+    if (n_fft == 1024) {
+      istft_geometry(batch, n_frames, &seg_hops, &segs_per_clip);
+      total_tasks = (int64_t)batch * segs_per_clip;
+      const int64_t wgs = (total_tasks + kIstftWaves - 1) / kIstftWaves;
+      grid = dim3((unsigned)(wgs < 512 ? wgs : 512));
+    }
     const float* wave_in = wave_a;
     float* wave_other = wave_b;
     const float* tin = tprev_a;
     float* tout = tprev_b;
     for (int it = 0; it < n_iter; ++it) {
       float* dst = it == n_iter - 1 ? out : wave_other;
-      hipLaunchKernelGGL(gla1024_iter_kernel, grid, block, 0, s, wave_in, mag, tin, tout, m, n_frames, hop, seg_hops, segs_per_clip,
-                         total_tasks, n_out, dst);
-      MMK_HIP(hipGetLastError());
+      if (n_fft == 1024) {
+        hipLaunchKernelGGL(gla1024_iter_kernel, grid, block, 0, s, wave_in, mag, tin, tout, m, n_frames, hop, seg_hops, segs_per_clip,
+                           total_tasks, n_out, dst);
+        MMK_HIP(hipGetLastError());
+      } else if (int rc = launch_gla2048_iter(wave_in, mag, tin, tout, m, batch, n_frames, hop, dst, s)) {
+        return rc;
+      }
       wave_other = const_cast<float*>(wave_in);
       wave_in = dst;
       float* t = const_cast<float*>(tin);

@@ -195,6 +195,12 @@ int launch_sample(const SampleArgs& a, hipStream_t stream);
 // n_fft = 1024 STFT (istft.hip); out_mode 0 (re, im), 1 (abs, angle), 2 angle, 3 Griffin-Lim update, 4 abs
 int launch_stft1024(const float* x, int64_t x_row_stride, int batch, int64_t n_samples, int hop, int center, int reflect, int out_mode,
                     float* out, float* tprev, float momentum, hipStream_t stream);
+// n_fft = 2048 (spectral2048.hip): one real frame = one 1024-point complex transform + an untangling pass
+int launch_stft2048(const float* x, int64_t x_row_stride, int batch, int64_t n_samples, int hop, int center, int reflect, int out_mode,
+                    float* out, hipStream_t stream);
+int launch_istft2048(const float* spec, const float* mag, int mode, int batch, int64_t n_frames, int hop, float* out, hipStream_t stream);
+int launch_gla2048_iter(const float* wave_in, const float* mag, const float* tprev_in, float* tprev_out, float momentum, int batch,
+                        int64_t n_frames, int hop, float* wave_out, hipStream_t stream);
 // any power-of-two n_fft in [64, 4096]: one pair per workgroup, Stockham passes through LDS (istft.hip); same out modes
 int launch_stft_generic(const float* x, int64_t x_row_stride, int batch, int64_t n_samples, int n_fft, int hop, int center, int reflect,
                         int out_mode, float* out, float* tprev, float momentum, hipStream_t stream);

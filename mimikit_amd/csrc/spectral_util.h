@@ -1,0 +1,44 @@
+// Small device helpers shared by the n_fft = 1024 kernels (istft.hip) and the n_fft = 2048 kernels (spectral2048.hip).
+#pragma once
+#include "fft1024.h"
+
+namespace mmk {
+
+constexpr int kIstftWaves = 4;
+
+__device__ __forceinline__ void make_twiddles(cf32* tw, int tid, int nthreads) {
+  for (int m = tid; m < 1024; m += nthreads) {
+    float sn, cs;
+    sincospif(-2.0f * (float)m / 1024.0f, &sn, &cs);
+    tw[m] = cf32{cs, sn};
+  }
+}
+
+// sin / cos of an angle in radians: three-constant Cody-Waite reduction to |r| <= pi/4 and the cephes single-precision
+// kernels (abs error ~1e-7 for |x| < 1e4; no Payne-Hanek path, which costs the library sincosf 300 B of scratch here).
+__device__ __forceinline__ void sincos_cw(float x, float* sn, float* cs) {
+  const float q = rintf(x * 0.636619772367581343f);
+  float r = fmaf(q, -1.5703125f, x);
+  r = fmaf(q, -4.837512969970703125e-4f, r);
+  r = fmaf(q, -7.54978995489188216e-8f, r);
+  const float z = r * r;
+  const float sp = fmaf(fmaf(fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f), z, -1.6666654611e-1f) * z, r, r);
+  const float cp = fmaf(fmaf(fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f), z, 4.166664568298827e-2f), z * z, fmaf(-0.5f, z, 1.0f));
+  const int qi = (int)q;
+  const float s0 = (qi & 1) ? cp : sp, c0 = (qi & 1) ? sp : cp;
+  *sn = (qi & 2) ? -s0 : s0;
+  *cs = ((qi + 1) & 2) ? -c0 : c0;
+}
+
+template <int MODE>
+__device__ __forceinline__ cf32 istft_bin(cf32 c, float m) {
+  if (MODE == 1) {                                          // abs * exp(i angle)   (functionals.py:556)
+    float sn, cs;
+    sincos_cw(c.y, &sn, &cs);
+    return cf32{c.x * cs, c.x * sn};
+  }
+  if (MODE == 2) return cf32{m * c.x, m * c.y};
+  return c;
+}
+
+}  // namespace mmk

@@ -232,6 +232,50 @@ def test_other_fft_sizes_vs_oracle(device, n_fft, hop):
     assert float((got - want).norm() / want.norm()) <= 2e-3
 
 
+@pytest.mark.parametrize("hop", [512, 100, 37, 1500, 2000])
+def test_n_fft_2048_kernels_vs_oracle(device, hop):
+    """n_fft = 2048 (the reference's default) has its own kernels: one real frame = one 1024-point complex transform +
+    an untangling pass.  Ragged hops, short and long clips, every coordinate, both paddings, ISTFT of random spectra for
+    2 .. 40 frames, Griffin-Lim 0 / 2 / 32 iterations.  Tolerances of the n_fft = 1024 tests."""
+    n_fft = 2048
+    gen = torch.Generator().manual_seed(hop)
+    for shape in [(1, 2048), (3, 3 * 2048 + 17), (2, 44100)]:
+        x = torch.randn(*shape, generator=gen)
+        for center in (True, False):
+            for pad_mode in ("constant", "reflect"):
+                want = O.stft_coord(x, n_fft, hop, "car", center=center, pad_mode=pad_mode)
+                got = mmk.STFT(n_fft, hop, "car", center=center, pad_mode=pad_mode)(x.to(device)).cpu()
+                _check_stft(got, want, "car", (shape, center, pad_mode))
+            _check_stft(mmk.STFT(n_fft, hop, "pol", center=center)(x.to(device)).cpu(), O.stft_coord(x, n_fft, hop, "pol", center=center), "pol", shape)
+            m = mmk.MagSpec(n_fft, hop, center=center)(x.to(device)).cpu()
+            want_m = O.magspec(x, n_fft, hop, center)
+            assert m.shape == want_m.shape and float((m - want_m).abs().max()) <= 2e-5 * float(want_m.abs().max())
+    tol = 1e-5 if hop <= 1024 else 5e-5
+    for frames in (2, 3, 9, 40):
+        spec = torch.stack((torch.rand(2, frames, 1025, generator=gen), (torch.rand(2, frames, 1025, generator=gen) * 2 - 1) * np.pi), -1)
+        want = O.istft(spec, n_fft, hop, "pol")
+        got = mmk.ISTFT(n_fft, hop, "pol")(spec.to(device)).cpu()
+        assert got.shape == want.shape
+        assert float((got - want).abs().max()) <= tol * float(want.abs().max())
+        z = torch.randn(2, frames, 1025, 2, generator=gen)
+        want = O.istft(torch.view_as_complex(z), n_fft, hop, "complex")
+        got = native.istft(z.to(device), n_fft, hop, polar=False).cpu()
+        assert float((got - want).abs().max()) <= tol * float(want.abs().max())
+    if hop <= 512:
+        x, gen2 = _gla_signal(n=32768)
+        mag = O.stft_coord(x, n_fft, hop, "mag", center=True)
+        init = torch.rand(mag.shape, dtype=torch.complex64, generator=gen2)
+        for n_iter, bar in ((0, 2e-6), (2, 2e-5), (32, 2e-3)):
+            want = O.griffin_lim(mag, n_fft, hop, n_iter, 0.99, init)
+            got = native.griffin_lim(mag.to(device), n_fft, hop, n_iter, 0.99, init.to(device)).cpu()
+            assert got.shape == want.shape
+            assert float((got - want).norm() / want.norm()) <= bar, n_iter
+        if hop == 512:                                                  # rand_init=False: ill-conditioned, see the n_fft = 1024 test
+            want1 = O.griffin_lim(mag, n_fft, hop, 1, 0.99, None)
+            got1 = native.griffin_lim(mag.to(device), n_fft, hop, 1, 0.99, None).cpu()
+            assert float((got1 - want1).norm() / want1.norm()) <= 2e-3
+
+
 def test_istft_full_size_round_trip(device):
     """cfg-5 sized: 64 clips x 30 s at 22.05 kHz, n_fft 1024 / hop 256; STFT -> ISTFT is the identity"""
     gen = torch.Generator(device=device).manual_seed(3)
@@ -249,6 +293,11 @@ def test_istft_errors(device):
         mmk.ISTFT(1024, 256, "pol")(torch.zeros(1, 1, 513, 2, device=device))      # one frame: nothing left after the trim
     with pytest.raises(ValueError):
         mmk.ISTFT(1024, 1024, "pol")(torch.zeros(1, 4, 513, 2, device=device))     # torch: window overlap-add is zero
+    for n_fft, hop in ((2048, 2047), (4096, 4095)):                                # ... and where it falls below torch's 1e-11
+        with pytest.raises(ValueError):
+            mmk.ISTFT(n_fft, hop, "pol")(torch.zeros(1, 4, n_fft // 2 + 1, 2, device=device))
+        with pytest.raises(RuntimeError):
+            O.istft(torch.zeros(1, 4, n_fft // 2 + 1, 2), n_fft, hop, "pol")
     with pytest.raises(RuntimeError):
         mmk.ISTFT(1024, 256, "mag")(torch.zeros(1, 4, 513, device=device))
     with pytest.raises(RuntimeError):

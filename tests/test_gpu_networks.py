@@ -152,7 +152,7 @@ def test_wavenet_sampling_matches_oracle_given_uniforms(device):
 
 
 def test_wavenet_unsupported_options_fail_loudly(device):
-    net = mmk.WaveNet.from_config(mmk.WaveNet.Config(io_spec=H.mu_emb(), blocks=(2,), dims_dilated=(8,), pad_side=1)).to(device).eval()
+    net = mmk.WaveNet.from_config(mmk.WaveNet.Config(io_spec=H.mu_emb(), blocks=(2,), dims_dilated=(8,), layerwise_inputs=True)).to(device).eval()
     with pytest.raises(NotImplementedError):
         net.before_generate((torch.zeros(1, 8, dtype=torch.int64, device=device),), 0)
 
