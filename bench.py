@@ -409,9 +409,15 @@ class FeatureJob:
             nbytes = frames * (it * (20 * 513 + 2 * 4 * 256) + 12 * 513 + 4 * 256)
             kernel = "Griffin-Lim chain: istft1024_kernel + 32 x gla1024_iter_kernel (stft -> phase update -> istft per launch)"
         achieved = nbytes / (us * 1e-6) / 1e9
+        traffic = None
+        try:  # PMC-derived HBM bytes per launch of this workload's shapes (separate rocprofv3 --pmc passes, profiles/)
+            with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+                traffic = json.load(f).get(self.name, {}).get("launch", {}).get("bytes")
+        except (OSError, ValueError):
+            pass
         return {"bound": "hbm", "kernel": kernel,
                 "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-                "traffic": None, "algorithmic_bytes_per_launch": nbytes, "avg_launch_us": round(us, 2)}
+                "traffic": traffic, "algorithmic_bytes_per_launch": nbytes, "avg_launch_us": round(us, 2)}
 
     def cpu_baseline(self, budget_s):
         from oracle import torch_ref as O
