@@ -19,9 +19,15 @@ struct SrnnGruArgs {
   float* h_ring; int64_t h_slot_stride;     // [2][B][H]: slot (cnt & 1) is read, slot ((cnt + 1) & 1) written
   int64_t* cnt; unsigned* done;             // update counter of the tier, finish ticket
   unsigned long long* stamps;               // diagnostic: phase totals (100 MHz ticks) + launch count, or nullptr
+  // optional second phase: the tier's up-sampler, out[b][n] = W_up[n] . h_new[b] + bias[n]  (n < 16 ups_n_tiles),
+  // behind a grid-wide barrier (the launcher only sets it when every workgroup of the grid is resident at once)
+  const float* ups_wp; const float* ups_bias; int32_t ups_n_tiles; int32_t ups_n;
+  float* ups_out; int64_t ups_out_ld;
+  int* err;                                 // sticky error word (a barrier that timed out), or nullptr
 };
 
 bool srnn_gru_supported(int H, int fs, bool lstm);
+bool srnn_gru_grid_resident(int H, int B);
 int launch_srnn_gru(const SrnnGruArgs& a, hipStream_t stream);
 
 }  // namespace mmk

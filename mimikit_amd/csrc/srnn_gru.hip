@@ -155,6 +155,13 @@ __global__ __launch_bounds__(kGruThreads) void srnn_gru_kernel(const SrnnGruArgs
   }
   __syncthreads();
   stamp(2);   // MFMAs (incl. the wait for the weights)
+  // the new state: plain stores, or - when the up-sampler phase of this launch reads it from other XCDs - write-through
+  // agent-scope stores (sc1), so that no L2 write-back / invalidate (a fence costs ~10 us here) is needed
+  const bool fused_up = a.ups_wp != nullptr;
+  auto store_state = [&](float* dst, float v) {
+    if (fused_up) __hip_atomic_store(dst, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else *dst = v;
+  };
   // ---- cell: one (clip, unit) pair per thread -----------------------------------------------------------------
   if (tid < 256) {
     const int m = tid >> 4, n = tid & 15;
@@ -179,7 +186,7 @@ __global__ __launch_bounds__(kGruThreads) void srnn_gru_kernel(const SrnnGruArgs
         const float ig = sigmoidf_(gt[0]), fg = sigmoidf_(gt[1]), cg = tanhf(gt[2]), og = sigmoidf_(gt[3]);
         const float cn = fg * a.c[o] + ig * cg;
         a.c[o] = cn;
-        h_new[o] = og * tanhf(cn);
+        store_state(h_new + o, og * tanhf(cn));
       } else {
         const float gi_r = s[0] + (a.wih_bias ? a.wih_bias[unit] : 0.f);
         const float gi_z = s[1] + (a.wih_bias ? a.wih_bias[H + unit] : 0.f);
@@ -191,7 +198,7 @@ __global__ __launch_bounds__(kGruThreads) void srnn_gru_kernel(const SrnnGruArgs
         const float z = sigmoidf_(gh_z + gi_z);
         const float nn = tanhf(gi_n + gh_n * r);
         const float hp = hs[m * ldx + unit];
-        h_new[o] = (hp - nn) * z + nn;
+        store_state(h_new + o, (hp - nn) * z + nn);
       }
     }
   }
@@ -202,19 +209,128 @@ __global__ __launch_bounds__(kGruThreads) void srnn_gru_kernel(const SrnnGruArgs
     for (int i = 0; i < 4; ++i) a.stamps[i] += st_acc[i];
     a.stamps[7] += 1;
   }
+  if (fused_up) {
+    __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0): this wave's rows of the new state have been written through
+    __syncthreads();
+  }
   if (tid == 0) {
-    __threadfence();
+    if (!fused_up) __threadfence();
     const unsigned ticket = atomicAdd(a.done, 1u);
     if (ticket == gridDim.x - 1) {
       *a.done = 0;
-      __threadfence();
-      *a.cnt = cnt + 1;
+      if (!fused_up) __threadfence();
+      __hip_atomic_store(a.cnt, cnt + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+  if (!fused_up) return;
+  // ---- grid-wide barrier: the update counter moves when the last workgroup has published its rows --------------------
+  int* s_flag = reinterpret_cast<int*>(s_lin);
+  if (tid == 0) {
+    unsigned spins = 0;
+    int ok = 1;
+    while (__hip_atomic_load(a.cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != cnt + 1) {
+      if (++spins > (1u << 22)) { ok = 0; break; }                 // ~1 s: a workgroup of the grid never became resident
+      __builtin_amdgcn_s_sleep(2);
+    }
+    *s_flag = ok;
+  }
+  __syncthreads();
+  if (!*s_flag) {
+    if (tid == 0 && a.err) atomicExch(a.err, 3);
+    return;
+  }
+  // ---- up-sampler: 16-column tiles of W_up over the workgroups, all clips, K split over the waves ----------------------
+  {
+    const int c0 = wave * CPW;
+    f32x4* red4 = red;                                            // [row block][wave][lane], 4 row blocks at a time
+    for (int tile = blockIdx.x; tile < a.ups_n_tiles; tile += gridDim.x) {
+      f32x4 wu[CPW];
+      gf32x4_ptr wsrc = (gf32x4_ptr)(uintptr_t)a.ups_wp + ((int64_t)tile * KC + c0) * 64 + lane;
+#pragma unroll
+      for (int u = 0; u < CPW; ++u) wu[u] = wsrc[u * 64];
+      for (int r0 = 0; r0 < a.B; r0 += 64) {
+        // agent-scope loads (sc1): the rows come from the other XCDs' workgroups.  Loads AND the wait sit in one asm
+        // statement: the compiler does not know these are loads and would otherwise be free to copy the destination
+        // registers before the data has arrived.
+        f32x4 hv[4][CPW];
+        const float* hr[4];
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb) {
+          const int m = r0 + rb * 16 + (lane & 15);
+          hr[rb] = h_new + (int64_t)(m < a.B ? m : a.B - 1) * H + c0 * 16 + 4 * (lane >> 4);   // clamped, unconditional
+        }
+#define MMK_LD(rb_, u_, d_, p_) "global_load_dwordx4 %" #d_ ", %" #p_ ", off offset:" #u_ " sc1\n\t"
+        if constexpr (CPW == 1) {
+          asm volatile(MMK_LD(0, 0, 0, 4) MMK_LD(1, 0, 1, 5) MMK_LD(2, 0, 2, 6) MMK_LD(3, 0, 3, 7) "s_waitcnt vmcnt(0)"
+                       : "=&v"(hv[0][0]), "=&v"(hv[1][0]), "=&v"(hv[2][0]), "=&v"(hv[3][0])
+                       : "v"(hr[0]), "v"(hr[1]), "v"(hr[2]), "v"(hr[3])
+                       : "memory");
+        } else if constexpr (CPW == 2) {
+          asm volatile(MMK_LD(0, 0, 0, 8) MMK_LD(0, 64, 1, 8) MMK_LD(1, 0, 2, 9) MMK_LD(1, 64, 3, 9)
+                       MMK_LD(2, 0, 4, 10) MMK_LD(2, 64, 5, 10) MMK_LD(3, 0, 6, 11) MMK_LD(3, 64, 7, 11) "s_waitcnt vmcnt(0)"
+                       : "=&v"(hv[0][0]), "=&v"(hv[0][1]), "=&v"(hv[1][0]), "=&v"(hv[1][1]), "=&v"(hv[2][0]), "=&v"(hv[2][1]),
+                         "=&v"(hv[3][0]), "=&v"(hv[3][1])
+                       : "v"(hr[0]), "v"(hr[1]), "v"(hr[2]), "v"(hr[3])
+                       : "memory");
+        } else {
+          static_assert(CPW == 4, "H in {128, 256, 512}");
+          asm volatile(MMK_LD(0, 0, 0, 16) MMK_LD(0, 64, 1, 16) MMK_LD(0, 128, 2, 16) MMK_LD(0, 192, 3, 16)
+                       MMK_LD(1, 0, 4, 17) MMK_LD(1, 64, 5, 17) MMK_LD(1, 128, 6, 17) MMK_LD(1, 192, 7, 17)
+                       MMK_LD(2, 0, 8, 18) MMK_LD(2, 64, 9, 18) MMK_LD(2, 128, 10, 18) MMK_LD(2, 192, 11, 18)
+                       MMK_LD(3, 0, 12, 19) MMK_LD(3, 64, 13, 19) MMK_LD(3, 128, 14, 19) MMK_LD(3, 192, 15, 19) "s_waitcnt vmcnt(0)"
+                       : "=&v"(hv[0][0]), "=&v"(hv[0][1]), "=&v"(hv[0][2]), "=&v"(hv[0][3]), "=&v"(hv[1][0]), "=&v"(hv[1][1]),
+                         "=&v"(hv[1][2]), "=&v"(hv[1][3]), "=&v"(hv[2][0]), "=&v"(hv[2][1]), "=&v"(hv[2][2]), "=&v"(hv[2][3]),
+                         "=&v"(hv[3][0]), "=&v"(hv[3][1]), "=&v"(hv[3][2]), "=&v"(hv[3][3])
+                       : "v"(hr[0]), "v"(hr[1]), "v"(hr[2]), "v"(hr[3])
+                       : "memory");
+        }
+#undef MMK_LD
+        f32x4 acc[4];
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb) acc[rb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int u = 0; u < CPW; ++u) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+#pragma unroll
+            for (int rb = 0; rb < 4; ++rb) acc[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(hv[rb][u][i], wu[u][i], acc[rb], 0, 0, 0);
+          }
+        }
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb) red4[(rb * kGruWaves + wave) * 64 + lane] = acc[rb];
+        __syncthreads();
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {                    // 64 rows x 16 columns: two outputs per thread
+          const int m = (tid >> 4) + 32 * half, n = tid & 15;
+          const int rb = m >> 4, r = m & 15;
+          const int frag = ((r >> 2) * 16 + n) * 4 + (r & 3);     // (row r, col n) of a 16x16 accumulator image
+          const float* f = reinterpret_cast<const float*>(red4 + rb * kGruWaves * 64) + frag;
+          float v = 0.f;
+#pragma unroll
+          for (int wv = 0; wv < kGruWaves; ++wv) v += f[wv * 256];
+          const int col = tile * 16 + n;
+          if (r0 + m < a.B && col < a.ups_n)
+            a.ups_out[(int64_t)(r0 + m) * a.ups_out_ld + col] = v + (a.ups_bias ? a.ups_bias[col] : 0.f);
+        }
+        __syncthreads();
+      }
     }
   }
 }
 
 size_t srnn_gru_lds_bytes(int H, int fs, bool lstm) {
   return (size_t)2 * 16 * (H + 4) * 4 + (size_t)(lstm ? 8 : 6) * kGruWaves * 64 * 16 + (size_t)16 * (((fs + 15) / 16) * 16 + 4) * 4;
+}
+
+// the fused up-sampler phase waits for every workgroup of the grid: they must all be resident (one 512-thread workgroup
+// with > 80 KB of LDS per CU)
+bool srnn_gru_grid_resident(int H, int B) {
+  static const int n_cu = [] {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+    return n;
+  }();
+  return (H / 16) * ((B + 15) / 16) <= n_cu;
 }
 
 bool srnn_gru_supported(int H, int fs, bool lstm) {
@@ -227,6 +343,7 @@ int launch_srnn_gru(const SrnnGruArgs& a, hipStream_t stream) {
   if (!srnn_gru_supported(a.H, a.fs, lstm)) return fail(MMK_ERR_UNSUPPORTED, "srnn tier kernel: geometry H=%d fs=%d", a.H, a.fs);
   const size_t lds = srnn_gru_lds_bytes(a.H, a.fs, lstm);
   dim3 grid((a.H / 16) * ((a.B + 15) / 16)), block(kGruThreads);
+  if (a.ups_wp && !srnn_gru_grid_resident(a.H, a.B)) return fail(MMK_ERR_INVALID, "srnn tier kernel: fused up-sampler on a grid that is not resident at once");
 #define MMK_GRU(KC_)                                                                                    \
   do {                                                                                                  \
     if (lstm) hipLaunchKernelGGL((srnn_gru_kernel<KC_, true>), grid, block, lds, stream, a);            \

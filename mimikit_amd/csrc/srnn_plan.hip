@@ -172,6 +172,16 @@ extern "C" size_t mmk_srnn_workspace_bytes(const mmk_srnn_plan* p) {
 extern "C" int mmk_srnn_reset(mmk_srnn_plan* p, mmk_stream_t stream) {
   if (!p || !p->committed) return fail(MMK_ERR_STATE, "srnn_reset: plan not committed");
   hipStream_t st = (hipStream_t)stream;
+  {   // a grid barrier of the fused tier kernel that timed out during the previous generation (never seen: the launcher
+      // only fuses when the grid is resident at once) would have left wrong samples behind - say so instead of hiding it
+    int64_t err = 0;
+    MMK_HIP(hipMemcpyAsync(&err, p->tau + 4, sizeof(err), hipMemcpyDeviceToHost, st));
+    MMK_HIP(hipStreamSynchronize(st));
+    if (err != 0) {
+      MMK_HIP(hipMemsetAsync(p->tau + 4, 0, sizeof(int64_t), st));
+      return fail(MMK_ERR_STATE, "srnn: a grid barrier of the tier kernel timed out during the previous generation (code %lld)", (long long)err);
+    }
+  }
   for (auto& t : p->tiers) {
     // h0_init zeros / ones (SampleRNNTier._init_h0, sample_rnn_v2.py:118-119)
     MMK_TRY(launch_fill(t.h, p->cfg.h0_ones ? 1.f : 0.f, (int64_t)2 * p->Bmax * p->H, st));
@@ -249,6 +259,7 @@ extern "C" int mmk_srnn_commit(mmk_srnn_plan* p, void* workspace, size_t workspa
   }
   if (!b.missing().empty()) return fail(MMK_ERR_KEY, "srnn_commit: state_dict tensor %s", b.missing().c_str());
   if (!p->cap_stream) MMK_HIP(hipStreamCreateWithFlags(&p->cap_stream, hipStreamNonBlocking));
+  MMK_HIP(hipMemsetAsync(p->tau, 0, 32 * sizeof(int64_t), st));     // position counter, error word, diagnostic stamps
   p->committed = true;
   return mmk_srnn_reset(p, stream);
 }
@@ -286,7 +297,17 @@ static int emit_step(mmk_srnn_plan* p, const SrnnCall& call, int64_t tau_off, in
         const char* senv = getenv("MMK_SRNN_STAMPS");
         g.stamps = (senv && senv[0] == '1') ? reinterpret_cast<unsigned long long*>(p->tau + 16) : nullptr;
       }
+      // the up-sampler rides in the same launch behind a grid-wide barrier when the whole grid is resident at once
+      // (MMK_SRNN_FUSED_UP=0: its own launch)
+      const char* fuenv = getenv("MMK_SRNN_FUSED_UP");
+      const bool fused_up = !(fuenv && fuenv[0] == '0') && srnn_gru_grid_resident(H, M);
+      if (fused_up) {
+        g.ups_wp = t.up_lin.Wp; g.ups_bias = t.up_lin.bias; g.ups_n_tiles = t.up_lin.n_tiles; g.ups_n = t.up_lin.N;
+        g.ups_out = t.out; g.ups_out_ld = (int64_t)t.up * H;
+        g.err = reinterpret_cast<int*>(p->tau + 4);      // sticky word, read by the next mmk_srnn_reset
+      }
       MMK_TRY(launch_srnn_gru(g, st));
+      if (fused_up) continue;
       // up-sampler on the slot the kernel has just published: its position counter is the tier's update counter
       LinearArgs a = {};
       t.up_lin.fill(a);

@@ -215,12 +215,15 @@ def test_sample_rnn_loop_with_temperature(device):
 
 
 @pytest.mark.parametrize("fused,frame_sizes,batch,kind", [("1", (16, 4, 1), 64, "gru"), ("0", (16, 4, 1), 64, "gru"),
-                                                          ("1", (8, 4, 2), 6, "gru"), ("1", (16, 4, 1), 21, "lstm")])
+                                                          ("1", (8, 4, 2), 6, "gru"), ("1", (16, 4, 1), 21, "lstm"),
+                                                          ("1u", (16, 4, 1), 64, "gru"), ("1u", (16, 4, 1), 37, "lstm")])
 def test_sample_rnn_cfg3_shape_vs_oracle(device, monkeypatch, fused, frame_sizes, batch, kind):
     """BASELINE config 3 geometry (frame sizes 16/4/1, GRU) at hidden 128, batch 64, prompt with P % rf != 0; with the
     fused bottom-tier kernel (several steps per launch) and with one launch per op; bottom frames of 2 samples, ragged
-    last workgroup; LSTM tiers (the reference's default) through the fused tier kernel"""
-    monkeypatch.setenv("MMK_SRNN_FUSED", fused)
+    last workgroup; LSTM tiers (the reference's default) through the fused tier kernel; "1u": the fused tier kernel with
+    the up-sampler as its own launch instead of behind the kernel's grid barrier"""
+    monkeypatch.setenv("MMK_SRNN_FUSED", fused[0])
+    monkeypatch.setenv("MMK_SRNN_FUSED_UP", "0" if fused.endswith("u") else "1")
     net, sd, arch = H.srnn("big", hidden=128, mlp_dim=128, seed=77, frame_sizes=frame_sizes, kind=kind)
     gen = torch.Generator().manual_seed(8)
     prompt = torch.randint(0, 256, (batch, frame_sizes[0] * 5 + 7), generator=gen)
@@ -233,6 +236,27 @@ def test_sample_rnn_cfg3_shape_vs_oracle(device, monkeypatch, fused, frame_sizes
     same = got[:, prompt.size(1):] == want[:, prompt.size(1):]
     assert bool((same | first_bad).all())
     assert float(ok.float().mean()) > 0.9
+
+
+def test_sample_rnn_grid_barrier_is_deterministic(device, monkeypatch):
+    """the up-sampler phase of the tier kernel reads rows that workgroups on other XCDs have just written (write-through
+    stores, agent-scope loads, one grid-wide barrier): H = 512, 64 clips, the same generation five times, bit-identical,
+    and identical to the path with the up-sampler as a separate launch"""
+    monkeypatch.setenv("MMK_SRNN_FUSED", "1")
+    gen = torch.Generator().manual_seed(12)
+    prompt = torch.randint(0, 256, (64, 64), generator=gen).to(device)
+    outs = []
+    for fused_up in ("1", "1", "1", "1", "1", "0"):
+        monkeypatch.setenv("MMK_SRNN_FUSED_UP", fused_up)
+        net, _, _ = H.srnn("big", hidden=512, mlp_dim=128, seed=79, frame_sizes=(16, 4, 1), kind="gru")
+        net = net.to(device)
+        idx = torch.cat([prompt, torch.zeros(64, 320, dtype=torch.int64, device=device)], 1)
+        net.before_generate((prompt,), None)
+        net.generate_block((idx,), 64, 320)
+        net.after_generate((idx,), None)
+        outs.append(idx.cpu())
+    for o in outs[1:]:
+        assert torch.equal(o, outs[0])
 
 
 def test_sample_rnn_fused_bottom_sampled_decode(device, monkeypatch):
