@@ -262,6 +262,8 @@ typedef struct mmk_s2s_config {
   int32_t enc_n_lstm, dec_n_lstm;          /* coverage: 1 + 1 */
   int32_t out_abs;                         /* output activation Abs */
   int32_t max_batch;
+  int32_t enc_downsampling;                /* 0 edge_sum, 1 edge_mean, 2 sum, 3 mean  (s2s_lstm_v2.py:105-113) */
+  int32_t dec_upsampling;                  /* 0 linear_resample, 1 repeat             (:158-163) */
 } mmk_s2s_config;
 
 typedef struct mmk_s2s_plan mmk_s2s_plan;

@@ -48,19 +48,39 @@ __global__ void pair_sum_kernel(const float* __restrict__ of, const float* __res
   for (int c = threadIdx.x; c < D; c += blockDim.x) out[(int64_t)r * D + c] = cat_at(f, b, D, 2 * c) + cat_at(f, b, D, 2 * c + 1);
 }
 
-// edge_sum: unfold(1, hop, hop)[..., [0, -1]].sum(-1) of the pair-summed output   (:108-112)
-__global__ void edge_pair_sum_kernel(const float* __restrict__ of, const float* __restrict__ ob, int D, int hop,
+// the encoder's pooling over the hop frames of the pair-summed output  (:105-113):  unfold(1, hop, hop), then
+//   mode 0 edge_sum: first + last      1 edge_mean: (first + last) / 2      2 sum: all frames      3 mean: sum / hop
+__global__ void pool_pair_sum_kernel(const float* __restrict__ of, const float* __restrict__ ob, int D, int hop, int mode,
                                      float* __restrict__ out) {
   const int bidx = blockIdx.x;
-  const float* f0 = of + (int64_t)(bidx * hop) * D;
-  const float* b0 = ob + (int64_t)(bidx * hop) * D;
-  const float* f1 = of + (int64_t)(bidx * hop + hop - 1) * D;
-  const float* b1 = ob + (int64_t)(bidx * hop + hop - 1) * D;
   for (int c = threadIdx.x; c < D; c += blockDim.x) {
-    const float first = cat_at(f0, b0, D, 2 * c) + cat_at(f0, b0, D, 2 * c + 1);
-    const float last = cat_at(f1, b1, D, 2 * c) + cat_at(f1, b1, D, 2 * c + 1);
-    out[(int64_t)bidx * D + c] = first + last;
+    float v = 0.f;
+    if (mode < 2) {
+      const float* f0 = of + (int64_t)(bidx * hop) * D;
+      const float* b0 = ob + (int64_t)(bidx * hop) * D;
+      const float* f1 = of + (int64_t)(bidx * hop + hop - 1) * D;
+      const float* b1 = ob + (int64_t)(bidx * hop + hop - 1) * D;
+      const float first = cat_at(f0, b0, D, 2 * c) + cat_at(f0, b0, D, 2 * c + 1);
+      const float last = cat_at(f1, b1, D, 2 * c) + cat_at(f1, b1, D, 2 * c + 1);
+      v = first + last;
+      if (mode == 1) v *= 0.5f;
+    } else {
+      for (int t = 0; t < hop; ++t) {
+        const float* f = of + (int64_t)(bidx * hop + t) * D;
+        const float* b = ob + (int64_t)(bidx * hop + t) * D;
+        v += cat_at(f, b, D, 2 * c) + cat_at(f, b, D, 2 * c + 1);
+      }
+      if (mode == 3) v /= (float)hop;
+    }
+    out[(int64_t)bidx * D + c] = v;
   }
+}
+
+// dec_upsampling="repeat": x.repeat_interleave(hop, 1)   (:161)
+__global__ void repeat_rows_kernel(const float* __restrict__ x, int D, int hop, float* __restrict__ out) {
+  const int row = blockIdx.x;                       // b * hop + t
+  const float* src = x + (int64_t)(row / hop) * D;
+  for (int c = threadIdx.x; c < D; c += blockDim.x) out[(int64_t)row * D + c] = src[c];
 }
 
 }  // namespace
@@ -109,6 +129,8 @@ static int derive(mmk_s2s_plan* p) {
   const mmk_s2s_config& c = p->cfg;
   if (c.in_dim < 1 || c.out_dim < 1 || c.model_dim < 1 || c.hop < 1 || c.max_batch < 1) return fail(MMK_ERR_INVALID, "s2s: bad dimensions");
   if (c.enc_n_lstm != 1 || c.dec_n_lstm != 1) return fail(MMK_ERR_UNSUPPORTED, "s2s: only enc_n_lstm = dec_n_lstm = 1 is covered");
+  if (c.enc_downsampling < 0 || c.enc_downsampling > 3 || c.dec_upsampling < 0 || c.dec_upsampling > 1)
+    return fail(MMK_ERR_UNSUPPORTED, "s2s: enc_downsampling %d / dec_upsampling %d are not covered", c.enc_downsampling, c.dec_upsampling);
   if (c.model_dim % 2 != 0) return fail(MMK_ERR_UNSUPPORTED, "s2s: model_dim must be even");
   p->D = c.model_dim;
   p->hop = c.hop;
@@ -193,9 +215,11 @@ extern "C" int mmk_s2s_commit(mmk_s2s_plan* p, void* workspace, size_t workspace
   MMK_TRY(pack_lstm(p, p->dec, "dec.lstm.0.", D, st));
   if (const float* w = b.need("enc.fc_out.weight", (int64_t)D * D))
     MMK_TRY(pack_rect(p->fc_out.Wp, p->fc_out.k_chunks, 0, 1, D, 0, D, w, D, 1, st));
-  if (const float* w = b.need("dec.fc.fc.weight", (int64_t)p->hop * D * D))
-    MMK_TRY(pack_rect(p->dec_fc.Wp, p->dec_fc.k_chunks, 0, 1, p->hop * D, 0, D, w, D, 1, st));
-  if (const float* bb = b.need("dec.fc.fc.bias", (int64_t)p->hop * D)) MMK_TRY(pack_bias(p->dec_fc.bias, 0, 1, p->hop * D, bb, 0, st));
+  if (c.dec_upsampling == 0) {   // "repeat" has no up-sampling weights
+    if (const float* w = b.need("dec.fc.fc.weight", (int64_t)p->hop * D * D))
+      MMK_TRY(pack_rect(p->dec_fc.Wp, p->dec_fc.k_chunks, 0, 1, p->hop * D, 0, D, w, D, 1, st));
+    if (const float* bb = b.need("dec.fc.fc.bias", (int64_t)p->hop * D)) MMK_TRY(pack_bias(p->dec_fc.bias, 0, 1, p->hop * D, bb, 0, st));
+  }
   if (const float* w = b.need("output_module.heads.0.0.weight", (int64_t)c.out_dim * D))
     MMK_TRY(pack_rect(p->out_lin.Wp, p->out_lin.k_chunks, 0, 1, c.out_dim, 0, D, w, D, 1, st));
   if (const float* bb = b.need("output_module.heads.0.0.bias", c.out_dim)) MMK_TRY(pack_bias(p->out_lin.bias, 0, 1, c.out_dim, bb, 0, st));
@@ -279,11 +303,16 @@ static int s2s_step(mmk_s2s_plan* p, int M, const float* x, int64_t xbs, int64_t
   MMK_HIP(hipGetLastError());
   // encoder
   MMK_TRY(run_bilstm(p, p->enc, p->xin, p->in_pad, M, true, st));
-  hipLaunchKernelGGL(edge_pair_sum_kernel, dim3(M), dim3(256), 0, st, p->of, p->ob, D, hop, p->es);
+  hipLaunchKernelGGL(pool_pair_sum_kernel, dim3(M), dim3(256), 0, st, p->of, p->ob, D, hop, c.enc_downsampling, p->es);
   MMK_HIP(hipGetLastError());
   MMK_TRY(plain_linear(p->fc_out, p->es, D, M, p->coded, D, ACT_NONE, st));
   // decoder: LinearResampler to hop frames, bi-LSTM seeded with the encoder's (h_n, c_n)  (:158-171)
-  MMK_TRY(plain_linear(p->dec_fc, p->coded, D, M, p->z, (int64_t)hop * D, ACT_NONE, st));
+  if (c.dec_upsampling == 0) {
+    MMK_TRY(plain_linear(p->dec_fc, p->coded, D, M, p->z, (int64_t)hop * D, ACT_NONE, st));
+  } else {
+    hipLaunchKernelGGL(repeat_rows_kernel, dim3(rows), dim3(256), 0, st, p->coded, D, hop, p->z);
+    MMK_HIP(hipGetLastError());
+  }
   MMK_TRY(run_bilstm(p, p->dec, p->z, D, M, false, st));
   hipLaunchKernelGGL(pair_sum_kernel, dim3(rows), dim3(256), 0, st, p->of, p->ob, D, rows, p->ysum);
   MMK_HIP(hipGetLastError());

@@ -200,9 +200,11 @@ class Seq2SeqLSTMNetwork(ARMWithHidden, nn.Module):
         unsupported = []
         if self.input_module is not sum:
             unsupported.append("discrete inputs (input module other than a plain sum)")
-        if str(cfg.enc_downsampling) != "edge_sum":
+        pooling = {"edge_sum": 0, "edge_mean": 1, "sum": 2, "mean": 3}
+        upsampling = {"linear_resample": 0, "repeat": 1}
+        if str(cfg.enc_downsampling) not in pooling:
             unsupported.append(f"enc_downsampling='{cfg.enc_downsampling}'")
-        if str(cfg.dec_upsampling) != "linear_resample":
+        if str(cfg.dec_upsampling) not in upsampling:
             unsupported.append(f"dec_upsampling='{cfg.dec_upsampling}'")
         if cfg.enc_n_lstm != 1 or cfg.dec_n_lstm != 1:
             unsupported.append("more than one LSTM per side")
@@ -226,6 +228,7 @@ class Seq2SeqLSTMNetwork(ARMWithHidden, nn.Module):
         c.in_dim = self.enc.input_dim
         c.model_dim, c.hop = cfg.model_dim, cfg.hop
         c.enc_n_lstm, c.dec_n_lstm = cfg.enc_n_lstm, cfg.dec_n_lstm
+        c.enc_downsampling, c.dec_upsampling = pooling[str(cfg.enc_downsampling)], upsampling[str(cfg.dec_upsampling)]
         c.max_batch = max_batch
         return c
 

@@ -401,15 +401,22 @@ def _bilstm(sd: SD, p: str, x: torch.Tensor, state=None):
     return torch.cat(outs, -1), (torch.stack(hs), torch.stack(cs))
 
 
-def s2s_step(sd: SD, x: torch.Tensor, hop: int, out_abs: bool = True) -> torch.Tensor:
-    """Seq2SeqLSTMNetwork.forward (s2s_lstm_v2.py:246-253) for the class defaults:
-    EncoderLSTM.forward edge_sum (:93-113), DecoderLSTM.forward linear_resample (:155-179)"""
+def s2s_step(sd: SD, x: torch.Tensor, hop: int, out_abs: bool = True, downsampling: str = "edge_sum",
+             upsampling: str = "linear_resample") -> torch.Tensor:
+    """Seq2SeqLSTMNetwork.forward (s2s_lstm_v2.py:246-253): EncoderLSTM.forward with the edge_sum / edge_mean / sum / mean
+    poolings (:93-113), DecoderLSTM.forward with linear_resample or repeat (:155-179)"""
     D = sd["enc.fc_out.weight"].shape[0]
     y, hidden = _bilstm(sd, "enc.lstm.0.", x)
     y = y.view(*y.shape[:-1], D, 2).sum(-1)
-    y = y.unfold(1, hop, hop)[..., [0, -1]].sum(-1)
+    y = y.unfold(1, hop, hop)
+    if "edge" in downsampling:
+        y = y[..., [0, -1]]
+    y = y.sum(-1) if "sum" in downsampling else y.mean(-1)
     coded = F.linear(y, sd["enc.fc_out.weight"])
-    z = F.linear(coded, sd["dec.fc.fc.weight"], sd["dec.fc.fc.bias"]).reshape(x.size(0), hop, D)
+    if upsampling == "linear_resample":
+        z = F.linear(coded, sd["dec.fc.fc.weight"], sd["dec.fc.fc.bias"]).reshape(x.size(0), hop, D)
+    else:
+        z = coded.repeat_interleave(hop, 1)
     y, _ = _bilstm(sd, "dec.lstm.0.", z, hidden)
     y = y.view(*y.shape[:-1], D, 2).sum(-1)
     out = F.linear(y, sd["output_module.heads.0.0.weight"], sd["output_module.heads.0.0.bias"])

@@ -267,6 +267,20 @@ def make_s2s():
     save("s2s.npz", x=x, y=y, prompt=prompt, out=out[0])
 
 
+def make_s2s_variants():
+    """the other encoder poolings and the 'repeat' decoder up-sampling (s2s_lstm_v2.py:105-113, :158-163)"""
+    g = torch.Generator().manual_seed(33)
+    io = ref.IOSpec.magspec_io(ref.IOSpec.MagSpecIOConfig(n_fft=128, hop_length=32))
+    x = torch.rand(3, 4, 65, generator=g)
+    arrays = {"x": x}
+    for ds, us in (("edge_mean", "linear_resample"), ("sum", "linear_resample"), ("mean", "repeat"), ("edge_sum", "repeat")):
+        cfg = ref.Seq2SeqLSTMNetwork.Config(io_spec=io, model_dim=32, hop=4, enc_downsampling=ds, dec_upsampling=us)
+        net = ref.Seq2SeqLSTMNetwork.from_config(cfg).eval()
+        load_recipe(net, seed=41, gain=1.5)
+        arrays[f"y_{ds}_{us}"] = net.generate_step((x,), t=4)
+    save("s2s_variants.npz", **arrays)
+
+
 def make_sampler():
     g = torch.Generator().manual_seed(51)
     logits = torch.randn(6, 1, 256, generator=g) * 3
@@ -347,5 +361,6 @@ if __name__ == "__main__":
     make_srnn()
     make_srnn_weight_norm()
     make_s2s()
+    make_s2s_variants()
     make_sampler()
     make_keys()

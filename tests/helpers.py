@@ -89,9 +89,13 @@ def srnn(tag, hidden=32, mlp_dim=32, seed=None, frame_sizes=None, kind=None, wei
     return net.eval(), sd, dict(frame_sizes=fs, hidden_dim=hidden, rnn_class=k)
 
 
-def s2s_tiny():
+S2S_VARIANTS = (("edge_mean", "linear_resample"), ("sum", "linear_resample"), ("mean", "repeat"), ("edge_sum", "repeat"))
+
+
+def s2s_tiny(downsampling="edge_sum", upsampling="linear_resample"):
     io = mmk.IOSpec.magspec_io(mmk.IOSpec.MagSpecIOConfig(n_fft=128, hop_length=32))
-    net = mmk.Seq2SeqLSTMNetwork.from_config(mmk.Seq2SeqLSTMNetwork.Config(io_spec=io, model_dim=32, hop=4))
+    net = mmk.Seq2SeqLSTMNetwork.from_config(mmk.Seq2SeqLSTMNetwork.Config(io_spec=io, model_dim=32, hop=4,
+                                                                           enc_downsampling=downsampling, dec_upsampling=upsampling))
     sd = load_recipe(net, seed=41, gain=1.5)
     return net.eval(), sd
 

@@ -297,6 +297,22 @@ def test_seq2seq_matches_reference_golden(device):
     assert bool((out[0][:, -10:] != 0).all())                 # tests/test_seq2seq.py:146
 
 
+@pytest.mark.parametrize("ds,us", H.S2S_VARIANTS)
+def test_seq2seq_pooling_and_upsampling_variants(device, ds, us):
+    """enc_downsampling edge_mean / sum / mean and dec_upsampling repeat (no up-sampling weights): golden from the
+    reference, and a larger batch against the oracle; fp32 tolerance 1e-4 of the largest output"""
+    g = H.golden("s2s_variants.npz")
+    net, sd = H.s2s_tiny(ds, us)
+    net.to(device)
+    y = net.generate_step((H.T(g["x"]).to(device),), t=4).cpu()
+    want = H.T(g[f"y_{ds}_{us}"])
+    assert float((y - want).abs().max()) <= 1e-4 * float(want.abs().max())
+    x = torch.rand(37, 4, 65, generator=torch.Generator().manual_seed(6))
+    want = O.s2s_step(sd, x, hop=4, downsampling=ds, upsampling=us)
+    got = net.generate_step((x.to(device),), t=4).cpu()
+    assert float((got - want).abs().max()) <= 1e-4 * float(want.abs().max())
+
+
 @pytest.mark.parametrize("fused,hop,batch", [("1", 8, 6), ("0", 8, 6), ("1", 5, 19), ("1", 8, 33), ("0", 3, 45)])
 def test_seq2seq_cfg5_geometry_vs_oracle(device, monkeypatch, fused, hop, batch):
     """magspec_io(22050, 1024, 256) -> 513 bins, hop 8, model_dim 128 (cfg 5 at reduced width), batch 6; with the fused

@@ -188,3 +188,12 @@ def test_seq2seq_matches_reference():
     assert torch.allclose(y, H.T(g["y"]), rtol=1e-5, atol=1e-6)
     out = O.s2s_generate(sd, H.T(g["prompt"]), 10, hop=4)
     assert torch.allclose(out, H.T(g["out"]), rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("ds,us", H.S2S_VARIANTS)
+def test_seq2seq_pooling_and_upsampling_variants_match_reference(ds, us):
+    g = H.golden("s2s_variants.npz")
+    _, sd = H.s2s_tiny(ds, us)
+    assert ("dec.fc.fc.weight" in sd) == (us == "linear_resample")
+    y = O.s2s_step(sd, H.T(g["x"]), hop=4, downsampling=ds, upsampling=us)
+    assert torch.allclose(y, H.T(g[f"y_{ds}_{us}"]), rtol=1e-5, atol=1e-5)
