@@ -259,11 +259,13 @@ typedef struct mmk_s2s_config {
   int32_t out_dim;                         /* n_bins of the target */
   int32_t model_dim;
   int32_t hop;
-  int32_t enc_n_lstm, dec_n_lstm;          /* coverage: 1 + 1 */
+  int32_t enc_n_lstm, dec_n_lstm;          /* bi-LSTM layers per side (1 .. 8) */
   int32_t out_abs;                         /* output activation Abs */
   int32_t max_batch;
   int32_t enc_downsampling;                /* 0 edge_sum, 1 edge_mean, 2 sum, 3 mean  (s2s_lstm_v2.py:105-113) */
   int32_t dec_upsampling;                  /* 0 linear_resample, 1 repeat             (:158-163) */
+  int32_t enc_apply_residuals;             /* x = x + y from the second encoder layer on (:101-104) */
+  int32_t dec_apply_residuals;             /* x = x + y after every decoder layer       (:175-178) */
 } mmk_s2s_config;
 
 typedef struct mmk_s2s_plan mmk_s2s_plan;

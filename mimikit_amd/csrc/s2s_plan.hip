@@ -39,37 +39,31 @@ __global__ void scatter_frames_kernel(const float* __restrict__ in, int in_ld, i
 // y'[r][c] = cat(f, b)[r][2c] + cat(f, b)[r][2c+1]                (s2s_lstm_v2.py:100)
 __device__ __forceinline__ float cat_at(const float* f, const float* b, int D, int i) { return i < D ? f[i] : b[i - D]; }
 
+// y.view(..., D, 2).sum(-1) of the [forward | backward] concatenation (:100, :174), optionally x + y (:101-104, :175-178)
 __global__ void pair_sum_kernel(const float* __restrict__ of, const float* __restrict__ ob, int D, int rows,
-                                float* __restrict__ out) {
+                                const float* __restrict__ res, float* __restrict__ out) {
   const int r = blockIdx.x;
   if (r >= rows) return;
   const float* f = of + (int64_t)r * D;
   const float* b = ob + (int64_t)r * D;
-  for (int c = threadIdx.x; c < D; c += blockDim.x) out[(int64_t)r * D + c] = cat_at(f, b, D, 2 * c) + cat_at(f, b, D, 2 * c + 1);
+  for (int c = threadIdx.x; c < D; c += blockDim.x) {
+    const float y = cat_at(f, b, D, 2 * c) + cat_at(f, b, D, 2 * c + 1);
+    out[(int64_t)r * D + c] = res ? res[(int64_t)r * D + c] + y : y;
+  }
 }
 
-// the encoder's pooling over the hop frames of the pair-summed output  (:105-113):  unfold(1, hop, hop), then
+// the encoder's pooling over the hop frames of its (folded) output  (:105-113):  unfold(1, hop, hop), then
 //   mode 0 edge_sum: first + last      1 edge_mean: (first + last) / 2      2 sum: all frames      3 mean: sum / hop
-__global__ void pool_pair_sum_kernel(const float* __restrict__ of, const float* __restrict__ ob, int D, int hop, int mode,
-                                     float* __restrict__ out) {
+__global__ void pool_frames_kernel(const float* __restrict__ x, int D, int hop, int mode, float* __restrict__ out) {
   const int bidx = blockIdx.x;
+  const float* x0 = x + (int64_t)(bidx * hop) * D;
   for (int c = threadIdx.x; c < D; c += blockDim.x) {
     float v = 0.f;
     if (mode < 2) {
-      const float* f0 = of + (int64_t)(bidx * hop) * D;
-      const float* b0 = ob + (int64_t)(bidx * hop) * D;
-      const float* f1 = of + (int64_t)(bidx * hop + hop - 1) * D;
-      const float* b1 = ob + (int64_t)(bidx * hop + hop - 1) * D;
-      const float first = cat_at(f0, b0, D, 2 * c) + cat_at(f0, b0, D, 2 * c + 1);
-      const float last = cat_at(f1, b1, D, 2 * c) + cat_at(f1, b1, D, 2 * c + 1);
-      v = first + last;
+      v = x0[c] + x0[(int64_t)(hop - 1) * D + c];
       if (mode == 1) v *= 0.5f;
     } else {
-      for (int t = 0; t < hop; ++t) {
-        const float* f = of + (int64_t)(bidx * hop + t) * D;
-        const float* b = ob + (int64_t)(bidx * hop + t) * D;
-        v += cat_at(f, b, D, 2 * c) + cat_at(f, b, D, 2 * c + 1);
-      }
+      for (int t = 0; t < hop; ++t) v += x0[(int64_t)t * D + c];
       if (mode == 3) v /= (float)hop;
     }
     out[(int64_t)bidx * D + c] = v;
@@ -94,17 +88,19 @@ struct mmk_s2s_plan {
   Binder binder;
   bool committed = false;
   int D = 0, hop = 0, Bmax = 0, in_pad = 0, out_pad = 0;
-  BiLstm enc, dec;
+  std::vector<BiLstm> enc, dec;        // the bi-LSTM layers of each side
   PackedLinear fc_out, dec_fc, out_lin;
   float *xin = nullptr, *gi[2] = {nullptr, nullptr}, *gates = nullptr;
   float *h[2] = {nullptr, nullptr}, *c[2] = {nullptr, nullptr};
   float* h2[2] = {nullptr, nullptr};   // second state buffer of each direction (the fused step kernel ping-pongs)
   bool fused_lstm = false;
   float *of = nullptr, *ob = nullptr, *es = nullptr, *coded = nullptr, *z = nullptr, *ysum = nullptr, *yout = nullptr;
+  float* yalt = nullptr;                         // second folded-output buffer (layer n reads one, writes the other)
+  float *hs[2] = {nullptr, nullptr}, *cs[2] = {nullptr, nullptr};   // the encoder's final state: every decoder layer starts from it
 
   void layout(Carver& cv) {
-    for (int d = 0; d < 2; ++d) { enc.ih[d].carve(cv, true); enc.hh[d].carve(cv, false); }
-    for (int d = 0; d < 2; ++d) { dec.ih[d].carve(cv, true); dec.hh[d].carve(cv, false); }
+    for (auto& l : enc) for (int d = 0; d < 2; ++d) { l.ih[d].carve(cv, true); l.hh[d].carve(cv, false); }
+    for (auto& l : dec) for (int d = 0; d < 2; ++d) { l.ih[d].carve(cv, true); l.hh[d].carve(cv, false); }
     fc_out.carve(cv, false);
     dec_fc.carve(cv, true);
     out_lin.carve(cv, true);
@@ -121,6 +117,8 @@ struct mmk_s2s_plan {
     coded = cv.take<float>((int64_t)Bmax * D);
     z = cv.take<float>(rows * D);
     ysum = cv.take<float>(rows * D);
+    yalt = cv.take<float>(rows * D);
+    for (int d = 0; d < 2; ++d) { hs[d] = cv.take<float>((int64_t)Bmax * D); cs[d] = cv.take<float>((int64_t)Bmax * D); }
     yout = cv.take<float>(rows * out_pad);
   }
 };
@@ -128,7 +126,8 @@ struct mmk_s2s_plan {
 static int derive(mmk_s2s_plan* p) {
   const mmk_s2s_config& c = p->cfg;
   if (c.in_dim < 1 || c.out_dim < 1 || c.model_dim < 1 || c.hop < 1 || c.max_batch < 1) return fail(MMK_ERR_INVALID, "s2s: bad dimensions");
-  if (c.enc_n_lstm != 1 || c.dec_n_lstm != 1) return fail(MMK_ERR_UNSUPPORTED, "s2s: only enc_n_lstm = dec_n_lstm = 1 is covered");
+  if (c.enc_n_lstm < 1 || c.enc_n_lstm > 8 || c.dec_n_lstm < 1 || c.dec_n_lstm > 8)
+    return fail(MMK_ERR_UNSUPPORTED, "s2s: 1 .. 8 bi-LSTM layers per side, got %d + %d", c.enc_n_lstm, c.dec_n_lstm);
   if (c.enc_downsampling < 0 || c.enc_downsampling > 3 || c.dec_upsampling < 0 || c.dec_upsampling > 1)
     return fail(MMK_ERR_UNSUPPORTED, "s2s: enc_downsampling %d / dec_upsampling %d are not covered", c.enc_downsampling, c.dec_upsampling);
   if (c.model_dim % 2 != 0) return fail(MMK_ERR_UNSUPPORTED, "s2s: model_dim must be even");
@@ -137,11 +136,17 @@ static int derive(mmk_s2s_plan* p) {
   p->Bmax = c.max_batch;
   p->in_pad = (int)round_up(c.in_dim, 4);
   p->out_pad = (int)round_up(c.out_dim, 4);
+  p->enc.assign((size_t)c.enc_n_lstm, BiLstm());
+  p->dec.assign((size_t)c.dec_n_lstm, BiLstm());
   for (int d = 0; d < 2; ++d) {
-    p->enc.ih[d].set_geometry(4 * p->D, {p->in_pad});
-    p->enc.hh[d].set_geometry(4 * p->D, {p->D});
-    p->dec.ih[d].set_geometry(4 * p->D, {p->D});
-    p->dec.hh[d].set_geometry(4 * p->D, {p->D});
+    for (size_t n = 0; n < p->enc.size(); ++n) {
+      p->enc[n].ih[d].set_geometry(4 * p->D, {n == 0 ? p->in_pad : p->D});
+      p->enc[n].hh[d].set_geometry(4 * p->D, {p->D});
+    }
+    for (auto& l : p->dec) {
+      l.ih[d].set_geometry(4 * p->D, {p->D});
+      l.hh[d].set_geometry(4 * p->D, {p->D});
+    }
   }
   p->fc_out.set_geometry(p->D, {p->D});
   p->dec_fc.set_geometry(p->hop * p->D, {p->D});
@@ -211,8 +216,9 @@ extern "C" int mmk_s2s_commit(mmk_s2s_plan* p, void* workspace, size_t workspace
   Binder& b = p->binder;
   b.clear_missing();
   const int D = p->D;
-  MMK_TRY(pack_lstm(p, p->enc, "enc.lstm.0.", c.in_dim, st));
-  MMK_TRY(pack_lstm(p, p->dec, "dec.lstm.0.", D, st));
+  for (size_t n = 0; n < p->enc.size(); ++n)
+    MMK_TRY(pack_lstm(p, p->enc[n], "enc.lstm." + std::to_string(n) + ".", n == 0 ? c.in_dim : D, st));
+  for (size_t n = 0; n < p->dec.size(); ++n) MMK_TRY(pack_lstm(p, p->dec[n], "dec.lstm." + std::to_string(n) + ".", D, st));
   if (const float* w = b.need("enc.fc_out.weight", (int64_t)D * D))
     MMK_TRY(pack_rect(p->fc_out.Wp, p->fc_out.k_chunks, 0, 1, D, 0, D, w, D, 1, st));
   if (c.dec_upsampling == 0) {   // "repeat" has no up-sampling weights
@@ -301,22 +307,50 @@ static int s2s_step(mmk_s2s_plan* p, int M, const float* x, int64_t xbs, int64_t
   const int rows = M * hop;
   hipLaunchKernelGGL(gather_frames_kernel, dim3(rows), dim3(256), 0, st, x, xbs, xfs, hop, c.in_dim, p->xin, p->in_pad);
   MMK_HIP(hipGetLastError());
-  // encoder
-  MMK_TRY(run_bilstm(p, p->enc, p->xin, p->in_pad, M, true, st));
-  hipLaunchKernelGGL(pool_pair_sum_kernel, dim3(M), dim3(256), 0, st, p->of, p->ob, D, hop, c.enc_downsampling, p->es);
+  const size_t state_bytes = (size_t)M * D * sizeof(float);
+  // encoder: every layer starts from a zero state; x = y, or x + y from the second layer on (:96-104)
+  const float* xl = p->xin;
+  int xl_ld = p->in_pad;
+  float* fold = p->ysum;
+  for (size_t n = 0; n < p->enc.size(); ++n) {
+    MMK_TRY(run_bilstm(p, p->enc[n], xl, xl_ld, M, true, st));
+    const float* res = (n > 0 && c.enc_apply_residuals) ? xl : nullptr;
+    hipLaunchKernelGGL(pair_sum_kernel, dim3(rows), dim3(256), 0, st, p->of, p->ob, D, rows, res, fold);
+    MMK_HIP(hipGetLastError());
+    xl = fold; xl_ld = D;
+    fold = fold == p->ysum ? p->yalt : p->ysum;
+  }
+  hipLaunchKernelGGL(pool_frames_kernel, dim3(M), dim3(256), 0, st, xl, D, hop, c.enc_downsampling, p->es);
   MMK_HIP(hipGetLastError());
   MMK_TRY(plain_linear(p->fc_out, p->es, D, M, p->coded, D, ACT_NONE, st));
-  // decoder: LinearResampler to hop frames, bi-LSTM seeded with the encoder's (h_n, c_n)  (:158-171)
+  // decoder: up-sampling to hop frames, every bi-LSTM seeded with the LAST encoder layer's (h_n, c_n)  (:158-171)
   if (c.dec_upsampling == 0) {
     MMK_TRY(plain_linear(p->dec_fc, p->coded, D, M, p->z, (int64_t)hop * D, ACT_NONE, st));
   } else {
     hipLaunchKernelGGL(repeat_rows_kernel, dim3(rows), dim3(256), 0, st, p->coded, D, hop, p->z);
     MMK_HIP(hipGetLastError());
   }
-  MMK_TRY(run_bilstm(p, p->dec, p->z, D, M, false, st));
-  hipLaunchKernelGGL(pair_sum_kernel, dim3(rows), dim3(256), 0, st, p->of, p->ob, D, rows, p->ysum);
-  MMK_HIP(hipGetLastError());
-  MMK_TRY(plain_linear(p->out_lin, p->ysum, D, rows, p->yout, p->out_pad, c.out_abs ? ACT_ABS : ACT_NONE, st));
+  if (p->dec.size() > 1)
+    for (int d = 0; d < 2; ++d) {
+      MMK_HIP(hipMemcpyAsync(p->hs[d], p->h[d], state_bytes, hipMemcpyDeviceToDevice, st));
+      MMK_HIP(hipMemcpyAsync(p->cs[d], p->c[d], state_bytes, hipMemcpyDeviceToDevice, st));
+    }
+  xl = p->z;
+  fold = p->ysum;
+  for (size_t n = 0; n < p->dec.size(); ++n) {
+    if (n > 0)
+      for (int d = 0; d < 2; ++d) {
+        MMK_HIP(hipMemcpyAsync(p->h[d], p->hs[d], state_bytes, hipMemcpyDeviceToDevice, st));
+        MMK_HIP(hipMemcpyAsync(p->c[d], p->cs[d], state_bytes, hipMemcpyDeviceToDevice, st));
+      }
+    MMK_TRY(run_bilstm(p, p->dec[n], xl, D, M, false, st));
+    hipLaunchKernelGGL(pair_sum_kernel, dim3(rows), dim3(256), 0, st, p->of, p->ob, D, rows,
+                       c.dec_apply_residuals ? xl : (const float*)nullptr, fold);
+    MMK_HIP(hipGetLastError());
+    xl = fold;
+    fold = fold == p->ysum ? p->yalt : p->ysum;
+  }
+  MMK_TRY(plain_linear(p->out_lin, xl, D, rows, p->yout, p->out_pad, c.out_abs ? ACT_ABS : ACT_NONE, st));
   hipLaunchKernelGGL(scatter_frames_kernel, dim3(rows), dim3(256), 0, st, p->yout, p->out_pad, hop, n_out, c.out_dim, y,
                      ybs, yfs);
   MMK_HIP(hipGetLastError());

@@ -46,6 +46,7 @@ class S2SConfig(C.Structure):
     _fields_ = [
         ("in_dim", i32), ("out_dim", i32), ("model_dim", i32), ("hop", i32), ("enc_n_lstm", i32),
         ("dec_n_lstm", i32), ("out_abs", i32), ("max_batch", i32), ("enc_downsampling", i32), ("dec_upsampling", i32),
+        ("enc_apply_residuals", i32), ("dec_apply_residuals", i32),
     ]
 
 

@@ -12,6 +12,7 @@ import dataclasses as dtc
 from typing import Dict, Optional, Set, Tuple
 
 import torch
+import torch.nn as nn
 
 from ..config import Config, Configurable
 from ..features.item_spec import ItemSpec
@@ -85,3 +86,27 @@ class ARMWithHidden(ARM, abc.ABC):
     @abc.abstractmethod
     def reset_hidden(self) -> None:
         ...
+
+
+# -- weight_norm (sample_rnn_v2.py:67-81, s2s_lstm_v2.py:86-91 of the reference) ---------------------------------------
+def weight_norm_leaves(root: nn.Module) -> None:
+    """``nn.utils.weight_norm`` on every parameter of every leaf module (reference :76-81 and SampleRNN.__init__)"""
+    for module in root.modules():
+        if isinstance(module, nn.ModuleList) or list(module.children()) != []:
+            continue
+        for name in dict(module.named_parameters()):
+            nn.utils.weight_norm(module, name)
+
+
+def fold_weight_norm(sd: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+    """state_dict as the HIP plan binds it: ``name_g`` / ``name_v`` pairs folded into ``name`` = g v / |v| (norm over
+    every dimension but the first, as ``torch._weight_norm(v, g, 0)``), which is what the module's pre-forward hook does"""
+    out = {}
+    for key, value in sd.items():
+        if key.endswith("_v") and key[:-2] + "_g" in sd:
+            out[key[:-2]] = torch._weight_norm(value, sd[key[:-2] + "_g"], 0)
+        elif key.endswith("_g") and key[:-2] + "_v" in sd:
+            continue
+        else:
+            out[key] = value
+    return out

@@ -23,7 +23,7 @@ from ..modules.io import ZipReduceVariables
 from ..modules.misc import Chunk
 from ..modules.resamplers import LinearResampler
 from ..utils import AutoStrEnum
-from .arm import ARMWithHidden, NetworkConfig
+from .arm import ARMWithHidden, NetworkConfig, fold_weight_norm, weight_norm_leaves
 
 __all__ = ["EncoderLSTM", "DecoderLSTM", "Seq2SeqLSTMNetwork"]
 
@@ -57,8 +57,6 @@ class EncoderLSTM(nn.Module):
     def __init__(self, downsampling: str, input_dim: int = 512, output_dim: int = 512, num_layers: int = 1,
                  hop: int = 4, apply_residuals: bool = False, weight_norm: bool = False):
         super().__init__()
-        if weight_norm:
-            raise NotImplementedError("weight_norm is outside the covered option space")
         self.downsampling, self.input_dim, self.output_dim = str(downsampling), input_dim, output_dim
         self.num_layers, self.hop, self.apply_residuals = num_layers, hop, apply_residuals
         self.lstm = _bi_lstms(input_dim, output_dim, num_layers)
@@ -66,6 +64,8 @@ class EncoderLSTM(nn.Module):
             self.fc = LinearResampler(output_dim, 1 / hop, 1)
         self.fc_out = nn.Linear(output_dim, output_dim, bias=False)
         self.hidden = [None] * num_layers
+        if weight_norm:
+            weight_norm_leaves(self)      # every parameter of every leaf becomes a (g, v) pair (:86-91)
 
     def forward(self, x):
         assert x.size(1) == self.hop
@@ -86,8 +86,6 @@ class DecoderLSTM(nn.Module):
     def __init__(self, upsampling: str, model_dim: int = 512, num_layers: int = 1, hop: int = 4,
                  apply_residuals: bool = False, weight_norm: bool = False):
         super().__init__()
-        if weight_norm:
-            raise NotImplementedError("weight_norm is outside the covered option space")
         self.upsampling = str(upsampling)
         self.output_dim = self.model_dim = model_dim
         self.num_layers, self.hop, self.apply_residuals = num_layers, hop, apply_residuals
@@ -95,6 +93,8 @@ class DecoderLSTM(nn.Module):
         if self.upsampling == "linear_resample":
             self.fc = LinearResampler(model_dim, hop, 1)
         self.hidden = [None] * num_layers
+        if weight_norm:
+            weight_norm_leaves(self)      # (:148-153)
 
     def forward(self, x, hidden=None):
         assert x.size(1) == 1
@@ -206,10 +206,8 @@ class Seq2SeqLSTMNetwork(ARMWithHidden, nn.Module):
             unsupported.append(f"enc_downsampling='{cfg.enc_downsampling}'")
         if str(cfg.dec_upsampling) not in upsampling:
             unsupported.append(f"dec_upsampling='{cfg.dec_upsampling}'")
-        if cfg.enc_n_lstm != 1 or cfg.dec_n_lstm != 1:
-            unsupported.append("more than one LSTM per side")
-        if cfg.enc_apply_residuals or cfg.dec_apply_residuals:
-            unsupported.append("residual LSTM stacks")
+        if not (1 <= cfg.enc_n_lstm <= 8 and 1 <= cfg.dec_n_lstm <= 8):
+            unsupported.append("more than 8 LSTMs per side")
         heads = list(self.output_module.heads)
         c = native.S2SConfig()
         if len(heads) != 1 or len(cfg.io_spec.inputs) != 1:
@@ -229,6 +227,7 @@ class Seq2SeqLSTMNetwork(ARMWithHidden, nn.Module):
         c.model_dim, c.hop = cfg.model_dim, cfg.hop
         c.enc_n_lstm, c.dec_n_lstm = cfg.enc_n_lstm, cfg.dec_n_lstm
         c.enc_downsampling, c.dec_upsampling = pooling[str(cfg.enc_downsampling)], upsampling[str(cfg.dec_upsampling)]
+        c.enc_apply_residuals, c.dec_apply_residuals = int(cfg.enc_apply_residuals), int(cfg.dec_apply_residuals)
         c.max_batch = max_batch
         return c
 
@@ -243,7 +242,8 @@ class Seq2SeqLSTMNetwork(ARMWithHidden, nn.Module):
             self._plan_batch = max(batch, 1)
             rebuilt = True
         if rebuilt or refresh_weights or self._stale:
-            self._plan.bind_state_dict(self.state_dict())
+            sd = self.state_dict()
+            self._plan.bind_state_dict(fold_weight_norm(sd) if any(k.endswith("_g") for k in sd) else sd)
             self._plan.commit()
             self._stale = False
 

@@ -24,7 +24,7 @@ from ..modules.mlp import MLP
 from ..modules.resamplers import LinearResampler
 from ..modules.targets import OutputWrapper, per_row_temperature
 from ..utils import AutoStrEnum
-from .arm import ARMWithHidden, NetworkConfig
+from .arm import fold_weight_norm, weight_norm_leaves, ARMWithHidden, NetworkConfig
 
 __all__ = ["SampleRNN", "SampleRNNTier"]
 
@@ -42,29 +42,6 @@ class H0Init(AutoStrEnum):
     zeros = auto()
     ones = auto()
     randn = auto()
-
-
-def weight_norm_leaves(root: nn.Module) -> None:
-    """``nn.utils.weight_norm`` on every parameter of every leaf module (reference :76-81 and SampleRNN.__init__)"""
-    for module in root.modules():
-        if isinstance(module, nn.ModuleList) or list(module.children()) != []:
-            continue
-        for name in dict(module.named_parameters()):
-            nn.utils.weight_norm(module, name)
-
-
-def fold_weight_norm(sd: Dict[str, T]) -> Dict[str, T]:
-    """state_dict as the HIP plan binds it: ``name_g`` / ``name_v`` pairs folded into ``name`` = g v / |v| (norm over
-    every dimension but the first, as ``torch._weight_norm(v, g, 0)``), which is what the module's pre-forward hook does"""
-    out = {}
-    for key, value in sd.items():
-        if key.endswith("_v") and key[:-2] + "_g" in sd:
-            out[key[:-2]] = torch._weight_norm(value, sd[key[:-2] + "_g"], 0)
-        elif key.endswith("_g") and key[:-2] + "_v" in sd:
-            continue
-        else:
-            out[key] = value
-    return out
 
 
 class SampleRNNTier(nn.Module):

@@ -402,24 +402,32 @@ def _bilstm(sd: SD, p: str, x: torch.Tensor, state=None):
 
 
 def s2s_step(sd: SD, x: torch.Tensor, hop: int, out_abs: bool = True, downsampling: str = "edge_sum",
-             upsampling: str = "linear_resample") -> torch.Tensor:
+             upsampling: str = "linear_resample", enc_residuals: bool = False, dec_residuals: bool = False) -> torch.Tensor:
     """Seq2SeqLSTMNetwork.forward (s2s_lstm_v2.py:246-253): EncoderLSTM.forward with the edge_sum / edge_mean / sum / mean
-    poolings (:93-113), DecoderLSTM.forward with linear_resample or repeat (:155-179)"""
+    poolings and stacked layers (:93-113), DecoderLSTM.forward with linear_resample or repeat (:155-179); the number of
+    layers is read off the state_dict; every decoder layer starts from the LAST encoder layer's final state (:171)"""
     D = sd["enc.fc_out.weight"].shape[0]
-    y, hidden = _bilstm(sd, "enc.lstm.0.", x)
-    y = y.view(*y.shape[:-1], D, 2).sum(-1)
-    y = y.unfold(1, hop, hop)
+    n_enc = 1 + max(int(k.split(".")[2]) for k in sd if k.startswith("enc.lstm."))
+    n_dec = 1 + max(int(k.split(".")[2]) for k in sd if k.startswith("dec.lstm."))
+    hidden = None
+    for n in range(n_enc):
+        y, hidden = _bilstm(sd, f"enc.lstm.{n}.", x)
+        y = y.view(*y.shape[:-1], D, 2).sum(-1)
+        x = x + y if (n > 0 and enc_residuals) else y
+    y = x.unfold(1, hop, hop)
     if "edge" in downsampling:
         y = y[..., [0, -1]]
     y = y.sum(-1) if "sum" in downsampling else y.mean(-1)
     coded = F.linear(y, sd["enc.fc_out.weight"])
     if upsampling == "linear_resample":
-        z = F.linear(coded, sd["dec.fc.fc.weight"], sd["dec.fc.fc.bias"]).reshape(x.size(0), hop, D)
+        z = F.linear(coded, sd["dec.fc.fc.weight"], sd["dec.fc.fc.bias"]).reshape(coded.size(0), hop, D)
     else:
         z = coded.repeat_interleave(hop, 1)
-    y, _ = _bilstm(sd, "dec.lstm.0.", z, hidden)
-    y = y.view(*y.shape[:-1], D, 2).sum(-1)
-    out = F.linear(y, sd["output_module.heads.0.0.weight"], sd["output_module.heads.0.0.bias"])
+    for n in range(n_dec):
+        y, _ = _bilstm(sd, f"dec.lstm.{n}.", z, hidden)
+        y = y.view(*y.shape[:-1], D, 2).sum(-1)
+        z = z + y if dec_residuals else y
+    out = F.linear(z, sd["output_module.heads.0.0.weight"], sd["output_module.heads.0.0.bias"])
     return out.abs() if out_abs else out
 
 

@@ -281,6 +281,24 @@ def make_s2s_variants():
     save("s2s_variants.npz", **arrays)
 
 
+def make_s2s_stacks():
+    """stacked bi-LSTMs with and without residuals (s2s_lstm_v2.py:96-104, :168-178)"""
+    g = torch.Generator().manual_seed(35)
+    io = ref.IOSpec.magspec_io(ref.IOSpec.MagSpecIOConfig(n_fft=128, hop_length=32))
+    x = torch.rand(3, 4, 65, generator=g)
+    arrays = {"x": x}
+    for tag, kw in S2S_STACKS.items():
+        cfg = ref.Seq2SeqLSTMNetwork.Config(io_spec=io, model_dim=32, hop=4, **kw)
+        net = ref.Seq2SeqLSTMNetwork.from_config(cfg).eval()
+        load_recipe(net, seed=43, gain=1.5)
+        arrays[f"y_{tag}"] = net.generate_step((x,), t=4)
+    save("s2s_stacks.npz", **arrays)
+
+
+S2S_STACKS = {"e2d1": dict(enc_n_lstm=2), "e1d3": dict(dec_n_lstm=3), "e2d2res": dict(enc_n_lstm=2, dec_n_lstm=2, enc_apply_residuals=True, dec_apply_residuals=True),
+              "e3d1res_sum": dict(enc_n_lstm=3, enc_apply_residuals=True, enc_downsampling="sum")}
+
+
 def make_sampler():
     g = torch.Generator().manual_seed(51)
     logits = torch.randn(6, 1, 256, generator=g) * 3
@@ -362,5 +380,6 @@ if __name__ == "__main__":
     make_srnn_weight_norm()
     make_s2s()
     make_s2s_variants()
+    make_s2s_stacks()
     make_sampler()
     make_keys()

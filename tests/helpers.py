@@ -92,11 +92,17 @@ def srnn(tag, hidden=32, mlp_dim=32, seed=None, frame_sizes=None, kind=None, wei
 S2S_VARIANTS = (("edge_mean", "linear_resample"), ("sum", "linear_resample"), ("mean", "repeat"), ("edge_sum", "repeat"))
 
 
-def s2s_tiny(downsampling="edge_sum", upsampling="linear_resample"):
+S2S_STACKS = {"e2d1": dict(enc_n_lstm=2), "e1d3": dict(dec_n_lstm=3),
+              "e2d2res": dict(enc_n_lstm=2, dec_n_lstm=2, enc_apply_residuals=True, dec_apply_residuals=True),
+              "e3d1res_sum": dict(enc_n_lstm=3, enc_apply_residuals=True, enc_downsampling="sum")}
+
+
+def s2s_tiny(downsampling="edge_sum", upsampling="linear_resample", seed=41, **kw):
     io = mmk.IOSpec.magspec_io(mmk.IOSpec.MagSpecIOConfig(n_fft=128, hop_length=32))
+    kw.setdefault("enc_downsampling", downsampling)
     net = mmk.Seq2SeqLSTMNetwork.from_config(mmk.Seq2SeqLSTMNetwork.Config(io_spec=io, model_dim=32, hop=4,
-                                                                           enc_downsampling=downsampling, dec_upsampling=upsampling))
-    sd = load_recipe(net, seed=41, gain=1.5)
+                                                                           dec_upsampling=upsampling, **kw))
+    sd = load_recipe(net, seed=seed, gain=1.5)
     return net.eval(), sd
 
 

@@ -297,6 +297,29 @@ def test_seq2seq_matches_reference_golden(device):
     assert bool((out[0][:, -10:] != 0).all())                 # tests/test_seq2seq.py:146
 
 
+@pytest.mark.parametrize("tag", list(H.S2S_STACKS))
+def test_seq2seq_lstm_stacks(device, tag):
+    """2 / 3 stacked bi-LSTMs per side, with and without residuals: golden from the reference, a larger batch against
+    the oracle, and the loop; fp32 tolerance 1e-4 of the largest output"""
+    import warnings
+    warnings.filterwarnings("ignore")
+    g = H.golden("s2s_stacks.npz")
+    kw = H.S2S_STACKS[tag]
+    net, sd = H.s2s_tiny(seed=43, **kw)
+    net.to(device)
+    y = net.generate_step((H.T(g["x"]).to(device),), t=4).cpu()
+    want = H.T(g[f"y_{tag}"])
+    assert float((y - want).abs().max()) <= 1e-4 * float(want.abs().max())
+    okw = dict(downsampling=kw.get("enc_downsampling", "edge_sum"), enc_residuals=kw.get("enc_apply_residuals", False),
+               dec_residuals=kw.get("dec_apply_residuals", False))
+    x = torch.rand(21, 4, 65, generator=torch.Generator().manual_seed(7))
+    want = O.s2s_step(O.fold_weight_norm(sd), x, hop=4, **okw)      # (the decoder is weight-normed when dec_apply_residuals, :221)
+    got = net.generate_step((x.to(device),), t=4).cpu()
+    assert float((got - want).abs().max()) <= 1e-4 * float(want.abs().max())
+    out = run_loop(net, (x[:2].to(device),), 8)[0]
+    assert out.shape == (2, 12, 65) and bool(torch.isfinite(out).all())
+
+
 @pytest.mark.parametrize("ds,us", H.S2S_VARIANTS)
 def test_seq2seq_pooling_and_upsampling_variants(device, ds, us):
     """enc_downsampling edge_mean / sum / mean and dec_upsampling repeat (no up-sampling weights): golden from the

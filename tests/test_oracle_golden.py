@@ -197,3 +197,18 @@ def test_seq2seq_pooling_and_upsampling_variants_match_reference(ds, us):
     assert ("dec.fc.fc.weight" in sd) == (us == "linear_resample")
     y = O.s2s_step(sd, H.T(g["x"]), hop=4, downsampling=ds, upsampling=us)
     assert torch.allclose(y, H.T(g[f"y_{ds}_{us}"]), rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("tag", list(H.S2S_STACKS))
+def test_seq2seq_lstm_stacks_match_reference(tag):
+    g = H.golden("s2s_stacks.npz")
+    kw = H.S2S_STACKS[tag]
+    import warnings
+    warnings.filterwarnings("ignore")
+    _, sd = H.s2s_tiny(seed=43, **kw)
+    # the reference hands dec_apply_residuals to the decoder as its weight_norm flag (s2s_lstm_v2.py:221): (g, v) pairs
+    assert any(k.endswith("_g") for k in sd) == bool(kw.get("dec_apply_residuals", False))
+    sd = O.fold_weight_norm(sd)
+    y = O.s2s_step(sd, H.T(g["x"]), hop=4, downsampling=kw.get("enc_downsampling", "edge_sum"),
+                   enc_residuals=kw.get("enc_apply_residuals", False), dec_residuals=kw.get("dec_apply_residuals", False))
+    assert torch.allclose(y, H.T(g[f"y_{tag}"]), rtol=1e-5, atol=1e-5)
