@@ -73,8 +73,30 @@ __global__ __launch_bounds__(kGruThreads) void srnn_gru_kernel(const SrnnGruArgs
       }
     }
   }
-  // ---- the window, linearized (modules/io.py:106-112), zero padded to whole K-chunks ----------------------------
   const int kci = (a.fs + 15) / 16, ldl = kci * 16 + 4;
+  // ---- the input projection's operands of this wave's column tiles (frame sizes <= 16: one K-chunk): requested now,
+  //      with the gate weights, instead of one round trip per tile inside the x phase ------------------------------------
+  constexpr int XT = KC / kGruWaves;                 // column tiles of x per wave
+  const int xslot = a.up_mod > 0 ? (int)((t / a.div) % a.up_mod) : 0;     // outputs[i-1][:, (t // fs) % ...]   (:251)
+  float x_up[XT][4], x_bias[XT];
+  f32x4 x_w[XT];
+  const bool x_hoisted = kci == 1;
+  if (x_hoisted) {
+    const int q = lane >> 4, n = lane & 15;
+#pragma unroll
+    for (int j = 0; j < XT; ++j) {
+      const int tile = wave + j * kGruWaves, col = tile * 16 + n;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {   // unconditional loads from clamped addresses
+        const int m = min(4 * q + r, mg - 1);
+        const float* src = a.upper ? a.upper + ((int64_t)(m_first + m) * a.up_mod + xslot) * H + col : a.win_bias + col;
+        x_up[j][r] = *src;
+      }
+      x_bias[j] = a.win_bias[col];
+      x_w[j] = ((gf32x4_ptr)(uintptr_t)a.win_wp)[(int64_t)tile * 64 + lane];
+    }
+  }
+  // ---- the window, linearized (modules/io.py:106-112), zero padded to whole K-chunks ----------------------------
   for (int e = tid; e < 16 * kci * 16; e += kGruThreads) {
     const int m = e / (kci * 16), i = e - m * (kci * 16);
     float v = 0.f;
@@ -94,8 +116,25 @@ __global__ __launch_bounds__(kGruThreads) void srnn_gru_kernel(const SrnnGruArgs
   __syncthreads();
   stamp(0);   // weights requested, window + old state in LDS
   // ---- x = W_in lin + b_in (+ upper): 16 x 16 tiles over the waves, K = fs (same MFMA order as the launch path) ----
-  {
-    const int slot = a.up_mod > 0 ? (int)((t / a.div) % a.up_mod) : 0;     // outputs[i-1][:, (t // fs) % ...]   (:251)
+  if (x_hoisted) {
+    const int q = lane >> 4, n = lane & 15;
+    const f32x4 xv = *reinterpret_cast<const f32x4*>(s_lin + n * ldl + 4 * q);
+#pragma unroll
+    for (int j = 0; j < XT; ++j) {
+      const int col = (wave + j * kGruWaves) * 16 + n;
+      f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[i], x_w[j][i], acc, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = 4 * q + r;
+        float v = acc[r] + x_bias[j];
+        if (a.upper) v += x_up[j][r];
+        xs[m * ldx + col] = m < mg ? v : 0.f;
+      }
+    }
+  } else {
+    const int slot = xslot;
     const int q = lane >> 4, n = lane & 15;
     for (int tile = wave; tile < KC; tile += kGruWaves) {
       const int col = tile * 16 + n;
