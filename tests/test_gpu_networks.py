@@ -417,6 +417,44 @@ def test_wavenet_on_magnitude_frames(device, tag):
     assert wave.shape == (5, 16 * (out2.shape[1] - 1)) and bool(torch.isfinite(wave).all())
 
 
+def test_reference_demo_networks_on_magnitude_frames(device):
+    """the two spectral demos of the reference at their real sizes, n_fft 2048 / hop 512 (1025 bins), against the oracle,
+    then through the loop into Griffin-Lim:
+      demos/freqnet.py:34-63   WaveNet, 3 layers x 2048 channels, groups=8, no residual / skip path, Identity output
+      demos/seq2seq.py:35-60   Seq2Seq, model_dim 512, hop 4, 2 + 2 residual bi-LSTMs, edge_sum pooling, repeat up-sampling"""
+    import warnings
+    warnings.filterwarnings("ignore")
+    from oracle.weights import load_recipe
+    io = mmk.IOSpec.magspec_io(mmk.IOSpec.MagSpecIOConfig(sr=22050, n_fft=2048, hop_length=512, activation="Identity"))
+    gen = torch.Generator().manual_seed(13)
+    # FreqNet
+    net = mmk.WaveNet.from_config(mmk.WaveNet.Config(io_spec=io, kernel_sizes=(2,), blocks=(3,), dims_dilated=(2048,),
+                                                     apply_residuals=False, residuals_dim=None, skips_dim=None, groups=8)).eval()
+    sd = load_recipe(net, seed=90, gain=1.5)
+    arch = dict(kernels=[2] * 3, dilations=[1, 2, 4], has_skips=False, residuals=False, groups=8, head="linear")
+    prompt = torch.rand(2, net.rf + 4, 1025, generator=gen)
+    want = O.wavenet_generate_frames(sd, prompt, 6, **arch)
+    net.to(device)
+    got = run_loop(net, (prompt.to(device),), 6)[0].cpu()
+    assert float((got - want).abs().max()) <= 1e-4 * float(want.abs().max())
+    wave = run_loop(net, (prompt.to(device),), 6, yield_inversed_outputs=True)[0]
+    assert wave.shape == (2, 512 * (got.shape[1] - 1)) and bool(torch.isfinite(wave).all())
+    del net
+    # Seq2Seq
+    io2 = mmk.IOSpec.magspec_io(mmk.IOSpec.MagSpecIOConfig(sr=22050, n_fft=2048, hop_length=512, activation="Identity"))
+    s2s = mmk.Seq2SeqLSTMNetwork.from_config(mmk.Seq2SeqLSTMNetwork.Config(
+        io_spec=io2, model_dim=512, hop=4, enc_downsampling="edge_sum", enc_n_lstm=2, enc_apply_residuals=True,
+        dec_upsampling="repeat", dec_n_lstm=2, dec_apply_residuals=True)).eval()
+    sd2 = load_recipe(s2s, seed=91, gain=1.5)
+    x = torch.rand(3, 4, 1025, generator=gen)
+    want = O.s2s_step(O.fold_weight_norm(sd2), x, hop=4, out_abs=False, upsampling="repeat", enc_residuals=True, dec_residuals=True)
+    s2s.to(device)
+    got = s2s.generate_step((x.to(device),), t=4).cpu()
+    assert float((got - want).abs().max()) <= 1e-4 * float(want.abs().max())
+    wave = run_loop(s2s, (x.to(device),), 8, yield_inversed_outputs=True)[0]
+    assert wave.shape == (3, 512 * 11) and bool(torch.isfinite(wave).all())
+
+
 def test_seq2seq_loop_ends_in_griffin_lim(device):
     """a MagSpec-target network's loop inverts its frames with GLA inside process_outputs (loops/generate.py:242-245):
     the waveform the loop yields is Griffin-Lim of the frames it generated, phases drawn from torch's device RNG"""
