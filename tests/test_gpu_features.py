@@ -310,6 +310,33 @@ def test_griffin_lim_full_size_properties(device, n_fft, hop):
     assert torch.equal(native.griffin_lim(mag, n_fft, hop, 32, 0.99, init), y32)
 
 
+def test_spectral_functionals_leading_dims_and_dtypes(device):
+    """extra leading dimensions, non-contiguous views and float64 inputs go through the same kernels (flattened / copied /
+    cast on the way in, reshaped on the way out)"""
+    gen = torch.Generator().manual_seed(21)
+    x = torch.randn(2, 3, 6000, generator=gen)
+    pol = mmk.STFT(1024, 256, "pol", center=True)(x.to(device))
+    assert pol.shape == (2, 3, 24, 513, 2)
+    want = O.stft_coord(x.reshape(6, -1), 1024, 256, "pol", center=True).reshape(2, 3, 24, 513, 2)
+    assert float((pol.cpu()[..., 0] - want[..., 0]).abs().max()) <= 2e-5 * float(want[..., 0].max())
+    y = mmk.ISTFT(1024, 256, "pol")(pol)
+    assert y.shape == (2, 3, 256 * 23)
+    kept = x[..., -O.stft_fixed_length(6000, 1024, 256, True):]              # STFT._fix_length, alignment="end"
+    assert float((y.cpu() - kept[..., :y.shape[-1]]).abs().max()) <= 5e-5
+    # a strided view and float64
+    xs = torch.randn(4, 12000, generator=gen, dtype=torch.float64)[:, ::2]
+    m64 = mmk.MagSpec(1024, 256, center=False)(xs.to(device))
+    m32 = mmk.MagSpec(1024, 256, center=False)(xs.float().contiguous().to(device))
+    assert m64.dtype == torch.float32 and torch.equal(m64, m32)
+    # Griffin-Lim with leading dimensions and without a batch dimension
+    mag = pol[..., 0]
+    init = torch.rand(mag.shape, dtype=torch.complex64, device=device, generator=torch.Generator(device=device).manual_seed(1))
+    g5 = native.griffin_lim(mag, 1024, 256, 4, 0.99, init)
+    g1 = native.griffin_lim(mag[1, 2], 1024, 256, 4, 0.99, init[1, 2])
+    assert g5.shape == (2, 3, 256 * 23) and g1.shape == (256 * 23,)
+    assert torch.equal(g5[1, 2], g1)                         # a clip's result does not depend on its batch
+
+
 def test_istft_errors(device):
     with pytest.raises(NotImplementedError):
         mmk.ISTFT(1000, 250, "pol")(torch.zeros(1, 4, 501, 2, device=device))      # powers of two in [64, 4096] only
