@@ -102,18 +102,19 @@ int launch_gemm_f32(const float* A, int64_t lda, int64_t a_batch, const float* W
 // ---- K-pipelined variant with an epilogue:  C[M, N] = act(A[M, K] . W^T + bias) ----------------------------------------------
 // For the GEMM-shaped ops of the Seq2Seq step (W_ih x over all hop frames of all clips: 512 x 4096 x 1024, and the
 // output projection), which the row-tile kernel of linear.hip (built for M <= 64) ran at 42 TFLOP/s.
-//   * 128 rows x 64 columns per workgroup, 8 waves as 4 x 2, a wave owns 32 x 32 = 2 x 2 MFMA tiles; 512 x 4096 gives
-//     256 workgroups: one per CU, two waves per SIMD
+//   * 64 rows x 64 columns per workgroup, 4 waves as 2 x 2, a wave owns 32 x 32 = 2 x 2 MFMA tiles; 512 x 4096 gives
+//     512 workgroups: two per CU, which run out of phase and fill each other's barrier / LDS waits (one 128 x 64
+//     workgroup of 8 waves per CU keeps all its waves in lock step: 57 us against 52 us)
 //   * A goes through LDS in 64-k slabs, double buffered; the next slab travels global -> registers while the current
 //     one is multiplied (2 x 64 MFMAs per SIMD and stage = 1.7 us, longer than the loads take)
 //   * W fragments (1 KiB, packed order) come straight from global / L2 into registers, one stage ahead
 //   * per K-chunk a wave issues 2 LDS reads and 16 MFMAs: the matrix pipe is the bound
-constexpr int kTgThreads = 512;             // 8 waves as 4 x 2: two waves per SIMD keep the matrix pipe fed across LDS / barrier waits
-constexpr int kTgBM = 128, kTgBN = 64;
+constexpr int kTgThreads = 256;             // 4 waves as 2 x 2; two workgroups per CU run out of phase and fill each other's barrier / LDS waits
+constexpr int kTgBM = 64, kTgBN = 64;
 constexpr int kTgCh = 4;                       // K-chunks (of 16) per pipeline stage: 1.7 us of MFMAs hide the next stage's loads
 constexpr int kTgLd = kTgCh * 16 + 4;          // LDS row stride: the 16 lanes of a quarter wave hit 64 different banks
 
-__global__ __launch_bounds__(kTgThreads) void gemm_bias_act_kernel(const float* __restrict__ A, int64_t lda, const float* __restrict__ Wp,
+__global__ __launch_bounds__(kTgThreads, 2) void gemm_bias_act_kernel(const float* __restrict__ A, int64_t lda, const float* __restrict__ Wp,
                                                                  const float* __restrict__ bias, float* __restrict__ C, int64_t ldc,
                                                                  int M, int n_tiles, int N, int K, int k_chunks, int act) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
