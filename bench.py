@@ -31,6 +31,19 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6.3 TB/s is the measured copy ceiling
+MFMA_F32_PEAK_TFLOPS = 157.3   # dense fp32 MFMA (v_mfma_f32_16x16x4_f32), MI355X_MICROARCH.md
+CPU_BASELINE_THREADS = 16      # the oracle's small ops get SLOWER on all 128 cores of the GPU box (intra-op pool overhead)
+
+
+class cpu_threads:
+    """time the CPU baseline with a thread count at which the reference algorithm actually scales"""
+
+    def __enter__(self):
+        self.old = torch.get_num_threads()
+        torch.set_num_threads(max(1, min(CPU_BASELINE_THREADS, os.cpu_count() or 1)))
+
+    def __exit__(self, *a):
+        torch.set_num_threads(self.old)
 
 
 def parse():
@@ -190,18 +203,25 @@ class WaveNetJob:
         b = min(self.clips, 2)
         prompt = self.prompt_cpu[:b]
         cond = [self.cond_cpu[:b]] if self.cond_cpu is not None else []
+        all_cores = torch.get_num_threads()
         t0 = time.perf_counter()
         O.wavenet_generate(sd, prompt, [x[:, :self.prompt_len + 1] for x in cond], 1, **arch)
-        one = time.perf_counter() - t0
-        n = max(2, min(64, int(budget_s / max(one, 1e-3))))
-        t0 = time.perf_counter()
-        out = O.wavenet_generate(sd, prompt, [x[:, :self.prompt_len + n] for x in cond], n, **arch)
-        dt = time.perf_counter() - t0
+        one_all = time.perf_counter() - t0
+        with cpu_threads():
+            cores = torch.get_num_threads()
+            t0 = time.perf_counter()
+            O.wavenet_generate(sd, prompt, [x[:, :self.prompt_len + 1] for x in cond], 1, **arch)
+            one = time.perf_counter() - t0
+            n = max(2, min(64, int(budget_s / max(one, 1e-3))))
+            t0 = time.perf_counter()
+            out = O.wavenet_generate(sd, prompt, [x[:, :self.prompt_len + n] for x in cond], n, **arch)
+            dt = time.perf_counter() - t0
         # the GPU run and the CPU run must agree on what they generated
         agree = bool((out[:, self.prompt_len:] == self.idx[:b, self.prompt_len:self.prompt_len + n].cpu()).all())
-        return {"value": round(b * n / dt, 3), "unit": self.unit, "cores": torch.get_num_threads(), "kind": "port",
+        return {"value": round(b * n / dt, 3), "unit": self.unit, "cores": cores, "kind": "port",
                 "sample": f"{b} clips x {n} steps of the same network/prompt, naive full-window forward per step "
-                          f"(reference algorithm), torch CPU fp32", "matches_gpu_output": agree}
+                          f"(reference algorithm), torch CPU fp32", "matches_gpu_output": agree,
+                "all_cores": {"cores": all_cores, "value": round(b / one_all, 3), "sample": f"{b} clips x 1 step"}}
 
 
 class SrnnJob:
@@ -283,11 +303,13 @@ class SrnnJob:
         sd = {k: v.detach().cpu() for k, v in self.net.state_dict().items()}
         o = O.SampleRNNOracle(sd, (16, 4, 1), 512, "gru")
         n = 400
-        t0 = time.perf_counter()
-        out = o.generate(self.prompt_cpu, n)
-        dt = time.perf_counter() - t0
+        with cpu_threads():
+            cores = torch.get_num_threads()
+            t0 = time.perf_counter()
+            out = o.generate(self.prompt_cpu, n)
+            dt = time.perf_counter() - t0
         agree = bool((out[:, self.prompt_len:] == self.idx[:, self.prompt_len:self.prompt_len + n].cpu()).all())
-        return {"value": round(self.clips * n / dt, 3), "unit": self.unit, "cores": torch.get_num_threads(),
+        return {"value": round(self.clips * n / dt, 3), "unit": self.unit, "cores": cores,
                 "kind": "port", "sample": f"{self.clips} clips x {n} steps (+ prompt warm-up), reference algorithm, torch CPU fp32",
                 "matches_gpu_output": agree}
 
@@ -328,22 +350,57 @@ class S2SJob:
                 "clips_per_gpu": self.clips, "global_clips": self.clips * world, "prompt_frames": self.prompt_frames,
                 "generated_frames_per_clip": self.n_steps, "parallelism": f"clip-shard x{world}"}
 
+    def step_flops(self):
+        """2 FLOP per weight of the matrices a generate_step multiplies, per clip and per frame they are
+        applied to: the four gate matrices of both directions of the two bi-LSTMs on all hop frames, the encoder output
+        projection and the decoder up-sampler once, the output projection on all hop frames (497 MFLOP per clip-step)"""
+        c = self.net.config
+        D, hop, nb = c.model_dim, c.hop, 513
+        macs = hop * 2 * 4 * D * (nb + D) + hop * 2 * 4 * D * (D + D) + D * D + D * hop * D + hop * D * nb
+        return 2 * macs
+
     def roofline(self):
-        return None
+        """the path is dense fp32 contraction (AI ~ 200 FLOP/B at 64 clips): fp32 MFMA roofline over one generate block,
+        HIP events on the launch stream"""
+        self.net.before_generate((self.frames[:, :self.prompt_frames],), None)
+        torch.cuda.synchronize()
+        start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        start.record()
+        self.net.generate_block((self.frames,), self.prompt_frames, self.n_steps)
+        stop.record()
+        torch.cuda.synchronize()
+        self.net.after_generate((self.frames,), None)
+        us = start.elapsed_time(stop) * 1e3
+        calls = -(-self.n_steps // self.net.config.hop)
+        flops = self.step_flops() * self.clips * calls
+        achieved = flops / (us * 1e-6) / 1e12
+        return {"bound": "mfma", "kernel": "Seq2Seq generate block: gemm_bias_act_kernel (input / output projections) + lstm_step_kernel "
+                                           "(recurrent products + cells), all generate_steps of one block",
+                "achieved": round(achieved, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(achieved / MFMA_F32_PEAK_TFLOPS, 5), "traffic": None,
+                "algorithmic_flops_per_launch": flops, "avg_launch_us": round(us, 1), "launches_timed": 1,
+                "generate_steps_per_launch": calls, "us_per_generate_step": round(us / calls, 2)}
 
     def cpu_baseline(self, budget_s):
         from oracle import torch_ref as O
         sd = {k: v.detach().cpu() for k, v in self.net.state_dict().items()}
         b = 4
-        x = self.frames[:b, self.prompt_frames - 8:self.prompt_frames].cpu()
-        t0 = time.perf_counter()
-        n = 0
-        while time.perf_counter() - t0 < min(budget_s, 10.0):
-            O.s2s_step(sd, x, 8)
-            n += 1
-        dt = time.perf_counter() - t0
-        return {"value": round(b * n * 8 * 256 / dt, 3), "unit": self.unit, "cores": torch.get_num_threads(),
-                "kind": "port", "sample": f"{b} clips x {n} generate_steps (8 frames each), torch CPU fp32"}
+        x_dev = self.frames[:b, self.prompt_frames - 8:self.prompt_frames].contiguous()
+        got = self.net.generate_step((x_dev,), t=self.prompt_frames).cpu()
+        x = x_dev.cpu()
+        want = O.s2s_step(sd, x, 8)
+        agree = bool(float((got - want).abs().max()) <= 1e-4 * float(want.abs().max()))
+        with cpu_threads():
+            t0 = time.perf_counter()
+            n = 0
+            while time.perf_counter() - t0 < min(budget_s, 10.0):
+                O.s2s_step(sd, x, 8)
+                n += 1
+            dt = time.perf_counter() - t0
+            cores = torch.get_num_threads()
+        return {"value": round(b * n * 8 * 256 / dt, 3), "unit": self.unit, "cores": cores,
+                "kind": "port", "sample": f"{b} clips x {n} generate_steps (8 frames each), torch CPU fp32",
+                "matches_gpu_output": agree}
 
 
 class FeatureJob:

@@ -48,6 +48,10 @@ typedef void* mmk_stream_t; /* hipStream_t */
 
 int mmk_abi_version(void);
 const char* mmk_last_error(void);
+/* Diagnostic: weight re-packing kernels (`*_commit`, mmk_pack_weight_f32) launched since the library was loaded.
+ * The host mirror re-commits a plan only when a parameter changed (in the reference `before_generate` never
+ * touches the weights, mimikit/networks/wavenet_v2.py:368-445); tests assert that through this counter. */
+int64_t mmk_pack_launch_count(void);
 
 /* ------------------------------------------------------------------------
  * Feature functionals

@@ -12,6 +12,8 @@ namespace mmk {
 // settles it against the q-1 decision thresholds of the reference formula
 // (built once on the host, mimikit_amd/features/functionals.py), which makes
 // in-range codes exact by construction.
+constexpr int kMuLawLdsLevels = 8192;   // tables up to 32 KiB are staged in LDS (the launch asks for exactly that much)
+
 __device__ __forceinline__ int64_t mulaw_code(float x, float mu, float C, float inv_log, const float* edges, int q) {
   const float ax = fabsf(x);
   const float sgn = (x > 0.f) ? 1.f : ((x < 0.f) ? -1.f : 0.f);
@@ -35,12 +37,13 @@ __global__ __launch_bounds__(256) void mulaw_compress_kernel(const float* __rest
                                                             int64_t n, int q, float C, const float* __restrict__ edges) {
   extern __shared__ float s_edges[];
   const bool have = edges != nullptr;
-  if (have)
+  const bool staged = have && q <= kMuLawLdsLevels;   // larger tables stay in global memory (L1 / L2 serve them)
+  if (staged)
     for (int i = threadIdx.x; i < q - 1; i += blockDim.x) s_edges[i] = edges[i];
   __syncthreads();
   const float mu = (float)(q - 1);
   const float inv_log = 1.f / log1pf(mu * C);
-  const float* e = have ? s_edges : nullptr;
+  const float* e = staged ? s_edges : edges;
   const int64_t n4 = n >> 2;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   const bool aligned = ((reinterpret_cast<uintptr_t>(x) & 15) == 0) && ((reinterpret_cast<uintptr_t>(codes) & 15) == 0);
@@ -75,12 +78,13 @@ __global__ __launch_bounds__(256) void mulaw_expand_kernel(const int64_t* __rest
                                                           int64_t n, int q, float C, const float* __restrict__ table) {
   extern __shared__ float s_table[];
   const bool have = table != nullptr;
-  if (have)
+  const bool staged = have && q <= kMuLawLdsLevels;
+  if (staged)
     for (int i = threadIdx.x; i < q; i += blockDim.x) s_table[i] = table[i];
   __syncthreads();
   const float mu = (float)(q - 1);
   const float logv = log1pf(mu * C);
-  const float* t = have ? s_table : nullptr;
+  const float* t = staged ? s_table : table;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   const int64_t n2 = n >> 1;
   const bool aligned = ((reinterpret_cast<uintptr_t>(x) & 7) == 0) && ((reinterpret_cast<uintptr_t>(codes) & 15) == 0);
@@ -111,8 +115,9 @@ extern "C" int mmk_mulaw_compress_f32_i64(const float* x, int64_t* codes, int64_
     return fail(MMK_ERR_INVALID, "mulaw_compress: bad arguments (n=%lld, q_levels=%d)", (long long)n, q_levels);
   int64_t blocks = (n / 4 + 255) / 256;
   blocks = blocks < 1 ? 1 : (blocks > 4096 ? 4096 : blocks);
-  hipLaunchKernelGGL(mulaw_compress_kernel, dim3((unsigned)blocks), dim3(256), (size_t)q_levels * sizeof(float),
-                     (hipStream_t)stream, x, codes, n, q_levels, compression, edges);
+  hipLaunchKernelGGL(mulaw_compress_kernel, dim3((unsigned)blocks), dim3(256),
+                     (size_t)(q_levels <= kMuLawLdsLevels ? q_levels : 1) * sizeof(float), (hipStream_t)stream, x, codes, n, q_levels,
+                     compression, edges);
   MMK_HIP(hipGetLastError());
   return MMK_OK;
 }
@@ -125,8 +130,9 @@ extern "C" int mmk_mulaw_expand_i64_f32(const int64_t* codes, float* x, int64_t 
     return fail(MMK_ERR_INVALID, "mulaw_expand: bad arguments (n=%lld, q_levels=%d)", (long long)n, q_levels);
   int64_t blocks = (n / 2 + 255) / 256;
   blocks = blocks < 1 ? 1 : (blocks > 4096 ? 4096 : blocks);
-  hipLaunchKernelGGL(mulaw_expand_kernel, dim3((unsigned)blocks), dim3(256), (size_t)q_levels * sizeof(float),
-                     (hipStream_t)stream, codes, x, n, q_levels, compression, table);
+  hipLaunchKernelGGL(mulaw_expand_kernel, dim3((unsigned)blocks), dim3(256),
+                     (size_t)(q_levels <= kMuLawLdsLevels ? q_levels : 1) * sizeof(float), (hipStream_t)stream, codes, x, n, q_levels,
+                     compression, table);
   MMK_HIP(hipGetLastError());
   return MMK_OK;
 }

@@ -15,6 +15,8 @@
 // time-indexed Addr (dilation queues, cond rows, int64 sample windows).
 #include <hip/hip_ext.h>
 
+#include <atomic>
+
 #include "mmk_common.h"
 
 namespace mmk {
@@ -296,11 +298,14 @@ __global__ void pack_rect_kernel(float* __restrict__ Wp, int k_chunks_total, int
   }
 }
 
+std::atomic<int64_t> g_pack_launches{0};   // weight re-packing launches since the library was loaded (mmk_pack_launch_count)
+
 int pack_rect(float* Wp, int k_chunks_total, int row0, int row_step, int n_rows, int chunk0, int K_real,
               const float* src, int64_t src_row_stride, int64_t src_col_stride, hipStream_t stream) {
   const int n_chunks = (K_real + 15) / 16;
   const int64_t total = (int64_t)n_rows * n_chunks * 16;
   if (total <= 0) return MMK_OK;
+  g_pack_launches.fetch_add(1, std::memory_order_relaxed);
   int blocks = (int)((total + 255) / 256);
   if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(pack_rect_kernel, dim3(blocks), dim3(256), 0, stream, Wp, k_chunks_total, row0, row_step,
@@ -319,6 +324,7 @@ __global__ void pack_bias_kernel(float* dst, int row0, int row_step, int n_rows,
 
 int pack_bias(float* dst, int row0, int row_step, int n_rows, const float* src, int accumulate, hipStream_t stream) {
   if (n_rows <= 0) return MMK_OK;
+  g_pack_launches.fetch_add(1, std::memory_order_relaxed);
   hipLaunchKernelGGL(pack_bias_kernel, dim3((n_rows + 255) / 256), dim3(256), 0, stream, dst, row0, row_step,
                      n_rows, src, accumulate);
   MMK_HIP(hipGetLastError());
@@ -328,6 +334,8 @@ int pack_bias(float* dst, int row0, int row_step, int n_rows, const float* src, 
 }  // namespace mmk
 
 // ---- exported building blocks -------------------------------------------------
+extern "C" int64_t mmk_pack_launch_count(void) { return mmk::g_pack_launches.load(std::memory_order_relaxed); }
+
 extern "C" int64_t mmk_packed_weight_floats(int32_t n_rows, int32_t k_cols) {
   return mmk::packed_floats(n_rows, k_cols);
 }

@@ -202,6 +202,7 @@ extern "C" int mmk_srnn_commit(mmk_srnn_plan* p, void* workspace, size_t workspa
   p->layout(carve);
   if (carve.used() > workspace_bytes)
     return fail(MMK_ERR_WORKSPACE, "srnn_commit: workspace of %zu bytes, %zu needed", workspace_bytes, carve.used());
+  MMK_HIP(hipStreamSynchronize(st));   // replays of the cached graph may still be queued: wait before destroying it
   p->gc.reset();
   MMK_HIP(hipMemsetAsync(workspace, 0, carve.used(), st));
   Binder& b = p->binder;

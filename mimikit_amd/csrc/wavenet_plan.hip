@@ -321,6 +321,7 @@ extern "C" int mmk_wavenet_commit(mmk_wavenet_plan* p, void* workspace, size_t w
   p->layout(carve);
   if (carve.used() > workspace_bytes)
     return fail(MMK_ERR_WORKSPACE, "wavenet_commit: workspace of %zu bytes, %zu needed", workspace_bytes, carve.used());
+  MMK_HIP(hipStreamSynchronize(st));   // replays of the cached graph may still be queued: wait before destroying it
   p->gc.reset();  // pointers inside a cached graph are stale now
   MMK_HIP(hipMemsetAsync(workspace, 0, carve.used(), st));
 

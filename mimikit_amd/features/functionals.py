@@ -13,8 +13,11 @@ here:
 * ``FileToSignal``, ``Normalize``, ``RemoveDC``, ``Compose``, ``Identity``: unit /
   elem_type carriers needed to build an ``IOSpec`` (dataset extraction itself is
   out of scope).
-* ``ISTFT`` / ``GLA`` are declared (they are the ``inv`` of STFT / MagSpec) but not
-  implemented yet.
+* ``ISTFT`` / ``GLA`` (:531-573, :609-646), the ``inv`` of STFT / MagSpec at the loop's tail, run on the HIP
+  kernels of ``csrc/istft.hip`` / ``spectral2048.hip``; GLA's parity is unpinned (torchaudio is not installed in the
+  build container).
+* float64 tensors are computed in fp32 on the device (the kernels are fp32; the reference computes in the input's
+  dtype, so float64 mu-law codes may differ from it for inputs within one fp32 ulp of a bin edge).
 """
 import abc
 import dataclasses as dtc

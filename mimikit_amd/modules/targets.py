@@ -65,4 +65,6 @@ class CategoricalSampler(nn.Module):
             return native.categorical_sample(rows, rows.shape[-1], False, 0., None, None).reshape(lead)
         t = as_tensor(temperature, logits).to(torch.float32).expand(*lead, 1).reshape(-1).contiguous()
         u = torch.rand(rows.shape[0], device=logits.device, dtype=torch.float32)
-        return native.categorical_sample(rows, rows.shape[-1], False, 0., t, u).reshape(lead)
+        out = native.categorical_sample(rows, rows.shape[-1], False, 0., t, u)
+        # torch.multinomial(.., 1) of 2-D logits is (B, 1) and the reference only reshapes > 2-D logits (:64-67)
+        return out.reshape(lead) if logits.dim() > 2 else (out.reshape(-1, 1) if logits.dim() == 2 else out.reshape(1))

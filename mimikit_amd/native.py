@@ -53,6 +53,7 @@ class S2SConfig(C.Structure):
 _SIGNATURES = {
     "mmk_abi_version": (i32, []),
     "mmk_last_error": (cp, []),
+    "mmk_pack_launch_count": (i64, []),
     "mmk_mulaw_compress_f32_i64": (i32, [vp, vp, i64, i32, f32, vp, vp]),
     "mmk_mulaw_expand_i64_f32": (i32, [vp, vp, i64, i32, f32, vp, vp]),
     "mmk_stft_n_frames": (i64, [i64, i32, i32, i32]),
@@ -182,13 +183,28 @@ def mulaw_expand(codes: torch.Tensor, q_levels: int, compression: float, table: 
     return out
 
 
+def _rows(x: torch.Tensor) -> torch.Tensor:
+    """(..., n) -> (rows, n) with unit stride along n and ONE stride between rows, without a copy where the layout already
+    is that (the length fix-up of STFT hands over a slice ``x[..., -keep:]`` of a contiguous tensor: rows keep their old
+    stride, and the kernels take a row stride)"""
+    if x.stride(-1) == 1 or x.shape[-1] == 1:
+        if x.dim() == 1:
+            return x.unsqueeze(0)
+        if x.dim() == 2:
+            return x
+        lead, st = x.shape[:-1], x.stride()[:-1]
+        if all(st[i] == st[i + 1] * lead[i + 1] for i in range(len(lead) - 1)):
+            return x.as_strided((int(torch.Size(lead).numel()), x.shape[-1]), (st[-1], 1), x.storage_offset())
+    return x.reshape(-1, x.shape[-1]).contiguous()
+
+
 def stft_mag(x: torch.Tensor, n_fft: int, hop: int, center: bool) -> torch.Tensor:
     """x: (..., n_samples) fp32 -> (..., n_frames, n_fft//2+1)"""
     require_device(x)
     if x.dtype != torch.float32:
         x = x.float()
     lead = x.shape[:-1]
-    x2 = x.reshape(-1, x.shape[-1]).contiguous()
+    x2 = _rows(x)
     n = x2.shape[-1]
     n_frames = lib().mmk_stft_n_frames(n, n_fft, hop, int(center))
     if n_frames <= 0:
@@ -210,7 +226,7 @@ def stft(x: torch.Tensor, n_fft: int, hop: int, center: bool, pad_mode: str, coo
     if x.dtype != torch.float32:
         x = x.float()
     lead = x.shape[:-1]
-    x2 = x.reshape(-1, x.shape[-1]).contiguous()
+    x2 = _rows(x)
     n = x2.shape[-1]
     n_frames = lib().mmk_stft_n_frames(n, n_fft, hop, int(center))
     if n_frames <= 0:
@@ -348,6 +364,18 @@ class _Plan:
         check(getattr(self._lib, self._prefix + "_commit")(self.handle, aligned, need, stream_ptr(self.device)),
               self._prefix + "_commit")
         self.workspace_bytes = need
+
+
+def pack_launch_count() -> int:
+    """weight re-packing kernels launched so far (diagnostic; see include/mmk.h)"""
+    return int(lib().mmk_pack_launch_count())
+
+
+def weights_token(module: torch.nn.Module):
+    """identity of a module's weights as a plan packed them: storage address, in-place version counter and shape of every
+    state_dict entry.  Optimiser steps and ``load_state_dict`` bump the version, ``.to(device)`` moves the storage, so an
+    unchanged token means the packed copy inside a committed plan is still current."""
+    return tuple((k, v.data_ptr(), v._version, tuple(v.shape)) for k, v in module.state_dict(keep_vars=True).items())
 
 
 def abs_ptr(view: torch.Tensor, t_first: int) -> int:

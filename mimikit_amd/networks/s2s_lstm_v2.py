@@ -156,7 +156,7 @@ class Seq2SeqLSTMNetwork(ARMWithHidden, nn.Module):
         self.output_length = lambda n: n
         self._plan = None
         self._plan_batch = 0
-        self._stale = True
+        self._weights_token = None
 
     # -- ARM properties -----------------------------------------------------------
     @property
@@ -241,11 +241,14 @@ class Seq2SeqLSTMNetwork(ARMWithHidden, nn.Module):
             self._plan = native.S2SPlan(self._describe(max(batch, 1)), device)
             self._plan_batch = max(batch, 1)
             rebuilt = True
-        if rebuilt or refresh_weights or self._stale:
+        # every call: a step keeps no state between calls, but the plan holds a re-packed copy of the weights, and eval
+        # forward / generate_step may follow training steps or a load_state_dict at any time (per-epoch validation)
+        token = native.weights_token(self)
+        if rebuilt or token != self._weights_token:
             sd = self.state_dict()
             self._plan.bind_state_dict(fold_weight_norm(sd) if any(k.endswith("_g") for k in sd) else sd)
             self._plan.commit()
-            self._stale = False
+            self._weights_token = token
 
     def _device_step(self, inputs: Tuple[torch.Tensor, ...]):
         native.require_device(*inputs)
@@ -281,4 +284,3 @@ class Seq2SeqLSTMNetwork(ARMWithHidden, nn.Module):
 
     def after_generate(self, final_outputs: Tuple[torch.Tensor, ...], batch_index) -> None:
         self.reset_hidden()
-        self._stale = True

@@ -152,6 +152,7 @@ class SampleRNN(ARMWithHidden, nn.Module):
         self.prompt_length = 0
         self._plan: Optional[native.SrnnPlan] = None
         self._plan_batch = 0
+        self._weights_token = None
         self._state_batch = 0
         self._next_t: Optional[int] = None
 
@@ -189,9 +190,8 @@ class SampleRNN(ARMWithHidden, nn.Module):
 
     # -- differentiable forward (training only) --------------------------------------
     def forward(self, inputs: Tuple):
-        if not self.training:
-            raise RuntimeError("SampleRNN.forward is the training graph; in eval mode use before_generate / "
-                               "generate_step / generate_block (HIP device)")
+        # mode-independent, as in the reference (:188-199): the teacher-forced graph over whole frames (training steps and
+        # the trainer's validation); generation goes through before_generate / generate_step / generate_block (HIP)
         fs0, prev = self.frame_sizes[0], None
         for tier, fs in zip(self.tiers[:-1], self.frame_sizes[:-1]):
             prev = tier((tuple(x[:, fs0 - fs:-fs] for x in inputs), prev))
@@ -253,9 +253,14 @@ class SampleRNN(ARMWithHidden, nn.Module):
             self._plan_batch = max(batch, 1)
             rebuilt = True
         if rebuilt or refresh_weights:
-            sd = self.state_dict()
-            self._plan.bind_state_dict(fold_weight_norm(sd) if self._config.weight_norm else sd)
-            self._plan.commit()
+            token = native.weights_token(self)
+            if rebuilt or token != self._weights_token:      # re-pack only when a parameter changed since the last commit
+                sd = self.state_dict()
+                self._plan.bind_state_dict(fold_weight_norm(sd) if self._config.weight_norm else sd)
+                self._plan.commit()
+                self._weights_token = token
+            else:
+                self._plan.reset()                           # hidden states back to h0, same packed weights
             self._next_t = None
 
     def _sampling(self, batch: int, n_steps: int, parameters: Dict):
@@ -298,7 +303,7 @@ class SampleRNN(ARMWithHidden, nn.Module):
             self._ensure_plan(batch, refresh_weights=True)
             self._state_batch = batch
         if t < self.prompt_length:
-            raise RuntimeError("steps inside the prompt are run by before_generate on the device")
+            return ()     # steps inside the prompt only advance the tiers (:254-255): before_generate did that on the device
         buf = torch.cat([window[:, -rf:], torch.zeros_like(window[:, :1])], dim=1)
         buf = (buf if buf.dtype == torch.int64 else buf.long()).contiguous()
         temp, uni = self._sampling(batch, 1, parameters)

@@ -238,15 +238,18 @@ def wavenet_generate_frames(sd: SD, prompt: torch.Tensor, n_steps: int, kernels,
 
 def wavenet_generate(sd: SD, prompt: torch.Tensor, cond: Sequence[torch.Tensor], n_steps: int, kernels, dilations,
                      min_temp: Optional[float] = 1e-4, temperature=None, uniforms=None, keep_logits: bool = False,
-                     **arch):
+                     forced: Optional[torch.Tensor] = None, **arch):
     """GenerateLoopV2.run's hot loop (loops/generate.py:195-219) around WaveNet.generate_step:
-    prompt + blanks, one full-window forward per step, in-place write."""
+    prompt + blanks, one full-window forward per step, in-place write.
+    ``forced`` (batch, prior + n_steps): teacher forcing for step-by-step checks of another implementation's output - every
+    step sees THAT history instead of the oracle's own picks (the returned indices are still the oracle's pick per step)."""
     rf = wavenet_rf(kernels, dilations)
     prior = prompt.size(1)
     idx = torch.cat([prompt, torch.zeros(prompt.size(0), n_steps, dtype=prompt.dtype)], dim=1)
+    hist = idx if forced is None else forced
     logits_log = []
     for s, t in enumerate(range(prior, prior + n_steps)):
-        window = (idx[:, t - rf:t], *[c[:, t - rf:t] for c in cond])
+        window = (hist[:, t - rf:t], *[c[:, t - rf:t] for c in cond])
         raw = wavenet_window_forward(sd, window, kernels, dilations, n_cond=len(cond), **arch)
         logits = mlp_logits(raw, min_temp)
         u = None if uniforms is None else uniforms[:, s]
@@ -361,14 +364,17 @@ class SampleRNNOracle:
         for t in range(self.rf, self.prompt_length):
             self.generate_step(prompt[:, t + offset - self.rf:t + offset], t)
 
-    def generate(self, prompt: torch.Tensor, n_steps: int, temperature=None, uniforms=None, keep_logits=False):
+    def generate(self, prompt: torch.Tensor, n_steps: int, temperature=None, uniforms=None, keep_logits=False, forced=None):
+        """``forced`` (batch, prior + n_steps): teacher forcing - every step sees that history instead of the oracle's own
+        picks (used to check another implementation's output step by step); the returned indices are the oracle's picks"""
         self.before_generate(prompt)
         prior = prompt.size(1)
         idx = torch.cat([prompt, torch.zeros(prompt.size(0), n_steps, dtype=prompt.dtype)], dim=1)
+        hist = idx if forced is None else forced
         logs = []
         for s, t in enumerate(range(prior, prior + n_steps)):
             u = None if uniforms is None else uniforms[:, s]
-            idx[:, t] = self.generate_step(idx[:, t - self.rf:t], t, temperature, u)
+            idx[:, t] = self.generate_step(hist[:, t - self.rf:t], t, temperature, u)
             if keep_logits:
                 logs.append(self.last_raw)
         self.reset_hidden()

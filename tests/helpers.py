@@ -112,3 +112,27 @@ def margin_ok(raw, min_gap=5e-5):
     ~1e-6; the committed fixtures have a smallest gap of 1.8e-4)"""
     top = torch.topk(T(raw)[..., :-1], 2, dim=-1).values
     return (top[..., 0] - top[..., 1]) > min_gap
+
+
+def sampled_picks_ok(raw, temperature, uniforms, picks, min_temp=1e-4, tol=2e-5):
+    """Sampled decode, checked step by step: `raw` (B, n, q+1) are the oracle's head outputs for the history the device
+    actually produced (teacher forcing), `picks` (B, n) the device's classes, drawn by inverting the CDF of
+    softmax(logits / T) at `uniforms` (B, n).  A pick k is right iff  cdf[k-1] <= u * total < cdf[k]; device and oracle
+    logits differ by fp32 re-association (~1e-6 relative, 2e-4 is the stated logit tolerance), which moves every CDF
+    step by about that fraction of the total, so a draw within `tol` * total of a step may fall on either side of it
+    and nowhere else.  Returns (ok (B, n) bool, exact (B, n) bool = inside the interval with no tolerance)."""
+    from oracle import torch_ref as O
+    raw = T(raw).double()
+    logits = O.mlp_logits(raw.float(), min_temp).double()
+    t = torch.as_tensor(temperature, dtype=torch.float64).reshape(-1, 1, 1)
+    l = logits / t
+    e = torch.exp(l - l.max(-1, keepdim=True).values)
+    cdf = torch.cumsum(e, -1)
+    total = cdf[..., -1]
+    target = T(uniforms).double() * total
+    k = T(picks).long()
+    hi = cdf.gather(-1, k.unsqueeze(-1)).squeeze(-1)
+    lo = hi - e.gather(-1, k.unsqueeze(-1)).squeeze(-1)
+    exact = (lo <= target) & (target < hi)
+    ok = (lo - tol * total <= target) & (target <= hi + tol * total)
+    return ok, exact

@@ -492,3 +492,36 @@ def test_sampler_module_shapes(device):
         assert out.shape == (3, 1) and out.dtype == torch.int64
     s.train()
     assert s(logits) is logits
+
+
+def test_stft_takes_row_strided_views_without_a_copy(device):
+    """the length fix-up hands the kernel a slice x[..., -keep:] of a contiguous tensor: rows keep their stride and nothing
+    is copied on the way in (mmk_stft_mag_f32 takes a row stride); result equals the one on a packed copy and the oracle"""
+    from mimikit_amd import native
+    x = torch.randn(6, 22050 + 77, generator=torch.Generator().manual_seed(3))
+    xd = x.to(device)
+    view = xd[:, 13:13 + 22050]
+    rows = native._rows(view)
+    assert rows.data_ptr() == view.data_ptr() and rows.stride(0) == xd.stride(0)          # no copy
+    rows3 = native._rows(xd.reshape(2, 3, -1)[..., 5:])
+    assert rows3.shape == (6, 22050 + 72) and rows3.data_ptr() == xd.data_ptr() + 20
+    for n_fft, hop in ((1024, 256), (2048, 512), (512, 128)):
+        f = mmk.MagSpec(n_fft, hop, center=False)
+        a = f(view)
+        b = f(view.contiguous())
+        assert torch.equal(a, b)
+        want = O.magspec(x[:, 13:13 + 22050], n_fft, hop, False)
+        assert float((a.cpu() - want).abs().max()) <= 2e-5 * float(want.abs().max())
+        c = mmk.STFT(n_fft, hop, coordinate="car", center=True)(view)
+        assert torch.equal(c, mmk.STFT(n_fft, hop, coordinate="car", center=True)(view.contiguous()))
+
+
+def test_mulaw_many_levels(device):
+    """q_levels up to 65536: tables beyond 32 KiB are read from global memory instead of LDS"""
+    x = torch.rand(3, 5000, generator=torch.Generator().manual_seed(4)) * 2 - 1
+    for q in (4096, 65536):
+        codes = mmk.MuLawCompress(q)(x.to(device)).cpu()
+        want = O.mulaw_compress(x, q)
+        assert int((codes - want).abs().max()) <= 1 and float((codes == want).float().mean()) > 0.999
+        back = mmk.MuLawExpand(q)(codes.to(device)).cpu()
+        assert torch.allclose(back, O.mulaw_expand(codes, q), rtol=1e-5, atol=1e-7)
