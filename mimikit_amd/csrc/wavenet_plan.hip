@@ -12,6 +12,7 @@
 #include <stdlib.h>
 
 #include "plan_util.h"
+#include "wavenet_chain.h"
 #include "wavenet_persist.h"
 #include "wavenet_prefill.h"
 
@@ -78,10 +79,16 @@ struct mmk_wavenet_plan {
   int32_t* err_flag = nullptr;
   unsigned* xcd_count = nullptr;
   bool xcd_local = false;       // one clip group per XCD, hand-offs through the XCD's L2 (verified in-kernel)
+  // one hand-off per layer (wavenet_chain.hip): gate matrices with the K segments [tap 0 | tap 1 | tap 1 . W_res of the
+  // layer below], pre-multiplied at commit
+  bool chain = false;
+  std::vector<PackedLinear> Ac;
+  WnChainIter* iter_tab = nullptr;
+  float* compose_scratch = nullptr;   // (2C, C) product + 2C bias terms of one layer
 
   void layout_persistent(Carver& c) {
     layer_tab = c.take<WnLayerTab>(L);
-    const int64_t n_h = (int64_t)Gc * 16 * C, n_y = 2 * n_h, n_s = (int64_t)Gc * 16 * S,
+    const int64_t n_h = (int64_t)Gc * 2 * 16 * C, n_y = n_h, n_s = (int64_t)Gc * 16 * S,   // y, h: two generations each
                   n_hid = (int64_t)Gc * 16 * cfg.mlp_hidden, n_l = (int64_t)Gc * 16 * n_logits_pad, n_i = (int64_t)Gc * 16;
     gran_words = n_h + n_y + n_s + n_hid + n_l + n_i + 8 + 2;   // + XCD registration counters + sticky error word
     unsigned long long* base = c.take<unsigned long long>(gran_words);
@@ -97,6 +104,11 @@ struct mmk_wavenet_plan {
     cproj = C1 > 0 ? c.take<float>((int64_t)Bmax * kCondBlock * C1) : nullptr;
     condall = C1 > 0 ? c.take<float>((int64_t)Bmax * kCondBlock * L * 2 * C) : nullptr;
     if (C1 > 0) cond_all.carve(c, false);
+    if (chain) {
+      for (auto& pl : Ac) pl.carve(c, true);
+      iter_tab = c.take<WnChainIter>(L + 1);
+      compose_scratch = c.take<float>((int64_t)2 * C * C + 2 * C);
+    }
     zero_pad = c.take<float>(64);
     pf_P = round_up(rf, 32);
     pf_h[0] = c.take<float>((int64_t)Bmax * pf_P * C);
@@ -139,6 +151,29 @@ struct mmk_wavenet_plan {
     return hist_slot(l + 1, 0);
   }
 };
+
+// out[n][k] = sum_c W1[n][c] R[c][k] and out_bias[n] = sum_c W1[n][c] r[c], with W1[n][c] = wd[(n C + c) 2 + 1] the tap-1
+// slice of a k = 2 dilated convolution (2C rows) and R, r the residual 1x1 convolution of the layer below.  Accumulated
+// in fp64 and rounded once: the pre-multiplied matrix is as close to the exact product as fp32 allows.
+__global__ __launch_bounds__(256) void compose_tap1_res_kernel(const float* __restrict__ wd, const float* __restrict__ wr,
+                                                              const float* __restrict__ br, float* __restrict__ out,
+                                                              float* __restrict__ out_bias, int C) {
+  const int64_t total = (int64_t)2 * C * C;
+  for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total + 2 * C; idx += (int64_t)gridDim.x * blockDim.x) {
+    if (idx < total) {
+      const int n = (int)(idx / C), k = (int)(idx % C);
+      double acc = 0.0;
+      for (int c = 0; c < C; ++c) acc += (double)wd[((int64_t)n * C + c) * 2 + 1] * (double)wr[(int64_t)c * C + k];
+      out[idx] = (float)acc;
+    } else {
+      const int n = (int)(idx - total);
+      double acc = 0.0;
+      if (br)
+        for (int c = 0; c < C; ++c) acc += (double)wd[((int64_t)n * C + c) * 2 + 1] * (double)br[c];
+      out_bias[n] = (float)acc;
+    }
+  }
+}
 
 static int derive(mmk_wavenet_plan* p) {
   const mmk_wavenet_config& c = p->cfg;
@@ -231,6 +266,15 @@ static int derive(mmk_wavenet_plan* p) {
     // (16 columns x Mg clips <= 64 * C/32 threads)
     const int mg_cap = 16;                           // one MFMA row tile; one epilogue element per I/O thread
     int gc = (p->Bmax + 7) / 8;                      // aim at 8 clips per group
+    // the one-hand-off kernel (wavenet_chain.hip) takes groups of at most 4 clips: prefer those when the grid allows it
+    // ... and it pays where the XCD's L2 (4 MiB) holds its weights: the pre-multiplied matrices are a third more bytes,
+    // and a layer set that has to come over the fabric every step is bound by that stream (measured, DESIGN.md 5.2:
+    // cfg 4 streams 62 MB per XCD and step at ~0.9 TB/s = 70 us, more than the two-hand-off kernel takes)
+    const char* chenv = getenv("MMK_WN_CHAIN");
+    const bool chain_fits_l2 = (int64_t)p->L * 8 * p->C * p->C * 4 <= ((int64_t)3 << 20);
+    bool chain_wanted = p->L >= 2 && (chenv ? chenv[0] != '0' : chain_fits_l2);
+    for (int l = 0; l + 1 < p->L; ++l) chain_wanted = chain_wanted && p->has_res[l];
+    if (chain_wanted && (p->Bmax + 3) / 4 <= gc_max) gc = (p->Bmax + 3) / 4;
     const char* genv = getenv("MMK_WN_GROUPS");
     if (genv && atoi(genv) > 0) gc = atoi(genv);
     if (gc < (p->Bmax + mg_cap - 1) / mg_cap) gc = (p->Bmax + mg_cap - 1) / mg_cap;
@@ -268,6 +312,26 @@ static int derive(mmk_wavenet_plan* p) {
         if (wn_persist_lds_bytes(probe) > 160 * 1024) p->persistent = false;
       }
       if (p->C1 > 0) p->cond_all.set_geometry(p->L * 2 * p->C, {p->C1});
+    }
+  }
+  // one hand-off per layer: every layer but the last needs its residual 1x1 (it is folded into the next layer's tap-1
+  // product), groups of at most 4 clips (4x4 MFMA blocks)
+  p->chain = false;
+  p->Ac.clear();
+  if (p->persistent) {
+    const char* cenv = getenv("MMK_WN_CHAIN");
+    const bool fits_l2 = (int64_t)p->L * 8 * p->C * p->C * 4 <= ((int64_t)3 << 20);
+    bool ok2 = (cenv ? cenv[0] != '0' : fits_l2) && wn_chain_supported(p->C, p->Mg, p->L);
+    for (int l = 0; l + 1 < p->L; ++l) ok2 = ok2 && p->has_res[l];
+    if (ok2) {
+      WnChainArgs probe = {};
+      probe.C = p->C; probe.H1 = c.mlp_hidden; probe.n_logits_pad = p->n_logits_pad; probe.L = p->L; probe.Gn = p->Gn;
+      ok2 = wn_chain_lds_bytes(probe) <= 160 * 1024;
+    }
+    if (ok2) {
+      p->chain = true;
+      p->Ac.resize(p->L);
+      for (auto& pl : p->Ac) pl.set_geometry(2 * p->C, {p->C, p->C, p->C});
     }
   }
   return MMK_OK;
@@ -424,6 +488,46 @@ extern "C" int mmk_wavenet_commit(mmk_wavenet_plan* p, void* workspace, size_t w
       }
     }
   }
+  // one-hand-off-per-layer mode: gate matrices [tap 0 | tap 1 | tap 1 . W_res(l-1)], bias + tap 1 . b_res(l-1)
+  if (p->chain) {
+    for (int l = 0; l < L; ++l) {
+      const std::string ly = "layers." + std::to_string(l) + ".";
+      const float* wd = b.need(ly + "conv_dil.0.0.weight", (int64_t)2 * C * C * 2);
+      const float* bd = bias ? b.need(ly + "conv_dil.0.0.bias", 2 * C) : nullptr;
+      PackedLinear& A = p->Ac[l];
+      if (!wd) continue;
+      for (int jt = 0; jt < 2; ++jt) {
+        MMK_TRY(pack_rect(A.Wp, A.k_chunks, 0, 2, C, A.seg_chunk0[jt], C, wd + jt, (int64_t)C * 2, 2, st));
+        MMK_TRY(pack_rect(A.Wp, A.k_chunks, 1, 2, C, A.seg_chunk0[jt], C, wd + (int64_t)C * C * 2 + jt, (int64_t)C * 2, 2, st));
+      }
+      if (bd) {
+        MMK_TRY(pack_bias(A.bias, 0, 2, C, bd, 0, st));
+        MMK_TRY(pack_bias(A.bias, 1, 2, C, bd + C, 0, st));
+      }
+      if (p->n_cond == 1 && bias) {
+        const float* b1 = b.need(ly + "conv_1x1.0.0.bias", 2 * C);
+        if (b1) {
+          MMK_TRY(pack_bias(A.bias, 0, 2, C, b1, 1, st));
+          MMK_TRY(pack_bias(A.bias, 1, 2, C, b1 + C, 1, st));
+        }
+      }
+      if (l >= 1) {
+        const std::string lp = "layers." + std::to_string(l - 1) + ".";
+        const float* wr = b.need(lp + "conv_res.weight", (int64_t)C * C);
+        const float* br = bias ? b.need(lp + "conv_res.bias", C) : nullptr;
+        if (wr) {
+          float* prod = p->compose_scratch;
+          float* pbias = prod + (int64_t)2 * C * C;
+          hipLaunchKernelGGL(compose_tap1_res_kernel, dim3(512), dim3(256), 0, st, wd, wr, br, prod, pbias, C);
+          MMK_HIP(hipGetLastError());
+          MMK_TRY(pack_rect(A.Wp, A.k_chunks, 0, 2, C, A.seg_chunk0[2], C, prod, C, 1, st));
+          MMK_TRY(pack_rect(A.Wp, A.k_chunks, 1, 2, C, A.seg_chunk0[2], C, prod + (int64_t)C * C, C, 1, st));
+          MMK_TRY(pack_bias(A.bias, 0, 2, C, pbias, 1, st));
+          MMK_TRY(pack_bias(A.bias, 1, 2, C, pbias + C, 1, st));
+        }
+      }
+    }
+  }
   // head
   if (c.head_kind == 0) {
     const std::string hb = "output_modules.0.estimator.0.fc.";
@@ -461,6 +565,22 @@ extern "C" int mmk_wavenet_commit(mmk_wavenet_plan* p, void* workspace, size_t w
       for (int l = 1; l < L; ++l) { tab[l].A_wp = tab[0].A_wp; tab[l].B_wp = tab[0].B_wp; }
     }
     MMK_HIP(hipMemcpyAsync(p->layer_tab, tab.data(), sizeof(WnLayerTab) * L, hipMemcpyHostToDevice, st));
+    std::vector<WnChainIter> it(L + 1);
+    if (p->chain) {
+      for (int i = 0; i <= L; ++i) {
+        const int la = i < L ? i : 0;
+        it[i].A_wp = p->Ac[la].Wp;
+        it[i].A_bias = p->Ac[la].bias;
+        it[i].B_wp = i >= 1 ? p->Bm[i - 1].Wp : nullptr;
+        it[i].B_bias = i >= 1 ? p->Bm[i - 1].bias : nullptr;
+        it[i].ring_offset = p->ring_offset[la];
+        it[i].dil = p->dil[la];
+        it[i].ring_mask = p->ring_mask[la];
+        it[i].prev_has_res = (i >= 1 && p->has_res[i - 1]) ? 1 : 0;
+        it[i].pad_ = 0;
+      }
+      MMK_HIP(hipMemcpyAsync(p->iter_tab, it.data(), sizeof(WnChainIter) * (L + 1), hipMemcpyHostToDevice, st));
+    }
     MMK_HIP(hipStreamSynchronize(st));   // `tab` is host-local
   }
   if (!p->cap_stream) MMK_HIP(hipStreamCreateWithFlags(&p->cap_stream, hipStreamNonBlocking));
@@ -608,6 +728,31 @@ static int run_persistent(mmk_wavenet_plan* p, const WnCall& call, int64_t tau0,
     }
     // hand-off words are zeroed before EVERY launch (epochs restart at 1); the error word after them is sticky
     MMK_HIP(hipMemsetAsync(p->gran_h, 0, (size_t)(p->gran_words - 2) * sizeof(unsigned long long), st));
+    const char* stamp_env = getenv("MMK_WN_STAMPS");
+    if (p->chain && with_head) {
+      WnChainArgs k = {};
+      k.B = call.M; k.Gc = p->Gc; k.Gn = p->Gn; k.Mg = p->Mg;
+      k.L = p->L; k.C = p->C; k.C1 = p->C1;
+      k.q_levels = c.q_levels; k.H1 = c.mlp_hidden; k.n_classes = c.out_dim; k.n_logits_pad = p->n_logits_pad;
+      k.learn_temp = c.learn_temp; k.min_temp = c.min_temp;
+      k.xcd_local = p->xcd_local ? 1 : 0;
+      k.t0 = tau_b + 1; k.n_steps = nb;
+      k.iters = p->iter_tab; k.ring_floats_per_wg = p->ring_floats_per_wg;
+      k.emb = p->emb; k.idx = (int64_t*)call.in0; k.idx_rs = call.in0_rs;
+      k.condall = p->condall; k.cond_steps = p->kCondBlock; k.zeros = p->zero_pad;
+      k.fc0_wp = p->mlp[0].Wp; k.fc0_bias = p->mlp[0].bias; k.fc2_wp = p->mlp[1].Wp; k.fc2_bias = p->mlp[1].bias;
+      k.temperature = call.temperature;
+      k.uniforms = call.uniforms ? call.uniforms + done : nullptr;
+      k.uni_ld = call.uni_ld;
+      k.logits_out = p->logits; k.logits_ld = p->logits_ld;
+      k.gran_h = p->gran_h; k.gran_y = p->gran_y; k.gran_skip = p->gran_skip; k.gran_hid = p->gran_hid;
+      k.gran_logit = p->gran_logit; k.gran_idx = p->gran_idx;
+      k.h_rings = p->h_rings; k.err_flag = p->err_flag; k.xcd_count = p->xcd_count;
+      k.stamps = (stamp_env && stamp_env[0] == '1') ? reinterpret_cast<unsigned long long*>(p->tau + 8) : nullptr;
+      MMK_TRY(launch_wavenet_chain(k, st));
+      done += nb;
+      continue;
+    }
     WnPersistArgs a = {};
     a.B = call.M; a.Gc = p->Gc; a.Gn = p->Gn; a.Mg = p->Mg;
     a.L = p->L; a.C = p->C; a.S = p->S; a.C1 = p->C1;
@@ -836,7 +981,7 @@ extern "C" int mmk_wavenet_profile_steps(mmk_wavenet_plan* p, int32_t batch, voi
   return rc;
 }
 
-extern "C" int mmk_wavenet_mode(const mmk_wavenet_plan* p) { return (p && p->persistent) ? 1 : 0; }
+extern "C" int mmk_wavenet_mode(const mmk_wavenet_plan* p) { return (p && p->persistent) ? (p->chain ? 2 : 1) : 0; }
 
 extern "C" int mmk_wavenet_sync_status(mmk_wavenet_plan* p, mmk_stream_t stream) {
   if (!p) return fail(MMK_ERR_INVALID, "wavenet_sync_status: null plan");
@@ -852,6 +997,14 @@ extern "C" int mmk_wavenet_sync_status(mmk_wavenet_plan* p, mmk_stream_t stream)
     if (senv && senv[0] == '1') {
       unsigned long long st[24];
       MMK_HIP(hipMemcpy(st, p->tau + 8, sizeof(st), hipMemcpyDeviceToHost));
+      if (p->chain) {
+        fprintf(stderr, "[mmk stamps] last chain launch, I/O wave 0 of workgroup 1, totals in ms: wait products=%.3f; epilogues + publish=%.3f; "
+                        "ring store=%.3f; wait y/h=%.3f; head=%.3f [skip wait + fc0=%.3f]; step start=%.3f | matrix wave 0: requests=%.3f; "
+                        "operands + MFMA=%.3f; B1 + small operands=%.3f; B1b + second half=%.3f; wait B4=%.3f; shader clock=%.0f MHz\n",
+                st[0] * 1e-5, st[1] * 1e-5, st[2] * 1e-5, st[3] * 1e-5, st[6] * 1e-5, st[16] * 1e-5, st[7] * 1e-5, st[8] * 1e-5, st[9] * 1e-5,
+                st[10] * 1e-5, st[11] * 1e-5, st[12] * 1e-5, st[15] ? 100.0 * (double)st[14] / (double)st[15] : 0.0);
+        return MMK_OK;
+      }
       const char* names[7] = {"wait phase A", "epilogue A + publish", "wait y", "wait phase B", "epilogue B + publish", "wait h'", "head"};
       const int slot[7] = {0, 1, 2, 3, 4, 5, 6};
       fprintf(stderr, "[mmk stamps] last persistent launch, I/O wave 0 of workgroup 1, totals in ms:");

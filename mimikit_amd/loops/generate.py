@@ -106,6 +106,16 @@ class _ArrayPromptLoader:
             yield [np.asarray(chunk, dtype=np.int32), *feats]
 
 
+def _same_device(a, b) -> bool:
+    a, b = torch.device(a), torch.device(b)
+    if a.type != b.type:
+        return False
+    if a.type != "cuda":
+        return True
+    cur = torch.cuda.current_device()
+    return (cur if a.index is None else a.index) == (cur if b.index is None else b.index)
+
+
 class GenerateLoopV2:
     @dtc.dataclass
     class Config(Config):
@@ -165,11 +175,14 @@ class GenerateLoopV2:
         self._was_training = net.training
         net.eval()
         self.device = default_device()
-        net.to(self.device)
+        self._moved = not _same_device(self._initial_device, self.device)
+        if self._moved:
+            net.to(self.device)     # (an unconditional .to() re-flattens nn.RNN weights into new storage every time)
         torch.set_grad_enabled(False)
 
     def teardown(self):
-        self.network.to(self._initial_device)
+        if self._moved:
+            self.network.to(self._initial_device)
         if self._was_training:
             self.network.train()
         torch.set_grad_enabled(True)

@@ -437,6 +437,11 @@ class WaveNetPlan(_Plan):
     def persistent(self) -> bool:
         return bool(self._lib.mmk_wavenet_mode(self.handle))
 
+    @property
+    def chain(self) -> bool:
+        """persistent mode with one hand-off per layer (csrc/wavenet_chain.hip)"""
+        return self._lib.mmk_wavenet_mode(self.handle) == 2
+
     def sync_status(self):
         """wait for the stream and raise if a hand-off inside the persistent kernel timed out"""
         check(self._lib.mmk_wavenet_sync_status(self.handle, stream_ptr(self.device)), "mmk_wavenet_sync_status")

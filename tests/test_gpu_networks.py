@@ -492,15 +492,18 @@ def _cond_net(seed=21):
     return net, sd, arch
 
 
-MODES = {"persistent_xcd": {}, "persistent_agent": {"MMK_WN_XCD_LOCAL": "0"}, "persistent_tiles": {"MMK_WN_SMALL": "0"},
-         "persistent_step_warmup": {"MMK_WN_PREFILL": "0"}, "launches": {"MMK_WN_PERSISTENT": "0"}}
+MODES = {"persistent_xcd": {}, "persistent_agent": {"MMK_WN_XCD_LOCAL": "0"}, "persistent_tiles": {"MMK_WN_SMALL": "0", "MMK_WN_CHAIN": "0"},
+         "persistent_step_warmup": {"MMK_WN_PREFILL": "0"}, "launches": {"MMK_WN_PERSISTENT": "0"},
+         "two_handoffs_xcd": {"MMK_WN_CHAIN": "0"}, "two_handoffs_agent": {"MMK_WN_CHAIN": "0", "MMK_WN_XCD_LOCAL": "0"},
+         "two_handoffs_step_warmup": {"MMK_WN_CHAIN": "0", "MMK_WN_PREFILL": "0"}}
 
 
 @pytest.mark.parametrize("mode", list(MODES))
 def test_wavenet_modes_agree_with_oracle(device, mode, monkeypatch):
-    """the persistent kernel (XCD-local and agent-scope hand-offs, 4x4 MFMA blocks and 16-row tiles, warm-up as a
-    prefill and step by step) and the per-layer launch path all reproduce the oracle: conditioned net, batch 5 (ragged clip groups), prompt longer than rf, 70 steps, greedy + sampled"""
-    for k in ("MMK_WN_XCD_LOCAL", "MMK_WN_PERSISTENT", "MMK_WN_GROUPS", "MMK_WN_SMALL", "MMK_WN_PREFILL"):
+    """the persistent kernels - one hand-off per layer (wavenet_chain.hip) and two (wavenet_persist.hip), XCD-local and
+    agent-scope hand-offs, 4x4 MFMA blocks and 16-row tiles, warm-up as a prefill and step by step - and the per-layer launch
+    path all reproduce the oracle: conditioned net, batch 5 (ragged clip groups), prompt longer than rf, 70 steps, greedy + sampled"""
+    for k in ("MMK_WN_XCD_LOCAL", "MMK_WN_PERSISTENT", "MMK_WN_GROUPS", "MMK_WN_SMALL", "MMK_WN_PREFILL", "MMK_WN_CHAIN"):
         monkeypatch.delenv(k, raising=False)
     for k, v in MODES[mode].items():
         monkeypatch.setenv(k, v)
@@ -515,6 +518,7 @@ def test_wavenet_modes_agree_with_oracle(device, mode, monkeypatch):
     net.generate_block((idx, cond.to(device)), prompt.size(1), n)
     net.after_generate((idx,), None)
     assert net._plan.persistent == (mode != "launches")
+    assert net._plan.chain == (mode in ("persistent_xcd", "persistent_agent", "persistent_step_warmup"))
     ok = H.margin_ok(raw.numpy())
     first_bad = (~ok).float().cumsum(1) > 0
     same = idx.cpu()[:, prompt.size(1):] == want[:, prompt.size(1):]
@@ -548,12 +552,16 @@ def _wide_net(C, cond_dim, seed):
     return net, sd, arch
 
 
-@pytest.mark.parametrize("C,B,env", [(96, 3, {}), (128, 72, {}), (128, 37, {"MMK_WN_XCD_LOCAL": "0"}), (256, 40, {})])
+@pytest.mark.parametrize("C,B,env", [(96, 3, {}), (128, 72, {}), (128, 37, {"MMK_WN_XCD_LOCAL": "0"}), (256, 40, {}),
+                                     (96, 3, {"MMK_WN_CHAIN": "0"}), (128, 37, {"MMK_WN_XCD_LOCAL": "0", "MMK_WN_CHAIN": "0"}), (160, 30, {"MMK_WN_CHAIN": "1"}), (224, 13, {"MMK_WN_XCD_LOCAL": "0", "MMK_WN_CHAIN": "1"}), (64, 32, {}),
+                                     (256, 27, {"MMK_WN_CHAIN": "1"})])
 def test_wavenet_persistent_kernel_shapes(device, monkeypatch, C, B, env):
-    """other instantiations of the persistent kernel against the oracle: 96 channels (2 K-chunks per matrix wave,
+    """other instantiations of the persistent kernels against the oracle: 96 channels (2 K-chunks per matrix wave,
     3 matrix waves), 128 channels with 9 clips per group (16-row MFMA tiles, two poll rounds per hand-off),
-    agent-scope groups with a ragged last group, 256 channels with 5 clips per group"""
-    for k in ("MMK_WN_XCD_LOCAL", "MMK_WN_PERSISTENT", "MMK_WN_GROUPS", "MMK_WN_SMALL", "MMK_WN_PREFILL"):
+    agent-scope groups with a ragged last group, 256 channels with 5 clips per group; the one-hand-off kernel at 96 / 160 /
+    224 / 64 / 256 channels (3 / 5 / 7 / 2 / 8 K-chunks per matrix wave, odd counts split 2 + 1 ... between the two
+    weight pieces), full and ragged groups of up to 4 clips, XCD-local and agent-scope"""
+    for k in ("MMK_WN_XCD_LOCAL", "MMK_WN_PERSISTENT", "MMK_WN_GROUPS", "MMK_WN_SMALL", "MMK_WN_PREFILL", "MMK_WN_CHAIN"):
         monkeypatch.delenv(k, raising=False)
     for k, v in env.items():
         monkeypatch.setenv(k, v)
@@ -626,6 +634,7 @@ def test_before_generate_repacks_only_changed_weights(device):
     assert torch.equal(run_loop(net, (prompt,), 24)[0].cpu(), out1)
     # SampleRNN: same contract, and the hidden state is reset without a repack
     snet, _, _ = H.srnn("gru")
+    snet.to(device)               # (a network that lives on the host is moved, hence re-packed, by every loop run)
     gs = H.golden("srnn.npz")
     a = run_loop(snet, (H.T(gs["gru_prompt"]),), 40, parameters=None)[0].cpu()
     n1 = native.pack_launch_count()
