@@ -13,6 +13,7 @@
 
 #include "plan_util.h"
 #include "wavenet_chain.h"
+#include "wavenet_pipe.h"
 #include "wavenet_persist.h"
 #include "wavenet_prefill.h"
 
@@ -68,6 +69,7 @@ struct mmk_wavenet_plan {
   unsigned long long *gran_h = nullptr, *gran_y = nullptr, *gran_skip = nullptr, *gran_hid = nullptr,
                      *gran_logit = nullptr, *gran_idx = nullptr;
   int64_t gran_words = 0;       // contiguous block [gran_h .. gran_idx] + err word, zeroed before every launch
+  int64_t pipe_gran_words = 0;  // the pipelined kernel's extra exchange buffers (their own block)
   float* h_rings = nullptr;     // per workgroup: past inputs of every layer (the delayed tap reads them)
   float* cproj = nullptr;       // (Bmax, kCondBlock, C1) conditioning after its LinearIO
   float* condall = nullptr;     // (Bmax, kCondBlock, L, 2C) every layer's conditioning product, packed gate order
@@ -82,6 +84,10 @@ struct mmk_wavenet_plan {
   // one hand-off per layer (wavenet_chain.hip): gate matrices with the K segments [tap 0 | tap 1 | tap 1 . W_res of the
   // layer below], pre-multiplied at commit
   bool chain = false;
+  // layers spread over the XCDs, weights resident on chip, clip groups pipelined through the stages (wavenet_pipe.hip)
+  bool pipe = false;
+  int pipe_nit = 0;
+  unsigned long long *px_yl = nullptr, *px_hl = nullptr, *px_hown = nullptr, *px_yx = nullptr, *px_hx = nullptr, *px_skipfwd = nullptr;
   std::vector<PackedLinear> Ac;
   WnChainIter* iter_tab = nullptr;
   float* compose_scratch = nullptr;   // (2C, C) product + 2C bias terms of one layer
@@ -100,11 +106,23 @@ struct mmk_wavenet_plan {
     gran_idx = gran_logit + (base ? n_l : 0);
     xcd_count = reinterpret_cast<unsigned*>(gran_idx + (base ? n_i : 0));
     err_flag = reinterpret_cast<int32_t*>(gran_idx + (base ? n_i + 8 : 0));
-    h_rings = c.take<float>((int64_t)Gc * Gn * ring_floats_per_wg);
+    if (pipe) {   // stage-local and stage-to-stage exchange buffers (see wavenet_pipe.h), zeroed with the block above: re-take it
+      const int64_t n_loc = (int64_t)8 * Gc * 2 * 16 * C, n_own = (int64_t)8 * Gc * 16 * C, n_x = (int64_t)Gc * 2 * 16 * C;
+      const int64_t extra = 2 * n_loc + n_own + 3 * n_x;
+      unsigned long long* more = c.take<unsigned long long>(extra);   // directly behind the block above (both 256-byte aligned sizes)
+      px_yl = more;
+      px_hl = px_yl + (more ? n_loc : 0);
+      px_hown = px_hl + (more ? n_loc : 0);
+      px_yx = px_hown + (more ? n_own : 0);
+      px_hx = px_yx + (more ? n_x : 0);
+      px_skipfwd = px_hx + (more ? n_x : 0);
+      pipe_gran_words = extra;
+    }
+    h_rings = c.take<float>((int64_t)(pipe ? 8 : Gc) * Gn * ring_floats_per_wg);
     cproj = C1 > 0 ? c.take<float>((int64_t)Bmax * kCondBlock * C1) : nullptr;
     condall = C1 > 0 ? c.take<float>((int64_t)Bmax * kCondBlock * L * 2 * C) : nullptr;
     if (C1 > 0) cond_all.carve(c, false);
-    if (chain) {
+    if (chain || pipe) {
       for (auto& pl : Ac) pl.carve(c, true);
       iter_tab = c.take<WnChainIter>(L + 1);
       compose_scratch = c.take<float>((int64_t)2 * C * C + 2 * C);
@@ -321,7 +339,8 @@ static int derive(mmk_wavenet_plan* p) {
   if (p->persistent) {
     const char* cenv = getenv("MMK_WN_CHAIN");
     const bool fits_l2 = (int64_t)p->L * 8 * p->C * p->C * 4 <= ((int64_t)3 << 20);
-    bool ok2 = (cenv ? cenv[0] != '0' : fits_l2) && wn_chain_supported(p->C, p->Mg, p->L);
+    const char* pforce = getenv("MMK_WN_PIPE");
+    bool ok2 = (cenv ? cenv[0] != '0' : fits_l2) && wn_chain_supported(p->C, p->Mg, p->L) && !(pforce && pforce[0] == '1');
     for (int l = 0; l + 1 < p->L; ++l) ok2 = ok2 && p->has_res[l];
     if (ok2) {
       WnChainArgs probe = {};
@@ -332,6 +351,49 @@ static int derive(mmk_wavenet_plan* p) {
       p->chain = true;
       p->Ac.resize(p->L);
       for (auto& pl : p->Ac) pl.set_geometry(2 * p->C, {p->C, p->C, p->C});
+    }
+  }
+  // Layer sets that do not fit an XCD's L2: spread the LAYERS over the XCDs (weights resident on chip) and pipeline the
+  // clip groups through them (wavenet_pipe.hip).  Needs the same structure as the chain kernel, at most 8 groups of 4
+  // clips, at most 4 iterations per XCD, one workgroup per CU and XCD (8 Gn <= 256), and the warm-up as a prefill (its
+  // history rings are laid out per stage, the teacher-forced mode of wavenet_persist.hip cannot fill them).
+  p->pipe = false;
+  if (p->persistent && !p->chain) {
+    const char* penv = getenv("MMK_WN_PIPE");
+    const char* fenv = getenv("MMK_WN_PREFILL");
+    const bool fits_l2 = (int64_t)p->L * 8 * p->C * p->C * 4 <= ((int64_t)3 << 20);
+    (void)fits_l2;
+    bool ok3 = (penv && penv[0] == '1') && !(fenv && fenv[0] == '0') && 8 * p->Gn <= 256 && p->Bmax <= 32;   // opt-in until it wins
+    for (int l = 0; l + 1 < p->L; ++l) ok3 = ok3 && p->has_res[l];
+    const int mg = (p->Bmax + 7) / 8, gc = (p->Bmax + mg - 1) / mg;
+    ok3 = ok3 && wn_pipe_supported(p->C, mg, gc, p->L);
+    if (ok3) {
+      WnPipeArgs probe = {};
+      probe.C = p->C; probe.H1 = c.mlp_hidden; probe.n_logits_pad = p->n_logits_pad; probe.L = p->L; probe.Gn = p->Gn;
+      ok3 = wn_pipe_lds_bytes(probe) <= 160 * 1024;
+    }
+    if (ok3) {
+      p->pipe = true;
+      p->xcd_local = false;
+      p->Mg = mg;
+      p->Gc = gc;
+      p->pipe_nit = wn_pipe_iters_per_stage(p->L);
+      p->Ac.resize(p->L);
+      for (auto& pl : p->Ac) pl.set_geometry(2 * p->C, {p->C, p->C, p->C});
+      // rings: per stage workgroup, the stage's layers x slots x (all Gc Mg clips) x C
+      const int64_t Bp = (int64_t)gc * mg;
+      int64_t worst = 0;
+      for (int x = 0; x * p->pipe_nit < p->L; ++x) {
+        int64_t off = 0;
+        for (int l = x * p->pipe_nit; l < (x + 1) * p->pipe_nit && l < p->L; ++l) {
+          p->ring_offset[l] = off;
+          off += (int64_t)(p->ring_mask[l] + 1) * Bp * p->C;
+        }
+        worst = off > worst ? off : worst;
+      }
+      p->ring_floats_per_wg = worst;
+      if (worst * 4 >= ((int64_t)1 << 32)) p->pipe = false;    // 32-bit byte offsets in the kernel
+      if (!p->pipe) return fail(MMK_ERR_UNSUPPORTED, "wavenet: history rings of %lld bytes per workgroup", (long long)worst * 4);
     }
   }
   return MMK_OK;
@@ -489,7 +551,7 @@ extern "C" int mmk_wavenet_commit(mmk_wavenet_plan* p, void* workspace, size_t w
     }
   }
   // one-hand-off-per-layer mode: gate matrices [tap 0 | tap 1 | tap 1 . W_res(l-1)], bias + tap 1 . b_res(l-1)
-  if (p->chain) {
+  if (p->chain || p->pipe) {
     for (int l = 0; l < L; ++l) {
       const std::string ly = "layers." + std::to_string(l) + ".";
       const float* wd = b.need(ly + "conv_dil.0.0.weight", (int64_t)2 * C * C * 2);
@@ -566,7 +628,7 @@ extern "C" int mmk_wavenet_commit(mmk_wavenet_plan* p, void* workspace, size_t w
     }
     MMK_HIP(hipMemcpyAsync(p->layer_tab, tab.data(), sizeof(WnLayerTab) * L, hipMemcpyHostToDevice, st));
     std::vector<WnChainIter> it(L + 1);
-    if (p->chain) {
+    if (p->chain || p->pipe) {
       for (int i = 0; i <= L; ++i) {
         const int la = i < L ? i : 0;
         it[i].A_wp = p->Ac[la].Wp;
@@ -729,6 +791,32 @@ static int run_persistent(mmk_wavenet_plan* p, const WnCall& call, int64_t tau0,
     // hand-off words are zeroed before EVERY launch (epochs restart at 1); the error word after them is sticky
     MMK_HIP(hipMemsetAsync(p->gran_h, 0, (size_t)(p->gran_words - 2) * sizeof(unsigned long long), st));
     const char* stamp_env = getenv("MMK_WN_STAMPS");
+    if (p->pipe) {
+      if (!with_head) return fail(MMK_ERR_STATE, "wavenet: the pipelined kernel has no teacher-forced mode (warm-up is a prefill)");
+      MMK_HIP(hipMemsetAsync(p->px_yl, 0, (size_t)p->pipe_gran_words * sizeof(unsigned long long), st));
+      WnPipeArgs k = {};
+      k.B = call.M; k.Gc = (call.M + p->Mg - 1) / p->Mg; k.Gn = p->Gn; k.Mg = p->Mg;
+      k.L = p->L; k.C = p->C; k.C1 = p->C1; k.n_it = p->pipe_nit;
+      k.q_levels = c.q_levels; k.H1 = c.mlp_hidden; k.n_classes = c.out_dim; k.n_logits_pad = p->n_logits_pad;
+      k.learn_temp = c.learn_temp; k.min_temp = c.min_temp;
+      k.t0 = tau_b + 1; k.n_steps = nb;
+      k.iters = p->iter_tab; k.ring_floats_per_wg = p->ring_floats_per_wg;
+      k.emb = p->emb; k.idx = (int64_t*)call.in0; k.idx_rs = call.in0_rs;
+      k.condall = p->condall; k.cond_steps = p->kCondBlock; k.zeros = p->zero_pad;
+      k.fc0_wp = p->mlp[0].Wp; k.fc0_bias = p->mlp[0].bias; k.fc2_wp = p->mlp[1].Wp; k.fc2_bias = p->mlp[1].bias;
+      k.temperature = call.temperature;
+      k.uniforms = call.uniforms ? call.uniforms + done : nullptr;
+      k.uni_ld = call.uni_ld;
+      k.logits_out = p->logits; k.logits_ld = p->logits_ld;
+      k.gran_yl = p->px_yl; k.gran_hl = p->px_hl; k.gran_hown = p->px_hown; k.gran_yx = p->px_yx; k.gran_hx = p->px_hx;
+      k.gran_skipfwd = p->px_skipfwd;
+      k.gran_skip = p->gran_skip; k.gran_hid = p->gran_hid; k.gran_logit = p->gran_logit; k.gran_idx = p->gran_idx;
+      k.h_rings = p->h_rings; k.err_flag = p->err_flag; k.xcd_count = p->xcd_count;
+      k.stamps = (stamp_env && stamp_env[0] == '1') ? reinterpret_cast<unsigned long long*>(p->tau + 8) : nullptr;
+      MMK_TRY(launch_wavenet_pipe(k, st));
+      done += nb;
+      continue;
+    }
     if (p->chain && with_head) {
       WnChainArgs k = {};
       k.B = call.M; k.Gc = p->Gc; k.Gn = p->Gn; k.Mg = p->Mg;
@@ -814,8 +902,13 @@ static int prefill(mmk_wavenet_plan* p, const WnCall& call, int64_t t_begin, int
     const int d = p->dil[l];
     // the ring of layer l holds its input at the last d positions
     const int64_t t_lo = t_end - d > t_begin ? t_end - d : t_begin;
-    MMK_TRY(launch_wn_prefill_scatter(p->pf_h[cur], P * C, t_begin, t_lo, (int)(t_end - t_lo), C, B, p->Mg, p->Gc, p->Gn, p->h_rings,
-                                      p->ring_floats_per_wg, p->ring_offset[l], p->ring_mask[l], st));
+    if (p->pipe)   // the rings of layer l live with the workgroups of its stage and hold all clips per slot
+      MMK_TRY(launch_wn_prefill_scatter(p->pf_h[cur], P * C, t_begin, t_lo, (int)(t_end - t_lo), C, B, p->Gc * p->Mg, 1, p->Gn,
+                                        p->h_rings + (int64_t)(l / p->pipe_nit) * p->Gn * p->ring_floats_per_wg, p->ring_floats_per_wg,
+                                        p->ring_offset[l], p->ring_mask[l], st));
+    else
+      MMK_TRY(launch_wn_prefill_scatter(p->pf_h[cur], P * C, t_begin, t_lo, (int)(t_end - t_lo), C, B, p->Mg, p->Gc, p->Gn, p->h_rings,
+                                        p->ring_floats_per_wg, p->ring_offset[l], p->ring_mask[l], st));
     if (l == L - 1) break;
     int64_t r_lo = t_end - sfx[l];                       // first position whose output is still needed
     if (r_lo < t_begin + d) r_lo = t_begin + d;          // the delayed input must exist
@@ -916,6 +1009,12 @@ extern "C" int mmk_wavenet_warmup(mmk_wavenet_plan* p, int32_t batch, const void
   call.in0_rs = in0_row_stride;
   if (t_begin < 0 || t_end < t_begin) return fail(MMK_ERR_INVALID, "wavenet_warmup: bad range [%lld, %lld)", (long long)t_begin, (long long)t_end);
   const char* penv = getenv("MMK_WN_PREFILL");
+  if (p->pipe) {
+    // the stage-owned rings are only filled by the prefill; a longer window than the receptive field adds nothing to the
+    // ring entries generation reads (each is determined by the rf - 1 positions before t_end)
+    if (t_end - t_begin > p->rf - 1) t_begin = t_end - (p->rf - 1);
+    return t_end > t_begin ? prefill(p, call, t_begin, t_end, (hipStream_t)stream) : MMK_OK;
+  }
   if (p->persistent && t_end > t_begin && t_end - t_begin <= p->pf_P && !(penv && penv[0] == '0'))
     return prefill(p, call, t_begin, t_end, (hipStream_t)stream);
   return run_steps(p, call, t_begin, t_end - t_begin, false, (hipStream_t)stream);
@@ -981,7 +1080,7 @@ extern "C" int mmk_wavenet_profile_steps(mmk_wavenet_plan* p, int32_t batch, voi
   return rc;
 }
 
-extern "C" int mmk_wavenet_mode(const mmk_wavenet_plan* p) { return (p && p->persistent) ? (p->chain ? 2 : 1) : 0; }
+extern "C" int mmk_wavenet_mode(const mmk_wavenet_plan* p) { return (p && p->persistent) ? (p->pipe ? 3 : (p->chain ? 2 : 1)) : 0; }
 
 extern "C" int mmk_wavenet_sync_status(mmk_wavenet_plan* p, mmk_stream_t stream) {
   if (!p) return fail(MMK_ERR_INVALID, "wavenet_sync_status: null plan");
@@ -997,6 +1096,14 @@ extern "C" int mmk_wavenet_sync_status(mmk_wavenet_plan* p, mmk_stream_t stream)
     if (senv && senv[0] == '1') {
       unsigned long long st[24];
       MMK_HIP(hipMemcpy(st, p->tau + 8, sizeof(st), hipMemcpyDeviceToHost));
+      if (p->pipe) {
+        fprintf(stderr, "[mmk stamps] last pipelined launch, thread 0 of workgroup 1 of stage 1, totals in ms: visit start (own h + wait for the "
+                        "group's inputs)=%.3f; operands + MFMA=%.3f; wait B1=%.3f; epilogues + publish=%.3f; small operands + ring store=%.3f; "
+                        "wait y/h=%.3f; whole launch=%.3f; shader clock=%.0f MHz\n",
+                st[7] * 1e-5, st[9] * 1e-5, st[0] * 1e-5, st[1] * 1e-5, st[2] * 1e-5, st[3] * 1e-5, st[15] * 1e-5,
+                st[15] ? 100.0 * (double)st[14] / (double)st[15] : 0.0);
+        return MMK_OK;
+      }
       if (p->chain) {
         fprintf(stderr, "[mmk stamps] last chain launch, I/O wave 0 of workgroup 1, totals in ms: wait products=%.3f; epilogues + publish=%.3f; "
                         "ring store=%.3f; wait y/h=%.3f; head=%.3f [skip wait + fc0=%.3f]; step start=%.3f | matrix wave 0: requests=%.3f; "

@@ -442,6 +442,11 @@ class WaveNetPlan(_Plan):
         """persistent mode with one hand-off per layer (csrc/wavenet_chain.hip)"""
         return self._lib.mmk_wavenet_mode(self.handle) == 2
 
+    @property
+    def pipelined(self) -> bool:
+        """persistent mode with the layers spread over the XCDs and the clip groups pipelined through them (csrc/wavenet_pipe.hip)"""
+        return self._lib.mmk_wavenet_mode(self.handle) == 3
+
     def sync_status(self):
         """wait for the stream and raise if a hand-off inside the persistent kernel timed out"""
         check(self._lib.mmk_wavenet_sync_status(self.handle, stream_ptr(self.device)), "mmk_wavenet_sync_status")
