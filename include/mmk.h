@@ -176,6 +176,12 @@ typedef struct mmk_wavenet_config {
   int32_t learn_temp;                      /* MLP.learn_temperature */
   float min_temp;
   int32_t max_batch;
+  /* reverse_layer_order (:253): the layers run in reversed construction order, so the layer built without a residual
+   * convolution (:216) is no longer the last one.  res_explicit != 0: layer_has_res[l] says whether layer l (in RUN
+   * order) has its conv_res; 0: every layer but the last has one when residuals_dim == dim_dilated. */
+  int32_t res_explicit;
+  int32_t layer_has_res[MMK_MAX_LAYERS];
+  int32_t layerwise_inputs;                /* Config.layerwise_inputs: the embedded input 0 is added to every layer's output (:285-286) */
 } mmk_wavenet_config;
 
 typedef struct mmk_wavenet_plan mmk_wavenet_plan;
@@ -235,6 +241,7 @@ typedef struct mmk_srnn_config {
   int32_t mlp_hidden, mlp_n_hidden, learn_temp;
   float min_temp;
   int32_t max_batch;
+  int32_t n_rnn;                           /* Config.n_rnn: stacked recurrent layers per tier (:65, nn.LSTM / GRU num_layers); 0 = 1 */
 } mmk_srnn_config;
 
 typedef struct mmk_srnn_plan mmk_srnn_plan;

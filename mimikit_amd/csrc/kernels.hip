@@ -89,6 +89,23 @@ __global__ void copy_rows_kernel(Addr src, int64_t src_ld, Addr dst, int64_t dst
   for (int c = threadIdx.x; c < C; c += blockDim.x) d[c] = s[c];
 }
 
+__global__ void add_rows_kernel(Addr src, int64_t src_ld, Addr dst, int64_t dst_ld, int M, int C, const int64_t* tau_ptr,
+                                int64_t tau_off) {
+  const int64_t tau = (tau_ptr ? *tau_ptr : 0) + tau_off;
+  const int m = blockIdx.x;
+  const float* s = (const float*)src.base + addr_elems(src, tau) + (int64_t)m * src_ld;
+  float* d = (float*)dst.base + addr_elems(dst, tau) + (int64_t)m * dst_ld;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) d[c] = d[c] + s[c];
+}
+
+// dst[m][:] = dst[m][:] + src[m][:]   (WaveNet layerwise_inputs: every layer output + the embedded input, wavenet_v2.py:285-286)
+int launch_add_rows(Addr src, int64_t src_ld, Addr dst, int64_t dst_ld, int M, int C, const int64_t* tau_ptr, int64_t tau_off,
+                    hipStream_t stream) {
+  hipLaunchKernelGGL(add_rows_kernel, dim3(M), dim3(C >= 256 ? 256 : 64), 0, stream, src, src_ld, dst, dst_ld, M, C, tau_ptr, tau_off);
+  MMK_HIP(hipGetLastError());
+  return MMK_OK;
+}
+
 int launch_copy_rows(Addr src, int64_t src_ld, Addr dst, int64_t dst_ld, int M, int C, const int64_t* tau_ptr,
                      int64_t tau_off, hipStream_t stream) {
   hipLaunchKernelGGL(copy_rows_kernel, dim3(M), dim3(C >= 256 ? 256 : 64), 0, stream, src, src_ld, dst, dst_ld, M,

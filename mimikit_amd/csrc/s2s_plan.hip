@@ -77,6 +77,18 @@ __global__ void repeat_rows_kernel(const float* __restrict__ x, int D, int hop, 
   for (int c = threadIdx.x; c < D; c += blockDim.x) out[(int64_t)row * D + c] = src[c];
 }
 
+// dec_upsampling="interp" (:162-165): x.expand(-1, hop, -1) + F.interpolate(h_n.permute(1, 2, 0), (hop,)).permute(0, 2, 1) -
+// nearest-neighbour interpolation of the encoder's two final states (forward, reverse) over the hop frames: frame t gets
+// direction floor(2 t / hop)
+__global__ void interp_rows_kernel(const float* __restrict__ x, const float* __restrict__ h_fwd, const float* __restrict__ h_rev, int D,
+                                   int hop, float* __restrict__ out) {
+  const int row = blockIdx.x;                       // b * hop + t
+  const int b = row / hop, t = row % hop;
+  const float* hsrc = ((2 * t) / hop == 0 ? h_fwd : h_rev) + (int64_t)b * D;
+  const float* src = x + (int64_t)b * D;
+  for (int c = threadIdx.x; c < D; c += blockDim.x) out[(int64_t)row * D + c] = src[c] + hsrc[c];
+}
+
 }  // namespace
 
 struct BiLstm {
@@ -89,7 +101,7 @@ struct mmk_s2s_plan {
   bool committed = false;
   int D = 0, hop = 0, Bmax = 0, in_pad = 0, out_pad = 0;
   std::vector<BiLstm> enc, dec;        // the bi-LSTM layers of each side
-  PackedLinear fc_out, dec_fc, out_lin;
+  PackedLinear fc_out, dec_fc, out_lin, enc_fc;     // enc_fc: LinearResampler(D, 1 / hop, 1) of enc_downsampling="linear_resample"
   float *xin = nullptr, *gi[2] = {nullptr, nullptr}, *gates = nullptr;
   float *h[2] = {nullptr, nullptr}, *c[2] = {nullptr, nullptr};
   float* h2[2] = {nullptr, nullptr};   // second state buffer of each direction (the fused step kernel ping-pongs)
@@ -102,6 +114,7 @@ struct mmk_s2s_plan {
     for (auto& l : enc) for (int d = 0; d < 2; ++d) { l.ih[d].carve(cv, true); l.hh[d].carve(cv, false); }
     for (auto& l : dec) for (int d = 0; d < 2; ++d) { l.ih[d].carve(cv, true); l.hh[d].carve(cv, false); }
     fc_out.carve(cv, false);
+    if (cfg.enc_downsampling == 4) enc_fc.carve(cv, true);
     dec_fc.carve(cv, true);
     out_lin.carve(cv, true);
     const int64_t rows = (int64_t)Bmax * hop;
@@ -128,8 +141,10 @@ static int derive(mmk_s2s_plan* p) {
   if (c.in_dim < 1 || c.out_dim < 1 || c.model_dim < 1 || c.hop < 1 || c.max_batch < 1) return fail(MMK_ERR_INVALID, "s2s: bad dimensions");
   if (c.enc_n_lstm < 1 || c.enc_n_lstm > 8 || c.dec_n_lstm < 1 || c.dec_n_lstm > 8)
     return fail(MMK_ERR_UNSUPPORTED, "s2s: 1 .. 8 bi-LSTM layers per side, got %d + %d", c.enc_n_lstm, c.dec_n_lstm);
-  if (c.enc_downsampling < 0 || c.enc_downsampling > 3 || c.dec_upsampling < 0 || c.dec_upsampling > 1)
+  if (c.enc_downsampling < 0 || c.enc_downsampling > 4 || c.dec_upsampling < 0 || c.dec_upsampling > 2)
     return fail(MMK_ERR_UNSUPPORTED, "s2s: enc_downsampling %d / dec_upsampling %d are not covered", c.enc_downsampling, c.dec_upsampling);
+  if (c.enc_downsampling == 4 && c.model_dim % c.hop != 0)
+    return fail(MMK_ERR_INVALID, "s2s: enc_downsampling='linear_resample' needs hop (%d) to divide model_dim (%d)", c.hop, c.model_dim);
   if (c.model_dim % 2 != 0) return fail(MMK_ERR_UNSUPPORTED, "s2s: model_dim must be even");
   p->D = c.model_dim;
   p->hop = c.hop;
@@ -149,6 +164,7 @@ static int derive(mmk_s2s_plan* p) {
     }
   }
   p->fc_out.set_geometry(p->D, {p->D});
+  if (c.enc_downsampling == 4) p->enc_fc.set_geometry(p->D / p->hop, {p->D});
   p->dec_fc.set_geometry(p->hop * p->D, {p->D});
   p->out_lin.set_geometry(c.out_dim, {p->D});
   const char* fenv = getenv("MMK_S2S_FUSED");
@@ -221,7 +237,12 @@ extern "C" int mmk_s2s_commit(mmk_s2s_plan* p, void* workspace, size_t workspace
   for (size_t n = 0; n < p->dec.size(); ++n) MMK_TRY(pack_lstm(p, p->dec[n], "dec.lstm." + std::to_string(n) + ".", D, st));
   if (const float* w = b.need("enc.fc_out.weight", (int64_t)D * D))
     MMK_TRY(pack_rect(p->fc_out.Wp, p->fc_out.k_chunks, 0, 1, D, 0, D, w, D, 1, st));
-  if (c.dec_upsampling == 0) {   // "repeat" has no up-sampling weights
+  if (c.enc_downsampling == 4) {   // LinearResampler(D, 1 / hop, 1): Linear(D, D / hop) per frame, the hop results concatenated (:21-23)
+    if (const float* w = b.need("enc.fc.fc.weight", (int64_t)(D / p->hop) * D))
+      MMK_TRY(pack_rect(p->enc_fc.Wp, p->enc_fc.k_chunks, 0, 1, D / p->hop, 0, D, w, D, 1, st));
+    if (const float* bb = b.need("enc.fc.fc.bias", D / p->hop)) MMK_TRY(pack_bias(p->enc_fc.bias, 0, 1, D / p->hop, bb, 0, st));
+  }
+  if (c.dec_upsampling == 0) {   // "repeat" / "interp" have no up-sampling weights
     if (const float* w = b.need("dec.fc.fc.weight", (int64_t)p->hop * D * D))
       MMK_TRY(pack_rect(p->dec_fc.Wp, p->dec_fc.k_chunks, 0, 1, p->hop * D, 0, D, w, D, 1, st));
     if (const float* bb = b.need("dec.fc.fc.bias", (int64_t)p->hop * D)) MMK_TRY(pack_bias(p->dec_fc.bias, 0, 1, p->hop * D, bb, 0, st));
@@ -320,14 +341,22 @@ static int s2s_step(mmk_s2s_plan* p, int M, const float* x, int64_t xbs, int64_t
     xl = fold; xl_ld = D;
     fold = fold == p->ysum ? p->yalt : p->ysum;
   }
-  hipLaunchKernelGGL(pool_frames_kernel, dim3(M), dim3(256), 0, st, xl, D, hop, c.enc_downsampling, p->es);
-  MMK_HIP(hipGetLastError());
+  if (c.enc_downsampling == 4) {
+    // rows (b hop + t) -> D / hop features each: (M, hop, D / hop) contiguous IS the reshape to (M, 1, D)   (resamplers.py:21-23)
+    MMK_TRY(plain_linear(p->enc_fc, xl, D, rows, p->es, D / hop, ACT_NONE, st));
+  } else {
+    hipLaunchKernelGGL(pool_frames_kernel, dim3(M), dim3(256), 0, st, xl, D, hop, c.enc_downsampling, p->es);
+    MMK_HIP(hipGetLastError());
+  }
   MMK_TRY(plain_linear(p->fc_out, p->es, D, M, p->coded, D, ACT_NONE, st));
   // decoder: up-sampling to hop frames, every bi-LSTM seeded with the LAST encoder layer's (h_n, c_n)  (:158-171)
   if (c.dec_upsampling == 0) {
     MMK_TRY(plain_linear(p->dec_fc, p->coded, D, M, p->z, (int64_t)hop * D, ACT_NONE, st));
-  } else {
+  } else if (c.dec_upsampling == 1) {
     hipLaunchKernelGGL(repeat_rows_kernel, dim3(rows), dim3(256), 0, st, p->coded, D, hop, p->z);
+    MMK_HIP(hipGetLastError());
+  } else {   // the encoder's final states are still in h[0] (forward) / h[1] (reverse)
+    hipLaunchKernelGGL(interp_rows_kernel, dim3(rows), dim3(256), 0, st, p->coded, p->h[0], p->h[1], D, hop, p->z);
     MMK_HIP(hipGetLastError());
   }
   if (p->dec.size() > 1)

@@ -23,8 +23,15 @@ struct SrnnCall {
   int64_t uni_off = 0;
 };
 
+// a stacked recurrent layer above the first one of a tier (n_rnn > 1): its input is the layer below's new state
+struct SrnnDeep {
+  PackedLinear gates, gates_hh;
+  float *h = nullptr, *c = nullptr;
+};
+
 struct SrnnTier {
   int fs = 0, up = 0;
+  std::vector<SrnnDeep> deep;
   PackedLinear in_lin, gates, gates_hh, up_lin;
   float *h = nullptr, *c = nullptr, *out = nullptr;   // h: [2][Bmax][H] (the fused GRU kernel alternates the slots)
   float *win_raw = nullptr, *bin_raw = nullptr;       // input Linear in its state_dict layout
@@ -64,6 +71,12 @@ struct mmk_srnn_plan {
       t.cnt = c.take<int64_t>(4);
       t.done = c.take<unsigned>(4);
       t.out = c.take<float>((int64_t)Bmax * t.up * H);
+      for (auto& d : t.deep) {
+        d.gates.carve(c, bias);
+        if (cfg.rnn_kind == 1) d.gates_hh.carve(c, bias);
+        d.h = c.take<float>((int64_t)Bmax * H);
+        d.c = c.take<float>((int64_t)Bmax * H);
+      }
     }
     bottom.carve(c, true);
     for (auto& m : mlp) m.carve(c, true);
@@ -109,6 +122,16 @@ static int derive(mmk_srnn_plan* p) {
       t.gates.set_geometry(p->G * p->H, {p->H, p->H});
     }
     t.up_lin.set_geometry(p->H * t.up, {p->H});
+    const int n_rnn = c.n_rnn > 1 ? c.n_rnn : 1;
+    t.deep.resize(n_rnn - 1);
+    for (auto& d : t.deep) {
+      if (c.rnn_kind == 1) {
+        d.gates.set_geometry(3 * p->H, {p->H});
+        d.gates_hh.set_geometry(3 * p->H, {p->H});
+      } else {
+        d.gates.set_geometry(p->G * p->H, {p->H, p->H});
+      }
+    }
   }
   if (c.frame_size[c.n_tiers - 1] < 1) return fail(MMK_ERR_INVALID, "srnn: bad bottom frame size");
   p->bottom.set_geometry(p->H, {c.frame_size[c.n_tiers - 1]});
@@ -129,6 +152,8 @@ static int derive(mmk_srnn_plan* p) {
                     srnn_bottom_supported(p->H, c.mlp_hidden, c.q_levels + (c.learn_temp ? 1 : 0), c.frame_size[c.n_tiers - 1]);
   p->fused_gru = !(fenv && fenv[0] == '0') && (c.rnn_kind == 1 || c.rnn_kind == 0);   // GRU or LSTM tiers
   for (auto& t : p->tiers) p->fused_gru = p->fused_gru && srnn_gru_supported(p->H, t.fs, c.rnn_kind == 0);
+  if (c.n_rnn > 1) p->fused_gru = false;    // stacked layers: one launch per op (the fused kernel's up-sampler reads layer 0)
+  if (c.n_rnn > 8) return fail(MMK_ERR_UNSUPPORTED, "srnn: n_rnn=%d", c.n_rnn);
   return MMK_OK;
 }
 
@@ -189,6 +214,10 @@ extern "C" int mmk_srnn_reset(mmk_srnn_plan* p, mmk_stream_t stream) {
     MMK_HIP(hipMemsetAsync(t.done, 0, 4 * sizeof(unsigned), st));
     MMK_TRY(launch_fill(t.c, p->cfg.h0_ones ? 1.f : 0.f, (int64_t)p->Bmax * p->H, st));
     MMK_HIP(hipMemsetAsync(t.out, 0, (size_t)p->Bmax * t.up * p->H * sizeof(float), st));
+    for (auto& d : t.deep) {
+      MMK_TRY(launch_fill(d.h, p->cfg.h0_ones ? 1.f : 0.f, (int64_t)p->Bmax * p->H, st));
+      MMK_TRY(launch_fill(d.c, p->cfg.h0_ones ? 1.f : 0.f, (int64_t)p->Bmax * p->H, st));
+    }
   }
   return MMK_OK;
 }
@@ -233,6 +262,25 @@ extern "C" int mmk_srnn_commit(mmk_srnn_plan* p, void* workspace, size_t workspa
       if (whh) MMK_TRY(pack_rect(t.gates.Wp, t.gates.k_chunks, 0, 1, G * H, t.gates.seg_chunk0[1], H, whh, H, 1, st));
       if (bih) MMK_TRY(pack_bias(t.gates.bias, 0, 1, G * H, bih, 0, st));
       if (bhh) MMK_TRY(pack_bias(t.gates.bias, 0, 1, G * H, bhh, 1, st));
+    }
+    for (size_t k = 0; k < t.deep.size(); ++k) {
+      SrnnDeep& d = t.deep[k];
+      const std::string sfx = "_l" + std::to_string(k + 1);
+      const float* dih = b.need(tb + "rnn.weight_ih" + sfx, (int64_t)G * H * H);
+      const float* dhh = b.need(tb + "rnn.weight_hh" + sfx, (int64_t)G * H * H);
+      const float* dbi = bias ? b.need(tb + "rnn.bias_ih" + sfx, (int64_t)G * H) : nullptr;
+      const float* dbh = bias ? b.need(tb + "rnn.bias_hh" + sfx, (int64_t)G * H) : nullptr;
+      if (c.rnn_kind == 1) {
+        if (dih) MMK_TRY(pack_rect(d.gates.Wp, d.gates.k_chunks, 0, 1, G * H, 0, H, dih, H, 1, st));
+        if (dhh) MMK_TRY(pack_rect(d.gates_hh.Wp, d.gates_hh.k_chunks, 0, 1, G * H, 0, H, dhh, H, 1, st));
+        if (dbi) MMK_TRY(pack_bias(d.gates.bias, 0, 1, G * H, dbi, 0, st));
+        if (dbh) MMK_TRY(pack_bias(d.gates_hh.bias, 0, 1, G * H, dbh, 0, st));
+      } else {
+        if (dih) MMK_TRY(pack_rect(d.gates.Wp, d.gates.k_chunks, 0, 1, G * H, d.gates.seg_chunk0[0], H, dih, H, 1, st));
+        if (dhh) MMK_TRY(pack_rect(d.gates.Wp, d.gates.k_chunks, 0, 1, G * H, d.gates.seg_chunk0[1], H, dhh, H, 1, st));
+        if (dbi) MMK_TRY(pack_bias(d.gates.bias, 0, 1, G * H, dbi, 0, st));
+        if (dbh) MMK_TRY(pack_bias(d.gates.bias, 0, 1, G * H, dbh, 1, st));
+      }
     }
     const float* wu = b.need(tb + "up_sampler.fc.weight", (int64_t)H * t.up * H);
     const float* bu = b.need(tb + "up_sampler.fc.bias", (int64_t)H * t.up);
@@ -368,10 +416,44 @@ static int emit_step(mmk_srnn_plan* p, const SrnnCall& call, int64_t tau_off, in
       else
         MMK_TRY(launch_rnn_tanh_cell(p->gi, t.h, M, H, st));
     }
+    const float* top_h = t.h;
+    for (auto& d : t.deep) {   // nn.LSTM / GRU / RNN with num_layers > 1: layer k's input is layer k-1's new state
+      if (c.rnn_kind == 1) {
+        LinearArgs a = {};
+        d.gates.fill(a);
+        a.seg[0].x = addr_static(top_h); a.seg[0].ld = H;
+        a.M = M; a.tau_ptr = p->tau; a.tau_off = tau_off;
+        a.epilogue = EPI_STORE; a.act = ACT_NONE;
+        a.out = addr_static(p->gi); a.out_ld = 3 * H;
+        MMK_TRY(launch_linear(a, st));
+        LinearArgs hh = {};
+        d.gates_hh.fill(hh);
+        hh.seg[0].x = addr_static(d.h); hh.seg[0].ld = H;
+        hh.M = M; hh.tau_ptr = p->tau; hh.tau_off = tau_off;
+        hh.epilogue = EPI_STORE; hh.act = ACT_NONE;
+        hh.out = addr_static(p->gh); hh.out_ld = 3 * H;
+        MMK_TRY(launch_linear(hh, st));
+        MMK_TRY(launch_gru_cell(p->gi, p->gh, d.h, M, H, st));
+      } else {
+        LinearArgs a = {};
+        d.gates.fill(a);
+        a.seg[0].x = addr_static(top_h); a.seg[0].ld = H;
+        a.seg[1].x = addr_static(d.h); a.seg[1].ld = H;
+        a.M = M; a.tau_ptr = p->tau; a.tau_off = tau_off;
+        a.epilogue = EPI_STORE; a.act = ACT_NONE;
+        a.out = addr_static(p->gi); a.out_ld = (int64_t)G * H;
+        MMK_TRY(launch_linear(a, st));
+        if (c.rnn_kind == 0)
+          MMK_TRY(launch_lstm_cell(p->gi, 4 * H, nullptr, 0, d.h, H, d.c, H, nullptr, 0, M, H, st));
+        else
+          MMK_TRY(launch_rnn_tanh_cell(p->gi, d.h, M, H, st));
+      }
+      top_h = d.h;
+    }
     {
       LinearArgs a = {};
       t.up_lin.fill(a);
-      a.seg[0].x = addr_static(t.h); a.seg[0].ld = H;
+      a.seg[0].x = addr_static(top_h); a.seg[0].ld = H;
       a.M = M; a.tau_ptr = p->tau; a.tau_off = tau_off;
       a.epilogue = EPI_STORE; a.act = ACT_NONE;
       a.out = addr_static(t.out); a.out_ld = (int64_t)t.up * H;

@@ -224,7 +224,7 @@ static int derive(mmk_wavenet_plan* p) {
     p->ring[l] = ring;
     p->rf += cause;
     // has_residuals (:78) with input_dim == dims_dilated[0]; last layer built with residuals_dim=None (:216)
-    p->has_res[l] = (l != p->L - 1) && c.residuals_dim != 0 && c.residuals_dim == p->C;
+    p->has_res[l] = c.residuals_dim != 0 && c.residuals_dim == p->C && (c.res_explicit ? c.layer_has_res[l] != 0 : l != p->L - 1);
   }
   p->head_in = p->S > 0 ? p->S : p->C;
 
@@ -271,7 +271,8 @@ static int derive(mmk_wavenet_plan* p) {
   const char* env = getenv("MMK_WN_PERSISTENT");
   bool ok = !(env && env[0] == '0');
   ok = ok && c.gated && c.q_levels > 0 && c.head_kind == 0 && c.mlp_n_hidden == 0 && c.n_cond <= 1;
-  ok = ok && p->C % 32 == 0 && p->C <= 256 && p->S == p->C && c.residuals_dim == p->C;
+  ok = ok && p->C % 32 == 0 && p->C <= 256 && p->S == p->C && c.residuals_dim == p->C && !c.layerwise_inputs;
+  for (int l = 0; l < p->L; ++l) ok = ok && (p->has_res[l] != 0) == (l != p->L - 1);   // (reverse_layer_order: launch path)
   ok = ok && c.mlp_hidden % 16 == 0 && c.mlp_hidden >= 16;
   if (c.n_cond == 1) ok = ok && c.cond_dim[0] % 16 == 0;
   for (int l = 0; l < p->L; ++l) ok = ok && p->ksz[l] == 2;
@@ -716,10 +717,16 @@ static int emit_step(mmk_wavenet_plan* p, const WnCall& call, int64_t tau_off, b
       g_prof_tag = 1;
       MMK_TRY(launch_linear(a, st));
     }
+    if (c.layerwise_inputs) {   // dilated = dilated + inputs[0]   (:285-286): the layer's output at tau + the embedded input at tau
+      g_prof_tag = 2;
+      const Addr dst = l + 1 < L ? p->hist_slot(l + 1, 0) : (p->has_res[l] ? p->hist_slot(L, 0) : addr_static(p->ybuf));
+      MMK_TRY(launch_add_rows(p->hist_slot(0, 0), C, dst, C, M, C, p->tau, tau_off, st));
+    }
   }
   g_prof_tag = 2;
   if (!with_head) return MMK_OK;
-  const float* x = S > 0 ? p->skipbuf : p->ybuf;
+  // without skips the head reads the last layer's output: its gated units, or (reverse_layer_order) the residual sum
+  const float* x = S > 0 ? p->skipbuf : (p->has_res[L - 1] ? p->hist[L] : p->ybuf);
   int x_ld = p->head_in;
   if (c.head_kind == 0) {
     for (size_t i = 0; i < p->mlp.size(); ++i) {

@@ -102,8 +102,12 @@ class DecoderLSTM(nn.Module):
             x = self.fc(x)
         elif self.upsampling == "repeat":
             x = x.repeat_interleave(self.hop, 1)
+        elif self.upsampling == "interp":
+            # the encoder's two final states (forward, reverse) spread over the hop frames, nearest neighbour (:162-165)
+            interp = nn.functional.interpolate(hidden[0].permute(1, 2, 0), (self.hop,)).permute(0, 2, 1)
+            x = x.expand(-1, self.hop, -1) + interp
         else:
-            raise NotImplementedError(f"dec_upsampling='{self.upsampling}' is outside the covered option space")
+            raise ValueError(f"unknown dec_upsampling '{self.upsampling}'")
         self.hidden[0] = hidden
         for n, lstm in enumerate(self.lstm):
             y, self.hidden[n] = lstm(x, hidden)   # every layer is seeded with the encoder state (:171)
@@ -200,8 +204,8 @@ class Seq2SeqLSTMNetwork(ARMWithHidden, nn.Module):
         unsupported = []
         if self.input_module is not sum:
             unsupported.append("discrete inputs (input module other than a plain sum)")
-        pooling = {"edge_sum": 0, "edge_mean": 1, "sum": 2, "mean": 3}
-        upsampling = {"linear_resample": 0, "repeat": 1}
+        pooling = {"edge_sum": 0, "edge_mean": 1, "sum": 2, "mean": 3, "linear_resample": 4}
+        upsampling = {"linear_resample": 0, "repeat": 1, "interp": 2}
         if str(cfg.enc_downsampling) not in pooling:
             unsupported.append(f"enc_downsampling='{cfg.enc_downsampling}'")
         if str(cfg.dec_upsampling) not in upsampling:

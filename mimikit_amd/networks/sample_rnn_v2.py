@@ -205,8 +205,8 @@ class SampleRNN(ARMWithHidden, nn.Module):
         unsupported = []
         if len(io.inputs) != 1 or len(io.targets) != 1:
             unsupported.append("more than one input / target")
-        if cfg.n_rnn != 1:
-            unsupported.append("n_rnn > 1")
+        if not 1 <= cfg.n_rnn <= 8:
+            unsupported.append("n_rnn outside [1, 8]")
         if cfg.rnn_dropout:
             unsupported.append("rnn_dropout")
         if str(cfg.h0_init) == "randn":
@@ -221,8 +221,8 @@ class SampleRNN(ARMWithHidden, nn.Module):
             mlp: MLP = head.estimator[0]
             if not isinstance(mlp.activation, nn.Mish) or not mlp.bias or mlp.dropout or mlp.dropout1d:
                 unsupported.append("MLP head with a non-Mish activation, no bias or dropout")
-            if mlp.n_hidden_layers > 1:
-                unsupported.append("n_mlp_layers > 1")
+            if mlp.n_hidden_layers > 4:
+                unsupported.append("n_mlp_layers > 4")
             c.mlp_hidden, c.mlp_n_hidden, c.learn_temp = mlp.hidden_dim, mlp.n_hidden_layers, int(mlp.learn_temperature)
             c.q_levels = mlp.out_dim - c.learn_temp
             c.min_temp = float(mlp.min_temp) if mlp.learn_temperature else 0.
@@ -238,6 +238,7 @@ class SampleRNN(ARMWithHidden, nn.Module):
         c.hidden_dim = cfg.hidden_dim
         c.rnn_kind = {"lstm": 0, "gru": 1, "rnn": 2}[str(cfg.rnn_class)]
         c.rnn_bias = int(cfg.rnn_bias)
+        c.n_rnn = int(cfg.n_rnn)
         c.h0_ones = int(str(cfg.h0_init) == "ones")
         c.max_batch = max_batch
         return c

@@ -178,7 +178,15 @@ class WaveNet(ARM, nn.Module):
         head_in = config.skips_dim if config.skips_dim is not None else hidden[0]
         output_modules = [spec.module.copy().set(in_dim=head_in).module() for spec in config.io_spec.targets]
         if config.tie_io_weights:
-            raise NotImplementedError("tie_io_weights is outside the covered option space (SURVEY 8(f) rank 4)")
+            # reference :240-249: every Linear of an input module hands its transposed weight to the same-named Linear of
+            # the output module (an initialisation: the new Parameter is a copy, the state_dict layout does not change)
+            for i_mod, o_mod in zip(input_modules, output_modules):
+                for name, m in i_mod.named_modules():
+                    if isinstance(m, nn.Linear):
+                        try:
+                            o_mod.get_submodule(name).weight = nn.Parameter(m.weight.transpose(0, 1))
+                        except AttributeError:
+                            continue
         return cls(config=config, layers=layers, input_modules=input_modules, output_modules=output_modules)
 
     def __init__(self, config: "WaveNet.Config", layers: List[WNLayer], input_modules: List[nn.Module],
@@ -275,8 +283,8 @@ class WaveNet(ARM, nn.Module):
             unsupported.append(f"groups={cfg.groups} does not divide the dilated width")
         if cfg.stride != 1:
             unsupported.append("stride != 1")
-        if cfg.layerwise_inputs or cfg.reverse_layer_order or cfg.with_affine_residuals:
-            unsupported.append("layerwise_inputs / reverse_layer_order / with_affine_residuals")
+        if cfg.with_affine_residuals:
+            unsupported.append("with_affine_residuals")
         if str(cfg.act_f) != "Tanh" or (cfg.act_g is not None and str(cfg.act_g) != "Sigmoid"):
             unsupported.append("activations other than Tanh / Sigmoid")
         if len(cfg.dims_dilated) != 1:
@@ -287,8 +295,11 @@ class WaveNet(ARM, nn.Module):
             unsupported.append("too many conditioning inputs / layers")
         c = native.WaveNetConfig()
         c.n_layers = len(self.layers)
+        c.res_explicit = 1           # per layer in RUN order (reverse_layer_order moves the residual-free layer to the front)
         for i, layer in enumerate(self.layers):
             c.kernel_size[i], c.dilation[i] = layer.kernel_size, layer.dilation
+            c.layer_has_res[i] = int(layer.has_residuals)
+        c.layerwise_inputs = int(cfg.layerwise_inputs)
         first = self.input_modules[0][0]
         if isinstance(first, nn.Embedding) and len(self.input_modules[0]) == 1:
             c.q_levels, c.in_dim = first.num_embeddings, 0
@@ -318,8 +329,8 @@ class WaveNet(ARM, nn.Module):
             c.learn_temp = int(mlp.learn_temperature)
             c.out_dim = mlp.out_dim - c.learn_temp
             c.min_temp = float(mlp.min_temp) if mlp.learn_temperature else 0.
-            if mlp.n_hidden_layers > 1:
-                unsupported.append("n_mlp_layers > 1")
+            if mlp.n_hidden_layers > 4:
+                unsupported.append("n_mlp_layers > 4")
         elif isinstance(head, nn.Sequential) and isinstance(head[0], nn.Linear) and head[0].bias is not None:
             tail = [m for m in list(head)[1:] if not (isinstance(m, Chunk) and m.chunks == 1)]
             kinds = [type(m).__name__ for m in tail]

@@ -185,38 +185,52 @@ def wavenet_rf(kernels: Sequence[int], dilations: Sequence[int]) -> int:
 
 def wavenet_window_forward(sd: SD, inputs: Tuple[torch.Tensor, ...], kernels: Sequence[int], dilations: Sequence[int],
                            n_cond: int = 0, has_skips: bool = True, residuals: bool = True,
-                           n_mlp_hidden: int = 0, embedding: bool = True, groups: int = 1, head: str = "mlp") -> torch.Tensor:
+                           n_mlp_hidden: int = 0, embedding: bool = True, groups: int = 1, head: str = "mlp",
+                           gated: bool = True, layerwise_inputs: bool = False,
+                           res_layers: Optional[Sequence[bool]] = None) -> torch.Tensor:
     """Full-window eval forward (wavenet_v2.py:276-293 with WNLayer.forward :131-176, pad_side=0):
     returns the RAW head outputs (B, 1, q+1) of the FIRST computable position (eval_slice, :273).
     ``groups`` applies to the dilated convolutions only (:93); ``head`` "linear" / "linear_abs" is the
-    (Chunked)LinearIO output module of a magnitude-frame target (io_spec.py:238-243) instead of the MLP."""
+    (Chunked)LinearIO output module of a magnitude-frame target (io_spec.py:238-243) instead of the MLP.
+    ``gated=False`` is act_g=None (:155-163: one tanh, plain Conv1d modules); ``layerwise_inputs`` adds the embedded
+    input 0 to every layer's output (:285-286); ``res_layers`` says per layer, in RUN order, whether it has its conv_res
+    (reverse_layer_order, :253, moves the layer built without one, :216, to the front) - default: all but the last."""
     if embedding:
         h = F.embedding(inputs[0], sd["input_modules.0.0.weight"])
     else:
         h = F.linear(inputs[0], sd["input_modules.0.0.weight"], sd["input_modules.0.0.bias"])
     h = h.transpose(1, 2).contiguous()
+    x0 = h
     conds = [F.linear(inputs[1 + j], sd[f"input_modules.{1 + j}.0.weight"], sd[f"input_modules.{1 + j}.0.bias"])
              .transpose(1, 2).contiguous() for j in range(n_cond)]
     skips = None
     n_layers = len(kernels)
+    if res_layers is None:
+        res_layers = [residuals and l != n_layers - 1 for l in range(n_layers)]   # last layer is built without residuals (:216)
+    dil_key = "conv_dil.0.0." if gated else "conv_dil.0."
     for l, (k, d) in enumerate(zip(kernels, dilations)):
         p = f"layers.{l}."
         cause = (k - 1) * d
-        z = F.conv1d(h, sd[p + "conv_dil.0.0.weight"], sd.get(p + "conv_dil.0.0.bias"), dilation=d, groups=groups)
-        z_f, z_g = torch.chunk(z, 2, dim=1)
-        c_f, c_g = 0, 0
+        z = F.conv1d(h, sd[p + dil_key + "weight"], sd.get(p + dil_key + "bias"), dilation=d, groups=groups)
+        cond_sum = 0          # the conditioning features are summed first (:141-147), then added to the dilated product
         for j in range(n_cond):
-            c = F.conv1d(conds[j][:, :, cause:], sd[p + f"conv_1x1.{j}.0.weight"], sd.get(p + f"conv_1x1.{j}.0.bias"))
-            a, b = torch.chunk(c, 2, dim=1)
-            c_f, c_g = c_f + a, c_g + b
-        y = torch.tanh(z_f + c_f) * torch.sigmoid(z_g + c_g)
+            ck = p + (f"conv_1x1.{j}.0." if gated else f"conv_1x1.{j}.")
+            cond_sum = cond_sum + F.conv1d(conds[j][:, :, cause:], sd[ck + "weight"], sd.get(ck + "bias"))
+        z = z + cond_sum
+        if gated:
+            z_f, z_g = torch.chunk(z, 2, dim=1)
+            y = torch.tanh(z_f) * torch.sigmoid(z_g)
+        else:
+            y = torch.tanh(z)
         if has_skips:
             s = F.conv1d(y, sd[p + "conv_skip.weight"], sd.get(p + "conv_skip.bias"))
             skips = s if skips is None else s + skips[:, :, cause:]
-        if residuals and l != n_layers - 1:   # last layer is built without residuals (:216)
+        if res_layers[l]:
             h = h[:, :, cause:] + F.conv1d(y, sd[p + "conv_res.weight"], sd.get(p + "conv_res.bias"))
         else:
             h = y
+        if layerwise_inputs:
+            h = h + x0[..., -h.size(-1):]
         conds = [c[:, :, cause:] for c in conds]
     y = (skips if has_skips else h).transpose(1, 2).contiguous()[:, 0:1]
     if head == "mlp":
@@ -267,10 +281,10 @@ def _linearize(q: torch.Tensor, class_size: int) -> torch.Tensor:
     return ((q.float() / class_size) - .5) * 2
 
 
-def _rnn_cell(kind: str, sd: SD, p: str, x: torch.Tensor, state):
-    """one time step of nn.LSTM / nn.GRU / nn.RNN (gate orders i,f,g,o and r,z,n)"""
-    w_ih, w_hh = sd[p + "weight_ih_l0"], sd[p + "weight_hh_l0"]
-    b_ih, b_hh = sd.get(p + "bias_ih_l0"), sd.get(p + "bias_hh_l0")
+def _rnn_cell(kind: str, sd: SD, p: str, x: torch.Tensor, state, layer: int = 0):
+    """one time step of one layer of nn.LSTM / nn.GRU / nn.RNN (gate orders i,f,g,o and r,z,n)"""
+    w_ih, w_hh = sd[p + f"weight_ih_l{layer}"], sd[p + f"weight_hh_l{layer}"]
+    b_ih, b_hh = sd.get(p + f"bias_ih_l{layer}"), sd.get(p + f"bias_hh_l{layer}")
     if kind == "lstm":
         h, c = state
         g = F.linear(x, w_ih, b_ih) + F.linear(h, w_hh, b_hh)
@@ -310,8 +324,10 @@ class SampleRNNOracle:
     SampleRNNTier.forward (:83-99) for n_rnn = 1, restated over a state_dict."""
 
     def __init__(self, sd: SD, frame_sizes: Sequence[int], hidden_dim: int, rnn_class: str = "lstm",
-                 q_levels: int = 256, n_mlp_hidden: int = 0, min_temp: Optional[float] = 1e-4, h0: str = "zeros"):
+                 q_levels: int = 256, n_mlp_hidden: int = 0, min_temp: Optional[float] = 1e-4, h0: str = "zeros",
+                 n_rnn: int = 1):
         self.sd, self.fs, self.H, self.kind = sd, tuple(frame_sizes), hidden_dim, rnn_class
+        self.n_rnn = n_rnn            # stacked layers per tier (nn.LSTM / GRU num_layers, sample_rnn_v2.py:65)
         self.q, self.n_mlp_hidden, self.min_temp, self.h0 = q_levels, n_mlp_hidden, min_temp, h0
         self.hidden = [None] * (len(self.fs) - 1)
         self.outputs = [None] * (len(self.fs) - 1)
@@ -332,9 +348,10 @@ class SampleRNNOracle:
             x = x + upper
         if self.hidden[i] is None:
             init = getattr(torch, self.h0)
-            z = init(x.size(0), self.H)
-            self.hidden[i] = (z, init(x.size(0), self.H)) if self.kind == "lstm" else z
-        x, self.hidden[i] = _rnn_cell(self.kind, sd, p + "rnn.", x, self.hidden[i])
+            self.hidden[i] = [(init(x.size(0), self.H), init(x.size(0), self.H)) if self.kind == "lstm" else init(x.size(0), self.H)
+                              for _ in range(self.n_rnn)]
+        for k in range(self.n_rnn):      # layer k's input is layer k-1's output at this time step
+            x, self.hidden[i][k] = _rnn_cell(self.kind, sd, p + "rnn.", x, self.hidden[i][k], layer=k)
         up = self.fs[i] // (self.fs[i + 1] if i < len(self.fs) - 2 else 1)
         out = F.linear(x, sd[p + "up_sampler.fc.weight"], sd[p + "up_sampler.fc.bias"])
         return out.reshape(x.size(0), up, self.H)
@@ -420,13 +437,18 @@ def s2s_step(sd: SD, x: torch.Tensor, hop: int, out_abs: bool = True, downsampli
         y, hidden = _bilstm(sd, f"enc.lstm.{n}.", x)
         y = y.view(*y.shape[:-1], D, 2).sum(-1)
         x = x + y if (n > 0 and enc_residuals) else y
-    y = x.unfold(1, hop, hop)
-    if "edge" in downsampling:
-        y = y[..., [0, -1]]
-    y = y.sum(-1) if "sum" in downsampling else y.mean(-1)
+    if downsampling == "linear_resample":      # LinearResampler(D, 1 / hop, 1) (:105-106, modules/resamplers.py:13-23)
+        y = F.linear(x, sd["enc.fc.fc.weight"], sd["enc.fc.fc.bias"]).reshape(x.size(0), 1, D)
+    else:
+        y = x.unfold(1, hop, hop)
+        if "edge" in downsampling:
+            y = y[..., [0, -1]]
+        y = y.sum(-1) if "sum" in downsampling else y.mean(-1)
     coded = F.linear(y, sd["enc.fc_out.weight"])
     if upsampling == "linear_resample":
         z = F.linear(coded, sd["dec.fc.fc.weight"], sd["dec.fc.fc.bias"]).reshape(coded.size(0), hop, D)
+    elif upsampling == "interp":               # (:162-165) nearest-neighbour spread of the two final states over the hop frames
+        z = coded.expand(-1, hop, -1) + F.interpolate(hidden[0].permute(1, 2, 0), (hop,)).permute(0, 2, 1)
     else:
         z = coded.repeat_interleave(hop, 1)
     for n in range(n_dec):

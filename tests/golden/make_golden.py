@@ -181,6 +181,52 @@ def make_wavenet():
     save("wavenet.npz", **arrays)
 
 
+WAVENET_OPTIONS = {
+    "mlp2": dict(io=dict(n_mlp_layers=2)),
+    "mlp3_cond": dict(io=dict(n_mlp_layers=3), cond=True),
+    "nogate": dict(act_g=None),
+    "nogate_cond": dict(act_g=None, cond=True),
+    "rev": dict(reverse_layer_order=True),
+    "rev_noskip": dict(reverse_layer_order=True, skips_dim=None),
+    "lw": dict(layerwise_inputs=True),
+    "lw_noskip_rev": dict(layerwise_inputs=True, reverse_layer_order=True, skips_dim=None),
+    "tied": dict(tie_io_weights=True),
+}
+
+
+def make_wavenet_options():
+    """the remaining WaveNet options: deeper MLP heads (ONE hidden block repeated, mlp.py:46-49),
+    act_g=None, reverse_layer_order, layerwise_inputs, tie_io_weights - 16 free-running steps through the reference's loop"""
+    g = torch.Generator().manual_seed(29)
+    arrays = {}
+    for tag, kw in WAVENET_OPTIONS.items():
+        kw = dict(kw)
+        io = ref.IOSpec.mulaw_io(ref.IOSpec.MuLawIOConfig(input_module_type="embedding", mlp_dim=32, **kw.pop("io", {})))
+        cond = kw.pop("cond", False)
+        if cond:
+            mag = ref.functionals.MagSpec(22, 4, center=False)
+            ext = ref.extractor.Extractor("signal", ref.functionals.FileToSignal(16000))
+            io = ref.IOSpec(inputs=(io.inputs[0], ref.io_spec.InputSpec("signal", mag, ref.io.LinearIO()).bind_to(ext)), targets=io.targets)
+            kw["dims_1x1"] = (8,)
+        kw.setdefault("skips_dim", 16)
+        cfg = ref.WaveNet.Config(io_spec=io, blocks=(3, 2), dims_dilated=(16,), residuals_dim=16, **kw)
+        net = ref.WaveNet.from_config(cfg).eval()
+        load_recipe(net, seed=100 + len(tag), gain=2.0)
+        rf = net.rf
+        n = 16
+        prompt = torch.randint(0, 256, (3, rf + 4), generator=g)
+        prompts = (prompt,)
+        if cond:
+            c = torch.rand(3, rf + 4, 12, generator=g)
+            prompts = (prompt, c)
+            arrays[f"{tag}_cond"] = c
+        log, h = capture_raw(net)
+        out = run_loop(net, prompts, n)
+        h.remove()
+        arrays.update({f"{tag}_prompt": prompt, f"{tag}_out": out[0], f"{tag}_raw": torch.cat(log, 1)})
+    save("wavenet_options.npz", **arrays)
+
+
 def make_freqnet():
     """WaveNet over magnitude frames (demos/freqnet.py:34-63 at reduced size): linear frame input and output, no residual
     and no skip path, grouped dilated convolutions"""
@@ -254,6 +300,33 @@ def make_srnn_weight_norm():
     save("srnn_wn.npz", **arrays)
 
 
+SRNN_OPTIONS = {
+    "gru_n2": dict(frame_sizes=(16, 4, 1), rnn_class="gru", n_rnn=2),
+    "lstm_n3": dict(frame_sizes=(16, 8, 8), rnn_class="lstm", n_rnn=3),
+    "rnn_n2_mlp2": dict(frame_sizes=(8, 2, 2), rnn_class="rnn", n_rnn=2, io=dict(n_mlp_layers=2)),
+    "gru_mean": dict(frame_sizes=(16, 4, 1), rnn_class="gru", inputs_mode="mean"),
+    "lstm_mix_ones": dict(frame_sizes=(16, 8, 8), rnn_class="lstm", inputs_mode="static_mix", h0_init="ones"),
+}
+
+
+def make_srnn_options():
+    """stacked recurrent layers per tier (n_rnn > 1), deeper MLP heads, the other inputs_mode values (one input: every mode
+    weights it by 1) and h0_init='ones' - 40 free-running steps through the reference's loop"""
+    g = torch.Generator().manual_seed(37)
+    arrays = {}
+    for tag, kw in SRNN_OPTIONS.items():
+        kw = dict(kw)
+        io = ref.IOSpec.mulaw_io(ref.IOSpec.MuLawIOConfig(mlp_dim=32, **kw.pop("io", {})))
+        net = ref.SampleRNN.from_config(ref.SampleRNN.Config(io_spec=io, hidden_dim=32, **kw)).eval()
+        load_recipe(net, seed=130 + len(tag), gain=2.0)
+        prompt = torch.randint(0, 256, (3, 2 * kw["frame_sizes"][0] + 5), generator=g)
+        log, h = capture_raw(net)
+        out = run_loop(net, (prompt,), 40)
+        h.remove()
+        arrays.update({f"{tag}_prompt": prompt, f"{tag}_out": out[0], f"{tag}_raw": torch.stack(log, 1)})
+    save("srnn_options.npz", **arrays)
+
+
 def make_s2s():
     g = torch.Generator().manual_seed(31)
     io = ref.IOSpec.magspec_io(ref.IOSpec.MagSpecIOConfig(n_fft=128, hop_length=32))
@@ -273,7 +346,8 @@ def make_s2s_variants():
     io = ref.IOSpec.magspec_io(ref.IOSpec.MagSpecIOConfig(n_fft=128, hop_length=32))
     x = torch.rand(3, 4, 65, generator=g)
     arrays = {"x": x}
-    for ds, us in (("edge_mean", "linear_resample"), ("sum", "linear_resample"), ("mean", "repeat"), ("edge_sum", "repeat")):
+    for ds, us in (("edge_mean", "linear_resample"), ("sum", "linear_resample"), ("mean", "repeat"), ("edge_sum", "repeat"),
+                   ("linear_resample", "interp"), ("edge_sum", "interp"), ("linear_resample", "linear_resample")):
         cfg = ref.Seq2SeqLSTMNetwork.Config(io_spec=io, model_dim=32, hop=4, enc_downsampling=ds, dec_upsampling=us)
         net = ref.Seq2SeqLSTMNetwork.from_config(cfg).eval()
         load_recipe(net, seed=41, gain=1.5)
@@ -374,10 +448,12 @@ if __name__ == "__main__":
     make_stft()
     make_istft()
     make_wavenet()
+    make_wavenet_options()
     make_freqnet()
     make_wavenet_padded()
     make_srnn()
     make_srnn_weight_norm()
+    make_srnn_options()
     make_s2s()
     make_s2s_variants()
     make_s2s_stacks()

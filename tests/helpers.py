@@ -62,6 +62,44 @@ def wavenet_c():
     return net.eval(), sd, arch
 
 
+WAVENET_OPTIONS = {       # tests/golden/make_golden.py: make_wavenet_options
+    "mlp2": dict(io=dict(n_mlp_layers=2)),
+    "mlp3_cond": dict(io=dict(n_mlp_layers=3), cond=True),
+    "nogate": dict(act_g=None),
+    "nogate_cond": dict(act_g=None, cond=True),
+    "rev": dict(reverse_layer_order=True),
+    "rev_noskip": dict(reverse_layer_order=True, skips_dim=None),
+    "lw": dict(layerwise_inputs=True),
+    "lw_noskip_rev": dict(layerwise_inputs=True, reverse_layer_order=True, skips_dim=None),
+    "tied": dict(tie_io_weights=True),
+}
+
+
+def wavenet_option(tag):
+    """the network of one wavenet_options.npz case and the matching oracle arguments"""
+    kw = dict(WAVENET_OPTIONS[tag])
+    io_kw = kw.pop("io", {})
+    io = mu_emb(mlp_dim=32, **io_kw)
+    cond = kw.pop("cond", False)
+    if cond:
+        ext = mmk.Extractor("signal", mmk.FileToSignal(16000))
+        io = mmk.IOSpec(inputs=(io.inputs[0], mmk.InputSpec("signal", mmk.MagSpec(22, 4, center=False), mmk.LinearIO()).bind_to(ext)),
+                        targets=io.targets)
+        kw["dims_1x1"] = (8,)
+    kw.setdefault("skips_dim", 16)
+    net = mmk.WaveNet.from_config(mmk.WaveNet.Config(io_spec=io, blocks=(3, 2), dims_dilated=(16,), residuals_dim=16, **kw))
+    load_recipe(net, seed=100 + len(tag), gain=2.0)
+    # (the hidden blocks of a deeper MLP head share ONE Linear: the state_dict, not the recipe, says what it ended up with)
+    sd = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    rev = bool(kw.get("reverse_layer_order"))
+    dil = [1, 2, 4, 1, 2]
+    arch = dict(kernels=[2] * 5, dilations=dil[::-1] if rev else dil, has_skips=kw["skips_dim"] is not None,
+                res_layers=[False, True, True, True, True] if rev else [True, True, True, True, False],
+                gated=kw.get("act_g", "Sigmoid") is not None, layerwise_inputs=bool(kw.get("layerwise_inputs")),
+                n_mlp_hidden=io_kw.get("n_mlp_layers", 0), n_cond=int(cond))
+    return net.eval(), sd, arch
+
+
 FREQNET_CASES = {"g1": (1, "Identity"), "g4": (4, "Identity"), "g2abs": (2, "Abs")}
 
 
@@ -89,7 +127,28 @@ def srnn(tag, hidden=32, mlp_dim=32, seed=None, frame_sizes=None, kind=None, wei
     return net.eval(), sd, dict(frame_sizes=fs, hidden_dim=hidden, rnn_class=k)
 
 
-S2S_VARIANTS = (("edge_mean", "linear_resample"), ("sum", "linear_resample"), ("mean", "repeat"), ("edge_sum", "repeat"))
+SRNN_OPTIONS = {      # tests/golden/make_golden.py: make_srnn_options
+    "gru_n2": dict(frame_sizes=(16, 4, 1), rnn_class="gru", n_rnn=2),
+    "lstm_n3": dict(frame_sizes=(16, 8, 8), rnn_class="lstm", n_rnn=3),
+    "rnn_n2_mlp2": dict(frame_sizes=(8, 2, 2), rnn_class="rnn", n_rnn=2, io=dict(n_mlp_layers=2)),
+    "gru_mean": dict(frame_sizes=(16, 4, 1), rnn_class="gru", inputs_mode="mean"),
+    "lstm_mix_ones": dict(frame_sizes=(16, 8, 8), rnn_class="lstm", inputs_mode="static_mix", h0_init="ones"),
+}
+
+
+def srnn_option(tag):
+    kw = dict(SRNN_OPTIONS[tag])
+    io_kw = kw.pop("io", {})
+    net = mmk.SampleRNN.from_config(mmk.SampleRNN.Config(io_spec=mu_lin(mlp_dim=32, **io_kw), hidden_dim=32, **kw))
+    load_recipe(net, seed=130 + len(tag), gain=2.0)
+    sd = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    arch = dict(frame_sizes=kw["frame_sizes"], hidden_dim=32, rnn_class=kw["rnn_class"], n_rnn=kw.get("n_rnn", 1),
+                n_mlp_hidden=io_kw.get("n_mlp_layers", 0), h0=kw.get("h0_init", "zeros"))
+    return net.eval(), sd, arch
+
+
+S2S_VARIANTS = (("edge_mean", "linear_resample"), ("sum", "linear_resample"), ("mean", "repeat"), ("edge_sum", "repeat"),
+                ("linear_resample", "interp"), ("edge_sum", "interp"), ("linear_resample", "linear_resample"))
 
 
 S2S_STACKS = {"e2d1": dict(enc_n_lstm=2), "e1d3": dict(dec_n_lstm=3),

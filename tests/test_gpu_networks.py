@@ -153,7 +153,9 @@ def test_wavenet_sampling_matches_oracle_given_uniforms(device):
 
 
 def test_wavenet_unsupported_options_fail_loudly(device):
-    net = mmk.WaveNet.from_config(mmk.WaveNet.Config(io_spec=H.mu_emb(), blocks=(2,), dims_dilated=(8,), layerwise_inputs=True)).to(device).eval()
+    with pytest.raises(NotImplementedError):
+        mmk.WaveNet.from_config(mmk.WaveNet.Config(io_spec=H.mu_emb(), blocks=(2,), dims_dilated=(8,), with_affine_residuals=True))
+    net = mmk.WaveNet.from_config(mmk.WaveNet.Config(io_spec=H.mu_emb(), blocks=(2,), dims_dilated=(8,), stride=2)).to(device).eval()
     with pytest.raises(NotImplementedError):
         net.before_generate((torch.zeros(1, 8, dtype=torch.int64, device=device),), 0)
 
@@ -723,3 +725,59 @@ def test_wavenet_pipelined_kernel_shapes(device, monkeypatch, blocks, C, B, n):
         if s_ == n - 1:
             assert torch.allclose(net._plan.last_logits(B).cpu()[gap_ok], raw[:, 0][gap_ok], **LOGIT_TOL)
     assert n_ok > 0.9 * len(steps) * B
+
+
+@pytest.mark.parametrize("tag", list(H.WAVENET_OPTIONS))
+def test_wavenet_options_match_reference_golden(device, tag):
+    """the remaining WaveNet options on the HIP path against the reference's loop: deeper MLP heads (one hidden block repeated),
+    act_g=None, reverse_layer_order (the residual-free layer runs first; without skips the head reads the residual sum),
+    layerwise_inputs, tie_io_weights; classes bit-exact, raw head outputs within the logit tolerance; then a batch of 9
+    against the oracle, teacher-forced on the device's history"""
+    g = H.golden("wavenet_options.npz")
+    net, sd, arch = H.wavenet_option(tag)
+    n_cond = arch.pop("n_cond")
+    prompt = H.T(g[f"{tag}_prompt"])
+    prompts = (prompt,) if not n_cond else (prompt, H.T(g[f"{tag}_cond"]))
+    out = run_loop(net, prompts, 16)
+    assert torch.equal(out[0].cpu(), H.T(g[f"{tag}_out"]))
+    assert torch.allclose(net._plan.last_logits(3).cpu(), H.T(g[f"{tag}_raw"])[:, -1], **LOGIT_TOL)
+    net = net.to(device)
+    gen = torch.Generator().manual_seed(len(tag))
+    rf, B, n = net.rf, 9, 24
+    p2 = torch.randint(0, 256, (B, rf + 2), generator=gen)
+    cond = (torch.rand(B, rf + 2 + n, 12, generator=gen),) if n_cond else ()
+    idx = torch.cat([p2, torch.zeros(B, n, dtype=torch.int64)], 1).to(device)
+    net.generate_block((idx, *[c.to(device) for c in cond]), p2.size(1), n)
+    net.after_generate((idx,), None)
+    got = idx.cpu()
+    want, raw = O.wavenet_generate(sd, p2, cond, n, keep_logits=True, forced=got, **arch)
+    ok = H.margin_ok(raw.numpy())
+    assert bool(((got[:, p2.size(1):] == want[:, p2.size(1):]) | ~ok).all()) and float(ok.float().mean()) > 0.9
+
+
+@pytest.mark.parametrize("tag", list(H.SRNN_OPTIONS))
+def test_sample_rnn_options_match_reference_golden(device, tag):
+    """stacked recurrent layers per tier, deeper MLP heads, inputs_mode mean / static_mix (one input), h0_init='ones' on the HIP
+    path against the reference's loop (classes bit-exact where the fixture's logit gap allows), then 11 clips against the
+    oracle teacher-forced on the device's history"""
+    g = H.golden("srnn_options.npz")
+    net, sd, arch = H.srnn_option(tag)
+    raw = g[f"{tag}_raw"].reshape(3, 40, 257)
+    ok = H.margin_ok(raw)
+    out = run_loop(net, (H.T(g[f"{tag}_prompt"]),), 40, parameters=None)[0].cpu()
+    P = g[f"{tag}_prompt"].shape[1]
+    bad = (~ok).float().cumsum(1) > 0
+    assert bool(((out[:, P:] == H.T(g[f"{tag}_out"])[:, P:]) | bad).all()) and float(ok.float().mean()) > 0.9
+    net = net.to(device)
+    gen = torch.Generator().manual_seed(len(tag))
+    fs0 = arch["frame_sizes"][0]
+    B, n = 11, 50
+    prompt = torch.randint(0, 256, (B, 3 * fs0 + 3), generator=gen)
+    idx = torch.cat([prompt, torch.zeros(B, n, dtype=torch.int64)], 1).to(device)
+    net.before_generate((idx[:, :prompt.size(1)],), None)
+    net.generate_block((idx,), prompt.size(1), n)
+    net.after_generate((idx,), None)
+    got = idx.cpu()
+    want, raw2 = O.SampleRNNOracle(sd, **arch).generate(prompt, n, keep_logits=True, forced=got)
+    ok2 = H.margin_ok(raw2.numpy())
+    assert bool(((got[:, prompt.size(1):] == want[:, prompt.size(1):]) | ~ok2).all()) and float(ok2.float().mean()) > 0.9

@@ -212,3 +212,33 @@ def test_seq2seq_lstm_stacks_match_reference(tag):
     y = O.s2s_step(sd, H.T(g["x"]), hop=4, downsampling=kw.get("enc_downsampling", "edge_sum"),
                    enc_residuals=kw.get("enc_apply_residuals", False), dec_residuals=kw.get("dec_apply_residuals", False))
     assert torch.allclose(y, H.T(g[f"y_{tag}"]), rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("tag", list(H.WAVENET_OPTIONS))
+def test_wavenet_options_oracle_matches_reference(tag):
+    """deeper MLP heads, act_g=None, reverse_layer_order, layerwise_inputs, tie_io_weights: the oracle's loop against the
+    reference's (classes exact, raw head outputs 1e-5) on the committed fixture"""
+    g = H.golden("wavenet_options.npz")
+    _, sd, arch = H.wavenet_option(tag)
+    n_cond = arch.pop("n_cond")
+    prompt = H.T(g[f"{tag}_prompt"])
+    n = 16
+    cond = ()
+    if n_cond:
+        c = H.T(g[f"{tag}_cond"])
+        cond = (torch.cat([c, torch.zeros(c.size(0), n, c.size(2))], 1),)     # the loop leaves blanks in the generated region
+    out, raw = O.wavenet_generate(sd, prompt, cond, n, keep_logits=True, **arch)
+    assert torch.equal(out, H.T(g[f"{tag}_out"]))
+    assert torch.allclose(raw, H.T(g[f"{tag}_raw"]), rtol=1e-5, atol=1e-5)
+    assert bool(H.margin_ok(g[f"{tag}_raw"]).all())
+
+
+@pytest.mark.parametrize("tag", list(H.SRNN_OPTIONS))
+def test_sample_rnn_options_oracle_matches_reference(tag):
+    """stacked recurrent layers (n_rnn 2 / 3), deeper MLP head, inputs_mode mean / static_mix, h0_init ones"""
+    g = H.golden("srnn_options.npz")
+    _, sd, arch = H.srnn_option(tag)
+    o = O.SampleRNNOracle(sd, **arch)
+    out, raw = o.generate(H.T(g[f"{tag}_prompt"]), 40, keep_logits=True)
+    assert torch.equal(out, H.T(g[f"{tag}_out"]))
+    assert torch.allclose(raw, H.T(g[f"{tag}_raw"]).reshape(raw.shape), rtol=1e-5, atol=1e-5)
