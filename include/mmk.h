@@ -72,6 +72,15 @@ int mmk_mulaw_compress_f32_i64(const float* x, int64_t* codes, int64_t n, int32_
 int mmk_mulaw_expand_i64_f32(const int64_t* codes, float* x, int64_t n, int32_t q_levels,
                              float compression, const float* table, mmk_stream_t stream);
 
+/* Resample.torch_func (mimikit/features/functionals.py:292-310) = torchaudio.functional.resample(x, orig_sr, target_sr):
+ * polyphase windowed-sinc FIR.  orig / nnew are the two rates divided by their gcd; `table` is the (nnew, 2*width + orig)
+ * filter bank torchaudio builds (Hann-windowed sinc, lowpass_filter_width 6, rolloff 0.99), row j = output phase j.
+ * x: (batch, n_in) rows x_row_stride apart; out: (batch, mmk_resample_n_out(n_in, orig, nnew)) rows out_row_stride apart.
+ * Used between the networks of an EnsembleGenerator event (mimikit/models/ensemble_generator.py:113-144). */
+int64_t mmk_resample_n_out(int64_t n_in, int32_t orig, int32_t nnew);
+int mmk_resample_f32(const float* x, int64_t x_row_stride, int32_t batch, int64_t n_in, const float* table, int32_t orig,
+                     int32_t nnew, int32_t width, float* out, int64_t out_row_stride, mmk_stream_t stream);
+
 /* STFT.torch_func with coordinate="mag" == MagSpec.torch_func
  * (mimikit/features/functionals.py:507-524, :576-606): periodic-Hann framed
  * real FFT magnitudes.  x: (batch, n_samples) rows `x_row_stride` apart,

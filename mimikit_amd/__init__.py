@@ -15,3 +15,4 @@ from .modules import *
 from .io_spec import *
 from .networks import *
 from .loops import *
+from .models import *

@@ -103,6 +103,44 @@ __global__ __launch_bounds__(256) void mulaw_expand_kernel(const int64_t* __rest
   }
 }
 
+// ---- band-limited resampling ---------------------------------------------------------
+// Resample.torch_func (features/functionals.py:305-306) = torchaudio.functional.resample: a polyphase windowed-sinc FIR.
+// With orig = orig_sr / gcd and new = new_sr / gcd, output sample n * new + j of a row is
+//     sum_k kernel[j][k] * x[n * orig + k - width]            (zero outside the row), k < 2 width + orig,
+// for n < ceil(T / orig), cut to ceil(new * T / orig) samples.  The (new, 2 width + orig) kernel table is built on the host
+// exactly as torchaudio builds it (float64, Hann-windowed sinc, rolloff 0.99, lowpass_filter_width 6;
+// mimikit_amd/features/functionals.py) - a filter table like the FFT's twiddles.  One workgroup per (row, block of input
+// steps): the input span is staged in LDS once and every output phase reads it from there; the table streams from L2.
+constexpr int kRsSteps = 8;          // input steps (of `orig` samples) per workgroup
+
+__global__ __launch_bounds__(256) void resample_kernel(const float* __restrict__ x, int64_t x_row_stride, int64_t n_in,
+                                                      const float* __restrict__ table, int orig, int nnew, int width,
+                                                      float* __restrict__ out, int64_t out_row_stride, int64_t n_out) {
+  extern __shared__ float s_x[];
+  const int row = blockIdx.y;
+  const int64_t step0 = (int64_t)blockIdx.x * kRsSteps;
+  const int taps = 2 * width + orig;
+  const int span = (kRsSteps - 1) * orig + taps;                 // input samples the block's outputs read
+  const float* xr = x + (int64_t)row * x_row_stride;
+  const int64_t first = step0 * orig - width;
+  for (int i = threadIdx.x; i < span; i += blockDim.x) {
+    const int64_t t = first + i;
+    s_x[i] = (t >= 0 && t < n_in) ? xr[t] : 0.f;
+  }
+  __syncthreads();
+  float* orow = out + (int64_t)row * out_row_stride;
+  for (int o = threadIdx.x; o < kRsSteps * nnew; o += blockDim.x) {
+    const int st = o / nnew, j = o - st * nnew;
+    const int64_t idx = (step0 + st) * nnew + j;
+    if (idx >= n_out) continue;
+    const float* w = table + (int64_t)j * taps;
+    const float* xs = s_x + st * orig;
+    float acc = 0.f;
+    for (int k = 0; k < taps; ++k) acc = fmaf(w[k], xs[k], acc);
+    orow[idx] = acc;
+  }
+}
+
 // (the framed STFT kernels live in istft.hip)
 
 }  // namespace mmk
@@ -133,6 +171,28 @@ extern "C" int mmk_mulaw_expand_i64_f32(const int64_t* codes, float* x, int64_t 
   hipLaunchKernelGGL(mulaw_expand_kernel, dim3((unsigned)blocks), dim3(256),
                      (size_t)(q_levels <= kMuLawLdsLevels ? q_levels : 1) * sizeof(float), (hipStream_t)stream, codes, x, n, q_levels,
                      compression, table);
+  MMK_HIP(hipGetLastError());
+  return MMK_OK;
+}
+
+extern "C" int64_t mmk_resample_n_out(int64_t n_in, int32_t orig, int32_t nnew) {
+  if (orig <= 0 || nnew <= 0 || n_in < 0) return 0;
+  return (nnew * n_in + orig - 1) / orig;          // ceil(new * T / orig), as torchaudio cuts its output
+}
+
+extern "C" int mmk_resample_f32(const float* x, int64_t x_row_stride, int32_t batch, int64_t n_in, const float* table, int32_t orig,
+                                int32_t nnew, int32_t width, float* out, int64_t out_row_stride, mmk_stream_t stream) {
+  using namespace mmk;
+  if (!x || !out || !table || batch <= 0 || n_in <= 0 || orig <= 0 || nnew <= 0 || width < 0)
+    return fail(MMK_ERR_INVALID, "resample: bad arguments");
+  const int taps = 2 * width + orig;
+  const size_t lds = (size_t)((kRsSteps - 1) * orig + taps) * sizeof(float);
+  if (lds > 160 * 1024) return fail(MMK_ERR_UNSUPPORTED, "resample: %d / %d needs %zu bytes of LDS per workgroup", orig, nnew, lds);
+  const int64_t n_out = mmk_resample_n_out(n_in, orig, nnew);
+  const int64_t steps = (n_in + orig - 1) / orig;
+  dim3 grid((unsigned)((steps + kRsSteps - 1) / kRsSteps), (unsigned)batch);
+  hipLaunchKernelGGL(resample_kernel, grid, dim3(256), lds, (hipStream_t)stream, x, x_row_stride, n_in, table, orig, nnew, width, out,
+                     out_row_stride, n_out);
   MMK_HIP(hipGetLastError());
   return MMK_OK;
 }

@@ -32,7 +32,7 @@ from .item_spec import Frame, Sample, Unit, convert
 
 __all__ = [
     "Continuous", "Discrete", "Functional", "Identity", "Compose", "FileToSignal", "RemoveDC", "Normalize",
-    "MuLawCompress", "MuLawExpand", "STFT", "ISTFT", "MagSpec", "GLA",
+    "MuLawCompress", "MuLawExpand", "STFT", "ISTFT", "MagSpec", "GLA", "Resample",
 ]
 
 N_FFT = 2048
@@ -182,6 +182,61 @@ class RemoveDC(Functional):
     @property
     def inv(self) -> Functional:
         return Identity()
+
+
+@functools.lru_cache(maxsize=16)
+def resample_filter_bank(orig_sr: int, target_sr: int, lowpass_filter_width: int = 6, rolloff: float = 0.99):
+    """(orig, new, width, table (new, 2 width + orig) fp32): the Hann-windowed sinc filter bank of
+    torchaudio.functional.resample (2.0.1: ``_get_sinc_resample_kernel``, sinc_interp_hann, computed in float64), built with
+    torch ops on the host - a filter table like the FFT's twiddles, not a data path."""
+    import math
+    g = math.gcd(int(orig_sr), int(target_sr))
+    orig, new = int(orig_sr) // g, int(target_sr) // g
+    base_freq = min(orig, new) * rolloff
+    width = math.ceil(lowpass_filter_width * orig / base_freq)
+    idx = torch.arange(-width, width + orig, dtype=torch.float64)[None, None] / orig
+    t = torch.arange(0, -new, -1, dtype=torch.float64)[:, None, None] / new + idx
+    t = (t * base_freq).clamp_(-lowpass_filter_width, lowpass_filter_width)
+    window = torch.cos(t * math.pi / lowpass_filter_width / 2) ** 2
+    t = t * math.pi
+    scale = base_freq / orig
+    kernels = torch.where(t == 0, torch.tensor(1.0, dtype=torch.float64), t.sin() / t)
+    kernels = kernels * window * scale
+    return orig, new, width, kernels.reshape(new, 2 * width + orig).to(torch.float32).contiguous()
+
+
+_RESAMPLE_TABLES = {}
+
+
+@dtc.dataclass
+class Resample(Functional):
+    """reference :292-310.  The torch path is ``torchaudio.functional.resample`` there; here its polyphase windowed-sinc
+    filter runs as a HIP kernel (``csrc/features.hip``).  Parity is UNPINNED (torchaudio is not installed in the build
+    container): the oracle restates torchaudio 2.0.1's published algorithm, see DESIGN.md section 4."""
+    orig_sr: int = SR
+    target_sr: int = 16000
+
+    @property
+    def unit(self) -> Optional[Unit]:
+        return Sample(self.target_sr)
+
+    def np_func(self, inputs):
+        raise NotImplementedError("the numpy path of Resample is librosa's soxr resampler (dataset preparation, out of scope)")
+
+    def torch_func(self, inputs):
+        from .. import native
+        native.require_device(inputs)
+        if int(self.orig_sr) == int(self.target_sr):
+            return inputs
+        orig, new, width, table = resample_filter_bank(int(self.orig_sr), int(self.target_sr))
+        key = (int(self.orig_sr), int(self.target_sr), str(inputs.device))
+        if key not in _RESAMPLE_TABLES:
+            _RESAMPLE_TABLES[key] = table.to(inputs.device)
+        return native.resample(inputs, _RESAMPLE_TABLES[key], orig, new, width)
+
+    @property
+    def inv(self) -> Functional:
+        return Resample(self.target_sr, self.orig_sr)
 
 
 @dtc.dataclass

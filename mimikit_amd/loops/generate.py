@@ -83,6 +83,7 @@ class _ArrayPromptLoader:
     def __init__(self, dataset, items, positions, max_i, batch_size, device, downsampling):
         self.dataset, self.items, self.positions = dataset, items, positions
         self.max_i, self.batch_size, self.device, self.downsampling = max_i, batch_size, device, downsampling
+        self.sampler = None
 
     def _source(self, name):
         if isinstance(self.dataset, dict):
@@ -90,8 +91,13 @@ class _ArrayPromptLoader:
         return getattr(self.dataset, name)
 
     def __iter__(self):
-        rng = np.random.default_rng()
-        where = [int(rng.integers(0, max(self.max_i, 1))) if p is None else int(p) for p in self.positions]
+        # reference get_dataloader (:113-139): fixed positions as given, None = a random position on the dataset's
+        # down-sampling stride, drawn again for every pass (IndicesSampler, loops/samplers.py:50-81)
+        if self.sampler is None:
+            from .samplers import IndicesSampler
+            self.sampler = IndicesSampler(N=len(self.positions), indices=tuple(self.positions), max_i=max(self.max_i, 1),
+                                          redraw=True, sampling_stride=self.downsampling)
+        where = [int(i) for i in self.sampler]
         for start in range(0, len(where), self.batch_size):
             chunk = where[start:start + self.batch_size]
             feats = []

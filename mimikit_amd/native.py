@@ -57,6 +57,8 @@ _SIGNATURES = {
     "mmk_pack_launch_count": (i64, []),
     "mmk_mulaw_compress_f32_i64": (i32, [vp, vp, i64, i32, f32, vp, vp]),
     "mmk_mulaw_expand_i64_f32": (i32, [vp, vp, i64, i32, f32, vp, vp]),
+    "mmk_resample_n_out": (i64, [i64, i32, i32]),
+    "mmk_resample_f32": (i32, [vp, i64, i32, i64, vp, i32, i32, i32, vp, i64, vp]),
     "mmk_stft_n_frames": (i64, [i64, i32, i32, i32]),
     "mmk_stft_mag_f32": (i32, [vp, i64, i32, i64, i32, i32, i32, vp, vp]),
     "mmk_stft_f32": (i32, [vp, i64, i32, i64, i32, i32, i32, i32, i32, vp, vp]),
@@ -182,6 +184,20 @@ def mulaw_expand(codes: torch.Tensor, q_levels: int, compression: float, table: 
     check(lib().mmk_mulaw_expand_i64_f32(ptr(codes), ptr(out), codes.numel(), q_levels, compression, ptr(table),
                                          stream_ptr(codes.device)), "mmk_mulaw_expand_i64_f32")
     return out
+
+
+def resample(x: torch.Tensor, table: torch.Tensor, orig: int, new: int, width: int) -> torch.Tensor:
+    """x: (..., n) fp32 -> (..., ceil(new * n / orig)); `table`: the (new, 2 * width + orig) polyphase filter bank"""
+    require_device(x, table)
+    if x.dtype != torch.float32:
+        x = x.float()
+    lead = x.shape[:-1]
+    x2 = _rows(x)
+    n_out = lib().mmk_resample_n_out(x2.shape[-1], orig, new)
+    out = torch.empty((x2.shape[0], n_out), dtype=torch.float32, device=x.device)
+    check(lib().mmk_resample_f32(ptr(x2), x2.stride(0), x2.shape[0], x2.shape[-1], ptr(table), orig, new, width, ptr(out), out.stride(0),
+                                 stream_ptr(x.device)), "mmk_resample_f32")
+    return out.reshape(*lead, n_out)
 
 
 def _rows(x: torch.Tensor) -> torch.Tensor:

@@ -129,6 +129,36 @@ def griffin_lim(mag: torch.Tensor, n_fft: int, hop: int, n_iter: int = 32, momen
     return torch.istft(spec * angles, n_fft=n_fft, hop_length=hop, win_length=n_fft, window=window, length=None)
 
 
+def resample(x: torch.Tensor, orig_sr: int, target_sr: int, lowpass_filter_width: int = 6, rolloff: float = 0.99) -> torch.Tensor:
+    """Resample.torch_func, features/functionals.py:305-306 = torchaudio.functional.resample(x, orig_sr, target_sr).
+
+    PARITY UNPINNED: torchaudio (pinned to 2.0.1 by the reference) is not installed in the build container.  This restates
+    torchaudio 2.0.1's published ``_get_sinc_resample_kernel`` / ``_apply_sinc_resample_kernel`` (sinc_interp_hann):
+    the filter bank in float64, then a strided conv1d over the zero-padded signal, cut to ceil(new * T / orig) samples."""
+    import math
+    if int(orig_sr) == int(target_sr):
+        return x
+    g = math.gcd(int(orig_sr), int(target_sr))
+    orig, new = int(orig_sr) // g, int(target_sr) // g
+    base_freq = min(orig, new) * rolloff
+    width = math.ceil(lowpass_filter_width * orig / base_freq)
+    idx = torch.arange(-width, width + orig, dtype=torch.float64)[None, None] / orig
+    t = torch.arange(0, -new, -1, dtype=torch.float64)[:, None, None] / new + idx
+    t = (t * base_freq).clamp_(-lowpass_filter_width, lowpass_filter_width)
+    window = torch.cos(t * math.pi / lowpass_filter_width / 2) ** 2
+    t = t * math.pi
+    kernels = torch.where(t == 0, torch.tensor(1.0, dtype=torch.float64), t.sin() / t) * window * (base_freq / orig)
+    kernels = kernels.to(x.dtype)
+    shape = x.shape
+    w = x.reshape(-1, shape[-1])
+    length = w.shape[-1]
+    w = F.pad(w, (width, width + orig))
+    res = F.conv1d(w[:, None], kernels, stride=orig)
+    res = res.transpose(1, 2).reshape(w.shape[0], -1)
+    target_length = int(math.ceil(new * length / orig))
+    return res[..., :target_length].reshape(*shape[:-1], target_length)
+
+
 # ---------------------------------------------------------------------------
 # head: MLP with learned temperature + categorical sampler
 # ---------------------------------------------------------------------------

@@ -436,6 +436,19 @@ def make_keys():
                 "s2f_len": I.convert(n, I.Sample(1), fr, True), "s2f_pos": I.convert(n, I.Sample(1), fr, False),
                 "f2s_len": I.convert(n // hop, fr, I.Sample(1), True), "f2s_pos": I.convert(n // hop, fr, I.Sample(1), False),
             })
+    # prompt positions of the generate loop: the reference's IndicesSampler (loops/samplers.py:50-81) under a fixed torch seed
+    import importlib
+    smp = importlib.import_module("mimikit.loops.samplers")
+    # (version skew: the reference calls Sampler.__init__(None), which torch 2.10's Sampler no longer accepts)
+    import torch.utils.data as tud
+    tud.Sampler.__init__ = lambda self, *a, **k: None
+    torch.manual_seed(123)
+    sampler = smp.IndicesSampler(N=4, indices=(None, 7, None, None), max_i=10000, redraw=True, sampling_stride=16)
+    host["indices_sampler"] = {"seed": 123, "indices": [None, 7, None, None], "max_i": 10000, "stride": 16,
+                               "passes": [[int(i) for i in sampler] for _ in range(3)]}
+    torch.manual_seed(321)
+    sampler = smp.IndicesSampler(N=5, indices=[], min_i=3, max_i=50, redraw=False)
+    host["indices_sampler_n"] = {"seed": 321, "N": 5, "min_i": 3, "max_i": 50, "passes": [[int(i) for i in sampler] for _ in range(2)]}
     out["host"] = host
     out["meta"] = META
     with open(os.path.join(OUT, "reference_facts.json"), "w") as f:

@@ -226,3 +226,65 @@ def test_product_never_imports_the_oracle():
             if name.endswith(".py"):
                 src = open(os.path.join(dirpath, name)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle", src, re.M), f"{name} imports the oracle"
+
+
+# ---------------------------------------------------------------------------- prompt serving / callers
+def test_indices_sampler_matches_reference_draws():
+    """IndicesSampler under a fixed torch seed against the draws of the reference's own class (reference_facts.json): fixed
+    positions stay, None entries are drawn on the sampling stride and redrawn after every pass; list form = N plain draws"""
+    import torch
+    f = H.facts()["host"]["indices_sampler"]
+    torch.manual_seed(f["seed"])
+    s = mmk.IndicesSampler(N=4, indices=tuple(f["indices"]), max_i=f["max_i"], redraw=True, sampling_stride=f["stride"])
+    assert [[int(i) for i in s] for _ in range(3)] == f["passes"]
+    assert all(i % f["stride"] == 0 for p in f["passes"] for k, i in enumerate(p) if k != 1)
+    g = H.facts()["host"]["indices_sampler_n"]
+    torch.manual_seed(g["seed"])
+    s = mmk.IndicesSampler(N=g["N"], indices=[], min_i=g["min_i"], max_i=g["max_i"], redraw=False)
+    assert [[int(i) for i in s] for _ in range(2)] == g["passes"]
+    assert mmk.PromptIndices(10)(7).tolist() == [7] and mmk.PromptIndices(10)(7).dtype == np.int32
+
+
+def test_generate_callback_contract():
+    """loops/callbacks.py:155-169: every `every_n_epochs` epochs the callback sets loop.template_vars = {epoch} and drains
+    loop.run() to the end"""
+    class Loop:
+        def __init__(self):
+            self.template_vars, self.drained = {}, 0
+
+        def run(self):
+            for i in range(3):
+                yield i
+            self.drained += 1
+
+    class Trainer:
+        current_epoch = 0
+
+    loop, tr = Loop(), Trainer()
+    cb = mmk.GenerateCallback(loop, every_n_epochs=2)
+    for epoch in range(4):
+        tr.current_epoch = epoch
+        cb.on_train_epoch_end(tr, None)
+    assert loop.drained == 2 and loop.template_vars == {"epoch": 4}
+
+
+def test_resample_filter_bank_and_oracle_properties():
+    """the polyphase filter bank the HIP kernel takes is the one the oracle's restatement of torchaudio's resample builds:
+    evaluating output sample n * new + j as sum_k table[j][k] x[n * orig + k - width] reproduces the oracle; a constant
+    stays a constant away from the edges (unit DC gain), lengths are ceil(new * T / orig)"""
+    import torch
+    from mimikit_amd.features.functionals import resample_filter_bank
+    for o_sr, n_sr in ((22050, 16000), (16000, 22050), (44100, 16000), (8000, 16000)):
+        orig, new, width, table = resample_filter_bank(o_sr, n_sr)
+        assert table.shape == (new, 2 * width + orig)
+        x = torch.randn(2, 3000, generator=torch.Generator().manual_seed(o_sr))
+        y = O.resample(x, o_sr, n_sr)
+        assert y.shape == (2, -(-new * 3000 // orig))
+        xp = torch.nn.functional.pad(x, (width, width + orig)).double()
+        for idx in (0, 1, new + 3, y.shape[1] - 1, y.shape[1] // 2):
+            n, j = divmod(idx, new)
+            want = (table[j].double() * xp[:, n * orig:n * orig + 2 * width + orig]).sum(-1)
+            assert torch.allclose(want.float(), y[:, idx], rtol=1e-4, atol=1e-5)
+        ones = O.resample(torch.ones(1, 4000), o_sr, n_sr)
+        mid = ones[0, ones.shape[1] // 4: 3 * ones.shape[1] // 4]
+        assert float((mid - 1).abs().max()) < 2e-3
