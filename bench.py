@@ -520,24 +520,8 @@ def main():
         from mimikit_amd.shard import broadcast_weights
         broadcast_weights(job.net, src=0)          # the path's only collective
 
-    def fence():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        job.one_pass()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        job.one_pass()
-    fence()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    from mimikit_amd.shard import timed_passes
+    elapsed = timed_passes(job.one_pass, args.steps, args.warmup, torch.cuda.synchronize)   # barrier + sync, MAX over ranks
 
     units = job.units_per_pass() * args.steps * world
     value = units / elapsed

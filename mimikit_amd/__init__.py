@@ -16,3 +16,4 @@ from .io_spec import *
 from .networks import *
 from .loops import *
 from .models import *
+from .checkpoint import *

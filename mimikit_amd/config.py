@@ -15,10 +15,17 @@ import dataclasses as dtc
 import sys
 from typing import Any, Dict, Tuple
 
-__all__ = ["private_runtime_field", "Config", "Configurable"]
+__all__ = ["private_runtime_field", "Config", "Configurable", "STATIC_TYPED_KEYS"]
 
 _RUNTIME_ONLY = "omegaconf_ignore"  # same metadata key as the reference, so views of it keep working
 _REGISTRY: Dict[str, type] = {}
+_UNTAGGED: set = set()              # classes declared with type_field=False: typed by the KEY they sit under
+# reference config.py:33-42: mappings under these keys carry no `type` tag in the YAML, the key says what they are
+STATIC_TYPED_KEYS = {
+    "dataset": "DatasetConfig", "io_spec": "IOSpec", "inputs": "InputSpec", "targets": "TargetSpec",
+    "objective": "Objective", "extra_loss_terms": "Objective", "extractor": "Extractor", "extractors": "Extractor",
+    "activation": "ActivationConfig",
+}
 
 
 def private_runtime_field(default):
@@ -59,6 +66,7 @@ class Config:
         tag = _qualified_name(cls)
         _REGISTRY[tag] = cls
         if not type_field:
+            _UNTAGGED.add(cls)
             return
         # inject `type: str = <qualified name>` as the first, non-init field
         own = dict(cls.__dict__.get("__annotations__", {}))
@@ -76,7 +84,8 @@ class Config:
         def plain(v):
             if isinstance(v, Config):
                 d = {k: plain(x) for k, x in v._public_items()}
-                d.setdefault("type", _qualified_name(type(v)))
+                if type(v) not in _UNTAGGED:            # the reference's layout: untagged classes are typed by their key
+                    d.setdefault("type", _qualified_name(type(v)))
                 return d
             if isinstance(v, (tuple, list)):
                 return [plain(x) for x in v]
@@ -101,15 +110,22 @@ class Config:
 
     @staticmethod
     def object(plain, as_type=None):
+        """plain YAML data -> config objects.  Mappings are typed by their `type` tag, else by the key they sit under
+        (STATIC_TYPED_KEYS, as the reference does, config.py:93-118), else stay dicts."""
         if isinstance(plain, dict):
             cls = as_type if as_type is not None else (_resolve(plain["type"]) if "type" in plain else None)
-            vals = {k: Config.object(v) for k, v in plain.items() if k != "type"}
+            vals = {}
+            for k, v in plain.items():
+                if k == "type":
+                    continue
+                key_type = _REGISTRY.get(STATIC_TYPED_KEYS[k]) if k in STATIC_TYPED_KEYS else None
+                vals[k] = Config.object(v, key_type)
             if cls is None:
                 return vals
             init_names = {f.name for f in dtc.fields(cls) if f.init}
             return cls(**{k: (tuple(v) if isinstance(v, list) else v) for k, v in vals.items() if k in init_names})
         if isinstance(plain, (list, tuple)):
-            return tuple(Config.object(v) for v in plain)
+            return tuple(Config.object(v, as_type) for v in plain)
         return plain
 
     # -- conveniences --------------------------------------------------------

@@ -6,12 +6,12 @@ only communication on the path is ONE broadcast of the flattened fp32 weight blo
 (RCCL over xGMI when the process group backend is "nccl"; gloo on CPU in the tests).  There is
 no per-step collective.  ``gather_clips`` optionally brings the finished clips back to rank 0.
 """
-from typing import List, Optional, Tuple
+from typing import Callable, List, Optional, Tuple
 
 import torch
 import torch.distributed as dist
 
-__all__ = ["clip_slice", "broadcast_weights", "gather_clips"]
+__all__ = ["clip_slice", "broadcast_weights", "gather_clips", "timed_passes"]
 
 
 def clip_slice(n_clips: int, rank: int, world_size: int) -> Tuple[int, int]:
@@ -42,17 +42,52 @@ def broadcast_weights(module: torch.nn.Module, src: int = 0, group=None) -> int:
 
 
 def gather_clips(local: torch.Tensor, dst: int = 0, group=None) -> Optional[torch.Tensor]:
-    """concatenate every rank's (clips, ...) tensor along dim 0 on rank `dst` (None elsewhere)"""
+    """concatenate every rank's (clips, ...) tensor along dim 0 on rank `dst` (None elsewhere): a true gather - only `dst`
+    receives data (the optional gather of the finished clips, 4.9 MB per rank at BASELINE config 4)"""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return local
-    world = dist.get_world_size(group)
-    sizes = [torch.zeros(1, dtype=torch.int64, device=local.device) for _ in range(world)]
-    dist.all_gather(sizes, torch.tensor([local.size(0)], dtype=torch.int64, device=local.device), group=group)
-    biggest = int(max(int(s) for s in sizes))
-    padded = torch.zeros((biggest, *local.shape[1:]), dtype=local.dtype, device=local.device)
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    n_local = torch.tensor([local.size(0)], dtype=torch.int64, device=local.device)
+    sizes = [torch.zeros(1, dtype=torch.int64, device=local.device) for _ in range(world)] if rank == dst else None
+    dist.gather(n_local, sizes, dst=dst, group=group)
+    # every rank pads to the size clip_slice gives the first rank (the largest one), so that no second round is needed
+    # to agree on a common shape: ranks differ by at most one clip
+    biggest = torch.tensor([local.size(0)], dtype=torch.int64, device=local.device)
+    dist.all_reduce(biggest, op=dist.ReduceOp.MAX, group=group)
+    padded = torch.zeros((int(biggest), *local.shape[1:]), dtype=local.dtype, device=local.device)
     padded[:local.size(0)] = local
-    parts: List[torch.Tensor] = [torch.empty_like(padded) for _ in range(world)]
-    dist.all_gather(parts, padded, group=group)
-    if dist.get_rank(group) != dst:
+    parts: Optional[List[torch.Tensor]] = [torch.empty_like(padded) for _ in range(world)] if rank == dst else None
+    dist.gather(padded, parts, dst=dst, group=group)
+    if rank != dst:
         return None
     return torch.cat([p[:int(n)] for p, n in zip(parts, sizes)], dim=0)
+
+
+def timed_passes(one_pass: Callable[[], None], steps: int, warmup: int, sync: Callable[[], None], group=None) -> float:
+    """the bench contract's timing (bench.py): `warmup` untimed passes, then EXACTLY `steps` passes between two fences
+    (device sync + barrier + device sync), elapsed time = MAX over ranks.  `sync` waits for the local device."""
+    import time
+    multi = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+
+    def fence():
+        sync()
+        if multi:
+            dist.barrier(group=group)
+        sync()
+
+    for _ in range(warmup):
+        one_pass()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        one_pass()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if multi:
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        backend = dist.get_backend(group)
+        if backend == "nccl":
+            t = t.cuda()
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+        elapsed = float(t.item())
+    return elapsed

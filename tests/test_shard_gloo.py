@@ -55,3 +55,38 @@ def test_two_rank_weight_broadcast_and_gather():
     assert not r0["changed"] and r1["changed"]
     assert r0["nbytes"] == r1["nbytes"] > 0
     assert r0["gathered"] == [[i] * 3 for i in range(5)] and r1["gathered"] is None
+
+
+def _bench_worker(rank, world, port, out):
+    """the bench contract under gloo with a stub job: per-rank seeds, weak-scaling units, fenced timing with MAX over ranks"""
+    import time
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from mimikit_amd.shard import timed_passes
+    gen = torch.Generator().manual_seed(1234 + rank)           # bench.py: every rank draws ITS clips' synthetic inputs
+    clips = torch.rand(4, 8, generator=gen)
+    calls = []
+
+    def one_pass():
+        calls.append(time.perf_counter())
+        time.sleep(0.05 * (rank + 1))                         # rank 1 is the slow one
+
+    elapsed = timed_passes(one_pass, steps=3, warmup=2, sync=lambda: None)
+    start, stop = clip_slice(8, rank, world)
+    out[rank] = dict(elapsed=elapsed, n_calls=len(calls), first=float(clips[0, 0]), span=(start, stop))
+    dist.destroy_process_group()
+
+
+def test_bench_timing_contract_two_ranks():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    with mp.Manager() as mgr:
+        out = mgr.dict()
+        mp.spawn(_bench_worker, args=(2, port, out), nprocs=2, join=True)
+        r0, r1 = out[0], out[1]
+    assert r0["n_calls"] == r1["n_calls"] == 5                 # 2 warm-up + exactly 3 timed passes
+    assert r0["elapsed"] == r1["elapsed"]                      # MAX over ranks, agreed by all
+    assert 0.29 <= r0["elapsed"] < 0.6                         # the slow rank's 3 x 0.1 s, not the fast rank's 0.15 s
+    assert r0["first"] != r1["first"]                          # different synthetic clips per rank
+    assert r0["span"] == (0, 4) and r1["span"] == (4, 8)       # weak scaling: per-rank units fixed, global = world x
