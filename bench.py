@@ -153,7 +153,9 @@ class WaveNetJob:
                 traffic = int(per_step * n) if per_step else None
             except (OSError, ValueError):
                 pass
-            return {"bound": "hbm", "kernel": "wavenet_persist_kernel (all layers + head of every step of a block)",
+            kname = ("wavenet_pipe_kernel (layers spread over the XCDs, weights resident on chip, clip groups pipelined)" if plan.pipelined
+                     else "wavenet_chain_kernel (one hand-off per layer)" if plan.chain else "wavenet_persist_kernel")
+            return {"bound": "hbm", "kernel": kname + ": all layers + head of every step of a block",
                     "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                     "algorithmic_bytes_per_launch": nbytes, "avg_launch_us": round(us, 1), "launches_timed": 1,

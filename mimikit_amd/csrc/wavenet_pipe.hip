@@ -175,17 +175,14 @@ __global__ __launch_bounds__(kPiThreads) void wavenet_pipe_kernel(const WnPipeAr
   f32x4* wlds = (f32x4*)sp;   sp += kLdsSlot ? (size_t)nw * CPW * 64 * 16 : 0;   // the fourth iteration's tiles: [wave][fragment][lane]
   float* headbuf = (float*)sp; sp += 16 * ldy * 4;                // head stage only from here on
   float* lbuf = (float*)sp;   sp += 16 * ldl * 4;
-  const int t_fc0 = a.H1 / 16, kc_fc0 = C / 16;
   const int t_fc2 = a.n_logits_pad / 16, kc_fc2 = a.H1 / 16;
-  const int nt0 = (head_stage && j < t_fc0) ? (t_fc0 - j + a.Gn - 1) / a.Gn : 0;
   const int nt2 = (head_stage && j < t_fc2) ? (t_fc2 - j + a.Gn - 1) / a.Gn : 0;
-  f32x4* hw0 = (f32x4*)sp;    sp += (size_t)((t_fc0 + a.Gn - 1) / a.Gn) * kc_fc0 * 1024;
   f32x4* hw2 = (f32x4*)sp;    sp += (size_t)((t_fc2 + a.Gn - 1) / a.Gn) * kc_fc2 * 1024;
-  float* hb0 = (float*)sp;    sp += (size_t)((t_fc0 + a.Gn - 1) / a.Gn) * 64;
   float* hb2 = (float*)sp;
 
   const int D_q = lane >> 4, D_n = lane & 15;
-  const bool owns_res = j < KC;
+  const bool owns_res = j < KC;                            // owners [0, C/16): residual rows of the [res ; hidden] matrix
+  const bool owns_hid = j >= KC && j < KC + a.H1 / 16;     // the next H1/16: rows of fc0 . W_skip (the head's first Linear folded in)
   const bool has_cond = a.C1 > 0;
 
   for (int i = tid; i < 2 * kRows * ldh; i += NT) hbuf[i] = 0.f;
@@ -199,7 +196,7 @@ __global__ __launch_bounds__(kPiThreads) void wavenet_pipe_kernel(const WnPipeAr
   if (tid < n_loc) {
     const int i = i0 + tid;
     const WnChainIter t = a.iters[i < L ? i : 0];
-    const bool has_b = i >= 1 && (!owns_res || a.iters[i].prev_has_res);
+    const bool has_b = i >= 1 && (owns_res ? a.iters[i].prev_has_res != 0 : owns_hid);
     PiEntry e;
     e.ring_off = (unsigned)(t.ring_offset * 4);
     e.dil = (unsigned)t.dil; e.mask = (unsigned)t.ring_mask;
@@ -210,14 +207,9 @@ __global__ __launch_bounds__(kPiThreads) void wavenet_pipe_kernel(const WnPipeAr
     const int i = i0 + (q >> 4), n = q & 15;
     const WnChainIter t = a.iters[i];
     biasA[q] = (i < L && t.A_bias) ? t.A_bias[j * 16 + n] : 0.f;
-    const bool has_b = i >= 1 && (!owns_res || t.prev_has_res);
+    const bool has_b = i >= 1 && (owns_res ? t.prev_has_res != 0 : owns_hid);
     const int btile = owns_res ? j : (j - KC + (t.prev_has_res ? KC : 0));
     biasB[q] = (has_b && t.B_bias) ? t.B_bias[btile * 16 + n] : 0.f;
-  }
-  for (int i = 0; i < nt0; ++i) {
-    const f32x4* src = reinterpret_cast<const f32x4*>(a.fc0_wp) + (int64_t)(j + i * a.Gn) * kc_fc0 * 64;
-    for (int q = tid; q < kc_fc0 * 64; q += NT) hw0[i * kc_fc0 * 64 + q] = src[q];
-    if (tid < 16) hb0[i * 16 + tid] = a.fc0_bias[(j + i * a.Gn) * 16 + tid];
   }
   for (int i = 0; i < nt2; ++i) {
     const f32x4* src = reinterpret_cast<const f32x4*>(a.fc2_wp) + (int64_t)(j + i * a.Gn) * kc_fc2 * 64;
@@ -240,9 +232,9 @@ __global__ __launch_bounds__(kPiThreads) void wavenet_pipe_kernel(const WnPipeAr
       // valid tile: the result is never used
       const int i = min(i0 + q, L);
       const WnChainIter ta = a.iters[i < L ? i : 0];
-      const bool has_b = i >= 1 && (!owns_res || a.iters[i].prev_has_res);
+      const bool has_b = i >= 1 && (owns_res ? a.iters[i].prev_has_res != 0 : owns_hid);
       const WnChainIter tb = a.iters[has_b ? i : 1];
-      const int btile = owns_res ? j : (j - KC + (tb.prev_has_res ? KC : 0));
+      const int btile = owns_res ? j : ((owns_hid ? j - KC : 0) + (tb.prev_has_res ? KC : 0));
       const char* tile = role < 3 ? (const char*)(ta.A_wp + (int64_t)j * (3 * KC) * 256) : (const char*)(tb.B_wp + (int64_t)btile * KC * 256);
       const f32x4* src = reinterpret_cast<const f32x4*>(tile + w_voff);
       if (q < NREG) {
@@ -304,30 +296,13 @@ __global__ __launch_bounds__(kPiThreads) void wavenet_pipe_kernel(const WnPipeAr
   // ---- head (wavenet_persist.hip's): the head stage's workgroups, every wave --------------------------
   auto head = [&](int64_t s, int64_t tau, int g, int mg, float skipacc) -> bool {
     const int m_first = g * a.Mg;
-    u64* gran_skip = a.gran_skip + (int64_t)g * 16 * C;
     u64* gran_hid = a.gran_hid + (int64_t)g * 16 * a.H1;
     u64* gran_logit = a.gran_logit + (int64_t)g * 16 * a.n_logits_pad;
     u64* gran_idx = a.gran_idx + (int64_t)g * 16;
     const unsigned he = (unsigned)(s + 1);
-    if (wave == 1 && e_m < mg && !owns_res) gran_store<true>(gran_skip + e_m * C + (j - KC) * 16 + e_n, he, skipacc);
-    const int sw_row_y = (tid * 4) / C;
-    float* const sw_head = headbuf + sw_row_y * ldy + (tid * 4 - sw_row_y * C);
-    if (j < t_fc0) {
-      if (!sweep<NT>(gran_skip, mg * C, he, sw_head, headbuf, C, ldy, err, s_fail)) return false;
-      const int per = (kc_fc0 + nw - 1) / nw;
-      const int k0 = min(wave * per, kc_fc0), k1 = min(k0 + per, kc_fc0);
-      for (int t = j, ti = 0; t < t_fc0; t += a.Gn, ++ti) {
-        f32x4 v = reduce_waves(tile_mma(headbuf, ldy, hw0 + ti * kc_fc0 * 64, 0, k0, k1, lane), red, wave, lane, nw);
-        if (wave == 0) {
-          const float bias = hb0[ti * 16 + D_n];
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int m = 4 * D_q + r;
-            if (m < mg) gran_store<true>(gran_hid + m * a.H1 + t * 16 + D_n, he, mish_fast(v[r] + bias));
-          }
-        }
-      }
-    }
+    // the hidden units: every layer's fc0 . W_skip product has been accumulated on the way (skipacc); + fc0's bias, Mish
+    if (wave == 1 && e_m < mg && owns_hid)
+      gran_store<true>(gran_hid + e_m * a.H1 + (j - KC) * 16 + e_n, he, mish_fast(skipacc + a.fc0_bias[(j - KC) * 16 + e_n]));
     if (j < t_fc2) {
       if (!sweep<NT>(gran_hid, mg * a.H1, he, nullptr, headbuf, a.H1, ldy, err, s_fail)) return false;
       const int per = (kc_fc2 + nw - 1) / nw;
@@ -459,7 +434,12 @@ __global__ __launch_bounds__(kPiThreads) void wavenet_pipe_kernel(const WnPipeAr
   // delayed input and conditioning terms of iteration q of visit (s, g): requested one iteration ahead into registers
   f32x4 hp = f32x4{0.f, 0.f, 0.f, 0.f};
   float cnd = 0.f;
-  auto request_small = [&](int q, int64_t s, int g) {
+  // Where the request AFTER the next one reads: worked out in a loader wave's idle time (between B1 and B4), so that the top
+  // of an iteration only issues two loads from ready-made addresses (the table look-up, the 64-bit address arithmetic and
+  // their waits otherwise sit in front of the loader waves' MFMAs, and every other wave waits for them at B1).
+  gf32x4_ptr nx_src = (gf32x4_ptr)(uintptr_t)a.zeros;
+  gcfloat_ptr nx_cp = (gcfloat_ptr)(uintptr_t)a.zeros;
+  auto compute_addr = [&](int q, int64_t s, int g) {
     const int m_first = g * a.Mg;
     const int mg = min(a.Mg, a.B - m_first);
     const int slot_f4 = mg * (C / 4);
@@ -468,12 +448,15 @@ __global__ __launch_bounds__(kPiThreads) void wavenet_pipe_kernel(const WnPipeAr
     const unsigned ring_off = sgpr(e.ring_off), dil = sgpr(e.dil), mask = sgpr(e.mask);
     const unsigned ntau = (unsigned)(tau0 + s);
     gf32x4_ptr src = (gf32x4_ptr)(uintptr_t)(h_ring + ring_off + (u64)((ntau - dil) & mask) * slot_bytes + (u64)g * group_bytes);
-    hp = src[max(0, min(lt, slot_f4 - 1))];
+    nx_src = src + max(0, min(lt, slot_f4 - 1));
     const bool c_real = has_cond && i < L && lt >= 0 && lt < mg * 16;
-    gcfloat_ptr cp = c_real ? (gcfloat_ptr)(uintptr_t)(a.condall + (int64_t)(m_first + (lt >> 4)) * cond_clip + (s * L + i) * (int64_t)(2 * C) +
-                                                       j * 16 + (lt & 15))
-                            : (gcfloat_ptr)(uintptr_t)a.zeros;
-    cnd = *cp;
+    nx_cp = c_real ? (gcfloat_ptr)(uintptr_t)(a.condall + (int64_t)(m_first + (lt >> 4)) * cond_clip + (s * L + i) * (int64_t)(2 * C) +
+                                              j * 16 + (lt & 15))
+                   : (gcfloat_ptr)(uintptr_t)a.zeros;
+  };
+  auto issue_request = [&]() {
+    hp = *nx_src;
+    cnd = *nx_cp;
   };
   auto small_to_lds = [&](int cpar, int g) {
     const int mg = min(a.Mg, a.B - g * a.Mg);
@@ -482,8 +465,12 @@ __global__ __launch_bounds__(kPiThreads) void wavenet_pipe_kernel(const WnPipeAr
     if (lq < mg * 16) cndbuf[cpar * 64 + lq] = cnd;
   };
   if (is_loader) {
-    request_small(0, 0, 0);
+    compute_addr(0, 0, 0);
+    issue_request();
     small_to_lds(0, 0);
+    // the request issued at the top of the very first iteration is for the one after it
+    if (n_loc > 1) compute_addr(1, 0, 0);
+    else compute_addr(0, (a.Gc > 1 || n_visits < 2) ? 0 : 1, (a.Gc > 1 && n_visits > 1) ? 1 : 0);
   }
 
   for (int64_t v = 0; v < n_visits; ++v) {
@@ -492,6 +479,9 @@ __global__ __launch_bounds__(kPiThreads) void wavenet_pipe_kernel(const WnPipeAr
     const int64_t vn = v + 1;
     const int64_t sn = vn < n_visits ? vn / a.Gc : s;      // the visit after this one (past the end: this one again, unused)
     const int gn = vn < n_visits ? (int)(vn - sn * a.Gc) : g;
+    const int64_t vn2 = v + 2;
+    const int64_t sn2 = vn2 < n_visits ? vn2 / a.Gc : sn;  // and the one after that
+    const int gn2 = vn2 < n_visits ? (int)(vn2 - sn2 * a.Gc) : gn;
     const int m_first = g * a.Mg;
     const int mg = min(a.Mg, a.B - m_first);
     const int64_t tau = tau0 + s;
@@ -557,7 +547,7 @@ __global__ __launch_bounds__(kPiThreads) void wavenet_pipe_kernel(const WnPipeAr
       if (!sweep_yh(a.gran_yx + (int64_t)(g * 2 + pin) * 16 * C, a.gran_hx + (int64_t)(g * 2 + pin) * 16 * C, true, mg * C, ep,
                     ybuf + par * kRows * ldh, hbuf + par * kRows * ldh))
         return;                                              // ... P1
-      if (wave == 1 && elem && !owns_res) {                  // the running skip sums come with them
+      if (wave == 1 && elem && owns_hid) {                   // the running sums of the hidden units' pre-activations come with them
         unsigned spins = 0;
         u64 w;
         const u64* gp = a.gran_skipfwd + (int64_t)(g * 2 + pin) * 16 * C + e_m * C + (j - KC) * 16 + e_n;
@@ -586,10 +576,7 @@ __global__ __launch_bounds__(kPiThreads) void wavenet_pipe_kernel(const WnPipeAr
         u64* gran_y = gran_yl0 + par * 16 * C;
         u64* gran_h = gran_hl0 + par * 16 * C;
         // the next iteration's small operands (after the last one: the next visit's first iteration)
-        if (is_loader) {
-          if (last_loc) request_small(0, sn, gn);
-          else request_small(q + 1, s, g);
-        }
+        if (is_loader) issue_request();                      // the next iteration's small operands (addresses ready-made)
         __builtin_amdgcn_sched_barrier(0);
         {
           const float* xsrc = (role == 0 ? hprev : (role == 1 ? hbuf + hsel * kRows * ldh : ybuf + ((i + 1) & 1) * kRows * ldh)) + opaque(x_off);
@@ -648,17 +635,24 @@ __global__ __launch_bounds__(kPiThreads) void wavenet_pipe_kernel(const WnPipeAr
               } else {
                 gran_store<true>(gran_h + hs, epoch, hn);
               }
-            } else {
+            } else {                                         // (flags & 2: a hidden-row owner)
               skipacc = (i == 1) ? vb : vb + skipacc;
             }
           }
-          if (cross && elem && !owns_res) gran_store<false>(gran_sk_out + e_m * C + (j - KC) * 16 + e_n, epoch, skipacc);
+          if (cross && elem && owns_hid) gran_store<false>(gran_sk_out + e_m * C + (j - KC) * 16 + e_n, epoch, skipacc);
           // (one iteration per stage: the embedding rows h_0 travel to the stage of layer 1 as every other layer input does)
           if (cross && i == 0 && elem && owns_res) gran_store<false>(gran_hx_out + h_slot, epoch, hbuf[res_off]);
         }
         stamp(1);
         // the next iteration's delayed input and conditioning terms -> LDS (hprev was last read before B1)
-        if (is_loader) small_to_lds((int)((v * n_loc + q + 1) & 1), last_loc ? gn : g);
+        if (is_loader) {
+          small_to_lds((int)((v * n_loc + q + 1) & 1), last_loc ? gn : g);
+          // address of the request the NEXT iteration's top will issue: for the iteration after that
+          if (q + 2 < n_loc) compute_addr(q + 2, s, g);
+          else if (q + 1 < n_loc) compute_addr(0, sn, gn);                 // next is the visit's last: then the next visit's first
+          else if (n_loc > 1) compute_addr(1, sn, gn);                     // next is the next visit's first: then its second
+          else compute_addr(0, sn2, gn2);                                  // one iteration per visit: the visit after the next
+        }
         if (!is_loader && q >= 1 && i >= 2) {   // h_{i-1}[tau] (complete since the last sweep) joins the history ring of layer i-1
           const PiEntry ep = tab[q - 1];
           gf32x4_wptr dst = (gf32x4_wptr)(uintptr_t)(h_ring + sgpr(ep.ring_off) + (u64)(tau_u & sgpr(ep.mask)) * slot_bytes + (u64)g * group_bytes);
@@ -688,7 +682,7 @@ __global__ __launch_bounds__(kPiThreads) void wavenet_pipe_kernel(const WnPipeAr
     }
   }
   if (pend_g >= 0) (void)own_h_to_ring(pend_g, pend_tau, pend_epoch);
-  if (STAMPS && a.stamps && stage == 1 && j == 1 && tid == 0) {
+  if (STAMPS && a.stamps && stage == a.stamp_stage && j == a.stamp_owner && tid == 0) {
     st_acc[14] = clock64() - clk_start;
     st_acc[15] = wall_clock64() - wall_start;
     for (int i = 0; i < 16; ++i) a.stamps[i] = st_acc[i];
@@ -708,7 +702,7 @@ size_t wn_pipe_lds_bytes(const WnPipeArgs& a) {
   const int ldh = a.C + 4, ldy = wide + 4, ldl = a.n_logits_pad + 4;
   return (size_t)5 * 4 * ldh * 4 + (size_t)nw * 64 * 16 + (size_t)kPiMaxIt * (16 + 128) + 2 * 64 * 4 + 16 * 4 + 16 +
          (wn_pipe_iters_per_stage(a.L) > kPiRegSlots ? (size_t)nw * (kc / 2) * 64 * 16 : 0) + (size_t)16 * ldy * 4 + (size_t)16 * ldl * 4 +
-         (size_t)((a.H1 / 16 + a.Gn - 1) / a.Gn) * (kc * 1024 + 64) + (size_t)((a.n_logits_pad / 16 + a.Gn - 1) / a.Gn) * ((a.H1 / 16) * 1024 + 64);
+         (size_t)((a.n_logits_pad / 16 + a.Gn - 1) / a.Gn) * ((a.H1 / 16) * 1024 + 64);
 }
 
 int launch_wavenet_pipe(const WnPipeArgs& a, hipStream_t stream) {

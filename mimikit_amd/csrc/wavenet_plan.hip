@@ -89,6 +89,7 @@ struct mmk_wavenet_plan {
   int pipe_nit = 0;
   unsigned long long *px_yl = nullptr, *px_hl = nullptr, *px_hown = nullptr, *px_yx = nullptr, *px_hx = nullptr, *px_skipfwd = nullptr;
   std::vector<PackedLinear> Ac;
+  std::vector<PackedLinear> Bh;       // pipelined mode: rows [res ; head fc0 . W_skip] of every layer (the head's first Linear folded in)
   WnChainIter* iter_tab = nullptr;
   float* compose_scratch = nullptr;   // (2C, C) product + 2C bias terms of one layer
 
@@ -122,10 +123,12 @@ struct mmk_wavenet_plan {
     cproj = C1 > 0 ? c.take<float>((int64_t)Bmax * kCondBlock * C1) : nullptr;
     condall = C1 > 0 ? c.take<float>((int64_t)Bmax * kCondBlock * L * 2 * C) : nullptr;
     if (C1 > 0) cond_all.carve(c, false);
+    if (pipe)
+      for (auto& pl : Bh) pl.carve(c, true);
     if (chain || pipe) {
       for (auto& pl : Ac) pl.carve(c, true);
       iter_tab = c.take<WnChainIter>(L + 1);
-      compose_scratch = c.take<float>((int64_t)2 * C * C + 2 * C);
+      compose_scratch = c.take<float>((int64_t)2 * C * C + 2 * C);     // (the pipelined mode's H1 x C products fit: H1 <= C there)
     }
     zero_pad = c.take<float>(64);
     pf_P = round_up(rf, 32);
@@ -170,24 +173,26 @@ struct mmk_wavenet_plan {
   }
 };
 
-// out[n][k] = sum_c W1[n][c] R[c][k] and out_bias[n] = sum_c W1[n][c] r[c], with W1[n][c] = wd[(n C + c) 2 + 1] the tap-1
-// slice of a k = 2 dilated convolution (2C rows) and R, r the residual 1x1 convolution of the layer below.  Accumulated
-// in fp64 and rounded once: the pre-multiplied matrix is as close to the exact product as fp32 allows.
-__global__ __launch_bounds__(256) void compose_tap1_res_kernel(const float* __restrict__ wd, const float* __restrict__ wr,
-                                                              const float* __restrict__ br, float* __restrict__ out,
-                                                              float* __restrict__ out_bias, int C) {
-  const int64_t total = (int64_t)2 * C * C;
-  for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total + 2 * C; idx += (int64_t)gridDim.x * blockDim.x) {
+// out[n][k] = sum_c A[n][c] R[c][k] and out_bias[n] = sum_c A[n][c] r[c] for n < N, with A addressed as a[n a_rs + c a_cs]
+// and R (C x C), r (C) a 1x1 convolution of the layer below.  Accumulated in fp64 and rounded once: the pre-multiplied
+// matrix is as close to the exact product as fp32 allows.  Used for
+//   * tap 1 of a k = 2 dilated convolution (2C rows, a = wd + 1, a_rs = 2C, a_cs = 2) times the residual convolution, and
+//   * the head's first Linear (H1 rows) times a layer's skip convolution (wavenet_pipe.hip).
+__global__ __launch_bounds__(256) void compose_kernel(const float* __restrict__ a, int64_t a_rs, int64_t a_cs, int N,
+                                                     const float* __restrict__ wr, const float* __restrict__ br,
+                                                     float* __restrict__ out, float* __restrict__ out_bias, int C) {
+  const int64_t total = (int64_t)N * C;
+  for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total + N; idx += (int64_t)gridDim.x * blockDim.x) {
     if (idx < total) {
       const int n = (int)(idx / C), k = (int)(idx % C);
       double acc = 0.0;
-      for (int c = 0; c < C; ++c) acc += (double)wd[((int64_t)n * C + c) * 2 + 1] * (double)wr[(int64_t)c * C + k];
+      for (int c = 0; c < C; ++c) acc += (double)a[n * a_rs + c * a_cs] * (double)wr[(int64_t)c * C + k];
       out[idx] = (float)acc;
     } else {
       const int n = (int)(idx - total);
       double acc = 0.0;
       if (br)
-        for (int c = 0; c < C; ++c) acc += (double)wd[((int64_t)n * C + c) * 2 + 1] * (double)br[c];
+        for (int c = 0; c < C; ++c) acc += (double)a[n * a_rs + c * a_cs] * (double)br[c];
       out_bias[n] = (float)acc;
     }
   }
@@ -363,11 +368,10 @@ static int derive(mmk_wavenet_plan* p) {
     const char* penv = getenv("MMK_WN_PIPE");
     const char* fenv = getenv("MMK_WN_PREFILL");
     const bool fits_l2 = (int64_t)p->L * 8 * p->C * p->C * 4 <= ((int64_t)3 << 20);
-    (void)fits_l2;
-    bool ok3 = (penv && penv[0] == '1') && !(fenv && fenv[0] == '0') && 8 * p->Gn <= 256 && p->Bmax <= 32;   // opt-in until it wins
+    bool ok3 = (penv ? penv[0] != '0' : !fits_l2) && !(fenv && fenv[0] == '0') && 8 * p->Gn <= 256 && p->Bmax <= 32;
     for (int l = 0; l + 1 < p->L; ++l) ok3 = ok3 && p->has_res[l];
     const int mg = (p->Bmax + 7) / 8, gc = (p->Bmax + mg - 1) / mg;
-    ok3 = ok3 && wn_pipe_supported(p->C, mg, gc, p->L);
+    ok3 = ok3 && wn_pipe_supported(p->C, mg, gc, p->L) && c.mlp_hidden <= p->C;   // (the skip-row owners take the H1 / 16 hidden-unit tiles)
     if (ok3) {
       WnPipeArgs probe = {};
       probe.C = p->C; probe.H1 = c.mlp_hidden; probe.n_logits_pad = p->n_logits_pad; probe.L = p->L; probe.Gn = p->Gn;
@@ -381,6 +385,8 @@ static int derive(mmk_wavenet_plan* p) {
       p->pipe_nit = wn_pipe_iters_per_stage(p->L);
       p->Ac.resize(p->L);
       for (auto& pl : p->Ac) pl.set_geometry(2 * p->C, {p->C, p->C, p->C});
+      p->Bh.resize(p->L);
+      for (int l = 0; l < p->L; ++l) p->Bh[l].set_geometry((p->has_res[l] ? p->C : 0) + c.mlp_hidden, {p->C});
       // rings: per stage workgroup, the stage's layers x slots x (all Gc Mg clips) x C
       const int64_t Bp = (int64_t)gc * mg;
       int64_t worst = 0;
@@ -581,13 +587,41 @@ extern "C" int mmk_wavenet_commit(mmk_wavenet_plan* p, void* workspace, size_t w
         if (wr) {
           float* prod = p->compose_scratch;
           float* pbias = prod + (int64_t)2 * C * C;
-          hipLaunchKernelGGL(compose_tap1_res_kernel, dim3(512), dim3(256), 0, st, wd, wr, br, prod, pbias, C);
+          hipLaunchKernelGGL(compose_kernel, dim3(512), dim3(256), 0, st, wd + 1, (int64_t)2 * C, (int64_t)2, 2 * C, wr, br, prod, pbias, C);
           MMK_HIP(hipGetLastError());
           MMK_TRY(pack_rect(A.Wp, A.k_chunks, 0, 2, C, A.seg_chunk0[2], C, prod, C, 1, st));
           MMK_TRY(pack_rect(A.Wp, A.k_chunks, 1, 2, C, A.seg_chunk0[2], C, prod + (int64_t)C * C, C, 1, st));
           MMK_TRY(pack_bias(A.bias, 0, 2, C, pbias, 1, st));
           MMK_TRY(pack_bias(A.bias, 1, 2, C, pbias + C, 1, st));
         }
+      }
+    }
+  }
+  // pipelined mode: [res ; fc0 . W_skip] per layer - the skip sums only ever feed the head's first Linear, so its product with
+  // every layer's skip convolution is taken once here and the layers accumulate the HIDDEN units' pre-activations directly
+  // (one exchange less per step, H1 instead of C rows to multiply and to hand from stage to stage)
+  if (p->pipe) {
+    const int H1 = c.mlp_hidden;
+    const float* f0 = b.need("output_modules.0.estimator.0.fc.0.weight", (int64_t)H1 * C);
+    for (int l = 0; l < L && f0; ++l) {
+      const std::string ly = "layers." + std::to_string(l) + ".";
+      PackedLinear& Bh = p->Bh[l];
+      const int n_res = p->has_res[l] ? C : 0;
+      if (p->has_res[l]) {
+        const float* wr = b.need(ly + "conv_res.weight", (int64_t)C * C);
+        const float* br = bias ? b.need(ly + "conv_res.bias", C) : nullptr;
+        if (wr) MMK_TRY(pack_rect(Bh.Wp, Bh.k_chunks, 0, 1, C, 0, C, wr, C, 1, st));
+        if (br) MMK_TRY(pack_bias(Bh.bias, 0, 1, C, br, 0, st));
+      }
+      const float* ws = b.need(ly + "conv_skip.weight", (int64_t)C * C);
+      const float* bs = bias ? b.need(ly + "conv_skip.bias", C) : nullptr;
+      if (ws) {
+        float* prod = p->compose_scratch;
+        float* pbias = prod + (int64_t)2 * C * C;
+        hipLaunchKernelGGL(compose_kernel, dim3(512), dim3(256), 0, st, f0, (int64_t)C, (int64_t)1, H1, ws, bs, prod, pbias, C);
+        MMK_HIP(hipGetLastError());
+        MMK_TRY(pack_rect(Bh.Wp, Bh.k_chunks, n_res, 1, H1, 0, C, prod, C, 1, st));
+        MMK_TRY(pack_bias(Bh.bias, n_res, 1, H1, pbias, 0, st));
       }
     }
   }
@@ -634,8 +668,9 @@ extern "C" int mmk_wavenet_commit(mmk_wavenet_plan* p, void* workspace, size_t w
         const int la = i < L ? i : 0;
         it[i].A_wp = p->Ac[la].Wp;
         it[i].A_bias = p->Ac[la].bias;
-        it[i].B_wp = i >= 1 ? p->Bm[i - 1].Wp : nullptr;
-        it[i].B_bias = i >= 1 ? p->Bm[i - 1].bias : nullptr;
+        const PackedLinear* Bsrc = i >= 1 ? (p->pipe ? &p->Bh[i - 1] : &p->Bm[i - 1]) : nullptr;
+        it[i].B_wp = Bsrc ? Bsrc->Wp : nullptr;
+        it[i].B_bias = Bsrc ? Bsrc->bias : nullptr;
         it[i].ring_offset = p->ring_offset[la];
         it[i].dil = p->dil[la];
         it[i].ring_mask = p->ring_mask[la];
@@ -820,6 +855,8 @@ static int run_persistent(mmk_wavenet_plan* p, const WnCall& call, int64_t tau0,
       k.gran_skip = p->gran_skip; k.gran_hid = p->gran_hid; k.gran_logit = p->gran_logit; k.gran_idx = p->gran_idx;
       k.h_rings = p->h_rings; k.err_flag = p->err_flag; k.xcd_count = p->xcd_count;
       k.stamps = (stamp_env && stamp_env[0] == '1') ? reinterpret_cast<unsigned long long*>(p->tau + 8) : nullptr;
+      k.stamp_stage = getenv("MMK_WN_STAMP_STAGE") ? atoi(getenv("MMK_WN_STAMP_STAGE")) : 1;
+      k.stamp_owner = getenv("MMK_WN_STAMP_OWNER") ? atoi(getenv("MMK_WN_STAMP_OWNER")) : 1;
       MMK_TRY(launch_wavenet_pipe(k, st));
       done += nb;
       continue;
@@ -1104,10 +1141,10 @@ extern "C" int mmk_wavenet_sync_status(mmk_wavenet_plan* p, mmk_stream_t stream)
       unsigned long long st[24];
       MMK_HIP(hipMemcpy(st, p->tau + 8, sizeof(st), hipMemcpyDeviceToHost));
       if (p->pipe) {
-        fprintf(stderr, "[mmk stamps] last pipelined launch, thread 0 of workgroup 1 of stage 1, totals in ms: visit start (own h + wait for the "
+        fprintf(stderr, "[mmk stamps] last pipelined launch, thread 0 of one workgroup (MMK_WN_STAMP_STAGE / _OWNER, default 1 / 1), totals in ms: visit start (own h + wait for the "
                         "group's inputs)=%.3f; operands + MFMA=%.3f; wait B1=%.3f; epilogues + publish=%.3f; small operands + ring store=%.3f; "
-                        "wait y/h=%.3f; whole launch=%.3f; shader clock=%.0f MHz\n",
-                st[7] * 1e-5, st[9] * 1e-5, st[0] * 1e-5, st[1] * 1e-5, st[2] * 1e-5, st[3] * 1e-5, st[15] * 1e-5,
+                        "wait y/h=%.3f; head=%.3f; whole launch=%.3f; shader clock=%.0f MHz\n",
+                st[7] * 1e-5, st[9] * 1e-5, st[0] * 1e-5, st[1] * 1e-5, st[2] * 1e-5, st[3] * 1e-5, st[6] * 1e-5, st[15] * 1e-5,
                 st[15] ? 100.0 * (double)st[14] / (double)st[15] : 0.0);
         return MMK_OK;
       }
