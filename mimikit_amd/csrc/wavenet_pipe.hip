@@ -303,8 +303,10 @@ __global__ __launch_bounds__(kPiThreads) void wavenet_pipe_kernel(const WnPipeAr
     // the hidden units: every layer's fc0 . W_skip product has been accumulated on the way (skipacc); + fc0's bias, Mish
     if (wave == 1 && e_m < mg && owns_hid)
       gran_store<true>(gran_hid + e_m * a.H1 + (j - KC) * 16 + e_n, he, mish_fast(skipacc + a.fc0_bias[(j - KC) * 16 + e_n]));
+    stamp(10);   // head: hidden units published
     if (j < t_fc2) {
       if (!sweep<NT>(gran_hid, mg * a.H1, he, nullptr, headbuf, a.H1, ldy, err, s_fail)) return false;
+      stamp(11);   // head: wait for the hidden units
       const int per = (kc_fc2 + nw - 1) / nw;
       const int k0 = min(wave * per, kc_fc2), k1 = min(k0 + per, kc_fc2);
       for (int t = j, ti = 0; t < t_fc2; t += a.Gn, ++ti) {
@@ -319,8 +321,10 @@ __global__ __launch_bounds__(kPiThreads) void wavenet_pipe_kernel(const WnPipeAr
         }
       }
     }
+    stamp(12);   // head: fc2 tile + publish
     if (j == 0) {
       if (!sweep<NT>(gran_logit, mg * a.n_logits_pad, he, nullptr, lbuf, a.n_logits_pad, ldl, err, s_fail)) return false;
+      stamp(13);   // head: wait for the logits
       const int nc = a.n_classes;
       const int per = (nc + 63) / 64;
       for (int m = wave; m < mg; m += nw) {
@@ -333,6 +337,17 @@ __global__ __launch_bounds__(kPiThreads) void wavenet_pipe_kernel(const WnPipeAr
         if (a.temperature == nullptr) {
           float best = -INFINITY;
           int bi = 0x7fffffff;
+          if (nc == 256) {   // four classes per lane in one 16-byte LDS read (this sits on every sample's chain)
+            const f32x4 v4 = *reinterpret_cast<const f32x4*>(lg + lane * 4);
+            const float inv_off = a.learn_temp ? denom : 1.f;
+            float vv[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) vv[q] = a.learn_temp ? v4[q] / inv_off : v4[q];
+            best = vv[0]; bi = lane * 4;
+#pragma unroll
+            for (int q = 1; q < 4; ++q)
+              if (vv[q] > best) { best = vv[q]; bi = lane * 4 + q; }
+          } else
           for (int q = 0; q < per; ++q) {
             const int c = lane * per + q;
             if (c < nc) {
@@ -406,6 +421,7 @@ __global__ __launch_bounds__(kPiThreads) void wavenet_pipe_kernel(const WnPipeAr
         if (keep_logits)
           for (int c = lane; c < nc + a.learn_temp; c += 64) a.logits_out[(int64_t)clip * a.logits_ld + c] = lg[c];
       }
+      stamp(8);    // head: sampler
     }
     __syncthreads();
     return true;
