@@ -336,12 +336,20 @@ __global__ __launch_bounds__(kBotThreads) void srnn_bottom_kernel(const SrnnBott
 // fp32 arithmetic in a different association (pinned by the same goldens / oracle tests).
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-template <int NF>   // NF = H / 16: f32x4 fragments of a thread's quarter of an fc0 row
+template <int NF>   // NF = H / 16
 __global__ __launch_bounds__(kBotThreads) void srnn_bottom1_kernel(const SrnnBottomArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   constexpr int H = NF * 16;
-  constexpr int kHmMax = 128;                 // hidden units of the MLP: four threads each
-  constexpr int kF2 = kHmMax / 8;             // f32x4 fragments of a thread's half of an fc2 row
+  constexpr int kHmMax = 128;
+  // Thread layout of both products: lane = 16 cgl + ks.  The 16 lanes of a DPP row split K in 16 slices (partial sums meet
+  // through row reductions), the 4 rows of a wave and the 8 waves give 32 column groups.  fc0: slice of H / 16 inputs, 4 hidden
+  // units per thread (Hm <= 128); fc2: slice of Hm / 16 hidden units, 8 output columns per thread (the first 256 outputs).
+  // Each thread reads only ITS slice of the input vector from LDS (the vector is read 32 times per step, not 512 times).
+  constexpr int KS0 = H / 16;                 // fc0 inputs per thread: H/16 (8, 16 or 32 floats)
+  constexpr int F0 = KS0 / 4;                 // ... as f32x4 fragments, per column
+  constexpr int kPad0 = KS0 + 4;              // LDS stride of a slice: 16 lanes x 16 bytes land in 16 different bank groups
+  constexpr int KS2 = kHmMax / 16;            // fc2 inputs per thread (8 floats)
+  constexpr int kPad2 = KS2 + 4;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int Hm = a.Hm;
@@ -360,61 +368,66 @@ __global__ __launch_bounds__(kBotThreads) void srnn_bottom1_kernel(const SrnnBot
   };
 
   char* sp = smem_raw;
-  float* xs = (float*)sp;   sp += H * 4;
-  float* hid = (float*)sp;  sp += kHmMax * 4;
+  float* xs = (float*)sp;   sp += 16 * kPad0 * 4;           // x, slice-padded: element k lives at (k / KS0) kPad0 + k % KS0
+  float* hid = (float*)sp;  sp += 16 * kPad2 * 4;           // hidden units, slice-padded likewise (KS2)
   float* lbuf = (float*)sp; sp += 1024 * 4;                 // logits (n_out <= 1024)
   int* s_win = (int*)sp;    sp += 16 * 4;
   float* wx = (float*)sp;                                   // fc2 rows past the first 256 outputs (the temperature column): (n_out - 256, Hm)
 
   // ---- once per launch: this thread's weights -> registers ------------------------------------------------------
-  // fc0: hidden unit u = tid / 4, quarter ks = tid % 4 of its row: k in [ks H/4, (ks+1) H/4)
-  const int u = tid >> 2, ks = tid & 3;
-  const bool has_u = u < Hm;
-  f32x4 w0[NF];
-  {
-    const int tile = (has_u ? u : 0) >> 4, n = (has_u ? u : 0) & 15;
-    gf32x4_ptr src = (gf32x4_ptr)(uintptr_t)a.fc0_wp + (int64_t)tile * (H / 16) * 64;
+  const int ks = lane & 15, cg = wave * 4 + (lane >> 4);    // K slice, column group (0 .. 31)
+  f32x4 w0[4][F0];                                          // hidden units cg * 4 + j, inputs ks * KS0 ..
+  // (from the row-major matrices: a thread's slice of a row is KS0 * 4 contiguous bytes - whole cache lines; the packed
+  //  MFMA order would scatter every 16 bytes of it over a different line)
 #pragma unroll
-    for (int f = 0; f < NF; ++f) {
-      const int k = ks * (H / 4) + 4 * f;
-      w0[f] = src[(k / 16) * 64 + ((k % 16) / 4) * 16 + n];
+  for (int j = 0; j < 4; ++j) {
+    const int u = cg * 4 + j;
+    const bool has = u < Hm;
+    gf32x4_ptr src = (gf32x4_ptr)(uintptr_t)(a.fc0_raw + (int64_t)(has ? u : 0) * H + ks * KS0);
+#pragma unroll
+    for (int f = 0; f < F0; ++f) {
+      const f32x4 v = src[f];
+      w0[j][f] = has ? v : f32x4{0.f, 0.f, 0.f, 0.f};
     }
   }
-  const float fc0_b = has_u ? a.fc0_bias[u] : 0.f;
-  // fc2: output column c = tid / 2 (< 256), half kh = tid % 2 of its row: k in [kh Hm/2, (kh+1) Hm/2)
-  const int c2 = tid >> 1, kh = tid & 1;
-  const bool has_c = c2 < n_out;
-  const int kc2 = Hm / 16;
-  f32x4 w2[kF2];
-  {
-    const int tile = (has_c ? c2 : 0) >> 4, n = (has_c ? c2 : 0) & 15;
-    gf32x4_ptr src = (gf32x4_ptr)(uintptr_t)a.fc2_wp + (int64_t)tile * kc2 * 64;
+  f32x4 w2[8][2];                                           // output columns cg * 8 + j (< 256), hidden units ks * 8 ..
 #pragma unroll
-    for (int f = 0; f < kF2; ++f) {
-      const int k = kh * (Hm / 2) + 4 * f;
-      const bool in = 4 * f < Hm / 2;
-      const int kk = in ? k : 0;
-      const f32x4 v = src[(kk / 16) * 64 + ((kk % 16) / 4) * 16 + n];
-      w2[f] = in ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int j = 0; j < 8; ++j) {
+    const int c = cg * 8 + j;
+    const bool has = c < n_out;
+#pragma unroll
+    for (int f = 0; f < 2; ++f) {
+      const int k = ks * KS2 + 4 * f;
+      const bool in = has && k < Hm;
+      const f32x4 v = *(gf32x4_ptr)(uintptr_t)(a.fc2_raw + (int64_t)(in ? c : 0) * Hm + (in ? k : 0));
+      w2[j][f] = in ? v : f32x4{0.f, 0.f, 0.f, 0.f};
     }
   }
-  const float fc2_b = has_c ? a.fc2_bias[c2] : 0.f;
-  // outputs 256 .. n_out-1 (with 256 classes: the temperature column): their rows unpacked into LDS, one wave per row
+  // the lane that ends up with a column's total after the row reduction keeps its bias: lane ks == j of the row for fc0
+  // (j < 4), ks == j for fc2 (j < 8)
+  const float fc0_b = (ks < 4 && cg * 4 + ks < Hm) ? a.fc0_bias[cg * 4 + ks] : 0.f;
+  const float fc2_b = (ks < 8 && cg * 8 + ks < n_out) ? a.fc2_bias[cg * 8 + ks] : 0.f;
   const int n_extra = n_out > 256 ? n_out - 256 : 0;
-  for (int i = tid; i < n_extra * Hm; i += kBotThreads) {
-    const int r = 256 + i / Hm, k = i % Hm;
-    const int tile = r >> 4, n = r & 15;
-    wx[i] = a.fc2_wp[(((int64_t)tile * kc2 + k / 16) * 64 + ((k % 16) / 4) * 16 + n) * 4 + (k & 3)];
-  }
+  for (int i = tid; i < n_extra * Hm; i += kBotThreads) wx[i] = a.fc2_raw[(int64_t)256 * Hm + i];
+  for (int i = tid; i < 16 * kPad2; i += kBotThreads) hid[i] = 0.f;
   if (tid < 16) s_win[tid] = tid < a.fs ? (int)a.idx[(int64_t)clip * a.idx_rs + t0 - a.fs + tid] : 0;
   // x phase: thread = column (H <= 512)
   const int xc = tid < H ? tid : 0;
+  const int xs_at = (xc / KS0) * kPad0 + xc % KS0;
   const float xb = a.bb[xc];
   const float* wb_col = a.wb + xc * a.fs;
   const float wb0 = wb_col[0];
   const int u0 = (int)(t0 % a.up_slots);                      // outputs[-1][:, (t % fs[-2]) - fs[-2]]   (:257)
   auto upper_at = [&](int step) -> float { return a.upper[((int64_t)clip * a.up_slots + (u0 + step) % a.up_slots) * H + xc]; };
   float up_next = upper_at(0);
+  // sum over the 16 lanes of a DPP row, every lane ends with the total (fixed order)
+  auto row_sum = [](float v) -> float {
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, false));    // quad_perm [1,0,3,2]
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xf, 0xf, false));    // quad_perm [2,3,0,1]
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xf, 0xf, false));   // row_half_mirror
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xf, 0xf, false));   // row_mirror
+    return v;
+  };
   __syncthreads();
   stamp(0);
 
@@ -428,43 +441,52 @@ __global__ __launch_bounds__(kBotThreads) void srnn_bottom1_kernel(const SrnnBot
       } else {
         for (int i = 0; i < a.fs; ++i) acc = fmaf((((float)s_win[i] / a.class_size) - .5f) * 2.f, wb_col[i], acc);
       }
-      xs[tid] = (acc + xb) + up_next;
+      xs[xs_at] = (acc + xb) + up_next;
     }
     if (s + 1 < a.n_steps) up_next = upper_at(s + 1);
     __syncthreads();
     stamp(1);
     // ---- fc0 + Mish ---------------------------------------------------------------------------------------------
     {
-      const f32x4* x4 = reinterpret_cast<const f32x4*>(xs + ks * (H / 4));
-      f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
+      const f32x4* x4 = reinterpret_cast<const f32x4*>(xs + ks * kPad0);
+      f32x4 acc[4];
+      {
+        const f32x4 xv = x4[0];
 #pragma unroll
-      for (int f = 0; f < NF; f += 2) {      // the 4 threads of a unit read 4 different quarters, the 16 units of a wave the same ones: broadcasts
-        const f32x4 xa = x4[f], xb4 = x4[f + 1];
-        acc += xa * w0[f];
-        acc1 += xb4 * w0[f + 1];
+        for (int j = 0; j < 4; ++j) acc[j] = xv * w0[j][0];
       }
-      acc += acc1;
-      float v = (acc[0] + acc[1]) + (acc[2] + acc[3]);
-      // the four quarters of a unit sit in four adjacent lanes: quad reductions through DPP
-      v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, false));   // quad_perm [1,0,3,2]
-      v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xf, 0xf, false));   // quad_perm [2,3,0,1]
-      if (ks == 0 && has_u) hid[u] = mish_fast(v + fc0_b);
+#pragma unroll
+      for (int f = 1; f < F0; ++f) {           // one input fragment at a time, four independent accumulation chains
+        const f32x4 xv = x4[f];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] += xv * w0[j][f];
+      }
+      float tot[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) tot[j] = row_sum((acc[j][0] + acc[j][1]) + (acc[j][2] + acc[j][3]));
+      const float mine = ks == 0 ? tot[0] : (ks == 1 ? tot[1] : (ks == 2 ? tot[2] : tot[3]));
+      const int u = cg * 4 + ks;
+      if (ks < 4 && u < Hm) hid[(u / KS2) * kPad2 + u % KS2] = mish_fast(mine + fc0_b);   // one Mish per lane, four lanes per row
     }
     __syncthreads();
     stamp(2);
     // ---- fc2 ---------------------------------------------------------------------------------------------------------
     {
-      const f32x4* h4 = reinterpret_cast<const f32x4*>(hid + kh * (Hm / 2));
-      f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+      const f32x4* h4 = reinterpret_cast<const f32x4*>(hid + ks * kPad2);
+      const f32x4 h0 = h4[0], h1 = h4[1];
+      float mine = 0.f;
 #pragma unroll
-      for (int f = 0; f < kF2; ++f)
-        if (4 * f < Hm / 2) acc += h4[f] * w2[f];
-      float v = (acc[0] + acc[1]) + (acc[2] + acc[3]);
-      v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, false));   // the row's other half
-      if (kh == 0 && has_c) lbuf[c2] = v + fc2_b;
+      for (int j = 0; j < 8; ++j) {
+        f32x4 acc = h0 * w2[j][0];
+        acc += h1 * w2[j][1];
+        const float tj = row_sum((acc[0] + acc[1]) + (acc[2] + acc[3]));
+        mine = ks == j ? tj : mine;
+      }
+      const int c = cg * 8 + ks;
+      if (ks < 8 && c < n_out) lbuf[c] = mine + fc2_b;
       for (int r = wave; r < n_extra; r += kBotThreads / 64) {      // rows past 256: one wave each, lanes over k
         float p = 0.f;
-        for (int k = lane; k < Hm; k += 64) p = fmaf(hid[k], wx[r * Hm + k], p);
+        for (int k = lane; k < Hm; k += 64) p = fmaf(hid[(k / KS2) * kPad2 + k % KS2], wx[r * Hm + k], p);
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) p += __shfl_xor(p, o);
         if (lane == 0) lbuf[256 + r] = p + a.fc2_bias[256 + r];
@@ -581,14 +603,14 @@ __global__ __launch_bounds__(kBotThreads) void srnn_bottom1_kernel(const SrnnBot
 
 static size_t srnn_bottom1_lds_bytes(const SrnnBottomArgs& a) {
   const int n_extra = a.n_out > 256 ? a.n_out - 256 : 0;
-  return (size_t)a.H * 4 + 128 * 4 + 1024 * 4 + 16 * 4 + (size_t)n_extra * a.Hm * 4 + 64;
+  return (size_t)16 * (a.H / 16 + 4) * 4 + (size_t)16 * 12 * 4 + 1024 * 4 + 16 * 4 + (size_t)n_extra * a.Hm * 4 + 64;
 }
 
 // one clip per workgroup pays while the clips fit the chip a few times over, and needs the first 256 outputs to cover the
 // classes (threads in pairs) and the whole MLP in a workgroup's registers
 static bool srnn_bottom1_applies(const SrnnBottomArgs& a) {
   static const bool off = [] { const char* e = getenv("MMK_SRNN_BOTTOM_MFMA"); return e && e[0] == '1'; }();
-  return !off && a.B <= 1024 && a.n_out <= 1024 && a.Q <= 256 && a.Hm % 8 == 0 && a.Hm <= 128 && srnn_bottom1_lds_bytes(a) <= 64 * 1024;
+  return !off && a.fc0_raw && a.fc2_raw && a.B <= 1024 && a.n_out <= 1024 && a.Q <= 256 && a.Hm % 16 == 0 && a.Hm <= 128 && srnn_bottom1_lds_bytes(a) <= 64 * 1024;
 }
 
 size_t srnn_bottom_lds_bytes(const SrnnBottomArgs& a) {

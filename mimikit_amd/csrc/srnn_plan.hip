@@ -56,6 +56,7 @@ struct mmk_srnn_plan {
   bool fused_bottom = false;
   bool fused_gru = false;                       // srnn_gru.hip: input linear + both gate products + cell in one launch
   float *wb_raw = nullptr, *bb_raw = nullptr;   // framed conv weight / bias in their state_dict layout
+  const float* mlp_raw[2] = {nullptr, nullptr}; // fc0 / fc2 weights as bound (row-major; the caller keeps them alive with the plan)
 
   void layout(Carver& c) {
     const bool bias = cfg.rnn_bias != 0;
@@ -305,6 +306,7 @@ extern "C" int mmk_srnn_commit(mmk_srnn_plan* p, void* workspace, size_t workspa
     const float* bb = b.need(kb + "bias", m.N);
     if (w) MMK_TRY(pack_rect(m.Wp, m.k_chunks, 0, 1, m.N, 0, m.segK[0], w, m.segK[0], 1, st));
     if (bb) MMK_TRY(pack_bias(m.bias, 0, 1, m.N, bb, 0, st));
+    if (p->mlp.size() == 2) p->mlp_raw[i] = w;
   }
   if (!b.missing().empty()) return fail(MMK_ERR_KEY, "srnn_commit: state_dict tensor %s", b.missing().c_str());
   if (!p->cap_stream) MMK_HIP(hipStreamCreateWithFlags(&p->cap_stream, hipStreamNonBlocking));
@@ -472,6 +474,7 @@ static int emit_step(mmk_srnn_plan* p, const SrnnCall& call, int64_t tau_off, in
     a.idx = const_cast<int64_t*>(call.idx); a.idx_rs = call.idx_rs;
     a.wb = p->wb_raw; a.bb = p->bb_raw; a.upper = up.out;
     a.fc0_wp = p->mlp[0].Wp; a.fc0_bias = p->mlp[0].bias; a.fc2_wp = p->mlp[1].Wp; a.fc2_bias = p->mlp[1].bias;
+    a.fc0_raw = p->mlp_raw[0]; a.fc2_raw = p->mlp_raw[1];
     a.temperature = call.temperature; a.uniforms = call.uniforms; a.uni_ld = call.uni_ld; a.uni_off = call.uni_off;
     a.logits_out = p->logits; a.logits_ld = p->logits_ld;
     {
