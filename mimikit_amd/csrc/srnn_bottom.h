@@ -18,9 +18,18 @@ struct SrnnBottomArgs {
   const float* temperature; const float* uniforms; int64_t uni_ld, uni_off;
   float* logits_out; int64_t logits_ld;     // logits of the launch's last step
   unsigned long long* stamps;               // diagnostic: phase totals (100 MHz ticks) + launch count, or nullptr
+  // Resident mode (srnn_plan.hip: run_resident): ONE launch for a whole generate block while the tier kernels of the block
+  // run on another stream.  The two sides meet through agent-scope words: a clip's workgroup waits for `ready` before the
+  // first step after every update of the tier above, and publishes how far its clip has been written in `progress`.
+  int32_t resident;
+  int64_t t_first;                          // first step (the device counter belongs to the tier stream in this mode)
+  const unsigned* ready; uint32_t ready_per_update;   // bumped once per workgroup of the tier above and update
+  unsigned* progress;                       // [B]: positions < progress[c] of clip c are written
+  int* err;                                 // sticky error word (a wait that timed out)
 };
 
 bool srnn_bottom_supported(int H, int Hm, int n_out, int fs);
+bool srnn_bottom_resident_supported(const SrnnBottomArgs& a);
 int launch_srnn_bottom(const SrnnBottomArgs& a, hipStream_t stream);
 
 }  // namespace mmk

@@ -355,7 +355,7 @@ __global__ __launch_bounds__(kBotThreads) void srnn_bottom1_kernel(const SrnnBot
   const int Hm = a.Hm;
   const int n_out = a.n_out;
   const int clip = blockIdx.x;
-  const int64_t t0 = *a.tau_ptr + a.tau_off;
+  const int64_t t0 = a.resident ? a.t_first : *a.tau_ptr + a.tau_off;
   const bool stamping = a.stamps != nullptr && blockIdx.x == 0 && tid == 0;
   unsigned long long st_prev = stamping ? wall_clock64() : 0, st_acc[5] = {0, 0, 0, 0, 0};
   const unsigned long long clk0 = stamping ? clock64() : 0, wall0 = st_prev;
@@ -372,6 +372,7 @@ __global__ __launch_bounds__(kBotThreads) void srnn_bottom1_kernel(const SrnnBot
   float* hid = (float*)sp;  sp += 16 * kPad2 * 4;           // hidden units, slice-padded likewise (KS2)
   float* lbuf = (float*)sp; sp += 1024 * 4;                 // logits (n_out <= 1024)
   int* s_win = (int*)sp;    sp += 16 * 4;
+  int* s_flag = (int*)sp;   sp += 16;
   float* wx = (float*)sp;                                   // fc2 rows past the first 256 outputs (the temperature column): (n_out - 256, Hm)
 
   // ---- once per launch: this thread's weights -> registers ------------------------------------------------------
@@ -418,8 +419,14 @@ __global__ __launch_bounds__(kBotThreads) void srnn_bottom1_kernel(const SrnnBot
   const float* wb_col = a.wb + xc * a.fs;
   const float wb0 = wb_col[0];
   const int u0 = (int)(t0 % a.up_slots);                      // outputs[-1][:, (t % fs[-2]) - fs[-2]]   (:257)
-  auto upper_at = [&](int step) -> float { return a.upper[((int64_t)clip * a.up_slots + (u0 + step) % a.up_slots) * H + xc]; };
-  float up_next = upper_at(0);
+  // resident mode: the rows come from a kernel that is still running (on other XCDs): agent-scope loads, and never before
+  // the update that writes them has been counted in
+  auto upper_at = [&](int step) -> float {
+    const float* src = a.upper + ((int64_t)clip * a.up_slots + (u0 + step) % a.up_slots) * H + xc;
+    return a.resident ? __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *src;
+  };
+  const int64_t upd0 = (t0 - 1) / a.up_slots;                // updates of the tier above before this launch (t0 >= 1)
+  float up_next = (a.resident && t0 % a.up_slots == 0) ? 0.f : upper_at(0);
   // sum over the 16 lanes of a DPP row, every lane ends with the total (fixed order)
   auto row_sum = [](float v) -> float {
     v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, false));    // quad_perm [1,0,3,2]
@@ -433,6 +440,23 @@ __global__ __launch_bounds__(kBotThreads) void srnn_bottom1_kernel(const SrnnBot
 
   for (int s = 0; s < a.n_steps; ++s) {
     const int64_t t = t0 + s;
+    if (a.resident && t % a.up_slots == 0) {
+      // the tier above updates at this step: wait until every workgroup of its launch has written its columns
+      if (tid == 0) {
+        const unsigned need = (unsigned)(t / a.up_slots - upd0) * a.ready_per_update;
+        unsigned spins = 0;
+        int ok = 1;
+        while (__hip_atomic_load(a.ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
+          // ~1 s: the tier stream is not running beside this kernel (or another wait has already failed: do not pile up)
+          if (++spins > (1u << 20) || ((spins & 255u) == 0 && a.err && __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) { ok = 0; break; }
+          __builtin_amdgcn_s_sleep(1);
+        }
+        *s_flag = ok;
+        if (!ok && a.err) atomicExch(a.err, 4);
+      }
+      __syncthreads();
+      up_next = upper_at(s);
+    }
     // ---- x = conv(linearize(window)) + bias + upper tier output -----------------------------------------
     if (tid < H) {
       float acc = 0.f;
@@ -443,7 +467,7 @@ __global__ __launch_bounds__(kBotThreads) void srnn_bottom1_kernel(const SrnnBot
       }
       xs[xs_at] = (acc + xb) + up_next;
     }
-    if (s + 1 < a.n_steps) up_next = upper_at(s + 1);
+    if (s + 1 < a.n_steps && !(a.resident && (t + 1) % a.up_slots == 0)) up_next = upper_at(s + 1);
     __syncthreads();
     stamp(1);
     // ---- fc0 + Mish ---------------------------------------------------------------------------------------------
@@ -588,7 +612,20 @@ __global__ __launch_bounds__(kBotThreads) void srnn_bottom1_kernel(const SrnnBot
         const int keep = lane + 1 < a.fs ? s_win[lane + 1] : result;
         s_win[lane] = keep;     // wave-synchronous shift: every lane read before any lane writes
       }
-      if (lane == 0) a.idx[(int64_t)clip * a.idx_rs + t] = result;
+      if (lane == 0) {
+        int64_t* dst = a.idx + (int64_t)clip * a.idx_rs + t;
+        if (!a.resident) {
+          *dst = result;
+        } else {
+          // written through (the tier kernels read it from other XCDs); before a tier update - and at the end - the clip's
+          // progress word follows once the stores have been acknowledged
+          __hip_atomic_store(dst, (int64_t)result, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if ((t + 1) % a.up_slots == 0 || s + 1 == a.n_steps) {
+            __builtin_amdgcn_s_waitcnt(0x0F70);
+            __hip_atomic_store(a.progress + clip, (unsigned)(t + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+        }
+      }
     }
     __syncthreads();
     stamp(4);
@@ -603,7 +640,7 @@ __global__ __launch_bounds__(kBotThreads) void srnn_bottom1_kernel(const SrnnBot
 
 static size_t srnn_bottom1_lds_bytes(const SrnnBottomArgs& a) {
   const int n_extra = a.n_out > 256 ? a.n_out - 256 : 0;
-  return (size_t)16 * (a.H / 16 + 4) * 4 + (size_t)16 * 12 * 4 + 1024 * 4 + 16 * 4 + (size_t)n_extra * a.Hm * 4 + 64;
+  return (size_t)16 * (a.H / 16 + 4) * 4 + (size_t)16 * 12 * 4 + 1024 * 4 + 16 * 4 + 16 + (size_t)n_extra * a.Hm * 4 + 64;
 }
 
 // one clip per workgroup pays while the clips fit the chip a few times over, and needs the first 256 outputs to cover the
@@ -628,8 +665,13 @@ bool srnn_bottom_supported(int H, int Hm, int n_out, int fs) {
   return srnn_bottom_lds_bytes(a) <= 160 * 1024;
 }
 
+bool srnn_bottom_resident_supported(const SrnnBottomArgs& a) {
+  return srnn_bottom_supported(a.H, a.Hm, a.n_out, a.fs) && srnn_bottom1_applies(a);
+}
+
 int launch_srnn_bottom(const SrnnBottomArgs& a, hipStream_t stream) {
   if (!srnn_bottom_supported(a.H, a.Hm, a.n_out, a.fs)) return fail(MMK_ERR_UNSUPPORTED, "srnn bottom kernel: geometry H=%d Hm=%d", a.H, a.Hm);
+  if (a.resident && !srnn_bottom1_applies(a)) return fail(MMK_ERR_UNSUPPORTED, "srnn bottom kernel: resident mode needs the one-clip-per-workgroup kernel");
   if (srnn_bottom1_applies(a)) {
     const size_t lds1 = srnn_bottom1_lds_bytes(a);
     dim3 grid1(a.B), block1(kBotThreads);

@@ -43,7 +43,7 @@ __global__ __launch_bounds__(kGruThreads) void srnn_gru_kernel(const SrnnGruArgs
 
   // diagnostic (MMK_SRNN_STAMPS=1): 100 MHz wall-clock totals per phase of thread 0 of workgroup 0
   const bool stamping = a.stamps != nullptr && blockIdx.x == 0 && tid == 0;
-  unsigned long long st_prev = stamping ? wall_clock64() : 0, st_acc[6] = {0, 0, 0, 0, 0, 0};
+  unsigned long long st_prev = stamping ? wall_clock64() : 0, st_acc[7] = {0, 0, 0, 0, 0, 0, 0};
   auto stamp = [&](int slot) {
     if (stamping) {
       const unsigned long long now = wall_clock64();
@@ -73,6 +73,20 @@ __global__ __launch_bounds__(kGruThreads) void srnn_gru_kernel(const SrnnGruArgs
       }
     }
   }
+  // ... and the first up-sampler tiles of this workgroup (second phase): nothing of them depends on this update.  The workgroup
+  // up-samples ITS OWN clips: columns [ub 16 up, (ub + 1) 16 up) of the tier's (up H) outputs, `up` tiles of 16
+  constexpr int UB = (LSTM && KC == 32) ? 2 : 4;   // tiles per batch (registers, partial-sum buffer)
+  const int up_tiles = a.ups_wp != nullptr ? a.ups_n_tiles / KC : 0;
+  f32x4 wu0[UB][CPW];
+  if (a.ups_wp != nullptr) {
+#pragma unroll
+    for (int j = 0; j < UB; ++j) {
+      const int tile = ub * up_tiles + min(j, up_tiles - 1);
+      gf32x4_ptr wsrc = (gf32x4_ptr)(uintptr_t)a.ups_wp + ((int64_t)tile * KC + wave * CPW) * 64 + lane;
+#pragma unroll
+      for (int u = 0; u < CPW; ++u) wu0[j][u] = wsrc[u * 64];
+    }
+  }
   const int kci = (a.fs + 15) / 16, ldl = kci * 16 + 4;
   // ---- the input projection's operands of this wave's column tiles (frame sizes <= 16: one K-chunk): requested now,
   //      with the gate weights, instead of one round trip per tile inside the x phase ------------------------------------
@@ -96,22 +110,63 @@ __global__ __launch_bounds__(kGruThreads) void srnn_gru_kernel(const SrnnGruArgs
       x_w[j] = ((gf32x4_ptr)(uintptr_t)a.win_wp)[(int64_t)tile * 64 + lane];
     }
   }
-  // ---- the window, linearized (modules/io.py:106-112), zero padded to whole K-chunks ----------------------------
-  for (int e = tid; e < 16 * kci * 16; e += kGruThreads) {
-    const int m = e / (kci * 16), i = e - m * (kci * 16);
-    float v = 0.f;
-    if (m < mg && i < a.fs) {
-      const int64_t cls = a.idx[(int64_t)(m_first + m) * a.idx_rs + t + a.shift - a.fs + i];
-      v = (((float)cls / a.class_size) - .5f) * 2.f;
-    }
-    s_lin[m * ldl + i] = v;
-  }
   // ---- old state rows -> LDS --------------------------------------------------------------------------------
   for (int q = tid; q < 16 * (H / 4); q += kGruThreads) {
     const int m = q / (H / 4), c = (q - m * (H / 4)) * 4;
     f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
     if (m < mg) v = *reinterpret_cast<const f32x4*>(h_old + (int64_t)(m_first + m) * H + c);
     *reinterpret_cast<f32x4*>(hs + m * ldx + c) = v;
+  }
+  __syncthreads();
+  // ---- the recurrent half of the products, W_hh h: it does not depend on the newest classes either ------------------
+  f32x4 acc[2 * NG];
+#pragma unroll
+  for (int g = 0; g < 2 * NG; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+  {
+    const float* hr = hs + (lane & 15) * ldx + wave * CPW * 16 + 4 * (lane >> 4);
+    f32x4 hv[CPW];
+#pragma unroll
+    for (int u = 0; u < CPW; ++u) hv[u] = *reinterpret_cast<const f32x4*>(hr + u * 16);
+#pragma unroll
+    for (int u = 0; u < CPW; ++u) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int g = 0; g < NG; ++g) acc[NG + g] = __builtin_amdgcn_mfma_f32_16x16x4f32(hv[u][i], w[NG + g][u][i], acc[NG + g], 0, 0, 0);
+      }
+    }
+  }
+  // ---- resident mode: the newest classes come from the bottom kernel running beside this launch ------------------
+  const bool gated = a.gate_progress != nullptr;
+  if (gated) {
+    stamp(0);
+    int* s_gate = reinterpret_cast<int*>(red);
+    if (tid == 0) *s_gate = 1;
+    __syncthreads();
+    if (tid < mg) {
+      const unsigned need = (unsigned)(t + a.shift);
+      unsigned spins = 0;
+      while (__hip_atomic_load(a.gate_progress + m_first + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
+        // ~1 s: the bottom kernel is not running beside this launch (or another wait has already failed)
+        if (++spins > (1u << 20) || ((spins & 255u) == 0 && a.err && __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) { *s_gate = 0; break; }
+        __builtin_amdgcn_s_sleep(1);
+      }
+    }
+    __syncthreads();
+    if (!*s_gate && tid == 0 && a.err) atomicExch(a.err, 5);
+    __syncthreads();
+    stamp(4);   // waiting for the bottom kernel
+  }
+  // ---- the window, linearized (modules/io.py:106-112), zero padded to whole K-chunks ----------------------------
+  for (int e = tid; e < 16 * kci * 16; e += kGruThreads) {
+    const int m = e / (kci * 16), i = e - m * (kci * 16);
+    float v = 0.f;
+    if (m < mg && i < a.fs) {
+      const int64_t* src = a.idx + (int64_t)(m_first + m) * a.idx_rs + t + a.shift - a.fs + i;
+      const int64_t cls = gated ? __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *src;
+      v = (((float)cls / a.class_size) - .5f) * 2.f;
+    }
+    s_lin[m * ldl + i] = v;
   }
   __syncthreads();
   stamp(0);   // weights requested, window + old state in LDS
@@ -164,29 +219,19 @@ __global__ __launch_bounds__(kGruThreads) void srnn_gru_kernel(const SrnnGruArgs
   }
   __syncthreads();
   stamp(1);   // x
-  // ---- six 16 x 16 tiles, this wave's K range ----------------------------------------------------------------
+  // ---- the input half, W_ih x: NG 16 x 16 tiles, this wave's K range ----------------------------------------------
   {
     const int c0 = wave * CPW;
     const float* xr = xs + (lane & 15) * ldx + c0 * 16 + 4 * (lane >> 4);
-    const float* hr = hs + (lane & 15) * ldx + c0 * 16 + 4 * (lane >> 4);
-    f32x4 xv[CPW], hv[CPW];
+    f32x4 xv[CPW];
 #pragma unroll
-    for (int u = 0; u < CPW; ++u) {
-      xv[u] = *reinterpret_cast<const f32x4*>(xr + u * 16);
-      hv[u] = *reinterpret_cast<const f32x4*>(hr + u * 16);
-    }
-    f32x4 acc[2 * NG];
-#pragma unroll
-    for (int g = 0; g < 2 * NG; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int u = 0; u < CPW; ++u) xv[u] = *reinterpret_cast<const f32x4*>(xr + u * 16);
 #pragma unroll
     for (int u = 0; u < CPW; ++u) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
 #pragma unroll
-        for (int g = 0; g < NG; ++g) {     // 2 NG independent accumulator chains
-          acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[u][i], w[g][u][i], acc[g], 0, 0, 0);
-          acc[NG + g] = __builtin_amdgcn_mfma_f32_16x16x4f32(hv[u][i], w[NG + g][u][i], acc[NG + g], 0, 0, 0);
-        }
+        for (int g = 0; g < NG; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[u][i], w[g][u][i], acc[g], 0, 0, 0);
       }
     }
 #pragma unroll
@@ -244,8 +289,8 @@ __global__ __launch_bounds__(kGruThreads) void srnn_gru_kernel(const SrnnGruArgs
   // ---- the last workgroup to finish publishes the new slot -----------------------------------------------------
   __syncthreads();
   stamp(3);   // cell
-  if (stamping) {
-    for (int i = 0; i < 4; ++i) a.stamps[i] += st_acc[i];
+  if (stamping && !fused_up) {
+    for (int i = 0; i < 5; ++i) a.stamps[i] += st_acc[i];
     a.stamps[7] += 1;
   }
   if (fused_up) {
@@ -278,82 +323,81 @@ __global__ __launch_bounds__(kGruThreads) void srnn_gru_kernel(const SrnnGruArgs
     if (tid == 0 && a.err) atomicExch(a.err, 3);
     return;
   }
-  // ---- up-sampler: 16-column tiles of W_up over the workgroups, all clips, K split over the waves ----------------------
+  stamp(5);   // grid-wide barrier
+  // ---- up-sampler: this workgroup's clips x its `up` column tiles, K split over the waves -------------------------------
+  // (the rows of the own row tile come from the H / 16 workgroups of the tile - 32 KB at H = 512; every workgroup reading
+  //  every clip's row for 16 columns was 4 x that and 6.4 us, measured)
   {
     const int c0 = wave * CPW;
-    f32x4* red4 = red;                                            // [row block][wave][lane], 4 row blocks at a time
-    for (int tile = blockIdx.x; tile < a.ups_n_tiles; tile += gridDim.x) {
-      f32x4 wu[CPW];
-      gf32x4_ptr wsrc = (gf32x4_ptr)(uintptr_t)a.ups_wp + ((int64_t)tile * KC + c0) * 64 + lane;
-#pragma unroll
-      for (int u = 0; u < CPW; ++u) wu[u] = wsrc[u * 64];
-      for (int r0 = 0; r0 < a.B; r0 += 64) {
-        // agent-scope loads (sc1): the rows come from the other XCDs' workgroups.  Loads AND the wait sit in one asm
-        // statement: the compiler does not know these are loads and would otherwise be free to copy the destination
-        // registers before the data has arrived.
-        f32x4 hv[4][CPW];
-        const float* hr[4];
-#pragma unroll
-        for (int rb = 0; rb < 4; ++rb) {
-          const int m = r0 + rb * 16 + (lane & 15);
-          hr[rb] = h_new + (int64_t)(m < a.B ? m : a.B - 1) * H + c0 * 16 + 4 * (lane >> 4);   // clamped, unconditional
-        }
-#define MMK_LD(rb_, u_, d_, p_) "global_load_dwordx4 %" #d_ ", %" #p_ ", off offset:" #u_ " sc1\n\t"
-        if constexpr (CPW == 1) {
-          asm volatile(MMK_LD(0, 0, 0, 4) MMK_LD(1, 0, 1, 5) MMK_LD(2, 0, 2, 6) MMK_LD(3, 0, 3, 7) "s_waitcnt vmcnt(0)"
-                       : "=&v"(hv[0][0]), "=&v"(hv[1][0]), "=&v"(hv[2][0]), "=&v"(hv[3][0])
-                       : "v"(hr[0]), "v"(hr[1]), "v"(hr[2]), "v"(hr[3])
-                       : "memory");
-        } else if constexpr (CPW == 2) {
-          asm volatile(MMK_LD(0, 0, 0, 8) MMK_LD(0, 64, 1, 8) MMK_LD(1, 0, 2, 9) MMK_LD(1, 64, 3, 9)
-                       MMK_LD(2, 0, 4, 10) MMK_LD(2, 64, 5, 10) MMK_LD(3, 0, 6, 11) MMK_LD(3, 64, 7, 11) "s_waitcnt vmcnt(0)"
-                       : "=&v"(hv[0][0]), "=&v"(hv[0][1]), "=&v"(hv[1][0]), "=&v"(hv[1][1]), "=&v"(hv[2][0]), "=&v"(hv[2][1]),
-                         "=&v"(hv[3][0]), "=&v"(hv[3][1])
-                       : "v"(hr[0]), "v"(hr[1]), "v"(hr[2]), "v"(hr[3])
-                       : "memory");
-        } else {
-          static_assert(CPW == 4, "H in {128, 256, 512}");
-          asm volatile(MMK_LD(0, 0, 0, 16) MMK_LD(0, 64, 1, 16) MMK_LD(0, 128, 2, 16) MMK_LD(0, 192, 3, 16)
-                       MMK_LD(1, 0, 4, 17) MMK_LD(1, 64, 5, 17) MMK_LD(1, 128, 6, 17) MMK_LD(1, 192, 7, 17)
-                       MMK_LD(2, 0, 8, 18) MMK_LD(2, 64, 9, 18) MMK_LD(2, 128, 10, 18) MMK_LD(2, 192, 11, 18)
-                       MMK_LD(3, 0, 12, 19) MMK_LD(3, 64, 13, 19) MMK_LD(3, 128, 14, 19) MMK_LD(3, 192, 15, 19) "s_waitcnt vmcnt(0)"
-                       : "=&v"(hv[0][0]), "=&v"(hv[0][1]), "=&v"(hv[0][2]), "=&v"(hv[0][3]), "=&v"(hv[1][0]), "=&v"(hv[1][1]),
-                         "=&v"(hv[1][2]), "=&v"(hv[1][3]), "=&v"(hv[2][0]), "=&v"(hv[2][1]), "=&v"(hv[2][2]), "=&v"(hv[2][3]),
-                         "=&v"(hv[3][0]), "=&v"(hv[3][1]), "=&v"(hv[3][2]), "=&v"(hv[3][3])
-                       : "v"(hr[0]), "v"(hr[1]), "v"(hr[2]), "v"(hr[3])
-                       : "memory");
-        }
-#undef MMK_LD
-        f32x4 acc[4];
-#pragma unroll
-        for (int rb = 0; rb < 4; ++rb) acc[rb] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int u = 0; u < CPW; ++u) {
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-#pragma unroll
-            for (int rb = 0; rb < 4; ++rb) acc[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(hv[rb][u][i], wu[u][i], acc[rb], 0, 0, 0);
-          }
-        }
-#pragma unroll
-        for (int rb = 0; rb < 4; ++rb) red4[(rb * kGruWaves + wave) * 64 + lane] = acc[rb];
-        __syncthreads();
-#pragma unroll
-        for (int half = 0; half < 2; ++half) {                    // 64 rows x 16 columns: two outputs per thread
-          const int m = (tid >> 4) + 32 * half, n = tid & 15;
-          const int rb = m >> 4, r = m & 15;
-          const int frag = ((r >> 2) * 16 + n) * 4 + (r & 3);     // (row r, col n) of a 16x16 accumulator image
-          const float* f = reinterpret_cast<const float*>(red4 + rb * kGruWaves * 64) + frag;
-          float v = 0.f;
-#pragma unroll
-          for (int wv = 0; wv < kGruWaves; ++wv) v += f[wv * 256];
-          const int col = tile * 16 + n;
-          if (r0 + m < a.B && col < a.ups_n)
-            a.ups_out[(int64_t)(r0 + m) * a.ups_out_ld + col] = v + (a.ups_bias ? a.ups_bias[col] : 0.f);
-        }
-        __syncthreads();
+    // agent-scope loads (sc1): the rows come from other XCDs' workgroups.  Loads AND the wait sit in one asm statement: the
+    // compiler does not know these are loads and would otherwise be free to copy the destination registers too early.
+    f32x4 hv[CPW];
+    {
+      const int m = lane & 15;
+      const float* hr = h_new + (int64_t)(m_first + (m < mg ? m : mg - 1)) * H + c0 * 16 + 4 * (lane >> 4);   // clamped, unconditional
+      if constexpr (CPW == 1) {
+        asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(hv[0]) : "v"(hr) : "memory");
+      } else if constexpr (CPW == 2) {
+        asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dwordx4 %1, %2, off offset:64 sc1\n\ts_waitcnt vmcnt(0)"
+                     : "=&v"(hv[0]), "=&v"(hv[1]) : "v"(hr) : "memory");
+      } else {
+        static_assert(CPW == 4, "H in {128, 256, 512}");
+        asm volatile("global_load_dwordx4 %0, %4, off sc1\n\tglobal_load_dwordx4 %1, %4, off offset:64 sc1\n\t"
+                     "global_load_dwordx4 %2, %4, off offset:128 sc1\n\tglobal_load_dwordx4 %3, %4, off offset:192 sc1\n\ts_waitcnt vmcnt(0)"
+                     : "=&v"(hv[0]), "=&v"(hv[1]), "=&v"(hv[2]), "=&v"(hv[3]) : "v"(hr) : "memory");
       }
     }
+    for (int j0 = 0; j0 < up_tiles; j0 += UB) {
+      const int nb = min(UB, up_tiles - j0);
+#pragma unroll
+      for (int j = 0; j < UB; ++j) {
+        if (j < nb) {
+          f32x4 wu[CPW];
+          if (j0 == 0) {
+#pragma unroll
+            for (int u = 0; u < CPW; ++u) wu[u] = wu0[j][u];
+          } else {
+            gf32x4_ptr wsrc = (gf32x4_ptr)(uintptr_t)a.ups_wp + ((int64_t)(ub * up_tiles + j0 + j) * KC + c0) * 64 + lane;
+#pragma unroll
+            for (int u = 0; u < CPW; ++u) wu[u] = wsrc[u * 64];
+          }
+          f32x4 ua = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int u = 0; u < CPW; ++u) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) ua = __builtin_amdgcn_mfma_f32_16x16x4f32(hv[u][i], wu[u][i], ua, 0, 0, 0);
+          }
+          red[(j * kGruWaves + wave) * 64 + lane] = ua;
+        }
+      }
+      __syncthreads();
+      for (int e = tid; e < nb * 256; e += kGruThreads) {       // 16 clips x 16 nb columns
+        const int j = e >> 8, r = (e >> 4) & 15, n = e & 15;
+        const int frag = ((r >> 2) * 16 + n) * 4 + (r & 3);     // (row r, col n) of a 16x16 accumulator image
+        const float* f = reinterpret_cast<const float*>(red + j * kGruWaves * 64) + frag;
+        float v = 0.f;
+#pragma unroll
+        for (int wv = 0; wv < kGruWaves; ++wv) v += f[wv * 256];
+        const int col = (ub * up_tiles + j0 + j) * 16 + n;
+        if (r < mg && col < a.ups_n) {
+          float* dst = a.ups_out + (int64_t)(m_first + r) * a.ups_out_ld + col;
+          const float o = v + (a.ups_bias ? a.ups_bias[col] : 0.f);
+          if (a.ready) __hip_atomic_store(dst, o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // read by the resident bottom kernel
+          else *dst = o;
+        }
+      }
+      __syncthreads();
+    }
+  }
+  if (a.ready) {
+    __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0): this wave's columns have been written through
+    __syncthreads();
+    if (tid == 0) __hip_atomic_fetch_add(a.ready, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  stamp(6);   // up-sampler
+  if (stamping) {
+    for (int i = 0; i < 7; ++i) a.stamps[i] += st_acc[i];
+    a.stamps[7] += 1;
   }
 }
 

@@ -21,6 +21,7 @@ struct SrnnCall {
   const float* uniforms = nullptr;
   int64_t uni_ld = 0;
   int64_t uni_off = 0;
+  bool gate = false;     // resident mode: the tier kernels wait for the bottom kernel's progress words (run_resident)
 };
 
 // a stacked recurrent layer above the first one of a tier (n_rnn > 1): its input is the layer below's new state
@@ -52,6 +53,12 @@ struct mmk_srnn_plan {
   int64_t* tau = nullptr;
   hipStream_t cap_stream = nullptr;
   GraphCache gc;
+  // resident mode: the bottom tier as ONE launch per generate block on the caller's stream, the tier kernels of the block on
+  // side_stream; both sides meet through `progress` / `ready` (srnn_bottom.h)
+  hipStream_t side_stream = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  bool streams_overlap = false;                 // probed at commit: kernels of the two streams do run side by side
+  unsigned *progress = nullptr, *ready = nullptr;
   // fused bottom tier (srnn_bottom.hip): chosen at create time when the geometry allows it
   bool fused_bottom = false;
   bool fused_gru = false;                       // srnn_gru.hip: input linear + both gate products + cell in one launch
@@ -90,6 +97,8 @@ struct mmk_srnn_plan {
     logits_ld = (int)round_up(cfg.q_levels + (cfg.learn_temp ? 1 : 0), 4);
     logits = c.take<float>((int64_t)Bmax * logits_ld);
     tau = c.take<int64_t>(32);
+    progress = c.take<unsigned>(round_up(Bmax, 4));
+    ready = reinterpret_cast<unsigned*>(tau + 24);   // [0]: update counter of the tier above the bottom; [2], [3]: stream probe
     wb_raw = c.take<float>((int64_t)H * cfg.frame_size[cfg.n_tiers - 1]);
     bb_raw = c.take<float>(H);
   }
@@ -175,6 +184,9 @@ extern "C" void mmk_srnn_plan_destroy(mmk_srnn_plan* p) {
   if (!p) return;
   p->gc.reset();
   if (p->cap_stream) (void)hipStreamDestroy(p->cap_stream);
+  if (p->side_stream) (void)hipStreamDestroy(p->side_stream);
+  if (p->ev_fork) (void)hipEventDestroy(p->ev_fork);
+  if (p->ev_join) (void)hipEventDestroy(p->ev_join);
   delete p;
 }
 
@@ -190,9 +202,47 @@ extern "C" size_t mmk_srnn_workspace_bytes(const mmk_srnn_plan* p) {
   mmk_srnn_plan tmp = *p;
   tmp.gc = GraphCache();
   tmp.cap_stream = nullptr;
+  tmp.side_stream = nullptr;
+  tmp.ev_fork = tmp.ev_join = nullptr;
   Carver c(nullptr);
   tmp.layout(c);
   return c.used();
+}
+
+// ---- resident mode helpers ---------------------------------------------------------------------------------------------
+__global__ void srnn_resident_init_kernel(unsigned* progress, int B, unsigned t_begin, unsigned* ready) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < B) progress[i] = t_begin;
+  if (i == 0) *ready = 0;
+}
+
+// Do kernels of two streams run side by side here?  A waits (bounded) for a word that only B writes; launched A first.
+__global__ void srnn_probe_wait_kernel(unsigned* flags) {
+  unsigned spins = 0;
+  while (__hip_atomic_load(flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+    if (++spins > (1u << 17)) {
+      __hip_atomic_store(flags + 1, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      return;
+    }
+    __builtin_amdgcn_s_sleep(8);
+  }
+  __hip_atomic_store(flags + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__global__ void srnn_probe_post_kernel(unsigned* flags) { __hip_atomic_store(flags, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+static int probe_stream_overlap(mmk_srnn_plan* p, hipStream_t st) {
+  unsigned* flags = p->ready + 2;
+  MMK_HIP(hipMemsetAsync(flags, 0, 2 * sizeof(unsigned), st));
+  MMK_HIP(hipStreamSynchronize(st));
+  hipLaunchKernelGGL(srnn_probe_wait_kernel, dim3(1), dim3(1), 0, st, flags);
+  hipLaunchKernelGGL(srnn_probe_post_kernel, dim3(1), dim3(1), 0, p->side_stream, flags);
+  MMK_HIP(hipGetLastError());
+  MMK_HIP(hipStreamSynchronize(p->side_stream));
+  MMK_HIP(hipStreamSynchronize(st));
+  unsigned out[2] = {0, 0};
+  MMK_HIP(hipMemcpy(out, flags, sizeof(out), hipMemcpyDeviceToHost));
+  p->streams_overlap = out[1] == 1u;
+  return MMK_OK;
 }
 
 extern "C" int mmk_srnn_reset(mmk_srnn_plan* p, mmk_stream_t stream) {
@@ -205,7 +255,8 @@ extern "C" int mmk_srnn_reset(mmk_srnn_plan* p, mmk_stream_t stream) {
     MMK_HIP(hipStreamSynchronize(st));
     if (err != 0) {
       MMK_HIP(hipMemsetAsync(p->tau + 4, 0, sizeof(int64_t), st));
-      return fail(MMK_ERR_STATE, "srnn: a grid barrier of the tier kernel timed out during the previous generation (code %lld)", (long long)err);
+      return fail(MMK_ERR_STATE, "srnn: a wait inside the tier / bottom kernels timed out during the previous generation (code %lld: 3 grid barrier, "
+                  "4 bottom kernel waiting for the tiers, 5 tier kernel waiting for the bottom kernel; MMK_SRNN_RESIDENT=0 runs the tiers and the bottom in turns)", (long long)err);
     }
   }
   for (auto& t : p->tiers) {
@@ -311,8 +362,35 @@ extern "C" int mmk_srnn_commit(mmk_srnn_plan* p, void* workspace, size_t workspa
   if (!b.missing().empty()) return fail(MMK_ERR_KEY, "srnn_commit: state_dict tensor %s", b.missing().c_str());
   if (!p->cap_stream) MMK_HIP(hipStreamCreateWithFlags(&p->cap_stream, hipStreamNonBlocking));
   MMK_HIP(hipMemsetAsync(p->tau, 0, 32 * sizeof(int64_t), st));     // position counter, error word, diagnostic stamps
+  if (!p->side_stream) MMK_HIP(hipStreamCreateWithFlags(&p->side_stream, hipStreamNonBlocking));
+  if (!p->ev_fork) MMK_HIP(hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming));
+  if (!p->ev_join) MMK_HIP(hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming));
+  if (p->fused_bottom && p->fused_gru) MMK_TRY(probe_stream_overlap(p, st));
   p->committed = true;
   return mmk_srnn_reset(p, stream);
+}
+
+static SrnnBottomArgs bottom_args(mmk_srnn_plan* p, const SrnnCall& call, int64_t tau_off, int64_t n_steps) {
+  const mmk_srnn_config& c = p->cfg;
+  const int H = p->H;
+  SrnnTier& up = p->tiers[p->n_rnn_tiers - 1];
+  SrnnBottomArgs a = {};
+  a.B = call.M; a.H = H; a.Hm = c.mlp_hidden; a.Q = c.q_levels; a.n_out = c.q_levels + (c.learn_temp ? 1 : 0);
+  a.learn_temp = c.learn_temp; a.min_temp = c.min_temp; a.class_size = (float)c.q_levels;
+  a.fs = c.frame_size[c.n_tiers - 1]; a.up_slots = up.up;
+  a.n_steps = (int32_t)n_steps;
+  a.tau_ptr = p->tau; a.tau_off = tau_off;
+  a.idx = const_cast<int64_t*>(call.idx); a.idx_rs = call.idx_rs;
+  a.wb = p->wb_raw; a.bb = p->bb_raw; a.upper = up.out;
+  a.fc0_wp = p->mlp[0].Wp; a.fc0_bias = p->mlp[0].bias; a.fc2_wp = p->mlp[1].Wp; a.fc2_bias = p->mlp[1].bias;
+  a.fc0_raw = p->mlp_raw[0]; a.fc2_raw = p->mlp_raw[1];
+  a.temperature = call.temperature; a.uniforms = call.uniforms; a.uni_ld = call.uni_ld; a.uni_off = call.uni_off;
+  a.logits_out = p->logits; a.logits_ld = p->logits_ld;
+  {
+    const char* senv = getenv("MMK_SRNN_STAMPS");
+    a.stamps = (senv && senv[0] == '1') ? reinterpret_cast<unsigned long long*>(p->tau + 8) : nullptr;
+  }
+  return a;
 }
 
 // enqueue step t = *tau + tau_off, whose residue modulo frame_sizes[0] is `phase`
@@ -356,6 +434,12 @@ static int emit_step(mmk_srnn_plan* p, const SrnnCall& call, int64_t tau_off, in
         g.ups_wp = t.up_lin.Wp; g.ups_bias = t.up_lin.bias; g.ups_n_tiles = t.up_lin.n_tiles; g.ups_n = t.up_lin.N;
         g.ups_out = t.out; g.ups_out_ld = (int64_t)t.up * H;
         g.err = reinterpret_cast<int*>(p->tau + 4);      // sticky word, read by the next mmk_srnn_reset
+        if (call.gate) {
+          g.gate_progress = p->progress;
+          if (i == p->n_rnn_tiers - 1) g.ready = p->ready;
+        }
+      } else if (call.gate) {
+        return fail(MMK_ERR_STATE, "srnn: resident mode without the fused up-sampler");
       }
       MMK_TRY(launch_srnn_gru(g, st));
       if (fused_up) continue;
@@ -464,23 +548,7 @@ static int emit_step(mmk_srnn_plan* p, const SrnnCall& call, int64_t tau_off, in
   }
   if (bottom_steps <= 0) return MMK_OK;
   if (p->fused_bottom) {
-    SrnnTier& up = p->tiers[p->n_rnn_tiers - 1];
-    SrnnBottomArgs a = {};
-    a.B = M; a.H = H; a.Hm = c.mlp_hidden; a.Q = c.q_levels; a.n_out = c.q_levels + (c.learn_temp ? 1 : 0);
-    a.learn_temp = c.learn_temp; a.min_temp = c.min_temp; a.class_size = (float)c.q_levels;
-    a.fs = c.frame_size[c.n_tiers - 1]; a.up_slots = up.up;
-    a.n_steps = bottom_steps;
-    a.tau_ptr = p->tau; a.tau_off = tau_off;
-    a.idx = const_cast<int64_t*>(call.idx); a.idx_rs = call.idx_rs;
-    a.wb = p->wb_raw; a.bb = p->bb_raw; a.upper = up.out;
-    a.fc0_wp = p->mlp[0].Wp; a.fc0_bias = p->mlp[0].bias; a.fc2_wp = p->mlp[1].Wp; a.fc2_bias = p->mlp[1].bias;
-    a.fc0_raw = p->mlp_raw[0]; a.fc2_raw = p->mlp_raw[1];
-    a.temperature = call.temperature; a.uniforms = call.uniforms; a.uni_ld = call.uni_ld; a.uni_off = call.uni_off;
-    a.logits_out = p->logits; a.logits_ld = p->logits_ld;
-    {
-      const char* senv = getenv("MMK_SRNN_STAMPS");
-      a.stamps = (senv && senv[0] == '1') ? reinterpret_cast<unsigned long long*>(p->tau + 8) : nullptr;
-    }
+    SrnnBottomArgs a = bottom_args(p, call, tau_off, bottom_steps);
     return launch_srnn_bottom(a, st);
   }
   {
@@ -550,34 +618,42 @@ static int emit_range(mmk_srnn_plan* p, const SrnnCall& call, int64_t first, int
   return MMK_OK;
 }
 
-static int run_steps(mmk_srnn_plan* p, const SrnnCall& call, int64_t t_begin, int64_t n, bool with_bottom, hipStream_t st) {
-  if (n <= 0) return MMK_OK;
+// The graph of one period (frame_sizes[0] steps from residue phase0) for this call, captured when the cached one is another;
+// `st` / `also_sync`: streams replays of the old graph may still be queued on
+static int prepare_period_graph(mmk_srnn_plan* p, const SrnnCall& call, int64_t t_begin, int64_t n, bool with_bottom, hipStream_t st,
+                                hipStream_t also_sync) {
   const int period = p->cfg.frame_size[0];
-  MMK_TRY(launch_set_i64(p->tau, t_begin, st));
-  int64_t done = 0;
+  if (n < 2 * period) return MMK_OK;
   const int phase0 = (int)(t_begin % period);
+  std::vector<int64_t> key = {call.M, (int64_t)(uintptr_t)call.idx, call.idx_rs, call.shift, with_bottom ? 1 : 0,
+                              (int64_t)(uintptr_t)call.temperature, (int64_t)(uintptr_t)call.uniforms, call.uni_ld,
+                              call.uni_off, phase0, call.gate ? 1 : 0};
+  if (p->gc.exec && p->gc.key == key) return MMK_OK;
+  MMK_HIP(hipStreamSynchronize(st));
+  if (also_sync) MMK_HIP(hipStreamSynchronize(also_sync));
+  p->gc.reset();
+  MMK_HIP(hipStreamBeginCapture(p->cap_stream, hipStreamCaptureModeThreadLocal));
+  int rc = emit_range(p, call, 0, period, phase0, with_bottom, p->cap_stream);
+  if (rc == MMK_OK) rc = launch_bump(p->tau, period, p->cap_stream);
+  hipGraph_t g = nullptr;
+  hipError_t e = hipStreamEndCapture(p->cap_stream, &g);
+  if (rc != MMK_OK) {
+    if (g) (void)hipGraphDestroy(g);
+    return rc;
+  }
+  if (e != hipSuccess) return fail(MMK_ERR_HIP, "hipStreamEndCapture failed: %s", hipGetErrorString(e));
+  p->gc.graph = g;
+  MMK_HIP(hipGraphInstantiate(&p->gc.exec, g, nullptr, nullptr, 0));
+  p->gc.key = key;
+  p->gc.steps = period;
+  return MMK_OK;
+}
+
+// n steps from the step *tau points at: whole periods as replays of the prepared graph, the rest eagerly
+static int enqueue_steps(mmk_srnn_plan* p, const SrnnCall& call, int64_t t_begin, int64_t n, bool with_bottom, hipStream_t st) {
+  const int period = p->cfg.frame_size[0];
+  int64_t done = 0;
   if (n >= 2 * period) {
-    std::vector<int64_t> key = {call.M, (int64_t)(uintptr_t)call.idx, call.idx_rs, call.shift, with_bottom ? 1 : 0,
-                                (int64_t)(uintptr_t)call.temperature, (int64_t)(uintptr_t)call.uniforms, call.uni_ld,
-                                call.uni_off, phase0};
-    if (!p->gc.exec || p->gc.key != key) {
-      MMK_HIP(hipStreamSynchronize(st));
-      p->gc.reset();
-      MMK_HIP(hipStreamBeginCapture(p->cap_stream, hipStreamCaptureModeThreadLocal));
-      int rc = emit_range(p, call, 0, period, phase0, with_bottom, p->cap_stream);
-      if (rc == MMK_OK) rc = launch_bump(p->tau, period, p->cap_stream);
-      hipGraph_t g = nullptr;
-      hipError_t e = hipStreamEndCapture(p->cap_stream, &g);
-      if (rc != MMK_OK) {
-        if (g) (void)hipGraphDestroy(g);
-        return rc;
-      }
-      if (e != hipSuccess) return fail(MMK_ERR_HIP, "hipStreamEndCapture failed: %s", hipGetErrorString(e));
-      p->gc.graph = g;
-      MMK_HIP(hipGraphInstantiate(&p->gc.exec, g, nullptr, nullptr, 0));
-      p->gc.key = key;
-      p->gc.steps = period;
-    }
     const int64_t reps = n / period;
     for (int64_t r = 0; r < reps; ++r) MMK_HIP(hipGraphLaunch(p->gc.exec, st));
     done = reps * period;
@@ -587,6 +663,56 @@ static int run_steps(mmk_srnn_plan* p, const SrnnCall& call, int64_t t_begin, in
     MMK_TRY(launch_bump(p->tau, n - done, st));
   }
   return MMK_OK;
+}
+
+// Resident mode applies when both fused kernels do, the two streams were seen to overlap, every tier's grid plus one
+// workgroup per clip fit the chip together, and the block is long enough to be worth a fork / join (MMK_SRNN_RESIDENT=0: never)
+static bool resident_applies(mmk_srnn_plan* p, const SrnnCall& call, int64_t n) {
+  const char* renv = getenv("MMK_SRNN_RESIDENT");
+  const char* uenv = getenv("MMK_SRNN_FUSED_UP");
+  const bool off = renv && renv[0] == '0', up_off = uenv && uenv[0] == '0';
+  static const int n_cu = [] {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+    return v;
+  }();
+  if (off || up_off || !p->streams_overlap || !p->fused_bottom || !p->fused_gru || n < p->cfg.frame_size[0]) return false;
+  if (!srnn_gru_grid_resident(p->H, call.M)) return false;
+  const int tier_grid = (p->H / 16) * ((call.M + 15) / 16);
+  if (tier_grid + call.M > n_cu) return false;
+  return srnn_bottom_resident_supported(bottom_args(p, call, 0, n));
+}
+
+static int run_resident(mmk_srnn_plan* p, const SrnnCall& call, int64_t t_begin, int64_t n, hipStream_t st) {
+  SrnnCall tiers = call;
+  tiers.gate = true;
+  // (before the bottom kernel is queued: a capture synchronises the streams, and that kernel only ends with the tiers' help)
+  MMK_TRY(prepare_period_graph(p, tiers, t_begin, n, false, st, p->side_stream));
+  MMK_TRY(launch_set_i64(p->tau, t_begin, st));
+  hipLaunchKernelGGL(srnn_resident_init_kernel, dim3((call.M + 255) / 256), dim3(256), 0, st, p->progress, call.M, (unsigned)t_begin, p->ready);
+  MMK_HIP(hipGetLastError());
+  MMK_HIP(hipEventRecord(p->ev_fork, st));
+  MMK_HIP(hipStreamWaitEvent(p->side_stream, p->ev_fork, 0));
+  SrnnBottomArgs a = bottom_args(p, call, 0, n);
+  a.resident = 1;
+  a.t_first = t_begin;
+  a.ready = p->ready;
+  a.ready_per_update = (uint32_t)((p->H / 16) * ((call.M + 15) / 16));
+  a.progress = p->progress;
+  a.err = reinterpret_cast<int*>(p->tau + 4);
+  MMK_TRY(launch_srnn_bottom(a, st));
+  MMK_TRY(enqueue_steps(p, tiers, t_begin, n, false, p->side_stream));
+  MMK_HIP(hipEventRecord(p->ev_join, p->side_stream));
+  MMK_HIP(hipStreamWaitEvent(st, p->ev_join, 0));
+  return MMK_OK;
+}
+
+static int run_steps(mmk_srnn_plan* p, const SrnnCall& call, int64_t t_begin, int64_t n, bool with_bottom, hipStream_t st) {
+  if (n <= 0) return MMK_OK;
+  if (with_bottom && resident_applies(p, call, n)) return run_resident(p, call, t_begin, n, st);
+  MMK_TRY(prepare_period_graph(p, call, t_begin, n, with_bottom, st, p->side_stream));
+  MMK_TRY(launch_set_i64(p->tau, t_begin, st));
+  return enqueue_steps(p, call, t_begin, n, with_bottom, st);
 }
 
 static int check_call(mmk_srnn_plan* p, int32_t batch, const int64_t* idx, SrnnCall& call) {
@@ -641,8 +767,8 @@ extern "C" int mmk_srnn_last_logits(mmk_srnn_plan* p, int32_t batch, float* out,
             st[6] ? 100.0 * (double)st[5] / (double)st[6] : 0.0);
     MMK_HIP(hipMemcpy(st, p->tau + 16, sizeof(st), hipMemcpyDeviceToHost));
     const double ng = st[7] ? (double)st[7] : 1.0;
-    fprintf(stderr, "[mmk stamps] srnn gru kernel, workgroup 0, us per launch over %llu launches: loads=%.2f x=%.2f mfma=%.2f cell=%.2f\n",
-            st[7], st[0] * 1e-2 / ng, st[1] * 1e-2 / ng, st[2] * 1e-2 / ng, st[3] * 1e-2 / ng);
+    fprintf(stderr, "[mmk stamps] srnn gru kernel, workgroup 0, us per launch over %llu launches: loads=%.2f wait for the bottom kernel=%.2f x=%.2f mfma=%.2f cell=%.2f grid barrier=%.2f up-sampler=%.2f\n",
+            st[7], st[0] * 1e-2 / ng, st[4] * 1e-2 / ng, st[1] * 1e-2 / ng, st[2] * 1e-2 / ng, st[3] * 1e-2 / ng, st[5] * 1e-2 / ng, st[6] * 1e-2 / ng);
   }
   const int n = p->cfg.q_levels + (p->cfg.learn_temp ? 1 : 0);
   MMK_HIP(hipMemcpy2DAsync(out, ld * sizeof(float), p->logits, p->logits_ld * sizeof(float), n * sizeof(float), batch,
