@@ -372,7 +372,6 @@ __global__ __launch_bounds__(kBotThreads) void srnn_bottom1_kernel(const SrnnBot
   float* hid = (float*)sp;  sp += 16 * kPad2 * 4;           // hidden units, slice-padded likewise (KS2)
   float* lbuf = (float*)sp; sp += 1024 * 4;                 // logits (n_out <= 1024)
   int* s_win = (int*)sp;    sp += 16 * 4;
-  int* s_flag = (int*)sp;   sp += 16;
   float* wx = (float*)sp;                                   // fc2 rows past the first 256 outputs (the temperature column): (n_out - 256, Hm)
 
   // ---- once per launch: this thread's weights -> registers ------------------------------------------------------
@@ -419,14 +418,15 @@ __global__ __launch_bounds__(kBotThreads) void srnn_bottom1_kernel(const SrnnBot
   const float* wb_col = a.wb + xc * a.fs;
   const float wb0 = wb_col[0];
   const int u0 = (int)(t0 % a.up_slots);                      // outputs[-1][:, (t % fs[-2]) - fs[-2]]   (:257)
-  // resident mode: the rows come from a kernel that is still running (on other XCDs): agent-scope loads, and never before
-  // the update that writes them has been counted in
-  auto upper_at = [&](int step) -> float {
-    const float* src = a.upper + ((int64_t)clip * a.up_slots + (u0 + step) % a.up_slots) * H + xc;
-    return a.resident ? __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *src;
+  auto upper_at = [&](int step) -> float { return a.upper[((int64_t)clip * a.up_slots + (u0 + step) % a.up_slots) * H + xc]; };
+  // resident mode: the rows come as granules from a kernel that is still running; a granule is requested a step ahead and
+  // checked (polled, if need be) when it is used
+  typedef unsigned long long u64;
+  auto gran_at = [&](int step) -> u64 {
+    return __hip_atomic_load(a.up_gran + ((int64_t)clip * a.up_slots + (u0 + step) % a.up_slots) * H + xc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   };
-  const int64_t upd0 = (t0 - 1) / a.up_slots;                // updates of the tier above before this launch (t0 >= 1)
-  float up_next = (a.resident && t0 % a.up_slots == 0) ? 0.f : upper_at(0);
+  float up_next = a.resident ? 0.f : upper_at(0);
+  u64 up_g = (a.resident && tid < H) ? gran_at(0) : 0;
   // sum over the 16 lanes of a DPP row, every lane ends with the total (fixed order)
   auto row_sum = [](float v) -> float {
     v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, false));    // quad_perm [1,0,3,2]
@@ -440,22 +440,19 @@ __global__ __launch_bounds__(kBotThreads) void srnn_bottom1_kernel(const SrnnBot
 
   for (int s = 0; s < a.n_steps; ++s) {
     const int64_t t = t0 + s;
-    if (a.resident && t % a.up_slots == 0) {
-      // the tier above updates at this step: wait until every workgroup of its launch has written its columns
-      if (tid == 0) {
-        const unsigned need = (unsigned)(t / a.up_slots - upd0) * a.ready_per_update;
-        unsigned spins = 0;
-        int ok = 1;
-        while (__hip_atomic_load(a.ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
-          // ~1 s: the tier stream is not running beside this kernel (or another wait has already failed: do not pile up)
-          if (++spins > (1u << 20) || ((spins & 255u) == 0 && a.err && __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) { ok = 0; break; }
-          __builtin_amdgcn_s_sleep(1);
+    if (a.resident && tid < H) {
+      const unsigned epoch = (unsigned)(t / a.up_slots) + 1u;      // of the update this step's row belongs to
+      unsigned spins = 0;
+      while ((unsigned)(up_g >> 32) != epoch) {
+        // ~1 s: the tier stream is not running beside this kernel (or another wait has already failed: do not pile up)
+        if (++spins > (1u << 20) || ((spins & 255u) == 0 && a.err && __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+          if (a.err) atomicExch(a.err, 4);
+          break;
         }
-        *s_flag = ok;
-        if (!ok && a.err) atomicExch(a.err, 4);
+        __builtin_amdgcn_s_sleep(1);
+        up_g = gran_at(s);
       }
-      __syncthreads();
-      up_next = upper_at(s);
+      up_next = __uint_as_float((unsigned)up_g);
     }
     // ---- x = conv(linearize(window)) + bias + upper tier output -----------------------------------------
     if (tid < H) {
@@ -467,7 +464,10 @@ __global__ __launch_bounds__(kBotThreads) void srnn_bottom1_kernel(const SrnnBot
       }
       xs[xs_at] = (acc + xb) + up_next;
     }
-    if (s + 1 < a.n_steps && !(a.resident && (t + 1) % a.up_slots == 0)) up_next = upper_at(s + 1);
+    if (s + 1 < a.n_steps) {
+      if (!a.resident) up_next = upper_at(s + 1);
+      else if (tid < H) up_g = gran_at(s + 1);
+    }
     __syncthreads();
     stamp(1);
     // ---- fc0 + Mish ---------------------------------------------------------------------------------------------
@@ -613,18 +613,10 @@ __global__ __launch_bounds__(kBotThreads) void srnn_bottom1_kernel(const SrnnBot
         s_win[lane] = keep;     // wave-synchronous shift: every lane read before any lane writes
       }
       if (lane == 0) {
-        int64_t* dst = a.idx + (int64_t)clip * a.idx_rs + t;
-        if (!a.resident) {
-          *dst = result;
-        } else {
-          // written through (the tier kernels read it from other XCDs); before a tier update - and at the end - the clip's
-          // progress word follows once the stores have been acknowledged
-          __hip_atomic_store(dst, (int64_t)result, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          if ((t + 1) % a.up_slots == 0 || s + 1 == a.n_steps) {
-            __builtin_amdgcn_s_waitcnt(0x0F70);
-            __hip_atomic_store(a.progress + clip, (unsigned)(t + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          }
-        }
+        a.idx[(int64_t)clip * a.idx_rs + t] = result;
+        if (a.resident)    // for the tier kernels running beside this launch
+          __hip_atomic_store(a.cls_gran + (int64_t)clip * 256 + (t & 255), ((u64)(unsigned)(t + 1) << 32) | (unsigned)result, __ATOMIC_RELAXED,
+                             __HIP_MEMORY_SCOPE_AGENT);
       }
     }
     __syncthreads();

@@ -24,11 +24,11 @@ struct SrnnGruArgs {
   const float* ups_wp; const float* ups_bias; int32_t ups_n_tiles; int32_t ups_n;
   float* ups_out; int64_t ups_out_ld;
   int* err;                                 // sticky error word (a barrier that timed out), or nullptr
-  // Resident mode (the bottom tier runs beside this launch as one long kernel on another stream): the window is read once
-  // every clip of the row tile has reached step t (`gate_progress`, written by the bottom kernel), and - for the tier right
-  // above the bottom - every workgroup counts itself into `ready` after its up-sampler columns have been written through
-  const unsigned* gate_progress;
-  unsigned* ready;
+  // Resident mode (the bottom tier runs beside this launch as one long kernel on another stream; granules: srnn_bottom.h):
+  // the newest classes of the window are polled from `gate_cls`, and - for the tier right above the bottom - the up-sampled
+  // rows are also published as granules `up_gran` [B][up][H] with epoch t / fs + 1
+  const unsigned long long* gate_cls;
+  unsigned long long* up_gran;
 };
 
 bool srnn_gru_supported(int H, int fs, bool lstm);

@@ -136,40 +136,39 @@ __global__ __launch_bounds__(kGruThreads) void srnn_gru_kernel(const SrnnGruArgs
       }
     }
   }
-  // ---- resident mode: the newest classes come from the bottom kernel running beside this launch ------------------
-  const bool gated = a.gate_progress != nullptr;
-  if (gated) {
-    stamp(0);
-    int* s_gate = reinterpret_cast<int*>(red);
-    if (tid == 0) *s_gate = 1;
-    __syncthreads();
-    if (tid < mg) {
-      const unsigned need = (unsigned)(t + a.shift);
-      unsigned spins = 0;
-      while (__hip_atomic_load(a.gate_progress + m_first + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
-        // ~1 s: the bottom kernel is not running beside this launch (or another wait has already failed)
-        if (++spins > (1u << 20) || ((spins & 255u) == 0 && a.err && __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) { *s_gate = 0; break; }
-        __builtin_amdgcn_s_sleep(1);
-      }
-    }
-    __syncthreads();
-    if (!*s_gate && tid == 0 && a.err) atomicExch(a.err, 5);
-    __syncthreads();
-    stamp(4);   // waiting for the bottom kernel
-  }
+  const bool gated = a.gate_cls != nullptr;
+  stamp(0);   // weights requested, old state in LDS, recurrent half multiplied
   // ---- the window, linearized (modules/io.py:106-112), zero padded to whole K-chunks ----------------------------
   for (int e = tid; e < 16 * kci * 16; e += kGruThreads) {
     const int m = e / (kci * 16), i = e - m * (kci * 16);
     float v = 0.f;
     if (m < mg && i < a.fs) {
-      const int64_t* src = a.idx + (int64_t)(m_first + m) * a.idx_rs + t + a.shift - a.fs + i;
-      const int64_t cls = gated ? __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *src;
+      const int64_t pos = t + a.shift - a.fs + i;
+      int64_t cls;
+      if (!gated) {
+        cls = a.idx[(int64_t)(m_first + m) * a.idx_rs + pos];
+      } else {
+        // resident mode: the newest classes come from the bottom kernel running beside this launch, as granules
+        const unsigned long long* src = a.gate_cls + (int64_t)(m_first + m) * 256 + (pos & 255);
+        unsigned long long g = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned spins = 0;
+        while ((unsigned)(g >> 32) != (unsigned)(pos + 1)) {
+          // ~1 s: the bottom kernel is not running beside this launch (or another wait has already failed)
+          if (++spins > (1u << 20) || ((spins & 255u) == 0 && a.err && __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+            if (a.err) atomicExch(a.err, 5);
+            break;
+          }
+          __builtin_amdgcn_s_sleep(1);
+          g = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        cls = (int64_t)(unsigned)g;
+      }
       v = (((float)cls / a.class_size) - .5f) * 2.f;
     }
     s_lin[m * ldl + i] = v;
   }
   __syncthreads();
-  stamp(0);   // weights requested, window + old state in LDS
+  stamp(4);   // window (resident mode: incl. the wait for the bottom kernel)
   // ---- x = W_in lin + b_in (+ upper): 16 x 16 tiles over the waves, K = fs (same MFMA order as the launch path) ----
   if (x_hoisted) {
     const int q = lane >> 4, n = lane & 15;
@@ -382,17 +381,14 @@ __global__ __launch_bounds__(kGruThreads) void srnn_gru_kernel(const SrnnGruArgs
         if (r < mg && col < a.ups_n) {
           float* dst = a.ups_out + (int64_t)(m_first + r) * a.ups_out_ld + col;
           const float o = v + (a.ups_bias ? a.ups_bias[col] : 0.f);
-          if (a.ready) __hip_atomic_store(dst, o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // read by the resident bottom kernel
-          else *dst = o;
+          *dst = o;
+          if (a.up_gran)    // read by the resident bottom kernel
+            __hip_atomic_store(a.up_gran + (int64_t)(m_first + r) * a.ups_out_ld + col,
+                               ((unsigned long long)((unsigned)(t / a.fs) + 1u) << 32) | __float_as_uint(o), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
       }
       __syncthreads();
     }
-  }
-  if (a.ready) {
-    __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0): this wave's columns have been written through
-    __syncthreads();
-    if (tid == 0) __hip_atomic_fetch_add(a.ready, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   stamp(6);   // up-sampler
   if (stamping) {

@@ -21,7 +21,7 @@ struct SrnnCall {
   const float* uniforms = nullptr;
   int64_t uni_ld = 0;
   int64_t uni_off = 0;
-  bool gate = false;     // resident mode: the tier kernels wait for the bottom kernel's progress words (run_resident)
+  bool gate = false;     // resident mode: the tier kernels poll the bottom kernel's class granules (run_resident)
 };
 
 // a stacked recurrent layer above the first one of a tier (n_rnn > 1): its input is the layer below's new state
@@ -54,11 +54,12 @@ struct mmk_srnn_plan {
   hipStream_t cap_stream = nullptr;
   GraphCache gc;
   // resident mode: the bottom tier as ONE launch per generate block on the caller's stream, the tier kernels of the block on
-  // side_stream; both sides meet through `progress` / `ready` (srnn_bottom.h)
+  // side_stream; both sides meet through data-tagged granules (srnn_bottom.h)
   hipStream_t side_stream = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   bool streams_overlap = false;                 // probed at commit: kernels of the two streams do run side by side
-  unsigned *progress = nullptr, *ready = nullptr;
+  unsigned long long *up_gran = nullptr, *cls_gran = nullptr;   // [Bmax][up of the last tier][H], [Bmax][256]
+  unsigned* probe = nullptr;
   // fused bottom tier (srnn_bottom.hip): chosen at create time when the geometry allows it
   bool fused_bottom = false;
   bool fused_gru = false;                       // srnn_gru.hip: input linear + both gate products + cell in one launch
@@ -97,8 +98,9 @@ struct mmk_srnn_plan {
     logits_ld = (int)round_up(cfg.q_levels + (cfg.learn_temp ? 1 : 0), 4);
     logits = c.take<float>((int64_t)Bmax * logits_ld);
     tau = c.take<int64_t>(32);
-    progress = c.take<unsigned>(round_up(Bmax, 4));
-    ready = reinterpret_cast<unsigned*>(tau + 24);   // [0]: update counter of the tier above the bottom; [2], [3]: stream probe
+    up_gran = c.take<unsigned long long>((int64_t)Bmax * tiers.back().up * H);
+    cls_gran = c.take<unsigned long long>((int64_t)Bmax * 256);
+    probe = reinterpret_cast<unsigned*>(tau + 24);
     wb_raw = c.take<float>((int64_t)H * cfg.frame_size[cfg.n_tiers - 1]);
     bb_raw = c.take<float>(H);
   }
@@ -210,10 +212,23 @@ extern "C" size_t mmk_srnn_workspace_bytes(const mmk_srnn_plan* p) {
 }
 
 // ---- resident mode helpers ---------------------------------------------------------------------------------------------
-__global__ void srnn_resident_init_kernel(unsigned* progress, int B, unsigned t_begin, unsigned* ready) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < B) progress[i] = t_begin;
-  if (i == 0) *ready = 0;
+// Start of a resident block at step t_begin: the class ring holds the 256 positions before it, the row granules are cleared
+// (a granule of an earlier generation could carry the epoch this one waits for) - or, when the block starts between two
+// updates of the tier above, rebuilt from that tier's float rows with the epoch of its last update
+__global__ void srnn_resident_init_kernel(unsigned long long* cls_gran, unsigned long long* up_gran, const int64_t* idx, int64_t idx_rs,
+                                          const float* up_out, int B, int64_t n_up, int64_t t_begin, int up_slots) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < (int64_t)B * 256) {
+    const int c = (int)(i >> 8), slot = (int)(i & 255);
+    int64_t pos = ((t_begin - 1) & ~(int64_t)255) + slot;          // the position < t_begin with this residue
+    if (pos >= t_begin) pos -= 256;
+    cls_gran[i] = pos >= 0 ? (((unsigned long long)(unsigned)(pos + 1) << 32) | (unsigned)idx[(int64_t)c * idx_rs + pos]) : 0ull;
+  }
+  if (i < (int64_t)B * n_up) {
+    unsigned long long g = 0;
+    if (t_begin % up_slots != 0) g = ((unsigned long long)((unsigned)(t_begin / up_slots) + 1u) << 32) | __float_as_uint(up_out[i]);
+    up_gran[i] = g;
+  }
 }
 
 // Do kernels of two streams run side by side here?  A waits (bounded) for a word that only B writes; launched A first.
@@ -231,7 +246,7 @@ __global__ void srnn_probe_wait_kernel(unsigned* flags) {
 __global__ void srnn_probe_post_kernel(unsigned* flags) { __hip_atomic_store(flags, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 static int probe_stream_overlap(mmk_srnn_plan* p, hipStream_t st) {
-  unsigned* flags = p->ready + 2;
+  unsigned* flags = p->probe;
   MMK_HIP(hipMemsetAsync(flags, 0, 2 * sizeof(unsigned), st));
   MMK_HIP(hipStreamSynchronize(st));
   hipLaunchKernelGGL(srnn_probe_wait_kernel, dim3(1), dim3(1), 0, st, flags);
@@ -435,8 +450,8 @@ static int emit_step(mmk_srnn_plan* p, const SrnnCall& call, int64_t tau_off, in
         g.ups_out = t.out; g.ups_out_ld = (int64_t)t.up * H;
         g.err = reinterpret_cast<int*>(p->tau + 4);      // sticky word, read by the next mmk_srnn_reset
         if (call.gate) {
-          g.gate_progress = p->progress;
-          if (i == p->n_rnn_tiers - 1) g.ready = p->ready;
+          g.gate_cls = p->cls_gran;
+          if (i == p->n_rnn_tiers - 1) g.up_gran = p->up_gran;
         }
       } else if (call.gate) {
         return fail(MMK_ERR_STATE, "srnn: resident mode without the fused up-sampler");
@@ -689,16 +704,21 @@ static int run_resident(mmk_srnn_plan* p, const SrnnCall& call, int64_t t_begin,
   // (before the bottom kernel is queued: a capture synchronises the streams, and that kernel only ends with the tiers' help)
   MMK_TRY(prepare_period_graph(p, tiers, t_begin, n, false, st, p->side_stream));
   MMK_TRY(launch_set_i64(p->tau, t_begin, st));
-  hipLaunchKernelGGL(srnn_resident_init_kernel, dim3((call.M + 255) / 256), dim3(256), 0, st, p->progress, call.M, (unsigned)t_begin, p->ready);
-  MMK_HIP(hipGetLastError());
+  {
+    SrnnTier& last = p->tiers[p->n_rnn_tiers - 1];
+    const int64_t n_up = (int64_t)last.up * p->H;
+    const int64_t n_el = (int64_t)call.M * (n_up > 256 ? n_up : 256);
+    hipLaunchKernelGGL(srnn_resident_init_kernel, dim3((unsigned)((n_el + 255) / 256)), dim3(256), 0, st, p->cls_gran, p->up_gran, call.idx,
+                       call.idx_rs, last.out, call.M, n_up, t_begin, last.up);
+    MMK_HIP(hipGetLastError());
+  }
   MMK_HIP(hipEventRecord(p->ev_fork, st));
   MMK_HIP(hipStreamWaitEvent(p->side_stream, p->ev_fork, 0));
   SrnnBottomArgs a = bottom_args(p, call, 0, n);
   a.resident = 1;
   a.t_first = t_begin;
-  a.ready = p->ready;
-  a.ready_per_update = (uint32_t)((p->H / 16) * ((call.M + 15) / 16));
-  a.progress = p->progress;
+  a.up_gran = p->up_gran;
+  a.cls_gran = p->cls_gran;
   a.err = reinterpret_cast<int*>(p->tau + 4);
   MMK_TRY(launch_srnn_bottom(a, st));
   MMK_TRY(enqueue_steps(p, tiers, t_begin, n, false, p->side_stream));
