@@ -17,6 +17,7 @@ struct SrnnGruArgs {
   int32_t lstm;                             // 0: GRU (3 gates, separate biases) ; 1: LSTM (4 gates, summed bias in wih_bias)
   float* c;                                 // LSTM cell state (B, H), in place
   float* h_ring; int64_t h_slot_stride;     // [2][B][H]: slot (cnt & 1) is read, slot ((cnt + 1) & 1) written
+  unsigned long long* h_gran;               // [B][H] granules {update number, new state}: with the up-sampler phase (ups_wp)
   int64_t* cnt; unsigned* done;             // update counter of the tier, finish ticket
   unsigned long long* stamps;               // diagnostic: phase totals (100 MHz ticks) + launch count, or nullptr
   // optional second phase: the tier's up-sampler, out[b][n] = W_up[n] . h_new[b] + bias[n]  (n < 16 ups_n_tiles),

@@ -13,6 +13,8 @@
 // the up-sampling launch that follows uses as its position counter.
 // LSTM tiers (the reference's default rnn_class) run through the same kernel: eight tiles (i, f, g, o of W_ih and W_hh,
 // which the plan packs side by side along K), the ATen LSTMCell, and a cell state updated in place.
+#include <type_traits>
+
 #include "mmk_common.h"
 #include "srnn_gru.h"
 
@@ -74,17 +76,35 @@ __global__ __launch_bounds__(kGruThreads) void srnn_gru_kernel(const SrnnGruArgs
     }
   }
   // ... and the first up-sampler tiles of this workgroup (second phase): nothing of them depends on this update.  The workgroup
-  // up-samples ITS OWN clips: columns [ub 16 up, (ub + 1) 16 up) of the tier's (up H) outputs, `up` tiles of 16
+  // up-samples ITS OWN clips: columns [j H + 16 ub, + 16) of the tier's (up H) outputs for every slot j < up (tile j KC + ub):
+  // slot 0 - the row the tier below needs first - is every workgroup's first tile and goes out on its own
   constexpr int UB = (LSTM && KC == 32) ? 2 : 4;   // tiles per batch (registers, partial-sum buffer)
   const int up_tiles = a.ups_wp != nullptr ? a.ups_n_tiles / KC : 0;
   f32x4 wu0[UB][CPW];
   if (a.ups_wp != nullptr) {
 #pragma unroll
     for (int j = 0; j < UB; ++j) {
-      const int tile = ub * up_tiles + min(j, up_tiles - 1);
+      const int tile = min(j, up_tiles - 1) * KC + ub;
       gf32x4_ptr wsrc = (gf32x4_ptr)(uintptr_t)a.ups_wp + ((int64_t)tile * KC + wave * CPW) * 64 + lane;
 #pragma unroll
       for (int u = 0; u < CPW; ++u) wu0[j][u] = wsrc[u * 64];
+    }
+  }
+  // ... and the biases of the cell (thread = (clip, unit) pair) and of the first up-sampler batch (two outputs per thread)
+  float cell_b[2 * NG], ups_b[2] = {0.f, 0.f};
+  {
+    const int unit = ub * 16 + (tid & 15);
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      cell_b[g] = a.wih_bias ? a.wih_bias[g * H + unit] : 0.f;
+      cell_b[NG + g] = (!LSTM && a.whh_bias) ? a.whh_bias[g * H + unit] : 0.f;
+    }
+    if (a.ups_wp != nullptr && a.ups_bias) {
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const int j = min(k == 0 ? 0 : 1 + (tid >> 8), up_tiles - 1);      // batch {0}: tile 0; batch {1, 2, 3}: first round
+        ups_b[k] = a.ups_bias[(j * KC + ub) * 16 + (tid & 15)];
+      }
     }
   }
   const int kci = (a.fs + 15) / 16, ldl = kci * 16 + 4;
@@ -238,12 +258,14 @@ __global__ __launch_bounds__(kGruThreads) void srnn_gru_kernel(const SrnnGruArgs
   }
   __syncthreads();
   stamp(2);   // MFMAs (incl. the wait for the weights)
-  // the new state: plain stores, or - when the up-sampler phase of this launch reads it from other XCDs - write-through
-  // agent-scope stores (sc1), so that no L2 write-back / invalidate (a fence costs ~10 us here) is needed
+  // the new state: plain stores for the next update; when the up-sampler phase of this launch reads it from other XCDs it
+  // also goes out as data-tagged granules {update number, value} (agent-scope stores, polled by the readers: one hop, where
+  // a grid barrier behind acknowledged write-through stores took 2.6 us + the read, and an L2 write-back fence ~10 us)
   const bool fused_up = a.ups_wp != nullptr;
-  auto store_state = [&](float* dst, float v) {
-    if (fused_up) __hip_atomic_store(dst, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    else *dst = v;
+  auto store_state = [&](int64_t o, float v) {
+    h_new[o] = v;
+    if (fused_up)
+      __hip_atomic_store(a.h_gran + o, ((unsigned long long)(unsigned)(cnt + 1) << 32) | __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   };
   // ---- cell: one (clip, unit) pair per thread -----------------------------------------------------------------
   if (tid < 256) {
@@ -265,23 +287,23 @@ __global__ __launch_bounds__(kGruThreads) void srnn_gru_kernel(const SrnnGruArgs
         // gates = (W_ih x + W_hh h) + (b_ih + b_hh); i, f, o = s(.), g = tanh(.); c' = f c + i g; h' = o tanh(c')
         float gt[4];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) gt[g] = (s[g] + s[NG + g]) + (a.wih_bias ? a.wih_bias[g * H + unit] : 0.f);
+        for (int g = 0; g < 4; ++g) gt[g] = (s[g] + s[NG + g]) + cell_b[g];
         const float ig = sigmoidf_(gt[0]), fg = sigmoidf_(gt[1]), cg = tanhf(gt[2]), og = sigmoidf_(gt[3]);
         const float cn = fg * a.c[o] + ig * cg;
         a.c[o] = cn;
-        store_state(h_new + o, og * tanhf(cn));
+        store_state(o, og * tanhf(cn));
       } else {
-        const float gi_r = s[0] + (a.wih_bias ? a.wih_bias[unit] : 0.f);
-        const float gi_z = s[1] + (a.wih_bias ? a.wih_bias[H + unit] : 0.f);
-        const float gi_n = s[2] + (a.wih_bias ? a.wih_bias[2 * H + unit] : 0.f);
-        const float gh_r = s[3] + (a.whh_bias ? a.whh_bias[unit] : 0.f);
-        const float gh_z = s[4] + (a.whh_bias ? a.whh_bias[H + unit] : 0.f);
-        const float gh_n = s[5] + (a.whh_bias ? a.whh_bias[2 * H + unit] : 0.f);
+        const float gi_r = s[0] + cell_b[0];
+        const float gi_z = s[1] + cell_b[1];
+        const float gi_n = s[2] + cell_b[2];
+        const float gh_r = s[3] + cell_b[NG];
+        const float gh_z = s[4] + cell_b[NG + 1];
+        const float gh_n = s[5] + cell_b[NG + 2];
         const float r = sigmoidf_(gh_r + gi_r);
         const float z = sigmoidf_(gh_z + gi_z);
         const float nn = tanhf(gi_n + gh_n * r);
         const float hp = hs[m * ldx + unit];
-        store_state(h_new + o, (hp - nn) * z + nn);
+        store_state(o, (hp - nn) * z + nn);
       }
     }
   }
@@ -291,10 +313,6 @@ __global__ __launch_bounds__(kGruThreads) void srnn_gru_kernel(const SrnnGruArgs
   if (stamping && !fused_up) {
     for (int i = 0; i < 5; ++i) a.stamps[i] += st_acc[i];
     a.stamps[7] += 1;
-  }
-  if (fused_up) {
-    __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0): this wave's rows of the new state have been written through
-    __syncthreads();
   }
   if (tid == 0) {
     if (!fused_up) __threadfence();
@@ -306,57 +324,79 @@ __global__ __launch_bounds__(kGruThreads) void srnn_gru_kernel(const SrnnGruArgs
     }
   }
   if (!fused_up) return;
-  // ---- grid-wide barrier: the update counter moves when the last workgroup has published its rows --------------------
-  int* s_flag = reinterpret_cast<int*>(s_lin);
-  if (tid == 0) {
-    unsigned spins = 0;
-    int ok = 1;
-    while (__hip_atomic_load(a.cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != cnt + 1) {
-      if (++spins > (1u << 22)) { ok = 0; break; }                 // ~1 s: a workgroup of the grid never became resident
-      __builtin_amdgcn_s_sleep(2);
-    }
-    *s_flag = ok;
-  }
-  __syncthreads();
-  if (!*s_flag) {
-    if (tid == 0 && a.err) atomicExch(a.err, 3);
-    return;
-  }
-  stamp(5);   // grid-wide barrier
   // ---- up-sampler: this workgroup's clips x its `up` column tiles, K split over the waves -------------------------------
   // (the rows of the own row tile come from the H / 16 workgroups of the tile - 32 KB at H = 512; every workgroup reading
   //  every clip's row for 16 columns was 4 x that and 6.4 us, measured)
   {
     const int c0 = wave * CPW;
-    // agent-scope loads (sc1): the rows come from other XCDs' workgroups.  Loads AND the wait sit in one asm statement: the
-    // compiler does not know these are loads and would otherwise be free to copy the destination registers too early.
+    // The rows of the new state as granules, polled with agent-scope loads (sc1) until every tag is this update's.  Loads AND
+    // the wait sit in one asm statement: the compiler does not know these are loads and would otherwise be free to copy the
+    // destination registers too early.
     f32x4 hv[CPW];
     {
+      typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
       const int m = lane & 15;
-      const float* hr = h_new + (int64_t)(m_first + (m < mg ? m : mg - 1)) * H + c0 * 16 + 4 * (lane >> 4);   // clamped, unconditional
-      if constexpr (CPW == 1) {
-        asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(hv[0]) : "v"(hr) : "memory");
-      } else if constexpr (CPW == 2) {
-        asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dwordx4 %1, %2, off offset:64 sc1\n\ts_waitcnt vmcnt(0)"
-                     : "=&v"(hv[0]), "=&v"(hv[1]) : "v"(hr) : "memory");
-      } else {
-        static_assert(CPW == 4, "H in {128, 256, 512}");
-        asm volatile("global_load_dwordx4 %0, %4, off sc1\n\tglobal_load_dwordx4 %1, %4, off offset:64 sc1\n\t"
-                     "global_load_dwordx4 %2, %4, off offset:128 sc1\n\tglobal_load_dwordx4 %3, %4, off offset:192 sc1\n\ts_waitcnt vmcnt(0)"
-                     : "=&v"(hv[0]), "=&v"(hv[1]), "=&v"(hv[2]), "=&v"(hv[3]) : "v"(hr) : "memory");
+      const unsigned long long* hr = a.h_gran + (int64_t)(m_first + (m < mg ? m : mg - 1)) * H + c0 * 16 + 4 * (lane >> 4);   // clamped
+      const unsigned epoch = (unsigned)(cnt + 1);
+      u32x4v g[2 * CPW];
+      unsigned spins = 0;
+      // first a light poll - one wave, one granule per producing workgroup (its last element) - so that 64 K granules per
+      // workgroup are not requested over and over while the producers' stores are still on their way; then everything
+      if (wave == 0 && lane < KC) {
+        const unsigned long long* sp = a.h_gran + (int64_t)(m_first + mg - 1) * H + lane * 16 + 15;
+        while ((unsigned)(__hip_atomic_load(sp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 32) != epoch) {
+          if (++spins > (1u << 20)) break;      // the full poll below reports it
+          __builtin_amdgcn_s_sleep(1);
+        }
+        spins = 0;
       }
+      __syncthreads();
+      for (;;) {
+        if constexpr (CPW == 1) {
+          asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dwordx4 %1, %2, off offset:16 sc1\n\ts_waitcnt vmcnt(0)"
+                       : "=&v"(g[0]), "=&v"(g[1]) : "v"(hr) : "memory");
+        } else if constexpr (CPW == 2) {
+          asm volatile("global_load_dwordx4 %0, %4, off sc1\n\tglobal_load_dwordx4 %1, %4, off offset:16 sc1\n\t"
+                       "global_load_dwordx4 %2, %4, off offset:128 sc1\n\tglobal_load_dwordx4 %3, %4, off offset:144 sc1\n\ts_waitcnt vmcnt(0)"
+                       : "=&v"(g[0]), "=&v"(g[1]), "=&v"(g[2]), "=&v"(g[3]) : "v"(hr) : "memory");
+        } else {
+          static_assert(CPW == 4, "H in {128, 256, 512}");
+          asm volatile("global_load_dwordx4 %0, %8, off sc1\n\tglobal_load_dwordx4 %1, %8, off offset:16 sc1\n\t"
+                       "global_load_dwordx4 %2, %8, off offset:128 sc1\n\tglobal_load_dwordx4 %3, %8, off offset:144 sc1\n\t"
+                       "global_load_dwordx4 %4, %8, off offset:256 sc1\n\tglobal_load_dwordx4 %5, %8, off offset:272 sc1\n\t"
+                       "global_load_dwordx4 %6, %8, off offset:384 sc1\n\tglobal_load_dwordx4 %7, %8, off offset:400 sc1\n\ts_waitcnt vmcnt(0)"
+                       : "=&v"(g[0]), "=&v"(g[1]), "=&v"(g[2]), "=&v"(g[3]), "=&v"(g[4]), "=&v"(g[5]), "=&v"(g[6]), "=&v"(g[7])
+                       : "v"(hr) : "memory");
+        }
+        bool all = true;
+#pragma unroll
+        for (int k = 0; k < 2 * CPW; ++k) all = all && g[k][1] == epoch && g[k][3] == epoch;
+        if (all) break;
+        // ~1 s: a workgroup of the grid never became resident (the launcher checks the grid against the CU count)
+        if (++spins > (1u << 20) || ((spins & 255u) == 0 && a.err && __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+          if (a.err) atomicExch(a.err, 3);
+          break;
+        }
+        __builtin_amdgcn_s_sleep(1);
+      }
+#pragma unroll
+      for (int u = 0; u < CPW; ++u)
+        hv[u] = f32x4{__uint_as_float(g[2 * u][0]), __uint_as_float(g[2 * u][2]), __uint_as_float(g[2 * u + 1][0]), __uint_as_float(g[2 * u + 1][2])};
     }
-    for (int j0 = 0; j0 < up_tiles; j0 += UB) {
-      const int nb = min(UB, up_tiles - j0);
+    stamp(5);   // the new state of the own clips has arrived
+    // batches of tiles: {0}, {1 .. UB - 1} (both from the registers filled at the top; PB = first preloaded tile of the
+    // batch, a compile-time index), then UB at a time streamed (PB < 0)
+    auto run_batch = [&](auto pb, int jb, int nb) {
+      constexpr int PB = decltype(pb)::value;
 #pragma unroll
       for (int j = 0; j < UB; ++j) {
         if (j < nb) {
           f32x4 wu[CPW];
-          if (j0 == 0) {
+          if constexpr (PB >= 0) {
 #pragma unroll
-            for (int u = 0; u < CPW; ++u) wu[u] = wu0[j][u];
+            for (int u = 0; u < CPW; ++u) wu[u] = wu0[(PB + j) < UB ? (PB + j) : 0][u];
           } else {
-            gf32x4_ptr wsrc = (gf32x4_ptr)(uintptr_t)a.ups_wp + ((int64_t)(ub * up_tiles + j0 + j) * KC + c0) * 64 + lane;
+            gf32x4_ptr wsrc = (gf32x4_ptr)(uintptr_t)a.ups_wp + ((int64_t)((jb + j) * KC + ub) * KC + c0) * 64 + lane;
 #pragma unroll
             for (int u = 0; u < CPW; ++u) wu[u] = wsrc[u * 64];
           }
@@ -377,10 +417,11 @@ __global__ __launch_bounds__(kGruThreads) void srnn_gru_kernel(const SrnnGruArgs
         float v = 0.f;
 #pragma unroll
         for (int wv = 0; wv < kGruWaves; ++wv) v += f[wv * 256];
-        const int col = (ub * up_tiles + j0 + j) * 16 + n;
+        const int col = ((jb + j) * KC + ub) * 16 + n;
         if (r < mg && col < a.ups_n) {
           float* dst = a.ups_out + (int64_t)(m_first + r) * a.ups_out_ld + col;
-          const float o = v + (a.ups_bias ? a.ups_bias[col] : 0.f);
+          const float bias = PB == 0 ? ups_b[0] : ((PB == 1 && e < kGruThreads) ? ups_b[1] : (a.ups_bias ? a.ups_bias[col] : 0.f));
+          const float o = v + bias;
           *dst = o;
           if (a.up_gran)    // read by the resident bottom kernel
             __hip_atomic_store(a.up_gran + (int64_t)(m_first + r) * a.ups_out_ld + col,
@@ -388,7 +429,10 @@ __global__ __launch_bounds__(kGruThreads) void srnn_gru_kernel(const SrnnGruArgs
         }
       }
       __syncthreads();
-    }
+    };
+    run_batch(std::integral_constant<int, 0>{}, 0, 1);
+    if (up_tiles > 1) run_batch(std::integral_constant<int, 1>{}, 1, min(up_tiles, UB) - 1);
+    for (int jb = UB; jb < up_tiles; jb += UB) run_batch(std::integral_constant<int, -1>{}, jb, min(UB, up_tiles - jb));
   }
   stamp(6);   // up-sampler
   if (stamping) {

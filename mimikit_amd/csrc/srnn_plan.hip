@@ -38,6 +38,7 @@ struct SrnnTier {
   float *win_raw = nullptr, *bin_raw = nullptr;       // input Linear in its state_dict layout
   int64_t* cnt = nullptr;                             // update counter (slot of the current state = cnt & 1)
   unsigned* done = nullptr;
+  unsigned long long* h_gran = nullptr;               // [Bmax][H]: the new state as granules (fused up-sampler phase)
 };
 
 struct mmk_srnn_plan {
@@ -79,6 +80,7 @@ struct mmk_srnn_plan {
       t.bin_raw = c.take<float>(H);
       t.cnt = c.take<int64_t>(4);
       t.done = c.take<unsigned>(4);
+      t.h_gran = c.take<unsigned long long>((int64_t)Bmax * H);
       t.out = c.take<float>((int64_t)Bmax * t.up * H);
       for (auto& d : t.deep) {
         d.gates.carve(c, bias);
@@ -279,6 +281,7 @@ extern "C" int mmk_srnn_reset(mmk_srnn_plan* p, mmk_stream_t stream) {
     MMK_TRY(launch_fill(t.h, p->cfg.h0_ones ? 1.f : 0.f, (int64_t)2 * p->Bmax * p->H, st));
     MMK_HIP(hipMemsetAsync(t.cnt, 0, 4 * sizeof(int64_t), st));
     MMK_HIP(hipMemsetAsync(t.done, 0, 4 * sizeof(unsigned), st));
+    MMK_HIP(hipMemsetAsync(t.h_gran, 0, (size_t)p->Bmax * p->H * sizeof(unsigned long long), st));   // update numbers restart at 1
     MMK_TRY(launch_fill(t.c, p->cfg.h0_ones ? 1.f : 0.f, (int64_t)p->Bmax * p->H, st));
     MMK_HIP(hipMemsetAsync(t.out, 0, (size_t)p->Bmax * t.up * p->H * sizeof(float), st));
     for (auto& d : t.deep) {
@@ -436,7 +439,7 @@ static int emit_step(mmk_srnn_plan* p, const SrnnCall& call, int64_t tau_off, in
         g.w_tile_chunks = t.gates.k_chunks; g.c = t.c;
       }
       g.h_ring = t.h; g.h_slot_stride = (int64_t)p->Bmax * H;
-      g.cnt = t.cnt; g.done = t.done;
+      g.cnt = t.cnt; g.done = t.done; g.h_gran = t.h_gran;
       {
         const char* senv = getenv("MMK_SRNN_STAMPS");
         g.stamps = (senv && senv[0] == '1') ? reinterpret_cast<unsigned long long*>(p->tau + 16) : nullptr;
