@@ -643,16 +643,18 @@ static int prepare_period_graph(mmk_srnn_plan* p, const SrnnCall& call, int64_t 
   const int period = p->cfg.frame_size[0];
   if (n < 2 * period) return MMK_OK;
   const int phase0 = (int)(t_begin % period);
+  // several periods per graph once the block is long: a replay boundary costs more than a kernel boundary inside a graph
+  const int periods = n >= 16 * (int64_t)period ? 4 : 1;
   std::vector<int64_t> key = {call.M, (int64_t)(uintptr_t)call.idx, call.idx_rs, call.shift, with_bottom ? 1 : 0,
                               (int64_t)(uintptr_t)call.temperature, (int64_t)(uintptr_t)call.uniforms, call.uni_ld,
-                              call.uni_off, phase0, call.gate ? 1 : 0};
+                              call.uni_off, phase0, call.gate ? 1 : 0, periods};
   if (p->gc.exec && p->gc.key == key) return MMK_OK;
   MMK_HIP(hipStreamSynchronize(st));
   if (also_sync) MMK_HIP(hipStreamSynchronize(also_sync));
   p->gc.reset();
   MMK_HIP(hipStreamBeginCapture(p->cap_stream, hipStreamCaptureModeThreadLocal));
-  int rc = emit_range(p, call, 0, period, phase0, with_bottom, p->cap_stream);
-  if (rc == MMK_OK) rc = launch_bump(p->tau, period, p->cap_stream);
+  int rc = emit_range(p, call, 0, (int64_t)period * periods, phase0, with_bottom, p->cap_stream);
+  if (rc == MMK_OK) rc = launch_bump(p->tau, (int64_t)period * periods, p->cap_stream);
   hipGraph_t g = nullptr;
   hipError_t e = hipStreamEndCapture(p->cap_stream, &g);
   if (rc != MMK_OK) {
@@ -663,7 +665,7 @@ static int prepare_period_graph(mmk_srnn_plan* p, const SrnnCall& call, int64_t 
   p->gc.graph = g;
   MMK_HIP(hipGraphInstantiate(&p->gc.exec, g, nullptr, nullptr, 0));
   p->gc.key = key;
-  p->gc.steps = period;
+  p->gc.steps = period * periods;
   return MMK_OK;
 }
 
@@ -672,9 +674,9 @@ static int enqueue_steps(mmk_srnn_plan* p, const SrnnCall& call, int64_t t_begin
   const int period = p->cfg.frame_size[0];
   int64_t done = 0;
   if (n >= 2 * period) {
-    const int64_t reps = n / period;
+    const int64_t reps = n / p->gc.steps;
     for (int64_t r = 0; r < reps; ++r) MMK_HIP(hipGraphLaunch(p->gc.exec, st));
-    done = reps * period;
+    done = reps * p->gc.steps;
   }
   if (n > done) {
     MMK_TRY(emit_range(p, call, 0, n - done, (int)((t_begin + done) % period), with_bottom, st));
