@@ -218,7 +218,10 @@ __global__ __launch_bounds__(kTgThreads, 2) void gemm_bias_act_kernel(const floa
 }
 
 bool gemm_bias_act_supported(const float* A, int64_t lda, int M, int K) {
-  return M >= 128 && K >= 16 && (lda % 4) == 0 && (reinterpret_cast<uintptr_t>(A) & 15) == 0;
+  // (M = 64 - dec.fc of the Seq2Seq decoder, 64 x 8192 x 1024 - was measured on this kernel too: slower than the row-tile
+  //  kernel's 27.7 us, cfg 5 218 instead of 227 M samples/s; MMK_GEMM_MIN_M moves the threshold)
+  static const int min_m = [] { const char* e = getenv("MMK_GEMM_MIN_M"); return e ? atoi(e) : 128; }();
+  return M >= min_m && K >= 16 && (lda % 4) == 0 && (reinterpret_cast<uintptr_t>(A) & 15) == 0;
 }
 
 int launch_gemm_bias_act(const float* A, int64_t lda, const float* Wp, const float* bias, int n_tiles, int k_chunks, int N, int K, float* C,

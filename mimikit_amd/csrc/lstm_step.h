@@ -16,6 +16,7 @@ struct LstmStepDir {
 struct LstmStepArgs {
   int32_t M, H, n_dir;          // rows, hidden size, directions processed by this launch (grid.z)
   int64_t gadd_ld, y_ld;
+  int32_t zero_state;           // 1: h_{t-1} = c_{t-1} = 0 (first step of `lstm(x)` without a state): no recurrent product, nothing read
   LstmStepDir dir[2];
 };
 

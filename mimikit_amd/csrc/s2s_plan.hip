@@ -280,8 +280,8 @@ static int run_bilstm(mmk_s2s_plan* p, BiLstm& l, const float* x, int x_ld, int 
   const int64_t rows = (int64_t)M * hop;
   for (int d = 0; d < 2; ++d) {
     MMK_TRY(plain_linear(l.ih[d], x, x_ld, (int)rows, p->gi[d], 4 * D, ACT_NONE, st));
-    if (zero_state) {
-      // `lstm(x,)` : fresh zero state on every call                    (s2s_lstm_v2.py:97)
+    if (zero_state && !p->fused_lstm) {
+      // `lstm(x,)` : fresh zero state on every call                    (s2s_lstm_v2.py:97); the fused step kernel takes a flag
       MMK_HIP(hipMemsetAsync(p->h[d], 0, (size_t)p->Bmax * D * sizeof(float), st));
       MMK_HIP(hipMemsetAsync(p->c[d], 0, (size_t)p->Bmax * D * sizeof(float), st));
     }
@@ -294,6 +294,7 @@ static int run_bilstm(mmk_s2s_plan* p, BiLstm& l, const float* x, int x_ld, int 
     for (int s = 0; s < hop; ++s) {
       LstmStepArgs a = {};
       a.M = M; a.H = D; a.n_dir = 2; a.gadd_ld = (int64_t)hop * 4 * D; a.y_ld = (int64_t)hop * D;
+      a.zero_state = (zero_state && s == 0) ? 1 : 0;
       for (int d = 0; d < 2; ++d) {
         const int t = d == 0 ? s : hop - 1 - s;
         a.dir[d].whh_wp = l.hh[d].Wp;
