@@ -33,7 +33,7 @@ struct WnPipeArgs {
   int32_t* err_flag;
   unsigned* xcd_count;
   unsigned long long* stamps;
-  int32_t stamp_stage, stamp_owner;   // diagnostic build: whose thread 0 records the stamps
+  int32_t stamp_stage, stamp_owner, stamp_wave;   // diagnostic build: which workgroup's / wave's lane 0 records the stamps
 };
 
 size_t wn_pipe_lds_bytes(const WnPipeArgs& a);

@@ -592,14 +592,21 @@ __global__ __launch_bounds__(kPiThreads) void wavenet_pipe_kernel(const WnPipeAr
         u64* gran_y = gran_yl0 + par * 16 * C;
         u64* gran_h = gran_hl0 + par * 16 * C;
         // the next iteration's small operands (after the last one: the next visit's first iteration)
+        // (measured on the product build, us per step: the two loads here 74.7; behind the wave's own operand reads 75.3; behind the
+        //  MFMAs 75.7; in the idle time before B4, a whole iteration ahead, 79.9 - the exchange polls then queue behind them)
         if (is_loader) issue_request();                      // the next iteration's small operands (addresses ready-made)
         __builtin_amdgcn_sched_barrier(0);
+        stamp(4);
         {
           const float* xsrc = (role == 0 ? hprev : (role == 1 ? hbuf + hsel * kRows * ldh : ybuf + ((i + 1) & 1) * kRows * ldh)) + opaque(x_off);
           f32x4 xv[CPW];
 #pragma unroll
           for (int u = 0; u < CPW; ++u) xv[u] = *reinterpret_cast<const f32x4*>(xsrc + u * 4);
           __builtin_amdgcn_sched_barrier(0);
+          if (STAMPS) {
+            __builtin_amdgcn_s_waitcnt(0xC07F);              // lgkmcnt(0): the operands have arrived
+            stamp(5);
+          }
           f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
           for (int u = 0; u < CPW; ++u) {
@@ -698,7 +705,7 @@ __global__ __launch_bounds__(kPiThreads) void wavenet_pipe_kernel(const WnPipeAr
     }
   }
   if (pend_g >= 0) (void)own_h_to_ring(pend_g, pend_tau, pend_epoch);
-  if (STAMPS && a.stamps && stage == a.stamp_stage && j == a.stamp_owner && tid == 0) {
+  if (STAMPS && a.stamps && stage == a.stamp_stage && j == a.stamp_owner && tid == a.stamp_wave * 64) {
     st_acc[14] = clock64() - clk_start;
     st_acc[15] = wall_clock64() - wall_start;
     for (int i = 0; i < 16; ++i) a.stamps[i] = st_acc[i];

@@ -857,6 +857,7 @@ static int run_persistent(mmk_wavenet_plan* p, const WnCall& call, int64_t tau0,
       k.stamps = (stamp_env && stamp_env[0] == '1') ? reinterpret_cast<unsigned long long*>(p->tau + 8) : nullptr;
       k.stamp_stage = getenv("MMK_WN_STAMP_STAGE") ? atoi(getenv("MMK_WN_STAMP_STAGE")) : 1;
       k.stamp_owner = getenv("MMK_WN_STAMP_OWNER") ? atoi(getenv("MMK_WN_STAMP_OWNER")) : 1;
+      k.stamp_wave = getenv("MMK_WN_STAMP_WAVE") ? atoi(getenv("MMK_WN_STAMP_WAVE")) : 0;
       MMK_TRY(launch_wavenet_pipe(k, st));
       done += nb;
       continue;
@@ -1141,11 +1142,11 @@ extern "C" int mmk_wavenet_sync_status(mmk_wavenet_plan* p, mmk_stream_t stream)
       unsigned long long st[24];
       MMK_HIP(hipMemcpy(st, p->tau + 8, sizeof(st), hipMemcpyDeviceToHost));
       if (p->pipe) {
-        fprintf(stderr, "[mmk stamps] last pipelined launch, thread 0 of one workgroup (MMK_WN_STAMP_STAGE / _OWNER, default 1 / 1), totals in ms: visit start (own h + wait for the "
-                        "group's inputs)=%.3f; operands + MFMA=%.3f; wait B1=%.3f; epilogues + publish=%.3f; small operands + ring store=%.3f; "
+        fprintf(stderr, "[mmk stamps] last pipelined launch, lane 0 of one wave (MMK_WN_STAMP_STAGE / _OWNER / _WAVE, default 1 / 1 / 0), totals in ms: visit start (own h + wait for the "
+                        "group's inputs)=%.3f; request issue=%.3f; operands from LDS=%.3f; MFMA + partial sums=%.3f; wait B1=%.3f; epilogues + publish=%.3f; small operands + ring store=%.3f; "
                         "wait y/h=%.3f; head [publish hidden=%.3f, wait hidden=%.3f, fc2=%.3f, wait logits=%.3f, sampler=%.3f, rest=%.3f]; "
                         "whole launch=%.3f; shader clock=%.0f MHz\n",
-                st[7] * 1e-5, st[9] * 1e-5, st[0] * 1e-5, st[1] * 1e-5, st[2] * 1e-5, st[3] * 1e-5, st[10] * 1e-5, st[11] * 1e-5,
+                st[7] * 1e-5, st[4] * 1e-5, st[5] * 1e-5, st[9] * 1e-5, st[0] * 1e-5, st[1] * 1e-5, st[2] * 1e-5, st[3] * 1e-5, st[10] * 1e-5, st[11] * 1e-5,
                 st[12] * 1e-5, st[13] * 1e-5, st[8] * 1e-5, st[6] * 1e-5, st[15] * 1e-5,
                 st[15] ? 100.0 * (double)st[14] / (double)st[15] : 0.0);
         return MMK_OK;
