@@ -270,6 +270,9 @@ int mmk_srnn_warmup(mmk_srnn_plan* plan, int32_t batch, const int64_t* idx, int6
 int mmk_srnn_generate(mmk_srnn_plan* plan, int32_t batch, int64_t* idx, int64_t idx_row_stride, int64_t t0,
                       int64_t n_steps, const float* temperature, const float* uniforms, mmk_stream_t stream);
 int mmk_srnn_last_logits(mmk_srnn_plan* plan, int32_t batch, float* out, int64_t ld, mmk_stream_t stream);
+/* diagnostic: generate blocks this plan has run in resident mode (the bottom tier as one launch beside the tier kernels of a
+ * second stream) since it was created; tests assert that the mode they mean to cover is the one that ran */
+int64_t mmk_srnn_resident_blocks(const mmk_srnn_plan* plan);
 
 /* ------------------------------------------------------------------------
  * Seq2SeqLSTMNetwork (mimikit/networks/s2s_lstm_v2.py)

@@ -59,6 +59,7 @@ struct mmk_srnn_plan {
   hipStream_t side_stream = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   bool streams_overlap = false;                 // probed at commit: kernels of the two streams do run side by side
+  int64_t resident_blocks = 0;
   unsigned long long *up_gran = nullptr, *cls_gran = nullptr;   // [Bmax][up of the last tier][H], [Bmax][256]
   unsigned* probe = nullptr;
   // fused bottom tier (srnn_bottom.hip): chosen at create time when the geometry allows it
@@ -729,6 +730,7 @@ static int run_resident(mmk_srnn_plan* p, const SrnnCall& call, int64_t t_begin,
   MMK_TRY(enqueue_steps(p, tiers, t_begin, n, false, p->side_stream));
   MMK_HIP(hipEventRecord(p->ev_join, p->side_stream));
   MMK_HIP(hipStreamWaitEvent(st, p->ev_join, 0));
+  ++p->resident_blocks;
   return MMK_OK;
 }
 
@@ -778,6 +780,8 @@ extern "C" int mmk_srnn_generate(mmk_srnn_plan* p, int32_t batch, int64_t* idx, 
   call.uni_off = -t0;
   return run_steps(p, call, t0, n_steps, true, (hipStream_t)stream);
 }
+
+extern "C" int64_t mmk_srnn_resident_blocks(const mmk_srnn_plan* p) { return p ? p->resident_blocks : 0; }
 
 extern "C" int mmk_srnn_last_logits(mmk_srnn_plan* p, int32_t batch, float* out, int64_t ld, mmk_stream_t stream) {
   if (!p || !out) return fail(MMK_ERR_INVALID, "srnn_last_logits: null argument");

@@ -282,9 +282,20 @@ static int derive(mmk_wavenet_plan* p) {
   if (c.n_cond == 1) ok = ok && c.cond_dim[0] % 16 == 0;
   for (int l = 0; l < p->L; ++l) ok = ok && p->ksz[l] == 2;
   p->persistent = false;
+  // The persistent kernels need every workgroup of their grid resident at once (one per CU: their LDS carve does not leave room
+  // for a second), and the XCD-local / pipelined placements one stage or clip group per XCD of an 8-XCD device: ask the device
+  // (a partitioned or smaller GPU falls back to agent-scope hand-offs or to the launch path instead of timing out)
+  int n_cu = 256, n_xcc = 8;
+  {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) == hipSuccess) {
+      if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) n_cu = v;
+      if (hipDeviceGetAttribute(&v, hipDeviceAttributeNumberOfXccs, dev) == hipSuccess && v > 0) n_xcc = v;
+    }
+  }
   if (ok) {
     p->Gn = 2 * p->C / 16;
-    int gc_max = 256 / p->Gn;
+    int gc_max = n_cu / p->Gn;
     if (gc_max < 1) gc_max = 1;
     // clips per group: one MFMA row tile (16) at most, and one epilogue element per thread
     // (16 columns x Mg clips <= 64 * C/32 threads)
@@ -308,14 +319,14 @@ static int derive(mmk_wavenet_plan* p) {
     p->Gc = (p->Bmax + p->Mg - 1) / p->Mg;
     // XCD-local mode: always 8 groups (one per XCD, some possibly without clips), 8 * Gn workgroups
     const char* xenv = getenv("MMK_WN_XCD_LOCAL");
-    p->xcd_local = !(xenv && xenv[0] == '0') && 8 * p->Gn <= 256 && (p->Bmax + 7) / 8 <= mg_cap;
+    p->xcd_local = !(xenv && xenv[0] == '0') && n_xcc == 8 && 8 * p->Gn <= n_cu && (p->Bmax + 7) / 8 <= mg_cap;
     if (p->xcd_local) {
       p->Gc = 8;
       p->Mg = (p->Bmax + 7) / 8;
     }
     p->C1 = c.n_cond == 1 ? c.cond_dim[0] : 0;
     p->n_logits_pad = (int)round_up(c.out_dim + (c.learn_temp ? 1 : 0), 16);
-    if (p->Mg <= mg_cap) {
+    if (p->Mg <= mg_cap && p->Gc * p->Gn <= n_cu) {
       p->persistent = true;
       p->ring_offset.assign(p->L, 0);
       p->ring_mask.assign(p->L, 0);
@@ -368,7 +379,7 @@ static int derive(mmk_wavenet_plan* p) {
     const char* penv = getenv("MMK_WN_PIPE");
     const char* fenv = getenv("MMK_WN_PREFILL");
     const bool fits_l2 = (int64_t)p->L * 8 * p->C * p->C * 4 <= ((int64_t)3 << 20);
-    bool ok3 = (penv ? penv[0] != '0' : !fits_l2) && !(fenv && fenv[0] == '0') && 8 * p->Gn <= 256 && p->Bmax <= 32;
+    bool ok3 = (penv ? penv[0] != '0' : !fits_l2) && !(fenv && fenv[0] == '0') && n_xcc == 8 && 8 * p->Gn <= n_cu && p->Bmax <= 32;
     for (int l = 0; l + 1 < p->L; ++l) ok3 = ok3 && p->has_res[l];
     const int mg = (p->Bmax + 7) / 8, gc = (p->Bmax + mg - 1) / mg;
     ok3 = ok3 && wn_pipe_supported(p->C, mg, gc, p->L) && c.mlp_hidden <= p->C;   // (the skip-row owners take the H1 / 16 hidden-unit tiles)
@@ -1135,7 +1146,9 @@ extern "C" int mmk_wavenet_sync_status(mmk_wavenet_plan* p, mmk_stream_t stream)
   MMK_HIP(hipMemcpy(&flag, p->err_flag, sizeof(flag), hipMemcpyDeviceToHost));
   if (flag == 2)
     return fail(MMK_ERR_STATE, "wavenet: the persistent kernel's workgroups were not spread 8 x %d over the XCDs; rerun with MMK_WN_XCD_LOCAL=0 (agent-scope hand-offs)", p->Gn);
-  if (flag != 0) return fail(MMK_ERR_STATE, "wavenet: a hand-off inside the persistent kernel timed out (not all workgroups resident?)");
+  if (flag != 0)
+    return fail(MMK_ERR_STATE, "wavenet: a hand-off inside the persistent kernel timed out - its workgroups were not all resident (another kernel "
+                "holding CUs?); the samples of this call are invalid, rerun it (MMK_WN_PERSISTENT=0 selects the per-layer launch path)");
   {
     const char* senv = getenv("MMK_WN_STAMPS");
     if (senv && senv[0] == '1') {

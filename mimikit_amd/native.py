@@ -93,6 +93,7 @@ _SIGNATURES = {
     "mmk_srnn_warmup": (i32, [vp, i32, vp, i64, i64, vp]),
     "mmk_srnn_generate": (i32, [vp, i32, vp, i64, i64, i64, vp, vp, vp]),
     "mmk_srnn_last_logits": (i32, [vp, i32, vp, i64, vp]),
+    "mmk_srnn_resident_blocks": (i64, [vp]),
     "mmk_s2s_plan_create": (i32, [C.POINTER(S2SConfig), C.POINTER(vp)]),
     "mmk_s2s_plan_destroy": (None, [vp]),
     "mmk_s2s_plan_bind": (i32, [vp, cp, vp, i64]),
@@ -512,6 +513,10 @@ class SrnnPlan(_Plan):
         check(self._lib.mmk_srnn_generate(self.handle, idx.shape[0], abs_ptr(idx, t_first), idx.stride(0), t0, n_steps,
                                           ptr(temperature), ptr(uniforms), stream_ptr(self.device)),
               "mmk_srnn_generate")
+
+    def resident_blocks(self) -> int:
+        """generate blocks run in resident mode so far (diagnostic, see include/mmk.h)"""
+        return int(self._lib.mmk_srnn_resident_blocks(self.handle))
 
     def last_logits(self, batch: int) -> torch.Tensor:
         n = self.cfg.q_levels + (1 if self.cfg.learn_temp else 0)

@@ -284,6 +284,64 @@ def test_sample_rnn_grid_barrier_is_deterministic(device, monkeypatch):
         assert torch.equal(o, outs[0])
 
 
+@pytest.mark.parametrize("kind", ["gru", "lstm"])
+def test_sample_rnn_resident_mode_blocks_and_oracle(device, monkeypatch, kind):
+    """resident mode (the bottom tier as one launch per block beside the tier kernels of a second stream): blocks that start
+    between two updates of the tier above, a block too short for the mode in the middle, the same generation in one block and
+    with the mode switched off - all identical, and equal to the oracle teacher-forced on the device's history"""
+    monkeypatch.setenv("MMK_SRNN_FUSED", "1")
+    gen = torch.Generator().manual_seed(31)
+    B, P = 21, 48                                   # a ragged last row tile
+    prompt = torch.randint(0, 256, (B, P), generator=gen)
+    splits = [(37, 5, 43, 16, 59), (160,)]          # 37 % 4 = 1: the next blocks start mid-frame; 5 < frame_sizes[0]: launch path
+    outs, resident = [], []
+    for env, parts in (("1", splits[0]), ("1", splits[1]), ("0", splits[1])):
+        monkeypatch.setenv("MMK_SRNN_RESIDENT", env)
+        net, sd, arch = H.srnn("big", hidden=256, mlp_dim=128, seed=83, frame_sizes=(16, 4, 1), kind=kind)
+        net = net.to(device)
+        idx = torch.cat([prompt, torch.zeros(B, 160, dtype=torch.int64)], 1).to(device)
+        net.before_generate((idx[:, :P],), None)
+        t = P
+        for n in parts:
+            net.generate_block((idx,), t, n)
+            t += n
+        resident.append(net._plan.resident_blocks())
+        net.after_generate((idx,), None)
+        outs.append(idx.cpu())
+    assert resident[0] == 4 and resident[1] == 1 and resident[2] == 0, resident
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[1], outs[2])
+    o = O.SampleRNNOracle(sd, **arch)
+    ref, _ = o.generate(prompt, 160, keep_logits=True, forced=outs[0])
+    assert torch.equal(ref[:, P:], outs[0][:, P:])
+
+
+def test_sample_rnn_resident_mode_sampled_decode_and_reuse(device, monkeypatch):
+    """resident mode with temperatures (uniforms indexed by the absolute step) and a second generation on the same plan
+    (the granules of the first one must not satisfy the second one's waits)"""
+    monkeypatch.setenv("MMK_SRNN_FUSED", "1")
+    net, sd, arch = H.srnn("big", hidden=128, mlp_dim=128, seed=84, frame_sizes=(16, 4, 1), kind="gru")
+    net = net.to(device)
+    o = O.SampleRNNOracle(sd, **arch)
+    B, P, n = 7, 32, 96
+    temp = torch.tensor([0.6, 1.0, 1.4, 0.8, 1.1, 0.9, 1.2])
+    for round_ in range(2):
+        gen = torch.Generator().manual_seed(40 + round_)
+        prompt = torch.randint(0, 256, (B, P), generator=gen)
+        torch.manual_seed(50 + round_)
+        u = torch.rand((B, n), device=device)
+        torch.manual_seed(50 + round_)
+        idx = torch.cat([prompt, torch.zeros(B, n, dtype=torch.int64)], 1).to(device)
+        net.before_generate((idx[:, :P],), None)
+        net.generate_block((idx,), P, n, temperature=temp)
+        net.after_generate((idx,), None)
+        assert net._plan.resident_blocks() == round_ + 1
+        got = idx.cpu()
+        _, raw = o.generate(prompt, n, keep_logits=True, forced=got)
+        ok, exact = H.sampled_picks_ok(raw, temp, u.cpu(), got[:, P:])
+        assert ok.all()
+        assert float(exact.float().mean()) > 0.97
+
+
 def test_sample_rnn_fused_bottom_sampled_decode(device, monkeypatch):
     """temperature sampling through the fused bottom kernel against the oracle's inverse-CDF draw for the same uniforms"""
     monkeypatch.setenv("MMK_SRNN_FUSED", "1")
