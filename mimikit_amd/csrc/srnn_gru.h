@@ -11,6 +11,7 @@ struct SrnnGruArgs {
   const int64_t* tau_ptr; int64_t tau_off;  // t = *tau_ptr + tau_off
   const int64_t* idx; int64_t idx_rs; int64_t shift;   // window idx[:, t + shift - fs : t + shift]
   const float* win_wp; const float* win_bias;   // input Linear (H x fs), packed (linear.hip), bias in row order
+  const float* v_comp;                      // (G H, 16) pre-multiplied W_ih W_in, zero padded columns (fs <= 16), or nullptr
   const float* upper;                       // (B, up_mod, H) output of the tier above, or nullptr
   const float* wih_wp; const float* wih_bias; const float* whh_wp; const float* whh_bias;   // packed (linear.hip)
   int32_t w_tile_chunks;                    // K-chunks per packed tile (H/16 for separate matrices, 2 H/16 for [x | h])

@@ -58,7 +58,8 @@ __global__ __launch_bounds__(kGruThreads) void srnn_gru_kernel(const SrnnGruArgs
   float* xs = (float*)sp;    sp += 16 * ldx * 4;                  // x rows of the 16 clips
   float* hs = (float*)sp;    sp += 16 * ldx * 4;                  // h rows (old state)
   f32x4* red = (f32x4*)sp;   sp += 2 * NG * kGruWaves * 64 * 16;  // split-K partials: [tile][wave][lane]
-  float* s_lin = (float*)sp;                                      // linearized window [16][fs]
+  float* s_lin = (float*)sp;  sp += 16 * ((((a.fs + 15) / 16) * 16) + 4) * 4;   // linearized window [16][fs]
+  float* vs = (float*)sp;                                         // composed mode: (W_ih W_in) rows of this workgroup's units [NG][16][16]
 
   // ---- weights first: 2 NG tiles x CPW chunks of this wave (nothing depends on them for a while) -----------------
   f32x4 w[2 * NG][CPW];
@@ -115,6 +116,11 @@ __global__ __launch_bounds__(kGruThreads) void srnn_gru_kernel(const SrnnGruArgs
   float x_up[XT][4], x_bias[XT];
   f32x4 x_w[XT];
   const bool x_hoisted = kci == 1;
+  // Composed mode (frame sizes <= 16): W_ih x = W_ih (b_in + upper) + (W_ih W_in) lin(window).  The first product does not depend
+  // on the newest classes and is multiplied ahead of the hand-over with the recurrent half; the second is a K = fs dot product
+  // per (clip, gate unit) against the pre-multiplied matrix (srnn_plan.hip: compose, fp64 accumulation, one rounding), done in the
+  // cell.  Same operands as the reference in another association.
+  const bool composed = a.v_comp != nullptr && x_hoisted;
   if (x_hoisted) {
     const int q = lane >> 4, n = lane & 15;
 #pragma unroll
@@ -127,7 +133,7 @@ __global__ __launch_bounds__(kGruThreads) void srnn_gru_kernel(const SrnnGruArgs
         x_up[j][r] = *src;
       }
       x_bias[j] = a.win_bias[col];
-      x_w[j] = ((gf32x4_ptr)(uintptr_t)a.win_wp)[(int64_t)tile * 64 + lane];
+      if (!composed) x_w[j] = ((gf32x4_ptr)(uintptr_t)a.win_wp)[(int64_t)tile * 64 + lane];
     }
   }
   // ---- old state rows -> LDS --------------------------------------------------------------------------------
@@ -136,6 +142,22 @@ __global__ __launch_bounds__(kGruThreads) void srnn_gru_kernel(const SrnnGruArgs
     f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
     if (m < mg) v = *reinterpret_cast<const f32x4*>(h_old + (int64_t)(m_first + m) * H + c);
     *reinterpret_cast<f32x4*>(hs + m * ldx + c) = v;
+  }
+  if (composed) {
+    const int q = lane >> 4, n = lane & 15;
+#pragma unroll
+    for (int j = 0; j < XT; ++j) {
+      const int col = (wave + j * kGruWaves) * 16 + n;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = 4 * q + r;
+        xs[m * ldx + col] = m < mg ? (a.upper ? x_bias[j] + x_up[j][r] : x_bias[j]) : 0.f;     // b_in + upper
+      }
+    }
+    if (tid < NG * 16 * 4) {                                   // this workgroup's rows of W_ih W_in: [gate][unit][16], zero padded
+      const int g = tid / 64, n = (tid >> 2) & 15, c4 = (tid & 3) * 4;
+      *reinterpret_cast<f32x4*>(vs + (g * 16 + n) * 16 + c4) = *reinterpret_cast<const f32x4*>(a.v_comp + ((int64_t)g * H + ub * 16 + n) * 16 + c4);
+    }
   }
   __syncthreads();
   // ---- the recurrent half of the products, W_hh h: it does not depend on the newest classes either ------------------
@@ -156,6 +178,25 @@ __global__ __launch_bounds__(kGruThreads) void srnn_gru_kernel(const SrnnGruArgs
       }
     }
   }
+  // ---- the input half, W_ih x (composed mode: W_ih (b_in + upper)): NG 16 x 16 tiles, this wave's K range, then all partial sums
+  auto input_half = [&]() {
+    const int c0 = wave * CPW;
+    const float* xr = xs + (lane & 15) * ldx + c0 * 16 + 4 * (lane >> 4);
+    f32x4 xv[CPW];
+#pragma unroll
+    for (int u = 0; u < CPW; ++u) xv[u] = *reinterpret_cast<const f32x4*>(xr + u * 16);
+#pragma unroll
+    for (int u = 0; u < CPW; ++u) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int g = 0; g < NG; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[u][i], w[g][u][i], acc[g], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int g = 0; g < 2 * NG; ++g) red[(g * kGruWaves + wave) * 64 + lane] = acc[g];
+  };
+  if (composed) input_half();
   const bool gated = a.gate_cls != nullptr;
   stamp(0);   // weights requested, old state in LDS, recurrent half multiplied
   // ---- the window, linearized (modules/io.py:106-112), zero padded to whole K-chunks ----------------------------
@@ -190,7 +231,9 @@ __global__ __launch_bounds__(kGruThreads) void srnn_gru_kernel(const SrnnGruArgs
   __syncthreads();
   stamp(4);   // window (resident mode: incl. the wait for the bottom kernel)
   // ---- x = W_in lin + b_in (+ upper): 16 x 16 tiles over the waves, K = fs (same MFMA order as the launch path) ----
-  if (x_hoisted) {
+  if (composed) {
+    // nothing: x never exists in this mode
+  } else if (x_hoisted) {
     const int q = lane >> 4, n = lane & 15;
     const f32x4 xv = *reinterpret_cast<const f32x4*>(s_lin + n * ldl + 4 * q);
 #pragma unroll
@@ -236,27 +279,12 @@ __global__ __launch_bounds__(kGruThreads) void srnn_gru_kernel(const SrnnGruArgs
       }
     }
   }
-  __syncthreads();
+  if (!composed) __syncthreads();
   stamp(1);   // x
-  // ---- the input half, W_ih x: NG 16 x 16 tiles, this wave's K range ----------------------------------------------
-  {
-    const int c0 = wave * CPW;
-    const float* xr = xs + (lane & 15) * ldx + c0 * 16 + 4 * (lane >> 4);
-    f32x4 xv[CPW];
-#pragma unroll
-    for (int u = 0; u < CPW; ++u) xv[u] = *reinterpret_cast<const f32x4*>(xr + u * 16);
-#pragma unroll
-    for (int u = 0; u < CPW; ++u) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-#pragma unroll
-        for (int g = 0; g < NG; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[u][i], w[g][u][i], acc[g], 0, 0, 0);
-      }
-    }
-#pragma unroll
-    for (int g = 0; g < 2 * NG; ++g) red[(g * kGruWaves + wave) * 64 + lane] = acc[g];
+  if (!composed) {
+    input_half();
+    __syncthreads();
   }
-  __syncthreads();
   stamp(2);   // MFMAs (incl. the wait for the weights)
   // the new state: plain stores for the next update; when the up-sampler phase of this launch reads it from other XCDs it
   // also goes out as data-tagged granules {update number, value} (agent-scope stores, polled by the readers: one hop, where
@@ -279,6 +307,16 @@ __global__ __launch_bounds__(kGruThreads) void srnn_gru_kernel(const SrnnGruArgs
 #pragma unroll
       for (int wv = 0; wv < kGruWaves; ++wv) v += f[wv * 256];
       s[g] = v;
+    }
+    if (composed) {                                            // + (W_ih W_in) lin(window): K = fs <= 16
+      const f32x4* l4 = reinterpret_cast<const f32x4*>(s_lin + m * ldl);
+      const f32x4 l0 = l4[0], l1 = l4[1], l2 = l4[2], l3 = l4[3];
+#pragma unroll
+      for (int g = 0; g < NG; ++g) {
+        const f32x4* v4 = reinterpret_cast<const f32x4*>(vs + (g * 16 + n) * 16);
+        const f32x4 p = l0 * v4[0] + l1 * v4[1] + l2 * v4[2] + l3 * v4[3];
+        s[g] += (p[0] + p[1]) + (p[2] + p[3]);
+      }
     }
     if (m < mg) {
       const int unit = ub * 16 + n;
@@ -442,7 +480,7 @@ __global__ __launch_bounds__(kGruThreads) void srnn_gru_kernel(const SrnnGruArgs
 }
 
 size_t srnn_gru_lds_bytes(int H, int fs, bool lstm) {
-  return (size_t)2 * 16 * (H + 4) * 4 + (size_t)(lstm ? 8 : 6) * kGruWaves * 64 * 16 + (size_t)16 * (((fs + 15) / 16) * 16 + 4) * 4;
+  return (size_t)2 * 16 * (H + 4) * 4 + (size_t)(lstm ? 8 : 6) * kGruWaves * 64 * 16 + (size_t)16 * (((fs + 15) / 16) * 16 + 4) * 4 + (size_t)4 * 16 * 16 * 4;
 }
 
 // the fused up-sampler phase waits for every workgroup of the grid: they must all be resident (one 512-thread workgroup

@@ -39,6 +39,7 @@ struct SrnnTier {
   int64_t* cnt = nullptr;                             // update counter (slot of the current state = cnt & 1)
   unsigned* done = nullptr;
   unsigned long long* h_gran = nullptr;               // [Bmax][H]: the new state as granules (fused up-sampler phase)
+  float* v_comp = nullptr;                            // [G H][16]: W_ih W_in, zero padded (frame sizes <= 16; srnn_gru.hip composed mode)
 };
 
 struct mmk_srnn_plan {
@@ -82,6 +83,7 @@ struct mmk_srnn_plan {
       t.cnt = c.take<int64_t>(4);
       t.done = c.take<unsigned>(4);
       t.h_gran = c.take<unsigned long long>((int64_t)Bmax * H);
+      t.v_comp = c.take<float>((int64_t)G * H * 16);
       t.out = c.take<float>((int64_t)Bmax * t.up * H);
       for (auto& d : t.deep) {
         d.gates.carve(c, bias);
@@ -214,6 +216,17 @@ extern "C" size_t mmk_srnn_workspace_bytes(const mmk_srnn_plan* p) {
   return c.used();
 }
 
+// V[r][i] = sum_k W_ih[r][k] W_in[k][i]  (i < fs; the other columns zero): fp64 accumulation, rounded once
+__global__ void srnn_compose_kernel(const float* __restrict__ wih, const float* __restrict__ win, int rows, int H, int fs, float* __restrict__ V) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= (int64_t)rows * 16) return;
+  const int r = (int)(e >> 4), i = (int)(e & 15);
+  double acc = 0.0;
+  if (i < fs)
+    for (int k = 0; k < H; ++k) acc += (double)wih[(int64_t)r * H + k] * (double)win[(int64_t)k * fs + i];
+  V[e] = (float)acc;
+}
+
 // ---- resident mode helpers ---------------------------------------------------------------------------------------------
 // Start of a resident block at step t_begin: the class ring holds the 256 positions before it, the row granules are cleared
 // (a granule of an earlier generation could carry the epoch this one waits for) - or, when the block starts between two
@@ -321,6 +334,10 @@ extern "C" int mmk_srnn_commit(mmk_srnn_plan* p, void* workspace, size_t workspa
     if (bb) MMK_HIP(hipMemcpyAsync(t.bin_raw, bb, (size_t)H * sizeof(float), hipMemcpyDeviceToDevice, st));
     const float* wih = b.need(tb + "rnn.weight_ih_l0", (int64_t)G * H * H);
     const float* whh = b.need(tb + "rnn.weight_hh_l0", (int64_t)G * H * H);
+    if (wih && w && t.fs <= 16 && p->fused_gru) {
+      hipLaunchKernelGGL(srnn_compose_kernel, dim3((unsigned)(((int64_t)G * H * 16 + 255) / 256)), dim3(256), 0, st, wih, w, G * H, H, t.fs, t.v_comp);
+      MMK_HIP(hipGetLastError());
+    }
     const float* bih = bias ? b.need(tb + "rnn.bias_ih_l0", (int64_t)G * H) : nullptr;
     const float* bhh = bias ? b.need(tb + "rnn.bias_hh_l0", (int64_t)G * H) : nullptr;
     if (c.rnn_kind == 1) {
@@ -427,6 +444,10 @@ static int emit_step(mmk_srnn_plan* p, const SrnnCall& call, int64_t tau_off, in
       g.tau_ptr = p->tau; g.tau_off = tau_off;
       g.idx = call.idx; g.idx_rs = call.idx_rs; g.shift = call.shift;
       g.win_wp = t.in_lin.Wp; g.win_bias = t.in_lin.bias;
+      {
+        const char* cenv = getenv("MMK_SRNN_COMPOSED");
+        g.v_comp = (t.fs <= 16 && !(cenv && cenv[0] == '0')) ? t.v_comp : nullptr;
+      }
       if (i > 0) {   // outputs[i-1][:, (t // fs[i]) % (fs[i-1] // fs[i])]      (:251)
         g.upper = p->tiers[i - 1].out;
         g.up_mod = p->tiers[i - 1].up;
