@@ -315,6 +315,35 @@ def test_sample_rnn_resident_mode_blocks_and_oracle(device, monkeypatch, kind):
     assert torch.equal(ref[:, P:], outs[0][:, P:])
 
 
+@pytest.mark.parametrize("frame_sizes,batch,hidden,kind", [
+    ((4, 1), 3, 128, "gru"),            # one recurrent tier above the bottom
+    ((32, 8, 2), 33, 128, "gru"),       # a bottom frame of 2 samples, a ragged third row tile
+    ((64, 16, 4, 4), 5, 128, "lstm"),   # three recurrent tiers, frame sizes above 16 (the tier kernel's uncomposed path) and equal ones
+    ((16, 4, 1), 16, 256, "lstm"),
+])
+def test_sample_rnn_resident_mode_geometries(device, monkeypatch, frame_sizes, batch, hidden, kind):
+    """resident mode over the tier geometries the fused kernels accept: classes equal to the oracle's, teacher-forced on the
+    device's own history; the mode itself must have run"""
+    monkeypatch.setenv("MMK_SRNN_FUSED", "1")
+    net, sd, arch = H.srnn("big", hidden=hidden, mlp_dim=64, seed=91, frame_sizes=frame_sizes, kind=kind)
+    net = net.to(device)
+    rf = frame_sizes[0]
+    P, n = 2 * rf + 3, 3 * rf + 5                     # a prompt that is not a multiple of rf (the warm-up window shift)
+    gen = torch.Generator().manual_seed(17)
+    prompt = torch.randint(0, 256, (batch, P), generator=gen)
+    idx = torch.cat([prompt, torch.zeros(batch, n, dtype=torch.int64)], 1).to(device)
+    net.before_generate((idx[:, :P],), None)
+    net.generate_block((idx,), P, n)
+    assert net._plan.resident_blocks() == 1
+    net.after_generate((idx,), None)
+    got = idx.cpu()
+    o = O.SampleRNNOracle(sd, **arch)
+    ref, raw = o.generate(prompt, n, keep_logits=True, forced=got)
+    ok = H.margin_ok(raw)
+    assert float(ok.float().mean()) > 0.9
+    assert torch.equal(ref[:, P:][ok], got[:, P:][ok])
+
+
 def test_sample_rnn_resident_mode_sampled_decode_and_reuse(device, monkeypatch):
     """resident mode with temperatures (uniforms indexed by the absolute step) and a second generation on the same plan
     (the granules of the first one must not satisfy the second one's waits)"""
