@@ -15,6 +15,7 @@ struct SrnnBottomArgs {
   const float* upper;                       // (B, up_slots, H) output of the tier above
   const float* fc0_wp; const float* fc0_bias; const float* fc2_wp; const float* fc2_bias;   // packed (linear.hip)
   const float* fc0_raw; const float* fc2_raw;   // the same matrices row-major, (Hm, H) and (n_out, Hm), as bound (may be null)
+  const float* a_comp; const float* b_comp; // composed mode of the one-clip kernel: (fs, Hm) = W0 wb_i and (Hm) = W0 bb + b0, or null
   const float* temperature; const float* uniforms; int64_t uni_ld, uni_off;
   float* logits_out; int64_t logits_ld;     // logits of the launch's last step
   unsigned long long* stamps;               // diagnostic: phase totals (100 MHz ticks) + launch count, or nullptr

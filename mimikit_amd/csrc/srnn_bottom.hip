@@ -336,7 +336,7 @@ __global__ __launch_bounds__(kBotThreads) void srnn_bottom_kernel(const SrnnBott
 // fp32 arithmetic in a different association (pinned by the same goldens / oracle tests).
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-template <int NF>   // NF = H / 16
+template <int NF, bool COMPOSED>   // NF = H / 16; COMPOSED: the pre-multiplied association (a.a_comp / a.b_comp), see the step loop
 __global__ __launch_bounds__(kBotThreads) void srnn_bottom1_kernel(const SrnnBottomArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   constexpr int H = NF * 16;
@@ -407,6 +407,10 @@ __global__ __launch_bounds__(kBotThreads) void srnn_bottom1_kernel(const SrnnBot
   // (j < 4), ks == j for fc2 (j < 8)
   const float fc0_b = (ks < 4 && cg * 4 + ks < Hm) ? a.fc0_bias[cg * 4 + ks] : 0.f;
   const float fc2_b = (ks < 8 && cg * 8 + ks < n_out) ? a.fc2_bias[cg * 8 + ks] : 0.f;
+  // composed mode (srnn_plan.hip: W0 wb_i and W0 bb + b0 pre-multiplied at commit): this lane's unit
+  constexpr bool composed = COMPOSED;
+  const float a_c0 = (composed && ks < 4 && cg * 4 + ks < Hm) ? a.a_comp[cg * 4 + ks] : 0.f;
+  const float b_c = (composed && ks < 4 && cg * 4 + ks < Hm) ? a.b_comp[cg * 4 + ks] : 0.f;
   const int n_extra = n_out > 256 ? n_out - 256 : 0;
   for (int i = tid; i < n_extra * Hm; i += kBotThreads) wx[i] = a.fc2_raw[(int64_t)256 * Hm + i];
   for (int i = tid; i < 16 * kPad2; i += kBotThreads) hid[i] = 0.f;
@@ -438,6 +442,153 @@ __global__ __launch_bounds__(kBotThreads) void srnn_bottom1_kernel(const SrnnBot
   __syncthreads();
   stamp(0);
 
+  // W0 . xs for this lane's K slice of its four hidden units, slices summed across the DPP row (no bias, no activation)
+  auto fc0_product = [&]() -> float {
+    const f32x4* x4 = reinterpret_cast<const f32x4*>(xs + ks * kPad0);
+    f32x4 acc[4];
+    {
+      const f32x4 xv = x4[0];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[j] = xv * w0[j][0];
+    }
+#pragma unroll
+    for (int f = 1; f < F0; ++f) {           // one input fragment at a time, four independent accumulation chains
+      const f32x4 xv = x4[f];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[j] += xv * w0[j][f];
+    }
+    float tot[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) tot[j] = row_sum((acc[j][0] + acc[j][1]) + (acc[j][2] + acc[j][3]));
+    return ks == 0 ? tot[0] : (ks == 1 ? tot[1] : (ks == 2 ? tot[2] : tot[3]));   // lane ks < 4 of a row: the total of unit cg * 4 + ks
+  };
+  auto fc2_phase = [&]() {
+    const f32x4* h4 = reinterpret_cast<const f32x4*>(hid + ks * kPad2);
+    const f32x4 h0 = h4[0], h1 = h4[1];
+    float mine = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      f32x4 acc = h0 * w2[j][0];
+      acc += h1 * w2[j][1];
+      const float tj = row_sum((acc[0] + acc[1]) + (acc[2] + acc[3]));
+      mine = ks == j ? tj : mine;
+    }
+    const int c = cg * 8 + ks;
+    if (ks < 8 && c < n_out) lbuf[c] = mine + fc2_b;
+    for (int r = wave; r < n_extra; r += kBotThreads / 64) {      // rows past 256: one wave each, lanes over k
+      float p = 0.f;
+      for (int k = lane; k < Hm; k += 64) p = fmaf(hid[(k / KS2) * kPad2 + k % KS2], wx[r * Hm + k], p);
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) p += __shfl_xor(p, o);
+      if (lane == 0) lbuf[256 + r] = p + a.fc2_bias[256 + r];
+    }
+  };
+  // temperature column + argmax / inverse-CDF sample: wave 0
+  auto sampler_phase = [&](int s, int64_t t) {
+  if (wave == 0) {
+    const float* lg = lbuf;
+    const int nc = a.Q;
+    const int per = (nc + 63) / 64;
+    if (a.logits_out && s + 1 == a.n_steps)
+      for (int c = lane; c < n_out; c += 64) a.logits_out[(int64_t)clip * a.logits_ld + c] = lg[c];
+    float denom = 1.f;
+    if (a.learn_temp) denom = fmaxf(sigmoidf_(lg[nc]), a.min_temp);   // mlp.py:60-62
+    int result;
+    if (a.temperature == nullptr) {
+      float best = -INFINITY;
+      int bi = 0x7fffffff;
+      if (nc == 256) {
+        const f32x4 v4 = *reinterpret_cast<const f32x4*>(lg + lane * 4);
+        float vv[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) vv[q] = a.learn_temp ? v4[q] / denom : v4[q];
+        best = vv[0]; bi = lane * 4;
+#pragma unroll
+        for (int q = 1; q < 4; ++q)
+          if (vv[q] > best) { best = vv[q]; bi = lane * 4 + q; }
+      } else {
+        for (int q = 0; q < per; ++q) {
+          const int c = lane * per + q;
+          if (c < nc) {
+            const float v = a.learn_temp ? lg[c] / denom : lg[c];
+            if (v > best || bi == 0x7fffffff) { best = v; bi = c; }
+          }
+        }
+      }
+      auto take = [&](float ob, int oi) {     // first maximum wins (torch.argmax)
+        if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+      };
+#define MMK_DPP_STEP(CTRL)                                                                                         \
+      take(__int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(best), CTRL, 0xf, 0xf, false)),            \
+           __builtin_amdgcn_update_dpp(0, bi, CTRL, 0xf, 0xf, false))
+      MMK_DPP_STEP(0xB1);
+      MMK_DPP_STEP(0x4E);
+      MMK_DPP_STEP(0x141);
+      MMK_DPP_STEP(0x140);
+#undef MMK_DPP_STEP
+#pragma unroll
+      for (int o = 16; o <= 32; o <<= 1) {
+        const float ob = __shfl_xor(best, o);
+        const int oi = __shfl_xor(bi, o);
+        take(ob, oi);
+      }
+      result = bi;
+    } else {
+      const float T = a.temperature[clip];
+      float mx = -INFINITY;
+      for (int q = 0; q < per; ++q) {
+        const int c = lane * per + q;
+        if (c < nc) mx = fmaxf(mx, (a.learn_temp ? lg[c] / denom : lg[c]) / T);
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+      float local = 0.f;
+      for (int q = 0; q < per; ++q) {
+        const int c = lane * per + q;
+        if (c < nc) local += expf((a.learn_temp ? lg[c] / denom : lg[c]) / T - mx);
+      }
+      float incl = local;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const float up = __shfl_up(incl, o);
+        if (lane >= o) incl += up;
+      }
+      const float total = __shfl(incl, 63);
+      const float target = a.uniforms[(int64_t)clip * a.uni_ld + t + a.uni_off] * total;
+      float run = incl - local;
+      int pick = 0x7fffffff, last_c = -1;
+      for (int q = 0; q < per; ++q) {
+        const int c = lane * per + q;
+        if (c < nc) {
+          const float e = expf((a.learn_temp ? lg[c] / denom : lg[c]) / T - mx);
+          run += e;
+          if (e > 0.f) last_c = c;
+          if (pick == 0x7fffffff && run > target && e > 0.f) pick = c;
+        }
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        const int op = __shfl_xor(pick, o), ol = __shfl_xor(last_c, o);
+        pick = op < pick ? op : pick;
+        last_c = ol > last_c ? ol : last_c;
+      }
+      result = pick != 0x7fffffff ? pick : (last_c < 0 ? 0 : last_c);
+    }
+    if (lane < a.fs) {
+      const int keep = lane + 1 < a.fs ? s_win[lane + 1] : result;
+      s_win[lane] = keep;     // wave-synchronous shift: every lane read before any lane writes
+    }
+    if (lane == 0) {
+      a.idx[(int64_t)clip * a.idx_rs + t] = result;
+      if (a.resident)    // for the tier kernels running beside this launch
+        __hip_atomic_store(a.cls_gran + (int64_t)clip * 256 + (t & 255), ((u64)(unsigned)(t + 1) << 32) | (unsigned)result, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+  };
+  const int hid_u = cg * 4 + ks;                              // the hidden unit lane ks < 4 of a row finishes
+  const int hid_at = (hid_u / KS2) * kPad2 + hid_u % KS2;
+  if constexpr (!composed) {
   for (int s = 0; s < a.n_steps; ++s) {
     const int64_t t = t0 + s;
     if (a.resident && tid < H) {
@@ -472,155 +623,82 @@ __global__ __launch_bounds__(kBotThreads) void srnn_bottom1_kernel(const SrnnBot
     stamp(1);
     // ---- fc0 + Mish ---------------------------------------------------------------------------------------------
     {
-      const f32x4* x4 = reinterpret_cast<const f32x4*>(xs + ks * kPad0);
-      f32x4 acc[4];
-      {
-        const f32x4 xv = x4[0];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[j] = xv * w0[j][0];
-      }
-#pragma unroll
-      for (int f = 1; f < F0; ++f) {           // one input fragment at a time, four independent accumulation chains
-        const f32x4 xv = x4[f];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[j] += xv * w0[j][f];
-      }
-      float tot[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) tot[j] = row_sum((acc[j][0] + acc[j][1]) + (acc[j][2] + acc[j][3]));
-      const float mine = ks == 0 ? tot[0] : (ks == 1 ? tot[1] : (ks == 2 ? tot[2] : tot[3]));
-      const int u = cg * 4 + ks;
-      if (ks < 4 && u < Hm) hid[(u / KS2) * kPad2 + u % KS2] = mish_fast(mine + fc0_b);   // one Mish per lane, four lanes per row
+      const float mine = fc0_product();
+      if (ks < 4 && hid_u < Hm) hid[hid_at] = mish_fast(mine + fc0_b);   // one Mish per lane, four lanes per row
     }
     __syncthreads();
     stamp(2);
     // ---- fc2 ---------------------------------------------------------------------------------------------------------
-    {
-      const f32x4* h4 = reinterpret_cast<const f32x4*>(hid + ks * kPad2);
-      const f32x4 h0 = h4[0], h1 = h4[1];
-      float mine = 0.f;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        f32x4 acc = h0 * w2[j][0];
-        acc += h1 * w2[j][1];
-        const float tj = row_sum((acc[0] + acc[1]) + (acc[2] + acc[3]));
-        mine = ks == j ? tj : mine;
-      }
-      const int c = cg * 8 + ks;
-      if (ks < 8 && c < n_out) lbuf[c] = mine + fc2_b;
-      for (int r = wave; r < n_extra; r += kBotThreads / 64) {      // rows past 256: one wave each, lanes over k
-        float p = 0.f;
-        for (int k = lane; k < Hm; k += 64) p = fmaf(hid[(k / KS2) * kPad2 + k % KS2], wx[r * Hm + k], p);
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) p += __shfl_xor(p, o);
-        if (lane == 0) lbuf[256 + r] = p + a.fc2_bias[256 + r];
-      }
-    }
+    fc2_phase();
     __syncthreads();
     stamp(3);
-    // ---- temperature column + argmax / inverse-CDF sample: wave 0 -----------------------------------------------
-    if (wave == 0) {
-      const float* lg = lbuf;
-      const int nc = a.Q;
-      const int per = (nc + 63) / 64;
-      if (a.logits_out && s + 1 == a.n_steps)
-        for (int c = lane; c < n_out; c += 64) a.logits_out[(int64_t)clip * a.logits_ld + c] = lg[c];
-      float denom = 1.f;
-      if (a.learn_temp) denom = fmaxf(sigmoidf_(lg[nc]), a.min_temp);   // mlp.py:60-62
-      int result;
-      if (a.temperature == nullptr) {
-        float best = -INFINITY;
-        int bi = 0x7fffffff;
-        if (nc == 256) {
-          const f32x4 v4 = *reinterpret_cast<const f32x4*>(lg + lane * 4);
-          float vv[4];
-#pragma unroll
-          for (int q = 0; q < 4; ++q) vv[q] = a.learn_temp ? v4[q] / denom : v4[q];
-          best = vv[0]; bi = lane * 4;
-#pragma unroll
-          for (int q = 1; q < 4; ++q)
-            if (vv[q] > best) { best = vv[q]; bi = lane * 4 + q; }
-        } else {
-          for (int q = 0; q < per; ++q) {
-            const int c = lane * per + q;
-            if (c < nc) {
-              const float v = a.learn_temp ? lg[c] / denom : lg[c];
-              if (v > best || bi == 0x7fffffff) { best = v; bi = c; }
-            }
-          }
-        }
-        auto take = [&](float ob, int oi) {     // first maximum wins (torch.argmax)
-          if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
-        };
-#define MMK_DPP_STEP(CTRL)                                                                                         \
-        take(__int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(best), CTRL, 0xf, 0xf, false)),            \
-             __builtin_amdgcn_update_dpp(0, bi, CTRL, 0xf, 0xf, false))
-        MMK_DPP_STEP(0xB1);
-        MMK_DPP_STEP(0x4E);
-        MMK_DPP_STEP(0x141);
-        MMK_DPP_STEP(0x140);
-#undef MMK_DPP_STEP
-#pragma unroll
-        for (int o = 16; o <= 32; o <<= 1) {
-          const float ob = __shfl_xor(best, o);
-          const int oi = __shfl_xor(bi, o);
-          take(ob, oi);
-        }
-        result = bi;
-      } else {
-        const float T = a.temperature[clip];
-        float mx = -INFINITY;
-        for (int q = 0; q < per; ++q) {
-          const int c = lane * per + q;
-          if (c < nc) mx = fmaxf(mx, (a.learn_temp ? lg[c] / denom : lg[c]) / T);
-        }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
-        float local = 0.f;
-        for (int q = 0; q < per; ++q) {
-          const int c = lane * per + q;
-          if (c < nc) local += expf((a.learn_temp ? lg[c] / denom : lg[c]) / T - mx);
-        }
-        float incl = local;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-          const float up = __shfl_up(incl, o);
-          if (lane >= o) incl += up;
-        }
-        const float total = __shfl(incl, 63);
-        const float target = a.uniforms[(int64_t)clip * a.uni_ld + t + a.uni_off] * total;
-        float run = incl - local;
-        int pick = 0x7fffffff, last_c = -1;
-        for (int q = 0; q < per; ++q) {
-          const int c = lane * per + q;
-          if (c < nc) {
-            const float e = expf((a.learn_temp ? lg[c] / denom : lg[c]) / T - mx);
-            run += e;
-            if (e > 0.f) last_c = c;
-            if (pick == 0x7fffffff && run > target && e > 0.f) pick = c;
-          }
-        }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-          const int op = __shfl_xor(pick, o), ol = __shfl_xor(last_c, o);
-          pick = op < pick ? op : pick;
-          last_c = ol > last_c ? ol : last_c;
-        }
-        result = pick != 0x7fffffff ? pick : (last_c < 0 ? 0 : last_c);
-      }
-      if (lane < a.fs) {
-        const int keep = lane + 1 < a.fs ? s_win[lane + 1] : result;
-        s_win[lane] = keep;     // wave-synchronous shift: every lane read before any lane writes
-      }
-      if (lane == 0) {
-        a.idx[(int64_t)clip * a.idx_rs + t] = result;
-        if (a.resident)    // for the tier kernels running beside this launch
-          __hip_atomic_store(a.cls_gran + (int64_t)clip * 256 + (t & 255), ((u64)(unsigned)(t + 1) << 32) | (unsigned)result, __ATOMIC_RELAXED,
-                             __HIP_MEMORY_SCOPE_AGENT);
-      }
-    }
+    sampler_phase(s, t);
     __syncthreads();
     stamp(4);
+  }
+  } else {
+    // Composed mode: fc0(x) = W0 up + sum_i lin_i (W0 wb_i) + (W0 bb + b0).  W0 up - the only real product - does not depend on
+    // the newest class: for every step but the first of a frame it is multiplied one step ahead, in the same phase as fc2 (two
+    // latency-bound products side by side), and the x phase with its barrier is gone.  Three barriers per step instead of four.
+    float p_cur = 0.f;                                        // W0 up of the current step (lanes ks < 4)
+    bool have_p = false;
+    u64 g_next = 0;                                           // resident mode: the next step's row granule, requested a phase ahead
+    auto in_frame = [&](int s) -> bool {                      // step s + 1 reads a row that is there when step s runs
+      return s + 1 < a.n_steps && !(a.resident && (t0 + s + 1) % a.up_slots == 0);
+    };
+    auto row_value = [&](int s, u64 g) -> float {             // the row of step s for this thread's column (tid < H)
+      if (!a.resident) return upper_at(s);
+      const unsigned epoch = (unsigned)((t0 + s) / a.up_slots) + 1u;
+      unsigned spins = 0;
+      while ((unsigned)(g >> 32) != epoch) {
+        if (++spins > (1u << 20) || ((spins & 255u) == 0 && a.err && __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+          if (a.err) atomicExch(a.err, 4);
+          break;
+        }
+        __builtin_amdgcn_s_sleep(1);
+        g = gran_at(s);
+      }
+      return __uint_as_float((unsigned)g);
+    };
+    for (int s = 0; s < a.n_steps; ++s) {
+      const int64_t t = t0 + s;
+      if (!have_p) {                                          // first step of the launch / of a frame: its row, then its product
+        if (tid < H) xs[xs_at] = row_value(s, (a.resident ? gran_at(s) : 0));
+        __syncthreads();
+        p_cur = fc0_product();
+        if (a.resident && tid < H && in_frame(s)) g_next = gran_at(s + 1);
+        __syncthreads();                                      // xs is rewritten below
+      }
+      stamp(1);
+      // ---- hidden units of step s; the next step's row -> LDS -------------------------------------------------------
+      const bool ahead = in_frame(s);
+      if (ks < 4 && hid_u < Hm) {
+        float pre = p_cur;
+        if (a.fs == 1) {
+          pre = fmaf((((float)s_win[0] / a.class_size) - .5f) * 2.f, a_c0, pre);
+        } else {
+          for (int i = 0; i < a.fs; ++i) pre = fmaf((((float)s_win[i] / a.class_size) - .5f) * 2.f, a.a_comp[i * Hm + hid_u], pre);
+        }
+        hid[hid_at] = mish_fast(pre + b_c);
+      }
+      if (ahead && tid < H) xs[xs_at] = row_value(s + 1, g_next);
+      __syncthreads();
+      stamp(2);
+      // ---- fc2 of step s next to W0 up of step s + 1 --------------------------------------------------------------
+      fc2_phase();
+      float p_next = 0.f;
+      if (ahead) {
+        p_next = fc0_product();
+        if (a.resident && tid < H && in_frame(s + 1)) g_next = gran_at(s + 2);
+      }
+      __syncthreads();
+      stamp(3);
+      sampler_phase(s, t);
+      __syncthreads();
+      stamp(4);
+      have_p = ahead;
+      p_cur = p_next;
+    }
   }
   if (stamping) {
     for (int i = 0; i < 5; ++i) a.stamps[i] += st_acc[i];
@@ -668,9 +746,18 @@ int launch_srnn_bottom(const SrnnBottomArgs& a, hipStream_t stream) {
     const size_t lds1 = srnn_bottom1_lds_bytes(a);
     dim3 grid1(a.B), block1(kBotThreads);
     switch (a.H) {
-      case 128: hipLaunchKernelGGL((srnn_bottom1_kernel<8>), grid1, block1, lds1, stream, a); break;
-      case 256: hipLaunchKernelGGL((srnn_bottom1_kernel<16>), grid1, block1, lds1, stream, a); break;
-      default: hipLaunchKernelGGL((srnn_bottom1_kernel<32>), grid1, block1, lds1, stream, a); break;
+      case 128:
+        if (a.a_comp) hipLaunchKernelGGL((srnn_bottom1_kernel<8, true>), grid1, block1, lds1, stream, a);
+        else hipLaunchKernelGGL((srnn_bottom1_kernel<8, false>), grid1, block1, lds1, stream, a);
+        break;
+      case 256:
+        if (a.a_comp) hipLaunchKernelGGL((srnn_bottom1_kernel<16, true>), grid1, block1, lds1, stream, a);
+        else hipLaunchKernelGGL((srnn_bottom1_kernel<16, false>), grid1, block1, lds1, stream, a);
+        break;
+      default:
+        if (a.a_comp) hipLaunchKernelGGL((srnn_bottom1_kernel<32, true>), grid1, block1, lds1, stream, a);
+        else hipLaunchKernelGGL((srnn_bottom1_kernel<32, false>), grid1, block1, lds1, stream, a);
+        break;
     }
     MMK_HIP(hipGetLastError());
     return MMK_OK;

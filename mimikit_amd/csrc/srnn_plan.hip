@@ -68,6 +68,8 @@ struct mmk_srnn_plan {
   bool fused_gru = false;                       // srnn_gru.hip: input linear + both gate products + cell in one launch
   float *wb_raw = nullptr, *bb_raw = nullptr;   // framed conv weight / bias in their state_dict layout
   const float* mlp_raw[2] = {nullptr, nullptr}; // fc0 / fc2 weights as bound (row-major; the caller keeps them alive with the plan)
+  float *a_comp = nullptr, *b_comp = nullptr;   // bottom tier, composed mode: (fs, Hm) = W0 wb_i, (Hm) = W0 bb + b0 (srnn_bottom.hip)
+  bool bottom_composed = false;
 
   void layout(Carver& c) {
     const bool bias = cfg.rnn_bias != 0;
@@ -106,6 +108,8 @@ struct mmk_srnn_plan {
     up_gran = c.take<unsigned long long>((int64_t)Bmax * tiers.back().up * H);
     cls_gran = c.take<unsigned long long>((int64_t)Bmax * 256);
     probe = reinterpret_cast<unsigned*>(tau + 24);
+    a_comp = c.take<float>((int64_t)cfg.frame_size[cfg.n_tiers - 1] * cfg.mlp_hidden);
+    b_comp = c.take<float>(cfg.mlp_hidden);
     wb_raw = c.take<float>((int64_t)H * cfg.frame_size[cfg.n_tiers - 1]);
     bb_raw = c.take<float>(H);
   }
@@ -225,6 +229,22 @@ __global__ void srnn_compose_kernel(const float* __restrict__ wih, const float* 
   if (i < fs)
     for (int k = 0; k < H; ++k) acc += (double)wih[(int64_t)r * H + k] * (double)win[(int64_t)k * fs + i];
   V[e] = (float)acc;
+}
+
+// bottom tier, composed mode: A[i][u] = sum_k W0[u][k] wb[k][i] (i < fs), b'[u] = sum_k W0[u][k] bb[k] + b0[u]; fp64, rounded once
+__global__ void srnn_compose_bottom_kernel(const float* __restrict__ w0, const float* __restrict__ b0, const float* __restrict__ wb,
+                                           const float* __restrict__ bb, int Hm, int H, int fs, float* __restrict__ A, float* __restrict__ B) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= (fs + 1) * Hm) return;
+  const int i = e / Hm, u = e - i * Hm;
+  double acc = 0.0;
+  if (i < fs) {
+    for (int k = 0; k < H; ++k) acc += (double)w0[(int64_t)u * H + k] * (double)wb[(int64_t)k * fs + i];
+    A[e] = (float)acc;
+  } else {
+    for (int k = 0; k < H; ++k) acc += (double)w0[(int64_t)u * H + k] * (double)bb[k];
+    B[u] = (float)(acc + (double)b0[u]);
+  }
 }
 
 // ---- resident mode helpers ---------------------------------------------------------------------------------------------
@@ -394,6 +414,13 @@ extern "C" int mmk_srnn_commit(mmk_srnn_plan* p, void* workspace, size_t workspa
     if (w) MMK_TRY(pack_rect(m.Wp, m.k_chunks, 0, 1, m.N, 0, m.segK[0], w, m.segK[0], 1, st));
     if (bb) MMK_TRY(pack_bias(m.bias, 0, 1, m.N, bb, 0, st));
     if (p->mlp.size() == 2) p->mlp_raw[i] = w;
+    if (p->mlp.size() == 2 && i == 0 && w && bb && p->fused_bottom) {   // (wb_raw / bb_raw were copied above, on this stream)
+      const int fsl = c.frame_size[c.n_tiers - 1];
+      hipLaunchKernelGGL(srnn_compose_bottom_kernel, dim3(((fsl + 1) * m.N + 255) / 256), dim3(256), 0, st, w, bb, p->wb_raw, p->bb_raw, m.N,
+                         H, fsl, p->a_comp, p->b_comp);
+      MMK_HIP(hipGetLastError());
+      p->bottom_composed = true;
+    }
   }
   if (!b.missing().empty()) return fail(MMK_ERR_KEY, "srnn_commit: state_dict tensor %s", b.missing().c_str());
   if (!p->cap_stream) MMK_HIP(hipStreamCreateWithFlags(&p->cap_stream, hipStreamNonBlocking));
@@ -420,6 +447,10 @@ static SrnnBottomArgs bottom_args(mmk_srnn_plan* p, const SrnnCall& call, int64_
   a.wb = p->wb_raw; a.bb = p->bb_raw; a.upper = up.out;
   a.fc0_wp = p->mlp[0].Wp; a.fc0_bias = p->mlp[0].bias; a.fc2_wp = p->mlp[1].Wp; a.fc2_bias = p->mlp[1].bias;
   a.fc0_raw = p->mlp_raw[0]; a.fc2_raw = p->mlp_raw[1];
+  {
+    const char* cenv = getenv("MMK_SRNN_COMPOSED");
+    if (p->bottom_composed && !(cenv && cenv[0] == '0')) { a.a_comp = p->a_comp; a.b_comp = p->b_comp; }
+  }
   a.temperature = call.temperature; a.uniforms = call.uniforms; a.uni_ld = call.uni_ld; a.uni_off = call.uni_off;
   a.logits_out = p->logits; a.logits_ld = p->logits_ld;
   {
