@@ -321,10 +321,13 @@ def test_sample_rnn_resident_mode_blocks_and_oracle(device, monkeypatch, kind):
     ((64, 16, 4, 4), 5, 128, "lstm"),   # three recurrent tiers, frame sizes above 16 (the tier kernel's uncomposed path) and equal ones
     ((16, 4, 1), 16, 256, "lstm"),
 ])
-def test_sample_rnn_resident_mode_geometries(device, monkeypatch, frame_sizes, batch, hidden, kind):
-    """resident mode over the tier geometries the fused kernels accept: classes equal to the oracle's, teacher-forced on the
-    device's own history; the mode itself must have run"""
+@pytest.mark.parametrize("composed", ["1", "0"])
+def test_sample_rnn_resident_mode_geometries(device, monkeypatch, frame_sizes, batch, hidden, kind, composed):
+    """resident mode over the tier geometries the fused kernels accept, with the pre-multiplied association of the input
+    products (W_ih W_in, W0 wb) and with the reference's: classes equal to the oracle's, teacher-forced on the device's own
+    history; the mode itself must have run"""
     monkeypatch.setenv("MMK_SRNN_FUSED", "1")
+    monkeypatch.setenv("MMK_SRNN_COMPOSED", composed)
     net, sd, arch = H.srnn("big", hidden=hidden, mlp_dim=64, seed=91, frame_sizes=frame_sizes, kind=kind)
     net = net.to(device)
     rf = frame_sizes[0]
