@@ -376,10 +376,17 @@ class S2SJob:
         calls = -(-self.n_steps // self.net.config.hop)
         flops = self.step_flops() * self.clips * calls
         achieved = flops / (us * 1e-6) / 1e12
+        traffic = None
+        try:   # HBM-side bytes of one generate_step from the PMC passes (profiles/traffic.json), times the block's generate_steps
+            with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+                per_call = json.load(f).get(self.name, {}).get("generate_step", {}).get("bytes")
+            traffic = int(per_call * calls) if per_call else None
+        except (OSError, ValueError):
+            traffic = None
         return {"bound": "mfma", "kernel": "Seq2Seq generate block: gemm_bias_act_kernel (input / output projections) + lstm_step_kernel "
                                            "(recurrent products + cells), all generate_steps of one block",
                 "achieved": round(achieved, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(achieved / MFMA_F32_PEAK_TFLOPS, 5), "traffic": None,
+                "frac": round(achieved / MFMA_F32_PEAK_TFLOPS, 5), "traffic": traffic,
                 "algorithmic_flops_per_launch": flops, "avg_launch_us": round(us, 1), "launches_timed": 1,
                 "generate_steps_per_launch": calls, "us_per_generate_step": round(us / calls, 2)}
 
