@@ -191,6 +191,9 @@ WAVENET_OPTIONS = {
     "lw": dict(layerwise_inputs=True),
     "lw_noskip_rev": dict(layerwise_inputs=True, reverse_layer_order=True, skips_dim=None),
     "tied": dict(tie_io_weights=True),
+    "k3": dict(kernel_sizes=(3,)),
+    "k3_cond": dict(kernel_sizes=(3,), cond=True),
+    "k4_noskip": dict(kernel_sizes=(4,), skips_dim=None),
 }
 
 

@@ -72,6 +72,9 @@ WAVENET_OPTIONS = {       # tests/golden/make_golden.py: make_wavenet_options
     "lw": dict(layerwise_inputs=True),
     "lw_noskip_rev": dict(layerwise_inputs=True, reverse_layer_order=True, skips_dim=None),
     "tied": dict(tie_io_weights=True),
+    "k3": dict(kernel_sizes=(3,)),                    # kernel sizes above 2: dilations 1, 3, 9 | 1, 3 (get_kernels_and_dilation)
+    "k3_cond": dict(kernel_sizes=(3,), cond=True),
+    "k4_noskip": dict(kernel_sizes=(4,), skips_dim=None),
 }
 
 
@@ -92,8 +95,9 @@ def wavenet_option(tag):
     # (the hidden blocks of a deeper MLP head share ONE Linear: the state_dict, not the recipe, says what it ended up with)
     sd = {k: v.detach().clone() for k, v in net.state_dict().items()}
     rev = bool(kw.get("reverse_layer_order"))
-    dil = [1, 2, 4, 1, 2]
-    arch = dict(kernels=[2] * 5, dilations=dil[::-1] if rev else dil, has_skips=kw["skips_dim"] is not None,
+    k = kw.get("kernel_sizes", (2,))[0]
+    dil = [1, k, k * k, 1, k]
+    arch = dict(kernels=[k] * 5, dilations=dil[::-1] if rev else dil, has_skips=kw["skips_dim"] is not None,
                 res_layers=[False, True, True, True, True] if rev else [True, True, True, True, False],
                 gated=kw.get("act_g", "Sigmoid") is not None, layerwise_inputs=bool(kw.get("layerwise_inputs")),
                 n_mlp_hidden=io_kw.get("n_mlp_layers", 0), n_cond=int(cond))
