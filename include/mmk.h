@@ -191,6 +191,9 @@ typedef struct mmk_wavenet_config {
   int32_t res_explicit;
   int32_t layer_has_res[MMK_MAX_LAYERS];
   int32_t layerwise_inputs;                /* Config.layerwise_inputs: the embedded input 0 is added to every layer's output (:285-286) */
+  int32_t with_affine_residuals;           /* Config.with_affine_residuals (:121-122, :148-149): every layer's input goes through
+                                            * x_hat * a + b of a 1x1 convolution to 3 x its width (ParametrizedLinear) first; launch path,
+                                            * without pad_side, layerwise_inputs, or conditioning inputs of an ungated network */
 } mmk_wavenet_config;
 
 typedef struct mmk_wavenet_plan mmk_wavenet_plan;

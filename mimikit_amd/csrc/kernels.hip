@@ -106,6 +106,23 @@ int launch_add_rows(Addr src, int64_t src_ld, Addr dst, int64_t dst_ld, int M, i
   return MMK_OK;
 }
 
+// dst[m][c] = P[m][c] * P[m][C + c] + P[m][2 C + c]      (ParametrizedLinear, networks/parametrized.py:45-47)
+__global__ void affine_rows_kernel(const float* __restrict__ P, int64_t p_ld, Addr dst, int64_t dst_ld, int M, int C, const int64_t* tau_ptr,
+                                   int64_t tau_off) {
+  const int64_t tau = (tau_ptr ? *tau_ptr : 0) + tau_off;
+  const int m = blockIdx.x;
+  const float* s = P + (int64_t)m * p_ld;
+  float* d = (float*)dst.base + addr_elems(dst, tau) + (int64_t)m * dst_ld;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) d[c] = s[c] * s[C + c] + s[2 * C + c];
+}
+
+int launch_affine_rows(const float* P, int64_t p_ld, Addr dst, int64_t dst_ld, int M, int C, const int64_t* tau_ptr, int64_t tau_off,
+                       hipStream_t stream) {
+  hipLaunchKernelGGL(affine_rows_kernel, dim3(M), dim3(C >= 256 ? 256 : 64), 0, stream, P, p_ld, dst, dst_ld, M, C, tau_ptr, tau_off);
+  MMK_HIP(hipGetLastError());
+  return MMK_OK;
+}
+
 int launch_copy_rows(Addr src, int64_t src_ld, Addr dst, int64_t dst_ld, int M, int C, const int64_t* tau_ptr,
                      int64_t tau_off, hipStream_t stream) {
   hipLaunchKernelGGL(copy_rows_kernel, dim3(M), dim3(C >= 256 ? 256 : 64), 0, stream, src, src_ld, dst, dst_ld, M,

@@ -182,6 +182,8 @@ int launch_copy_rows(Addr src, int64_t src_ld, Addr dst, int64_t dst_ld, int M, 
                      int64_t tau_off, hipStream_t stream);
 int launch_add_rows(Addr src, int64_t src_ld, Addr dst, int64_t dst_ld, int M, int C, const int64_t* tau_ptr, int64_t tau_off,
                     hipStream_t stream);
+int launch_affine_rows(const float* P, int64_t p_ld, Addr dst, int64_t dst_ld, int M, int C, const int64_t* tau_ptr, int64_t tau_off,
+                       hipStream_t stream);
 int launch_fill(float* p, float v, int64_t n, hipStream_t stream);
 
 struct SampleArgs {

@@ -37,6 +37,8 @@ struct mmk_wavenet_plan {
   bool committed = false;
   int L = 0, C = 0, S = 0, Bmax = 0, n_cond = 0;
   std::vector<int> ksz, dil, ring;
+  std::vector<PackedLinear> Aff;                 // with_affine_residuals: the layers' ParametrizedLinear (3 C x C)
+  float* affbuf = nullptr;                       // its (Bmax, 3 C) outputs
   std::vector<char> has_res;
   int64_t rf = 1;
   int head_in = 0;
@@ -143,6 +145,8 @@ struct mmk_wavenet_plan {
     if (cfg.q_levels == 0) in0_lin.carve(c, true);
     for (auto& p : cond_lin) p.carve(c, true);
     for (auto& p : A) p.carve(c, bias);
+    for (auto& p : Aff) p.carve(c, bias);
+    affbuf = Aff.empty() ? nullptr : c.take<float>((int64_t)Bmax * 3 * C);
     for (auto& p : Bm)
       if (p.n_tiles > 0) p.carve(c, bias);
     for (auto& p : mlp) p.carve(c, true);
@@ -239,6 +243,11 @@ static int derive(mmk_wavenet_plan* p) {
   for (int j = 0; j < p->n_cond; ++j) p->cond_lin[j].set_geometry(c.cond_dim[j], {c.cond_in_dim[j]});
   p->A.resize(p->L);
   p->Bm.resize(p->L);
+  p->Aff.clear();
+  if (c.with_affine_residuals) {
+    p->Aff.resize(p->L);
+    for (auto& a : p->Aff) a.set_geometry(3 * p->C, {p->C});
+  }
   for (int l = 0; l < p->L; ++l) {
     std::vector<int> ks;
     for (int j = 0; j < p->ksz[l]; ++j) ks.push_back(p->C);
@@ -276,7 +285,7 @@ static int derive(mmk_wavenet_plan* p) {
   const char* env = getenv("MMK_WN_PERSISTENT");
   bool ok = !(env && env[0] == '0');
   ok = ok && c.gated && c.q_levels > 0 && c.head_kind == 0 && c.mlp_n_hidden == 0 && c.n_cond <= 1;
-  ok = ok && p->C % 32 == 0 && p->C <= 256 && p->S == p->C && c.residuals_dim == p->C && !c.layerwise_inputs;
+  ok = ok && p->C % 32 == 0 && p->C <= 256 && p->S == p->C && c.residuals_dim == p->C && !c.layerwise_inputs && !c.with_affine_residuals;
   for (int l = 0; l < p->L; ++l) ok = ok && (p->has_res[l] != 0) == (l != p->L - 1);   // (reverse_layer_order: launch path)
   ok = ok && c.mlp_hidden % 16 == 0 && c.mlp_hidden >= 16;
   if (c.n_cond == 1) ok = ok && c.cond_dim[0] % 16 == 0;
@@ -505,6 +514,13 @@ extern "C" int mmk_wavenet_commit(mmk_wavenet_plan* p, void* workspace, size_t w
     const std::string dil_base = ly + (c.gated ? "conv_dil.0.0." : "conv_dil.0.");
     const float* wd = b.need(dil_base + "weight", (int64_t)rows_src * C * k);
     const float* bd = bias ? b.need(dil_base + "bias", rows_src) : nullptr;
+    if (c.with_affine_residuals) {
+      PackedLinear& F = p->Aff[l];
+      const float* wa = b.need(ly + "aff_res.params.weight", (int64_t)3 * C * C);
+      const float* ba = bias ? b.need(ly + "aff_res.params.bias", 3 * C) : nullptr;
+      if (wa) MMK_TRY(pack_rect(F.Wp, F.k_chunks, 0, 1, 3 * C, 0, C, wa, C, 1, st));
+      if (ba) MMK_TRY(pack_bias(F.bias, 0, 1, 3 * C, ba, 0, st));
+    }
     PackedLinear& A = p->A[l];
     if (wd) {
       for (int j = 0; j < k; ++j) {
@@ -728,6 +744,17 @@ static int emit_step(mmk_wavenet_plan* p, const WnCall& call, int64_t tau_off, b
   }
   for (int l = 0; l < L; ++l) {
     const int k = p->ksz[l], d = p->dil[l];
+    if (c.with_affine_residuals) {   // the layer's newest input becomes x_hat * a + b, in place: both taps and the residual sum see it
+      LinearArgs a = {};
+      p->Aff[l].fill(a);
+      a.seg[0].x = p->hist_slot(l, 0); a.seg[0].ld = C;
+      a.M = M; a.tau_ptr = p->tau; a.tau_off = tau_off;
+      a.epilogue = EPI_STORE; a.act = ACT_NONE;
+      a.out = addr_static(p->affbuf); a.out_ld = 3 * C;
+      g_prof_tag = 2;
+      MMK_TRY(launch_linear(a, st));
+      MMK_TRY(launch_affine_rows(p->affbuf, 3 * C, p->hist_slot(l, 0), C, M, C, p->tau, tau_off, st));
+    }
     {
       LinearArgs a = {};
       p->A[l].fill(a);

@@ -31,7 +31,7 @@ class WaveNetConfig(C.Structure):
         ("n_cond", i32), ("cond_in_dim", i32 * MAX_COND), ("cond_dim", i32 * MAX_COND),
         ("bias", i32), ("gated", i32), ("head_kind", i32), ("mlp_hidden", i32), ("mlp_n_hidden", i32),
         ("out_dim", i32), ("learn_temp", i32), ("min_temp", f32), ("max_batch", i32),
-        ("res_explicit", i32), ("layer_has_res", i32 * MAX_LAYERS), ("layerwise_inputs", i32),
+        ("res_explicit", i32), ("layer_has_res", i32 * MAX_LAYERS), ("layerwise_inputs", i32), ("with_affine_residuals", i32),
     ]
 
 

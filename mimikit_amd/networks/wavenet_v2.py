@@ -33,6 +33,20 @@ from .arm import ARM, NetworkConfig
 __all__ = ["WNLayer", "WaveNet"]
 
 
+class ParametrizedLinear(nn.Module):
+    """x_hat * a + b of one (1x1) convolution / Linear to three times the width (networks/parametrized.py:34-47); the
+    parameter lives in ``params`` as in the reference (state_dict key ``...aff_res.params.weight``)."""
+
+    def __init__(self, in_dim, out_dim, bias=True, as_1x1_conv=False):
+        super().__init__()
+        self.params = nn.Conv1d(in_dim, out_dim * 3, 1, bias=bias) if as_1x1_conv else nn.Linear(in_dim, out_dim * 3, bias=bias)
+        self.chunk_dim = -2 if as_1x1_conv else -1
+
+    def forward(self, x):
+        x_hat, a, b = torch.chunk(self.params(x), 3, dim=self.chunk_dim)
+        return x_hat.mul(a).add(b)
+
+
 class WNLayer(nn.Module):
     """One dilated causal conv layer with gated units, 1x1 conditioning, skip and residual
     connections.  Holds the parameters (reference names) and the differentiable forward."""
@@ -44,8 +58,6 @@ class WNLayer(nn.Module):
                  pad_side: int = 1, stride: int = 1, bias: bool = True, dilation: int = 1,
                  with_affine_residuals: bool = False):
         super().__init__()
-        if with_affine_residuals:
-            raise NotImplementedError("with_affine_residuals is outside the covered option space (SURVEY 8(f) rank 4)")
         self.input_dim, self.dims_dilated, self.dims_1x1 = input_dim, dims_dilated, dims_1x1
         self.residuals_dim, self.apply_residuals, self.skips_dim = residuals_dim, apply_residuals, skips_dim
         self.kernel_size, self.groups, self.act_f, self.act_g = kernel_size, groups, act_f, act_g
@@ -56,6 +68,7 @@ class WNLayer(nn.Module):
         self.has_gated_units = act_g is not None
         self.has_skips = skips_dim is not None
         self.has_residuals = residuals_dim is not None and (input_dim is None or input_dim == residuals_dim)
+        self.has_affine_residuals = with_affine_residuals
 
         inner = dims_dilated[0]
         outer = inner if residuals_dim is None else residuals_dim
@@ -77,6 +90,8 @@ class WNLayer(nn.Module):
             self.conv_skip = nn.Conv1d(inner, skips_dim, **kw_1x1)
         if self.has_residuals:
             self.conv_res = nn.Conv1d(inner, outer, **kw_1x1)
+        if self.has_affine_residuals:      # (wavenet_v2.py:121-122)
+            self.aff_res = ParametrizedLinear(in_dim, in_dim, as_1x1_conv=True)
 
     def trim_cause(self, x):
         cs = self.cause
@@ -87,6 +102,10 @@ class WNLayer(nn.Module):
         if self.needs_padding:
             x = self.pad(x)
         conds = [c if self.needs_padding else self.trim_cause(c) for c in inputs_1x1]
+        if self.has_affine_residuals:      # the dilated convolution AND the residual sum see aff(x) (:148-149, :160-161, :174)
+            if not self.has_gated_units:
+                conds = [self.aff_res(c) + c for c in conds]     # (:157-158)
+            x = self.aff_res(x)
         if self.has_gated_units:
             z_f, z_g = self.conv_dil[0](x)
             for conv, c in zip(self.conv_1x1, conds):
@@ -283,8 +302,8 @@ class WaveNet(ARM, nn.Module):
             unsupported.append(f"groups={cfg.groups} does not divide the dilated width")
         if cfg.stride != 1:
             unsupported.append("stride != 1")
-        if cfg.with_affine_residuals:
-            unsupported.append("with_affine_residuals")
+        if cfg.with_affine_residuals and (cfg.pad_side != 0 or cfg.layerwise_inputs or (cfg.act_g is None and cfg.dims_1x1)):
+            unsupported.append("with_affine_residuals together with pad_side, layerwise_inputs, or conditioning inputs of an ungated network")
         if str(cfg.act_f) != "Tanh" or (cfg.act_g is not None and str(cfg.act_g) != "Sigmoid"):
             unsupported.append("activations other than Tanh / Sigmoid")
         if len(cfg.dims_dilated) != 1:
@@ -300,6 +319,7 @@ class WaveNet(ARM, nn.Module):
             c.kernel_size[i], c.dilation[i] = layer.kernel_size, layer.dilation
             c.layer_has_res[i] = int(layer.has_residuals)
         c.layerwise_inputs = int(cfg.layerwise_inputs)
+        c.with_affine_residuals = int(cfg.with_affine_residuals)
         first = self.input_modules[0][0]
         if isinstance(first, nn.Embedding) and len(self.input_modules[0]) == 1:
             c.q_levels, c.in_dim = first.num_embeddings, 0

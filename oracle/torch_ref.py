@@ -217,14 +217,17 @@ def wavenet_window_forward(sd: SD, inputs: Tuple[torch.Tensor, ...], kernels: Se
                            n_cond: int = 0, has_skips: bool = True, residuals: bool = True,
                            n_mlp_hidden: int = 0, embedding: bool = True, groups: int = 1, head: str = "mlp",
                            gated: bool = True, layerwise_inputs: bool = False,
-                           res_layers: Optional[Sequence[bool]] = None) -> torch.Tensor:
+                           res_layers: Optional[Sequence[bool]] = None, affine: bool = False) -> torch.Tensor:
     """Full-window eval forward (wavenet_v2.py:276-293 with WNLayer.forward :131-176, pad_side=0):
     returns the RAW head outputs (B, 1, q+1) of the FIRST computable position (eval_slice, :273).
     ``groups`` applies to the dilated convolutions only (:93); ``head`` "linear" / "linear_abs" is the
     (Chunked)LinearIO output module of a magnitude-frame target (io_spec.py:238-243) instead of the MLP.
     ``gated=False`` is act_g=None (:155-163: one tanh, plain Conv1d modules); ``layerwise_inputs`` adds the embedded
     input 0 to every layer's output (:285-286); ``res_layers`` says per layer, in RUN order, whether it has its conv_res
-    (reverse_layer_order, :253, moves the layer built without one, :216, to the front) - default: all but the last."""
+    (reverse_layer_order, :253, moves the layer built without one, :216, to the front) - default: all but the last;
+    ``affine`` is with_affine_residuals (:122, :148-149, :157-161; ParametrizedLinear, parametrized.py:34-47): the layer's
+    input goes through x_hat * a + b of a 1x1 convolution to three times its width first - the dilated convolution AND the
+    residual sum see the transformed input - and, without gated units, every conditioning input c becomes aff(c) + c."""
     if embedding:
         h = F.embedding(inputs[0], sd["input_modules.0.0.weight"])
     else:
@@ -241,11 +244,21 @@ def wavenet_window_forward(sd: SD, inputs: Tuple[torch.Tensor, ...], kernels: Se
     for l, (k, d) in enumerate(zip(kernels, dilations)):
         p = f"layers.{l}."
         cause = (k - 1) * d
+
+        def aff(v, p=p):
+            x_hat, a, b = torch.chunk(F.conv1d(v, sd[p + "aff_res.params.weight"], sd.get(p + "aff_res.params.bias")), 3, dim=1)
+            return x_hat * a + b
+
+        if affine:
+            h = aff(h)
         z = F.conv1d(h, sd[p + dil_key + "weight"], sd.get(p + dil_key + "bias"), dilation=d, groups=groups)
         cond_sum = 0          # the conditioning features are summed first (:141-147), then added to the dilated product
         for j in range(n_cond):
             ck = p + (f"conv_1x1.{j}.0." if gated else f"conv_1x1.{j}.")
-            cond_sum = cond_sum + F.conv1d(conds[j][:, :, cause:], sd[ck + "weight"], sd.get(ck + "bias"))
+            cj = conds[j][:, :, cause:]
+            if affine and not gated:
+                cj = aff(cj) + cj
+            cond_sum = cond_sum + F.conv1d(cj, sd[ck + "weight"], sd.get(ck + "bias"))
         z = z + cond_sum
         if gated:
             z_f, z_g = torch.chunk(z, 2, dim=1)

@@ -194,6 +194,8 @@ WAVENET_OPTIONS = {
     "k3": dict(kernel_sizes=(3,)),
     "k3_cond": dict(kernel_sizes=(3,), cond=True),
     "k4_noskip": dict(kernel_sizes=(4,), skips_dim=None),
+    "aff": dict(with_affine_residuals=True),
+    "aff_nogate_noskip": dict(with_affine_residuals=True, act_g=None, skips_dim=None),
 }
 
 

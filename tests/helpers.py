@@ -75,6 +75,8 @@ WAVENET_OPTIONS = {       # tests/golden/make_golden.py: make_wavenet_options
     "k3": dict(kernel_sizes=(3,)),                    # kernel sizes above 2: dilations 1, 3, 9 | 1, 3 (get_kernels_and_dilation)
     "k3_cond": dict(kernel_sizes=(3,), cond=True),
     "k4_noskip": dict(kernel_sizes=(4,), skips_dim=None),
+    "aff": dict(with_affine_residuals=True),
+    "aff_nogate_noskip": dict(with_affine_residuals=True, act_g=None, skips_dim=None),
 }
 
 
@@ -100,7 +102,7 @@ def wavenet_option(tag):
     arch = dict(kernels=[k] * 5, dilations=dil[::-1] if rev else dil, has_skips=kw["skips_dim"] is not None,
                 res_layers=[False, True, True, True, True] if rev else [True, True, True, True, False],
                 gated=kw.get("act_g", "Sigmoid") is not None, layerwise_inputs=bool(kw.get("layerwise_inputs")),
-                n_mlp_hidden=io_kw.get("n_mlp_layers", 0), n_cond=int(cond))
+                n_mlp_hidden=io_kw.get("n_mlp_layers", 0), n_cond=int(cond), affine=bool(kw.get("with_affine_residuals")))
     return net.eval(), sd, arch
 
 

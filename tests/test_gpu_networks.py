@@ -153,8 +153,10 @@ def test_wavenet_sampling_matches_oracle_given_uniforms(device):
 
 
 def test_wavenet_unsupported_options_fail_loudly(device):
+    net = mmk.WaveNet.from_config(mmk.WaveNet.Config(io_spec=H.mu_emb(), blocks=(2,), dims_dilated=(8,), with_affine_residuals=True,
+                                                     pad_side=1)).to(device).eval()      # (padding zeros would have to become aff(0))
     with pytest.raises(NotImplementedError):
-        mmk.WaveNet.from_config(mmk.WaveNet.Config(io_spec=H.mu_emb(), blocks=(2,), dims_dilated=(8,), with_affine_residuals=True))
+        net.before_generate((torch.zeros(1, 8, dtype=torch.int64, device=device),), 0)
     net = mmk.WaveNet.from_config(mmk.WaveNet.Config(io_spec=H.mu_emb(), blocks=(2,), dims_dilated=(8,), stride=2)).to(device).eval()
     with pytest.raises(NotImplementedError):
         net.before_generate((torch.zeros(1, 8, dtype=torch.int64, device=device),), 0)
