@@ -59,6 +59,24 @@ def test_rf_should_be_correct(blocks):
     assert net((torch.randn(2, 9, bins),))[0].size(1) == 2
 
 
+def test_wavenet_should_support_multiple_io():
+    """tests/test_wavenet.py:168-212: two real-valued inputs (the second one conditions every layer) and two targets: a tuple of
+    equally shaped outputs (the training graph; the HIP generate path refuses a second target)"""
+    ext = mmk.Extractor("signal", mmk.FileToSignal(16000))
+
+    def an_input():
+        return mmk.InputSpec(extractor_name=ext.name, transform=mmk.Normalize(), module=mmk.LinearIO()).bind_to(ext)
+
+    def a_target():
+        return mmk.TargetSpec(extractor_name=ext.name, transform=mmk.Normalize(), module=mmk.LinearIO(),
+                              objective=mmk.Objective("reconstruction")).bind_to(ext)
+
+    io = mmk.IOSpec(inputs=(an_input(), an_input()), targets=(a_target(), a_target()))
+    net = mmk.WaveNet.from_config(mmk.WaveNet.Config(io_spec=io, dims_dilated=(128,), dims_1x1=(44,))).train()
+    out = net.forward((torch.randn(1, 32, 1), torch.randn(1, 32, 1)))
+    assert isinstance(out, tuple) and len(out) == 2 and out[0].size() == out[1].size()
+
+
 # ---------------------------------------------------------------------------- tests/test_sample_rnn.py
 def test_sample_rnn_should_instantiate_from_default_config():
     """tests/test_sample_rnn.py:16-24"""
