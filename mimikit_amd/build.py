@@ -13,7 +13,8 @@ CSRC = os.path.join(HERE, "csrc")
 LIB_PATH = os.path.join(HERE, "libmmk_hip.so")
 SOURCES = ["kernels.hip", "linear.hip", "gemm.hip", "features.hip", "wavenet_plan.hip", "wavenet_persist.hip", "wavenet_chain.hip", "wavenet_pipe.hip", "wavenet_prefill.hip", "srnn_plan.hip",
            "srnn_bottom.hip", "srnn_gru.hip", "lstm_step.hip", "istft.hip", "spectral2048.hip", "s2s_plan.hip"]
-HEADERS = ["mmk_common.h", "plan_util.h", "wavenet_persist.h", "wavenet_chain.h", "wavenet_pipe.h", "wavenet_handoff.h", "wavenet_prefill.h", "srnn_bottom.h", "srnn_gru.h", "lstm_step.h", "fft1024.h", "spectral_util.h", os.path.join("..", "..", "include", "mmk.h")]
+# every header under csrc/ (a header missing from a hand-kept list once left a stale library behind) + the C ABI
+HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith(".h")) + [os.path.join("..", "..", "include", "mmk.h")]
 ARCH = "gfx950"
 
 

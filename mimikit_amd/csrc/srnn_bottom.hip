@@ -16,6 +16,7 @@
 
 #include "mmk_common.h"
 #include "srnn_bottom.h"
+#include "sampler256.h"
 
 namespace mmk {
 
@@ -533,6 +534,8 @@ __global__ __launch_bounds__(kBotThreads) void srnn_bottom1_kernel(const SrnnBot
         take(ob, oi);
       }
       result = bi;
+    } else if (nc == 256) {
+      result = sample_256(lg, a.learn_temp != 0, denom, a.temperature[clip], a.uniforms[(int64_t)clip * a.uni_ld + t + a.uni_off], lane);
     } else {
       const float T = a.temperature[clip];
       float mx = -INFINITY;

@@ -34,6 +34,7 @@
 // other's state (the warm-up stays a prefill or the teacher-forced mode of wavenet_persist.hip).
 #include "wavenet_chain.h"
 #include "wavenet_handoff.h"
+#include "sampler256.h"
 
 namespace mmk {
 
@@ -383,6 +384,8 @@ __global__ __launch_bounds__(kChThreads) void wavenet_chain_kernel(const WnChain
             take(ob, oi);
           }
           result = bi;
+        } else if (nc == 256) {
+          result = sample_256(lg, a.learn_temp != 0, denom, a.temperature[clip], a.uniforms[(int64_t)clip * a.uni_ld + s], lane);
         } else {
           const float T = a.temperature[clip];
           float mx = -INFINITY;

@@ -22,6 +22,7 @@
 // stage through a stage-local exchange buffer and joins its ring at the start of the next visit.
 #include "wavenet_pipe.h"
 #include "wavenet_handoff.h"
+#include "sampler256.h"
 
 namespace mmk {
 
@@ -373,6 +374,8 @@ __global__ __launch_bounds__(kPiThreads) void wavenet_pipe_kernel(const WnPipeAr
             take(ob, oi);
           }
           result = bi;
+        } else if (nc == 256) {
+          result = sample_256(lg, a.learn_temp != 0, denom, a.temperature[clip], a.uniforms[(int64_t)clip * a.uni_ld + s], lane);
         } else {
           const float T = a.temperature[clip];
           float mx = -INFINITY;
