@@ -111,7 +111,10 @@ __device__ __forceinline__ bool poll4(const u64* gp, unsigned epoch, f32x4& out,
   return true;
 }
 
-template <int KC, int NIT, bool STAMPS>
+// SAMPLER: 0 = greedy decode only, 1 = sampled decode only, 2 = decided at run time (the diagnostic build).  Two product kernels
+// rather than one with both paths: this kernel has no register to spare (256 VGPRs, ~190 spilled SGPRs), and the sampled path
+// compiled into the greedy kernel cost the greedy decode 13 % (363 instead of 420 k samples/s, measured).
+template <int KC, int NIT, bool STAMPS, int SAMPLER>
 __global__ __launch_bounds__(kPiThreads) void wavenet_pipe_kernel(const WnPipeArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   constexpr int CPW = KC / 2;          // K-chunks per wave: a pair of waves covers one K = C segment
@@ -301,6 +304,14 @@ __global__ __launch_bounds__(kPiThreads) void wavenet_pipe_kernel(const WnPipeAr
     u64* gran_logit = a.gran_logit + (int64_t)g * 16 * a.n_logits_pad;
     u64* gran_idx = a.gran_idx + (int64_t)g * 16;
     const unsigned he = (unsigned)(s + 1);
+    const bool greedy = SAMPLER == 0 ? true : (SAMPLER == 1 ? false : a.temperature == nullptr);
+    // sampled decode: this wave's clip's uniform and temperature are requested now - the draw at the end of the head would wait a
+    // memory round trip for them on every sample's chain (the uniforms are streamed once, never cached)
+    float u_pre = 0.f, T_pre = 1.f;
+    if (SAMPLER != 0 && !greedy && j == 0 && wave < mg) {
+      u_pre = a.uniforms[(int64_t)(m_first + wave) * a.uni_ld + s];
+      T_pre = a.temperature[m_first + wave];
+    }
     // the hidden units: every layer's fc0 . W_skip product has been accumulated on the way (skipacc); + fc0's bias, Mish
     if (wave == 1 && e_m < mg && owns_hid)
       gran_store<true>(gran_hid + e_m * a.H1 + (j - KC) * 16 + e_n, he, mish_fast(skipacc + a.fc0_bias[(j - KC) * 16 + e_n]));
@@ -335,7 +346,7 @@ __global__ __launch_bounds__(kPiThreads) void wavenet_pipe_kernel(const WnPipeAr
         float denom = 1.f;
         if (a.learn_temp) denom = fmaxf(sigmoidf_(lg[nc]), a.min_temp);   // mlp.py:60-62
         int result;
-        if (a.temperature == nullptr) {
+        if (greedy) {
           float best = -INFINITY;
           int bi = 0x7fffffff;
           if (nc == 256) {   // four classes per lane in one 16-byte LDS read (this sits on every sample's chain)
@@ -375,7 +386,8 @@ __global__ __launch_bounds__(kPiThreads) void wavenet_pipe_kernel(const WnPipeAr
           }
           result = bi;
         } else if (nc == 256) {
-          result = sample_256(lg, a.learn_temp != 0, denom, a.temperature[clip], a.uniforms[(int64_t)clip * a.uni_ld + s], lane);
+          result = sample_256(lg, a.learn_temp != 0, denom, m == wave ? T_pre : a.temperature[clip],
+                              m == wave ? u_pre : a.uniforms[(int64_t)clip * a.uni_ld + s], lane);
         } else {
           const float T = a.temperature[clip];
           float mx = -INFINITY;
@@ -741,8 +753,9 @@ int launch_wavenet_pipe(const WnPipeArgs& a, hipStream_t stream) {
   const int nit = a.n_it;
 #define MMK_WNP3(KC_, NIT_)                                                                                            \
   do {                                                                                                                 \
-    if (a.stamps) hipLaunchKernelGGL((wavenet_pipe_kernel<KC_, NIT_, true>), grid, block, lds, stream, a);            \
-    else hipLaunchKernelGGL((wavenet_pipe_kernel<KC_, NIT_, false>), grid, block, lds, stream, a);                    \
+    if (a.stamps) hipLaunchKernelGGL((wavenet_pipe_kernel<KC_, NIT_, true, 2>), grid, block, lds, stream, a);         \
+    else if (a.temperature) hipLaunchKernelGGL((wavenet_pipe_kernel<KC_, NIT_, false, 1>), grid, block, lds, stream, a); \
+    else hipLaunchKernelGGL((wavenet_pipe_kernel<KC_, NIT_, false, 0>), grid, block, lds, stream, a);                  \
   } while (0)
 #define MMK_WNP2(KC_)                                                                                                  \
   do {                                                                                                                 \
