@@ -116,7 +116,7 @@ constexpr int kTgLd = kTgCh * 16 + 4;          // LDS row stride: the 16 lanes o
 
 __global__ __launch_bounds__(kTgThreads, 2) void gemm_bias_act_kernel(const float* __restrict__ A, int64_t lda, const float* __restrict__ Wp,
                                                                  const float* __restrict__ bias, float* __restrict__ C, int64_t ldc,
-                                                                 int M, int n_tiles, int N, int K, int k_chunks, int act) {
+                                                                 int M, int n_tiles, int N, int K, int k_chunks, int act, GemmRowMap rm) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   float* as = reinterpret_cast<float*>(smem_raw);              // [2][kTgBM][kTgLd]
   const int tid = threadIdx.x, lane = tid & 63;
@@ -211,7 +211,14 @@ __global__ __launch_bounds__(kTgThreads, 2) void gemm_bias_act_kernel(const floa
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int m = m_first + wm * 32 + r * 16 + 4 * (lane >> 4) + j;
-        if (m < M) C[(int64_t)m * ldc + col] = apply_act(acc[r][t][j] + b, act);
+        if (m < M) {
+          if (rm.group <= 0) {
+            C[(int64_t)m * ldc + col] = apply_act(acc[r][t][j] + b, act);
+          } else {   // rows (g, i) = (m / group, m % group) scattered to C + g group_stride + i row_stride; rows i >= kept dropped
+            const int g = m / rm.group, i = m - g * rm.group;
+            if (i < rm.kept) C[(int64_t)g * rm.group_stride + (int64_t)i * rm.row_stride + col] = apply_act(acc[r][t][j] + b, act);
+          }
+        }
       }
     }
   }
@@ -225,12 +232,12 @@ bool gemm_bias_act_supported(const float* A, int64_t lda, int M, int K) {
 }
 
 int launch_gemm_bias_act(const float* A, int64_t lda, const float* Wp, const float* bias, int n_tiles, int k_chunks, int N, int K, float* C,
-                         int64_t ldc, int M, int act, hipStream_t stream) {
+                         int64_t ldc, int M, int act, hipStream_t stream, GemmRowMap rm) {
   if (M <= 0 || n_tiles <= 0) return MMK_OK;
   if (!gemm_bias_act_supported(A, lda, M, K)) return fail(MMK_ERR_UNSUPPORTED, "gemm_bias_act: needs M >= 128 and a 16-byte aligned A");
   dim3 grid((n_tiles + kTgBN / 16 - 1) / (kTgBN / 16), (M + kTgBM - 1) / kTgBM), block(kTgThreads);
   const size_t lds = (size_t)2 * kTgBM * kTgLd * sizeof(float);
-  hipLaunchKernelGGL(gemm_bias_act_kernel, grid, block, lds, stream, A, lda, Wp, bias, C, ldc, M, n_tiles, N, K, k_chunks, act);
+  hipLaunchKernelGGL(gemm_bias_act_kernel, grid, block, lds, stream, A, lda, Wp, bias, C, ldc, M, n_tiles, N, K, k_chunks, act, rm);
   MMK_HIP(hipGetLastError());
   return MMK_OK;
 }

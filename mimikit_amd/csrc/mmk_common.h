@@ -213,8 +213,14 @@ int launch_gemm_f32(const float* A, int64_t lda, int64_t a_batch, const float* W
                     float* C, int64_t ldc, int64_t c_batch, int M, int batch, hipStream_t stream);
 // C[M, N] = act(A[M, K] . W^T + bias) on a packed weight matrix, 128 x 64 tiles with a pipelined K loop (gemm.hip); M >= 128
 bool gemm_bias_act_supported(const float* A, int64_t lda, int M, int K);
+// optional scatter of the output rows: row m = (g, i) with g = m / group, i = m % group goes to C + g group_stride + i row_stride,
+// rows with i >= kept are not written (group == 0: plain rows at ldc)
+struct GemmRowMap {
+  int32_t group = 0, kept = 0;
+  int64_t group_stride = 0, row_stride = 0;
+};
 int launch_gemm_bias_act(const float* A, int64_t lda, const float* Wp, const float* bias, int n_tiles, int k_chunks, int N, int K, float* C,
-                         int64_t ldc, int M, int act, hipStream_t stream);
+                         int64_t ldc, int M, int act, hipStream_t stream, GemmRowMap rm = GemmRowMap());
 
 // recurrent cells (elementwise)
 int launch_gru_cell(const float* gi, const float* gh, float* h, int M, int H, hipStream_t stream);

@@ -70,6 +70,28 @@ __global__ void pool_frames_kernel(const float* __restrict__ x, int D, int hop, 
   }
 }
 
+// the last encoder layer's fold and the pooling in one pass (the folded frames of that layer are read by nothing else)
+__global__ void pair_sum_pool_kernel(const float* __restrict__ of, const float* __restrict__ ob, int D, int hop, int mode,
+                                     const float* __restrict__ res, float* __restrict__ out) {
+  const int bidx = blockIdx.x;
+  for (int c = threadIdx.x; c < D; c += blockDim.x) {
+    auto folded = [&](int t) -> float {
+      const int64_t r = (int64_t)bidx * hop + t;
+      const float y = cat_at(of + r * D, ob + r * D, D, 2 * c) + cat_at(of + r * D, ob + r * D, D, 2 * c + 1);
+      return res ? res[r * D + c] + y : y;
+    };
+    float v = 0.f;
+    if (mode < 2) {
+      v = folded(0) + folded(hop - 1);
+      if (mode == 1) v *= 0.5f;
+    } else {
+      for (int t = 0; t < hop; ++t) v += folded(t);
+      if (mode == 3) v /= (float)hop;
+    }
+    out[(int64_t)bidx * D + c] = v;
+  }
+}
+
 // dec_upsampling="repeat": x.repeat_interleave(hop, 1)   (:161)
 __global__ void repeat_rows_kernel(const float* __restrict__ x, int D, int hop, float* __restrict__ out) {
   const int row = blockIdx.x;                       // b * hop + t
@@ -108,6 +130,8 @@ struct mmk_s2s_plan {
   bool fused_lstm = false;
   float *of = nullptr, *ob = nullptr, *es = nullptr, *coded = nullptr, *z = nullptr, *ysum = nullptr, *yout = nullptr;
   float* yalt = nullptr;                         // second folded-output buffer (layer n reads one, writes the other)
+  float* compose_tmp = nullptr;                  // (hop D, D): dec.fc . enc.fc_out, row-major, before it is packed
+  bool fc_composed = false;                      // dec_fc holds the pre-multiplied matrix: the coded frame is never materialised
   float *hs[2] = {nullptr, nullptr}, *cs[2] = {nullptr, nullptr};   // the encoder's final state: every decoder layer starts from it
 
   void layout(Carver& cv) {
@@ -128,6 +152,7 @@ struct mmk_s2s_plan {
     ob = cv.take<float>(rows * D);
     es = cv.take<float>((int64_t)Bmax * D);
     coded = cv.take<float>((int64_t)Bmax * D);
+    compose_tmp = cfg.dec_upsampling == 0 ? cv.take<float>((int64_t)hop * D * D) : nullptr;
     z = cv.take<float>(rows * D);
     ysum = cv.take<float>(rows * D);
     yalt = cv.take<float>(rows * D);
@@ -219,6 +244,18 @@ static int pack_lstm(mmk_s2s_plan* p, BiLstm& l, const std::string& base, int in
   return MMK_OK;
 }
 
+// C[r][k] = sum_j A[r][j] B[j][k]   (A: (R, D) = dec.fc weight, B: (D, D) = enc.fc_out weight): fp64 accumulation, one rounding.
+// The decoder's up-sampler then takes the pooled encoder frame directly: z = dec.fc(fc_out(e)) = (dec.fc . fc_out) e + b
+// (s2s_lstm_v2.py:113, :158-159) - one launch and 4 MB of weights less per generate_step, same operands in another association.
+__global__ void s2s_compose_kernel(const float* __restrict__ A, const float* __restrict__ B, int R, int D, float* __restrict__ C) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;      // consecutive threads: consecutive columns of B (coalesced)
+  const int r = blockIdx.y;
+  if (k >= D || r >= R) return;
+  double acc = 0.0;
+  for (int j = 0; j < D; ++j) acc += (double)A[(int64_t)r * D + j] * (double)B[(int64_t)j * D + k];
+  C[(int64_t)r * D + k] = (float)acc;
+}
+
 extern "C" int mmk_s2s_commit(mmk_s2s_plan* p, void* workspace, size_t workspace_bytes, mmk_stream_t stream) {
   if (!p || !workspace) return fail(MMK_ERR_INVALID, "s2s_commit: null argument");
   if ((reinterpret_cast<uintptr_t>(workspace) & 255) != 0) return fail(MMK_ERR_WORKSPACE, "s2s_commit: workspace must be 256-byte aligned");
@@ -242,8 +279,18 @@ extern "C" int mmk_s2s_commit(mmk_s2s_plan* p, void* workspace, size_t workspace
       MMK_TRY(pack_rect(p->enc_fc.Wp, p->enc_fc.k_chunks, 0, 1, D / p->hop, 0, D, w, D, 1, st));
     if (const float* bb = b.need("enc.fc.fc.bias", D / p->hop)) MMK_TRY(pack_bias(p->enc_fc.bias, 0, 1, D / p->hop, bb, 0, st));
   }
+  p->fc_composed = false;
   if (c.dec_upsampling == 0) {   // "repeat" / "interp" have no up-sampling weights
-    if (const float* w = b.need("dec.fc.fc.weight", (int64_t)p->hop * D * D))
+    const float* w = b.need("dec.fc.fc.weight", (int64_t)p->hop * D * D);
+    const float* wo = b.need("enc.fc_out.weight", (int64_t)D * D);
+    const char* cenv = getenv("MMK_S2S_COMPOSED");
+    if (w && wo && !(cenv && cenv[0] == '0')) {
+      hipLaunchKernelGGL(s2s_compose_kernel, dim3((D + 255) / 256, p->hop * D), dim3(256), 0, st, w, wo, p->hop * D, D, p->compose_tmp);
+      MMK_HIP(hipGetLastError());
+      w = p->compose_tmp;
+      p->fc_composed = true;
+    }
+    if (w)
       MMK_TRY(pack_rect(p->dec_fc.Wp, p->dec_fc.k_chunks, 0, 1, p->hop * D, 0, D, w, D, 1, st));
     if (const float* bb = b.need("dec.fc.fc.bias", (int64_t)p->hop * D)) MMK_TRY(pack_bias(p->dec_fc.bias, 0, 1, p->hop * D, bb, 0, st));
   }
@@ -334,9 +381,16 @@ static int s2s_step(mmk_s2s_plan* p, int M, const float* x, int64_t xbs, int64_t
   const float* xl = p->xin;
   int xl_ld = p->in_pad;
   float* fold = p->ysum;
+  bool pooled = false;
   for (size_t n = 0; n < p->enc.size(); ++n) {
     MMK_TRY(run_bilstm(p, p->enc[n], xl, xl_ld, M, true, st));
     const float* res = (n > 0 && c.enc_apply_residuals) ? xl : nullptr;
+    if (n + 1 == p->enc.size() && c.enc_downsampling != 4) {   // last layer: fold + pool in one launch
+      hipLaunchKernelGGL(pair_sum_pool_kernel, dim3(M), dim3(256), 0, st, p->of, p->ob, D, hop, c.enc_downsampling, res, p->es);
+      MMK_HIP(hipGetLastError());
+      pooled = true;
+      break;
+    }
     hipLaunchKernelGGL(pair_sum_kernel, dim3(rows), dim3(256), 0, st, p->of, p->ob, D, rows, res, fold);
     MMK_HIP(hipGetLastError());
     xl = fold; xl_ld = D;
@@ -345,14 +399,15 @@ static int s2s_step(mmk_s2s_plan* p, int M, const float* x, int64_t xbs, int64_t
   if (c.enc_downsampling == 4) {
     // rows (b hop + t) -> D / hop features each: (M, hop, D / hop) contiguous IS the reshape to (M, 1, D)   (resamplers.py:21-23)
     MMK_TRY(plain_linear(p->enc_fc, xl, D, rows, p->es, D / hop, ACT_NONE, st));
-  } else {
+  } else if (!pooled) {
     hipLaunchKernelGGL(pool_frames_kernel, dim3(M), dim3(256), 0, st, xl, D, hop, c.enc_downsampling, p->es);
     MMK_HIP(hipGetLastError());
   }
-  MMK_TRY(plain_linear(p->fc_out, p->es, D, M, p->coded, D, ACT_NONE, st));
+  const bool composed_up = c.dec_upsampling == 0 && p->fc_composed;
+  if (!composed_up) MMK_TRY(plain_linear(p->fc_out, p->es, D, M, p->coded, D, ACT_NONE, st));
   // decoder: up-sampling to hop frames, every bi-LSTM seeded with the LAST encoder layer's (h_n, c_n)  (:158-171)
   if (c.dec_upsampling == 0) {
-    MMK_TRY(plain_linear(p->dec_fc, p->coded, D, M, p->z, (int64_t)hop * D, ACT_NONE, st));
+    MMK_TRY(plain_linear(p->dec_fc, composed_up ? p->es : p->coded, D, M, p->z, (int64_t)hop * D, ACT_NONE, st));
   } else if (c.dec_upsampling == 1) {
     hipLaunchKernelGGL(repeat_rows_kernel, dim3(rows), dim3(256), 0, st, p->coded, D, hop, p->z);
     MMK_HIP(hipGetLastError());
@@ -379,6 +434,16 @@ static int s2s_step(mmk_s2s_plan* p, int M, const float* x, int64_t xbs, int64_t
     MMK_HIP(hipGetLastError());
     xl = fold;
     fold = fold == p->ysum ? p->yalt : p->ysum;
+  }
+  {
+    // the output projection writes the caller's (batch, frame, bin) rows itself when the tiled kernel takes it
+    static const bool tiled = [] { const char* e = getenv("MMK_S2S_GEMM"); return !(e && e[0] == '0'); }();
+    const PackedLinear& w = p->out_lin;
+    if (tiled && w.nseg == 1 && gemm_bias_act_supported(xl, D, rows, w.segK[0])) {
+      GemmRowMap rm;
+      rm.group = hop; rm.kept = n_out; rm.group_stride = ybs; rm.row_stride = yfs;
+      return launch_gemm_bias_act(xl, D, w.Wp, w.bias, w.n_tiles, w.k_chunks, w.N, w.segK[0], y, 0, rows, c.out_abs ? ACT_ABS : ACT_NONE, st, rm);
+    }
   }
   MMK_TRY(plain_linear(p->out_lin, xl, D, rows, p->yout, p->out_pad, c.out_abs ? ACT_ABS : ACT_NONE, st));
   hipLaunchKernelGGL(scatter_frames_kernel, dim3(rows), dim3(256), 0, st, p->yout, p->out_pad, hop, n_out, c.out_dim, y,
