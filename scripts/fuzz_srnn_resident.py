@@ -1,0 +1,50 @@
+"""One-off stress of the SampleRNN resident mode: random geometries / batch sizes / block splits, resident against non-resident
+(same kernels, same arithmetic: the classes must be identical) and repeated runs against each other (hand-over races would show
+as differences).  python scripts/fuzz_srnn_resident.py [n_cases]"""
+import os
+import random
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ["MMK_SRNN_FUSED"] = "1"
+import mimikit_amd as mmk  # noqa: E402
+from tests import helpers as H  # noqa: E402
+
+torch.set_grad_enabled(False)
+device = torch.device("cuda", 0)
+rng = random.Random(7)
+n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 24
+FS = [(16, 4, 1), (4, 1), (32, 8, 2), (64, 16, 4, 4), (8, 2, 2), (16, 8, 8), (16, 16, 1)]
+bad = 0
+for case in range(n_cases):
+    fs = rng.choice(FS)
+    hidden = rng.choice([128, 256, 512])
+    kind = rng.choice(["gru", "lstm"])
+    B = rng.choice([1, 3, 16, 17, 33, 64])
+    P = fs[0] * rng.randint(1, 3) + rng.randint(0, fs[0] - 1)
+    n = fs[0] * rng.randint(2, 6) + rng.randint(0, 7)
+    cut = rng.randint(fs[0], n - 1) if n > fs[0] + 1 else n
+    temp = None if rng.random() < 0.5 else torch.tensor([rng.uniform(0.5, 1.5) for _ in range(B)])
+    prompt = torch.randint(0, 256, (B, P), generator=torch.Generator().manual_seed(case))
+    outs = []
+    for resident, split in (("1", False), ("1", True), ("1", False), ("0", False)):
+        os.environ["MMK_SRNN_RESIDENT"] = resident
+        net, _, _ = H.srnn("big", hidden=hidden, mlp_dim=128, seed=200 + case, frame_sizes=fs, kind=kind)
+        net = net.to(device)
+        idx = torch.cat([prompt, torch.zeros(B, n, dtype=torch.int64)], 1).to(device)
+        torch.manual_seed(1000 + case)
+        net.before_generate((idx[:, :P],), None)
+        if split and temp is None:
+            net.generate_block((idx,), P, cut)
+            net.generate_block((idx,), P + cut, n - cut)
+        else:
+            net.generate_block((idx,), P, n, **({} if temp is None else {"temperature": temp}))
+        net.after_generate((idx,), None)
+        outs.append(idx.cpu())
+    same = all(torch.equal(o, outs[0]) for o in outs[1:])
+    print(f"case {case:2d}: fs={fs} H={hidden} {kind} B={B} P={P} n={n} cut={cut} sampled={temp is not None}: {'ok' if same else 'MISMATCH'}")
+    bad += 0 if same else 1
+print("mismatching cases:", bad)
+sys.exit(1 if bad else 0)
