@@ -222,6 +222,11 @@ struct GemmRowMap {
 int launch_gemm_bias_act(const float* A, int64_t lda, const float* Wp, const float* bias, int n_tiles, int k_chunks, int N, int K, float* C,
                          int64_t ldc, int M, int act, hipStream_t stream, GemmRowMap rm = GemmRowMap());
 
+// C[M <= 64, N] = act(A . W^T + bias) for few rows against a large packed matrix (skinny.hip)
+bool skinny_linear_supported(const float* A, int64_t lda, int M, int K, int k_chunks);
+int launch_skinny_linear(const float* A, int64_t lda, const float* Wp, const float* bias, int n_tiles, int k_chunks, int N, int K, float* C,
+                         int64_t ldc, int M, int act, hipStream_t stream);
+
 // recurrent cells (elementwise)
 int launch_gru_cell(const float* gi, const float* gh, float* h, int M, int H, hipStream_t stream);
 int launch_lstm_cell(const float* gates, int64_t gates_ld, const float* gadd, int64_t gadd_ld, float* h, int64_t h_ld,

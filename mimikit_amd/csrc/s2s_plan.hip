@@ -308,6 +308,10 @@ static int plain_linear(const PackedLinear& w, const float* x, int64_t ldx, int 
   static const bool tiled = [] { const char* e = getenv("MMK_S2S_GEMM"); return !(e && e[0] == '0'); }();
   if (tiled && w.nseg == 1 && gemm_bias_act_supported(x, ldx, M, w.segK[0]))
     return launch_gemm_bias_act(x, ldx, w.Wp, w.bias, w.n_tiles, w.k_chunks, w.N, w.segK[0], y, ldy, M, act, st);
+  // few rows against a large matrix (dec.fc, enc.fc_out): the weight-streaming kernel; MMK_S2S_SKINNY=0 keeps the row-tile one
+  static const bool skinny = [] { const char* e = getenv("MMK_S2S_SKINNY"); return !(e && e[0] == '0'); }();
+  if (skinny && w.nseg == 1 && w.n_tiles >= 32 && skinny_linear_supported(x, ldx, M, w.segK[0], w.k_chunks))
+    return launch_skinny_linear(x, ldx, w.Wp, w.bias, w.n_tiles, w.k_chunks, w.N, w.segK[0], y, ldy, M, act, st);
   LinearArgs a = {};
   w.fill(a);
   a.seg[0].x = addr_static(x);
