@@ -1173,6 +1173,7 @@ extern "C" int mmk_wavenet_sync_status(mmk_wavenet_plan* p, mmk_stream_t stream)
   MMK_HIP(hipMemcpy(&flag, p->err_flag, sizeof(flag), hipMemcpyDeviceToHost));
   if (flag == 2)
     return fail(MMK_ERR_STATE, "wavenet: the persistent kernel's workgroups were not spread 8 x %d over the XCDs; rerun with MMK_WN_XCD_LOCAL=0 (agent-scope hand-offs)", p->Gn);
+  if (const char* fe = getenv("MMK_WN_FORCE_SYNC_ERROR"); fe && fe[0] == '1') flag = 1;   // test hook: exercise the callers' retry path
   if (flag != 0)
     return fail(MMK_ERR_STATE, "wavenet: a hand-off inside the persistent kernel timed out - its workgroups were not all resident (another kernel "
                 "holding CUs?); the samples of this call are invalid, rerun it (MMK_WN_PERSISTENT=0 selects the per-layer launch path)");

@@ -452,6 +452,7 @@ class WaveNet(ARM, nn.Module):
         prompts = tuple(prompts)
         native.require_device(*prompts)
         batch, length, rf = prompts[0].size(0), prompts[0].size(1), self.rf
+        self._blocks = []                       # the generate_block calls since this warm-up (replayed if the kernel reports a timeout)
         self._ensure_plan(batch, refresh_weights=True)
         if length < rf:
             # the reference fails at its first step on such a prompt (negative window start)
@@ -495,11 +496,43 @@ class WaveNet(ARM, nn.Module):
         temp, uni = self._sampling(batch, n_steps, parameters)
         self._plan.generate(in0, cond, t0, n_steps, temp, uni, t_first=0)
         self._next_t = t0 + n_steps
+        if self._plan.persistent:
+            getattr(self, "_blocks", []).append((tensors, t0, n_steps, dict(parameters)))
         return True
 
     def after_generate(self, final_outputs: Tuple[torch.Tensor, ...], batch_index) -> None:
         self._next_t = None
         if self._plan is not None and self._plan.persistent:
-            # the loop reads the outputs right after this call anyway; surface a hand-off timeout
-            # of the persistent kernel as an exception instead of silently returning blanks
-            self._plan.sync_status()
+            # the loop reads the outputs right after this call anyway: a hand-off timeout of the persistent kernel (its
+            # workgroups were not all resident - another kernel held CUs) must not return blanks.  The generation is redone
+            # once on the per-layer launch path, which needs no co-residency; if that is not possible the error is raised.
+            try:
+                self._plan.sync_status()
+            except native.NativeError as err:
+                self._redo_on_launch_path(err)
+
+    def _redo_on_launch_path(self, err):
+        import os
+        import warnings
+        blocks, self._blocks = getattr(self, "_blocks", []), []
+        if not blocks or getattr(self, "_redoing", False):
+            raise err
+        warnings.warn(f"{err}; regenerating this batch on the per-layer launch path")
+        old = os.environ.get("MMK_WN_PERSISTENT")
+        os.environ["MMK_WN_PERSISTENT"] = "0"
+        self._redoing = True
+        try:
+            self._plan = None                   # the mode is chosen when the plan is created
+            first_tensors, first_t0 = blocks[0][0], blocks[0][1]
+            self.before_generate(tuple(x[:, :first_t0] for x in first_tensors), None)
+            for tensors, t0, n_steps, params in blocks:
+                self.generate_block(tensors, t0, n_steps, **params)
+            torch.cuda.synchronize(self.device)
+        finally:
+            self._redoing = False
+            if old is None:
+                os.environ.pop("MMK_WN_PERSISTENT", None)
+            else:
+                os.environ["MMK_WN_PERSISTENT"] = old
+            self._plan = None                   # the next generation gets a persistent plan again
+            self._next_t = None

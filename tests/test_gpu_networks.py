@@ -592,6 +592,32 @@ MODES = {"persistent_xcd": {}, "persistent_agent": {"MMK_WN_XCD_LOCAL": "0"}, "p
          "two_handoffs_step_warmup": {"MMK_WN_CHAIN": "0", "MMK_WN_PREFILL": "0"}, "pipelined": {"MMK_WN_PIPE": "1"}}
 
 
+def test_wavenet_timeout_is_redone_on_launch_path(device, monkeypatch):
+    """a hand-off timeout reported by the persistent kernel (forced here through the library's test hook) must not return
+    blanks: the batch is regenerated on the per-layer launch path, with a warning; both generations are held to the oracle the way
+    the modes test does (the two paths associate their sums differently)"""
+    for k in ("MMK_WN_XCD_LOCAL", "MMK_WN_PERSISTENT", "MMK_WN_GROUPS", "MMK_WN_SMALL", "MMK_WN_PREFILL", "MMK_WN_CHAIN", "MMK_WN_PIPE"):
+        monkeypatch.delenv(k, raising=False)
+    net, sd, arch = _cond_net()
+    net = net.to(device)
+    gen = torch.Generator().manual_seed(23)
+    rf, n, B = net.rf, 40, 3
+    prompt = torch.randint(0, 256, (B, rf + 5), generator=gen)
+    cond = torch.rand(B, rf + 5 + n, 12, generator=gen)
+    want, raw = O.wavenet_generate(sd, prompt, (cond,), n, keep_logits=True, **arch)
+    ok = H.margin_ok(raw.numpy())
+    first_bad = (~ok).float().cumsum(1) > 0
+    monkeypatch.setenv("MMK_WN_FORCE_SYNC_ERROR", "1")
+    idx = torch.cat([prompt, torch.zeros(B, n, dtype=torch.int64)], 1).to(device)
+    net.generate_block((idx, cond.to(device)), prompt.size(1), n)
+    assert net._plan.persistent
+    with pytest.warns(UserWarning, match="launch path"):
+        net.after_generate((idx,), None)
+    same = idx.cpu()[:, prompt.size(1):] == want[:, prompt.size(1):]
+    assert bool((same | first_bad).all()) and float(ok.float().mean()) > 0.9
+    assert net._plan is None                      # the next generation starts on a fresh (persistent) plan
+
+
 @pytest.mark.parametrize("mode", list(MODES))
 def test_wavenet_modes_agree_with_oracle(device, mode, monkeypatch):
     """the persistent kernels - one hand-off per layer (wavenet_chain.hip) and two (wavenet_persist.hip), XCD-local and
