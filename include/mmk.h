@@ -273,6 +273,9 @@ int mmk_srnn_warmup(mmk_srnn_plan* plan, int32_t batch, const int64_t* idx, int6
 int mmk_srnn_generate(mmk_srnn_plan* plan, int32_t batch, int64_t* idx, int64_t idx_row_stride, int64_t t0,
                       int64_t n_steps, const float* temperature, const float* uniforms, mmk_stream_t stream);
 int mmk_srnn_last_logits(mmk_srnn_plan* plan, int32_t batch, float* out, int64_t ld, mmk_stream_t stream);
+/* waits for the stream; fails (and clears the word) if a wait inside the tier / bottom kernels timed out since the last call -
+ * the samples of that generation are invalid (MMK_SRNN_FORCE_SYNC_ERROR=1: test hook, always reports one) */
+int mmk_srnn_sync_status(mmk_srnn_plan* plan, mmk_stream_t stream);
 /* diagnostic: generate blocks this plan has run in resident mode (the bottom tier as one launch beside the tier kernels of a
  * second stream) since it was created; tests assert that the mode they mean to cover is the one that ran */
 int64_t mmk_srnn_resident_blocks(const mmk_srnn_plan* plan);

@@ -833,6 +833,23 @@ extern "C" int mmk_srnn_generate(mmk_srnn_plan* p, int32_t batch, int64_t* idx, 
   return run_steps(p, call, t0, n_steps, true, (hipStream_t)stream);
 }
 
+extern "C" int mmk_srnn_sync_status(mmk_srnn_plan* p, mmk_stream_t stream) {
+  if (!p) return fail(MMK_ERR_INVALID, "srnn_sync_status: null plan");
+  hipStream_t st = (hipStream_t)stream;
+  MMK_HIP(hipStreamSynchronize(st));
+  if (!p->committed) return MMK_OK;
+  int64_t err = 0;
+  MMK_HIP(hipMemcpy(&err, p->tau + 4, sizeof(err), hipMemcpyDeviceToHost));
+  if (const char* fe = getenv("MMK_SRNN_FORCE_SYNC_ERROR"); fe && fe[0] == '1' && p->resident_blocks > 0) err = 4;   // test hook
+  if (err != 0) {
+    MMK_HIP(hipMemset(p->tau + 4, 0, sizeof(int64_t)));
+    return fail(MMK_ERR_STATE, "srnn: a wait inside the tier / bottom kernels timed out (code %lld: 3 tier hand-over, 4 bottom kernel waiting for the tiers, "
+                "5 tier kernel waiting for the bottom kernel) - the kernels were not running side by side; the samples of this generation are invalid",
+                (long long)err);
+  }
+  return MMK_OK;
+}
+
 extern "C" int64_t mmk_srnn_resident_blocks(const mmk_srnn_plan* p) { return p ? p->resident_blocks : 0; }
 
 extern "C" int mmk_srnn_last_logits(mmk_srnn_plan* p, int32_t batch, float* out, int64_t ld, mmk_stream_t stream) {

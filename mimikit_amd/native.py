@@ -94,6 +94,7 @@ _SIGNATURES = {
     "mmk_srnn_generate": (i32, [vp, i32, vp, i64, i64, i64, vp, vp, vp]),
     "mmk_srnn_last_logits": (i32, [vp, i32, vp, i64, vp]),
     "mmk_srnn_resident_blocks": (i64, [vp]),
+    "mmk_srnn_sync_status": (i32, [vp, vp]),
     "mmk_s2s_plan_create": (i32, [C.POINTER(S2SConfig), C.POINTER(vp)]),
     "mmk_s2s_plan_destroy": (None, [vp]),
     "mmk_s2s_plan_bind": (i32, [vp, cp, vp, i64]),
@@ -513,6 +514,10 @@ class SrnnPlan(_Plan):
         check(self._lib.mmk_srnn_generate(self.handle, idx.shape[0], abs_ptr(idx, t_first), idx.stride(0), t0, n_steps,
                                           ptr(temperature), ptr(uniforms), stream_ptr(self.device)),
               "mmk_srnn_generate")
+
+    def sync_status(self):
+        """wait for the stream and raise if a wait inside the resident-mode kernels timed out"""
+        check(self._lib.mmk_srnn_sync_status(self.handle, stream_ptr(self.device)), "mmk_srnn_sync_status")
 
     def resident_blocks(self) -> int:
         """generate blocks run in resident mode so far (diagnostic, see include/mmk.h)"""

@@ -284,6 +284,7 @@ class SampleRNN(ARMWithHidden, nn.Module):
         native.require_device(*prompts)
         idx = prompts[0]
         batch, length = idx.size(0), idx.size(1)
+        self._blocks = []                       # the generate_block calls since this warm-up (replayed after a reported timeout)
         self._ensure_plan(batch, refresh_weights=True)   # also resets the hidden state
         offset = length % self.rf
         self.prompt_length = length - offset
@@ -324,8 +325,40 @@ class SampleRNN(ARMWithHidden, nn.Module):
         temp, uni = self._sampling(batch, n_steps, parameters)
         self._plan.generate(idx, t0, n_steps, temp, uni, t_first=0)
         self._next_t = t0 + n_steps
+        getattr(self, "_blocks", []).append((tensors, t0, n_steps, dict(parameters)))
         return True
 
     def after_generate(self, final_outputs: Tuple[torch.Tensor, ...], batch_index) -> None:
         self.outputs = []
+        if self._plan is not None and self._plan.resident_blocks() != getattr(self, "_resident_seen", 0):   # (a new plan counts from 0)
+            # resident mode relies on the tier kernels and the bottom kernel running side by side; a wait that timed out (the
+            # CUs were held by something else) leaves invalid samples: regenerate the batch once with the kernels in turns
+            self._resident_seen = self._plan.resident_blocks()
+            try:
+                self._plan.sync_status()
+            except native.NativeError as err:
+                self._redo_in_turns(err)
         self.reset_hidden()
+
+    def _redo_in_turns(self, err):
+        import os
+        import warnings
+        blocks, self._blocks = getattr(self, "_blocks", []), []
+        if not blocks or getattr(self, "_redoing", False):
+            raise err
+        warnings.warn(f"{err}; regenerating this batch with the tier and bottom kernels in turns")
+        old = os.environ.get("MMK_SRNN_RESIDENT")
+        os.environ["MMK_SRNN_RESIDENT"] = "0"
+        self._redoing = True
+        try:
+            first_tensors, first_t0 = blocks[0][0], blocks[0][1]
+            self.before_generate((first_tensors[0][:, :first_t0],), None)
+            for tensors, t0, n_steps, params in blocks:
+                self.generate_block(tensors, t0, n_steps, **params)
+            torch.cuda.synchronize(self.device)
+        finally:
+            self._redoing = False
+            if old is None:
+                os.environ.pop("MMK_SRNN_RESIDENT", None)
+            else:
+                os.environ["MMK_SRNN_RESIDENT"] = old

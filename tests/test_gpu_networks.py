@@ -349,6 +349,28 @@ def test_sample_rnn_resident_mode_geometries(device, monkeypatch, frame_sizes, b
     assert torch.equal(ref[:, P:][ok], got[:, P:][ok])
 
 
+def test_sample_rnn_timeout_is_redone_in_turns(device, monkeypatch):
+    """a timed-out wait of the resident mode (forced through the library's test hook) must not return invalid samples: the batch
+    is regenerated with the kernels in turns, with a warning, and equals an undisturbed generation"""
+    monkeypatch.setenv("MMK_SRNN_FUSED", "1")
+    net, sd, arch = H.srnn("big", hidden=128, mlp_dim=64, seed=93, frame_sizes=(16, 4, 1), kind="gru")
+    net = net.to(device)
+    prompt = torch.randint(0, 256, (5, 32), generator=torch.Generator().manual_seed(3))
+
+    def generate():
+        idx = torch.cat([prompt, torch.zeros(5, 80, dtype=torch.int64)], 1).to(device)
+        net.before_generate((idx[:, :32],), None)
+        net.generate_block((idx,), 32, 80)
+        net.after_generate((idx,), None)
+        return idx.cpu()
+
+    want = generate()
+    monkeypatch.setenv("MMK_SRNN_FORCE_SYNC_ERROR", "1")
+    with pytest.warns(UserWarning, match="in turns"):
+        got = generate()
+    assert torch.equal(got, want)
+
+
 def test_sample_rnn_resident_mode_sampled_decode_and_reuse(device, monkeypatch):
     """resident mode with temperatures (uniforms indexed by the absolute step) and a second generation on the same plan
     (the granules of the first one must not satisfy the second one's waits)"""
