@@ -59,6 +59,29 @@ __device__ __forceinline__ int wave_max_dpp_i(int v) {
              max(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
 }
 
+// argmax with torch.argmax's tie rule (the first maximum wins), every lane of the wave holding a candidate (value, index):
+// DPP inside the rows, four scalar reads across them
+__device__ __forceinline__ int wave_argmax_first(float best, int bi) {
+  auto take = [&](float ob, int oi) {
+    if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+  };
+#define MMK_ARGMAX_STEP(CTRL) take(MMK_DPP_F(best, best, CTRL, 0xf), MMK_DPP_I(bi, bi, CTRL, 0xf))
+  MMK_ARGMAX_STEP(0xB1);
+  MMK_ARGMAX_STEP(0x4E);
+  MMK_ARGMAX_STEP(0x141);
+  MMK_ARGMAX_STEP(0x140);
+#undef MMK_ARGMAX_STEP
+  float rb = readlane_f(best, 0);
+  int ri = __builtin_amdgcn_readlane(bi, 0);
+#pragma unroll
+  for (int row = 1; row < 4; ++row) {
+    const float ob = readlane_f(best, 16 * row);
+    const int oi = __builtin_amdgcn_readlane(bi, 16 * row);
+    if (ob > rb || (ob == rb && oi < ri)) { rb = ob; ri = oi; }
+  }
+  return ri;
+}
+
 // lg: the row's 256 class logits (16-byte aligned, LDS or global); scale_by_denom: the learned-temperature divisor applies
 __device__ __forceinline__ int sample_256(const float* lg, bool scale_by_denom, float denom, float T, float uniform, int lane) {
   typedef float f32x4_ __attribute__((ext_vector_type(4)));

@@ -516,23 +516,7 @@ __global__ __launch_bounds__(kBotThreads) void srnn_bottom1_kernel(const SrnnBot
           }
         }
       }
-      auto take = [&](float ob, int oi) {     // first maximum wins (torch.argmax)
-        if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
-      };
-#define MMK_DPP_STEP(CTRL)                                                                                         \
-      take(__int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(best), CTRL, 0xf, 0xf, false)),            \
-           __builtin_amdgcn_update_dpp(0, bi, CTRL, 0xf, 0xf, false))
-      MMK_DPP_STEP(0xB1);
-      MMK_DPP_STEP(0x4E);
-      MMK_DPP_STEP(0x141);
-      MMK_DPP_STEP(0x140);
-#undef MMK_DPP_STEP
-#pragma unroll
-      for (int o = 16; o <= 32; o <<= 1) {
-        const float ob = __shfl_xor(best, o);
-        const int oi = __shfl_xor(bi, o);
-        take(ob, oi);
-      }
+      bi = wave_argmax_first(best, bi);        // first maximum wins (torch.argmax)
       result = bi;
     } else if (nc == 256) {
       result = sample_256(lg, a.learn_temp != 0, denom, a.temperature[clip], a.uniforms[(int64_t)clip * a.uni_ld + t + a.uni_off], lane);
