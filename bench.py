@@ -553,7 +553,7 @@ def main():
         roof = job.roofline()
         if roof is not None:
             line["roofline"] = roof
-        if not args.no_cpu_baseline and not args.temperature > 0:    # the CPU leg re-checks the GREEDY samples
+        if world == 1 and not args.no_cpu_baseline and not args.temperature > 0:    # N = 1 only; the CPU leg re-checks the GREEDY samples
             line["cpu_baseline"] = job.cpu_baseline(args.cpu_seconds)
         print(json.dumps(line), flush=True)
     if world > 1:
