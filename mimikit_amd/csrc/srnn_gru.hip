@@ -13,6 +13,15 @@
 // the up-sampling launch that follows uses as its position counter.
 // LSTM tiers (the reference's default rnn_class) run through the same kernel: eight tiles (i, f, g, o of W_ih and W_hh,
 // which the plan packs side by side along K), the ATen LSTMCell, and a cell state updated in place.
+//
+// Round 2.  (1) Second phase in the same launch: the tier's up-sampler, out = W_up h' + b.  The new state goes out as data-tagged
+// granules {update number, value}; a workgroup polls the state of ITS OWN 16 clips (32 KB at H = 512; a light sentinel poll by one
+// wave first) and multiplies its `up` column tiles, slot 0 - the row the tier below needs first - ahead of the others.
+// (2) Resident mode (srnn_plan.hip: run_resident): the bottom tier runs beside this launch as one long kernel; its newest classes
+// are polled as granules (`gate_cls`), and the up-sampled rows are published as granules (`up_gran`) as well.  Everything that
+// does not depend on the newest classes - weights, W_hh h, biases, up-sampler tiles - is done before that poll.
+// (3) Composed mode (frame sizes <= 16): W_ih x = W_ih (b_in + upper) + (W_ih W_in) lin(window); the first product joins the
+// work ahead of the poll, the second is a K = fs dot product per (clip, gate unit) in the cell.
 #include <type_traits>
 
 #include "mmk_common.h"
