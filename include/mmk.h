@@ -295,6 +295,14 @@ typedef struct mmk_s2s_config {
   int32_t dec_upsampling;                  /* 0 linear_resample, 1 repeat             (:158-163) */
   int32_t enc_apply_residuals;             /* x = x + y from the second encoder layer on (:101-104) */
   int32_t dec_apply_residuals;             /* x = x + y after every decoder layer       (:175-178) */
+  /* discrete IO (IOSpec.mulaw_io with an embedding input, tests/test_seq2seq.py:149-154): */
+  int32_t in_classes;                      /* > 0: inputs are class indices through nn.Embedding(in_classes, model_dim)
+                                              under ZipReduceVariables (:205-210); in_dim must equal model_dim */
+  int32_t head_kind;                       /* 0: Linear [+ Abs] to out_dim bins; 1: MLP (networks/mlp.py:42-63) over out_dim
+                                              classes, then the argmax of CategoricalSampler (modules/targets.py:43-44) */
+  int32_t mlp_hidden, mlp_n_hidden;        /* head_kind 1: width, number of extra hidden blocks (0 .. 4) */
+  int32_t learn_temp;                      /* head_kind 1: one more output, logits / max(sigmoid(it), min_temp) */
+  float min_temp;
 } mmk_s2s_config;
 
 typedef struct mmk_s2s_plan mmk_s2s_plan;
@@ -314,6 +322,17 @@ int mmk_s2s_step(mmk_s2s_plan* plan, int32_t batch, const float* x, int64_t x_ba
  * frames at t0 + i*hop (clipped at t_total), as loops/generate.py:207-219 does. */
 int mmk_s2s_generate(mmk_s2s_plan* plan, int32_t batch, float* frames, int64_t batch_stride,
                      int64_t frame_stride, int64_t t0, int64_t n_steps, int64_t t_total, mmk_stream_t stream);
+
+/* The same two calls for a plan with in_classes > 0 and head_kind 1: x / y / classes hold int64 class indices, one per
+ * (clip, position); generate_step hands the sampler no temperature (s2s_lstm_v2.py:262-263), so every class is an argmax. */
+int mmk_s2s_step_classes(mmk_s2s_plan* plan, int32_t batch, const int64_t* x, int64_t x_batch_stride,
+                         int64_t x_elem_stride, int64_t* y, int64_t y_batch_stride, int64_t y_elem_stride,
+                         mmk_stream_t stream);
+int mmk_s2s_generate_classes(mmk_s2s_plan* plan, int32_t batch, int64_t* classes, int64_t batch_stride,
+                             int64_t elem_stride, int64_t t0, int64_t n_steps, int64_t t_total, mmk_stream_t stream);
+/* the MLP head's outputs (before the learned-temperature division) of the last step: (batch * hop, out_dim + learn_temp)
+ * rows (clip-major) copied to `out` with leading dimension out_ld - what the parity tests compare with the oracle's */
+int mmk_s2s_last_logits(mmk_s2s_plan* plan, int32_t batch, float* out, int64_t out_ld, mmk_stream_t stream);
 
 #ifdef __cplusplus
 }

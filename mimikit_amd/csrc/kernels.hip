@@ -243,7 +243,13 @@ __global__ __launch_bounds__(64) void sample_kernel(const SampleArgs a) {
     }
     result = pick;
   }
-  if (lane == 0) a.out[(int64_t)row * a.out_row_stride + tau + a.out_tau_off] = result;
+  if (lane == 0) {
+    if (a.group > 0) {
+      if (row % a.group < a.kept) a.out[(int64_t)(row / a.group) * a.group_stride + (int64_t)(row % a.group) * a.out_row_stride + tau + a.out_tau_off] = result;
+    } else {
+      a.out[(int64_t)row * a.out_row_stride + tau + a.out_tau_off] = result;
+    }
+  }
 }
 
 int launch_sample(const SampleArgs& a, hipStream_t stream) {

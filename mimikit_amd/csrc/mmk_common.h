@@ -193,6 +193,9 @@ struct SampleArgs {
   int64_t uniform_ld; int64_t uni_off;
   int64_t* out; int64_t out_row_stride; int64_t out_tau_off;  // out[r*stride + tau + out_tau_off]
   const int64_t* tau_ptr; int64_t tau_off;
+  // group > 0: row r = (g, i) = (r / group, r % group) is written to out[g * group_stride + i * out_row_stride + ...], rows with
+  // i >= kept are not written (the hop classes of a Seq2Seq step; clipped at the end of the tensor)
+  int32_t group; int32_t kept; int64_t group_stride;
 };
 int launch_sample(const SampleArgs& a, hipStream_t stream);
 

@@ -25,6 +25,20 @@ __global__ void gather_frames_kernel(const float* __restrict__ x, int64_t bs, in
   for (int c = threadIdx.x; c < out_ld; c += blockDim.x) dst[c] = c < dim ? src[c] : 0.f;
 }
 
+// class indices (batch, hop) -> rows (b*hop + t) of the embedding table: nn.Embedding under ZipReduceVariables, whose weight for
+// a single input is 1 (s2s_lstm_v2.py:205-210, modules/io.py:299-313).  An index outside the table (torch raises for it) reads
+// the nearest row.
+__global__ void embed_rows_kernel(const int64_t* __restrict__ idx, int64_t bs, int64_t es, int hop, int n_classes, int dim,
+                                  const float* __restrict__ table, float* __restrict__ out, int out_ld) {
+  const int row = blockIdx.x;  // b*hop + t
+  const int b = row / hop, t = row % hop;
+  int64_t k = idx[b * bs + t * es];
+  k = k < 0 ? 0 : (k >= n_classes ? n_classes - 1 : k);
+  const float* src = table + k * dim;
+  float* dst = out + (int64_t)row * out_ld;
+  for (int c = threadIdx.x; c < out_ld; c += blockDim.x) dst[c] = c < dim ? src[c] * 1.f : 0.f;
+}
+
 // scatter rows (b*hop + t) to a strided (batch, n_out<=hop, dim) destination
 __global__ void scatter_frames_kernel(const float* __restrict__ in, int in_ld, int hop, int n_out, int dim,
                                       float* __restrict__ y, int64_t bs, int64_t fs) {
@@ -133,6 +147,11 @@ struct mmk_s2s_plan {
   float* compose_tmp = nullptr;                  // (hop D, D): dec.fc . enc.fc_out, row-major, before it is packed
   bool fc_composed = false;                      // dec_fc holds the pre-multiplied matrix: the coded frame is never materialised
   float *hs[2] = {nullptr, nullptr}, *cs[2] = {nullptr, nullptr};   // the encoder's final state: every decoder layer starts from it
+  // discrete IO: the embedding table (a copy: in_classes x D), the MLP head's Linears, its hidden rows and raw outputs
+  float* embed = nullptr;
+  std::vector<PackedLinear> mlp;
+  float *hid[2] = {nullptr, nullptr}, *logits = nullptr;
+  int logits_ld = 0;
 
   void layout(Carver& cv) {
     for (auto& l : enc) for (int d = 0; d < 2; ++d) { l.ih[d].carve(cv, true); l.hh[d].carve(cv, false); }
@@ -140,8 +159,16 @@ struct mmk_s2s_plan {
     fc_out.carve(cv, false);
     if (cfg.enc_downsampling == 4) enc_fc.carve(cv, true);
     dec_fc.carve(cv, true);
-    out_lin.carve(cv, true);
     const int64_t rows = (int64_t)Bmax * hop;
+    if (cfg.head_kind == 1) {
+      for (auto& m : mlp) m.carve(cv, true);
+      hid[0] = cv.take<float>(rows * cfg.mlp_hidden);
+      hid[1] = cv.take<float>(rows * cfg.mlp_hidden);
+      logits = cv.take<float>(rows * logits_ld);
+    } else {
+      out_lin.carve(cv, true);
+    }
+    if (cfg.in_classes > 0) embed = cv.take<float>((int64_t)cfg.in_classes * D);
     xin = cv.take<float>(rows * in_pad);
     gi[0] = cv.take<float>(rows * 4 * D);
     gi[1] = cv.take<float>(rows * 4 * D);
@@ -171,6 +198,13 @@ static int derive(mmk_s2s_plan* p) {
   if (c.enc_downsampling == 4 && c.model_dim % c.hop != 0)
     return fail(MMK_ERR_INVALID, "s2s: enc_downsampling='linear_resample' needs hop (%d) to divide model_dim (%d)", c.hop, c.model_dim);
   if (c.model_dim % 2 != 0) return fail(MMK_ERR_UNSUPPORTED, "s2s: model_dim must be even");
+  if (c.in_classes < 0 || (c.in_classes > 0 && c.in_dim != c.model_dim))
+    return fail(MMK_ERR_INVALID, "s2s: an embedding input has in_dim == model_dim (got %d, %d)", c.in_dim, c.model_dim);
+  if (c.head_kind < 0 || c.head_kind > 1) return fail(MMK_ERR_INVALID, "s2s: head_kind %d unknown", c.head_kind);
+  if (c.head_kind == 1 && (c.mlp_hidden < 1 || c.mlp_n_hidden < 0 || c.mlp_n_hidden > MMK_MAX_MLP_HIDDEN))
+    return fail(MMK_ERR_INVALID, "s2s: bad MLP head geometry (hidden %d, %d extra blocks)", c.mlp_hidden, c.mlp_n_hidden);
+  if ((c.head_kind == 1) != (c.in_classes > 0))
+    return fail(MMK_ERR_UNSUPPORTED, "s2s: class indices in and out go together (in_classes %d, head_kind %d): the loop feeds outputs back", c.in_classes, c.head_kind);
   p->D = c.model_dim;
   p->hop = c.hop;
   p->Bmax = c.max_batch;
@@ -192,6 +226,20 @@ static int derive(mmk_s2s_plan* p) {
   if (c.enc_downsampling == 4) p->enc_fc.set_geometry(p->D / p->hop, {p->D});
   p->dec_fc.set_geometry(p->hop * p->D, {p->D});
   p->out_lin.set_geometry(c.out_dim, {p->D});
+  p->mlp.clear();
+  if (c.head_kind == 1) {   // Linear, Mish, [Linear, Mish] * n, Linear   (networks/mlp.py:42-53)
+    PackedLinear first, last;
+    first.set_geometry(c.mlp_hidden, {p->D});
+    p->mlp.push_back(first);
+    for (int i = 0; i < c.mlp_n_hidden; ++i) {
+      PackedLinear h;
+      h.set_geometry(c.mlp_hidden, {c.mlp_hidden});
+      p->mlp.push_back(h);
+    }
+    last.set_geometry(c.out_dim + (c.learn_temp ? 1 : 0), {c.mlp_hidden});
+    p->mlp.push_back(last);
+    p->logits_ld = (int)round_up(c.out_dim + (c.learn_temp ? 1 : 0), 4);
+  }
   const char* fenv = getenv("MMK_S2S_FUSED");
   p->fused_lstm = !(fenv && fenv[0] == '0') && lstm_step_supported(p->D);
   return MMK_OK;
@@ -294,9 +342,24 @@ extern "C" int mmk_s2s_commit(mmk_s2s_plan* p, void* workspace, size_t workspace
       MMK_TRY(pack_rect(p->dec_fc.Wp, p->dec_fc.k_chunks, 0, 1, p->hop * D, 0, D, w, D, 1, st));
     if (const float* bb = b.need("dec.fc.fc.bias", (int64_t)p->hop * D)) MMK_TRY(pack_bias(p->dec_fc.bias, 0, 1, p->hop * D, bb, 0, st));
   }
-  if (const float* w = b.need("output_module.heads.0.0.weight", (int64_t)c.out_dim * D))
-    MMK_TRY(pack_rect(p->out_lin.Wp, p->out_lin.k_chunks, 0, 1, c.out_dim, 0, D, w, D, 1, st));
-  if (const float* bb = b.need("output_module.heads.0.0.bias", c.out_dim)) MMK_TRY(pack_bias(p->out_lin.bias, 0, 1, c.out_dim, bb, 0, st));
+  if (c.head_kind == 1) {
+    const std::string hb = "output_module.heads.0.estimator.0.fc.";
+    for (size_t i = 0; i < p->mlp.size(); ++i) {
+      PackedLinear& m = p->mlp[i];
+      const std::string kb = hb + std::to_string(2 * i) + ".";
+      const float* w = b.need(kb + "weight", (int64_t)m.N * m.segK[0]);
+      const float* bb = b.need(kb + "bias", m.N);
+      if (w) MMK_TRY(pack_rect(m.Wp, m.k_chunks, 0, 1, m.N, 0, m.segK[0], w, m.segK[0], 1, st));
+      if (bb) MMK_TRY(pack_bias(m.bias, 0, 1, m.N, bb, 0, st));
+    }
+  } else {
+    if (const float* w = b.need("output_module.heads.0.0.weight", (int64_t)c.out_dim * D))
+      MMK_TRY(pack_rect(p->out_lin.Wp, p->out_lin.k_chunks, 0, 1, c.out_dim, 0, D, w, D, 1, st));
+    if (const float* bb = b.need("output_module.heads.0.0.bias", c.out_dim)) MMK_TRY(pack_bias(p->out_lin.bias, 0, 1, c.out_dim, bb, 0, st));
+  }
+  if (c.in_classes > 0)
+    if (const float* w = b.need("input_module.heads.0.0.weight", (int64_t)c.in_classes * D))
+      MMK_HIP(hipMemcpyAsync(p->embed, w, (size_t)c.in_classes * D * sizeof(float), hipMemcpyDeviceToDevice, st));
   if (!b.missing().empty()) return fail(MMK_ERR_KEY, "s2s_commit: state_dict tensor %s", b.missing().c_str());
   p->committed = true;
   return MMK_OK;
@@ -373,12 +436,23 @@ static int run_bilstm(mmk_s2s_plan* p, BiLstm& l, const float* x, int x_ld, int 
   return MMK_OK;
 }
 
-static int s2s_step(mmk_s2s_plan* p, int M, const float* x, int64_t xbs, int64_t xfs, float* y, int64_t ybs, int64_t yfs,
-                    int n_out, hipStream_t st) {
+// one step's input and output: frames (x, y) or class indices (xi, yi), strides per clip and per frame / position
+struct S2SIo {
+  const float* x = nullptr; float* y = nullptr;
+  const int64_t* xi = nullptr; int64_t* yi = nullptr;
+  int64_t xbs = 0, xfs = 0, ybs = 0, yfs = 0;
+};
+
+static int s2s_step(mmk_s2s_plan* p, int M, const S2SIo& io, int n_out, hipStream_t st) {
   const mmk_s2s_config& c = p->cfg;
   const int D = p->D, hop = p->hop;
   const int rows = M * hop;
-  hipLaunchKernelGGL(gather_frames_kernel, dim3(rows), dim3(256), 0, st, x, xbs, xfs, hop, c.in_dim, p->xin, p->in_pad);
+  float* y = io.y;
+  const int64_t ybs = io.ybs, yfs = io.yfs;
+  if (c.in_classes > 0)
+    hipLaunchKernelGGL(embed_rows_kernel, dim3(rows), dim3(256), 0, st, io.xi, io.xbs, io.xfs, hop, c.in_classes, D, p->embed, p->xin, p->in_pad);
+  else
+    hipLaunchKernelGGL(gather_frames_kernel, dim3(rows), dim3(256), 0, st, io.x, io.xbs, io.xfs, hop, c.in_dim, p->xin, p->in_pad);
   MMK_HIP(hipGetLastError());
   const size_t state_bytes = (size_t)M * D * sizeof(float);
   // encoder: every layer starts from a zero state; x = y, or x + y from the second layer on (:96-104)
@@ -439,6 +513,24 @@ static int s2s_step(mmk_s2s_plan* p, int M, const float* x, int64_t xbs, int64_t
     xl = fold;
     fold = fold == p->ysum ? p->yalt : p->ysum;
   }
+  if (c.head_kind == 1) {
+    // MLP head over all hop positions of all clips, then one wave per row: learned-temperature division + argmax
+    const float* hx = xl;
+    int64_t hx_ld = D;
+    for (size_t i = 0; i < p->mlp.size(); ++i) {
+      const bool last = i + 1 == p->mlp.size();
+      float* o = last ? p->logits : p->hid[i & 1];
+      const int64_t o_ld = last ? p->logits_ld : c.mlp_hidden;
+      MMK_TRY(plain_linear(p->mlp[i], hx, hx_ld, rows, o, o_ld, last ? ACT_NONE : ACT_MISH, st));   // MLPIO's default activation (modules/io.py:205)
+      hx = o;
+      hx_ld = o_ld;
+    }
+    SampleArgs sa = {};
+    sa.logits = p->logits; sa.ld = p->logits_ld; sa.rows = rows; sa.n_classes = c.out_dim; sa.has_temp_col = c.learn_temp;
+    sa.min_temp = c.min_temp;
+    sa.out = io.yi; sa.out_row_stride = yfs; sa.group = hop; sa.kept = n_out; sa.group_stride = ybs;
+    return launch_sample(sa, st);
+  }
   {
     // the output projection writes the caller's (batch, frame, bin) rows itself when the tiled kernel takes it
     static const bool tiled = [] { const char* e = getenv("MMK_S2S_GEMM"); return !(e && e[0] == '0'); }();
@@ -461,7 +553,32 @@ extern "C" int mmk_s2s_step(mmk_s2s_plan* p, int32_t batch, const float* x, int6
   if (!p || !x || !y) return fail(MMK_ERR_INVALID, "s2s_step: null argument");
   if (!p->committed) return fail(MMK_ERR_STATE, "s2s_step: plan not committed");
   if (batch < 1 || batch > p->Bmax) return fail(MMK_ERR_INVALID, "s2s_step: batch %d outside [1, %d]", batch, p->Bmax);
-  return s2s_step(p, batch, x, x_batch_stride, x_frame_stride, y, y_batch_stride, y_frame_stride, p->hop, (hipStream_t)stream);
+  if (p->cfg.in_classes > 0) return fail(MMK_ERR_INVALID, "s2s_step: this plan takes class indices (mmk_s2s_step_classes)");
+  S2SIo io;
+  io.x = x; io.xbs = x_batch_stride; io.xfs = x_frame_stride; io.y = y; io.ybs = y_batch_stride; io.yfs = y_frame_stride;
+  return s2s_step(p, batch, io, p->hop, (hipStream_t)stream);
+}
+
+extern "C" int mmk_s2s_step_classes(mmk_s2s_plan* p, int32_t batch, const int64_t* x, int64_t x_batch_stride, int64_t x_elem_stride,
+                                    int64_t* y, int64_t y_batch_stride, int64_t y_elem_stride, mmk_stream_t stream) {
+  if (!p || !x || !y) return fail(MMK_ERR_INVALID, "s2s_step_classes: null argument");
+  if (!p->committed) return fail(MMK_ERR_STATE, "s2s_step_classes: plan not committed");
+  if (batch < 1 || batch > p->Bmax) return fail(MMK_ERR_INVALID, "s2s_step_classes: batch %d outside [1, %d]", batch, p->Bmax);
+  if (p->cfg.in_classes <= 0) return fail(MMK_ERR_INVALID, "s2s_step_classes: this plan takes frames (mmk_s2s_step)");
+  S2SIo io;
+  io.xi = x; io.xbs = x_batch_stride; io.xfs = x_elem_stride; io.yi = y; io.ybs = y_batch_stride; io.yfs = y_elem_stride;
+  return s2s_step(p, batch, io, p->hop, (hipStream_t)stream);
+}
+
+extern "C" int mmk_s2s_last_logits(mmk_s2s_plan* p, int32_t batch, float* out, int64_t out_ld, mmk_stream_t stream) {
+  if (!p || !out) return fail(MMK_ERR_INVALID, "s2s_last_logits: null argument");
+  if (!p->committed || p->cfg.head_kind != 1) return fail(MMK_ERR_STATE, "s2s_last_logits: only for a committed plan with the MLP head");
+  if (batch < 1 || batch > p->Bmax) return fail(MMK_ERR_INVALID, "s2s_last_logits: batch %d outside [1, %d]", batch, p->Bmax);
+  const int n = p->cfg.out_dim + (p->cfg.learn_temp ? 1 : 0);
+  if (out_ld < n) return fail(MMK_ERR_INVALID, "s2s_last_logits: out_ld %lld < %d", (long long)out_ld, n);
+  MMK_HIP(hipMemcpy2DAsync(out, (size_t)out_ld * sizeof(float), p->logits, (size_t)p->logits_ld * sizeof(float), (size_t)n * sizeof(float),
+                           (size_t)batch * p->hop, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  return MMK_OK;
 }
 
 extern "C" int mmk_s2s_generate(mmk_s2s_plan* p, int32_t batch, float* frames, int64_t batch_stride, int64_t frame_stride,
@@ -470,12 +587,33 @@ extern "C" int mmk_s2s_generate(mmk_s2s_plan* p, int32_t batch, float* frames, i
   if (!p->committed) return fail(MMK_ERR_STATE, "s2s_generate: plan not committed");
   if (batch < 1 || batch > p->Bmax) return fail(MMK_ERR_INVALID, "s2s_generate: batch %d outside [1, %d]", batch, p->Bmax);
   if (t0 < p->hop) return fail(MMK_ERR_INVALID, "s2s_generate: t0=%lld is shorter than hop=%d", (long long)t0, p->hop);
+  if (p->cfg.in_classes > 0) return fail(MMK_ERR_INVALID, "s2s_generate: this plan takes class indices (mmk_s2s_generate_classes)");
   // loops/generate.py:207-219 : steps covered by the previous call's hop outputs are skipped
   for (int64_t t = t0; t < t0 + n_steps && t < t_total; t += p->hop) {
     const int64_t room = t_total - t;
     const int n_out = (int)(room < p->hop ? room : p->hop);
-    MMK_TRY(s2s_step(p, batch, frames + (t - p->hop) * frame_stride, batch_stride, frame_stride,
-                     frames + t * frame_stride, batch_stride, frame_stride, n_out, (hipStream_t)stream));
+    S2SIo io;
+    io.x = frames + (t - p->hop) * frame_stride; io.y = frames + t * frame_stride;
+    io.xbs = io.ybs = batch_stride; io.xfs = io.yfs = frame_stride;
+    MMK_TRY(s2s_step(p, batch, io, n_out, (hipStream_t)stream));
+  }
+  return MMK_OK;
+}
+
+extern "C" int mmk_s2s_generate_classes(mmk_s2s_plan* p, int32_t batch, int64_t* classes, int64_t batch_stride, int64_t elem_stride,
+                                        int64_t t0, int64_t n_steps, int64_t t_total, mmk_stream_t stream) {
+  if (!p || !classes) return fail(MMK_ERR_INVALID, "s2s_generate_classes: null argument");
+  if (!p->committed) return fail(MMK_ERR_STATE, "s2s_generate_classes: plan not committed");
+  if (batch < 1 || batch > p->Bmax) return fail(MMK_ERR_INVALID, "s2s_generate_classes: batch %d outside [1, %d]", batch, p->Bmax);
+  if (t0 < p->hop) return fail(MMK_ERR_INVALID, "s2s_generate_classes: t0=%lld is shorter than hop=%d", (long long)t0, p->hop);
+  if (p->cfg.in_classes <= 0) return fail(MMK_ERR_INVALID, "s2s_generate_classes: this plan takes frames (mmk_s2s_generate)");
+  for (int64_t t = t0; t < t0 + n_steps && t < t_total; t += p->hop) {
+    const int64_t room = t_total - t;
+    const int n_out = (int)(room < p->hop ? room : p->hop);
+    S2SIo io;
+    io.xi = classes + (t - p->hop) * elem_stride; io.yi = classes + t * elem_stride;
+    io.xbs = io.ybs = batch_stride; io.xfs = io.yfs = elem_stride;
+    MMK_TRY(s2s_step(p, batch, io, n_out, (hipStream_t)stream));
   }
   return MMK_OK;
 }

@@ -48,6 +48,7 @@ class S2SConfig(C.Structure):
         ("in_dim", i32), ("out_dim", i32), ("model_dim", i32), ("hop", i32), ("enc_n_lstm", i32),
         ("dec_n_lstm", i32), ("out_abs", i32), ("max_batch", i32), ("enc_downsampling", i32), ("dec_upsampling", i32),
         ("enc_apply_residuals", i32), ("dec_apply_residuals", i32),
+        ("in_classes", i32), ("head_kind", i32), ("mlp_hidden", i32), ("mlp_n_hidden", i32), ("learn_temp", i32), ("min_temp", f32),
     ]
 
 
@@ -102,6 +103,9 @@ _SIGNATURES = {
     "mmk_s2s_commit": (i32, [vp, vp, C.c_size_t, vp]),
     "mmk_s2s_step": (i32, [vp, i32, vp, i64, i64, vp, i64, i64, vp]),
     "mmk_s2s_generate": (i32, [vp, i32, vp, i64, i64, i64, i64, i64, vp]),
+    "mmk_s2s_step_classes": (i32, [vp, i32, vp, i64, i64, vp, i64, i64, vp]),
+    "mmk_s2s_generate_classes": (i32, [vp, i32, vp, i64, i64, i64, i64, i64, vp]),
+    "mmk_s2s_last_logits": (i32, [vp, i32, vp, i64, vp]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
@@ -549,3 +553,27 @@ class S2SPlan(_Plan):
             raise ValueError("Seq2Seq frames must be fp32 (batch, T, n_bins) with unit stride on the last dim")
         check(self._lib.mmk_s2s_generate(self.handle, frames.shape[0], ptr(frames), frames.stride(0), frames.stride(1),
                                          t0, n_steps, frames.shape[1], stream_ptr(self.device)), "mmk_s2s_generate")
+
+    # -- class indices in and out (embedding input + MLP head, IOSpec.mulaw_io) --------------------------------
+    def step_classes(self, x: torch.Tensor) -> torch.Tensor:
+        require_device(x)
+        if x.dtype != torch.int64 or x.dim() != 2:
+            raise ValueError("Seq2Seq class input must be int64 (batch, hop)")
+        y = torch.empty((x.shape[0], self.cfg.hop), dtype=torch.int64, device=x.device)
+        check(self._lib.mmk_s2s_step_classes(self.handle, x.shape[0], ptr(x), x.stride(0), x.stride(1), ptr(y), y.stride(0),
+                                             y.stride(1), stream_ptr(self.device)), "mmk_s2s_step_classes")
+        return y
+
+    def generate_classes(self, classes: torch.Tensor, t0: int, n_steps: int):
+        require_device(classes)
+        if classes.dtype != torch.int64 or classes.dim() != 2:
+            raise ValueError("Seq2Seq classes must be int64 (batch, T)")
+        check(self._lib.mmk_s2s_generate_classes(self.handle, classes.shape[0], ptr(classes), classes.stride(0), classes.stride(1),
+                                                 t0, n_steps, classes.shape[1], stream_ptr(self.device)), "mmk_s2s_generate_classes")
+
+    def last_logits(self, batch: int) -> torch.Tensor:
+        """the MLP head's raw outputs of the last step, (batch, hop, out_dim + learn_temp)"""
+        n = self.cfg.out_dim + (1 if self.cfg.learn_temp else 0)
+        out = torch.empty((batch, self.cfg.hop, n), dtype=torch.float32, device=self.device)
+        check(self._lib.mmk_s2s_last_logits(self.handle, batch, ptr(out), n, stream_ptr(self.device)), "mmk_s2s_last_logits")
+        return out

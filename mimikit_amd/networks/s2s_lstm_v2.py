@@ -5,8 +5,8 @@ Config, module wiring and ``state_dict`` layout follow the reference
 :119-182, ``Seq2SeqLSTMNetwork`` :185-303).  One ``generate_step`` maps the last
 ``hop`` frames to the next ``hop`` frames; on the HIP device it runs as
 ``csrc/s2s_plan.hip`` (GEMM-shaped: fp32 matrix cores).  Covered option space:
-continuous (magspec) input, ``enc_downsampling='edge_sum'``,
-``dec_upsampling='linear_resample'``, one LSTM each, no residuals / weight norm.
+continuous (magspec) frames or class indices (embedding in, MLP head + argmax out), every ``enc_downsampling`` /
+``dec_upsampling``, up to 8 LSTMs per side, residuals, weight norm (DESIGN.md section 8 lists what is refused).
 """
 import dataclasses as dtc
 from enum import auto
@@ -21,6 +21,8 @@ from ..features.item_spec import ItemSpec
 from ..io_spec import IOSpec
 from ..modules.io import ZipReduceVariables
 from ..modules.misc import Chunk
+from ..modules.mlp import MLP
+from ..modules.targets import CategoricalSampler
 from ..modules.resamplers import LinearResampler
 from ..utils import AutoStrEnum
 from .arm import ARMWithHidden, NetworkConfig, fold_weight_norm, weight_norm_leaves
@@ -202,8 +204,16 @@ class Seq2SeqLSTMNetwork(ARMWithHidden, nn.Module):
     def _describe(self, max_batch: int) -> native.S2SConfig:
         cfg = self._config
         unsupported = []
-        if self.input_module is not sum:
-            unsupported.append("discrete inputs (input module other than a plain sum)")
+        c = native.S2SConfig()
+        discrete = self.input_module is not sum
+        if discrete:
+            # class indices through nn.Embedding under ZipReduceVariables (:205-210); the loop feeds the head's classes back
+            first = list(self.input_module.heads)[0] if len(self.input_module.heads) == 1 else None
+            table = first[0] if isinstance(first, nn.Sequential) and len(first) == 1 else first
+            if not isinstance(table, nn.Embedding) or table.padding_idx is not None or table.max_norm is not None:
+                unsupported.append("discrete inputs through a module other than one plain nn.Embedding")
+            else:
+                c.in_classes = table.num_embeddings
         pooling = {"edge_sum": 0, "edge_mean": 1, "sum": 2, "mean": 3, "linear_resample": 4}
         upsampling = {"linear_resample": 0, "repeat": 1, "interp": 2}
         if str(cfg.enc_downsampling) not in pooling:
@@ -213,9 +223,22 @@ class Seq2SeqLSTMNetwork(ARMWithHidden, nn.Module):
         if not (1 <= cfg.enc_n_lstm <= 8 and 1 <= cfg.dec_n_lstm <= 8):
             unsupported.append("more than 8 LSTMs per side")
         heads = list(self.output_module.heads)
-        c = native.S2SConfig()
         if len(heads) != 1 or len(cfg.io_spec.inputs) != 1:
             unsupported.append("more than one input / target")
+        elif discrete:
+            head = heads[0]
+            est = getattr(head, "estimator", None)
+            mlp = est[0] if isinstance(est, nn.Sequential) and len(est) == 1 else None
+            if not isinstance(mlp, MLP) or not isinstance(getattr(head, "sampler", None), CategoricalSampler):
+                unsupported.append("discrete inputs with a head other than MLPIO + CategoricalSampler")
+            elif not isinstance(mlp.activation, nn.Mish) or mlp.dropout > 0 or mlp.dropout1d > 0 or not mlp.bias \
+                    or mlp.n_hidden_layers > 4:
+                unsupported.append("MLP head with a non-Mish activation, dropout, no bias or more than 4 hidden blocks")
+            else:
+                c.head_kind, c.mlp_hidden, c.mlp_n_hidden = 1, mlp.hidden_dim, mlp.n_hidden_layers
+                c.learn_temp = int(mlp.learn_temperature)
+                c.min_temp = float(mlp.min_temp) if mlp.learn_temperature else 0.
+                c.out_dim = mlp.out_dim - int(mlp.learn_temperature)
         else:
             head = heads[0]
             lin = head[0] if isinstance(head, nn.Sequential) else None
@@ -256,6 +279,13 @@ class Seq2SeqLSTMNetwork(ARMWithHidden, nn.Module):
 
     def _device_step(self, inputs: Tuple[torch.Tensor, ...]):
         native.require_device(*inputs)
+        if self.input_module is not sum:
+            x = inputs[0]
+            if x.size(1) != self._config.hop:
+                raise AssertionError(f"expected {self._config.hop} input classes, got {x.size(1)}")
+            self._ensure_plan(x.size(0), refresh_weights=False)
+            # the reference returns argmax * w with w the float weight of ZipReduceVariables: a float tensor (modules/io.py:310)
+            return self._plan.step_classes(x.long()).to(torch.float32)
         x = inputs[0] if len(inputs) == 1 else sum(inputs)
         if x.size(1) != self._config.hop:
             raise AssertionError(f"expected {self._config.hop} input frames, got {x.size(1)}")
@@ -279,9 +309,17 @@ class Seq2SeqLSTMNetwork(ARMWithHidden, nn.Module):
     def generate_block(self, tensors: Tuple[torch.Tensor, ...], t0: int, n_steps: int, **parameters):
         tensors = tuple(tensors)
         native.require_device(*tensors)
-        if len(tensors) != 1 or tensors[0].dtype != torch.float32:
+        if len(tensors) != 1:
             return None
         frames = tensors[0]
+        if self.input_module is not sum:
+            if frames.dtype != torch.int64 or frames.dim() != 2:
+                return None
+            self._ensure_plan(frames.size(0), refresh_weights=False)
+            self._plan.generate_classes(frames, t0, n_steps)
+            return True
+        if frames.dtype != torch.float32:
+            return None
         self._ensure_plan(frames.size(0), refresh_weights=False)
         self._plan.generate(frames, t0, n_steps)
         return True

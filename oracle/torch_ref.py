@@ -468,11 +468,19 @@ def _bilstm(sd: SD, p: str, x: torch.Tensor, state=None):
 
 
 def s2s_step(sd: SD, x: torch.Tensor, hop: int, out_abs: bool = True, downsampling: str = "edge_sum",
-             upsampling: str = "linear_resample", enc_residuals: bool = False, dec_residuals: bool = False) -> torch.Tensor:
+             upsampling: str = "linear_resample", enc_residuals: bool = False, dec_residuals: bool = False,
+             min_temp: Optional[float] = 1e-4, return_raw: bool = False) -> torch.Tensor:
     """Seq2SeqLSTMNetwork.forward (s2s_lstm_v2.py:246-253): EncoderLSTM.forward with the edge_sum / edge_mean / sum / mean
     poolings and stacked layers (:93-113), DecoderLSTM.forward with linear_resample or repeat (:155-179); the number of
-    layers is read off the state_dict; every decoder layer starts from the LAST encoder layer's final state (:171)"""
+    layers is read off the state_dict; every decoder layer starts from the LAST encoder layer's final state (:171).
+
+    Discrete IO (read off the state_dict too): class indices go through the nn.Embedding of `input_module` (:205-210, the
+    ZipReduceVariables weight of a single input is 1), the MLP head's argmax comes back TIMES that weight, i.e. as a float
+    tensor (modules/io.py:310, modules/targets.py:43-44; generate_step hands the sampler no temperature, :262-263).  With
+    return_raw the head's outputs before the learned-temperature division are returned beside the classes."""
     D = sd["enc.fc_out.weight"].shape[0]
+    if "input_module.heads.0.0.weight" in sd:
+        x = F.embedding(x, sd["input_module.heads.0.0.weight"]) * torch.ones(())
     n_enc = 1 + max(int(k.split(".")[2]) for k in sd if k.startswith("enc.lstm."))
     n_dec = 1 + max(int(k.split(".")[2]) for k in sd if k.startswith("dec.lstm."))
     hidden = None
@@ -498,19 +506,25 @@ def s2s_step(sd: SD, x: torch.Tensor, hop: int, out_abs: bool = True, downsampli
         y, _ = _bilstm(sd, f"dec.lstm.{n}.", z, hidden)
         y = y.view(*y.shape[:-1], D, 2).sum(-1)
         z = z + y if dec_residuals else y
+    mlp = "output_module.heads.0.estimator.0."
+    if mlp + "fc.0.weight" in sd:
+        n_hidden = max(int(k[len(mlp) + 3:].split(".")[0]) for k in sd if k.startswith(mlp + "fc.")) // 2 - 1
+        raw = mlp_raw(sd, mlp, z, n_hidden)
+        classes = categorical(mlp_logits(raw, min_temp)) * torch.ones(())
+        return (classes, raw) if return_raw else classes
     out = F.linear(z, sd["output_module.heads.0.0.weight"], sd["output_module.heads.0.0.bias"])
     return out.abs() if out_abs else out
 
 
-def s2s_generate(sd: SD, prompt: torch.Tensor, n_steps: int, hop: int, out_abs: bool = True) -> torch.Tensor:
-    """the loop of loops/generate.py:207-219 for a net that returns hop frames per call"""
+def s2s_generate(sd: SD, prompt: torch.Tensor, n_steps: int, hop: int, out_abs: bool = True, **arch) -> torch.Tensor:
+    """the loop of loops/generate.py:207-219 for a net that returns hop frames (or hop classes) per call"""
     prior = prompt.size(1)
-    frames = torch.cat([prompt, torch.zeros(prompt.size(0), n_steps, prompt.size(2))], dim=1)
+    frames = torch.cat([prompt, torch.zeros(prompt.size(0), n_steps, *prompt.shape[2:], dtype=prompt.dtype)], dim=1)
     until = 0
     for t in range(prior, prior + n_steps):
         if t < until:
             continue
-        out = s2s_step(sd, frames[:, t - hop:t], hop, out_abs)
+        out = s2s_step(sd, frames[:, t - hop:t], hop, out_abs, **arch)
         n_out = min(out.size(1), frames.size(1) - t)
         frames[:, t:t + n_out] = out[:, :n_out]
         until = t + n_out

@@ -374,6 +374,35 @@ def make_s2s_stacks():
     save("s2s_stacks.npz", **arrays)
 
 
+S2S_MULAW = {"mlp0": dict(hop=4, io=dict(n_mlp_layers=0)),
+             "mlp2_stack": dict(hop=2, enc_n_lstm=2, dec_n_lstm=2, dec_apply_residuals=True, enc_downsampling="mean", io=dict(n_mlp_layers=2))}
+
+
+def make_s2s_mulaw():
+    """class indices in (an nn.Embedding under ZipReduceVariables, s2s_lstm_v2.py:205-210), an MLP head with a learned temperature
+    and the argmax of CategoricalSampler out (generate_step passes no temperature, :262-263; modules/targets.py:43-44) - the IO the
+    reference's tests/test_seq2seq.py:149-154 trains and generates with"""
+    g = torch.Generator().manual_seed(39)
+    arrays = {}
+    for tag, kw in S2S_MULAW.items():
+        kw = dict(kw)
+        io = ref.IOSpec.mulaw_io(ref.IOSpec.MuLawIOConfig(input_module_type="embedding", mlp_dim=32, **kw.pop("io")))
+        net = ref.Seq2SeqLSTMNetwork.from_config(ref.Seq2SeqLSTMNetwork.Config(io_spec=io, model_dim=32, **kw)).eval()
+        load_recipe(net, seed=47, gain=1.5)
+        hop = kw["hop"]
+        log = []
+        h = net.output_module.heads[0].estimator[0].fc.register_forward_hook(lambda m, i, o: log.append(o.detach().clone()))
+        x = torch.randint(0, 256, (3, hop), generator=g)
+        y = net.generate_step((x,), t=hop)
+        raw = log.pop()
+        prompt = torch.randint(0, 256, (2, hop + 2), generator=g)
+        out = run_loop(net, (prompt,), 10)
+        h.remove()
+        arrays.update({f"{tag}_x": x, f"{tag}_y": y, f"{tag}_raw": raw, f"{tag}_prompt": prompt, f"{tag}_out": out[0],
+                       f"{tag}_loop_raw": torch.cat(log, 1)})
+    save("s2s_mulaw.npz", **arrays)
+
+
 S2S_STACKS = {"e2d1": dict(enc_n_lstm=2), "e1d3": dict(dec_n_lstm=3), "e2d2res": dict(enc_n_lstm=2, dec_n_lstm=2, enc_apply_residuals=True, dec_apply_residuals=True),
               "e3d1res_sum": dict(enc_n_lstm=3, enc_apply_residuals=True, enc_downsampling="sum")}
 
@@ -475,5 +504,6 @@ if __name__ == "__main__":
     make_s2s()
     make_s2s_variants()
     make_s2s_stacks()
+    make_s2s_mulaw()
     make_sampler()
     make_keys()

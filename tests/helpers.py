@@ -171,6 +171,23 @@ def s2s_tiny(downsampling="edge_sum", upsampling="linear_resample", seed=41, **k
     return net.eval(), sd
 
 
+S2S_MULAW = {"mlp0": dict(hop=4, io=dict(n_mlp_layers=0)),
+             "mlp2_stack": dict(hop=2, enc_n_lstm=2, dec_n_lstm=2, dec_apply_residuals=True, enc_downsampling="mean", io=dict(n_mlp_layers=2))}
+
+
+def s2s_mulaw(tag, model_dim=32, mlp_dim=32):
+    """Seq2Seq on class indices: embedding in, MLP head + argmax out (the IO of the reference's tests/test_seq2seq.py:149-154)"""
+    kw = dict(S2S_MULAW[tag])
+    io = mmk.IOSpec.mulaw_io(mmk.IOSpec.MuLawIOConfig(input_module_type="embedding", mlp_dim=mlp_dim, **kw.pop("io")))
+    net = mmk.Seq2SeqLSTMNetwork.from_config(mmk.Seq2SeqLSTMNetwork.Config(io_spec=io, model_dim=model_dim, **kw))
+    load_recipe(net, seed=47, gain=1.5)
+    # (the hidden blocks of a deeper MLP head share ONE Linear: the state_dict, not the recipe, says what it ended up with)
+    sd = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    arch = dict(downsampling=kw.get("enc_downsampling", "edge_sum"), enc_residuals=kw.get("enc_apply_residuals", False),
+                dec_residuals=kw.get("dec_apply_residuals", False))
+    return net.eval(), sd, kw["hop"], arch
+
+
 def margin_ok(raw, min_gap=5e-5):
     """top-1 / top-2 gap of the class logits (temperature column excluded): greedy decode is only
     comparable bit-exactly where no near-tie exists (fp32 re-association noise on these logits is

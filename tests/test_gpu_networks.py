@@ -472,6 +472,86 @@ def test_seq2seq_lstm_stacks(device, tag):
     assert out.shape == (2, 12, 65) and bool(torch.isfinite(out).all())
 
 
+@pytest.mark.parametrize("tag", list(H.S2S_MULAW))
+def test_seq2seq_on_class_indices_matches_reference_golden(device, tag):
+    """IOSpec.mulaw_io with an embedding input (tests/test_seq2seq.py:149-154): class indices in, the MLP head's argmax out, as
+    a float tensor from generate_step and in place in the loop's int64 tensor; classes exact (the fixture's smallest top-1 /
+    top-2 gap is above helpers.margin_ok's bound), raw head outputs rtol 1e-4 / atol 2e-4"""
+    import warnings
+    warnings.filterwarnings("ignore")
+    g = H.golden("s2s_mulaw.npz")
+    net, sd, hop, arch = H.s2s_mulaw(tag)
+    net.to(device)
+    x = H.T(g[f"{tag}_x"]).to(device)
+    y = net.generate_step((x,), t=hop)
+    assert y.dtype == torch.float32 and y.shape == x.shape
+    raw = net._plan.last_logits(x.size(0)).cpu()
+    assert torch.allclose(raw, H.T(g[f"{tag}_raw"]), rtol=1e-4, atol=2e-4)
+    assert bool(H.margin_ok(g[f"{tag}_raw"]).all()) and torch.equal(y.cpu(), H.T(g[f"{tag}_y"]))
+    assert torch.equal(net((x,)).cpu(), y.cpu())              # eval forward is the same path
+    assert bool(H.margin_ok(g[f"{tag}_loop_raw"]).all())
+    out = run_loop(net, (H.T(g[f"{tag}_prompt"]),), 10)
+    assert out[0].dtype == torch.int64 and torch.equal(out[0].cpu(), H.T(g[f"{tag}_out"]))
+
+
+@pytest.mark.parametrize("hop,batch,model_dim,mlp_dim,n_mlp", [(8, 24, 128, 128, 0), (5, 7, 64, 48, 1), (4, 40, 256, 128, 3)])
+def test_seq2seq_on_class_indices_vs_oracle(device, hop, batch, model_dim, mlp_dim, n_mlp):
+    """wider nets (batch x hop above and below the tiled GEMM's 128 rows, ragged tiles, a head width that is no multiple of
+    16), every step checked against the oracle on the history the device produced: raw head outputs rtol 1e-4 / atol 2e-4,
+    classes exact wherever the oracle's top-1 / top-2 gap is above 5e-5; the in-place block call on a strided tensor whose
+    length is not a multiple of hop (the last step is clipped)"""
+    import warnings
+    warnings.filterwarnings("ignore")
+    H.S2S_MULAW["_t"] = dict(hop=hop, io=dict(n_mlp_layers=n_mlp))
+    try:
+        net, sd, hop, arch = H.s2s_mulaw("_t", model_dim=model_dim, mlp_dim=mlp_dim)
+    finally:
+        del H.S2S_MULAW["_t"]
+    net.to(device)
+    g = torch.Generator().manual_seed(17)
+    n = 3 * hop - 1
+    wide = torch.zeros(batch, 2 * (hop + n), dtype=torch.int64)
+    seq = wide[:, ::2]                                        # element stride 2
+    seq[:, :hop] = torch.randint(0, 256, (batch, hop), generator=g)
+    dev = wide.to(device)
+    dseq = dev[:, ::2]
+    net.before_generate((dseq[:, :hop],), 0)
+    assert net.generate_block((dseq,), hop, n) is True
+    net.after_generate((dseq,), 0)
+    got = dseq.cpu()
+    assert bool((dev[:, 1::2] == 0).all())                    # nothing written between the elements
+    fsd = O.fold_weight_norm(sd)
+    checked = 0
+    for t in range(hop, hop + n, hop):
+        want, raw = O.s2s_step(fsd, got[:, t - hop:t], hop, return_raw=True, **arch)
+        k = min(hop, hop + n - t)
+        ok = H.margin_ok(raw)[:, :k]
+        assert bool((got[:, t:t + k][ok] == want[:, :k].long()[ok]).all())
+        checked += int(ok.sum())
+    assert checked > 0.9 * batch * n
+    # one step through generate_step on the last window, its raw outputs against the oracle's
+    x = got[:, -hop:].contiguous()
+    y = net.generate_step((x.to(device),), t=hop)
+    want, raw = O.s2s_step(fsd, x, hop, return_raw=True, **arch)
+    assert torch.allclose(net._plan.last_logits(batch).cpu(), raw, rtol=1e-4, atol=2e-4)
+    ok = H.margin_ok(raw)
+    assert torch.equal(y.cpu()[ok], want[ok])
+
+
+def test_seq2seq_class_and_frame_entry_points_do_not_mix(device):
+    """a plan for class indices refuses frames and the other way round (the C-ABI's error, not a crash)"""
+    net, sd, hop, arch = H.s2s_mulaw("mlp0")
+    net.to(device)
+    net.generate_step((torch.randint(0, 256, (2, hop)).to(device),), t=hop)
+    with pytest.raises(Exception, match="class indices"):
+        net._plan.step(torch.rand(2, hop, 32, device=device))
+    fnet, _ = H.s2s_tiny()
+    fnet.to(device)
+    fnet.generate_step((torch.rand(2, 4, 65, device=device),), t=4)
+    with pytest.raises(Exception, match="takes frames"):
+        fnet._plan.step_classes(torch.randint(0, 256, (2, 4), device=device))
+
+
 @pytest.mark.parametrize("ds,us", H.S2S_VARIANTS)
 def test_seq2seq_pooling_and_upsampling_variants(device, ds, us):
     """enc_downsampling edge_mean / sum / mean and dec_upsampling repeat (no up-sampling weights): golden from the

@@ -214,6 +214,23 @@ def test_seq2seq_lstm_stacks_match_reference(tag):
     assert torch.allclose(y, H.T(g[f"y_{tag}"]), rtol=1e-5, atol=1e-5)
 
 
+@pytest.mark.parametrize("tag", list(H.S2S_MULAW))
+def test_seq2seq_on_class_indices_matches_reference(tag):
+    """embedding in, MLP head + argmax out: one generate_step (float classes, as the reference returns them) and the loop"""
+    import warnings
+    warnings.filterwarnings("ignore")
+    g = H.golden("s2s_mulaw.npz")
+    _, sd, hop, arch = H.s2s_mulaw(tag)
+    sd = O.fold_weight_norm(sd)
+    y, raw = O.s2s_step(sd, H.T(g[f"{tag}_x"]), hop, return_raw=True, **arch)
+    assert y.dtype == torch.float32
+    assert torch.allclose(raw, H.T(g[f"{tag}_raw"]), rtol=1e-5, atol=1e-5)
+    assert bool(H.margin_ok(raw).all()) and torch.equal(y, H.T(g[f"{tag}_y"]))
+    out = O.s2s_generate(sd, H.T(g[f"{tag}_prompt"]), 10, hop, **arch)
+    assert out.dtype == torch.int64 and bool(H.margin_ok(g[f"{tag}_loop_raw"]).all())
+    assert torch.equal(out, H.T(g[f"{tag}_out"]))
+
+
 @pytest.mark.parametrize("tag", list(H.WAVENET_OPTIONS))
 def test_wavenet_options_oracle_matches_reference(tag):
     """deeper MLP heads, act_g=None, reverse_layer_order, layerwise_inputs, tie_io_weights: the oracle's loop against the
