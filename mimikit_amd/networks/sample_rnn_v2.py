@@ -132,7 +132,10 @@ class SampleRNN(ARMWithHidden, nn.Module):
         heads = []
         for spec in config.io_spec.inputs:
             if isinstance(spec.elem_type, Discrete) and not isinstance(spec.module, FramedLinearIO):
-                raise NotImplementedError("EmbeddingConv1d bottom tier is outside the covered option space")
+                # (the reference builds an EmbeddingConv1d bottom tier here, :161-167, but cannot run the resulting network: its
+                #  upper tiers then embed samples, not frames, and forward fails on mismatched lengths - DESIGN.md section 8)
+                raise NotImplementedError("a SampleRNN on discrete inputs needs FramedLinearIO input modules (IOSpec.mulaw_io's default): "
+                                          "the reference's own network fails in forward with any other")
             params = dict(class_size=spec.elem_type.size) if isinstance(spec.elem_type, Discrete) else {}
             heads.append(FramedConv1dIO().set(**params, frame_size=fs[-1], hop_length=1, out_dim=h).module())
         tiers.append(SampleRNNTier(input_module=ZipReduceVariables(mode=config.inputs_mode, modules=heads),

@@ -111,6 +111,26 @@ def test_encoder_decoder_forward_shapes(downsampling, n_lstm, residuals):
     assert out.shape == (3, 4, 33)
 
 
+def test_seq2seq_takes_class_indices():
+    """tests/test_seq2seq.py:149-154 builds (and trains) the network on IOSpec.mulaw_io with an embedding input: the training graph
+    maps (batch, hop) classes to (batch, hop, q_levels) logits; generating with it is tests/test_gpu_networks.py's
+    test_seq2seq_on_class_indices_*"""
+    io = mmk.IOSpec.mulaw_io(mmk.IOSpec.MuLawIOConfig(input_module_type="embedding"))
+    net = mmk.Seq2SeqLSTMNetwork.from_config(mmk.Seq2SeqLSTMNetwork.Config(io_spec=io, model_dim=32, hop=2)).train()
+    out = net((torch.randint(0, 256, (3, 2)),))
+    out = out[0] if isinstance(out, tuple) else out
+    assert out.shape == (3, 2, 256)
+    assert net.generate_params == {"temperature"}
+
+
+def test_sample_rnn_on_embedding_inputs_is_refused_when_built():
+    """sample_rnn_v2.py:161-167 would build an EmbeddingConv1d bottom tier; the reference's forward then fails on mismatched tier
+    lengths, so there is nothing to reproduce: refused with the reason"""
+    io = mmk.IOSpec.mulaw_io(mmk.IOSpec.MuLawIOConfig(input_module_type="embedding"))
+    with pytest.raises(NotImplementedError, match="FramedLinearIO"):
+        mmk.SampleRNN.from_config(mmk.SampleRNN.Config(io_spec=io))
+
+
 # ---------------------------------------------------------------------------- tests/test_fft_alignment.py
 def _signal(n, device):
     x = torch.randn(n, generator=torch.Generator().manual_seed(n))
