@@ -109,6 +109,11 @@ int launch_gemm_f32(const float* A, int64_t lda, int64_t a_batch, const float* W
 //     one is multiplied (2 x 64 MFMAs per SIMD and stage = 1.7 us, longer than the loads take)
 //   * W fragments (1 KiB, packed order) come straight from global / L2 into registers, one stage ahead
 //   * per K-chunk a wave issues 2 LDS reads and 16 MFMAs: the matrix pipe is the bound
+//   * measured and dropped: the operands of TWO stages in flight (unconditional, masked loads so that the compiler's waits are
+//     counted ones, 182 VGPRs, no spills): 459.6 -> 458.8 us per cfg-5 generate step, i.e. nothing - a stage does not end in a
+//     wait for its loads when the grid fills the chip
+//   * a launch with few tiles (the output projection: 72 workgroups, 16 dependent stages of ~2 us each when a workgroup has a CU to
+//     itself) splits K over blockIdx.z and a second launch adds the partial sums in split order: 33 -> ~21 us for both launches
 constexpr int kTgThreads = 256;             // 4 waves as 2 x 2; two workgroups per CU run out of phase and fill each other's barrier / LDS waits
 constexpr int kTgBM = 64, kTgBN = 64;
 constexpr int kTgCh = 4;                       // K-chunks (of 16) per pipeline stage: 1.7 us of MFMAs hide the next stage's loads
@@ -116,7 +121,8 @@ constexpr int kTgLd = kTgCh * 16 + 4;          // LDS row stride: the 16 lanes o
 
 __global__ __launch_bounds__(kTgThreads, 2) void gemm_bias_act_kernel(const float* __restrict__ A, int64_t lda, const float* __restrict__ Wp,
                                                                  const float* __restrict__ bias, float* __restrict__ C, int64_t ldc,
-                                                                 int M, int n_tiles, int N, int K, int k_chunks, int act, GemmRowMap rm) {
+                                                                 int M, int n_tiles, int N, int K, int k_chunks, int act, GemmRowMap rm,
+                                                                 int k_split, float* __restrict__ partial) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   float* as = reinterpret_cast<float*>(smem_raw);              // [2][kTgBM][kTgLd]
   const int tid = threadIdx.x, lane = tid & 63;
@@ -164,13 +170,16 @@ __global__ __launch_bounds__(kTgThreads, 2) void gemm_bias_act_kernel(const floa
   f32x4 acc[2][2];
 #pragma unroll
   for (int r = 0; r < 2; ++r) acc[r][0] = acc[r][1] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const int n_stages = (k_chunks + kTgCh - 1) / kTgCh;
-  load_a(0);
-  load_w(0, wc);
-  store_a(0);
+  // k_split > 1: workgroup z of a tile takes the stages [z S / k_split, (z + 1) S / k_split) and leaves its raw sums in `partial`
+  const int all_stages = (k_chunks + kTgCh - 1) / kTgCh;
+  const int st_first = (int)(((int64_t)blockIdx.z * all_stages) / k_split);
+  const int n_stages = (int)(((int64_t)(blockIdx.z + 1) * all_stages) / k_split);
+  load_a(st_first);
+  load_w(st_first, wc);
+  store_a(st_first & 1);
   __syncthreads();
   const int x_off = (wm * 32 + (lane & 15)) * kTgLd + 4 * (lane >> 4);
-  for (int st = 0; st < n_stages; ++st) {
+  for (int st = st_first; st < n_stages; ++st) {
     const bool more = st + 1 < n_stages;
     if (more) {                                                // next stage's slab and fragments in flight
       load_a(st + 1);
@@ -200,6 +209,24 @@ __global__ __launch_bounds__(kTgThreads, 2) void gemm_bias_act_kernel(const floa
     __syncthreads();
   }
   // ---- D: column lane & 15, rows 4 (lane >> 4) + j of each 16-row block ------------------------------------------------------
+  if (k_split > 1) {
+    const int np = n_tiles * 16;
+    float* dst = partial + (int64_t)blockIdx.z * M * np;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int tile = tile0 + t;
+      if (tile >= n_tiles) continue;
+      const int col = tile * 16 + (lane & 15);
+#pragma unroll
+      for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int m = m_first + wm * 32 + r * 16 + 4 * (lane >> 4) + j;
+          if (m < M) dst[(int64_t)m * np + col] = acc[r][t][j];
+        }
+    }
+    return;
+  }
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
     const int tile = tile0 + t;
@@ -224,6 +251,21 @@ __global__ __launch_bounds__(kTgThreads, 2) void gemm_bias_act_kernel(const floa
   }
 }
 
+// the partial sums of a split-K launch, added in split order (the same order on every run), then bias / activation / row map
+__global__ __launch_bounds__(256) void gemm_split_reduce_kernel(const float* __restrict__ partial, int k_split, int M, int np, int N,
+                                                                const float* __restrict__ bias, float* __restrict__ C, int64_t ldc, int act,
+                                                                GemmRowMap rm) {
+  const int m = blockIdx.x;
+  const int g = rm.group > 0 ? m / rm.group : 0, i = rm.group > 0 ? m - g * rm.group : 0;
+  if (rm.group > 0 && i >= rm.kept) return;
+  float* dst = rm.group > 0 ? C + (int64_t)g * rm.group_stride + (int64_t)i * rm.row_stride : C + (int64_t)m * ldc;
+  for (int col = threadIdx.x; col < N; col += blockDim.x) {
+    float v = partial[(int64_t)m * np + col];
+    for (int z = 1; z < k_split; ++z) v += partial[((int64_t)z * M + m) * np + col];
+    dst[col] = apply_act(v + (bias ? bias[col] : 0.f), act);
+  }
+}
+
 bool gemm_bias_act_supported(const float* A, int64_t lda, int M, int K) {
   // (M = 64 - dec.fc of the Seq2Seq decoder, 64 x 8192 x 1024 - was measured on this kernel too: slower than the row-tile
   //  kernel's 27.7 us, cfg 5 218 instead of 227 M samples/s; MMK_GEMM_MIN_M moves the threshold)
@@ -231,14 +273,38 @@ bool gemm_bias_act_supported(const float* A, int64_t lda, int M, int K) {
   return M >= min_m && K >= 16 && (lda % 4) == 0 && (reinterpret_cast<uintptr_t>(A) & 15) == 0;
 }
 
+// How many ways a launch with few tiles splits K: a tile's K loop is a chain of stages of ~2 us each (a slab's way from L2 is
+// longer than its MFMAs), so a grid that leaves CUs idle is cut along K until it fills them (512 workgroups = two per CU)
+int gemm_bias_act_k_split(int M, int n_tiles, int k_chunks) {
+  const char* fe = getenv("MMK_GEMM_KSPLIT");                  // (read per call: the tests force splits)
+  const int forced = fe ? atoi(fe) : 0;
+  const int wgs = ((n_tiles + kTgBN / 16 - 1) / (kTgBN / 16)) * ((M + kTgBM - 1) / kTgBM);
+  const int stages = (k_chunks + kTgCh - 1) / kTgCh;
+  int ks = 1;
+  while (ks * 2 <= stages && wgs * ks * 2 <= 512 && ks < 8) ks *= 2;
+  if (forced > 0) ks = forced < stages ? forced : stages;
+  return ks;
+}
+
+int64_t gemm_bias_act_partial_floats(int M, int n_tiles, int k_chunks) {
+  const int ks = gemm_bias_act_k_split(M, n_tiles, k_chunks);
+  return ks > 1 ? (int64_t)ks * M * n_tiles * 16 : 0;
+}
+
 int launch_gemm_bias_act(const float* A, int64_t lda, const float* Wp, const float* bias, int n_tiles, int k_chunks, int N, int K, float* C,
-                         int64_t ldc, int M, int act, hipStream_t stream, GemmRowMap rm) {
+                         int64_t ldc, int M, int act, hipStream_t stream, GemmRowMap rm, float* partial, int64_t partial_floats) {
   if (M <= 0 || n_tiles <= 0) return MMK_OK;
   if (!gemm_bias_act_supported(A, lda, M, K)) return fail(MMK_ERR_UNSUPPORTED, "gemm_bias_act: needs M >= 128 and a 16-byte aligned A");
-  dim3 grid((n_tiles + kTgBN / 16 - 1) / (kTgBN / 16), (M + kTgBM - 1) / kTgBM), block(kTgThreads);
+  int ks = partial ? gemm_bias_act_k_split(M, n_tiles, k_chunks) : 1;
+  if (ks > 1 && (int64_t)ks * M * n_tiles * 16 > partial_floats) ks = 1;
+  dim3 grid((n_tiles + kTgBN / 16 - 1) / (kTgBN / 16), (M + kTgBM - 1) / kTgBM, ks), block(kTgThreads);
   const size_t lds = (size_t)2 * kTgBM * kTgLd * sizeof(float);
-  hipLaunchKernelGGL(gemm_bias_act_kernel, grid, block, lds, stream, A, lda, Wp, bias, C, ldc, M, n_tiles, N, K, k_chunks, act, rm);
+  hipLaunchKernelGGL(gemm_bias_act_kernel, grid, block, lds, stream, A, lda, Wp, bias, C, ldc, M, n_tiles, N, K, k_chunks, act, rm, ks, partial);
   MMK_HIP(hipGetLastError());
+  if (ks > 1) {
+    hipLaunchKernelGGL(gemm_split_reduce_kernel, dim3(M), dim3(256), 0, stream, partial, ks, M, n_tiles * 16, N, bias, C, ldc, act, rm);
+    MMK_HIP(hipGetLastError());
+  }
   return MMK_OK;
 }
 

@@ -149,6 +149,8 @@ struct mmk_s2s_plan {
   float *hs[2] = {nullptr, nullptr}, *cs[2] = {nullptr, nullptr};   // the encoder's final state: every decoder layer starts from it
   // discrete IO: the embedding table (a copy: in_classes x D), the MLP head's Linears, its hidden rows and raw outputs
   float* embed = nullptr;
+  float* gemm_partial = nullptr;                 // split-K partial sums of the GEMM launches that would not fill the chip
+  static constexpr int64_t kPartialFloats = 512 * 64 * 64;   // k_split x workgroups <= 512 tiles of 64 x 64
   std::vector<PackedLinear> mlp;
   float *hid[2] = {nullptr, nullptr}, *logits = nullptr;
   int logits_ld = 0;
@@ -169,6 +171,7 @@ struct mmk_s2s_plan {
       out_lin.carve(cv, true);
     }
     if (cfg.in_classes > 0) embed = cv.take<float>((int64_t)cfg.in_classes * D);
+    gemm_partial = cv.take<float>(kPartialFloats);
     xin = cv.take<float>(rows * in_pad);
     gi[0] = cv.take<float>(rows * 4 * D);
     gi[1] = cv.take<float>(rows * 4 * D);
@@ -366,11 +369,12 @@ extern "C" int mmk_s2s_commit(mmk_s2s_plan* p, void* workspace, size_t workspace
 }
 
 static int plain_linear(const PackedLinear& w, const float* x, int64_t ldx, int M, float* y, int64_t ldy, int act,
-                        hipStream_t st) {
+                        hipStream_t st, float* partial = nullptr) {
   // GEMM-shaped calls (all hop frames of all clips at once) take the tiled kernel; MMK_S2S_GEMM=0 keeps the row-tile one
   static const bool tiled = [] { const char* e = getenv("MMK_S2S_GEMM"); return !(e && e[0] == '0'); }();
   if (tiled && w.nseg == 1 && gemm_bias_act_supported(x, ldx, M, w.segK[0]))
-    return launch_gemm_bias_act(x, ldx, w.Wp, w.bias, w.n_tiles, w.k_chunks, w.N, w.segK[0], y, ldy, M, act, st);
+    return launch_gemm_bias_act(x, ldx, w.Wp, w.bias, w.n_tiles, w.k_chunks, w.N, w.segK[0], y, ldy, M, act, st, GemmRowMap(), partial,
+                                partial ? mmk_s2s_plan::kPartialFloats : 0);
   // few rows against a large matrix (dec.fc, enc.fc_out): the weight-streaming kernel; MMK_S2S_SKINNY=0 keeps the row-tile one
   static const bool skinny = [] { const char* e = getenv("MMK_S2S_SKINNY"); return !(e && e[0] == '0'); }();
   if (skinny && w.nseg == 1 && w.n_tiles >= 32 && skinny_linear_supported(x, ldx, M, w.segK[0], w.k_chunks))
@@ -393,7 +397,7 @@ static int run_bilstm(mmk_s2s_plan* p, BiLstm& l, const float* x, int x_ld, int 
   const int D = p->D, hop = p->hop;
   const int64_t rows = (int64_t)M * hop;
   for (int d = 0; d < 2; ++d) {
-    MMK_TRY(plain_linear(l.ih[d], x, x_ld, (int)rows, p->gi[d], 4 * D, ACT_NONE, st));
+    MMK_TRY(plain_linear(l.ih[d], x, x_ld, (int)rows, p->gi[d], 4 * D, ACT_NONE, st, p->gemm_partial));
     if (zero_state && !p->fused_lstm) {
       // `lstm(x,)` : fresh zero state on every call                    (s2s_lstm_v2.py:97); the fused step kernel takes a flag
       MMK_HIP(hipMemsetAsync(p->h[d], 0, (size_t)p->Bmax * D * sizeof(float), st));
@@ -521,7 +525,7 @@ static int s2s_step(mmk_s2s_plan* p, int M, const S2SIo& io, int n_out, hipStrea
       const bool last = i + 1 == p->mlp.size();
       float* o = last ? p->logits : p->hid[i & 1];
       const int64_t o_ld = last ? p->logits_ld : c.mlp_hidden;
-      MMK_TRY(plain_linear(p->mlp[i], hx, hx_ld, rows, o, o_ld, last ? ACT_NONE : ACT_MISH, st));   // MLPIO's default activation (modules/io.py:205)
+      MMK_TRY(plain_linear(p->mlp[i], hx, hx_ld, rows, o, o_ld, last ? ACT_NONE : ACT_MISH, st, p->gemm_partial));   // MLPIO's default activation (modules/io.py:205)
       hx = o;
       hx_ld = o_ld;
     }
@@ -538,7 +542,8 @@ static int s2s_step(mmk_s2s_plan* p, int M, const S2SIo& io, int n_out, hipStrea
     if (tiled && w.nseg == 1 && gemm_bias_act_supported(xl, D, rows, w.segK[0])) {
       GemmRowMap rm;
       rm.group = hop; rm.kept = n_out; rm.group_stride = ybs; rm.row_stride = yfs;
-      return launch_gemm_bias_act(xl, D, w.Wp, w.bias, w.n_tiles, w.k_chunks, w.N, w.segK[0], y, 0, rows, c.out_abs ? ACT_ABS : ACT_NONE, st, rm);
+      return launch_gemm_bias_act(xl, D, w.Wp, w.bias, w.n_tiles, w.k_chunks, w.N, w.segK[0], y, 0, rows, c.out_abs ? ACT_ABS : ACT_NONE, st, rm,
+                                  p->gemm_partial, mmk_s2s_plan::kPartialFloats);
     }
   }
   MMK_TRY(plain_linear(p->out_lin, xl, D, rows, p->yout, p->out_pad, c.out_abs ? ACT_ABS : ACT_NONE, st));

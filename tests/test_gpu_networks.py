@@ -472,6 +472,24 @@ def test_seq2seq_lstm_stacks(device, tag):
     assert out.shape == (2, 12, 65) and bool(torch.isfinite(out).all())
 
 
+@pytest.mark.parametrize("ksplit", ["1", "2", "3", "8"])
+def test_seq2seq_gemm_split_k(device, monkeypatch, ksplit):
+    """the tiled GEMM with K cut over 1 / 2 / 3 / 8 workgroups per tile (uneven stage ranges, K = 513 with a ragged last stage) and
+    the partial sums added in split order: against the oracle at 1e-4 of the largest output, and bit-identical from run to run"""
+    monkeypatch.setenv("MMK_GEMM_KSPLIT", ksplit)
+    io = mmk.IOSpec.magspec_io(mmk.IOSpec.MagSpecIOConfig(sr=22050, n_fft=1024, hop_length=256))
+    net = mmk.Seq2SeqLSTMNetwork.from_config(mmk.Seq2SeqLSTMNetwork.Config(io_spec=io, model_dim=128, hop=8)).eval()
+    from oracle.weights import load_recipe
+    sd = load_recipe(net, seed=53, gain=1.5)
+    net.to(device)
+    x = torch.rand(21, 8, 513, generator=torch.Generator().manual_seed(9))
+    want = O.s2s_step(sd, x, hop=8)
+    got = net.generate_step((x.to(device),), t=8)
+    again = net.generate_step((x.to(device),), t=8)
+    assert float((got.cpu() - want).abs().max()) <= 1e-4 * float(want.abs().max())
+    assert torch.equal(got, again)
+
+
 @pytest.mark.parametrize("tag", list(H.S2S_MULAW))
 def test_seq2seq_on_class_indices_matches_reference_golden(device, tag):
     """IOSpec.mulaw_io with an embedding input (tests/test_seq2seq.py:149-154): class indices in, the MLP head's argmax out, as
