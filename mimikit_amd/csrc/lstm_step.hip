@@ -11,6 +11,16 @@
 // workgroups, one per CU, 2 waves per SIMD; the first version (16 rows per workgroup, h staged in 64 KB of LDS) needed
 // two rounds of 512 single-resident workgroups and re-read the weights four times: 22 us against 6.8 us of MFMA work.
 // The new state goes to a second buffer (other workgroups still read the old one); the host swaps the two.
+//
+// What the weight stream costs (scripts/probes/l2_persist.hip, loads only, per launch of a back-to-back train): an XCD's L2 keeps
+// its lines from launch to launch - a 32 MB set read by the same workgroups comes back at > 11 TB/s (2.9 us with 2.5 us of launch),
+// a 40 MB one at 6 TB/s.  The two W_hh of H = 1024 are 33.5 MB = 4.19 MB per XCD beside the state and the gate terms: this kernel's
+// pattern (pairs of workgroups on 256 KiB of weights, 128 KiB of state each) takes 9.4 us there, ~100 MB through the L1s per step.
+// Measured and dropped in round 2: (1) the `nt` bit on the weight loads of a wave's last 1 - 4 chunks, so that the rest stays
+// resident: 456 -> 460 / 465 / 468 / 475 us per cfg-5 generate step (an nt line read by a pair of workgroups is fetched twice);
+// (2) a workgroup per 8 units and all 64 rows, W_hh packed as (i, f) / (g, o) tiles - every weight line has one reader, 7.1 us
+// in the probe: 483 us per generate step against 458 (549 without the bubbles): four state fragments per chunk instead of two put
+// 64 MB of reads on the same 512 KB of L2 lines.
 #include <type_traits>
 
 #include "lstm_step.h"
