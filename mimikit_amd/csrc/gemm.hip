@@ -112,6 +112,10 @@ int launch_gemm_f32(const float* A, int64_t lda, int64_t a_batch, const float* W
 //   * measured and dropped: the operands of TWO stages in flight (unconditional, masked loads so that the compiler's waits are
 //     counted ones, 182 VGPRs, no spills): 459.6 -> 458.8 us per cfg-5 generate step, i.e. nothing - a stage does not end in a
 //     wait for its loads when the grid fills the chip
+//   * the W fragments go through LDS as well (WLDS): each of the workgroup's four column tiles is fetched by one wave instead of two,
+//     a third less through the L1s - 462 -> 452 us per cfg-5 generate step (the 512 x 4096 x 516 products 34 -> 30 us; the
+//     512 x 4096 x 1024 ones stay at 50 us: they are neither L2-bound nor, at 146 - 155 TFLOP/s of sustained MFMA rate on this chip
+//     (scripts/probes/mfma_clock.hip), clock-bound; starting the CUs' second residents a part of a stage late changed nothing either)
 //   * a launch with few tiles (the output projection: 72 workgroups, 16 dependent stages of ~2 us each when a workgroup has a CU to
 //     itself) splits K over blockIdx.z and a second launch adds the partial sums in split order: 33 -> ~21 us for both launches
 constexpr int kTgThreads = 256;             // 4 waves as 2 x 2; two workgroups per CU run out of phase and fill each other's barrier / LDS waits
@@ -119,12 +123,14 @@ constexpr int kTgBM = 64, kTgBN = 64;
 constexpr int kTgCh = 4;                       // K-chunks (of 16) per pipeline stage: 1.7 us of MFMAs hide the next stage's loads
 constexpr int kTgLd = kTgCh * 16 + 4;          // LDS row stride: the 16 lanes of a quarter wave hit 64 different banks
 
+template <bool WLDS>   // WLDS: the W fragments go through LDS too (each of a workgroup's four column tiles is fetched by ONE wave)
 __global__ __launch_bounds__(kTgThreads, 2) void gemm_bias_act_kernel(const float* __restrict__ A, int64_t lda, const float* __restrict__ Wp,
                                                                  const float* __restrict__ bias, float* __restrict__ C, int64_t ldc,
                                                                  int M, int n_tiles, int N, int K, int k_chunks, int act, GemmRowMap rm,
                                                                  int k_split, float* __restrict__ partial) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   float* as = reinterpret_cast<float*>(smem_raw);              // [2][kTgBM][kTgLd]
+
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;                       // 32 rows x 32 columns per wave
@@ -157,15 +163,34 @@ __global__ __launch_bounds__(kTgThreads, 2) void gemm_bias_act_kernel(const floa
   const int t0 = tile0 < n_tiles ? tile0 : n_tiles - 1, t1 = tile0 + 1 < n_tiles ? tile0 + 1 : n_tiles - 1;
   gf32x4_ptr w0 = (gf32x4_ptr)(uintptr_t)Wp + (int64_t)t0 * k_chunks * 64 + lane;
   gf32x4_ptr w1 = (gf32x4_ptr)(uintptr_t)Wp + (int64_t)t1 * k_chunks * 64 + lane;
-  f32x4 wc[kTgCh][2], wx[kTgCh][2];
-  auto load_w = [&](int stage, f32x4 (&w)[kTgCh][2]) {
+  f32x4 wc[WLDS ? 1 : kTgCh][2], wx[WLDS ? 1 : kTgCh][2];
+  auto load_w = [&](int stage, f32x4 (&w)[WLDS ? 1 : kTgCh][2]) {
+    if constexpr (!WLDS) {
+#pragma unroll
+      for (int cc = 0; cc < kTgCh; ++cc) {
+        const int c = stage * kTgCh + cc;
+        const int cl = c < k_chunks ? c : k_chunks - 1;           // beyond K the A slab is zero: any fragment will do
+        w[cc][0] = w0[(int64_t)cl * 64];
+        w[cc][1] = w1[(int64_t)cl * 64];
+      }
+    }
+  };
+  // WLDS: wave (wm, wn) fetches column tile 2 wn + wm of the workgroup's four; every wave reads its two tiles back from LDS
+  f32x4* ws = reinterpret_cast<f32x4*>(as + 2 * kTgBM * kTgLd);      // [2][4 tiles][kTgCh][64 lanes]
+  const int tl = wn * 2 + wm;
+  const int tg = blockIdx.x * (kTgBN / 16) + tl;
+  gf32x4_ptr wl = (gf32x4_ptr)(uintptr_t)Wp + (int64_t)(tg < n_tiles ? tg : n_tiles - 1) * k_chunks * 64 + lane;
+  f32x4 vw[kTgCh];
+  auto load_wl = [&](int stage) {
 #pragma unroll
     for (int cc = 0; cc < kTgCh; ++cc) {
       const int c = stage * kTgCh + cc;
-      const int cl = c < k_chunks ? c : k_chunks - 1;           // beyond K the A slab is zero: any fragment will do
-      w[cc][0] = w0[(int64_t)cl * 64];
-      w[cc][1] = w1[(int64_t)cl * 64];
+      vw[cc] = wl[(int64_t)(c < k_chunks ? c : k_chunks - 1) * 64];
     }
+  };
+  auto store_wl = [&](int buf) {
+#pragma unroll
+    for (int cc = 0; cc < kTgCh; ++cc) ws[((buf * 4 + tl) * kTgCh + cc) * 64 + lane] = vw[cc];
   };
   f32x4 acc[2][2];
 #pragma unroll
@@ -175,36 +200,51 @@ __global__ __launch_bounds__(kTgThreads, 2) void gemm_bias_act_kernel(const floa
   const int st_first = (int)(((int64_t)blockIdx.z * all_stages) / k_split);
   const int n_stages = (int)(((int64_t)(blockIdx.z + 1) * all_stages) / k_split);
   load_a(st_first);
-  load_w(st_first, wc);
+  if constexpr (WLDS) load_wl(st_first);
+  else load_w(st_first, wc);
   store_a(st_first & 1);
+  if constexpr (WLDS) store_wl(st_first & 1);
   __syncthreads();
   const int x_off = (wm * 32 + (lane & 15)) * kTgLd + 4 * (lane >> 4);
   for (int st = st_first; st < n_stages; ++st) {
     const bool more = st + 1 < n_stages;
     if (more) {                                                // next stage's slab and fragments in flight
       load_a(st + 1);
-      load_w(st + 1, wx);
+      if constexpr (WLDS) load_wl(st + 1);
+      else load_w(st + 1, wx);
     }
     const float* x = as + (st & 1) * (kTgBM * kTgLd) + x_off;
+    const f32x4* wsb = ws + (((st & 1) * 4 + wn * 2) * kTgCh) * 64 + lane;
 #pragma unroll
     for (int cc = 0; cc < kTgCh; ++cc) {
-      f32x4 xv[2];
+      f32x4 xv[2], wf[2];
 #pragma unroll
       for (int r = 0; r < 2; ++r) xv[r] = *reinterpret_cast<const f32x4*>(x + r * 16 * kTgLd + cc * 16);
+      if constexpr (WLDS) {
+        wf[0] = wsb[cc * 64];
+        wf[1] = wsb[(kTgCh + cc) * 64];
+      } else {
+        wf[0] = wc[cc][0];
+        wf[1] = wc[cc][1];
+      }
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
-          acc[r][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[r][i], wc[cc][0][i], acc[r][0], 0, 0, 0);
-          acc[r][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[r][i], wc[cc][1][i], acc[r][1], 0, 0, 0);
+          acc[r][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[r][i], wf[0][i], acc[r][0], 0, 0, 0);
+          acc[r][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[r][i], wf[1][i], acc[r][1], 0, 0, 0);
         }
       }
     }
     if (more) {
       // the other buffer was last read in stage st - 1, which every wave left through the barrier below
       store_a((st + 1) & 1);
+      if constexpr (WLDS) {
+        store_wl((st + 1) & 1);
+      } else {
 #pragma unroll
-      for (int cc = 0; cc < kTgCh; ++cc) wc[cc][0] = wx[cc][0], wc[cc][1] = wx[cc][1];
+        for (int cc = 0; cc < kTgCh; ++cc) wc[cc][0] = wx[cc][0], wc[cc][1] = wx[cc][1];
+      }
     }
     __syncthreads();
   }
@@ -299,7 +339,12 @@ int launch_gemm_bias_act(const float* A, int64_t lda, const float* Wp, const flo
   if (ks > 1 && (int64_t)ks * M * n_tiles * 16 > partial_floats) ks = 1;
   dim3 grid((n_tiles + kTgBN / 16 - 1) / (kTgBN / 16), (M + kTgBM - 1) / kTgBM, ks), block(kTgThreads);
   const size_t lds = (size_t)2 * kTgBM * kTgLd * sizeof(float);
-  hipLaunchKernelGGL(gemm_bias_act_kernel, grid, block, lds, stream, A, lda, Wp, bias, C, ldc, M, n_tiles, N, K, k_chunks, act, rm, ks, partial);
+  const char* we = getenv("MMK_GEMM_WLDS");
+  if (!(we && we[0] == '0'))
+    hipLaunchKernelGGL(gemm_bias_act_kernel<true>, grid, block, lds + (size_t)2 * 4 * kTgCh * 64 * 16, stream, A, lda, Wp, bias, C, ldc, M, n_tiles, N, K,
+                       k_chunks, act, rm, ks, partial);
+  else
+    hipLaunchKernelGGL(gemm_bias_act_kernel<false>, grid, block, lds, stream, A, lda, Wp, bias, C, ldc, M, n_tiles, N, K, k_chunks, act, rm, ks, partial);
   MMK_HIP(hipGetLastError());
   if (ks > 1) {
     hipLaunchKernelGGL(gemm_split_reduce_kernel, dim3(M), dim3(256), 0, stream, partial, ks, M, n_tiles * 16, N, bias, C, ldc, act, rm);

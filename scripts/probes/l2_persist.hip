@@ -97,11 +97,13 @@ __global__ __launch_bounds__(512) void read_step_kernel(const f32x4* __restrict_
 
 // today's LSTM step: workgroups b and b + 64 share 256 KiB of weights, each reads the 128 KiB state of its 32 rows (shared by the 64
 // workgroups of its direction and row block) and 16 KiB of moving gate terms
+template <int ROT, bool WITH_H>
 __global__ __launch_bounds__(512) void read_step_now_kernel(const f32x4* __restrict__ wbase, const f32x4* __restrict__ hbase,
                                                             const f32x4* __restrict__ gbase, float* sink) {
   const int slice = (blockIdx.x % 64) + 64 * (blockIdx.x / 128);
   const f32x4* p = wbase + (size_t)slice * 32 * 512 + threadIdx.x;
   const f32x4* h = hbase + (size_t)(blockIdx.x / 64) * 16 * 512 + threadIdx.x;
+  const int rot = ROT ? (blockIdx.x * ROT) & 15 : 0;       // ROT: every workgroup starts its sweep over the shared state elsewhere
   const f32x4* g = gbase + (size_t)blockIdx.x * 2 * 512 + threadIdx.x;
   f32x4 v[32], hv[16], gv[2];
 #pragma unroll
@@ -110,7 +112,8 @@ __global__ __launch_bounds__(512) void read_step_now_kernel(const f32x4* __restr
   for (int u = 0; u < 16; ++u) {
     asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v[2 * u]) : "v"(p + (size_t)(2 * u) * 512) : "memory");
     asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v[2 * u + 1]) : "v"(p + (size_t)(2 * u + 1) * 512) : "memory");
-    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(hv[u]) : "v"(h + (size_t)u * 512) : "memory");
+    if (WITH_H) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(hv[u]) : "v"(h + (size_t)((u + rot) & 15) * 512) : "memory");
+    else hv[u] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
@@ -122,13 +125,14 @@ __global__ __launch_bounds__(512) void read_step_now_kernel(const f32x4* __restr
   if (acc[0] == 123.456f) sink[blockIdx.x] = acc[1];
 }
 
+template <int ROT, bool WITH_H>
 static void step_now_train(const f32x4* base, float* sink) {
   hipEvent_t a, b;
   hipEventCreate(&a); hipEventCreate(&b);
   const f32x4* hbase = base + ((size_t)64 << 20) / 16;
   const f32x4* gbase = base + ((size_t)96 << 20) / 16;
   auto go = [&](int i) {
-    hipLaunchKernelGGL(read_step_now_kernel, dim3(256), dim3(512), 0, 0, base, hbase + (size_t)(i % 2) * 64 * 512, gbase + (size_t)(i % 8) * 512 * 512, sink);
+    hipLaunchKernelGGL((read_step_now_kernel<ROT, WITH_H>), dim3(256), dim3(512), 0, 0, base, hbase + (size_t)(i % 2) * 64 * 512, gbase + (size_t)(i % 8) * 512 * 512, sink);
   };
   for (int i = 0; i < 4; ++i) go(i);
   hipDeviceSynchronize();
@@ -138,7 +142,8 @@ static void step_now_train(const f32x4* base, float* sink) {
   hipDeviceSynchronize();
   float ms = 0;
   hipEventElapsedTime(&ms, a, b);
-  printf("today's step pattern (pairs on 256 KiB of weights; 128 KiB state per row block; moving gate terms): %6.2f us per launch\n", 1e3 * ms / 40);
+  printf("today's step pattern (pairs on 256 KiB of weights; %s; moving gate terms; sweep rotated by %d x workgroup): %6.2f us per launch\n",
+         WITH_H ? "128 KiB state per row block" : "no state reads", ROT, 1e3 * ms / 40);
 }
 
 template <int NT_F4>
@@ -204,7 +209,10 @@ int main() {
   one<32>(base, sink);    //  64 MB
   one<17>(base, sink);    //  34 MB: just over
   one<18>(base, sink);    //  36 MB
-  step_now_train(base, sink);
+  step_now_train<0, true>(base, sink);
+  step_now_train<1, true>(base, sink);
+  step_now_train<3, true>(base, sink);
+  step_now_train<0, false>(base, sink);
   step_train<0>(base, sink);
   step_train<2>(base, sink);
   step_train<4>(base, sink);
