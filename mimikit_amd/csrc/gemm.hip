@@ -116,6 +116,13 @@ int launch_gemm_f32(const float* A, int64_t lda, int64_t a_batch, const float* W
 //     a third less through the L1s - 462 -> 452 us per cfg-5 generate step (the 512 x 4096 x 516 products 34 -> 30 us; the
 //     512 x 4096 x 1024 ones stay at 50 us: they are neither L2-bound nor, at 146 - 155 TFLOP/s of sustained MFMA rate on this chip
 //     (scripts/probes/mfma_clock.hip), clock-bound; starting the CUs' second residents a part of a stage late changed nothing either)
+//   * where the 50 us of a 512 x 4096 x 1024 product are (timing builds, rocprofv3 durations): without the global loads after the first
+//     stage 45 us, without loads and LDS stores 41 us, without the MFMAs 25 us; the fp32 MFMA rate of this chip is 133 - 140 TFLOP/s
+//     with one wave per SIMD, 146 - 153 with two, 154 with four (the clock follows occupancy and kernel length: 2.12 - 2.39 GHz), i.e.
+//     ~35 us for this structure at its best.  No effect: starting one of a CU's two workgroups late (by grid half, by hardware wave
+//     slot parity), the LDS reads of chunk c + 1 in front of the MFMAs of chunk c.  Next: one workgroup of 4 waves per CU on a
+//     64 x 128 tile (no SIMD shared between workgroups with their own barriers), three LDS buffers so that a stage's first reads can
+//     go out before the barrier.
 //   * a launch with few tiles (the output projection: 72 workgroups, 16 dependent stages of ~2 us each when a workgroup has a CU to
 //     itself) splits K over blockIdx.z and a second launch adds the partial sums in split order: 33 -> ~21 us for both launches
 constexpr int kTgThreads = 256;             // 4 waves as 2 x 2; two workgroups per CU run out of phase and fill each other's barrier / LDS waits

@@ -39,7 +39,7 @@ int main() {
   srand(1);
   for (auto& v : h) v = (rand() / (float)RAND_MAX - 0.5f) * 1e-3f;
   hipMemcpy(src, h.data(), 4096 * 4, hipMemcpyHostToDevice);
-  for (int wgs_per_cu = 2; wgs_per_cu <= 4; wgs_per_cu += 2) {
+  for (int wgs_per_cu = 1; wgs_per_cu <= 4; wgs_per_cu *= 2) {
     for (int iters : {2000, 20000}) {
       const int grid = 256 * wgs_per_cu;
       hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
