@@ -120,9 +120,9 @@ int launch_gemm_f32(const float* A, int64_t lda, int64_t a_batch, const float* W
 //     stage 45 us, without loads and LDS stores 41 us, without the MFMAs 25 us; the fp32 MFMA rate of this chip is 133 - 140 TFLOP/s
 //     with one wave per SIMD, 146 - 153 with two, 154 with four (the clock follows occupancy and kernel length: 2.12 - 2.39 GHz), i.e.
 //     ~35 us for this structure at its best.  No effect: starting one of a CU's two workgroups late (by grid half, by hardware wave
-//     slot parity), the LDS reads of chunk c + 1 in front of the MFMAs of chunk c.  Next: one workgroup of 4 waves per CU on a
-//     64 x 128 tile (no SIMD shared between workgroups with their own barriers), three LDS buffers so that a stage's first reads can
-//     go out before the barrier.
+//     slot parity), the LDS reads of chunk c + 1 in front of the MFMAs of chunk c.  One workgroup of 4 waves per CU on a
+//     64 x 128 tile (no SIMD shared between workgroups with their own barriers, 32 MFMAs per 6 LDS reads, masked unconditional
+//     loads, 148 VGPRs) was built and measured too: 63 us - with one wave per SIMD every wait is the SIMD's.
 //   * a launch with few tiles (the output projection: 72 workgroups, 16 dependent stages of ~2 us each when a workgroup has a CU to
 //     itself) splits K over blockIdx.z and a second launch adds the partial sums in split order: 33 -> ~21 us for both launches
 constexpr int kTgThreads = 256;             // 4 waves as 2 x 2; two workgroups per CU run out of phase and fill each other's barrier / LDS waits
