@@ -122,7 +122,10 @@ int launch_gemm_f32(const float* A, int64_t lda, int64_t a_batch, const float* W
 //     ~35 us for this structure at its best.  No effect: starting one of a CU's two workgroups late (by grid half, by hardware wave
 //     slot parity), the LDS reads of chunk c + 1 in front of the MFMAs of chunk c.  One workgroup of 4 waves per CU on a
 //     64 x 128 tile (no SIMD shared between workgroups with their own barriers, 32 MFMAs per 6 LDS reads, masked unconditional
-//     loads, 148 VGPRs) was built and measured too: 63 us - with one wave per SIMD every wait is the SIMD's.
+//     loads, 148 VGPRs) was built and measured too: 63 us - with one wave per SIMD every wait is the SIMD's.  Stages of 32 k (twice the barriers) take
+//     the same 50 us, so do 1024 workgroups (split K, four per CU): neither the barriers nor the number of waves that can hide a
+//     wait is the limit.  s_memtime / s_memrealtime around the K loop of a workgroup: 43.4 us at 2.05 - 2.19 GHz = 5700 clocks per
+//     stage against the 4096 its SIMD's 128 MFMAs take (72 % busy inside the loop); 6.6 us of a launch are outside the loop.
 //   * a launch with few tiles (the output projection: 72 workgroups, 16 dependent stages of ~2 us each when a workgroup has a CU to
 //     itself) splits K over blockIdx.z and a second launch adds the partial sums in split order: 33 -> ~21 us for both launches
 constexpr int kTgThreads = 256;             // 4 waves as 2 x 2; two workgroups per CU run out of phase and fill each other's barrier / LDS waits
