@@ -223,8 +223,9 @@ class Seq2SeqLSTMNetwork(ARMWithHidden, nn.Module):
         if not (1 <= cfg.enc_n_lstm <= 8 and 1 <= cfg.dec_n_lstm <= 8):
             unsupported.append("more than 8 LSTMs per side")
         heads = list(self.output_module.heads)
-        if len(heads) != 1 or len(cfg.io_spec.inputs) != 1:
-            unsupported.append("more than one input / target")
+        if len(heads) != 1 or (discrete and len(cfg.io_spec.inputs) != 1):
+            # (several continuous inputs are just added up, `input_module = sum`, :202-204: done in front of the plan)
+            unsupported.append("more than one target, or more than one discrete input")
         elif discrete:
             head = heads[0]
             est = getattr(head, "estimator", None)

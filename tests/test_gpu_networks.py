@@ -472,6 +472,28 @@ def test_seq2seq_lstm_stacks(device, tag):
     assert out.shape == (2, 12, 65) and bool(torch.isfinite(out).all())
 
 
+def test_seq2seq_adds_up_several_continuous_inputs(device):
+    """`input_module = sum` for continuous inputs (s2s_lstm_v2.py:202-204): two frame inputs are added in front of the encoder; the
+    loop writes the one output into the first tensor and leaves the second as the dataloader gave it (loops/generate.py:214-219)"""
+    io1 = mmk.IOSpec.magspec_io(mmk.IOSpec.MagSpecIOConfig(n_fft=128, hop_length=32))
+    io = mmk.IOSpec(inputs=(io1.inputs[0], io1.inputs[0]), targets=io1.targets)
+    net = mmk.Seq2SeqLSTMNetwork.from_config(mmk.Seq2SeqLSTMNetwork.Config(io_spec=io, model_dim=32, hop=4)).eval()
+    from oracle.weights import load_recipe
+    sd = load_recipe(net, seed=41, gain=1.5)
+    net.to(device)
+    g = torch.Generator().manual_seed(12)
+    a, b = torch.rand(5, 4, 65, generator=g), torch.rand(5, 4, 65, generator=g)
+    want = O.s2s_step(sd, a + b, hop=4)
+    got = net.generate_step((a.to(device), b.to(device)), t=4).cpu()
+    assert float((got - want).abs().max()) <= 1e-4 * float(want.abs().max())
+    pa, pb = torch.rand(2, 6, 65, generator=g), torch.rand(2, 6, 65, generator=g)
+    out = run_loop(net, (pa, pb), 8)
+    assert len(out) == 2 and out[0].shape == (2, 14, 65)
+    first = O.s2s_step(sd, (pa + pb)[:, -4:], hop=4)
+    assert float((out[0][:, 6:10].cpu() - first).abs().max()) <= 1e-4 * float(first.abs().max())
+    assert bool((out[1][:, 6:].cpu() == 0).all()) and torch.equal(out[1][:, :6].cpu(), pb)
+
+
 @pytest.mark.parametrize("ksplit", ["1", "2", "3", "8"])
 def test_seq2seq_gemm_split_k(device, monkeypatch, ksplit):
     """the tiled GEMM with K cut over 1 / 2 / 3 / 8 workgroups per tile (uneven stage ranges, K = 513 with a ragged last stage) and
