@@ -472,6 +472,33 @@ def test_seq2seq_lstm_stacks(device, tag):
     assert out.shape == (2, 12, 65) and bool(torch.isfinite(out).all())
 
 
+def test_seq2seq_block_with_a_clipped_last_step_through_the_tiled_gemm(device):
+    """20 clips x hop 8 = 160 rows: the output projection takes the tiled GEMM (27 tiles: K split eight ways) and scatters its
+    rows into the caller's strided tensor itself; 19 new frames = two whole steps and one clipped to 3 frames, whose other 5
+    rows must not be written anywhere (the frames behind the tensor's end belong to the next clip)"""
+    io = mmk.IOSpec.magspec_io(mmk.IOSpec.MagSpecIOConfig(sr=22050, n_fft=1024, hop_length=256))
+    net = mmk.Seq2SeqLSTMNetwork.from_config(mmk.Seq2SeqLSTMNetwork.Config(io_spec=io, model_dim=128, hop=8)).eval()
+    from oracle.weights import load_recipe
+    sd = load_recipe(net, seed=59, gain=1.5)
+    net.to(device)
+    B, P, n = 20, 8, 19
+    prompt = torch.rand(B, P, 513, generator=torch.Generator().manual_seed(15))
+    want = O.s2s_generate(sd, prompt, n, hop=8)
+    flat = torch.full((B * (P + n) + 8, 513), -7.0)              # clips back to back, a guard of 8 frames behind the last one
+    frames = flat[:B * (P + n)].view(B, P + n, 513)
+    frames[:, :P] = prompt
+    frames[:, P:] = 0
+    dev = flat.to(device)
+    dframes = dev[:B * (P + n)].view(B, P + n, 513)
+    net.before_generate((dframes[:, :P],), 0)
+    assert net.generate_block((dframes,), P, n) is True
+    net.after_generate((dframes,), 0)
+    got = dframes.cpu()
+    assert float((got - want).abs().max()) <= 2e-4 * float(want.abs().max())
+    assert bool((dev[B * (P + n):] == -7.0).all())                # nothing behind the last clip
+    assert torch.equal(got[:, :P], prompt)                        # a clipped step of clip b must not reach into clip b + 1's prompt
+
+
 def test_seq2seq_adds_up_several_continuous_inputs(device):
     """`input_module = sum` for continuous inputs (s2s_lstm_v2.py:202-204): two frame inputs are added in front of the encoder; the
     loop writes the one output into the first tensor and leaves the second as the dataloader gave it (loops/generate.py:214-219)"""
