@@ -22,7 +22,7 @@ from ..io_spec import IOSpec
 from ..modules.io import ZipReduceVariables
 from ..modules.misc import Chunk
 from ..modules.mlp import MLP
-from ..modules.targets import CategoricalSampler
+from ..modules.targets import CategoricalSampler, per_row_temperature
 from ..modules.resamplers import LinearResampler
 from ..utils import AutoStrEnum
 from .arm import ARMWithHidden, NetworkConfig, fold_weight_norm, weight_norm_leaves
@@ -198,7 +198,7 @@ class Seq2SeqLSTMNetwork(ARMWithHidden, nn.Module):
     def forward(self, x: Tuple, temperature=None):
         if self.training:
             return self._forward_autograd(x, temperature)
-        return self._device_step(tuple(x))
+        return self._device_step(tuple(x), temperature)
 
     # -- HIP plan ---------------------------------------------------------------------
     def _describe(self, max_batch: int) -> native.S2SConfig:
@@ -278,15 +278,26 @@ class Seq2SeqLSTMNetwork(ARMWithHidden, nn.Module):
             self._plan.commit()
             self._weights_token = token
 
-    def _device_step(self, inputs: Tuple[torch.Tensor, ...]):
+    def _device_step(self, inputs: Tuple[torch.Tensor, ...], temperature=None):
         native.require_device(*inputs)
         if self.input_module is not sum:
             x = inputs[0]
             if x.size(1) != self._config.hop:
                 raise AssertionError(f"expected {self._config.hop} input classes, got {x.size(1)}")
             self._ensure_plan(x.size(0), refresh_weights=False)
-            # the reference returns argmax * w with w the float weight of ZipReduceVariables: a float tensor (modules/io.py:310)
-            return self._plan.step_classes(x.long()).to(torch.float32)
+            y = self._plan.step_classes(x.long())
+            if temperature is not None:
+                # an eval-mode forward with a temperature (decode hands it to the sampler, :250-253; generate_step never does): one draw
+                # per (clip, position) from softmax(logits / T) - the reference's torch.multinomial stream cannot be reproduced, the HIP
+                # sampler inverts the CDF of the same distribution at uniforms drawn here
+                c = self._plan.cfg
+                raw = self._plan.last_logits(x.size(0))
+                rows = x.size(0) * c.hop
+                t = per_row_temperature(temperature, x.size(0), x.device).repeat_interleave(c.hop)
+                u = torch.rand(rows, device=x.device, dtype=torch.float32)
+                y = native.categorical_sample(raw, c.out_dim, bool(c.learn_temp), float(c.min_temp), t, u).reshape(x.size(0), c.hop)
+            # the reference returns classes * w with w the float weight of ZipReduceVariables: a float tensor (modules/io.py:310)
+            return y.to(torch.float32)
         x = inputs[0] if len(inputs) == 1 else sum(inputs)
         if x.size(1) != self._config.hop:
             raise AssertionError(f"expected {self._config.hop} input frames, got {x.size(1)}")

@@ -605,6 +605,33 @@ def test_seq2seq_on_class_indices_vs_oracle(device, hop, batch, model_dim, mlp_d
     assert torch.equal(y.cpu()[ok], want[ok])
 
 
+def test_seq2seq_on_class_indices_eval_forward_with_a_temperature(device, monkeypatch):
+    """`net(x, temperature=T)` in eval mode samples (s2s_lstm_v2.py:246-253 hands the temperature to the sampler; generate_step does
+    not): every draw lies in the CDF interval of softmax(logits / T) that its uniform selects (helpers.sampled_picks_ok), for a
+    scalar and for one temperature per clip"""
+    import warnings
+    warnings.filterwarnings("ignore")
+    net, sd, hop, arch = H.s2s_mulaw("mlp0")
+    net.to(device)
+    x = torch.randint(0, 256, (6, hop), generator=torch.Generator().manual_seed(4))
+    _, raw = O.s2s_step(O.fold_weight_norm(sd), x, hop, return_raw=True, **arch)
+    drawn = {}
+    real_rand = torch.rand
+
+    def rand(*a, **k):
+        drawn["u"] = real_rand(*a, **k)
+        return drawn["u"]
+
+    monkeypatch.setattr(torch, "rand", rand)
+    for temp in (0.7, torch.tensor([0.5, 1.0, 2.0, 0.25, 1.5, 1.0])):
+        y = net((x.to(device),), temperature=temp)
+        assert y.dtype == torch.float32 and y.shape == (6, hop)
+        t = torch.as_tensor(temp, dtype=torch.float32).reshape(-1).expand(6) if not isinstance(temp, torch.Tensor) else temp
+        ok, exact = H.sampled_picks_ok(raw, t, drawn["u"].cpu().reshape(6, hop), y.cpu().long())
+        assert bool(ok.all())
+    assert len({float(v) for v in y.cpu().flatten()}) > 1
+
+
 def test_seq2seq_class_and_frame_entry_points_do_not_mix(device):
     """a plan for class indices refuses frames and the other way round (the C-ABI's error, not a crash)"""
     net, sd, hop, arch = H.s2s_mulaw("mlp0")
