@@ -146,8 +146,11 @@ __global__ __launch_bounds__(kTgThreads, 2) void gemm_bias_act_kernel(const floa
   const int wm = wave >> 1, wn = wave & 1;                       // 32 rows x 32 columns per wave
   const int m_first = blockIdx.y * kTgBM;
   const int tile0 = blockIdx.x * (kTgBN / 16) + wn * 2;         // this wave's two column tiles
-  // A slab loader: thread t moves row t / 4, floats 4 (t % 4) .. + 3 of each of the stage's chunks
-  const int a_row = tid >> 2, a_col = (tid & 3) * 4;
+  // A slab loader: four lanes move one row's 16 floats of each of the stage's chunks.  Rows 4 apart sit in neighbouring lane quads:
+  // at a row stride of 68 floats the sixteen lanes of a quarter wave then write 64 different banks (consecutive rows in consecutive
+  // quads collide four ways: SQ_LDS_BANK_CONFLICT 13.7 M -> 6.8 M cycles over the GEMM launches of a cfg-5 pass, LDS-active 41 -> 34 M;
+  // the launches take the same time - LDS is not what they wait for)
+  const int a_row = 16 * wave + (lane >> 4) + 4 * ((lane >> 2) & 3), a_col = (lane & 3) * 4;
   const int r0 = m_first + a_row;
   const float* a0 = A + (int64_t)(r0 < M ? r0 : M - 1) * lda + a_col;     // clamped rows are never stored
   f32x4 va[kTgCh];
