@@ -154,6 +154,7 @@ class WaveNetJob:
             except (OSError, ValueError):
                 pass
             kname = ("wavenet_pipe_kernel (layers spread over the XCDs, weights resident on chip, clip groups pipelined)" if plan.pipelined
+                     else "wavenet_lpipe_kernel (four workgroups per clip that own whole layers, weights in registers)" if plan.layer_pipelined
                      else "wavenet_chain_kernel (one hand-off per layer)" if plan.chain else "wavenet_persist_kernel")
             return {"bound": "hbm", "kernel": kname + ": all layers + head of every step of a block",
                     "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -1,0 +1,287 @@
+// WaveNet generation as a PIPELINE OF WORKGROUPS THAT OWN WHOLE LAYERS (gfx950) - for networks small enough that a layer's matrices
+// fit a fraction of a CU's registers: C = S = 64 channels, kernel 2, gated, MLP head 64 -> 128 -> 256 (+ temperature), no conditioning
+// (BASELINE config 2: ten layers, dilations 1 .. 512, 8 clips).
+//
+// Reference: WaveNet.forward / WNLayer.forward (wavenet_v2.py:120-180, :277-296), MLP head and CategoricalSampler (networks/mlp.py:58-63,
+// modules/targets.py:37-52) - the same arithmetic as the other step kernels, on the launch path's packed matrices.
+//
+// The chain kernel (wavenet_chain.hip) spreads every layer over C / 8 workgroups and pays one cross-CU exchange per layer: 11 dependent
+// exchanges of ~1.5 us bound a step of this network at 18 us.  Here a clip is served by four workgroups (placed on one XCD: workgroup b
+// serves clip (b % 8) + 8 (b / 32) as stage (b / 8) % 4); a stage keeps the matrices of its two or three layers in registers for the
+// whole launch (48 floats per thread and layer: thread (o, kq) holds a quarter of output row o) and runs them back to back out of LDS
+// (a layer = 32 + 16 FMAs per thread, two quad reductions, four workgroup barriers).  A step crosses the chip four times instead of
+// eleven: the layer input and the skip sum travel to the next stage as 128 data-tagged 8-byte granules {step + 1, value}, the head's
+// class goes back to stage 0 the same way.  The delayed taps x_l[t - d_l] are read from the launch path's history rings in global
+// memory (L2), requested at the start of a stage's visit, and every layer input is written there - so the warm-up is the same prefill
+// as for the other persistent kernels, scattered into those rings.  scripts/probes/wn_layer_pipe.hip is the stand-alone form.
+#include "wavenet_lpipe.h"
+#include "sampler256.h"
+
+namespace mmk {
+
+namespace {
+
+typedef unsigned long long u64;
+typedef float f32x4_lp __attribute__((ext_vector_type(4)));
+constexpr int kC = 64, kH1 = 128, kQ = 256;
+constexpr int kLpThreads = 512;
+constexpr unsigned kLpSpinLimit = 1u << 22;
+
+// element (row n, column k) of a matrix packed for the fused-linear kernel: Wp[tile][chunk][lane = 16 (k % 16 / 4) + n % 16][k % 4]
+__device__ __forceinline__ float packed_at(const float* wp, int k_chunks, int n, int k) {
+  return wp[((((int64_t)(n >> 4) * k_chunks + (k >> 4)) * 64) + ((k & 15) >> 2) * 16 + (n & 15)) * 4 + (k & 3)];
+}
+
+__device__ __forceinline__ float quad_sum(float v) {
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, false));   // quad_perm [1,0,3,2]
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xf, 0xf, false));   // quad_perm [2,3,0,1]
+  return v;
+}
+
+__device__ __forceinline__ u64 poll(const u64* p, unsigned epoch, int32_t* err) {
+  u64 g = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  unsigned spins = 0;
+  while ((unsigned)(g >> 32) != epoch) {
+    // ~1 s: the other stages are not running beside this one (or another wait has already failed: do not pile up)
+    if (++spins > kLpSpinLimit || ((spins & 1023u) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+      atomicExch(err, 3);
+      break;
+    }
+    g = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  return g;
+}
+
+template <int NL, bool HEAD, bool FIRST>
+__device__ void run_stage(const WnLpipeArgs& a, int clip, int stage, int l0, float* embs) {
+  __shared__ __attribute__((aligned(16))) float xs[kC], taps[3][kC], fg[2 * kC], zs[kC], sk[kC], hid[kH1], lg[kQ + 4];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int o = tid >> 2, kq = tid & 3;
+  // ---- this stage's matrices -> registers (once per launch) -------------------------------------------------------------------
+  float wc[NL][32], wr[NL][16], bc[NL], br[NL];
+  int dil[NL], has_res[NL];
+#pragma unroll
+  for (int i = 0; i < NL; ++i) {
+    const WnLayerTab lt = a.layers[l0 + i];
+    dil[i] = lt.dil;
+    has_res[i] = lt.has_res;
+    // (f | g) rows: unit u < 64 -> packed row 2 u (f), unit 64 + u -> packed row 2 u + 1 (g); K = [x(t - d) | x(t)]
+    const int ra = o < kC ? 2 * o : 2 * (o - kC) + 1;
+#pragma unroll
+    for (int k = 0; k < 32; ++k) wc[i][k] = packed_at(lt.A_wp, 8, ra, kq * 32 + k);
+    bc[i] = lt.A_bias ? lt.A_bias[ra] : 0.f;
+    // [res ; skip] rows: without residual rows (the last layer) the skip rows come first
+    const int rb = lt.has_res ? o : o - kC;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) wr[i][k] = rb >= 0 ? packed_at(lt.B_wp, 4, rb, kq * 16 + k) : 0.f;
+    br[i] = (rb >= 0 && lt.B_bias) ? lt.B_bias[rb] : 0.f;
+  }
+  float w0[HEAD ? 16 : 1], w2[HEAD ? 64 : 1], wt[HEAD ? 2 : 1], b0 = 0.f, b2 = 0.f, bt = 0.f;
+  if constexpr (HEAD) {
+#pragma unroll
+    for (int k = 0; k < 16; ++k) w0[k] = packed_at(a.fc0_wp, 4, o, kq * 16 + k);
+    b0 = a.fc0_bias[o];
+#pragma unroll
+    for (int k = 0; k < 64; ++k) w2[k] = packed_at(a.fc2_wp, 8, tid >> 1, (tid & 1) * 64 + k);
+    b2 = a.fc2_bias[tid >> 1];
+    wt[0] = wt[1] = 0.f;
+    if (a.learn_temp) {   // row 256: the temperature column, on wave 0 (two inputs per lane)
+      wt[0] = packed_at(a.fc2_wp, 8, kQ, lane);
+      wt[1] = packed_at(a.fc2_wp, 8, kQ, 64 + lane);
+      bt = a.fc2_bias[kQ];
+    }
+  }
+  if constexpr (FIRST) {
+    for (int i = tid; i < kQ * kC; i += kLpThreads) embs[i] = a.emb[i];
+  }
+  __syncthreads();
+  const u64* in_g = a.xg + ((int64_t)stage * a.Bmax + clip) * 128;
+  u64* out_g = a.xg + ((int64_t)(stage + 1) * a.Bmax + clip) * 128;
+  const int64_t slot_stride = (int64_t)a.Bmax * kC;
+  for (int s = 0; s < (int)a.n_steps; ++s) {
+    const int64_t tau = a.t0 - 1 + s;                    // the input position of this step; the class it produces goes to tau + 1
+    // ---- the delayed taps of my layers (addresses known) ------------------------------------------------------------------------
+    float tap = 0.f;
+    if (tid < kC * NL) {
+      const int i = tid >> 6;
+      const int64_t tp = tau - dil[i];
+      // (past this CU's L1: the slot was read a ring ago and rewritten since)
+      tap = tp >= 0 ? __hip_atomic_load(a.hist[l0 + i] + (tp & (a.ring[l0 + i] - 1)) * slot_stride + (int64_t)clip * kC + lane, __ATOMIC_RELAXED,
+                                        __HIP_MEMORY_SCOPE_AGENT)
+                    : 0.f;
+    }
+    // ---- this step's input -----------------------------------------------------------------------------------------------------------
+    if constexpr (FIRST) {
+      if (wave == 0) {
+        int64_t cls;
+        if (s == 0) cls = a.idx[(int64_t)clip * a.idx_rs + tau];
+        else cls = (int64_t)(unsigned)poll(a.cg + clip, (unsigned)s, a.err_flag);
+        cls = cls < 0 ? 0 : (cls >= kQ ? kQ - 1 : cls);
+        xs[lane] = embs[cls * kC + lane];
+        sk[lane] = 0.f;
+      }
+    } else if (tid < 2 * kC) {
+      const u64 g = poll(in_g + tid, (unsigned)(s + 1), a.err_flag);
+      (tid < kC ? xs : sk)[tid & (kC - 1)] = __uint_as_float((unsigned)g);
+    }
+    if (tid < kC * NL) taps[tid >> 6][lane] = tap;
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+      // the layer's input at tau goes to its ring for later taps (and for the launch path, should the batch be redone there)
+      if (tid < kC) a.hist[l0 + i][(tau & (a.ring[l0 + i] - 1)) * slot_stride + (int64_t)clip * kC + tid] = xs[tid];
+      const float* src = kq < 2 ? taps[i] + kq * 32 : xs + (kq - 2) * 32;
+      float acc = 0.f;
+#pragma unroll
+      for (int k = 0; k < 32; ++k) acc = fmaf(wc[i][k], src[k], acc);
+      acc = quad_sum(acc);
+      if (kq == 0) fg[o] = acc + bc[i];
+      __syncthreads();
+      if (tid < kC) zs[tid] = tanhf(fg[tid]) * sigmoidf_(fg[kC + tid]);      // wavenet_v2.py:151
+      __syncthreads();
+      float a2 = 0.f;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) a2 = fmaf(wr[i][k], zs[kq * 16 + k], a2);
+      a2 = quad_sum(a2);
+      __syncthreads();                                                      // every thread has read xs / zs of this layer
+      if (kq == 0) {
+        if (has_res[i]) {
+          if (o < kC) xs[o] = xs[o] + (a2 + br[i]);                         // :165-170
+          else sk[o - kC] += a2 + br[i];                                    // :172-176
+        } else if (o >= kC) {
+          sk[o - kC] += a2 + br[i];
+        }
+      }
+      __syncthreads();
+    }
+    if constexpr (!HEAD) {
+      if (tid < 2 * kC) {
+        const float v = tid < kC ? xs[tid] : sk[tid - kC];
+        __hip_atomic_store(out_g + tid, ((u64)(unsigned)(s + 1) << 32) | __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    } else {
+      // ---- head: Linear(64 -> 128), Mish, Linear(128 -> 256 [+ 1]), [temperature], argmax / inverse-CDF draw -----------------
+      float h = 0.f;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) h = fmaf(w0[k], sk[kq * 16 + k], h);
+      h = quad_sum(h);
+      if (kq == 0) hid[o] = mishf_(h + b0);
+      __syncthreads();
+      float q = 0.f;
+      const float* hs = hid + (tid & 1) * 64;
+#pragma unroll
+      for (int k = 0; k < 64; ++k) q = fmaf(w2[k], hs[k], q);
+      q += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(q), 0xB1, 0xf, 0xf, false));
+      if ((tid & 1) == 0) lg[tid >> 1] = q + b2;
+      if (wave == 0 && a.learn_temp) {
+        float tv = fmaf(wt[0], hid[lane], wt[1] * hid[64 + lane]);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) tv += __shfl_xor(tv, off);
+        if (lane == 0) lg[kQ] = tv + bt;
+      }
+      __syncthreads();
+      if (wave == 0) {
+        float denom = 1.f;
+        if (a.learn_temp) denom = fmaxf(sigmoidf_(lg[kQ]), a.min_temp);       // mlp.py:60-62
+        if (a.logits_out && s + 1 == (int)a.n_steps)
+          for (int c = lane; c < kQ + (a.learn_temp ? 1 : 0); c += 64) a.logits_out[(int64_t)clip * a.logits_ld + c] = lg[c];
+        int result;
+        if (a.temperature == nullptr) {
+          const f32x4_lp v4 = *reinterpret_cast<const f32x4_lp*>(lg + lane * 4);
+          float vv[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) vv[j] = a.learn_temp ? v4[j] / denom : v4[j];
+          float best = vv[0];
+          int bi = lane * 4;
+#pragma unroll
+          for (int j = 1; j < 4; ++j)
+            if (vv[j] > best) { best = vv[j]; bi = lane * 4 + j; }
+          result = wave_argmax_first(best, bi);
+        } else {
+          result = sample_256(lg, a.learn_temp != 0, denom, a.temperature[clip], a.uniforms[(int64_t)clip * a.uni_ld + s], lane);
+        }
+        if (lane == 0) {
+          a.idx[(int64_t)clip * a.idx_rs + tau + 1] = result;
+          __hip_atomic_store(a.cg + clip, ((u64)(unsigned)(s + 1) << 32) | (unsigned)result, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(kLpThreads) void wavenet_lpipe_kernel(const WnLpipeArgs a) {
+  __shared__ float embs[kQ * kC];                    // stage 0's copy of the embedding table (64 KiB)
+  const int b = blockIdx.x;
+  const int clip = (b & 7) + 8 * (b >> 5), stage = (b >> 3) & 3;
+  if (clip >= a.B) return;
+  const int l0 = a.first[stage], nl = a.first[stage + 1] - l0;
+  if (stage == 0) {
+    if (nl == 3) run_stage<3, false, true>(a, clip, stage, l0, embs);
+    else if (nl == 2) run_stage<2, false, true>(a, clip, stage, l0, embs);
+    else run_stage<1, false, true>(a, clip, stage, l0, embs);
+  } else if (stage < kLpStages - 1) {
+    if (nl == 3) run_stage<3, false, false>(a, clip, stage, l0, embs);
+    else if (nl == 2) run_stage<2, false, false>(a, clip, stage, l0, embs);
+    else run_stage<1, false, false>(a, clip, stage, l0, embs);
+  } else {
+    if (nl == 2) run_stage<2, true, false>(a, clip, stage, l0, embs);
+    else run_stage<1, true, false>(a, clip, stage, l0, embs);
+  }
+}
+
+__global__ __launch_bounds__(256) void wn_lpipe_scatter_kernel(const float* __restrict__ h, int64_t h_batch, int64_t t_begin, int64_t t_lo, int n_pos,
+                                                               int C, int B, int Bmax, float* __restrict__ ring, int ring_slots) {
+  const int64_t total = (int64_t)n_pos * B * C;
+  for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(q % C);
+    const int b = (int)((q / C) % B);
+    const int64_t t = t_lo + q / ((int64_t)C * B);
+    ring[((t & (ring_slots - 1)) * Bmax + b) * C + c] = h[(int64_t)b * h_batch + (t - t_begin) * C + c];
+  }
+}
+
+}  // namespace
+
+void wn_lpipe_split(int L, int32_t (&first)[kLpStages + 1]) {
+  // the head's stage takes at most 2 layers, the others at most 3; later stages get the smaller shares
+  int n[kLpStages];
+  n[kLpStages - 1] = L >= 8 ? 2 : 1;
+  int rest = L - n[kLpStages - 1];
+  for (int s = 0; s < kLpStages - 1; ++s) {
+    n[s] = (rest + (kLpStages - 2 - s)) / (kLpStages - 1 - s);
+    rest -= n[s];
+  }
+  first[0] = 0;
+  for (int s = 0; s < kLpStages; ++s) first[s + 1] = first[s] + n[s];
+}
+
+bool wn_lpipe_supported(int C, int S, int H1, int n_classes, int L, int n_cond, int batch) {
+  return C == kC && S == kC && H1 == kH1 && n_classes == kQ && n_cond == 0 && L >= kLpStages && L <= kLpMaxLayers && batch >= 1 && batch <= 64;
+}
+
+int launch_wavenet_lpipe(const WnLpipeArgs& a, hipStream_t stream) {
+  if (a.n_steps <= 0 || a.B <= 0) return MMK_OK;
+  if (a.B > 64 || a.L > kLpMaxLayers) return fail(MMK_ERR_UNSUPPORTED, "wavenet layer pipeline: %d clips, %d layers", a.B, a.L);
+  for (int s = 0; s < kLpStages; ++s) {
+    const int nl = a.first[s + 1] - a.first[s];
+    if (nl < 1 || nl > 3 || (s == kLpStages - 1 && nl > 2)) return fail(MMK_ERR_UNSUPPORTED, "wavenet layer pipeline: stage %d would own %d layers", s, nl);
+  }
+  const int grid = 32 * ((a.B + 7) / 8);
+  hipLaunchKernelGGL(wavenet_lpipe_kernel, dim3(grid), dim3(kLpThreads), 0, stream, a);
+  MMK_HIP(hipGetLastError());
+  return MMK_OK;
+}
+
+int launch_wn_lpipe_scatter(const float* h, int64_t h_batch, int64_t t_begin, int64_t t_lo, int n_pos, int C, int B, int Bmax, float* ring,
+                            int ring_slots, hipStream_t stream) {
+  if (n_pos <= 0) return MMK_OK;
+  const int64_t total = (int64_t)n_pos * B * C;
+  hipLaunchKernelGGL(wn_lpipe_scatter_kernel, dim3((unsigned)((total + 255) / 256 > 1024 ? 1024 : (total + 255) / 256)), dim3(256), 0, stream, h, h_batch,
+                     t_begin, t_lo, n_pos, C, B, Bmax, ring, ring_slots);
+  MMK_HIP(hipGetLastError());
+  return MMK_OK;
+}
+
+}  // namespace mmk

@@ -14,6 +14,7 @@
 #include "plan_util.h"
 #include "wavenet_chain.h"
 #include "wavenet_pipe.h"
+#include "wavenet_lpipe.h"
 #include "wavenet_persist.h"
 #include "wavenet_prefill.h"
 
@@ -89,6 +90,10 @@ struct mmk_wavenet_plan {
   // layers spread over the XCDs, weights resident on chip, clip groups pipelined through the stages (wavenet_pipe.hip)
   bool pipe = false;
   int pipe_nit = 0;
+  // four workgroups per clip that own whole layers (wavenet_lpipe.hip): small networks (C = S = 64, H1 = 128, 256 classes)
+  bool lpipe = false;
+  unsigned long long *lp_xg = nullptr, *lp_cg = nullptr;
+  int64_t lp_gran_words = 0;
   unsigned long long *px_yl = nullptr, *px_hl = nullptr, *px_hown = nullptr, *px_yx = nullptr, *px_hx = nullptr, *px_skipfwd = nullptr;
   std::vector<PackedLinear> Ac;
   std::vector<PackedLinear> Bh;       // pipelined mode: rows [res ; head fc0 . W_skip] of every layer (the head's first Linear folded in)
@@ -120,6 +125,11 @@ struct mmk_wavenet_plan {
       px_hx = px_yx + (more ? n_x : 0);
       px_skipfwd = px_hx + (more ? n_x : 0);
       pipe_gran_words = extra;
+    }
+    if (lpipe) {
+      lp_gran_words = (int64_t)(kLpStages + 1) * Bmax * 128 + Bmax;
+      lp_xg = c.take<unsigned long long>(lp_gran_words);
+      lp_cg = lp_xg + (lp_xg ? (int64_t)(kLpStages + 1) * Bmax * 128 : 0);
     }
     h_rings = c.take<float>((int64_t)(pipe ? 8 : Gc) * Gn * ring_floats_per_wg);
     cproj = C1 > 0 ? c.take<float>((int64_t)Bmax * kCondBlock * C1) : nullptr;
@@ -422,6 +432,17 @@ static int derive(mmk_wavenet_plan* p) {
       if (worst * 4 >= ((int64_t)1 << 32)) p->pipe = false;    // 32-bit byte offsets in the kernel
       if (!p->pipe) return fail(MMK_ERR_UNSUPPORTED, "wavenet: history rings of %lld bytes per workgroup", (long long)worst * 4);
     }
+  }
+  // ---- layer pipeline (wavenet_lpipe.hip): small networks whose layers fit a fraction of a CU's registers; 32 workgroups per 8 clips,
+  // all resident, four per clip on one XCD; the warm-up is the prefill, scattered into the launch path's rings.  MMK_WN_LPIPE=0: off.
+  p->lpipe = false;
+  if (p->persistent && !p->pipe) {
+    const char* lenv = getenv("MMK_WN_LPIPE");
+    const char* fenv = getenv("MMK_WN_PREFILL");
+    bool ok4 = !(lenv && lenv[0] == '0') && !(fenv && fenv[0] == '0') && n_xcc == 8 && 32 * ((p->Bmax + 7) / 8) <= n_cu && c.q_levels == 256;
+    ok4 = ok4 && wn_lpipe_supported(p->C, p->S, c.mlp_hidden, c.out_dim, p->L, c.n_cond, p->Bmax);
+    for (int l = 0; l + 1 < p->L; ++l) ok4 = ok4 && p->has_res[l];
+    p->lpipe = ok4;
   }
   return MMK_OK;
 }
@@ -871,6 +892,28 @@ static int run_persistent(mmk_wavenet_plan* p, const WnCall& call, int64_t tau0,
     // hand-off words are zeroed before EVERY launch (epochs restart at 1); the error word after them is sticky
     MMK_HIP(hipMemsetAsync(p->gran_h, 0, (size_t)(p->gran_words - 2) * sizeof(unsigned long long), st));
     const char* stamp_env = getenv("MMK_WN_STAMPS");
+    if (p->lpipe) {
+      if (!with_head) return fail(MMK_ERR_STATE, "wavenet: the layer-pipeline kernel has no teacher-forced mode (warm-up is a prefill)");
+      MMK_HIP(hipMemsetAsync(p->lp_xg, 0, (size_t)p->lp_gran_words * sizeof(unsigned long long), st));
+      WnLpipeArgs k = {};
+      k.B = call.M; k.L = p->L;
+      wn_lpipe_split(p->L, k.first);
+      k.learn_temp = c.learn_temp; k.min_temp = c.min_temp;
+      k.t0 = tau_b + 1; k.n_steps = nb;
+      k.layers = p->layer_tab;
+      for (int l = 0; l < p->L; ++l) { k.hist[l] = p->hist[l]; k.ring[l] = p->ring[l]; }
+      k.Bmax = p->Bmax;
+      k.emb = p->emb; k.idx = (int64_t*)call.in0; k.idx_rs = call.in0_rs;
+      k.fc0_wp = p->mlp[0].Wp; k.fc0_bias = p->mlp[0].bias; k.fc2_wp = p->mlp[1].Wp; k.fc2_bias = p->mlp[1].bias;
+      k.temperature = call.temperature;
+      k.uniforms = call.uniforms ? call.uniforms + done : nullptr;
+      k.uni_ld = call.uni_ld;
+      k.logits_out = p->logits; k.logits_ld = p->logits_ld;
+      k.xg = p->lp_xg; k.cg = p->lp_cg; k.err_flag = p->err_flag;
+      MMK_TRY(launch_wavenet_lpipe(k, st));
+      done += nb;
+      continue;
+    }
     if (p->pipe) {
       if (!with_head) return fail(MMK_ERR_STATE, "wavenet: the pipelined kernel has no teacher-forced mode (warm-up is a prefill)");
       MMK_HIP(hipMemsetAsync(p->px_yl, 0, (size_t)p->pipe_gran_words * sizeof(unsigned long long), st));
@@ -985,7 +1028,9 @@ static int prefill(mmk_wavenet_plan* p, const WnCall& call, int64_t t_begin, int
     const int d = p->dil[l];
     // the ring of layer l holds its input at the last d positions
     const int64_t t_lo = t_end - d > t_begin ? t_end - d : t_begin;
-    if (p->pipe)   // the rings of layer l live with the workgroups of its stage and hold all clips per slot
+    if (p->lpipe)  // the launch path's rings: [slot][Bmax][C]
+      MMK_TRY(launch_wn_lpipe_scatter(p->pf_h[cur], P * C, t_begin, t_lo, (int)(t_end - t_lo), C, B, p->Bmax, p->hist[l], p->ring[l], st));
+    else if (p->pipe)   // the rings of layer l live with the workgroups of its stage and hold all clips per slot
       MMK_TRY(launch_wn_prefill_scatter(p->pf_h[cur], P * C, t_begin, t_lo, (int)(t_end - t_lo), C, B, p->Gc * p->Mg, 1, p->Gn,
                                         p->h_rings + (int64_t)(l / p->pipe_nit) * p->Gn * p->ring_floats_per_wg, p->ring_floats_per_wg,
                                         p->ring_offset[l], p->ring_mask[l], st));
@@ -1092,7 +1137,7 @@ extern "C" int mmk_wavenet_warmup(mmk_wavenet_plan* p, int32_t batch, const void
   call.in0_rs = in0_row_stride;
   if (t_begin < 0 || t_end < t_begin) return fail(MMK_ERR_INVALID, "wavenet_warmup: bad range [%lld, %lld)", (long long)t_begin, (long long)t_end);
   const char* penv = getenv("MMK_WN_PREFILL");
-  if (p->pipe) {
+  if (p->pipe || p->lpipe) {
     // the stage-owned rings are only filled by the prefill; a longer window than the receptive field adds nothing to the
     // ring entries generation reads (each is determined by the rf - 1 positions before t_end)
     if (t_end - t_begin > p->rf - 1) t_begin = t_end - (p->rf - 1);
@@ -1163,7 +1208,7 @@ extern "C" int mmk_wavenet_profile_steps(mmk_wavenet_plan* p, int32_t batch, voi
   return rc;
 }
 
-extern "C" int mmk_wavenet_mode(const mmk_wavenet_plan* p) { return (p && p->persistent) ? (p->pipe ? 3 : (p->chain ? 2 : 1)) : 0; }
+extern "C" int mmk_wavenet_mode(const mmk_wavenet_plan* p) { return (p && p->persistent) ? (p->lpipe ? 4 : (p->pipe ? 3 : (p->chain ? 2 : 1))) : 0; }
 
 extern "C" int mmk_wavenet_sync_status(mmk_wavenet_plan* p, mmk_stream_t stream) {
   if (!p) return fail(MMK_ERR_INVALID, "wavenet_sync_status: null plan");

@@ -470,6 +470,11 @@ class WaveNetPlan(_Plan):
         """persistent mode with the layers spread over the XCDs and the clip groups pipelined through them (csrc/wavenet_pipe.hip)"""
         return self._lib.mmk_wavenet_mode(self.handle) == 3
 
+    @property
+    def layer_pipelined(self) -> bool:
+        """persistent mode with four workgroups per clip that own whole layers (csrc/wavenet_lpipe.hip)"""
+        return self._lib.mmk_wavenet_mode(self.handle) == 4
+
     def sync_status(self):
         """wait for the stream and raise if a hand-off inside the persistent kernel timed out"""
         check(self._lib.mmk_wavenet_sync_status(self.handle, stream_ptr(self.device)), "mmk_wavenet_sync_status")

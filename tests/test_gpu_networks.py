@@ -868,6 +868,64 @@ def test_wavenet_modes_agree_with_oracle(device, mode, monkeypatch):
     assert bool(okp.all()) and float(exact.float().mean()) > 0.97
 
 
+def _small_net(blocks, seed):
+    """the geometry family of BASELINE config 2: 64 channels, kernel 2, gated, skips 64, embedding in, MLP head 128 -> 256 (+ temperature)"""
+    from oracle.weights import load_recipe
+    net = mmk.WaveNet.from_config(mmk.WaveNet.Config(io_spec=H.mu_emb(mlp_dim=128), blocks=blocks, dims_dilated=(64,), residuals_dim=64,
+                                                     skips_dim=64)).eval()
+    sd = load_recipe(net, seed=seed, gain=2.0)
+    dil = [2 ** i for b in blocks for i in range(b)]
+    arch = dict(kernels=[2] * len(dil), dilations=dil, has_skips=True, residuals=True)
+    return net, sd, arch
+
+
+@pytest.mark.parametrize("blocks,B", [((10,), 8), ((4, 3), 13), ((3, 3, 3, 2), 3), ((4,), 64)])
+def test_wavenet_layer_pipeline_agrees_with_oracle(device, monkeypatch, blocks, B):
+    """wavenet_lpipe.hip - four workgroups per clip that own whole layers: 10 / 7 / 11 / 4 layers (3 + 3 + 2 + 2, 2 + 2 + 2 + 1,
+    3 + 3 + 3 + 2, 1 + 1 + 1 + 1 layers per stage), 8 / 13 / 3 / 64 clips (a ragged last group of eight; every CU slot of the grid),
+    prompt longer than rf, two generate blocks, greedy against the oracle (classes exact where the oracle's margin allows, last
+    logits within tolerance) and sampled against the oracle's CDF intervals; and the same net with the mode switched off"""
+    for k in ("MMK_WN_XCD_LOCAL", "MMK_WN_PERSISTENT", "MMK_WN_GROUPS", "MMK_WN_SMALL", "MMK_WN_PREFILL", "MMK_WN_CHAIN", "MMK_WN_PIPE", "MMK_WN_LPIPE"):
+        monkeypatch.delenv(k, raising=False)
+    net, sd, arch = _small_net(blocks, seed=60 + len(blocks))
+    net = net.to(device)
+    gen = torch.Generator().manual_seed(29 + B)
+    rf, n = net.rf, 45
+    prompt = torch.randint(0, 256, (B, rf + 6), generator=gen)
+    want, raw = O.wavenet_generate(sd, prompt, (), n, keep_logits=True, **arch)
+    idx = torch.cat([prompt, torch.zeros(B, n, dtype=torch.int64)], 1).to(device)
+    net.generate_block((idx,), prompt.size(1), 20)
+    net.generate_block((idx,), prompt.size(1) + 20, n - 20)
+    net.after_generate((idx,), None)
+    assert net._plan.layer_pipelined
+    ok = H.margin_ok(raw.numpy())
+    first_bad = (~ok).float().cumsum(1) > 0
+    same = idx.cpu()[:, prompt.size(1):] == want[:, prompt.size(1):]
+    assert bool((same | first_bad).all())
+    assert float(ok.float().mean()) > 0.9
+    assert torch.allclose(net._plan.last_logits(B).cpu()[ok[:, -1]], raw[:, -1][ok[:, -1]], **LOGIT_TOL)
+    temp = torch.linspace(0.5, 1.5, B)
+    torch.manual_seed(5)
+    u = torch.rand((B, n), device=device)
+    torch.manual_seed(5)
+    idx2 = torch.cat([prompt, torch.zeros(B, n, dtype=torch.int64)], 1).to(device)
+    net.generate_block((idx2,), prompt.size(1), n, temperature=temp)
+    net.after_generate((idx2,), None)
+    got2 = idx2.cpu()
+    _, raw2 = O.wavenet_generate(sd, prompt, (), n, keep_logits=True, forced=got2, **arch)
+    okp, exact = H.sampled_picks_ok(raw2, temp, u.cpu(), got2[:, prompt.size(1):])
+    assert bool(okp.all()) and float(exact.float().mean()) > 0.97
+    # switched off: the chain kernel generates the same classes wherever the margin allows
+    monkeypatch.setenv("MMK_WN_LPIPE", "0")
+    net2, _, _ = _small_net(blocks, seed=60 + len(blocks))
+    net2 = net2.to(device)
+    idx3 = torch.cat([prompt, torch.zeros(B, n, dtype=torch.int64)], 1).to(device)
+    net2.generate_block((idx3,), prompt.size(1), n)
+    net2.after_generate((idx3,), None)
+    assert not net2._plan.layer_pipelined
+    assert bool(((idx3.cpu()[:, prompt.size(1):] == want[:, prompt.size(1):]) | first_bad).all())
+
+
 def _wide_net(C, cond_dim, seed):
     from oracle.weights import load_recipe
     io = H.mu_emb(mlp_dim=32)
