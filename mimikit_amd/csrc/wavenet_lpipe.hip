@@ -9,7 +9,9 @@
 // exchanges of ~1.5 us bound a step of this network at 18 us.  Here a clip is served by four workgroups (placed on one XCD: workgroup b
 // serves clip (b % 8) + 8 (b / 32) as stage (b / 8) % 4); a stage keeps the matrices of its two or three layers in registers for the
 // whole launch (48 floats per thread and layer: thread (o, kq) holds a quarter of output row o) and runs them back to back out of LDS
-// (a layer = 32 + 16 FMAs per thread, two quad reductions, four workgroup barriers).  A step crosses the chip four times instead of
+// (a layer = 32 + 16 FMAs per thread, two quad reductions, the gate across two neighbouring quads by DPP, two workgroup barriers;
+// four barriers, single FMA chains or no barrier at the end of a step change the step by < 0.3 us: it is the four crossings, ~1.2 us
+// each with the poll, and the head that make up most of its 11.5 us).  A step crosses the chip four times instead of
 // eleven: the layer input and the skip sum travel to the next stage as 128 data-tagged 8-byte granules {step + 1, value}, the head's
 // class goes back to stage 0 the same way.  The delayed taps x_l[t - d_l] are read from the launch path's history rings in global
 // memory (L2), requested at the start of a stage's visit, and every layer input is written there - so the warm-up is the same prefill
@@ -54,7 +56,7 @@ __device__ __forceinline__ u64 poll(const u64* p, unsigned epoch, int32_t* err) 
 
 template <int NL, bool HEAD, bool FIRST>
 __device__ void run_stage(const WnLpipeArgs& a, int clip, int stage, int l0, float* embs) {
-  __shared__ __attribute__((aligned(16))) float xs[kC], taps[3][kC], fg[2 * kC], zs[kC], sk[kC], hid[kH1], lg[kQ + 4];
+  __shared__ __attribute__((aligned(16))) float xs[2][kC], taps[3][kC], zs[kC], sk[kC], hid[kH1], lg[kQ + 4];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int o = tid >> 2, kq = tid & 3;
@@ -66,8 +68,9 @@ __device__ void run_stage(const WnLpipeArgs& a, int clip, int stage, int l0, flo
     const WnLayerTab lt = a.layers[l0 + i];
     dil[i] = lt.dil;
     has_res[i] = lt.has_res;
-    // (f | g) rows: unit u < 64 -> packed row 2 u (f), unit 64 + u -> packed row 2 u + 1 (g); K = [x(t - d) | x(t)]
-    const int ra = o < kC ? 2 * o : 2 * (o - kC) + 1;
+    // (f, g) rows in packed (interleaved) order: quad 2 u holds f of unit u, quad 2 u + 1 its g - four lanes apart, so the gate needs
+    // no LDS round trip; K = [x(t - d) | x(t)]
+    const int ra = o;
 #pragma unroll
     for (int k = 0; k < 32; ++k) wc[i][k] = packed_at(lt.A_wp, 8, ra, kq * 32 + k);
     bc[i] = lt.A_bias ? lt.A_bias[ra] : 0.f;
@@ -118,60 +121,65 @@ __device__ void run_stage(const WnLpipeArgs& a, int clip, int stage, int l0, flo
         if (s == 0) cls = a.idx[(int64_t)clip * a.idx_rs + tau];
         else cls = (int64_t)(unsigned)poll(a.cg + clip, (unsigned)s, a.err_flag);
         cls = cls < 0 ? 0 : (cls >= kQ ? kQ - 1 : cls);
-        xs[lane] = embs[cls * kC + lane];
+        xs[0][lane] = embs[cls * kC + lane];
         sk[lane] = 0.f;
       }
     } else if (tid < 2 * kC) {
       const u64 g = poll(in_g + tid, (unsigned)(s + 1), a.err_flag);
-      (tid < kC ? xs : sk)[tid & (kC - 1)] = __uint_as_float((unsigned)g);
+      (tid < kC ? xs[0] : sk)[tid & (kC - 1)] = __uint_as_float((unsigned)g);
     }
     if (tid < kC * NL) taps[tid >> 6][lane] = tap;
     __syncthreads();
+    // two barriers per layer: the layer input ping-pongs between two LDS rows, a skip element belongs to one thread for the whole step
 #pragma unroll
     for (int i = 0; i < NL; ++i) {
+      const float* xc = xs[i & 1];
+      float* xn = xs[(i + 1) & 1];
       // the layer's input at tau goes to its ring for later taps (and for the launch path, should the batch be redone there)
-      if (tid < kC) a.hist[l0 + i][(tau & (a.ring[l0 + i] - 1)) * slot_stride + (int64_t)clip * kC + tid] = xs[tid];
-      const float* src = kq < 2 ? taps[i] + kq * 32 : xs + (kq - 2) * 32;
-      float acc = 0.f;
+      if (tid < kC) a.hist[l0 + i][(tau & (a.ring[l0 + i] - 1)) * slot_stride + (int64_t)clip * kC + tid] = xc[tid];
+      const float* src = kq < 2 ? taps[i] + kq * 32 : xc + (kq - 2) * 32;
+      float acc4[4] = {0.f, 0.f, 0.f, 0.f};                                  // four chains of 8 instead of one of 32
 #pragma unroll
-      for (int k = 0; k < 32; ++k) acc = fmaf(wc[i][k], src[k], acc);
-      acc = quad_sum(acc);
-      if (kq == 0) fg[o] = acc + bc[i];
+      for (int k = 0; k < 32; ++k) acc4[k & 3] = fmaf(wc[i][k], src[k], acc4[k & 3]);
+      float acc = quad_sum((acc4[0] + acc4[1]) + (acc4[2] + acc4[3])) + bc[i];
+      const float g_other = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(acc), 0x104, 0xf, 0xf, false));   // row_shl:4: the g quad's sum
+      if ((tid & 7) == 0) zs[tid >> 3] = tanhf(acc) * sigmoidf_(g_other);    // wavenet_v2.py:151
       __syncthreads();
-      if (tid < kC) zs[tid] = tanhf(fg[tid]) * sigmoidf_(fg[kC + tid]);      // wavenet_v2.py:151
-      __syncthreads();
-      float a2 = 0.f;
+      float a4[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int k = 0; k < 16; ++k) a2 = fmaf(wr[i][k], zs[kq * 16 + k], a2);
-      a2 = quad_sum(a2);
-      __syncthreads();                                                      // every thread has read xs / zs of this layer
+      for (int k = 0; k < 16; ++k) a4[k & 3] = fmaf(wr[i][k], zs[kq * 16 + k], a4[k & 3]);
+      const float a2 = quad_sum((a4[0] + a4[1]) + (a4[2] + a4[3]));
       if (kq == 0) {
         if (has_res[i]) {
-          if (o < kC) xs[o] = xs[o] + (a2 + br[i]);                         // :165-170
+          if (o < kC) xn[o] = xc[o] + (a2 + br[i]);                         // :165-170
           else sk[o - kC] += a2 + br[i];                                    // :172-176
         } else if (o >= kC) {
           sk[o - kC] += a2 + br[i];
+        } else {
+          xn[o] = xc[o];                                                    // (the last layer: its residual sum is never used)
         }
       }
       __syncthreads();
     }
+    const float* xfin = xs[NL & 1];
     if constexpr (!HEAD) {
       if (tid < 2 * kC) {
-        const float v = tid < kC ? xs[tid] : sk[tid - kC];
+        const float v = tid < kC ? xfin[tid] : sk[tid - kC];
         __hip_atomic_store(out_g + tid, ((u64)(unsigned)(s + 1) << 32) | __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     } else {
       // ---- head: Linear(64 -> 128), Mish, Linear(128 -> 256 [+ 1]), [temperature], argmax / inverse-CDF draw -----------------
-      float h = 0.f;
+      float h4[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int k = 0; k < 16; ++k) h = fmaf(w0[k], sk[kq * 16 + k], h);
-      h = quad_sum(h);
+      for (int k = 0; k < 16; ++k) h4[k & 3] = fmaf(w0[k], sk[kq * 16 + k], h4[k & 3]);
+      const float h = quad_sum((h4[0] + h4[1]) + (h4[2] + h4[3]));
       if (kq == 0) hid[o] = mishf_(h + b0);
       __syncthreads();
-      float q = 0.f;
+      float q4[4] = {0.f, 0.f, 0.f, 0.f};
       const float* hs = hid + (tid & 1) * 64;
 #pragma unroll
-      for (int k = 0; k < 64; ++k) q = fmaf(w2[k], hs[k], q);
+      for (int k = 0; k < 64; ++k) q4[k & 3] = fmaf(w2[k], hs[k], q4[k & 3]);
+      float q = (q4[0] + q4[1]) + (q4[2] + q4[3]);
       q += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(q), 0xB1, 0xf, 0xf, false));
       if ((tid & 1) == 0) lg[tid >> 1] = q + b2;
       if (wave == 0 && a.learn_temp) {
