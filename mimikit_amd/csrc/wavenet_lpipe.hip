@@ -60,6 +60,9 @@ __device__ void run_stage(const WnLpipeArgs& a, int clip, int stage, int l0, flo
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int o = tid >> 2, kq = tid & 3;
+  const bool g_quad = (o & 1) != 0;
+  const float gate_scale = g_quad ? -1.4426950408889634f : -2.8853900817779268f;
+  const float gate_k = g_quad ? 1.f : 2.f, gate_shift = g_quad ? 0.f : -1.f;
   // ---- this stage's matrices -> registers (once per launch) -------------------------------------------------------------------
   float wc[NL][32], wr[NL][16], bc[NL], br[NL];
   int dil[NL], has_res[NL];
@@ -141,9 +144,12 @@ __device__ void run_stage(const WnLpipeArgs& a, int clip, int stage, int l0, flo
       float acc4[4] = {0.f, 0.f, 0.f, 0.f};                                  // four chains of 8 instead of one of 32
 #pragma unroll
       for (int k = 0; k < 32; ++k) acc4[k & 3] = fmaf(wc[i][k], src[k], acc4[k & 3]);
-      float acc = quad_sum((acc4[0] + acc4[1]) + (acc4[2] + acc4[3])) + bc[i];
-      const float g_other = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(acc), 0x104, 0xf, 0xf, false));   // row_shl:4: the g quad's sum
-      if ((tid & 7) == 0) zs[tid >> 3] = tanhf(acc) * sigmoidf_(g_other);    // wavenet_v2.py:151
+      const float acc = quad_sum((acc4[0] + acc4[1]) + (acc4[2] + acc4[3])) + bc[i];
+      // tanh(f) sigmoid(g) (wavenet_v2.py:151), both halves at once on their own quads with the hardware exp2 / rcp, as in the other
+      // step kernels: sigmoid(x) = 1 / (1 + 2^(-x log2 e)), tanh(x) = 2 sigmoid(2 x) - 1; the g quad sits four lanes up (row_shl:4)
+      const float act = fmaf(__frcp_rn(1.0f + __builtin_amdgcn_exp2f(acc * gate_scale)), gate_k, gate_shift);
+      const float other = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(act), 0x104, 0xf, 0xf, false));
+      if ((tid & 7) == 0) zs[tid >> 3] = act * other;
       __syncthreads();
       float a4[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -173,7 +179,7 @@ __device__ void run_stage(const WnLpipeArgs& a, int clip, int stage, int l0, flo
 #pragma unroll
       for (int k = 0; k < 16; ++k) h4[k & 3] = fmaf(w0[k], sk[kq * 16 + k], h4[k & 3]);
       const float h = quad_sum((h4[0] + h4[1]) + (h4[2] + h4[3]));
-      if (kq == 0) hid[o] = mishf_(h + b0);
+      if (kq == 0) hid[o] = mish_fast(h + b0);
       __syncthreads();
       float q4[4] = {0.f, 0.f, 0.f, 0.f};
       const float* hs = hid + (tid & 1) * 64;
