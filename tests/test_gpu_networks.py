@@ -915,6 +915,22 @@ def test_wavenet_layer_pipeline_agrees_with_oracle(device, monkeypatch, blocks, 
     _, raw2 = O.wavenet_generate(sd, prompt, (), n, keep_logits=True, forced=got2, **arch)
     okp, exact = H.sampled_picks_ok(raw2, temp, u.cpu(), got2[:, prompt.size(1):])
     assert bool(okp.all()) and float(exact.float().mean()) > 0.97
+    # the per-step protocol (one launch per step) and a forced hand-off timeout (the batch is redone on the launch path)
+    net.before_generate((prompt.to(device),), 0)
+    step = net.generate_step((prompt[:, -rf:].to(device),), t=prompt.size(1))[0].cpu()
+    assert bool(((step[:, 0] == want[:, prompt.size(1)]) | ~ok[:, 0]).all())
+    nxt = torch.cat([prompt[:, -rf + 1:], step], 1)
+    step2 = net.generate_step((nxt.to(device),), t=prompt.size(1) + 1)[0].cpu()
+    assert bool(((step2[:, 0] == want[:, prompt.size(1) + 1]) | first_bad[:, 1]).all())
+    net.after_generate((idx,), None)
+    monkeypatch.setenv("MMK_WN_FORCE_SYNC_ERROR", "1")
+    idx4 = torch.cat([prompt, torch.zeros(B, n, dtype=torch.int64)], 1).to(device)
+    net.generate_block((idx4,), prompt.size(1), n)
+    assert net._plan.layer_pipelined
+    with pytest.warns(UserWarning, match="launch path"):
+        net.after_generate((idx4,), None)
+    monkeypatch.delenv("MMK_WN_FORCE_SYNC_ERROR")
+    assert bool(((idx4.cpu()[:, prompt.size(1):] == want[:, prompt.size(1):]) | first_bad).all())
     # switched off: the chain kernel generates the same classes wherever the margin allows
     monkeypatch.setenv("MMK_WN_LPIPE", "0")
     net2, _, _ = _small_net(blocks, seed=60 + len(blocks))
