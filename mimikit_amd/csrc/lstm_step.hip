@@ -145,9 +145,9 @@ __global__ __launch_bounds__(kLsThreads) void lstm_step_kernel(const LstmStepArg
       s[g] = v + ga[g];
     }
     if (cell) {
-      const float ig = sigmoidf_(s[0]), fg = sigmoidf_(s[1]), cg = tanhf(s[2]), og = sigmoidf_(s[3]);
+      const float ig = sigmoid_fast(s[0]), fg = sigmoid_fast(s[1]), cg = tanh_fast(s[2]), og = sigmoid_fast(s[3]);
       const float cn = fg * c_old + ig * cg;
-      const float hn = og * tanhf(cn);
+      const float hn = og * tanh_fast(cn);
       const int64_t row = m_first + e_m;
       d.c[row * H + unit] = cn;
       d.h_out[row * H + unit] = hn;

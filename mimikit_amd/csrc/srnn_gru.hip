@@ -335,10 +335,10 @@ __global__ __launch_bounds__(kGruThreads) void srnn_gru_kernel(const SrnnGruArgs
         float gt[4];
 #pragma unroll
         for (int g = 0; g < 4; ++g) gt[g] = (s[g] + s[NG + g]) + cell_b[g];
-        const float ig = sigmoidf_(gt[0]), fg = sigmoidf_(gt[1]), cg = tanhf(gt[2]), og = sigmoidf_(gt[3]);
+        const float ig = sigmoid_fast(gt[0]), fg = sigmoid_fast(gt[1]), cg = tanh_fast(gt[2]), og = sigmoid_fast(gt[3]);
         const float cn = fg * a.c[o] + ig * cg;
         a.c[o] = cn;
-        store_state(o, og * tanhf(cn));
+        store_state(o, og * tanh_fast(cn));
       } else {
         const float gi_r = s[0] + cell_b[0];
         const float gi_z = s[1] + cell_b[1];
@@ -346,9 +346,9 @@ __global__ __launch_bounds__(kGruThreads) void srnn_gru_kernel(const SrnnGruArgs
         const float gh_r = s[3] + cell_b[NG];
         const float gh_z = s[4] + cell_b[NG + 1];
         const float gh_n = s[5] + cell_b[NG + 2];
-        const float r = sigmoidf_(gh_r + gi_r);
-        const float z = sigmoidf_(gh_z + gi_z);
-        const float nn = tanhf(gi_n + gh_n * r);
+        const float r = sigmoid_fast(gh_r + gi_r);
+        const float z = sigmoid_fast(gh_z + gi_z);
+        const float nn = tanh_fast(gi_n + gh_n * r);
         const float hp = hs[m * ldx + unit];
         store_state(o, (hp - nn) * z + nn);
       }
