@@ -74,8 +74,13 @@ __device__ void run_stage(const WnLpipeArgs& a, int clip, int stage, int l0, flo
     // (f, g) rows in packed (interleaved) order: quad 2 u holds f of unit u, quad 2 u + 1 its g - four lanes apart, so the gate needs
     // no LDS round trip; K = [x(t - d) | x(t)]
     const int ra = o;
+    // wc[.][0 .. 15]: this lane's sixteenth-to-quarter of the TAP columns, wc[.][16 .. 31]: the same columns of x(t) - the tap half of
+    // every layer's product is formed before the step's input arrives
 #pragma unroll
-    for (int k = 0; k < 32; ++k) wc[i][k] = packed_at(lt.A_wp, 8, ra, kq * 32 + k);
+    for (int k = 0; k < 16; ++k) {
+      wc[i][k] = packed_at(lt.A_wp, 8, ra, kq * 16 + k);
+      wc[i][16 + k] = packed_at(lt.A_wp, 8, ra, kC + kq * 16 + k);
+    }
     bc[i] = lt.A_bias ? lt.A_bias[ra] : 0.f;
     // [res ; skip] rows: without residual rows (the last layer) the skip rows come first
     const int rb = lt.has_res ? o : o - kC;
@@ -117,6 +122,16 @@ __device__ void run_stage(const WnLpipeArgs& a, int clip, int stage, int l0, flo
                                         __HIP_MEMORY_SCOPE_AGENT)
                     : 0.f;
     }
+    if (tid < kC * NL) taps[tid >> 6][lane] = tap;
+    __syncthreads();
+    float ptap[NL];                                       // W_tap x(t - d) of my rows, off the step's chain
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+      float p4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int k = 0; k < 16; ++k) p4[k & 3] = fmaf(wc[i][k], taps[i][kq * 16 + k], p4[k & 3]);
+      ptap[i] = (p4[0] + p4[1]) + (p4[2] + p4[3]);
+    }
     // ---- this step's input -----------------------------------------------------------------------------------------------------------
     if constexpr (FIRST) {
       if (wave == 0) {
@@ -131,7 +146,6 @@ __device__ void run_stage(const WnLpipeArgs& a, int clip, int stage, int l0, flo
       const u64 g = poll(in_g + tid, (unsigned)(s + 1), a.err_flag);
       (tid < kC ? xs[0] : sk)[tid & (kC - 1)] = __uint_as_float((unsigned)g);
     }
-    if (tid < kC * NL) taps[tid >> 6][lane] = tap;
     __syncthreads();
     // two barriers per layer: the layer input ping-pongs between two LDS rows, a skip element belongs to one thread for the whole step
 #pragma unroll
@@ -140,10 +154,9 @@ __device__ void run_stage(const WnLpipeArgs& a, int clip, int stage, int l0, flo
       float* xn = xs[(i + 1) & 1];
       // the layer's input at tau goes to its ring for later taps (and for the launch path, should the batch be redone there)
       if (tid < kC) a.hist[l0 + i][(tau & (a.ring[l0 + i] - 1)) * slot_stride + (int64_t)clip * kC + tid] = xc[tid];
-      const float* src = kq < 2 ? taps[i] + kq * 32 : xc + (kq - 2) * 32;
-      float acc4[4] = {0.f, 0.f, 0.f, 0.f};                                  // four chains of 8 instead of one of 32
+      float acc4[4] = {ptap[i], 0.f, 0.f, 0.f};                              // four chains of 4
 #pragma unroll
-      for (int k = 0; k < 32; ++k) acc4[k & 3] = fmaf(wc[i][k], src[k], acc4[k & 3]);
+      for (int k = 0; k < 16; ++k) acc4[k & 3] = fmaf(wc[i][16 + k], xc[kq * 16 + k], acc4[k & 3]);
       const float acc = quad_sum((acc4[0] + acc4[1]) + (acc4[2] + acc4[3])) + bc[i];
       // tanh(f) sigmoid(g) (wavenet_v2.py:151), both halves at once on their own quads with the hardware exp2 / rcp, as in the other
       // step kernels: sigmoid(x) = 1 / (1 + 2^(-x log2 e)), tanh(x) = 2 sigmoid(2 x) - 1; the g quad sits four lanes up (row_shl:4)
