@@ -14,7 +14,12 @@
 #include <vector>
 
 typedef unsigned long long u64;
-constexpr int C = 256, MG = 4, NWG = 32, ROWS = 16, NIT = 4, K = 3 * C;
+#ifdef FAT   // one layer per 8 workgroups: 64 rows each, 8 lanes per row, an 8-way all-gather
+constexpr int C = 256, MG = 4, NWG = 8, ROWS = 64, NIT = 1, K = 3 * C, LPR = 8;
+#else
+constexpr int C = 256, MG = 4, NWG = 32, ROWS = 16, NIT = 4, K = 3 * C, LPR = 32;
+#endif
+constexpr int KPT = K / LPR;     // inputs per thread
 constexpr int kThreads = 512;
 
 struct Params {
@@ -31,33 +36,35 @@ __device__ __forceinline__ float row32_sum(float v) {      // sum over the 32 la
   v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, false));
   v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xf, 0xf, false));
   v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xf, 0xf, false));
-  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xf, 0xf, false));
-  v += __shfl_xor(v, 16);
+  if (LPR == 32) {
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xf, 0xf, false));
+    v += __shfl_xor(v, 16);
+  }
   return v;
 }
 
 __global__ __launch_bounds__(kThreads) void lean_stage_kernel(const Params p) {
-  if (blockIdx.x % 8 != 0) return;
-  const int j = blockIdx.x / 8;                      // tile owner 0 .. 31
+  if (blockIdx.x % 8 != 0 || blockIdx.x / 8 >= NWG) return;
+  const int j = blockIdx.x / 8;                      // tile owner
   __shared__ __attribute__((aligned(16))) float xin[MG][K];
   const int tid = threadIdx.x;
-  const int r = tid >> 5, kq = tid & 31;             // row 0 .. 15, K slice of 24
+  const int r = tid / LPR, kq = tid % LPR;           // row, K slice
   if (tid == 0) {
     unsigned id;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(id));
     p.xcc[j] = id & 0xf;
   }
-  float w[NIT][24];
+  float w[NIT][KPT];
 #pragma unroll
   for (int it = 0; it < NIT; ++it)
 #pragma unroll
-    for (int k = 0; k < 24; ++k) w[it][k] = p.w[(((size_t)j * NIT + it) * ROWS + r) * K + kq * 24 + k];
+    for (int k = 0; k < KPT; ++k) w[it][k] = p.w[(((size_t)j * NIT + it) * ROWS + r) * K + kq * KPT + k];
   const float gscale = (r & 1) ? -1.4426950408889634f : -2.8853900817779268f, gk = (r & 1) ? 1.f : 2.f, gs = (r & 1) ? 0.f : -1.f;
   // everybody publishes generation-0 values for "iteration -1"
   unsigned epoch = 1;
   if (tid < ROWS * MG) {
     const int c = tid & 3, rr = tid >> 2;
-    __hip_atomic_store(p.gran + ((size_t)(0 * 2 + (rr >> 3)) * MG + c) * C + j * 8 + (rr & 7), ((u64)epoch << 32) | __float_as_uint(0.01f * rr), __ATOMIC_RELAXED,
+    __hip_atomic_store(p.gran + ((size_t)(0 * 2 + (rr / (ROWS / 2))) * MG + c) * C + j * (ROWS / 2) + (rr % (ROWS / 2)), ((u64)epoch << 32) | __float_as_uint(0.01f * rr), __ATOMIC_RELAXED,
                        __HIP_MEMORY_SCOPE_AGENT);
   }
   float acc_sink = 0.f;
@@ -69,6 +76,19 @@ __global__ __launch_bounds__(kThreads) void lean_stage_kernel(const Params p) {
       const float t0 = p.ring[(((size_t)it * 64 + (s & 63)) * MG) * C + tid], t1 = p.ring[(((size_t)it * 64 + (s & 63)) * MG) * C + 512 + tid];
       // gather y | h of the previous iteration: 2048 granules, 4 per thread
       float v[4];
+#ifndef PARPOLL
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const u64* g = p.gran + (size_t)gen * 2 * MG * C + q * 512 + tid;
+        u64 x = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned spins = 0;
+        while ((unsigned)(x >> 32) != epoch) {
+          if (++spins > (1u << 22)) { atomicExch(p.err, 1u); break; }
+          x = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        v[q] = __uint_as_float((unsigned)x);
+      }
+#else
       {
         // all four requests out at once; only the stale ones are asked for again
         const u64* g = p.gran + (size_t)gen * 2 * MG * C + tid;
@@ -89,6 +109,7 @@ __global__ __launch_bounds__(kThreads) void lean_stage_kernel(const Params p) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) v[q] = __uint_as_float((unsigned)x[q]);
       }
+#endif
       // LDS layout xin[clip][tap 256 | y 256 | h 256]; gathered index q * 512 + tid = (vector, clip, channel)
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
@@ -100,9 +121,9 @@ __global__ __launch_bounds__(kThreads) void lean_stage_kernel(const Params p) {
       __syncthreads();
       float acc[MG] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int k = 0; k < 24; ++k)
+      for (int k = 0; k < KPT; ++k)
 #pragma unroll
-        for (int c = 0; c < MG; ++c) acc[c] = fmaf(w[it][k], xin[c][kq * 24 + k], acc[c]);
+        for (int c = 0; c < MG; ++c) acc[c] = fmaf(w[it][k], xin[c][kq * KPT + k], acc[c]);
 #pragma unroll
       for (int c = 0; c < MG; ++c) acc[c] = row32_sum(acc[c]);
       ++epoch;
@@ -111,12 +132,12 @@ __global__ __launch_bounds__(kThreads) void lean_stage_kernel(const Params p) {
 #pragma unroll
       for (int c = 0; c < MG; ++c) {
         const float act = fmaf(__frcp_rn(1.0f + __builtin_amdgcn_exp2f(acc[c] * gscale)), gk, gs);
-        const float other = __shfl_xor(act, 32);
+        const float other = LPR == 32 ? __shfl_xor(act, 32) : __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(act), 0x108, 0xf, 0xf, false));
         out[c] = (r & 1) ? act : act * other;
       }
       if (kq < MG) {                                  // lanes 0 .. 3 of every row publish that row's value for clip kq
         const float val = kq == 0 ? out[0] : (kq == 1 ? out[1] : (kq == 2 ? out[2] : out[3]));
-        __hip_atomic_store(p.gran + ((size_t)(((epoch - 1) & 1) * 2 + (r >> 3)) * MG + kq) * C + j * 8 + (r & 7), ((u64)epoch << 32) | __float_as_uint(val),
+        __hip_atomic_store(p.gran + ((size_t)(((epoch - 1) & 1) * 2 + (r / (ROWS / 2))) * MG + kq) * C + j * (ROWS / 2) + (r % (ROWS / 2)), ((u64)epoch << 32) | __float_as_uint(val),
                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
       acc_sink += out[0];
@@ -151,6 +172,7 @@ int main() {
   bool same = true;
   for (int i = 1; i < NWG; ++i) same = same && xcc[i] == xcc[0];
   printf("launch: %s, timeouts: %u, the 32 workgroups on one XCD: %s (XCC %u)\n", hipGetErrorString(rc), err, same ? "yes" : "NO", xcc[0]);
-  printf("%d steps x %d iterations: %.1f us total, %.2f us per iteration (pipelined kernel: 2.2 - 2.4 us)\n", n_steps, NIT, ms * 1e3, ms * 1e3 / (n_steps * NIT));
+  printf("%d workgroups x %d rows: %d steps x %d iterations: %.1f us total, %.2f us per iteration (pipelined kernel: 2.2 - 2.4 us)\n", NWG, ROWS, n_steps, NIT, ms * 1e3,
+         ms * 1e3 / (n_steps * NIT));
   return 0;
 }
