@@ -867,7 +867,9 @@ static constexpr int kGraphSteps = 8;
 static int run_persistent(mmk_wavenet_plan* p, const WnCall& call, int64_t tau0, int64_t n, bool with_head, hipStream_t st) {
   const mmk_wavenet_config& c = p->cfg;
   for (int64_t done = 0; done < n;) {
-    const int64_t nb = (n - done) < p->kCondBlock ? (n - done) : p->kCondBlock;
+    // (the layer pipeline has no conditioning block to prepare: one launch reads its weights once for up to 2^20 steps)
+    const int64_t block = p->lpipe ? ((int64_t)1 << 20) : (int64_t)p->kCondBlock;
+    const int64_t nb = (n - done) < block ? (n - done) : block;
     const int64_t tau_b = tau0 + done;
     if (p->C1 > 0) {
       // c[b, tau, :] = LinearIO(cond[b, tau, :]) for the block's positions (modules/io.py:115-122)
