@@ -106,7 +106,23 @@ __device__ void run_stage(const WnLpipeArgs& a, int clip, int stage, int l0, flo
   if constexpr (FIRST) {
     for (int i = tid; i < kQ * kC; i += kLpThreads) embs[i] = a.emb[i];
   }
+  // Is the stage I hand over to on my XCD?  Then my granules may stay in the XCD's L2 (plain stores; its CUs' sc1 loads find them there)
+  // instead of being written through to memory.  Every workgroup registers its XCC id, then reads its successor's.
+  __shared__ int s_local;
+  if (tid == 0) {
+    unsigned id;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(id));
+    id = (id & 0xf) + 1;
+    __hip_atomic_store(a.xcc_ids + clip * kLpStages + stage, id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned* nxt = a.xcc_ids + clip * kLpStages + (stage + 1) % kLpStages;
+    unsigned other = 0, spins = 0;
+    while ((other = __hip_atomic_load(nxt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0) {
+      if (++spins > kLpSpinLimit) { atomicExch(a.err_flag, 3); break; }
+    }
+    s_local = (other == id && a.xcd_local) ? 1 : 0;
+  }
   __syncthreads();
+  const bool local = s_local != 0;
   const u64* in_g = a.xg + ((int64_t)stage * a.Bmax + clip) * 128;
   u64* out_g = a.xg + ((int64_t)(stage + 1) * a.Bmax + clip) * 128;
   const int64_t slot_stride = (int64_t)a.Bmax * kC;
@@ -137,14 +153,29 @@ __device__ void run_stage(const WnLpipeArgs& a, int clip, int stage, int l0, flo
       if (wave == 0) {
         int64_t cls;
         if (s == 0) cls = a.idx[(int64_t)clip * a.idx_rs + tau];
-        else cls = (int64_t)(unsigned)poll(a.cg + clip, (unsigned)s, a.err_flag);
+        else cls = (int64_t)(unsigned)poll(a.cg + (int64_t)clip * 16, (unsigned)s, a.err_flag);
         cls = cls < 0 ? 0 : (cls >= kQ ? kQ - 1 : cls);
         xs[0][lane] = embs[cls * kC + lane];
         sk[lane] = 0.f;
       }
-    } else if (tid < 2 * kC) {
-      const u64 g = poll(in_g + tid, (unsigned)(s + 1), a.err_flag);
-      (tid < kC ? xs[0] : sk)[tid & (kC - 1)] = __uint_as_float((unsigned)g);
+    } else if (wave == 0) {
+      // the 128 granules (x | skip) in one 16-byte L1-bypassing load per lane; a granule is one aligned 8-byte store inside it, so
+      // it is seen entirely old or entirely new and its tag is checked either way
+      typedef unsigned u32x4_lp __attribute__((ext_vector_type(4)));
+      const u64* gp = in_g + 2 * lane;
+      u32x4_lp v;
+      unsigned spins = 0;
+      for (;;) {
+        asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(gp) : "memory");
+        if (v[1] == (unsigned)(s + 1) && v[3] == (unsigned)(s + 1)) break;
+        if (++spins > kLpSpinLimit || ((spins & 1023u) == 0 && __hip_atomic_load(a.err_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+          atomicExch(a.err_flag, 3);
+          break;
+        }
+      }
+      float* dst = lane < 32 ? xs[0] + 2 * lane : sk + 2 * (lane - 32);
+      dst[0] = __uint_as_float(v[0]);
+      dst[1] = __uint_as_float(v[2]);
     }
     __syncthreads();
     // two barriers per layer: the layer input ping-pongs between two LDS rows, a skip element belongs to one thread for the whole step
@@ -184,7 +215,9 @@ __device__ void run_stage(const WnLpipeArgs& a, int clip, int stage, int l0, flo
     if constexpr (!HEAD) {
       if (tid < 2 * kC) {
         const float v = tid < kC ? xfin[tid] : sk[tid - kC];
-        __hip_atomic_store(out_g + tid, ((u64)(unsigned)(s + 1) << 32) | __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const u64 gv = ((u64)(unsigned)(s + 1) << 32) | __float_as_uint(v);
+        if (local) __hip_atomic_store(out_g + tid, gv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // stays in this XCD's L2
+        else __hip_atomic_store(out_g + tid, gv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     } else {
       // ---- head: Linear(64 -> 128), Mish, Linear(128 -> 256 [+ 1]), [temperature], argmax / inverse-CDF draw -----------------
@@ -230,7 +263,9 @@ __device__ void run_stage(const WnLpipeArgs& a, int clip, int stage, int l0, flo
         }
         if (lane == 0) {
           a.idx[(int64_t)clip * a.idx_rs + tau + 1] = result;
-          __hip_atomic_store(a.cg + clip, ((u64)(unsigned)(s + 1) << 32) | (unsigned)result, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const u64 gv = ((u64)(unsigned)(s + 1) << 32) | (unsigned)result;
+          if (local) __hip_atomic_store(a.cg + (int64_t)clip * 16, gv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          else __hip_atomic_store(a.cg + (int64_t)clip * 16, gv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
       }
     }

@@ -127,7 +127,7 @@ struct mmk_wavenet_plan {
       pipe_gran_words = extra;
     }
     if (lpipe) {
-      lp_gran_words = (int64_t)(kLpStages + 1) * Bmax * 128 + Bmax;
+      lp_gran_words = (int64_t)(kLpStages + 1) * Bmax * 128 + (int64_t)Bmax * 16 + (int64_t)Bmax * 2;   // x | skip, class (a line per clip), XCC ids
       lp_xg = c.take<unsigned long long>(lp_gran_words);
       lp_cg = lp_xg + (lp_xg ? (int64_t)(kLpStages + 1) * Bmax * 128 : 0);
     }
@@ -912,6 +912,11 @@ static int run_persistent(mmk_wavenet_plan* p, const WnCall& call, int64_t tau0,
       k.uni_ld = call.uni_ld;
       k.logits_out = p->logits; k.logits_ld = p->logits_ld;
       k.xg = p->lp_xg; k.cg = p->lp_cg; k.err_flag = p->err_flag;
+      k.xcc_ids = reinterpret_cast<unsigned*>(p->lp_cg + (int64_t)p->Bmax * 16);
+      {
+        const char* xe = getenv("MMK_WN_XCD_LOCAL");
+        k.xcd_local = !(xe && xe[0] == '0');
+      }
       MMK_TRY(launch_wavenet_lpipe(k, st));
       done += nb;
       continue;
