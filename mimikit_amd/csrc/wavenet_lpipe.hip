@@ -13,7 +13,9 @@
 // four barriers, single FMA chains or no barrier at the end of a step change the step by < 0.3 us: it is the four crossings, ~1.2 us
 // each with the poll, and the head that make up most of its 11.5 us).  A step crosses the chip four times instead of
 // eleven: the layer input and the skip sum travel to the next stage as 128 data-tagged 8-byte granules {step + 1, value}, the head's
-// class goes back to stage 0 the same way.  The delayed taps x_l[t - d_l] are read from the launch path's history rings in global
+// class goes back to stage 0 the same way.  Where producer and consumer sit on one XCD (every workgroup registers its XCC id at the
+// start and reads its successor's) the granules are plain stores that stay in that XCD's L2; one wave of the consumer polls all 128
+// with one 16-byte L1-bypassing load per lane.  9.2 -> 8.4 us per step against write-through hand-overs.  The delayed taps x_l[t - d_l] are read from the launch path's history rings in global
 // memory (L2), requested at the start of a stage's visit, and every layer input is written there - so the warm-up is the same prefill
 // as for the other persistent kernels, scattered into those rings.  scripts/probes/wn_layer_pipe.hip is the stand-alone form.
 #include "wavenet_lpipe.h"
