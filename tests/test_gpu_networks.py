@@ -879,14 +879,17 @@ def _small_net(blocks, seed):
     return net, sd, arch
 
 
-@pytest.mark.parametrize("blocks,B", [((10,), 8), ((4, 3), 13), ((3, 3, 3, 2), 3), ((4,), 64)])
-def test_wavenet_layer_pipeline_agrees_with_oracle(device, monkeypatch, blocks, B):
+@pytest.mark.parametrize("blocks,B,env", [((10,), 8, {}), ((4, 3), 13, {}), ((3, 3, 3, 2), 3, {}), ((4,), 64, {}),
+                                          ((10,), 5, {"MMK_WN_XCD_LOCAL": "0"})])
+def test_wavenet_layer_pipeline_agrees_with_oracle(device, monkeypatch, blocks, B, env):
     """wavenet_lpipe.hip - four workgroups per clip that own whole layers: 10 / 7 / 11 / 4 layers (3 + 3 + 2 + 2, 2 + 2 + 2 + 1,
     3 + 3 + 3 + 2, 1 + 1 + 1 + 1 layers per stage), 8 / 13 / 3 / 64 clips (a ragged last group of eight; every CU slot of the grid),
     prompt longer than rf, two generate blocks, greedy against the oracle (classes exact where the oracle's margin allows, last
     logits within tolerance) and sampled against the oracle's CDF intervals; and the same net with the mode switched off"""
     for k in ("MMK_WN_XCD_LOCAL", "MMK_WN_PERSISTENT", "MMK_WN_GROUPS", "MMK_WN_SMALL", "MMK_WN_PREFILL", "MMK_WN_CHAIN", "MMK_WN_PIPE", "MMK_WN_LPIPE"):
         monkeypatch.delenv(k, raising=False)
+    for k, v in env.items():                 # (MMK_WN_XCD_LOCAL=0: every hand-over written through to memory)
+        monkeypatch.setenv(k, v)
     net, sd, arch = _small_net(blocks, seed=60 + len(blocks))
     net = net.to(device)
     gen = torch.Generator().manual_seed(29 + B)
