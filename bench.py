@@ -153,7 +153,8 @@ class WaveNetJob:
                 traffic = int(per_step * n) if per_step else None
             except (OSError, ValueError):
                 pass
-            kname = ("wavenet_pipe_kernel (layers spread over the XCDs, weights resident on chip, clip groups pipelined)" if plan.pipelined
+            kname = ("wavenet_spipe_kernel (one layer per stage of 8 CUs, weights in registers, clips streamed through one at a time)" if plan.stage_pipelined
+                     else "wavenet_pipe_kernel (layers spread over the XCDs, weights resident on chip, clip groups pipelined)" if plan.pipelined
                      else "wavenet_lpipe_kernel (four workgroups per clip that own whole layers, weights in registers)" if plan.layer_pipelined
                      else "wavenet_chain_kernel (one hand-off per layer)" if plan.chain else "wavenet_persist_kernel")
             return {"bound": "hbm", "kernel": kname + ": all layers + head of every step of a block",

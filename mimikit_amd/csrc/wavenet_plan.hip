@@ -17,6 +17,7 @@
 #include "wavenet_lpipe.h"
 #include "wavenet_persist.h"
 #include "wavenet_prefill.h"
+#include "wavenet_spipe.h"
 
 using namespace mmk;
 
@@ -99,11 +100,18 @@ struct mmk_wavenet_plan {
   std::vector<PackedLinear> Bh;       // pipelined mode: rows [res ; head fc0 . W_skip] of every layer (the head's first Linear folded in)
   WnChainIter* iter_tab = nullptr;
   float* compose_scratch = nullptr;   // (2C, C) product + 2C bias terms of one layer
+  // one layer per stage of 8 CUs, clips streamed through one at a time (wavenet_spipe.hip): C = 256, <= 31 layers, <= 32 clips
+  bool spipe = false;
+  float *sp_img_chain = nullptr, *sp_img_helper = nullptr, *sp_cst_chain = nullptr, *sp_cst_helper = nullptr, *sp_head_w0 = nullptr, *sp_head_b0 = nullptr;
+  unsigned *sp_msg = nullptr, *sp_hidmsg = nullptr;
+  WnSpRaw* sp_raw = nullptr;
+  const float *sp_fc2_w = nullptr, *sp_fc2_b = nullptr;
 
   void layout_persistent(Carver& c) {
     layer_tab = c.take<WnLayerTab>(L);
-    const int64_t n_h = (int64_t)Gc * 2 * 16 * C, n_y = n_h, n_s = (int64_t)Gc * 16 * S,   // y, h: two generations each
-                  n_hid = (int64_t)Gc * 16 * cfg.mlp_hidden, n_l = (int64_t)Gc * 16 * n_logits_pad, n_i = (int64_t)Gc * 16;
+    const int gq = spipe ? 0 : Gc;   // (the stage pipeline keeps its messages in blocks of its own; only the XCD counters + error word here)
+    const int64_t n_h = (int64_t)gq * 2 * 16 * C, n_y = n_h, n_s = (int64_t)gq * 16 * S,   // y, h: two generations each
+                  n_hid = (int64_t)gq * 16 * cfg.mlp_hidden, n_l = (int64_t)gq * 16 * n_logits_pad, n_i = (int64_t)gq * 16;
     gran_words = n_h + n_y + n_s + n_hid + n_l + n_i + 8 + 2;   // + XCD registration counters + sticky error word
     unsigned long long* base = c.take<unsigned long long>(gran_words);
     gran_h = base;
@@ -131,7 +139,18 @@ struct mmk_wavenet_plan {
       lp_xg = c.take<unsigned long long>(lp_gran_words);
       lp_cg = lp_xg + (lp_xg ? (int64_t)(kLpStages + 1) * Bmax * 128 : 0);
     }
-    h_rings = c.take<float>((int64_t)(pipe ? 8 : Gc) * Gn * ring_floats_per_wg);
+    if (spipe) {
+      sp_img_chain = c.take<float>(wn_spipe_img_chain_floats(L, C));
+      sp_img_helper = c.take<float>(wn_spipe_img_helper_floats(L, C));
+      sp_cst_chain = c.take<float>(wn_spipe_cst_floats(L, C));
+      sp_cst_helper = c.take<float>(wn_spipe_cst_floats(L, C));
+      sp_head_w0 = c.take<float>((int64_t)cfg.mlp_hidden * C);
+      sp_head_b0 = c.take<float>(cfg.mlp_hidden);
+      sp_msg = c.take<unsigned>(wn_spipe_msg_words(L, C, Bmax) + wn_spipe_hidmsg_words(L, Bmax));   // one block: poisoned by one memset
+      sp_hidmsg = sp_msg + (sp_msg ? wn_spipe_msg_words(L, C, Bmax) : 0);
+      sp_raw = c.take<WnSpRaw>(L);
+    }
+    h_rings = spipe ? nullptr : c.take<float>((int64_t)(pipe ? 8 : Gc) * Gn * ring_floats_per_wg);
     cproj = C1 > 0 ? c.take<float>((int64_t)Bmax * kCondBlock * C1) : nullptr;
     condall = C1 > 0 ? c.take<float>((int64_t)Bmax * kCondBlock * L * 2 * C) : nullptr;
     if (C1 > 0) cond_all.carve(c, false);
@@ -368,11 +387,36 @@ static int derive(mmk_wavenet_plan* p) {
       if (p->C1 > 0) p->cond_all.set_geometry(p->L * 2 * p->C, {p->C1});
     }
   }
+  // ---- stage pipeline (wavenet_spipe.hip): one layer per stage of 8 CUs, 4 stages per XCD, clips streamed through one at a time.
+  // 256 channels, <= 31 layers, <= 32 clips, the same layer structure as the other persistent kernels; needs the whole 8 x 32 CU
+  // chip and the warm-up as a prefill into the launch path's rings.  MMK_WN_SPIPE=0, or forcing another kernel (MMK_WN_PIPE=1 /
+  // MMK_WN_CHAIN=1), turns it off.
+  p->spipe = false;
+  if (ok) {
+    const char* senv = getenv("MMK_WN_SPIPE");
+    const char* fenv = getenv("MMK_WN_PREFILL");
+    const char* penv = getenv("MMK_WN_PIPE");
+    const char* cenv = getenv("MMK_WN_CHAIN");
+    bool ok5 = !(senv && senv[0] == '0') && !(fenv && fenv[0] == '0') && !(penv && penv[0] == '1') && !(cenv && cenv[0] == '1');
+    ok5 = ok5 && n_xcc == 8 && n_cu == 256 && c.q_levels == 256;
+    ok5 = ok5 && wn_spipe_supported(p->C, p->S, c.mlp_hidden, c.out_dim, p->L, c.n_cond, p->Bmax);
+    if (ok5) {
+      p->spipe = true;
+      p->persistent = true;
+      p->xcd_local = false;
+      p->C1 = c.n_cond == 1 ? c.cond_dim[0] : 0;
+      p->n_logits_pad = (int)round_up(c.out_dim + (c.learn_temp ? 1 : 0), 16);
+      p->ring_offset.assign(p->L, 0);
+      p->ring_mask.assign(p->L, 0);
+      p->ring_floats_per_wg = 0;
+      if (p->C1 > 0) p->cond_all.set_geometry(p->L * 2 * p->C, {p->C1});
+    }
+  }
   // one hand-off per layer: every layer but the last needs its residual 1x1 (it is folded into the next layer's tap-1
   // product), groups of at most 4 clips (4x4 MFMA blocks)
   p->chain = false;
   p->Ac.clear();
-  if (p->persistent) {
+  if (p->persistent && !p->spipe) {
     const char* cenv = getenv("MMK_WN_CHAIN");
     const bool fits_l2 = (int64_t)p->L * 8 * p->C * p->C * 4 <= ((int64_t)3 << 20);
     const char* pforce = getenv("MMK_WN_PIPE");
@@ -394,7 +438,7 @@ static int derive(mmk_wavenet_plan* p) {
   // clips, at most 4 iterations per XCD, one workgroup per CU and XCD (8 Gn <= 256), and the warm-up as a prefill (its
   // history rings are laid out per stage, the teacher-forced mode of wavenet_persist.hip cannot fill them).
   p->pipe = false;
-  if (p->persistent && !p->chain) {
+  if (p->persistent && !p->chain && !p->spipe) {
     const char* penv = getenv("MMK_WN_PIPE");
     const char* fenv = getenv("MMK_WN_PREFILL");
     const bool fits_l2 = (int64_t)p->L * 8 * p->C * p->C * 4 <= ((int64_t)3 << 20);
@@ -436,7 +480,7 @@ static int derive(mmk_wavenet_plan* p) {
   // ---- layer pipeline (wavenet_lpipe.hip): small networks whose layers fit a fraction of a CU's registers; 32 workgroups per 8 clips,
   // all resident, four per clip on one XCD; the warm-up is the prefill, scattered into the launch path's rings.  MMK_WN_LPIPE=0: off.
   p->lpipe = false;
-  if (p->persistent && !p->pipe) {
+  if (p->persistent && !p->pipe && !p->spipe) {
     const char* lenv = getenv("MMK_WN_LPIPE");
     const char* fenv = getenv("MMK_WN_PREFILL");
     bool ok4 = !(lenv && lenv[0] == '0') && !(fenv && fenv[0] == '0') && n_xcc == 8 && 32 * ((p->Bmax + 7) / 8) <= n_cu && c.q_levels == 256;
@@ -673,6 +717,32 @@ extern "C" int mmk_wavenet_commit(mmk_wavenet_plan* p, void* workspace, size_t w
       }
     }
   }
+  // stage pipeline: the per-lane register images of every stage, from the raw tensors (W1 R and fc0 W_skip composed in fp64)
+  if (p->spipe) {
+    std::vector<WnSpRaw> raw(L);
+    for (int l = 0; l < L; ++l) {
+      const std::string ly = "layers." + std::to_string(l) + ".";
+      WnSpRaw& r = raw[l];
+      r.wd = b.need(ly + "conv_dil.0.0.weight", (int64_t)2 * C * C * 2);
+      r.bd = bias ? b.need(ly + "conv_dil.0.0.bias", 2 * C) : nullptr;
+      r.b1 = (bias && p->n_cond == 1) ? b.need(ly + "conv_1x1.0.0.bias", 2 * C) : nullptr;
+      r.wr = p->has_res[l] ? b.need(ly + "conv_res.weight", (int64_t)C * C) : nullptr;
+      r.br = (bias && p->has_res[l]) ? b.need(ly + "conv_res.bias", C) : nullptr;
+      r.ws = b.need(ly + "conv_skip.weight", (int64_t)C * C);
+      r.bs = bias ? b.need(ly + "conv_skip.bias", C) : nullptr;
+    }
+    const int H1 = c.mlp_hidden;
+    const float* f0 = b.need("output_modules.0.estimator.0.fc.0.weight", (int64_t)H1 * C);
+    const float* fb0 = b.need("output_modules.0.estimator.0.fc.0.bias", H1);
+    p->sp_fc2_w = b.need("output_modules.0.estimator.0.fc.2.weight", (int64_t)(c.out_dim + (c.learn_temp ? 1 : 0)) * H1);
+    p->sp_fc2_b = b.need("output_modules.0.estimator.0.fc.2.bias", c.out_dim + (c.learn_temp ? 1 : 0));
+    if (b.missing().empty()) {
+      MMK_HIP(hipMemcpyAsync(p->sp_raw, raw.data(), sizeof(WnSpRaw) * L, hipMemcpyHostToDevice, st));
+      MMK_TRY(wn_spipe_build_image(p->sp_raw, L, C, f0, fb0, p->sp_img_chain, p->sp_img_helper, p->sp_cst_chain, p->sp_cst_helper, p->sp_head_w0,
+                                   p->sp_head_b0, st));
+      MMK_HIP(hipStreamSynchronize(st));   // `raw` is host-local
+    }
+  }
   // head
   if (c.head_kind == 0) {
     const std::string hb = "output_modules.0.estimator.0.fc.";
@@ -692,7 +762,7 @@ extern "C" int mmk_wavenet_commit(mmk_wavenet_plan* p, void* workspace, size_t w
     if (bb) MMK_TRY(pack_bias(m.bias, 0, 1, m.N, bb, 0, st));
   }
   if (!b.missing().empty()) return fail(MMK_ERR_KEY, "wavenet_commit: state_dict tensor %s", b.missing().c_str());
-  if (p->persistent) {
+  if (p->persistent && !p->spipe) {
     std::vector<WnLayerTab> tab(L);
     for (int l = 0; l < L; ++l) {
       tab[l].dil = p->dil[l];
@@ -921,6 +991,30 @@ static int run_persistent(mmk_wavenet_plan* p, const WnCall& call, int64_t tau0,
       done += nb;
       continue;
     }
+    if (p->spipe) {
+      if (!with_head) return fail(MMK_ERR_STATE, "wavenet: the stage-pipeline kernel has no teacher-forced mode (warm-up is a prefill)");
+      // every message word starts as poison (0xFFFFFFFF): "not arrived"
+      MMK_HIP(hipMemsetAsync(p->sp_msg, 0xFF, (size_t)(wn_spipe_msg_words(p->L, p->C, p->Bmax) + wn_spipe_hidmsg_words(p->L, p->Bmax)) * sizeof(unsigned), st));
+      WnSpipeArgs k = {};
+      k.B = call.M; k.L = p->L; k.C = p->C; k.C1 = p->C1;
+      k.learn_temp = c.learn_temp; k.min_temp = c.min_temp; k.Bmax = p->Bmax;
+      k.t0 = tau_b + 1; k.n_steps = nb;
+      k.img_chain = p->sp_img_chain; k.img_helper = p->sp_img_helper; k.cst_chain = p->sp_cst_chain; k.cst_helper = p->sp_cst_helper;
+      k.head_w0 = p->sp_head_w0; k.head_b0 = p->sp_head_b0; k.fc2_w = p->sp_fc2_w; k.fc2_b = p->sp_fc2_b;
+      for (int l = 0; l < p->L; ++l) { k.hist[l] = p->hist[l]; k.ring[l] = p->ring[l]; k.dil[l] = p->dil[l]; }
+      k.emb = p->emb; k.idx = (int64_t*)call.in0; k.idx_rs = call.in0_rs;
+      k.condall = p->condall; k.cond_steps = p->kCondBlock;
+      k.temperature = call.temperature;
+      k.uniforms = call.uniforms ? call.uniforms + done : nullptr;
+      k.uni_ld = call.uni_ld;
+      k.logits_out = p->logits; k.logits_ld = p->logits_ld;
+      k.msg = p->sp_msg; k.hidmsg = p->sp_hidmsg; k.xcd_count = p->xcd_count; k.err_flag = p->err_flag;
+      k.stamps = (stamp_env && stamp_env[0] == '1') ? reinterpret_cast<unsigned long long*>(p->tau + 8) : nullptr;
+      k.stamp_stage = getenv("MMK_WN_STAMP_STAGE") ? atoi(getenv("MMK_WN_STAMP_STAGE")) : 1;
+      MMK_TRY(launch_wavenet_spipe(k, st));
+      done += nb;
+      continue;
+    }
     if (p->pipe) {
       if (!with_head) return fail(MMK_ERR_STATE, "wavenet: the pipelined kernel has no teacher-forced mode (warm-up is a prefill)");
       MMK_HIP(hipMemsetAsync(p->px_yl, 0, (size_t)p->pipe_gran_words * sizeof(unsigned long long), st));
@@ -1035,7 +1129,7 @@ static int prefill(mmk_wavenet_plan* p, const WnCall& call, int64_t t_begin, int
     const int d = p->dil[l];
     // the ring of layer l holds its input at the last d positions
     const int64_t t_lo = t_end - d > t_begin ? t_end - d : t_begin;
-    if (p->lpipe)  // the launch path's rings: [slot][Bmax][C]
+    if (p->lpipe || p->spipe)  // the launch path's rings: [slot][Bmax][C]
       MMK_TRY(launch_wn_lpipe_scatter(p->pf_h[cur], P * C, t_begin, t_lo, (int)(t_end - t_lo), C, B, p->Bmax, p->hist[l], p->ring[l], st));
     else if (p->pipe)   // the rings of layer l live with the workgroups of its stage and hold all clips per slot
       MMK_TRY(launch_wn_prefill_scatter(p->pf_h[cur], P * C, t_begin, t_lo, (int)(t_end - t_lo), C, B, p->Gc * p->Mg, 1, p->Gn,
@@ -1144,7 +1238,7 @@ extern "C" int mmk_wavenet_warmup(mmk_wavenet_plan* p, int32_t batch, const void
   call.in0_rs = in0_row_stride;
   if (t_begin < 0 || t_end < t_begin) return fail(MMK_ERR_INVALID, "wavenet_warmup: bad range [%lld, %lld)", (long long)t_begin, (long long)t_end);
   const char* penv = getenv("MMK_WN_PREFILL");
-  if (p->pipe || p->lpipe) {
+  if (p->pipe || p->lpipe || p->spipe) {
     // the stage-owned rings are only filled by the prefill; a longer window than the receptive field adds nothing to the
     // ring entries generation reads (each is determined by the rf - 1 positions before t_end)
     if (t_end - t_begin > p->rf - 1) t_begin = t_end - (p->rf - 1);
@@ -1215,7 +1309,9 @@ extern "C" int mmk_wavenet_profile_steps(mmk_wavenet_plan* p, int32_t batch, voi
   return rc;
 }
 
-extern "C" int mmk_wavenet_mode(const mmk_wavenet_plan* p) { return (p && p->persistent) ? (p->lpipe ? 4 : (p->pipe ? 3 : (p->chain ? 2 : 1))) : 0; }
+extern "C" int mmk_wavenet_mode(const mmk_wavenet_plan* p) {
+  return (p && p->persistent) ? (p->spipe ? 5 : (p->lpipe ? 4 : (p->pipe ? 3 : (p->chain ? 2 : 1)))) : 0;
+}
 
 extern "C" int mmk_wavenet_sync_status(mmk_wavenet_plan* p, mmk_stream_t stream) {
   if (!p) return fail(MMK_ERR_INVALID, "wavenet_sync_status: null plan");
@@ -1234,6 +1330,12 @@ extern "C" int mmk_wavenet_sync_status(mmk_wavenet_plan* p, mmk_stream_t stream)
     if (senv && senv[0] == '1') {
       unsigned long long st[24];
       MMK_HIP(hipMemcpy(st, p->tau + 8, sizeof(st), hipMemcpyDeviceToHost));
+      if (p->spipe) {
+        fprintf(stderr, "[mmk stamps] last stage-pipeline launch, chain wave 0 of CU 0 of stage MMK_WN_STAMP_STAGE (default 1), shader cycles per visit: "
+                        "wait for the message=%.0f; products + gate + publish=%.0f; poison + ring store=%.0f; visits=%llu\n",
+                st[3] ? (double)st[0] / (double)st[3] : 0.0, st[3] ? (double)st[1] / (double)st[3] : 0.0, st[3] ? (double)st[2] / (double)st[3] : 0.0, st[3]);
+        return MMK_OK;
+      }
       if (p->pipe) {
         fprintf(stderr, "[mmk stamps] last pipelined launch, lane 0 of one wave (MMK_WN_STAMP_STAGE / _OWNER / _WAVE, default 1 / 1 / 0), totals in ms: visit start (own h + wait for the "
                         "group's inputs)=%.3f; request issue=%.3f; operands from LDS=%.3f; MFMA + partial sums=%.3f; wait B1=%.3f; epilogues + publish=%.3f; small operands + ring store=%.3f; "

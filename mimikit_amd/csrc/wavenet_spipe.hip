@@ -1,0 +1,632 @@
+// WaveNet generation as a PIPELINE OF LAYER STAGES (gfx950): every layer is a stage of C / 32 = 8 CUs that hold the layer's matrices in
+// registers for the whole launch; the clips of the batch stream through the stages ONE AT A TIME, so the chip holds up to 32 clips in
+// flight, each at a different layer.  BASELINE config 4: 30 layers x 256 channels, conditioned, 32 clips per GPU.
+//
+// Reference: WaveNet.forward / WNLayer.forward (wavenet_v2.py:131-182, :276-293), MLP head and CategoricalSampler (networks/mlp.py:58-63,
+// modules/targets.py:37-52).  Same arithmetic as the other step kernels in the one-hand-off form of wavenet_chain.hip:
+//   x_s     = x_{s-1} + R_{s-1} y_{s-1} + br_{s-1}                                  (layer s's input: :172-176 of the layer below)
+//   z_s     = W0_s x_s[t - d_s] + W1_s x_{s-1} + (W1_s R_{s-1}) y_{s-1} + cond_s + b  (:141-150; tap 1 through the residual sum)
+//   y_s     = tanh(z_f) sigmoid(z_g)                                                 (:151)
+//   hid    += (fc0 W_skip_s) y_s                                                     (:165-171 folded into the head's first Linear)
+// with W1 R and fc0 W_skip pre-multiplied at commit (fp64 accumulation, one rounding).
+//
+// Why this shape.  A step of one clip is a chain of L + 1 dependent all-to-all exchanges; arithmetic (0.75 GFLOP per step and batch)
+// and bytes are a tenth of it.  wavenet_pipe.hip spreads a layer over 32 CUs and moves groups of 4 clips: 2.3 us per layer, of which
+// two workgroup barriers, the K-split reduction through LDS and a 32-way gather are most.  Here
+//   * a layer lives on 8 CUs (the whole net on 30 x 8 + 8 = 248 of the 256 CUs, 4 stages per XCD: 7 of 8 exchanges stay in one L2);
+//   * a visit is ONE clip: per wave 16 gate rows x 512 inputs = 128 weights per lane, all in registers, packed-fp32 FMAs out of a
+//     broadcast LDS read, a quad reduction by DPP, the gate, one store - no MFMA (a 1-row tile wastes it), no workgroup barrier;
+//   * messages are raw floats checked against a poison word (a NaN no layer produces): no tags, half the bytes; the producer
+//     re-poisons its own words two steps ahead (same wave, same address: ordered), so there is nothing to acknowledge;
+//   * the four chain waves of a CU gather a message together (a quarter each, straight into a shared LDS image, one counter per
+//     quarter): the L2 sees each message once per CU instead of once per wave;
+//   * everything that does not depend on the newest sample - the delayed-tap product W0 x[t - d], the conditioning term, biases -
+//     is prepared one step ahead by four helper waves (the second wave of every SIMD) and handed over through LDS; they also carry
+//     the head's running hidden pre-activations from stage to stage beside the chain.
+// Delayed taps come from the launch path's history rings in global memory (so warm-up = the prefill scattered into those rings,
+// and a timed-out batch can be redone on the launch path); a layer with d = 1 reads its own previous output message instead.
+#include "wavenet_spipe.h"
+#include "sampler256.h"
+
+namespace mmk {
+
+namespace {
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4s __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4s __attribute__((ext_vector_type(4)));
+typedef unsigned long long u64;
+
+constexpr int kC = 256, kH1 = 128, kQ = 256;
+constexpr int kThreads = 512;
+constexpr int kCuPerStage = kC / 32;          // 8
+constexpr int kWavesPerStage = kC / 8;        // 32 chain waves (and as many helpers)
+constexpr int kMsgFloats = 2 * kC;            // 512
+constexpr int kPadBlk = 36;                   // 32 channels + 4 floats of padding: the K slices of a broadcast read fall on different banks
+constexpr int kHalf = (kC / 32) * kPadBlk;    // 288 floats: one padded vector of C channels
+constexpr int kXyRing = 4;
+constexpr unsigned kSpinLimit = 1u << 22;
+
+__device__ __forceinline__ int pad_of(int ch) { return (ch >> 5) * kPadBlk + (ch & 31); }
+
+__device__ __forceinline__ float dpp_quad_sum(float v) {
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, false));   // quad_perm [1,0,3,2]
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xf, 0xf, false));   // quad_perm [2,3,0,1]
+  return v;
+}
+__device__ __forceinline__ float dpp_half_mirror_add(float v) {
+  return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float dpp_mirror_add(float v) {
+  return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xf, 0xf, false));
+}
+
+__device__ __forceinline__ f32x2 fma2(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+
+// LDS counters: written by one lane of one wave, read by all; LDS serves a wave's operations in issue order, so data written before
+// the counter is visible to whoever has read the new counter value.  The signal fences only pin the compiler's order.
+__device__ __forceinline__ void lds_signal(unsigned* p, unsigned v, int lane) {
+  __atomic_signal_fence(__ATOMIC_SEQ_CST);
+  if (lane == 0) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  __atomic_signal_fence(__ATOMIC_SEQ_CST);
+}
+__device__ __forceinline__ unsigned lds_min4(const unsigned* p) {
+  const unsigned a = __hip_atomic_load(p + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  const unsigned b = __hip_atomic_load(p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  const unsigned c = __hip_atomic_load(p + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  const unsigned d = __hip_atomic_load(p + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  return min(min(a, b), min(c, d));
+}
+// wait until all four counters reach `want`; false after ~1 s (the other waves of the workgroup have failed or the kernel is wedged)
+__device__ __forceinline__ bool lds_wait4(const unsigned* p, unsigned want, int32_t* err) {
+  unsigned spins = 0;
+  while (lds_min4(p) < want) {
+    if (++spins > kSpinLimit || ((spins & 4095u) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+      atomicExch(err, 1);
+      return false;
+    }
+  }
+  __atomic_signal_fence(__ATOMIC_SEQ_CST);
+  return true;
+}
+__device__ __forceinline__ bool lds_wait1(const unsigned* p, unsigned want, int32_t* err) {
+  unsigned spins = 0;
+  while (__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < want) {
+    if (++spins > kSpinLimit || ((spins & 4095u) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+      atomicExch(err, 1);
+      return false;
+    }
+  }
+  __atomic_signal_fence(__ATOMIC_SEQ_CST);
+  return true;
+}
+
+// message words: plain stores stay in the producer XCD's L2 (consumer on the same XCD, whose L2 is the coherence point of its CUs);
+// otherwise written through (sc1).  Consumers always read past their L1 (sc1).
+__device__ __forceinline__ void msg_store(unsigned* p, unsigned v, bool local) {
+  if (local) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  else __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ unsigned msg_load(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+struct Lds {
+  float xy[kXyRing][2 * kHalf];               // the newest messages of this stage: [x padded | y padded]
+  float xd[2][kHalf];                         // delayed layer input of the visit whose bias is being prepared
+  float bias[4][2][32][16];                   // [chain wave][step parity][clip][gate row]: everything of z that is known a step ahead
+  unsigned arrived[4];                        // per quarter: visits staged into xy
+  unsigned hdone[4];                          // per helper: visits whose xy image it no longer needs
+  unsigned xd_arrived[4];                     // per quarter: visits staged into xd
+  unsigned ready[4];                          // per helper: biases prepared (visit count)
+};
+
+struct Stamps {
+  u64 t_wait = 0, t_compute = 0, t_post = 0, t_bias = 0, visits = 0;
+};
+
+// ------------------------------------------------------------------------------------------------------------------------------------
+// chain waves (waves 0-3 of a layer stage's workgroup): gate rows 16 W .. 16 W + 15, residual channels 8 W .. 8 W + 7, W = 4 p + q
+// ------------------------------------------------------------------------------------------------------------------------------------
+template <bool STAMPS>
+__device__ void chain_role(const WnSpipeArgs& a, Lds& S, int stage, int p, int q, int lane) {
+  const int W = 4 * p + q;
+  const int j = lane >> 2, ks = lane & 3;       // gate row of the wave's 16, K slice of 128 of [x | y]
+  const int j8 = lane >> 3, ks8 = lane & 7;     // residual channel of the wave's 8, K slice of 32 of y
+  f32x4s wz[32], wr[8];
+  {
+    const f32x4s* img = reinterpret_cast<const f32x4s*>(a.img_chain) + ((int64_t)stage * kWavesPerStage + W) * 40 * 64 + lane;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) wz[i] = img[i * 64];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) wr[i] = img[(32 + i) * 64];
+  }
+  const float bx = a.cst_chain[((int64_t)stage * kWavesPerStage + W) * 64 + lane];
+  const bool g_row = (j & 1) != 0;
+  const float gate_scale = g_row ? -1.4426950408889634f : -2.8853900817779268f;
+  const float gate_k = g_row ? 1.f : 2.f, gate_shift = g_row ? 0.f : -1.f;
+  const bool local_next = ((stage + 1) >> 2) == (stage >> 2);
+  const int64_t stage_words = (int64_t)a.Bmax * kSpSlots * kMsgFloats;
+  const unsigned* msg_in = a.msg + (int64_t)stage * stage_words;
+  unsigned* msg_out = a.msg + (int64_t)(stage + 1) * stage_words;
+  // my quarter of an arriving message: floats 128 q + 2 lane, + 1 = producing wave Ws, 8 x then 8 y of its channels
+  int st_off;
+  {
+    const int f = 128 * q + 2 * lane, Ws = f >> 4, r = f & 15;
+    st_off = (r < 8 ? 0 : kHalf) + pad_of(8 * Ws + (r & 7));
+  }
+  const int kso = (ks < 2 ? 0 : kHalf) + (ks & 1) * 4 * kPadBlk;        // K slice ks: x[0:128], x[128:256], y[0:128], y[128:256]
+  const int xr_off = kHalf + ks8 * kPadBlk;                            // y[32 ks8 ...]
+  const int xin_off = pad_of(8 * W + j8);
+  const bool pub_lane = (lane & 7) < 2;
+  const int pub_off = W * 16 + (lane & 1) * 8 + (lane >> 3);
+  const int ring_mask = a.ring[stage] - 1;
+  float* hist = a.hist[stage];
+  const int64_t slot_stride = (int64_t)a.Bmax * kC;
+  const int B = a.B;
+  Stamps st;
+  u64 t0c = 0;
+  unsigned v = 0;
+  for (int s = 0; s < (int)a.n_steps; ++s) {
+    const int64_t tau = a.t0 - 1 + s;
+    const int slot = s & 3, pslot = (s + 2) & 3;
+    for (int c = 0; c < B; ++c, ++v) {
+      if (STAMPS) t0c = __builtin_amdgcn_s_memtime();
+      // the image of visit v - 4 must have been read by the helpers before it is overwritten (they run beside the chain, not behind it)
+      if (v >= (unsigned)kXyRing && !lds_wait4(S.hdone, v - (kXyRing - 1), a.err_flag)) return;
+      // ---- my quarter of the message: two words per lane, until neither is poison -----------------------------------------------------
+      {
+        const unsigned* src = msg_in + ((int64_t)c * kSpSlots + slot) * kMsgFloats + 128 * q + 2 * lane;
+        u32x2 w2;
+        unsigned spins = 0;
+        for (;;) {
+          asm volatile("global_load_dwordx2 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(w2) : "v"(src) : "memory");
+          const bool ok = w2[0] != kSpPoison && w2[1] != kSpPoison;
+          if (__all(ok)) break;
+          if (++spins > kSpinLimit || ((spins & 1023u) == 0 && __hip_atomic_load(a.err_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+            atomicExch(a.err_flag, 1);
+            return;
+          }
+        }
+        *reinterpret_cast<f32x2*>(&S.xy[v & (kXyRing - 1)][st_off]) = f32x2{__uint_as_float(w2[0]), __uint_as_float(w2[1])};
+      }
+      lds_signal(&S.arrived[q], v + 1, lane);
+      if (!lds_wait4(S.arrived, v + 1, a.err_flag)) return;
+      if (STAMPS) { const u64 t = __builtin_amdgcn_s_memtime(); st.t_wait += t - t0c; t0c = t; }
+      // ---- z = [W1 | W1 R] . [x ; y]: 32 broadcast reads of 4 inputs, 64 packed FMAs -----------------------------------------------------
+      const float* xb = S.xy[v & (kXyRing - 1)];
+      f32x2 acc[4] = {f32x2{0.f, 0.f}, f32x2{0.f, 0.f}, f32x2{0.f, 0.f}, f32x2{0.f, 0.f}};
+#pragma unroll
+      for (int i = 0; i < 32; ++i) {
+        const f32x4s xv = *reinterpret_cast<const f32x4s*>(xb + kso + (i >> 3) * kPadBlk + (i & 7) * 4);
+        acc[(i & 1) * 2 + 0] = fma2(f32x2{wz[i][0], wz[i][1]}, f32x2{xv[0], xv[1]}, acc[(i & 1) * 2 + 0]);
+        acc[(i & 1) * 2 + 1] = fma2(f32x2{wz[i][2], wz[i][3]}, f32x2{xv[2], xv[3]}, acc[(i & 1) * 2 + 1]);
+      }
+      // ---- the layer's own input x_s = x_{s-1} + (R y + br): 8 channels per wave, K = 256 over 8 lanes ------------------------------------
+      f32x2 rac[2] = {f32x2{0.f, 0.f}, f32x2{0.f, 0.f}};
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const f32x4s yv = *reinterpret_cast<const f32x4s*>(xb + xr_off + i * 4);
+        rac[0] = fma2(f32x2{wr[i][0], wr[i][1]}, f32x2{yv[0], yv[1]}, rac[0]);
+        rac[1] = fma2(f32x2{wr[i][2], wr[i][3]}, f32x2{yv[2], yv[3]}, rac[1]);
+      }
+      const float xin = xb[xin_off];
+      float z = dpp_quad_sum(((acc[0][0] + acc[0][1]) + (acc[1][0] + acc[1][1])) + ((acc[2][0] + acc[2][1]) + (acc[3][0] + acc[3][1])));
+      float xs = dpp_half_mirror_add(dpp_quad_sum((rac[0][0] + rac[0][1]) + (rac[1][0] + rac[1][1])));
+      const float xnew = xin + (xs + bx);
+      // ---- what the helper prepared a step ahead: W0 x[t - d] + conditioning + biases ----------------------------------------------------
+      if (!lds_wait1(&S.ready[q], v + 1, a.err_flag)) return;
+      z += S.bias[q][s & 1][c][j];
+      // tanh(f) sigmoid(g) (wavenet_v2.py:151) with the hardware exp2 / rcp as in the other step kernels; the g row sits four lanes up
+      const float act = fmaf(__frcp_rn(1.0f + __builtin_amdgcn_exp2f(z * gate_scale)), gate_k, gate_shift);
+      const float other = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(act), 0x104, 0xf, 0xf, false));   // row_shl:4
+      const float y = act * other;
+      // ---- publish 8 x | 8 y, re-poison the same words two steps ahead, keep x_s for the delayed taps -------------------------------------
+      if (pub_lane) {
+        unsigned* dst = msg_out + ((int64_t)c * kSpSlots + slot) * kMsgFloats + pub_off;
+        msg_store(dst, __float_as_uint((lane & 1) ? y : xnew), local_next);
+      }
+      if (STAMPS) { const u64 t = __builtin_amdgcn_s_memtime(); st.t_compute += t - t0c; t0c = t; }
+      if (pub_lane) msg_store(msg_out + ((int64_t)c * kSpSlots + pslot) * kMsgFloats + pub_off, kSpPoison, local_next);
+      if ((lane & 7) == 0) hist[(tau & ring_mask) * slot_stride + (int64_t)c * kC + 8 * W + j8] = xnew;
+      if (STAMPS) { const u64 t = __builtin_amdgcn_s_memtime(); st.t_post += t - t0c; st.visits += 1; }
+    }
+  }
+  if (STAMPS && a.stamps && stage == a.stamp_stage && p == 0 && q == 0 && lane == 0) {
+    a.stamps[0] = st.t_wait; a.stamps[1] = st.t_compute; a.stamps[2] = st.t_post; a.stamps[3] = st.visits;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------------
+// helper waves (waves 4-7): for chain wave h of the same workgroup the part of z known a step ahead, and the head's hidden units 4 W ..
+// ------------------------------------------------------------------------------------------------------------------------------------
+template <bool STAMPS>
+__device__ void helper_role(const WnSpipeArgs& a, Lds& S, int stage, int p, int h, int lane) {
+  const int W = 4 * p + h;
+  const int j = lane >> 2, ks = lane & 3;       // gate row, K slice of 64 of the delayed input
+  const int j4 = lane >> 4, ks16 = lane & 15;   // hidden unit of the wave's 4, K slice of 16 of y
+  f32x4s w0[16], wh[4];
+  {
+    const f32x4s* img = reinterpret_cast<const f32x4s*>(a.img_helper) + ((int64_t)stage * kWavesPerStage + W) * 20 * 64 + lane;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) w0[i] = img[i * 64];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) wh[i] = img[(16 + i) * 64];
+  }
+  const float bz = a.cst_helper[((int64_t)stage * kWavesPerStage + W) * 64 + lane];
+  const int d = a.dil[stage], ring_mask = a.ring[stage] - 1;
+  const float* hist = a.hist[stage];
+  const int64_t slot_stride = (int64_t)a.Bmax * kC;
+  const bool local_next = ((stage + 1) >> 2) == (stage >> 2);
+  const int64_t stage_words = (int64_t)a.Bmax * kSpSlots * kMsgFloats;
+  const unsigned* msg_own = a.msg + (int64_t)(stage + 1) * stage_words;     // what THIS stage publishes: x_s of the newest step
+  const int64_t hid_words = (int64_t)a.Bmax * kSpSlots * kH1;
+  const unsigned* hid_in = a.hidmsg + (int64_t)stage * hid_words;
+  unsigned* hid_out = a.hidmsg + (int64_t)(stage + 1) * hid_words;
+  const int B = a.B;
+  const int n_visits = (int)a.n_steps * B;
+  const int xd_ch = 64 * h + lane;                                          // my quarter of the delayed input: one channel per lane
+  const int xd_st = pad_of(xd_ch);
+  const int xd_msg = (xd_ch >> 3) * 16 + (xd_ch & 7);
+  const int yh_off = kHalf + pad_of(16 * ks16);
+  const int w0_off = (ks * 64 >> 5) * kPadBlk;                              // pad_of(64 ks)
+  for (int it = -B; it < n_visits; ++it) {
+    if (it >= 0) {
+      const int s = it / B, c = it - s * B, slot = s & 3, pslot = (s + 2) & 3;
+      if (stage >= 1) {
+        // ---- hidden pre-activations: hid_s = hid_{s-1} + (fc0 W_skip_{s-1}) y_{s-1}, my 4 units, K = 256 over 16 lanes ---------------------
+        if (!lds_wait4(S.arrived, (unsigned)it + 1, a.err_flag)) return;
+        const float* yb = S.xy[it & (kXyRing - 1)] + yh_off;
+        f32x2 hc[2] = {f32x2{0.f, 0.f}, f32x2{0.f, 0.f}};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const f32x4s yv = *reinterpret_cast<const f32x4s*>(yb + i * 4);
+          hc[0] = fma2(f32x2{wh[i][0], wh[i][1]}, f32x2{yv[0], yv[1]}, hc[0]);
+          hc[1] = fma2(f32x2{wh[i][2], wh[i][3]}, f32x2{yv[2], yv[3]}, hc[1]);
+        }
+        float hs = dpp_mirror_add(dpp_half_mirror_add(dpp_quad_sum((hc[0][0] + hc[0][1]) + (hc[1][0] + hc[1][1]))));
+        lds_signal(&S.hdone[h], (unsigned)it + 1, lane);
+        float hin = 0.f;
+        if (stage >= 2) {
+          const unsigned* src = hid_in + ((int64_t)c * kSpSlots + slot) * kH1 + 4 * W + j4;
+          unsigned w1, spins = 0;
+          for (;;) {
+            w1 = msg_load(src);
+            if (__all(w1 != kSpPoison)) break;
+            if (++spins > kSpinLimit || ((spins & 1023u) == 0 && __hip_atomic_load(a.err_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+              atomicExch(a.err_flag, 1);
+              return;
+            }
+          }
+          hin = __uint_as_float(w1);
+        }
+        if (ks16 == 0) {
+          msg_store(hid_out + ((int64_t)c * kSpSlots + slot) * kH1 + 4 * W + j4, __float_as_uint(hin + hs), local_next);
+          msg_store(hid_out + ((int64_t)c * kSpSlots + pslot) * kH1 + 4 * W + j4, kSpPoison, local_next);
+        }
+      } else {
+        lds_signal(&S.hdone[h], (unsigned)it + 1, lane);
+      }
+    }
+    const int v2 = it + B;
+    if (v2 < n_visits) {
+      // ---- the bias of visit v2 = (c2, s2): W0 x_s[t - d] + conditioning + constants ------------------------------------------------------
+      const int s2 = v2 / B, c2 = v2 - s2 * B;
+      const int64_t tau2 = a.t0 - 1 + s2;
+      float xv1;
+      if (d == 1 && s2 >= 1) {      // the previous step's x_s is this stage's own newest message (its ring entry has no arrival check)
+        const unsigned* src = msg_own + ((int64_t)c2 * kSpSlots + ((s2 - 1) & 3)) * kMsgFloats + xd_msg;
+        unsigned w1, spins = 0;
+        for (;;) {
+          w1 = msg_load(src);
+          if (__all(w1 != kSpPoison)) break;
+          if (++spins > kSpinLimit || ((spins & 1023u) == 0 && __hip_atomic_load(a.err_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+            atomicExch(a.err_flag, 1);
+            return;
+          }
+        }
+        xv1 = __uint_as_float(w1);
+      } else {                      // written at least two steps ago (or by the warm-up): the chain has passed it on every CU of the stage
+        const int64_t tp = tau2 - d;
+        xv1 = tp >= 0 ? __uint_as_float(msg_load(reinterpret_cast<const unsigned*>(hist + (tp & ring_mask) * slot_stride + (int64_t)c2 * kC + xd_ch))) : 0.f;
+      }
+      float cnd = 0.f;
+      if (a.C1 > 0) cnd = a.condall[(((int64_t)c2 * a.cond_steps + s2) * a.L + stage) * (2 * kC) + 16 * W + j];
+      S.xd[v2 & 1][xd_st] = xv1;
+      lds_signal(&S.xd_arrived[h], (unsigned)v2 + 1, lane);
+      if (!lds_wait4(S.xd_arrived, (unsigned)v2 + 1, a.err_flag)) return;
+      const float* xb = S.xd[v2 & 1] + w0_off;
+      f32x2 acc[4] = {f32x2{0.f, 0.f}, f32x2{0.f, 0.f}, f32x2{0.f, 0.f}, f32x2{0.f, 0.f}};
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const f32x4s xv = *reinterpret_cast<const f32x4s*>(xb + (i >> 3) * kPadBlk + (i & 7) * 4);
+        acc[(i & 1) * 2 + 0] = fma2(f32x2{w0[i][0], w0[i][1]}, f32x2{xv[0], xv[1]}, acc[(i & 1) * 2 + 0]);
+        acc[(i & 1) * 2 + 1] = fma2(f32x2{w0[i][2], w0[i][3]}, f32x2{xv[2], xv[3]}, acc[(i & 1) * 2 + 1]);
+      }
+      const float t = dpp_quad_sum(((acc[0][0] + acc[0][1]) + (acc[1][0] + acc[1][1])) + ((acc[2][0] + acc[2][1]) + (acc[3][0] + acc[3][1])));
+      if (ks == 0) S.bias[h][s2 & 1][c2][j] = t + (cnd + bz);
+      lds_signal(&S.ready[h], (unsigned)v2 + 1, lane);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------------
+// head stage: workgroup p serves the clips c = p (mod 8): last skip product, Mish, second Linear, [temperature], argmax / draw,
+// and the next step's embedded sample as the message for stage 0
+// ------------------------------------------------------------------------------------------------------------------------------------
+__device__ void head_role(const WnSpipeArgs& a, int p) {
+  __shared__ __attribute__((aligned(16))) float ys[kC], hin[kH1], hid[kH1], lg[kQ + 4];
+  __shared__ int s_fail;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int o = tid >> 2, kq = tid & 3;
+  float w0[64], w2[64], wt[2] = {0.f, 0.f}, bt = 0.f;
+#pragma unroll
+  for (int k = 0; k < 64; ++k) w0[k] = a.head_w0[(int64_t)o * kC + 64 * kq + k];
+  const float b0 = a.head_b0[o];
+#pragma unroll
+  for (int k = 0; k < 64; ++k) w2[k] = a.fc2_w[(int64_t)(tid >> 1) * kH1 + 64 * (tid & 1) + k];
+  const float b2 = a.fc2_b[tid >> 1];
+  if (a.learn_temp) {
+    wt[0] = a.fc2_w[(int64_t)kQ * kH1 + lane];
+    wt[1] = a.fc2_w[(int64_t)kQ * kH1 + 64 + lane];
+    bt = a.fc2_b[kQ];
+  }
+  if (tid == 0) s_fail = 0;
+  const int L = a.L;
+  const int64_t stage_words = (int64_t)a.Bmax * kSpSlots * kMsgFloats;
+  const unsigned* msg_in = a.msg + (int64_t)L * stage_words;
+  unsigned* msg_out = a.msg;                                               // stage 0's inbox (another XCD: written through)
+  const unsigned* hid_in = a.hidmsg + (int64_t)L * (int64_t)a.Bmax * kSpSlots * kH1;
+  // wave 0: the embedded class as stage 0's message of step s1 (x = E[class], y = 0), in the producers' layout (per 8 channels: 8 x | 8 y)
+  auto publish_class = [&](int c, int s1, int cls) {
+    cls = cls < 0 ? 0 : (cls >= kQ ? kQ - 1 : cls);
+    const f32x4s e = *reinterpret_cast<const f32x4s*>(a.emb + (int64_t)cls * kC + 4 * lane);
+    const int off = (lane >> 1) * 16 + (lane & 1) * 4;
+    u64* dx = reinterpret_cast<u64*>(msg_out + ((int64_t)c * kSpSlots + (s1 & 3)) * kMsgFloats + off);
+    u64* dp = reinterpret_cast<u64*>(msg_out + ((int64_t)c * kSpSlots + ((s1 + 2) & 3)) * kMsgFloats + off);
+    __hip_atomic_store(dx + 0, ((u64)__float_as_uint(e[1]) << 32) | __float_as_uint(e[0]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(dx + 1, ((u64)__float_as_uint(e[3]) << 32) | __float_as_uint(e[2]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(dx + 4, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(dx + 5, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const u64 pp = ((u64)kSpPoison << 32) | kSpPoison;
+    __hip_atomic_store(dp + 0, pp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(dp + 1, pp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(dp + 4, pp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(dp + 5, pp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  };
+  if (wave == 0)
+    for (int c = p; c < a.B; c += kCuPerStage) publish_class(c, 0, (int)a.idx[(int64_t)c * a.idx_rs + a.t0 - 1]);
+  __syncthreads();
+  for (int s = 0; s < (int)a.n_steps; ++s) {
+    const int64_t tau = a.t0 - 1 + s;
+    const int slot = s & 3;
+    for (int c = p; c < a.B; c += kCuPerStage) {
+      if (wave == 0) {             // y of the last layer: channels 4 lane .. + 3
+        const unsigned* src = msg_in + ((int64_t)c * kSpSlots + slot) * kMsgFloats + (lane >> 1) * 16 + 8 + (lane & 1) * 4;
+        u32x4s w4;
+        unsigned spins = 0;
+        for (;;) {
+          asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(w4) : "v"(src) : "memory");
+          const bool ok = w4[0] != kSpPoison && w4[1] != kSpPoison && w4[2] != kSpPoison && w4[3] != kSpPoison;
+          if (__all(ok)) break;
+          if (++spins > kSpinLimit || ((spins & 1023u) == 0 && __hip_atomic_load(a.err_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+            atomicExch(a.err_flag, 1);
+            s_fail = 1;
+            break;
+          }
+        }
+        *reinterpret_cast<f32x4s*>(ys + 4 * lane) = f32x4s{__uint_as_float(w4[0]), __uint_as_float(w4[1]), __uint_as_float(w4[2]), __uint_as_float(w4[3])};
+      } else if (wave == 1) {      // the hidden pre-activations the layer stages have accumulated (layers 0 .. L - 2)
+        f32x2 hv = f32x2{0.f, 0.f};
+        if (L >= 2) {
+          const unsigned* src = hid_in + ((int64_t)c * kSpSlots + slot) * kH1 + 2 * lane;
+          u32x2 w2v;
+          unsigned spins = 0;
+          for (;;) {
+            asm volatile("global_load_dwordx2 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(w2v) : "v"(src) : "memory");
+            if (__all(w2v[0] != kSpPoison && w2v[1] != kSpPoison)) break;
+            if (++spins > kSpinLimit || ((spins & 1023u) == 0 && __hip_atomic_load(a.err_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+              atomicExch(a.err_flag, 1);
+              s_fail = 1;
+              break;
+            }
+          }
+          hv = f32x2{__uint_as_float(w2v[0]), __uint_as_float(w2v[1])};
+        }
+        *reinterpret_cast<f32x2*>(hin + 2 * lane) = hv;
+      }
+      __syncthreads();
+      if (s_fail) return;
+      float h4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int k = 0; k < 64; ++k) h4[k & 3] = fmaf(w0[k], ys[64 * kq + k], h4[k & 3]);
+      const float hsum = dpp_quad_sum((h4[0] + h4[1]) + (h4[2] + h4[3]));
+      if (kq == 0) hid[o] = mish_fast(hin[o] + (hsum + b0));
+      __syncthreads();
+      float q4[4] = {0.f, 0.f, 0.f, 0.f};
+      const float* hs = hid + (tid & 1) * 64;
+#pragma unroll
+      for (int k = 0; k < 64; ++k) q4[k & 3] = fmaf(w2[k], hs[k], q4[k & 3]);
+      float qv = (q4[0] + q4[1]) + (q4[2] + q4[3]);
+      qv += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(qv), 0xB1, 0xf, 0xf, false));
+      if ((tid & 1) == 0) lg[tid >> 1] = qv + b2;
+      if (wave == 0 && a.learn_temp) {
+        float tv = fmaf(wt[0], hid[lane], wt[1] * hid[64 + lane]);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) tv += __shfl_xor(tv, off);
+        if (lane == 0) lg[kQ] = tv + bt;
+      }
+      __syncthreads();
+      if (wave == 0) {
+        float denom = 1.f;
+        if (a.learn_temp) denom = fmaxf(sigmoidf_(lg[kQ]), a.min_temp);       // mlp.py:60-62
+        if (a.logits_out && s + 1 == (int)a.n_steps)
+          for (int k = lane; k < kQ + (a.learn_temp ? 1 : 0); k += 64) a.logits_out[(int64_t)c * a.logits_ld + k] = lg[k];
+        int result;
+        if (a.temperature == nullptr) {
+          const f32x4s v4 = *reinterpret_cast<const f32x4s*>(lg + lane * 4);
+          float vv[4];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) vv[k] = a.learn_temp ? v4[k] / denom : v4[k];
+          float best = vv[0];
+          int bi = lane * 4;
+#pragma unroll
+          for (int k = 1; k < 4; ++k)
+            if (vv[k] > best) { best = vv[k]; bi = lane * 4 + k; }
+          result = wave_argmax_first(best, bi);
+        } else {
+          result = sample_256(lg, a.learn_temp != 0, denom, a.temperature[c], a.uniforms[(int64_t)c * a.uni_ld + s], lane);
+        }
+        if (s + 1 < (int)a.n_steps) publish_class(c, s + 1, result);
+        if (lane == 0) a.idx[(int64_t)c * a.idx_rs + tau + 1] = result;
+      }
+      __syncthreads();
+    }
+  }
+}
+
+template <bool STAMPS>
+__global__ __launch_bounds__(kThreads) void wavenet_spipe_kernel(const WnSpipeArgs a) {
+  __shared__ __attribute__((aligned(16))) Lds S;
+  __shared__ int s_role;
+  const int tid = threadIdx.x;
+  // Roles come from where the workgroup RUNS: XCD x hosts stages 4 x .. 4 x + 3, eight workgroups each, in arrival order.  A launch
+  // that does not put 32 workgroups on every XCD reports error 2 (the caller falls back to the launch path).
+  if (tid == 0) {
+    unsigned id;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(id));
+    id &= 0xf;
+    const unsigned ticket = atomicAdd(a.xcd_count + (id & 7), 1u);
+    int role = -1;
+    if (id >= 8 || ticket >= 32) atomicExch(a.err_flag, 2);
+    else role = (int)(id * 32 + ticket);
+    s_role = role;
+  }
+  if (tid < 16) (&S.arrived[0])[tid] = 0;       // arrived, hdone, xd_arrived, ready are adjacent
+  __syncthreads();
+  const int role = s_role;
+  if (role < 0) return;
+  const int stage = role >> 3, p = role & 7;
+  if (stage > a.L) return;
+  if (stage == a.L) {
+    head_role(a, p);
+    return;
+  }
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  if (wave < 4) {
+    __builtin_amdgcn_s_setprio(3);
+    chain_role<STAMPS>(a, S, stage, p, wave, lane);
+  } else {
+    helper_role<STAMPS>(a, S, stage, p, wave - 4, lane);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------------
+// commit: the per-lane register images.  One thread per float4; composed entries (W1 R, fc0 W_skip) are fp64 dot products of length C.
+// ------------------------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int gate_raw_row(int W, int j) { return (j & 1) ? kC + 8 * W + (j >> 1) : 8 * W + (j >> 1); }
+
+__device__ double dot_cols(const float* arow, int64_t a_stride, const float* bcol, int64_t b_stride, int n) {
+  double acc = 0.0;
+  for (int c = 0; c < n; ++c) acc += (double)arow[c * a_stride] * (double)bcol[c * b_stride];
+  return acc;
+}
+
+__global__ __launch_bounds__(256) void spipe_image_kernel(const WnSpRaw* __restrict__ raw, int L, const float* __restrict__ f0, const float* __restrict__ fb0,
+                                                          float* __restrict__ img_chain, float* __restrict__ img_helper, float* __restrict__ cst_chain,
+                                                          float* __restrict__ cst_helper, float* __restrict__ head_w0, float* __restrict__ head_b0) {
+  const int64_t n_chain = (int64_t)L * kWavesPerStage * 40 * 64, n_helper = (int64_t)L * kWavesPerStage * 20 * 64;
+  const int64_t n_cst = (int64_t)L * kWavesPerStage * 64, n_hw = (int64_t)kH1 * kC / 4, n_hb = kH1;
+  const int64_t total = n_chain + n_helper + 2 * n_cst + n_hw + n_hb;
+  for (int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; id < total; id += (int64_t)gridDim.x * blockDim.x) {
+    if (id < n_chain) {
+      const int lane = (int)(id & 63), qi = (int)((id >> 6) % 40), W = (int)((id / (40 * 64)) % kWavesPerStage), s = (int)(id / (40 * 64 * kWavesPerStage));
+      const WnSpRaw r = raw[s];
+      float out[4] = {0.f, 0.f, 0.f, 0.f};
+      if (qi < 32) {
+        const int j = lane >> 2, ks = lane & 3, n = gate_raw_row(W, j);
+        for (int e = 0; e < 4; ++e) {
+          const int k = 128 * (ks & 1) + 4 * qi + e;
+          if (ks < 2) out[e] = r.wd[((int64_t)n * kC + k) * 2 + 1];                                                        // W1[n][k]
+          else if (s >= 1 && raw[s - 1].wr) out[e] = (float)dot_cols(r.wd + (int64_t)n * kC * 2 + 1, 2, raw[s - 1].wr + k, kC, kC);   // (W1 R)[n][k]
+        }
+      } else if (s >= 1 && raw[s - 1].wr) {
+        const int j8 = lane >> 3, ks8 = lane & 7, i = qi - 32;
+        for (int e = 0; e < 4; ++e) out[e] = raw[s - 1].wr[(int64_t)(8 * W + j8) * kC + 32 * ks8 + 4 * i + e];
+      }
+      reinterpret_cast<f32x4s*>(img_chain)[id] = f32x4s{out[0], out[1], out[2], out[3]};
+    } else if (id < n_chain + n_helper) {
+      const int64_t t = id - n_chain;
+      const int lane = (int)(t & 63), qi = (int)((t >> 6) % 20), W = (int)((t / (20 * 64)) % kWavesPerStage), s = (int)(t / (20 * 64 * kWavesPerStage));
+      const WnSpRaw r = raw[s];
+      float out[4] = {0.f, 0.f, 0.f, 0.f};
+      if (qi < 16) {
+        const int j = lane >> 2, ks = lane & 3, n = gate_raw_row(W, j);
+        for (int e = 0; e < 4; ++e) out[e] = r.wd[((int64_t)n * kC + 64 * ks + 4 * qi + e) * 2 + 0];                       // W0[n][k]
+      } else if (s >= 1) {
+        const int j4 = lane >> 4, ks16 = lane & 15, i = qi - 16, hrow = 4 * W + j4;
+        for (int e = 0; e < 4; ++e) out[e] = (float)dot_cols(f0 + (int64_t)hrow * kC, 1, raw[s - 1].ws + 16 * ks16 + 4 * i + e, kC, kC);   // (fc0 W_skip)[h][k]
+      }
+      reinterpret_cast<f32x4s*>(img_helper)[t] = f32x4s{out[0], out[1], out[2], out[3]};
+    } else if (id < n_chain + n_helper + n_cst) {
+      const int64_t t = id - n_chain - n_helper;
+      const int lane = (int)(t & 63), W = (int)((t >> 6) % kWavesPerStage), s = (int)(t / (64 * kWavesPerStage));
+      float bx = 0.f;
+      if (s >= 1 && raw[s - 1].wr && raw[s - 1].br) bx = raw[s - 1].br[8 * W + (lane >> 3)];
+      cst_chain[t] = bx;
+    } else if (id < n_chain + n_helper + 2 * n_cst) {
+      const int64_t t = id - n_chain - n_helper - n_cst;
+      const int lane = (int)(t & 63), W = (int)((t >> 6) % kWavesPerStage), s = (int)(t / (64 * kWavesPerStage));
+      const WnSpRaw r = raw[s];
+      const int n = gate_raw_row(W, lane >> 2);
+      // b_dil + b_1x1, then tap 1 . b_res of the layer below: the order the one-hand-off kernels add them in
+      float bz = (r.bd ? r.bd[n] : 0.f) + (r.b1 ? r.b1[n] : 0.f);
+      if (s >= 1 && raw[s - 1].wr && raw[s - 1].br) bz += (float)dot_cols(r.wd + (int64_t)n * kC * 2 + 1, 2, raw[s - 1].br, 1, kC);
+      cst_helper[t] = bz;
+    } else if (id < n_chain + n_helper + 2 * n_cst + n_hw) {
+      const int64_t t = id - n_chain - n_helper - 2 * n_cst;
+      const int hrow = (int)(t / (kC / 4)), k0 = (int)(t % (kC / 4)) * 4;
+      float out[4];
+      for (int e = 0; e < 4; ++e) out[e] = (float)dot_cols(f0 + (int64_t)hrow * kC, 1, raw[L - 1].ws + k0 + e, kC, kC);
+      reinterpret_cast<f32x4s*>(head_w0)[t] = f32x4s{out[0], out[1], out[2], out[3]};
+    } else {
+      const int hrow = (int)(id - (n_chain + n_helper + 2 * n_cst + n_hw));
+      double acc = fb0 ? (double)fb0[hrow] : 0.0;
+      for (int l = 0; l < L; ++l)
+        if (raw[l].bs) acc += dot_cols(f0 + (int64_t)hrow * kC, 1, raw[l].bs, 1, kC);
+      head_b0[hrow] = (float)acc;
+    }
+  }
+}
+
+}  // namespace
+
+bool wn_spipe_supported(int C, int S, int H1, int n_classes, int L, int n_cond, int batch) {
+  return C == kC && S == kC && H1 == kH1 && n_classes == kQ && n_cond <= 1 && L >= 1 && L <= kSpMaxLayers && batch >= 1 && batch <= 32;
+}
+int64_t wn_spipe_img_chain_floats(int L, int C) { return (int64_t)L * (C / 8) * 40 * 64 * 4; }
+int64_t wn_spipe_img_helper_floats(int L, int C) { return (int64_t)L * (C / 8) * 20 * 64 * 4; }
+int64_t wn_spipe_cst_floats(int L, int C) { return (int64_t)L * (C / 8) * 64; }
+int64_t wn_spipe_msg_words(int L, int C, int Bmax) { return (int64_t)(L + 1) * Bmax * kSpSlots * 2 * C; }
+int64_t wn_spipe_hidmsg_words(int L, int Bmax) { return (int64_t)(L + 1) * Bmax * kSpSlots * kH1; }
+
+int wn_spipe_build_image(const WnSpRaw* raw_dev, int L, int C, const float* f0, const float* fb0, float* img_chain, float* img_helper,
+                         float* cst_chain, float* cst_helper, float* head_w0, float* head_b0, hipStream_t stream) {
+  if (C != kC || L < 1 || L > kSpMaxLayers) return fail(MMK_ERR_UNSUPPORTED, "wavenet stage pipeline: C = %d, L = %d", C, L);
+  hipLaunchKernelGGL(spipe_image_kernel, dim3(2048), dim3(256), 0, stream, raw_dev, L, f0, fb0, img_chain, img_helper, cst_chain, cst_helper, head_w0,
+                     head_b0);
+  MMK_HIP(hipGetLastError());
+  return MMK_OK;
+}
+
+int launch_wavenet_spipe(const WnSpipeArgs& a, hipStream_t stream) {
+  if (a.n_steps <= 0 || a.B <= 0) return MMK_OK;
+  if (a.B > 32 || a.L > kSpMaxLayers || a.C != kC) return fail(MMK_ERR_UNSUPPORTED, "wavenet stage pipeline: %d clips, %d layers, %d channels", a.B, a.L, a.C);
+  if (a.stamps) hipLaunchKernelGGL(wavenet_spipe_kernel<true>, dim3(256), dim3(kThreads), 0, stream, a);
+  else hipLaunchKernelGGL(wavenet_spipe_kernel<false>, dim3(256), dim3(kThreads), 0, stream, a);
+  MMK_HIP(hipGetLastError());
+  return MMK_OK;
+}
+
+}  // namespace mmk

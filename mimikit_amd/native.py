@@ -475,6 +475,11 @@ class WaveNetPlan(_Plan):
         """persistent mode with four workgroups per clip that own whole layers (csrc/wavenet_lpipe.hip)"""
         return self._lib.mmk_wavenet_mode(self.handle) == 4
 
+    @property
+    def stage_pipelined(self) -> bool:
+        """persistent mode with one layer per stage of 8 CUs and the clips streamed through one at a time (csrc/wavenet_spipe.hip)"""
+        return self._lib.mmk_wavenet_mode(self.handle) == 5
+
     def sync_status(self):
         """wait for the stream and raise if a hand-off inside the persistent kernel timed out"""
         check(self._lib.mmk_wavenet_sync_status(self.handle, stream_ptr(self.device)), "mmk_wavenet_sync_status")

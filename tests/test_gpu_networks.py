@@ -1130,6 +1130,80 @@ def test_wavenet_pipelined_kernel_shapes(device, monkeypatch, blocks, C, B, n):
     assert n_ok > 0.9 * len(steps) * B
 
 
+def _wide_net(blocks, seed, cond):
+    """the geometry family of BASELINE config 4: 256 channels, kernel 2, gated, skips 256, embedding in, MLP head 128 -> 256 (+ temperature),
+    optionally one conditioning input (12 -> 16 channels)"""
+    from oracle.weights import load_recipe
+    io = H.mu_emb(mlp_dim=128)
+    kw = {}
+    if cond:
+        ext = mmk.Extractor("signal", mmk.FileToSignal(16000))
+        io = mmk.IOSpec(inputs=(io.inputs[0], mmk.InputSpec("signal", mmk.MagSpec(22, 4, center=False), mmk.LinearIO()).bind_to(ext)),
+                        targets=io.targets)
+        kw["dims_1x1"] = (16,)
+    net = mmk.WaveNet.from_config(mmk.WaveNet.Config(io_spec=io, blocks=blocks, dims_dilated=(256,), residuals_dim=256, skips_dim=256, **kw)).eval()
+    sd = load_recipe(net, seed=seed, gain=2.0)
+    dil = [2 ** i for b in blocks for i in range(b)]
+    arch = dict(kernels=[2] * len(dil), dilations=dil, has_skips=True, residuals=True)
+    return net, sd, arch
+
+
+SPIPE_ENV = ("MMK_WN_XCD_LOCAL", "MMK_WN_PERSISTENT", "MMK_WN_GROUPS", "MMK_WN_SMALL", "MMK_WN_PREFILL", "MMK_WN_CHAIN", "MMK_WN_PIPE", "MMK_WN_LPIPE",
+             "MMK_WN_SPIPE")
+
+
+@pytest.mark.parametrize("blocks,B,cond,n", [((3,), 1, False, 40), ((4, 2), 5, True, 60), ((1,), 3, True, 24), ((2, 1, 1), 32, True, 30),
+                                             ((10, 10, 10, 1), 3, False, 6), ((5, 3), 17, True, 1100)])
+def test_wavenet_stage_pipeline_agrees_with_oracle(device, monkeypatch, blocks, B, cond, n):
+    """the stage pipeline (wavenet_spipe.hip: one layer per stage of 8 CUs, clips streamed through one at a time) against the oracle,
+    teacher-forced on the device's own history: 1 - 31 layers (1 - 8 XCDs in use, layers with d = 1 first, in the middle and last),
+    1 - 32 clips, with and without conditioning, more steps than one conditioning block (two launches chained through the rings);
+    greedy, then sampled with the uniforms generate_block draws; the same generation twice is bit-identical"""
+    for k in SPIPE_ENV:
+        monkeypatch.delenv(k, raising=False)
+    net, sd, arch = _wide_net(blocks, 300 + len(blocks) + B, cond)
+    net = net.to(device)
+    gen = torch.Generator().manual_seed(B + n)
+    rf = net.rf
+    P = rf + 3
+    prompt = torch.randint(0, 256, (B, P), generator=gen)
+    conds = (torch.rand(B, P + n, 12, generator=gen),) if cond else ()
+    conds_d = tuple(c.to(device) for c in conds)
+
+    def run(**kw):
+        idx = torch.cat([prompt, torch.zeros(B, n, dtype=torch.int64)], 1).to(device)
+        net.generate_block((idx, *conds_d), P, n, **kw)
+        net.after_generate((idx,), None)
+        return idx.cpu()
+
+    got = run()
+    assert net._plan.stage_pipelined
+    last = net._plan.last_logits(B).cpu()
+    assert torch.equal(got, run())
+    steps = list(range(n)) if n <= 60 else list(range(0, 4)) + list(range(1020, 1030)) + list(range(n - 4, n))
+    n_ok = 0
+    for s_ in steps:
+        t = P + s_
+        raw = O.wavenet_window_forward(sd, (got[:, t - rf:t], *[c[:, t - rf:t] for c in conds]), n_cond=len(conds), **arch)
+        pick = O.categorical(O.mlp_logits(raw))[:, 0]
+        gap_ok = H.margin_ok(raw.numpy())[:, 0]
+        assert bool(((pick == got[:, t]) | ~gap_ok).all()), f"step {s_}"
+        n_ok += int(gap_ok.sum())
+        if s_ == n - 1:
+            assert torch.allclose(last[gap_ok], raw[:, 0][gap_ok], **LOGIT_TOL)
+    assert n_ok >= 0.98 * len(steps) * B
+    if n > 60 or sum(blocks) > 12:
+        return
+    temp = torch.linspace(0.6, 1.4, B)
+    torch.manual_seed(5)
+    u = torch.rand((B, n), device=device)
+    torch.manual_seed(5)
+    got2 = run(temperature=temp)
+    _, raw2 = O.wavenet_generate(sd, prompt, conds, n, keep_logits=True, forced=got2, **arch)
+    okp, exact = H.sampled_picks_ok(raw2, temp, u.cpu(), got2[:, P:])
+    assert bool(okp.all()) and float(exact.float().mean()) > 0.97
+
+
 @pytest.mark.parametrize("tag", list(H.WAVENET_OPTIONS))
 def test_wavenet_options_match_reference_golden(device, tag):
     """the remaining WaveNet options on the HIP path against the reference's loop: deeper MLP heads (one hidden block repeated),
