@@ -152,8 +152,9 @@ struct mmk_wavenet_plan {
     }
     h_rings = spipe ? nullptr : c.take<float>((int64_t)(pipe ? 8 : Gc) * Gn * ring_floats_per_wg);
     cproj = C1 > 0 ? c.take<float>((int64_t)Bmax * kCondBlock * C1) : nullptr;
-    condall = C1 > 0 ? c.take<float>((int64_t)Bmax * kCondBlock * L * 2 * C) : nullptr;
-    if (C1 > 0) cond_all.carve(c, false);
+    // (the stage pipeline multiplies the layers' conditioning products itself, from cproj)
+    condall = (C1 > 0 && !spipe) ? c.take<float>((int64_t)Bmax * kCondBlock * L * 2 * C) : nullptr;
+    if (C1 > 0 && !spipe) cond_all.carve(c, false);
     if (pipe)
       for (auto& pl : Bh) pl.carve(c, true);
     if (chain || pipe) {
@@ -191,7 +192,7 @@ struct mmk_wavenet_plan {
     hid[1] = c.take<float>((int64_t)Bmax * hmax);
     logits_ld = (int)round_up(cfg.out_dim + (cfg.learn_temp ? 1 : 0), 4);
     logits = c.take<float>((int64_t)Bmax * logits_ld);
-    tau = c.take<int64_t>(32);
+    tau = c.take<int64_t>(256);   // [0]: the launch path's position; [8 ..]: stamps of the diagnostic builds
     if (persistent) layout_persistent(c);
   }
 
@@ -409,7 +410,6 @@ static int derive(mmk_wavenet_plan* p) {
       p->ring_offset.assign(p->L, 0);
       p->ring_mask.assign(p->L, 0);
       p->ring_floats_per_wg = 0;
-      if (p->C1 > 0) p->cond_all.set_geometry(p->L * 2 * p->C, {p->C1});
     }
   }
   // one hand-off per layer: every layer but the last needs its residual 1x1 (it is folded into the next layer's tap-1
@@ -615,7 +615,7 @@ extern "C" int mmk_wavenet_commit(mmk_wavenet_plan* p, void* workspace, size_t w
         if (c.gated) {
           MMK_TRY(pack_rect(A.Wp, A.k_chunks, 0, 2, C, A.seg_chunk0[k + j], cd, w1, cd, 1, st));
           MMK_TRY(pack_rect(A.Wp, A.k_chunks, 1, 2, C, A.seg_chunk0[k + j], cd, w1 + (int64_t)C * cd, cd, 1, st));
-          if (p->persistent && p->C1 > 0) {   // same gate-interleaved rows, all layers stacked (bias stays in A.bias)
+          if (p->persistent && p->C1 > 0 && !p->spipe) {   // same gate-interleaved rows, all layers stacked (bias stays in A.bias)
             MMK_TRY(pack_rect(p->cond_all.Wp, p->cond_all.k_chunks, l * 2 * C, 2, C, 0, cd, w1, cd, 1, st));
             MMK_TRY(pack_rect(p->cond_all.Wp, p->cond_all.k_chunks, l * 2 * C + 1, 2, C, 0, cd, w1 + (int64_t)C * cd, cd, 1, st));
           }
@@ -725,6 +725,7 @@ extern "C" int mmk_wavenet_commit(mmk_wavenet_plan* p, void* workspace, size_t w
       WnSpRaw& r = raw[l];
       r.wd = b.need(ly + "conv_dil.0.0.weight", (int64_t)2 * C * C * 2);
       r.bd = bias ? b.need(ly + "conv_dil.0.0.bias", 2 * C) : nullptr;
+      r.w1 = p->n_cond == 1 ? b.need(ly + "conv_1x1.0.0.weight", (int64_t)2 * C * p->C1) : nullptr;
       r.b1 = (bias && p->n_cond == 1) ? b.need(ly + "conv_1x1.0.0.bias", 2 * C) : nullptr;
       r.wr = p->has_res[l] ? b.need(ly + "conv_res.weight", (int64_t)C * C) : nullptr;
       r.br = (bias && p->has_res[l]) ? b.need(ly + "conv_res.bias", C) : nullptr;
@@ -738,7 +739,7 @@ extern "C" int mmk_wavenet_commit(mmk_wavenet_plan* p, void* workspace, size_t w
     p->sp_fc2_b = b.need("output_modules.0.estimator.0.fc.2.bias", c.out_dim + (c.learn_temp ? 1 : 0));
     if (b.missing().empty()) {
       MMK_HIP(hipMemcpyAsync(p->sp_raw, raw.data(), sizeof(WnSpRaw) * L, hipMemcpyHostToDevice, st));
-      MMK_TRY(wn_spipe_build_image(p->sp_raw, L, C, f0, fb0, p->sp_img_chain, p->sp_img_helper, p->sp_cst_chain, p->sp_cst_helper, p->sp_head_w0,
+      MMK_TRY(wn_spipe_build_image(p->sp_raw, L, C, p->C1, f0, fb0, p->sp_img_chain, p->sp_img_helper, p->sp_cst_chain, p->sp_cst_helper, p->sp_head_w0,
                                    p->sp_head_b0, st));
       MMK_HIP(hipStreamSynchronize(st));   // `raw` is host-local
     }
@@ -957,7 +958,7 @@ static int run_persistent(mmk_wavenet_plan* p, const WnCall& call, int64_t tau0,
       }
       // every layer's conv_1x1(c) for the same positions (wavenet_v2.py:140-150): off the per-sample chain; one
       // GEMM over all clips (M = positions, N = L x 2C, K = C1)
-      MMK_TRY(launch_gemm_f32(p->cproj, p->C1, (int64_t)p->kCondBlock * p->C1, p->cond_all.Wp, p->cond_all.n_tiles,
+      if (!p->spipe) MMK_TRY(launch_gemm_f32(p->cproj, p->C1, (int64_t)p->kCondBlock * p->C1, p->cond_all.Wp, p->cond_all.n_tiles,
                               p->cond_all.k_chunks, p->cond_all.N, p->C1, p->condall, (int64_t)p->L * 2 * p->C,
                               (int64_t)p->kCondBlock * p->L * 2 * p->C, (int)nb, call.M, st));
     }
@@ -1003,7 +1004,7 @@ static int run_persistent(mmk_wavenet_plan* p, const WnCall& call, int64_t tau0,
       k.head_w0 = p->sp_head_w0; k.head_b0 = p->sp_head_b0; k.fc2_w = p->sp_fc2_w; k.fc2_b = p->sp_fc2_b;
       for (int l = 0; l < p->L; ++l) { k.hist[l] = p->hist[l]; k.ring[l] = p->ring[l]; k.dil[l] = p->dil[l]; }
       k.emb = p->emb; k.idx = (int64_t*)call.in0; k.idx_rs = call.in0_rs;
-      k.condall = p->condall; k.cond_steps = p->kCondBlock;
+      k.cproj = p->cproj; k.cond_steps = p->kCondBlock;
       k.temperature = call.temperature;
       k.uniforms = call.uniforms ? call.uniforms + done : nullptr;
       k.uni_ld = call.uni_ld;
@@ -1011,6 +1012,7 @@ static int run_persistent(mmk_wavenet_plan* p, const WnCall& call, int64_t tau0,
       k.msg = p->sp_msg; k.hidmsg = p->sp_hidmsg; k.xcd_count = p->xcd_count; k.err_flag = p->err_flag;
       k.stamps = (stamp_env && stamp_env[0] == '1') ? reinterpret_cast<unsigned long long*>(p->tau + 8) : nullptr;
       k.stamp_stage = getenv("MMK_WN_STAMP_STAGE") ? atoi(getenv("MMK_WN_STAMP_STAGE")) : 1;
+      k.dbg = (k.stamps && getenv("MMK_WN_SPIPE_DBG")) ? atoi(getenv("MMK_WN_SPIPE_DBG")) : 0;
       MMK_TRY(launch_wavenet_spipe(k, st));
       done += nb;
       continue;
@@ -1328,12 +1330,21 @@ extern "C" int mmk_wavenet_sync_status(mmk_wavenet_plan* p, mmk_stream_t stream)
   {
     const char* senv = getenv("MMK_WN_STAMPS");
     if (senv && senv[0] == '1') {
-      unsigned long long st[24];
-      MMK_HIP(hipMemcpy(st, p->tau + 8, sizeof(st), hipMemcpyDeviceToHost));
+      unsigned long long st[176];
+      MMK_HIP(hipMemcpy(st, p->tau + 8, p->spipe ? sizeof(st) : 24 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
       if (p->spipe) {
         fprintf(stderr, "[mmk stamps] last stage-pipeline launch, chain wave 0 of CU 0 of stage MMK_WN_STAMP_STAGE (default 1), shader cycles per visit: "
                         "wait for the message=%.0f; products + gate + publish=%.0f; poison + ring store=%.0f; visits=%llu\n",
                 st[3] ? (double)st[0] / (double)st[3] : 0.0, st[3] ? (double)st[1] / (double)st[3] : 0.0, st[3] ? (double)st[2] / (double)st[3] : 0.0, st[3]);
+        fprintf(stderr, "[mmk stamps] extra looks per visit=%.2f; clip 0, last step, publish time of stage s minus stage s - 1 in 10 ns ticks:",
+                st[3] ? (double)st[4] / (double)st[3] : 0.0);
+        for (int l = 1; l < p->L; ++l) fprintf(stderr, " %lld", (long long)(st[16 + l] - st[16 + l - 1]));
+        fprintf(stderr, "\n[mmk stamps] per stage [publish of the stage below -> my quarter seen | -> all quarters + flags | -> my publish]:");
+        for (int l = 1; l < p->L; ++l)
+          fprintf(stderr, " %d:[%lld %lld %lld]", l, (long long)(st[64 + l] - st[16 + l - 1]), (long long)(st[112 + l] - st[64 + l]), (long long)(st[16 + l] - st[112 + l]));
+        fprintf(stderr, " | head: last layer -> class of the step before the last: n/a; step before last's class -> last step's stage 0 publish=%lld; "
+                        "last stage publish -> head done=%lld\n",
+                (long long)(st[16] - st[16 + p->L + 1]), (long long)(st[16 + p->L + 2] - st[16 + p->L - 1]));
         return MMK_OK;
       }
       if (p->pipe) {

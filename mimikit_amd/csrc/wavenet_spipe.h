@@ -13,7 +13,8 @@ constexpr unsigned kSpPoison = 0xFFFFFFFFu;   // a NaN no layer produces: "this 
 struct WnSpRaw {
   const float* wd;      // conv_dil weight (2C, C, 2): rows [f ; g], tap 0 = delayed sample
   const float* bd;      // (2C)
-  const float* b1;      // conv_1x1 bias (2C) of the conditioning input, or null
+  const float* w1;      // conv_1x1 weight (2C, C1) of the conditioning input, or null
+  const float* b1;      // its bias (2C), or null
   const float* wr;      // conv_res weight (C, C) or null (layer without residual)
   const float* br;      // (C)
   const float* ws;      // conv_skip weight (C, C)
@@ -28,7 +29,7 @@ struct WnSpipeArgs {
   int64_t t0, n_steps;                // positions t0 .. t0 + n_steps - 1 are produced
   // per-stage register images (built at commit by wn_spipe_build_image)
   const float* img_chain;             // [L][C / 8 waves][40][64][4]
-  const float* img_helper;            // [L][C / 8 waves][20][64][4]
+  const float* img_helper;            // [L][C / 8 waves][36][64][4]
   const float* cst_chain;             // [L][C / 8][64]   residual bias of the layer below
   const float* cst_helper;            // [L][C / 8][64]   gate bias (dilated + conditioning conv + tap 1 . b_res below)
   const float* head_w0;               // (128, C): fc0 . W_skip of the LAST layer, row-major
@@ -41,7 +42,7 @@ struct WnSpipeArgs {
   int32_t dil[kSpMaxLayers];
   const float* emb;                   // (256, C)
   int64_t* idx; int64_t idx_rs;
-  const float* condall; int64_t cond_steps;   // (Bmax, cond_steps, L, 2C): every layer's conditioning product, rows (f, g) interleaved
+  const float* cproj; int64_t cond_steps;     // (Bmax, cond_steps, C1): the conditioning input after its LinearIO, for the block's positions
   const float* temperature; const float* uniforms; int64_t uni_ld;
   float* logits_out; int64_t logits_ld;
   // exchange state: every word 0xFFFFFFFF before every launch
@@ -51,6 +52,7 @@ struct WnSpipeArgs {
   int32_t* err_flag;
   unsigned long long* stamps;         // diagnostic build only
   int32_t stamp_stage;
+  int32_t dbg;                        // diagnostic build, timing experiments (results wrong): 1 no conditioning reads, 2 delayed rows from L2
 };
 
 bool wn_spipe_supported(int C, int S, int H1, int n_classes, int L, int n_cond, int batch);
@@ -59,8 +61,8 @@ int64_t wn_spipe_img_helper_floats(int L, int C);
 int64_t wn_spipe_cst_floats(int L, int C);
 int64_t wn_spipe_msg_words(int L, int C, int Bmax);
 int64_t wn_spipe_hidmsg_words(int L, int Bmax);
-// commit: raw (host array of L entries), f0 = the head's first Linear (128, C) and its bias
-int wn_spipe_build_image(const WnSpRaw* raw_dev, int L, int C, const float* f0, const float* fb0, float* img_chain, float* img_helper,
+// commit: raw (device array of L entries), C1 = conditioning channels (0: none, <= C), f0 = the head's first Linear (128, C) and its bias
+int wn_spipe_build_image(const WnSpRaw* raw_dev, int L, int C, int C1, const float* f0, const float* fb0, float* img_chain, float* img_helper,
                          float* cst_chain, float* cst_helper, float* head_w0, float* head_b0, hipStream_t stream);
 int launch_wavenet_spipe(const WnSpipeArgs& a, hipStream_t stream);
 

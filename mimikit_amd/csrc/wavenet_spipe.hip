@@ -45,8 +45,13 @@ constexpr int kWavesPerStage = kC / 8;        // 32 chain waves (and as many hel
 constexpr int kMsgFloats = 2 * kC;            // 512
 constexpr int kPadBlk = 36;                   // 32 channels + 4 floats of padding: the K slices of a broadcast read fall on different banks
 constexpr int kHalf = (kC / 32) * kPadBlk;    // 288 floats: one padded vector of C channels
-constexpr int kXyRing = 4;
+constexpr int kXyRing = 8;
+constexpr int kChainRegs = 40, kHelperRegs = 36;   // float4 registers per lane in the stage images
 constexpr unsigned kSpinLimit = 1u << 22;
+#ifndef MMK_SP_POLL_GAP
+#define MMK_SP_POLL_GAP 2
+#endif
+constexpr int kPollGap = MMK_SP_POLL_GAP;     // s_sleep units (64 cycles) between two looks at a message that has not arrived
 
 __device__ __forceinline__ int pad_of(int ch) { return (ch >> 5) * kPadBlk + (ch & 31); }
 
@@ -62,6 +67,33 @@ __device__ __forceinline__ float dpp_mirror_add(float v) {
   return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xf, 0xf, false));
 }
 
+__device__ __forceinline__ float dpp_mirror(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xf, 0xf, false)); }
+__device__ __forceinline__ float dpp_half_mirror(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xf, 0xf, false)); }
+
+// Four partial sums per lane, 16 lanes (one DPP row) that each hold a different K slice: add them up across the row and leave column c's
+// total in lanes 4 c .. 4 c + 3 of the row (lane l of the wave ends with column l / 4 of the wave's 16).  Fixed order: own + mirror
+// partner, + half-mirror partner, then the quad.  A lane reads 1/4 of the inputs it would need with one column per lane: the LDS, which
+// all four SIMDs share, is what bounds a visit otherwise.
+__device__ __forceinline__ float row_reduce_scatter4(float v0, float v1, float v2, float v3, int ks) {
+  const bool hi = (ks & 8) != 0, q4 = (ks & 4) != 0;
+  float t0 = hi ? v2 : v0, t1 = hi ? v3 : v1;
+  const float u0 = hi ? v0 : v2, u1 = hi ? v1 : v3;
+  t0 += dpp_mirror(u0);
+  t1 += dpp_mirror(u1);
+  float w = q4 ? t1 : t0;
+  const float sd = q4 ? t0 : t1;
+  w += dpp_half_mirror(sd);
+  return dpp_quad_sum(w);
+}
+// two partial sums per lane: lanes 0-7 of the row end with column 0's total, lanes 8-15 with column 1's
+__device__ __forceinline__ float row_reduce_scatter2(float v0, float v1, int ks) {
+  const bool hi = (ks & 8) != 0;
+  float t = hi ? v1 : v0;
+  const float u = hi ? v0 : v1;
+  t += dpp_mirror(u);
+  return dpp_quad_sum(dpp_half_mirror_add(t));
+}
+
 __device__ __forceinline__ f32x2 fma2(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
 
 // LDS counters: written by one lane of one wave, read by all; LDS serves a wave's operations in issue order, so data written before
@@ -72,11 +104,8 @@ __device__ __forceinline__ void lds_signal(unsigned* p, unsigned v, int lane) {
   __atomic_signal_fence(__ATOMIC_SEQ_CST);
 }
 __device__ __forceinline__ unsigned lds_min4(const unsigned* p) {
-  const unsigned a = __hip_atomic_load(p + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-  const unsigned b = __hip_atomic_load(p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-  const unsigned c = __hip_atomic_load(p + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-  const unsigned d = __hip_atomic_load(p + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-  return min(min(a, b), min(c, d));
+  const u32x4s v = *reinterpret_cast<const volatile u32x4s*>(p);     // one 16-byte read (the four counters share an aligned line)
+  return min(min(v[0], v[1]), min(v[2], v[3]));
 }
 // wait until all four counters reach `want`; false after ~1 s (the other waves of the workgroup have failed or the kernel is wedged)
 __device__ __forceinline__ bool lds_wait4(const unsigned* p, unsigned want, int32_t* err) {
@@ -113,28 +142,48 @@ __device__ __forceinline__ unsigned msg_load(const unsigned* p) { return __hip_a
 struct Lds {
   float xy[kXyRing][2 * kHalf];               // the newest messages of this stage: [x padded | y padded]
   float xd[2][kHalf];                         // delayed layer input of the visit whose bias is being prepared
+  float cd[2][kHalf];                         // projected conditioning row of that visit (zeros above C1)
   float bias[4][2][32][16];                   // [chain wave][step parity][clip][gate row]: everything of z that is known a step ahead
-  unsigned arrived[4];                        // per quarter: visits staged into xy
+  unsigned arrived[4];                        // [0]: visits staged into xy by the polling wave
   unsigned hdone[4];                          // per helper: visits whose xy image it no longer needs
   unsigned xd_arrived[4];                     // per quarter: visits staged into xd
   unsigned ready[4];                          // per helper: biases prepared (visit count)
 };
 
 struct Stamps {
-  u64 t_wait = 0, t_compute = 0, t_post = 0, t_bias = 0, visits = 0;
+  u64 t_wait = 0, t_compute = 0, t_post = 0, t_bias = 0, visits = 0, polls = 0;
 };
 
 // ------------------------------------------------------------------------------------------------------------------------------------
 // chain waves (waves 0-3 of a layer stage's workgroup): gate rows 16 W .. 16 W + 15, residual channels 8 W .. 8 W + 7, W = 4 p + q
 // ------------------------------------------------------------------------------------------------------------------------------------
+// the three things a chain wave waits for in LDS before it computes visit v, read together: the message staged by the polling wave,
+// the helpers past the image that visit v + 1 will overwrite, this wave's bias prepared
+__device__ __forceinline__ bool chain_wait(const Lds& S, int q, unsigned v, int32_t* err) {
+  unsigned spins = 0;
+  for (;;) {
+    const unsigned arr = *reinterpret_cast<const volatile unsigned*>(&S.arrived[0]), hd = lds_min4(S.hdone);
+    const unsigned rd = *reinterpret_cast<const volatile unsigned*>(&S.ready[q]);
+    if (arr >= v + 1 && hd + (kXyRing - 2) >= v + 1 && rd >= v + 1) break;
+    if (++spins > kSpinLimit || ((spins & 4095u) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+      atomicExch(err, 1);
+      return false;
+    }
+  }
+  __atomic_signal_fence(__ATOMIC_SEQ_CST);
+  return true;
+}
+
 template <bool STAMPS>
 __device__ void chain_role(const WnSpipeArgs& a, Lds& S, int stage, int p, int q, int lane) {
   const int W = 4 * p + q;
-  const int j = lane >> 2, ks = lane & 3;       // gate row of the wave's 16, K slice of 128 of [x | y]
-  const int j8 = lane >> 3, ks8 = lane & 7;     // residual channel of the wave's 8, K slice of 32 of y
+  // products: a lane holds 4 gate rows x one K slice of 32 of [x | y] (and 2 residual rows x 16 of y); the rows' totals come out of a
+  // reduce-scatter over the DPP row, so that lane l ends with gate row l / 4 and residual channel l / 8 of the wave
+  const int ks = lane & 15;
+  const int j = lane >> 2, j8 = lane >> 3;
   f32x4s wz[32], wr[8];
   {
-    const f32x4s* img = reinterpret_cast<const f32x4s*>(a.img_chain) + ((int64_t)stage * kWavesPerStage + W) * 40 * 64 + lane;
+    const f32x4s* img = reinterpret_cast<const f32x4s*>(a.img_chain) + ((int64_t)stage * kWavesPerStage + W) * kChainRegs * 64 + lane;
 #pragma unroll
     for (int i = 0; i < 32; ++i) wz[i] = img[i * 64];
 #pragma unroll
@@ -146,76 +195,119 @@ __device__ void chain_role(const WnSpipeArgs& a, Lds& S, int stage, int p, int q
   const float gate_k = g_row ? 1.f : 2.f, gate_shift = g_row ? 0.f : -1.f;
   const bool local_next = ((stage + 1) >> 2) == (stage >> 2);
   const int64_t stage_words = (int64_t)a.Bmax * kSpSlots * kMsgFloats;
-  const unsigned* msg_in = a.msg + (int64_t)stage * stage_words;
   unsigned* msg_out = a.msg + (int64_t)(stage + 1) * stage_words;
-  // my quarter of an arriving message: floats 128 q + 2 lane, + 1 = producing wave Ws, 8 x then 8 y of its channels
-  int st_off;
-  {
-    const int f = 128 * q + 2 * lane, Ws = f >> 4, r = f & 15;
-    st_off = (r < 8 ? 0 : kHalf) + pad_of(8 * Ws + (r & 7));
-  }
-  const int kso = (ks < 2 ? 0 : kHalf) + (ks & 1) * 4 * kPadBlk;        // K slice ks: x[0:128], x[128:256], y[0:128], y[128:256]
-  const int xr_off = kHalf + ks8 * kPadBlk;                            // y[32 ks8 ...]
+  // Wave 0 of the workgroup polls for the whole CU: lane l looks at floats 8 l .. 8 l + 7 of the message = 8 x (l even) or 8 y (l odd)
+  // channels of producing wave l / 2, and stages them into the LDS image the other waves read.  One poller per CU: the message
+  // crosses the CU's memory pipe once, and nobody waits for the slowest of several pollers.
+  const bool poller = q == 0;
+  const __amdgpu_buffer_rsrc_t inbox = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned*>(a.msg + (int64_t)stage * stage_words), 0, -1, 0x00020000);
+  const int look_off = 32 * lane;                                       // bytes inside one message
+  const int st_off = ((lane & 1) ? kHalf : 0) + pad_of(8 * (lane >> 1));
+  const int kso = (ks < 8 ? 0 : kHalf) + (ks & 7) * kPadBlk;           // K slice ks: x[32 ks ..] for ks < 8, y[32 (ks - 8) ..] above
+  const int xr_off = kHalf + pad_of(16 * ks);                          // y[16 ks ..]
   const int xin_off = pad_of(8 * W + j8);
   const bool pub_lane = (lane & 7) < 2;
   const int pub_off = W * 16 + (lane & 1) * 8 + (lane >> 3);
   const int ring_mask = a.ring[stage] - 1;
   float* hist = a.hist[stage];
   const int64_t slot_stride = (int64_t)a.Bmax * kC;
-  const int B = a.B;
+  const int B = a.B, n_steps = (int)a.n_steps;
   Stamps st;
   u64 t0c = 0;
   unsigned v = 0;
-  for (int s = 0; s < (int)a.n_steps; ++s) {
+  auto look = [&](int byte_off, u32x4s& lo, u32x4s& hi) {               // 32 bytes per lane past this CU's L1 (sc1), counted by the compiler
+    lo = __builtin_amdgcn_raw_buffer_load_b128(inbox, byte_off, 0, 16);
+    hi = __builtin_amdgcn_raw_buffer_load_b128(inbox, byte_off + 16, 0, 16);
+  };
+  auto landed = [&](const u32x4s& lo, const u32x4s& hi) {
+    const bool ok = lo[0] != kSpPoison && lo[1] != kSpPoison && lo[2] != kSpPoison && lo[3] != kSpPoison && hi[0] != kSpPoison &&
+                    hi[1] != kSpPoison && hi[2] != kSpPoison && hi[3] != kSpPoison;
+    return __all(ok) != 0;
+  };
+  u32x4s pre_lo = u32x4s{0, 0, 0, 0}, pre_hi = u32x4s{0, 0, 0, 0};
+  if (poller) look(look_off, pre_lo, pre_hi);                           // (clip 0, slot 0)
+  for (int s = 0; s < n_steps; ++s) {
     const int64_t tau = a.t0 - 1 + s;
     const int slot = s & 3, pslot = (s + 2) & 3;
     for (int c = 0; c < B; ++c, ++v) {
       if (STAMPS) t0c = __builtin_amdgcn_s_memtime();
-      // the image of visit v - 4 must have been read by the helpers before it is overwritten (they run beside the chain, not behind it)
-      if (v >= (unsigned)kXyRing && !lds_wait4(S.hdone, v - (kXyRing - 1), a.err_flag)) return;
-      // ---- my quarter of the message: two words per lane, until neither is poison -----------------------------------------------------
-      {
-        const unsigned* src = msg_in + ((int64_t)c * kSpSlots + slot) * kMsgFloats + 128 * q + 2 * lane;
-        u32x2 w2;
-        unsigned spins = 0;
-        for (;;) {
-          asm volatile("global_load_dwordx2 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(w2) : "v"(src) : "memory");
-          const bool ok = w2[0] != kSpPoison && w2[1] != kSpPoison;
-          if (__all(ok)) break;
-          if (++spins > kSpinLimit || ((spins & 1023u) == 0 && __hip_atomic_load(a.err_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
-            atomicExch(a.err_flag, 1);
-            return;
+      if (poller) {
+        // ---- the message: until no word is poison (the first look was requested a visit ago) ------------------------------------------
+        const int off = ((c * kSpSlots + slot) * kMsgFloats) * 4 + look_off;
+        u32x4s w_lo = pre_lo, w_hi = pre_hi;
+        if (!landed(w_lo, w_hi)) {
+          // two more looks in flight, a short sleep apart: the message is seen a fraction of a round trip after it lands
+          u32x4s a_lo, a_hi, b_lo, b_hi;
+          look(off, a_lo, a_hi);
+          __builtin_amdgcn_s_sleep(kPollGap);
+          look(off, b_lo, b_hi);
+          unsigned spins = 0;
+          for (;;) {
+            w_lo = a_lo; w_hi = a_hi;
+            if (landed(w_lo, w_hi)) break;
+            if (++spins > kSpinLimit || ((spins & 1023u) == 0 && __hip_atomic_load(a.err_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+              atomicExch(a.err_flag, 1);
+              return;
+            }
+            a_lo = b_lo; a_hi = b_hi;
+            __builtin_amdgcn_s_sleep(kPollGap);
+            look(off, b_lo, b_hi);
           }
+          if (STAMPS) st.polls += spins + 1;
         }
-        *reinterpret_cast<f32x2*>(&S.xy[v & (kXyRing - 1)][st_off]) = f32x2{__uint_as_float(w2[0]), __uint_as_float(w2[1])};
+        float* dst = &S.xy[v & (kXyRing - 1)][st_off];
+        *reinterpret_cast<f32x4s*>(dst) = f32x4s{__uint_as_float(w_lo[0]), __uint_as_float(w_lo[1]), __uint_as_float(w_lo[2]), __uint_as_float(w_lo[3])};
+        *reinterpret_cast<f32x4s*>(dst + 4) = f32x4s{__uint_as_float(w_hi[0]), __uint_as_float(w_hi[1]), __uint_as_float(w_hi[2]), __uint_as_float(w_hi[3])};
+        if (STAMPS && a.stamps && c == 0 && s + 1 == n_steps && p == 0 && lane == 0) a.stamps[64 + stage] = __builtin_amdgcn_s_memrealtime();
+        lds_signal(&S.arrived[0], v + 1, lane);
+        // first look at the NEXT visit's message: in flight while this visit computes
+        int cn = c + 1, sn = s;
+        if (cn == B) { cn = 0; sn = s + 1; }
+        if (sn < n_steps) look(((cn * kSpSlots + (sn & 3)) * kMsgFloats) * 4 + look_off, pre_lo, pre_hi);
       }
-      lds_signal(&S.arrived[q], v + 1, lane);
-      if (!lds_wait4(S.arrived, v + 1, a.err_flag)) return;
-      if (STAMPS) { const u64 t = __builtin_amdgcn_s_memtime(); st.t_wait += t - t0c; t0c = t; }
-      // ---- z = [W1 | W1 R] . [x ; y]: 32 broadcast reads of 4 inputs, 64 packed FMAs -----------------------------------------------------
+      if (!chain_wait(S, q, v, a.err_flag)) return;
+      if (STAMPS) {
+        const u64 t = __builtin_amdgcn_s_memtime(); st.t_wait += t - t0c; t0c = t;
+        if (a.stamps && c == 0 && s + 1 == n_steps && p == 0 && q == 0 && lane == 0) a.stamps[112 + stage] = __builtin_amdgcn_s_memrealtime();
+      }
+      // what the helper prepared a step ahead: W0 x[t - d] + conditioning + biases
+      const float bzv = S.bias[q][s & 1][c][j];
+      // ---- z = [W1 | W1 R] . [x ; y]: 8 reads of 4 inputs, 64 packed FMAs (4 rows x 32 inputs per lane) ---------------------------------
       const float* xb = S.xy[v & (kXyRing - 1)];
-      f32x2 acc[4] = {f32x2{0.f, 0.f}, f32x2{0.f, 0.f}, f32x2{0.f, 0.f}, f32x2{0.f, 0.f}};
+      f32x2 acc[4][2];
 #pragma unroll
-      for (int i = 0; i < 32; ++i) {
-        const f32x4s xv = *reinterpret_cast<const f32x4s*>(xb + kso + (i >> 3) * kPadBlk + (i & 7) * 4);
-        acc[(i & 1) * 2 + 0] = fma2(f32x2{wz[i][0], wz[i][1]}, f32x2{xv[0], xv[1]}, acc[(i & 1) * 2 + 0]);
-        acc[(i & 1) * 2 + 1] = fma2(f32x2{wz[i][2], wz[i][3]}, f32x2{xv[2], xv[3]}, acc[(i & 1) * 2 + 1]);
-      }
-      // ---- the layer's own input x_s = x_{s-1} + (R y + br): 8 channels per wave, K = 256 over 8 lanes ------------------------------------
-      f32x2 rac[2] = {f32x2{0.f, 0.f}, f32x2{0.f, 0.f}};
+      for (int cc = 0; cc < 4; ++cc) acc[cc][0] = acc[cc][1] = f32x2{0.f, 0.f};
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
+        const f32x4s xv = *reinterpret_cast<const f32x4s*>(xb + kso + i * 4);
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) {
+          acc[cc][0] = fma2(f32x2{wz[cc * 8 + i][0], wz[cc * 8 + i][1]}, f32x2{xv[0], xv[1]}, acc[cc][0]);
+          acc[cc][1] = fma2(f32x2{wz[cc * 8 + i][2], wz[cc * 8 + i][3]}, f32x2{xv[2], xv[3]}, acc[cc][1]);
+        }
+      }
+      // ---- the layer's own input x_s = x_{s-1} + (R y + br): 2 channels x 16 inputs per lane ---------------------------------------------
+      f32x2 rac[2][2];
+#pragma unroll
+      for (int cc = 0; cc < 2; ++cc) rac[cc][0] = rac[cc][1] = f32x2{0.f, 0.f};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
         const f32x4s yv = *reinterpret_cast<const f32x4s*>(xb + xr_off + i * 4);
-        rac[0] = fma2(f32x2{wr[i][0], wr[i][1]}, f32x2{yv[0], yv[1]}, rac[0]);
-        rac[1] = fma2(f32x2{wr[i][2], wr[i][3]}, f32x2{yv[2], yv[3]}, rac[1]);
+#pragma unroll
+        for (int cc = 0; cc < 2; ++cc) {
+          rac[cc][0] = fma2(f32x2{wr[cc * 4 + i][0], wr[cc * 4 + i][1]}, f32x2{yv[0], yv[1]}, rac[cc][0]);
+          rac[cc][1] = fma2(f32x2{wr[cc * 4 + i][2], wr[cc * 4 + i][3]}, f32x2{yv[2], yv[3]}, rac[cc][1]);
+        }
       }
       const float xin = xb[xin_off];
-      float z = dpp_quad_sum(((acc[0][0] + acc[0][1]) + (acc[1][0] + acc[1][1])) + ((acc[2][0] + acc[2][1]) + (acc[3][0] + acc[3][1])));
-      float xs = dpp_half_mirror_add(dpp_quad_sum((rac[0][0] + rac[0][1]) + (rac[1][0] + rac[1][1])));
+      float zc[4];
+#pragma unroll
+      for (int cc = 0; cc < 4; ++cc) zc[cc] = (acc[cc][0][0] + acc[cc][0][1]) + (acc[cc][1][0] + acc[cc][1][1]);
+      float z = row_reduce_scatter4(zc[0], zc[1], zc[2], zc[3], ks);
+      const float xs = row_reduce_scatter2((rac[0][0][0] + rac[0][0][1]) + (rac[0][1][0] + rac[0][1][1]),
+                                           (rac[1][0][0] + rac[1][0][1]) + (rac[1][1][0] + rac[1][1][1]), ks);
       const float xnew = xin + (xs + bx);
-      // ---- what the helper prepared a step ahead: W0 x[t - d] + conditioning + biases ----------------------------------------------------
-      if (!lds_wait1(&S.ready[q], v + 1, a.err_flag)) return;
-      z += S.bias[q][s & 1][c][j];
+      z += bzv;
       // tanh(f) sigmoid(g) (wavenet_v2.py:151) with the hardware exp2 / rcp as in the other step kernels; the g row sits four lanes up
       const float act = fmaf(__frcp_rn(1.0f + __builtin_amdgcn_exp2f(z * gate_scale)), gate_k, gate_shift);
       const float other = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(act), 0x104, 0xf, 0xf, false));   // row_shl:4
@@ -225,14 +317,18 @@ __device__ void chain_role(const WnSpipeArgs& a, Lds& S, int stage, int p, int q
         unsigned* dst = msg_out + ((int64_t)c * kSpSlots + slot) * kMsgFloats + pub_off;
         msg_store(dst, __float_as_uint((lane & 1) ? y : xnew), local_next);
       }
-      if (STAMPS) { const u64 t = __builtin_amdgcn_s_memtime(); st.t_compute += t - t0c; t0c = t; }
+      if (STAMPS) {
+        const u64 t = __builtin_amdgcn_s_memtime(); st.t_compute += t - t0c; t0c = t;
+        // wall clock (100 MHz, one counter for the chip) of clip 0's publish in the last step, per stage: the chain's time line
+        if (a.stamps && c == 0 && s + 1 == n_steps && p == 0 && q == 0 && lane == 0) a.stamps[16 + stage] = __builtin_amdgcn_s_memrealtime();
+      }
       if (pub_lane) msg_store(msg_out + ((int64_t)c * kSpSlots + pslot) * kMsgFloats + pub_off, kSpPoison, local_next);
       if ((lane & 7) == 0) hist[(tau & ring_mask) * slot_stride + (int64_t)c * kC + 8 * W + j8] = xnew;
       if (STAMPS) { const u64 t = __builtin_amdgcn_s_memtime(); st.t_post += t - t0c; st.visits += 1; }
     }
   }
   if (STAMPS && a.stamps && stage == a.stamp_stage && p == 0 && q == 0 && lane == 0) {
-    a.stamps[0] = st.t_wait; a.stamps[1] = st.t_compute; a.stamps[2] = st.t_post; a.stamps[3] = st.visits;
+    a.stamps[0] = st.t_wait; a.stamps[1] = st.t_compute; a.stamps[2] = st.t_post; a.stamps[3] = st.visits; a.stamps[4] = st.polls;
   }
 }
 
@@ -242,15 +338,17 @@ __device__ void chain_role(const WnSpipeArgs& a, Lds& S, int stage, int p, int q
 template <bool STAMPS>
 __device__ void helper_role(const WnSpipeArgs& a, Lds& S, int stage, int p, int h, int lane) {
   const int W = 4 * p + h;
-  const int j = lane >> 2, ks = lane & 3;       // gate row, K slice of 64 of the delayed input
-  const int j4 = lane >> 4, ks16 = lane & 15;   // hidden unit of the wave's 4, K slice of 16 of y
-  f32x4s w0[16], wh[4];
+  const int ks = lane & 15;                     // K slice of 16: of the delayed input (4 gate rows per lane), of y (one hidden unit per lane)
+  const int j = lane >> 2, j4 = lane >> 4;
+  f32x4s w0[16], wc[16], wh[4];
   {
-    const f32x4s* img = reinterpret_cast<const f32x4s*>(a.img_helper) + ((int64_t)stage * kWavesPerStage + W) * 20 * 64 + lane;
+    const f32x4s* img = reinterpret_cast<const f32x4s*>(a.img_helper) + ((int64_t)stage * kWavesPerStage + W) * kHelperRegs * 64 + lane;
 #pragma unroll
     for (int i = 0; i < 16; ++i) w0[i] = img[i * 64];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) wh[i] = img[(16 + i) * 64];
+    for (int i = 0; i < 16; ++i) wc[i] = img[(16 + i) * 64];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) wh[i] = img[(32 + i) * 64];
   }
   const float bz = a.cst_helper[((int64_t)stage * kWavesPerStage + W) * 64 + lane];
   const int d = a.dil[stage], ring_mask = a.ring[stage] - 1;
@@ -267,15 +365,14 @@ __device__ void helper_role(const WnSpipeArgs& a, Lds& S, int stage, int p, int 
   const int xd_ch = 64 * h + lane;                                          // my quarter of the delayed input: one channel per lane
   const int xd_st = pad_of(xd_ch);
   const int xd_msg = (xd_ch >> 3) * 16 + (xd_ch & 7);
-  const int yh_off = kHalf + pad_of(16 * ks16);
-  const int w0_off = (ks * 64 >> 5) * kPadBlk;                              // pad_of(64 ks)
+  const int ks_off = pad_of(16 * ks);
   for (int it = -B; it < n_visits; ++it) {
     if (it >= 0) {
       const int s = it / B, c = it - s * B, slot = s & 3, pslot = (s + 2) & 3;
       if (stage >= 1) {
         // ---- hidden pre-activations: hid_s = hid_{s-1} + (fc0 W_skip_{s-1}) y_{s-1}, my 4 units, K = 256 over 16 lanes ---------------------
-        if (!lds_wait4(S.arrived, (unsigned)it + 1, a.err_flag)) return;
-        const float* yb = S.xy[it & (kXyRing - 1)] + yh_off;
+        if (!lds_wait1(&S.arrived[0], (unsigned)it + 1, a.err_flag)) return;
+        const float* yb = S.xy[it & (kXyRing - 1)] + kHalf + ks_off;
         f32x2 hc[2] = {f32x2{0.f, 0.f}, f32x2{0.f, 0.f}};
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -299,7 +396,7 @@ __device__ void helper_role(const WnSpipeArgs& a, Lds& S, int stage, int p, int 
           }
           hin = __uint_as_float(w1);
         }
-        if (ks16 == 0) {
+        if (ks == 0) {
           msg_store(hid_out + ((int64_t)c * kSpSlots + slot) * kH1 + 4 * W + j4, __float_as_uint(hin + hs), local_next);
           msg_store(hid_out + ((int64_t)c * kSpSlots + pslot) * kH1 + 4 * W + j4, kSpPoison, local_next);
         }
@@ -326,24 +423,47 @@ __device__ void helper_role(const WnSpipeArgs& a, Lds& S, int stage, int p, int 
         }
         xv1 = __uint_as_float(w1);
       } else {                      // written at least two steps ago (or by the warm-up): the chain has passed it on every CU of the stage
-        const int64_t tp = tau2 - d;
+        const int64_t tp = (STAMPS && (a.dbg & 2)) ? tau2 - 2 : tau2 - d;     // (diagnostic build, timing only: every delayed row from L2)
         xv1 = tp >= 0 ? __uint_as_float(msg_load(reinterpret_cast<const unsigned*>(hist + (tp & ring_mask) * slot_stride + (int64_t)c2 * kC + xd_ch))) : 0.f;
       }
-      float cnd = 0.f;
-      if (a.C1 > 0) cnd = a.condall[(((int64_t)c2 * a.cond_steps + s2) * a.L + stage) * (2 * kC) + 16 * W + j];
+      // my quarter of the projected conditioning row c[t] (LinearIO of input 1, modules/io.py:115-122): the layer's 1x1 product with
+      // it (wavenet_v2.py:140-150) is multiplied here, beside the delayed-tap product - no per-layer table in HBM
+      float cv1 = 0.f;
+      if (xd_ch < a.C1 && !(STAMPS && (a.dbg & 1))) cv1 = a.cproj[((int64_t)c2 * a.cond_steps + s2) * a.C1 + xd_ch];
       S.xd[v2 & 1][xd_st] = xv1;
+      S.cd[v2 & 1][xd_st] = cv1;
       lds_signal(&S.xd_arrived[h], (unsigned)v2 + 1, lane);
       if (!lds_wait4(S.xd_arrived, (unsigned)v2 + 1, a.err_flag)) return;
-      const float* xb = S.xd[v2 & 1] + w0_off;
-      f32x2 acc[4] = {f32x2{0.f, 0.f}, f32x2{0.f, 0.f}, f32x2{0.f, 0.f}, f32x2{0.f, 0.f}};
+      const float* xb = S.xd[v2 & 1] + ks_off;
+      f32x2 acc[4][2];
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const f32x4s xv = *reinterpret_cast<const f32x4s*>(xb + (i >> 3) * kPadBlk + (i & 7) * 4);
-        acc[(i & 1) * 2 + 0] = fma2(f32x2{w0[i][0], w0[i][1]}, f32x2{xv[0], xv[1]}, acc[(i & 1) * 2 + 0]);
-        acc[(i & 1) * 2 + 1] = fma2(f32x2{w0[i][2], w0[i][3]}, f32x2{xv[2], xv[3]}, acc[(i & 1) * 2 + 1]);
+      for (int cc = 0; cc < 4; ++cc) acc[cc][0] = acc[cc][1] = f32x2{0.f, 0.f};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const f32x4s xv = *reinterpret_cast<const f32x4s*>(xb + i * 4);
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) {
+          acc[cc][0] = fma2(f32x2{w0[cc * 4 + i][0], w0[cc * 4 + i][1]}, f32x2{xv[0], xv[1]}, acc[cc][0]);
+          acc[cc][1] = fma2(f32x2{w0[cc * 4 + i][2], w0[cc * 4 + i][3]}, f32x2{xv[2], xv[3]}, acc[cc][1]);
+        }
       }
-      const float t = dpp_quad_sum(((acc[0][0] + acc[0][1]) + (acc[1][0] + acc[1][1])) + ((acc[2][0] + acc[2][1]) + (acc[3][0] + acc[3][1])));
-      if (ks == 0) S.bias[h][s2 & 1][c2][j] = t + (cnd + bz);
+      if (a.C1 > 0) {
+        const float* cb = S.cd[v2 & 1] + ks_off;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const f32x4s xv = *reinterpret_cast<const f32x4s*>(cb + i * 4);
+#pragma unroll
+          for (int cc = 0; cc < 4; ++cc) {
+            acc[cc][0] = fma2(f32x2{wc[cc * 4 + i][0], wc[cc * 4 + i][1]}, f32x2{xv[0], xv[1]}, acc[cc][0]);
+            acc[cc][1] = fma2(f32x2{wc[cc * 4 + i][2], wc[cc * 4 + i][3]}, f32x2{xv[2], xv[3]}, acc[cc][1]);
+          }
+        }
+      }
+      float zc[4];
+#pragma unroll
+      for (int cc = 0; cc < 4; ++cc) zc[cc] = (acc[cc][0][0] + acc[cc][0][1]) + (acc[cc][1][0] + acc[cc][1][1]);
+      const float t = row_reduce_scatter4(zc[0], zc[1], zc[2], zc[3], ks);
+      if ((lane & 3) == 0) S.bias[h][s2 & 1][c2][j] = t + bz;
       lds_signal(&S.ready[h], (unsigned)v2 + 1, lane);
     }
   }
@@ -478,6 +598,8 @@ __device__ void head_role(const WnSpipeArgs& a, int p) {
           result = sample_256(lg, a.learn_temp != 0, denom, a.temperature[c], a.uniforms[(int64_t)c * a.uni_ld + s], lane);
         }
         if (s + 1 < (int)a.n_steps) publish_class(c, s + 1, result);
+        if (a.stamps && c == 0 && lane == 0 && (s + 1 == (int)a.n_steps || s + 2 == (int)a.n_steps))
+          a.stamps[16 + a.L + (s + 2 == (int)a.n_steps ? 1 : 2)] = __builtin_amdgcn_s_memrealtime();
         if (lane == 0) a.idx[(int64_t)c * a.idx_rs + tau + 1] = result;
       }
       __syncthreads();
@@ -533,39 +655,45 @@ __device__ double dot_cols(const float* arow, int64_t a_stride, const float* bco
   return acc;
 }
 
-__global__ __launch_bounds__(256) void spipe_image_kernel(const WnSpRaw* __restrict__ raw, int L, const float* __restrict__ f0, const float* __restrict__ fb0,
+__global__ __launch_bounds__(256) void spipe_image_kernel(const WnSpRaw* __restrict__ raw, int L, int C1, const float* __restrict__ f0, const float* __restrict__ fb0,
                                                           float* __restrict__ img_chain, float* __restrict__ img_helper, float* __restrict__ cst_chain,
                                                           float* __restrict__ cst_helper, float* __restrict__ head_w0, float* __restrict__ head_b0) {
-  const int64_t n_chain = (int64_t)L * kWavesPerStage * 40 * 64, n_helper = (int64_t)L * kWavesPerStage * 20 * 64;
+  const int64_t n_chain = (int64_t)L * kWavesPerStage * kChainRegs * 64, n_helper = (int64_t)L * kWavesPerStage * kHelperRegs * 64;
   const int64_t n_cst = (int64_t)L * kWavesPerStage * 64, n_hw = (int64_t)kH1 * kC / 4, n_hb = kH1;
   const int64_t total = n_chain + n_helper + 2 * n_cst + n_hw + n_hb;
   for (int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; id < total; id += (int64_t)gridDim.x * blockDim.x) {
     if (id < n_chain) {
-      const int lane = (int)(id & 63), qi = (int)((id >> 6) % 40), W = (int)((id / (40 * 64)) % kWavesPerStage), s = (int)(id / (40 * 64 * kWavesPerStage));
+      const int lane = (int)(id & 63), qi = (int)((id >> 6) % kChainRegs), W = (int)((id / (kChainRegs * 64)) % kWavesPerStage), s = (int)(id / (kChainRegs * 64 * kWavesPerStage));
       const WnSpRaw r = raw[s];
       float out[4] = {0.f, 0.f, 0.f, 0.f};
-      if (qi < 32) {
-        const int j = lane >> 2, ks = lane & 3, n = gate_raw_row(W, j);
+      if (qi < 32) {      // register cc * 8 + i: gate row 4 (lane / 16) + cc of the wave, inputs 32 (ks & 7) + 4 i .. of x (ks < 8) or y
+        const int ks = lane & 15, cc = qi >> 3, i = qi & 7, n = gate_raw_row(W, 4 * (lane >> 4) + cc);
         for (int e = 0; e < 4; ++e) {
-          const int k = 128 * (ks & 1) + 4 * qi + e;
-          if (ks < 2) out[e] = r.wd[((int64_t)n * kC + k) * 2 + 1];                                                        // W1[n][k]
+          const int k = 32 * (ks & 7) + 4 * i + e;
+          if (ks < 8) out[e] = r.wd[((int64_t)n * kC + k) * 2 + 1];                                                        // W1[n][k]
           else if (s >= 1 && raw[s - 1].wr) out[e] = (float)dot_cols(r.wd + (int64_t)n * kC * 2 + 1, 2, raw[s - 1].wr + k, kC, kC);   // (W1 R)[n][k]
         }
-      } else if (s >= 1 && raw[s - 1].wr) {
-        const int j8 = lane >> 3, ks8 = lane & 7, i = qi - 32;
-        for (int e = 0; e < 4; ++e) out[e] = raw[s - 1].wr[(int64_t)(8 * W + j8) * kC + 32 * ks8 + 4 * i + e];
+      } else if (s >= 1 && raw[s - 1].wr) {      // register 32 + cc * 4 + i: residual channel 2 (lane / 16) + cc of the wave, inputs 16 ks + 4 i .. of y
+        const int ks = lane & 15, cc = (qi - 32) >> 2, i = (qi - 32) & 3;
+        for (int e = 0; e < 4; ++e) out[e] = raw[s - 1].wr[(int64_t)(8 * W + 2 * (lane >> 4) + cc) * kC + 16 * ks + 4 * i + e];
       }
       reinterpret_cast<f32x4s*>(img_chain)[id] = f32x4s{out[0], out[1], out[2], out[3]};
     } else if (id < n_chain + n_helper) {
       const int64_t t = id - n_chain;
-      const int lane = (int)(t & 63), qi = (int)((t >> 6) % 20), W = (int)((t / (20 * 64)) % kWavesPerStage), s = (int)(t / (20 * 64 * kWavesPerStage));
+      const int lane = (int)(t & 63), qi = (int)((t >> 6) % kHelperRegs), W = (int)((t / (kHelperRegs * 64)) % kWavesPerStage), s = (int)(t / (kHelperRegs * 64 * kWavesPerStage));
       const WnSpRaw r = raw[s];
       float out[4] = {0.f, 0.f, 0.f, 0.f};
-      if (qi < 16) {
-        const int j = lane >> 2, ks = lane & 3, n = gate_raw_row(W, j);
-        for (int e = 0; e < 4; ++e) out[e] = r.wd[((int64_t)n * kC + 64 * ks + 4 * qi + e) * 2 + 0];                       // W0[n][k]
+      if (qi < 16) {      // register cc * 4 + i: gate row 4 (lane / 16) + cc, delayed inputs 16 ks + 4 i ..
+        const int ks = lane & 15, cc = qi >> 2, i = qi & 3, n = gate_raw_row(W, 4 * (lane >> 4) + cc);
+        for (int e = 0; e < 4; ++e) out[e] = r.wd[((int64_t)n * kC + 16 * ks + 4 * i + e) * 2 + 0];                        // W0[n][k]
+      } else if (qi < 32) {      // register 16 + cc * 4 + i: the same rows of the conditioning 1x1 convolution, inputs 16 ks + 4 i .. (zeros above C1)
+        const int ks = lane & 15, cc = (qi - 16) >> 2, i = (qi - 16) & 3, n = gate_raw_row(W, 4 * (lane >> 4) + cc);
+        for (int e = 0; e < 4; ++e) {
+          const int k = 16 * ks + 4 * i + e;
+          out[e] = (r.w1 && k < C1) ? r.w1[(int64_t)n * C1 + k] : 0.f;
+        }
       } else if (s >= 1) {
-        const int j4 = lane >> 4, ks16 = lane & 15, i = qi - 16, hrow = 4 * W + j4;
+        const int j4 = lane >> 4, ks16 = lane & 15, i = qi - 32, hrow = 4 * W + j4;
         for (int e = 0; e < 4; ++e) out[e] = (float)dot_cols(f0 + (int64_t)hrow * kC, 1, raw[s - 1].ws + 16 * ks16 + 4 * i + e, kC, kC);   // (fc0 W_skip)[h][k]
       }
       reinterpret_cast<f32x4s*>(img_helper)[t] = f32x4s{out[0], out[1], out[2], out[3]};
@@ -605,16 +733,16 @@ __global__ __launch_bounds__(256) void spipe_image_kernel(const WnSpRaw* __restr
 bool wn_spipe_supported(int C, int S, int H1, int n_classes, int L, int n_cond, int batch) {
   return C == kC && S == kC && H1 == kH1 && n_classes == kQ && n_cond <= 1 && L >= 1 && L <= kSpMaxLayers && batch >= 1 && batch <= 32;
 }
-int64_t wn_spipe_img_chain_floats(int L, int C) { return (int64_t)L * (C / 8) * 40 * 64 * 4; }
-int64_t wn_spipe_img_helper_floats(int L, int C) { return (int64_t)L * (C / 8) * 20 * 64 * 4; }
+int64_t wn_spipe_img_chain_floats(int L, int C) { return (int64_t)L * (C / 8) * kChainRegs * 64 * 4; }
+int64_t wn_spipe_img_helper_floats(int L, int C) { return (int64_t)L * (C / 8) * kHelperRegs * 64 * 4; }
 int64_t wn_spipe_cst_floats(int L, int C) { return (int64_t)L * (C / 8) * 64; }
 int64_t wn_spipe_msg_words(int L, int C, int Bmax) { return (int64_t)(L + 1) * Bmax * kSpSlots * 2 * C; }
 int64_t wn_spipe_hidmsg_words(int L, int Bmax) { return (int64_t)(L + 1) * Bmax * kSpSlots * kH1; }
 
-int wn_spipe_build_image(const WnSpRaw* raw_dev, int L, int C, const float* f0, const float* fb0, float* img_chain, float* img_helper,
+int wn_spipe_build_image(const WnSpRaw* raw_dev, int L, int C, int C1, const float* f0, const float* fb0, float* img_chain, float* img_helper,
                          float* cst_chain, float* cst_helper, float* head_w0, float* head_b0, hipStream_t stream) {
-  if (C != kC || L < 1 || L > kSpMaxLayers) return fail(MMK_ERR_UNSUPPORTED, "wavenet stage pipeline: C = %d, L = %d", C, L);
-  hipLaunchKernelGGL(spipe_image_kernel, dim3(2048), dim3(256), 0, stream, raw_dev, L, f0, fb0, img_chain, img_helper, cst_chain, cst_helper, head_w0,
+  if (C != kC || L < 1 || L > kSpMaxLayers || C1 < 0 || C1 > kC) return fail(MMK_ERR_UNSUPPORTED, "wavenet stage pipeline: C = %d, L = %d, C1 = %d", C, L, C1);
+  hipLaunchKernelGGL(spipe_image_kernel, dim3(2048), dim3(256), 0, stream, raw_dev, L, C1, f0, fb0, img_chain, img_helper, cst_chain, cst_helper, head_w0,
                      head_b0);
   MMK_HIP(hipGetLastError());
   return MMK_OK;
