@@ -1336,6 +1336,10 @@ extern "C" int mmk_wavenet_sync_status(mmk_wavenet_plan* p, mmk_stream_t stream)
         fprintf(stderr, "[mmk stamps] last stage-pipeline launch, chain wave 0 of CU 0 of stage MMK_WN_STAMP_STAGE (default 1), shader cycles per visit: "
                         "wait for the message=%.0f; products + gate + publish=%.0f; poison + ring store=%.0f; visits=%llu\n",
                 st[3] ? (double)st[0] / (double)st[3] : 0.0, st[3] ? (double)st[1] / (double)st[3] : 0.0, st[3] ? (double)st[2] / (double)st[3] : 0.0, st[3]);
+        fprintf(stderr, "[mmk stamps] helper wave 0 of that CU, cycles per iteration: rows requested=%.0f; wait for the message=%.0f; hidden-unit products=%.0f; "
+                        "their hand-over (rest of the poll + store)=%.0f; rows landed=%.0f; bias products=%.0f\n",
+                st[3] ? (double)st[6] / (double)st[3] : 0.0, st[3] ? (double)st[7] / (double)st[3] : 0.0, st[3] ? (double)st[8] / (double)st[3] : 0.0,
+                st[3] ? (double)st[9] / (double)st[3] : 0.0, st[3] ? (double)st[10] / (double)st[3] : 0.0, st[3] ? (double)st[11] / (double)st[3] : 0.0);
         fprintf(stderr, "[mmk stamps] extra looks per visit=%.2f; clip 0, last step, publish time of stage s minus stage s - 1 in 10 ns ticks:",
                 st[3] ? (double)st[4] / (double)st[3] : 0.0);
         for (int l = 1; l < p->L; ++l) fprintf(stderr, " %lld", (long long)(st[16 + l] - st[16 + l - 1]));

@@ -49,9 +49,13 @@ constexpr int kXyRing = 8;
 constexpr int kChainRegs = 40, kHelperRegs = 36;   // float4 registers per lane in the stage images
 constexpr unsigned kSpinLimit = 1u << 22;
 #ifndef MMK_SP_POLL_GAP
-#define MMK_SP_POLL_GAP 2
+#define MMK_SP_POLL_GAP 1
 #endif
 constexpr int kPollGap = MMK_SP_POLL_GAP;     // s_sleep units (64 cycles) between two looks at a message that has not arrived
+#ifndef MMK_SP_LOOKS
+#define MMK_SP_LOOKS 1
+#endif
+constexpr int kLooks = MMK_SP_LOOKS;          // looks in flight while it has not
 
 __device__ __forceinline__ int pad_of(int ch) { return (ch >> 5) * kPadBlk + (ch & 31); }
 
@@ -141,12 +145,10 @@ __device__ __forceinline__ unsigned msg_load(const unsigned* p) { return __hip_a
 
 struct Lds {
   float xy[kXyRing][2 * kHalf];               // the newest messages of this stage: [x padded | y padded]
-  float xd[2][kHalf];                         // delayed layer input of the visit whose bias is being prepared
-  float cd[2][kHalf];                         // projected conditioning row of that visit (zeros above C1)
   float bias[4][2][32][16];                   // [chain wave][step parity][clip][gate row]: everything of z that is known a step ahead
   unsigned arrived[4];                        // [0]: visits staged into xy by the polling wave
   unsigned hdone[4];                          // per helper: visits whose xy image it no longer needs
-  unsigned xd_arrived[4];                     // per quarter: visits staged into xd
+  unsigned pad_[4];
   unsigned ready[4];                          // per helper: biases prepared (visit count)
 };
 
@@ -236,22 +238,26 @@ __device__ void chain_role(const WnSpipeArgs& a, Lds& S, int stage, int p, int q
         const int off = ((c * kSpSlots + slot) * kMsgFloats) * 4 + look_off;
         u32x4s w_lo = pre_lo, w_hi = pre_hi;
         if (!landed(w_lo, w_hi)) {
-          // two more looks in flight, a short sleep apart: the message is seen a fraction of a round trip after it lands
-          u32x4s a_lo, a_hi, b_lo, b_hi;
-          look(off, a_lo, a_hi);
-          __builtin_amdgcn_s_sleep(kPollGap);
-          look(off, b_lo, b_hi);
+          // kLooks looks in flight, a short sleep apart.  Measured on cfg 4 (scripts/gpu_ab.sh): ONE look at a time 55.5 us per step, two
+          // 60.5, three 66 - every extra outstanding look costs all stages more in the L2 than it gains this one in reaction time.
+          u32x4s q_lo[kLooks], q_hi[kLooks];
+#pragma unroll
+          for (int k = 0; k < kLooks; ++k) {
+            look(off, q_lo[k], q_hi[k]);
+            if (k + 1 < kLooks) __builtin_amdgcn_s_sleep(kPollGap);
+          }
           unsigned spins = 0;
           for (;;) {
-            w_lo = a_lo; w_hi = a_hi;
+            w_lo = q_lo[0]; w_hi = q_hi[0];
             if (landed(w_lo, w_hi)) break;
             if (++spins > kSpinLimit || ((spins & 1023u) == 0 && __hip_atomic_load(a.err_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
               atomicExch(a.err_flag, 1);
               return;
             }
-            a_lo = b_lo; a_hi = b_hi;
+#pragma unroll
+            for (int k = 0; k + 1 < kLooks; ++k) { q_lo[k] = q_lo[k + 1]; q_hi[k] = q_hi[k + 1]; }
             __builtin_amdgcn_s_sleep(kPollGap);
-            look(off, b_lo, b_hi);
+            look(off, q_lo[kLooks - 1], q_hi[kLooks - 1]);
           }
           if (STAMPS) st.polls += spins + 1;
         }
@@ -266,6 +272,7 @@ __device__ void chain_role(const WnSpipeArgs& a, Lds& S, int stage, int p, int q
         if (sn < n_steps) look(((cn * kSpSlots + (sn & 3)) * kMsgFloats) * 4 + look_off, pre_lo, pre_hi);
       }
       if (!chain_wait(S, q, v, a.err_flag)) return;
+      __builtin_amdgcn_s_setprio(3);              // (low while it spins: the helper wave of this SIMD gets the issue slots)
       if (STAMPS) {
         const u64 t = __builtin_amdgcn_s_memtime(); st.t_wait += t - t0c; t0c = t;
         if (a.stamps && c == 0 && s + 1 == n_steps && p == 0 && q == 0 && lane == 0) a.stamps[112 + stage] = __builtin_amdgcn_s_memrealtime();
@@ -322,6 +329,7 @@ __device__ void chain_role(const WnSpipeArgs& a, Lds& S, int stage, int p, int q
         // wall clock (100 MHz, one counter for the chip) of clip 0's publish in the last step, per stage: the chain's time line
         if (a.stamps && c == 0 && s + 1 == n_steps && p == 0 && q == 0 && lane == 0) a.stamps[16 + stage] = __builtin_amdgcn_s_memrealtime();
       }
+      __builtin_amdgcn_s_setprio(0);
       if (pub_lane) msg_store(msg_out + ((int64_t)c * kSpSlots + pslot) * kMsgFloats + pub_off, kSpPoison, local_next);
       if ((lane & 7) == 0) hist[(tau & ring_mask) * slot_stride + (int64_t)c * kC + 8 * W + j8] = xnew;
       if (STAMPS) { const u64 t = __builtin_amdgcn_s_memtime(); st.t_post += t - t0c; st.visits += 1; }
@@ -338,7 +346,7 @@ __device__ void chain_role(const WnSpipeArgs& a, Lds& S, int stage, int p, int q
 template <bool STAMPS>
 __device__ void helper_role(const WnSpipeArgs& a, Lds& S, int stage, int p, int h, int lane) {
   const int W = 4 * p + h;
-  const int ks = lane & 15;                     // K slice of 16: of the delayed input (4 gate rows per lane), of y (one hidden unit per lane)
+  const int ks = lane & 15;                     // K slice of 16: of the delayed input and the conditioning row (4 gate rows per lane), of y (one hidden unit per lane)
   const int j = lane >> 2, j4 = lane >> 4;
   f32x4s w0[16], wc[16], wh[4];
   {
@@ -352,26 +360,75 @@ __device__ void helper_role(const WnSpipeArgs& a, Lds& S, int stage, int p, int 
   }
   const float bz = a.cst_helper[((int64_t)stage * kWavesPerStage + W) * 64 + lane];
   const int d = a.dil[stage], ring_mask = a.ring[stage] - 1;
-  const float* hist = a.hist[stage];
   const int64_t slot_stride = (int64_t)a.Bmax * kC;
   const bool local_next = ((stage + 1) >> 2) == (stage >> 2);
   const int64_t stage_words = (int64_t)a.Bmax * kSpSlots * kMsgFloats;
-  const unsigned* msg_own = a.msg + (int64_t)(stage + 1) * stage_words;     // what THIS stage publishes: x_s of the newest step
   const int64_t hid_words = (int64_t)a.Bmax * kSpSlots * kH1;
   const unsigned* hid_in = a.hidmsg + (int64_t)stage * hid_words;
   unsigned* hid_out = a.hidmsg + (int64_t)(stage + 1) * hid_words;
   const int B = a.B;
   const int n_visits = (int)a.n_steps * B;
-  const int xd_ch = 64 * h + lane;                                          // my quarter of the delayed input: one channel per lane
-  const int xd_st = pad_of(xd_ch);
-  const int xd_msg = (xd_ch >> 3) * 16 + (xd_ch & 7);
   const int ks_off = pad_of(16 * ks);
+  // A lane reads ITS 16 inputs of a row straight into registers (64 contiguous bytes; the four row groups of the wave ask for the
+  // same bytes): no staging through LDS, no hand-shake between the helper waves.
+  const __amdgpu_buffer_rsrc_t ring = __builtin_amdgcn_make_buffer_rsrc(a.hist[stage], 0, -1, 0x00020000);      // rows other CUs write: past L1 (sc1)
+  const __amdgpu_buffer_rsrc_t own = __builtin_amdgcn_make_buffer_rsrc(a.msg + (int64_t)(stage + 1) * stage_words, 0, -1, 0x00020000);
+  const bool cond_lane = 16 * ks < a.C1;        // (C1 is a multiple of 16: a slice lies inside the row or above it)
+  // What makes a ring entry safe to read: every wave works through the visits in one order, and the arrival of message (c, s) says
+  // that step s - 1 of clip c has left the head - so every visit up to (c, s - 1) is complete on every CU of this stage.  The rows
+  // of the bias of visit it + B are asked for at the TOP of iteration it, before message `it` has arrived (they land while the wave
+  // waits for it): the newest evidence then is message it - 1, which covers the row iff d >= 3.  d = 2 reads its row when it is
+  // used (an L2 hit: written two steps ago), d = 1 polls this stage's own newest message (its ring entry has no arrival check).
+  const bool early = d >= 3;
+  u64 hs_t[6] = {0, 0, 0, 0, 0, 0}, hs_t0 = 0;      // diagnostic build: cycles in the phases of an iteration
+  auto hstamp = [&](int k) {
+    if (STAMPS) { const u64 t = __builtin_amdgcn_s_memtime(); hs_t[k] += t - hs_t0; hs_t0 = t; }
+  };
+  auto ring_row = [&](int s2, int c2, u32x4s (&xv)[4]) {
+    const int64_t tp = (STAMPS && (a.dbg & 2)) ? a.t0 - 1 + s2 - 2 : a.t0 - 1 + s2 - d;     // (dbg 2: diagnostic build, timing only)
+    if (tp >= 0) {
+      const int off = (int)(((tp & ring_mask) * slot_stride + (int64_t)c2 * kC + 16 * ks) * 4);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) xv[i] = __builtin_amdgcn_raw_buffer_load_b128(ring, off + 16 * i, 0, 16);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) xv[i] = u32x4s{0, 0, 0, 0};
+    }
+  };
+  int s = -1, c = 0, s2 = 0, c2 = 0;              // visit it = (c, s), visit it + B = (c2, s2) = (c, s + 1)
   for (int it = -B; it < n_visits; ++it) {
+    if (STAMPS) hs_t0 = __builtin_amdgcn_s_memtime();
+    const int v2 = it + B;
+    const bool valid = v2 < n_visits;
+    // ---- the rows of the NEXT bias, requested before anything waits -----------------------------------------------------------------------
+    u32x4s xv[4];
+    f32x4s cv[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { xv[i] = u32x4s{0, 0, 0, 0}; cv[i] = f32x4s{0.f, 0.f, 0.f, 0.f}; }
+    const bool row_now = valid && (early || s2 == 0);       // (step 0 reads what the warm-up wrote)
+    if (valid) {
+      // my slice of the projected conditioning row c[t] (LinearIO of input 1, modules/io.py:115-122): the layer's 1x1 product with it
+      // (wavenet_v2.py:140-150) is multiplied here, beside the delayed-tap product - no per-layer table in HBM
+      if (cond_lane && !(STAMPS && (a.dbg & 1))) {
+        const f32x4s* src = reinterpret_cast<const f32x4s*>(a.cproj + ((int64_t)c2 * a.cond_steps + s2) * a.C1 + 16 * ks);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) cv[i] = src[i];
+      }
+      if (row_now) ring_row(s2, c2, xv);
+    }
+    hstamp(0);
+    bool hid_pending = false;
+    float hs = 0.f;
+    unsigned w1 = 0;
+    const unsigned* hsrc = nullptr;
+    const int slot = s & 3, pslot = (s + 2) & 3;
     if (it >= 0) {
-      const int s = it / B, c = it - s * B, slot = s & 3, pslot = (s + 2) & 3;
       if (stage >= 1) {
         // ---- hidden pre-activations: hid_s = hid_{s-1} + (fc0 W_skip_{s-1}) y_{s-1}, my 4 units, K = 256 over 16 lanes ---------------------
         if (!lds_wait1(&S.arrived[0], (unsigned)it + 1, a.err_flag)) return;
+        hstamp(1);
+        hsrc = hid_in + ((int64_t)c * kSpSlots + slot) * kH1 + 4 * W + j4;
+        if (stage >= 2) w1 = msg_load(hsrc);            // a first look at the hand-over of the stage below, in flight under the products
         const float* yb = S.xy[it & (kXyRing - 1)] + kHalf + ks_off;
         f32x2 hc[2] = {f32x2{0.f, 0.f}, f32x2{0.f, 0.f}};
 #pragma unroll
@@ -380,82 +437,58 @@ __device__ void helper_role(const WnSpipeArgs& a, Lds& S, int stage, int p, int 
           hc[0] = fma2(f32x2{wh[i][0], wh[i][1]}, f32x2{yv[0], yv[1]}, hc[0]);
           hc[1] = fma2(f32x2{wh[i][2], wh[i][3]}, f32x2{yv[2], yv[3]}, hc[1]);
         }
-        float hs = dpp_mirror_add(dpp_half_mirror_add(dpp_quad_sum((hc[0][0] + hc[0][1]) + (hc[1][0] + hc[1][1]))));
+        hs = dpp_mirror_add(dpp_half_mirror_add(dpp_quad_sum((hc[0][0] + hc[0][1]) + (hc[1][0] + hc[1][1]))));
         lds_signal(&S.hdone[h], (unsigned)it + 1, lane);
-        float hin = 0.f;
-        if (stage >= 2) {
-          const unsigned* src = hid_in + ((int64_t)c * kSpSlots + slot) * kH1 + 4 * W + j4;
-          unsigned w1, spins = 0;
+        hid_pending = true;      // handed on below, behind the bias products: the look's round trip runs under them
+        hstamp(2);
+      } else {
+        lds_signal(&S.hdone[h], (unsigned)it + 1, lane);
+      }
+    }
+    if (valid) {
+      // ---- the bias of visit v2 = (c2, s2): W0 x_s[t - d] + W_1x1 c[t] + constants ---------------------------------------------------------
+      if (!row_now) {
+        if (d == 1) {             // x_s of the previous step = channels 16 ks .. + 15 of this stage's newest message: 8 x of producing waves 2 ks, 2 ks + 1
+          const int off = (((c2 * kSpSlots + ((s2 - 1) & 3)) * kMsgFloats) + 32 * ks) * 4;
+          unsigned spins = 0;
           for (;;) {
-            w1 = msg_load(src);
-            if (__all(w1 != kSpPoison)) break;
+            xv[0] = __builtin_amdgcn_raw_buffer_load_b128(own, off, 0, 16);
+            xv[1] = __builtin_amdgcn_raw_buffer_load_b128(own, off + 16, 0, 16);
+            xv[2] = __builtin_amdgcn_raw_buffer_load_b128(own, off + 64, 0, 16);
+            xv[3] = __builtin_amdgcn_raw_buffer_load_b128(own, off + 80, 0, 16);
+            bool ok = true;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) ok = ok && xv[i][0] != kSpPoison && xv[i][1] != kSpPoison && xv[i][2] != kSpPoison && xv[i][3] != kSpPoison;
+            if (__all(ok)) break;
             if (++spins > kSpinLimit || ((spins & 1023u) == 0 && __hip_atomic_load(a.err_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
               atomicExch(a.err_flag, 1);
               return;
             }
           }
-          hin = __uint_as_float(w1);
+        } else {
+          ring_row(s2, c2, xv);
         }
-        if (ks == 0) {
-          msg_store(hid_out + ((int64_t)c * kSpSlots + slot) * kH1 + 4 * W + j4, __float_as_uint(hin + hs), local_next);
-          msg_store(hid_out + ((int64_t)c * kSpSlots + pslot) * kH1 + 4 * W + j4, kSpPoison, local_next);
-        }
-      } else {
-        lds_signal(&S.hdone[h], (unsigned)it + 1, lane);
       }
-    }
-    const int v2 = it + B;
-    if (v2 < n_visits) {
-      // ---- the bias of visit v2 = (c2, s2): W0 x_s[t - d] + conditioning + constants ------------------------------------------------------
-      const int s2 = v2 / B, c2 = v2 - s2 * B;
-      const int64_t tau2 = a.t0 - 1 + s2;
-      float xv1;
-      if (d == 1 && s2 >= 1) {      // the previous step's x_s is this stage's own newest message (its ring entry has no arrival check)
-        const unsigned* src = msg_own + ((int64_t)c2 * kSpSlots + ((s2 - 1) & 3)) * kMsgFloats + xd_msg;
-        unsigned w1, spins = 0;
-        for (;;) {
-          w1 = msg_load(src);
-          if (__all(w1 != kSpPoison)) break;
-          if (++spins > kSpinLimit || ((spins & 1023u) == 0 && __hip_atomic_load(a.err_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
-            atomicExch(a.err_flag, 1);
-            return;
-          }
-        }
-        xv1 = __uint_as_float(w1);
-      } else {                      // written at least two steps ago (or by the warm-up): the chain has passed it on every CU of the stage
-        const int64_t tp = (STAMPS && (a.dbg & 2)) ? tau2 - 2 : tau2 - d;     // (diagnostic build, timing only: every delayed row from L2)
-        xv1 = tp >= 0 ? __uint_as_float(msg_load(reinterpret_cast<const unsigned*>(hist + (tp & ring_mask) * slot_stride + (int64_t)c2 * kC + xd_ch))) : 0.f;
-      }
-      // my quarter of the projected conditioning row c[t] (LinearIO of input 1, modules/io.py:115-122): the layer's 1x1 product with
-      // it (wavenet_v2.py:140-150) is multiplied here, beside the delayed-tap product - no per-layer table in HBM
-      float cv1 = 0.f;
-      if (xd_ch < a.C1 && !(STAMPS && (a.dbg & 1))) cv1 = a.cproj[((int64_t)c2 * a.cond_steps + s2) * a.C1 + xd_ch];
-      S.xd[v2 & 1][xd_st] = xv1;
-      S.cd[v2 & 1][xd_st] = cv1;
-      lds_signal(&S.xd_arrived[h], (unsigned)v2 + 1, lane);
-      if (!lds_wait4(S.xd_arrived, (unsigned)v2 + 1, a.err_flag)) return;
-      const float* xb = S.xd[v2 & 1] + ks_off;
+      hstamp(4);
       f32x2 acc[4][2];
 #pragma unroll
       for (int cc = 0; cc < 4; ++cc) acc[cc][0] = acc[cc][1] = f32x2{0.f, 0.f};
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const f32x4s xv = *reinterpret_cast<const f32x4s*>(xb + i * 4);
+        const f32x4s xf = f32x4s{__uint_as_float(xv[i][0]), __uint_as_float(xv[i][1]), __uint_as_float(xv[i][2]), __uint_as_float(xv[i][3])};
 #pragma unroll
         for (int cc = 0; cc < 4; ++cc) {
-          acc[cc][0] = fma2(f32x2{w0[cc * 4 + i][0], w0[cc * 4 + i][1]}, f32x2{xv[0], xv[1]}, acc[cc][0]);
-          acc[cc][1] = fma2(f32x2{w0[cc * 4 + i][2], w0[cc * 4 + i][3]}, f32x2{xv[2], xv[3]}, acc[cc][1]);
+          acc[cc][0] = fma2(f32x2{w0[cc * 4 + i][0], w0[cc * 4 + i][1]}, f32x2{xf[0], xf[1]}, acc[cc][0]);
+          acc[cc][1] = fma2(f32x2{w0[cc * 4 + i][2], w0[cc * 4 + i][3]}, f32x2{xf[2], xf[3]}, acc[cc][1]);
         }
       }
       if (a.C1 > 0) {
-        const float* cb = S.cd[v2 & 1] + ks_off;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          const f32x4s xv = *reinterpret_cast<const f32x4s*>(cb + i * 4);
 #pragma unroll
           for (int cc = 0; cc < 4; ++cc) {
-            acc[cc][0] = fma2(f32x2{wc[cc * 4 + i][0], wc[cc * 4 + i][1]}, f32x2{xv[0], xv[1]}, acc[cc][0]);
-            acc[cc][1] = fma2(f32x2{wc[cc * 4 + i][2], wc[cc * 4 + i][3]}, f32x2{xv[2], xv[3]}, acc[cc][1]);
+            acc[cc][0] = fma2(f32x2{wc[cc * 4 + i][0], wc[cc * 4 + i][1]}, f32x2{cv[i][0], cv[i][1]}, acc[cc][0]);
+            acc[cc][1] = fma2(f32x2{wc[cc * 4 + i][2], wc[cc * 4 + i][3]}, f32x2{cv[i][2], cv[i][3]}, acc[cc][1]);
           }
         }
       }
@@ -465,8 +498,32 @@ __device__ void helper_role(const WnSpipeArgs& a, Lds& S, int stage, int p, int 
       const float t = row_reduce_scatter4(zc[0], zc[1], zc[2], zc[3], ks);
       if ((lane & 3) == 0) S.bias[h][s2 & 1][c2][j] = t + bz;
       lds_signal(&S.ready[h], (unsigned)v2 + 1, lane);
+      hstamp(5);
     }
+    if (hid_pending) {
+      float hin = 0.f;
+      if (stage >= 2) {
+        unsigned spins = 0;
+        while (!__all(w1 != kSpPoison)) {
+          if (++spins > kSpinLimit || ((spins & 1023u) == 0 && __hip_atomic_load(a.err_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+            atomicExch(a.err_flag, 1);
+            return;
+          }
+          w1 = msg_load(hsrc);
+        }
+        hin = __uint_as_float(w1);
+      }
+      if (ks == 0) {
+        msg_store(hid_out + ((int64_t)c * kSpSlots + slot) * kH1 + 4 * W + j4, __float_as_uint(hin + hs), local_next);
+        msg_store(hid_out + ((int64_t)c * kSpSlots + pslot) * kH1 + 4 * W + j4, kSpPoison, local_next);
+      }
+      hstamp(3);
+    }
+    if (++c == B) { c = 0; ++s; }
+    c2 = c; s2 = s + 1;
   }
+  if (STAMPS && a.stamps && stage == a.stamp_stage && p == 0 && h == 0 && lane == 0)
+    for (int k = 0; k < 6; ++k) a.stamps[6 + k] = hs_t[k];
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------------
@@ -474,7 +531,7 @@ __device__ void helper_role(const WnSpipeArgs& a, Lds& S, int stage, int p, int 
 // and the next step's embedded sample as the message for stage 0
 // ------------------------------------------------------------------------------------------------------------------------------------
 __device__ void head_role(const WnSpipeArgs& a, int p) {
-  __shared__ __attribute__((aligned(16))) float ys[kC], hin[kH1], hid[kH1], lg[kQ + 4];
+  __shared__ __attribute__((aligned(16))) float ys[kC], hid[kH1], lg[kQ + 4];
   __shared__ int s_fail;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -536,24 +593,6 @@ __device__ void head_role(const WnSpipeArgs& a, int p) {
           }
         }
         *reinterpret_cast<f32x4s*>(ys + 4 * lane) = f32x4s{__uint_as_float(w4[0]), __uint_as_float(w4[1]), __uint_as_float(w4[2]), __uint_as_float(w4[3])};
-      } else if (wave == 1) {      // the hidden pre-activations the layer stages have accumulated (layers 0 .. L - 2)
-        f32x2 hv = f32x2{0.f, 0.f};
-        if (L >= 2) {
-          const unsigned* src = hid_in + ((int64_t)c * kSpSlots + slot) * kH1 + 2 * lane;
-          u32x2 w2v;
-          unsigned spins = 0;
-          for (;;) {
-            asm volatile("global_load_dwordx2 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(w2v) : "v"(src) : "memory");
-            if (__all(w2v[0] != kSpPoison && w2v[1] != kSpPoison)) break;
-            if (++spins > kSpinLimit || ((spins & 1023u) == 0 && __hip_atomic_load(a.err_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
-              atomicExch(a.err_flag, 1);
-              s_fail = 1;
-              break;
-            }
-          }
-          hv = f32x2{__uint_as_float(w2v[0]), __uint_as_float(w2v[1])};
-        }
-        *reinterpret_cast<f32x2*>(hin + 2 * lane) = hv;
       }
       __syncthreads();
       if (s_fail) return;
@@ -561,7 +600,24 @@ __device__ void head_role(const WnSpipeArgs& a, int p) {
 #pragma unroll
       for (int k = 0; k < 64; ++k) h4[k & 3] = fmaf(w0[k], ys[64 * kq + k], h4[k & 3]);
       const float hsum = dpp_quad_sum((h4[0] + h4[1]) + (h4[2] + h4[3]));
-      if (kq == 0) hid[o] = mish_fast(hin[o] + (hsum + b0));
+      // the hidden pre-activations the layer stages have accumulated (layers 0 .. L - 2) travel beside the chain and arrive a little after
+      // y: waited for behind the products, by the lanes that need them (a quad shares a word)
+      float hacc = 0.f;
+      if (L >= 2) {
+        const unsigned* src = hid_in + ((int64_t)c * kSpSlots + slot) * kH1 + o;
+        unsigned w1, spins = 0;
+        for (;;) {
+          w1 = msg_load(src);
+          if (__all(w1 != kSpPoison)) break;
+          if (++spins > kSpinLimit || ((spins & 1023u) == 0 && __hip_atomic_load(a.err_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+            atomicExch(a.err_flag, 1);
+            s_fail = 1;
+            break;
+          }
+        }
+        hacc = __uint_as_float(w1);
+      }
+      if (kq == 0) hid[o] = mish_fast(hacc + (hsum + b0));
       __syncthreads();
       float q4[4] = {0.f, 0.f, 0.f, 0.f};
       const float* hs = hid + (tid & 1) * 64;
@@ -637,7 +693,6 @@ __global__ __launch_bounds__(kThreads) void wavenet_spipe_kernel(const WnSpipeAr
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   if (wave < 4) {
-    __builtin_amdgcn_s_setprio(3);
     chain_role<STAMPS>(a, S, stage, p, wave, lane);
   } else {
     helper_role<STAMPS>(a, S, stage, p, wave - 4, lane);

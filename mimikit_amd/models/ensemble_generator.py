@@ -1,12 +1,21 @@
-"""``EnsembleGenerator`` (reference ``mimikit/models/ensemble_generator.py:54-163``): one long clip generated by a stream of
-events, each naming a network, a duration and a temperature; between networks the audio is resampled on the device
-(``Resample``, HIP kernel) to the network's rate and back to the base rate."""
+"""Long-form generation by a sequence of networks.
+
+Behaviour of the reference's ``EnsembleGenerator`` (``mimikit/models/ensemble_generator.py:54-163``): a clip of
+``max_seconds`` at ``base_sr`` starts with the caller's prompt; a stream of events ``{generator, seconds, temperature}``
+extends it.  Every event sees the most recent ``len(prompt)`` samples of the clip, brought to its network's sample rate,
+generates ``seconds`` of audio and hands it back at ``base_sr``.  The first event that does not fit before ``max_seconds``
+ends the clip: what is left stays silent.  An exhausted stream raises ``StopIteration`` like the reference's ``next()``.
+
+Here the whole event runs on the device: ``Resample`` is the HIP polyphase kernel (``csrc/features.hip``), the network's
+input transforms and ``GenerateLoopV2`` are the package's own, and an event may name a network or a ``Checkpoint`` of this
+package (``.npz`` weights + the reference's YAML config, see ``mimikit_amd/checkpoint.py``).
+"""
 import dataclasses as dtc
-from pprint import pprint
-from typing import Generator, Optional
+from typing import Dict, Iterator, Optional, Tuple, Union
 
 import torch
 
+from ..checkpoint import Checkpoint
 from ..features.functionals import Resample
 from ..features.item_spec import Sample, convert
 from ..loops.generate import GenerateLoopV2
@@ -18,61 +27,82 @@ __all__ = ["Event", "EnsembleGenerator"]
 
 @dtc.dataclass
 class Event:
-    generator: ARM           # (the reference also takes a Checkpoint or a NearestNextNeighbor model: out of scope here)
+    generator: Union[ARM, Checkpoint]
     seconds: float
     temperature: Optional[float] = None
 
+    def network(self) -> ARM:
+        g = self.generator
+        if isinstance(g, Checkpoint):
+            return g.network
+        if isinstance(g, ARM):
+            return g
+        raise TypeError(f"event generator type '{type(g)}' not supported")
+
+    def loop_parameters(self) -> Dict:
+        return {} if self.temperature is None else {"temperature": self.temperature}
+
 
 class EnsembleGenerator:
-    def __init__(self, prompt: torch.Tensor, max_seconds: float = 10., base_sr: int = 22050, stream: Generator = (),
+    def __init__(self, prompt: torch.Tensor, max_seconds: float = 10., base_sr: int = 22050, stream: Iterator[dict] = (),
                  print_events: bool = False, device=None):
         self.device = default_device() if device is None else device
         self.prompt = prompt.to(self.device)
-        self.max_seconds, self.base_sr, self.stream, self.print_events = max_seconds, base_sr, stream, print_events
+        self.max_seconds = max_seconds
+        self.base_sr = base_sr
+        self.stream = stream
+        self.print_events = print_events
 
-    def run(self):
-        prompt_length = t = self.prompt.size(-1)
-        n_samples = int(self.max_seconds * self.base_sr)
-        output = torch.zeros(self.prompt.size(0), n_samples, dtype=self.prompt.dtype).to(self.device)
-        output[:, :t] = self.prompt
-        while t < n_samples:
-            step_output = self.generate_step(t, output[:, t - prompt_length:t])
-            if step_output is None:
+    # -- the clip as a timeline ---------------------------------------------------------------------
+    @property
+    def total_samples(self) -> int:
+        return int(self.max_seconds * self.base_sr)
+
+    def run(self) -> torch.Tensor:
+        context = self.prompt.size(-1)
+        clip = self.prompt.new_zeros(self.prompt.size(0), self.total_samples)
+        clip[:, :context] = self.prompt
+        cursor = context
+        while cursor < self.total_samples:
+            piece = self.generate_step(cursor, clip[:, cursor - context:cursor])
+            if piece is None:
                 break
-            n = min(step_output.size(1), n_samples - t)
-            output[:, t:t + n] = step_output[:, :n]
-            t += step_output.size(1)
-        return output
+            room = self.total_samples - cursor
+            clip[:, cursor:cursor + min(room, piece.size(1))] = piece[:, :room]
+            cursor += piece.size(1)
+        return clip
 
-    def generate_step(self, t, inputs):
-        if t >= int(self.max_seconds * self.base_sr):
+    def generate_step(self, t: int, inputs: torch.Tensor) -> Optional[torch.Tensor]:
+        """the audio (at ``base_sr``) that follows position ``t``: one event's output, or silence up to the end of the clip
+        when the next event would overrun it; ``None`` past the end"""
+        if t >= self.total_samples:
             return None
         event, net, n_steps, params = self.next_event()
-        if hasattr(net, "to"):
-            net = net.to(self.device)
-        if (t / self.base_sr + event.seconds) < self.max_seconds:
-            if self.print_events:
-                e = {"seconds": event.seconds, "temperature": event.temperature, "start": t / self.base_sr}
-                pprint(e)
-            return self.run_event(inputs, net, n_steps, params)
-        return torch.zeros(inputs.size(0), int(self.max_seconds * self.base_sr - t)).to(self.device)
+        if t / self.base_sr + event.seconds >= self.max_seconds:
+            return inputs.new_zeros(inputs.size(0), self.total_samples - t)
+        if self.print_events:
+            print({"generator": type(net).__name__, "seconds": event.seconds, "temperature": event.temperature,
+                   "start": t / self.base_sr})
+        return self.run_event(inputs, net.to(self.device), n_steps, params)
 
-    def run_event(self, inputs: torch.Tensor, net: ARM, n_steps: int, params: dict):
-        network_sr = net.config.io_spec.sr
-        inputs_resampled = Resample(self.base_sr, network_sr)(inputs)
-        prompt = tuple(in_spec.transform(inputs_resampled) for in_spec in net.config.io_spec.inputs)
-        # ffts use LESS input samples than provided (reference :121-122)
-        n_prompt_samples = convert(prompt[0].shape[1], net.config.io_spec.targets[0].unit, Sample(sr=network_sr), True)
-        cfg = GenerateLoopV2.Config(parameters=params, display_waveform=False, write_waveform=False, yield_inversed_outputs=True)
-        loop = GenerateLoopV2(cfg, network=net, n_steps=n_steps, dataloader=[[torch.ones(1), *prompt]], logger=None)
-        for outputs in loop.run():
-            return Resample(network_sr, self.base_sr)(outputs[0][:, n_prompt_samples:])
-
-    def next_event(self):
+    def next_event(self) -> Tuple[Event, ARM, int, Dict]:
         event = Event(**next(self.stream))
-        if not isinstance(event.generator, ARM):
-            raise TypeError(f"event generator type '{type(event.generator)}' not supported")
-        net = event.generator
+        net = event.network()
         n_steps = GenerateLoopV2.get_n_steps(GenerateLoopV2.Config(output_duration_sec=event.seconds), net)
-        params = dict(temperature=event.temperature) if event.temperature is not None else {}
-        return event, net, n_steps, params
+        return event, net, n_steps, event.loop_parameters()
+
+    # -- one event ------------------------------------------------------------------------------------
+    def run_event(self, inputs: torch.Tensor, net: ARM, n_steps: int, params: Dict) -> torch.Tensor:
+        spec = net.config.io_spec
+        to_net, to_base = Resample(self.base_sr, spec.sr), Resample(spec.sr, self.base_sr)
+        at_net_rate = to_net(inputs)
+        prompts = [feature.transform(at_net_rate) for feature in spec.inputs]
+        # a framed input (an STFT) covers fewer samples than it was given: what the loop returns in front of the new audio
+        # is the prompt as the TARGET unit counts it
+        kept = convert(prompts[0].shape[1], spec.targets[0].unit, Sample(sr=spec.sr), True)
+        loop = GenerateLoopV2(GenerateLoopV2.Config(parameters=params, display_waveform=False, write_waveform=False,
+                                                    yield_inversed_outputs=True),
+                              network=net, n_steps=n_steps, logger=None,
+                              dataloader=[[torch.ones(1), *prompts]])      # (first entry: the prompt's index, unused without a logger)
+        outputs = next(iter(loop.run()))
+        return to_base(outputs[0][:, kept:])

@@ -1130,7 +1130,7 @@ def test_wavenet_pipelined_kernel_shapes(device, monkeypatch, blocks, C, B, n):
     assert n_ok > 0.9 * len(steps) * B
 
 
-def _wide_net(blocks, seed, cond):
+def _cfg4_family_net(blocks, seed, cond):
     """the geometry family of BASELINE config 4: 256 channels, kernel 2, gated, skips 256, embedding in, MLP head 128 -> 256 (+ temperature),
     optionally one conditioning input (12 -> 16 channels)"""
     from oracle.weights import load_recipe
@@ -1161,7 +1161,7 @@ def test_wavenet_stage_pipeline_agrees_with_oracle(device, monkeypatch, blocks, 
     greedy, then sampled with the uniforms generate_block draws; the same generation twice is bit-identical"""
     for k in SPIPE_ENV:
         monkeypatch.delenv(k, raising=False)
-    net, sd, arch = _wide_net(blocks, 300 + len(blocks) + B, cond)
+    net, sd, arch = _cfg4_family_net(blocks, 300 + len(blocks) + B, cond)
     net = net.to(device)
     gen = torch.Generator().manual_seed(B + n)
     rf = net.rf
