@@ -17,7 +17,10 @@
  *   - kernels are enqueued on the `stream` argument (a `hipStream_t`, passed as
  *     void*) and the library never synchronises it, except inside
  *     `*_commit` which may wait for its own one-off graph capture;
- *   - no torch / C++ types cross the boundary.
+ *   - no torch / C++ types cross the boundary;
+ *   - diagnostics (in-kernel phase stamps, timing experiments that change results) are compiled only into the diagnostic
+ *     build of the library (`python -m mimikit_amd.build --diag` -> libmmk_hip_diag.so, -DMMK_DIAG); the product library has
+ *     no code path that produces wrong results on purpose.
  */
 #ifndef MMK_H_
 #define MMK_H_
@@ -29,7 +32,7 @@
 extern "C" {
 #endif
 
-#define MMK_ABI_VERSION 1
+#define MMK_ABI_VERSION 2   /* 2: exec_mode in the WaveNet / SampleRNN configs, mmk_*_inject_sync_error */
 
 #define MMK_OK 0
 #define MMK_ERR_INVALID (-1)     /* bad argument / shape / unsupported option value */
@@ -191,6 +194,10 @@ typedef struct mmk_wavenet_config {
   int32_t res_explicit;
   int32_t layer_has_res[MMK_MAX_LAYERS];
   int32_t layerwise_inputs;                /* Config.layerwise_inputs: the embedded input 0 is added to every layer's output (:285-286) */
+  int32_t exec_mode;                       /* how the steps of a call are run: 0 = the library chooses (a persistent kernel where the
+                                            * geometry and the device allow one), 1 = one fused kernel per layer half, hipGraph-replayed -
+                                            * needs no co-residency of workgroups: what a caller asks for to redo a batch after
+                                            * mmk_wavenet_sync_status reported a timed-out hand-off */
   int32_t with_affine_residuals;           /* Config.with_affine_residuals (:121-122, :148-149): every layer's input goes through
                                             * x_hat * a + b of a 1x1 convolution to 3 x its width (ParametrizedLinear) first; launch path,
                                             * without pad_side, layerwise_inputs, or conditioning inputs of an ungated network */
@@ -238,6 +245,9 @@ int mmk_wavenet_profile_steps(mmk_wavenet_plan* plan, int32_t batch, void* in0, 
 int mmk_wavenet_mode(const mmk_wavenet_plan* plan);
 /* waits for `stream`; MMK_ERR_STATE if a hand-off inside the persistent kernel timed out */
 int mmk_wavenet_sync_status(mmk_wavenet_plan* plan, mmk_stream_t stream);
+/* Fault injection for the callers' tests: marks the plan as if a hand-off of its last call had timed out, so that the next
+ * mmk_wavenet_sync_status fails exactly as it would after a real time-out (and the caller's redo path runs). */
+int mmk_wavenet_inject_sync_error(mmk_wavenet_plan* plan, mmk_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * SampleRNN (mimikit/networks/sample_rnn_v2.py)
@@ -254,6 +264,9 @@ typedef struct mmk_srnn_config {
   float min_temp;
   int32_t max_batch;
   int32_t n_rnn;                           /* Config.n_rnn: stacked recurrent layers per tier (:65, nn.LSTM / GRU num_layers); 0 = 1 */
+  int32_t exec_mode;                       /* 0 = the library chooses (resident mode: the bottom tier's launch beside the tier kernels of a
+                                            * second stream, where they are co-resident), 1 = the kernels in turns on one stream: what a
+                                            * caller asks for to redo a batch after mmk_srnn_sync_status reported a timed-out wait */
 } mmk_srnn_config;
 
 typedef struct mmk_srnn_plan mmk_srnn_plan;
@@ -274,8 +287,10 @@ int mmk_srnn_generate(mmk_srnn_plan* plan, int32_t batch, int64_t* idx, int64_t 
                       int64_t n_steps, const float* temperature, const float* uniforms, mmk_stream_t stream);
 int mmk_srnn_last_logits(mmk_srnn_plan* plan, int32_t batch, float* out, int64_t ld, mmk_stream_t stream);
 /* waits for the stream; fails (and clears the word) if a wait inside the tier / bottom kernels timed out since the last call -
- * the samples of that generation are invalid (MMK_SRNN_FORCE_SYNC_ERROR=1: test hook, always reports one) */
+ * the samples of that generation are invalid */
 int mmk_srnn_sync_status(mmk_srnn_plan* plan, mmk_stream_t stream);
+/* fault injection for the callers' tests: the next mmk_srnn_sync_status reports a timed-out wait (once) */
+int mmk_srnn_inject_sync_error(mmk_srnn_plan* plan, mmk_stream_t stream);
 /* diagnostic: generate blocks this plan has run in resident mode (the bottom tier as one launch beside the tier kernels of a
  * second stream) since it was created; tests assert that the mode they mean to cover is the one that ran */
 int64_t mmk_srnn_resident_blocks(const mmk_srnn_plan* plan);

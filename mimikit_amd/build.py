@@ -33,18 +33,25 @@ def _stale() -> bool:
     return any(os.path.getmtime(d) > built for d in deps)
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
+def build(force: bool = False, verbose: bool = False, diag: bool = False) -> str:
+    """``diag``: the diagnostic build ``libmmk_hip_diag.so`` (-DMMK_DIAG: in-kernel phase stamps and the timing experiments of
+    DESIGN.md; selected at import by MMK_DIAG_LIB=1) instead of the product library"""
+    if diag:
+        return _build(os.path.join(HERE, "libmmk_hip_diag.so"), os.path.join(HERE, "build_diag"), ["-DMMK_DIAG"], verbose)
     if not force and not _stale():
         return LIB_PATH
+    return _build(LIB_PATH, os.path.join(HERE, "build"), [], verbose)
+
+
+def _build(lib_path: str, obj_dir: str, defines, verbose: bool) -> str:
     hipcc = _hipcc()
-    obj_dir = os.path.join(HERE, "build")
     os.makedirs(obj_dir, exist_ok=True)
     objs = []
     procs = []
     for src in SOURCES:
         obj = os.path.join(obj_dir, src.replace(".hip", ".o"))
         objs.append(obj)
-        cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", *defines, "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
@@ -52,12 +59,12 @@ def build(force: bool = False, verbose: bool = False) -> str:
         out, _ = pr.communicate()
         if pr.returncode != 0:
             raise RuntimeError(f"hipcc failed on {src}:\n{out}")
-    cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB_PATH] + objs
+    cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", lib_path] + objs
     res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if res.returncode != 0:
         raise RuntimeError(f"link failed:\n{res.stdout}")
-    return LIB_PATH
+    return lib_path
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    print(build(force="--force" in sys.argv, verbose=True, diag="--diag" in sys.argv))

@@ -52,12 +52,18 @@ def _owner_class(config):
 def save_network(path: str, network, training_config=None) -> str:
     """state_dict + configs -> one .npz (see the module docstring)"""
     sd = {k: v.detach().cpu().numpy() for k, v in network.state_dict().items()}
-    features = [*network.config.io_spec.inputs, *network.config.io_spec.targets]
-    schema = {f.extractor_name: f.extractor for f in features}        # reference :78-82: enough to load the network later
-    ds = DatasetConfig(filename="unknown", sources=(), extractors=tuple(schema.values()))
-    extra = {_CFG: np.asarray(network.config.serialize()), _DS: np.asarray(ds.serialize())}
-    if training_config is not None:
-        extra[_TR] = np.asarray(training_config.serialize())
+    extra = {_CFG: np.asarray(network.config.serialize())}
+    if training_config is not None and hasattr(training_config, "dataset") and hasattr(training_config, "training"):
+        # reference :79-81: a TrainingConfig carries the dataset's config and the loop's config; they are stored side by side
+        extra[_DS] = np.asarray(training_config.dataset.serialize())
+        extra[_TR] = np.asarray(training_config.training.serialize())
+    else:
+        # reference :83-87: without one, a schema-only dataset config - enough to load the network later
+        features = [*network.config.io_spec.inputs, *network.config.io_spec.targets]
+        schema = {f.extractor_name: f.extractor for f in features}
+        extra[_DS] = np.asarray(DatasetConfig(filename="unknown", sources=(), extractors=tuple(schema.values())).serialize())
+        if training_config is not None:               # a bare loop config (no dataset of its own)
+            extra[_TR] = np.asarray(training_config.serialize())
     os.makedirs(os.path.dirname(os.path.abspath(path)) or ".", exist_ok=True)
     with open(path, "wb") as f:                                        # (np.savez would append ".npz" to a ".ckpt" name)
         np.savez(f, **sd, **extra)

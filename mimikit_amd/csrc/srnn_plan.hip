@@ -12,6 +12,17 @@
 
 using namespace mmk;
 
+// environment switches of the DIAGNOSTIC build (phase stamps): the product library does not read them
+static inline const char* diag_env(const char* name) {
+#ifdef MMK_DIAG
+  return getenv(name);
+#else
+  (void)name;
+  return nullptr;
+#endif
+}
+
+
 struct SrnnCall {
   int M = 0;
   const int64_t* idx = nullptr;
@@ -454,7 +465,7 @@ static SrnnBottomArgs bottom_args(mmk_srnn_plan* p, const SrnnCall& call, int64_
   a.temperature = call.temperature; a.uniforms = call.uniforms; a.uni_ld = call.uni_ld; a.uni_off = call.uni_off;
   a.logits_out = p->logits; a.logits_ld = p->logits_ld;
   {
-    const char* senv = getenv("MMK_SRNN_STAMPS");
+    const char* senv = diag_env("MMK_SRNN_STAMPS");
     a.stamps = (senv && senv[0] == '1') ? reinterpret_cast<unsigned long long*>(p->tau + 8) : nullptr;
   }
   return a;
@@ -494,7 +505,7 @@ static int emit_step(mmk_srnn_plan* p, const SrnnCall& call, int64_t tau_off, in
       g.h_ring = t.h; g.h_slot_stride = (int64_t)p->Bmax * H;
       g.cnt = t.cnt; g.done = t.done; g.h_gran = t.h_gran;
       {
-        const char* senv = getenv("MMK_SRNN_STAMPS");
+        const char* senv = diag_env("MMK_SRNN_STAMPS");
         g.stamps = (senv && senv[0] == '1') ? reinterpret_cast<unsigned long long*>(p->tau + 16) : nullptr;
       }
       // the up-sampler rides in the same launch behind a grid-wide barrier when the whole grid is resident at once
@@ -743,7 +754,7 @@ static int enqueue_steps(mmk_srnn_plan* p, const SrnnCall& call, int64_t t_begin
 static bool resident_applies(mmk_srnn_plan* p, const SrnnCall& call, int64_t n) {
   const char* renv = getenv("MMK_SRNN_RESIDENT");
   const char* uenv = getenv("MMK_SRNN_FUSED_UP");
-  const bool off = renv && renv[0] == '0', up_off = uenv && uenv[0] == '0';
+  const bool off = (renv && renv[0] == '0') || p->cfg.exec_mode == 1, up_off = uenv && uenv[0] == '0';     // (exec_mode 1: the caller asks for the kernels in turns)
   static const int n_cu = [] {
     int dev = 0, v = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
@@ -833,6 +844,15 @@ extern "C" int mmk_srnn_generate(mmk_srnn_plan* p, int32_t batch, int64_t* idx, 
   return run_steps(p, call, t0, n_steps, true, (hipStream_t)stream);
 }
 
+extern "C" int mmk_srnn_inject_sync_error(mmk_srnn_plan* p, mmk_stream_t stream) {
+  if (!p) return fail(MMK_ERR_INVALID, "srnn_inject_sync_error: null plan");
+  if (!p->committed) return fail(MMK_ERR_STATE, "srnn_inject_sync_error: plan not committed");
+  const int64_t code = 4;                 // the word a timed-out wait of the bottom kernel sets
+  MMK_HIP(hipMemcpyAsync(p->tau + 4, &code, sizeof(code), hipMemcpyHostToDevice, (hipStream_t)stream));
+  MMK_HIP(hipStreamSynchronize((hipStream_t)stream));
+  return MMK_OK;
+}
+
 extern "C" int mmk_srnn_sync_status(mmk_srnn_plan* p, mmk_stream_t stream) {
   if (!p) return fail(MMK_ERR_INVALID, "srnn_sync_status: null plan");
   hipStream_t st = (hipStream_t)stream;
@@ -840,7 +860,6 @@ extern "C" int mmk_srnn_sync_status(mmk_srnn_plan* p, mmk_stream_t stream) {
   if (!p->committed) return MMK_OK;
   int64_t err = 0;
   MMK_HIP(hipMemcpy(&err, p->tau + 4, sizeof(err), hipMemcpyDeviceToHost));
-  if (const char* fe = getenv("MMK_SRNN_FORCE_SYNC_ERROR"); fe && fe[0] == '1' && p->resident_blocks > 0) err = 4;   // test hook
   if (err != 0) {
     MMK_HIP(hipMemset(p->tau + 4, 0, sizeof(int64_t)));
     return fail(MMK_ERR_STATE, "srnn: a wait inside the tier / bottom kernels timed out (code %lld: 3 tier hand-over, 4 bottom kernel waiting for the tiers, "
@@ -855,7 +874,7 @@ extern "C" int64_t mmk_srnn_resident_blocks(const mmk_srnn_plan* p) { return p ?
 extern "C" int mmk_srnn_last_logits(mmk_srnn_plan* p, int32_t batch, float* out, int64_t ld, mmk_stream_t stream) {
   if (!p || !out) return fail(MMK_ERR_INVALID, "srnn_last_logits: null argument");
   if (!p->committed) return fail(MMK_ERR_STATE, "srnn_last_logits: plan not committed");
-  if (const char* senv = getenv("MMK_SRNN_STAMPS"); senv && senv[0] == '1') {
+  if (const char* senv = diag_env("MMK_SRNN_STAMPS"); senv && senv[0] == '1') {
     unsigned long long st[8];
     MMK_HIP(hipStreamSynchronize((hipStream_t)stream));
     MMK_HIP(hipMemcpy(st, p->tau + 8, sizeof(st), hipMemcpyDeviceToHost));

@@ -21,6 +21,16 @@
 
 using namespace mmk;
 
+// environment switches of the DIAGNOSTIC build (phase stamps, timing experiments): the product library does not read them
+static inline const char* diag_env(const char* name) {
+#ifdef MMK_DIAG
+  return getenv(name);
+#else
+  (void)name;
+  return nullptr;
+#endif
+}
+
 struct WnCall {
   int M = 0;
   const void* in0 = nullptr;
@@ -241,6 +251,7 @@ static int derive(mmk_wavenet_plan* p) {
   if (c.head_kind == 0 && (c.mlp_hidden < 1 || c.mlp_n_hidden < 0 || c.mlp_n_hidden > MMK_MAX_MLP_HIDDEN))
     return fail(MMK_ERR_INVALID, "wavenet: bad MLP head geometry");
   if (c.head_kind < 0 || c.head_kind > 2) return fail(MMK_ERR_INVALID, "wavenet: head_kind %d unknown", c.head_kind);
+  if (c.exec_mode < 0 || c.exec_mode > 1) return fail(MMK_ERR_INVALID, "wavenet: exec_mode %d unknown", c.exec_mode);
   if (c.head_kind != 0 && c.q_levels != 0) return fail(MMK_ERR_UNSUPPORTED, "wavenet: linear head needs a continuous input 0");
   if (c.head_kind != 0 && c.out_dim != c.in_dim) return fail(MMK_ERR_UNSUPPORTED, "wavenet: linear head out_dim must equal in_dim");
   p->L = c.n_layers;
@@ -313,7 +324,7 @@ static int derive(mmk_wavenet_plan* p) {
   // C = skips = residuals in {32..256 step 32}, at most one conditioning input of a multiple of 16
   // channels.  Anything else stays on the per-layer launch path.
   const char* env = getenv("MMK_WN_PERSISTENT");
-  bool ok = !(env && env[0] == '0');
+  bool ok = !(env && env[0] == '0') && c.exec_mode != 1;     // (exec_mode 1: the caller asks for the per-layer launch path)
   ok = ok && c.gated && c.q_levels > 0 && c.head_kind == 0 && c.mlp_n_hidden == 0 && c.n_cond <= 1;
   ok = ok && p->C % 32 == 0 && p->C <= 256 && p->S == p->C && c.residuals_dim == p->C && !c.layerwise_inputs && !c.with_affine_residuals;
   for (int l = 0; l < p->L; ++l) ok = ok && (p->has_res[l] != 0) == (l != p->L - 1);   // (reverse_layer_order: launch path)
@@ -776,10 +787,12 @@ extern "C" int mmk_wavenet_commit(mmk_wavenet_plan* p, void* workspace, size_t w
       tab[l].B_wp = p->Bm[l].Wp;
       tab[l].B_bias = p->Bm[l].bias;
     }
+#ifdef MMK_DIAG
     if (const char* x = getenv("MMK_WN_EXPERIMENT_SAME_WEIGHTS"); x && x[0] == '1') {
-      // timing experiment only (results are wrong): every layer reads layer 0's weights, which then stay in L2
+      // timing experiment only (results are wrong; diagnostic build): every layer reads layer 0's weights, which then stay in L2
       for (int l = 1; l < L; ++l) { tab[l].A_wp = tab[0].A_wp; tab[l].B_wp = tab[0].B_wp; }
     }
+#endif
     MMK_HIP(hipMemcpyAsync(p->layer_tab, tab.data(), sizeof(WnLayerTab) * L, hipMemcpyHostToDevice, st));
     std::vector<WnChainIter> it(L + 1);
     if (p->chain || p->pipe) {
@@ -964,7 +977,7 @@ static int run_persistent(mmk_wavenet_plan* p, const WnCall& call, int64_t tau0,
     }
     // hand-off words are zeroed before EVERY launch (epochs restart at 1); the error word after them is sticky
     MMK_HIP(hipMemsetAsync(p->gran_h, 0, (size_t)(p->gran_words - 2) * sizeof(unsigned long long), st));
-    const char* stamp_env = getenv("MMK_WN_STAMPS");
+    const char* stamp_env = diag_env("MMK_WN_STAMPS");
     if (p->lpipe) {
       if (!with_head) return fail(MMK_ERR_STATE, "wavenet: the layer-pipeline kernel has no teacher-forced mode (warm-up is a prefill)");
       MMK_HIP(hipMemsetAsync(p->lp_xg, 0, (size_t)p->lp_gran_words * sizeof(unsigned long long), st));
@@ -1011,8 +1024,8 @@ static int run_persistent(mmk_wavenet_plan* p, const WnCall& call, int64_t tau0,
       k.logits_out = p->logits; k.logits_ld = p->logits_ld;
       k.msg = p->sp_msg; k.hidmsg = p->sp_hidmsg; k.xcd_count = p->xcd_count; k.err_flag = p->err_flag;
       k.stamps = (stamp_env && stamp_env[0] == '1') ? reinterpret_cast<unsigned long long*>(p->tau + 8) : nullptr;
-      k.stamp_stage = getenv("MMK_WN_STAMP_STAGE") ? atoi(getenv("MMK_WN_STAMP_STAGE")) : 1;
-      k.dbg = (k.stamps && getenv("MMK_WN_SPIPE_DBG")) ? atoi(getenv("MMK_WN_SPIPE_DBG")) : 0;
+      k.stamp_stage = diag_env("MMK_WN_STAMP_STAGE") ? atoi(diag_env("MMK_WN_STAMP_STAGE")) : 1;
+      k.dbg = (k.stamps && diag_env("MMK_WN_SPIPE_DBG")) ? atoi(diag_env("MMK_WN_SPIPE_DBG")) : 0;
       MMK_TRY(launch_wavenet_spipe(k, st));
       done += nb;
       continue;
@@ -1093,7 +1106,7 @@ static int run_persistent(mmk_wavenet_plan* p, const WnCall& call, int64_t tau0,
     a.gran_logit = p->gran_logit; a.gran_idx = p->gran_idx;
     a.h_rings = p->h_rings; a.err_flag = p->err_flag;
     {
-      const char* senv = getenv("MMK_WN_STAMPS");
+      const char* senv = diag_env("MMK_WN_STAMPS");
       a.stamps = (senv && senv[0] == '1') ? reinterpret_cast<unsigned long long*>(p->tau + 8) : nullptr;
     }
     MMK_TRY(launch_wavenet_persist(a, st));
@@ -1315,6 +1328,16 @@ extern "C" int mmk_wavenet_mode(const mmk_wavenet_plan* p) {
   return (p && p->persistent) ? (p->spipe ? 5 : (p->lpipe ? 4 : (p->pipe ? 3 : (p->chain ? 2 : 1)))) : 0;
 }
 
+extern "C" int mmk_wavenet_inject_sync_error(mmk_wavenet_plan* p, mmk_stream_t stream) {
+  if (!p) return fail(MMK_ERR_INVALID, "wavenet_inject_sync_error: null plan");
+  if (!p->committed) return fail(MMK_ERR_STATE, "wavenet_inject_sync_error: plan not committed");
+  if (!p->persistent) return MMK_OK;      // (the launch path has no hand-off that could time out)
+  const int32_t one = 1;                  // the word a timed-out wait inside the kernel sets
+  MMK_HIP(hipMemcpyAsync(p->err_flag, &one, sizeof(one), hipMemcpyHostToDevice, (hipStream_t)stream));
+  MMK_HIP(hipStreamSynchronize((hipStream_t)stream));
+  return MMK_OK;
+}
+
 extern "C" int mmk_wavenet_sync_status(mmk_wavenet_plan* p, mmk_stream_t stream) {
   if (!p) return fail(MMK_ERR_INVALID, "wavenet_sync_status: null plan");
   MMK_HIP(hipStreamSynchronize((hipStream_t)stream));
@@ -1323,12 +1346,11 @@ extern "C" int mmk_wavenet_sync_status(mmk_wavenet_plan* p, mmk_stream_t stream)
   MMK_HIP(hipMemcpy(&flag, p->err_flag, sizeof(flag), hipMemcpyDeviceToHost));
   if (flag == 2)
     return fail(MMK_ERR_STATE, "wavenet: the persistent kernel's workgroups were not spread 8 x %d over the XCDs; rerun with MMK_WN_XCD_LOCAL=0 (agent-scope hand-offs)", p->Gn);
-  if (const char* fe = getenv("MMK_WN_FORCE_SYNC_ERROR"); fe && fe[0] == '1') flag = 1;   // test hook: exercise the callers' retry path
   if (flag != 0)
     return fail(MMK_ERR_STATE, "wavenet: a hand-off inside the persistent kernel timed out - its workgroups were not all resident (another kernel "
                 "holding CUs?); the samples of this call are invalid, rerun it (MMK_WN_PERSISTENT=0 selects the per-layer launch path)");
   {
-    const char* senv = getenv("MMK_WN_STAMPS");
+    const char* senv = diag_env("MMK_WN_STAMPS");
     if (senv && senv[0] == '1') {
       unsigned long long st[176];
       MMK_HIP(hipMemcpy(st, p->tau + 8, p->spipe ? sizeof(st) : 24 * sizeof(unsigned long long), hipMemcpyDeviceToHost));

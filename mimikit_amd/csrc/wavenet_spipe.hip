@@ -806,8 +806,14 @@ int wn_spipe_build_image(const WnSpRaw* raw_dev, int L, int C, int C1, const flo
 int launch_wavenet_spipe(const WnSpipeArgs& a, hipStream_t stream) {
   if (a.n_steps <= 0 || a.B <= 0) return MMK_OK;
   if (a.B > 32 || a.L > kSpMaxLayers || a.C != kC) return fail(MMK_ERR_UNSUPPORTED, "wavenet stage pipeline: %d clips, %d layers, %d channels", a.B, a.L, a.C);
-  if (a.stamps) hipLaunchKernelGGL(wavenet_spipe_kernel<true>, dim3(256), dim3(kThreads), 0, stream, a);
-  else hipLaunchKernelGGL(wavenet_spipe_kernel<false>, dim3(256), dim3(kThreads), 0, stream, a);
+#ifdef MMK_DIAG
+  if (a.stamps) {      // the stamped instantiation (and its timing switches) exist in the diagnostic build only
+    hipLaunchKernelGGL(wavenet_spipe_kernel<true>, dim3(256), dim3(kThreads), 0, stream, a);
+    MMK_HIP(hipGetLastError());
+    return MMK_OK;
+  }
+#endif
+  hipLaunchKernelGGL(wavenet_spipe_kernel<false>, dim3(256), dim3(kThreads), 0, stream, a);
   MMK_HIP(hipGetLastError());
   return MMK_OK;
 }

@@ -12,9 +12,12 @@ from typing import Optional, Sequence
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmmk_hip.so")
+# MMK_DIAG_LIB=1 (read once, at import) selects the diagnostic build (`python -m mimikit_amd.build --diag`): the same library with
+# in-kernel phase stamps and the timing experiments compiled in; the product library contains neither
+LIB_PATH = os.path.join(_HERE, "libmmk_hip_diag.so" if os.environ.get("MMK_DIAG_LIB") == "1" else "libmmk_hip.so")
 
 MAX_LAYERS, MAX_COND, MAX_TIERS = 128, 4, 8
+ABI_VERSION = 2          # include/mmk.h: MMK_ABI_VERSION (bumped whenever a config struct or a signature changes)
 ACT = {"none": 0, None: 0, "Identity": 0, "Tanh": 1, "Sigmoid": 2, "Mish": 3, "Abs": 4, "ReLU": 5}
 
 i32, i64, f32, vp, cp = C.c_int32, C.c_int64, C.c_float, C.c_void_p, C.c_char_p
@@ -31,7 +34,7 @@ class WaveNetConfig(C.Structure):
         ("n_cond", i32), ("cond_in_dim", i32 * MAX_COND), ("cond_dim", i32 * MAX_COND),
         ("bias", i32), ("gated", i32), ("head_kind", i32), ("mlp_hidden", i32), ("mlp_n_hidden", i32),
         ("out_dim", i32), ("learn_temp", i32), ("min_temp", f32), ("max_batch", i32),
-        ("res_explicit", i32), ("layer_has_res", i32 * MAX_LAYERS), ("layerwise_inputs", i32), ("with_affine_residuals", i32),
+        ("res_explicit", i32), ("layer_has_res", i32 * MAX_LAYERS), ("layerwise_inputs", i32), ("exec_mode", i32), ("with_affine_residuals", i32),
     ]
 
 
@@ -39,7 +42,7 @@ class SrnnConfig(C.Structure):
     _fields_ = [
         ("n_tiers", i32), ("frame_size", i32 * MAX_TIERS), ("hidden_dim", i32), ("rnn_kind", i32),
         ("rnn_bias", i32), ("h0_ones", i32), ("q_levels", i32), ("mlp_hidden", i32), ("mlp_n_hidden", i32),
-        ("learn_temp", i32), ("min_temp", f32), ("max_batch", i32), ("n_rnn", i32),
+        ("learn_temp", i32), ("min_temp", f32), ("max_batch", i32), ("n_rnn", i32), ("exec_mode", i32),
     ]
 
 
@@ -85,6 +88,7 @@ _SIGNATURES = {
                                         C.POINTER(C.c_double), C.POINTER(i64), vp]),
     "mmk_wavenet_mode": (i32, [vp]),
     "mmk_wavenet_sync_status": (i32, [vp, vp]),
+    "mmk_wavenet_inject_sync_error": (i32, [vp, vp]),
     "mmk_srnn_plan_create": (i32, [C.POINTER(SrnnConfig), C.POINTER(vp)]),
     "mmk_srnn_plan_destroy": (None, [vp]),
     "mmk_srnn_plan_bind": (i32, [vp, cp, vp, i64]),
@@ -96,6 +100,7 @@ _SIGNATURES = {
     "mmk_srnn_last_logits": (i32, [vp, i32, vp, i64, vp]),
     "mmk_srnn_resident_blocks": (i64, [vp]),
     "mmk_srnn_sync_status": (i32, [vp, vp]),
+    "mmk_srnn_inject_sync_error": (i32, [vp, vp]),
     "mmk_s2s_plan_create": (i32, [C.POINTER(S2SConfig), C.POINTER(vp)]),
     "mmk_s2s_plan_destroy": (None, [vp]),
     "mmk_s2s_plan_bind": (i32, [vp, cp, vp, i64]),
@@ -128,8 +133,9 @@ def load_library(path: Optional[str] = None):
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
-    if lib.mmk_abi_version() != 1:
-        raise NativeError(f"ABI version mismatch: library reports {lib.mmk_abi_version()}, binding expects 1")
+    if lib.mmk_abi_version() != ABI_VERSION:
+        raise NativeError(f"ABI version mismatch: library reports {lib.mmk_abi_version()}, binding expects {ABI_VERSION} "
+                          "(a stale libmmk_hip.so: rebuild with `python -m mimikit_amd.build`)")
     _lib = lib
     return lib
 
@@ -396,9 +402,20 @@ def pack_launch_count() -> int:
 
 def weights_token(module: torch.nn.Module):
     """identity of a module's weights as a plan packed them: storage address, in-place version counter and shape of every
-    state_dict entry.  Optimiser steps and ``load_state_dict`` bump the version, ``.to(device)`` moves the storage, so an
-    unchanged token means the packed copy inside a committed plan is still current."""
-    return tuple((k, v.data_ptr(), v._version, tuple(v.shape)) for k, v in module.state_dict(keep_vars=True).items())
+    state_dict entry, plus a fingerprint of the CONTENT.  Optimiser steps and ``load_state_dict`` bump the version,
+    ``.to(device)`` moves the storage - but a write through ``.data`` (``p.data.copy_(ema)``, weight surgery) does neither,
+    so the bit patterns of all entries are summed on their device as well (one concatenation + one 64-bit integer sum + one
+    read-back per ``before_generate``: ~0.1 ms next to a generation of seconds).  An unchanged token means the packed copy
+    inside a committed plan is still current."""
+    entries = module.state_dict(keep_vars=True)
+    ident = tuple((k, v.data_ptr(), v._version, tuple(v.shape)) for k, v in entries.items())
+    words = [v.detach().reshape(-1).view(torch.int32) for v in entries.values() if v.dtype == torch.float32 and v.numel() > 0]
+    if not words:
+        return ident, 0
+    bits = torch.cat(words).to(torch.int64)
+    # the plain sum misses a swap of two values; the second sum weights every word by its position (mod a prime)
+    pos = torch.arange(1, bits.numel() + 1, device=bits.device, dtype=torch.int64) % 1000003
+    return ident, (int(bits.sum()), int((bits * pos).sum()))
 
 
 def abs_ptr(view: torch.Tensor, t_first: int) -> int:
@@ -484,6 +501,10 @@ class WaveNetPlan(_Plan):
         """wait for the stream and raise if a hand-off inside the persistent kernel timed out"""
         check(self._lib.mmk_wavenet_sync_status(self.handle, stream_ptr(self.device)), "mmk_wavenet_sync_status")
 
+    def inject_sync_error(self):
+        """fault injection for tests: the next ``sync_status`` fails as after a timed-out hand-off (include/mmk.h)"""
+        check(self._lib.mmk_wavenet_inject_sync_error(self.handle, stream_ptr(self.device)), "mmk_wavenet_inject_sync_error")
+
     def profile_steps(self, in0: torch.Tensor, cond: Sequence[torch.Tensor], t0: int, n_steps: int, t_first: int = 0):
         """measurement aid: per-kernel-class device time from HIP events (see include/mmk.h);
         returns {"layer_a": (ms_total, launches), "layer_b": ..., "other": ...}"""
@@ -532,6 +553,10 @@ class SrnnPlan(_Plan):
     def sync_status(self):
         """wait for the stream and raise if a wait inside the resident-mode kernels timed out"""
         check(self._lib.mmk_srnn_sync_status(self.handle, stream_ptr(self.device)), "mmk_srnn_sync_status")
+
+    def inject_sync_error(self):
+        """fault injection for tests: the next ``sync_status`` reports a timed-out wait (include/mmk.h)"""
+        check(self._lib.mmk_srnn_inject_sync_error(self.handle, stream_ptr(self.device)), "mmk_srnn_inject_sync_error")
 
     def resident_blocks(self) -> int:
         """generate blocks run in resident mode so far (diagnostic, see include/mmk.h)"""

@@ -203,6 +203,8 @@ class SampleRNN(ARMWithHidden, nn.Module):
         return tuple(mod(prev) for mod in self.output_modules)
 
     # -- HIP plan ---------------------------------------------------------------------
+    _exec_mode = 0          # 1 while a batch is being redone with the kernels in turns (mmk_srnn_config.exec_mode)
+
     def _describe(self, max_batch: int) -> native.SrnnConfig:
         cfg, io = self._config, self._config.io_spec
         unsupported = []
@@ -242,6 +244,7 @@ class SampleRNN(ARMWithHidden, nn.Module):
         c.rnn_kind = {"lstm": 0, "gru": 1, "rnn": 2}[str(cfg.rnn_class)]
         c.rnn_bias = int(cfg.rnn_bias)
         c.n_rnn = int(cfg.n_rnn)
+        c.exec_mode = int(self._exec_mode)
         c.h0_ones = int(str(cfg.h0_init) == "ones")
         c.max_batch = max_batch
         return c
@@ -255,6 +258,7 @@ class SampleRNN(ARMWithHidden, nn.Module):
         if self._plan is None or self._plan_batch < batch or self._plan.device != device:
             self._plan = native.SrnnPlan(self._describe(max(batch, 1)), device)
             self._plan_batch = max(batch, 1)
+            self._resident_seen = 0                          # (the new plan's resident-block counter starts over)
             rebuilt = True
         if rebuilt or refresh_weights:
             token = native.weights_token(self)
@@ -344,24 +348,21 @@ class SampleRNN(ARMWithHidden, nn.Module):
         self.reset_hidden()
 
     def _redo_in_turns(self, err):
-        import os
         import warnings
         blocks, self._blocks = getattr(self, "_blocks", []), []
-        if not blocks or getattr(self, "_redoing", False):
+        if not blocks or self._exec_mode == 1:
             raise err
         warnings.warn(f"{err}; regenerating this batch with the tier and bottom kernels in turns")
-        old = os.environ.get("MMK_SRNN_RESIDENT")
-        os.environ["MMK_SRNN_RESIDENT"] = "0"
-        self._redoing = True
+        self._exec_mode = 1                      # the next plan is created with exec_mode = 1: no resident mode
         try:
+            self._plan = None
             first_tensors, first_t0 = blocks[0][0], blocks[0][1]
             self.before_generate((first_tensors[0][:, :first_t0],), None)
             for tensors, t0, n_steps, params in blocks:
                 self.generate_block(tensors, t0, n_steps, **params)
             torch.cuda.synchronize(self.device)
         finally:
-            self._redoing = False
-            if old is None:
-                os.environ.pop("MMK_SRNN_RESIDENT", None)
-            else:
-                os.environ["MMK_SRNN_RESIDENT"] = old
+            self._exec_mode = 0
+            self._blocks = []
+            self._plan = None                    # the next generation may run resident again
+            self._next_t = None

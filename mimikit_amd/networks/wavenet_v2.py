@@ -293,6 +293,8 @@ class WaveNet(ARM, nn.Module):
         return self._window_step(tuple(x[:, :rf] for x in inputs), t=rf, **parameters)
 
     # -- HIP plan ---------------------------------------------------------------------
+    _exec_mode = 0          # 1 while a batch is being redone on the per-layer launch path (mmk_wavenet_config.exec_mode)
+
     def _describe(self, max_batch: int) -> native.WaveNetConfig:
         cfg, io = self._config, self._config.io_spec
         unsupported = []
@@ -318,6 +320,7 @@ class WaveNet(ARM, nn.Module):
         for i, layer in enumerate(self.layers):
             c.kernel_size[i], c.dilation[i] = layer.kernel_size, layer.dilation
             c.layer_has_res[i] = int(layer.has_residuals)
+        c.exec_mode = int(self._exec_mode)
         c.layerwise_inputs = int(cfg.layerwise_inputs)
         c.with_affine_residuals = int(cfg.with_affine_residuals)
         first = self.input_modules[0][0]
@@ -508,31 +511,26 @@ class WaveNet(ARM, nn.Module):
             # once on the per-layer launch path, which needs no co-residency; if that is not possible the error is raised.
             try:
                 self._plan.sync_status()
+                self._blocks = []               # (nothing to redo: drop the references to the loop's tensors)
             except native.NativeError as err:
                 self._redo_on_launch_path(err)
 
     def _redo_on_launch_path(self, err):
-        import os
         import warnings
         blocks, self._blocks = getattr(self, "_blocks", []), []
-        if not blocks or getattr(self, "_redoing", False):
+        if not blocks or self._exec_mode == 1:
             raise err
         warnings.warn(f"{err}; regenerating this batch on the per-layer launch path")
-        old = os.environ.get("MMK_WN_PERSISTENT")
-        os.environ["MMK_WN_PERSISTENT"] = "0"
-        self._redoing = True
+        self._exec_mode = 1                     # the next plan is created with exec_mode = 1: one fused kernel per layer half
         try:
-            self._plan = None                   # the mode is chosen when the plan is created
+            self._plan = None
             first_tensors, first_t0 = blocks[0][0], blocks[0][1]
             self.before_generate(tuple(x[:, :first_t0] for x in first_tensors), None)
             for tensors, t0, n_steps, params in blocks:
                 self.generate_block(tensors, t0, n_steps, **params)
             torch.cuda.synchronize(self.device)
         finally:
-            self._redoing = False
-            if old is None:
-                os.environ.pop("MMK_WN_PERSISTENT", None)
-            else:
-                os.environ["MMK_WN_PERSISTENT"] = old
+            self._exec_mode = 0
+            self._blocks = []
             self._plan = None                   # the next generation gets a persistent plan again
             self._next_t = None

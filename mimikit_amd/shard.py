@@ -46,19 +46,20 @@ def gather_clips(local: torch.Tensor, dst: int = 0, group=None) -> Optional[torc
     receives data (the optional gather of the finished clips, 4.9 MB per rank at BASELINE config 4)"""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return local
-    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    # `dst` is a GLOBAL rank (what torch.distributed.gather takes); inside a sub-group the group rank differs from it
+    world, is_dst = dist.get_world_size(group), dist.get_rank() == dst
     n_local = torch.tensor([local.size(0)], dtype=torch.int64, device=local.device)
-    sizes = [torch.zeros(1, dtype=torch.int64, device=local.device) for _ in range(world)] if rank == dst else None
+    sizes = [torch.zeros(1, dtype=torch.int64, device=local.device) for _ in range(world)] if is_dst else None
     dist.gather(n_local, sizes, dst=dst, group=group)
-    # every rank pads to the size clip_slice gives the first rank (the largest one), so that no second round is needed
-    # to agree on a common shape: ranks differ by at most one clip
+    # gather needs one shape on every rank: all pad to the largest share (a max over the ranks - clip_slice shares differ by
+    # at most one clip, but the callers' tensors need not come from clip_slice)
     biggest = torch.tensor([local.size(0)], dtype=torch.int64, device=local.device)
     dist.all_reduce(biggest, op=dist.ReduceOp.MAX, group=group)
     padded = torch.zeros((int(biggest), *local.shape[1:]), dtype=local.dtype, device=local.device)
     padded[:local.size(0)] = local
-    parts: Optional[List[torch.Tensor]] = [torch.empty_like(padded) for _ in range(world)] if rank == dst else None
+    parts: Optional[List[torch.Tensor]] = [torch.empty_like(padded) for _ in range(world)] if is_dst else None
     dist.gather(padded, parts, dst=dst, group=group)
-    if rank != dst:
+    if not is_dst:
         return None
     return torch.cat([p[:int(n)] for p, n in zip(parts, sizes)], dim=0)
 

@@ -6,7 +6,7 @@ mkdir -p gpurun_out
 for ST in ${STAMP_SETS:-0:0:0 3:0:0 6:0:0 7:0:0 7:5:0}; do
   IFS=: read -r S O W <<< "$ST"
   echo "== stage $S owner $O wave ${W:-0}" >> gpurun_out/pipe_stamps.log
-  MMK_WN_STAMPS=1 MMK_WN_STAMP_STAGE=$S MMK_WN_STAMP_OWNER=$O MMK_WN_STAMP_WAVE=${W:-0} timeout 300 python bench.py --steps 1 --warmup 0 --seconds 0.064 --no-cpu-baseline 2>&1 | grep -E "stamps" | tail -1 >> gpurun_out/pipe_stamps.log
+  MMK_DIAG_LIB=1 MMK_WN_STAMPS=1 MMK_WN_STAMP_STAGE=$S MMK_WN_STAMP_OWNER=$O MMK_WN_STAMP_WAVE=${W:-0} timeout 300 python bench.py --steps 1 --warmup 0 --seconds 0.064 --no-cpu-baseline 2>&1 | grep -E "stamps" | tail -1 >> gpurun_out/pipe_stamps.log
 done
 python - <<'PY'
 import re

@@ -7,5 +7,5 @@ echo "pytest exit: $?" >> gpurun_out/pytest_wn.log
 tail -25 gpurun_out/pytest_wn.log
 timeout 300 python bench.py --no-cpu-baseline > gpurun_out/bench_wn.json 2> gpurun_out/bench_wn.err; echo "bench exit $?"
 cut -c1-400 gpurun_out/bench_wn.json; grep -o '"roofline".*' gpurun_out/bench_wn.json | cut -c1-600
-MMK_WN_STAMPS=1 timeout 300 python bench.py --steps 1 --warmup 0 --seconds 0.064 --no-cpu-baseline 2>&1 | grep -E "stamps" | cut -c1-1200
+MMK_DIAG_LIB=1 MMK_WN_STAMPS=1 timeout 300 python bench.py --steps 1 --warmup 0 --seconds 0.064 --no-cpu-baseline 2>&1 | grep -E "stamps" | cut -c1-1200
 timeout 300 python bench.py --workload wavenet_cfg2 --no-cpu-baseline 2>/dev/null | grep -o '"value".\{0,30\}\|"us_per_ar_step".\{0,10\}'

@@ -4,6 +4,7 @@ import sys
 
 import torch
 
+os.environ["MMK_DIAG_LIB"] = "1"          # the diagnostic build: python -m mimikit_amd.build --diag
 os.environ["MMK_SRNN_STAMPS"] = "1"
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench  # noqa: E402

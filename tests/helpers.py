@@ -196,6 +196,15 @@ def margin_ok(raw, min_gap=5e-5):
     return (top[..., 0] - top[..., 1]) > min_gap
 
 
+def excluded_fraction(ok, what, limit=0.02):
+    """share of the checked (clip, step) pairs whose oracle top-2 gap is too small for a bit-exact class comparison
+    (margin_ok False): printed, and bounded - a regression that flattens the logits must not hide in the excluded share"""
+    frac = 1.0 - float(T(ok).float().mean())
+    print(f"[margin] {what}: {frac * 100:.3f} % of {T(ok).numel()} checked steps excluded (top-2 gap <= 5e-5); limit {limit * 100:.1f} %")
+    assert frac <= limit, f"{what}: {frac * 100:.2f} % of the steps have near-tied logits"
+    return frac
+
+
 def sampled_picks_ok(raw, temperature, uniforms, picks, min_temp=1e-4, tol=2e-5):
     """Sampled decode, checked step by step: `raw` (B, n, q+1) are the oracle's head outputs for the history the device
     actually produced (teacher forcing), `picks` (B, n) the device's classes, drawn by inverting the CDF of

@@ -89,10 +89,106 @@ def test_cfg4_wavenet_30x256_conditioned_32_clips(device):
         return n_ok / n_all
 
     one_per_group = [4 * g + (g % 4) for g in range(8)]
+    pick_gen = torch.Generator().manual_seed(4)
+    mid_steps = sorted(set(int(x) for x in torch.randint(2, n - 4, (40,), generator=pick_gen)))[:36]
     with host_threads(32):
         frac = check(list(range(B)), range(P + n - 4, P + n))
-        assert frac > 0.9
         check(one_per_group, [P, P + 1, P + 1023, P + 1024, P + 1025])
+        # 36 random steps inside the blocks, four clips each (another four every time): a transient glitch of a hand-over that
+        # leaves the rings intact would show here
+        seen = ok_seen = 0
+        for k, s_ in enumerate(mid_steps):
+            clips = [(7 * k + 8 * j) % B for j in range(4)]
+            f = check(clips, [P + s_])
+            seen += 4
+            ok_seen += round(f * 4)
+    print(f"[margin] cfg 4 greedy: last 4 steps of 32 clips {100 * (1 - frac):.2f} % excluded; {len(mid_steps)} mid-block steps x 4 clips "
+          f"{100 * (1 - ok_seen / seen):.2f} % excluded")
+    assert 1 - frac <= 0.02 and 1 - ok_seen / seen <= 0.05
+
+    # ---- sampled decode at the same size (another instantiation of the head): every checked pick lies in the oracle's CDF
+    # interval of its uniform draw (helpers.sampled_picks_ok), for the device's own history
+    temp = torch.linspace(0.6, 1.4, B)
+    torch.manual_seed(8)
+    u = torch.rand((B, n), device=device).cpu()
+    torch.manual_seed(8)
+    idx = torch.cat([prompt, torch.zeros(B, n, dtype=torch.int64)], 1).to(device)
+    net.before_generate((idx[:, :P], cond_d[:, :P]), None)
+    net.generate_block((idx, cond_d), P, n, temperature=temp)
+    net.after_generate((idx,), None)
+    hist_s = idx.cpu()
+    assert len(torch.unique(hist_s[:, P:])) > 64
+    n_exact = n_all = 0
+    with host_threads(32):
+        for k, s_ in enumerate([0, 1, 1023, 1024, n - 2, n - 1] + mid_steps[:10]):
+            clips = list(range(B)) if s_ == n - 1 else [(5 * k + 8 * j) % B for j in range(4)]
+            t = P + s_
+            raw = O.wavenet_window_forward(sd, (hist_s[clips, t - rf:t], cond[clips, t - rf:t]), n_cond=1, **arch)
+            okp, exact = H.sampled_picks_ok(raw, temp[clips], u[clips, s_:s_ + 1], hist_s[clips, t:t + 1])
+            assert bool(okp.all()), f"sampled step {s_}"
+            n_exact += int(exact.sum())
+            n_all += len(clips)
+    assert n_exact >= 0.97 * n_all
+
+
+def test_cfg4_composed_products_against_the_reference_association(device, monkeypatch):
+    """The stage pipeline multiplies pre-composed matrices (tap 1 . W_res of the layer below, fc0 . W_skip: fp64 products rounded
+    once); the per-layer launch path keeps the reference's association.  Same window, same step, both against the oracle: the
+    raw head outputs of the two paths differ by fp32 re-association only - the difference is printed and held to the logit
+    tolerance, so the share of the error budget that composition uses is on record."""
+    net, sd, arch = cfg4_network()
+    net = net.to(device)
+    rf, B = net.rf, 8
+    gen = torch.Generator().manual_seed(45)
+    win = torch.randint(0, 256, (B, rf), generator=gen)
+    cond = torch.rand(B, rf + 1, 513, generator=gen)
+    raws = {}
+    for mode, env in (("composed", {}), ("reference association", {"MMK_WN_PERSISTENT": "0"})):
+        for k in ("MMK_WN_PERSISTENT", "MMK_WN_SPIPE", "MMK_WN_PIPE", "MMK_WN_CHAIN"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        net._plan = None
+        net.generate_step((win.to(device), cond[:, :rf].to(device)), t=rf)
+        assert net._plan.stage_pipelined == (mode == "composed")
+        raws[mode] = net._plan.last_logits(B).cpu()
+        net.after_generate((), None)
+    with host_threads(32):
+        want = O.wavenet_window_forward(sd, (win, cond[:, :rf]), n_cond=1, **arch)[:, 0]
+    d_paths = float((raws["composed"] - raws["reference association"]).abs().max())
+    d_comp = float((raws["composed"] - want).abs().max())
+    d_ref = float((raws["reference association"] - want).abs().max())
+    scale = float(want.abs().max())
+    print(f"[composition] cfg 4 raw head outputs (|max| {scale:.3f}): composed vs launch path {d_paths:.3e}, composed vs oracle {d_comp:.3e}, "
+          f"launch path vs oracle {d_ref:.3e}")
+    assert torch.allclose(raws["composed"], want, **LOGIT_TOL) and torch.allclose(raws["reference association"], want, **LOGIT_TOL)
+    assert d_paths <= 2e-4 + 1e-4 * scale
+
+
+def test_cfg5_composed_products_against_the_reference_association(device, monkeypatch):
+    """Seq2Seq cfg 5 with and without the pre-multiplied dec.fc . enc.fc_out (MMK_S2S_COMPOSED=0: the reference's association):
+    one generate_step of 16 clips, both against the oracle; the difference between the two paths is printed and bounded"""
+    io = mmk.IOSpec.magspec_io(mmk.IOSpec.MagSpecIOConfig(sr=22050, n_fft=1024, hop_length=256))
+    net = mmk.Seq2SeqLSTMNetwork.from_config(mmk.Seq2SeqLSTMNetwork.Config(io_spec=io)).eval()
+    sd = load_recipe(net, seed=505, gain=1.5)
+    net.to(device)
+    x = torch.rand(16, 8, 513, generator=torch.Generator().manual_seed(56))
+    with host_threads(32):
+        want = O.s2s_step(sd, x, hop=8)
+    outs = {}
+    for mode, env in (("composed", None), ("reference association", "0")):
+        monkeypatch.delenv("MMK_S2S_COMPOSED", raising=False)
+        if env is not None:
+            monkeypatch.setenv("MMK_S2S_COMPOSED", env)
+        net._plan = None
+        outs[mode] = net.generate_step((x.to(device),), t=8).cpu()
+    scale = float(want.abs().max())
+    d_paths = float((outs["composed"] - outs["reference association"]).abs().max())
+    print(f"[composition] cfg 5 frames (|max| {scale:.3f}): composed vs uncomposed {d_paths:.3e}, composed vs oracle "
+          f"{float((outs['composed'] - want).abs().max()):.3e}, uncomposed vs oracle {float((outs['reference association'] - want).abs().max()):.3e}")
+    for o in outs.values():
+        assert float((o - want).abs().max()) <= 1e-4 * scale
+    assert d_paths <= 1e-4 * scale
 
 
 def test_cfg5_seq2seq_d1024_hop8_64_clips(device):
@@ -142,7 +238,7 @@ def test_cfg1_sample_rnn_defaults_h256_lstm(device):
     want, raw = o.generate(prompt, n, keep_logits=True, forced=got)
     ok = H.margin_ok(raw.numpy())
     assert bool(((got[:, P:] == want[:, P:]) | ~ok).all())
-    assert float(ok.float().mean()) > 0.9
+    H.excluded_fraction(ok, "cfg 1 SampleRNN defaults, 2 clips x 600 steps")
     assert torch.allclose(last_raw[ok[:, -1]], raw[:, -1][ok[:, -1]], **LOGIT_TOL)
     # the same network through the loop with a temperature, as the reference's test runs it
     loop = mmk.GenerateLoopV2(mmk.GenerateLoopV2.Config(display_waveform=False, parameters=dict(temperature=(1.,))), net, 512,
@@ -171,7 +267,7 @@ def test_cfg3_sample_rnn_h512_gru_64_clips(device):
     want, raw = o.generate(prompt, n, keep_logits=True, forced=got)
     ok = H.margin_ok(raw.numpy())
     assert bool(((got[:, P:] == want[:, P:]) | ~ok).all())
-    assert float(ok.float().mean()) > 0.9
+    H.excluded_fraction(ok, "cfg 3 SampleRNN (16, 4, 1) GRU 512, 64 clips x 130 steps")
     assert torch.allclose(last_raw[ok[:, -1]], raw[:, -1][ok[:, -1]], **LOGIT_TOL)
     # sampled decode at the same size: every pick sits in the CDF interval of its uniform draw
     temp = torch.linspace(0.5, 1.5, B)
@@ -201,9 +297,12 @@ def test_cfg2_wavenet_10x64_8_clips_every_step(device):
     net.after_generate((idx,), None)
     got = idx.cpu()
     steps = list(range(0, 40)) + list(range(n - 40, n))      # 80 window forwards of 8 clips on the host
+    oks = []
     for s in steps:
         t = P + s
         raw = O.wavenet_window_forward(sd, (got[:, t - net.rf:t],), **arch)
         pick = O.categorical(O.mlp_logits(raw))[:, 0]
         gap_ok = H.margin_ok(raw.numpy())[:, 0]
+        oks.append(gap_ok)
         assert bool(((pick == got[:, t]) | ~gap_ok).all()), f"step {s}"
+    H.excluded_fraction(torch.stack(oks), "cfg 2 WaveNet 10 x 64, 8 clips x 80 steps")

@@ -175,7 +175,7 @@ def test_library_exports_every_declared_symbol():
     declared = set(re.findall(r"\b(mmk_[a-z0-9_]+)\s*\(", header))
     declared -= {"mmk_stream_t"}
     lib = native.load_library()
-    assert lib.mmk_abi_version() == 1
+    assert lib.mmk_abi_version() == native.ABI_VERSION == int(re.search(r"#define MMK_ABI_VERSION (\d+)", header).group(1))
     for name in sorted(declared):
         assert hasattr(lib, name), f"{name} is declared in include/mmk.h but not exported"
     assert declared == set(native.EXPORTED_SYMBOLS), declared ^ set(native.EXPORTED_SYMBOLS)
