@@ -146,11 +146,17 @@ class WaveNetJob:
             us = start.elapsed_time(stop) * 1e3
             nbytes = self.step_bytes() * n
             achieved = nbytes / (us * 1e-6) / 1e9
-            traffic = None
-            try:  # PMC-derived HBM bytes of one 1024-step launch (separate rocprofv3 --pmc passes, profiles/)
+            kshort = ("wavenet_spipe_kernel" if plan.stage_pipelined else "wavenet_pipe_kernel" if plan.pipelined
+                      else "wavenet_lpipe_kernel" if plan.layer_pipelined else "wavenet_chain_kernel" if plan.chain else "wavenet_persist_kernel")
+            traffic, traffic_source = None, None
+            try:  # PMC-derived HBM bytes of one 1024-step launch: NOT measured in this run (counters need their own rocprofv3
+                  # --pmc passes) - taken from profiles/traffic.json, and only if that entry was collected on THIS kernel
                 with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
-                    per_step = json.load(f).get(self.name, {}).get("persistent", {}).get("bytes_per_step")
-                traffic = int(per_step * n) if per_step else None
+                    entry = json.load(f).get(self.name, {}).get("persistent", {})
+                if entry.get("bytes_per_step") and str(entry.get("kernel", "")).startswith(kshort):
+                    traffic = int(entry["bytes_per_step"] * n)
+                    traffic_source = (f"profiles/traffic.json, build {entry.get('build')} (commit {entry.get('commit')}): rocprofv3 --pmc "
+                                      f"FETCH_SIZE / WRITE_SIZE passes of {entry.get('kernel')}, scaled to {n} steps; not re-measured in this run")
             except (OSError, ValueError):
                 pass
             kname = ("wavenet_spipe_kernel (one layer per stage of 8 CUs, weights in registers, clips streamed through one at a time)" if plan.stage_pipelined
@@ -159,7 +165,7 @@ class WaveNetJob:
                      else "wavenet_chain_kernel (one hand-off per layer)" if plan.chain else "wavenet_persist_kernel")
             return {"bound": "hbm", "kernel": kname + ": all layers + head of every step of a block",
                     "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_source,
                     "algorithmic_bytes_per_launch": nbytes, "avg_launch_us": round(us, 1), "launches_timed": 1,
                     "steps_per_launch": n, "us_per_step_in_kernel": round(us / n, 2)}
         stats = plan.profile_steps(self.idx, self.cond, p, 48)
