@@ -303,9 +303,19 @@ class SrnnJob:
         us = start.elapsed_time(stop) * 1e3
         nbytes = self.step_bytes() * n
         achieved = nbytes / (us * 1e-6) / 1e9
+        traffic, traffic_source = None, None
+        try:  # PMC-derived HBM bytes per step (separate rocprofv3 --pmc passes with the kernels in turns, profiles/): not measured in this run
+            with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+                entry = json.load(f).get("srnn_cfg3", {}).get("step_chain", {})
+            if entry.get("bytes_per_step"):
+                traffic = int(entry["bytes_per_step"] * n)
+                traffic_source = (f"profiles/traffic.json, build {entry.get('build')} (commit {entry.get('commit')}): rocprofv3 --pmc FETCH_SIZE / "
+                                  f"WRITE_SIZE passes of {entry.get('kernel')} with the kernels in turns, scaled to {n} steps; not re-measured in this run")
+        except (OSError, ValueError):
+            pass
         return {"bound": "hbm", "kernel": "SampleRNN step chain (srnn_bottom_kernel + srnn_gru_kernel + up-sampler GEMM), one generate block",
                 "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-                "traffic": None, "algorithmic_bytes_per_launch": nbytes, "avg_launch_us": round(us, 1), "launches_timed": 1,
+                "traffic": traffic, "traffic_source": traffic_source, "algorithmic_bytes_per_launch": nbytes, "avg_launch_us": round(us, 1), "launches_timed": 1,
                 "steps_per_launch": n, "us_per_step": round(us / n, 2)}
 
     def cpu_baseline(self, budget_s):
