@@ -55,6 +55,10 @@ const char* mmk_last_error(void);
  * The host mirror re-commits a plan only when a parameter changed (in the reference `before_generate` never
  * touches the weights, mimikit/networks/wavenet_v2.py:368-445); tests assert that through this counter. */
 int64_t mmk_pack_launch_count(void);
+/* Content fingerprint of `n_words` 32-bit words on the device (position-mixed hash, summed as 64-bit integers: deterministic): the host
+ * mirror takes it over the concatenated weights where a generation starts, to notice writes through `tensor.data` that no version
+ * counter records.  `out`: one uint64 on the device (cleared by the call). */
+int mmk_fingerprint_u32(const void* words, int64_t n_words, uint64_t* out, mmk_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * Feature functionals

@@ -336,6 +336,38 @@ int pack_bias(float* dst, int row0, int row_step, int n_rows, const float* src, 
 // ---- exported building blocks -------------------------------------------------
 extern "C" int64_t mmk_pack_launch_count(void) { return mmk::g_pack_launches.load(std::memory_order_relaxed); }
 
+// Content fingerprint of a buffer of 32-bit words: every word is mixed with its position (a multiplicative hash, so that sign flips,
+// swaps and shifted copies all move the sum) and the results are added up as 64-bit integers - addition commutes, so the order the
+// waves finish in does not matter.  One launch over the concatenated weights of a network; the host compares the number with the one
+// it took when it last committed a plan (mimikit_amd/native.py: WeightsTracker).
+namespace mmk {
+__global__ __launch_bounds__(256) void fingerprint_kernel(const uint32_t* __restrict__ w, int64_t n, unsigned long long* __restrict__ out) {
+  unsigned long long acc = 0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    uint32_t h = (w[i] ^ ((uint32_t)i * 0x9E3779B1u)) * 0x85EBCA77u;
+    h ^= h >> 15;
+    h *= 0xC2B2AE3Du;
+    acc += (unsigned long long)(h ^ (h >> 13)) + ((unsigned long long)w[i] << 20);
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+  if ((threadIdx.x & 63) == 0 && acc != 0) atomicAdd(out, acc);
+}
+}  // namespace mmk
+
+extern "C" int mmk_fingerprint_u32(const void* words, int64_t n_words, uint64_t* out, mmk_stream_t stream) {
+  using namespace mmk;
+  if (!out || n_words < 0 || (n_words > 0 && !words)) return fail(MMK_ERR_INVALID, "fingerprint: bad arguments");
+  MMK_HIP(hipMemsetAsync(out, 0, sizeof(uint64_t), (hipStream_t)stream));
+  if (n_words == 0) return MMK_OK;
+  int64_t blocks = (n_words + 255) / 256;
+  blocks = blocks > 2048 ? 2048 : blocks;
+  hipLaunchKernelGGL(fingerprint_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const uint32_t*)words, n_words,
+                     (unsigned long long*)out);
+  MMK_HIP(hipGetLastError());
+  return MMK_OK;
+}
+
 extern "C" int64_t mmk_packed_weight_floats(int32_t n_rows, int32_t k_cols) {
   return mmk::packed_floats(n_rows, k_cols);
 }

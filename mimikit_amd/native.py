@@ -59,6 +59,7 @@ _SIGNATURES = {
     "mmk_abi_version": (i32, []),
     "mmk_last_error": (cp, []),
     "mmk_pack_launch_count": (i64, []),
+    "mmk_fingerprint_u32": (i32, [vp, i64, vp, vp]),
     "mmk_mulaw_compress_f32_i64": (i32, [vp, vp, i64, i32, f32, vp, vp]),
     "mmk_mulaw_expand_i64_f32": (i32, [vp, vp, i64, i32, f32, vp, vp]),
     "mmk_resample_n_out": (i64, [i64, i32, i32]),
@@ -400,22 +401,45 @@ def pack_launch_count() -> int:
     return int(lib().mmk_pack_launch_count())
 
 
-def weights_token(module: torch.nn.Module):
-    """identity of a module's weights as a plan packed them: storage address, in-place version counter and shape of every
-    state_dict entry, plus a fingerprint of the CONTENT.  Optimiser steps and ``load_state_dict`` bump the version,
-    ``.to(device)`` moves the storage - but a write through ``.data`` (``p.data.copy_(ema)``, weight surgery) does neither,
-    so the bit patterns of all entries are summed on their device as well (one concatenation + one 64-bit integer sum + one
-    read-back per ``before_generate``: ~0.1 ms next to a generation of seconds).  An unchanged token means the packed copy
-    inside a committed plan is still current."""
-    entries = module.state_dict(keep_vars=True)
-    ident = tuple((k, v.data_ptr(), v._version, tuple(v.shape)) for k, v in entries.items())
-    words = [v.detach().reshape(-1).view(torch.int32) for v in entries.values() if v.dtype == torch.float32 and v.numel() > 0]
-    if not words:
-        return ident, 0
-    bits = torch.cat(words).to(torch.int64)
-    # the plain sum misses a swap of two values; the second sum weights every word by its position (mod a prime)
-    pos = torch.arange(1, bits.numel() + 1, device=bits.device, dtype=torch.int64) % 1000003
-    return ident, (int(bits.sum()), int((bits * pos).sum()))
+def weights_identity(module: torch.nn.Module):
+    """host-side identity of a module's weights as a plan packed them: storage address, in-place version counter and shape of
+    every state_dict entry.  Optimiser steps and ``load_state_dict`` bump the version, ``.to(device)`` moves the storage."""
+    return tuple((k, v.data_ptr(), v._version, tuple(v.shape)) for k, v in module.state_dict(keep_vars=True).items())
+
+
+def weights_fingerprint(module: torch.nn.Module) -> int:
+    """A write through ``.data`` (``p.data.copy_(ema)``, weight surgery) bumps no version counter and moves no storage: a
+    position-mixed hash of all fp32 entries is summed on their device (``mmk_fingerprint_u32``: one concatenation, one launch, one
+    read-back - which waits for the stream; ~0.1 ms of device work).  Taken where a generation starts (``before_generate``),
+    not on every step of one.  Entries on the host are hashed there."""
+    entries = [v.detach() for v in module.state_dict(keep_vars=True).values() if v.dtype == torch.float32 and v.numel() > 0]
+    if not entries:
+        return 0
+    dev = entries[0].device
+    if dev.type != "cuda":
+        import zlib
+        return zlib.crc32(b"".join(v.contiguous().cpu().numpy().tobytes() for v in entries))
+    words = torch.cat([v.reshape(-1) for v in entries])
+    out = torch.zeros(1, dtype=torch.int64, device=dev)
+    check(lib().mmk_fingerprint_u32(ptr(words), words.numel(), ptr(out), stream_ptr(dev)), "mmk_fingerprint_u32")
+    return int(out.item())
+
+
+class WeightsTracker:
+    """decides whether a plan's packed copy of the weights is still current"""
+
+    def __init__(self):
+        self.ident, self.print_ = None, None
+
+    def changed(self, module: torch.nn.Module, content: bool) -> bool:
+        """``content``: also compare the content fingerprint (the start of a generation); without it only the host-side identity"""
+        ident = weights_identity(module)
+        if ident != self.ident:
+            return True
+        return content and weights_fingerprint(module) != self.print_
+
+    def committed(self, module: torch.nn.Module):
+        self.ident, self.print_ = weights_identity(module), weights_fingerprint(module)
 
 
 def abs_ptr(view: torch.Tensor, t_first: int) -> int:

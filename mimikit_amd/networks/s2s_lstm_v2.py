@@ -162,7 +162,7 @@ class Seq2SeqLSTMNetwork(ARMWithHidden, nn.Module):
         self.output_length = lambda n: n
         self._plan = None
         self._plan_batch = 0
-        self._weights_token = None
+        self._weights = native.WeightsTracker()
 
     # -- ARM properties -----------------------------------------------------------
     @property
@@ -271,12 +271,13 @@ class Seq2SeqLSTMNetwork(ARMWithHidden, nn.Module):
             rebuilt = True
         # every call: a step keeps no state between calls, but the plan holds a re-packed copy of the weights, and eval
         # forward / generate_step may follow training steps or a load_state_dict at any time (per-epoch validation)
-        token = native.weights_token(self)
-        if rebuilt or token != self._weights_token:
+        # (the content fingerprint - a device reduction and a read-back - only where a generation starts; the steps of one compare
+        # the host-side identity, which training steps and load_state_dict change)
+        if rebuilt or self._weights.changed(self, content=refresh_weights):
             sd = self.state_dict()
             self._plan.bind_state_dict(fold_weight_norm(sd) if any(k.endswith("_g") for k in sd) else sd)
             self._plan.commit()
-            self._weights_token = token
+            self._weights.committed(self)
 
     def _device_step(self, inputs: Tuple[torch.Tensor, ...], temperature=None):
         native.require_device(*inputs)

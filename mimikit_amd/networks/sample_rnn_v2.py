@@ -155,7 +155,7 @@ class SampleRNN(ARMWithHidden, nn.Module):
         self.prompt_length = 0
         self._plan: Optional[native.SrnnPlan] = None
         self._plan_batch = 0
-        self._weights_token = None
+        self._weights = native.WeightsTracker()
         self._state_batch = 0
         self._next_t: Optional[int] = None
 
@@ -261,12 +261,11 @@ class SampleRNN(ARMWithHidden, nn.Module):
             self._resident_seen = 0                          # (the new plan's resident-block counter starts over)
             rebuilt = True
         if rebuilt or refresh_weights:
-            token = native.weights_token(self)
-            if rebuilt or token != self._weights_token:      # re-pack only when a parameter changed since the last commit
+            if rebuilt or self._weights.changed(self, content=True):      # re-pack only when a parameter changed since the last commit
                 sd = self.state_dict()
                 self._plan.bind_state_dict(fold_weight_norm(sd) if self._config.weight_norm else sd)
                 self._plan.commit()
-                self._weights_token = token
+                self._weights.committed(self)
             else:
                 self._plan.reset()                           # hidden states back to h0, same packed weights
             self._next_t = None

@@ -220,7 +220,7 @@ class WaveNet(ARM, nn.Module):
         self.eval_slice = slice(-1, None) if config.pad_side == 1 else slice(0, 1)
         self._plan: Optional[native.WaveNetPlan] = None
         self._plan_batch = 0
-        self._weights_token = None
+        self._weights = native.WeightsTracker()
         self._next_t: Optional[int] = None   # absolute time the queues are ready to produce
         self._state_batch = 0
 
@@ -385,11 +385,10 @@ class WaveNet(ARM, nn.Module):
             # the plan holds a re-packed copy of the weights: redo it only when a parameter changed since (optimiser step,
             # load_state_dict, .to(device)); the reference's before_generate never touches the weights either.  The queues
             # need no clearing: every slot a step reads is rewritten by the warm-up that precedes it.
-            token = native.weights_token(self)
-            if rebuilt or token != self._weights_token:
+            if rebuilt or self._weights.changed(self, content=True):
                 self._plan.bind_state_dict(self._plan_tensors())
                 self._plan.commit()
-                self._weights_token = token
+                self._weights.committed(self)
             self._next_t = None
 
     def _plan_tensors(self):
