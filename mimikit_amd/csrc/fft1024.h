@@ -71,8 +71,16 @@ __device__ __forceinline__ void dft16(cf32 (&v)[16]) {
 
 constexpr int kFftWaveLds = 16 * 68;      // complex elements of a wave's private buffer (>= 64 x 17 and >= 1024)
 
-// Forward DFT of 1024 points.  In: v[r] = x[lane + 64 r].  Out: X[k] in natural order in buf[0..1023] (wave-private
-// LDS, kFftWaveLds complex); tw[m] = exp(-2 pi i m / 1024).  Wave-synchronous: no workgroup barrier.
+// Where X[k] lives in the buffer when the transform is asked for the swizzled natural order: bits 2-3 of k flipped by bits 4-5.
+// The last pass stores X[k1 + 16 c + 256 d] from lane (k1, c mod 4): in plain natural order the four lanes of a k1 that differ in
+// c mod 4 write the same bank pair (16 complex apart), a 4-way conflict on all 16 stores of a transform (SQ_LDS_BANK_CONFLICT: 41 %
+// of the STFT kernel's LDS-active cycles); with the flip the 16 lanes of a store group write 16 different bank pairs, and a reader
+// whose lanes walk k = lane + 64 j reads conflict-free as before (lane -> fft_swz(lane) is a permutation inside each group of 16).
+__device__ __forceinline__ int fft_swz(int k) { return k ^ (((k >> 4) & 3) << 2); }
+
+// Forward DFT of 1024 points.  In: v[r] = x[lane + 64 r].  Out: X[k] in natural order in buf[0..1023] (SWZ: at buf[fft_swz(k)];
+// wave-private LDS, kFftWaveLds complex); tw[m] = exp(-2 pi i m / 1024).  Wave-synchronous: no workgroup barrier.
+template <bool SWZ = false>
 __device__ __forceinline__ void fft1024_wave(cf32 (&v)[16], cf32* buf, const cf32* tw, int lane) {
   constexpr int N = 1024;
   const int k1b = lane >> 2, lo2 = lane & 3;                  // (k1, b) of pass 2 = (k1, c mod 4) of pass 3
@@ -107,7 +115,7 @@ __device__ __forceinline__ void fft1024_wave(cf32 (&v)[16], cf32* buf, const cf3
   for (int g = 0; g < 4; ++g) {
     radix4(v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]);
 #pragma unroll
-    for (int d = 0; d < 4; ++d) buf[k1b + 16 * (lo2 + 4 * g) + 256 * d] = v[4 * g + d];
+    for (int d = 0; d < 4; ++d) buf[(SWZ ? (k1b ^ (lo2 << 2)) : k1b) + 16 * (lo2 + 4 * g) + 256 * d] = v[4 * g + d];
   }
   __builtin_amdgcn_wave_barrier();
 }

@@ -77,14 +77,14 @@ __device__ __forceinline__ void ola_pair(float* ring, const cf32* buf, const flo
 #pragma unroll
   for (int j = 0; j < 16; ++j) {
     const int q = (pa + lane + 64 * j) & (kRing - 1);
-    ring[q] += buf[lane + 64 * j].x * win[j];
+    ring[q] += buf[fft_swz(lane) + 64 * j].x * win[j];
   }
   if (has_b) {
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
       const int q = (pa + hop + lane + 64 * j) & (kRing - 1);
-      ring[q] -= buf[lane + 64 * j].y * win[j];
+      ring[q] -= buf[fft_swz(lane) + 64 * j].y * win[j];
     }
   }
   __builtin_amdgcn_wave_barrier();
@@ -177,7 +177,7 @@ void istft1024_kernel(const float* __restrict__ spec, const float* __restrict__ 
         const int64_t nb = f + 3 <= f_last ? f + 3 : f_last;
         istft_load<MODE>(raw, spec, mag, fbase + na, fbase + nb, lane);
       }
-      fft1024_wave(v, buf, tw, lane);
+      fft1024_wave<true>(v, buf, tw, lane);
       const bool more = f + 2 <= f_hi;
       const int64_t upto = more ? (f + 2) * hop : t1;             // the ring is cleared again by the next segment
       ola_pair(ring, buf, win, envt, f, hop, has_b, frontier, upto, t0, t1, n_frames, orow, lane);
@@ -199,11 +199,21 @@ __device__ __forceinline__ void stft_load(StftRaw& raw, const float* __restrict_
   if (start >= 0 && start + hop + N <= n_samples) {
     // interior pair (all but the first / last few): one base address per frame, compile-time offsets
     const float* pa = xr + start + lane;
-    const float* pb = pa + hop;
+    if (hop == N / 4) {
+      // frame B starts a quarter frame later: its first 12 register rows ARE frame A's rows 4 .. 15 - 20 loads instead of 32
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      raw.a[r] = pa[64 * r];
-      raw.b[r] = pb[64 * r];
+      for (int r = 0; r < 16; ++r) raw.a[r] = pa[64 * r];
+#pragma unroll
+      for (int r = 0; r < 12; ++r) raw.b[r] = raw.a[r + 4];
+#pragma unroll
+      for (int r = 12; r < 16; ++r) raw.b[r] = pa[64 * (r + 4)];
+    } else {
+      const float* pb = pa + hop;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        raw.a[r] = pa[64 * r];
+        raw.b[r] = pb[64 * r];
+      }
     }
   } else {
 #pragma unroll
@@ -296,15 +306,15 @@ void gla1024_iter_kernel(const float* __restrict__ wave_in, const float* __restr
         mga[jj] = mag[ea + kc];
         mgb[jj] = mag[eb + kc];
       }
-      fft1024_wave(v, buf, tw, lane);
+      fft1024_wave<true>(v, buf, tw, lane);
       // ---- phase update on the two real spectra; the new spectra mag * angles go back to LDS as A (0..512), B (513..1025) ---
       cf32 za[9], zb[9];
 #pragma unroll
       for (int jj = 0; jj < 9; ++jj) {
         const int k = lane + 64 * jj;
         if (k < bins) {
-          const cf32 z = buf[k];
-          const cf32 zc = buf[(N - k) & (N - 1)];
+          const cf32 z = buf[fft_swz(lane) + 64 * jj];
+          const cf32 zc = buf[(((N - k) & (N - 1)) & ~63) | fft_swz((64 - lane) & 63)];
           const cf32 sa = cf32{0.5f * (z.x + zc.x), 0.5f * (z.y - zc.y)};
           const cf32 sb = cf32{0.5f * (z.y + zc.y), -0.5f * (z.x - zc.x)};
           const cf32 ga = cf32{sa.x - momentum * tpa[jj].x, sa.y - momentum * tpa[jj].y};
@@ -335,7 +345,7 @@ void gla1024_iter_kernel(const float* __restrict__ wave_in, const float* __restr
         else v[r] = cf32{A.x + B.y, -(B.x - A.y)};
       }
       __builtin_amdgcn_wave_barrier();
-      fft1024_wave(v, buf, tw, lane);
+      fft1024_wave<true>(v, buf, tw, lane);
       const bool more = f + 2 <= f_hi;
       const int64_t upto = more ? (f + 2) * hop : t1;
       ola_pair(ring, buf, win_n, envt, f, hop, has_b, frontier, upto, t0, t1, n_frames, orow, lane);
@@ -345,16 +355,24 @@ void gla1024_iter_kernel(const float* __restrict__ wave_in, const float* __restr
   }
 }
 
+#ifndef MMK_STFT_WAVES
+#define MMK_STFT_WAVES 4
+#endif
+#ifndef MMK_STFT_WPE
+#define MMK_STFT_WPE 3
+#endif
+constexpr int kStftWaves = MMK_STFT_WAVES;      // waves (= frame pairs in flight) per workgroup of the n_fft = 1024 STFT kernel
+
 template <int OUT>
-__global__ __launch_bounds__(64 * kIstftWaves) __attribute__((amdgpu_waves_per_eu(3, 3)))
+__global__ __launch_bounds__(64 * kStftWaves) __attribute__((amdgpu_waves_per_eu(MMK_STFT_WPE, MMK_STFT_WPE)))
 void stft1024_kernel(const float* __restrict__ x, int64_t x_row_stride, int64_t n_samples, int hop, int center, int reflect,
                      int64_t n_frames, int64_t total_pairs, float* __restrict__ out, float* __restrict__ tprev, float momentum) {
   constexpr int N = 1024, bins = 513;
   __shared__ cf32 tw[N];
-  __shared__ cf32 bufs[kIstftWaves * kFftWaveLds];
+  __shared__ cf32 bufs[kStftWaves * kFftWaveLds];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  make_twiddles(tw, tid, 64 * kIstftWaves);
+  make_twiddles(tw, tid, 64 * kStftWaves);
   float win[16];                                            // periodic Hann at n = lane + 64 r (functionals.py:513)
 #pragma unroll
   for (int r = 0; r < 16; ++r) win[r] = 0.5f - 0.5f * cospif(2.0f * (float)(lane + 64 * r) / (float)N);
@@ -362,10 +380,11 @@ void stft1024_kernel(const float* __restrict__ x, int64_t x_row_stride, int64_t 
   cf32* buf = bufs + wave * kFftWaveLds;
   const int64_t pairs_per_row = (n_frames + 1) >> 1;
   const int64_t pad = center ? N / 2 : 0;
-  const int64_t stride = (int64_t)gridDim.x * kIstftWaves;
+  const int64_t stride = (int64_t)gridDim.x * kStftWaves;
 
-  for (int64_t pair = (int64_t)blockIdx.x * kIstftWaves + wave; pair < total_pairs; pair += stride) {
-    const int64_t b = pair / pairs_per_row;
+  const bool small = total_pairs < (1ll << 31);            // (32-bit division of the pair index where it fits: an int64 division is ~100 vector instructions)
+  for (int64_t pair = (int64_t)blockIdx.x * kStftWaves + wave; pair < total_pairs; pair += stride) {
+    const int64_t b = small ? (int64_t)((unsigned)pair / (unsigned)pairs_per_row) : pair / pairs_per_row;
     const int64_t f0 = (pair - b * pairs_per_row) * 2;
     const bool has_b = (f0 + 1) < n_frames;
     // (loading the next pair before this transform was measured: slower, the kernel is bound by vector-ALU issue)
@@ -375,14 +394,26 @@ void stft1024_kernel(const float* __restrict__ x, int64_t x_row_stride, int64_t 
 #pragma unroll
     for (int r = 0; r < 16; ++r) v[r] = cf32{raw.a[r] * win[r], has_b ? raw.b[r] * win[r] : 0.f};   // frame f0 -> re, f0 + 1 -> im
     const int64_t ea = (b * n_frames + f0) * bins;
-    fft1024_wave(v, buf, tw, lane);
+    fft1024_wave<true>(v, buf, tw, lane);
     // the two real spectra:  A[k] = (Z[k] + conj(Z[N-k])) / 2 ,  B[k] = (Z[k] - conj(Z[N-k])) / (2i)
 #pragma unroll
     for (int jj = 0; jj < 9; ++jj) {
       const int k = lane + 64 * jj;
       if (k < bins) {
-        const cf32 z = buf[k];
-        const cf32 zc = buf[(N - k) & (N - 1)];
+        const cf32 z = buf[fft_swz(lane) + 64 * jj];
+        const cf32 zc = buf[(((N - k) & (N - 1)) & ~63) | fft_swz((64 - lane) & 63)];
+        if (OUT == 4) {
+          // MagSpec: with p = Z[k] + Z[N-k], m = Z[k] - Z[N-k] (two packed ops), |A| = sqrt(p.x^2 + m.y^2) / 2 and
+          // |B| = sqrt(p.y^2 + m.x^2) / 2: packed squares, the hardware square root (1 ulp; the reference's abs() of a complex64 is
+          // held to 2e-5 of the largest magnitude in the tests), 32-bit offsets from the pair's base - the epilogue was a third of the
+          // kernel's vector instructions
+          const cf32 pz = z + zc, mz = z - zc;
+          const cf32 pp = pz * pz, mm = mz * mz;
+          float* o = out + ea;
+          o[k] = 0.5f * __builtin_amdgcn_sqrtf(pp.x + mm.y);
+          if (has_b) o[bins + k] = 0.5f * __builtin_amdgcn_sqrtf(pp.y + mm.x);
+          continue;
+        }
         cf32 s[2];
         s[0] = cf32{0.5f * (z.x + zc.x), 0.5f * (z.y - zc.y)};
         s[1] = cf32{0.5f * (z.y + zc.y), -0.5f * (z.x - zc.x)};
@@ -393,7 +424,6 @@ void stft1024_kernel(const float* __restrict__ x, int64_t x_row_stride, int64_t 
           if (OUT == 0) *reinterpret_cast<cf32*>(out + 2 * e) = s[q];
           if (OUT == 1) *reinterpret_cast<cf32*>(out + 2 * e) = cf32{sqrtf(s[q].x * s[q].x + s[q].y * s[q].y), atan2f(s[q].y, s[q].x)};
           if (OUT == 2) out[e] = atan2f(s[q].y, s[q].x);
-          if (OUT == 4) out[e] = sqrtf(s[q].x * s[q].x + s[q].y * s[q].y);
           if (OUT == 3) {
             const cf32 tp = *reinterpret_cast<const cf32*>(tprev + 2 * e);
             const cf32 g = cf32{s[q].x - momentum * tp.x, s[q].y - momentum * tp.y};
@@ -702,7 +732,9 @@ int launch_stft1024(const float* x, int64_t x_row_stride, int batch, int64_t n_s
                     float* out, float* tprev, float momentum, hipStream_t stream) {
   const int64_t n_frames = mmk_stft_n_frames(n_samples, 1024, hop, center);
   const int64_t total_pairs = (int64_t)batch * ((n_frames + 1) / 2);
-  const dim3 grid(pair_grid(total_pairs)), block(64 * kIstftWaves);
+  const int64_t wgs = (total_pairs + kStftWaves - 1) / kStftWaves;
+  const int64_t resident = 256 * (4 * MMK_STFT_WPE / kStftWaves);          // workgroups that are resident together on the chip
+  const dim3 grid((unsigned)(wgs < resident ? wgs : resident)), block(64 * kStftWaves);
 #define MMK_STFT_LAUNCH(O) \
   hipLaunchKernelGGL((stft1024_kernel<O>), grid, block, 0, stream, x, x_row_stride, n_samples, hop, center, reflect, n_frames, \
                      total_pairs, out, tprev, momentum)

@@ -30,11 +30,19 @@ __device__ __forceinline__ void sincos_cw(float x, float* sn, float* cs) {
   *cs = ((qi + 1) & 2) ? -c0 : c0;
 }
 
+// the same through the hardware: v_sin_f32 / v_cos_f32 take revolutions; the fraction of x / 2 pi keeps the argument exact enough for
+// angles of a few turns (|x| < ~100 rad: the reduction's error is one ulp of the quotient), 4 instructions instead of 22
+__device__ __forceinline__ void sincos_hw(float x, float* sn, float* cs) {
+  const float t = __builtin_amdgcn_fractf(x * 0.15915494309189535f);
+  *sn = __builtin_amdgcn_sinf(t);
+  *cs = __builtin_amdgcn_cosf(t);
+}
+
 template <int MODE>
 __device__ __forceinline__ cf32 istft_bin(cf32 c, float m) {
   if (MODE == 1) {                                          // abs * exp(i angle)   (functionals.py:556)
     float sn, cs;
-    sincos_cw(c.y, &sn, &cs);
+    sincos_hw(c.y, &sn, &cs);      // (sincos_cw, 22 instructions per bin, was a fifth of the ISTFT kernel: 153 -> 127 us for 64 x 862 frames)
     return cf32{c.x * cs, c.x * sn};
   }
   if (MODE == 2) return cf32{m * c.x, m * c.y};
