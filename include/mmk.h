@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define MMK_ABI_VERSION 2   /* 2: exec_mode in the WaveNet / SampleRNN configs, mmk_*_inject_sync_error */
+#define MMK_ABI_VERSION 2   /* 2: exec_mode in the WaveNet / SampleRNN / Seq2Seq configs, mmk_*_sync_status for all three, mmk_*_inject_sync_error */
 
 #define MMK_OK 0
 #define MMK_ERR_INVALID (-1)     /* bad argument / shape / unsupported option value */
@@ -322,6 +322,9 @@ typedef struct mmk_s2s_config {
   int32_t mlp_hidden, mlp_n_hidden;        /* head_kind 1: width, number of extra hidden blocks (0 .. 4) */
   int32_t learn_temp;                      /* head_kind 1: one more output, logits / max(sigmoid(it), min_temp) */
   float min_temp;
+  int32_t exec_mode;                       /* 0 = the library chooses (one resident launch per bi-LSTM layer where its workgroups are
+                                            * co-resident), 1 = one launch per frame: what a caller asks for to redo a call after
+                                            * mmk_s2s_sync_status reported a timed-out wait */
 } mmk_s2s_config;
 
 typedef struct mmk_s2s_plan mmk_s2s_plan;
@@ -352,6 +355,13 @@ int mmk_s2s_generate_classes(mmk_s2s_plan* plan, int32_t batch, int64_t* classes
 /* the MLP head's outputs (before the learned-temperature division) of the last step: (batch * hop, out_dim + learn_temp)
  * rows (clip-major) copied to `out` with leading dimension out_ld - what the parity tests compare with the oracle's */
 int mmk_s2s_last_logits(mmk_s2s_plan* plan, int32_t batch, float* out, int64_t out_ld, mmk_stream_t stream);
+/* waits for the stream; fails (and clears the word) if a wait inside the resident bi-LSTM kernel (csrc/lstm_seq.hip) timed out
+ * since the last call - the outputs of the calls in between are invalid */
+int mmk_s2s_sync_status(mmk_s2s_plan* plan, mmk_stream_t stream);
+/* fault injection for the callers' tests: the next mmk_s2s_sync_status reports a timed-out wait (once) */
+int mmk_s2s_inject_sync_error(mmk_s2s_plan* plan, mmk_stream_t stream);
+/* diagnostic: bi-LSTM layers this plan has run as ONE resident launch since it was created */
+int64_t mmk_s2s_resident_launches(const mmk_s2s_plan* plan);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,228 @@
+// All time steps of one bidirectional LSTM layer in ONE launch, the recurrent weights resident in registers (gfx950).
+//
+// Reference: torch.nn.LSTM(bidirectional=True) inside the Seq2Seq encoder / decoder (s2s_lstm_v2.py:90-171); per frame
+//     gates = (W_ih x_t + b)  [one GEMM over all frames, done before this kernel]  +  W_hh h_{t-1}
+//     i, f, o = sigmoid(.), g = tanh(.);  c' = f c + i g;  h' = o tanh(c')                    (ATen LSTMCell)
+//
+// The per-step kernel (lstm_step.hip) streams both W_hh (33.5 MB at H = 1024) through every CU once per frame: 17.6 us per frame
+// against 6.8 us of fp32 MFMA work, and the stream and the MFMAs get in each other's way.  Here the launch lasts for the whole
+// sequence and a workgroup keeps its slice of W_hh - 16 hidden units x 4 gates x all of K, 128 registers per lane at H = 1024 - for
+// all frames.  Same split as the per-step kernel: a workgroup owns 16 units x 32 rows of one direction (64 rows x 1024 units x 2
+// directions = 256 workgroups = one per CU), its 8 waves take 1/8 of K each, the partial sums meet in LDS, one thread runs the cell
+// of one (row, unit) pair and keeps that pair's cell state in a register.
+//
+// What crosses workgroups is the new hidden state: the 64 workgroups of a (direction, 32-row half) group need each other's 16 units.
+// No barrier and no counters: the state of sequence step s lives at its own address (`xch`, one image per step), every word of it
+// starts out as a poison pattern (0xFFFFFFFF: a NaN no LSTM arithmetic produces) and the consumer's load of a K range IS the poll:
+// a 16-byte fragment with no poison word in it is final, one with poison is requested again.  The set of images alternates between
+// launches and a launch poisons the set of the next one, so no memset sits between the layers.  The two 16-row blocks of a workgroup
+// are independent sequences: block 1's products run while block 0's new state travels, and the other way round.
+//
+// A consumer that sees poison for ~20 ms gives up, raises `err` and lets the launch drain (everybody else follows through `err`):
+// the plan then repeats the call with the per-step kernel.  That covers a chip on which the 256 workgroups are not co-resident.
+#include <type_traits>
+
+#include "lstm_seq.h"
+
+namespace mmk {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kSqThreads = 512;
+constexpr int kSqWaves = kSqThreads / 64;
+constexpr uint32_t kSqPoison = 0xFFFFFFFFu;
+constexpr unsigned kSqSpinLimit = 1u << 14;     // re-requests of one fragment (1 - 2 us each) before giving up
+
+#ifndef MMK_SQ_BUBBLE
+#define MMK_SQ_BUBBLE 0        // s_nop behind every second MFMA (what the per-step kernel needs to let its weight stream land)
+#endif
+
+template <int N>
+__device__ __forceinline__ void sq_wait(f32x4& h) { asm volatile("s_waitcnt vmcnt(%1)" : "+v"(h) : "n"(N)); }
+
+__device__ __forceinline__ bool sq_poisoned(const f32x4& v) {
+  return (__float_as_uint(v.x) == kSqPoison) | (__float_as_uint(v.y) == kSqPoison) | (__float_as_uint(v.z) == kSqPoison) |
+         (__float_as_uint(v.w) == kSqPoison);
+}
+
+template <int CPW, int RB>   // K-chunks per wave: H = 128 CPW; 16-row blocks per workgroup
+__global__ __launch_bounds__(kSqThreads) void lstm_seq_kernel(const LstmSeqArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  constexpr int KC = CPW * kSqWaves;
+  constexpr int H = KC * 16;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ub = blockIdx.x;                       // block of 16 hidden units
+  const int m_first = blockIdx.y * (16 * RB);
+  const int mg = min(16 * RB, a.M - m_first);
+  const int di = blockIdx.z;
+  const LstmSeqDir d = a.dir[di];
+  f32x4* red = reinterpret_cast<f32x4*>(smem_raw);                      // split-K partials [row block][gate][wave][lane]
+
+  const int e_m = tid >> 4, e_n = tid & 15;                             // this thread's (row, unit) pair
+  const int unit = ub * 16 + e_n;
+  const bool has_pair = e_m < 16 * RB;
+  const bool cell = e_m < mg;
+  const int my_rb = e_m >> 4;
+  const int64_t row = m_first + (cell ? e_m : 0);
+  const int64_t image = (int64_t)a.rows_pad * H;                        // floats of one (step, direction) state image
+
+  // ---- poison the images of the next launch (all rows of the plan's largest batch, whatever this launch's M is) ----------------
+  if (has_pair)
+    for (int r = m_first + e_m; r < a.rows_pad; r += gridDim.y * 16 * RB)
+      for (int s = 0; s + 1 < a.n_steps; ++s)
+        reinterpret_cast<uint32_t*>(a.xch_next)[(int64_t)(s * 2 + di) * image + (int64_t)r * H + unit] = kSqPoison;
+
+  // ---- this wave's slice of W_hh: 4 gate tiles x CPW chunks, resident for the launch -----------------------------------------------
+  f32x4 w[CPW][4];
+  const int c0 = wave * CPW;
+  {
+    const f32x4* wsrc = reinterpret_cast<const f32x4*>(d.whh_wp) + ((int64_t)ub * KC + c0) * 64 + lane;
+    const int64_t gate_stride = (int64_t)KC * KC * 64;                   // f32x4 elements between the gates' tile rows
+#pragma unroll
+    for (int u = 0; u < CPW; ++u)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) w[u][g] = wsrc[g * gate_stride + u * 64];
+  }
+  float c_reg = 0.f;
+  if (cell && !a.zero_state) c_reg = d.c[row * H + unit];
+
+  // rows of the two blocks this lane reads the state of (MFMA A operand: row lane & 15, K offset 4 (lane >> 4)); clamped, unconditional
+  int64_t hoff[RB];
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb) {
+    const int m = rb * 16 + (lane & 15);
+    hoff[rb] = (int64_t)(m_first + (m < mg ? m : 0)) * H + c0 * 16 + 4 * (lane >> 4);
+  }
+  bool check = true;                                // false once this wave has given up: the launch only drains
+
+  for (int s = 0; s < a.n_steps; ++s) {
+    const int t = di == 0 ? s : a.n_steps - 1 - s;
+    const bool product = s > 0 || !a.zero_state;
+    const bool polled = s > 0;                      // the first step reads the caller's state: final before the launch
+    const float* hin = s == 0 ? d.h : a.xch + (int64_t)((s - 1) * 2 + di) * image;
+    const bool last = s + 1 == a.n_steps;
+    float* hout = last ? d.h : a.xch + (int64_t)(s * 2 + di) * image;
+
+    auto phase = [&](auto rbc) {
+      constexpr int rb = decltype(rbc)::value;
+      const bool mine = has_pair && my_rb == rb;
+      // partial-sum slot of this phase: one barrier per phase, so a slot must not be rewritten before the barrier after its readers
+      const int slot = RB == 2 ? rb : (s & 1);
+      // the additive gate terms of this thread's pair: the oldest entries of the memory pipe
+      float ga[4] = {0.f, 0.f, 0.f, 0.f};
+      if (mine) {
+        const float* g0 = d.gadd + row * a.gadd_ld + (int64_t)t * a.gadd_ts + unit;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) ga[g] = g0[g * H];
+      }
+      f32x4 acc[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (product) {
+        f32x4 hv[CPW];
+        const float* hsrc = hin + hoff[rb];
+#pragma unroll
+        for (int u = 0; u < CPW; ++u) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=&v"(hv[u]) : "v"(hsrc + u * 16) : "memory");
+        auto chunk = [&](auto uc) {
+          constexpr int u = decltype(uc)::value;
+          if constexpr (u < CPW) {
+            sq_wait<CPW - 1 - u>(hv[u]);
+            if (polled && check) {
+              unsigned spins = 0;
+              while (__builtin_amdgcn_ballot_w64(sq_poisoned(hv[u])) != 0) {
+                asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(hv[u]) : "v"(hsrc + u * 16) : "memory");
+                if (++spins > kSqSpinLimit || ((spins & 63u) == 0 && __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+                  if (lane == 0) atomicOr(a.err, 1u);
+                  check = false;
+                  break;
+                }
+              }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+#pragma unroll
+              for (int g = 0; g < 4; ++g) {
+                acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(hv[u][i], w[u][g][i], acc[g], 0, 0, 0);
+#if MMK_SQ_BUBBLE
+                if (g & 1) {
+                  __builtin_amdgcn_sched_barrier(0);
+                  asm volatile("s_nop 7");
+                  __builtin_amdgcn_sched_barrier(0);
+                }
+#endif
+              }
+            }
+            __builtin_amdgcn_sched_barrier(0);     // the next chunk's wait stays behind these MFMAs
+          }
+        };
+        chunk(std::integral_constant<int, 0>{}); chunk(std::integral_constant<int, 1>{}); chunk(std::integral_constant<int, 2>{});
+        chunk(std::integral_constant<int, 3>{}); chunk(std::integral_constant<int, 4>{}); chunk(std::integral_constant<int, 5>{});
+        chunk(std::integral_constant<int, 6>{}); chunk(std::integral_constant<int, 7>{});
+        static_assert(CPW <= 8, "H <= 1024");
+#pragma unroll
+        for (int g = 0; g < 4; ++g) red[((slot * 4 + g) * kSqWaves + wave) * 64 + lane] = acc[g];
+      }
+      __syncthreads();
+      if (mine) {
+        const int r = e_m & 15;
+        const int frag = ((r >> 2) * 16 + e_n) * 4 + (r & 3);          // (row r, col n) of a 16x16 accumulator image
+        float sum[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          float v = 0.f;
+          if (product) {
+            const float* f = reinterpret_cast<const float*>(red + (slot * 4 + g) * kSqWaves * 64) + frag;
+#pragma unroll
+            for (int wv = 0; wv < kSqWaves; ++wv) v += f[wv * 256];
+          }
+          sum[g] = v + ga[g];
+        }
+        if (cell) {
+          const float ig = sigmoid_fast(sum[0]), fg = sigmoid_fast(sum[1]), cg = tanh_fast(sum[2]), og = sigmoid_fast(sum[3]);
+          c_reg = fg * c_reg + ig * cg;
+          const float hn = og * tanh_fast(c_reg);
+          if (last) {
+            hout[row * H + unit] = hn;
+            d.c[row * H + unit] = c_reg;
+          } else {
+            __hip_atomic_store(hout + row * H + unit, hn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);    // written through: other XCDs poll it
+          }
+          d.y[row * a.y_ld + (int64_t)t * a.y_ts + unit] = hn;
+        }
+      }
+    };
+    phase(std::integral_constant<int, 0>{});
+    if constexpr (RB > 1) phase(std::integral_constant<int, 1>{});
+  }
+}
+
+bool lstm_seq_supported(int H, int M, int n_steps, int n_cu) {
+  if (!(H == 128 || H == 256 || H == 512 || H == 1024) || n_steps < 2 || M < 1) return false;
+  const int rb = M > 16 ? 2 : 1;
+  const int64_t wgs = (int64_t)(H / 16) * ((M + 16 * rb - 1) / (16 * rb)) * 2;
+  return wgs <= n_cu;          // every workgroup waits for the others: all of them have to be on the chip at once
+}
+
+size_t lstm_seq_xch_floats(int H, int rows_pad, int n_steps) { return (size_t)(n_steps - 1) * 2 * rows_pad * H; }
+
+int launch_lstm_seq(const LstmSeqArgs& a, hipStream_t stream) {
+  const int rb = a.M > 16 ? 2 : 1;
+  const size_t lds = (size_t)2 * 4 * kSqWaves * 64 * 16;          // two slots of split-K partials
+  dim3 grid(a.H / 16, (a.M + 16 * rb - 1) / (16 * rb), 2), block(kSqThreads);
+#define MMK_SQ(CPW_)                                                                             \
+  if (rb == 2) hipLaunchKernelGGL((lstm_seq_kernel<CPW_, 2>), grid, block, lds, stream, a);      \
+  else hipLaunchKernelGGL((lstm_seq_kernel<CPW_, 1>), grid, block, lds, stream, a)
+  switch (a.H) {
+    case 128: MMK_SQ(1); break;
+    case 256: MMK_SQ(2); break;
+    case 512: MMK_SQ(4); break;
+    case 1024: MMK_SQ(8); break;
+    default: return fail(MMK_ERR_UNSUPPORTED, "lstm sequence kernel: H=%d", a.H);
+  }
+#undef MMK_SQ
+  MMK_HIP(hipGetLastError());
+  return MMK_OK;
+}
+
+}  // namespace mmk

@@ -10,6 +10,7 @@
 //     channels of the concatenation (:100, :174); reproduced literally.
 #include "plan_util.h"
 #include "lstm_step.h"
+#include "lstm_seq.h"
 
 using namespace mmk;
 
@@ -142,6 +143,14 @@ struct mmk_s2s_plan {
   float *h[2] = {nullptr, nullptr}, *c[2] = {nullptr, nullptr};
   float* h2[2] = {nullptr, nullptr};   // second state buffer of each direction (the fused step kernel ping-pongs)
   bool fused_lstm = false;
+  // the resident sequence kernel (lstm_seq.hip): two sets of exchange images (a launch uses one and poisons the other), the word a
+  // timed-out workgroup raises, launches since the last status check
+  bool seq_lstm = false;
+  float* xch[2] = {nullptr, nullptr};
+  int xch_cur = 0;
+  uint32_t* seq_err = nullptr;
+  int n_cu = 0;
+  int64_t seq_launches = 0;
   float *of = nullptr, *ob = nullptr, *es = nullptr, *coded = nullptr, *z = nullptr, *ysum = nullptr, *yout = nullptr;
   float* yalt = nullptr;                         // second folded-output buffer (layer n reads one, writes the other)
   float* compose_tmp = nullptr;                  // (hop D, D): dec.fc . enc.fc_out, row-major, before it is packed
@@ -178,6 +187,10 @@ struct mmk_s2s_plan {
     gates = cv.take<float>((int64_t)Bmax * 4 * D);
     for (int d = 0; d < 2; ++d) { h[d] = cv.take<float>((int64_t)Bmax * D); c[d] = cv.take<float>((int64_t)Bmax * D); }
     for (int d = 0; d < 2; ++d) h2[d] = cv.take<float>((int64_t)Bmax * D);
+    if (seq_lstm) {
+      for (int k = 0; k < 2; ++k) xch[k] = cv.take<float>((int64_t)lstm_seq_xch_floats(D, Bmax, hop));
+      seq_err = reinterpret_cast<uint32_t*>(cv.take<float>(64));
+    }
     of = cv.take<float>(rows * D);
     ob = cv.take<float>(rows * D);
     es = cv.take<float>((int64_t)Bmax * D);
@@ -245,6 +258,15 @@ static int derive(mmk_s2s_plan* p) {
   }
   const char* fenv = getenv("MMK_S2S_FUSED");
   p->fused_lstm = !(fenv && fenv[0] == '0') && lstm_step_supported(p->D);
+  {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) p->n_cu = prop.multiProcessorCount;
+  }
+  // one launch per bi-LSTM layer where all its workgroups fit on the chip at once (exec_mode 1: the per-step kernel, which
+  // needs no co-residency - what a caller asks for after mmk_s2s_sync_status reported a timed-out wait)
+  const char* senv = getenv("MMK_S2S_SEQ");
+  p->seq_lstm = p->fused_lstm && c.exec_mode != 1 && !(senv && senv[0] == '0') && lstm_seq_supported(p->D, 1, p->hop, p->n_cu);
   return MMK_OK;
 }
 
@@ -317,6 +339,10 @@ extern "C" int mmk_s2s_commit(mmk_s2s_plan* p, void* workspace, size_t workspace
   if (carve.used() > workspace_bytes)
     return fail(MMK_ERR_WORKSPACE, "s2s_commit: workspace of %zu bytes, %zu needed", workspace_bytes, carve.used());
   MMK_HIP(hipMemsetAsync(workspace, 0, carve.used(), st));
+  if (p->seq_lstm) {
+    for (int k = 0; k < 2; ++k) MMK_HIP(hipMemsetAsync(p->xch[k], 0xFF, lstm_seq_xch_floats(p->D, p->Bmax, p->hop) * sizeof(float), st));
+    p->xch_cur = 0;
+  }
   Binder& b = p->binder;
   b.clear_missing();
   const int D = p->D;
@@ -403,6 +429,19 @@ static int run_bilstm(mmk_s2s_plan* p, BiLstm& l, const float* x, int x_ld, int 
       MMK_HIP(hipMemsetAsync(p->h[d], 0, (size_t)p->Bmax * D * sizeof(float), st));
       MMK_HIP(hipMemsetAsync(p->c[d], 0, (size_t)p->Bmax * D * sizeof(float), st));
     }
+  }
+  if (p->seq_lstm && lstm_seq_supported(D, M, hop, p->n_cu)) {
+    LstmSeqArgs a = {};
+    a.M = M; a.H = D; a.n_steps = hop; a.zero_state = zero_state ? 1 : 0; a.rows_pad = p->Bmax;
+    a.gadd_ld = (int64_t)hop * 4 * D; a.gadd_ts = 4 * D; a.y_ld = (int64_t)hop * D; a.y_ts = D;
+    for (int d = 0; d < 2; ++d) {
+      a.dir[d].whh_wp = l.hh[d].Wp; a.dir[d].gadd = p->gi[d]; a.dir[d].h = p->h[d]; a.dir[d].c = p->c[d];
+      a.dir[d].y = d == 0 ? p->of : p->ob;
+    }
+    a.xch = p->xch[p->xch_cur]; a.xch_next = p->xch[p->xch_cur ^ 1]; a.err = p->seq_err;
+    p->xch_cur ^= 1;
+    p->seq_launches += 1;
+    return launch_lstm_seq(a, st);
   }
   if (p->fused_lstm) {
     // both directions of a time step in one launch; the state ping-pongs between h and h2 (an even number of steps
@@ -622,3 +661,32 @@ extern "C" int mmk_s2s_generate_classes(mmk_s2s_plan* p, int32_t batch, int64_t*
   }
   return MMK_OK;
 }
+
+extern "C" int mmk_s2s_sync_status(mmk_s2s_plan* p, mmk_stream_t stream) {
+  if (!p) return fail(MMK_ERR_INVALID, "s2s_sync_status: null argument");
+  hipStream_t st = (hipStream_t)stream;
+  if (!p->committed || !p->seq_lstm) {
+    MMK_HIP(hipStreamSynchronize(st));
+    return MMK_OK;
+  }
+  uint32_t word = 0;
+  MMK_HIP(hipMemcpyAsync(&word, p->seq_err, sizeof(word), hipMemcpyDeviceToHost, st));
+  MMK_HIP(hipStreamSynchronize(st));
+  if (word == 0) return MMK_OK;
+  // a workgroup of the resident bi-LSTM kernel gave up waiting: the exchange images are in an unknown state - poison both sets again
+  MMK_HIP(hipMemsetAsync(p->seq_err, 0, sizeof(uint32_t), st));
+  for (int k = 0; k < 2; ++k) MMK_HIP(hipMemsetAsync(p->xch[k], 0xFF, lstm_seq_xch_floats(p->D, p->Bmax, p->hop) * sizeof(float), st));
+  MMK_HIP(hipStreamSynchronize(st));
+  return fail(MMK_ERR_STATE, "s2s: a wait inside the resident bi-LSTM kernel timed out (code %u): the outputs since the last check are invalid", word);
+}
+
+extern "C" int mmk_s2s_inject_sync_error(mmk_s2s_plan* p, mmk_stream_t stream) {
+  if (!p || !p->committed) return fail(MMK_ERR_STATE, "s2s_inject_sync_error: plan not committed");
+  if (!p->seq_lstm) return fail(MMK_ERR_STATE, "s2s_inject_sync_error: this plan runs the per-step kernels, nothing can time out");
+  const uint32_t word = 4;
+  MMK_HIP(hipMemcpyAsync(p->seq_err, &word, sizeof(word), hipMemcpyHostToDevice, (hipStream_t)stream));
+  MMK_HIP(hipStreamSynchronize((hipStream_t)stream));
+  return MMK_OK;
+}
+
+extern "C" int64_t mmk_s2s_resident_launches(const mmk_s2s_plan* p) { return p ? p->seq_launches : 0; }

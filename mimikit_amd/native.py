@@ -52,6 +52,7 @@ class S2SConfig(C.Structure):
         ("dec_n_lstm", i32), ("out_abs", i32), ("max_batch", i32), ("enc_downsampling", i32), ("dec_upsampling", i32),
         ("enc_apply_residuals", i32), ("dec_apply_residuals", i32),
         ("in_classes", i32), ("head_kind", i32), ("mlp_hidden", i32), ("mlp_n_hidden", i32), ("learn_temp", i32), ("min_temp", f32),
+        ("exec_mode", i32),
     ]
 
 
@@ -112,6 +113,9 @@ _SIGNATURES = {
     "mmk_s2s_step_classes": (i32, [vp, i32, vp, i64, i64, vp, i64, i64, vp]),
     "mmk_s2s_generate_classes": (i32, [vp, i32, vp, i64, i64, i64, i64, i64, vp]),
     "mmk_s2s_last_logits": (i32, [vp, i32, vp, i64, vp]),
+    "mmk_s2s_sync_status": (i32, [vp, vp]),
+    "mmk_s2s_inject_sync_error": (i32, [vp, vp]),
+    "mmk_s2s_resident_launches": (i64, [vp]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
@@ -629,6 +633,18 @@ class S2SPlan(_Plan):
             raise ValueError("Seq2Seq classes must be int64 (batch, T)")
         check(self._lib.mmk_s2s_generate_classes(self.handle, classes.shape[0], ptr(classes), classes.stride(0), classes.stride(1),
                                                  t0, n_steps, classes.shape[1], stream_ptr(self.device)), "mmk_s2s_generate_classes")
+
+    def sync_status(self):
+        """wait for the stream and raise if a wait inside the resident bi-LSTM kernel timed out"""
+        check(self._lib.mmk_s2s_sync_status(self.handle, stream_ptr(self.device)), "mmk_s2s_sync_status")
+
+    def inject_sync_error(self):
+        """fault injection for tests: the next ``sync_status`` reports a timed-out wait (include/mmk.h)"""
+        check(self._lib.mmk_s2s_inject_sync_error(self.handle, stream_ptr(self.device)), "mmk_s2s_inject_sync_error")
+
+    def resident_launches(self) -> int:
+        """bi-LSTM layers run as one resident launch so far (diagnostic, see include/mmk.h)"""
+        return int(self._lib.mmk_s2s_resident_launches(self.handle))
 
     def last_logits(self, batch: int) -> torch.Tensor:
         """the MLP head's raw outputs of the last step, (batch, hop, out_dim + learn_temp)"""

@@ -257,7 +257,12 @@ class Seq2SeqLSTMNetwork(ARMWithHidden, nn.Module):
         c.enc_downsampling, c.dec_upsampling = pooling[str(cfg.enc_downsampling)], upsampling[str(cfg.dec_upsampling)]
         c.enc_apply_residuals, c.dec_apply_residuals = int(cfg.enc_apply_residuals), int(cfg.dec_apply_residuals)
         c.max_batch = max_batch
+        c.exec_mode = int(self._exec_mode)
         return c
+
+    _blocks = ()            # generate_block calls since before_generate: (tensor, t0, n_steps)
+    _exec_mode = 0          # 1 while a call is being redone with one launch per frame (mmk_s2s_config.exec_mode)
+    _resident_seen = 0
 
     def _ensure_plan(self, batch: int, refresh_weights: bool):
         device = self.device
@@ -268,6 +273,7 @@ class Seq2SeqLSTMNetwork(ARMWithHidden, nn.Module):
         if self._plan is None or self._plan_batch < batch or self._plan.device != device:
             self._plan = native.S2SPlan(self._describe(max(batch, 1)), device)
             self._plan_batch = max(batch, 1)
+            self._resident_seen = 0
             rebuilt = True
         # every call: a step keeps no state between calls, but the plan holds a re-packed copy of the weights, and eval
         # forward / generate_step may follow training steps or a load_state_dict at any time (per-epoch validation)
@@ -279,6 +285,32 @@ class Seq2SeqLSTMNetwork(ARMWithHidden, nn.Module):
             self._plan.commit()
             self._weights.committed(self)
 
+    def _checked(self, run, rerun=None):
+        """``run()`` on the plan (``rerun`` if what has to be repeated differs); when a wait inside the resident bi-LSTM kernel (csrc/lstm_seq.hip: one launch per layer, its
+        workgroups wait for each other) timed out - the CUs were held by something else - once more with one launch per frame"""
+        out = run()
+        if self._plan.resident_launches() == self._resident_seen:
+            return out
+        self._resident_seen = self._plan.resident_launches()
+        try:
+            self._plan.sync_status()
+            return out
+        except native.NativeError as err:
+            if self._exec_mode == 1:
+                raise
+            import warnings
+            warnings.warn(f"{err}; repeating the call with one bi-LSTM launch per frame")
+            self._exec_mode = 1
+            try:
+                self._plan = None
+                self._ensure_plan(self._plan_batch, refresh_weights=False)
+                out = (rerun or run)()
+                torch.cuda.synchronize(self.device)
+                return out
+            finally:
+                self._exec_mode = 0
+                self._plan = None                # the next call may run resident again
+
     def _device_step(self, inputs: Tuple[torch.Tensor, ...], temperature=None):
         native.require_device(*inputs)
         if self.input_module is not sum:
@@ -286,7 +318,7 @@ class Seq2SeqLSTMNetwork(ARMWithHidden, nn.Module):
             if x.size(1) != self._config.hop:
                 raise AssertionError(f"expected {self._config.hop} input classes, got {x.size(1)}")
             self._ensure_plan(x.size(0), refresh_weights=False)
-            y = self._plan.step_classes(x.long())
+            y = self._checked(lambda: self._plan.step_classes(x.long()))
             if temperature is not None:
                 # an eval-mode forward with a temperature (decode hands it to the sampler, :250-253; generate_step never does): one draw
                 # per (clip, position) from softmax(logits / T) - the reference's torch.multinomial stream cannot be reproduced, the HIP
@@ -304,7 +336,7 @@ class Seq2SeqLSTMNetwork(ARMWithHidden, nn.Module):
             raise AssertionError(f"expected {self._config.hop} input frames, got {x.size(1)}")
         self._ensure_plan(x.size(0), refresh_weights=False)
         x = x.float() if x.dtype != torch.float32 else x
-        return self._plan.step(x if x.stride(2) == 1 else x.contiguous())
+        return self._checked(lambda: self._plan.step(x if x.stride(2) == 1 else x.contiguous()))
 
     # -- ARM generation protocol ------------------------------------------------------
     def reset_hidden(self):
@@ -314,6 +346,7 @@ class Seq2SeqLSTMNetwork(ARMWithHidden, nn.Module):
     def before_generate(self, prompts: Tuple[torch.Tensor, ...], batch_index) -> None:
         self.reset_hidden()
         native.require_device(*tuple(prompts))
+        self._blocks = []
         self._ensure_plan(prompts[0].size(0), refresh_weights=True)
 
     def generate_step(self, inputs: Tuple[torch.Tensor, ...], *, t: int = 0, **parameters):
@@ -330,12 +363,22 @@ class Seq2SeqLSTMNetwork(ARMWithHidden, nn.Module):
                 return None
             self._ensure_plan(frames.size(0), refresh_weights=False)
             self._plan.generate_classes(frames, t0, n_steps)
+            self._blocks = list(self._blocks) + [(frames, t0, n_steps)]
             return True
         if frames.dtype != torch.float32:
             return None
         self._ensure_plan(frames.size(0), refresh_weights=False)
         self._plan.generate(frames, t0, n_steps)
+        self._blocks = list(self._blocks) + [(frames, t0, n_steps)]
         return True
 
     def after_generate(self, final_outputs: Tuple[torch.Tensor, ...], batch_index) -> None:
+        blocks, self._blocks = self._blocks, []
+        if blocks and self._plan is not None:
+            # the blocks of this generation wrote their frames in place, each from the frames before its t0: after a reported
+            # time-out they are run again, in order, with one launch per frame
+            def again():
+                for frames, t0, n_steps in blocks:
+                    (self._plan.generate_classes if frames.dtype == torch.int64 else self._plan.generate)(frames, t0, n_steps)
+            self._checked(lambda: None, again)
         self.reset_hidden()
