@@ -21,6 +21,8 @@ struct LstmSeqArgs {
   float* xch;                   // (n_steps - 1, 2, rows_pad, H) state images the workgroups exchange, all words poisoned (0xFFFFFFFF)
   float* xch_next;              // the set the NEXT launch will use: this launch poisons it
   uint32_t* err;                // set when a workgroup gave up waiting (the outputs are then undefined)
+  unsigned long long* stamps;   // diagnostic build only: (16 phases, 8 waves, 8) words of workgroup (stamp_wg, 0, 0), else null
+  int32_t stamp_wg;
 };
 
 bool lstm_seq_supported(int H, int M, int n_steps, int n_cu);

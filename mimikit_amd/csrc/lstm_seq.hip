@@ -33,19 +33,44 @@ constexpr int kSqWaves = kSqThreads / 64;
 constexpr uint32_t kSqPoison = 0xFFFFFFFFu;
 constexpr unsigned kSqSpinLimit = 1u << 14;     // re-requests of one fragment (1 - 2 us each) before giving up
 
+#ifndef MMK_SQ_AHEAD
+#define MMK_SQ_AHEAD 1         // request a phase's state fragments during the phase before (two row blocks)
+#endif
+#ifndef MMK_SQ_AHEAD_AT
+#define MMK_SQ_AHEAD_AT 5      // ... in front of the products of chunk CPW * this / 8
+#endif
+#ifndef MMK_SQ_FIRST_SC1
+#define MMK_SQ_FIRST_SC1 1     // 1: a fragment's FIRST request goes past the L2 as well (re-requests always do)
+#endif
+#ifndef MMK_SQ_ACC2
+#define MMK_SQ_ACC2 0          // experiment: two accumulator sets per gate (even / odd K quarter of a chunk)
+#endif
+#ifndef MMK_SQ_NOCHECK
+#define MMK_SQ_NOCHECK 0       // experiment only (wrong results possible): no poison check
+#endif
 #ifndef MMK_SQ_BUBBLE
 #define MMK_SQ_BUBBLE 0        // s_nop behind every second MFMA (what the per-step kernel needs to let its weight stream land)
 #endif
 
-template <int N>
-__device__ __forceinline__ void sq_wait(f32x4& h) { asm volatile("s_waitcnt vmcnt(%1)" : "+v"(h) : "n"(N)); }
+typedef unsigned u32x4s __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ bool sq_poisoned(const f32x4& v) {
-  return (__float_as_uint(v.x) == kSqPoison) | (__float_as_uint(v.y) == kSqPoison) | (__float_as_uint(v.z) == kSqPoison) |
-         (__float_as_uint(v.w) == kSqPoison);
+__device__ __forceinline__ bool sq_poisoned(const u32x4s& v) { return (v.x == kSqPoison) | (v.y == kSqPoison) | (v.z == kSqPoison) | (v.w == kSqPoison); }
+
+// CPW - FROM state fragments of a wave's K range for one row block, 16 bytes per lane each, past the L2 (sc1): buffer loads the
+// compiler counts itself - a fragment is in flight across the frame loop's back edge, where only the compiler knows which of its
+// copies of a register is the live one
+template <int CPW, int FROM = 0>
+__device__ __forceinline__ void sq_request(u32x4s (&set)[CPW], const __amdgpu_buffer_rsrc_t& image, int byte_off) {
+#pragma unroll
+  for (int u = FROM; u < CPW; ++u) set[u] = __builtin_amdgcn_raw_buffer_load_b128(image, byte_off, u * 64, MMK_SQ_FIRST_SC1 ? 16 : 0);
+}
+template <int CPW, int FROM>
+__device__ __forceinline__ void sq_rerequest(u32x4s (&set)[CPW], const __amdgpu_buffer_rsrc_t& image, int byte_off) {
+#pragma unroll
+  for (int u = FROM; u < CPW; ++u) set[u] = __builtin_amdgcn_raw_buffer_load_b128(image, byte_off, u * 64, 16);
 }
 
-template <int CPW, int RB>   // K-chunks per wave: H = 128 CPW; 16-row blocks per workgroup
+template <int CPW, int RB, bool STAMPS>   // K-chunks per wave: H = 128 CPW; 16-row blocks per workgroup; STAMPS: diagnostic build
 __global__ __launch_bounds__(kSqThreads) void lstm_seq_kernel(const LstmSeqArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   constexpr int KC = CPW * kSqWaves;
@@ -57,7 +82,7 @@ __global__ __launch_bounds__(kSqThreads) void lstm_seq_kernel(const LstmSeqArgs 
   const int mg = min(16 * RB, a.M - m_first);
   const int di = blockIdx.z;
   const LstmSeqDir d = a.dir[di];
-  f32x4* red = reinterpret_cast<f32x4*>(smem_raw);                      // split-K partials [row block][gate][wave][lane]
+  f32x4* red = reinterpret_cast<f32x4*>(smem_raw);                      // split-K partials [slot][gate][wave][lane]
 
   const int e_m = tid >> 4, e_n = tid & 15;                             // this thread's (row, unit) pair
   const int unit = ub * 16 + e_n;
@@ -86,52 +111,104 @@ __global__ __launch_bounds__(kSqThreads) void lstm_seq_kernel(const LstmSeqArgs 
   }
   float c_reg = 0.f;
   if (cell && !a.zero_state) c_reg = d.c[row * H + unit];
+  // The weights have to be IN their registers before the frame loop: a load still pending for the compiler at the loop's entry makes
+  // it wait in front of the first products of every phase of every frame - and such a wait drains the whole memory pipe, the cell's
+  // written-through stores and the next phase's fragments included (measured: the phase then starts ~1 us late).
+#pragma unroll
+  for (int u = 0; u < CPW; ++u)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) asm volatile("" : "+v"(w[u][g]));
+  asm volatile("" : "+v"(c_reg));
 
-  // rows of the two blocks this lane reads the state of (MFMA A operand: row lane & 15, K offset 4 (lane >> 4)); clamped, unconditional
-  int64_t hoff[RB];
+  // byte offsets of the two row blocks this lane reads the state of (MFMA A operand: row lane & 15, K offset 4 (lane >> 4)); clamped
+  int hoff[RB];
 #pragma unroll
   for (int rb = 0; rb < RB; ++rb) {
     const int m = rb * 16 + (lane & 15);
-    hoff[rb] = (int64_t)(m_first + (m < mg ? m : 0)) * H + c0 * 16 + 4 * (lane >> 4);
+    hoff[rb] = (int)(((int64_t)(m_first + (m < mg ? m : 0)) * H + c0 * 16 + 4 * (lane >> 4)) * sizeof(float));
   }
+  auto image_of = [&](int s_src) {     // the state a step reads: the caller's before step 0, else the image step s_src - 1 wrote
+    const float* base = s_src == 0 ? d.h : a.xch + (int64_t)((s_src - 1) * 2 + di) * image;
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, -1, 0x00020000);
+  };
   bool check = true;                                // false once this wave has given up: the launch only drains
+  // diagnostic build: 10 ns ticks of [phase start, products done, barrier passed, cell done, re-requests] per (phase, wave) of one workgroup
+  const bool stamping = STAMPS && a.stamps != nullptr && blockIdx.x == a.stamp_wg && blockIdx.y == 0 && blockIdx.z == 0 && lane == 0;
+  auto stamp = [&](int ph, int k, unsigned long long v) { if (stamping && ph < 16) a.stamps[(ph * kSqWaves + wave) * 8 + k] = v; };
+  unsigned rerequests = 0;
+
+  // The state fragments of a phase are requested during the phase before (two register sets, RB == 2): block 1's fragments of step s
+  // while block 0's products of step s run, block 0's of step s + 1 during block 1's.  With one block there is nothing to overlap:
+  // the fragments are requested where the phase starts.
+  constexpr bool kAhead = RB == 2 && MMK_SQ_AHEAD;
+  constexpr int kAheadAt = (CPW * MMK_SQ_AHEAD_AT) / 8;     // chunk in front of whose products the next phase's requests go out
+  u32x4s hv[RB][CPW];
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+    for (int u = 0; u < CPW; ++u) hv[rb][u] = u32x4s{0u, 0u, 0u, 0u};
+  if (kAhead && !a.zero_state) sq_request<CPW>(hv[0], image_of(0), hoff[0]);
 
   for (int s = 0; s < a.n_steps; ++s) {
     const int t = di == 0 ? s : a.n_steps - 1 - s;
     const bool product = s > 0 || !a.zero_state;
     const bool polled = s > 0;                      // the first step reads the caller's state: final before the launch
-    const float* hin = s == 0 ? d.h : a.xch + (int64_t)((s - 1) * 2 + di) * image;
     const bool last = s + 1 == a.n_steps;
+    const __amdgpu_buffer_rsrc_t src_now = image_of(s), src_next = image_of(last ? s : s + 1);
     float* hout = last ? d.h : a.xch + (int64_t)(s * 2 + di) * image;
 
     auto phase = [&](auto rbc) {
       constexpr int rb = decltype(rbc)::value;
+      constexpr int nrb = RB == 2 ? rb ^ 1 : 0;
       const bool mine = has_pair && my_rb == rb;
+      if (STAMPS) { rerequests = 0; stamp(s * RB + rb, 0, __builtin_amdgcn_s_memrealtime()); }
       // partial-sum slot of this phase: one barrier per phase, so a slot must not be rewritten before the barrier after its readers
       const int slot = RB == 2 ? rb : (s & 1);
-      // the additive gate terms of this thread's pair: the oldest entries of the memory pipe
-      float ga[4] = {0.f, 0.f, 0.f, 0.f};
-      if (mine) {
+      // the additive gate terms of this thread's pair
+      // (loaded where they are used - `mine && cell` - so that no path leaves them pending: the compiler would wait for the whole
+      //  memory pipe, the written-through store included, where the registers are written next)
+      float ga[4];          // (no initial value: it would be a write the compiler orders behind everything pending)
+      if (mine && cell) {
         const float* g0 = d.gadd + row * a.gadd_ld + (int64_t)t * a.gadd_ts + unit;
 #pragma unroll
         for (int g = 0; g < 4; ++g) ga[g] = g0[g * H];
       }
+      __builtin_amdgcn_sched_barrier(0);
+      // what the next phase reads: the other block of this step, or block 0 of the next one.  Every path through a phase defines
+      // the other set anew (the launch's last phase asks for its own source once more): a set that could keep its old value is
+      // alive around the loop for the compiler, which then moves it from register to register at the phase boundaries - and waits
+      // for every fragment in flight first.
+      auto request_next = [&]() {
+        if constexpr (rb == 0 && RB == 2) sq_request<CPW>(hv[nrb], src_now, hoff[nrb]);
+        else sq_request<CPW>(hv[nrb], src_next, hoff[nrb]);
+      };
       f32x4 acc[4];
 #pragma unroll
       for (int g = 0; g < 4; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (product) {
-        f32x4 hv[CPW];
-        const float* hsrc = hin + hoff[rb];
+#if MMK_SQ_ACC2
+      f32x4 acc2[4];
 #pragma unroll
-        for (int u = 0; u < CPW; ++u) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=&v"(hv[u]) : "v"(hsrc + u * 16) : "memory");
+      for (int g = 0; g < 4; ++g) acc2[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+#endif
+      if (product) {
+        if (!kAhead) sq_request<CPW>(hv[rb], src_now, hoff[rb]);
         auto chunk = [&](auto uc) {
           constexpr int u = decltype(uc)::value;
           if constexpr (u < CPW) {
-            sq_wait<CPW - 1 - u>(hv[u]);
-            if (polled && check) {
+            if constexpr (kAhead && u == kAheadAt) {
+              request_next();
+              __builtin_amdgcn_sched_barrier(0);
+            }
+            if (polled && check && !MMK_SQ_NOCHECK) {
               unsigned spins = 0;
-              while (__builtin_amdgcn_ballot_w64(sq_poisoned(hv[u])) != 0) {
-                asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(hv[u]) : "v"(hsrc + u * 16) : "memory");
+              while (__builtin_amdgcn_ballot_w64(sq_poisoned(hv[rb][u])) != 0) {
+                // not there yet: ask again for this fragment and the ones behind it (their producers are as late), past the L2
+                sq_rerequest<CPW, u>(hv[rb], src_now, hoff[rb]);
+                // (all of them landed before the check: the compiler's count of what is pending where the loop is left then is the
+                //  straight path's, not "whatever this loop may have requested last")
+#pragma unroll
+                for (int v = u; v < CPW; ++v) asm volatile("" : "+v"(hv[rb][v]));
+                if (STAMPS) ++rerequests;
                 if (++spins > kSqSpinLimit || ((spins & 63u) == 0 && __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
                   if (lane == 0) atomicOr(a.err, 1u);
                   check = false;
@@ -143,7 +220,11 @@ __global__ __launch_bounds__(kSqThreads) void lstm_seq_kernel(const LstmSeqArgs 
             for (int i = 0; i < 4; ++i) {
 #pragma unroll
               for (int g = 0; g < 4; ++g) {
-                acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(hv[u][i], w[u][g][i], acc[g], 0, 0, 0);
+#if MMK_SQ_ACC2
+                if (i & 1) acc2[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(hv[rb][u][i]), w[u][g][i], acc2[g], 0, 0, 0);
+                else
+#endif
+                acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(hv[rb][u][i]), w[u][g][i], acc[g], 0, 0, 0);
 #if MMK_SQ_BUBBLE
                 if (g & 1) {
                   __builtin_amdgcn_sched_barrier(0);
@@ -160,10 +241,26 @@ __global__ __launch_bounds__(kSqThreads) void lstm_seq_kernel(const LstmSeqArgs 
         chunk(std::integral_constant<int, 3>{}); chunk(std::integral_constant<int, 4>{}); chunk(std::integral_constant<int, 5>{});
         chunk(std::integral_constant<int, 6>{}); chunk(std::integral_constant<int, 7>{});
         static_assert(CPW <= 8, "H <= 1024");
+#if MMK_SQ_ACC2
+#pragma unroll
+        for (int g = 0; g < 4; ++g) acc[g] += acc2[g];
+#endif
 #pragma unroll
         for (int g = 0; g < 4; ++g) red[((slot * 4 + g) * kSqWaves + wave) * 64 + lane] = acc[g];
+      } else if (kAhead) {
+        // (the gate terms landed: on this path they would be the youngest requests, and the compiler's wait for them in the cell is
+        //  the more cautious of the two paths' - behind the products they are OLDER than the next phase's fragments)
+        if (mine && cell) asm volatile("" : "+v"(ga[0]), "+v"(ga[1]), "+v"(ga[2]), "+v"(ga[3]));
+        if constexpr (rb == RB - 1) {
+          request_next();   // zero state: the first products are block 0's of step 1
+        } else {
+#pragma unroll
+          for (int u = 0; u < CPW; ++u) hv[nrb][u] = u32x4s{0u, 0u, 0u, 0u};
+        }
       }
+      if (STAMPS) stamp(s * RB + rb, 1, __builtin_amdgcn_s_memrealtime());
       __syncthreads();
+      if (STAMPS) { stamp(s * RB + rb, 2, __builtin_amdgcn_s_memrealtime()); stamp(s * RB + rb, 4, rerequests); }
       if (mine) {
         const int r = e_m & 15;
         const int frag = ((r >> 2) * 16 + e_n) * 4 + (r & 3);          // (row r, col n) of a 16x16 accumulator image
@@ -176,9 +273,11 @@ __global__ __launch_bounds__(kSqThreads) void lstm_seq_kernel(const LstmSeqArgs 
 #pragma unroll
             for (int wv = 0; wv < kSqWaves; ++wv) v += f[wv * 256];
           }
-          sum[g] = v + ga[g];
+          sum[g] = v;
         }
         if (cell) {
+#pragma unroll
+          for (int g = 0; g < 4; ++g) sum[g] += ga[g];
           const float ig = sigmoid_fast(sum[0]), fg = sigmoid_fast(sum[1]), cg = tanh_fast(sum[2]), og = sigmoid_fast(sum[3]);
           c_reg = fg * c_reg + ig * cg;
           const float hn = og * tanh_fast(c_reg);
@@ -191,6 +290,7 @@ __global__ __launch_bounds__(kSqThreads) void lstm_seq_kernel(const LstmSeqArgs 
           d.y[row * a.y_ld + (int64_t)t * a.y_ts + unit] = hn;
         }
       }
+      if (STAMPS) stamp(s * RB + rb, 3, __builtin_amdgcn_s_memrealtime());
     };
     phase(std::integral_constant<int, 0>{});
     if constexpr (RB > 1) phase(std::integral_constant<int, 1>{});
@@ -210,9 +310,16 @@ int launch_lstm_seq(const LstmSeqArgs& a, hipStream_t stream) {
   const int rb = a.M > 16 ? 2 : 1;
   const size_t lds = (size_t)2 * 4 * kSqWaves * 64 * 16;          // two slots of split-K partials
   dim3 grid(a.H / 16, (a.M + 16 * rb - 1) / (16 * rb), 2), block(kSqThreads);
-#define MMK_SQ(CPW_)                                                                             \
-  if (rb == 2) hipLaunchKernelGGL((lstm_seq_kernel<CPW_, 2>), grid, block, lds, stream, a);      \
-  else hipLaunchKernelGGL((lstm_seq_kernel<CPW_, 1>), grid, block, lds, stream, a)
+#ifdef MMK_DIAG
+#define MMK_SQ_ST(CPW_, RB_)                                                                                          \
+  if (a.stamps) hipLaunchKernelGGL((lstm_seq_kernel<CPW_, RB_, true>), grid, block, lds, stream, a);                  \
+  else hipLaunchKernelGGL((lstm_seq_kernel<CPW_, RB_, false>), grid, block, lds, stream, a)
+#else
+#define MMK_SQ_ST(CPW_, RB_) hipLaunchKernelGGL((lstm_seq_kernel<CPW_, RB_, false>), grid, block, lds, stream, a)
+#endif
+#define MMK_SQ(CPW_)                   \
+  if (rb == 2) { MMK_SQ_ST(CPW_, 2); } \
+  else { MMK_SQ_ST(CPW_, 1); }
   switch (a.H) {
     case 128: MMK_SQ(1); break;
     case 256: MMK_SQ(2); break;
@@ -221,6 +328,7 @@ int launch_lstm_seq(const LstmSeqArgs& a, hipStream_t stream) {
     default: return fail(MMK_ERR_UNSUPPORTED, "lstm sequence kernel: H=%d", a.H);
   }
 #undef MMK_SQ
+#undef MMK_SQ_ST
   MMK_HIP(hipGetLastError());
   return MMK_OK;
 }

@@ -14,6 +14,16 @@
 
 using namespace mmk;
 
+// environment switches of the DIAGNOSTIC build (phase stamps): the product library does not read them
+static inline const char* diag_env(const char* name) {
+#ifdef MMK_DIAG
+  return getenv(name);
+#else
+  (void)name;
+  return nullptr;
+#endif
+}
+
 namespace {
 
 // gather a strided (batch, hop, dim) window into rows (b*hop + t) of a padded buffer
@@ -149,6 +159,7 @@ struct mmk_s2s_plan {
   float* xch[2] = {nullptr, nullptr};
   int xch_cur = 0;
   uint32_t* seq_err = nullptr;
+  unsigned long long* seq_stamps = nullptr;      // diagnostic build: phase stamps of the last resident launch
   int n_cu = 0;
   int64_t seq_launches = 0;
   float *of = nullptr, *ob = nullptr, *es = nullptr, *coded = nullptr, *z = nullptr, *ysum = nullptr, *yout = nullptr;
@@ -190,6 +201,7 @@ struct mmk_s2s_plan {
     if (seq_lstm) {
       for (int k = 0; k < 2; ++k) xch[k] = cv.take<float>((int64_t)lstm_seq_xch_floats(D, Bmax, hop));
       seq_err = reinterpret_cast<uint32_t*>(cv.take<float>(64));
+      seq_stamps = reinterpret_cast<unsigned long long*>(cv.take<float>(2 * 16 * 8 * 8));
     }
     of = cv.take<float>(rows * D);
     ob = cv.take<float>(rows * D);
@@ -439,6 +451,10 @@ static int run_bilstm(mmk_s2s_plan* p, BiLstm& l, const float* x, int x_ld, int 
       a.dir[d].y = d == 0 ? p->of : p->ob;
     }
     a.xch = p->xch[p->xch_cur]; a.xch_next = p->xch[p->xch_cur ^ 1]; a.err = p->seq_err;
+    if (const char* senv = diag_env("MMK_S2S_STAMPS"); senv && senv[0] == '1') {
+      a.stamps = p->seq_stamps;
+      a.stamp_wg = diag_env("MMK_S2S_STAMP_WG") ? atoi(diag_env("MMK_S2S_STAMP_WG")) : 0;
+    }
     p->xch_cur ^= 1;
     p->seq_launches += 1;
     return launch_lstm_seq(a, st);
@@ -672,6 +688,21 @@ extern "C" int mmk_s2s_sync_status(mmk_s2s_plan* p, mmk_stream_t stream) {
   uint32_t word = 0;
   MMK_HIP(hipMemcpyAsync(&word, p->seq_err, sizeof(word), hipMemcpyDeviceToHost, st));
   MMK_HIP(hipStreamSynchronize(st));
+  if (const char* senv = diag_env("MMK_S2S_STAMPS"); senv && senv[0] == '1') {
+    std::vector<unsigned long long> h(16 * 8 * 8);
+    MMK_HIP(hipMemcpy(h.data(), p->seq_stamps, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    const unsigned long long t0 = h[0];
+    fprintf(stderr, "[mmk stamps] last resident bi-LSTM launch, workgroup (MMK_S2S_STAMP_WG, 0, 0), per phase and wave, 10 ns ticks since the first phase of wave 0: "
+                    "start / products done / barrier passed / cell done / fragments re-requested\n");
+    for (int ph = 0; ph < 16; ++ph) {
+      fprintf(stderr, "[mmk stamps] phase %2d:", ph);
+      for (int wv = 0; wv < 8; wv += 1) {
+        const unsigned long long* e = h.data() + (ph * 8 + wv) * 8;
+        fprintf(stderr, "  w%d %lld/%lld/%lld/%lld/%llu", wv, (long long)(e[0] - t0), (long long)(e[1] - t0), (long long)(e[2] - t0), (long long)(e[3] - t0), e[4]);
+      }
+      fprintf(stderr, "\n");
+    }
+  }
   if (word == 0) return MMK_OK;
   // a workgroup of the resident bi-LSTM kernel gave up waiting: the exchange images are in an unknown state - poison both sets again
   MMK_HIP(hipMemsetAsync(p->seq_err, 0, sizeof(uint32_t), st));

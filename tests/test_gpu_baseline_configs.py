@@ -207,6 +207,7 @@ def test_cfg5_seq2seq_d1024_hop8_64_clips(device):
     got = net.generate_step((x.to(device),), t=8).cpu()
     assert got.shape == (B, 8, 513)
     assert float((got - want).abs().max()) <= 1e-4 * float(want.abs().max())
+    assert net._plan.resident_launches() == 2        # encoder and decoder layer as one resident launch each (csrc/lstm_seq.hip)
     frames = torch.cat([x, torch.zeros(B, 16, 513)], 1).to(device)
     net.before_generate((frames[:, :8],), None)
     assert net.generate_block((frames,), 8, 16)

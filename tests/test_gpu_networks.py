@@ -686,6 +686,72 @@ def test_seq2seq_cfg5_geometry_vs_oracle(device, monkeypatch, fused, hop, batch)
         assert mmk.GenerateLoopV2.get_n_steps(loop_cfg, net) == 84
 
 
+@pytest.mark.parametrize("dim,hop,batch,layers", [(128, 2, 3, 1), (128, 8, 16, 2), (256, 5, 17, 1), (256, 8, 40, 2), (512, 3, 33, 1),
+                                                  (512, 8, 64, 1), (128, 7, 128, 1)])
+def test_seq2seq_resident_bilstm_kernel_vs_oracle(device, monkeypatch, dim, hop, batch, layers):
+    """the resident bi-LSTM kernel (csrc/lstm_seq.hip: all frames of a layer in one launch, W_hh in registers, the state exchanged
+    through poison-checked images) over its geometry: every register-resident width below 1024 (cfg 5 covers that), one and two
+    16-row blocks per workgroup, a ragged last block, one and several row halves, 2 .. 8 frames, stacked layers (the decoder's
+    start from the encoder's final state) - three chained generate_steps against the oracle and against the per-frame kernel"""
+    for k in ("MMK_S2S_FUSED", "MMK_S2S_SEQ"):
+        monkeypatch.delenv(k, raising=False)
+    io = mmk.IOSpec.magspec_io(mmk.IOSpec.MagSpecIOConfig(n_fft=128, hop_length=32))
+    cfg = mmk.Seq2SeqLSTMNetwork.Config(io_spec=io, model_dim=dim, hop=hop, enc_n_lstm=layers, dec_n_lstm=layers)
+    net = mmk.Seq2SeqLSTMNetwork.from_config(cfg).eval()
+    from oracle.weights import load_recipe
+    sd = load_recipe(net, seed=7 + dim + hop, gain=1.5)
+    net.to(device)
+    prompt = torch.rand(batch, hop, 65, generator=torch.Generator().manual_seed(batch))
+    want = O.s2s_generate(sd, prompt, 3 * hop, hop=hop)
+
+    def generate():
+        frames = torch.cat([prompt, torch.zeros(batch, 3 * hop, 65)], 1).to(device)
+        net.before_generate((frames[:, :hop],), None)
+        assert net.generate_block((frames,), hop, 3 * hop)
+        launches = net._plan.resident_launches()
+        net.after_generate((frames,), None)
+        return frames.cpu(), launches
+
+    got, launches = generate()
+    assert launches == 3 * 2 * layers
+    assert float((got - want).abs().max()) <= 2e-4 * float(want.abs().max())
+    again, _ = generate()
+    assert torch.equal(again, got)                    # the exchange images alternate between launches: a second pass sees the same
+    monkeypatch.setenv("MMK_S2S_SEQ", "0")
+    net._plan = None
+    per_frame, launches = generate()
+    assert launches == 0
+    assert float((got - per_frame).abs().max()) <= 1e-5 * float(want.abs().max())
+
+
+def test_seq2seq_timeout_is_redone_frame_by_frame(device, monkeypatch):
+    """a timed-out wait inside the resident bi-LSTM kernel (injected through mmk_s2s_inject_sync_error) must not return invalid
+    frames: the blocks of the generation are run again with one launch per frame, with a warning"""
+    for k in ("MMK_S2S_FUSED", "MMK_S2S_SEQ"):
+        monkeypatch.delenv(k, raising=False)
+    io = mmk.IOSpec.magspec_io(mmk.IOSpec.MagSpecIOConfig(n_fft=128, hop_length=32))
+    net = mmk.Seq2SeqLSTMNetwork.from_config(mmk.Seq2SeqLSTMNetwork.Config(io_spec=io, model_dim=128, hop=4)).eval()
+    from oracle.weights import load_recipe
+    sd = load_recipe(net, seed=71, gain=1.5)
+    net.to(device)
+    prompt = torch.rand(9, 4, 65, generator=torch.Generator().manual_seed(2))
+    want = O.s2s_generate(sd, prompt, 8, hop=4)
+    frames = torch.cat([prompt, torch.zeros(9, 8, 65)], 1).to(device)
+    net.before_generate((frames[:, :4],), None)
+    assert net.generate_block((frames,), 4, 8)
+    assert net._plan.resident_launches() == 4
+    frames[:, 4:] = -3.0                      # what a timed-out launch may leave behind
+    net._plan.inject_sync_error()
+    with pytest.warns(UserWarning, match="per frame"):
+        net.after_generate((frames,), None)
+    assert float((frames.cpu() - want).abs().max()) <= 2e-4 * float(want.abs().max())
+    assert net._plan is None                  # the next generation starts on a fresh (resident) plan
+    x = torch.rand(9, 4, 65, generator=torch.Generator().manual_seed(3))
+    got = net.generate_step((x.to(device),), t=4).cpu()
+    assert net._plan.resident_launches() == 2
+    assert float((got - O.s2s_step(sd, x, hop=4)).abs().max()) <= 1e-4 * float(got.abs().max())
+
+
 def test_wavenet_pad_side_1(device):
     """pad_side=1: golden from the reference's loop and eval forward (classes bit-exact, as for pad_side=0)"""
     g = H.golden("wavenet_pad1.npz")
