@@ -59,6 +59,9 @@ int64_t mmk_pack_launch_count(void);
  * mirror takes it over the concatenated weights where a generation starts, to notice writes through `tensor.data` that no version
  * counter records.  `out`: one uint64 on the device (cleared by the call). */
 int mmk_fingerprint_u32(const void* words, int64_t n_words, uint64_t* out, mmk_stream_t stream);
+/* the same number for `n_buffers` device buffers taken as one concatenation (host arrays of pointers and word counts), without
+ * concatenating them: one launch per 96 buffers */
+int mmk_fingerprint_buffers_u32(const void* const* buffers, const int64_t* n_words, int32_t n_buffers, uint64_t* out, mmk_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * Feature functionals

@@ -341,31 +341,94 @@ extern "C" int64_t mmk_pack_launch_count(void) { return mmk::g_pack_launches.loa
 // waves finish in does not matter.  One launch over the concatenated weights of a network; the host compares the number with the one
 // it took when it last committed a plan (mimikit_amd/native.py: WeightsTracker).
 namespace mmk {
-__global__ __launch_bounds__(256) void fingerprint_kernel(const uint32_t* __restrict__ w, int64_t n, unsigned long long* __restrict__ out) {
+__device__ __forceinline__ unsigned long long fingerprint_word(uint32_t w, uint32_t pos) {
+  uint32_t h = (w ^ (pos * 0x9E3779B1u)) * 0x85EBCA77u;
+  h ^= h >> 15;
+  h *= 0xC2B2AE3Du;
+  return (unsigned long long)(h ^ (h >> 13)) + ((unsigned long long)w << 20);
+}
+
+constexpr int kFpMaxBuffers = 96;
+struct FingerprintArgs {
+  const uint32_t* w[kFpMaxBuffers];
+  int64_t n[kFpMaxBuffers];
+  uint32_t pos0[kFpMaxBuffers];      // position of a buffer's first word in the concatenation (mod 2^32)
+  uint32_t blk0[kFpMaxBuffers + 1];  // first workgroup of a buffer: workgroups are dealt out in proportion to the sizes
+  int32_t count;
+};
+
+// 16 bytes per lane and load where the buffer allows it (every torch allocation does); one atomic per workgroup - thousands of
+// atomics on the one result word were the whole cost of the first version
+__global__ __launch_bounds__(256) void fingerprint_kernel(const FingerprintArgs a, unsigned long long* __restrict__ out) {
+  __shared__ unsigned long long part[4];
+  int bi = 0;
+  while (bi + 1 < a.count && blockIdx.x >= a.blk0[bi + 1]) ++bi;
+  const uint32_t* __restrict__ w = a.w[bi];
+  const int64_t n = a.n[bi];
+  const uint32_t pos0 = a.pos0[bi];
   unsigned long long acc = 0;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-    uint32_t h = (w[i] ^ ((uint32_t)i * 0x9E3779B1u)) * 0x85EBCA77u;
-    h ^= h >> 15;
-    h *= 0xC2B2AE3Du;
-    acc += (unsigned long long)(h ^ (h >> 13)) + ((unsigned long long)w[i] << 20);
+  const int64_t tid = (int64_t)(blockIdx.x - a.blk0[bi]) * blockDim.x + threadIdx.x;
+  const int64_t nthreads = (int64_t)(a.blk0[bi + 1] - a.blk0[bi]) * blockDim.x;
+  if ((reinterpret_cast<uintptr_t>(w) & 15) == 0) {
+    const uint4* w4 = reinterpret_cast<const uint4*>(w);
+    const int64_t n4 = n >> 2;
+    for (int64_t i = tid; i < n4; i += nthreads) {
+      const uint4 v = w4[i];
+      const uint32_t p = pos0 + (uint32_t)(4 * i);
+      acc += fingerprint_word(v.x, p) + fingerprint_word(v.y, p + 1) + fingerprint_word(v.z, p + 2) + fingerprint_word(v.w, p + 3);
+    }
+    for (int64_t i = 4 * n4 + tid; i < n; i += nthreads) acc += fingerprint_word(w[i], pos0 + (uint32_t)i);
+  } else {
+    for (int64_t i = tid; i < n; i += nthreads) acc += fingerprint_word(w[i], pos0 + (uint32_t)i);
   }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
-  if ((threadIdx.x & 63) == 0 && acc != 0) atomicAdd(out, acc);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned long long sum = part[0] + part[1] + part[2] + part[3];
+    if (sum != 0) atomicAdd(out, sum);
+  }
 }
 }  // namespace mmk
 
-extern "C" int mmk_fingerprint_u32(const void* words, int64_t n_words, uint64_t* out, mmk_stream_t stream) {
+extern "C" int mmk_fingerprint_buffers_u32(const void* const* buffers, const int64_t* n_words, int32_t n_buffers, uint64_t* out,
+                                           mmk_stream_t stream) {
   using namespace mmk;
-  if (!out || n_words < 0 || (n_words > 0 && !words)) return fail(MMK_ERR_INVALID, "fingerprint: bad arguments");
+  if (!out || n_buffers < 0 || (n_buffers > 0 && (!buffers || !n_words))) return fail(MMK_ERR_INVALID, "fingerprint: bad arguments");
   MMK_HIP(hipMemsetAsync(out, 0, sizeof(uint64_t), (hipStream_t)stream));
-  if (n_words == 0) return MMK_OK;
-  int64_t blocks = (n_words + 255) / 256;
-  blocks = blocks > 2048 ? 2048 : blocks;
-  hipLaunchKernelGGL(fingerprint_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const uint32_t*)words, n_words,
-                     (unsigned long long*)out);
-  MMK_HIP(hipGetLastError());
+  uint64_t pos = 0;
+  for (int first = 0; first < n_buffers; first += kFpMaxBuffers) {
+    FingerprintArgs a = {};
+    const int count = n_buffers - first < kFpMaxBuffers ? n_buffers - first : kFpMaxBuffers;
+    int64_t total = 0;
+    for (int i = 0; i < count; ++i) {
+      if (n_words[first + i] < 0 || (n_words[first + i] > 0 && !buffers[first + i])) return fail(MMK_ERR_INVALID, "fingerprint: bad buffer %d", first + i);
+      total += n_words[first + i];
+    }
+    if (total == 0) continue;
+    // ~2048 workgroups over the launch, 8192 words (32 per thread) or more each, one at least per buffer
+    const int64_t per_block = total / 2048 > 8192 ? total / 2048 : 8192;
+    uint32_t blocks = 0;
+    for (int i = 0; i < count; ++i) {
+      a.w[i] = (const uint32_t*)buffers[first + i];
+      a.n[i] = n_words[first + i];
+      a.pos0[i] = (uint32_t)pos;
+      a.blk0[i] = blocks;
+      pos += (uint64_t)a.n[i];
+      const int64_t nb = (a.n[i] + per_block - 1) / per_block;
+      blocks += (uint32_t)(nb > 0 ? nb : 1);
+    }
+    a.blk0[count] = blocks;
+    a.count = count;
+    hipLaunchKernelGGL(fingerprint_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a, (unsigned long long*)out);
+    MMK_HIP(hipGetLastError());
+  }
   return MMK_OK;
+}
+
+extern "C" int mmk_fingerprint_u32(const void* words, int64_t n_words, uint64_t* out, mmk_stream_t stream) {
+  return mmk_fingerprint_buffers_u32(&words, &n_words, 1, out, stream);
 }
 
 extern "C" int64_t mmk_packed_weight_floats(int32_t n_rows, int32_t k_cols) {

@@ -1,0 +1,23 @@
+// Arguments of the input-projection kernel of a bidirectional LSTM layer (see lstm_inproj.hip).
+#pragma once
+#include "mmk_common.h"
+
+namespace mmk {
+
+struct LstmInProjDir {
+  const float* wih_wp;          // packed (linear.hip) W_ih: 4H rows (i, f, g, o), K columns in k_chunks chunks of 16 (zero padded)
+  const float* bias;            // 4H sums b_ih + b_hh, or null
+  float* out;                   // (rows, 4H) with row stride out_ld
+};
+
+struct LstmInProjArgs {
+  const float* x;               // (rows, K) with row stride x_ld (a multiple of 4 floats, 16-byte aligned)
+  int64_t x_ld, out_ld;
+  int32_t rows, K, k_chunks, H;
+  LstmInProjDir dir[2];         // [forward, reverse]
+};
+
+bool lstm_inproj_supported(const float* x, int64_t x_ld, int rows, int K, int k_chunks, int H);
+int launch_lstm_inproj(const LstmInProjArgs& a, int n_cu, hipStream_t stream);
+
+}  // namespace mmk

@@ -39,11 +39,29 @@ constexpr unsigned kSqSpinLimit = 1u << 14;     // re-requests of one fragment (
 #ifndef MMK_SQ_AHEAD_AT
 #define MMK_SQ_AHEAD_AT 5      // ... in front of the products of chunk CPW * this / 8
 #endif
+#ifndef MMK_SQ_FAST_RCP
+#define MMK_SQ_FAST_RCP 1      // v_rcp_f32 in the cell's activations
+#endif
+#ifndef MMK_SQ_MAX3
+#define MMK_SQ_MAX3 1
+#endif
+#ifndef MMK_SQ_SPREAD
+#define MMK_SQ_SPREAD 1        // ... and dealt out over the chunks from there to the phase's last (0: all at once)
+#endif
 #ifndef MMK_SQ_FIRST_SC1
 #define MMK_SQ_FIRST_SC1 1     // 1: a fragment's FIRST request goes past the L2 as well (re-requests always do)
 #endif
 #ifndef MMK_SQ_ACC2
 #define MMK_SQ_ACC2 0          // experiment: two accumulator sets per gate (even / odd K quarter of a chunk)
+#endif
+#ifndef MMK_SQ_NOLOAD
+#define MMK_SQ_NOLOAD 0        // timing experiment only (wrong results): no state fragments are requested
+#endif
+#ifndef MMK_SQ_LOCALSRC
+#define MMK_SQ_LOCALSRC 0      // timing experiment only (wrong results): every fragment is read from the caller's state (never poisoned)
+#endif
+#ifndef MMK_SQ_NOCELL
+#define MMK_SQ_NOCELL 0        // timing experiment only (wrong results): the cell does not read the partial sums
 #endif
 #ifndef MMK_SQ_NOCHECK
 #define MMK_SQ_NOCHECK 0       // experiment only (wrong results possible): no poison check
@@ -54,13 +72,27 @@ constexpr unsigned kSqSpinLimit = 1u << 14;     // re-requests of one fragment (
 
 typedef unsigned u32x4s __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ bool sq_poisoned(const u32x4s& v) { return (v.x == kSqPoison) | (v.y == kSqPoison) | (v.z == kSqPoison) | (v.w == kSqPoison); }
+// any of the four words still the poison pattern (the largest unsigned value: one v_max3, one v_max, one compare)
+__device__ __forceinline__ bool sq_poisoned(const u32x4s& v) {
+#if !MMK_SQ_MAX3
+  return (v.x == kSqPoison) | (v.y == kSqPoison) | (v.z == kSqPoison) | (v.w == kSqPoison);
+#endif
+  unsigned m;
+  asm("v_max3_u32 %0, %1, %2, %3" : "=v"(m) : "v"(v.x), "v"(v.y), "v"(v.z));
+  return max(m, v.w) == kSqPoison;
+}
+
+// the cell's activations on the hardware reciprocal (1 ulp; the correctly rounded one of sigmoid_fast / tanh_fast is a ten-instruction
+// sequence, five of them per cell between a block's partial sums and its new state on the wire)
+__device__ __forceinline__ float sq_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.4426950408889634f)); }
+__device__ __forceinline__ float sq_tanh(float x) { return fmaf(__builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -2.8853900817779268f)), 2.f, -1.f); }
 
 // CPW - FROM state fragments of a wave's K range for one row block, 16 bytes per lane each, past the L2 (sc1): buffer loads the
 // compiler counts itself - a fragment is in flight across the frame loop's back edge, where only the compiler knows which of its
 // copies of a register is the live one
 template <int CPW, int FROM = 0>
 __device__ __forceinline__ void sq_request(u32x4s (&set)[CPW], const __amdgpu_buffer_rsrc_t& image, int byte_off) {
+  if (MMK_SQ_NOLOAD) return;
 #pragma unroll
   for (int u = FROM; u < CPW; ++u) set[u] = __builtin_amdgcn_raw_buffer_load_b128(image, byte_off, u * 64, MMK_SQ_FIRST_SC1 ? 16 : 0);
 }
@@ -128,7 +160,7 @@ __global__ __launch_bounds__(kSqThreads) void lstm_seq_kernel(const LstmSeqArgs 
     hoff[rb] = (int)(((int64_t)(m_first + (m < mg ? m : 0)) * H + c0 * 16 + 4 * (lane >> 4)) * sizeof(float));
   }
   auto image_of = [&](int s_src) {     // the state a step reads: the caller's before step 0, else the image step s_src - 1 wrote
-    const float* base = s_src == 0 ? d.h : a.xch + (int64_t)((s_src - 1) * 2 + di) * image;
+    const float* base = (s_src == 0 || MMK_SQ_LOCALSRC) ? d.h : a.xch + (int64_t)((s_src - 1) * 2 + di) * image;
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, -1, 0x00020000);
   };
   bool check = true;                                // false once this wave has given up: the launch only drains
@@ -161,7 +193,7 @@ __global__ __launch_bounds__(kSqThreads) void lstm_seq_kernel(const LstmSeqArgs 
       constexpr int rb = decltype(rbc)::value;
       constexpr int nrb = RB == 2 ? rb ^ 1 : 0;
       const bool mine = has_pair && my_rb == rb;
-      if (STAMPS) { rerequests = 0; stamp(s * RB + rb, 0, __builtin_amdgcn_s_memrealtime()); }
+      if (STAMPS) { rerequests = 0; stamp(s * RB + rb, 0, __builtin_amdgcn_s_memrealtime()); stamp(s * RB + rb, 5, __builtin_amdgcn_s_memtime()); }
       // partial-sum slot of this phase: one barrier per phase, so a slot must not be rewritten before the barrier after its readers
       const int slot = RB == 2 ? rb : (s & 1);
       // the additive gate terms of this thread's pair
@@ -182,6 +214,19 @@ __global__ __launch_bounds__(kSqThreads) void lstm_seq_kernel(const LstmSeqArgs 
         if constexpr (rb == 0 && RB == 2) sq_request<CPW>(hv[nrb], src_now, hoff[nrb]);
         else sq_request<CPW>(hv[nrb], src_next, hoff[nrb]);
       };
+      // ... dealt out over the chunks kAheadAt .. CPW - 1 of this phase's products, in the order they will be used: eight requests
+      // at once from every wave of the CU queue up in its address unit for ~1000 clocks, and a wave waiting there issues no MFMA
+      auto request_next_part = [&](auto uc) {
+        constexpr int u = decltype(uc)::value;
+        constexpr int span = CPW - kAheadAt;
+#pragma unroll
+        for (int v = 0; v < CPW; ++v)
+          if (kAheadAt + (v * span) / CPW == u) {
+            if (MMK_SQ_NOLOAD) continue;
+            if constexpr (rb == 0 && RB == 2) hv[nrb][v] = __builtin_amdgcn_raw_buffer_load_b128(src_now, hoff[nrb], v * 64, MMK_SQ_FIRST_SC1 ? 16 : 0);
+            else hv[nrb][v] = __builtin_amdgcn_raw_buffer_load_b128(src_next, hoff[nrb], v * 64, MMK_SQ_FIRST_SC1 ? 16 : 0);
+          }
+      };
       f32x4 acc[4];
 #pragma unroll
       for (int g = 0; g < 4; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -195,11 +240,14 @@ __global__ __launch_bounds__(kSqThreads) void lstm_seq_kernel(const LstmSeqArgs 
         auto chunk = [&](auto uc) {
           constexpr int u = decltype(uc)::value;
           if constexpr (u < CPW) {
-            if constexpr (kAhead && u == kAheadAt) {
+            if constexpr (kAhead && MMK_SQ_SPREAD && u >= kAheadAt) {
+              request_next_part(uc);
+              __builtin_amdgcn_sched_barrier(0);
+            } else if constexpr (kAhead && !MMK_SQ_SPREAD && u == kAheadAt) {
               request_next();
               __builtin_amdgcn_sched_barrier(0);
             }
-            if (polled && check && !MMK_SQ_NOCHECK) {
+            if (polled && check && !MMK_SQ_NOCHECK && !MMK_SQ_NOLOAD) {
               unsigned spins = 0;
               while (__builtin_amdgcn_ballot_w64(sq_poisoned(hv[rb][u])) != 0) {
                 // not there yet: ask again for this fragment and the ones behind it (their producers are as late), past the L2
@@ -268,7 +316,7 @@ __global__ __launch_bounds__(kSqThreads) void lstm_seq_kernel(const LstmSeqArgs 
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           float v = 0.f;
-          if (product) {
+          if (product && !MMK_SQ_NOCELL) {
             const float* f = reinterpret_cast<const float*>(red + (slot * 4 + g) * kSqWaves * 64) + frag;
 #pragma unroll
             for (int wv = 0; wv < kSqWaves; ++wv) v += f[wv * 256];
@@ -278,9 +326,15 @@ __global__ __launch_bounds__(kSqThreads) void lstm_seq_kernel(const LstmSeqArgs 
         if (cell) {
 #pragma unroll
           for (int g = 0; g < 4; ++g) sum[g] += ga[g];
+#if MMK_SQ_FAST_RCP
+          const float ig = sq_sigmoid(sum[0]), fg = sq_sigmoid(sum[1]), cg = sq_tanh(sum[2]), og = sq_sigmoid(sum[3]);
+          c_reg = fg * c_reg + ig * cg;
+          const float hn = og * sq_tanh(c_reg);
+#else
           const float ig = sigmoid_fast(sum[0]), fg = sigmoid_fast(sum[1]), cg = tanh_fast(sum[2]), og = sigmoid_fast(sum[3]);
           c_reg = fg * c_reg + ig * cg;
           const float hn = og * tanh_fast(c_reg);
+#endif
           if (last) {
             hout[row * H + unit] = hn;
             d.c[row * H + unit] = c_reg;

@@ -11,6 +11,7 @@
 #include "plan_util.h"
 #include "lstm_step.h"
 #include "lstm_seq.h"
+#include "lstm_inproj.h"
 
 using namespace mmk;
 
@@ -434,8 +435,18 @@ static int plain_linear(const PackedLinear& w, const float* x, int64_t ldx, int 
 static int run_bilstm(mmk_s2s_plan* p, BiLstm& l, const float* x, int x_ld, int M, bool zero_state, hipStream_t st) {
   const int D = p->D, hop = p->hop;
   const int64_t rows = (int64_t)M * hop;
+  // the input half of both directions: one launch with W_ih in registers where the chip holds it (lstm_inproj.hip), else a GEMM each
+  static const bool inproj_on = [] { const char* e = getenv("MMK_S2S_INPROJ"); return !(e && e[0] == '0'); }();
+  const bool inproj = inproj_on && p->seq_lstm && l.ih[0].nseg == 1 && l.ih[0].k_chunks <= 64 && D % 16 == 0 &&
+                      lstm_inproj_supported(x, x_ld, (int)rows, l.ih[0].segK[0], l.ih[0].k_chunks, D);
+  if (inproj) {
+    LstmInProjArgs ia = {};
+    ia.x = x; ia.x_ld = x_ld; ia.out_ld = 4 * D; ia.rows = (int)rows; ia.K = l.ih[0].segK[0]; ia.k_chunks = l.ih[0].k_chunks; ia.H = D;
+    for (int d = 0; d < 2; ++d) { ia.dir[d].wih_wp = l.ih[d].Wp; ia.dir[d].bias = l.ih[d].bias; ia.dir[d].out = p->gi[d]; }
+    MMK_TRY(launch_lstm_inproj(ia, p->n_cu, st));
+  }
   for (int d = 0; d < 2; ++d) {
-    MMK_TRY(plain_linear(l.ih[d], x, x_ld, (int)rows, p->gi[d], 4 * D, ACT_NONE, st, p->gemm_partial));
+    if (!inproj) MMK_TRY(plain_linear(l.ih[d], x, x_ld, (int)rows, p->gi[d], 4 * D, ACT_NONE, st, p->gemm_partial));
     if (zero_state && !p->fused_lstm) {
       // `lstm(x,)` : fresh zero state on every call                    (s2s_lstm_v2.py:97); the fused step kernel takes a flag
       MMK_HIP(hipMemsetAsync(p->h[d], 0, (size_t)p->Bmax * D * sizeof(float), st));
@@ -702,6 +713,8 @@ extern "C" int mmk_s2s_sync_status(mmk_s2s_plan* p, mmk_stream_t stream) {
       }
       fprintf(stderr, "\n");
     }
+    const double ticks = (double)(h[(15 * 8) * 8] - h[8 * 8]), clocks = (double)(h[(15 * 8) * 8 + 5] - h[8 * 8 + 5]);
+    if (ticks > 0) fprintf(stderr, "[mmk stamps] in-kernel clock over phases 1 .. 15 of wave 0: %.0f shader clocks in %.0f ticks of 10 ns = %.3f GHz\n", clocks, ticks, clocks / ticks * 0.1);
   }
   if (word == 0) return MMK_OK;
   // a workgroup of the resident bi-LSTM kernel gave up waiting: the exchange images are in an unknown state - poison both sets again

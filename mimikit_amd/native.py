@@ -61,6 +61,7 @@ _SIGNATURES = {
     "mmk_last_error": (cp, []),
     "mmk_pack_launch_count": (i64, []),
     "mmk_fingerprint_u32": (i32, [vp, i64, vp, vp]),
+    "mmk_fingerprint_buffers_u32": (i32, [vp, vp, i32, vp, vp]),
     "mmk_mulaw_compress_f32_i64": (i32, [vp, vp, i64, i32, f32, vp, vp]),
     "mmk_mulaw_expand_i64_f32": (i32, [vp, vp, i64, i32, f32, vp, vp]),
     "mmk_resample_n_out": (i64, [i64, i32, i32]),
@@ -413,8 +414,8 @@ def weights_identity(module: torch.nn.Module):
 
 def weights_fingerprint(module: torch.nn.Module) -> int:
     """A write through ``.data`` (``p.data.copy_(ema)``, weight surgery) bumps no version counter and moves no storage: a
-    position-mixed hash of all fp32 entries is summed on their device (``mmk_fingerprint_u32``: one concatenation, one launch, one
-    read-back - which waits for the stream; ~0.1 ms of device work).  Taken where a generation starts (``before_generate``),
+    position-mixed hash of all fp32 entries is summed on their device (``mmk_fingerprint_buffers_u32``: the entries where they lie,
+    one launch per 96 of them, one read-back - which waits for the stream).  Taken where a generation starts (``before_generate``),
     not on every step of one.  Entries on the host are hashed there."""
     entries = [v.detach() for v in module.state_dict(keep_vars=True).values() if v.dtype == torch.float32 and v.numel() > 0]
     if not entries:
@@ -423,9 +424,12 @@ def weights_fingerprint(module: torch.nn.Module) -> int:
     if dev.type != "cuda":
         import zlib
         return zlib.crc32(b"".join(v.contiguous().cpu().numpy().tobytes() for v in entries))
-    words = torch.cat([v.reshape(-1) for v in entries])
-    out = torch.zeros(1, dtype=torch.int64, device=dev)
-    check(lib().mmk_fingerprint_u32(ptr(words), words.numel(), ptr(out), stream_ptr(dev)), "mmk_fingerprint_u32")
+    entries = [v if v.is_contiguous() else v.contiguous() for v in entries]
+    n = len(entries)
+    ptrs = (C.c_void_p * n)(*[v.data_ptr() for v in entries])
+    counts = (i64 * n)(*[v.numel() for v in entries])
+    out = torch.empty(1, dtype=torch.int64, device=dev)
+    check(lib().mmk_fingerprint_buffers_u32(ptrs, counts, n, ptr(out), stream_ptr(dev)), "mmk_fingerprint_buffers_u32")
     return int(out.item())
 
 
