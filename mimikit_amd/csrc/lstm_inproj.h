@@ -11,13 +11,16 @@ struct LstmInProjDir {
 };
 
 struct LstmInProjArgs {
-  const float* x;               // (rows, K) with row stride x_ld (a multiple of 4 floats, 16-byte aligned)
-  int64_t x_ld, out_ld;
+  const float* x;               // (rows, K) with row stride x_ld; or, x_group > 0, row r at x + (r / x_group) x_group_stride + (r % x_group) x_ld:
+  int64_t x_ld, out_ld;         //   the frames of a caller's (clip, frame, bin) tensor read where they lie (x_group frames per clip)
+  int32_t x_group;
+  int64_t x_group_stride;
+  int64_t x_floats;             // floats from x that may be read (reads past them return zeros)
   int32_t rows, K, k_chunks, H;
   LstmInProjDir dir[2];         // [forward, reverse]
 };
 
-bool lstm_inproj_supported(const float* x, int64_t x_ld, int rows, int K, int k_chunks, int H);
+bool lstm_inproj_supported(int rows, int K, int k_chunks, int H);
 int launch_lstm_inproj(const LstmInProjArgs& a, int n_cu, hipStream_t stream);
 
 }  // namespace mmk

@@ -69,8 +69,10 @@ __global__ __launch_bounds__(kIpThreads) void lstm_inproj_kernel(const LstmInPro
   if (b_first >= b_end) return;
 
   // ---- this wave's slice of W_ih: 4 gate tiles x CPW chunks, resident for the launch (zeros beyond K) --------------------------------
-  const int c0 = wave * CPW;
-  const int n_valid = min(CPW, max(0, a.k_chunks - c0));                // chunks of this wave inside K
+  // K's chunks dealt out evenly: k_chunks / 8 per wave, the first k_chunks % 8 waves one more (CPW is the larger of the two counts)
+  const int c_base = a.k_chunks / kIpWaves, c_extra = a.k_chunks % kIpWaves;
+  const int c0 = wave * c_base + min(wave, c_extra);
+  const int n_valid = c_base + (wave < c_extra ? 1 : 0);
   f32x4 w[CPW][4];
   {
     const f32x4* wsrc = reinterpret_cast<const f32x4*>(d.wih_wp) + ((int64_t)ub * a.k_chunks + c0) * 64 + lane;
@@ -90,10 +92,16 @@ __global__ __launch_bounds__(kIpThreads) void lstm_inproj_kernel(const LstmInPro
 #pragma unroll
     for (int g = 0; g < 4; ++g) asm volatile("" : "+v"(w[u][g]));
 
-  const __amdgpu_buffer_rsrc_t xsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, (int)((int64_t)a.rows * a.x_ld * sizeof(float)), 0x00020000);   // reads past the last row: zeros
+  const __amdgpu_buffer_rsrc_t xsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, (int)(a.x_floats * sizeof(float)), 0x00020000);   // reads past the end: zeros
   auto frag_off = [&](int blk) {    // MFMA A operand: row lane & 15 of the block (clamped), K offset 4 (lane >> 4)
-    const int r = blk * 16 + (lane & 15);
-    return (int)(((int64_t)(r < a.rows ? r : a.rows - 1) * a.x_ld + (n_valid > 0 ? c0 : 0) * 16 + 4 * (lane >> 4)) * sizeof(float));   // (a wave beyond K: zero weights, the row's first chunks)
+    int r = blk * 16 + (lane & 15);
+    r = r < a.rows ? r : a.rows - 1;
+    int64_t at = (int64_t)r * a.x_ld;
+    if (a.x_group > 0) {
+      const int gq = r / a.x_group;
+      at = (int64_t)gq * a.x_group_stride + (int64_t)(r - gq * a.x_group) * a.x_ld;
+    }
+    return (int)((at + (n_valid > 0 ? c0 : 0) * 16 + 4 * (lane >> 4)) * sizeof(float));   // (a wave without chunks: zero weights, the row's first chunks)
   };
   u32x4s xa[2][CPW];
 #pragma unroll
@@ -135,10 +143,12 @@ __global__ __launch_bounds__(kIpThreads) void lstm_inproj_kernel(const LstmInPro
       }
       if (!MMK_IP_NOEPI && has_prev && ((u == kEpiEarly && !late_half) || (u == kEpiLate && late_half))) epilogue(blk - 1, set ^ 1);
       __builtin_amdgcn_sched_barrier(0);
+      if (u < n_valid) {      // (same for the whole wave)
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(xa[set][u][i]), w[u][g][i], acc[g], 0, 0, 0);
+          for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(xa[set][u][i]), w[u][g][i], acc[g], 0, 0, 0);
+      }
       __builtin_amdgcn_sched_barrier(0);
     }
     const int slot = set;
@@ -154,12 +164,13 @@ __global__ __launch_bounds__(kIpThreads) void lstm_inproj_kernel(const LstmInPro
   if (!MMK_IP_NOEPI) epilogue(b_end - 1, (b_end - 1 - b_first) & 1);
 }
 
-bool lstm_inproj_supported(const float* x, int64_t x_ld, int rows, int K, int k_chunks, int H) {
-  return rows >= 16 && H >= 16 && H % 16 == 0 && K >= 1 && k_chunks >= 1 && k_chunks <= 64 && (x_ld % 4) == 0 &&
-         (reinterpret_cast<uintptr_t>(x) & 15) == 0 && (int64_t)rows * x_ld * 4 < (int64_t)1 << 31;
+bool lstm_inproj_supported(int rows, int K, int k_chunks, int H) {
+  return rows >= 16 && H >= 16 && H % 16 == 0 && K >= 1 && k_chunks >= 1 && k_chunks <= 64;
 }
 
 int launch_lstm_inproj(const LstmInProjArgs& a, int n_cu, hipStream_t stream) {
+  if (a.x_floats <= 0 || a.x_floats * (int64_t)sizeof(float) >= ((int64_t)1 << 31) || (reinterpret_cast<uintptr_t>(a.x) & 3) != 0)
+    return fail(MMK_ERR_UNSUPPORTED, "lstm input projection kernel: %lld input floats", (long long)a.x_floats);
   const int n_blocks = (a.rows + 15) / 16;
   // one workgroup per CU where the rows allow it: units x directions workgroups per row share
   int split = n_cu / ((a.H / 16) * 2);

@@ -42,6 +42,9 @@ constexpr unsigned kSqSpinLimit = 1u << 14;     // re-requests of one fragment (
 #ifndef MMK_SQ_FAST_RCP
 #define MMK_SQ_FAST_RCP 1      // v_rcp_f32 in the cell's activations
 #endif
+#ifndef MMK_SQ_CHECK_GROUP
+#define MMK_SQ_CHECK_GROUP 1   // fragments whose poison check is one compare and one branch
+#endif
 #ifndef MMK_SQ_MAX3
 #define MMK_SQ_MAX3 1
 #endif
@@ -247,9 +250,19 @@ __global__ __launch_bounds__(kSqThreads) void lstm_seq_kernel(const LstmSeqArgs 
               request_next();
               __builtin_amdgcn_sched_barrier(0);
             }
-            if (polled && check && !MMK_SQ_NOCHECK && !MMK_SQ_NOLOAD) {
+            constexpr int kGroup = MMK_SQ_CHECK_GROUP < CPW ? MMK_SQ_CHECK_GROUP : CPW;     // fragments checked together
+            if (u % kGroup == 0 && polled && check && !MMK_SQ_NOCHECK && !MMK_SQ_NOLOAD) {
               unsigned spins = 0;
-              while (__builtin_amdgcn_ballot_w64(sq_poisoned(hv[rb][u])) != 0) {
+              auto group_poisoned = [&]() {
+                unsigned m = 0;
+#pragma unroll
+                for (int v = u; v < u + kGroup && v < CPW; ++v) {
+                  asm("v_max3_u32 %0, %1, %2, %3" : "=v"(m) : "v"(m), "v"(hv[rb][v].x), "v"(hv[rb][v].y));
+                  asm("v_max3_u32 %0, %1, %2, %3" : "=v"(m) : "v"(m), "v"(hv[rb][v].z), "v"(hv[rb][v].w));
+                }
+                return m == kSqPoison;
+              };
+              while (__builtin_amdgcn_ballot_w64(kGroup == 1 ? sq_poisoned(hv[rb][u]) : group_poisoned()) != 0) {
                 // not there yet: ask again for this fragment and the ones behind it (their producers are as late), past the L2
                 sq_rerequest<CPW, u>(hv[rb], src_now, hoff[rb]);
                 // (all of them landed before the check: the compiler's count of what is pending where the loop is left then is the

@@ -432,16 +432,28 @@ static int plain_linear(const PackedLinear& w, const float* x, int64_t ldx, int 
 }
 
 // one bidirectional LSTM over hop frames; rows of x/of/ob are (b*hop + t)
-static int run_bilstm(mmk_s2s_plan* p, BiLstm& l, const float* x, int x_ld, int M, bool zero_state, hipStream_t st) {
+// where the rows (clip, frame) of a layer's input lie when they are the caller's frames, read in place (group = frames per clip)
+struct FrameMap {
+  int group = 0;
+  int64_t clip_stride = 0, frame_stride = 0, floats = 0;
+};
+
+static bool inproj_enabled() {
+  static const bool on = [] { const char* e = getenv("MMK_S2S_INPROJ"); return !(e && e[0] == '0'); }();
+  return on;
+}
+
+static int run_bilstm(mmk_s2s_plan* p, BiLstm& l, const float* x, int x_ld, int M, bool zero_state, hipStream_t st, const FrameMap& fm = FrameMap()) {
   const int D = p->D, hop = p->hop;
   const int64_t rows = (int64_t)M * hop;
   // the input half of both directions: one launch with W_ih in registers where the chip holds it (lstm_inproj.hip), else a GEMM each
-  static const bool inproj_on = [] { const char* e = getenv("MMK_S2S_INPROJ"); return !(e && e[0] == '0'); }();
-  const bool inproj = inproj_on && p->seq_lstm && l.ih[0].nseg == 1 && l.ih[0].k_chunks <= 64 && D % 16 == 0 &&
-                      lstm_inproj_supported(x, x_ld, (int)rows, l.ih[0].segK[0], l.ih[0].k_chunks, D);
+  const bool inproj = inproj_enabled() && p->seq_lstm && l.ih[0].nseg == 1 && lstm_inproj_supported((int)rows, l.ih[0].segK[0], l.ih[0].k_chunks, D);
+  if (fm.group > 0 && !inproj) return fail(MMK_ERR_STATE, "s2s: frames in place need the input-projection kernel");
   if (inproj) {
     LstmInProjArgs ia = {};
     ia.x = x; ia.x_ld = x_ld; ia.out_ld = 4 * D; ia.rows = (int)rows; ia.K = l.ih[0].segK[0]; ia.k_chunks = l.ih[0].k_chunks; ia.H = D;
+    ia.x_floats = rows * x_ld;
+    if (fm.group > 0) { ia.x_group = fm.group; ia.x_group_stride = fm.clip_stride; ia.x_ld = fm.frame_stride; ia.x_floats = fm.floats; }
     for (int d = 0; d < 2; ++d) { ia.dir[d].wih_wp = l.ih[d].Wp; ia.dir[d].bias = l.ih[d].bias; ia.dir[d].out = p->gi[d]; }
     MMK_TRY(launch_lstm_inproj(ia, p->n_cu, st));
   }
@@ -519,9 +531,18 @@ static int s2s_step(mmk_s2s_plan* p, int M, const S2SIo& io, int n_out, hipStrea
   const int rows = M * hop;
   float* y = io.y;
   const int64_t ybs = io.ybs, yfs = io.yfs;
+  // continuous inputs: the first encoder layer's input projection reads the caller's frames where they lie (lstm_inproj.hip); else
+  // they (or the embedded classes) are gathered into padded rows first
+  FrameMap fm;
+  if (c.in_classes <= 0 && inproj_enabled() && p->seq_lstm && lstm_seq_supported(D, M, hop, p->n_cu) && p->enc[0].ih[0].nseg == 1 &&
+      lstm_inproj_supported(rows, p->enc[0].ih[0].segK[0], p->enc[0].ih[0].k_chunks, D) && io.xbs >= 0 && io.xfs >= 0) {
+    fm.group = hop; fm.clip_stride = io.xbs; fm.frame_stride = io.xfs;
+    fm.floats = (int64_t)(M - 1) * io.xbs + (int64_t)(hop - 1) * io.xfs + c.in_dim;
+    if (fm.floats * (int64_t)sizeof(float) >= ((int64_t)1 << 31)) fm = FrameMap();
+  }
   if (c.in_classes > 0)
     hipLaunchKernelGGL(embed_rows_kernel, dim3(rows), dim3(256), 0, st, io.xi, io.xbs, io.xfs, hop, c.in_classes, D, p->embed, p->xin, p->in_pad);
-  else
+  else if (fm.group == 0)
     hipLaunchKernelGGL(gather_frames_kernel, dim3(rows), dim3(256), 0, st, io.x, io.xbs, io.xfs, hop, c.in_dim, p->xin, p->in_pad);
   MMK_HIP(hipGetLastError());
   const size_t state_bytes = (size_t)M * D * sizeof(float);
@@ -531,7 +552,8 @@ static int s2s_step(mmk_s2s_plan* p, int M, const S2SIo& io, int n_out, hipStrea
   float* fold = p->ysum;
   bool pooled = false;
   for (size_t n = 0; n < p->enc.size(); ++n) {
-    MMK_TRY(run_bilstm(p, p->enc[n], xl, xl_ld, M, true, st));
+    if (n == 0 && fm.group > 0) MMK_TRY(run_bilstm(p, p->enc[n], io.x, xl_ld, M, true, st, fm));
+    else MMK_TRY(run_bilstm(p, p->enc[n], xl, xl_ld, M, true, st));
     const float* res = (n > 0 && c.enc_apply_residuals) ? xl : nullptr;
     if (n + 1 == p->enc.size() && c.enc_downsampling != 4) {   // last layer: fold + pool in one launch
       hipLaunchKernelGGL(pair_sum_pool_kernel, dim3(M), dim3(256), 0, st, p->of, p->ob, D, hop, c.enc_downsampling, res, p->es);
