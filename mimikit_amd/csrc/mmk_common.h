@@ -82,6 +82,19 @@ __device__ __forceinline__ int64_t addr_elems(const Addr& a, int tau) {
 }
 
 // ---- activations (match the torch CPU formulas the reference runs) ------------
+// Reciprocal of the activations below: __frcp_rn is a correctly rounded division (v_div_scale / v_fma / v_div_fixup: ten instructions),
+// MMK_FAST_RCP = 1 takes the hardware's v_rcp_f32 (1 ulp) - per translation unit, where the activation sits on a per-step chain.
+#ifndef MMK_FAST_RCP
+#define MMK_FAST_RCP 0
+#endif
+__device__ __forceinline__ float mmk_rcp(float x) {
+#if MMK_FAST_RCP
+  return __builtin_amdgcn_rcpf(x);
+#else
+  return __frcp_rn(x);
+#endif
+}
+
 enum Act : int32_t { ACT_NONE = 0, ACT_TANH = 1, ACT_SIGMOID = 2, ACT_MISH = 3, ACT_ABS = 4, ACT_RELU = 5 };
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
@@ -92,13 +105,13 @@ __device__ __forceinline__ float mishf_(float x) { return x * tanhf(log1pf(expf(
 __device__ __forceinline__ float mish_fast(float x) {
   const float e = __expf(fminf(x, 20.f));
   const float n = e * (e + 2.f);
-  return x > 20.f ? x : x * (n * __frcp_rn(n + 2.f));
+  return x > 20.f ? x : x * (n * mmk_rcp(n + 2.f));
 }
 
 // sigmoid / tanh with the hardware exp2 / rcp (the gate arithmetic of the WaveNet step kernels): sigmoid(x) = 1 / (1 + 2^(-x log2 e)),
 // tanh(x) = 2 sigmoid(2 x) - 1; ~1e-7 absolute, a handful of instructions instead of a libm call - for cells on a per-step chain
-__device__ __forceinline__ float sigmoid_fast(float x) { return __frcp_rn(1.0f + __builtin_amdgcn_exp2f(x * -1.4426950408889634f)); }
-__device__ __forceinline__ float tanh_fast(float x) { return fmaf(__frcp_rn(1.0f + __builtin_amdgcn_exp2f(x * -2.8853900817779268f)), 2.f, -1.f); }
+__device__ __forceinline__ float sigmoid_fast(float x) { return mmk_rcp(1.0f + __builtin_amdgcn_exp2f(x * -1.4426950408889634f)); }
+__device__ __forceinline__ float tanh_fast(float x) { return fmaf(mmk_rcp(1.0f + __builtin_amdgcn_exp2f(x * -2.8853900817779268f)), 2.f, -1.f); }
 
 __device__ __forceinline__ float apply_act(float v, int act) {
   switch (act) {

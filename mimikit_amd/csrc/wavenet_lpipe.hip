@@ -193,7 +193,7 @@ __device__ void run_stage(const WnLpipeArgs& a, int clip, int stage, int l0, flo
       const float acc = quad_sum((acc4[0] + acc4[1]) + (acc4[2] + acc4[3])) + bc[i];
       // tanh(f) sigmoid(g) (wavenet_v2.py:151), both halves at once on their own quads with the hardware exp2 / rcp, as in the other
       // step kernels: sigmoid(x) = 1 / (1 + 2^(-x log2 e)), tanh(x) = 2 sigmoid(2 x) - 1; the g quad sits four lanes up (row_shl:4)
-      const float act = fmaf(__frcp_rn(1.0f + __builtin_amdgcn_exp2f(acc * gate_scale)), gate_k, gate_shift);
+      const float act = fmaf(mmk_rcp(1.0f + __builtin_amdgcn_exp2f(acc * gate_scale)), gate_k, gate_shift);
       const float other = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(act), 0x104, 0xf, 0xf, false));
       if ((tid & 7) == 0) zs[tid >> 3] = act * other;
       __syncthreads();
