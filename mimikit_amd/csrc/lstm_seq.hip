@@ -171,6 +171,7 @@ __global__ __launch_bounds__(kSqThreads) void lstm_seq_kernel(const LstmSeqArgs 
   const bool stamping = STAMPS && a.stamps != nullptr && blockIdx.x == a.stamp_wg && blockIdx.y == 0 && blockIdx.z == 0 && lane == 0;
   auto stamp = [&](int ph, int k, unsigned long long v) { if (stamping && ph < 16) a.stamps[(ph * kSqWaves + wave) * 8 + k] = v; };
   unsigned rerequests = 0;
+  float pooled = 0.f;                               // this thread's folded column summed over the frames the pooling takes
 
   // The state fragments of a phase are requested during the phase before (two register sets, RB == 2): block 1's fragments of step s
   // while block 0's products of step s run, block 0's of step s + 1 during block 1's.  With one block there is nothing to overlap:
@@ -354,7 +355,23 @@ __global__ __launch_bounds__(kSqThreads) void lstm_seq_kernel(const LstmSeqArgs 
           } else {
             __hip_atomic_store(hout + row * H + unit, hn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);    // written through: other XCDs poll it
           }
-          d.y[row * a.y_ld + (int64_t)t * a.y_ts + unit] = hn;
+          if (d.y) d.y[row * a.y_ld + (int64_t)t * a.y_ts + unit] = hn;
+          if (a.fold || a.pool) {
+            // folded column (di H + unit) / 2 = this unit + its odd neighbour (the next lane; rows live or dead sixteen lanes at a time)
+            const float pair = hn + __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, hn), 0xB1, 0xF, 0xF, true));
+            if ((e_n & 1) == 0) {
+              const int64_t at = row * a.y_ld + (int64_t)t * a.y_ts + ((di * H + unit) >> 1);
+              const float v = a.res ? a.res[at] + pair : pair;
+              if (a.fold) a.fold[at] = v;
+              if (a.pool) {
+                if (a.pool_mode >= 2 || t == 0 || t == a.n_steps - 1) pooled += v;
+                if (last) {
+                  const float scale = a.pool_mode == 1 ? 0.5f : (a.pool_mode == 3 ? 1.f / (float)a.n_steps : 1.f);
+                  a.pool[row * H + ((di * H + unit) >> 1)] = a.pool_mode == 3 ? pooled / (float)a.n_steps : pooled * scale;
+                }
+              }
+            }
+          }
         }
       }
       if (STAMPS) stamp(s * RB + rb, 3, __builtin_amdgcn_s_memrealtime());

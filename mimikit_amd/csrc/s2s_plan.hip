@@ -443,7 +443,25 @@ static bool inproj_enabled() {
   return on;
 }
 
-static int run_bilstm(mmk_s2s_plan* p, BiLstm& l, const float* x, int x_ld, int M, bool zero_state, hipStream_t st, const FrameMap& fm = FrameMap()) {
+// what becomes of a layer's (forward | reverse) output: folded rows (+ residual) in `fold`, or those pooled per clip in `pool`
+struct FoldSpec {
+  float* fold = nullptr;
+  const float* res = nullptr;
+  float* pool = nullptr;
+  int pool_mode = 0;
+};
+
+// the fold as its own launch, for the paths that leave the two directions' rows in of / ob
+static int fold_rows(mmk_s2s_plan* p, int M, const FoldSpec& fs, hipStream_t st) {
+  const int rows = M * p->hop;
+  if (fs.pool) hipLaunchKernelGGL(pair_sum_pool_kernel, dim3(M), dim3(256), 0, st, p->of, p->ob, p->D, p->hop, fs.pool_mode, fs.res, fs.pool);
+  else hipLaunchKernelGGL(pair_sum_kernel, dim3(rows), dim3(256), 0, st, p->of, p->ob, p->D, rows, fs.res, fs.fold);
+  MMK_HIP(hipGetLastError());
+  return MMK_OK;
+}
+
+static int run_bilstm(mmk_s2s_plan* p, BiLstm& l, const float* x, int x_ld, int M, bool zero_state, hipStream_t st, const FoldSpec& fs,
+                      const FrameMap& fm = FrameMap()) {
   const int D = p->D, hop = p->hop;
   const int64_t rows = (int64_t)M * hop;
   // the input half of both directions: one launch with W_ih in registers where the chip holds it (lstm_inproj.hip), else a GEMM each
@@ -474,6 +492,9 @@ static int run_bilstm(mmk_s2s_plan* p, BiLstm& l, const float* x, int x_ld, int 
       a.dir[d].y = d == 0 ? p->of : p->ob;
     }
     a.xch = p->xch[p->xch_cur]; a.xch_next = p->xch[p->xch_cur ^ 1]; a.err = p->seq_err;
+    // the fold (and the encoder's pooling) happen in the cell: nobody reads the two directions' rows themselves
+    a.fold = fs.fold; a.res = fs.res; a.pool = fs.pool; a.pool_mode = fs.pool_mode;
+    a.dir[0].y = a.dir[1].y = nullptr;
     if (const char* senv = diag_env("MMK_S2S_STAMPS"); senv && senv[0] == '1') {
       a.stamps = p->seq_stamps;
       a.stamp_wg = diag_env("MMK_S2S_STAMP_WG") ? atoi(diag_env("MMK_S2S_STAMP_WG")) : 0;
@@ -504,7 +525,7 @@ static int run_bilstm(mmk_s2s_plan* p, BiLstm& l, const float* x, int x_ld, int 
     if (cur[0] != p->h[0])
       for (int d = 0; d < 2; ++d)
         MMK_HIP(hipMemcpyAsync(p->h[d], cur[d], (size_t)M * D * sizeof(float), hipMemcpyDeviceToDevice, st));
-    return MMK_OK;
+    return fold_rows(p, M, fs, st);
   }
   for (int s = 0; s < hop; ++s) {
     for (int d = 0; d < 2; ++d) {
@@ -515,7 +536,7 @@ static int run_bilstm(mmk_s2s_plan* p, BiLstm& l, const float* x, int x_ld, int 
                                p->c[d], D, y, (int64_t)hop * D, M, D, st));
     }
   }
-  return MMK_OK;
+  return fold_rows(p, M, fs, st);
 }
 
 // one step's input and output: frames (x, y) or class indices (xi, yi), strides per clip and per frame / position
@@ -552,17 +573,17 @@ static int s2s_step(mmk_s2s_plan* p, int M, const S2SIo& io, int n_out, hipStrea
   float* fold = p->ysum;
   bool pooled = false;
   for (size_t n = 0; n < p->enc.size(); ++n) {
-    if (n == 0 && fm.group > 0) MMK_TRY(run_bilstm(p, p->enc[n], io.x, xl_ld, M, true, st, fm));
-    else MMK_TRY(run_bilstm(p, p->enc[n], xl, xl_ld, M, true, st));
-    const float* res = (n > 0 && c.enc_apply_residuals) ? xl : nullptr;
-    if (n + 1 == p->enc.size() && c.enc_downsampling != 4) {   // last layer: fold + pool in one launch
-      hipLaunchKernelGGL(pair_sum_pool_kernel, dim3(M), dim3(256), 0, st, p->of, p->ob, D, hop, c.enc_downsampling, res, p->es);
-      MMK_HIP(hipGetLastError());
+    FoldSpec fs;
+    fs.res = (n > 0 && c.enc_apply_residuals) ? xl : nullptr;
+    const bool pool_here = n + 1 == p->enc.size() && c.enc_downsampling != 4;     // last layer: fold + pool together
+    if (pool_here) { fs.pool = p->es; fs.pool_mode = c.enc_downsampling; }
+    else fs.fold = fold;
+    if (n == 0 && fm.group > 0) MMK_TRY(run_bilstm(p, p->enc[n], io.x, xl_ld, M, true, st, fs, fm));
+    else MMK_TRY(run_bilstm(p, p->enc[n], xl, xl_ld, M, true, st, fs));
+    if (pool_here) {
       pooled = true;
       break;
     }
-    hipLaunchKernelGGL(pair_sum_kernel, dim3(rows), dim3(256), 0, st, p->of, p->ob, D, rows, res, fold);
-    MMK_HIP(hipGetLastError());
     xl = fold; xl_ld = D;
     fold = fold == p->ysum ? p->yalt : p->ysum;
   }
@@ -598,10 +619,10 @@ static int s2s_step(mmk_s2s_plan* p, int M, const S2SIo& io, int n_out, hipStrea
         MMK_HIP(hipMemcpyAsync(p->h[d], p->hs[d], state_bytes, hipMemcpyDeviceToDevice, st));
         MMK_HIP(hipMemcpyAsync(p->c[d], p->cs[d], state_bytes, hipMemcpyDeviceToDevice, st));
       }
-    MMK_TRY(run_bilstm(p, p->dec[n], xl, D, M, false, st));
-    hipLaunchKernelGGL(pair_sum_kernel, dim3(rows), dim3(256), 0, st, p->of, p->ob, D, rows,
-                       c.dec_apply_residuals ? xl : (const float*)nullptr, fold);
-    MMK_HIP(hipGetLastError());
+    FoldSpec fs;
+    fs.fold = fold;
+    fs.res = c.dec_apply_residuals ? xl : nullptr;
+    MMK_TRY(run_bilstm(p, p->dec[n], xl, D, M, false, st, fs));
     xl = fold;
     fold = fold == p->ysum ? p->yalt : p->ysum;
   }
