@@ -401,8 +401,9 @@ class S2SJob:
             traffic = int(per_call * calls) if per_call else None
         except (OSError, ValueError):
             traffic = None
-        return {"bound": "mfma", "kernel": "Seq2Seq generate block: gemm_bias_act_kernel (input / output projections) + lstm_step_kernel "
-                                           "(recurrent products + cells), all generate_steps of one block",
+        return {"bound": "mfma", "kernel": "Seq2Seq generate block: lstm_inproj_kernel (input half of a bi-LSTM layer, W_ih in registers) + "
+                                           "lstm_seq_kernel (all frames of a layer in one launch, W_hh in registers) + skinny_linear_kernel / "
+                                           "gemm_bias_act_kernel (up-sampler, output projection), all generate_steps of one block",
                 "achieved": round(achieved, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(achieved / MFMA_F32_PEAK_TFLOPS, 5), "traffic": traffic,
                 "algorithmic_flops_per_launch": flops, "avg_launch_us": round(us, 1), "launches_timed": 1,

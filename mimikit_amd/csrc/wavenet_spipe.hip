@@ -56,9 +56,9 @@ constexpr unsigned kSpinLimit = 1u << 22;
 #endif
 constexpr int kPollGap = MMK_SP_POLL_GAP;     // s_sleep units (64 cycles) between two looks at a message that has not arrived
 #ifndef MMK_SP_LDS_SLEEP
-#define MMK_SP_LDS_SLEEP 3
+#define MMK_SP_LDS_SLEEP 5
 #endif
-constexpr int kLdsSleep = MMK_SP_LDS_SLEEP;   // s_sleep units inside the spins on LDS counters: measured 0 / 1 / 3 / 6 / 10 -> 55.7 / 55.6 / 55.3 / 55.9 / 56.5 us per step
+constexpr int kLdsSleep = MMK_SP_LDS_SLEEP;   // s_sleep units inside the spins on LDS counters: with the chain waves' wait as three FLAT loads 0 / 1 / 3 / 6 / 10 -> 55.7 / 55.6 / 55.3 / 55.9 / 56.5 us per step; as ds_reads (55.3 -> 54.4) 0 / 1 / 2 / 3 / 5 / 7 / 10 / 15 -> 54.3 / 54.9 / 54.6 / 54.3 / 53.9 / 54.1 / 54.2 / 54.7
 #ifndef MMK_SP_LOOKS
 #define MMK_SP_LOOKS 1
 #endif
@@ -114,9 +114,12 @@ __device__ __forceinline__ void lds_signal(unsigned* p, unsigned v, int lane) {
   if (lane == 0) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   __atomic_signal_fence(__ATOMIC_SEQ_CST);
 }
+// (atomic loads, not volatile ones: the compiler leaves a volatile access through a generic pointer a FLAT instruction - which reaches
+//  LDS through the CU's vector-memory pipe, behind every global load and store in flight, and is waited for with vmcnt(0))
 __device__ __forceinline__ unsigned lds_min4(const unsigned* p) {
-  const u32x4s v = *reinterpret_cast<const volatile u32x4s*>(p);     // one 16-byte read (the four counters share an aligned line)
-  return min(min(v[0], v[1]), min(v[2], v[3]));
+  const unsigned v0 = __hip_atomic_load(p + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP), v1 = __hip_atomic_load(p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  const unsigned v2 = __hip_atomic_load(p + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP), v3 = __hip_atomic_load(p + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  return min(min(v0, v1), min(v2, v3));
 }
 // wait until all four counters reach `want`; false after ~1 s (the other waves of the workgroup have failed or the kernel is wedged)
 __device__ __forceinline__ bool lds_wait4(const unsigned* p, unsigned want, int32_t* err) {
@@ -173,8 +176,8 @@ struct Stamps {
 __device__ __forceinline__ bool chain_wait(const Lds& S, int q, unsigned v, int32_t* err) {
   unsigned spins = 0;
   for (;;) {
-    const unsigned arr = *reinterpret_cast<const volatile unsigned*>(&S.arrived[0]), hd = lds_min4(S.hdone);
-    const unsigned rd = *reinterpret_cast<const volatile unsigned*>(&S.ready[q]);
+    const unsigned arr = __hip_atomic_load(&S.arrived[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP), hd = lds_min4(S.hdone);
+    const unsigned rd = __hip_atomic_load(&S.ready[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     if (arr >= v + 1 && hd + (kXyRing - 2) >= v + 1 && rd >= v + 1) break;
     if (kLdsSleep > 0) __builtin_amdgcn_s_sleep(kLdsSleep);
     if (++spins > kSpinLimit || ((spins & 4095u) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
