@@ -204,7 +204,15 @@ __device__ void chain_role(const WnSpipeArgs& a, Lds& S, int stage, int p, int q
 #pragma unroll
     for (int i = 0; i < 8; ++i) wr[i] = img[(32 + i) * 64];
   }
-  const float bx = a.cst_chain[((int64_t)stage * kWavesPerStage + W) * 64 + lane];
+  float bx = a.cst_chain[((int64_t)stage * kWavesPerStage + W) * 64 + lane];
+  // IN their registers before the visit loop: a load the compiler still counts as pending at the loop's entry makes it wait inside
+  // every visit - vmcnt(40) ... vmcnt(0) along the products - and the last of those waits also cover the visit's own stores, the
+  // written-through message of the previous visit included
+#pragma unroll
+  for (int i = 0; i < 32; ++i) asm volatile("" : "+v"(wz[i]));
+#pragma unroll
+  for (int i = 0; i < 8; ++i) asm volatile("" : "+v"(wr[i]));
+  asm volatile("" : "+v"(bx));
   const bool g_row = (j & 1) != 0;
   const float gate_scale = g_row ? -1.4426950408889634f : -2.8853900817779268f;
   const float gate_k = g_row ? 1.f : 2.f, gate_shift = g_row ? 0.f : -1.f;
@@ -371,7 +379,15 @@ __device__ void helper_role(const WnSpipeArgs& a, Lds& S, int stage, int p, int 
 #pragma unroll
     for (int i = 0; i < 4; ++i) wh[i] = img[(32 + i) * 64];
   }
-  const float bz = a.cst_helper[((int64_t)stage * kWavesPerStage + W) * 64 + lane];
+  float bz = a.cst_helper[((int64_t)stage * kWavesPerStage + W) * 64 + lane];
+  // (in their registers before the loop, as in the chain role)
+#pragma unroll
+  for (int i = 0; i < 16; ++i) asm volatile("" : "+v"(w0[i]));
+#pragma unroll
+  for (int i = 0; i < 16; ++i) asm volatile("" : "+v"(wc[i]));
+#pragma unroll
+  for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(wh[i]));
+  asm volatile("" : "+v"(bz));
   const int d = a.dil[stage], ring_mask = a.ring[stage] - 1;
   const int64_t slot_stride = (int64_t)a.Bmax * kC;
   const bool local_next = ((stage + 1) >> 2) == (stage >> 2);
@@ -561,6 +577,12 @@ __device__ void head_role(const WnSpipeArgs& a, int p) {
     wt[1] = a.fc2_w[(int64_t)kQ * kH1 + 64 + lane];
     bt = a.fc2_b[kQ];
   }
+  // (in their registers before the step loop, as in the chain role)
+#pragma unroll
+  for (int k = 0; k < 64; ++k) asm volatile("" : "+v"(w0[k]));
+#pragma unroll
+  for (int k = 0; k < 64; ++k) asm volatile("" : "+v"(w2[k]));
+  asm volatile("" : "+v"(wt[0]), "+v"(wt[1]), "+v"(bt));
   if (tid == 0) s_fail = 0;
   const int L = a.L;
   const int64_t stage_words = (int64_t)a.Bmax * kSpSlots * kMsgFloats;
