@@ -412,6 +412,14 @@ __global__ __launch_bounds__(kBotThreads) void srnn_bottom1_kernel(const SrnnBot
   constexpr bool composed = COMPOSED;
   const float a_c0 = (composed && ks < 4 && cg * 4 + ks < Hm) ? a.a_comp[cg * 4 + ks] : 0.f;
   const float b_c = (composed && ks < 4 && cg * 4 + ks < Hm) ? a.b_comp[cg * 4 + ks] : 0.f;
+  // (the MLP slices IN their registers before the step loop: a load the compiler still counts as pending at the loop's entry makes
+  //  it wait inside every step, and such a wait also covers the step's own stores - see wavenet_spipe.hip)
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int f = 0; f < F0; ++f) asm volatile("" : "+v"(w0[j][f]));
+#pragma unroll
+  for (int j = 0; j < 8; ++j) asm volatile("" : "+v"(w2[j][0]), "+v"(w2[j][1]));
   const int n_extra = n_out > 256 ? n_out - 256 : 0;
   for (int i = tid; i < n_extra * Hm; i += kBotThreads) wx[i] = a.fc2_raw[(int64_t)256 * Hm + i];
   for (int i = tid; i < 16 * kPad2; i += kBotThreads) hid[i] = 0.f;

@@ -105,6 +105,23 @@ __device__ void run_stage(const WnLpipeArgs& a, int clip, int stage, int l0, flo
       bt = a.fc2_bias[kQ];
     }
   }
+  // (IN their registers before the step loop: a load the compiler still counts as pending at the loop's entry makes it wait inside
+  //  every step, and such a wait also covers the step's own written-through stores - see wavenet_spipe.hip)
+#pragma unroll
+  for (int i = 0; i < NL; ++i) {
+#pragma unroll
+    for (int k = 0; k < 32; ++k) asm volatile("" : "+v"(wc[i][k]));
+#pragma unroll
+    for (int k = 0; k < 16; ++k) asm volatile("" : "+v"(wr[i][k]));
+    asm volatile("" : "+v"(bc[i]), "+v"(br[i]));
+  }
+  if constexpr (HEAD) {
+#pragma unroll
+    for (int k = 0; k < 16; ++k) asm volatile("" : "+v"(w0[k]));
+#pragma unroll
+    for (int k = 0; k < 64; ++k) asm volatile("" : "+v"(w2[k]));
+    asm volatile("" : "+v"(wt[0]), "+v"(wt[1]), "+v"(b0), "+v"(b2), "+v"(bt));
+  }
   if constexpr (FIRST) {
     for (int i = tid; i < kQ * kC; i += kLpThreads) embs[i] = a.emb[i];
   }
