@@ -394,18 +394,23 @@ class S2SJob:
         calls = -(-self.n_steps // self.net.config.hop)
         flops = self.step_flops() * self.clips * calls
         achieved = flops / (us * 1e-6) / 1e12
-        traffic = None
-        try:   # HBM-side bytes of one generate_step from the PMC passes (profiles/traffic.json), times the block's generate_steps
+        traffic, traffic_source = None, None
+        try:   # HBM-side bytes of one generate_step from the PMC passes (profiles/traffic.json), times the block's generate_steps -
+               # only if that entry was collected with the resident bi-LSTM kernel this build runs
             with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
-                per_call = json.load(f).get(self.name, {}).get("generate_step", {}).get("bytes")
-            traffic = int(per_call * calls) if per_call else None
-        except (OSError, ValueError):
-            traffic = None
+                entry = json.load(f).get(self.name, {}).get("generate_step", {})
+            per_call = entry.get("bytes")
+            if per_call and any("lstm_seq_kernel" in k for k in entry.get("kib_by_kernel", {})) and self.net._plan.resident_launches() > 0:
+                traffic = int(per_call * calls)
+                traffic_source = (f"profiles/traffic.json, build {entry.get('build')} (commit {entry.get('commit')}): rocprofv3 --pmc FETCH_SIZE / "
+                                  "WRITE_SIZE passes over all kernels of a generate_step, times the block's generate_steps; not re-measured in this run")
+        except (OSError, ValueError, AttributeError):
+            traffic, traffic_source = None, None
         return {"bound": "mfma", "kernel": "Seq2Seq generate block: lstm_inproj_kernel (input half of a bi-LSTM layer, W_ih in registers) + "
                                            "lstm_seq_kernel (all frames of a layer in one launch, W_hh in registers) + skinny_linear_kernel / "
                                            "gemm_bias_act_kernel (up-sampler, output projection), all generate_steps of one block",
                 "achieved": round(achieved, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(achieved / MFMA_F32_PEAK_TFLOPS, 5), "traffic": traffic,
+                "frac": round(achieved / MFMA_F32_PEAK_TFLOPS, 5), "traffic": traffic, "traffic_source": traffic_source,
                 "algorithmic_flops_per_launch": flops, "avg_launch_us": round(us, 1), "launches_timed": 1,
                 "generate_steps_per_launch": calls, "us_per_generate_step": round(us / calls, 2)}
 
