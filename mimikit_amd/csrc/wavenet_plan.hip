@@ -202,7 +202,7 @@ struct mmk_wavenet_plan {
     hid[1] = c.take<float>((int64_t)Bmax * hmax);
     logits_ld = (int)round_up(cfg.out_dim + (cfg.learn_temp ? 1 : 0), 4);
     logits = c.take<float>((int64_t)Bmax * logits_ld);
-    tau = c.take<int64_t>(256);   // [0]: the launch path's position; [8 ..]: stamps of the diagnostic builds
+    tau = c.take<int64_t>(8 + 256 + 2048 + 256 + 8);   // [0]: the launch path's position; [8 ..]: stamps of the diagnostic builds
     if (persistent) layout_persistent(c);
   }
 
@@ -1371,6 +1371,29 @@ extern "C" int mmk_wavenet_sync_status(mmk_wavenet_plan* p, mmk_stream_t stream)
         fprintf(stderr, " | head: last layer -> class of the step before the last: n/a; step before last's class -> last step's stage 0 publish=%lld; "
                         "last stage publish -> head done=%lld\n",
                 (long long)(st[16] - st[16 + p->L + 1]), (long long)(st[16 + p->L + 2] - st[16 + p->L - 1]));
+        {   // the last step of every clip: mean over the clips of [publish of the stage below -> seen | seen -> my publish], 10 ns ticks
+          std::vector<unsigned long long> all(256 + 2048 + 256);
+          MMK_HIP(hipMemcpy(all.data(), p->tau + 8, all.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+          fprintf(stderr, "[mmk stamps] the middle step of the launch, mean over the clips, per stage [publish of the stage below -> message seen | seen -> my publish]:");
+          double tot = 0;
+          for (int l = 1; l < p->L && l < 32; ++l) {
+            double a = 0, b = 0;
+            int n = 0;
+            for (int cidx = 0; cidx < 32 && cidx < p->Bmax; ++cidx) {
+              const unsigned long long pub0 = all[256 + (l - 1) * 32 + cidx], seen = all[256 + 1024 + l * 32 + cidx], pub1 = all[256 + l * 32 + cidx];
+              if (!pub0 || !seen || !pub1) continue;
+              a += (double)((long long)(seen - pub0)); b += (double)((long long)(pub1 - seen)); ++n;
+            }
+            if (n) { fprintf(stderr, " %d:[%.0f %.0f]", l, a / n, b / n); tot += (a + b) / n; }
+          }
+          fprintf(stderr, " | sum %.0f\n", tot);
+          fprintf(stderr, "[mmk stamps] the middle step, clip 5: publish time of a stage's CUs 1 .. 7 minus its CU 0's, 10 ns ticks:");
+          for (int l = 0; l < p->L && l < 31; ++l) {
+            fprintf(stderr, " %d:[", l);
+            for (int q = 1; q < 8; ++q) fprintf(stderr, "%lld%s", (long long)(all[256 + 2048 + l * 8 + q] - all[256 + 2048 + l * 8]), q < 7 ? " " : "]");
+          }
+          fprintf(stderr, "\n");
+        }
         return MMK_OK;
       }
       if (p->pipe) {

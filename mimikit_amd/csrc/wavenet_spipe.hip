@@ -286,6 +286,7 @@ __device__ void chain_role(const WnSpipeArgs& a, Lds& S, int stage, int p, int q
         *reinterpret_cast<f32x4s*>(dst) = f32x4s{__uint_as_float(w_lo[0]), __uint_as_float(w_lo[1]), __uint_as_float(w_lo[2]), __uint_as_float(w_lo[3])};
         *reinterpret_cast<f32x4s*>(dst + 4) = f32x4s{__uint_as_float(w_hi[0]), __uint_as_float(w_hi[1]), __uint_as_float(w_hi[2]), __uint_as_float(w_hi[3])};
         if (STAMPS && a.stamps && c == 0 && s + 1 == n_steps && p == 0 && lane == 0) a.stamps[64 + stage] = __builtin_amdgcn_s_memrealtime();
+        if (STAMPS && a.stamps && s == n_steps / 2 && p == 0 && lane == 0 && c < 32) a.stamps[256 + 1024 + stage * 32 + c] = __builtin_amdgcn_s_memrealtime();   // seen, every clip, the launch's middle step
         lds_signal(&S.arrived[0], v + 1, lane);
         // first look at the NEXT visit's message: in flight while this visit computes
         int cn = c + 1, sn = s;
@@ -349,6 +350,8 @@ __device__ void chain_role(const WnSpipeArgs& a, Lds& S, int stage, int p, int q
         const u64 t = __builtin_amdgcn_s_memtime(); st.t_compute += t - t0c; t0c = t;
         // wall clock (100 MHz, one counter for the chip) of clip 0's publish in the last step, per stage: the chain's time line
         if (a.stamps && c == 0 && s + 1 == n_steps && p == 0 && q == 0 && lane == 0) a.stamps[16 + stage] = __builtin_amdgcn_s_memrealtime();
+        if (a.stamps && s == n_steps / 2 && p == 0 && q == 0 && lane == 0 && c < 32) a.stamps[256 + stage * 32 + c] = __builtin_amdgcn_s_memrealtime();        // published, every clip
+        if (a.stamps && s == n_steps / 2 && c == 5 && q == 0 && lane == 0) a.stamps[256 + 2048 + stage * 8 + p] = __builtin_amdgcn_s_memrealtime();               // published, every CU of the stage, clip 5
       }
       __builtin_amdgcn_s_setprio(0);
       if (pub_lane) msg_store(msg_out + ((int64_t)c * kSpSlots + pslot) * kMsgFloats + pub_off, kSpPoison, local_next);
