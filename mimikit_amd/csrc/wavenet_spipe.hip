@@ -59,6 +59,11 @@ constexpr int kPollGap = MMK_SP_POLL_GAP;     // s_sleep units (64 cycles) betwe
 #define MMK_SP_LDS_SLEEP 5
 #endif
 constexpr int kLdsSleep = MMK_SP_LDS_SLEEP;   // s_sleep units inside the spins on LDS counters: with the chain waves' wait as three FLAT loads 0 / 1 / 3 / 6 / 10 -> 55.7 / 55.6 / 55.3 / 55.9 / 56.5 us per step; as ds_reads (55.3 -> 54.4) 0 / 1 / 2 / 3 / 5 / 7 / 10 / 15 -> 54.3 / 54.9 / 54.6 / 54.3 / 53.9 / 54.1 / 54.2 / 54.7
+#ifndef MMK_SP_SLOT_SHIFT
+#define MMK_SP_SLOT_SHIFT 0     // empty slots in front of layer 0 (which layers are the first and the last of an XCD).  Measured on cfg 4: 1 -> 58.8 us
+                                // per step against 50.9 (layer 10, a dilation-1 stage, is then the LAST of its XCD; with 0 layers 0 and 20 are the first of theirs)
+#endif
+constexpr int kSlotShift = MMK_SP_SLOT_SHIFT;
 #ifndef MMK_SP_LOOKS
 #define MMK_SP_LOOKS 1
 #endif
@@ -106,6 +111,9 @@ __device__ __forceinline__ float row_reduce_scatter2(float v0, float v1, int ks)
 }
 
 __device__ __forceinline__ f32x2 fma2(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+
+// layers + head + the empty slots have to fit the chip's 32 slots
+__device__ __forceinline__ int slot_shift(const WnSpipeArgs& a) { return a.L + 1 + kSlotShift <= 32 ? kSlotShift : 0; }
 
 // LDS counters: written by one lane of one wave, read by all; LDS serves a wave's operations in issue order, so data written before
 // the counter is visible to whoever has read the new counter value.  The signal fences only pin the compiler's order.
@@ -216,7 +224,7 @@ __device__ void chain_role(const WnSpipeArgs& a, Lds& S, int stage, int p, int q
   const bool g_row = (j & 1) != 0;
   const float gate_scale = g_row ? -1.4426950408889634f : -2.8853900817779268f;
   const float gate_k = g_row ? 1.f : 2.f, gate_shift = g_row ? 0.f : -1.f;
-  const bool local_next = ((stage + 1) >> 2) == (stage >> 2);
+  const bool local_next = ((stage + 1 + slot_shift(a)) >> 2) == ((stage + slot_shift(a)) >> 2);
   const int64_t stage_words = (int64_t)a.Bmax * kSpSlots * kMsgFloats;
   unsigned* msg_out = a.msg + (int64_t)(stage + 1) * stage_words;
   // Wave 0 of the workgroup polls for the whole CU: lane l looks at floats 8 l .. 8 l + 7 of the message = 8 x (l even) or 8 y (l odd)
@@ -393,7 +401,7 @@ __device__ void helper_role(const WnSpipeArgs& a, Lds& S, int stage, int p, int 
   asm volatile("" : "+v"(bz));
   const int d = a.dil[stage], ring_mask = a.ring[stage] - 1;
   const int64_t slot_stride = (int64_t)a.Bmax * kC;
-  const bool local_next = ((stage + 1) >> 2) == (stage >> 2);
+  const bool local_next = ((stage + 1 + slot_shift(a)) >> 2) == ((stage + slot_shift(a)) >> 2);
   const int64_t stage_words = (int64_t)a.Bmax * kSpSlots * kMsgFloats;
   const int64_t hid_words = (int64_t)a.Bmax * kSpSlots * kH1;
   const unsigned* hid_in = a.hidmsg + (int64_t)stage * hid_words;
@@ -722,8 +730,9 @@ __global__ __launch_bounds__(kThreads) void wavenet_spipe_kernel(const WnSpipeAr
   __syncthreads();
   const int role = s_role;
   if (role < 0) return;
-  const int stage = role >> 3, p = role & 7;
-  if (stage > a.L) return;
+  // slot = role / 8 of the chip's 32 (four per XCD); the first kSlotShift slots stay empty, so that layer l sits in slot l + kSlotShift
+  const int stage = (role >> 3) - slot_shift(a), p = role & 7;
+  if (stage < 0 || stage > a.L) return;
   if (stage == a.L) {
     head_role(a, p);
     return;
