@@ -58,6 +58,10 @@ constexpr int kPollGap = MMK_SP_POLL_GAP;     // s_sleep units (64 cycles) betwe
 #ifndef MMK_SP_LDS_SLEEP
 #define MMK_SP_LDS_SLEEP 5
 #endif
+#ifndef MMK_SP_CHAIN_SLEEP
+#define MMK_SP_CHAIN_SLEEP MMK_SP_LDS_SLEEP     // the same inside the chain waves' wait for their message (the helpers' waits keep MMK_SP_LDS_SLEEP)
+#endif
+constexpr int kChainSleep = MMK_SP_CHAIN_SLEEP;
 constexpr int kLdsSleep = MMK_SP_LDS_SLEEP;   // s_sleep units inside the spins on LDS counters: with the chain waves' wait as three FLAT loads 0 / 1 / 3 / 6 / 10 -> 55.7 / 55.6 / 55.3 / 55.9 / 56.5 us per step; as ds_reads (55.3 -> 54.4) 0 / 1 / 2 / 3 / 5 / 7 / 10 / 15 -> 54.3 / 54.9 / 54.6 / 54.3 / 53.9 / 54.1 / 54.2 / 54.7
 #ifndef MMK_SP_SLOT_SHIFT
 #define MMK_SP_SLOT_SHIFT 0     // empty slots in front of layer 0 (which layers are the first and the last of an XCD).  Measured on cfg 4: 1 -> 58.8 us
@@ -187,7 +191,7 @@ __device__ __forceinline__ bool chain_wait(const Lds& S, int q, unsigned v, int3
     const unsigned arr = __hip_atomic_load(&S.arrived[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP), hd = lds_min4(S.hdone);
     const unsigned rd = __hip_atomic_load(&S.ready[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     if (arr >= v + 1 && hd + (kXyRing - 2) >= v + 1 && rd >= v + 1) break;
-    if (kLdsSleep > 0) __builtin_amdgcn_s_sleep(kLdsSleep);
+    if (kChainSleep > 0) __builtin_amdgcn_s_sleep(kChainSleep);
     if (++spins > kSpinLimit || ((spins & 4095u) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
       atomicExch(err, 1);
       return false;
