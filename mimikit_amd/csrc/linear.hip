@@ -68,11 +68,12 @@ __global__ __launch_bounds__(1024) void linear_kernel(const LinearArgs a) {
   const int c_end = (int)(((long)a.k_chunks * (wave + 1)) / nw);
   const int r = lane & 15, q = lane >> 4;
 
-  int64_t row[MT];
+  int64_t row[MT], gx[MT];       // gx: what a row's group adds to its offset (elements), beyond row * ld
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
     const int m = m0 + mt * 16 + r;
     row[mt] = m < a.M ? m : a.M - 1;
+    gx[mt] = a.row_group > 0 ? (row[mt] / a.row_group) * (a.x_group_stride - (int64_t)a.row_group * a.seg[0].ld) : 0;
   }
 
   f32x4 acc[MT];
@@ -101,7 +102,7 @@ __global__ __launch_bounds__(1024) void linear_kernel(const LinearArgs a) {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
           if (live && kk < K)
-            x[u][mt] = *reinterpret_cast<const f32x4*>(base + (row[mt] * ld + kk) * 4);
+            x[u][mt] = *reinterpret_cast<const f32x4*>(base + (row[mt] * ld + gx[mt] + kk) * 4);
           else
             x[u][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
@@ -116,10 +117,10 @@ __global__ __launch_bounds__(1024) void linear_kernel(const LinearArgs a) {
             float v = 0.f;
             if (live && kk + i < K) {
               if (kind == SEG_I64_LINEARIZED) {
-                const int64_t cls = *reinterpret_cast<const int64_t*>(base + (row[mt] * ld + kk + i) * 8);
+                const int64_t cls = *reinterpret_cast<const int64_t*>(base + (row[mt] * ld + gx[mt] + kk + i) * 8);
                 v = (((float)cls / cs) - .5f) * 2.f;  // Linearizer, modules/io.py:106-112
               } else {
-                v = *reinterpret_cast<const float*>(base + (row[mt] * ld + kk + i) * 4);
+                v = *reinterpret_cast<const float*>(base + (row[mt] * ld + gx[mt] + kk + i) * 4);
               }
             }
             x[u][mt][i] = v;
@@ -198,7 +199,8 @@ __global__ __launch_bounds__(1024) void linear_kernel(const LinearArgs a) {
             float t = val[j] + b;
             if (a.has_add) t += ((const float*)a.add.base)[aoff + (int64_t)m * a.add_ld + n];
             t = apply_act(t, a.act);
-            float* o = (float*)a.out.base + ooff + (int64_t)m * a.out_ld + n;
+            const int64_t go = a.row_group > 0 ? (int64_t)(m / a.row_group) * (a.out_group_stride - (int64_t)a.row_group * a.out_ld) : 0;
+            float* o = (float*)a.out.base + ooff + (int64_t)m * a.out_ld + go + n;
             *o = a.accumulate ? (*o + t) : t;
           }
         }
@@ -236,8 +238,11 @@ int launch_linear(const LinearArgs& a_in, hipStream_t stream) {
     a.seg[s].K = 0;
   }
   for (int s = a.nseg; s <= kMaxSeg; ++s) a.seg_chunk0[s] = a.k_chunks;
+  if (a.row_group > 0 && (a.nseg != 1 || a.epilogue != EPI_STORE || a.has_add))
+    return fail(MMK_ERR_INVALID, "linear: grouped rows take one segment and a plain store");
   bool vec = true;
   for (int s = 0; s < a.nseg; ++s) vec = vec && seg_vec_ok(a.seg[s]);
+  if (a.row_group > 0) vec = vec && (a.x_group_stride % 4 == 0);
   // latency-bound shapes (few tiles): one 16-row tile per workgroup to spread over more CUs;
   // GEMM-like shapes: up to 64 rows per workgroup so a weight fragment is reused from registers
   const int m_tiles = (a.M + 15) / 16;

@@ -171,6 +171,10 @@ struct LinearArgs {
   Addr res_in; int64_t res_in_ld;
   Addr res_out; int64_t res_out_ld;
   Addr skip; int64_t skip_ld;
+  // rows in groups (EPI_STORE, one segment): row m = group m / row_group, row m % row_group of it; a group's rows lie x_group_stride /
+  // out_group_stride elements after the previous group's - the clips of a (clip, position, feature) tensor as ONE launch.  0: plain rows
+  int32_t row_group;
+  int64_t x_group_stride, out_group_stride;
 };
 
 int launch_linear(const LinearArgs& a, hipStream_t stream);

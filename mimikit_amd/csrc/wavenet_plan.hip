@@ -958,15 +958,16 @@ static int run_persistent(mmk_wavenet_plan* p, const WnCall& call, int64_t tau0,
     if (p->C1 > 0) {
       // c[b, tau, :] = LinearIO(cond[b, tau, :]) for the block's positions (modules/io.py:115-122)
       g_prof_tag = 2;
-      for (int b = 0; b < call.M; ++b) {
+      {   // all clips in one launch: row m = position m % nb of clip m / nb
         LinearArgs a = {};
         p->cond_lin[0].fill(a);
-        a.seg[0].x = addr_static(call.cond[0] + (int64_t)b * call.cond_rs[0] + tau_b * c.cond_in_dim[0]);
+        a.seg[0].x = addr_static(call.cond[0] + tau_b * c.cond_in_dim[0]);
         a.seg[0].ld = c.cond_in_dim[0];
-        a.M = (int)nb; a.tau_ptr = nullptr; a.tau_off = 0;
+        a.M = (int)(nb * call.M); a.tau_ptr = nullptr; a.tau_off = 0;
         a.epilogue = EPI_STORE; a.act = ACT_NONE;
-        a.out = addr_static(p->cproj + (int64_t)b * p->kCondBlock * p->C1);
+        a.out = addr_static(p->cproj);
         a.out_ld = p->C1;
+        a.row_group = (int)nb; a.x_group_stride = call.cond_rs[0]; a.out_group_stride = (int64_t)p->kCondBlock * p->C1;
         MMK_TRY(launch_linear(a, st));
       }
       // every layer's conv_1x1(c) for the same positions (wavenet_v2.py:140-150): off the per-sample chain; one
