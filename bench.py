@@ -3,6 +3,7 @@
     python bench.py --gpus 1 --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N ...      (no launcher around it: bench.py starts its own N ranks, see launch_ranks)
 
 Workload (BASELINE.json `metric`: "WaveNet 256-ch mu-law, 16 kHz" = configs[3]): WaveNet
 blocks=(10,10,10), 256 dilated/residual/skip channels, one STFT-magnitude conditioning input
@@ -52,7 +53,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="wavenet_cfg4",
-                    choices=["wavenet_cfg4", "wavenet_cfg2", "srnn_cfg3", "s2s_cfg5", "mulaw", "stft", "istft", "gla"])
+                    choices=["wavenet_cfg4", "wavenet_cfg2", "srnn_cfg3", "s2s_cfg5", "mulaw", "stft", "istft", "gla", "stub"])
     ap.add_argument("--clips", type=int, default=0, help="clips per GPU (0 = the workload's BASELINE value)")
     ap.add_argument("--seconds", type=float, default=1.0, help="generated audio per clip")
     ap.add_argument("--temperature", type=float, default=0.0,
@@ -526,25 +527,107 @@ class FeatureJob:
                 "sample": f"8 of the 64 rows, {n} repetitions, torch CPU fp32"}
 
 
-JOBS = {"wavenet_cfg4": WaveNetJob, "wavenet_cfg2": WaveNetJob, "srnn_cfg3": SrnnJob, "s2s_cfg5": S2SJob,
+class StubJob:
+    """No device work: a tiny module to broadcast and a pass that sleeps longer on higher ranks.  Lets the multi-rank plumbing of
+    this file (own launcher, rendezvous, ONE broadcast, fenced max-over-ranks clock, rank 0's line) run under gloo on a box
+    without GPUs - tests/test_shard_gloo.py drives `bench.py --workload stub --gpus 2`."""
+    unit = "stub units/s"
+
+    def __init__(self, args, device, rank):
+        torch.manual_seed(900 + rank)                 # ranks start from different weights
+        self.net = torch.nn.Linear(8, 8)
+        self.clips, self.rank, self.dtype = args.clips or 4, rank, "f32"
+        self.pass_s = 0.02 * (1 + rank)
+
+    def to_device(self):
+        pass
+
+    def one_pass(self):
+        time.sleep(self.pass_s)
+
+    def units_per_pass(self):
+        return self.clips
+
+    def config(self, world):
+        import torch.distributed as dist
+        w = torch.cat([p.detach().reshape(-1) for p in self.net.parameters()]).double().sum().reshape(1)
+        lo, hi = w.clone(), w.clone()
+        if world > 1:                                 # (every rank builds the line: a collective here is matched)
+            dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+            dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        return {"workload": "stub (no device work)", "clips_per_gpu": self.clips, "global_clips": self.clips * world,
+                "parallelism": f"clip-shard x{world}", "weights_checksum": float(w), "weights_checksum_spread": float(hi - lo),
+                "broadcasts": getattr(self, "broadcasts", 0), "slowest_pass_s": self.pass_s}
+
+    def roofline(self):
+        return None
+
+
+JOBS = {"stub": StubJob, "wavenet_cfg4": WaveNetJob, "wavenet_cfg2": WaveNetJob, "srnn_cfg3": SrnnJob, "s2s_cfg5": S2SJob,
         "mulaw": FeatureJob, "stft": FeatureJob, "istft": FeatureJob, "gla": FeatureJob}
 
 
 # ----------------------------------------------------------------------------- main
+def launch_ranks(args) -> int:
+    """`bench.py --gpus N` without a launcher around it (WORLD_SIZE unset): start N ranks of this file, one per GPU, and pass rank 0's
+    JSON line on.  The parent never initialises the GPU (`device_count` only counts) and never re-execs; fewer than N visible
+    devices, or any rank failing, is a non-zero exit - never a silent single-GPU run."""
+    import socket
+    import subprocess
+    n = args.gpus
+    stub = args.workload == "stub"
+    if not stub:
+        have = torch.cuda.device_count()
+        if have < n:
+            print(f"bench.py: --gpus {n} but only {have} GPU(s) are visible on this node", file=sys.stderr)
+            return 2
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # (dmabuf IPC: what RCCL needs on this driver)
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *sys.argv[1:]], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out0, _ = procs[0].communicate()
+    codes = [procs[0].returncode] + [pr.wait() for pr in procs[1:]]
+    if any(codes):
+        print(f"bench.py: rank exit codes {codes}", file=sys.stderr)
+        for pr in procs:
+            if pr.poll() is None:
+                pr.kill()
+        return 1
+    sys.stdout.write(out0)
+    sys.stdout.flush()
+    return 0
+
+
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(launch_ranks(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs the MI355X: the generate path has no CPU implementation")
     import torch.distributed as dist
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
-    if world > 1:
-        dist.init_process_group(backend="nccl", device_id=device)     # RCCL over xGMI
+    stub = args.workload == "stub"
+    if stub:
+        device, sync = torch.device("cpu"), (lambda: None)
+        if world > 1:
+            dist.init_process_group(backend="gloo")
+    else:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs the MI355X: the generate path has no CPU implementation")
+        if torch.cuda.device_count() <= local_rank:
+            raise SystemExit(f"rank {rank}: no GPU {local_rank} on this node ({torch.cuda.device_count()} visible)")
+        torch.cuda.set_device(local_rank)
+        device, sync = torch.device("cuda", local_rank), torch.cuda.synchronize
+        if world > 1:
+            dist.init_process_group(backend="nccl", device_id=device)     # RCCL over xGMI
     torch.set_grad_enabled(False)
 
     job = JOBS[args.workload](args, device, rank)
@@ -552,9 +635,10 @@ def main():
     if world > 1 and hasattr(job, "net"):
         from mimikit_amd.shard import broadcast_weights
         broadcast_weights(job.net, src=0)          # the path's only collective
+        job.broadcasts = 1
 
     from mimikit_amd.shard import timed_passes
-    elapsed = timed_passes(job.one_pass, args.steps, args.warmup, torch.cuda.synchronize)   # barrier + sync, MAX over ranks
+    elapsed = timed_passes(job.one_pass, args.steps, args.warmup, sync)   # barrier + sync, MAX over ranks
 
     units = job.units_per_pass() * args.steps * world
     value = units / elapsed

@@ -103,6 +103,11 @@ __global__ __launch_bounds__(kIpThreads) void lstm_inproj_kernel(const LstmInPro
     }
     return (int)((at + (n_valid > 0 ? c0 : 0) * 16 + 4 * (lane >> 4)) * sizeof(float));   // (a wave without chunks: zero weights, the row's first chunks)
   };
+  // Rows read where the caller's frames lie are not padded: the chunk that holds a row's last inputs (K % 16 != 0, e.g. 513 bins) also
+  // covers the first floats of the NEXT frame or clip.  Their weights are zero, but 0 x NaN / Inf is NaN: those elements are replaced by
+  // 0 before the product, so that a non-finite neighbour never reaches another row's gates.
+  const int tail_u = (a.K % 16 != 0) ? a.K / 16 - c0 : -1;              // which of this wave's chunks that is (none: out of 0 .. n_valid - 1)
+  const int tail_nv = a.K - (a.K / 16) * 16 - 4 * (lane >> 4);            // this lane's valid elements in it (<= 0: none, >= 4: all)
   u32x4s xa[2][CPW];
 #pragma unroll
   for (int u = 0; u < CPW; ++u) xa[1][u] = u32x4s{0u, 0u, 0u, 0u};
@@ -145,9 +150,12 @@ __global__ __launch_bounds__(kIpThreads) void lstm_inproj_kernel(const LstmInPro
       __builtin_amdgcn_sched_barrier(0);
       if (u < n_valid) {      // (same for the whole wave)
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < 4; ++i) {
+          float xv = __uint_as_float(xa[set][u][i]);
+          if (u == tail_u) xv = i < tail_nv ? xv : 0.f;
 #pragma unroll
-          for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(xa[set][u][i]), w[u][g][i], acc[g], 0, 0, 0);
+          for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(xv, w[u][g][i], acc[g], 0, 0, 0);
+        }
       }
       __builtin_amdgcn_sched_barrier(0);
     }

@@ -113,7 +113,7 @@ struct mmk_wavenet_plan {
   // one layer per stage of 8 CUs, clips streamed through one at a time (wavenet_spipe.hip): C = 256, <= 31 layers, <= 32 clips
   bool spipe = false;
   float *sp_img_chain = nullptr, *sp_img_helper = nullptr, *sp_cst_chain = nullptr, *sp_cst_helper = nullptr, *sp_head_w0 = nullptr, *sp_head_b0 = nullptr;
-  unsigned *sp_msg = nullptr, *sp_hidmsg = nullptr;
+  unsigned *sp_msg = nullptr, *sp_hidmsg = nullptr, *sp_hidgrp = nullptr;
   WnSpRaw* sp_raw = nullptr;
   const float *sp_fc2_w = nullptr, *sp_fc2_b = nullptr;
 
@@ -156,8 +156,9 @@ struct mmk_wavenet_plan {
       sp_cst_helper = c.take<float>(wn_spipe_cst_floats(L, C));
       sp_head_w0 = c.take<float>((int64_t)cfg.mlp_hidden * C);
       sp_head_b0 = c.take<float>(cfg.mlp_hidden);
-      sp_msg = c.take<unsigned>(wn_spipe_msg_words(L, C, Bmax) + wn_spipe_hidmsg_words(L, Bmax));   // one block: poisoned by one memset
+      sp_msg = c.take<unsigned>(wn_spipe_msg_words(L, C, Bmax) + wn_spipe_hidmsg_words(L, Bmax) + wn_spipe_hidgrp_words(Bmax));   // one block: poisoned by one memset
       sp_hidmsg = sp_msg + (sp_msg ? wn_spipe_msg_words(L, C, Bmax) : 0);
+      sp_hidgrp = sp_hidmsg + (sp_msg ? wn_spipe_hidmsg_words(L, Bmax) : 0);
       sp_raw = c.take<WnSpRaw>(L);
     }
     h_rings = spipe ? nullptr : c.take<float>((int64_t)(pipe ? 8 : Gc) * Gn * ring_floats_per_wg);
@@ -411,7 +412,7 @@ static int derive(mmk_wavenet_plan* p) {
     const char* cenv = getenv("MMK_WN_CHAIN");
     bool ok5 = !(senv && senv[0] == '0') && !(fenv && fenv[0] == '0') && !(penv && penv[0] == '1') && !(cenv && cenv[0] == '1');
     ok5 = ok5 && n_xcc == 8 && n_cu == 256 && c.q_levels == 256;
-    ok5 = ok5 && wn_spipe_supported(p->C, p->S, c.mlp_hidden, c.out_dim, p->L, c.n_cond, p->Bmax);
+    ok5 = ok5 && wn_spipe_supported(p->C, p->S, c.mlp_hidden, c.out_dim, p->L, c.n_cond, c.n_cond == 1 ? c.cond_dim[0] : 0, p->Bmax);
     if (ok5) {
       p->spipe = true;
       p->persistent = true;
@@ -1009,7 +1010,7 @@ static int run_persistent(mmk_wavenet_plan* p, const WnCall& call, int64_t tau0,
     if (p->spipe) {
       if (!with_head) return fail(MMK_ERR_STATE, "wavenet: the stage-pipeline kernel has no teacher-forced mode (warm-up is a prefill)");
       // every message word starts as poison (0xFFFFFFFF): "not arrived"
-      MMK_HIP(hipMemsetAsync(p->sp_msg, 0xFF, (size_t)(wn_spipe_msg_words(p->L, p->C, p->Bmax) + wn_spipe_hidmsg_words(p->L, p->Bmax)) * sizeof(unsigned), st));
+      MMK_HIP(hipMemsetAsync(p->sp_msg, 0xFF, (size_t)(wn_spipe_msg_words(p->L, p->C, p->Bmax) + wn_spipe_hidmsg_words(p->L, p->Bmax) + wn_spipe_hidgrp_words(p->Bmax)) * sizeof(unsigned), st));
       WnSpipeArgs k = {};
       k.B = call.M; k.L = p->L; k.C = p->C; k.C1 = p->C1;
       k.learn_temp = c.learn_temp; k.min_temp = c.min_temp; k.Bmax = p->Bmax;
@@ -1023,7 +1024,7 @@ static int run_persistent(mmk_wavenet_plan* p, const WnCall& call, int64_t tau0,
       k.uniforms = call.uniforms ? call.uniforms + done : nullptr;
       k.uni_ld = call.uni_ld;
       k.logits_out = p->logits; k.logits_ld = p->logits_ld;
-      k.msg = p->sp_msg; k.hidmsg = p->sp_hidmsg; k.xcd_count = p->xcd_count; k.err_flag = p->err_flag;
+      k.msg = p->sp_msg; k.hidmsg = p->sp_hidmsg; k.hidgrp = p->sp_hidgrp; k.xcd_count = p->xcd_count; k.err_flag = p->err_flag;
       k.stamps = (stamp_env && stamp_env[0] == '1') ? reinterpret_cast<unsigned long long*>(p->tau + 8) : nullptr;
       k.stamp_stage = diag_env("MMK_WN_STAMP_STAGE") ? atoi(diag_env("MMK_WN_STAMP_STAGE")) : 1;
       k.dbg = (k.stamps && diag_env("MMK_WN_SPIPE_DBG")) ? atoi(diag_env("MMK_WN_SPIPE_DBG")) : 0;

@@ -22,7 +22,7 @@ struct WnSpRaw {
 };
 
 struct WnSpipeArgs {
-  int32_t B, L, C, C1;                // clips (<= 32), layers (<= 31), channels (256), conditioning channels (0 = none)
+  int32_t B, L, C, C1;                // clips (<= kSpMaxClips), layers (<= 31), channels (256), conditioning channels (0 = none)
   int32_t learn_temp;
   float min_temp;
   int32_t Bmax;
@@ -47,7 +47,8 @@ struct WnSpipeArgs {
   float* logits_out; int64_t logits_ld;
   // exchange state: every word 0xFFFFFFFF before every launch
   unsigned* msg;                      // [L + 1][Bmax][4][2 C]: what stage s receives: per producing wave 8 x | 8 y
-  unsigned* hidmsg;                   // [L + 1][Bmax][4][128]: running hidden pre-activations of the head's first Linear
+  unsigned* hidmsg;                   // [L + 1][Bmax][4][128]: running hidden pre-activations of the head's first Linear, handed on INSIDE an XCD
+  unsigned* hidgrp;                   // [8][Bmax][4][128]: the sum an XCD's stages have accumulated, written by its last stage, added up by the head
   unsigned* xcd_count;                // [8] arrivals per XCD (zeroed before every launch)
   int32_t* err_flag;
   unsigned long long* stamps;         // diagnostic build only
@@ -55,12 +56,15 @@ struct WnSpipeArgs {
   int32_t dbg;                        // diagnostic build, timing experiments (results wrong): 1 no conditioning reads, 2 delayed rows from L2
 };
 
-bool wn_spipe_supported(int C, int S, int H1, int n_classes, int L, int n_cond, int batch);
+constexpr int kSpMaxClips = 128;        // clips in the ring (the LDS image of the prepared gate terms is 512 B per clip)
+
+bool wn_spipe_supported(int C, int S, int H1, int n_classes, int L, int n_cond, int cond_dim, int batch);
 int64_t wn_spipe_img_chain_floats(int L, int C);
 int64_t wn_spipe_img_helper_floats(int L, int C);
 int64_t wn_spipe_cst_floats(int L, int C);
 int64_t wn_spipe_msg_words(int L, int C, int Bmax);
 int64_t wn_spipe_hidmsg_words(int L, int Bmax);
+int64_t wn_spipe_hidgrp_words(int Bmax);
 // commit: raw (device array of L entries), C1 = conditioning channels (0: none, <= C), f0 = the head's first Linear (128, C) and its bias
 int wn_spipe_build_image(const WnSpRaw* raw_dev, int L, int C, int C1, const float* f0, const float* fb0, float* img_chain, float* img_helper,
                          float* cst_chain, float* cst_helper, float* head_w0, float* head_b0, hipStream_t stream);

@@ -169,12 +169,14 @@ __device__ __forceinline__ unsigned msg_load(const unsigned* p) { return __hip_a
 
 struct Lds {
   float xy[kXyRing][2 * kHalf];               // the newest messages of this stage: [x padded | y padded]
-  float bias[4][2][32][16];                   // [chain wave][step parity][clip][gate row]: everything of z that is known a step ahead
   unsigned arrived[4];                        // [0]: visits staged into xy by the polling wave
   unsigned hdone[4];                          // per helper: visits whose xy image it no longer needs
   unsigned pad_[4];
   unsigned ready[4];                          // per helper: biases prepared (visit count)
+  float bias[];                               // [chain wave][step parity][Bcap clips][gate row]: everything of z that is known a step ahead (dynamic LDS: 512 B per clip)
 };
+__device__ __forceinline__ int bias_off(int q, int parity, int c, int j, int Bcap) { return ((q * 2 + parity) * Bcap + c) * 16 + j; }
+__host__ __device__ __forceinline__ int bias_cap(int B) { return (B + 7) & ~7; }
 
 struct Stamps {
   u64 t_wait = 0, t_compute = 0, t_post = 0, t_bias = 0, visits = 0, polls = 0;
@@ -191,6 +193,24 @@ __device__ __forceinline__ bool chain_wait(const Lds& S, int q, unsigned v, int3
     const unsigned arr = __hip_atomic_load(&S.arrived[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP), hd = lds_min4(S.hdone);
     const unsigned rd = __hip_atomic_load(&S.ready[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     if (arr >= v + 1 && hd + (kXyRing - 2) >= v + 1 && rd >= v + 1) break;
+    if (kChainSleep > 0) __builtin_amdgcn_s_sleep(kChainSleep);
+    if (++spins > kSpinLimit || ((spins & 4095u) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+      atomicExch(err, 1);
+      return false;
+    }
+  }
+  __atomic_signal_fence(__ATOMIC_SEQ_CST);
+  return true;
+}
+
+// the polling wave checks the two LDS conditions BEFORE it looks for the message (they are true long before it arrives - the bias was
+// prepared a step ago, the helpers trail by a visit): between "message seen" and its products stands the staging store only
+__device__ __forceinline__ bool poller_wait(const Lds& S, unsigned v, int32_t* err) {
+  unsigned spins = 0;
+  for (;;) {
+    const unsigned hd = lds_min4(S.hdone);
+    const unsigned rd = __hip_atomic_load(&S.ready[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (hd + (kXyRing - 2) >= v + 1 && rd >= v + 1) break;
     if (kChainSleep > 0) __builtin_amdgcn_s_sleep(kChainSleep);
     if (++spins > kSpinLimit || ((spins & 4095u) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
       atomicExch(err, 1);
@@ -246,7 +266,7 @@ __device__ void chain_role(const WnSpipeArgs& a, Lds& S, int stage, int p, int q
   const int ring_mask = a.ring[stage] - 1;
   float* hist = a.hist[stage];
   const int64_t slot_stride = (int64_t)a.Bmax * kC;
-  const int B = a.B, n_steps = (int)a.n_steps;
+  const int B = a.B, n_steps = (int)a.n_steps, Bcap = bias_cap(a.B);
   Stamps st;
   u64 t0c = 0;
   unsigned v = 0;
@@ -267,6 +287,7 @@ __device__ void chain_role(const WnSpipeArgs& a, Lds& S, int stage, int p, int q
     for (int c = 0; c < B; ++c, ++v) {
       if (STAMPS) t0c = __builtin_amdgcn_s_memtime();
       if (poller) {
+        if (!poller_wait(S, v, a.err_flag)) return;
         // ---- the message: until no word is poison (the first look was requested a visit ago) ------------------------------------------
         const int off = ((c * kSpSlots + slot) * kMsgFloats) * 4 + look_off;
         u32x4s w_lo = pre_lo, w_hi = pre_hi;
@@ -304,15 +325,14 @@ __device__ void chain_role(const WnSpipeArgs& a, Lds& S, int stage, int p, int q
         int cn = c + 1, sn = s;
         if (cn == B) { cn = 0; sn = s + 1; }
         if (sn < n_steps) look(((cn * kSpSlots + (sn & 3)) * kMsgFloats) * 4 + look_off, pre_lo, pre_hi);
-      }
-      if (!chain_wait(S, q, v, a.err_flag)) return;
+      } else if (!chain_wait(S, q, v, a.err_flag)) return;
       __builtin_amdgcn_s_setprio(3);              // (low while it spins: the helper wave of this SIMD gets the issue slots)
       if (STAMPS) {
         const u64 t = __builtin_amdgcn_s_memtime(); st.t_wait += t - t0c; t0c = t;
         if (a.stamps && c == 0 && s + 1 == n_steps && p == 0 && q == 0 && lane == 0) a.stamps[112 + stage] = __builtin_amdgcn_s_memrealtime();
       }
       // what the helper prepared a step ahead: W0 x[t - d] + conditioning + biases
-      const float bzv = S.bias[q][s & 1][c][j];
+      const float bzv = S.bias[bias_off(q, s & 1, c, j, Bcap)];
       // ---- z = [W1 | W1 R] . [x ; y]: 8 reads of 4 inputs, 64 packed FMAs (4 rows x 32 inputs per lane) ---------------------------------
       const float* xb = S.xy[v & (kXyRing - 1)];
       f32x2 acc[4][2];
@@ -407,10 +427,17 @@ __device__ void helper_role(const WnSpipeArgs& a, Lds& S, int stage, int p, int 
   const int64_t slot_stride = (int64_t)a.Bmax * kC;
   const bool local_next = ((stage + 1 + slot_shift(a)) >> 2) == ((stage + slot_shift(a)) >> 2);
   const int64_t stage_words = (int64_t)a.Bmax * kSpSlots * kMsgFloats;
+  // The head's hidden pre-activations are added up INSIDE an XCD only (a hand-over from another XCD is a 0.8-us load that sits in front of
+  // this wave's local polls in its in-order memory counter): the first stage of an XCD starts a new sum, the last one writes the XCD's
+  // sum where the head collects the (at most eight) of them.
   const int64_t hid_words = (int64_t)a.Bmax * kSpSlots * kH1;
+  const int grp = (stage + slot_shift(a)) >> 2;
+  const bool hid_chain_in = stage >= 2 && ((stage - 1 + slot_shift(a)) >> 2) == grp;
+  const bool hid_last = stage == a.L - 1 || ((stage + 1 + slot_shift(a)) >> 2) != grp;
+  const bool hid_local = hid_last ? grp == ((a.L + slot_shift(a)) >> 2) : true;      // (the head's own XCD: its L2 is the meeting point)
   const unsigned* hid_in = a.hidmsg + (int64_t)stage * hid_words;
-  unsigned* hid_out = a.hidmsg + (int64_t)(stage + 1) * hid_words;
-  const int B = a.B;
+  unsigned* hid_out = hid_last ? a.hidgrp + (int64_t)grp * hid_words : a.hidmsg + (int64_t)(stage + 1) * hid_words;
+  const int B = a.B, Bcap = bias_cap(a.B);
   const int n_visits = (int)a.n_steps * B;
   const int ks_off = pad_of(16 * ks);
   // A lane reads ITS 16 inputs of a row straight into registers (64 contiguous bytes; the four row groups of the wave ask for the
@@ -472,7 +499,7 @@ __device__ void helper_role(const WnSpipeArgs& a, Lds& S, int stage, int p, int 
         if (!lds_wait1(&S.arrived[0], (unsigned)it + 1, a.err_flag)) return;
         hstamp(1);
         hsrc = hid_in + ((int64_t)c * kSpSlots + slot) * kH1 + 4 * W + j4;
-        if (stage >= 2) w1 = msg_load(hsrc);            // a first look at the hand-over of the stage below, in flight under the products
+        if (hid_chain_in) w1 = msg_load(hsrc);          // a first look at the hand-over of the stage below, in flight under the products
         const float* yb = S.xy[it & (kXyRing - 1)] + kHalf + ks_off;
         f32x2 hc[2] = {f32x2{0.f, 0.f}, f32x2{0.f, 0.f}};
 #pragma unroll
@@ -486,6 +513,9 @@ __device__ void helper_role(const WnSpipeArgs& a, Lds& S, int stage, int p, int 
         hid_pending = true;      // handed on below, behind the bias products: the look's round trip runs under them
         hstamp(2);
       } else {
+        // (stage 0 has no hidden units to add; it waits for the arrival all the same, so that no helper runs ahead of the chain whatever
+        //  the first layer's dilation is)
+        if (!lds_wait1(&S.arrived[0], (unsigned)it + 1, a.err_flag)) return;
         lds_signal(&S.hdone[h], (unsigned)it + 1, lane);
       }
     }
@@ -540,13 +570,13 @@ __device__ void helper_role(const WnSpipeArgs& a, Lds& S, int stage, int p, int 
 #pragma unroll
       for (int cc = 0; cc < 4; ++cc) zc[cc] = (acc[cc][0][0] + acc[cc][0][1]) + (acc[cc][1][0] + acc[cc][1][1]);
       const float t = row_reduce_scatter4(zc[0], zc[1], zc[2], zc[3], ks);
-      if ((lane & 3) == 0) S.bias[h][s2 & 1][c2][j] = t + bz;
+      if ((lane & 3) == 0) S.bias[bias_off(h, s2 & 1, c2, j, Bcap)] = t + bz;
       lds_signal(&S.ready[h], (unsigned)v2 + 1, lane);
       hstamp(5);
     }
     if (hid_pending) {
       float hin = 0.f;
-      if (stage >= 2) {
+      if (hid_chain_in) {
         unsigned spins = 0;
         while (!__all(w1 != kSpPoison)) {
           if (++spins > kSpinLimit || ((spins & 1023u) == 0 && __hip_atomic_load(a.err_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
@@ -558,8 +588,8 @@ __device__ void helper_role(const WnSpipeArgs& a, Lds& S, int stage, int p, int 
         hin = __uint_as_float(w1);
       }
       if (ks == 0) {
-        msg_store(hid_out + ((int64_t)c * kSpSlots + slot) * kH1 + 4 * W + j4, __float_as_uint(hin + hs), local_next);
-        msg_store(hid_out + ((int64_t)c * kSpSlots + pslot) * kH1 + 4 * W + j4, kSpPoison, local_next);
+        msg_store(hid_out + ((int64_t)c * kSpSlots + slot) * kH1 + 4 * W + j4, __float_as_uint(hin + hs), hid_local);
+        msg_store(hid_out + ((int64_t)c * kSpSlots + pslot) * kH1 + 4 * W + j4, kSpPoison, hid_local);
       }
       hstamp(3);
     }
@@ -574,18 +604,24 @@ __device__ void helper_role(const WnSpipeArgs& a, Lds& S, int stage, int p, int 
 // head stage: workgroup p serves the clips c = p (mod 8): last skip product, Mish, second Linear, [temperature], argmax / draw,
 // and the next step's embedded sample as the message for stage 0
 // ------------------------------------------------------------------------------------------------------------------------------------
+constexpr int kHeadPad = 68;      // a 64-float K slice + 4 floats: the slices' 16-byte reads of a quad / a lane pair fall on different banks
+
+template <bool STAMPS>
 __device__ void head_role(const WnSpipeArgs& a, int p) {
-  __shared__ __attribute__((aligned(16))) float ys[kC], hid[kH1], lg[kQ + 4];
+  __shared__ __attribute__((aligned(16))) float ys[4 * kHeadPad], hid[2 * kHeadPad], lg[kQ + 4];
   __shared__ int s_fail;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int o = tid >> 2, kq = tid & 3;
-  float w0[64], w2[64], wt[2] = {0.f, 0.f}, bt = 0.f;
+  f32x2 w0[32], w2[32];
+  float wt[2] = {0.f, 0.f}, bt = 0.f;
+  {
+    const f32x2* src0 = reinterpret_cast<const f32x2*>(a.head_w0 + (int64_t)o * kC + 64 * kq);
+    const f32x2* src2 = reinterpret_cast<const f32x2*>(a.fc2_w + (int64_t)(tid >> 1) * kH1 + 64 * (tid & 1));
 #pragma unroll
-  for (int k = 0; k < 64; ++k) w0[k] = a.head_w0[(int64_t)o * kC + 64 * kq + k];
+    for (int k = 0; k < 32; ++k) { w0[k] = src0[k]; w2[k] = src2[k]; }
+  }
   const float b0 = a.head_b0[o];
-#pragma unroll
-  for (int k = 0; k < 64; ++k) w2[k] = a.fc2_w[(int64_t)(tid >> 1) * kH1 + 64 * (tid & 1) + k];
   const float b2 = a.fc2_b[tid >> 1];
   if (a.learn_temp) {
     wt[0] = a.fc2_w[(int64_t)kQ * kH1 + lane];
@@ -594,16 +630,21 @@ __device__ void head_role(const WnSpipeArgs& a, int p) {
   }
   // (in their registers before the step loop, as in the chain role)
 #pragma unroll
-  for (int k = 0; k < 64; ++k) asm volatile("" : "+v"(w0[k]));
-#pragma unroll
-  for (int k = 0; k < 64; ++k) asm volatile("" : "+v"(w2[k]));
+  for (int k = 0; k < 32; ++k) { asm volatile("" : "+v"(w0[k])); asm volatile("" : "+v"(w2[k])); }
   asm volatile("" : "+v"(wt[0]), "+v"(wt[1]), "+v"(bt));
   if (tid == 0) s_fail = 0;
   const int L = a.L;
   const int64_t stage_words = (int64_t)a.Bmax * kSpSlots * kMsgFloats;
+  const int64_t hid_words = (int64_t)a.Bmax * kSpSlots * kH1;
   const unsigned* msg_in = a.msg + (int64_t)L * stage_words;
   unsigned* msg_out = a.msg;                                               // stage 0's inbox (another XCD: written through)
-  const unsigned* hid_in = a.hidmsg + (int64_t)L * (int64_t)a.Bmax * kSpSlots * kH1;
+  // the XCDs' sums of hidden pre-activations (layers 0 .. L - 2): groups g_first .. g_last, thread (o, kq) adds up those with g = g_first + kq (mod 4)
+  const int g_first = (1 + slot_shift(a)) >> 2, g_last = (L - 1 + slot_shift(a)) >> 2;
+  const bool last_mine = L >= 2 && ((g_last - g_first) & 3) == kq;
+  u64 hs_t[8] = {0, 0, 0, 0, 0, 0, 0, 0}, hs_t0 = 0;      // diagnostic build: cycles in the phases of a visit (workgroup 0)
+  auto hstamp = [&](int k) {
+    if (STAMPS) { const u64 t = __builtin_amdgcn_s_memtime(); hs_t[k] += t - hs_t0; hs_t0 = t; }
+  };
   // wave 0: the embedded class as stage 0's message of step s1 (x = E[class], y = 0), in the producers' layout (per 8 channels: 8 x | 8 y)
   auto publish_class = [&](int c, int s1, int cls) {
     cls = cls < 0 ? 0 : (cls >= kQ ? kQ - 1 : cls);
@@ -621,6 +662,21 @@ __device__ void head_role(const WnSpipeArgs& a, int p) {
     __hip_atomic_store(dp + 4, pp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_store(dp + 5, pp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   };
+  // one word of an XCD's sum, looked at until it is there (every lane of the wave: the producers of a row are equally late)
+  auto hid_word = [&](const unsigned* src, bool mine) -> float {
+    unsigned w1 = 0, spins = 0;
+    for (;;) {
+      if (mine) w1 = msg_load(src);
+      if (__all(!mine || w1 != kSpPoison)) break;
+      if (++spins > kSpinLimit || ((spins & 1023u) == 0 && __hip_atomic_load(a.err_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+        atomicExch(a.err_flag, 1);
+        s_fail = 1;
+        return 0.f;
+      }
+      __builtin_amdgcn_s_sleep(2);
+    }
+    return mine ? __uint_as_float(w1) : 0.f;
+  };
   if (wave == 0)
     for (int c = p; c < a.B; c += kCuPerStage) publish_class(c, 0, (int)a.idx[(int64_t)c * a.idx_rs + a.t0 - 1]);
   __syncthreads();
@@ -628,6 +684,17 @@ __device__ void head_role(const WnSpipeArgs& a, int p) {
     const int64_t tau = a.t0 - 1 + s;
     const int slot = s & 3;
     for (int c = p; c < a.B; c += kCuPerStage) {
+      if (STAMPS) hs_t0 = __builtin_amdgcn_s_memtime();
+      // ---- the sums of the XCDs below the last one: complete several stages before y gets here, collected while it travels ---------------
+      float hacc = 0.f;
+      const unsigned* hsrc = a.hidgrp + ((int64_t)c * kSpSlots + slot) * kH1 + o;
+      if (L >= 2) {
+        for (int g0 = g_first; g0 < g_last; g0 += 4) {                   // (uniform trip count; a thread's group is g0 + kq)
+          const bool mine = g0 + kq < g_last;
+          hacc += hid_word(hsrc + (int64_t)(g0 + kq) * hid_words, mine);
+        }
+      }
+      hstamp(0);
       if (wave == 0) {             // y of the last layer: channels 4 lane .. + 3
         const unsigned* src = msg_in + ((int64_t)c * kSpSlots + slot) * kMsgFloats + (lane >> 1) * 16 + 8 + (lane & 1) * 4;
         u32x4s w4;
@@ -642,80 +709,110 @@ __device__ void head_role(const WnSpipeArgs& a, int p) {
             break;
           }
         }
-        *reinterpret_cast<f32x4s*>(ys + 4 * lane) = f32x4s{__uint_as_float(w4[0]), __uint_as_float(w4[1]), __uint_as_float(w4[2]), __uint_as_float(w4[3])};
+        *reinterpret_cast<f32x4s*>(ys + (lane >> 4) * kHeadPad + 4 * (lane & 15)) =
+            f32x4s{__uint_as_float(w4[0]), __uint_as_float(w4[1]), __uint_as_float(w4[2]), __uint_as_float(w4[3])};
+        if (STAMPS && a.stamps && c == 0 && s + 1 == (int)a.n_steps && lane == 0) a.stamps[64 + L] = __builtin_amdgcn_s_memrealtime();
       }
       __syncthreads();
       if (s_fail) return;
-      float h4[4] = {0.f, 0.f, 0.f, 0.f};
+      hstamp(1);
+      // ---- hidden units: (fc0 W_skip of the last layer) y, 4 threads per unit, 64 inputs each --------------------------------------------
+      f32x2 h2[2] = {f32x2{0.f, 0.f}, f32x2{0.f, 0.f}};
+      {
+        const float* yk = ys + kq * kHeadPad;
 #pragma unroll
-      for (int k = 0; k < 64; ++k) h4[k & 3] = fmaf(w0[k], ys[64 * kq + k], h4[k & 3]);
-      const float hsum = dpp_quad_sum((h4[0] + h4[1]) + (h4[2] + h4[3]));
-      // the hidden pre-activations the layer stages have accumulated (layers 0 .. L - 2) travel beside the chain and arrive a little after
-      // y: waited for behind the products, by the lanes that need them (a quad shares a word)
-      float hacc = 0.f;
-      if (L >= 2) {
-        const unsigned* src = hid_in + ((int64_t)c * kSpSlots + slot) * kH1 + o;
-        unsigned w1, spins = 0;
-        for (;;) {
-          w1 = msg_load(src);
-          if (__all(w1 != kSpPoison)) break;
-          if (++spins > kSpinLimit || ((spins & 1023u) == 0 && __hip_atomic_load(a.err_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
-            atomicExch(a.err_flag, 1);
-            s_fail = 1;
-            break;
-          }
+        for (int k = 0; k < 16; ++k) {
+          const f32x4s yv = *reinterpret_cast<const f32x4s*>(yk + 4 * k);
+          h2[0] = fma2(w0[2 * k], f32x2{yv[0], yv[1]}, h2[0]);
+          h2[1] = fma2(w0[2 * k + 1], f32x2{yv[2], yv[3]}, h2[1]);
         }
-        hacc = __uint_as_float(w1);
       }
-      if (kq == 0) hid[o] = mish_fast(hacc + (hsum + b0));
+      // the sum of the last XCD below (or beside) the head arrives a little after y: looked at behind the products
+      if (L >= 2) hacc += hid_word(hsrc + (int64_t)g_last * hid_words, last_mine);
+      const float hsum = dpp_quad_sum(((h2[0][0] + h2[0][1]) + (h2[1][0] + h2[1][1])) + hacc);
+      if (kq == 0) hid[(o >> 6) * kHeadPad + (o & 63)] = mish_fast(hsum + b0);
       __syncthreads();
-      float q4[4] = {0.f, 0.f, 0.f, 0.f};
-      const float* hs = hid + (tid & 1) * 64;
+      hstamp(2);
+      // ---- logits: 2 threads per class, 64 hidden units each -------------------------------------------------------------------------------
+      f32x2 q2[2] = {f32x2{0.f, 0.f}, f32x2{0.f, 0.f}};
+      {
+        const float* hk = hid + (tid & 1) * kHeadPad;
 #pragma unroll
-      for (int k = 0; k < 64; ++k) q4[k & 3] = fmaf(w2[k], hs[k], q4[k & 3]);
-      float qv = (q4[0] + q4[1]) + (q4[2] + q4[3]);
+        for (int k = 0; k < 16; ++k) {
+          const f32x4s hv = *reinterpret_cast<const f32x4s*>(hk + 4 * k);
+          q2[0] = fma2(w2[2 * k], f32x2{hv[0], hv[1]}, q2[0]);
+          q2[1] = fma2(w2[2 * k + 1], f32x2{hv[2], hv[3]}, q2[1]);
+        }
+      }
+      float qv = (q2[0][0] + q2[0][1]) + (q2[1][0] + q2[1][1]);
       qv += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(qv), 0xB1, 0xf, 0xf, false));
       if ((tid & 1) == 0) lg[tid >> 1] = qv + b2;
       if (wave == 0 && a.learn_temp) {
-        float tv = fmaf(wt[0], hid[lane], wt[1] * hid[64 + lane]);
+        float tv = fmaf(wt[0], hid[lane], wt[1] * hid[kHeadPad + lane]);
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) tv += __shfl_xor(tv, off);
         if (lane == 0) lg[kQ] = tv + bt;
       }
       __syncthreads();
+      hstamp(3);
       if (wave == 0) {
-        float denom = 1.f;
-        if (a.learn_temp) denom = fmaxf(sigmoidf_(lg[kQ]), a.min_temp);       // mlp.py:60-62
         if (a.logits_out && s + 1 == (int)a.n_steps)
           for (int k = lane; k < kQ + (a.learn_temp ? 1 : 0); k += 64) a.logits_out[(int64_t)c * a.logits_ld + k] = lg[k];
         int result;
         if (a.temperature == nullptr) {
+          // argmax of logits / max(sigmoid(t), min_temp) (mlp.py:60-62, targets.py:37-52): a division by one positive number keeps the
+          // order, so the maximum of the raw logits is the answer - unless the division rounds an EARLIER, slightly smaller logit onto
+          // the maximum's quotient (first-maximum rule).  Only then (some other logit within 4 ulp of the maximum) divide and compare.
           const f32x4s v4 = *reinterpret_cast<const f32x4s*>(lg + lane * 4);
-          float vv[4];
-#pragma unroll
-          for (int k = 0; k < 4; ++k) vv[k] = a.learn_temp ? v4[k] / denom : v4[k];
-          float best = vv[0];
+          float best = v4[0];
           int bi = lane * 4;
 #pragma unroll
           for (int k = 1; k < 4; ++k)
-            if (vv[k] > best) { best = vv[k]; bi = lane * 4 + k; }
+            if (v4[k] > best) { best = v4[k]; bi = lane * 4 + k; }
           result = wave_argmax_first(best, bi);
+          if (a.learn_temp) {
+            const float m = wave_max_dpp(best);
+            const float lim = m - fmaxf(fabsf(m) * 4.8e-7f, 1e-37f);
+            bool near = false;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) near = near || (v4[k] != m && v4[k] >= lim);
+            if (__any(near)) {
+              const float denom = fmaxf(sigmoidf_(lg[kQ]), a.min_temp);
+              float vv[4];
+#pragma unroll
+              for (int k = 0; k < 4; ++k) vv[k] = v4[k] / denom;
+              best = vv[0];
+              bi = lane * 4;
+#pragma unroll
+              for (int k = 1; k < 4; ++k)
+                if (vv[k] > best) { best = vv[k]; bi = lane * 4 + k; }
+              result = wave_argmax_first(best, bi);
+            }
+          }
         } else {
+          float denom = 1.f;
+          if (a.learn_temp) denom = fmaxf(sigmoidf_(lg[kQ]), a.min_temp);       // mlp.py:60-62
           result = sample_256(lg, a.learn_temp != 0, denom, a.temperature[c], a.uniforms[(int64_t)c * a.uni_ld + s], lane);
         }
+        hstamp(4);
         if (s + 1 < (int)a.n_steps) publish_class(c, s + 1, result);
         if (a.stamps && c == 0 && lane == 0 && (s + 1 == (int)a.n_steps || s + 2 == (int)a.n_steps))
           a.stamps[16 + a.L + (s + 2 == (int)a.n_steps ? 1 : 2)] = __builtin_amdgcn_s_memrealtime();
         if (lane == 0) a.idx[(int64_t)c * a.idx_rs + tau + 1] = result;
+        hstamp(5);
       }
-      __syncthreads();
+      // (no barrier here: the next visit's first shared write - ys, by wave 0 - comes after wave 0 has read lg, and nobody reads ys or
+      //  hid of this visit past the barrier above)
     }
   }
+  if (STAMPS && a.stamps && p == 0 && tid == 0)
+    for (int k = 0; k < 6; ++k) a.stamps[176 + k] = hs_t[k];
 }
 
 template <bool STAMPS>
 __global__ __launch_bounds__(kThreads) void wavenet_spipe_kernel(const WnSpipeArgs a) {
-  __shared__ __attribute__((aligned(16))) Lds S;
+  extern __shared__ __attribute__((aligned(16))) unsigned char spipe_lds[];      // Lds + the bias image of bias_cap(B) clips (launch_wavenet_spipe sizes it)
+  Lds& S = *reinterpret_cast<Lds*>(spipe_lds);
   __shared__ int s_role;
   const int tid = threadIdx.x;
   // Roles come from where the workgroup RUNS: XCD x hosts stages 4 x .. 4 x + 3, eight workgroups each, in arrival order.  A launch
@@ -738,7 +835,7 @@ __global__ __launch_bounds__(kThreads) void wavenet_spipe_kernel(const WnSpipeAr
   const int stage = (role >> 3) - slot_shift(a), p = role & 7;
   if (stage < 0 || stage > a.L) return;
   if (stage == a.L) {
-    head_role(a, p);
+    head_role<STAMPS>(a, p);
     return;
   }
   const int lane = tid & 63;
@@ -836,14 +933,17 @@ __global__ __launch_bounds__(256) void spipe_image_kernel(const WnSpRaw* __restr
 
 }  // namespace
 
-bool wn_spipe_supported(int C, int S, int H1, int n_classes, int L, int n_cond, int batch) {
-  return C == kC && S == kC && H1 == kH1 && n_classes == kQ && n_cond <= 1 && L >= 1 && L <= kSpMaxLayers && batch >= 1 && batch <= 32;
+bool wn_spipe_supported(int C, int S, int H1, int n_classes, int L, int n_cond, int cond_dim, int batch) {
+  // (the helper waves multiply 16 K slices of 16 conditioning channels: at most 256 of them, in whole slices)
+  const bool cond_ok = n_cond == 0 || (n_cond == 1 && cond_dim > 0 && cond_dim <= kC && cond_dim % 16 == 0);
+  return C == kC && S == kC && H1 == kH1 && n_classes == kQ && cond_ok && L >= 1 && L <= kSpMaxLayers && batch >= 1 && batch <= kSpMaxClips;
 }
 int64_t wn_spipe_img_chain_floats(int L, int C) { return (int64_t)L * (C / 8) * kChainRegs * 64 * 4; }
 int64_t wn_spipe_img_helper_floats(int L, int C) { return (int64_t)L * (C / 8) * kHelperRegs * 64 * 4; }
 int64_t wn_spipe_cst_floats(int L, int C) { return (int64_t)L * (C / 8) * 64; }
 int64_t wn_spipe_msg_words(int L, int C, int Bmax) { return (int64_t)(L + 1) * Bmax * kSpSlots * 2 * C; }
 int64_t wn_spipe_hidmsg_words(int L, int Bmax) { return (int64_t)(L + 1) * Bmax * kSpSlots * kH1; }
+int64_t wn_spipe_hidgrp_words(int Bmax) { return (int64_t)8 * Bmax * kSpSlots * kH1; }
 
 int wn_spipe_build_image(const WnSpRaw* raw_dev, int L, int C, int C1, const float* f0, const float* fb0, float* img_chain, float* img_helper,
                          float* cst_chain, float* cst_helper, float* head_w0, float* head_b0, hipStream_t stream) {
@@ -856,15 +956,23 @@ int wn_spipe_build_image(const WnSpRaw* raw_dev, int L, int C, int C1, const flo
 
 int launch_wavenet_spipe(const WnSpipeArgs& a, hipStream_t stream) {
   if (a.n_steps <= 0 || a.B <= 0) return MMK_OK;
-  if (a.B > 32 || a.L > kSpMaxLayers || a.C != kC) return fail(MMK_ERR_UNSUPPORTED, "wavenet stage pipeline: %d clips, %d layers, %d channels", a.B, a.L, a.C);
+  if (a.B > kSpMaxClips || a.L > kSpMaxLayers || a.C != kC) return fail(MMK_ERR_UNSUPPORTED, "wavenet stage pipeline: %d clips, %d layers, %d channels", a.B, a.L, a.C);
+  const size_t lds = sizeof(Lds) + (size_t)4 * 2 * bias_cap(a.B) * 16 * sizeof(float);
+  {      // (more than 64 KB of dynamic LDS has to be asked for; per launch: the attribute belongs to the current device)
+    const size_t lds_max = sizeof(Lds) + (size_t)4 * 2 * kSpMaxClips * 16 * sizeof(float);
+    MMK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&wavenet_spipe_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
+#ifdef MMK_DIAG
+    MMK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&wavenet_spipe_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
+#endif
+  }
 #ifdef MMK_DIAG
   if (a.stamps) {      // the stamped instantiation (and its timing switches) exist in the diagnostic build only
-    hipLaunchKernelGGL(wavenet_spipe_kernel<true>, dim3(256), dim3(kThreads), 0, stream, a);
+    hipLaunchKernelGGL(wavenet_spipe_kernel<true>, dim3(256), dim3(kThreads), lds, stream, a);
     MMK_HIP(hipGetLastError());
     return MMK_OK;
   }
 #endif
-  hipLaunchKernelGGL(wavenet_spipe_kernel<false>, dim3(256), dim3(kThreads), 0, stream, a);
+  hipLaunchKernelGGL(wavenet_spipe_kernel<false>, dim3(256), dim3(kThreads), lds, stream, a);
   MMK_HIP(hipGetLastError());
   return MMK_OK;
 }

@@ -557,6 +557,93 @@ class WaveNetPlan(_Plan):
         return out
 
 
+SPIPE_MAX_CLIPS = 128      # clips one ring of the stage pipeline streams (csrc/wavenet_spipe.h: kSpMaxClips)
+
+
+class WaveNetPlanSet:
+    """Several :class:`WaveNetPlan` s, each owning a contiguous slice of the batch, behind the interface of one.
+
+    The stage pipeline (``csrc/wavenet_spipe.hip``) streams at most ``SPIPE_MAX_CLIPS`` clips through its ring; the reference's
+    loop takes any batch (``loops/generate.py:207-219``), so a larger one runs as successive passes of the same kernel, one
+    per slice - each slice has its own history rings and message blocks, the weights are packed once per plan."""
+
+    def __init__(self, plans: Sequence["WaveNetPlan"], sizes: Sequence[int]):
+        self.plans, self.sizes = list(plans), list(sizes)
+        self.cfg, self.device = self.plans[0].cfg, self.plans[0].device
+
+    def _slices(self, batch: int):
+        off = 0
+        for plan, size in zip(self.plans, self.sizes):
+            n = min(size, batch - off)
+            if n <= 0:
+                break
+            yield plan, off, off + n
+            off += n
+        if off < batch:
+            raise ValueError(f"batch of {batch} clips exceeds the {sum(self.sizes)} this plan set was built for")
+
+    def bind_state_dict(self, tensors):
+        for plan in self.plans:
+            plan.bind_state_dict(tensors)
+
+    def commit(self):
+        for plan in self.plans:
+            plan.commit()
+
+    @property
+    def rf(self) -> int:
+        return self.plans[0].rf
+
+    def warmup(self, in0, cond, t_begin, t_end, t_first=0):
+        for plan, a, b in self._slices(in0.shape[0]):
+            plan.warmup(in0[a:b], [c[a:b] for c in cond], t_begin, t_end, t_first=t_first)
+
+    def generate(self, in0, cond, t0, n_steps, temperature=None, uniforms=None, t_first=0):
+        for plan, a, b in self._slices(in0.shape[0]):
+            plan.generate(in0[a:b], [c[a:b] for c in cond], t0, n_steps,
+                          None if temperature is None else temperature[a:b].contiguous(),
+                          None if uniforms is None else uniforms[a:b].contiguous(), t_first=t_first)
+
+    persistent = property(lambda self: self.plans[0].persistent)
+    chain = property(lambda self: self.plans[0].chain)
+    pipelined = property(lambda self: self.plans[0].pipelined)
+    layer_pipelined = property(lambda self: self.plans[0].layer_pipelined)
+    stage_pipelined = property(lambda self: self.plans[0].stage_pipelined)
+
+    def sync_status(self):
+        err = None
+        for plan in self.plans:          # (every plan's error word is read and cleared; the first error is the one raised)
+            try:
+                plan.sync_status()
+            except NativeError as e:
+                err = err or e
+        if err is not None:
+            raise err
+
+    def inject_sync_error(self):
+        self.plans[-1].inject_sync_error()
+
+    def profile_steps(self, *args, **kwargs):
+        raise NotImplementedError("profile_steps measures the per-layer launch path of ONE plan")
+
+    def last_logits(self, batch: int) -> torch.Tensor:
+        return torch.cat([plan.last_logits(b - a) for plan, a, b in self._slices(batch)], dim=0)
+
+
+def make_wavenet_plan(describe, batch: int, device) -> "WaveNetPlan":
+    """``describe(max_batch)`` -> :class:`WaveNetConfig`.  One plan for the batch, unless the batch is beyond one ring of the
+    stage pipeline and the network is one that kernel runs: then evenly sized slices of at most ``SPIPE_MAX_CLIPS`` clips."""
+    batch = max(int(batch), 1)
+    if batch > SPIPE_MAX_CLIPS:
+        n = -(-batch // SPIPE_MAX_CLIPS)
+        size = -(-batch // n)
+        first = WaveNetPlan(describe(size), device)
+        if first.stage_pipelined:
+            sizes = [size] * (n - 1) + [batch - size * (n - 1)]
+            return WaveNetPlanSet([first] + [WaveNetPlan(describe(sz), device) for sz in sizes[1:]], sizes)
+    return WaveNetPlan(describe(batch), device)
+
+
 class SrnnPlan(_Plan):
     _prefix = "mmk_srnn"
 

@@ -263,6 +263,7 @@ class Seq2SeqLSTMNetwork(ARMWithHidden, nn.Module):
     _blocks = ()            # generate_block calls since before_generate: (tensor, t0, n_steps)
     _exec_mode = 0          # 1 while a call is being redone with one launch per frame (mmk_s2s_config.exec_mode)
     _resident_seen = 0
+    _plan_stale = False     # the plan is the one-launch-per-frame plan of a repeated call: replaced at the next _ensure_plan
 
     def _ensure_plan(self, batch: int, refresh_weights: bool):
         device = self.device
@@ -270,7 +271,8 @@ class Seq2SeqLSTMNetwork(ARMWithHidden, nn.Module):
             raise RuntimeError("Seq2SeqLSTMNetwork generates on the MI355X only: move the network to the HIP device "
                                "('cuda'); there is no CPU implementation in this package")
         rebuilt = False
-        if self._plan is None or self._plan_batch < batch or self._plan.device != device:
+        if self._plan is None or self._plan_batch < batch or self._plan.device != device or (self._plan_stale and self._exec_mode == 0):
+            self._plan_stale = False
             self._plan = native.S2SPlan(self._describe(max(batch, 1)), device)
             self._plan_batch = max(batch, 1)
             self._resident_seen = 0
@@ -309,7 +311,9 @@ class Seq2SeqLSTMNetwork(ARMWithHidden, nn.Module):
                 return out
             finally:
                 self._exec_mode = 0
-                self._plan = None                # the next call may run resident again
+                # the one-launch-per-frame plan stays until the caller has read what the repeated call left in it (last_logits of a
+                # sampled step); the next _ensure_plan replaces it, so that the next call runs resident again
+                self._plan_stale = True
 
     def _device_step(self, inputs: Tuple[torch.Tensor, ...], temperature=None):
         native.require_device(*inputs)

@@ -378,7 +378,7 @@ class WaveNet(ARM, nn.Module):
                                "there is no CPU implementation in this package")
         rebuilt = False
         if self._plan is None or self._plan_batch < batch or self._plan.device != device:
-            self._plan = native.WaveNetPlan(self._describe(max(batch, 1)), device)
+            self._plan = native.make_wavenet_plan(self._describe, max(batch, 1), device)
             self._plan_batch = max(batch, 1)
             rebuilt = True
         if rebuilt or refresh_weights:

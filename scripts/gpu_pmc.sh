@@ -5,6 +5,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 WL=${WORKLOAD:-wavenet_cfg4}
 cd /tmp
 for C in FETCH_SIZE WRITE_SIZE; do
+  rm -rf $R/gpurun_out/pmc_${WL}_$C      # a fresh directory per pass: the summary globs whatever lies in it
   timeout 600 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $R/gpurun_out/pmc_${WL}_$C -- python3 $R/scripts/pmc_target.py > $R/gpurun_out/pmc_${WL}_$C.log 2>&1
   echo "pmc $C exit: $?"; tail -2 $R/gpurun_out/pmc_${WL}_$C.log
 done

@@ -6,6 +6,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp
 for WL in ${WORKLOADS:-stft istft gla}; do
   for C in FETCH_SIZE WRITE_SIZE; do
+    rm -rf $R/gpurun_out/pmcf_${WL}_$C      # a fresh directory per pass: the summary globs whatever lies in it
     timeout 600 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $R/gpurun_out/pmcf_${WL}_$C -- python3 $R/bench.py --workload $WL --steps 1 --warmup 0 --no-cpu-baseline > $R/gpurun_out/pmcf_${WL}_$C.log 2>&1
     echo "pmc $WL $C exit: $?"
   done

@@ -4,8 +4,10 @@ mkdir -p gpurun_out
 export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp
+rm -rf $R/gpurun_out/pmc_mfma_wavenet      # a fresh directory per pass: the summary globs whatever lies in it
 timeout 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $R/gpurun_out/pmc_mfma_wavenet -- python3 $R/scripts/pmc_target.py > $R/gpurun_out/pmc_mfma_wavenet.log 2>&1
 echo "wavenet exit: $?"; tail -2 $R/gpurun_out/pmc_mfma_wavenet.log | cut -c1-300
+rm -rf $R/gpurun_out/pmc_mfma_s2s      # a fresh directory per pass: the summary globs whatever lies in it
 timeout 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $R/gpurun_out/pmc_mfma_s2s -- python3 $R/bench.py --workload s2s_cfg5 --steps 1 --warmup 0 --seconds 1 --no-cpu-baseline > $R/gpurun_out/pmc_mfma_s2s.log 2>&1
 echo "s2s exit: $?"; tail -2 $R/gpurun_out/pmc_mfma_s2s.log | cut -c1-300
 cd $R

@@ -5,6 +5,7 @@ export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp
 for C in FETCH_SIZE WRITE_SIZE; do
+  rm -rf $R/gpurun_out/pmcs_s2s_$C      # a fresh directory per pass: the summary globs whatever lies in it
   timeout 240 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $R/gpurun_out/pmcs_s2s_$C -- python3 $R/bench.py --workload s2s_cfg5 --steps 1 --warmup 0 --no-cpu-baseline > $R/gpurun_out/pmcs_s2s_$C.log 2>&1 < /dev/null
   echo "pmc s2s $C exit: $?"
 done

@@ -6,6 +6,7 @@ export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp
 for C in FETCH_SIZE WRITE_SIZE; do
+  rm -rf $R/gpurun_out/pmcs_srnn_$C      # a fresh directory per pass: the summary globs whatever lies in it
   MMK_SRNN_RESIDENT=0 timeout 200 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $R/gpurun_out/pmcs_srnn_$C -- python3 $R/bench.py --workload srnn_cfg3 --steps 1 --warmup 0 --seconds 0.1 --no-cpu-baseline > $R/gpurun_out/pmcs_srnn_$C.log 2>&1
   echo "pmc srnn $C exit: $?"
 done

@@ -131,6 +131,82 @@ def test_cfg4_wavenet_30x256_conditioned_32_clips(device):
     assert n_exact >= 0.97 * n_all
 
 
+def _cfg4_greedy_against_oracle(device, B, n, n_last, n_mid, seed, expect_set=None):
+    """cfg 4 at ``B`` clips: ``n`` free-running greedy steps, twice (bit-identical), then the oracle teacher-forced on the device's
+    own history: the last ``n_last`` steps of all clips, the steps around the start and the first launch boundary for eight clips,
+    ``n_mid`` random mid-block steps for four clips each"""
+    net, sd, arch = cfg4_network()
+    net = net.to(device)
+    rf, P = net.rf, 3072
+    gen = torch.Generator().manual_seed(seed)
+    prompt = torch.randint(0, 256, (B, P), generator=gen)
+    cond = torch.rand(B, P + n, 513, generator=gen)
+    cond_d = cond.to(device)
+
+    def run():
+        idx = torch.cat([prompt, torch.zeros(B, n, dtype=torch.int64)], 1).to(device)
+        net.before_generate((idx[:, :P], cond_d[:, :P]), None)
+        net.generate_block((idx, cond_d), P, n)
+        net.after_generate((idx,), None)
+        return idx.cpu(), net._plan.last_logits(B).cpu()
+
+    hist, last_raw = run()
+    assert net._plan.stage_pipelined
+    if expect_set is not None:
+        assert isinstance(net._plan, mmk.native.WaveNetPlanSet) == expect_set
+    hist2, _ = run()
+    assert torch.equal(hist, hist2)
+    assert int(hist[:, P:].min()) >= 0 and int(hist[:, P:].max()) < 256
+    assert len(torch.unique(hist[:, P:])) > 32
+
+    def check(clips, steps):
+        n_ok = n_all = 0
+        for t in steps:
+            raw = O.wavenet_window_forward(sd, (hist[clips, t - rf:t], cond[clips, t - rf:t]), n_cond=1, **arch)
+            pick = O.categorical(O.mlp_logits(raw))[:, 0]
+            gap_ok = H.margin_ok(raw.numpy())[:, 0]
+            assert bool(((pick == hist[clips, t]) | ~gap_ok).all()), f"step {t - P}: classes differ from the oracle"
+            n_ok += int(gap_ok.sum())
+            n_all += len(clips)
+            if t == P + n - 1:
+                assert torch.allclose(last_raw[clips][gap_ok], raw[:, 0][gap_ok], **LOGIT_TOL)
+        return n_ok, n_all
+
+    spread = [(B * g) // 8 + (g % max(B // 8, 1)) for g in range(8)]
+    pick_gen = torch.Generator().manual_seed(seed + 1)
+    mid_steps = sorted(set(int(x) for x in torch.randint(2, n - 4, (n_mid + 4,), generator=pick_gen)))[:n_mid]
+    with host_threads(32):
+        ok, al = check(list(range(B)), range(P + n - n_last, P + n))
+        edge = [P, P + 1] + ([P + 1023, P + 1024, P + 1025] if n > 1030 else [])
+        check(spread, edge)
+        seen = ok_seen = 0
+        for k, s_ in enumerate(mid_steps):
+            clips = [(7 * k + (B // 4) * j + k // 3) % B for j in range(4)]
+            f_ok, f_all = check(clips, [P + s_])
+            seen += f_all
+            ok_seen += f_ok
+    print(f"[margin] cfg 4 greedy, {B} clips: last {n_last} steps of all clips {100 * (1 - ok / al):.2f} % excluded; {len(mid_steps)} mid-block steps x 4 clips "
+          f"{100 * (1 - ok_seen / max(seen, 1)):.2f} % excluded")
+    assert 1 - ok / al <= 0.02 and 1 - ok_seen / max(seen, 1) <= 0.05
+
+
+def test_cfg4_wavenet_64_clips_in_one_ring(device):
+    """R = 4 GPUs of the 256-clip job give 64 clips per GPU.  The stage pipeline streams them through ONE ring (two
+    clips per stage slot on average): 1100 free-running steps across a launch boundary, against the oracle"""
+    _cfg4_greedy_against_oracle(device, B=64, n=1100, n_last=2, n_mid=16, seed=464, expect_set=False)
+
+
+def test_cfg4_wavenet_128_clips_in_one_ring(device):
+    """R = 2: 128 clips per GPU, the most one ring takes (the bias image of a stage CU is 64 KB of its LDS then)"""
+    _cfg4_greedy_against_oracle(device, B=128, n=600, n_last=1, n_mid=12, seed=4128, expect_set=False)
+
+
+def test_cfg4_wavenet_more_clips_than_one_ring(device):
+    """the reference's loop takes any batch (loops/generate.py:207-219): 136 clips run as two passes of 68 through the stage
+    pipeline (native.WaveNetPlanSet), never on the round-1 fallback kernel"""
+    _cfg4_greedy_against_oracle(device, B=136, n=1030, n_last=1, n_mid=10, seed=4136, expect_set=True)
+
+
 def test_cfg4_composed_products_against_the_reference_association(device, monkeypatch):
     """The stage pipeline multiplies pre-composed matrices (tap 1 . W_res of the layer below, fc0 . W_skip: fp64 products rounded
     once); the per-layer launch path keeps the reference's association.  Same window, same step, both against the oracle: the

@@ -636,6 +636,51 @@ def test_seq2seq_on_class_indices_eval_forward_with_a_temperature(device, monkey
     assert len({float(v) for v in y.cpu().flatten()}) > 1
 
 
+def test_seq2seq_timeout_during_a_sampled_forward_keeps_the_logits(device, monkeypatch):
+    """a timed-out wait reported right after a `net(x, temperature=T)` call: the call is repeated with one launch per frame AND the
+    draw that follows reads the repeated call's logits (the one-launch-per-frame plan must outlive the repeat); the next call runs
+    resident again on a fresh plan"""
+    H.S2S_MULAW["_t"] = dict(hop=4, io=dict(n_mlp_layers=0))
+    try:
+        net, sd, hop, arch = H.s2s_mulaw("_t", model_dim=128, mlp_dim=32)
+    finally:
+        del H.S2S_MULAW["_t"]
+    net.to(device)
+    x = torch.randint(0, 256, (6, hop), generator=torch.Generator().manual_seed(14))
+    _, raw = O.s2s_step(O.fold_weight_norm(sd), x, hop, return_raw=True, **arch)
+    net.generate_step((x.to(device),), t=hop)                   # builds the plan
+    assert net._plan.resident_launches() > 0
+    first_plan = net._plan
+    real_step = first_plan.step_classes
+
+    def failing_step(xx):
+        y = real_step(xx)
+        first_plan.inject_sync_error()
+        return y
+
+    monkeypatch.setattr(first_plan, "step_classes", failing_step)
+    drawn = {}
+    real_rand = torch.rand
+
+    def rand(*a, **k):
+        drawn["u"] = real_rand(*a, **k)
+        return drawn["u"]
+
+    monkeypatch.setattr(torch, "rand", rand)
+    temp = torch.tensor([0.5, 1.0, 2.0, 0.25, 1.5, 1.0])
+    with pytest.warns(UserWarning, match="per frame"):
+        y = net((x.to(device),), temperature=temp)
+    assert net._plan is not first_plan and net._plan_stale
+    ok, exact = H.sampled_picks_ok(raw, temp, drawn["u"].cpu().reshape(6, hop), y.cpu().long())
+    assert bool(ok.all())
+    assert torch.allclose(net._plan.last_logits(6).cpu(), raw, rtol=1e-4, atol=2e-4)
+    y2 = net.generate_step((x.to(device),), t=hop)               # a fresh resident plan
+    assert not net._plan_stale and net._plan.resident_launches() > 0
+    want, _ = O.s2s_step(O.fold_weight_norm(sd), x, hop, return_raw=True, **arch)
+    okm = H.margin_ok(raw)
+    assert torch.equal(y2.cpu()[okm], want[okm])
+
+
 def test_seq2seq_class_and_frame_entry_points_do_not_mix(device):
     """a plan for class indices refuses frames and the other way round (the C-ABI's error, not a crash)"""
     net, sd, hop, arch = H.s2s_mulaw("mlp0")
@@ -745,11 +790,32 @@ def test_seq2seq_timeout_is_redone_frame_by_frame(device, monkeypatch):
     with pytest.warns(UserWarning, match="per frame"):
         net.after_generate((frames,), None)
     assert float((frames.cpu() - want).abs().max()) <= 2e-4 * float(want.abs().max())
-    assert net._plan is None                  # the next generation starts on a fresh (resident) plan
+    assert net._plan_stale                    # the next generation starts on a fresh (resident) plan
     x = torch.rand(9, 4, 65, generator=torch.Generator().manual_seed(3))
     got = net.generate_step((x.to(device),), t=4).cpu()
     assert net._plan.resident_launches() == 2
     assert float((got - O.s2s_step(sd, x, hop=4)).abs().max()) <= 1e-4 * float(got.abs().max())
+
+
+def test_seq2seq_frames_in_place_ignore_what_lies_behind_a_row(device):
+    """the first encoder layer reads the caller's frames where they lie, in 16-float chunks: with 65 bins the last chunk of a row
+    covers 15 floats that belong to whatever follows the row in memory.  Non-finite data there (here: NaN in the padding columns
+    of a strided view) must not reach any gate"""
+    io = mmk.IOSpec.magspec_io(mmk.IOSpec.MagSpecIOConfig(n_fft=128, hop_length=32))
+    net = mmk.Seq2SeqLSTMNetwork.from_config(mmk.Seq2SeqLSTMNetwork.Config(io_spec=io, model_dim=128, hop=4)).eval()
+    from oracle.weights import load_recipe
+    sd = load_recipe(net, seed=72, gain=1.5)
+    net.to(device)
+    x = torch.rand(9, 4, 65, generator=torch.Generator().manual_seed(5))
+    want = O.s2s_step(sd, x, hop=4)
+    wide = torch.full((9, 4, 80), float("nan"), device=device)
+    wide[:, :, :65] = x.to(device)
+    view = wide[:, :, :65]
+    assert view.stride(2) == 1 and not view.is_contiguous()
+    got = net.generate_step((view,), t=4).cpu()
+    assert net._plan.resident_launches() > 0          # (the resident path: the one that reads in place)
+    assert bool(torch.isfinite(got).all())
+    assert float((got - want).abs().max()) <= 1e-4 * float(want.abs().max())
 
 
 def test_wavenet_pad_side_1(device):

@@ -90,3 +90,46 @@ def test_bench_timing_contract_two_ranks():
     assert 0.29 <= r0["elapsed"] < 0.6                         # the slow rank's 3 x 0.1 s, not the fast rank's 0.15 s
     assert r0["first"] != r1["first"]                          # different synthetic clips per rank
     assert r0["span"] == (0, 4) and r1["span"] == (4, 8)       # weak scaling: per-rank units fixed, global = world x
+
+
+def _run_bench(*argv):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), *argv], env=env, capture_output=True, text=True, timeout=300)
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    return res.returncode, (json.loads(lines[-1]) if lines else None), res.stderr
+
+
+def test_bench_launches_its_own_ranks():
+    """`bench.py --gpus 2` with no launcher around it (WORLD_SIZE unset) starts two ranks itself: rank 0's line says n_gpus 2, the
+    weights were broadcast once and are equal on both ranks, the time is the SLOWER rank's (rank 1 sleeps 40 ms per pass, rank 0
+    20 ms), the value counts both ranks' units"""
+    rc, line, err = _run_bench("--workload", "stub", "--gpus", "2", "--steps", "3", "--warmup", "1", "--clips", "4")
+    assert rc == 0, err
+    assert line["n_gpus"] == 2 and line["steps"] == 3 and line["warmup"] == 1
+    cfg = line["config"]
+    assert cfg["broadcasts"] == 1 and cfg["weights_checksum_spread"] == 0.0 and cfg["global_clips"] == 8
+    assert 39.0 <= line["ms_per_step"] <= 80.0              # max over ranks: rank 1's 40 ms, not rank 0's 20
+    assert abs(line["value"] - 8 / (line["ms_per_step"] * 1e-3)) / line["value"] < 1e-3
+
+
+def test_bench_refuses_more_gpus_than_the_node_has():
+    """a box with fewer devices than --gpus must fail loudly, never report a single-GPU number as the N-GPU one"""
+    n = torch.cuda.device_count() + 7
+    rc, line, err = _run_bench("--gpus", str(n), "--steps", "1", "--warmup", "0")
+    assert rc != 0 and line is None
+    assert f"--gpus {n}" in err and "visible" in err
+
+
+def test_bench_rank_failure_is_the_launchers_failure():
+    """--gpus disagreeing with the WORLD_SIZE a launcher set is refused by every rank"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--workload", "stub", "--gpus", "2"], env=env,
+                         capture_output=True, text=True, timeout=120)
+    assert res.returncode != 0 and "WORLD_SIZE=1" in res.stderr
