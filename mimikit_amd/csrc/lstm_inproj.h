@@ -17,6 +17,7 @@ struct LstmInProjArgs {
   int64_t x_group_stride;
   int64_t x_floats;             // floats from x that may be read (reads past them return zeros)
   int32_t rows, K, k_chunks, H;
+  int32_t k_valid;              // > 0: a row holds only k_valid inputs (<= K); what lies behind them in memory is NOT the row's and is multiplied as 0
   LstmInProjDir dir[2];         // [forward, reverse]
 };
 

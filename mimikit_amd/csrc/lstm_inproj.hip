@@ -106,8 +106,9 @@ __global__ __launch_bounds__(kIpThreads) void lstm_inproj_kernel(const LstmInPro
   // Rows read where the caller's frames lie are not padded: the chunk that holds a row's last inputs (K % 16 != 0, e.g. 513 bins) also
   // covers the first floats of the NEXT frame or clip.  Their weights are zero, but 0 x NaN / Inf is NaN: those elements are replaced by
   // 0 before the product, so that a non-finite neighbour never reaches another row's gates.
-  const int tail_u = (a.K % 16 != 0) ? a.K / 16 - c0 : -1;              // which of this wave's chunks that is (none: out of 0 .. n_valid - 1)
-  const int tail_nv = a.K - (a.K / 16) * 16 - 4 * (lane >> 4);            // this lane's valid elements in it (<= 0: none, >= 4: all)
+  const int kv = a.k_valid > 0 ? a.k_valid : a.K;
+  const int tail_u = (kv % 16 != 0) ? kv / 16 - c0 : -1;                // which of this wave's chunks that is (none: out of 0 .. n_valid - 1)
+  const int tail_nv = kv - (kv / 16) * 16 - 4 * (lane >> 4);              // this lane's valid elements in it (<= 0: none, >= 4: all)
   u32x4s xa[2][CPW];
 #pragma unroll
   for (int u = 0; u < CPW; ++u) xa[1][u] = u32x4s{0u, 0u, 0u, 0u};

@@ -434,7 +434,7 @@ static int plain_linear(const PackedLinear& w, const float* x, int64_t ldx, int 
 // one bidirectional LSTM over hop frames; rows of x/of/ob are (b*hop + t)
 // where the rows (clip, frame) of a layer's input lie when they are the caller's frames, read in place (group = frames per clip)
 struct FrameMap {
-  int group = 0;
+  int group = 0, valid = 0;      // frames per clip; inputs per frame (what follows them in memory belongs to something else)
   int64_t clip_stride = 0, frame_stride = 0, floats = 0;
 };
 
@@ -471,7 +471,7 @@ static int run_bilstm(mmk_s2s_plan* p, BiLstm& l, const float* x, int x_ld, int 
     LstmInProjArgs ia = {};
     ia.x = x; ia.x_ld = x_ld; ia.out_ld = 4 * D; ia.rows = (int)rows; ia.K = l.ih[0].segK[0]; ia.k_chunks = l.ih[0].k_chunks; ia.H = D;
     ia.x_floats = rows * x_ld;
-    if (fm.group > 0) { ia.x_group = fm.group; ia.x_group_stride = fm.clip_stride; ia.x_ld = fm.frame_stride; ia.x_floats = fm.floats; }
+    if (fm.group > 0) { ia.x_group = fm.group; ia.x_group_stride = fm.clip_stride; ia.x_ld = fm.frame_stride; ia.x_floats = fm.floats; ia.k_valid = fm.valid; }
     for (int d = 0; d < 2; ++d) { ia.dir[d].wih_wp = l.ih[d].Wp; ia.dir[d].bias = l.ih[d].bias; ia.dir[d].out = p->gi[d]; }
     MMK_TRY(launch_lstm_inproj(ia, p->n_cu, st));
   }
@@ -557,7 +557,7 @@ static int s2s_step(mmk_s2s_plan* p, int M, const S2SIo& io, int n_out, hipStrea
   FrameMap fm;
   if (c.in_classes <= 0 && inproj_enabled() && p->seq_lstm && lstm_seq_supported(D, M, hop, p->n_cu) && p->enc[0].ih[0].nseg == 1 &&
       lstm_inproj_supported(rows, p->enc[0].ih[0].segK[0], p->enc[0].ih[0].k_chunks, D) && io.xbs >= 0 && io.xfs >= 0) {
-    fm.group = hop; fm.clip_stride = io.xbs; fm.frame_stride = io.xfs;
+    fm.group = hop; fm.valid = c.in_dim; fm.clip_stride = io.xbs; fm.frame_stride = io.xfs;
     fm.floats = (int64_t)(M - 1) * io.xbs + (int64_t)(hop - 1) * io.xfs + c.in_dim;
     if (fm.floats * (int64_t)sizeof(float) >= ((int64_t)1 << 31)) fm = FrameMap();
   }

@@ -1389,6 +1389,13 @@ extern "C" int mmk_wavenet_sync_status(mmk_wavenet_plan* p, mmk_stream_t stream)
             if (n) { fprintf(stderr, " %d:[%.0f %.0f]", l, a / n, b / n); tot += (a + b) / n; }
           }
           fprintf(stderr, " | sum %.0f\n", tot);
+          {   // head workgroup 0, thread 0: shader cycles per visit in the phases of the head
+            const double nv = (double)((p->Bmax + 7) / 8) * (double)(st[3] / (unsigned long long)(p->Bmax > 0 ? p->Bmax : 1));
+            if (nv > 0)
+              fprintf(stderr, "[mmk stamps] head, cycles per visit of workgroup 0: XCD sums collected=%.0f; wait for y + staging + barrier=%.0f; products + last sum + Mish + barrier=%.0f; "
+                              "logits + barrier=%.0f; argmax / draw=%.0f; embedding row + publish=%.0f\n",
+                      (double)all[176] / nv, (double)all[177] / nv, (double)all[178] / nv, (double)all[179] / nv, (double)all[180] / nv, (double)all[181] / nv);
+          }
           fprintf(stderr, "[mmk stamps] the middle step, clip 5: publish time of a stage's CUs 1 .. 7 minus its CU 0's, 10 ns ticks:");
           for (int l = 0; l < p->L && l < 31; ++l) {
             fprintf(stderr, " %d:[", l);

@@ -28,8 +28,8 @@ struct WnSpipeArgs {
   int32_t Bmax;
   int64_t t0, n_steps;                // positions t0 .. t0 + n_steps - 1 are produced
   // per-stage register images (built at commit by wn_spipe_build_image)
-  const float* img_chain;             // [L][C / 8 waves][40][64][4]
-  const float* img_helper;            // [L][C / 8 waves][36][64][4]
+  const float* img_chain;             // [L][C / 8 waves][44][64][4]
+  const float* img_helper;            // [L][C / 8 waves][32][64][4]
   const float* cst_chain;             // [L][C / 8][64]   residual bias of the layer below
   const float* cst_helper;            // [L][C / 8][64]   gate bias (dilated + conditioning conv + tap 1 . b_res below)
   const float* head_w0;               // (128, C): fc0 . W_skip of the LAST layer, row-major

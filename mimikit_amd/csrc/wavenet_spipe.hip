@@ -49,7 +49,7 @@ constexpr int kMsgFloats = 2 * kC;            // 512
 constexpr int kPadBlk = 36;                   // 32 channels + 4 floats of padding: the K slices of a broadcast read fall on different banks
 constexpr int kHalf = (kC / 32) * kPadBlk;    // 288 floats: one padded vector of C channels
 constexpr int kXyRing = 8;
-constexpr int kChainRegs = 40, kHelperRegs = 36;   // float4 registers per lane in the stage images
+constexpr int kChainRegs = 44, kHelperRegs = 32;   // float4 registers per lane in the stage images
 constexpr unsigned kSpinLimit = 1u << 22;
 #ifndef MMK_SP_POLL_GAP
 #define MMK_SP_POLL_GAP 1
@@ -68,11 +68,9 @@ constexpr int kLdsSleep = MMK_SP_LDS_SLEEP;   // s_sleep units inside the spins 
                                 // per step against 50.9 (layer 10, a dilation-1 stage, is then the LAST of its XCD; with 0 layers 0 and 20 are the first of theirs)
 #endif
 constexpr int kSlotShift = MMK_SP_SLOT_SHIFT;
-#ifndef MMK_SP_LOOKS
-#define MMK_SP_LOOKS 1
+#ifndef MMK_SP_WAKEUP
+#define MMK_SP_WAKEUP 1        // the looking helper wakes the chain waves out of their s_sleep when it has staged a message
 #endif
-constexpr int kLooks = MMK_SP_LOOKS;          // looks in flight while it has not
-
 __device__ __forceinline__ int pad_of(int ch) { return (ch >> 5) * kPadBlk + (ch & 31); }
 
 __device__ __forceinline__ float dpp_quad_sum(float v) {
@@ -112,6 +110,20 @@ __device__ __forceinline__ float row_reduce_scatter2(float v0, float v1, int ks)
   const float u = hi ? v0 : v1;
   t += dpp_mirror(u);
   return dpp_quad_sum(dpp_half_mirror_add(t));
+}
+
+// eight partial sums per lane: lanes 2 c, 2 c + 1 of the row end with column c's total (own + mirror partner, + half-mirror partner, + the lane
+// two further, + the neighbour)
+__device__ __forceinline__ float row_reduce_scatter8(const float (&v)[8], int ks) {
+  const bool b3 = (ks & 8) != 0, b2 = (ks & 4) != 0, b1 = (ks & 2) != 0;
+  float k4[4], k2[2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) k4[i] = (b3 ? v[4 + i] : v[i]) + dpp_mirror(b3 ? v[i] : v[4 + i]);
+#pragma unroll
+  for (int i = 0; i < 2; ++i) k2[i] = (b2 ? k4[2 + i] : k4[i]) + dpp_half_mirror(b2 ? k4[i] : k4[2 + i]);
+  float r = (b1 ? k2[1] : k2[0]) + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(b1 ? k2[0] : k2[1]), 0x4E, 0xf, 0xf, false));   // quad_perm [2,3,0,1]
+  r += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(r), 0xB1, 0xf, 0xf, false));                                             // quad_perm [1,0,3,2]
+  return r;
 }
 
 __device__ __forceinline__ f32x2 fma2(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
@@ -165,13 +177,22 @@ __device__ __forceinline__ void msg_store(unsigned* p, unsigned v, bool local) {
   if (local) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   else __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// the bits of a value that goes into a message: 0xFFFFFFFF means "not arrived" there, and a NaN with exactly that payload CAN come out of
+// the arithmetic (NaNs keep the payload of their source: a checkpoint or a conditioning input that carries such a NaN would make a consumer
+// wait for a word that has arrived - until the 1-s timeout and the redo on the launch path).  One integer minimum maps it to the
+// neighbouring NaN.
+__device__ __forceinline__ unsigned msg_bits(float v) { return min(__float_as_uint(v), 0xFFFFFFFEu); }
 __device__ __forceinline__ unsigned msg_load(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
+constexpr int kRowRing = 4;                   // (= the number of helper waves: helper v mod 4 stages visit v) visits whose rows (delayed input | conditioning) the loading helper keeps staged
+constexpr int kRowSlice = 20;                 // a K slice of 16 floats + 4 of padding: the 16 slices' 16-byte reads fall on different banks
+constexpr int kRowPad = 16 * kRowSlice;
 struct Lds {
   float xy[kXyRing][2 * kHalf];               // the newest messages of this stage: [x padded | y padded]
-  unsigned arrived[4];                        // [0]: visits staged into xy by the polling wave
-  unsigned hdone[4];                          // per helper: visits whose xy image it no longer needs
-  unsigned pad_[4];
+  float rows[kRowRing][2][kRowPad];           // [visit][x_s[t - d] | c[t]]: what the biases of the next visits are multiplied with
+  unsigned arrived[4];                        // [v mod 4]: v + 1 once the message of visit v is staged into xy (by helper v mod 4)
+  unsigned hdone[4];                          // per chain wave: visits whose xy image it no longer needs
+  unsigned rows_ready[4];                     // [v mod 4]: v + 1 once the rows of visit v are staged (by helper v mod 4: every word has ONE writer, so it only grows)
   unsigned ready[4];                          // per helper: biases prepared (visit count)
   float bias[];                               // [chain wave][step parity][Bcap clips][gate row]: everything of z that is known a step ahead (dynamic LDS: 512 B per clip)
 };
@@ -185,32 +206,14 @@ struct Stamps {
 // ------------------------------------------------------------------------------------------------------------------------------------
 // chain waves (waves 0-3 of a layer stage's workgroup): gate rows 16 W .. 16 W + 15, residual channels 8 W .. 8 W + 7, W = 4 p + q
 // ------------------------------------------------------------------------------------------------------------------------------------
-// the three things a chain wave waits for in LDS before it computes visit v, read together: the message staged by the polling wave,
-// the helpers past the image that visit v + 1 will overwrite, this wave's bias prepared
+// the two things a chain wave waits for in LDS before it computes visit v, read together: the message staged by the polling helper, this
+// wave's bias prepared
 __device__ __forceinline__ bool chain_wait(const Lds& S, int q, unsigned v, int32_t* err) {
   unsigned spins = 0;
   for (;;) {
-    const unsigned arr = __hip_atomic_load(&S.arrived[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP), hd = lds_min4(S.hdone);
+    const unsigned arr = __hip_atomic_load(&S.arrived[v & 3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     const unsigned rd = __hip_atomic_load(&S.ready[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    if (arr >= v + 1 && hd + (kXyRing - 2) >= v + 1 && rd >= v + 1) break;
-    if (kChainSleep > 0) __builtin_amdgcn_s_sleep(kChainSleep);
-    if (++spins > kSpinLimit || ((spins & 4095u) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
-      atomicExch(err, 1);
-      return false;
-    }
-  }
-  __atomic_signal_fence(__ATOMIC_SEQ_CST);
-  return true;
-}
-
-// the polling wave checks the two LDS conditions BEFORE it looks for the message (they are true long before it arrives - the bias was
-// prepared a step ago, the helpers trail by a visit): between "message seen" and its products stands the staging store only
-__device__ __forceinline__ bool poller_wait(const Lds& S, unsigned v, int32_t* err) {
-  unsigned spins = 0;
-  for (;;) {
-    const unsigned hd = lds_min4(S.hdone);
-    const unsigned rd = __hip_atomic_load(&S.ready[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    if (hd + (kXyRing - 2) >= v + 1 && rd >= v + 1) break;
+    if (arr >= v + 1 && rd >= v + 1) break;
     if (kChainSleep > 0) __builtin_amdgcn_s_sleep(kChainSleep);
     if (++spins > kSpinLimit || ((spins & 4095u) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
       atomicExch(err, 1);
@@ -228,13 +231,15 @@ __device__ void chain_role(const WnSpipeArgs& a, Lds& S, int stage, int p, int q
   // reduce-scatter over the DPP row, so that lane l ends with gate row l / 4 and residual channel l / 8 of the wave
   const int ks = lane & 15;
   const int j = lane >> 2, j8 = lane >> 3;
-  f32x4s wz[32], wr[8];
+  f32x4s wz[32], wr[8], wh[4];
   {
     const f32x4s* img = reinterpret_cast<const f32x4s*>(a.img_chain) + ((int64_t)stage * kWavesPerStage + W) * kChainRegs * 64 + lane;
 #pragma unroll
     for (int i = 0; i < 32; ++i) wz[i] = img[i * 64];
 #pragma unroll
     for (int i = 0; i < 8; ++i) wr[i] = img[(32 + i) * 64];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) wh[i] = img[(40 + i) * 64];
   }
   float bx = a.cst_chain[((int64_t)stage * kWavesPerStage + W) * 64 + lane];
   // IN their registers before the visit loop: a load the compiler still counts as pending at the loop's entry makes it wait inside
@@ -244,20 +249,26 @@ __device__ void chain_role(const WnSpipeArgs& a, Lds& S, int stage, int p, int q
   for (int i = 0; i < 32; ++i) asm volatile("" : "+v"(wz[i]));
 #pragma unroll
   for (int i = 0; i < 8; ++i) asm volatile("" : "+v"(wr[i]));
+#pragma unroll
+  for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(wh[i]));
   asm volatile("" : "+v"(bx));
+  // The head's hidden pre-activations hid_s = hid_{s-1} + (fc0 W_skip_{s-1}) y_{s-1}: this wave's 4 units (4 W + lane / 16), K = 256 over the
+  // 16 lanes of a row - with the 16 y values a lane holds for the residual product anyway, BEHIND the publish (off the chain).  They are
+  // added up INSIDE an XCD only (a hand-over from another XCD is a 0.8-us load): the first stage of an XCD starts a new sum, the last one
+  // writes the XCD's sum where the head collects the (at most eight) of them.
+  const int64_t hid_words = (int64_t)a.Bmax * kSpSlots * kH1;
+  const int grp = (stage + slot_shift(a)) >> 2;
+  const bool hid_chain_in = stage >= 2 && ((stage - 1 + slot_shift(a)) >> 2) == grp;
+  const bool hid_last = stage == a.L - 1 || ((stage + 1 + slot_shift(a)) >> 2) != grp;
+  const bool hid_local = hid_last ? grp == ((a.L + slot_shift(a)) >> 2) : true;      // (the head's own XCD: its L2 is the meeting point)
+  const unsigned* hid_in = a.hidmsg + (int64_t)stage * hid_words + 4 * W + (lane >> 4);
+  unsigned* hid_out = (hid_last ? a.hidgrp + (int64_t)grp * hid_words : a.hidmsg + (int64_t)(stage + 1) * hid_words) + 4 * W + (lane >> 4);
   const bool g_row = (j & 1) != 0;
   const float gate_scale = g_row ? -1.4426950408889634f : -2.8853900817779268f;
   const float gate_k = g_row ? 1.f : 2.f, gate_shift = g_row ? 0.f : -1.f;
   const bool local_next = ((stage + 1 + slot_shift(a)) >> 2) == ((stage + slot_shift(a)) >> 2);
   const int64_t stage_words = (int64_t)a.Bmax * kSpSlots * kMsgFloats;
   unsigned* msg_out = a.msg + (int64_t)(stage + 1) * stage_words;
-  // Wave 0 of the workgroup polls for the whole CU: lane l looks at floats 8 l .. 8 l + 7 of the message = 8 x (l even) or 8 y (l odd)
-  // channels of producing wave l / 2, and stages them into the LDS image the other waves read.  One poller per CU: the message
-  // crosses the CU's memory pipe once, and nobody waits for the slowest of several pollers.
-  const bool poller = q == 0;
-  const __amdgpu_buffer_rsrc_t inbox = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned*>(a.msg + (int64_t)stage * stage_words), 0, -1, 0x00020000);
-  const int look_off = 32 * lane;                                       // bytes inside one message
-  const int st_off = ((lane & 1) ? kHalf : 0) + pad_of(8 * (lane >> 1));
   const int kso = (ks < 8 ? 0 : kHalf) + (ks & 7) * kPadBlk;           // K slice ks: x[32 ks ..] for ks < 8, y[32 (ks - 8) ..] above
   const int xr_off = kHalf + pad_of(16 * ks);                          // y[16 ks ..]
   const int xin_off = pad_of(8 * W + j8);
@@ -270,62 +281,12 @@ __device__ void chain_role(const WnSpipeArgs& a, Lds& S, int stage, int p, int q
   Stamps st;
   u64 t0c = 0;
   unsigned v = 0;
-  auto look = [&](int byte_off, u32x4s& lo, u32x4s& hi) {               // 32 bytes per lane past this CU's L1 (sc1), counted by the compiler
-    lo = __builtin_amdgcn_raw_buffer_load_b128(inbox, byte_off, 0, 16);
-    hi = __builtin_amdgcn_raw_buffer_load_b128(inbox, byte_off + 16, 0, 16);
-  };
-  auto landed = [&](const u32x4s& lo, const u32x4s& hi) {
-    const bool ok = lo[0] != kSpPoison && lo[1] != kSpPoison && lo[2] != kSpPoison && lo[3] != kSpPoison && hi[0] != kSpPoison &&
-                    hi[1] != kSpPoison && hi[2] != kSpPoison && hi[3] != kSpPoison;
-    return __all(ok) != 0;
-  };
-  u32x4s pre_lo = u32x4s{0, 0, 0, 0}, pre_hi = u32x4s{0, 0, 0, 0};
-  if (poller) look(look_off, pre_lo, pre_hi);                           // (clip 0, slot 0)
   for (int s = 0; s < n_steps; ++s) {
     const int64_t tau = a.t0 - 1 + s;
     const int slot = s & 3, pslot = (s + 2) & 3;
     for (int c = 0; c < B; ++c, ++v) {
       if (STAMPS) t0c = __builtin_amdgcn_s_memtime();
-      if (poller) {
-        if (!poller_wait(S, v, a.err_flag)) return;
-        // ---- the message: until no word is poison (the first look was requested a visit ago) ------------------------------------------
-        const int off = ((c * kSpSlots + slot) * kMsgFloats) * 4 + look_off;
-        u32x4s w_lo = pre_lo, w_hi = pre_hi;
-        if (!landed(w_lo, w_hi)) {
-          // kLooks looks in flight, a short sleep apart.  Measured on cfg 4 (scripts/gpu_ab.sh): ONE look at a time 55.5 us per step, two
-          // 60.5, three 66 - every extra outstanding look costs all stages more in the L2 than it gains this one in reaction time.
-          u32x4s q_lo[kLooks], q_hi[kLooks];
-#pragma unroll
-          for (int k = 0; k < kLooks; ++k) {
-            look(off, q_lo[k], q_hi[k]);
-            if (k + 1 < kLooks) __builtin_amdgcn_s_sleep(kPollGap);
-          }
-          unsigned spins = 0;
-          for (;;) {
-            w_lo = q_lo[0]; w_hi = q_hi[0];
-            if (landed(w_lo, w_hi)) break;
-            if (++spins > kSpinLimit || ((spins & 1023u) == 0 && __hip_atomic_load(a.err_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
-              atomicExch(a.err_flag, 1);
-              return;
-            }
-#pragma unroll
-            for (int k = 0; k + 1 < kLooks; ++k) { q_lo[k] = q_lo[k + 1]; q_hi[k] = q_hi[k + 1]; }
-            __builtin_amdgcn_s_sleep(kPollGap);
-            look(off, q_lo[kLooks - 1], q_hi[kLooks - 1]);
-          }
-          if (STAMPS) st.polls += spins + 1;
-        }
-        float* dst = &S.xy[v & (kXyRing - 1)][st_off];
-        *reinterpret_cast<f32x4s*>(dst) = f32x4s{__uint_as_float(w_lo[0]), __uint_as_float(w_lo[1]), __uint_as_float(w_lo[2]), __uint_as_float(w_lo[3])};
-        *reinterpret_cast<f32x4s*>(dst + 4) = f32x4s{__uint_as_float(w_hi[0]), __uint_as_float(w_hi[1]), __uint_as_float(w_hi[2]), __uint_as_float(w_hi[3])};
-        if (STAMPS && a.stamps && c == 0 && s + 1 == n_steps && p == 0 && lane == 0) a.stamps[64 + stage] = __builtin_amdgcn_s_memrealtime();
-        if (STAMPS && a.stamps && s == n_steps / 2 && p == 0 && lane == 0 && c < 32) a.stamps[256 + 1024 + stage * 32 + c] = __builtin_amdgcn_s_memrealtime();   // seen, every clip, the launch's middle step
-        lds_signal(&S.arrived[0], v + 1, lane);
-        // first look at the NEXT visit's message: in flight while this visit computes
-        int cn = c + 1, sn = s;
-        if (cn == B) { cn = 0; sn = s + 1; }
-        if (sn < n_steps) look(((cn * kSpSlots + (sn & 3)) * kMsgFloats) * 4 + look_off, pre_lo, pre_hi);
-      } else if (!chain_wait(S, q, v, a.err_flag)) return;
+      if (!chain_wait(S, q, v, a.err_flag)) return;
       __builtin_amdgcn_s_setprio(3);              // (low while it spins: the helper wave of this SIMD gets the issue slots)
       if (STAMPS) {
         const u64 t = __builtin_amdgcn_s_memtime(); st.t_wait += t - t0c; t0c = t;
@@ -333,6 +294,9 @@ __device__ void chain_role(const WnSpipeArgs& a, Lds& S, int stage, int p, int q
       }
       // what the helper prepared a step ahead: W0 x[t - d] + conditioning + biases
       const float bzv = S.bias[bias_off(q, s & 1, c, j, Bcap)];
+      unsigned hw1 = 0;
+      const unsigned* hsrc = hid_in + ((int64_t)c * kSpSlots + slot) * kH1;
+      if (hid_chain_in) hw1 = msg_load(hsrc);         // the hand-over of the stage below: published before its message was, looked at now, used behind the publish
       // ---- z = [W1 | W1 R] . [x ; y]: 8 reads of 4 inputs, 64 packed FMAs (4 rows x 32 inputs per lane) ---------------------------------
       const float* xb = S.xy[v & (kXyRing - 1)];
       f32x2 acc[4][2];
@@ -376,7 +340,7 @@ __device__ void chain_role(const WnSpipeArgs& a, Lds& S, int stage, int p, int q
       // ---- publish 8 x | 8 y, re-poison the same words two steps ahead, keep x_s for the delayed taps -------------------------------------
       if (pub_lane) {
         unsigned* dst = msg_out + ((int64_t)c * kSpSlots + slot) * kMsgFloats + pub_off;
-        msg_store(dst, __float_as_uint((lane & 1) ? y : xnew), local_next);
+        msg_store(dst, msg_bits((lane & 1) ? y : xnew), local_next);
       }
       if (STAMPS) {
         const u64 t = __builtin_amdgcn_s_memtime(); st.t_compute += t - t0c; t0c = t;
@@ -388,31 +352,78 @@ __device__ void chain_role(const WnSpipeArgs& a, Lds& S, int stage, int p, int q
       __builtin_amdgcn_s_setprio(0);
       if (pub_lane) msg_store(msg_out + ((int64_t)c * kSpSlots + pslot) * kMsgFloats + pub_off, kSpPoison, local_next);
       if ((lane & 7) == 0) hist[(tau & ring_mask) * slot_stride + (int64_t)c * kC + 8 * W + j8] = xnew;
+      // ---- the hidden units' sum, handed on ---------------------------------------------------------------------------------------------------
+      if (stage >= 1) {
+        f32x2 hc[2] = {f32x2{0.f, 0.f}, f32x2{0.f, 0.f}};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {      // (the y slice of the residual product, read again: 16 registers kept across the gate would not fit)
+          const f32x4s yv = *reinterpret_cast<const f32x4s*>(xb + xr_off + i * 4);
+          hc[0] = fma2(f32x2{wh[i][0], wh[i][1]}, f32x2{yv[0], yv[1]}, hc[0]);
+          hc[1] = fma2(f32x2{wh[i][2], wh[i][3]}, f32x2{yv[2], yv[3]}, hc[1]);
+        }
+        const float hs = dpp_mirror_add(dpp_half_mirror_add(dpp_quad_sum((hc[0][0] + hc[0][1]) + (hc[1][0] + hc[1][1]))));
+        float hin = 0.f;
+        if (hid_chain_in) {
+          unsigned spins = 0;
+          while (!__all(hw1 != kSpPoison)) {
+            if (++spins > kSpinLimit || ((spins & 1023u) == 0 && __hip_atomic_load(a.err_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+              atomicExch(a.err_flag, 1);
+              return;
+            }
+            hw1 = msg_load(hsrc);
+          }
+          hin = __uint_as_float(hw1);
+        }
+        if (ks == 0) {
+          msg_store(hid_out + ((int64_t)c * kSpSlots + slot) * kH1, msg_bits(hin + hs), hid_local);
+          msg_store(hid_out + ((int64_t)c * kSpSlots + pslot) * kH1, kSpPoison, hid_local);
+        }
+      }
+      lds_signal(&S.hdone[q], v + 1, lane);        // this wave is through with the LDS image of visit v
       if (STAMPS) { const u64 t = __builtin_amdgcn_s_memtime(); st.t_post += t - t0c; st.visits += 1; }
     }
   }
   if (STAMPS && a.stamps && stage == a.stamp_stage && p == 0 && q == 0 && lane == 0) {
-    a.stamps[0] = st.t_wait; a.stamps[1] = st.t_compute; a.stamps[2] = st.t_post; a.stamps[3] = st.visits; a.stamps[4] = st.polls;
+    a.stamps[0] = st.t_wait; a.stamps[1] = st.t_compute; a.stamps[2] = st.t_post; a.stamps[3] = st.visits;
   }
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------------
-// helper waves (waves 4-7): for chain wave h of the same workgroup the part of z known a step ahead, and the head's hidden units 4 W ..
+// helper waves (waves 4-7): the CU's eyes - they look for the messages and stage them - and, for chain wave h of the same workgroup, the
+// part of z known a step ahead
 // ------------------------------------------------------------------------------------------------------------------------------------
+// One iteration per visit `it` = (clip c, step s):
+//   1. the visit's message.  Helper it mod 4 LOOKS for it (lane l: floats 8 l .. 8 l + 7 = 8 x or 8 y channels of producing wave l / 2; past
+//      this CU's L1) until no word is poison, stages it into the LDS image the chain waves read, tells them (S.arrived, s_wakeup) and
+//      sends the first look at the message of visit it + 4; the other three wait for S.arrived - as evidence, they read nothing of it.
+//   2. the bias of visit it - 1 + B from the rows asked for one or three iterations ago (staged in LDS by the helper that asked)
+//   3. the helper that looked asks for the rows of the bias of visit it + B [+ 2]: the conditioning row c[t] and this stage's input x_s[t - d]
+// Why the helpers look and not a chain wave (round 3, and this round's first builds): a wave's memory operations retire in order, so a
+// look waits behind every store the same wave sent before it.  The chain waves publish - and the last stage of an XCD writes THROUGH to
+// memory, ~1 us per store: with a chain wave looking, such a stage saw its message 0.2 us later than the others (two stores a visit), and 1.5
+// us later once the chain waves also handed on the hidden units' sums (four).  The helpers store nothing outside LDS.  Their own slow loads
+// (a row 512 steps old comes from HBM) are asked for right AFTER a look duty, four visits before the next one.  And four lookers in turn
+// have four messages' looks in flight: a stage whose message comes from another XCD (~0.8 us per look) is no longer held to one visit
+// per round trip when the clips queue up (64 and more clips in the ring).
+// Nothing a step ahead is waited for where it is asked for.  That matters most for the rows of a dilation-1 layer, which are this stage's
+// OWN output of visit `it` (published ~0.8 us after the message arrived): waiting for them inside the iteration that asked made such a
+// stage's helpers take 1.66 us per visit whatever the chain did - the beat of the whole ring, 32 or 128 clips alike (64 clips: 106 us a step).
+// What makes a ring row safe to read: every wave works through the visits in one order, and the arrival of message (c, s) says that step
+// s - 1 of clip c has left the head - every visit up to (c, s - 1) is complete on every CU of this stage.  Row t_{s+1} - d of clip c was
+// written by visit (c, s + 1 - d): covered iff d >= 2.  d = 1 polls the stage's own newest message instead (its ring entry has no
+// arrival check).  Step 0's biases (rows the warm-up wrote) are prepared before the loop.
 template <bool STAMPS>
 __device__ void helper_role(const WnSpipeArgs& a, Lds& S, int stage, int p, int h, int lane) {
   const int W = 4 * p + h;
-  const int ks = lane & 15;                     // K slice of 16: of the delayed input and the conditioning row (4 gate rows per lane), of y (one hidden unit per lane)
-  const int j = lane >> 2, j4 = lane >> 4;
-  f32x4s w0[16], wc[16], wh[4];
+  const int ks = lane & 15;                     // K slice of 16 of the delayed input and the conditioning row (4 gate rows per lane)
+  const int j = lane >> 2;
+  f32x4s w0[16], wc[16];
   {
     const f32x4s* img = reinterpret_cast<const f32x4s*>(a.img_helper) + ((int64_t)stage * kWavesPerStage + W) * kHelperRegs * 64 + lane;
 #pragma unroll
     for (int i = 0; i < 16; ++i) w0[i] = img[i * 64];
 #pragma unroll
     for (int i = 0; i < 16; ++i) wc[i] = img[(16 + i) * 64];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) wh[i] = img[(32 + i) * 64];
   }
   float bz = a.cst_helper[((int64_t)stage * kWavesPerStage + W) * 64 + lane];
   // (in their registers before the loop, as in the chain role)
@@ -420,209 +431,227 @@ __device__ void helper_role(const WnSpipeArgs& a, Lds& S, int stage, int p, int 
   for (int i = 0; i < 16; ++i) asm volatile("" : "+v"(w0[i]));
 #pragma unroll
   for (int i = 0; i < 16; ++i) asm volatile("" : "+v"(wc[i]));
-#pragma unroll
-  for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(wh[i]));
   asm volatile("" : "+v"(bz));
   const int d = a.dil[stage], ring_mask = a.ring[stage] - 1;
   const int64_t slot_stride = (int64_t)a.Bmax * kC;
-  const bool local_next = ((stage + 1 + slot_shift(a)) >> 2) == ((stage + slot_shift(a)) >> 2);
   const int64_t stage_words = (int64_t)a.Bmax * kSpSlots * kMsgFloats;
-  // The head's hidden pre-activations are added up INSIDE an XCD only (a hand-over from another XCD is a 0.8-us load that sits in front of
-  // this wave's local polls in its in-order memory counter): the first stage of an XCD starts a new sum, the last one writes the XCD's
-  // sum where the head collects the (at most eight) of them.
-  const int64_t hid_words = (int64_t)a.Bmax * kSpSlots * kH1;
-  const int grp = (stage + slot_shift(a)) >> 2;
-  const bool hid_chain_in = stage >= 2 && ((stage - 1 + slot_shift(a)) >> 2) == grp;
-  const bool hid_last = stage == a.L - 1 || ((stage + 1 + slot_shift(a)) >> 2) != grp;
-  const bool hid_local = hid_last ? grp == ((a.L + slot_shift(a)) >> 2) : true;      // (the head's own XCD: its L2 is the meeting point)
-  const unsigned* hid_in = a.hidmsg + (int64_t)stage * hid_words;
-  unsigned* hid_out = hid_last ? a.hidgrp + (int64_t)grp * hid_words : a.hidmsg + (int64_t)(stage + 1) * hid_words;
   const int B = a.B, Bcap = bias_cap(a.B);
   const int n_visits = (int)a.n_steps * B;
-  const int ks_off = pad_of(16 * ks);
-  // A lane reads ITS 16 inputs of a row straight into registers (64 contiguous bytes; the four row groups of the wave ask for the
-  // same bytes): no staging through LDS, no hand-shake between the helper waves.
+  // The rows a bias is multiplied with - this stage's delayed input and the projected conditioning row, 1 KB each - come into the CU ONCE:
+  // helper v mod 4 asks for those of visit v (lane l: floats 4 l .. 4 l + 3 of each) and stages them in LDS, all four helpers read their
+  // K slices from there.  (Every lane asking for its own 2 x 64 bytes - the form of round 3 - moves 32 KB per visit through the CU's
+  // address unit, 64 bytes per clock: ~500 clocks per visit, in front of every look, every publish and every hand-over of that CU.)
+  // A helper has one request in flight: asked for three iterations before its visit's bias is due where the row is old enough for that
+  // (d >= 3: the arrival that has been seen then covers it, and a row 512 steps old comes from HBM), one iteration before otherwise.
+  const int ahead = (d - 2) * a.B >= 2 ? 2 : 0;      // (visit it + B + 2's row was written by visit it + B + 2 - d B; proven complete: up to it - B)
+  // who asks for (and stages) the rows of visit v: the helper that looks in iteration v - B - ahead, right after its look duty
+  auto rows_mine = [&](int v) { return (((unsigned)(v - B - ahead)) & 3u) == (unsigned)h; };
+  // ---- looking for messages -----------------------------------------------------------------------------------------------------------------
+  const __amdgpu_buffer_rsrc_t inbox = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned*>(a.msg + (int64_t)stage * stage_words), 0, -1, 0x00020000);
+  const int look_off = 32 * lane;                                       // bytes inside one message
+  const int st_off = ((lane & 1) ? kHalf : 0) + pad_of(8 * (lane >> 1));
+  auto look = [&](int byte_off, u32x4s& lo, u32x4s& hi) {               // 32 bytes per lane past this CU's L1 (sc1), counted by the compiler
+    asm volatile("" ::: "memory");              // (every look is a load of its own: two looks at one address must not be merged into one)
+    lo = __builtin_amdgcn_raw_buffer_load_b128(inbox, byte_off, 0, 16);
+    hi = __builtin_amdgcn_raw_buffer_load_b128(inbox, byte_off + 16, 0, 16);
+  };
+  auto landed = [&](const u32x4s& lo, const u32x4s& hi) {
+    const bool ok = lo[0] != kSpPoison && lo[1] != kSpPoison && lo[2] != kSpPoison && lo[3] != kSpPoison && hi[0] != kSpPoison &&
+                    hi[1] != kSpPoison && hi[2] != kSpPoison && hi[3] != kSpPoison;
+    return __all(ok) != 0;
+  };
+  u32x4s pre_lo = u32x4s{0, 0, 0, 0}, pre_hi = u32x4s{0, 0, 0, 0};
+  u64 n_polls = 0;
   const __amdgpu_buffer_rsrc_t ring = __builtin_amdgcn_make_buffer_rsrc(a.hist[stage], 0, -1, 0x00020000);      // rows other CUs write: past L1 (sc1)
   const __amdgpu_buffer_rsrc_t own = __builtin_amdgcn_make_buffer_rsrc(a.msg + (int64_t)(stage + 1) * stage_words, 0, -1, 0x00020000);
-  const bool cond_lane = 16 * ks < a.C1;        // (C1 is a multiple of 16: a slice lies inside the row or above it)
-  // What makes a ring entry safe to read: every wave works through the visits in one order, and the arrival of message (c, s) says
-  // that step s - 1 of clip c has left the head - so every visit up to (c, s - 1) is complete on every CU of this stage.  The rows
-  // of the bias of visit it + B are asked for at the TOP of iteration it, before message `it` has arrived (they land while the wave
-  // waits for it): the newest evidence then is message it - 1, which covers the row iff d >= 3.  d = 2 reads its row when it is
-  // used (an L2 hit: written two steps ago), d = 1 polls this stage's own newest message (its ring entry has no arrival check).
-  const bool early = d >= 3;
+  const bool cond_lane = 4 * lane < a.C1;       // (C1 is a multiple of 16)
   u64 hs_t[6] = {0, 0, 0, 0, 0, 0}, hs_t0 = 0;      // diagnostic build: cycles in the phases of an iteration
   auto hstamp = [&](int k) {
     if (STAMPS) { const u64 t = __builtin_amdgcn_s_memtime(); hs_t[k] += t - hs_t0; hs_t0 = t; }
   };
-  auto ring_row = [&](int s2, int c2, u32x4s (&xv)[4]) {
-    const int64_t tp = (STAMPS && (a.dbg & 2)) ? a.t0 - 1 + s2 - 2 : a.t0 - 1 + s2 - d;     // (dbg 2: diagnostic build, timing only)
-    if (tp >= 0) {
-      const int off = (int)(((tp & ring_mask) * slot_stride + (int64_t)c2 * kC + 16 * ks) * 4);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) xv[i] = __builtin_amdgcn_raw_buffer_load_b128(ring, off + 16 * i, 0, 16);
+  // request the rows of the bias of visit (c2, s2).  x: this stage's input at position t_{s2} - d, from the history ring (zeros
+  // in front of the sequence) - or, d = 1 past step 0, from this stage's newest message: channels 4 l .. + 3 are words (l / 2) 16 +
+  // (l & 1) 4 of it (per producing wave 8 x | 8 y).  c: my four floats of the projected conditioning row c[t] (LinearIO of input 1,
+  // modules/io.py:115-122): the layer's 1x1 product with it (wavenet_v2.py:140-150) is multiplied here, beside the delayed-tap product
+  auto request_rows = [&](int s2, int c2, bool from_own, u32x4s& xr, f32x4s& cr, bool with_cond = true) {
+    if (from_own) {
+      const int off = (((c2 * kSpSlots + ((s2 - 1) & 3)) * kMsgFloats) + (lane >> 1) * 16 + (lane & 1) * 4) * 4;
+      xr = __builtin_amdgcn_raw_buffer_load_b128(own, off, 0, 16);
     } else {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) xv[i] = u32x4s{0, 0, 0, 0};
+      const int64_t tp = (STAMPS && (a.dbg & 2)) ? a.t0 - 1 + s2 - 2 : a.t0 - 1 + s2 - d;     // (dbg 2: diagnostic build, timing only)
+      if (tp >= 0) xr = __builtin_amdgcn_raw_buffer_load_b128(ring, (int)(((tp & ring_mask) * slot_stride + (int64_t)c2 * kC + 4 * lane) * 4), 0, 16);
+      else xr = u32x4s{0, 0, 0, 0};
     }
+    // (a repeated look at the stage's own message does not ask for the conditioning row again: that one comes from HBM, and the look
+    //  behind it would wait for it - a wave's loads return in order)
+    if (!with_cond) return;
+    if (cond_lane && !(STAMPS && (a.dbg & 1))) cr = *reinterpret_cast<const f32x4s*>(a.cproj + ((int64_t)c2 * a.cond_steps + s2) * a.C1 + 4 * lane);
+    else cr = f32x4s{0.f, 0.f, 0.f, 0.f};
   };
-  int s = -1, c = 0, s2 = 0, c2 = 0;              // visit it = (c, s), visit it + B = (c2, s2) = (c, s + 1)
-  for (int it = -B; it < n_visits; ++it) {
-    if (STAMPS) hs_t0 = __builtin_amdgcn_s_memtime();
-    const int v2 = it + B;
-    const bool valid = v2 < n_visits;
-    // ---- the rows of the NEXT bias, requested before anything waits -----------------------------------------------------------------------
-    u32x4s xv[4];
-    f32x4s cv[4];
+  // the requested rows into the LDS slot of visit v3, once every helper is through with the visit that used the slot before
+  auto stage_rows = [&](unsigned v3, const u32x4s& xr, const f32x4s& cr) -> bool {
+    if (v3 >= (unsigned)kRowRing && !lds_wait4(S.ready, v3 - kRowRing + 1, a.err_flag)) return false;
+    float* dst = &S.rows[v3 & (kRowRing - 1)][0][kRowSlice * (lane >> 2) + 4 * (lane & 3)];
+    *reinterpret_cast<f32x4s*>(dst) = f32x4s{__uint_as_float(xr[0]), __uint_as_float(xr[1]), __uint_as_float(xr[2]), __uint_as_float(xr[3])};
+    *reinterpret_cast<f32x4s*>(dst + kRowPad) = cr;
+    lds_signal(&S.rows_ready[v3 & (kRowRing - 1)], v3 + 1, lane);
+    return true;
+  };
+  // the bias of visit v3 = (c2, s2): W0 x_s[t - d] + W_1x1 c[t] + constants, into the LDS image the chain wave reads
+  auto bias_of = [&](unsigned v3, int s2, int c2) -> bool {
+    if (!lds_wait1(&S.rows_ready[v3 & (kRowRing - 1)], v3 + 1, a.err_flag)) return false;
+    const float* xs = &S.rows[v3 & (kRowRing - 1)][0][kRowSlice * ks];
+    f32x2 acc[4][2];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { xv[i] = u32x4s{0, 0, 0, 0}; cv[i] = f32x4s{0.f, 0.f, 0.f, 0.f}; }
-    const bool row_now = valid && (early || s2 == 0);       // (step 0 reads what the warm-up wrote)
-    if (valid) {
-      // my slice of the projected conditioning row c[t] (LinearIO of input 1, modules/io.py:115-122): the layer's 1x1 product with it
-      // (wavenet_v2.py:140-150) is multiplied here, beside the delayed-tap product - no per-layer table in HBM
-      if (cond_lane && !(STAMPS && (a.dbg & 1))) {
-        const f32x4s* src = reinterpret_cast<const f32x4s*>(a.cproj + ((int64_t)c2 * a.cond_steps + s2) * a.C1 + 16 * ks);
+    for (int cc = 0; cc < 4; ++cc) acc[cc][0] = acc[cc][1] = f32x2{0.f, 0.f};
 #pragma unroll
-        for (int i = 0; i < 4; ++i) cv[i] = src[i];
+    for (int i = 0; i < 4; ++i) {
+      const f32x4s xf = *reinterpret_cast<const f32x4s*>(xs + 4 * i);
+#pragma unroll
+      for (int cc = 0; cc < 4; ++cc) {
+        acc[cc][0] = fma2(f32x2{w0[cc * 4 + i][0], w0[cc * 4 + i][1]}, f32x2{xf[0], xf[1]}, acc[cc][0]);
+        acc[cc][1] = fma2(f32x2{w0[cc * 4 + i][2], w0[cc * 4 + i][3]}, f32x2{xf[2], xf[3]}, acc[cc][1]);
       }
-      if (row_now) ring_row(s2, c2, xv);
     }
-    hstamp(0);
-    bool hid_pending = false;
-    float hs = 0.f;
-    unsigned w1 = 0;
-    const unsigned* hsrc = nullptr;
-    const int slot = s & 3, pslot = (s + 2) & 3;
-    if (it >= 0) {
-      if (stage >= 1) {
-        // ---- hidden pre-activations: hid_s = hid_{s-1} + (fc0 W_skip_{s-1}) y_{s-1}, my 4 units, K = 256 over 16 lanes ---------------------
-        if (!lds_wait1(&S.arrived[0], (unsigned)it + 1, a.err_flag)) return;
-        hstamp(1);
-        hsrc = hid_in + ((int64_t)c * kSpSlots + slot) * kH1 + 4 * W + j4;
-        if (hid_chain_in) w1 = msg_load(hsrc);          // a first look at the hand-over of the stage below, in flight under the products
-        const float* yb = S.xy[it & (kXyRing - 1)] + kHalf + ks_off;
-        f32x2 hc[2] = {f32x2{0.f, 0.f}, f32x2{0.f, 0.f}};
+    if (a.C1 > 0) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const f32x4s yv = *reinterpret_cast<const f32x4s*>(yb + i * 4);
-          hc[0] = fma2(f32x2{wh[i][0], wh[i][1]}, f32x2{yv[0], yv[1]}, hc[0]);
-          hc[1] = fma2(f32x2{wh[i][2], wh[i][3]}, f32x2{yv[2], yv[3]}, hc[1]);
+      for (int i = 0; i < 4; ++i) {
+        const f32x4s cf = *reinterpret_cast<const f32x4s*>(xs + kRowPad + 4 * i);
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) {
+          acc[cc][0] = fma2(f32x2{wc[cc * 4 + i][0], wc[cc * 4 + i][1]}, f32x2{cf[0], cf[1]}, acc[cc][0]);
+          acc[cc][1] = fma2(f32x2{wc[cc * 4 + i][2], wc[cc * 4 + i][3]}, f32x2{cf[2], cf[3]}, acc[cc][1]);
         }
-        hs = dpp_mirror_add(dpp_half_mirror_add(dpp_quad_sum((hc[0][0] + hc[0][1]) + (hc[1][0] + hc[1][1]))));
-        lds_signal(&S.hdone[h], (unsigned)it + 1, lane);
-        hid_pending = true;      // handed on below, behind the bias products: the look's round trip runs under them
-        hstamp(2);
-      } else {
-        // (stage 0 has no hidden units to add; it waits for the arrival all the same, so that no helper runs ahead of the chain whatever
-        //  the first layer's dilation is)
-        if (!lds_wait1(&S.arrived[0], (unsigned)it + 1, a.err_flag)) return;
-        lds_signal(&S.hdone[h], (unsigned)it + 1, lane);
       }
     }
-    if (valid) {
-      // ---- the bias of visit v2 = (c2, s2): W0 x_s[t - d] + W_1x1 c[t] + constants ---------------------------------------------------------
-      if (!row_now) {
-        if (d == 1) {             // x_s of the previous step = channels 16 ks .. + 15 of this stage's newest message: 8 x of producing waves 2 ks, 2 ks + 1
-          const int off = (((c2 * kSpSlots + ((s2 - 1) & 3)) * kMsgFloats) + 32 * ks) * 4;
-          unsigned spins = 0;
-          for (;;) {
-            xv[0] = __builtin_amdgcn_raw_buffer_load_b128(own, off, 0, 16);
-            xv[1] = __builtin_amdgcn_raw_buffer_load_b128(own, off + 16, 0, 16);
-            xv[2] = __builtin_amdgcn_raw_buffer_load_b128(own, off + 64, 0, 16);
-            xv[3] = __builtin_amdgcn_raw_buffer_load_b128(own, off + 80, 0, 16);
-            bool ok = true;
+    float zc[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) ok = ok && xv[i][0] != kSpPoison && xv[i][1] != kSpPoison && xv[i][2] != kSpPoison && xv[i][3] != kSpPoison;
-            if (__all(ok)) break;
+    for (int cc = 0; cc < 4; ++cc) zc[cc] = (acc[cc][0][0] + acc[cc][0][1]) + (acc[cc][1][0] + acc[cc][1][1]);
+    const float t = row_reduce_scatter4(zc[0], zc[1], zc[2], zc[3], ks);
+    if ((lane & 3) == 0) S.bias[bias_off(h, s2 & 1, c2, j, Bcap)] = t + bz;
+    lds_signal(&S.ready[h], v3 + 1, lane);
+    return true;
+  };
+  u32x4s xr = u32x4s{0, 0, 0, 0};
+  f32x4s cr = f32x4s{0.f, 0.f, 0.f, 0.f};
+  // ---- step 0: the rows the warm-up wrote, one clip after the other -------------------------------------------------------------------------
+  for (int c0 = 0; c0 < B; ++c0) {
+    if (rows_mine(c0)) {
+      request_rows(0, c0, false, xr, cr);
+      if (!stage_rows((unsigned)c0, xr, cr)) return;
+    }
+    if (!bias_of((unsigned)c0, 0, c0)) return;
+  }
+  int s = 0, c = 0;                               // visit it = (c, s)
+  int sp = 0, cp = 0;                             // visit it - 1 + B = (cp, sp): the bias that is due in iteration it
+  int sa = (B + ahead) / B, ca = (B + ahead) % B; // visit it + B + ahead = (ca, sa): the rows asked for in iteration it
+  int sl = 4 / B, cl = 4 % B;                     // visit it + 4 = (cl, sl): the message whose first look goes out in iteration it
+  if (ahead > 0)                                  // (what iterations -2 and -1 would have asked for: positions the warm-up wrote)
+    for (int k = 0; k < ahead; ++k) {
+      const int vr = B + k;
+      if (vr < n_visits && rows_mine(vr)) request_rows(vr / B, vr % B, false, xr, cr);
+    }
+  // A first look four visits ahead is a look at a slot of ANOTHER clip (or of this step + 1) only with four clips or more: the slot
+  // (clip, step mod 4) was poisoned when step - 2 of that clip was published, which lies behind the visit that is being staged.  With
+  // fewer clips, four visits ahead is up to four STEPS ahead - a slot that still holds the message of four steps ago.
+  const bool lookahead = B >= 4;
+  if (lookahead && h < n_visits) look(((((h % B) * kSpSlots + ((h / B) & 3)) * kMsgFloats) * 4) + look_off, pre_lo, pre_hi);   // the first look at "my" first message
+  else pre_lo[0] = kSpPoison;
+  for (int it = 0; it < n_visits; ++it) {
+    if (STAMPS) hs_t0 = __builtin_amdgcn_s_memtime();
+    const bool duty = (it & 3) == h;
+    // ---- 1. the visit's message ------------------------------------------------------------------------------------------------------------
+    if (duty) {
+      // (the LDS image of visit it - 8 is overwritten: every chain wave has to be through with it)
+      if (it >= kXyRing - 2 && !lds_wait4(S.hdone, (unsigned)it - (kXyRing - 2) + 1, a.err_flag)) return;
+      const int off = ((c * kSpSlots + (s & 3)) * kMsgFloats) * 4 + look_off;
+      unsigned spins = 0;
+      while (!landed(pre_lo, pre_hi)) {
+        if (++spins > kSpinLimit || ((spins & 1023u) == 0 && __hip_atomic_load(a.err_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+          atomicExch(a.err_flag, 1);
+          return;
+        }
+        if (kPollGap > 0 && spins > 1) __builtin_amdgcn_s_sleep(kPollGap);
+        look(off, pre_lo, pre_hi);
+      }
+      if (STAMPS) n_polls += spins;
+      float* dst = &S.xy[it & (kXyRing - 1)][st_off];
+      *reinterpret_cast<f32x4s*>(dst) = f32x4s{__uint_as_float(pre_lo[0]), __uint_as_float(pre_lo[1]), __uint_as_float(pre_lo[2]), __uint_as_float(pre_lo[3])};
+      *reinterpret_cast<f32x4s*>(dst + 4) = f32x4s{__uint_as_float(pre_hi[0]), __uint_as_float(pre_hi[1]), __uint_as_float(pre_hi[2]), __uint_as_float(pre_hi[3])};
+      if (STAMPS && a.stamps && c == 0 && s + 1 == (int)a.n_steps && p == 0 && lane == 0) a.stamps[64 + stage] = __builtin_amdgcn_s_memrealtime();
+      if (STAMPS && a.stamps && s == (int)a.n_steps / 2 && p == 0 && lane == 0 && c < 32) a.stamps[256 + 1024 + stage * 32 + c] = __builtin_amdgcn_s_memrealtime();   // seen, every clip, the launch's middle step
+      lds_signal(&S.arrived[it & 3], (unsigned)it + 1, lane);
+#if MMK_SP_WAKEUP
+      asm volatile("s_wakeup");            // the other waves of the workgroup out of their s_sleep: they look at the counter again at once
+#endif
+      if (lookahead && it + 4 < n_visits) look(((cl * kSpSlots + (sl & 3)) * kMsgFloats) * 4 + look_off, pre_lo, pre_hi);
+      else pre_lo[0] = kSpPoison;
+    } else if (!lds_wait1(&S.arrived[it & 3], (unsigned)it + 1, a.err_flag)) return;
+    hstamp(1);
+    // ---- 2. the bias of visit it - 1 + B (its rows were asked for one or three iterations ago) ---------------------------------------------------
+    if (it >= 1 && it - 1 + B < n_visits) {
+      const unsigned v3 = (unsigned)(it - 1 + B);
+      if (rows_mine((int)v3)) {
+        if (d == 1) {
+          unsigned spins = 0;
+          while (!__all(xr[0] != kSpPoison && xr[1] != kSpPoison && xr[2] != kSpPoison && xr[3] != kSpPoison)) {
             if (++spins > kSpinLimit || ((spins & 1023u) == 0 && __hip_atomic_load(a.err_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
               atomicExch(a.err_flag, 1);
               return;
             }
+            request_rows(sp, cp, true, xr, cr, false);
           }
-        } else {
-          ring_row(s2, c2, xv);
         }
+        if (!stage_rows(v3, xr, cr)) return;
       }
       hstamp(4);
-      f32x2 acc[4][2];
-#pragma unroll
-      for (int cc = 0; cc < 4; ++cc) acc[cc][0] = acc[cc][1] = f32x2{0.f, 0.f};
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const f32x4s xf = f32x4s{__uint_as_float(xv[i][0]), __uint_as_float(xv[i][1]), __uint_as_float(xv[i][2]), __uint_as_float(xv[i][3])};
-#pragma unroll
-        for (int cc = 0; cc < 4; ++cc) {
-          acc[cc][0] = fma2(f32x2{w0[cc * 4 + i][0], w0[cc * 4 + i][1]}, f32x2{xf[0], xf[1]}, acc[cc][0]);
-          acc[cc][1] = fma2(f32x2{w0[cc * 4 + i][2], w0[cc * 4 + i][3]}, f32x2{xf[2], xf[3]}, acc[cc][1]);
-        }
-      }
-      if (a.C1 > 0) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-#pragma unroll
-          for (int cc = 0; cc < 4; ++cc) {
-            acc[cc][0] = fma2(f32x2{wc[cc * 4 + i][0], wc[cc * 4 + i][1]}, f32x2{cv[i][0], cv[i][1]}, acc[cc][0]);
-            acc[cc][1] = fma2(f32x2{wc[cc * 4 + i][2], wc[cc * 4 + i][3]}, f32x2{cv[i][2], cv[i][3]}, acc[cc][1]);
-          }
-        }
-      }
-      float zc[4];
-#pragma unroll
-      for (int cc = 0; cc < 4; ++cc) zc[cc] = (acc[cc][0][0] + acc[cc][0][1]) + (acc[cc][1][0] + acc[cc][1][1]);
-      const float t = row_reduce_scatter4(zc[0], zc[1], zc[2], zc[3], ks);
-      if ((lane & 3) == 0) S.bias[bias_off(h, s2 & 1, c2, j, Bcap)] = t + bz;
-      lds_signal(&S.ready[h], (unsigned)v2 + 1, lane);
+      if (!bias_of(v3, sp, cp)) return;
       hstamp(5);
     }
-    if (hid_pending) {
-      float hin = 0.f;
-      if (hid_chain_in) {
-        unsigned spins = 0;
-        while (!__all(w1 != kSpPoison)) {
-          if (++spins > kSpinLimit || ((spins & 1023u) == 0 && __hip_atomic_load(a.err_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
-            atomicExch(a.err_flag, 1);
-            return;
-          }
-          w1 = msg_load(hsrc);
-        }
-        hin = __uint_as_float(w1);
-      }
-      if (ks == 0) {
-        msg_store(hid_out + ((int64_t)c * kSpSlots + slot) * kH1 + 4 * W + j4, __float_as_uint(hin + hs), hid_local);
-        msg_store(hid_out + ((int64_t)c * kSpSlots + pslot) * kH1 + 4 * W + j4, kSpPoison, hid_local);
-      }
-      hstamp(3);
-    }
+    // ---- 3. the rows of the bias of visit it + B + ahead (the helper that looked: its next look duty is four visits away) ------------------------
+    cp = c; sp = s + 1;
+    if (duty && it + B + ahead < n_visits) request_rows(sa, ca, d == 1, xr, cr);
+    if (++ca == B) { ca = 0; ++sa; }
+    if (++cl == B) { cl = 0; ++sl; }
+    hstamp(0);
     if (++c == B) { c = 0; ++s; }
-    c2 = c; s2 = s + 1;
   }
-  if (STAMPS && a.stamps && stage == a.stamp_stage && p == 0 && h == 0 && lane == 0)
+  if (STAMPS && a.stamps && stage == a.stamp_stage && p == 0 && h == 0 && lane == 0) {
     for (int k = 0; k < 6; ++k) a.stamps[6 + k] = hs_t[k];
+    a.stamps[4] = 4 * n_polls;          // (helper 0 looks for a quarter of the visits)
+  }
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------------
 // head stage: workgroup p serves the clips c = p (mod 8): last skip product, Mish, second Linear, [temperature], argmax / draw,
 // and the next step's embedded sample as the message for stage 0
 // ------------------------------------------------------------------------------------------------------------------------------------
-constexpr int kHeadPad = 68;      // a 64-float K slice + 4 floats: the slices' 16-byte reads of a quad / a lane pair fall on different banks
+// The head's two products like a layer stage's: a lane holds a few rows x ONE K slice and the rows' totals come out of a reduce-scatter over
+// the DPP row - 4 units x 16 inputs of y, then 8 logits x 8 hidden units.  (With a quarter / a half of a row's K per lane - the first
+// form - the 512 threads read 128 KB of LDS per product, which the LDS serves in ~1000 clocks: both products were bound by that.)
+constexpr int kYsSlice = 20;      // a 16-float K slice of y + 4 floats of padding: the 16 slices' 16-byte reads fall on different banks
+constexpr int kHidSlice = 12;     // an 8-float K slice of the hidden units + 4
 
 template <bool STAMPS>
 __device__ void head_role(const WnSpipeArgs& a, int p) {
-  __shared__ __attribute__((aligned(16))) float ys[4 * kHeadPad], hid[2 * kHeadPad], lg[kQ + 4];
+  __shared__ __attribute__((aligned(16))) float ys[16 * kYsSlice], hid[16 * kHidSlice], lg[kQ + 4];
   __shared__ int s_fail;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int o = tid >> 2, kq = tid & 3;
-  f32x2 w0[32], w2[32];
+  const int o = tid >> 2, kq = tid & 3;           // the hidden unit this lane ends up with (4 lanes each), and which of the four it is
+  const int rg = tid >> 4, ks = tid & 15;         // row group (4 hidden units / 8 logits) and K slice
+  f32x4s w0[16], w2[16];                          // w0[cc * 4 + i]: unit 4 rg + cc, inputs 16 ks + 4 i ..; w2[cc * 2 + i]: logit 8 rg + cc, units 8 ks + 4 i ..
   float wt[2] = {0.f, 0.f}, bt = 0.f;
-  {
-    const f32x2* src0 = reinterpret_cast<const f32x2*>(a.head_w0 + (int64_t)o * kC + 64 * kq);
-    const f32x2* src2 = reinterpret_cast<const f32x2*>(a.fc2_w + (int64_t)(tid >> 1) * kH1 + 64 * (tid & 1));
 #pragma unroll
-    for (int k = 0; k < 32; ++k) { w0[k] = src0[k]; w2[k] = src2[k]; }
-  }
+  for (int cc = 0; cc < 4; ++cc)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) w0[cc * 4 + i] = *reinterpret_cast<const f32x4s*>(a.head_w0 + (int64_t)(4 * rg + cc) * kC + 16 * ks + 4 * i);
+#pragma unroll
+  for (int cc = 0; cc < 8; ++cc)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) w2[cc * 2 + i] = *reinterpret_cast<const f32x4s*>(a.fc2_w + (int64_t)(8 * rg + cc) * kH1 + 8 * ks + 4 * i);
   const float b0 = a.head_b0[o];
-  const float b2 = a.fc2_b[tid >> 1];
+  const float b2 = a.fc2_b[8 * rg + (ks >> 1)];
   if (a.learn_temp) {
     wt[0] = a.fc2_w[(int64_t)kQ * kH1 + lane];
     wt[1] = a.fc2_w[(int64_t)kQ * kH1 + 64 + lane];
@@ -630,7 +659,7 @@ __device__ void head_role(const WnSpipeArgs& a, int p) {
   }
   // (in their registers before the step loop, as in the chain role)
 #pragma unroll
-  for (int k = 0; k < 32; ++k) { asm volatile("" : "+v"(w0[k])); asm volatile("" : "+v"(w2[k])); }
+  for (int k = 0; k < 16; ++k) { asm volatile("" : "+v"(w0[k])); asm volatile("" : "+v"(w2[k])); }
   asm volatile("" : "+v"(wt[0]), "+v"(wt[1]), "+v"(bt));
   if (tid == 0) s_fail = 0;
   const int L = a.L;
@@ -652,8 +681,8 @@ __device__ void head_role(const WnSpipeArgs& a, int p) {
     const int off = (lane >> 1) * 16 + (lane & 1) * 4;
     u64* dx = reinterpret_cast<u64*>(msg_out + ((int64_t)c * kSpSlots + (s1 & 3)) * kMsgFloats + off);
     u64* dp = reinterpret_cast<u64*>(msg_out + ((int64_t)c * kSpSlots + ((s1 + 2) & 3)) * kMsgFloats + off);
-    __hip_atomic_store(dx + 0, ((u64)__float_as_uint(e[1]) << 32) | __float_as_uint(e[0]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(dx + 1, ((u64)__float_as_uint(e[3]) << 32) | __float_as_uint(e[2]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(dx + 0, ((u64)msg_bits(e[1]) << 32) | msg_bits(e[0]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(dx + 1, ((u64)msg_bits(e[3]) << 32) | msg_bits(e[2]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_store(dx + 4, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_store(dx + 5, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const u64 pp = ((u64)kSpPoison << 32) | kSpPoison;
@@ -695,13 +724,19 @@ __device__ void head_role(const WnSpipeArgs& a, int p) {
         }
       }
       hstamp(0);
+      // the sum of the last XCD below (or beside) the head arrives about when y does: waves 1 - 7 look for it while wave 0 looks for y,
+      // wave 0's lanes take their word of it in the same looks as y - nothing of it is left to wait for behind the barrier
+      const unsigned* hlast = hsrc + (int64_t)g_last * hid_words;
+      if (wave != 0 && L >= 2) hacc += hid_word(hlast, last_mine);
       if (wave == 0) {             // y of the last layer: channels 4 lane .. + 3
         const unsigned* src = msg_in + ((int64_t)c * kSpSlots + slot) * kMsgFloats + (lane >> 1) * 16 + 8 + (lane & 1) * 4;
+        const bool want_h = L >= 2 && last_mine;
         u32x4s w4;
-        unsigned spins = 0;
+        unsigned wh1 = 0, spins = 0;
         for (;;) {
+          if (want_h) wh1 = msg_load(hlast);
           asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(w4) : "v"(src) : "memory");
-          const bool ok = w4[0] != kSpPoison && w4[1] != kSpPoison && w4[2] != kSpPoison && w4[3] != kSpPoison;
+          const bool ok = w4[0] != kSpPoison && w4[1] != kSpPoison && w4[2] != kSpPoison && w4[3] != kSpPoison && (!want_h || wh1 != kSpPoison);
           if (__all(ok)) break;
           if (++spins > kSpinLimit || ((spins & 1023u) == 0 && __hip_atomic_load(a.err_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
             atomicExch(a.err_flag, 1);
@@ -709,48 +744,58 @@ __device__ void head_role(const WnSpipeArgs& a, int p) {
             break;
           }
         }
-        *reinterpret_cast<f32x4s*>(ys + (lane >> 4) * kHeadPad + 4 * (lane & 15)) =
+        if (want_h) hacc += __uint_as_float(wh1);
+        *reinterpret_cast<f32x4s*>(ys + (lane >> 2) * kYsSlice + 4 * (lane & 3)) =
             f32x4s{__uint_as_float(w4[0]), __uint_as_float(w4[1]), __uint_as_float(w4[2]), __uint_as_float(w4[3])};
         if (STAMPS && a.stamps && c == 0 && s + 1 == (int)a.n_steps && lane == 0) a.stamps[64 + L] = __builtin_amdgcn_s_memrealtime();
       }
       __syncthreads();
       if (s_fail) return;
       hstamp(1);
-      // ---- hidden units: (fc0 W_skip of the last layer) y, 4 threads per unit, 64 inputs each --------------------------------------------
-      f32x2 h2[2] = {f32x2{0.f, 0.f}, f32x2{0.f, 0.f}};
+      // ---- hidden units: (fc0 W_skip of the last layer) y: 4 units x 16 inputs per lane, totals by the row's reduce-scatter ---------------
+      float hsum;
       {
-        const float* yk = ys + kq * kHeadPad;
+        f32x2 acc[4][2];
 #pragma unroll
-        for (int k = 0; k < 16; ++k) {
-          const f32x4s yv = *reinterpret_cast<const f32x4s*>(yk + 4 * k);
-          h2[0] = fma2(w0[2 * k], f32x2{yv[0], yv[1]}, h2[0]);
-          h2[1] = fma2(w0[2 * k + 1], f32x2{yv[2], yv[3]}, h2[1]);
+        for (int cc = 0; cc < 4; ++cc) acc[cc][0] = acc[cc][1] = f32x2{0.f, 0.f};
+        const float* yk = ys + ks * kYsSlice;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const f32x4s yv = *reinterpret_cast<const f32x4s*>(yk + 4 * i);
+#pragma unroll
+          for (int cc = 0; cc < 4; ++cc) {
+            acc[cc][0] = fma2(f32x2{w0[cc * 4 + i][0], w0[cc * 4 + i][1]}, f32x2{yv[0], yv[1]}, acc[cc][0]);
+            acc[cc][1] = fma2(f32x2{w0[cc * 4 + i][2], w0[cc * 4 + i][3]}, f32x2{yv[2], yv[3]}, acc[cc][1]);
+          }
         }
+        float zc[4];
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) zc[cc] = (acc[cc][0][0] + acc[cc][0][1]) + (acc[cc][1][0] + acc[cc][1][1]);
+        hsum = row_reduce_scatter4(zc[0], zc[1], zc[2], zc[3], ks) + dpp_quad_sum(hacc);      // (unit 4 rg + ks / 4 = o, in its four lanes)
       }
-      // the sum of the last XCD below (or beside) the head arrives a little after y: looked at behind the products
-      if (L >= 2) hacc += hid_word(hsrc + (int64_t)g_last * hid_words, last_mine);
-      const float hsum = dpp_quad_sum(((h2[0][0] + h2[0][1]) + (h2[1][0] + h2[1][1])) + hacc);
-      if (kq == 0) hid[(o >> 6) * kHeadPad + (o & 63)] = mish_fast(hsum + b0);
+      if (kq == 0) hid[(o >> 3) * kHidSlice + (o & 7)] = mish_fast(hsum + b0);
       __syncthreads();
       hstamp(2);
-      // ---- logits: 2 threads per class, 64 hidden units each -------------------------------------------------------------------------------
-      f32x2 q2[2] = {f32x2{0.f, 0.f}, f32x2{0.f, 0.f}};
+      // ---- logits: 8 classes x 8 hidden units per lane ---------------------------------------------------------------------------------------
       {
-        const float* hk = hid + (tid & 1) * kHeadPad;
+        const float* hk = hid + ks * kHidSlice;
+        const f32x4s hv0 = *reinterpret_cast<const f32x4s*>(hk), hv1 = *reinterpret_cast<const f32x4s*>(hk + 4);
+        float qs[8];
 #pragma unroll
-        for (int k = 0; k < 16; ++k) {
-          const f32x4s hv = *reinterpret_cast<const f32x4s*>(hk + 4 * k);
-          q2[0] = fma2(w2[2 * k], f32x2{hv[0], hv[1]}, q2[0]);
-          q2[1] = fma2(w2[2 * k + 1], f32x2{hv[2], hv[3]}, q2[1]);
+        for (int cc = 0; cc < 8; ++cc) {
+          f32x2 q = fma2(f32x2{w2[cc * 2][0], w2[cc * 2][1]}, f32x2{hv0[0], hv0[1]}, f32x2{0.f, 0.f});
+          q = fma2(f32x2{w2[cc * 2][2], w2[cc * 2][3]}, f32x2{hv0[2], hv0[3]}, q);
+          q = fma2(f32x2{w2[cc * 2 + 1][0], w2[cc * 2 + 1][1]}, f32x2{hv1[0], hv1[1]}, q);
+          q = fma2(f32x2{w2[cc * 2 + 1][2], w2[cc * 2 + 1][3]}, f32x2{hv1[2], hv1[3]}, q);
+          qs[cc] = q[0] + q[1];
         }
+        const float qv = row_reduce_scatter8(qs, ks);                 // (class 8 rg + ks / 2, in two lanes)
+        if ((ks & 1) == 0) lg[8 * rg + (ks >> 1)] = qv + b2;
       }
-      float qv = (q2[0][0] + q2[0][1]) + (q2[1][0] + q2[1][1]);
-      qv += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(qv), 0xB1, 0xf, 0xf, false));
-      if ((tid & 1) == 0) lg[tid >> 1] = qv + b2;
       if (wave == 0 && a.learn_temp) {
-        float tv = fmaf(wt[0], hid[lane], wt[1] * hid[kHeadPad + lane]);
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) tv += __shfl_xor(tv, off);
+        float tv = fmaf(wt[0], hid[(lane >> 3) * kHidSlice + (lane & 7)], wt[1] * hid[(8 + (lane >> 3)) * kHidSlice + (lane & 7)]);
+        tv = dpp_mirror_add(dpp_half_mirror_add(dpp_quad_sum(tv)));        // every lane: its row's sum (DPP; six ds_bpermute round trips before)
+        tv = (readlane_f(tv, 0) + readlane_f(tv, 16)) + (readlane_f(tv, 32) + readlane_f(tv, 48));
         if (lane == 0) lg[kQ] = tv + bt;
       }
       __syncthreads();
@@ -764,31 +809,38 @@ __device__ void head_role(const WnSpipeArgs& a, int p) {
           // order, so the maximum of the raw logits is the answer - unless the division rounds an EARLIER, slightly smaller logit onto
           // the maximum's quotient (first-maximum rule).  Only then (some other logit within 4 ulp of the maximum) divide and compare.
           const f32x4s v4 = *reinterpret_cast<const f32x4s*>(lg + lane * 4);
-          float best = v4[0];
-          int bi = lane * 4;
+          const float m = wave_max_dpp(fmaxf(fmaxf(v4[0], v4[1]), fmaxf(v4[2], v4[3])));
+          int cand = 0x7fffffff;
 #pragma unroll
-          for (int k = 1; k < 4; ++k)
-            if (v4[k] > best) { best = v4[k]; bi = lane * 4 + k; }
-          result = wave_argmax_first(best, bi);
-          if (a.learn_temp) {
-            const float m = wave_max_dpp(best);
-            const float lim = m - fmaxf(fabsf(m) * 4.8e-7f, 1e-37f);
-            bool near = false;
+          for (int k = 3; k >= 0; --k)
+            if (v4[k] == m) cand = lane * 4 + k;                  // (the first maximum wins, targets.py / torch.argmax)
+          result = wave_min_dpp(cand);
+          bool odd = false, near = false;                         // NaN logits (argmax takes the first), or a logit within 4 ulp of the maximum
+          const float lim = m - fmaxf(fabsf(m) * 4.8e-7f, 1e-37f);
 #pragma unroll
-            for (int k = 0; k < 4; ++k) near = near || (v4[k] != m && v4[k] >= lim);
-            if (__any(near)) {
-              const float denom = fmaxf(sigmoidf_(lg[kQ]), a.min_temp);
-              float vv[4];
-#pragma unroll
-              for (int k = 0; k < 4; ++k) vv[k] = v4[k] / denom;
-              best = vv[0];
-              bi = lane * 4;
-#pragma unroll
-              for (int k = 1; k < 4; ++k)
-                if (vv[k] > best) { best = vv[k]; bi = lane * 4 + k; }
-              result = wave_argmax_first(best, bi);
-            }
+          for (int k = 0; k < 4; ++k) {
+            odd = odd || v4[k] != v4[k];
+            near = near || (v4[k] != m && v4[k] >= lim);
           }
+          if (__any(odd)) {
+            cand = 0x7fffffff;
+#pragma unroll
+            for (int k = 3; k >= 0; --k)
+              if (v4[k] != v4[k]) cand = lane * 4 + k;
+            result = wave_min_dpp(cand);
+          } else if (a.learn_temp && __any(near)) {
+            const float denom = fmaxf(sigmoidf_(lg[kQ]), a.min_temp);
+            float vv[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) vv[k] = v4[k] / denom;
+            float best = vv[0];
+            int bi = lane * 4;
+#pragma unroll
+            for (int k = 1; k < 4; ++k)
+              if (vv[k] > best) { best = vv[k]; bi = lane * 4 + k; }
+            result = wave_argmax_first(best, bi);
+          }
+          result = result > kQ - 1 ? kQ - 1 : result;
         } else {
           float denom = 1.f;
           if (a.learn_temp) denom = fmaxf(sigmoidf_(lg[kQ]), a.min_temp);       // mlp.py:60-62
@@ -827,7 +879,7 @@ __global__ __launch_bounds__(kThreads) void wavenet_spipe_kernel(const WnSpipeAr
     else role = (int)(id * 32 + ticket);
     s_role = role;
   }
-  if (tid < 16) (&S.arrived[0])[tid] = 0;       // arrived, hdone, xd_arrived, ready are adjacent
+  if (tid < 16) (&S.arrived[0])[tid] = 0;       // arrived, hdone, rows_ready, ready are adjacent
   __syncthreads();
   const int role = s_role;
   if (role < 0) return;
@@ -876,9 +928,14 @@ __global__ __launch_bounds__(256) void spipe_image_kernel(const WnSpRaw* __restr
           if (ks < 8) out[e] = r.wd[((int64_t)n * kC + k) * 2 + 1];                                                        // W1[n][k]
           else if (s >= 1 && raw[s - 1].wr) out[e] = (float)dot_cols(r.wd + (int64_t)n * kC * 2 + 1, 2, raw[s - 1].wr + k, kC, kC);   // (W1 R)[n][k]
         }
-      } else if (s >= 1 && raw[s - 1].wr) {      // register 32 + cc * 4 + i: residual channel 2 (lane / 16) + cc of the wave, inputs 16 ks + 4 i .. of y
-        const int ks = lane & 15, cc = (qi - 32) >> 2, i = (qi - 32) & 3;
-        for (int e = 0; e < 4; ++e) out[e] = raw[s - 1].wr[(int64_t)(8 * W + 2 * (lane >> 4) + cc) * kC + 16 * ks + 4 * i + e];
+      } else if (qi < 40) {
+        if (s >= 1 && raw[s - 1].wr) {      // register 32 + cc * 4 + i: residual channel 2 (lane / 16) + cc of the wave, inputs 16 ks + 4 i .. of y
+          const int ks = lane & 15, cc = (qi - 32) >> 2, i = (qi - 32) & 3;
+          for (int e = 0; e < 4; ++e) out[e] = raw[s - 1].wr[(int64_t)(8 * W + 2 * (lane >> 4) + cc) * kC + 16 * ks + 4 * i + e];
+        }
+      } else if (s >= 1) {                  // register 40 + i: hidden unit 4 W + lane / 16 of the head's first Linear, inputs 16 ks + 4 i .. of y
+        const int j4 = lane >> 4, ks16 = lane & 15, i = qi - 40, hrow = 4 * W + j4;
+        for (int e = 0; e < 4; ++e) out[e] = (float)dot_cols(f0 + (int64_t)hrow * kC, 1, raw[s - 1].ws + 16 * ks16 + 4 * i + e, kC, kC);   // (fc0 W_skip)[h][k]
       }
       reinterpret_cast<f32x4s*>(img_chain)[id] = f32x4s{out[0], out[1], out[2], out[3]};
     } else if (id < n_chain + n_helper) {
@@ -889,15 +946,12 @@ __global__ __launch_bounds__(256) void spipe_image_kernel(const WnSpRaw* __restr
       if (qi < 16) {      // register cc * 4 + i: gate row 4 (lane / 16) + cc, delayed inputs 16 ks + 4 i ..
         const int ks = lane & 15, cc = qi >> 2, i = qi & 3, n = gate_raw_row(W, 4 * (lane >> 4) + cc);
         for (int e = 0; e < 4; ++e) out[e] = r.wd[((int64_t)n * kC + 16 * ks + 4 * i + e) * 2 + 0];                        // W0[n][k]
-      } else if (qi < 32) {      // register 16 + cc * 4 + i: the same rows of the conditioning 1x1 convolution, inputs 16 ks + 4 i .. (zeros above C1)
+      } else {      // register 16 + cc * 4 + i: the same rows of the conditioning 1x1 convolution, inputs 16 ks + 4 i .. (zeros above C1)
         const int ks = lane & 15, cc = (qi - 16) >> 2, i = (qi - 16) & 3, n = gate_raw_row(W, 4 * (lane >> 4) + cc);
         for (int e = 0; e < 4; ++e) {
           const int k = 16 * ks + 4 * i + e;
           out[e] = (r.w1 && k < C1) ? r.w1[(int64_t)n * C1 + k] : 0.f;
         }
-      } else if (s >= 1) {
-        const int j4 = lane >> 4, ks16 = lane & 15, i = qi - 32, hrow = 4 * W + j4;
-        for (int e = 0; e < 4; ++e) out[e] = (float)dot_cols(f0 + (int64_t)hrow * kC, 1, raw[s - 1].ws + 16 * ks16 + 4 * i + e, kC, kC);   // (fc0 W_skip)[h][k]
       }
       reinterpret_cast<f32x4s*>(img_helper)[t] = f32x4s{out[0], out[1], out[2], out[3]};
     } else if (id < n_chain + n_helper + n_cst) {

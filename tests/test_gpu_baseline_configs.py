@@ -207,6 +207,31 @@ def test_cfg4_wavenet_more_clips_than_one_ring(device):
     _cfg4_greedy_against_oracle(device, B=136, n=1030, n_last=1, n_mid=10, seed=4136, expect_set=True)
 
 
+def test_cfg4_nan_with_the_poison_payload_is_a_value_not_a_missing_word(device):
+    """the stage pipeline's messages mark "not arrived" with 0xFFFFFFFF - which is also a NaN.  A weight that carries exactly that
+    NaN (here: one embedding entry of a class the prompt contains) must flow through the ring as the value it is: no hand-off
+    waits for it, no timeout, no redo on the launch path (a warning).  What comes out is NaN-driven garbage, as in the reference."""
+    import warnings
+    net, sd, arch = cfg4_network()
+    poison = torch.tensor([-1], dtype=torch.int32).view(torch.float32)
+    with torch.no_grad():
+        net.input_modules[0][0].weight[5, 7] = poison[0]
+    net = net.to(device)
+    assert net.input_modules[0][0].weight.view(torch.int32)[5, 7].item() == -1
+    B, P, n = 8, 3072, 40
+    prompt = torch.full((B, P), 5, dtype=torch.int64)
+    cond_d = torch.rand(B, P + n, 513, generator=torch.Generator().manual_seed(3)).to(device)
+    idx = torch.cat([prompt, torch.zeros(B, n, dtype=torch.int64)], 1).to(device)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        net.before_generate((idx[:, :P], cond_d[:, :P]), None)
+        net.generate_block((idx, cond_d), P, n)
+        net.after_generate((idx,), None)
+    assert net._plan is not None and net._plan.stage_pipelined
+    out = idx[:, P:].cpu()
+    assert int(out.min()) >= 0 and int(out.max()) < 256
+
+
 def test_cfg4_composed_products_against_the_reference_association(device, monkeypatch):
     """The stage pipeline multiplies pre-composed matrices (tap 1 . W_res of the layer below, fc0 . W_skip: fp64 products rounded
     once); the per-layer launch path keeps the reference's association.  Same window, same step, both against the oracle: the
