@@ -56,10 +56,10 @@ constexpr unsigned kSpinLimit = 1u << 22;
 #endif
 constexpr int kPollGap = MMK_SP_POLL_GAP;     // s_sleep units (64 cycles) between two looks at a message that has not arrived
 #ifndef MMK_SP_LDS_SLEEP
-#define MMK_SP_LDS_SLEEP 5
+#define MMK_SP_LDS_SLEEP 1      // (round 4, helpers look and stage: helpers 1 / chain waves 2 -> 50.85 us per cfg-4 step, 5 / 5 -> 51.45, 1 / 10 -> 51.4, 0 / 5 -> 51.0)
 #endif
 #ifndef MMK_SP_CHAIN_SLEEP
-#define MMK_SP_CHAIN_SLEEP MMK_SP_LDS_SLEEP     // the same inside the chain waves' wait for their message (the helpers' waits keep MMK_SP_LDS_SLEEP)
+#define MMK_SP_CHAIN_SLEEP 2    // the same inside the chain waves' wait for their message (the helpers' waits keep MMK_SP_LDS_SLEEP)
 #endif
 constexpr int kChainSleep = MMK_SP_CHAIN_SLEEP;
 constexpr int kLdsSleep = MMK_SP_LDS_SLEEP;   // s_sleep units inside the spins on LDS counters: with the chain waves' wait as three FLAT loads 0 / 1 / 3 / 6 / 10 -> 55.7 / 55.6 / 55.3 / 55.9 / 56.5 us per step; as ds_reads (55.3 -> 54.4) 0 / 1 / 2 / 3 / 5 / 7 / 10 / 15 -> 54.3 / 54.9 / 54.6 / 54.3 / 53.9 / 54.1 / 54.2 / 54.7
@@ -68,6 +68,25 @@ constexpr int kLdsSleep = MMK_SP_LDS_SLEEP;   // s_sleep units inside the spins 
                                 // per step against 50.9 (layer 10, a dilation-1 stage, is then the LAST of its XCD; with 0 layers 0 and 20 are the first of theirs)
 #endif
 constexpr int kSlotShift = MMK_SP_SLOT_SHIFT;
+#ifndef MMK_SP_LAG
+#define MMK_SP_LAG 1           // the biases run four iterations behind the messages ...
+#endif
+#ifndef MMK_SP_LAG_CLIPS
+#define MMK_SP_LAG_CLIPS 40    // ... from this many clips on (>= 8).  Measured on one box, cfg 4, us per step: 32 clips 53.2 with the lag, 52.0 without; 64 clips
+                               // (with the early looks) 92.1 with it, 97.3 without: the lag pays where the clips queue up, and costs where one clip's latency binds
+#endif
+#ifndef MMK_SP_BACKUP
+#define MMK_SP_BACKUP 0        // the helper halfway between two look duties looks for the current message too, half a round trip behind
+#endif
+#ifndef MMK_SP_G_LOCAL
+#define MMK_SP_G_LOCAL 6       // s_sleep units (64 clocks) by which the second pair of eyes trails: message from this XCD ...
+#endif
+#ifndef MMK_SP_G_REMOTE
+#define MMK_SP_G_REMOTE 16     // ... and from another one
+#endif
+#ifndef MMK_SP_EARLY
+#define MMK_SP_EARLY 1         // a helper looks for its next message already while it waits for the one before (staged by another helper): cfg 4, 64 clips 99.2 -> 92.1 us per step
+#endif
 #ifndef MMK_SP_WAKEUP
 #define MMK_SP_WAKEUP 1        // the looking helper wakes the chain waves out of their s_sleep when it has staged a message
 #endif
@@ -444,8 +463,16 @@ __device__ void helper_role(const WnSpipeArgs& a, Lds& S, int stage, int p, int 
   // A helper has one request in flight: asked for three iterations before its visit's bias is due where the row is old enough for that
   // (d >= 3: the arrival that has been seen then covers it, and a row 512 steps old comes from HBM), one iteration before otherwise.
   const int ahead = (d - 2) * a.B >= 2 ? 2 : 0;      // (visit it + B + 2's row was written by visit it + B + 2 - d B; proven complete: up to it - B)
-  // who asks for (and stages) the rows of visit v: the helper that looks in iteration v - B - ahead, right after its look duty
-  auto rows_mine = [&](int v) { return (((unsigned)(v - B - ahead)) & 3u) == (unsigned)h; };
+  // With eight clips or more the biases run FOUR iterations behind: the helper that has looked in iteration `it` asks for the rows of visit
+  // it + B - 1 and makes that bias in its next duty iteration, it + 4 (still B - 5 visits before the chain wave needs it).  Then nothing
+  // in a helper's loop waits for memory in the steady state - neither for a conditioning row from HBM nor, in a dilation-1 stage, for the
+  // stage's own output of the visit before (which the chain waves may still be working on when the next message is already staged:
+  // with the bias of visit it + B made in iteration it + 1, the helpers - and with them the staging of the next messages - went at the
+  // pace of chain visit + look round trip + bias products: 1.7 us per visit in front of stages 10 and 20, the ring's beat).
+  const int lag = (MMK_SP_LAG && B >= MMK_SP_LAG_CLIPS) ? 4 : 0;
+  // who asks for (and stages) the rows of visit v: the helper that looks in iteration v - B + 1 (lag 4) or v - B - ahead (no lag), right after
+  // its look duty
+  auto rows_mine = [&](int v) { return (((unsigned)(lag ? v - B + 1 : v - B - ahead)) & 3u) == (unsigned)h; };
   // ---- looking for messages -----------------------------------------------------------------------------------------------------------------
   const __amdgpu_buffer_rsrc_t inbox = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned*>(a.msg + (int64_t)stage * stage_words), 0, -1, 0x00020000);
   const int look_off = 32 * lane;                                       // bytes inside one message
@@ -543,10 +570,11 @@ __device__ void helper_role(const WnSpipeArgs& a, Lds& S, int stage, int p, int 
     if (!bias_of((unsigned)c0, 0, c0)) return;
   }
   int s = 0, c = 0;                               // visit it = (c, s)
-  int sp = 0, cp = 0;                             // visit it - 1 + B = (cp, sp): the bias that is due in iteration it
-  int sa = (B + ahead) / B, ca = (B + ahead) % B; // visit it + B + ahead = (ca, sa): the rows asked for in iteration it
+  int sp = 0, cp = B - 1 - lag;                   // visit it - 1 - lag + B = (cp, sp): the bias that is due in iteration it
+  const int roff = lag ? B - 1 : B + ahead;
+  int sa = roff / B, ca = roff % B;               // visit it + roff = (ca, sa): the rows asked for in iteration it
   int sl = 4 / B, cl = 4 % B;                     // visit it + 4 = (cl, sl): the message whose first look goes out in iteration it
-  if (ahead > 0)                                  // (what iterations -2 and -1 would have asked for: positions the warm-up wrote)
+  if (lag == 0 && ahead > 0)                      // (what iterations -2 and -1 would have asked for: positions the warm-up wrote)
     for (int k = 0; k < ahead; ++k) {
       const int vr = B + k;
       if (vr < n_visits && rows_mine(vr)) request_rows(vr / B, vr % B, false, xr, cr);
@@ -555,42 +583,98 @@ __device__ void helper_role(const WnSpipeArgs& a, Lds& S, int stage, int p, int 
   // (clip, step mod 4) was poisoned when step - 2 of that clip was published, which lies behind the visit that is being staged.  With
   // fewer clips, four visits ahead is up to four STEPS ahead - a slot that still holds the message of four steps ago.
   const bool lookahead = B >= 4;
+  bool staged_next = false;                       // my next message is staged already (in the iteration before the duty)
+  // this stage's message comes from another XCD (or, stage 0, from the head): a look is a ~0.8-us round trip there, ~0.3 inside an XCD
+  const bool remote_in = stage == 0 ? ((a.L + slot_shift(a)) >> 2) != (slot_shift(a) >> 2) : ((stage - 1 + slot_shift(a)) >> 2) != ((stage + slot_shift(a)) >> 2);
   if (lookahead && h < n_visits) look(((((h % B) * kSpSlots + ((h / B) & 3)) * kMsgFloats) * 4) + look_off, pre_lo, pre_hi);   // the first look at "my" first message
   else pre_lo[0] = kSpPoison;
   for (int it = 0; it < n_visits; ++it) {
     if (STAMPS) hs_t0 = __builtin_amdgcn_s_memtime();
     const bool duty = (it & 3) == h;
     // ---- 1. the visit's message ------------------------------------------------------------------------------------------------------------
+    // a landed message (in the look registers) into the LDS image of visit vv = (cc, ss); the chain waves are told
+    auto stage_message = [&](int vv, int cc, int ss, const u32x4s& m_lo, const u32x4s& m_hi) {
+      float* dst = &S.xy[vv & (kXyRing - 1)][st_off];
+      *reinterpret_cast<f32x4s*>(dst) = f32x4s{__uint_as_float(m_lo[0]), __uint_as_float(m_lo[1]), __uint_as_float(m_lo[2]), __uint_as_float(m_lo[3])};
+      *reinterpret_cast<f32x4s*>(dst + 4) = f32x4s{__uint_as_float(m_hi[0]), __uint_as_float(m_hi[1]), __uint_as_float(m_hi[2]), __uint_as_float(m_hi[3])};
+      if (STAMPS && a.stamps && cc == 0 && ss + 1 == (int)a.n_steps && p == 0 && lane == 0) a.stamps[64 + stage] = __builtin_amdgcn_s_memrealtime();
+      if (STAMPS && a.stamps && ss == (int)a.n_steps / 2 && p == 0 && lane == 0 && cc < 32) a.stamps[256 + 1024 + stage * 32 + cc] = __builtin_amdgcn_s_memrealtime();   // seen, every clip, the launch's middle step
+      lds_signal(&S.arrived[vv & 3], (unsigned)vv + 1, lane);
+#if MMK_SP_WAKEUP
+      asm volatile("s_wakeup");            // the other waves of the workgroup out of their s_sleep: they look at the counter again at once
+#endif
+    };
     if (duty) {
-      // (the LDS image of visit it - 8 is overwritten: every chain wave has to be through with it)
-      if (it >= kXyRing - 2 && !lds_wait4(S.hdone, (unsigned)it - (kXyRing - 2) + 1, a.err_flag)) return;
-      const int off = ((c * kSpSlots + (s & 3)) * kMsgFloats) * 4 + look_off;
+      if (!staged_next) {
+        // (the LDS image of visit it - 8 is overwritten: every chain wave has to be through with it)
+        if (it >= kXyRing - 2 && !lds_wait4(S.hdone, (unsigned)it - (kXyRing - 2) + 1, a.err_flag)) return;
+        const int off = ((c * kSpSlots + (s & 3)) * kMsgFloats) * 4 + look_off;
+        unsigned spins = 0;
+        while (!landed(pre_lo, pre_hi)) {
+          if (++spins > kSpinLimit || ((spins & 1023u) == 0 && __hip_atomic_load(a.err_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+            atomicExch(a.err_flag, 1);
+            return;
+          }
+          if (kPollGap > 0 && spins > 1) __builtin_amdgcn_s_sleep(kPollGap);
+          look(off, pre_lo, pre_hi);
+        }
+        if (STAMPS) n_polls += spins;
+        stage_message(it, c, s, pre_lo, pre_hi);
+      }
+      staged_next = false;
+      if (lookahead && it + 4 < n_visits) look(((cl * kSpSlots + (sl & 3)) * kMsgFloats) * 4 + look_off, pre_lo, pre_hi);
+      else pre_lo[0] = kSpPoison;
+    } else if (MMK_SP_EARLY && ((it + 1) & 3) == h && it + 1 < n_visits) {
+      // the iteration before my look duty: while message `it` is not staged (by its helper), I look for MINE already - when the clips
+      // queue up it is there, and a look at another XCD's memory is a ~0.8-us round trip that would otherwise start only now
+      const int cn = c + 1 == B ? 0 : c + 1, sn = c + 1 == B ? s + 1 : s;
+      const int off = ((cn * kSpSlots + (sn & 3)) * kMsgFloats) * 4 + look_off;
       unsigned spins = 0;
-      while (!landed(pre_lo, pre_hi)) {
+      while (__hip_atomic_load(&S.arrived[it & 3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < (unsigned)it + 1) {
+        if (!staged_next) {
+          if (landed(pre_lo, pre_hi)) {
+            if (it + 1 < kXyRing - 2 || lds_min4(S.hdone) + (kXyRing - 2) >= (unsigned)it + 2) {
+              stage_message(it + 1, cn, sn, pre_lo, pre_hi);
+              staged_next = true;
+            } else if (kLdsSleep > 0) __builtin_amdgcn_s_sleep(kLdsSleep);
+          } else {
+            look(off, pre_lo, pre_hi);
+          }
+        } else if (kLdsSleep > 0) __builtin_amdgcn_s_sleep(kLdsSleep);
         if (++spins > kSpinLimit || ((spins & 1023u) == 0 && __hip_atomic_load(a.err_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
           atomicExch(a.err_flag, 1);
           return;
         }
-        if (kPollGap > 0 && spins > 1) __builtin_amdgcn_s_sleep(kPollGap);
-        look(off, pre_lo, pre_hi);
       }
-      if (STAMPS) n_polls += spins;
-      float* dst = &S.xy[it & (kXyRing - 1)][st_off];
-      *reinterpret_cast<f32x4s*>(dst) = f32x4s{__uint_as_float(pre_lo[0]), __uint_as_float(pre_lo[1]), __uint_as_float(pre_lo[2]), __uint_as_float(pre_lo[3])};
-      *reinterpret_cast<f32x4s*>(dst + 4) = f32x4s{__uint_as_float(pre_hi[0]), __uint_as_float(pre_hi[1]), __uint_as_float(pre_hi[2]), __uint_as_float(pre_hi[3])};
-      if (STAMPS && a.stamps && c == 0 && s + 1 == (int)a.n_steps && p == 0 && lane == 0) a.stamps[64 + stage] = __builtin_amdgcn_s_memrealtime();
-      if (STAMPS && a.stamps && s == (int)a.n_steps / 2 && p == 0 && lane == 0 && c < 32) a.stamps[256 + 1024 + stage * 32 + c] = __builtin_amdgcn_s_memrealtime();   // seen, every clip, the launch's middle step
-      lds_signal(&S.arrived[it & 3], (unsigned)it + 1, lane);
-#if MMK_SP_WAKEUP
-      asm volatile("s_wakeup");            // the other waves of the workgroup out of their s_sleep: they look at the counter again at once
-#endif
-      if (lookahead && it + 4 < n_visits) look(((cl * kSpSlots + (sl & 3)) * kMsgFloats) * 4 + look_off, pre_lo, pre_hi);
-      else pre_lo[0] = kSpPoison;
+      __atomic_signal_fence(__ATOMIC_SEQ_CST);
+    } else if (MMK_SP_BACKUP && ((it + 2) & 3) == h && it >= 2) {
+      // Halfway between two look duties: a SECOND pair of eyes on message `it`, half a look's round trip behind the helper on duty, in
+      // registers of its own (the first look at this helper's next message is in flight in the others).  A CU then looks twice per round
+      // trip, and what a stage waits for is the slowest of its eight CUs: the mean of that maximum shrinks with the looks' period.
+      // Whoever sees the message first stages it; the other one finds S.arrived set, or stages the same bytes once more.
+      if (it >= kXyRing - 2 && !lds_wait4(S.hdone, (unsigned)it - (kXyRing - 2) + 1, a.err_flag)) return;
+      const int off = ((c * kSpSlots + (s & 3)) * kMsgFloats) * 4 + look_off;
+      u32x4s bk_lo, bk_hi;
+      unsigned spins = 0;
+      if (remote_in) __builtin_amdgcn_s_sleep(MMK_SP_G_REMOTE); else __builtin_amdgcn_s_sleep(MMK_SP_G_LOCAL);
+      while (__hip_atomic_load(&S.arrived[it & 3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < (unsigned)it + 1) {
+        look(off, bk_lo, bk_hi);
+        if (landed(bk_lo, bk_hi)) {
+          stage_message(it, c, s, bk_lo, bk_hi);
+          break;
+        }
+        if (++spins > kSpinLimit || ((spins & 1023u) == 0 && __hip_atomic_load(a.err_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+          atomicExch(a.err_flag, 1);
+          return;
+        }
+        if (kPollGap > 0) __builtin_amdgcn_s_sleep(kPollGap);
+      }
+      __atomic_signal_fence(__ATOMIC_SEQ_CST);
     } else if (!lds_wait1(&S.arrived[it & 3], (unsigned)it + 1, a.err_flag)) return;
     hstamp(1);
-    // ---- 2. the bias of visit it - 1 + B (its rows were asked for one or three iterations ago) ---------------------------------------------------
-    if (it >= 1 && it - 1 + B < n_visits) {
-      const unsigned v3 = (unsigned)(it - 1 + B);
+    // ---- 2. the bias of visit it - 1 - lag + B (its rows were asked for one, three or four iterations ago) -------------------------------------
+    if (it >= 1 + lag && it - 1 - lag + B < n_visits) {
+      const unsigned v3 = (unsigned)(it - 1 - lag + B);
       if (rows_mine((int)v3)) {
         if (d == 1) {
           unsigned spins = 0;
@@ -608,10 +692,10 @@ __device__ void helper_role(const WnSpipeArgs& a, Lds& S, int stage, int p, int 
       if (!bias_of(v3, sp, cp)) return;
       hstamp(5);
     }
-    // ---- 3. the rows of the bias of visit it + B + ahead (the helper that looked: its next look duty is four visits away) ------------------------
-    cp = c; sp = s + 1;
-    if (duty && it + B + ahead < n_visits) request_rows(sa, ca, d == 1, xr, cr);
+    // ---- 3. the rows of the bias of visit it + roff (the helper that looked: its next look duty is four visits away) ------------------------------
+    if (duty && sa >= 1 && it + roff < n_visits) request_rows(sa, ca, d == 1, xr, cr);
     if (++ca == B) { ca = 0; ++sa; }
+    if (++cp == B) { cp = 0; ++sp; }
     if (++cl == B) { cl = 0; ++sl; }
     hstamp(0);
     if (++c == B) { c = 0; ++s; }

@@ -1296,7 +1296,8 @@ SPIPE_ENV = ("MMK_WN_XCD_LOCAL", "MMK_WN_PERSISTENT", "MMK_WN_GROUPS", "MMK_WN_S
 
 
 @pytest.mark.parametrize("blocks,B,cond,n", [((3,), 1, False, 40), ((4, 2), 5, True, 60), ((1,), 3, True, 24), ((2, 1, 1), 32, True, 30),
-                                             ((10, 10, 10, 1), 3, False, 6), ((5, 3), 17, True, 1100)])
+                                             ((10, 10, 10, 1), 3, False, 6), ((5, 3), 17, True, 1100), ((3, 1), 8, True, 40), ((2,), 2, False, 30),
+                                             ((4, 4, 3), 9, False, 50), ((1, 1), 4, True, 33), ((6,), 70, True, 12)])
 def test_wavenet_stage_pipeline_agrees_with_oracle(device, monkeypatch, blocks, B, cond, n):
     """the stage pipeline (wavenet_spipe.hip: one layer per stage of 8 CUs, clips streamed through one at a time) against the oracle,
     teacher-forced on the device's own history: 1 - 31 layers (1 - 8 XCDs in use, layers with d = 1 first, in the middle and last),
