@@ -71,9 +71,15 @@ constexpr int kSlotShift = MMK_SP_SLOT_SHIFT;
 #ifndef MMK_SP_LAG
 #define MMK_SP_LAG 1           // the biases run four iterations behind the messages ...
 #endif
+#ifndef MMK_SP_LAG_DIL
+#define MMK_SP_LAG_DIL 0       // ... and, from eight clips on, in the stages with a dilation up to this
+#endif
 #ifndef MMK_SP_LAG_CLIPS
 #define MMK_SP_LAG_CLIPS 40    // ... from this many clips on (>= 8).  Measured on one box, cfg 4, us per step: 32 clips 53.2 with the lag, 52.0 without; 64 clips
                                // (with the early looks) 92.1 with it, 97.3 without: the lag pays where the clips queue up, and costs where one clip's latency binds
+#endif
+#ifndef MMK_SP_ROWS8
+#define MMK_SP_ROWS8 0         // chain products as 8 gate rows x a K slice of 16 per lane (half the LDS reads, one v_permlane16_swap level more)
 #endif
 #ifndef MMK_SP_BACKUP
 #define MMK_SP_BACKUP 0        // the helper halfway between two look duties looks for the current message too, half a round trip behind
@@ -84,8 +90,15 @@ constexpr int kSlotShift = MMK_SP_SLOT_SHIFT;
 #ifndef MMK_SP_G_REMOTE
 #define MMK_SP_G_REMOTE 16     // ... and from another one
 #endif
+#ifndef MMK_SP_DUTYFIRST
+#define MMK_SP_DUTYFIRST 1     // the helper whose look duty is next looks for that message before it makes the current iteration's bias: cfg 4, 32 clips 52.4 -> 44.9 us per step
+#endif
+#ifndef MMK_SP_EARLY_DEPTH
+#define MMK_SP_EARLY_DEPTH 3   // ... up to this many visits ahead of the message that is being waited for
+#endif
 #ifndef MMK_SP_EARLY
-#define MMK_SP_EARLY 1         // a helper looks for its next message already while it waits for the one before (staged by another helper): cfg 4, 64 clips 99.2 -> 92.1 us per step
+#define MMK_SP_EARLY 0         // a helper looks for its next message already while it waits for the one before (staged by another helper): cfg 4, 64 clips 99.2 -> 92.1 us
+                               // per step before the next-duty helper looked first; with that, 32 clips 44.9 without the early looks, 46.4 - 47.4 with them
 #endif
 #ifndef MMK_SP_WAKEUP
 #define MMK_SP_WAKEUP 1        // the looking helper wakes the chain waves out of their s_sleep when it has staged a message
@@ -288,7 +301,11 @@ __device__ void chain_role(const WnSpipeArgs& a, Lds& S, int stage, int p, int q
   const bool local_next = ((stage + 1 + slot_shift(a)) >> 2) == ((stage + slot_shift(a)) >> 2);
   const int64_t stage_words = (int64_t)a.Bmax * kSpSlots * kMsgFloats;
   unsigned* msg_out = a.msg + (int64_t)(stage + 1) * stage_words;
+#if MMK_SP_ROWS8
+  const int kso = ((lane & 16) ? kHalf : 0) + pad_of(16 * ks);        // K slice lane & 31 of 16: x[16 ks ..] in the even rows of 16 lanes, y[16 ks ..] in the odd ones
+#else
   const int kso = (ks < 8 ? 0 : kHalf) + (ks & 7) * kPadBlk;           // K slice ks: x[32 ks ..] for ks < 8, y[32 (ks - 8) ..] above
+#endif
   const int xr_off = kHalf + pad_of(16 * ks);                          // y[16 ks ..]
   const int xin_off = pad_of(8 * W + j8);
   const bool pub_lane = (lane & 7) < 2;
@@ -316,8 +333,25 @@ __device__ void chain_role(const WnSpipeArgs& a, Lds& S, int stage, int p, int q
       unsigned hw1 = 0;
       const unsigned* hsrc = hid_in + ((int64_t)c * kSpSlots + slot) * kH1;
       if (hid_chain_in) hw1 = msg_load(hsrc);         // the hand-over of the stage below: published before its message was, looked at now, used behind the publish
-      // ---- z = [W1 | W1 R] . [x ; y]: 8 reads of 4 inputs, 64 packed FMAs (4 rows x 32 inputs per lane) ---------------------------------
       const float* xb = S.xy[v & (kXyRing - 1)];
+#if MMK_SP_ROWS8
+      // ---- z = [W1 | W1 R] . [x ; y]: 8 gate rows x ONE K slice of 16 per lane: 4 reads of 4 inputs (half of what 4 rows x 32 inputs read:
+      //      the four chain waves' reads share one LDS), 64 packed FMAs; the two rows of 16 lanes that hold the same 8 gate rows swap
+      //      halves (v_permlane16_swap: even rows keep gate rows 0-3, odd rows 4-7), then the row's reduce-scatter as before -----------------
+      f32x2 acc8[8];
+#pragma unroll
+      for (int cc = 0; cc < 8; ++cc) acc8[cc] = f32x2{0.f, 0.f};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const f32x4s xv = *reinterpret_cast<const f32x4s*>(xb + kso + i * 4);
+#pragma unroll
+        for (int cc = 0; cc < 8; ++cc) {
+          acc8[cc] = fma2(f32x2{wz[cc * 4 + i][0], wz[cc * 4 + i][1]}, f32x2{xv[0], xv[1]}, acc8[cc]);
+          acc8[cc] = fma2(f32x2{wz[cc * 4 + i][2], wz[cc * 4 + i][3]}, f32x2{xv[2], xv[3]}, acc8[cc]);
+        }
+      }
+#else
+      // ---- z = [W1 | W1 R] . [x ; y]: 8 reads of 4 inputs, 64 packed FMAs (4 rows x 32 inputs per lane) ---------------------------------
       f32x2 acc[4][2];
 #pragma unroll
       for (int cc = 0; cc < 4; ++cc) acc[cc][0] = acc[cc][1] = f32x2{0.f, 0.f};
@@ -330,6 +364,7 @@ __device__ void chain_role(const WnSpipeArgs& a, Lds& S, int stage, int p, int q
           acc[cc][1] = fma2(f32x2{wz[cc * 8 + i][2], wz[cc * 8 + i][3]}, f32x2{xv[2], xv[3]}, acc[cc][1]);
         }
       }
+#endif
       // ---- the layer's own input x_s = x_{s-1} + (R y + br): 2 channels x 16 inputs per lane ---------------------------------------------
       f32x2 rac[2][2];
 #pragma unroll
@@ -345,8 +380,16 @@ __device__ void chain_role(const WnSpipeArgs& a, Lds& S, int stage, int p, int q
       }
       const float xin = xb[xin_off];
       float zc[4];
+#if MMK_SP_ROWS8
+#pragma unroll
+      for (int cc = 0; cc < 4; ++cc) {
+        const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc8[cc][0] + acc8[cc][1]), __float_as_uint(acc8[4 + cc][0] + acc8[4 + cc][1]), false, false);
+        zc[cc] = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+      }
+#else
 #pragma unroll
       for (int cc = 0; cc < 4; ++cc) zc[cc] = (acc[cc][0][0] + acc[cc][0][1]) + (acc[cc][1][0] + acc[cc][1][1]);
+#endif
       float z = row_reduce_scatter4(zc[0], zc[1], zc[2], zc[3], ks);
       const float xs = row_reduce_scatter2((rac[0][0][0] + rac[0][0][1]) + (rac[0][1][0] + rac[0][1][1]),
                                            (rac[1][0][0] + rac[1][0][1]) + (rac[1][1][0] + rac[1][1][1]), ks);
@@ -469,7 +512,7 @@ __device__ void helper_role(const WnSpipeArgs& a, Lds& S, int stage, int p, int 
   // stage's own output of the visit before (which the chain waves may still be working on when the next message is already staged:
   // with the bias of visit it + B made in iteration it + 1, the helpers - and with them the staging of the next messages - went at the
   // pace of chain visit + look round trip + bias products: 1.7 us per visit in front of stages 10 and 20, the ring's beat).
-  const int lag = (MMK_SP_LAG && B >= MMK_SP_LAG_CLIPS) ? 4 : 0;
+  const int lag = (MMK_SP_LAG && B >= 8 && (B >= MMK_SP_LAG_CLIPS || d <= MMK_SP_LAG_DIL)) ? 4 : 0;
   // who asks for (and stages) the rows of visit v: the helper that looks in iteration v - B + 1 (lag 4) or v - B - ahead (no lag), right after
   // its look duty
   auto rows_mine = [&](int v) { return (((unsigned)(lag ? v - B + 1 : v - B - ahead)) & 3u) == (unsigned)h; };
@@ -624,17 +667,19 @@ __device__ void helper_role(const WnSpipeArgs& a, Lds& S, int stage, int p, int 
       staged_next = false;
       if (lookahead && it + 4 < n_visits) look(((cl * kSpSlots + (sl & 3)) * kMsgFloats) * 4 + look_off, pre_lo, pre_hi);
       else pre_lo[0] = kSpPoison;
-    } else if (MMK_SP_EARLY && ((it + 1) & 3) == h && it + 1 < n_visits) {
-      // the iteration before my look duty: while message `it` is not staged (by its helper), I look for MINE already - when the clips
-      // queue up it is there, and a look at another XCD's memory is a ~0.8-us round trip that would otherwise start only now
-      const int cn = c + 1 == B ? 0 : c + 1, sn = c + 1 == B ? s + 1 : s;
+    } else if (MMK_SP_EARLY && it + ((h - it) & 3) < n_visits && (((h - it) & 3) <= MMK_SP_EARLY_DEPTH) && (((h - it) & 3) == 1 || lookahead)) {
+      // not my look duty: while message `it` is not staged (by its helper), I look for MY next one already (1 - 3 visits ahead) - when the
+      // clips queue up it is there, and a look at another XCD's memory is a ~0.8-us round trip that would otherwise start only when the
+      // messages before it have been staged one after the other: the four helpers' looks then run side by side
+      const int nahead = (h - it) & 3, nd = it + nahead;
+      const int cn = c + nahead >= B ? c + nahead - B : c + nahead, sn = c + nahead >= B ? s + 1 : s;
       const int off = ((cn * kSpSlots + (sn & 3)) * kMsgFloats) * 4 + look_off;
       unsigned spins = 0;
       while (__hip_atomic_load(&S.arrived[it & 3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < (unsigned)it + 1) {
         if (!staged_next) {
           if (landed(pre_lo, pre_hi)) {
-            if (it + 1 < kXyRing - 2 || lds_min4(S.hdone) + (kXyRing - 2) >= (unsigned)it + 2) {
-              stage_message(it + 1, cn, sn, pre_lo, pre_hi);
+            if (nd < kXyRing - 2 || lds_min4(S.hdone) + (kXyRing - 2) >= (unsigned)nd + 1) {
+              stage_message(nd, cn, sn, pre_lo, pre_hi);
               staged_next = true;
             } else if (kLdsSleep > 0) __builtin_amdgcn_s_sleep(kLdsSleep);
           } else {
@@ -688,7 +733,34 @@ __device__ void helper_role(const WnSpipeArgs& a, Lds& S, int stage, int p, int 
         }
         if (!stage_rows(v3, xr, cr)) return;
       }
-      hstamp(4);
+    }
+    hstamp(4);
+#if MMK_SP_DUTYFIRST
+    // My look duty is the NEXT visit: I look for that message NOW and make this iteration's bias afterwards (it has B - 2 visits of
+    // slack).  Otherwise all four helpers start their products when message `it` is staged, and nobody looks for message it + 1 until
+    // the helper whose duty it is has finished them: a stage then takes (products + look) per visit however few clips wait - with 32
+    // clips in 31 stages that, not the latency of one clip's trip, set the step (41 us up to 24 clips, + 1.3 us for every further one).
+    if (B >= 4 && ((it + 1) & 3) == h && it + 1 < n_visits && !staged_next) {      // (fewer clips: the bias may be the one the next message waits for)
+      const int vn = it + 1;
+      const int cn = c + 1 == B ? 0 : c + 1, sn = c + 1 == B ? s + 1 : s;
+      if (vn >= kXyRing - 2 && !lds_wait4(S.hdone, (unsigned)vn - (kXyRing - 2) + 1, a.err_flag)) return;
+      const int off = ((cn * kSpSlots + (sn & 3)) * kMsgFloats) * 4 + look_off;
+      unsigned spins = 0;
+      while (!landed(pre_lo, pre_hi)) {
+        if (++spins > kSpinLimit || ((spins & 1023u) == 0 && __hip_atomic_load(a.err_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+          atomicExch(a.err_flag, 1);
+          return;
+        }
+        if (kPollGap > 0 && spins > 1) __builtin_amdgcn_s_sleep(kPollGap);
+        look(off, pre_lo, pre_hi);
+      }
+      if (STAMPS) n_polls += spins;
+      stage_message(vn, cn, sn, pre_lo, pre_hi);
+      staged_next = true;
+    }
+#endif
+    if (it >= 1 + lag && it - 1 - lag + B < n_visits) {
+      const unsigned v3 = (unsigned)(it - 1 - lag + B);
       if (!bias_of(v3, sp, cp)) return;
       hstamp(5);
     }
@@ -894,20 +966,20 @@ __device__ void head_role(const WnSpipeArgs& a, int p) {
           // the maximum's quotient (first-maximum rule).  Only then (some other logit within 4 ulp of the maximum) divide and compare.
           const f32x4s v4 = *reinterpret_cast<const f32x4s*>(lg + lane * 4);
           const float m = wave_max_dpp(fmaxf(fmaxf(v4[0], v4[1]), fmaxf(v4[2], v4[3])));
-          int cand = 0x7fffffff;
-#pragma unroll
-          for (int k = 3; k >= 0; --k)
-            if (v4[k] == m) cand = lane * 4 + k;                  // (the first maximum wins, targets.py / torch.argmax)
-          result = wave_min_dpp(cand);
+          // the first maximum (targets.py / torch.argmax): per k the lanes that hold it as a scalar mask, the lowest such lane, the smallest
+          // 4 lane + k - scalar instructions beside the vector unit instead of a second trip through the DPP rows
+          result = 0x7fffffff;
           bool odd = false, near = false;                         // NaN logits (argmax takes the first), or a logit within 4 ulp of the maximum
           const float lim = m - fmaxf(fabsf(m) * 4.8e-7f, 1e-37f);
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
+            const unsigned long long mk = __ballot(v4[k] == m);
+            if (mk) result = min(result, 4 * (int)__builtin_ctzll(mk) + k);
             odd = odd || v4[k] != v4[k];
             near = near || (v4[k] != m && v4[k] >= lim);
           }
           if (__any(odd)) {
-            cand = 0x7fffffff;
+            int cand = 0x7fffffff;
 #pragma unroll
             for (int k = 3; k >= 0; --k)
               if (v4[k] != v4[k]) cand = lane * 4 + k;
@@ -1005,11 +1077,23 @@ __global__ __launch_bounds__(256) void spipe_image_kernel(const WnSpRaw* __restr
       const int lane = (int)(id & 63), qi = (int)((id >> 6) % kChainRegs), W = (int)((id / (kChainRegs * 64)) % kWavesPerStage), s = (int)(id / (kChainRegs * 64 * kWavesPerStage));
       const WnSpRaw r = raw[s];
       float out[4] = {0.f, 0.f, 0.f, 0.f};
-      if (qi < 32) {      // register cc * 8 + i: gate row 4 (lane / 16) + cc of the wave, inputs 32 (ks & 7) + 4 i .. of x (ks < 8) or y
+      if (qi < 32) {
+#if MMK_SP_ROWS8
+        // register cc * 4 + i: gate row 8 (lane / 32) + cc of the wave, inputs 16 (lane & 15) + 4 i .. of x (even rows of 16 lanes) or y (odd rows).
+        // After the swap of halves even rows hold the sums of cc = 0 .. 3, odd rows of cc = 4 .. 7, and the row's reduce-scatter leaves lane l
+        // with gate row 8 (l / 32) + 4 (l / 16 & 1) + (l & 15) / 4 = l / 4, as in the other form.
+        const int ks = lane & 15, cc = qi >> 2, i = qi & 3, n = gate_raw_row(W, 8 * (lane >> 5) + cc);
+        const bool xpart = (lane & 16) == 0;
+        for (int e = 0; e < 4; ++e) {
+          const int k = 16 * ks + 4 * i + e;
+#else
+        // register cc * 8 + i: gate row 4 (lane / 16) + cc of the wave, inputs 32 (ks & 7) + 4 i .. of x (ks < 8) or y
         const int ks = lane & 15, cc = qi >> 3, i = qi & 7, n = gate_raw_row(W, 4 * (lane >> 4) + cc);
+        const bool xpart = ks < 8;
         for (int e = 0; e < 4; ++e) {
           const int k = 32 * (ks & 7) + 4 * i + e;
-          if (ks < 8) out[e] = r.wd[((int64_t)n * kC + k) * 2 + 1];                                                        // W1[n][k]
+#endif
+          if (xpart) out[e] = r.wd[((int64_t)n * kC + k) * 2 + 1];                                                        // W1[n][k]
           else if (s >= 1 && raw[s - 1].wr) out[e] = (float)dot_cols(r.wd + (int64_t)n * kC * 2 + 1, 2, raw[s - 1].wr + k, kC, kC);   // (W1 R)[n][k]
         }
       } else if (qi < 40) {
