@@ -78,8 +78,11 @@ constexpr int kSlotShift = MMK_SP_SLOT_SHIFT;
 #define MMK_SP_LAG_CLIPS 40    // ... from this many clips on (>= 8).  Measured on one box, cfg 4, us per step: 32 clips 53.2 with the lag, 52.0 without; 64 clips
                                // (with the early looks) 92.1 with it, 97.3 without: the lag pays where the clips queue up, and costs where one clip's latency binds
 #endif
+#ifndef MMK_SP_CHAIN_PRIO
+#define MMK_SP_CHAIN_PRIO 3
+#endif
 #ifndef MMK_SP_ROWS8
-#define MMK_SP_ROWS8 0         // chain products as 8 gate rows x a K slice of 16 per lane (half the LDS reads, one v_permlane16_swap level more)
+#define MMK_SP_ROWS8 1         // chain products as 8 gate rows x a K slice of 16 per lane (half the LDS reads, one v_permlane16_swap level more): cfg 4, 32 clips 44.9 -> 44.2 us per step
 #endif
 #ifndef MMK_SP_BACKUP
 #define MMK_SP_BACKUP 0        // the helper halfway between two look duties looks for the current message too, half a round trip behind
@@ -226,6 +229,8 @@ struct Lds {
   unsigned hdone[4];                          // per chain wave: visits whose xy image it no longer needs
   unsigned rows_ready[4];                     // [v mod 4]: v + 1 once the rows of visit v are staged (by helper v mod 4: every word has ONE writer, so it only grows)
   unsigned ready[4];                          // per helper: biases prepared (visit count)
+  unsigned hidin_ready[4];                    // [v mod 4]: v + 1 once the hidden units' hand-over of the stage below is staged for visit v
+  float hidin[kXyRing][16];                   // that hand-over: this CU's 16 units
   float bias[];                               // [chain wave][step parity][Bcap clips][gate row]: everything of z that is known a step ahead (dynamic LDS: 512 B per clip)
 };
 __device__ __forceinline__ int bias_off(int q, int parity, int c, int j, int Bcap) { return ((q * 2 + parity) * Bcap + c) * 16 + j; }
@@ -293,7 +298,6 @@ __device__ void chain_role(const WnSpipeArgs& a, Lds& S, int stage, int p, int q
   const bool hid_chain_in = stage >= 2 && ((stage - 1 + slot_shift(a)) >> 2) == grp;
   const bool hid_last = stage == a.L - 1 || ((stage + 1 + slot_shift(a)) >> 2) != grp;
   const bool hid_local = hid_last ? grp == ((a.L + slot_shift(a)) >> 2) : true;      // (the head's own XCD: its L2 is the meeting point)
-  const unsigned* hid_in = a.hidmsg + (int64_t)stage * hid_words + 4 * W + (lane >> 4);
   unsigned* hid_out = (hid_last ? a.hidgrp + (int64_t)grp * hid_words : a.hidmsg + (int64_t)(stage + 1) * hid_words) + 4 * W + (lane >> 4);
   const bool g_row = (j & 1) != 0;
   const float gate_scale = g_row ? -1.4426950408889634f : -2.8853900817779268f;
@@ -323,16 +327,13 @@ __device__ void chain_role(const WnSpipeArgs& a, Lds& S, int stage, int p, int q
     for (int c = 0; c < B; ++c, ++v) {
       if (STAMPS) t0c = __builtin_amdgcn_s_memtime();
       if (!chain_wait(S, q, v, a.err_flag)) return;
-      __builtin_amdgcn_s_setprio(3);              // (low while it spins: the helper wave of this SIMD gets the issue slots)
+      __builtin_amdgcn_s_setprio(MMK_SP_CHAIN_PRIO);              // (low while it spins: the helper wave of this SIMD gets the issue slots)
       if (STAMPS) {
         const u64 t = __builtin_amdgcn_s_memtime(); st.t_wait += t - t0c; t0c = t;
         if (a.stamps && c == 0 && s + 1 == n_steps && p == 0 && q == 0 && lane == 0) a.stamps[112 + stage] = __builtin_amdgcn_s_memrealtime();
       }
       // what the helper prepared a step ahead: W0 x[t - d] + conditioning + biases
       const float bzv = S.bias[bias_off(q, s & 1, c, j, Bcap)];
-      unsigned hw1 = 0;
-      const unsigned* hsrc = hid_in + ((int64_t)c * kSpSlots + slot) * kH1;
-      if (hid_chain_in) hw1 = msg_load(hsrc);         // the hand-over of the stage below: published before its message was, looked at now, used behind the publish
       const float* xb = S.xy[v & (kXyRing - 1)];
 #if MMK_SP_ROWS8
       // ---- z = [W1 | W1 R] . [x ; y]: 8 gate rows x ONE K slice of 16 per lane: 4 reads of 4 inputs (half of what 4 rows x 32 inputs read:
@@ -424,17 +425,13 @@ __device__ void chain_role(const WnSpipeArgs& a, Lds& S, int stage, int p, int q
           hc[1] = fma2(f32x2{wh[i][2], wh[i][3]}, f32x2{yv[2], yv[3]}, hc[1]);
         }
         const float hs = dpp_mirror_add(dpp_half_mirror_add(dpp_quad_sum((hc[0][0] + hc[0][1]) + (hc[1][0] + hc[1][1]))));
+        // the sum so far (the stage below handed it on behind its own publish) was fetched by the helper that staged this visit's message:
+        // the chain waves load NOTHING from memory - a load's data is waited for with a count that also covers the stores before it,
+        // i.e. every visit would wait for its own publish to be acknowledged (a written-through one: ~1 us)
         float hin = 0.f;
         if (hid_chain_in) {
-          unsigned spins = 0;
-          while (!__all(hw1 != kSpPoison)) {
-            if (++spins > kSpinLimit || ((spins & 1023u) == 0 && __hip_atomic_load(a.err_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
-              atomicExch(a.err_flag, 1);
-              return;
-            }
-            hw1 = msg_load(hsrc);
-          }
-          hin = __uint_as_float(hw1);
+          if (!lds_wait1(&S.hidin_ready[v & 3], v + 1, a.err_flag)) return;
+          hin = S.hidin[v & (kXyRing - 1)][4 * q + (lane >> 4)];
         }
         if (ks == 0) {
           msg_store(hid_out + ((int64_t)c * kSpSlots + slot) * kH1, msg_bits(hin + hs), hid_local);
@@ -499,6 +496,8 @@ __device__ void helper_role(const WnSpipeArgs& a, Lds& S, int stage, int p, int 
   const int64_t stage_words = (int64_t)a.Bmax * kSpSlots * kMsgFloats;
   const int B = a.B, Bcap = bias_cap(a.B);
   const int n_visits = (int)a.n_steps * B;
+  const int64_t hid_words = (int64_t)a.Bmax * kSpSlots * kH1;
+  const bool hid_chain_in = stage >= 2 && ((stage - 1 + slot_shift(a)) >> 2) == ((stage + slot_shift(a)) >> 2);      // (as in the chain role)
   // The rows a bias is multiplied with - this stage's delayed input and the projected conditioning row, 1 KB each - come into the CU ONCE:
   // helper v mod 4 asks for those of visit v (lane l: floats 4 l .. 4 l + 3 of each) and stages them in LDS, all four helpers read their
   // K slices from there.  (Every lane asking for its own 2 x 64 bytes - the form of round 3 - moves 32 KB per visit through the CU's
@@ -636,6 +635,23 @@ __device__ void helper_role(const WnSpipeArgs& a, Lds& S, int stage, int p, int 
     const bool duty = (it & 3) == h;
     // ---- 1. the visit's message ------------------------------------------------------------------------------------------------------------
     // a landed message (in the look registers) into the LDS image of visit vv = (cc, ss); the chain waves are told
+    // ... and behind it the hidden units' hand-over of the stage below for the same visit (this CU's 16 units), for the chain waves' sums
+    auto fetch_hid = [&](int vv, int cc, int ss) -> bool {
+      if (!hid_chain_in) return true;
+      const unsigned* src = a.hidmsg + (int64_t)stage * hid_words + ((int64_t)cc * kSpSlots + (ss & 3)) * kH1 + 16 * p + (lane & 15);
+      unsigned w, spins = 0;
+      for (;;) {
+        w = msg_load(src);
+        if (__all(w != kSpPoison)) break;
+        if (++spins > kSpinLimit || ((spins & 1023u) == 0 && __hip_atomic_load(a.err_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+          atomicExch(a.err_flag, 1);
+          return false;
+        }
+      }
+      if (lane < 16) S.hidin[vv & (kXyRing - 1)][lane] = __uint_as_float(w);
+      lds_signal(&S.hidin_ready[vv & 3], (unsigned)vv + 1, lane);
+      return true;
+    };
     auto stage_message = [&](int vv, int cc, int ss, const u32x4s& m_lo, const u32x4s& m_hi) {
       float* dst = &S.xy[vv & (kXyRing - 1)][st_off];
       *reinterpret_cast<f32x4s*>(dst) = f32x4s{__uint_as_float(m_lo[0]), __uint_as_float(m_lo[1]), __uint_as_float(m_lo[2]), __uint_as_float(m_lo[3])};
@@ -663,11 +679,12 @@ __device__ void helper_role(const WnSpipeArgs& a, Lds& S, int stage, int p, int 
         }
         if (STAMPS) n_polls += spins;
         stage_message(it, c, s, pre_lo, pre_hi);
+        if (!fetch_hid(it, c, s)) return;
       }
       staged_next = false;
       if (lookahead && it + 4 < n_visits) look(((cl * kSpSlots + (sl & 3)) * kMsgFloats) * 4 + look_off, pre_lo, pre_hi);
       else pre_lo[0] = kSpPoison;
-    } else if (MMK_SP_EARLY && it + ((h - it) & 3) < n_visits && (((h - it) & 3) <= MMK_SP_EARLY_DEPTH) && (((h - it) & 3) == 1 || lookahead)) {
+    } else if (MMK_SP_EARLY && (MMK_SP_EARLY == 1 || remote_in) && it + ((h - it) & 3) < n_visits && (((h - it) & 3) <= MMK_SP_EARLY_DEPTH) && (((h - it) & 3) == 1 || lookahead)) {
       // not my look duty: while message `it` is not staged (by its helper), I look for MY next one already (1 - 3 visits ahead) - when the
       // clips queue up it is there, and a look at another XCD's memory is a ~0.8-us round trip that would otherwise start only when the
       // messages before it have been staged one after the other: the four helpers' looks then run side by side
@@ -680,6 +697,7 @@ __device__ void helper_role(const WnSpipeArgs& a, Lds& S, int stage, int p, int 
           if (landed(pre_lo, pre_hi)) {
             if (nd < kXyRing - 2 || lds_min4(S.hdone) + (kXyRing - 2) >= (unsigned)nd + 1) {
               stage_message(nd, cn, sn, pre_lo, pre_hi);
+              if (!fetch_hid(nd, cn, sn)) return;
               staged_next = true;
             } else if (kLdsSleep > 0) __builtin_amdgcn_s_sleep(kLdsSleep);
           } else {
@@ -706,6 +724,7 @@ __device__ void helper_role(const WnSpipeArgs& a, Lds& S, int stage, int p, int 
         look(off, bk_lo, bk_hi);
         if (landed(bk_lo, bk_hi)) {
           stage_message(it, c, s, bk_lo, bk_hi);
+          if (!fetch_hid(it, c, s)) return;
           break;
         }
         if (++spins > kSpinLimit || ((spins & 1023u) == 0 && __hip_atomic_load(a.err_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
@@ -756,6 +775,7 @@ __device__ void helper_role(const WnSpipeArgs& a, Lds& S, int stage, int p, int 
       }
       if (STAMPS) n_polls += spins;
       stage_message(vn, cn, sn, pre_lo, pre_hi);
+      if (!fetch_hid(vn, cn, sn)) return;
       staged_next = true;
     }
 #endif
@@ -1035,7 +1055,7 @@ __global__ __launch_bounds__(kThreads) void wavenet_spipe_kernel(const WnSpipeAr
     else role = (int)(id * 32 + ticket);
     s_role = role;
   }
-  if (tid < 16) (&S.arrived[0])[tid] = 0;       // arrived, hdone, rows_ready, ready are adjacent
+  if (tid < 20) (&S.arrived[0])[tid] = 0;       // arrived, hdone, rows_ready, ready, hidin_ready are adjacent
   __syncthreads();
   const int role = s_role;
   if (role < 0) return;
