@@ -32,7 +32,9 @@
 extern "C" {
 #endif
 
-#define MMK_ABI_VERSION 2   /* 2: exec_mode in the WaveNet / SampleRNN / Seq2Seq configs, mmk_*_sync_status for all three, mmk_*_inject_sync_error */
+#define MMK_ABI_VERSION 3   /* 2: exec_mode in the WaveNet / SampleRNN / Seq2Seq configs, mmk_*_sync_status for all three, mmk_*_inject_sync_error;
+                              * 3: `tuning` text at the end of the three configs - the library reads no environment variable */
+#define MMK_TUNING_CHARS 256
 
 #define MMK_OK 0
 #define MMK_ERR_INVALID (-1)     /* bad argument / shape / unsupported option value */
@@ -208,6 +210,9 @@ typedef struct mmk_wavenet_config {
   int32_t with_affine_residuals;           /* Config.with_affine_residuals (:121-122, :148-149): every layer's input goes through
                                             * x_hat * a + b of a 1x1 convolution to 3 x its width (ParametrizedLinear) first; launch path,
                                             * without pad_side, layerwise_inputs, or conditioning inputs of an ungated network */
+  char tuning[MMK_TUNING_CHARS];           /* execution switches of THIS plan as "NAME=VALUE;NAME=VALUE" (empty: the library's choices), e.g.
+                                            * "MMK_WN_SPIPE=0;MMK_WN_CHAIN=1" - what the parity tests use to put one network on every kernel that can run it.  The
+                                            * library reads no environment variable (the diagnostic build, -DMMK_DIAG, falls back to it) */
 } mmk_wavenet_config;
 
 typedef struct mmk_wavenet_plan mmk_wavenet_plan;
@@ -274,6 +279,9 @@ typedef struct mmk_srnn_config {
   int32_t exec_mode;                       /* 0 = the library chooses (resident mode: the bottom tier's launch beside the tier kernels of a
                                             * second stream, where they are co-resident), 1 = the kernels in turns on one stream: what a
                                             * caller asks for to redo a batch after mmk_srnn_sync_status reported a timed-out wait */
+  char tuning[MMK_TUNING_CHARS];           /* execution switches of THIS plan as "NAME=VALUE;NAME=VALUE" (empty: the library's choices), e.g.
+                                            * "MMK_SRNN_RESIDENT=0" - what the parity tests use to put one network on every kernel that can run it.  The
+                                            * library reads no environment variable (the diagnostic build, -DMMK_DIAG, falls back to it) */
 } mmk_srnn_config;
 
 typedef struct mmk_srnn_plan mmk_srnn_plan;
@@ -328,6 +336,9 @@ typedef struct mmk_s2s_config {
   int32_t exec_mode;                       /* 0 = the library chooses (one resident launch per bi-LSTM layer where its workgroups are
                                             * co-resident), 1 = one launch per frame: what a caller asks for to redo a call after
                                             * mmk_s2s_sync_status reported a timed-out wait */
+  char tuning[MMK_TUNING_CHARS];           /* execution switches of THIS plan as "NAME=VALUE;NAME=VALUE" (empty: the library's choices), e.g.
+                                            * "MMK_S2S_SEQ=0" - what the parity tests use to put one network on every kernel that can run it.  The
+                                            * library reads no environment variable (the diagnostic build, -DMMK_DIAG, falls back to it) */
 } mmk_s2s_config;
 
 typedef struct mmk_s2s_plan mmk_s2s_plan;

@@ -8,6 +8,7 @@
 //     tile w and four 16-row accumulators; per K-chunk a wave issues one 1-KiB fragment load (next chunk's, while the
 //     current one is multiplied), four LDS reads and 16 MFMAs - the matrix pipe is the bound, not memory.
 #include "mmk_common.h"
+#include "plan_util.h"
 
 namespace mmk {
 
@@ -322,15 +323,13 @@ __global__ __launch_bounds__(256) void gemm_split_reduce_kernel(const float* __r
 bool gemm_bias_act_supported(const float* A, int64_t lda, int M, int K) {
   // (M = 64 - dec.fc of the Seq2Seq decoder, 64 x 8192 x 1024 - was measured on this kernel too: slower than the row-tile
   //  kernel's 27.7 us, cfg 5 218 instead of 227 M samples/s; MMK_GEMM_MIN_M moves the threshold)
-  static const int min_m = [] { const char* e = getenv("MMK_GEMM_MIN_M"); return e ? atoi(e) : 128; }();
+  static const int min_m = [] { const char* e = diag_only("MMK_GEMM_MIN_M"); return e ? atoi(e) : 128; }();
   return M >= min_m && K >= 16 && (lda % 4) == 0 && (reinterpret_cast<uintptr_t>(A) & 15) == 0;
 }
 
 // How many ways a launch with few tiles splits K: a tile's K loop is a chain of stages of ~2 us each (a slab's way from L2 is
 // longer than its MFMAs), so a grid that leaves CUs idle is cut along K until it fills them (512 workgroups = two per CU)
-int gemm_bias_act_k_split(int M, int n_tiles, int k_chunks) {
-  const char* fe = getenv("MMK_GEMM_KSPLIT");                  // (read per call: the tests force splits)
-  const int forced = fe ? atoi(fe) : 0;
+int gemm_bias_act_k_split(int M, int n_tiles, int k_chunks, int forced = 0) {
   const int wgs = ((n_tiles + kTgBN / 16 - 1) / (kTgBN / 16)) * ((M + kTgBM - 1) / kTgBM);
   const int stages = (k_chunks + kTgCh - 1) / kTgCh;
   int ks = 1;
@@ -345,14 +344,14 @@ int64_t gemm_bias_act_partial_floats(int M, int n_tiles, int k_chunks) {
 }
 
 int launch_gemm_bias_act(const float* A, int64_t lda, const float* Wp, const float* bias, int n_tiles, int k_chunks, int N, int K, float* C,
-                         int64_t ldc, int M, int act, hipStream_t stream, GemmRowMap rm, float* partial, int64_t partial_floats) {
+                         int64_t ldc, int M, int act, hipStream_t stream, GemmRowMap rm, float* partial, int64_t partial_floats, int forced_k_split) {
   if (M <= 0 || n_tiles <= 0) return MMK_OK;
   if (!gemm_bias_act_supported(A, lda, M, K)) return fail(MMK_ERR_UNSUPPORTED, "gemm_bias_act: needs M >= 128 and a 16-byte aligned A");
-  int ks = partial ? gemm_bias_act_k_split(M, n_tiles, k_chunks) : 1;
+  int ks = partial ? gemm_bias_act_k_split(M, n_tiles, k_chunks, forced_k_split) : 1;
   if (ks > 1 && (int64_t)ks * M * n_tiles * 16 > partial_floats) ks = 1;
   dim3 grid((n_tiles + kTgBN / 16 - 1) / (kTgBN / 16), (M + kTgBM - 1) / kTgBM, ks), block(kTgThreads);
   const size_t lds = (size_t)2 * kTgBM * kTgLd * sizeof(float);
-  const char* we = getenv("MMK_GEMM_WLDS");
+  const char* we = diag_only("MMK_GEMM_WLDS");
   if (!(we && we[0] == '0'))
     hipLaunchKernelGGL(gemm_bias_act_kernel<true>, grid, block, lds + (size_t)2 * 4 * kTgCh * 64 * 16, stream, A, lda, Wp, bias, C, ldc, M, n_tiles, N, K,
                        k_chunks, act, rm, ks, partial);

@@ -247,9 +247,10 @@ struct GemmRowMap {
 // with a `partial` buffer of gemm_bias_act_partial_floats(M, n_tiles, k_chunks) floats a launch of few tiles splits K over more
 // workgroups and adds the partial sums in a fixed order in a second launch (0 floats: the launch fills the chip as it is)
 int64_t gemm_bias_act_partial_floats(int M, int n_tiles, int k_chunks);
+// (forced_k_split > 0: that many K splits instead of the launch's own choice - the parity tests' way to every split width)
 int launch_gemm_bias_act(const float* A, int64_t lda, const float* Wp, const float* bias, int n_tiles, int k_chunks, int N, int K, float* C,
                          int64_t ldc, int M, int act, hipStream_t stream, GemmRowMap rm = GemmRowMap(), float* partial = nullptr,
-                         int64_t partial_floats = 0);
+                         int64_t partial_floats = 0, int forced_k_split = 0);
 
 // C[M <= 64, N] = act(A . W^T + bias) for few rows against a large packed matrix (skinny.hip)
 bool skinny_linear_supported(const float* A, int64_t lda, int M, int K, int k_chunks);

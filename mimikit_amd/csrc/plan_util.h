@@ -1,6 +1,8 @@
 // Host-side helpers shared by the network plans: state_dict binding, workspace
 // carving, packed-linear descriptors and the hipGraph step cache.
 #pragma once
+#include <cstdlib>
+#include <cstring>
 #include <map>
 #include <string>
 #include <vector>
@@ -8,6 +10,44 @@
 #include "mmk_common.h"
 
 namespace mmk {
+
+// The execution switches of ONE plan: the `tuning` text of its config ("MMK_WN_CHAIN=0;MMK_WN_PIPE=1"), parsed when the plan is created.
+// Nothing comes from the environment in the product library - a stray variable, or another thread's setenv between two plan creations,
+// must not change which kernel a plan gets.  The diagnostic build (-DMMK_DIAG: stamps and timing experiments) falls back to the
+// environment for names the text does not set; `diag_only` is the same fall-back for switches that exist in that build only.
+inline const char* diag_only(const char* name) {
+#ifdef MMK_DIAG
+  return getenv(name);
+#else
+  (void)name;
+  return nullptr;
+#endif
+}
+class Tuning {
+ public:
+  void parse(const char* text, size_t cap) {
+    kv_.clear();
+    std::string s(text, strnlen(text, cap));
+    size_t at = 0;
+    while (at < s.size()) {
+      size_t end = s.find(';', at);
+      if (end == std::string::npos) end = s.size();
+      const std::string item = s.substr(at, end - at);
+      const size_t eq = item.find('=');
+      if (eq != std::string::npos && eq > 0) kv_[item.substr(0, eq)] = item.substr(eq + 1);
+      at = end + 1;
+    }
+  }
+  // the value's text, or nullptr when the switch is not set (the pointer lives as long as the plan)
+  const char* get(const char* name) const {
+    auto it = kv_.find(name);
+    if (it != kv_.end()) return it->second.c_str();
+    return diag_only(name);
+  }
+
+ private:
+  std::map<std::string, std::string> kv_;
+};
 
 struct Bound {
   const float* ptr = nullptr;

@@ -15,15 +15,6 @@
 
 using namespace mmk;
 
-// environment switches of the DIAGNOSTIC build (phase stamps): the product library does not read them
-static inline const char* diag_env(const char* name) {
-#ifdef MMK_DIAG
-  return getenv(name);
-#else
-  (void)name;
-  return nullptr;
-#endif
-}
 
 namespace {
 
@@ -144,6 +135,7 @@ struct BiLstm {
 };
 
 struct mmk_s2s_plan {
+  Tuning tune;                  // the config's execution switches (plan_util.h): never the environment in the product library
   mmk_s2s_config cfg;
   Binder binder;
   bool committed = false;
@@ -171,6 +163,7 @@ struct mmk_s2s_plan {
   // discrete IO: the embedding table (a copy: in_classes x D), the MLP head's Linears, its hidden rows and raw outputs
   float* embed = nullptr;
   float* gemm_partial = nullptr;                 // split-K partial sums of the GEMM launches that would not fill the chip
+  int gemm_ksplit = 0;                           // > 0: every GEMM launch splits K this many ways (tuning MMK_GEMM_KSPLIT: a parity-test mode)
   static constexpr int64_t kPartialFloats = 512 * 64 * 64;   // k_split x workgroups <= 512 tiles of 64 x 64
   std::vector<PackedLinear> mlp;
   float *hid[2] = {nullptr, nullptr}, *logits = nullptr;
@@ -269,7 +262,7 @@ static int derive(mmk_s2s_plan* p) {
     p->mlp.push_back(last);
     p->logits_ld = (int)round_up(c.out_dim + (c.learn_temp ? 1 : 0), 4);
   }
-  const char* fenv = getenv("MMK_S2S_FUSED");
+  const char* fenv = p->tune.get("MMK_S2S_FUSED");
   p->fused_lstm = !(fenv && fenv[0] == '0') && lstm_step_supported(p->D);
   {
     int dev = 0;
@@ -278,7 +271,7 @@ static int derive(mmk_s2s_plan* p) {
   }
   // one launch per bi-LSTM layer where all its workgroups fit on the chip at once (exec_mode 1: the per-step kernel, which
   // needs no co-residency - what a caller asks for after mmk_s2s_sync_status reported a timed-out wait)
-  const char* senv = getenv("MMK_S2S_SEQ");
+  const char* senv = p->tune.get("MMK_S2S_SEQ");
   p->seq_lstm = p->fused_lstm && c.exec_mode != 1 && !(senv && senv[0] == '0') && lstm_seq_supported(p->D, 1, p->hop, p->n_cu);
   return MMK_OK;
 }
@@ -287,6 +280,8 @@ extern "C" int mmk_s2s_plan_create(const mmk_s2s_config* cfg, mmk_s2s_plan** out
   if (!cfg || !out) return fail(MMK_ERR_INVALID, "s2s_plan_create: null argument");
   mmk_s2s_plan* p = new mmk_s2s_plan();
   p->cfg = *cfg;
+  p->tune.parse(cfg->tuning, sizeof(cfg->tuning));
+  if (const char* ks = p->tune.get("MMK_GEMM_KSPLIT")) p->gemm_ksplit = atoi(ks);
   int rc = derive(p);
   if (rc != MMK_OK) {
     delete p;
@@ -373,7 +368,7 @@ extern "C" int mmk_s2s_commit(mmk_s2s_plan* p, void* workspace, size_t workspace
   if (c.dec_upsampling == 0) {   // "repeat" / "interp" have no up-sampling weights
     const float* w = b.need("dec.fc.fc.weight", (int64_t)p->hop * D * D);
     const float* wo = b.need("enc.fc_out.weight", (int64_t)D * D);
-    const char* cenv = getenv("MMK_S2S_COMPOSED");
+    const char* cenv = p->tune.get("MMK_S2S_COMPOSED");
     if (w && wo && !(cenv && cenv[0] == '0')) {
       hipLaunchKernelGGL(s2s_compose_kernel, dim3((D + 255) / 256, p->hop * D), dim3(256), 0, st, w, wo, p->hop * D, D, p->compose_tmp);
       MMK_HIP(hipGetLastError());
@@ -408,14 +403,14 @@ extern "C" int mmk_s2s_commit(mmk_s2s_plan* p, void* workspace, size_t workspace
 }
 
 static int plain_linear(const PackedLinear& w, const float* x, int64_t ldx, int M, float* y, int64_t ldy, int act,
-                        hipStream_t st, float* partial = nullptr) {
+                        hipStream_t st, float* partial = nullptr, int forced_k_split = 0) {
   // GEMM-shaped calls (all hop frames of all clips at once) take the tiled kernel; MMK_S2S_GEMM=0 keeps the row-tile one
-  static const bool tiled = [] { const char* e = getenv("MMK_S2S_GEMM"); return !(e && e[0] == '0'); }();
+  static const bool tiled = [] { const char* e = diag_only("MMK_S2S_GEMM"); return !(e && e[0] == '0'); }();
   if (tiled && w.nseg == 1 && gemm_bias_act_supported(x, ldx, M, w.segK[0]))
     return launch_gemm_bias_act(x, ldx, w.Wp, w.bias, w.n_tiles, w.k_chunks, w.N, w.segK[0], y, ldy, M, act, st, GemmRowMap(), partial,
-                                partial ? mmk_s2s_plan::kPartialFloats : 0);
+                                partial ? mmk_s2s_plan::kPartialFloats : 0, forced_k_split);
   // few rows against a large matrix (dec.fc, enc.fc_out): the weight-streaming kernel; MMK_S2S_SKINNY=0 keeps the row-tile one
-  static const bool skinny = [] { const char* e = getenv("MMK_S2S_SKINNY"); return !(e && e[0] == '0'); }();
+  static const bool skinny = [] { const char* e = diag_only("MMK_S2S_SKINNY"); return !(e && e[0] == '0'); }();
   if (skinny && w.nseg == 1 && w.n_tiles >= 32 && skinny_linear_supported(x, ldx, M, w.segK[0], w.k_chunks))
     return launch_skinny_linear(x, ldx, w.Wp, w.bias, w.n_tiles, w.k_chunks, w.N, w.segK[0], y, ldy, M, act, st);
   LinearArgs a = {};
@@ -439,7 +434,7 @@ struct FrameMap {
 };
 
 static bool inproj_enabled() {
-  static const bool on = [] { const char* e = getenv("MMK_S2S_INPROJ"); return !(e && e[0] == '0'); }();
+  static const bool on = [] { const char* e = diag_only("MMK_S2S_INPROJ"); return !(e && e[0] == '0'); }();
   return on;
 }
 
@@ -476,7 +471,7 @@ static int run_bilstm(mmk_s2s_plan* p, BiLstm& l, const float* x, int x_ld, int 
     MMK_TRY(launch_lstm_inproj(ia, p->n_cu, st));
   }
   for (int d = 0; d < 2; ++d) {
-    if (!inproj) MMK_TRY(plain_linear(l.ih[d], x, x_ld, (int)rows, p->gi[d], 4 * D, ACT_NONE, st, p->gemm_partial));
+    if (!inproj) MMK_TRY(plain_linear(l.ih[d], x, x_ld, (int)rows, p->gi[d], 4 * D, ACT_NONE, st, p->gemm_partial, p->gemm_ksplit));
     if (zero_state && !p->fused_lstm) {
       // `lstm(x,)` : fresh zero state on every call                    (s2s_lstm_v2.py:97); the fused step kernel takes a flag
       MMK_HIP(hipMemsetAsync(p->h[d], 0, (size_t)p->Bmax * D * sizeof(float), st));
@@ -495,9 +490,9 @@ static int run_bilstm(mmk_s2s_plan* p, BiLstm& l, const float* x, int x_ld, int 
     // the fold (and the encoder's pooling) happen in the cell: nobody reads the two directions' rows themselves
     a.fold = fs.fold; a.res = fs.res; a.pool = fs.pool; a.pool_mode = fs.pool_mode;
     a.dir[0].y = a.dir[1].y = nullptr;
-    if (const char* senv = diag_env("MMK_S2S_STAMPS"); senv && senv[0] == '1') {
+    if (const char* senv = diag_only("MMK_S2S_STAMPS"); senv && senv[0] == '1') {
       a.stamps = p->seq_stamps;
-      a.stamp_wg = diag_env("MMK_S2S_STAMP_WG") ? atoi(diag_env("MMK_S2S_STAMP_WG")) : 0;
+      a.stamp_wg = diag_only("MMK_S2S_STAMP_WG") ? atoi(diag_only("MMK_S2S_STAMP_WG")) : 0;
     }
     p->xch_cur ^= 1;
     p->seq_launches += 1;
@@ -634,7 +629,7 @@ static int s2s_step(mmk_s2s_plan* p, int M, const S2SIo& io, int n_out, hipStrea
       const bool last = i + 1 == p->mlp.size();
       float* o = last ? p->logits : p->hid[i & 1];
       const int64_t o_ld = last ? p->logits_ld : c.mlp_hidden;
-      MMK_TRY(plain_linear(p->mlp[i], hx, hx_ld, rows, o, o_ld, last ? ACT_NONE : ACT_MISH, st, p->gemm_partial));   // MLPIO's default activation (modules/io.py:205)
+      MMK_TRY(plain_linear(p->mlp[i], hx, hx_ld, rows, o, o_ld, last ? ACT_NONE : ACT_MISH, st, p->gemm_partial, p->gemm_ksplit));   // MLPIO's default activation (modules/io.py:205)
       hx = o;
       hx_ld = o_ld;
     }
@@ -646,13 +641,13 @@ static int s2s_step(mmk_s2s_plan* p, int M, const S2SIo& io, int n_out, hipStrea
   }
   {
     // the output projection writes the caller's (batch, frame, bin) rows itself when the tiled kernel takes it
-    static const bool tiled = [] { const char* e = getenv("MMK_S2S_GEMM"); return !(e && e[0] == '0'); }();
+    static const bool tiled = [] { const char* e = diag_only("MMK_S2S_GEMM"); return !(e && e[0] == '0'); }();
     const PackedLinear& w = p->out_lin;
     if (tiled && w.nseg == 1 && gemm_bias_act_supported(xl, D, rows, w.segK[0])) {
       GemmRowMap rm;
       rm.group = hop; rm.kept = n_out; rm.group_stride = ybs; rm.row_stride = yfs;
       return launch_gemm_bias_act(xl, D, w.Wp, w.bias, w.n_tiles, w.k_chunks, w.N, w.segK[0], y, 0, rows, c.out_abs ? ACT_ABS : ACT_NONE, st, rm,
-                                  p->gemm_partial, mmk_s2s_plan::kPartialFloats);
+                                  p->gemm_partial, mmk_s2s_plan::kPartialFloats, p->gemm_ksplit);
     }
   }
   MMK_TRY(plain_linear(p->out_lin, xl, D, rows, p->yout, p->out_pad, c.out_abs ? ACT_ABS : ACT_NONE, st));
@@ -742,7 +737,7 @@ extern "C" int mmk_s2s_sync_status(mmk_s2s_plan* p, mmk_stream_t stream) {
   uint32_t word = 0;
   MMK_HIP(hipMemcpyAsync(&word, p->seq_err, sizeof(word), hipMemcpyDeviceToHost, st));
   MMK_HIP(hipStreamSynchronize(st));
-  if (const char* senv = diag_env("MMK_S2S_STAMPS"); senv && senv[0] == '1') {
+  if (const char* senv = diag_only("MMK_S2S_STAMPS"); senv && senv[0] == '1') {
     std::vector<unsigned long long> h(16 * 8 * 8);
     MMK_HIP(hipMemcpy(h.data(), p->seq_stamps, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     const unsigned long long t0 = h[0];

@@ -16,6 +16,7 @@
 
 #include "mmk_common.h"
 #include "srnn_bottom.h"
+#include "plan_util.h"
 #include "sampler256.h"
 
 namespace mmk {
@@ -711,7 +712,7 @@ static size_t srnn_bottom1_lds_bytes(const SrnnBottomArgs& a) {
 // one clip per workgroup pays while the clips fit the chip a few times over, and needs the first 256 outputs to cover the
 // classes (threads in pairs) and the whole MLP in a workgroup's registers
 static bool srnn_bottom1_applies(const SrnnBottomArgs& a) {
-  static const bool off = [] { const char* e = getenv("MMK_SRNN_BOTTOM_MFMA"); return e && e[0] == '1'; }();
+  static const bool off = [] { const char* e = diag_only("MMK_SRNN_BOTTOM_MFMA"); return e && e[0] == '1'; }();
   return !off && a.fc0_raw && a.fc2_raw && a.B <= 1024 && a.n_out <= 1024 && a.Q <= 256 && a.Hm % 16 == 0 && a.Hm <= 128 && srnn_bottom1_lds_bytes(a) <= 64 * 1024;
 }
 

@@ -12,15 +12,6 @@
 
 using namespace mmk;
 
-// environment switches of the DIAGNOSTIC build (phase stamps): the product library does not read them
-static inline const char* diag_env(const char* name) {
-#ifdef MMK_DIAG
-  return getenv(name);
-#else
-  (void)name;
-  return nullptr;
-#endif
-}
 
 
 struct SrnnCall {
@@ -54,6 +45,7 @@ struct SrnnTier {
 };
 
 struct mmk_srnn_plan {
+  Tuning tune;                  // the config's execution switches (plan_util.h): never the environment in the product library
   mmk_srnn_config cfg;
   Binder binder;
   bool committed = false;
@@ -179,7 +171,7 @@ static int derive(mmk_srnn_plan* p) {
   PackedLinear last;
   last.set_geometry(c.q_levels + (c.learn_temp ? 1 : 0), {c.mlp_hidden});
   p->mlp.push_back(last);
-  const char* fenv = getenv("MMK_SRNN_FUSED");
+  const char* fenv = p->tune.get("MMK_SRNN_FUSED");
   p->fused_bottom = !(fenv && fenv[0] == '0') && c.mlp_n_hidden == 0 &&
                     srnn_bottom_supported(p->H, c.mlp_hidden, c.q_levels + (c.learn_temp ? 1 : 0), c.frame_size[c.n_tiers - 1]);
   p->fused_gru = !(fenv && fenv[0] == '0') && (c.rnn_kind == 1 || c.rnn_kind == 0);   // GRU or LSTM tiers
@@ -193,6 +185,7 @@ extern "C" int mmk_srnn_plan_create(const mmk_srnn_config* cfg, mmk_srnn_plan** 
   if (!cfg || !out) return fail(MMK_ERR_INVALID, "srnn_plan_create: null argument");
   mmk_srnn_plan* p = new mmk_srnn_plan();
   p->cfg = *cfg;
+  p->tune.parse(cfg->tuning, sizeof(cfg->tuning));
   int rc = derive(p);
   if (rc != MMK_OK) {
     delete p;
@@ -459,13 +452,13 @@ static SrnnBottomArgs bottom_args(mmk_srnn_plan* p, const SrnnCall& call, int64_
   a.fc0_wp = p->mlp[0].Wp; a.fc0_bias = p->mlp[0].bias; a.fc2_wp = p->mlp[1].Wp; a.fc2_bias = p->mlp[1].bias;
   a.fc0_raw = p->mlp_raw[0]; a.fc2_raw = p->mlp_raw[1];
   {
-    const char* cenv = getenv("MMK_SRNN_COMPOSED");
+    const char* cenv = p->tune.get("MMK_SRNN_COMPOSED");
     if (p->bottom_composed && !(cenv && cenv[0] == '0')) { a.a_comp = p->a_comp; a.b_comp = p->b_comp; }
   }
   a.temperature = call.temperature; a.uniforms = call.uniforms; a.uni_ld = call.uni_ld; a.uni_off = call.uni_off;
   a.logits_out = p->logits; a.logits_ld = p->logits_ld;
   {
-    const char* senv = diag_env("MMK_SRNN_STAMPS");
+    const char* senv = diag_only("MMK_SRNN_STAMPS");
     a.stamps = (senv && senv[0] == '1') ? reinterpret_cast<unsigned long long*>(p->tau + 8) : nullptr;
   }
   return a;
@@ -487,7 +480,7 @@ static int emit_step(mmk_srnn_plan* p, const SrnnCall& call, int64_t tau_off, in
       g.idx = call.idx; g.idx_rs = call.idx_rs; g.shift = call.shift;
       g.win_wp = t.in_lin.Wp; g.win_bias = t.in_lin.bias;
       {
-        const char* cenv = getenv("MMK_SRNN_COMPOSED");
+        const char* cenv = p->tune.get("MMK_SRNN_COMPOSED");
         g.v_comp = (t.fs <= 16 && !(cenv && cenv[0] == '0')) ? t.v_comp : nullptr;
       }
       if (i > 0) {   // outputs[i-1][:, (t // fs[i]) % (fs[i-1] // fs[i])]      (:251)
@@ -505,12 +498,12 @@ static int emit_step(mmk_srnn_plan* p, const SrnnCall& call, int64_t tau_off, in
       g.h_ring = t.h; g.h_slot_stride = (int64_t)p->Bmax * H;
       g.cnt = t.cnt; g.done = t.done; g.h_gran = t.h_gran;
       {
-        const char* senv = diag_env("MMK_SRNN_STAMPS");
+        const char* senv = diag_only("MMK_SRNN_STAMPS");
         g.stamps = (senv && senv[0] == '1') ? reinterpret_cast<unsigned long long*>(p->tau + 16) : nullptr;
       }
       // the up-sampler rides in the same launch behind a grid-wide barrier when the whole grid is resident at once
       // (MMK_SRNN_FUSED_UP=0: its own launch)
-      const char* fuenv = getenv("MMK_SRNN_FUSED_UP");
+      const char* fuenv = p->tune.get("MMK_SRNN_FUSED_UP");
       const bool fused_up = !(fuenv && fuenv[0] == '0') && srnn_gru_grid_resident(H, M);
       if (fused_up) {
         g.ups_wp = t.up_lin.Wp; g.ups_bias = t.up_lin.bias; g.ups_n_tiles = t.up_lin.n_tiles; g.ups_n = t.up_lin.N;
@@ -752,8 +745,8 @@ static int enqueue_steps(mmk_srnn_plan* p, const SrnnCall& call, int64_t t_begin
 // Resident mode applies when both fused kernels do, the two streams were seen to overlap, every tier's grid plus one
 // workgroup per clip fit the chip together, and the block is long enough to be worth a fork / join (MMK_SRNN_RESIDENT=0: never)
 static bool resident_applies(mmk_srnn_plan* p, const SrnnCall& call, int64_t n) {
-  const char* renv = getenv("MMK_SRNN_RESIDENT");
-  const char* uenv = getenv("MMK_SRNN_FUSED_UP");
+  const char* renv = p->tune.get("MMK_SRNN_RESIDENT");
+  const char* uenv = p->tune.get("MMK_SRNN_FUSED_UP");
   const bool off = (renv && renv[0] == '0') || p->cfg.exec_mode == 1, up_off = uenv && uenv[0] == '0';     // (exec_mode 1: the caller asks for the kernels in turns)
   static const int n_cu = [] {
     int dev = 0, v = 0;
@@ -874,7 +867,7 @@ extern "C" int64_t mmk_srnn_resident_blocks(const mmk_srnn_plan* p) { return p ?
 extern "C" int mmk_srnn_last_logits(mmk_srnn_plan* p, int32_t batch, float* out, int64_t ld, mmk_stream_t stream) {
   if (!p || !out) return fail(MMK_ERR_INVALID, "srnn_last_logits: null argument");
   if (!p->committed) return fail(MMK_ERR_STATE, "srnn_last_logits: plan not committed");
-  if (const char* senv = diag_env("MMK_SRNN_STAMPS"); senv && senv[0] == '1') {
+  if (const char* senv = diag_only("MMK_SRNN_STAMPS"); senv && senv[0] == '1') {
     unsigned long long st[8];
     MMK_HIP(hipStreamSynchronize((hipStream_t)stream));
     MMK_HIP(hipMemcpy(st, p->tau + 8, sizeof(st), hipMemcpyDeviceToHost));

@@ -24,6 +24,7 @@ struct WnPersistArgs {
   int32_t q_levels, H1, n_classes, n_logits_pad, learn_temp;
   float min_temp;
   int32_t teacher_forced;         // warm-up: inputs come from idx[], no head
+  int32_t force_tiles;            // 16-row MFMA tiles also for groups of at most 4 clips (the plan's MMK_WN_SMALL=0 switch: a parity-test mode)
   int64_t tf_end;                 // warm-up: first position that generation will consume (layers above the need line are skipped)
   int32_t xcd_local;              // 1: one clip group per XCD, hand-offs through that XCD's L2 (see .hip)
   int64_t t0, n_steps;            // positions t0 .. t0+n_steps-1 are produced (newest input = t0-1+s)

@@ -718,8 +718,7 @@ int launch_wavenet_persist(const WnPersistArgs& a, hipStream_t stream) {
     else MMK_WNP2(KC_, false);         \
   } while (0)
   // groups of at most 4 clips use 4x4 MFMA blocks instead of 16-row tiles (MMK_WN_SMALL=0 forces the tiles)
-  const char* senv = getenv("MMK_WN_SMALL");
-  const bool small = a.Mg <= 4 && !(senv && senv[0] == '0');
+  const bool small = a.Mg <= 4 && !a.force_tiles;
   switch (kc) {
     case 2: MMK_WNP(2); break;
     case 4: MMK_WNP(4); break;

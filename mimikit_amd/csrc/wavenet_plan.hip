@@ -21,16 +21,6 @@
 
 using namespace mmk;
 
-// environment switches of the DIAGNOSTIC build (phase stamps, timing experiments): the product library does not read them
-static inline const char* diag_env(const char* name) {
-#ifdef MMK_DIAG
-  return getenv(name);
-#else
-  (void)name;
-  return nullptr;
-#endif
-}
-
 struct WnCall {
   int M = 0;
   const void* in0 = nullptr;
@@ -44,6 +34,7 @@ struct WnCall {
 };
 
 struct mmk_wavenet_plan {
+  Tuning tune;                  // the config's execution switches (plan_util.h): never the environment in the product library
   mmk_wavenet_config cfg;
   Binder binder;
   bool committed = false;
@@ -324,7 +315,7 @@ static int derive(mmk_wavenet_plan* p) {
   // Geometry it covers: gated k=2 layers, embedding input, MLP head without extra hidden layers,
   // C = skips = residuals in {32..256 step 32}, at most one conditioning input of a multiple of 16
   // channels.  Anything else stays on the per-layer launch path.
-  const char* env = getenv("MMK_WN_PERSISTENT");
+  const char* env = p->tune.get("MMK_WN_PERSISTENT");
   bool ok = !(env && env[0] == '0') && c.exec_mode != 1;     // (exec_mode 1: the caller asks for the per-layer launch path)
   ok = ok && c.gated && c.q_levels > 0 && c.head_kind == 0 && c.mlp_n_hidden == 0 && c.n_cond <= 1;
   ok = ok && p->C % 32 == 0 && p->C <= 256 && p->S == p->C && c.residuals_dim == p->C && !c.layerwise_inputs && !c.with_affine_residuals;
@@ -356,12 +347,15 @@ static int derive(mmk_wavenet_plan* p) {
     // ... and it pays where the XCD's L2 (4 MiB) holds its weights: the pre-multiplied matrices are a third more bytes,
     // and a layer set that has to come over the fabric every step is bound by that stream (measured, DESIGN.md 5.2:
     // cfg 4 streams 62 MB per XCD and step at ~0.9 TB/s = 70 us, more than the two-hand-off kernel takes)
-    const char* chenv = getenv("MMK_WN_CHAIN");
-    const bool chain_fits_l2 = (int64_t)p->L * 8 * p->C * p->C * 4 <= ((int64_t)3 << 20);
-    bool chain_wanted = p->L >= 2 && (chenv ? chenv[0] != '0' : chain_fits_l2);
+    // (round 4's sweep, DESIGN 5.6: up to 128 channels the one-hand-off kernel is the fastest wherever it runs - 44 against 57 us per step at
+    //  64 channels x 30 layers, 20 against 40 at 128 x 10, 48 against 62 - 64 at 128 x 30 -, whether its pre-multiplied matrices fit an L2 or
+    //  not; at 256 channels it loses to the other kernels)
+    const char* chenv = p->tune.get("MMK_WN_CHAIN");
+    const bool chain_default = p->C <= 128;
+    bool chain_wanted = p->L >= 2 && (chenv ? chenv[0] != '0' : chain_default);
     for (int l = 0; l + 1 < p->L; ++l) chain_wanted = chain_wanted && p->has_res[l];
     if (chain_wanted && (p->Bmax + 3) / 4 <= gc_max) gc = (p->Bmax + 3) / 4;
-    const char* genv = getenv("MMK_WN_GROUPS");
+    const char* genv = p->tune.get("MMK_WN_GROUPS");
     if (genv && atoi(genv) > 0) gc = atoi(genv);
     if (gc < (p->Bmax + mg_cap - 1) / mg_cap) gc = (p->Bmax + mg_cap - 1) / mg_cap;
     if (gc > gc_max) gc = gc_max;
@@ -369,7 +363,7 @@ static int derive(mmk_wavenet_plan* p) {
     p->Mg = (p->Bmax + gc - 1) / gc;
     p->Gc = (p->Bmax + p->Mg - 1) / p->Mg;
     // XCD-local mode: always 8 groups (one per XCD, some possibly without clips), 8 * Gn workgroups
-    const char* xenv = getenv("MMK_WN_XCD_LOCAL");
+    const char* xenv = p->tune.get("MMK_WN_XCD_LOCAL");
     p->xcd_local = !(xenv && xenv[0] == '0') && n_xcc == 8 && 8 * p->Gn <= n_cu && (p->Bmax + 7) / 8 <= mg_cap;
     if (p->xcd_local) {
       p->Gc = 8;
@@ -406,13 +400,17 @@ static int derive(mmk_wavenet_plan* p) {
   // MMK_WN_CHAIN=1), turns it off.
   p->spipe = false;
   if (ok) {
-    const char* senv = getenv("MMK_WN_SPIPE");
-    const char* fenv = getenv("MMK_WN_PREFILL");
-    const char* penv = getenv("MMK_WN_PIPE");
-    const char* cenv = getenv("MMK_WN_CHAIN");
+    const char* senv = p->tune.get("MMK_WN_SPIPE");
+    const char* fenv = p->tune.get("MMK_WN_PREFILL");
+    const char* penv = p->tune.get("MMK_WN_PIPE");
+    const char* cenv = p->tune.get("MMK_WN_CHAIN");
     bool ok5 = !(senv && senv[0] == '0') && !(fenv && fenv[0] == '0') && !(penv && penv[0] == '1') && !(cenv && cenv[0] == '1');
     ok5 = ok5 && n_xcc == 8 && n_cu == 256 && c.q_levels == 256;
     ok5 = ok5 && wn_spipe_supported(p->C, p->S, c.mlp_hidden, c.out_dim, p->L, c.n_cond, c.n_cond == 1 ? c.cond_dim[0] : 0, p->Bmax);
+    // A ring of few stages is beat-bound early (one clip's trip: ~1.3 us per stage; ~1.25 us per clip once the clips queue up): 10 layers x 32 clips
+    // 38 us per step against 31 on the two-hand-off kernel, x 64 clips 74 against 43 (round 4's sweep).  Asked for by name
+    // (MMK_WN_SPIPE=1) it is taken all the same.
+    if (!(senv && senv[0] == '1') && p->L <= 15 && 1.25 * p->Bmax > 3.0 * p->L + 8.0) ok5 = false;
     if (ok5) {
       p->spipe = true;
       p->persistent = true;
@@ -429,10 +427,9 @@ static int derive(mmk_wavenet_plan* p) {
   p->chain = false;
   p->Ac.clear();
   if (p->persistent && !p->spipe) {
-    const char* cenv = getenv("MMK_WN_CHAIN");
-    const bool fits_l2 = (int64_t)p->L * 8 * p->C * p->C * 4 <= ((int64_t)3 << 20);
-    const char* pforce = getenv("MMK_WN_PIPE");
-    bool ok2 = (cenv ? cenv[0] != '0' : fits_l2) && wn_chain_supported(p->C, p->Mg, p->L) && !(pforce && pforce[0] == '1');
+    const char* cenv = p->tune.get("MMK_WN_CHAIN");
+    const char* pforce = p->tune.get("MMK_WN_PIPE");
+    bool ok2 = (cenv ? cenv[0] != '0' : p->C <= 128) && wn_chain_supported(p->C, p->Mg, p->L) && !(pforce && pforce[0] == '1');
     for (int l = 0; l + 1 < p->L; ++l) ok2 = ok2 && p->has_res[l];
     if (ok2) {
       WnChainArgs probe = {};
@@ -451,10 +448,12 @@ static int derive(mmk_wavenet_plan* p) {
   // history rings are laid out per stage, the teacher-forced mode of wavenet_persist.hip cannot fill them).
   p->pipe = false;
   if (p->persistent && !p->chain && !p->spipe) {
-    const char* penv = getenv("MMK_WN_PIPE");
-    const char* fenv = getenv("MMK_WN_PREFILL");
+    const char* penv = p->tune.get("MMK_WN_PIPE");
+    const char* fenv = p->tune.get("MMK_WN_PREFILL");
     const bool fits_l2 = (int64_t)p->L * 8 * p->C * p->C * 4 <= ((int64_t)3 << 20);
-    bool ok3 = (penv ? penv[0] != '0' : !fits_l2) && !(fenv && fenv[0] == '0') && n_xcc == 8 && 8 * p->Gn <= n_cu && p->Bmax <= 32;
+    // (default: 256-channel networks whose layer set does not fit an L2 and that the stage pipeline does not take - more than 31 layers, another
+    //  head width; at 128 channels and below it loses to the one- and the two-hand-off kernel everywhere)
+    bool ok3 = (penv ? penv[0] != '0' : (!fits_l2 && p->C > 128)) && !(fenv && fenv[0] == '0') && n_xcc == 8 && 8 * p->Gn <= n_cu && p->Bmax <= 32;
     for (int l = 0; l + 1 < p->L; ++l) ok3 = ok3 && p->has_res[l];
     const int mg = (p->Bmax + 7) / 8, gc = (p->Bmax + mg - 1) / mg;
     ok3 = ok3 && wn_pipe_supported(p->C, mg, gc, p->L) && c.mlp_hidden <= p->C;   // (the skip-row owners take the H1 / 16 hidden-unit tiles)
@@ -493,8 +492,8 @@ static int derive(mmk_wavenet_plan* p) {
   // all resident, four per clip on one XCD; the warm-up is the prefill, scattered into the launch path's rings.  MMK_WN_LPIPE=0: off.
   p->lpipe = false;
   if (p->persistent && !p->pipe && !p->spipe) {
-    const char* lenv = getenv("MMK_WN_LPIPE");
-    const char* fenv = getenv("MMK_WN_PREFILL");
+    const char* lenv = p->tune.get("MMK_WN_LPIPE");
+    const char* fenv = p->tune.get("MMK_WN_PREFILL");
     bool ok4 = !(lenv && lenv[0] == '0') && !(fenv && fenv[0] == '0') && n_xcc == 8 && 32 * ((p->Bmax + 7) / 8) <= n_cu && c.q_levels == 256;
     ok4 = ok4 && wn_lpipe_supported(p->C, p->S, c.mlp_hidden, c.out_dim, p->L, c.n_cond, p->Bmax);
     for (int l = 0; l + 1 < p->L; ++l) ok4 = ok4 && p->has_res[l];
@@ -507,6 +506,7 @@ extern "C" int mmk_wavenet_plan_create(const mmk_wavenet_config* cfg, mmk_wavene
   if (!cfg || !out) return fail(MMK_ERR_INVALID, "wavenet_plan_create: null argument");
   mmk_wavenet_plan* p = new mmk_wavenet_plan();
   p->cfg = *cfg;
+  p->tune.parse(cfg->tuning, sizeof(cfg->tuning));
   int rc = derive(p);
   if (rc != MMK_OK) {
     delete p;
@@ -789,7 +789,7 @@ extern "C" int mmk_wavenet_commit(mmk_wavenet_plan* p, void* workspace, size_t w
       tab[l].B_bias = p->Bm[l].bias;
     }
 #ifdef MMK_DIAG
-    if (const char* x = getenv("MMK_WN_EXPERIMENT_SAME_WEIGHTS"); x && x[0] == '1') {
+    if (const char* x = p->tune.get("MMK_WN_EXPERIMENT_SAME_WEIGHTS"); x && x[0] == '1') {
       // timing experiment only (results are wrong; diagnostic build): every layer reads layer 0's weights, which then stay in L2
       for (int l = 1; l < L; ++l) { tab[l].A_wp = tab[0].A_wp; tab[l].B_wp = tab[0].B_wp; }
     }
@@ -979,7 +979,7 @@ static int run_persistent(mmk_wavenet_plan* p, const WnCall& call, int64_t tau0,
     }
     // hand-off words are zeroed before EVERY launch (epochs restart at 1); the error word after them is sticky
     MMK_HIP(hipMemsetAsync(p->gran_h, 0, (size_t)(p->gran_words - 2) * sizeof(unsigned long long), st));
-    const char* stamp_env = diag_env("MMK_WN_STAMPS");
+    const char* stamp_env = diag_only("MMK_WN_STAMPS");
     if (p->lpipe) {
       if (!with_head) return fail(MMK_ERR_STATE, "wavenet: the layer-pipeline kernel has no teacher-forced mode (warm-up is a prefill)");
       MMK_HIP(hipMemsetAsync(p->lp_xg, 0, (size_t)p->lp_gran_words * sizeof(unsigned long long), st));
@@ -1000,7 +1000,7 @@ static int run_persistent(mmk_wavenet_plan* p, const WnCall& call, int64_t tau0,
       k.xg = p->lp_xg; k.cg = p->lp_cg; k.err_flag = p->err_flag;
       k.xcc_ids = reinterpret_cast<unsigned*>(p->lp_cg + (int64_t)p->Bmax * 16);
       {
-        const char* xe = getenv("MMK_WN_XCD_LOCAL");
+        const char* xe = p->tune.get("MMK_WN_XCD_LOCAL");
         k.xcd_local = !(xe && xe[0] == '0');
       }
       MMK_TRY(launch_wavenet_lpipe(k, st));
@@ -1026,8 +1026,8 @@ static int run_persistent(mmk_wavenet_plan* p, const WnCall& call, int64_t tau0,
       k.logits_out = p->logits; k.logits_ld = p->logits_ld;
       k.msg = p->sp_msg; k.hidmsg = p->sp_hidmsg; k.hidgrp = p->sp_hidgrp; k.xcd_count = p->xcd_count; k.err_flag = p->err_flag;
       k.stamps = (stamp_env && stamp_env[0] == '1') ? reinterpret_cast<unsigned long long*>(p->tau + 8) : nullptr;
-      k.stamp_stage = diag_env("MMK_WN_STAMP_STAGE") ? atoi(diag_env("MMK_WN_STAMP_STAGE")) : 1;
-      k.dbg = (k.stamps && diag_env("MMK_WN_SPIPE_DBG")) ? atoi(diag_env("MMK_WN_SPIPE_DBG")) : 0;
+      k.stamp_stage = diag_only("MMK_WN_STAMP_STAGE") ? atoi(diag_only("MMK_WN_STAMP_STAGE")) : 1;
+      k.dbg = (k.stamps && diag_only("MMK_WN_SPIPE_DBG")) ? atoi(diag_only("MMK_WN_SPIPE_DBG")) : 0;
       MMK_TRY(launch_wavenet_spipe(k, st));
       done += nb;
       continue;
@@ -1054,9 +1054,9 @@ static int run_persistent(mmk_wavenet_plan* p, const WnCall& call, int64_t tau0,
       k.gran_skip = p->gran_skip; k.gran_hid = p->gran_hid; k.gran_logit = p->gran_logit; k.gran_idx = p->gran_idx;
       k.h_rings = p->h_rings; k.err_flag = p->err_flag; k.xcd_count = p->xcd_count;
       k.stamps = (stamp_env && stamp_env[0] == '1') ? reinterpret_cast<unsigned long long*>(p->tau + 8) : nullptr;
-      k.stamp_stage = getenv("MMK_WN_STAMP_STAGE") ? atoi(getenv("MMK_WN_STAMP_STAGE")) : 1;
-      k.stamp_owner = getenv("MMK_WN_STAMP_OWNER") ? atoi(getenv("MMK_WN_STAMP_OWNER")) : 1;
-      k.stamp_wave = getenv("MMK_WN_STAMP_WAVE") ? atoi(getenv("MMK_WN_STAMP_WAVE")) : 0;
+      k.stamp_stage = p->tune.get("MMK_WN_STAMP_STAGE") ? atoi(p->tune.get("MMK_WN_STAMP_STAGE")) : 1;
+      k.stamp_owner = p->tune.get("MMK_WN_STAMP_OWNER") ? atoi(p->tune.get("MMK_WN_STAMP_OWNER")) : 1;
+      k.stamp_wave = p->tune.get("MMK_WN_STAMP_WAVE") ? atoi(p->tune.get("MMK_WN_STAMP_WAVE")) : 0;
       MMK_TRY(launch_wavenet_pipe(k, st));
       done += nb;
       continue;
@@ -1092,6 +1092,7 @@ static int run_persistent(mmk_wavenet_plan* p, const WnCall& call, int64_t tau0,
     a.q_levels = c.q_levels; a.H1 = c.mlp_hidden; a.n_classes = c.out_dim; a.n_logits_pad = p->n_logits_pad;
     a.learn_temp = c.learn_temp; a.min_temp = c.min_temp;
     a.teacher_forced = with_head ? 0 : 1;
+    { const char* sm = p->tune.get("MMK_WN_SMALL"); a.force_tiles = (sm && sm[0] == '0') ? 1 : 0; }
     a.tf_end = tau0 + n;   // warm-up: generation starts consuming here
     a.xcd_local = p->xcd_local ? 1 : 0;
     a.xcd_count = p->xcd_count;
@@ -1108,7 +1109,7 @@ static int run_persistent(mmk_wavenet_plan* p, const WnCall& call, int64_t tau0,
     a.gran_logit = p->gran_logit; a.gran_idx = p->gran_idx;
     a.h_rings = p->h_rings; a.err_flag = p->err_flag;
     {
-      const char* senv = diag_env("MMK_WN_STAMPS");
+      const char* senv = diag_only("MMK_WN_STAMPS");
       a.stamps = (senv && senv[0] == '1') ? reinterpret_cast<unsigned long long*>(p->tau + 8) : nullptr;
     }
     MMK_TRY(launch_wavenet_persist(a, st));
@@ -1254,7 +1255,7 @@ extern "C" int mmk_wavenet_warmup(mmk_wavenet_plan* p, int32_t batch, const void
   MMK_TRY(check_call(p, batch, in0, cond, cond_row_stride, call));
   call.in0_rs = in0_row_stride;
   if (t_begin < 0 || t_end < t_begin) return fail(MMK_ERR_INVALID, "wavenet_warmup: bad range [%lld, %lld)", (long long)t_begin, (long long)t_end);
-  const char* penv = getenv("MMK_WN_PREFILL");
+  const char* penv = p->tune.get("MMK_WN_PREFILL");
   if (p->pipe || p->lpipe || p->spipe) {
     // the stage-owned rings are only filled by the prefill; a longer window than the receptive field adds nothing to the
     // ring entries generation reads (each is determined by the rf - 1 positions before t_end)
@@ -1352,7 +1353,7 @@ extern "C" int mmk_wavenet_sync_status(mmk_wavenet_plan* p, mmk_stream_t stream)
     return fail(MMK_ERR_STATE, "wavenet: a hand-off inside the persistent kernel timed out - its workgroups were not all resident (another kernel "
                 "holding CUs?); the samples of this call are invalid, rerun it (MMK_WN_PERSISTENT=0 selects the per-layer launch path)");
   {
-    const char* senv = diag_env("MMK_WN_STAMPS");
+    const char* senv = diag_only("MMK_WN_STAMPS");
     if (senv && senv[0] == '1') {
       unsigned long long st[176];
       MMK_HIP(hipMemcpy(st, p->tau + 8, p->spipe ? sizeof(st) : 24 * sizeof(unsigned long long), hipMemcpyDeviceToHost));

@@ -7,7 +7,7 @@ stream.  A missing library, or a tensor that is not on a HIP device, raises.
 """
 import ctypes as C
 import os
-from typing import Optional, Sequence
+from typing import Dict, Optional, Sequence
 
 import torch
 
@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmmk_hip_diag.so" if os.environ.get("MMK_DIAG_LIB") == "1" else "libmmk_hip.so")
 
 MAX_LAYERS, MAX_COND, MAX_TIERS = 128, 4, 8
-ABI_VERSION = 2          # include/mmk.h: MMK_ABI_VERSION (bumped whenever a config struct or a signature changes)
+ABI_VERSION = 3          # include/mmk.h: MMK_ABI_VERSION (bumped whenever a config struct or a signature changes)
 ACT = {"none": 0, None: 0, "Identity": 0, "Tanh": 1, "Sigmoid": 2, "Mish": 3, "Abs": 4, "ReLU": 5}
 
 i32, i64, f32, vp, cp = C.c_int32, C.c_int64, C.c_float, C.c_void_p, C.c_char_p
@@ -25,6 +25,24 @@ i32, i64, f32, vp, cp = C.c_int32, C.c_int64, C.c_float, C.c_void_p, C.c_char_p
 
 class NativeError(RuntimeError):
     pass
+
+
+TUNING_CHARS = 256        # include/mmk.h: MMK_TUNING_CHARS
+
+# Execution switches handed to every plan this process creates, as {"MMK_WN_CHAIN": "0", ...} (merged under a network's own
+# ``exec_tuning``).  They travel inside the plan's config (``tuning``): the library reads no environment variable, so nothing outside
+# this dictionary and the network decides which kernel a plan gets.  The parity tests use it to put one network on every kernel.
+PLAN_TUNING: Dict[str, str] = {}
+
+
+def tuning_text(*dicts) -> bytes:
+    merged = {}
+    for d in dicts:
+        merged.update(d or {})
+    text = ";".join(f"{k}={v}" for k, v in merged.items())
+    if len(text) >= TUNING_CHARS:
+        raise ValueError(f"execution switches do not fit the config's {TUNING_CHARS} characters: {text}")
+    return text.encode()
 
 
 class WaveNetConfig(C.Structure):
@@ -35,6 +53,7 @@ class WaveNetConfig(C.Structure):
         ("bias", i32), ("gated", i32), ("head_kind", i32), ("mlp_hidden", i32), ("mlp_n_hidden", i32),
         ("out_dim", i32), ("learn_temp", i32), ("min_temp", f32), ("max_batch", i32),
         ("res_explicit", i32), ("layer_has_res", i32 * MAX_LAYERS), ("layerwise_inputs", i32), ("exec_mode", i32), ("with_affine_residuals", i32),
+        ("tuning", C.c_char * TUNING_CHARS),
     ]
 
 
@@ -43,6 +62,7 @@ class SrnnConfig(C.Structure):
         ("n_tiers", i32), ("frame_size", i32 * MAX_TIERS), ("hidden_dim", i32), ("rnn_kind", i32),
         ("rnn_bias", i32), ("h0_ones", i32), ("q_levels", i32), ("mlp_hidden", i32), ("mlp_n_hidden", i32),
         ("learn_temp", i32), ("min_temp", f32), ("max_batch", i32), ("n_rnn", i32), ("exec_mode", i32),
+        ("tuning", C.c_char * TUNING_CHARS),
     ]
 
 
@@ -53,6 +73,7 @@ class S2SConfig(C.Structure):
         ("enc_apply_residuals", i32), ("dec_apply_residuals", i32),
         ("in_classes", i32), ("head_kind", i32), ("mlp_hidden", i32), ("mlp_n_hidden", i32), ("learn_temp", i32), ("min_temp", f32),
         ("exec_mode", i32),
+        ("tuning", C.c_char * TUNING_CHARS),
     ]
 
 
@@ -361,6 +382,8 @@ class _Plan:
         if self.device.type != "cuda":
             raise RuntimeError(f"plans live on the HIP device; got '{device}' (no CPU implementation in this package)")
         self.cfg = cfg_struct
+        if not cfg_struct.tuning:         # (a network's own switches are already in it; the process-wide ones otherwise)
+            cfg_struct.tuning = tuning_text(PLAN_TUNING)
         handle = vp()
         check(getattr(self._lib, self._prefix + "_plan_create")(C.byref(cfg_struct), C.byref(handle)),
               self._prefix + "_plan_create")

@@ -258,10 +258,12 @@ class Seq2SeqLSTMNetwork(ARMWithHidden, nn.Module):
         c.enc_apply_residuals, c.dec_apply_residuals = int(cfg.enc_apply_residuals), int(cfg.dec_apply_residuals)
         c.max_batch = max_batch
         c.exec_mode = int(self._exec_mode)
+        c.tuning = native.tuning_text(native.PLAN_TUNING, self.exec_tuning)       # execution switches of this plan (never the environment)
         return c
 
     _blocks = ()            # generate_block calls since before_generate: (tensor, t0, n_steps)
     _exec_mode = 0          # 1 while a call is being redone with one launch per frame (mmk_s2s_config.exec_mode)
+    exec_tuning: dict = {}   # execution switches of THIS network's plans ({"MMK_...": "0"}: include/mmk.h `tuning`); merged over native.PLAN_TUNING
     _resident_seen = 0
     _plan_stale = False     # the plan is the one-launch-per-frame plan of a repeated call: replaced at the next _ensure_plan
 

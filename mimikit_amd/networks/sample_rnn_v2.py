@@ -204,6 +204,7 @@ class SampleRNN(ARMWithHidden, nn.Module):
 
     # -- HIP plan ---------------------------------------------------------------------
     _exec_mode = 0          # 1 while a batch is being redone with the kernels in turns (mmk_srnn_config.exec_mode)
+    exec_tuning: dict = {}   # execution switches of THIS network's plans ({"MMK_...": "0"}: include/mmk.h `tuning`); merged over native.PLAN_TUNING
 
     def _describe(self, max_batch: int) -> native.SrnnConfig:
         cfg, io = self._config, self._config.io_spec
@@ -245,6 +246,7 @@ class SampleRNN(ARMWithHidden, nn.Module):
         c.rnn_bias = int(cfg.rnn_bias)
         c.n_rnn = int(cfg.n_rnn)
         c.exec_mode = int(self._exec_mode)
+        c.tuning = native.tuning_text(native.PLAN_TUNING, self.exec_tuning)       # execution switches of this plan (never the environment)
         c.h0_ones = int(str(cfg.h0_init) == "ones")
         c.max_batch = max_batch
         return c

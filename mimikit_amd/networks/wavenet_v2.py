@@ -294,6 +294,7 @@ class WaveNet(ARM, nn.Module):
 
     # -- HIP plan ---------------------------------------------------------------------
     _exec_mode = 0          # 1 while a batch is being redone on the per-layer launch path (mmk_wavenet_config.exec_mode)
+    exec_tuning: dict = {}   # execution switches of THIS network's plans ({"MMK_...": "0"}: include/mmk.h `tuning`); merged over native.PLAN_TUNING
 
     def _describe(self, max_batch: int) -> native.WaveNetConfig:
         cfg, io = self._config, self._config.io_spec
@@ -321,6 +322,7 @@ class WaveNet(ARM, nn.Module):
             c.kernel_size[i], c.dilation[i] = layer.kernel_size, layer.dilation
             c.layer_has_res[i] = int(layer.has_residuals)
         c.exec_mode = int(self._exec_mode)
+        c.tuning = native.tuning_text(native.PLAN_TUNING, self.exec_tuning)       # execution switches of this plan (never the environment)
         c.layerwise_inputs = int(cfg.layerwise_inputs)
         c.with_affine_residuals = int(cfg.with_affine_residuals)
         first = self.input_modules[0][0]

@@ -8,8 +8,8 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-os.environ["MMK_SRNN_FUSED"] = "1"
 import mimikit_amd as mmk  # noqa: E402
+mmk.native.PLAN_TUNING["MMK_SRNN_FUSED"] = "1"          # (execution switches travel in the plan config: include/mmk.h `tuning`)
 from tests import helpers as H  # noqa: E402
 
 torch.set_grad_enabled(False)
@@ -30,7 +30,7 @@ for case in range(n_cases):
     prompt = torch.randint(0, 256, (B, P), generator=torch.Generator().manual_seed(case))
     outs = []
     for resident, split in (("1", False), ("1", True), ("1", False), ("0", False)):
-        os.environ["MMK_SRNN_RESIDENT"] = resident
+        mmk.native.PLAN_TUNING["MMK_SRNN_RESIDENT"] = resident
         net, _, _ = H.srnn("big", hidden=hidden, mlp_dim=128, seed=200 + case, frame_sizes=fs, kind=kind)
         net = net.to(device)
         idx = torch.cat([prompt, torch.zeros(B, n, dtype=torch.int64)], 1).to(device)

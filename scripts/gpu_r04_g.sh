@@ -1,0 +1,7 @@
+#!/bin/bash
+# round 4: the whole GPU suite on the library without environment switches, then the WaveNet path sweep
+mkdir -p gpurun_out/r04
+export TMPDIR=/tmp
+timeout 2400 python -m pytest tests -m gpu -q -x 2>&1 | tail -6
+timeout 1500 python scripts/wn_path_sweep.py --steps 192 --out gpurun_out/r04/wn_path_sweep.json 2> gpurun_out/r04/wn_path_sweep.err | tee gpurun_out/r04/wn_path_sweep.log | tail -45
+tail -3 gpurun_out/r04/wn_path_sweep.err

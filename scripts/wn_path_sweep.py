@@ -15,13 +15,13 @@ import mimikit_amd as mmk  # noqa: E402
 
 torch.set_grad_enabled(False)
 KNOBS = ("MMK_WN_PERSISTENT", "MMK_WN_CHAIN", "MMK_WN_PIPE", "MMK_WN_LPIPE", "MMK_WN_SPIPE")
-PATHS = {                   # forced through the environment the plan reads when it is created
+PATHS = {                   # forced through the plan's `tuning` switches (native.PLAN_TUNING)
     "launch": dict(MMK_WN_PERSISTENT="0"),
     "persist": dict(MMK_WN_SPIPE="0", MMK_WN_CHAIN="0", MMK_WN_PIPE="0", MMK_WN_LPIPE="0"),
     "chain": dict(MMK_WN_SPIPE="0", MMK_WN_CHAIN="1"),
     "pipe": dict(MMK_WN_SPIPE="0", MMK_WN_CHAIN="0", MMK_WN_PIPE="1"),
     "lpipe": dict(MMK_WN_SPIPE="0", MMK_WN_CHAIN="0", MMK_WN_PIPE="0", MMK_WN_LPIPE="1"),
-    "spipe": dict(),
+    "spipe": dict(MMK_WN_SPIPE="1"),
     "default": None,        # whatever the plan picks on its own
 }
 MODE_NAMES = {0: "launch", 1: "persist", 2: "chain", 3: "pipe", 4: "lpipe", 5: "spipe"}
@@ -77,10 +77,9 @@ def main():
                 for B in [int(x) for x in args.clips.split(",")]:
                     row = {"C": C, "L": sum(blocks), "cond": cond, "B": B, "us": {}, "ran": {}}
                     for name, env in PATHS.items():
-                        for k in KNOBS:
-                            os.environ.pop(k, None)
+                        mmk.native.PLAN_TUNING.clear()          # (the switches travel in the plan's config: include/mmk.h `tuning`)
                         if env:
-                            os.environ.update(env)
+                            mmk.native.PLAN_TUNING.update(env)
                         net._plan = None
                         try:
                             us, ran = run(net, B, args.steps, cond_dim, device)
@@ -95,8 +94,7 @@ def main():
                 net._plan = None
                 del net
                 torch.cuda.empty_cache()
-    for k in KNOBS:
-        os.environ.pop(k, None)
+    mmk.native.PLAN_TUNING.clear()
     os.makedirs(os.path.dirname(args.out), exist_ok=True)
     with open(args.out, "w") as f:
         json.dump(rows, f, indent=1)

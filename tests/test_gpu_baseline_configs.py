@@ -246,9 +246,9 @@ def test_cfg4_composed_products_against_the_reference_association(device, monkey
     raws = {}
     for mode, env in (("composed", {}), ("reference association", {"MMK_WN_PERSISTENT": "0"})):
         for k in ("MMK_WN_PERSISTENT", "MMK_WN_SPIPE", "MMK_WN_PIPE", "MMK_WN_CHAIN"):
-            monkeypatch.delenv(k, raising=False)
+            monkeypatch.delitem(mmk.native.PLAN_TUNING, k, raising=False)
         for k, v in env.items():
-            monkeypatch.setenv(k, v)
+            monkeypatch.setitem(mmk.native.PLAN_TUNING, k, v)
         net._plan = None
         net.generate_step((win.to(device), cond[:, :rf].to(device)), t=rf)
         assert net._plan.stage_pipelined == (mode == "composed")
@@ -278,9 +278,9 @@ def test_cfg5_composed_products_against_the_reference_association(device, monkey
         want = O.s2s_step(sd, x, hop=8)
     outs = {}
     for mode, env in (("composed", None), ("reference association", "0")):
-        monkeypatch.delenv("MMK_S2S_COMPOSED", raising=False)
+        monkeypatch.delitem(mmk.native.PLAN_TUNING, "MMK_S2S_COMPOSED", raising=False)
         if env is not None:
-            monkeypatch.setenv("MMK_S2S_COMPOSED", env)
+            monkeypatch.setitem(mmk.native.PLAN_TUNING, "MMK_S2S_COMPOSED", env)
         net._plan = None
         outs[mode] = net.generate_step((x.to(device),), t=8).cpu()
     scale = float(want.abs().max())

@@ -181,7 +181,7 @@ def test_sample_rnn_weight_norm_matches_reference_golden(device, monkeypatch, ta
     and one launch per op); classes bit-exact against the reference's loop"""
     import warnings
     warnings.filterwarnings("ignore")
-    monkeypatch.setenv("MMK_SRNN_FUSED", fused)
+    monkeypatch.setitem(mmk.native.PLAN_TUNING, "MMK_SRNN_FUSED", fused)
     g = H.golden("srnn_wn.npz")
     assert bool(H.margin_ok(g[f"{tag}_raw"].reshape(3, 40, 257)).all())
     net, sd, _ = H.srnn(tag, weight_norm=True)
@@ -227,8 +227,8 @@ def test_sample_rnn_cfg3_shape_vs_oracle(device, monkeypatch, fused, frame_sizes
     fused bottom-tier kernel (several steps per launch) and with one launch per op; bottom frames of 2 samples, ragged
     last workgroup; LSTM tiers (the reference's default) through the fused tier kernel; "1u": the fused tier kernel with
     the up-sampler as its own launch instead of behind the kernel's grid barrier"""
-    monkeypatch.setenv("MMK_SRNN_FUSED", fused[0])
-    monkeypatch.setenv("MMK_SRNN_FUSED_UP", "0" if fused.endswith("u") else "1")
+    monkeypatch.setitem(mmk.native.PLAN_TUNING, "MMK_SRNN_FUSED", fused[0])
+    monkeypatch.setitem(mmk.native.PLAN_TUNING, "MMK_SRNN_FUSED_UP", "0" if fused.endswith("u") else "1")
     net, sd, arch = H.srnn("big", hidden=128, mlp_dim=128, seed=77, frame_sizes=frame_sizes, kind=kind)
     gen = torch.Generator().manual_seed(8)
     prompt = torch.randint(0, 256, (batch, frame_sizes[0] * 5 + 7), generator=gen)
@@ -249,7 +249,7 @@ def test_sample_rnn_demo_geometry_vs_oracle(device, monkeypatch, fused):
     (256, 128, 64, 32, 16, 8, 4, 8), LSTM, hidden 128, weight_norm=True; 300 free-running steps against the oracle"""
     import warnings
     warnings.filterwarnings("ignore")
-    monkeypatch.setenv("MMK_SRNN_FUSED", fused)
+    monkeypatch.setitem(mmk.native.PLAN_TUNING, "MMK_SRNN_FUSED", fused)
     fs = (256, 128, 64, 32, 16, 8, 4, 8)
     net, sd, arch = H.srnn("demo", hidden=128, mlp_dim=128, seed=81, frame_sizes=fs, kind="lstm", weight_norm=True)
     gen = torch.Generator().manual_seed(10)
@@ -269,12 +269,12 @@ def test_sample_rnn_grid_barrier_is_deterministic(device, monkeypatch):
     """the up-sampler phase of the tier kernel reads rows that workgroups on other XCDs have just written (write-through
     stores, agent-scope loads, one grid-wide barrier): H = 512, 64 clips, the same generation five times, bit-identical,
     and identical to the path with the up-sampler as a separate launch"""
-    monkeypatch.setenv("MMK_SRNN_FUSED", "1")
+    monkeypatch.setitem(mmk.native.PLAN_TUNING, "MMK_SRNN_FUSED", "1")
     gen = torch.Generator().manual_seed(12)
     prompt = torch.randint(0, 256, (64, 64), generator=gen).to(device)
     outs = []
     for fused_up in ("1", "1", "1", "1", "1", "0"):
-        monkeypatch.setenv("MMK_SRNN_FUSED_UP", fused_up)
+        monkeypatch.setitem(mmk.native.PLAN_TUNING, "MMK_SRNN_FUSED_UP", fused_up)
         net, _, _ = H.srnn("big", hidden=512, mlp_dim=128, seed=79, frame_sizes=(16, 4, 1), kind="gru")
         net = net.to(device)
         idx = torch.cat([prompt, torch.zeros(64, 320, dtype=torch.int64, device=device)], 1)
@@ -298,14 +298,14 @@ def test_sample_rnn_resident_mode_blocks_and_oracle(device, monkeypatch, kind):
     """resident mode (the bottom tier as one launch per block beside the tier kernels of a second stream): blocks that start
     between two updates of the tier above, a block too short for the mode in the middle, the same generation in one block and
     with the mode switched off - all identical, and equal to the oracle teacher-forced on the device's history"""
-    monkeypatch.setenv("MMK_SRNN_FUSED", "1")
+    monkeypatch.setitem(mmk.native.PLAN_TUNING, "MMK_SRNN_FUSED", "1")
     gen = torch.Generator().manual_seed(31)
     B, P = 21, 48                                   # a ragged last row tile
     prompt = torch.randint(0, 256, (B, P), generator=gen)
     splits = [(37, 5, 43, 16, 59), (160,)]          # 37 % 4 = 1: the next blocks start mid-frame; 5 < frame_sizes[0]: launch path
     outs, resident = [], []
     for env, parts in (("1", splits[0]), ("1", splits[1]), ("0", splits[1])):
-        monkeypatch.setenv("MMK_SRNN_RESIDENT", env)
+        monkeypatch.setitem(mmk.native.PLAN_TUNING, "MMK_SRNN_RESIDENT", env)
         net, sd, arch = H.srnn("big", hidden=256, mlp_dim=128, seed=83, frame_sizes=(16, 4, 1), kind=kind)
         net = net.to(device)
         idx = torch.cat([prompt, torch.zeros(B, 160, dtype=torch.int64)], 1).to(device)
@@ -337,8 +337,8 @@ def test_sample_rnn_resident_mode_geometries(device, monkeypatch, frame_sizes, b
     """resident mode over the tier geometries the fused kernels accept, with the pre-multiplied association of the input
     products (W_ih W_in, W0 wb) and with the reference's: classes equal to the oracle's, teacher-forced on the device's own
     history; the mode itself must have run"""
-    monkeypatch.setenv("MMK_SRNN_FUSED", "1")
-    monkeypatch.setenv("MMK_SRNN_COMPOSED", composed)
+    monkeypatch.setitem(mmk.native.PLAN_TUNING, "MMK_SRNN_FUSED", "1")
+    monkeypatch.setitem(mmk.native.PLAN_TUNING, "MMK_SRNN_COMPOSED", composed)
     net, sd, arch = H.srnn("big", hidden=hidden, mlp_dim=64, seed=91, frame_sizes=frame_sizes, kind=kind)
     net = net.to(device)
     rf = frame_sizes[0]
@@ -362,7 +362,7 @@ def test_sample_rnn_resident_mode_geometries(device, monkeypatch, frame_sizes, b
 def test_sample_rnn_timeout_is_redone_in_turns(device, monkeypatch):
     """a timed-out wait of the resident mode (injected through mmk_srnn_inject_sync_error) must not return invalid samples: the batch
     is regenerated with the kernels in turns, with a warning, and equals an undisturbed generation"""
-    monkeypatch.setenv("MMK_SRNN_FUSED", "1")
+    monkeypatch.setitem(mmk.native.PLAN_TUNING, "MMK_SRNN_FUSED", "1")
     net, sd, arch = H.srnn("big", hidden=128, mlp_dim=64, seed=93, frame_sizes=(16, 4, 1), kind="gru")
     net = net.to(device)
     prompt = torch.randint(0, 256, (5, 32), generator=torch.Generator().manual_seed(3))
@@ -389,7 +389,7 @@ def test_sample_rnn_timeout_is_redone_in_turns(device, monkeypatch):
 def test_sample_rnn_resident_mode_sampled_decode_and_reuse(device, monkeypatch):
     """resident mode with temperatures (uniforms indexed by the absolute step) and a second generation on the same plan
     (the granules of the first one must not satisfy the second one's waits)"""
-    monkeypatch.setenv("MMK_SRNN_FUSED", "1")
+    monkeypatch.setitem(mmk.native.PLAN_TUNING, "MMK_SRNN_FUSED", "1")
     net, sd, arch = H.srnn("big", hidden=128, mlp_dim=128, seed=84, frame_sizes=(16, 4, 1), kind="gru")
     net = net.to(device)
     o = O.SampleRNNOracle(sd, **arch)
@@ -416,7 +416,7 @@ def test_sample_rnn_resident_mode_sampled_decode_and_reuse(device, monkeypatch):
 
 def test_sample_rnn_fused_bottom_sampled_decode(device, monkeypatch):
     """temperature sampling through the fused bottom kernel against the oracle's inverse-CDF draw for the same uniforms"""
-    monkeypatch.setenv("MMK_SRNN_FUSED", "1")
+    monkeypatch.setitem(mmk.native.PLAN_TUNING, "MMK_SRNN_FUSED", "1")
     net, sd, arch = H.srnn("big", hidden=128, mlp_dim=128, seed=78, frame_sizes=(16, 4, 1), kind="gru")
     net = net.to(device)
     gen = torch.Generator().manual_seed(9)
@@ -529,7 +529,7 @@ def test_seq2seq_adds_up_several_continuous_inputs(device):
 def test_seq2seq_gemm_split_k(device, monkeypatch, ksplit):
     """the tiled GEMM with K cut over 1 / 2 / 3 / 8 workgroups per tile (uneven stage ranges, K = 513 with a ragged last stage) and
     the partial sums added in split order: against the oracle at 1e-4 of the largest output, and bit-identical from run to run"""
-    monkeypatch.setenv("MMK_GEMM_KSPLIT", ksplit)
+    monkeypatch.setitem(mmk.native.PLAN_TUNING, "MMK_GEMM_KSPLIT", ksplit)
     io = mmk.IOSpec.magspec_io(mmk.IOSpec.MagSpecIOConfig(sr=22050, n_fft=1024, hop_length=256))
     net = mmk.Seq2SeqLSTMNetwork.from_config(mmk.Seq2SeqLSTMNetwork.Config(io_spec=io, model_dim=128, hop=8)).eval()
     from oracle.weights import load_recipe
@@ -717,7 +717,7 @@ def test_seq2seq_cfg5_geometry_vs_oracle(device, monkeypatch, fused, hop, batch)
     LSTM time-step kernel (both directions per launch) and with one launch per op; an odd hop (state ends in the
     second buffer) with a ragged row tile; 264 and 135 rows (batch x hop >= 128) take the tiled GEMM for the
     input-to-hidden and output projections, with a ragged last row tile and K = 513"""
-    monkeypatch.setenv("MMK_S2S_FUSED", fused)
+    monkeypatch.setitem(mmk.native.PLAN_TUNING, "MMK_S2S_FUSED", fused)
     io = mmk.IOSpec.magspec_io(mmk.IOSpec.MagSpecIOConfig(sr=22050, n_fft=1024, hop_length=256))
     net = mmk.Seq2SeqLSTMNetwork.from_config(mmk.Seq2SeqLSTMNetwork.Config(io_spec=io, model_dim=128, hop=hop)).eval()
     from oracle.weights import load_recipe
@@ -739,7 +739,7 @@ def test_seq2seq_resident_bilstm_kernel_vs_oracle(device, monkeypatch, dim, hop,
     16-row blocks per workgroup, a ragged last block, one and several row halves, 2 .. 8 frames, stacked layers (the decoder's
     start from the encoder's final state) - three chained generate_steps against the oracle and against the per-frame kernel"""
     for k in ("MMK_S2S_FUSED", "MMK_S2S_SEQ"):
-        monkeypatch.delenv(k, raising=False)
+        monkeypatch.delitem(mmk.native.PLAN_TUNING, k, raising=False)
     io = mmk.IOSpec.magspec_io(mmk.IOSpec.MagSpecIOConfig(n_fft=128, hop_length=32))
     cfg = mmk.Seq2SeqLSTMNetwork.Config(io_spec=io, model_dim=dim, hop=hop, enc_n_lstm=layers, dec_n_lstm=layers)
     net = mmk.Seq2SeqLSTMNetwork.from_config(cfg).eval()
@@ -762,7 +762,7 @@ def test_seq2seq_resident_bilstm_kernel_vs_oracle(device, monkeypatch, dim, hop,
     assert float((got - want).abs().max()) <= 2e-4 * float(want.abs().max())
     again, _ = generate()
     assert torch.equal(again, got)                    # the exchange images alternate between launches: a second pass sees the same
-    monkeypatch.setenv("MMK_S2S_SEQ", "0")
+    monkeypatch.setitem(mmk.native.PLAN_TUNING, "MMK_S2S_SEQ", "0")
     net._plan = None
     per_frame, launches = generate()
     assert launches == 0
@@ -773,7 +773,7 @@ def test_seq2seq_timeout_is_redone_frame_by_frame(device, monkeypatch):
     """a timed-out wait inside the resident bi-LSTM kernel (injected through mmk_s2s_inject_sync_error) must not return invalid
     frames: the blocks of the generation are run again with one launch per frame, with a warning"""
     for k in ("MMK_S2S_FUSED", "MMK_S2S_SEQ"):
-        monkeypatch.delenv(k, raising=False)
+        monkeypatch.delitem(mmk.native.PLAN_TUNING, k, raising=False)
     io = mmk.IOSpec.magspec_io(mmk.IOSpec.MagSpecIOConfig(n_fft=128, hop_length=32))
     net = mmk.Seq2SeqLSTMNetwork.from_config(mmk.Seq2SeqLSTMNetwork.Config(io_spec=io, model_dim=128, hop=4)).eval()
     from oracle.weights import load_recipe
@@ -941,7 +941,7 @@ def test_wavenet_timeout_is_redone_on_launch_path(device, monkeypatch):
     blanks: the batch is regenerated on the per-layer launch path, with a warning; both generations are held to the oracle the way
     the modes test does (the two paths associate their sums differently)"""
     for k in ("MMK_WN_XCD_LOCAL", "MMK_WN_PERSISTENT", "MMK_WN_GROUPS", "MMK_WN_SMALL", "MMK_WN_PREFILL", "MMK_WN_CHAIN", "MMK_WN_PIPE"):
-        monkeypatch.delenv(k, raising=False)
+        monkeypatch.delitem(mmk.native.PLAN_TUNING, k, raising=False)
     net, sd, arch = _cond_net()
     net = net.to(device)
     gen = torch.Generator().manual_seed(23)
@@ -968,9 +968,9 @@ def test_wavenet_modes_agree_with_oracle(device, mode, monkeypatch):
     agent-scope hand-offs, 4x4 MFMA blocks and 16-row tiles, warm-up as a prefill and step by step - and the per-layer launch
     path all reproduce the oracle: conditioned net, batch 5 (ragged clip groups), prompt longer than rf, 70 steps, greedy + sampled"""
     for k in ("MMK_WN_XCD_LOCAL", "MMK_WN_PERSISTENT", "MMK_WN_GROUPS", "MMK_WN_SMALL", "MMK_WN_PREFILL", "MMK_WN_CHAIN", "MMK_WN_PIPE"):
-        monkeypatch.delenv(k, raising=False)
+        monkeypatch.delitem(mmk.native.PLAN_TUNING, k, raising=False)
     for k, v in MODES[mode].items():
-        monkeypatch.setenv(k, v)
+        monkeypatch.setitem(mmk.native.PLAN_TUNING, k, v)
     net, sd, arch = _cond_net()
     net = net.to(device)
     gen = torch.Generator().manual_seed(17)
@@ -1023,9 +1023,9 @@ def test_wavenet_layer_pipeline_agrees_with_oracle(device, monkeypatch, blocks, 
     prompt longer than rf, two generate blocks, greedy against the oracle (classes exact where the oracle's margin allows, last
     logits within tolerance) and sampled against the oracle's CDF intervals; and the same net with the mode switched off"""
     for k in ("MMK_WN_XCD_LOCAL", "MMK_WN_PERSISTENT", "MMK_WN_GROUPS", "MMK_WN_SMALL", "MMK_WN_PREFILL", "MMK_WN_CHAIN", "MMK_WN_PIPE", "MMK_WN_LPIPE"):
-        monkeypatch.delenv(k, raising=False)
+        monkeypatch.delitem(mmk.native.PLAN_TUNING, k, raising=False)
     for k, v in env.items():                 # (MMK_WN_XCD_LOCAL=0: every hand-over written through to memory)
-        monkeypatch.setenv(k, v)
+        monkeypatch.setitem(mmk.native.PLAN_TUNING, k, v)
     net, sd, arch = _small_net(blocks, seed=60 + len(blocks))
     net = net.to(device)
     gen = torch.Generator().manual_seed(29 + B)
@@ -1070,7 +1070,7 @@ def test_wavenet_layer_pipeline_agrees_with_oracle(device, monkeypatch, blocks, 
         net.after_generate((idx4,), None)
     assert bool(((idx4.cpu()[:, prompt.size(1):] == want[:, prompt.size(1):]) | first_bad).all())
     # switched off: the chain kernel generates the same classes wherever the margin allows
-    monkeypatch.setenv("MMK_WN_LPIPE", "0")
+    monkeypatch.setitem(mmk.native.PLAN_TUNING, "MMK_WN_LPIPE", "0")
     net2, _, _ = _small_net(blocks, seed=60 + len(blocks))
     net2 = net2.to(device)
     idx3 = torch.cat([prompt, torch.zeros(B, n, dtype=torch.int64)], 1).to(device)
@@ -1103,9 +1103,9 @@ def test_wavenet_persistent_kernel_shapes(device, monkeypatch, C, B, env):
     224 / 64 / 256 channels (3 / 5 / 7 / 2 / 8 K-chunks per matrix wave, odd counts split 2 + 1 ... between the two
     weight pieces), full and ragged groups of up to 4 clips, XCD-local and agent-scope"""
     for k in ("MMK_WN_XCD_LOCAL", "MMK_WN_PERSISTENT", "MMK_WN_GROUPS", "MMK_WN_SMALL", "MMK_WN_PREFILL", "MMK_WN_CHAIN", "MMK_WN_PIPE"):
-        monkeypatch.delenv(k, raising=False)
+        monkeypatch.delitem(mmk.native.PLAN_TUNING, k, raising=False)
     for k, v in env.items():
-        monkeypatch.setenv(k, v)
+        monkeypatch.setitem(mmk.native.PLAN_TUNING, k, v)
     net, sd, arch = _wide_net(C, 16, seed=40 + C)
     net = net.to(device)
     gen = torch.Generator().manual_seed(C + B)
@@ -1128,7 +1128,7 @@ def test_wavenet_persistent_kernel_shapes(device, monkeypatch, C, B, env):
 def test_wavenet_persistent_long_block_crosses_cond_blocks(device, monkeypatch):
     """more steps than one conditioning block (1024): two persistent launches chained through the product rings"""
     for k in ("MMK_WN_XCD_LOCAL", "MMK_WN_PERSISTENT", "MMK_WN_GROUPS", "MMK_WN_SMALL", "MMK_WN_PREFILL"):
-        monkeypatch.delenv(k, raising=False)
+        monkeypatch.delitem(mmk.native.PLAN_TUNING, k, raising=False)
     net, sd, arch = _cond_net(seed=22)
     net = net.to(device)
     gen = torch.Generator().manual_seed(3)
@@ -1236,8 +1236,8 @@ def test_wavenet_pipelined_kernel_shapes(device, monkeypatch, blocks, C, B, n):
     (9 / 19 / 4 / 31 / 32 iterations over 5 / 7 / 4 / 8 / 8 stages), full and ragged groups, one to eight groups in flight,
     more steps than one conditioning block (two launches chained through the stage-owned history rings), conditioned"""
     for k in ("MMK_WN_XCD_LOCAL", "MMK_WN_PERSISTENT", "MMK_WN_GROUPS", "MMK_WN_SMALL", "MMK_WN_PREFILL", "MMK_WN_CHAIN", "MMK_WN_PIPE"):
-        monkeypatch.delenv(k, raising=False)
-    monkeypatch.setenv("MMK_WN_PIPE", "1")
+        monkeypatch.delitem(mmk.native.PLAN_TUNING, k, raising=False)
+    monkeypatch.setitem(mmk.native.PLAN_TUNING, "MMK_WN_PIPE", "1")
     from oracle.weights import load_recipe
     io = H.mu_emb(mlp_dim=32)
     ext = mmk.Extractor("signal", mmk.FileToSignal(16000))
@@ -1304,7 +1304,7 @@ def test_wavenet_stage_pipeline_agrees_with_oracle(device, monkeypatch, blocks, 
     1 - 32 clips, with and without conditioning, more steps than one conditioning block (two launches chained through the rings);
     greedy, then sampled with the uniforms generate_block draws; the same generation twice is bit-identical"""
     for k in SPIPE_ENV:
-        monkeypatch.delenv(k, raising=False)
+        monkeypatch.delitem(mmk.native.PLAN_TUNING, k, raising=False)
     net, sd, arch = _cfg4_family_net(blocks, 300 + len(blocks) + B, cond)
     net = net.to(device)
     gen = torch.Generator().manual_seed(B + n)

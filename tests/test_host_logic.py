@@ -181,6 +181,43 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(native.EXPORTED_SYMBOLS), declared ^ set(native.EXPORTED_SYMBOLS)
 
 
+def _cfg4_plan_mode(tuning: bytes) -> int:
+    """create (not commit) a plan of BASELINE config 4's geometry and say which step path it chose (mmk_wavenet_mode)"""
+    lib = native.load_library()
+    cfg = native.WaveNetConfig()
+    cfg.n_layers, cfg.dim_dilated, cfg.residuals_dim, cfg.skips_dim, cfg.max_batch, cfg.q_levels = 30, 256, 256, 256, 32, 256
+    for l in range(30):
+        cfg.kernel_size[l], cfg.dilation[l] = 2, 2 ** (l % 10)
+    cfg.n_cond, cfg.cond_in_dim[0], cfg.cond_dim[0] = 1, 513, 256
+    cfg.mlp_hidden, cfg.out_dim, cfg.learn_temp, cfg.gated, cfg.bias = 128, 256, 1, 1, 1
+    cfg.tuning = tuning
+    handle = native.vp()
+    assert lib.mmk_wavenet_plan_create(native.C.byref(cfg), native.C.byref(handle)) == 0, lib.mmk_last_error()
+    mode = lib.mmk_wavenet_mode(handle)
+    lib.mmk_wavenet_plan_destroy(handle)
+    return mode
+
+
+def test_execution_switches_travel_in_the_config_not_in_the_environment(monkeypatch):
+    """which kernel a plan gets is decided by its config's `tuning` text (include/mmk.h) - an environment variable of the same name
+    changes nothing (round 3's library read ~35 of them at plan creation)"""
+    assert _cfg4_plan_mode(b"") == 5                                  # the stage pipeline
+    assert _cfg4_plan_mode(b"MMK_WN_SPIPE=0") == 3                    # the XCD-pipelined kernel
+    assert _cfg4_plan_mode(b"MMK_WN_SPIPE=0;MMK_WN_PIPE=0") in (1, 2)
+    assert _cfg4_plan_mode(b"MMK_WN_PERSISTENT=0") == 0               # the per-layer launch path
+    monkeypatch.setenv("MMK_WN_SPIPE", "0")
+    monkeypatch.setenv("MMK_WN_PERSISTENT", "0")
+    assert _cfg4_plan_mode(b"") == 5
+    assert native.tuning_text({"A": "1"}, {"B": "0", "A": "2"}) == b"A=2;B=0"
+    with pytest.raises(ValueError):
+        native.tuning_text({f"MMK_SWITCH_{i}": "1" for i in range(40)})
+    header = open(os.path.join(ROOT, "include", "mmk.h")).read()
+    assert int(re.search(r"#define MMK_TUNING_CHARS (\d+)", header).group(1)) == native.TUNING_CHARS
+    for src in os.listdir(os.path.join(ROOT, "mimikit_amd", "csrc")):
+        text = open(os.path.join(ROOT, "mimikit_amd", "csrc", src)).read()
+        assert text.count("getenv(") == (1 if src == "plan_util.h" else 0), f"{src} reads the environment"
+
+
 def test_abi_argument_validation_needs_no_gpu():
     lib = native.load_library()
     cfg = native.WaveNetConfig()
