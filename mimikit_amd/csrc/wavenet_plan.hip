@@ -453,7 +453,9 @@ static int derive(mmk_wavenet_plan* p) {
     const bool fits_l2 = (int64_t)p->L * 8 * p->C * p->C * 4 <= ((int64_t)3 << 20);
     // (default: 256-channel networks whose layer set does not fit an L2 and that the stage pipeline does not take - more than 31 layers, another
     //  head width; at 128 channels and below it loses to the one- and the two-hand-off kernel everywhere)
-    bool ok3 = (penv ? penv[0] != '0' : (!fits_l2 && p->C > 128)) && !(fenv && fenv[0] == '0') && n_xcc == 8 && 8 * p->Gn <= n_cu && p->Bmax <= 32;
+    //  (and from ~22 layers on: 256 x 10 x 32 clips 41.7 us per step against 31.2 on the two-hand-off kernel, 256 x 30 65 - 76 against 74 - 87: the
+    //   pipeline gains 1.35 us per layer, the two-hand-off kernel 2.3)
+    bool ok3 = (penv ? penv[0] != '0' : (!fits_l2 && p->C > 128 && p->L >= 22)) && !(fenv && fenv[0] == '0') && n_xcc == 8 && 8 * p->Gn <= n_cu && p->Bmax <= 32;
     for (int l = 0; l + 1 < p->L; ++l) ok3 = ok3 && p->has_res[l];
     const int mg = (p->Bmax + 7) / 8, gc = (p->Bmax + mg - 1) / mg;
     ok3 = ok3 && wn_pipe_supported(p->C, mg, gc, p->L) && c.mlp_hidden <= p->C;   // (the skip-row owners take the H1 / 16 hidden-unit tiles)

@@ -1305,6 +1305,7 @@ def test_wavenet_stage_pipeline_agrees_with_oracle(device, monkeypatch, blocks, 
     greedy, then sampled with the uniforms generate_block draws; the same generation twice is bit-identical"""
     for k in SPIPE_ENV:
         monkeypatch.delitem(mmk.native.PLAN_TUNING, k, raising=False)
+    monkeypatch.setitem(mmk.native.PLAN_TUNING, "MMK_WN_SPIPE", "1")      # (by name: a ring of few stages is not the default for many clips)
     net, sd, arch = _cfg4_family_net(blocks, 300 + len(blocks) + B, cond)
     net = net.to(device)
     gen = torch.Generator().manual_seed(B + n)
