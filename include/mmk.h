@@ -48,10 +48,14 @@ extern "C" {
 #define MMK_MAX_COND 4
 #define MMK_MAX_TIERS 8
 #define MMK_MAX_MLP_HIDDEN 4
+#define MMK_MAX_STREAMS 4                  /* inputs / targets of one network (len(IOSpec.inputs), len(IOSpec.targets)) */
 
 typedef void* mmk_stream_t; /* hipStream_t */
 
 int mmk_abi_version(void);
+/* sizeof the config struct as this library was compiled: 0 mmk_wavenet_config, 1 mmk_srnn_config, 2 mmk_s2s_config; -1 for any other number -
+ * what a binding that mirrors the structs by hand (ctypes, cgo, JNI) compares its own layout with before the first call */
+int64_t mmk_config_bytes(int which);
 const char* mmk_last_error(void);
 /* Diagnostic: weight re-packing kernels (`*_commit`, mmk_pack_weight_f32) launched since the library was loaded.
  * The host mirror re-commits a plan only when a parameter changed (in the reference `before_generate` never
@@ -188,6 +192,8 @@ typedef struct mmk_wavenet_config {
   int32_t n_cond;                          /* len(dims_1x1) */
   int32_t cond_in_dim[MMK_MAX_COND];       /* feature size of input 1+j (LinearIO) */
   int32_t cond_dim[MMK_MAX_COND];          /* dims_1x1[j] */
+  int32_t cond_q_levels[MMK_MAX_COND];     /* > 0: input 1+j is a stream of class indices through an EmbeddingIO (no bias) of that many
+                                            * classes - cond[j] of the calls below is then int64 (batch, T); 0: fp32 features through a LinearIO */
   int32_t bias;                            /* Config.bias */
   int32_t gated;                           /* act_g is not None (Sigmoid) ; act_f = Tanh */
   int32_t head_kind;                       /* 0: MLPIO + categorical sampler, 1: linear + Abs (magspec), 2: linear */
@@ -210,6 +216,13 @@ typedef struct mmk_wavenet_config {
   int32_t with_affine_residuals;           /* Config.with_affine_residuals (:121-122, :148-149): every layer's input goes through
                                             * x_hat * a + b of a 1x1 convolution to 3 x its width (ParametrizedLinear) first; launch path,
                                             * without pad_side, layerwise_inputs, or conditioning inputs of an ungated network */
+  /* more than one target (WaveNet.forward returns one output per output module, :293; the generate loop writes output k into input k,
+   * loops/generate.py:213-218): n_targets in [0, MMK_MAX_STREAMS], 0 = 1.  Target 0 is the head described above and is written to in0;
+   * target k >= 1 is an MLPIO + categorical sampler of x_out_dim[k] classes on the same hidden vector, written IN PLACE to cond[k - 1],
+   * which must be a class stream (cond_q_levels[k - 1] > 0).  Entry 0 of the x_ arrays is unused.  Such networks run on the launch path. */
+  int32_t n_targets;
+  int32_t x_out_dim[MMK_MAX_STREAMS], x_mlp_hidden[MMK_MAX_STREAMS], x_mlp_n_hidden[MMK_MAX_STREAMS], x_learn_temp[MMK_MAX_STREAMS];
+  float x_min_temp[MMK_MAX_STREAMS];
   char tuning[MMK_TUNING_CHARS];           /* execution switches of THIS plan as "NAME=VALUE;NAME=VALUE" (empty: the library's choices), e.g.
                                             * "MMK_WN_SPIPE=0;MMK_WN_CHAIN=1" - what the parity tests use to put one network on every kernel that can run it.  The
                                             * library reads no environment variable (the diagnostic build, -DMMK_DIAG, falls back to it) */
@@ -230,26 +243,29 @@ int mmk_wavenet_commit(mmk_wavenet_plan* plan, void* workspace, size_t workspace
  * per-layer dilation queues exactly as a full-window WaveNet.forward
  * (:276-293) over those positions would see them.  in0: int64 class indices
  * (batch, T) when q_levels > 0, else fp32 (batch, T, in_dim).  cond[j]: fp32
- * (batch, T, cond_in_dim[j]).  Strides in elements. */
+ * (batch, T, cond_in_dim[j]), or int64 class indices (batch, T) when cond_q_levels[j] > 0.  Strides in elements. */
 int mmk_wavenet_warmup(mmk_wavenet_plan* plan, int32_t batch, const void* in0, int64_t in0_row_stride,
-                       const float* const* cond, const int64_t* cond_row_stride, int64_t t_begin,
+                       const void* const* cond, const int64_t* cond_row_stride, int64_t t_begin,
                        int64_t t_end, mmk_stream_t stream);
 /* n_steps of GenerateLoopV2's hot loop (mimikit/loops/generate.py:207-219)
  * fused with WaveNet.generate_step (:447-452): for t in [t0, t0+n_steps) the
  * class drawn from the network output is written IN PLACE to in0[:, t].
- * temperature: NULL (argmax) or `batch` floats; uniforms: (batch, n_steps). */
+ * temperature: NULL (argmax) or `batch` floats; uniforms: (batch, n_steps) - with n_targets > 1 (n_targets, batch, n_steps), and the
+ * class of target k >= 1 is written IN PLACE to cond[k - 1][:, t] (the const of that argument does not cover those streams). */
 int mmk_wavenet_generate(mmk_wavenet_plan* plan, int32_t batch, void* in0, int64_t in0_row_stride,
-                         const float* const* cond, const int64_t* cond_row_stride, int64_t t0,
+                         const void* const* cond, const int64_t* cond_row_stride, int64_t t0,
                          int64_t n_steps, const float* temperature, const float* uniforms,
                          mmk_stream_t stream);
 /* raw head outputs of the most recent step: (batch, out_dim + learn_temp) fp32 */
 int mmk_wavenet_last_logits(mmk_wavenet_plan* plan, int32_t batch, float* out, int64_t ld, mmk_stream_t stream);
+/* the same for target k: (batch, x_out_dim[k] + x_learn_temp[k]) */
+int mmk_wavenet_last_logits_of(mmk_wavenet_plan* plan, int32_t target, int32_t batch, float* out, int64_t ld, mmk_stream_t stream);
 /* Measurement aid for bench.py: runs n_steps like mmk_wavenet_generate (greedy) but eagerly, with HIP
  * start/stop events attached to every fused-linear launch on `stream`; waits for completion and returns
  * summed device time (ms) and launch counts per kernel class: [0] dilated+cond+gate layer kernel,
  * [1] residual+skip layer kernel, [2] input / conditioning / head linears. */
 int mmk_wavenet_profile_steps(mmk_wavenet_plan* plan, int32_t batch, void* in0, int64_t in0_row_stride,
-                              const float* const* cond, const int64_t* cond_row_stride, int64_t t0,
+                              const void* const* cond, const int64_t* cond_row_stride, int64_t t0,
                               int64_t n_steps, double* ms_total, int64_t* launches, mmk_stream_t stream);
 
 /* > 0 when the plan runs all steps of a call inside one persistent kernel (1 csrc/wavenet_persist.hip, 2 wavenet_chain.hip,
@@ -279,6 +295,17 @@ typedef struct mmk_srnn_config {
   int32_t exec_mode;                       /* 0 = the library chooses (resident mode: the bottom tier's launch beside the tier kernels of a
                                             * second stream, where they are co-resident), 1 = the kernels in turns on one stream: what a
                                             * caller asks for to redo a batch after mmk_srnn_sync_status reported a timed-out wait */
+  /* more than one input / target (from_config, sample_rnn_v2.py:141-145, :160-173, :181-182): every tier's input module is a
+   * ZipReduceVariables (modules/io.py:289-313) over one framed linear per input, reduced with the weights of `inputs_mode`; the bottom
+   * tier's hidden vector goes through one output module per target, and the loop writes output k into input k (loops/generate.py:213-218).
+   * n_inputs / n_targets in [0, MMK_MAX_STREAMS], 0 = 1, n_targets <= n_inputs.  in_class[m]: classes of input m (0: q_levels).  Target 0 is
+   * the head described above; target k >= 1 an MLPIO of x_q_levels[k] classes (entry 0 of the x_ arrays is unused).  Such networks run
+   * with one launch per operation (mmk_srnn_warmup_multi / mmk_srnn_generate_multi). */
+  int32_t n_inputs, n_targets;
+  int32_t inputs_mode;                     /* ZipMode: 0 sum, 1 mean, 2 static_mix (softmax of the bound "tiers.i.input_module.weights") */
+  int32_t in_class[MMK_MAX_STREAMS];
+  int32_t x_q_levels[MMK_MAX_STREAMS], x_mlp_hidden[MMK_MAX_STREAMS], x_mlp_n_hidden[MMK_MAX_STREAMS], x_learn_temp[MMK_MAX_STREAMS];
+  float x_min_temp[MMK_MAX_STREAMS];
   char tuning[MMK_TUNING_CHARS];           /* execution switches of THIS plan as "NAME=VALUE;NAME=VALUE" (empty: the library's choices), e.g.
                                             * "MMK_SRNN_RESIDENT=0" - what the parity tests use to put one network on every kernel that can run it.  The
                                             * library reads no environment variable (the diagnostic build, -DMMK_DIAG, falls back to it) */
@@ -301,6 +328,13 @@ int mmk_srnn_warmup(mmk_srnn_plan* plan, int32_t batch, const int64_t* idx, int6
 int mmk_srnn_generate(mmk_srnn_plan* plan, int32_t batch, int64_t* idx, int64_t idx_row_stride, int64_t t0,
                       int64_t n_steps, const float* temperature, const float* uniforms, mmk_stream_t stream);
 int mmk_srnn_last_logits(mmk_srnn_plan* plan, int32_t batch, float* out, int64_t ld, mmk_stream_t stream);
+/* the same calls for n_inputs class streams: idx[m] / idx_row_stride[m] for m < n_inputs; the class of target k is written IN PLACE to
+ * idx[k][:, t]; uniforms: (n_targets, batch, n_steps).  With one input they are the calls above. */
+int mmk_srnn_warmup_multi(mmk_srnn_plan* plan, int32_t batch, const int64_t* const* idx, const int64_t* idx_row_stride,
+                          int64_t prompt_len, mmk_stream_t stream);
+int mmk_srnn_generate_multi(mmk_srnn_plan* plan, int32_t batch, int64_t* const* idx, const int64_t* idx_row_stride, int64_t t0,
+                            int64_t n_steps, const float* temperature, const float* uniforms, mmk_stream_t stream);
+int mmk_srnn_last_logits_of(mmk_srnn_plan* plan, int32_t target, int32_t batch, float* out, int64_t ld, mmk_stream_t stream);
 /* waits for the stream; fails (and clears the word) if a wait inside the tier / bottom kernels timed out since the last call -
  * the samples of that generation are invalid */
 int mmk_srnn_sync_status(mmk_srnn_plan* plan, mmk_stream_t stream);

@@ -329,6 +329,9 @@ int launch_rnn_tanh_cell(const float* g, float* h, int M, int H, hipStream_t str
 }  // namespace mmk
 
 extern "C" int mmk_abi_version(void) { return MMK_ABI_VERSION; }
+extern "C" int64_t mmk_config_bytes(int which) {
+  return which == 0 ? (int64_t)sizeof(mmk_wavenet_config) : which == 1 ? (int64_t)sizeof(mmk_srnn_config) : which == 2 ? (int64_t)sizeof(mmk_s2s_config) : -1;
+}
 extern "C" const char* mmk_last_error(void) { return mmk::g_err; }
 
 extern "C" int mmk_categorical_sample_f32_i64(const float* logits, int64_t ld, int32_t rows, int32_t n_classes,

@@ -16,8 +16,10 @@ using namespace mmk;
 
 struct SrnnCall {
   int M = 0;
-  const int64_t* idx = nullptr;
+  const int64_t* idx = nullptr;                       // input 0 (the fused kernels know one input)
   int64_t idx_rs = 0;
+  const int64_t* xidx[MMK_MAX_STREAMS] = {nullptr, nullptr, nullptr, nullptr};   // every input (entry 0 = idx); target k is written to input k
+  int64_t xidx_rs[MMK_MAX_STREAMS] = {0, 0, 0, 0};
   int64_t shift = 0;
   const float* temperature = nullptr;
   const float* uniforms = nullptr;
@@ -30,6 +32,15 @@ struct SrnnCall {
 struct SrnnDeep {
   PackedLinear gates, gates_hh;
   float *h = nullptr, *c = nullptr;
+};
+
+// an output module beyond the first (one per target, sample_rnn_v2.py:181-182): an MLPIO + sampler of its own geometry on the same hidden vector
+struct SrnnHead {
+  std::vector<PackedLinear> mlp;
+  int q = 0, hidden = 0, learn_temp = 0;
+  float min_temp = 0.f;
+  float* logits = nullptr;
+  int logits_ld = 0;
 };
 
 struct SrnnTier {
@@ -53,6 +64,12 @@ struct mmk_srnn_plan {
   std::vector<SrnnTier> tiers;
   PackedLinear bottom;
   std::vector<PackedLinear> mlp;
+  // more than one input / target (include/mmk.h): one launch per operation; the ZipReduceVariables weights are folded into the packed
+  // input products at commit (zip_w: the weights of tier i at [4 i, 4 i + 4), zip_tmp: a scaled copy on its way into the packed matrix)
+  int n_in = 1, n_tgt = 1, in_class[MMK_MAX_STREAMS] = {0, 0, 0, 0};
+  bool multi = false;
+  std::vector<SrnnHead> xheads;                 // targets 1 ..
+  float *zip_w = nullptr, *zip_tmp = nullptr;
   float *xbuf = nullptr, *gi = nullptr, *gh = nullptr, *xbot = nullptr, *hid[2] = {nullptr, nullptr}, *logits = nullptr;
   int logits_ld = 0;
   int64_t* tau = nullptr;
@@ -99,12 +116,22 @@ struct mmk_srnn_plan {
     }
     bottom.carve(c, true);
     for (auto& m : mlp) m.carve(c, true);
+    int hid_w = cfg.mlp_hidden, fs_max = 1;
+    for (auto& h : xheads) {
+      for (auto& m : h.mlp) m.carve(c, true);
+      h.logits_ld = (int)round_up(h.q + (h.learn_temp ? 1 : 0), 4);
+      h.logits = c.take<float>((int64_t)Bmax * h.logits_ld);
+      hid_w = h.hidden > hid_w ? h.hidden : hid_w;
+    }
+    for (int i = 0; i < cfg.n_tiers; ++i) fs_max = cfg.frame_size[i] > fs_max ? cfg.frame_size[i] : fs_max;
+    zip_w = c.take<float>(4 * MMK_MAX_TIERS);
+    zip_tmp = c.take<float>((int64_t)H * fs_max + H);
     xbuf = c.take<float>((int64_t)Bmax * H);
     gi = c.take<float>((int64_t)Bmax * G * H);
     gh = c.take<float>((int64_t)Bmax * G * H);
     xbot = c.take<float>((int64_t)Bmax * H);
-    hid[0] = c.take<float>((int64_t)Bmax * cfg.mlp_hidden);
-    hid[1] = c.take<float>((int64_t)Bmax * cfg.mlp_hidden);
+    hid[0] = c.take<float>((int64_t)Bmax * hid_w);
+    hid[1] = c.take<float>((int64_t)Bmax * hid_w);
     logits_ld = (int)round_up(cfg.q_levels + (cfg.learn_temp ? 1 : 0), 4);
     logits = c.take<float>((int64_t)Bmax * logits_ld);
     tau = c.take<int64_t>(32);
@@ -129,6 +156,17 @@ static int derive(mmk_srnn_plan* p) {
   p->G = c.rnn_kind == 0 ? 4 : (c.rnn_kind == 1 ? 3 : 1);
   p->n_rnn_tiers = c.n_tiers - 1;
   p->tiers.resize(p->n_rnn_tiers);
+  p->n_in = c.n_inputs > 1 ? c.n_inputs : 1;
+  p->n_tgt = c.n_targets > 1 ? c.n_targets : 1;
+  if (p->n_in > MMK_MAX_STREAMS) return fail(MMK_ERR_UNSUPPORTED, "srnn: %d inputs (at most %d)", p->n_in, MMK_MAX_STREAMS);
+  if (p->n_tgt > p->n_in) return fail(MMK_ERR_UNSUPPORTED, "srnn: %d targets for %d inputs (the loop writes output k into input k)", p->n_tgt, p->n_in);
+  if (c.inputs_mode < 0 || c.inputs_mode > 2) return fail(MMK_ERR_INVALID, "srnn: inputs_mode %d unknown", c.inputs_mode);
+  for (int m = 0; m < p->n_in; ++m) {
+    p->in_class[m] = c.in_class[m] > 0 ? c.in_class[m] : c.q_levels;
+    if (p->in_class[m] < 2) return fail(MMK_ERR_INVALID, "srnn: input %d has %d classes", m, p->in_class[m]);
+  }
+  p->multi = p->n_in > 1 || p->n_tgt > 1 || p->in_class[0] != c.q_levels;
+
   for (int i = 0; i < p->n_rnn_tiers; ++i) {
     SrnnTier& t = p->tiers[i];
     t.fs = c.frame_size[i];
@@ -138,7 +176,7 @@ static int derive(mmk_srnn_plan* p) {
     if (c.frame_size[0] % t.fs != 0)
       return fail(MMK_ERR_UNSUPPORTED, "srnn: frame_sizes[%d]=%d does not divide frame_sizes[0]=%d", i, t.fs, c.frame_size[0]);
     t.up = t.fs / next;
-    t.in_lin.set_geometry(p->H, {t.fs});
+    t.in_lin.set_geometry(p->H, std::vector<int>(p->n_in, t.fs));      // K = [frame of input 0 | frame of input 1 | ...]
     if (c.rnn_kind == 1) {
       t.gates.set_geometry(3 * p->H, {p->H});
       t.gates_hh.set_geometry(3 * p->H, {p->H});
@@ -158,7 +196,7 @@ static int derive(mmk_srnn_plan* p) {
     }
   }
   if (c.frame_size[c.n_tiers - 1] < 1) return fail(MMK_ERR_INVALID, "srnn: bad bottom frame size");
-  p->bottom.set_geometry(p->H, {c.frame_size[c.n_tiers - 1]});
+  p->bottom.set_geometry(p->H, std::vector<int>(p->n_in, c.frame_size[c.n_tiers - 1]));
   p->mlp.clear();
   PackedLinear first;
   first.set_geometry(c.mlp_hidden, {p->H});
@@ -171,12 +209,33 @@ static int derive(mmk_srnn_plan* p) {
   PackedLinear last;
   last.set_geometry(c.q_levels + (c.learn_temp ? 1 : 0), {c.mlp_hidden});
   p->mlp.push_back(last);
+  p->xheads.clear();
+  for (int k = 1; k < p->n_tgt; ++k) {
+    SrnnHead h;
+    h.q = c.x_q_levels[k]; h.hidden = c.x_mlp_hidden[k]; h.learn_temp = c.x_learn_temp[k]; h.min_temp = c.x_min_temp[k];
+    const int nh = c.x_mlp_n_hidden[k];
+    if (h.q < 2 || h.hidden < 1 || nh < 0 || nh > MMK_MAX_MLP_HIDDEN) return fail(MMK_ERR_INVALID, "srnn: bad MLP head geometry of target %d", k);
+    if (h.q > p->in_class[k]) return fail(MMK_ERR_INVALID, "srnn: target %d draws from %d classes, input %d holds %d", k, h.q, k, p->in_class[k]);
+    PackedLinear f0;
+    f0.set_geometry(h.hidden, {p->H});
+    h.mlp.push_back(f0);
+    for (int i = 0; i < nh; ++i) {
+      PackedLinear m;
+      m.set_geometry(h.hidden, {h.hidden});
+      h.mlp.push_back(m);
+    }
+    PackedLinear out;
+    out.set_geometry(h.q + (h.learn_temp ? 1 : 0), {h.hidden});
+    h.mlp.push_back(out);
+    p->xheads.push_back(h);
+  }
   const char* fenv = p->tune.get("MMK_SRNN_FUSED");
   p->fused_bottom = !(fenv && fenv[0] == '0') && c.mlp_n_hidden == 0 &&
                     srnn_bottom_supported(p->H, c.mlp_hidden, c.q_levels + (c.learn_temp ? 1 : 0), c.frame_size[c.n_tiers - 1]);
   p->fused_gru = !(fenv && fenv[0] == '0') && (c.rnn_kind == 1 || c.rnn_kind == 0);   // GRU or LSTM tiers
   for (auto& t : p->tiers) p->fused_gru = p->fused_gru && srnn_gru_supported(p->H, t.fs, c.rnn_kind == 0);
   if (c.n_rnn > 1) p->fused_gru = false;    // stacked layers: one launch per op (the fused kernel's up-sampler reads layer 0)
+  if (p->multi) p->fused_gru = p->fused_bottom = false;     // the fused kernels know one class stream, read and written
   if (c.n_rnn > 8) return fail(MMK_ERR_UNSUPPORTED, "srnn: n_rnn=%d", c.n_rnn);
   return MMK_OK;
 }
@@ -222,6 +281,24 @@ extern "C" size_t mmk_srnn_workspace_bytes(const mmk_srnn_plan* p) {
   Carver c(nullptr);
   tmp.layout(c);
   return c.used();
+}
+
+// ZipReduceVariables' weights (modules/io.py:296-302, :305-308): sum -> 1, mean -> 1 / M, static_mix -> softmax of the parameter
+__global__ void srnn_zip_weights_kernel(const float* __restrict__ param, int M, int mode, float* __restrict__ out) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  if (mode == 2 && param) {
+    float mx = param[0], sum = 0.f, e[MMK_MAX_STREAMS];
+    for (int m = 1; m < M; ++m) mx = fmaxf(mx, param[m]);
+    for (int m = 0; m < M; ++m) { e[m] = expf(param[m] - mx); sum += e[m]; }
+    for (int m = 0; m < M; ++m) out[m] = e[m] / sum;
+  } else {
+    for (int m = 0; m < M; ++m) out[m] = mode == 1 ? 1.f / (float)M : 1.f;
+  }
+}
+// dst = src * w[0]: head m's matrix and bias with its weight folded in ((W x + b) w = (w W) x + w b)
+__global__ void srnn_scale_kernel(const float* __restrict__ src, int64_t n, const float* __restrict__ w, float* __restrict__ dst) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < n) dst[e] = src[e] * w[0];
 }
 
 // V[r][i] = sum_k W_ih[r][k] W_in[k][i]  (i < fs; the other columns zero): fp64 accumulation, rounded once
@@ -330,6 +407,31 @@ extern "C" int mmk_srnn_reset(mmk_srnn_plan* p, mmk_stream_t stream) {
   return MMK_OK;
 }
 
+// the input module of a tier over several inputs: head m's framed linear, times its ZipReduceVariables weight, into K segment m of `lin`
+// (`mod` = "tiers.i.input_module.", `leaf` = the key between "heads.m." and "weight": "2." for a tier, "2.2.cv." for the bottom tier's convolution)
+static int pack_zipped(mmk_srnn_plan* p, int tier, const std::string& mod, const std::string& leaf, PackedLinear& lin, int fs, hipStream_t st) {
+  Binder& b = p->binder;
+  const int H = p->H, M = p->n_in;
+  float* wz = p->zip_w + 4 * tier;
+  const float* param = p->cfg.inputs_mode == 2 ? b.need(mod + "weights", M) : nullptr;
+  if (p->cfg.inputs_mode == 2 && !param) return MMK_OK;          // (reported with the other missing keys)
+  hipLaunchKernelGGL(srnn_zip_weights_kernel, dim3(1), dim3(64), 0, st, param, M, (int)p->cfg.inputs_mode, wz);
+  MMK_HIP(hipGetLastError());
+  for (int m = 0; m < M; ++m) {
+    const std::string hb = mod + "heads." + std::to_string(m) + "." + leaf;
+    const float* w = b.need(hb + "weight", (int64_t)H * fs);
+    const float* bb = b.need(hb + "bias", H);
+    if (!w || !bb) continue;
+    const int64_t nw = (int64_t)H * fs;
+    hipLaunchKernelGGL(srnn_scale_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, st, w, nw, wz + m, p->zip_tmp);
+    hipLaunchKernelGGL(srnn_scale_kernel, dim3((unsigned)((H + 255) / 256)), dim3(256), 0, st, bb, (int64_t)H, wz + m, p->zip_tmp + nw);
+    MMK_HIP(hipGetLastError());
+    MMK_TRY(pack_rect(lin.Wp, lin.k_chunks, 0, 1, H, lin.seg_chunk0[m], fs, p->zip_tmp, fs, 1, st));
+    MMK_TRY(pack_bias(lin.bias, 0, 1, H, p->zip_tmp + nw, m > 0 ? 1 : 0, st));
+  }
+  return MMK_OK;
+}
+
 extern "C" int mmk_srnn_commit(mmk_srnn_plan* p, void* workspace, size_t workspace_bytes, mmk_stream_t stream) {
   if (!p || !workspace) return fail(MMK_ERR_INVALID, "srnn_commit: null argument");
   if ((reinterpret_cast<uintptr_t>(workspace) & 255) != 0) return fail(MMK_ERR_WORKSPACE, "srnn_commit: workspace must be 256-byte aligned");
@@ -352,8 +454,12 @@ extern "C" int mmk_srnn_commit(mmk_srnn_plan* p, void* workspace, size_t workspa
     // input_module = ZipReduceVariables([Sequential(Linearizer, Unfold, Linear)])  -> heads.0.2
     const float* w = b.need(tb + "input_module.heads.0.2.weight", (int64_t)H * t.fs);
     const float* bb = b.need(tb + "input_module.heads.0.2.bias", H);
-    if (w) MMK_TRY(pack_rect(t.in_lin.Wp, t.in_lin.k_chunks, 0, 1, H, 0, t.fs, w, t.fs, 1, st));
-    if (bb) MMK_TRY(pack_bias(t.in_lin.bias, 0, 1, H, bb, 0, st));
+    if (p->n_in > 1) {
+      MMK_TRY(pack_zipped(p, i, tb + "input_module.", "2.", t.in_lin, t.fs, st));
+    } else {
+      if (w) MMK_TRY(pack_rect(t.in_lin.Wp, t.in_lin.k_chunks, 0, 1, H, 0, t.fs, w, t.fs, 1, st));
+      if (bb) MMK_TRY(pack_bias(t.in_lin.bias, 0, 1, H, bb, 0, st));
+    }
     if (w) MMK_HIP(hipMemcpyAsync(t.win_raw, w, (size_t)H * t.fs * sizeof(float), hipMemcpyDeviceToDevice, st));
     if (bb) MMK_HIP(hipMemcpyAsync(t.bin_raw, bb, (size_t)H * sizeof(float), hipMemcpyDeviceToDevice, st));
     const float* wih = b.need(tb + "rnn.weight_ih_l0", (int64_t)G * H * H);
@@ -405,8 +511,12 @@ extern "C" int mmk_srnn_commit(mmk_srnn_plan* p, void* workspace, size_t workspa
     const std::string tb = "tiers." + std::to_string(c.n_tiers - 1) + ".input_module.heads.0.2.2.cv.";
     const float* w = b.need(tb + "weight", (int64_t)H * fsl);
     const float* bb = b.need(tb + "bias", H);
-    if (w) MMK_TRY(pack_rect(p->bottom.Wp, p->bottom.k_chunks, 0, 1, H, 0, fsl, w, fsl, 1, st));
-    if (bb) MMK_TRY(pack_bias(p->bottom.bias, 0, 1, H, bb, 0, st));
+    if (p->n_in > 1) {
+      MMK_TRY(pack_zipped(p, c.n_tiers - 1, "tiers." + std::to_string(c.n_tiers - 1) + ".input_module.", "2.2.cv.", p->bottom, fsl, st));
+    } else {
+      if (w) MMK_TRY(pack_rect(p->bottom.Wp, p->bottom.k_chunks, 0, 1, H, 0, fsl, w, fsl, 1, st));
+      if (bb) MMK_TRY(pack_bias(p->bottom.bias, 0, 1, H, bb, 0, st));
+    }
     if (w) MMK_HIP(hipMemcpyAsync(p->wb_raw, w, (size_t)H * fsl * sizeof(float), hipMemcpyDeviceToDevice, st));
     if (bb) MMK_HIP(hipMemcpyAsync(p->bb_raw, bb, (size_t)H * sizeof(float), hipMemcpyDeviceToDevice, st));
   }
@@ -424,6 +534,17 @@ extern "C" int mmk_srnn_commit(mmk_srnn_plan* p, void* workspace, size_t workspa
                          H, fsl, p->a_comp, p->b_comp);
       MMK_HIP(hipGetLastError());
       p->bottom_composed = true;
+    }
+  }
+  for (size_t k = 0; k < p->xheads.size(); ++k) {
+    SrnnHead& h = p->xheads[k];
+    for (size_t i = 0; i < h.mlp.size(); ++i) {
+      PackedLinear& m = h.mlp[i];
+      const std::string kb = "output_modules." + std::to_string(k + 1) + ".estimator.0.fc." + std::to_string(2 * i) + ".";
+      const float* w = b.need(kb + "weight", (int64_t)m.N * m.segK[0]);
+      const float* bb = b.need(kb + "bias", m.N);
+      if (w) MMK_TRY(pack_rect(m.Wp, m.k_chunks, 0, 1, m.N, 0, m.segK[0], w, m.segK[0], 1, st));
+      if (bb) MMK_TRY(pack_bias(m.bias, 0, 1, m.N, bb, 0, st));
     }
   }
   if (!b.missing().empty()) return fail(MMK_ERR_KEY, "srnn_commit: state_dict tensor %s", b.missing().c_str());
@@ -531,10 +652,12 @@ static int emit_step(mmk_srnn_plan* p, const SrnnCall& call, int64_t tau_off, in
     {
       LinearArgs a = {};
       t.in_lin.fill(a);
-      a.seg[0].x = addr_time(call.idx, 1, (int32_t)(call.shift - t.fs), 1, 0);
-      a.seg[0].ld = call.idx_rs;
-      a.seg[0].kind = SEG_I64_LINEARIZED;
-      a.seg[0].class_size = (float)c.q_levels;
+      for (int m = 0; m < p->n_in; ++m) {       // ZipReduceVariables: K = [frame of input 0 | frame of input 1 | ...], weights folded in at commit
+        a.seg[m].x = addr_time(call.xidx[m], 1, (int32_t)(call.shift - t.fs), 1, 0);
+        a.seg[m].ld = call.xidx_rs[m];
+        a.seg[m].kind = SEG_I64_LINEARIZED;
+        a.seg[m].class_size = (float)p->in_class[m];
+      }
       a.M = M; a.tau_ptr = p->tau; a.tau_off = tau_off;
       a.epilogue = EPI_STORE; a.act = ACT_NONE;
       a.out = addr_static(p->xbuf); a.out_ld = H;
@@ -631,10 +754,12 @@ static int emit_step(mmk_srnn_plan* p, const SrnnCall& call, int64_t tau_off, in
     SrnnTier& up = p->tiers[p->n_rnn_tiers - 1];
     LinearArgs a = {};
     p->bottom.fill(a);
-    a.seg[0].x = addr_time(call.idx, 1, (int32_t)(call.shift - fsl), 1, 0);
-    a.seg[0].ld = call.idx_rs;
-    a.seg[0].kind = SEG_I64_LINEARIZED;
-    a.seg[0].class_size = (float)c.q_levels;
+    for (int m = 0; m < p->n_in; ++m) {
+      a.seg[m].x = addr_time(call.xidx[m], 1, (int32_t)(call.shift - fsl), 1, 0);
+      a.seg[m].ld = call.xidx_rs[m];
+      a.seg[m].kind = SEG_I64_LINEARIZED;
+      a.seg[m].class_size = (float)p->in_class[m];
+    }
     a.M = M; a.tau_ptr = p->tau; a.tau_off = tau_off;
     a.epilogue = EPI_STORE; a.act = ACT_NONE;
     a.out = addr_static(p->xbot); a.out_ld = H;
@@ -643,29 +768,41 @@ static int emit_step(mmk_srnn_plan* p, const SrnnCall& call, int64_t tau_off, in
     a.add_ld = (int64_t)up.up * H;
     MMK_TRY(launch_linear(a, st));
   }
-  const float* x = p->xbot;
-  int x_ld = H;
-  for (size_t i = 0; i < p->mlp.size(); ++i) {
-    const bool last = (i + 1 == p->mlp.size());
-    LinearArgs a = {};
-    p->mlp[i].fill(a);
-    a.seg[0].x = addr_static(x); a.seg[0].ld = x_ld;
-    a.M = M; a.tau_ptr = p->tau; a.tau_off = tau_off;
-    a.epilogue = EPI_STORE; a.act = last ? ACT_NONE : ACT_MISH;
-    float* o = last ? p->logits : p->hid[i & 1];
-    a.out = addr_static(o);
-    a.out_ld = last ? p->logits_ld : c.mlp_hidden;
-    MMK_TRY(launch_linear(a, st));
-    x = o;
-    x_ld = (int)a.out_ld;
+  // one output module per target on the same hidden vector (:259); output k goes into input k (loops/generate.py:213-218)
+  for (int k = 0; k < p->n_tgt; ++k) {
+    const std::vector<PackedLinear>& mlp = k == 0 ? p->mlp : p->xheads[k - 1].mlp;
+    float* logits = k == 0 ? p->logits : p->xheads[k - 1].logits;
+    const int logits_ld = k == 0 ? p->logits_ld : p->xheads[k - 1].logits_ld;
+    const int hidden = k == 0 ? c.mlp_hidden : p->xheads[k - 1].hidden;
+    const float* x = p->xbot;
+    int x_ld = H;
+    for (size_t i = 0; i < mlp.size(); ++i) {
+      const bool last = (i + 1 == mlp.size());
+      LinearArgs a = {};
+      mlp[i].fill(a);
+      a.seg[0].x = addr_static(x); a.seg[0].ld = x_ld;
+      a.M = M; a.tau_ptr = p->tau; a.tau_off = tau_off;
+      a.epilogue = EPI_STORE; a.act = last ? ACT_NONE : ACT_MISH;
+      float* o = last ? logits : p->hid[i & 1];
+      a.out = addr_static(o);
+      a.out_ld = last ? logits_ld : hidden;
+      MMK_TRY(launch_linear(a, st));
+      x = o;
+      x_ld = (int)a.out_ld;
+    }
+    SampleArgs s = {};
+    s.logits = logits; s.ld = logits_ld; s.rows = M;
+    s.n_classes = k == 0 ? c.q_levels : p->xheads[k - 1].q;
+    s.has_temp_col = k == 0 ? c.learn_temp : p->xheads[k - 1].learn_temp;
+    s.min_temp = k == 0 ? c.min_temp : p->xheads[k - 1].min_temp;
+    s.temperature = call.temperature;
+    s.uniforms = call.uniforms ? call.uniforms + (int64_t)k * M * call.uni_ld : nullptr;       // (n_targets, batch, n_steps)
+    s.uniform_ld = call.uni_ld; s.uni_off = call.uni_off;
+    s.out = const_cast<int64_t*>(call.xidx[k]); s.out_row_stride = call.xidx_rs[k]; s.out_tau_off = 0;
+    s.tau_ptr = p->tau; s.tau_off = tau_off;
+    MMK_TRY(launch_sample(s, st));
   }
-  SampleArgs s = {};
-  s.logits = p->logits; s.ld = p->logits_ld; s.rows = M; s.n_classes = c.q_levels; s.has_temp_col = c.learn_temp;
-  s.min_temp = c.min_temp; s.temperature = call.temperature; s.uniforms = call.uniforms;
-  s.uniform_ld = call.uni_ld; s.uni_off = call.uni_off;
-  s.out = const_cast<int64_t*>(call.idx); s.out_row_stride = call.idx_rs; s.out_tau_off = 0;
-  s.tau_ptr = p->tau; s.tau_off = tau_off;
-  return launch_sample(s, st);
+  return MMK_OK;
 }
 
 // steps [first, first + count) relative to *tau; `phase` = residue of the first step modulo frame_sizes[0].
@@ -705,6 +842,10 @@ static int prepare_period_graph(mmk_srnn_plan* p, const SrnnCall& call, int64_t 
   std::vector<int64_t> key = {call.M, (int64_t)(uintptr_t)call.idx, call.idx_rs, call.shift, with_bottom ? 1 : 0,
                               (int64_t)(uintptr_t)call.temperature, (int64_t)(uintptr_t)call.uniforms, call.uni_ld,
                               call.uni_off, phase0, call.gate ? 1 : 0, periods};
+  for (int m = 1; m < p->n_in; ++m) {
+    key.push_back((int64_t)(uintptr_t)call.xidx[m]);
+    key.push_back(call.xidx_rs[m]);
+  }
   if (p->gc.exec && p->gc.key == key) return MMK_OK;
   MMK_HIP(hipStreamSynchronize(st));
   if (also_sync) MMK_HIP(hipStreamSynchronize(also_sync));
@@ -798,21 +939,32 @@ static int run_steps(mmk_srnn_plan* p, const SrnnCall& call, int64_t t_begin, in
   return enqueue_steps(p, call, t_begin, n, with_bottom, st);
 }
 
-static int check_call(mmk_srnn_plan* p, int32_t batch, const int64_t* idx, SrnnCall& call) {
+static int check_call(mmk_srnn_plan* p, int32_t batch, const int64_t* const* idx, const int64_t* idx_row_stride, SrnnCall& call) {
   if (!p) return fail(MMK_ERR_INVALID, "srnn: null plan");
   if (!p->committed) return fail(MMK_ERR_STATE, "srnn: plan not committed (bind weights, then mmk_srnn_commit)");
   if (batch < 1 || batch > p->Bmax) return fail(MMK_ERR_INVALID, "srnn: batch %d outside [1, %d]", batch, p->Bmax);
-  if (!idx) return fail(MMK_ERR_INVALID, "srnn: null input");
+  if (!idx || !idx_row_stride) return fail(MMK_ERR_INVALID, "srnn: null input");
   call.M = batch;
-  call.idx = idx;
+  for (int m = 0; m < p->n_in; ++m) {
+    if (!idx[m]) return fail(MMK_ERR_INVALID, "srnn: input %d is null (%d inputs expected)", m, p->n_in);
+    call.xidx[m] = idx[m];
+    call.xidx_rs[m] = idx_row_stride[m];
+  }
+  call.idx = call.xidx[0];
+  call.idx_rs = call.xidx_rs[0];
   return MMK_OK;
 }
 
 extern "C" int mmk_srnn_warmup(mmk_srnn_plan* p, int32_t batch, const int64_t* idx, int64_t idx_row_stride,
                                int64_t prompt_len, mmk_stream_t stream) {
+  if (p && p->n_in != 1) return fail(MMK_ERR_INVALID, "srnn_warmup: this network has %d inputs (mmk_srnn_warmup_multi)", p->n_in);
+  return mmk_srnn_warmup_multi(p, batch, &idx, &idx_row_stride, prompt_len, stream);
+}
+
+extern "C" int mmk_srnn_warmup_multi(mmk_srnn_plan* p, int32_t batch, const int64_t* const* idx, const int64_t* idx_row_stride,
+                                     int64_t prompt_len, mmk_stream_t stream) {
   SrnnCall call;
-  MMK_TRY(check_call(p, batch, idx, call));
-  call.idx_rs = idx_row_stride;
+  MMK_TRY(check_call(p, batch, idx, idx_row_stride, call));
   const int64_t rf = p->cfg.frame_size[0];
   if (prompt_len < rf) return fail(MMK_ERR_INVALID, "srnn_warmup: prompt of %lld steps is shorter than rf=%lld", (long long)prompt_len, (long long)rf);
   const int64_t offset = prompt_len % rf;     // :230
@@ -824,9 +976,14 @@ extern "C" int mmk_srnn_warmup(mmk_srnn_plan* p, int32_t batch, const int64_t* i
 
 extern "C" int mmk_srnn_generate(mmk_srnn_plan* p, int32_t batch, int64_t* idx, int64_t idx_row_stride, int64_t t0,
                                  int64_t n_steps, const float* temperature, const float* uniforms, mmk_stream_t stream) {
+  if (p && p->n_in != 1) return fail(MMK_ERR_INVALID, "srnn_generate: this network has %d inputs (mmk_srnn_generate_multi)", p->n_in);
+  return mmk_srnn_generate_multi(p, batch, &idx, &idx_row_stride, t0, n_steps, temperature, uniforms, stream);
+}
+
+extern "C" int mmk_srnn_generate_multi(mmk_srnn_plan* p, int32_t batch, int64_t* const* idx, const int64_t* idx_row_stride, int64_t t0,
+                                       int64_t n_steps, const float* temperature, const float* uniforms, mmk_stream_t stream) {
   SrnnCall call;
-  MMK_TRY(check_call(p, batch, idx, call));
-  call.idx_rs = idx_row_stride;
+  MMK_TRY(check_call(p, batch, idx, idx_row_stride, call));
   if (t0 < p->cfg.frame_size[0] || n_steps < 0) return fail(MMK_ERR_INVALID, "srnn_generate: t0 must be >= rf and n_steps >= 0");
   if (temperature && !uniforms) return fail(MMK_ERR_INVALID, "srnn_generate: temperature given without uniforms");
   call.shift = 0;
@@ -882,6 +1039,18 @@ extern "C" int mmk_srnn_last_logits(mmk_srnn_plan* p, int32_t batch, float* out,
   }
   const int n = p->cfg.q_levels + (p->cfg.learn_temp ? 1 : 0);
   MMK_HIP(hipMemcpy2DAsync(out, ld * sizeof(float), p->logits, p->logits_ld * sizeof(float), n * sizeof(float), batch,
+                           hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  return MMK_OK;
+}
+
+extern "C" int mmk_srnn_last_logits_of(mmk_srnn_plan* p, int32_t target, int32_t batch, float* out, int64_t ld, mmk_stream_t stream) {
+  if (!p || !out) return fail(MMK_ERR_INVALID, "srnn_last_logits_of: null argument");
+  if (target == 0) return mmk_srnn_last_logits(p, batch, out, ld, stream);
+  if (!p->committed) return fail(MMK_ERR_STATE, "srnn_last_logits_of: plan not committed");
+  if (target < 0 || target >= p->n_tgt) return fail(MMK_ERR_INVALID, "srnn_last_logits_of: target %d of %d", target, p->n_tgt);
+  const SrnnHead& h = p->xheads[target - 1];
+  const int n = h.q + (h.learn_temp ? 1 : 0);
+  MMK_HIP(hipMemcpy2DAsync(out, ld * sizeof(float), h.logits, h.logits_ld * sizeof(float), n * sizeof(float), batch,
                            hipMemcpyDeviceToDevice, (hipStream_t)stream));
   return MMK_OK;
 }

@@ -25,12 +25,21 @@ struct WnCall {
   int M = 0;
   const void* in0 = nullptr;
   int64_t in0_rs = 0;
-  const float* cond[MMK_MAX_COND] = {nullptr, nullptr, nullptr, nullptr};
+  const float* cond[MMK_MAX_COND] = {nullptr, nullptr, nullptr, nullptr};      // (int64 class indices where cond_q_levels[j] > 0)
   int64_t cond_rs[MMK_MAX_COND] = {0, 0, 0, 0};
   const float* temperature = nullptr;
   const float* uniforms = nullptr;
   int64_t uni_ld = 0;
   int64_t uni_off = 0;
+};
+
+// an output module beyond the first (one per target, wavenet_v2.py:240-243, :293): an MLPIO + sampler of its own geometry on the same hidden vector
+struct WnHead {
+  std::vector<PackedLinear> mlp;
+  int q = 0, hidden = 0, learn_temp = 0;
+  float min_temp = 0.f;
+  float* logits = nullptr;
+  int logits_ld = 0;
 };
 
 struct mmk_wavenet_plan {
@@ -47,6 +56,9 @@ struct mmk_wavenet_plan {
   int head_in = 0;
 
   const float* emb = nullptr;
+  const float* cond_emb[MMK_MAX_COND] = {nullptr, nullptr, nullptr, nullptr};   // class conditioning inputs: their EmbeddingIO tables as bound
+  int n_tgt = 1;
+  std::vector<WnHead> xheads;                    // targets 1 .. (written to cond[k - 1]); launch path
   PackedLinear in0_lin;
   std::vector<PackedLinear> cond_lin, A, Bm, mlp;
 
@@ -182,6 +194,13 @@ struct mmk_wavenet_plan {
     for (auto& p : Bm)
       if (p.n_tiles > 0) p.carve(c, bias);
     for (auto& p : mlp) p.carve(c, true);
+    int hmax = cfg.mlp_hidden > 0 ? cfg.mlp_hidden : 1;
+    for (auto& h : xheads) {
+      for (auto& m : h.mlp) m.carve(c, true);
+      h.logits_ld = (int)round_up(h.q + (h.learn_temp ? 1 : 0), 4);
+      h.logits = c.take<float>((int64_t)Bmax * h.logits_ld);
+      hmax = h.hidden > hmax ? h.hidden : hmax;
+    }
     hist.resize(L + 1);
     for (int l = 0; l < L; ++l) hist[l] = c.take<float>((int64_t)ring[l] * Bmax * C);
     hist[L] = c.take<float>((int64_t)Bmax * C);  // sink for the last layer's dilated output
@@ -189,7 +208,6 @@ struct mmk_wavenet_plan {
     for (int j = 0; j < n_cond; ++j) cbuf[j] = c.take<float>((int64_t)Bmax * cfg.cond_dim[j]);
     ybuf = c.take<float>((int64_t)Bmax * C);
     skipbuf = c.take<float>((int64_t)Bmax * (S > 0 ? S : 1));
-    const int hmax = cfg.mlp_hidden > 0 ? cfg.mlp_hidden : 1;
     hid[0] = c.take<float>((int64_t)Bmax * hmax);
     hid[1] = c.take<float>((int64_t)Bmax * hmax);
     logits_ld = (int)round_up(cfg.out_dim + (cfg.learn_temp ? 1 : 0), 4);
@@ -273,7 +291,34 @@ static int derive(mmk_wavenet_plan* p) {
   // geometry of the packed matrices
   if (c.q_levels == 0) p->in0_lin.set_geometry(p->C, {c.in_dim});
   p->cond_lin.resize(p->n_cond);
-  for (int j = 0; j < p->n_cond; ++j) p->cond_lin[j].set_geometry(c.cond_dim[j], {c.cond_in_dim[j]});
+  for (int j = 0; j < p->n_cond; ++j) p->cond_lin[j].set_geometry(c.cond_dim[j], {c.cond_q_levels[j] > 0 ? 1 : c.cond_in_dim[j]});   // (a class input has its table instead)
+  p->n_tgt = c.n_targets > 1 ? c.n_targets : 1;
+  if (p->n_tgt > MMK_MAX_STREAMS || p->n_tgt > 1 + p->n_cond)
+    return fail(MMK_ERR_UNSUPPORTED, "wavenet: %d targets for %d inputs (the loop writes output k into input k)", p->n_tgt, 1 + p->n_cond);
+  bool multi = p->n_tgt > 1;
+  for (int j = 0; j < p->n_cond; ++j) multi = multi || c.cond_q_levels[j] > 0;
+  p->xheads.clear();
+  for (int k = 1; k < p->n_tgt; ++k) {
+    WnHead h;
+    h.q = c.x_out_dim[k]; h.hidden = c.x_mlp_hidden[k]; h.learn_temp = c.x_learn_temp[k]; h.min_temp = c.x_min_temp[k];
+    const int nh = c.x_mlp_n_hidden[k];
+    if (h.q < 2 || h.hidden < 1 || nh < 0 || nh > MMK_MAX_MLP_HIDDEN) return fail(MMK_ERR_INVALID, "wavenet: bad MLP head geometry of target %d", k);
+    if (c.cond_q_levels[k - 1] < h.q)
+      return fail(MMK_ERR_INVALID, "wavenet: target %d draws from %d classes, but input %d is %s", k, h.q, k,
+                  c.cond_q_levels[k - 1] > 0 ? "a stream of fewer classes" : "not a class stream");
+    PackedLinear f0;
+    f0.set_geometry(h.hidden, {p->S > 0 ? p->S : p->C});
+    h.mlp.push_back(f0);
+    for (int i = 0; i < nh; ++i) {
+      PackedLinear m;
+      m.set_geometry(h.hidden, {h.hidden});
+      h.mlp.push_back(m);
+    }
+    PackedLinear out;
+    out.set_geometry(h.q + (h.learn_temp ? 1 : 0), {h.hidden});
+    h.mlp.push_back(out);
+    p->xheads.push_back(h);
+  }
   p->A.resize(p->L);
   p->Bm.resize(p->L);
   p->Aff.clear();
@@ -318,6 +363,7 @@ static int derive(mmk_wavenet_plan* p) {
   const char* env = p->tune.get("MMK_WN_PERSISTENT");
   bool ok = !(env && env[0] == '0') && c.exec_mode != 1;     // (exec_mode 1: the caller asks for the per-layer launch path)
   ok = ok && c.gated && c.q_levels > 0 && c.head_kind == 0 && c.mlp_n_hidden == 0 && c.n_cond <= 1;
+  ok = ok && !multi;            // class conditioning streams and further targets: the launch path (a step's conditioning row depends on the step before)
   ok = ok && p->C % 32 == 0 && p->C <= 256 && p->S == p->C && c.residuals_dim == p->C && !c.layerwise_inputs && !c.with_affine_residuals;
   for (int l = 0; l < p->L; ++l) ok = ok && (p->has_res[l] != 0) == (l != p->L - 1);   // (reverse_layer_order: launch path)
   ok = ok && c.mlp_hidden % 16 == 0 && c.mlp_hidden >= 16;
@@ -577,6 +623,10 @@ extern "C" int mmk_wavenet_commit(mmk_wavenet_plan* p, void* workspace, size_t w
   // conditioning inputs (LinearIO, modules/io.py:115-122)
   for (int j = 0; j < p->n_cond; ++j) {
     const std::string base = "input_modules." + std::to_string(j + 1) + ".0.";
+    if (c.cond_q_levels[j] > 0) {           // EmbeddingIO (modules/io.py:132-136): the table itself, no bias
+      p->cond_emb[j] = b.need(base + "weight", (int64_t)c.cond_q_levels[j] * c.cond_dim[j]);
+      continue;
+    }
     const float* w = b.need(base + "weight", (int64_t)c.cond_dim[j] * c.cond_in_dim[j]);
     const float* bb = b.need(base + "bias", c.cond_dim[j]);
     if (w && bb) {
@@ -776,6 +826,17 @@ extern "C" int mmk_wavenet_commit(mmk_wavenet_plan* p, void* workspace, size_t w
     if (w) MMK_TRY(pack_rect(m.Wp, m.k_chunks, 0, 1, m.N, 0, m.segK[0], w, m.segK[0], 1, st));
     if (bb) MMK_TRY(pack_bias(m.bias, 0, 1, m.N, bb, 0, st));
   }
+  for (size_t k = 0; k < p->xheads.size(); ++k) {
+    WnHead& h = p->xheads[k];
+    for (size_t i = 0; i < h.mlp.size(); ++i) {
+      PackedLinear& m = h.mlp[i];
+      const std::string kb = "output_modules." + std::to_string(k + 1) + ".estimator.0.fc." + std::to_string(2 * i) + ".";
+      const float* w = b.need(kb + "weight", (int64_t)m.N * m.segK[0]);
+      const float* bb = b.need(kb + "bias", m.N);
+      if (w) MMK_TRY(pack_rect(m.Wp, m.k_chunks, 0, 1, m.N, 0, m.segK[0], w, m.segK[0], 1, st));
+      if (bb) MMK_TRY(pack_bias(m.bias, 0, 1, m.N, bb, 0, st));
+    }
+  }
   if (!b.missing().empty()) return fail(MMK_ERR_KEY, "wavenet_commit: state_dict tensor %s", b.missing().c_str());
   if (p->persistent && !p->spipe) {
     std::vector<WnLayerTab> tab(L);
@@ -841,6 +902,11 @@ static int emit_step(mmk_wavenet_plan* p, const WnCall& call, int64_t tau_off, b
     MMK_TRY(launch_linear(a, st));
   }
   for (int j = 0; j < p->n_cond; ++j) {
+    if (c.cond_q_levels[j] > 0) {      // a class stream: the row of its table for position tau (written by the step before when a target feeds it)
+      MMK_TRY(launch_embed(reinterpret_cast<const int64_t*>(call.cond[j]), call.cond_rs[j], 0, p->cond_emb[j], c.cond_dim[j], c.cond_q_levels[j],
+                           addr_static(p->cbuf[j]), c.cond_dim[j], M, p->tau, tau_off, st));
+      continue;
+    }
     LinearArgs a = {};
     p->cond_lin[j].fill(a);
     a.seg[0].x = addr_time(call.cond[j], c.cond_in_dim[j], 0, 1, 0);
@@ -933,6 +999,36 @@ static int emit_step(mmk_wavenet_plan* p, const WnCall& call, int64_t tau_off, b
     s.out = (int64_t*)call.in0; s.out_row_stride = call.in0_rs; s.out_tau_off = 1;
     s.tau_ptr = p->tau; s.tau_off = tau_off;
     MMK_TRY(launch_sample(s, st));
+    const float* x_head = S > 0 ? p->skipbuf : (p->has_res[L - 1] ? p->hist[L] : p->ybuf);
+    for (size_t k = 0; k < p->xheads.size(); ++k) {     // one output module per target on the same vector (:293); output k + 1 goes into input k + 1
+      const WnHead& h = p->xheads[k];
+      const float* xk = x_head;
+      int xk_ld = p->head_in;
+      for (size_t i = 0; i < h.mlp.size(); ++i) {
+        const bool last = (i + 1 == h.mlp.size());
+        LinearArgs a = {};
+        h.mlp[i].fill(a);
+        a.seg[0].x = addr_static(xk);
+        a.seg[0].ld = xk_ld;
+        a.M = M; a.tau_ptr = p->tau; a.tau_off = tau_off;
+        a.epilogue = EPI_STORE;
+        a.act = last ? ACT_NONE : ACT_MISH;
+        float* o = last ? h.logits : p->hid[i & 1];
+        a.out = addr_static(o);
+        a.out_ld = last ? h.logits_ld : h.hidden;
+        MMK_TRY(launch_linear(a, st));
+        xk = o;
+        xk_ld = (int)a.out_ld;
+      }
+      SampleArgs sk = {};
+      sk.logits = h.logits; sk.ld = h.logits_ld; sk.rows = M; sk.n_classes = h.q; sk.has_temp_col = h.learn_temp;
+      sk.min_temp = h.min_temp; sk.temperature = call.temperature;
+      sk.uniforms = call.uniforms ? call.uniforms + (int64_t)(k + 1) * M * call.uni_ld : nullptr;     // (n_targets, batch, n_steps)
+      sk.uniform_ld = call.uni_ld; sk.uni_off = call.uni_off;
+      sk.out = reinterpret_cast<int64_t*>(const_cast<float*>(call.cond[k])); sk.out_row_stride = call.cond_rs[k]; sk.out_tau_off = 1;
+      sk.tau_ptr = p->tau; sk.tau_off = tau_off;
+      MMK_TRY(launch_sample(sk, st));
+    }
   } else {
     LinearArgs a = {};
     p->mlp[0].fill(a);
@@ -1233,7 +1329,7 @@ static int run_steps(mmk_wavenet_plan* p, const WnCall& call, int64_t tau0, int6
   return MMK_OK;
 }
 
-static int check_call(mmk_wavenet_plan* p, int32_t batch, const void* in0, const float* const* cond,
+static int check_call(mmk_wavenet_plan* p, int32_t batch, const void* in0, const void* const* cond,
                       const int64_t* cond_rs, WnCall& call) {
   if (!p) return fail(MMK_ERR_INVALID, "wavenet: null plan");
   if (!p->committed) return fail(MMK_ERR_STATE, "wavenet: plan not committed (bind weights, then mmk_wavenet_commit)");
@@ -1244,14 +1340,14 @@ static int check_call(mmk_wavenet_plan* p, int32_t batch, const void* in0, const
   call.in0 = in0;
   for (int j = 0; j < p->n_cond; ++j) {
     if (!cond[j]) return fail(MMK_ERR_INVALID, "wavenet: conditioning input %d is null", j);
-    call.cond[j] = cond[j];
+    call.cond[j] = static_cast<const float*>(cond[j]);
     call.cond_rs[j] = cond_rs[j];
   }
   return MMK_OK;
 }
 
 extern "C" int mmk_wavenet_warmup(mmk_wavenet_plan* p, int32_t batch, const void* in0, int64_t in0_row_stride,
-                                  const float* const* cond, const int64_t* cond_row_stride, int64_t t_begin,
+                                  const void* const* cond, const int64_t* cond_row_stride, int64_t t_begin,
                                   int64_t t_end, mmk_stream_t stream) {
   WnCall call;
   MMK_TRY(check_call(p, batch, in0, cond, cond_row_stride, call));
@@ -1270,7 +1366,7 @@ extern "C" int mmk_wavenet_warmup(mmk_wavenet_plan* p, int32_t batch, const void
 }
 
 extern "C" int mmk_wavenet_generate(mmk_wavenet_plan* p, int32_t batch, void* in0, int64_t in0_row_stride,
-                                    const float* const* cond, const int64_t* cond_row_stride, int64_t t0,
+                                    const void* const* cond, const int64_t* cond_row_stride, int64_t t0,
                                     int64_t n_steps, const float* temperature, const float* uniforms,
                                     mmk_stream_t stream) {
   WnCall call;
@@ -1297,8 +1393,20 @@ extern "C" int mmk_wavenet_last_logits(mmk_wavenet_plan* p, int32_t batch, float
   return MMK_OK;
 }
 
+extern "C" int mmk_wavenet_last_logits_of(mmk_wavenet_plan* p, int32_t target, int32_t batch, float* out, int64_t ld, mmk_stream_t stream) {
+  if (target == 0) return mmk_wavenet_last_logits(p, batch, out, ld, stream);
+  if (!p || !out) return fail(MMK_ERR_INVALID, "wavenet_last_logits_of: null argument");
+  if (!p->committed) return fail(MMK_ERR_STATE, "wavenet_last_logits_of: plan not committed");
+  if (target < 0 || target >= p->n_tgt) return fail(MMK_ERR_INVALID, "wavenet_last_logits_of: target %d of %d", target, p->n_tgt);
+  const WnHead& h = p->xheads[target - 1];
+  const int n = h.q + (h.learn_temp ? 1 : 0);
+  MMK_HIP(hipMemcpy2DAsync(out, ld * sizeof(float), h.logits, h.logits_ld * sizeof(float), n * sizeof(float), batch,
+                           hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  return MMK_OK;
+}
+
 extern "C" int mmk_wavenet_profile_steps(mmk_wavenet_plan* p, int32_t batch, void* in0, int64_t in0_row_stride,
-                                         const float* const* cond, const int64_t* cond_row_stride, int64_t t0,
+                                         const void* const* cond, const int64_t* cond_row_stride, int64_t t0,
                                          int64_t n_steps, double* ms_total, int64_t* launches, mmk_stream_t stream) {
   WnCall call;
   MMK_TRY(check_call(p, batch, in0, cond, cond_row_stride, call));

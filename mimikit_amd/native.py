@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # in-kernel phase stamps and the timing experiments compiled in; the product library contains neither
 LIB_PATH = os.path.join(_HERE, "libmmk_hip_diag.so" if os.environ.get("MMK_DIAG_LIB") == "1" else "libmmk_hip.so")
 
-MAX_LAYERS, MAX_COND, MAX_TIERS = 128, 4, 8
+MAX_LAYERS, MAX_COND, MAX_TIERS, MAX_STREAMS = 128, 4, 8, 4
 ABI_VERSION = 3          # include/mmk.h: MMK_ABI_VERSION (bumped whenever a config struct or a signature changes)
 ACT = {"none": 0, None: 0, "Identity": 0, "Tanh": 1, "Sigmoid": 2, "Mish": 3, "Abs": 4, "ReLU": 5}
 
@@ -49,10 +49,12 @@ class WaveNetConfig(C.Structure):
     _fields_ = [
         ("n_layers", i32), ("kernel_size", i32 * MAX_LAYERS), ("dilation", i32 * MAX_LAYERS),
         ("q_levels", i32), ("in_dim", i32), ("dim_dilated", i32), ("residuals_dim", i32), ("skips_dim", i32),
-        ("n_cond", i32), ("cond_in_dim", i32 * MAX_COND), ("cond_dim", i32 * MAX_COND),
+        ("n_cond", i32), ("cond_in_dim", i32 * MAX_COND), ("cond_dim", i32 * MAX_COND), ("cond_q_levels", i32 * MAX_COND),
         ("bias", i32), ("gated", i32), ("head_kind", i32), ("mlp_hidden", i32), ("mlp_n_hidden", i32),
         ("out_dim", i32), ("learn_temp", i32), ("min_temp", f32), ("max_batch", i32),
         ("res_explicit", i32), ("layer_has_res", i32 * MAX_LAYERS), ("layerwise_inputs", i32), ("exec_mode", i32), ("with_affine_residuals", i32),
+        ("n_targets", i32), ("x_out_dim", i32 * MAX_STREAMS), ("x_mlp_hidden", i32 * MAX_STREAMS), ("x_mlp_n_hidden", i32 * MAX_STREAMS),
+        ("x_learn_temp", i32 * MAX_STREAMS), ("x_min_temp", f32 * MAX_STREAMS),
         ("tuning", C.c_char * TUNING_CHARS),
     ]
 
@@ -62,6 +64,9 @@ class SrnnConfig(C.Structure):
         ("n_tiers", i32), ("frame_size", i32 * MAX_TIERS), ("hidden_dim", i32), ("rnn_kind", i32),
         ("rnn_bias", i32), ("h0_ones", i32), ("q_levels", i32), ("mlp_hidden", i32), ("mlp_n_hidden", i32),
         ("learn_temp", i32), ("min_temp", f32), ("max_batch", i32), ("n_rnn", i32), ("exec_mode", i32),
+        ("n_inputs", i32), ("n_targets", i32), ("inputs_mode", i32), ("in_class", i32 * MAX_STREAMS),
+        ("x_q_levels", i32 * MAX_STREAMS), ("x_mlp_hidden", i32 * MAX_STREAMS), ("x_mlp_n_hidden", i32 * MAX_STREAMS),
+        ("x_learn_temp", i32 * MAX_STREAMS), ("x_min_temp", f32 * MAX_STREAMS),
         ("tuning", C.c_char * TUNING_CHARS),
     ]
 
@@ -79,6 +84,7 @@ class S2SConfig(C.Structure):
 
 _SIGNATURES = {
     "mmk_abi_version": (i32, []),
+    "mmk_config_bytes": (i64, [i32]),
     "mmk_last_error": (cp, []),
     "mmk_pack_launch_count": (i64, []),
     "mmk_fingerprint_u32": (i32, [vp, i64, vp, vp]),
@@ -108,6 +114,7 @@ _SIGNATURES = {
     "mmk_wavenet_warmup": (i32, [vp, i32, vp, i64, C.POINTER(vp), C.POINTER(i64), i64, i64, vp]),
     "mmk_wavenet_generate": (i32, [vp, i32, vp, i64, C.POINTER(vp), C.POINTER(i64), i64, i64, vp, vp, vp]),
     "mmk_wavenet_last_logits": (i32, [vp, i32, vp, i64, vp]),
+    "mmk_wavenet_last_logits_of": (i32, [vp, i32, i32, vp, i64, vp]),
     "mmk_wavenet_profile_steps": (i32, [vp, i32, vp, i64, C.POINTER(vp), C.POINTER(i64), i64, i64,
                                         C.POINTER(C.c_double), C.POINTER(i64), vp]),
     "mmk_wavenet_mode": (i32, [vp]),
@@ -122,6 +129,9 @@ _SIGNATURES = {
     "mmk_srnn_warmup": (i32, [vp, i32, vp, i64, i64, vp]),
     "mmk_srnn_generate": (i32, [vp, i32, vp, i64, i64, i64, vp, vp, vp]),
     "mmk_srnn_last_logits": (i32, [vp, i32, vp, i64, vp]),
+    "mmk_srnn_warmup_multi": (i32, [vp, i32, C.POINTER(vp), C.POINTER(i64), i64, vp]),
+    "mmk_srnn_generate_multi": (i32, [vp, i32, C.POINTER(vp), C.POINTER(i64), i64, i64, vp, vp, vp]),
+    "mmk_srnn_last_logits_of": (i32, [vp, i32, i32, vp, i64, vp]),
     "mmk_srnn_resident_blocks": (i64, [vp]),
     "mmk_srnn_sync_status": (i32, [vp, vp]),
     "mmk_srnn_inject_sync_error": (i32, [vp, vp]),
@@ -163,6 +173,10 @@ def load_library(path: Optional[str] = None):
     if lib.mmk_abi_version() != ABI_VERSION:
         raise NativeError(f"ABI version mismatch: library reports {lib.mmk_abi_version()}, binding expects {ABI_VERSION} "
                           "(a stale libmmk_hip.so: rebuild with `python -m mimikit_amd.build`)")
+    for which, struct in enumerate((WaveNetConfig, SrnnConfig, S2SConfig)):
+        if lib.mmk_config_bytes(which) != C.sizeof(struct):
+            raise NativeError(f"{struct.__name__} is {C.sizeof(struct)} bytes here and {lib.mmk_config_bytes(which)} in the library "
+                              "(a stale libmmk_hip.so: rebuild with `python -m mimikit_amd.build`)")
     _lib = lib
     return lib
 
@@ -505,8 +519,11 @@ class WaveNetPlan(_Plan):
                 raise ValueError("input 0 must be fp32 (batch, T, dim), contiguous along time and dim")
         if len(cond) != self.cfg.n_cond:
             raise ValueError(f"expected {self.cfg.n_cond} conditioning inputs, got {len(cond)}")
-        for c in cond:
-            if c.dtype != torch.float32 or c.dim() != 3 or c.stride(2) != 1 or c.stride(1) != c.shape[2]:
+        for j, c in enumerate(cond):
+            if self.cfg.cond_q_levels[j] > 0:
+                if c.dtype != torch.int64 or c.dim() != 2 or c.stride(1) != 1:
+                    raise ValueError(f"input {j + 1} is a class stream: int64 (batch, T) with unit stride along time")
+            elif c.dtype != torch.float32 or c.dim() != 3 or c.stride(2) != 1 or c.stride(1) != c.shape[2]:
                 raise ValueError("conditioning inputs must be fp32 (batch, T, dim), contiguous along time and dim")
 
     def warmup(self, in0: torch.Tensor, cond: Sequence[torch.Tensor], t_begin: int, t_end: int, t_first: int = 0):
@@ -520,9 +537,10 @@ class WaveNetPlan(_Plan):
                  t_first: int = 0):
         self._check_inputs(in0, cond)
         require_device(temperature, uniforms)
+        n_tgt = max(int(self.cfg.n_targets), 1)
         if uniforms is not None and (uniforms.dtype != torch.float32 or not uniforms.is_contiguous()
-                                     or uniforms.numel() != in0.shape[0] * n_steps):
-            raise ValueError("uniforms must be contiguous fp32 of shape (batch, n_steps)")
+                                     or uniforms.numel() != n_tgt * in0.shape[0] * n_steps):
+            raise ValueError("uniforms must be contiguous fp32 of shape (batch, n_steps) - (n_targets, batch, n_steps) with several targets")
         ptrs, strides = _cond_arrays(cond, t_first)
         check(self._lib.mmk_wavenet_generate(self.handle, in0.shape[0], abs_ptr(in0, t_first), in0.stride(0), ptrs,
                                              strides, t0, n_steps, ptr(temperature), ptr(uniforms),
@@ -572,11 +590,12 @@ class WaveNetPlan(_Plan):
               "mmk_wavenet_profile_steps")
         return {name: (ms[i], cnt[i]) for i, name in enumerate(("layer_a", "layer_b", "other"))}
 
-    def last_logits(self, batch: int) -> torch.Tensor:
-        n = self.cfg.out_dim + (1 if self.cfg.learn_temp else 0)
+    def last_logits(self, batch: int, target: int = 0) -> torch.Tensor:
+        c = self.cfg
+        n = (c.out_dim + (1 if c.learn_temp else 0)) if target == 0 else (c.x_out_dim[target] + (1 if c.x_learn_temp[target] else 0))
         out = torch.empty((batch, n), dtype=torch.float32, device=self.device)
-        check(self._lib.mmk_wavenet_last_logits(self.handle, batch, ptr(out), out.stride(0), stream_ptr(self.device)),
-              "mmk_wavenet_last_logits")
+        check(self._lib.mmk_wavenet_last_logits_of(self.handle, target, batch, ptr(out), out.stride(0), stream_ptr(self.device)),
+              "mmk_wavenet_last_logits_of")
         return out
 
 
@@ -649,8 +668,8 @@ class WaveNetPlanSet:
     def profile_steps(self, *args, **kwargs):
         raise NotImplementedError("profile_steps measures the per-layer launch path of ONE plan")
 
-    def last_logits(self, batch: int) -> torch.Tensor:
-        return torch.cat([plan.last_logits(b - a) for plan, a, b in self._slices(batch)], dim=0)
+    def last_logits(self, batch: int, target: int = 0) -> torch.Tensor:
+        return torch.cat([plan.last_logits(b - a, target) for plan, a, b in self._slices(batch)], dim=0)
 
 
 def make_wavenet_plan(describe, batch: int, device) -> "WaveNetPlan":
@@ -673,24 +692,42 @@ class SrnnPlan(_Plan):
     def reset(self):
         check(self._lib.mmk_srnn_reset(self.handle, stream_ptr(self.device)), "mmk_srnn_reset")
 
-    def warmup(self, idx: torch.Tensor, prompt_len: int):
-        """idx: (batch, >= prompt_len) prompt, column 0 = time 0"""
-        require_device(idx)
-        if idx.dtype != torch.int64 or idx.stride(1) != 1:
-            raise ValueError("SampleRNN input must be int64 (batch, T), contiguous along time")
-        if idx.shape[1] < prompt_len:
-            raise ValueError(f"prompt tensor holds {idx.shape[1]} steps, prompt_len={prompt_len}")
-        check(self._lib.mmk_srnn_warmup(self.handle, idx.shape[0], ptr(idx), idx.stride(0), prompt_len,
-                                        stream_ptr(self.device)), "mmk_srnn_warmup")
+    def _streams(self, idx):
+        """one (batch, T) int64 tensor per input of the network (a single tensor: the network's only input)"""
+        idx = (idx,) if isinstance(idx, torch.Tensor) else tuple(idx)
+        n_in = max(int(self.cfg.n_inputs), 1)
+        if len(idx) != n_in:
+            raise ValueError(f"expected {n_in} input streams, got {len(idx)}")
+        require_device(*idx)
+        for x in idx:
+            if x.dtype != torch.int64 or x.dim() != 2 or x.stride(1) != 1 or x.shape != idx[0].shape:
+                raise ValueError("SampleRNN inputs must be int64 (batch, T) of one shape, contiguous along time")
+        return idx
 
-    def generate(self, idx: torch.Tensor, t0: int, n_steps: int, temperature=None, uniforms=None, t_first: int = 0):
-        """idx: (batch, T) tensor or view whose column 0 is absolute time t_first"""
-        require_device(idx, temperature, uniforms)
-        if idx.dtype != torch.int64 or idx.stride(1) != 1:
-            raise ValueError("SampleRNN input must be int64 (batch, T), contiguous along time")
-        check(self._lib.mmk_srnn_generate(self.handle, idx.shape[0], abs_ptr(idx, t_first), idx.stride(0), t0, n_steps,
-                                          ptr(temperature), ptr(uniforms), stream_ptr(self.device)),
-              "mmk_srnn_generate")
+    def warmup(self, idx, prompt_len: int):
+        """idx: (batch, >= prompt_len) prompt, column 0 = time 0 (a tuple of them for a network of several inputs)"""
+        idx = self._streams(idx)
+        if idx[0].shape[1] < prompt_len:
+            raise ValueError(f"prompt tensor holds {idx[0].shape[1]} steps, prompt_len={prompt_len}")
+        ptrs = (vp * len(idx))(*[ptr(x) for x in idx])
+        strides = (i64 * len(idx))(*[x.stride(0) for x in idx])
+        check(self._lib.mmk_srnn_warmup_multi(self.handle, idx[0].shape[0], ptrs, strides, prompt_len,
+                                              stream_ptr(self.device)), "mmk_srnn_warmup_multi")
+
+    def generate(self, idx, t0: int, n_steps: int, temperature=None, uniforms=None, t_first: int = 0):
+        """idx: (batch, T) tensor or view whose column 0 is absolute time t_first (a tuple of them for several inputs: the class of
+        target k is written into idx[k]); uniforms: (batch, n_steps), (n_targets, batch, n_steps) with several targets"""
+        idx = self._streams(idx)
+        require_device(temperature, uniforms)
+        n_tgt = max(int(self.cfg.n_targets), 1)
+        if uniforms is not None and (uniforms.dtype != torch.float32 or not uniforms.is_contiguous()
+                                     or uniforms.numel() != n_tgt * idx[0].shape[0] * n_steps):
+            raise ValueError("uniforms must be contiguous fp32 of shape (batch, n_steps) - (n_targets, batch, n_steps) with several targets")
+        ptrs = (vp * len(idx))(*[abs_ptr(x, t_first) for x in idx])
+        strides = (i64 * len(idx))(*[x.stride(0) for x in idx])
+        check(self._lib.mmk_srnn_generate_multi(self.handle, idx[0].shape[0], ptrs, strides, t0, n_steps,
+                                                ptr(temperature), ptr(uniforms), stream_ptr(self.device)),
+              "mmk_srnn_generate_multi")
 
     def sync_status(self):
         """wait for the stream and raise if a wait inside the resident-mode kernels timed out"""
@@ -704,11 +741,12 @@ class SrnnPlan(_Plan):
         """generate blocks run in resident mode so far (diagnostic, see include/mmk.h)"""
         return int(self._lib.mmk_srnn_resident_blocks(self.handle))
 
-    def last_logits(self, batch: int) -> torch.Tensor:
-        n = self.cfg.q_levels + (1 if self.cfg.learn_temp else 0)
+    def last_logits(self, batch: int, target: int = 0) -> torch.Tensor:
+        c = self.cfg
+        n = (c.q_levels + (1 if c.learn_temp else 0)) if target == 0 else (c.x_q_levels[target] + (1 if c.x_learn_temp[target] else 0))
         out = torch.empty((batch, n), dtype=torch.float32, device=self.device)
-        check(self._lib.mmk_srnn_last_logits(self.handle, batch, ptr(out), out.stride(0), stream_ptr(self.device)),
-              "mmk_srnn_last_logits")
+        check(self._lib.mmk_srnn_last_logits_of(self.handle, target, batch, ptr(out), out.stride(0), stream_ptr(self.device)),
+              "mmk_srnn_last_logits_of")
         return out
 
 

@@ -209,8 +209,10 @@ class SampleRNN(ARMWithHidden, nn.Module):
     def _describe(self, max_batch: int) -> native.SrnnConfig:
         cfg, io = self._config, self._config.io_spec
         unsupported = []
-        if len(io.inputs) != 1 or len(io.targets) != 1:
-            unsupported.append("more than one input / target")
+        n_in, n_tgt = len(io.inputs), len(io.targets)
+        if n_in > native.MAX_STREAMS or n_tgt > n_in:
+            unsupported.append(f"more than {native.MAX_STREAMS} inputs, or more targets than inputs (the loop writes output k into "
+                               "input k, loops/generate.py:213-218)")
         if not 1 <= cfg.n_rnn <= 8:
             unsupported.append("n_rnn outside [1, 8]")
         if cfg.rnn_dropout:
@@ -234,10 +236,27 @@ class SampleRNN(ARMWithHidden, nn.Module):
             c.min_temp = float(mlp.min_temp) if mlp.learn_temperature else 0.
         else:
             unsupported.append(f"output module of type {type(head).__name__}")
+        # several inputs (every tier's ZipReduceVariables, :141-145, :160-173) and targets (:181-182)
+        c.n_inputs, c.n_targets = n_in, n_tgt
+        c.inputs_mode = {"sum": 0, "mean": 1, "static_mix": 2}[str(cfg.inputs_mode)]
+        for m, spec in enumerate(io.inputs[:native.MAX_STREAMS]):
+            c.in_class[m] = spec.elem_type.size
+        for k in range(1, min(n_tgt, native.MAX_STREAMS)):
+            hk = self.output_modules[k]
+            if not (isinstance(hk, OutputWrapper) and isinstance(hk.estimator[0], MLP) and len(hk.estimator) == 1):
+                unsupported.append(f"output module {k} of type {type(hk).__name__}")
+                continue
+            mlp = hk.estimator[0]
+            if not isinstance(mlp.activation, nn.Mish) or not mlp.bias or mlp.dropout or mlp.dropout1d or mlp.n_hidden_layers > 4:
+                unsupported.append(f"target {k}: MLP head with a non-Mish activation, no bias, dropout or more than 4 hidden layers")
+            c.x_mlp_hidden[k], c.x_mlp_n_hidden[k], c.x_learn_temp[k] = mlp.hidden_dim, mlp.n_hidden_layers, int(mlp.learn_temperature)
+            c.x_q_levels[k] = mlp.out_dim - c.x_learn_temp[k]
+            c.x_min_temp[k] = float(mlp.min_temp) if mlp.learn_temperature else 0.
+        for k in range(min(n_tgt, n_in, native.MAX_STREAMS)):
+            if (c.q_levels if k == 0 else c.x_q_levels[k]) > c.in_class[k]:
+                unsupported.append(f"target {k} draws classes that input {k} cannot take")
         if unsupported:
             raise NotImplementedError("the HIP generate path does not cover: " + "; ".join(unsupported))
-        if io.inputs[0].elem_type.size != c.q_levels:
-            raise NotImplementedError("input and target class sizes differ")
         c.n_tiers = len(cfg.frame_sizes)
         for i, fs in enumerate(cfg.frame_sizes):
             c.frame_size[i] = fs
@@ -276,8 +295,9 @@ class SampleRNN(ARMWithHidden, nn.Module):
         temperature = parameters.get("temperature", None)
         if temperature is None:
             return None, None
+        n_tgt = len(self.output_modules)
         return (per_row_temperature(temperature, batch, self.device),
-                torch.rand((batch, n_steps), device=self.device, dtype=torch.float32))
+                torch.rand((batch, n_steps) if n_tgt == 1 else (n_tgt, batch, n_steps), device=self.device, dtype=torch.float32))
 
     # -- ARM generation protocol ------------------------------------------------------
     def reset_hidden(self) -> None:
@@ -298,8 +318,8 @@ class SampleRNN(ARMWithHidden, nn.Module):
         self.prompt_length = length - offset
         if length < self.rf:
             raise RuntimeError(f"prompt of {length} steps is shorter than frame_sizes[0]={self.rf}")
-        idx = idx if idx.stride(1) == 1 else idx.contiguous()
-        self._plan.warmup(idx.long() if idx.dtype != torch.int64 else idx, length)
+        streams = tuple((x if x.stride(1) == 1 else x.contiguous()) for x in prompts[:len(self.tiers[0].input_module.heads)])
+        self._plan.warmup(tuple(x.long() if x.dtype != torch.int64 else x for x in streams), length)
         self._next_t, self._state_batch = length, batch
 
     def generate_step(self, inputs: Tuple[torch.Tensor, ...], *, t: int = 0, **parameters):
@@ -314,24 +334,26 @@ class SampleRNN(ARMWithHidden, nn.Module):
             self._state_batch = batch
         if t < self.prompt_length:
             return ()     # steps inside the prompt only advance the tiers (:254-255): before_generate did that on the device
-        buf = torch.cat([window[:, -rf:], torch.zeros_like(window[:, :1])], dim=1)
-        buf = (buf if buf.dtype == torch.int64 else buf.long()).contiguous()
+        bufs = []
+        for x in inputs:               # scratch copies of the windows with one free column for the produced step
+            buf = torch.cat([x[:, -rf:], torch.zeros_like(x[:, :1])], dim=1)
+            bufs.append((buf if buf.dtype == torch.int64 else buf.long()).contiguous())
         temp, uni = self._sampling(batch, 1, parameters)
-        self._plan.generate(buf, t, 1, temp, uni, t_first=t - rf)
+        self._plan.generate(tuple(bufs), t, 1, temp, uni, t_first=t - rf)
         self._next_t = t + 1
-        return (buf[:, rf:rf + 1],)
+        return tuple(bufs[k][:, rf:rf + 1] for k in range(len(self.output_modules)))
 
     def generate_block(self, tensors: Tuple[torch.Tensor, ...], t0: int, n_steps: int, **parameters):
         tensors = tuple(tensors)
         native.require_device(*tensors)
         idx = tensors[0]
         batch = idx.size(0)
-        if idx.dtype != torch.int64:
-            raise TypeError("generate_block writes in place: tensors[0] must be int64 class indices")
+        if any(x.dtype != torch.int64 for x in tensors):
+            raise TypeError("generate_block writes in place: the tensors must be int64 class indices")
         if self._plan is None or self._next_t != t0 or self._state_batch != batch:
-            self.before_generate((idx[:, :t0],), None)
+            self.before_generate(tuple(x[:, :t0] for x in tensors), None)
         temp, uni = self._sampling(batch, n_steps, parameters)
-        self._plan.generate(idx, t0, n_steps, temp, uni, t_first=0)
+        self._plan.generate(tensors, t0, n_steps, temp, uni, t_first=0)
         self._next_t = t0 + n_steps
         getattr(self, "_blocks", []).append((tensors, t0, n_steps, dict(parameters)))
         return True
@@ -358,7 +380,7 @@ class SampleRNN(ARMWithHidden, nn.Module):
         try:
             self._plan = None
             first_tensors, first_t0 = blocks[0][0], blocks[0][1]
-            self.before_generate((first_tensors[0][:, :first_t0],), None)
+            self.before_generate(tuple(x[:, :first_t0] for x in first_tensors), None)
             for tensors, t0, n_steps, params in blocks:
                 self.generate_block(tensors, t0, n_steps, **params)
             torch.cuda.synchronize(self.device)

@@ -311,8 +311,10 @@ class WaveNet(ARM, nn.Module):
             unsupported.append("activations other than Tanh / Sigmoid")
         if len(cfg.dims_dilated) != 1:
             unsupported.append("more than one dilated path")
-        if len(io.targets) != 1:
-            unsupported.append("more than one target")
+        n_tgt = len(io.targets)
+        if n_tgt > min(len(io.inputs), native.MAX_STREAMS):
+            unsupported.append("more targets than inputs (the loop writes output k into input k, loops/generate.py:213-218) or than "
+                               f"{native.MAX_STREAMS}")
         if len(cfg.dims_1x1) > native.MAX_COND or len(self.layers) > native.MAX_LAYERS:
             unsupported.append("too many conditioning inputs / layers")
         c = native.WaveNetConfig()
@@ -339,6 +341,9 @@ class WaveNet(ARM, nn.Module):
         c.n_cond = len(cfg.dims_1x1)
         for j, mod in enumerate(self.input_modules[1:]):
             lin = mod[0]
+            if isinstance(lin, nn.Embedding) and len(mod) == 1:       # a class stream through an EmbeddingIO: its row of the table per position
+                c.cond_q_levels[j], c.cond_dim[j] = lin.num_embeddings, lin.embedding_dim
+                continue
             if not isinstance(lin, nn.Linear) or lin.bias is None or not all(
                     isinstance(m, Chunk) and m.chunks == 1 for m in list(mod)[1:]):
                 unsupported.append(f"conditioning input module {j + 1} is not a plain (Chunked)LinearIO")
@@ -368,6 +373,21 @@ class WaveNet(ARM, nn.Module):
             c.out_dim = head[0].out_features
         else:
             unsupported.append(f"output module of type {type(head).__name__}")
+        # further targets (:293: one output module per target on the same vector): MLP heads whose class goes into input k
+        c.n_targets = n_tgt
+        for k in range(1, min(n_tgt, native.MAX_STREAMS)):
+            hk = self.output_modules[k]
+            if not (isinstance(hk, OutputWrapper) and isinstance(hk.estimator[0], MLP) and len(hk.estimator) == 1) or c.head_kind != 0:
+                unsupported.append(f"target {k}: several targets need MLP heads with samplers")
+                continue
+            mlp = hk.estimator[0]
+            if not isinstance(mlp.activation, nn.Mish) or not mlp.bias or mlp.dropout or mlp.dropout1d or mlp.n_hidden_layers > 4:
+                unsupported.append(f"target {k}: MLP head with a non-Mish activation, no bias, dropout or more than 4 hidden layers")
+            c.x_mlp_hidden[k], c.x_mlp_n_hidden[k], c.x_learn_temp[k] = mlp.hidden_dim, mlp.n_hidden_layers, int(mlp.learn_temperature)
+            c.x_out_dim[k] = mlp.out_dim - c.x_learn_temp[k]
+            c.x_min_temp[k] = float(mlp.min_temp) if mlp.learn_temperature else 0.
+            if k - 1 < len(cfg.dims_1x1) and c.cond_q_levels[k - 1] < c.x_out_dim[k]:
+                unsupported.append(f"target {k} draws classes that input {k} (not a class stream of as many classes) cannot take")
         c.max_batch = max_batch
         if unsupported:
             raise NotImplementedError("the HIP generate path does not cover: " + "; ".join(unsupported))
@@ -420,7 +440,8 @@ class WaveNet(ARM, nn.Module):
         if self._plan.cfg.head_kind != 0:
             return None, None
         t = per_row_temperature(temperature, batch, self.device)
-        u = torch.rand((batch, n_steps), device=self.device, dtype=torch.float32)
+        n_tgt = max(int(self._plan.cfg.n_targets), 1)
+        u = torch.rand((batch, n_steps) if n_tgt == 1 else (n_tgt, batch, n_steps), device=self.device, dtype=torch.float32)
         return t, u
 
     @staticmethod
@@ -434,8 +455,20 @@ class WaveNet(ARM, nn.Module):
         in0, cond = tensors[0], tuple(tensors[1:])
         if self._plan.cfg.q_levels == 0 and in0.dtype != torch.float32:
             in0 = in0.float()
-        cond = tuple(self._time_major(c if c.dtype == torch.float32 else c.float()) for c in cond)
+        classes = self._plan.cfg.cond_q_levels
+        cond = tuple(self._time_major((c if c.dtype == torch.int64 else c.long()) if classes[j] > 0 else
+                                      (c if c.dtype == torch.float32 else c.float())) for j, c in enumerate(cond))
         return self._time_major(in0), cond
+
+    def _with_blank(self, in0, cond):
+        """scratch copies with one free column behind the window for the streams a target is written to"""
+        n_tgt = max(int(self._plan.cfg.n_targets), 1)
+        blank = lambda x: torch.cat([x, torch.zeros_like(x[:, :1])], dim=1).contiguous()
+        return blank(in0), tuple(blank(c) if j + 1 < n_tgt else c for j, c in enumerate(cond))
+
+    def _outputs(self, buf, cond, col: int):
+        n_tgt = max(int(self._plan.cfg.n_targets), 1)
+        return (buf[:, col:col + 1],) + tuple(cond[k - 1][:, col:col + 1] for k in range(1, n_tgt))
 
     def _window_step(self, window: Tuple[torch.Tensor, ...], t: int, **parameters):
         """rebuild the queues from an rf-long window ending at absolute time t, then produce step t"""
@@ -443,13 +476,13 @@ class WaveNet(ARM, nn.Module):
         self._ensure_plan(batch, refresh_weights=True)
         in0, cond = self._prepare(window)
         # scratch copy of the window with one free column for the produced step
-        buf = torch.cat([in0, torch.zeros_like(in0[:, :1])], dim=1).contiguous()
+        buf, cond = self._with_blank(in0, cond)
         t_first = t - rf
         self._plan.warmup(buf, cond, t_first, t - 1, t_first=t_first)
         temp, uni = self._sampling(batch, 1, parameters)
         self._plan.generate(buf, cond, t, 1, temp, uni, t_first=t_first)
         self._next_t, self._state_batch = t + 1, batch
-        return (buf[:, rf:rf + 1],)
+        return self._outputs(buf, cond, rf)
 
     # -- ARM generation protocol ------------------------------------------------------
     def before_generate(self, prompts: Tuple[torch.Tensor, ...], batch_index) -> None:
@@ -478,11 +511,11 @@ class WaveNet(ARM, nn.Module):
             return self._window_step(tuple(x[:, -rf:] for x in inputs), t=t, **parameters)
         # queues are in sync: only the newest position (t - 1) is consumed
         in0, cond = self._prepare(tuple(x[:, -1:] for x in inputs))
-        buf = torch.cat([in0, torch.zeros_like(in0)], dim=1).contiguous()
+        buf, cond = self._with_blank(in0, cond)
         temp, uni = self._sampling(batch, 1, parameters)
         self._plan.generate(buf, cond, t, 1, temp, uni, t_first=t - 1)
         self._next_t = t + 1
-        return (buf[:, 1:2],)
+        return self._outputs(buf, cond, 1)
 
     def generate_block(self, tensors: Tuple[torch.Tensor, ...], t0: int, n_steps: int, **parameters):
         """all steps of one batch in one device call; ``tensors`` are the loop's (batch, prior+steps[, dim])
@@ -497,6 +530,9 @@ class WaveNet(ARM, nn.Module):
         in0, cond = self._prepare(tensors)
         if in0.data_ptr() != tensors[0].data_ptr():
             raise TypeError("generate_block writes in place: tensors[0] must already have the network's input dtype")
+        for k in range(1, max(int(self._plan.cfg.n_targets), 1)):
+            if cond[k - 1].data_ptr() != tensors[k].data_ptr():
+                raise TypeError(f"generate_block writes in place: tensors[{k}] must be int64 class indices, contiguous along time")
         temp, uni = self._sampling(batch, n_steps, parameters)
         self._plan.generate(in0, cond, t0, n_steps, temp, uni, t_first=0)
         self._next_t = t0 + n_steps

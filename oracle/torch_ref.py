@@ -217,7 +217,8 @@ def wavenet_window_forward(sd: SD, inputs: Tuple[torch.Tensor, ...], kernels: Se
                            n_cond: int = 0, has_skips: bool = True, residuals: bool = True,
                            n_mlp_hidden: int = 0, embedding: bool = True, groups: int = 1, head: str = "mlp",
                            gated: bool = True, layerwise_inputs: bool = False,
-                           res_layers: Optional[Sequence[bool]] = None, affine: bool = False) -> torch.Tensor:
+                           res_layers: Optional[Sequence[bool]] = None, affine: bool = False,
+                           cond_classes: Optional[Sequence[int]] = None, heads_n_hidden: Optional[Sequence[int]] = None):
     """Full-window eval forward (wavenet_v2.py:276-293 with WNLayer.forward :131-176, pad_side=0):
     returns the RAW head outputs (B, 1, q+1) of the FIRST computable position (eval_slice, :273).
     ``groups`` applies to the dilated convolutions only (:93); ``head`` "linear" / "linear_abs" is the
@@ -227,14 +228,18 @@ def wavenet_window_forward(sd: SD, inputs: Tuple[torch.Tensor, ...], kernels: Se
     (reverse_layer_order, :253, moves the layer built without one, :216, to the front) - default: all but the last;
     ``affine`` is with_affine_residuals (:122, :148-149, :157-161; ParametrizedLinear, parametrized.py:34-47): the layer's
     input goes through x_hat * a + b of a 1x1 convolution to three times its width first - the dilated convolution AND the
-    residual sum see the transformed input - and, without gated units, every conditioning input c becomes aff(c) + c."""
+    residual sum see the transformed input - and, without gated units, every conditioning input c becomes aff(c) + c.
+    ``cond_classes[j]`` > 0: conditioning input j is a stream of class indices through an EmbeddingIO (from_config :231-234 builds
+    the module of EVERY input from its spec); ``heads_n_hidden`` (one entry per target): the network has that many output modules
+    (:240-243) and the function returns the tuple of their raw outputs (:293)."""
     if embedding:
         h = F.embedding(inputs[0], sd["input_modules.0.0.weight"])
     else:
         h = F.linear(inputs[0], sd["input_modules.0.0.weight"], sd["input_modules.0.0.bias"])
     h = h.transpose(1, 2).contiguous()
     x0 = h
-    conds = [F.linear(inputs[1 + j], sd[f"input_modules.{1 + j}.0.weight"], sd[f"input_modules.{1 + j}.0.bias"])
+    conds = [(F.embedding(inputs[1 + j], sd[f"input_modules.{1 + j}.0.weight"]) if cond_classes and cond_classes[j] > 0 else
+              F.linear(inputs[1 + j], sd[f"input_modules.{1 + j}.0.weight"], sd[f"input_modules.{1 + j}.0.bias"]))
              .transpose(1, 2).contiguous() for j in range(n_cond)]
     skips = None
     n_layers = len(kernels)
@@ -276,6 +281,8 @@ def wavenet_window_forward(sd: SD, inputs: Tuple[torch.Tensor, ...], kernels: Se
             h = h + x0[..., -h.size(-1):]
         conds = [c[:, :, cause:] for c in conds]
     y = (skips if has_skips else h).transpose(1, 2).contiguous()[:, 0:1]
+    if heads_n_hidden is not None:
+        return tuple(mlp_raw(sd, f"output_modules.{k}.estimator.0.", y, n) for k, n in enumerate(heads_n_hidden))
     if head == "mlp":
         return mlp_raw(sd, "output_modules.0.estimator.0.", y, n_mlp_hidden)
     out = F.linear(y, sd["output_modules.0.0.weight"], sd["output_modules.0.0.bias"])
@@ -314,6 +321,32 @@ def wavenet_generate(sd: SD, prompt: torch.Tensor, cond: Sequence[torch.Tensor],
         if keep_logits:
             logits_log.append(raw[:, 0])
     return (idx, torch.stack(logits_log, 1)) if keep_logits else idx
+
+
+def wavenet_generate_streams(sd: SD, prompts: Sequence[torch.Tensor], n_steps: int, kernels, dilations, heads_n_hidden: Sequence[int],
+                             min_temps: Optional[Sequence[Optional[float]]] = None, temperature=None, uniforms=None,
+                             keep_logits: bool = False, forced: Optional[Sequence[torch.Tensor]] = None, **arch):
+    """the same loop for a network of several targets: output k of every step is written into input k (loops/generate.py:213-218,
+    ``zip(tensors, outputs)``).  ``prompts``: one tensor per input - the first len(heads_n_hidden) are class streams of ``prior`` steps,
+    the others (plain conditioning features, if any) cover prior + n_steps.  ``uniforms``: (targets, batch, n_steps).  Returns the tuple
+    of the streams (and the tuple of per-target raw outputs with ``keep_logits``)."""
+    rf = wavenet_rf(kernels, dilations)
+    n_tgt = len(heads_n_hidden)
+    prior = prompts[0].size(1)
+    min_temps = [1e-4] * n_tgt if min_temps is None else list(min_temps)
+    streams = [torch.cat([p, torch.zeros(p.size(0), n_steps, dtype=p.dtype)], dim=1) if k < n_tgt else p for k, p in enumerate(prompts)]
+    hist = streams if forced is None else [forced[k] if k < n_tgt else streams[k] for k in range(len(streams))]
+    logs = [[] for _ in range(n_tgt)]
+    for s, t in enumerate(range(prior, prior + n_steps)):
+        raws = wavenet_window_forward(sd, tuple(x[:, t - rf:t] for x in hist), kernels, dilations, n_cond=len(prompts) - 1,
+                                      heads_n_hidden=heads_n_hidden, **arch)
+        for k, raw in enumerate(raws):
+            u = None if uniforms is None else uniforms[k][:, s]
+            streams[k][:, t:t + 1] = categorical(mlp_logits(raw, min_temps[k]), temperature, u)
+            if keep_logits:
+                logs[k].append(raw[:, 0])
+    out = tuple(streams[:n_tgt])
+    return (out, tuple(torch.stack(l, 1) for l in logs)) if keep_logits else out
 
 
 # ---------------------------------------------------------------------------
@@ -368,7 +401,15 @@ class SampleRNNOracle:
 
     def __init__(self, sd: SD, frame_sizes: Sequence[int], hidden_dim: int, rnn_class: str = "lstm",
                  q_levels: int = 256, n_mlp_hidden: int = 0, min_temp: Optional[float] = 1e-4, h0: str = "zeros",
-                 n_rnn: int = 1):
+                 n_rnn: int = 1, in_classes: Optional[Sequence[int]] = None, inputs_mode: str = "sum",
+                 heads: Optional[Sequence[dict]] = None):
+        """``in_classes`` (one class size per input) / ``inputs_mode``: a network of several inputs - every tier's input module is
+        a ZipReduceVariables over one framed linear per input (from_config :141-145, :160-173; modules/io.py:289-313);
+        ``heads`` (one dict(n_mlp_hidden=, min_temp=) per target): several output modules on the bottom tier's vector (:181-182, :259).
+        With either, windows / prompts / results are tuples of streams and output k goes into input k (loops/generate.py:213-218)."""
+        self.in_classes = None if in_classes is None else tuple(in_classes)
+        self.inputs_mode = inputs_mode
+        self.heads = None if heads is None else [dict(h) for h in heads]
         self.sd, self.fs, self.H, self.kind = sd, tuple(frame_sizes), hidden_dim, rnn_class
         self.n_rnn = n_rnn            # stacked layers per tier (nn.LSTM / GRU num_layers, sample_rnn_v2.py:65)
         self.q, self.n_mlp_hidden, self.min_temp, self.h0 = q_levels, n_mlp_hidden, min_temp, h0
@@ -384,9 +425,33 @@ class SampleRNNOracle:
     def reset_hidden(self):
         self.hidden = [None] * (len(self.fs) - 1)
 
-    def _tier(self, i: int, frames: torch.Tensor, upper: Optional[torch.Tensor]) -> torch.Tensor:
+    def _zip(self, i: int, frames, leaf: str) -> torch.Tensor:
+        """ZipReduceVariables.forward (modules/io.py:304-313): y = head_0(x_0) w_0, then y += head_m(x_m) w_m"""
+        sd, p = self.sd, f"tiers.{i}.input_module."
+        frames = (frames,) if isinstance(frames, torch.Tensor) else tuple(frames)
+        classes = self.in_classes or (self.q,) * len(frames)
+        M = len(frames)
+        if self.inputs_mode == "sum":
+            w = torch.ones(M)
+        elif self.inputs_mode == "mean":
+            w = torch.ones(M) / M
+        else:
+            w = torch.softmax(sd[p + "weights"], dim=0)
+
+        def head(m):
+            wt = sd[p + f"heads.{m}.{leaf}weight"]
+            return F.linear(_linearize(frames[m], classes[m]), wt.reshape(self.H, -1), sd[p + f"heads.{m}.{leaf}bias"])
+
+        if M == 1 and self.in_classes is None:
+            return head(0)            # (one input: every mode weights it by 1)
+        y = head(0) * w[0]
+        for m in range(1, M):
+            y = y + head(m) * w[m]
+        return y
+
+    def _tier(self, i: int, frames, upper: Optional[torch.Tensor]) -> torch.Tensor:
         sd, p = self.sd, f"tiers.{i}."
-        x = F.linear(_linearize(frames, self.q), sd[p + "input_module.heads.0.2.weight"], sd[p + "input_module.heads.0.2.bias"])
+        x = self._zip(i, frames, "2.")
         if upper is not None:
             x = x + upper
         if self.hidden[i] is None:
@@ -399,34 +464,44 @@ class SampleRNNOracle:
         out = F.linear(x, sd[p + "up_sampler.fc.weight"], sd[p + "up_sampler.fc.bias"])
         return out.reshape(x.size(0), up, self.H)
 
-    def generate_step(self, window: torch.Tensor, t: int, temperature=None, uniforms=None):
+    def generate_step(self, window, t: int, temperature=None, uniforms=None):
         fs, n = self.fs, len(self.fs)
+        multi = not isinstance(window, torch.Tensor)
+        streams = tuple(window) if multi else (window,)
         for i in range(n - 1):
             if t % fs[i] == 0:
                 upper = None if i == 0 else self.outputs[i - 1][:, (t // fs[i]) % (fs[i - 1] // fs[i])]
-                self.outputs[i] = self._tier(i, window[:, -fs[i]:], upper)
+                self.outputs[i] = self._tier(i, tuple(x[:, -fs[i]:] for x in streams), upper)
         if t < self.prompt_length:
             return None
-        sd, p = self.sd, f"tiers.{n - 1}.input_module.heads.0.2.2.cv."
-        frames = _linearize(window[:, -fs[-1]:], self.q)
-        x = F.linear(frames, sd[p + "weight"].reshape(self.H, fs[-1]), sd[p + "bias"])
+        sd = self.sd
+        x = self._zip(n - 1, tuple(x[:, -fs[-1]:] for x in streams), "2.2.cv.")
         x = x + self.outputs[-1][:, (t % fs[-2]) - fs[-2]]
+        if self.heads is not None:
+            raws = tuple(mlp_raw(sd, f"output_modules.{k}.estimator.0.", x, h.get("n_mlp_hidden", 0)) for k, h in enumerate(self.heads))
+            self.last_raw = raws
+            return tuple(categorical(mlp_logits(raw, h.get("min_temp", 1e-4)), temperature, None if uniforms is None else uniforms[k])
+                         for k, (raw, h) in enumerate(zip(raws, self.heads)))
         raw = mlp_raw(sd, "output_modules.0.estimator.0.", x, self.n_mlp_hidden)
         self.last_raw = raw
         return categorical(mlp_logits(raw, self.min_temp), temperature, uniforms)
 
-    def before_generate(self, prompt: torch.Tensor):
+    def before_generate(self, prompt):
         self.outputs = [None] * (len(self.fs) - 1)
         self.reset_hidden()
-        length = prompt.size(1)
+        multi = not isinstance(prompt, torch.Tensor)
+        length = (prompt[0] if multi else prompt).size(1)
         offset = length % self.rf
         self.prompt_length = length - offset
         for t in range(self.rf, self.prompt_length):
-            self.generate_step(prompt[:, t + offset - self.rf:t + offset], t)
+            lo, hi = t + offset - self.rf, t + offset
+            self.generate_step(tuple(p[:, lo:hi] for p in prompt) if multi else prompt[:, lo:hi], t)
 
     def generate(self, prompt: torch.Tensor, n_steps: int, temperature=None, uniforms=None, keep_logits=False, forced=None):
         """``forced`` (batch, prior + n_steps): teacher forcing - every step sees that history instead of the oracle's own
         picks (used to check another implementation's output step by step); the returned indices are the oracle's picks"""
+        if not isinstance(prompt, torch.Tensor):
+            return self._generate_streams(tuple(prompt), n_steps, temperature, uniforms, keep_logits, forced)
         self.before_generate(prompt)
         prior = prompt.size(1)
         idx = torch.cat([prompt, torch.zeros(prompt.size(0), n_steps, dtype=prompt.dtype)], dim=1)
@@ -439,6 +514,28 @@ class SampleRNNOracle:
                 logs.append(self.last_raw)
         self.reset_hidden()
         return (idx, torch.stack(logs, 1)) if keep_logits else idx
+
+
+    def _generate_streams(self, prompts, n_steps, temperature, uniforms, keep_logits, forced):
+        """several inputs / targets: one stream per input, output k written into stream k; ``uniforms`` (targets, batch, n_steps)"""
+        self.before_generate(prompts)
+        prior = prompts[0].size(1)
+        streams = [torch.cat([p, torch.zeros(p.size(0), n_steps, dtype=p.dtype)], dim=1) for p in prompts]
+        hist = streams if forced is None else list(forced)
+        n_tgt = len(self.heads) if self.heads is not None else 1
+        logs = [[] for _ in range(n_tgt)]
+        for s, t in enumerate(range(prior, prior + n_steps)):
+            u = None if uniforms is None else [uniforms[k][:, s] for k in range(n_tgt)]
+            outs = self.generate_step(tuple(x[:, t - self.rf:t] for x in hist), t, temperature, u if self.heads is not None else (None if u is None else u[0]))
+            outs = outs if isinstance(outs, tuple) else (outs,)
+            raws = self.last_raw if isinstance(self.last_raw, tuple) else (self.last_raw,)
+            for k, o in enumerate(outs[:len(streams)]):
+                streams[k][:, t] = o
+                if keep_logits:
+                    logs[k].append(raws[k])
+        self.reset_hidden()
+        out = tuple(streams)
+        return (out, tuple(torch.stack(l, 1) for l in logs)) if keep_logits else out
 
 
 # ---------------------------------------------------------------------------

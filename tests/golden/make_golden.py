@@ -332,6 +332,65 @@ def make_srnn_options():
     save("srnn_options.npz", **arrays)
 
 
+MULTI_IO = {
+    # tag: (network, input class sizes, per-target dict(mlp_dim, n_mlp_layers), network keywords)
+    "srnn_sum_2x2": ("srnn", (256, 64), (dict(mlp_dim=32), dict(mlp_dim=48, n_mlp_layers=1)),
+                     dict(frame_sizes=(16, 4, 1), rnn_class="gru", inputs_mode="sum")),
+    "srnn_mix_2x1": ("srnn", (256, 64), (dict(mlp_dim=32),),
+                     dict(frame_sizes=(16, 8, 8), rnn_class="lstm", inputs_mode="static_mix")),
+    "srnn_mean_3x3": ("srnn", (256, 64, 32), (dict(mlp_dim=32), dict(mlp_dim=32, n_mlp_layers=2), dict(mlp_dim=16)),
+                      dict(frame_sizes=(8, 2, 2), rnn_class="rnn", inputs_mode="mean")),
+    "wn_2x2": ("wavenet", (256, 64), (dict(mlp_dim=32), dict(mlp_dim=48, n_mlp_layers=1)),
+               dict(blocks=(3, 2), dims_dilated=(32,), dims_1x1=(16,), residuals_dim=32, skips_dim=32)),
+    "wn_2x1": ("wavenet", (256, 64), (dict(mlp_dim=32),),
+               dict(blocks=(4,), dims_dilated=(32,), dims_1x1=(16,), residuals_dim=32, skips_dim=32)),
+    "wn_3x3_noskip": ("wavenet", (128, 64, 16), (dict(mlp_dim=32), dict(mlp_dim=32), dict(mlp_dim=16, n_mlp_layers=1)),
+                      dict(blocks=(3,), dims_dilated=(32,), dims_1x1=(16, 16), residuals_dim=32)),
+}
+
+
+def multi_io_spec(net_kind, classes, heads):
+    """an IOSpec of several mu-law streams: input m / target k are the input / target of IOSpec.mulaw_io at that class size
+    (io_spec.py:222-256) - the composition the reference's IOSpec(inputs=..., targets=...) dataclass is made for"""
+    kind = "embedding" if net_kind == "wavenet" else "framed_linear"
+    ins = tuple(ref.IOSpec.mulaw_io(ref.IOSpec.MuLawIOConfig(q_levels=q, input_module_type=kind)).inputs[0] for q in classes)
+    tgs = tuple(ref.IOSpec.mulaw_io(ref.IOSpec.MuLawIOConfig(q_levels=q, input_module_type=kind, **h)).targets[0]
+                for q, h in zip(classes, heads))
+    return ref.IOSpec(inputs=ins, targets=tgs)
+
+
+def make_multi_io():
+    """networks of several inputs and targets (modules/io.py:289-313 ZipReduceVariables over the inputs of a SampleRNN,
+    sample_rnn_v2.py:141-145 / :160-173 / :181-182; one WaveNet input module per input and one output module per target,
+    wavenet_v2.py:231-243 / :293) through the reference's loop, which writes output k into input k (loops/generate.py:213-218):
+    24 free-running greedy steps; the raw outputs of every head at every step"""
+    g = torch.Generator().manual_seed(47)
+    arrays = {}
+    for tag, (kind, classes, heads, kw) in MULTI_IO.items():
+        io = multi_io_spec(kind, classes, heads)
+        if kind == "srnn":
+            net = ref.SampleRNN.from_config(ref.SampleRNN.Config(io_spec=io, hidden_dim=32, **kw)).eval()
+            plen = 2 * kw["frame_sizes"][0] + 3
+        else:
+            net = ref.WaveNet.from_config(ref.WaveNet.Config(io_spec=io, **kw)).eval()
+            plen = net.rf + 5
+        load_recipe(net, seed=170 + len(tag), gain=2.0)
+        prompts = tuple(torch.randint(0, q, (3, plen), generator=g) for q in classes)
+        logs, handles = [], []
+        for mod in net.output_modules:
+            log = []
+            handles.append(mod.estimator[0].fc.register_forward_hook(lambda m, i, o, log=log: log.append(o.detach().clone())))
+            logs.append(log)
+        out = run_loop(net, prompts, 24)
+        for h in handles:
+            h.remove()
+        for m, (p_m, o_m) in enumerate(zip(prompts, out)):
+            arrays[f"{tag}_prompt{m}"], arrays[f"{tag}_out{m}"] = p_m, o_m
+        for k, log in enumerate(logs):
+            arrays[f"{tag}_raw{k}"] = torch.stack(log, 1)
+    save("multi_io.npz", **arrays)
+
+
 def make_s2s():
     g = torch.Generator().manual_seed(31)
     io = ref.IOSpec.magspec_io(ref.IOSpec.MagSpecIOConfig(n_fft=128, hop_length=32))
@@ -491,6 +550,10 @@ def make_keys():
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1:              # python make_golden.py multi_io [...]: only those files
+        for name in sys.argv[1:]:
+            globals()["make_" + name]()
+        sys.exit(0)
     make_mulaw()
     make_stft()
     make_istft()
@@ -506,4 +569,5 @@ if __name__ == "__main__":
     make_s2s_stacks()
     make_s2s_mulaw()
     make_sampler()
+    make_multi_io()
     make_keys()

@@ -1403,3 +1403,85 @@ def test_sample_rnn_options_match_reference_golden(device, tag):
     want, raw2 = O.SampleRNNOracle(sd, **arch).generate(prompt, n, keep_logits=True, forced=got)
     ok2 = H.margin_ok(raw2.numpy())
     assert bool(((got[:, prompt.size(1):] == want[:, prompt.size(1):]) | ~ok2).all()) and float(ok2.float().mean()) > 0.9
+
+
+# ---------------------------------------------------------------------------- several inputs / targets
+@pytest.mark.parametrize("tag", list(H.MULTI_IO))
+def test_multi_input_multi_target_matches_reference_golden(tag, device):
+    """networks of several inputs and targets on the HIP path (the loop writes output k into input k): (a) the fused block against
+    the reference's loop - every stream, every head's raw outputs of the last step; (b) the per-step protocol gives the same
+    streams; (c) 9 clips, teacher-forced on the device's own history, against the oracle - greedy, then sampled (every pick inside
+    the oracle's CDF interval of the same uniform, per target)"""
+    g = H.golden("multi_io.npz")
+    net, sd, arch, classes = H.multi_io(tag)
+    M = len(classes)
+    n_tgt = len(H.MULTI_IO[tag][2])
+    prompts = tuple(H.T(g[f"{tag}_prompt{m}"]) for m in range(M))
+    raws = [H.T(g[f"{tag}_raw{k}"]) for k in range(n_tgt)]
+    raws = [r.reshape(3, 24, r.shape[-1]) for r in raws]
+    ok = torch.stack([H.margin_ok(r) for r in raws]).all(0)
+    assert float(ok.float().mean()) > 0.9
+    bad = (~ok).float().cumsum(1) > 0                      # a near-tie in any head frees every later step of the clip
+    P, n = prompts[0].size(1), 24
+    out = run_loop(net, prompts, n)
+    assert len(out) == M
+    for m in range(M):
+        got, want = out[m].cpu(), H.T(g[f"{tag}_out{m}"])
+        assert torch.equal(got[:, :P], want[:, :P]) and bool(((got[:, P:] == want[:, P:]) | bad).all()), (tag, m)
+    if bool(ok.all()):
+        for k in range(n_tgt):
+            assert torch.allclose(net._plan.last_logits(3, k).cpu(), raws[k][:, -1], **LOGIT_TOL), (tag, k)
+    # (b) step by step through the ARM protocol
+    net = net.to(device)
+    rf = net.rf
+    tens = [torch.cat([p, torch.zeros(3, n, dtype=torch.int64)], 1).to(device) for p in prompts]
+    net.before_generate(tuple(x[:, :P] for x in tens), None)
+    for t in range(P, P + n):
+        outs = net.generate_step(tuple(x[:, t - rf:t] for x in tens), t=t)
+        assert type(outs) is tuple and len(outs) == n_tgt and all(o.shape == (3, 1) for o in outs)
+        for x, o in zip(tens, outs):
+            x[:, t:t + 1] = o
+    net.after_generate(tuple(tens), None)
+    for m in range(M):
+        assert torch.equal(tens[m].cpu(), out[m].cpu()), (tag, m)
+    # (c) more clips than the fixture holds, against the oracle
+    gen = torch.Generator().manual_seed(len(tag))
+    B, n2 = 9, 40
+    P2 = 3 * rf + 2 if tag.startswith("srnn") else rf + 7
+    pr = tuple(torch.randint(0, q, (B, P2), generator=gen) for q in classes)
+
+    def oracle(forced, temperature=None, uniforms=None):
+        if tag.startswith("srnn"):
+            return O.SampleRNNOracle(sd, **arch).generate(pr, n2, temperature=temperature, uniforms=uniforms, keep_logits=True, forced=forced)
+        ks, ds, kw = arch
+        blank = tuple(torch.cat([p, torch.zeros(B, n2, dtype=p.dtype)], 1) for p in pr[n_tgt:])
+        return O.wavenet_generate_streams(sd, pr[:n_tgt] + blank, n2, ks, ds, temperature=temperature, uniforms=uniforms, keep_logits=True,
+                                          forced=forced, **kw)
+
+    tens = [torch.cat([p, torch.zeros(B, n2, dtype=torch.int64)], 1).to(device) for p in pr]
+    net.before_generate(tuple(x[:, :P2] for x in tens), None)
+    assert net.generate_block(tuple(tens), P2, n2)
+    net.after_generate(tuple(tens), None)
+    got = [x.cpu() for x in tens]
+    want, raw2 = oracle(got)
+    for k in range(n_tgt):
+        ok2 = H.margin_ok(raw2[k].numpy())
+        assert bool(((got[k][:, P2:] == want[k][:, P2:]) | ~ok2).all()) and float(ok2.float().mean()) > 0.9, (tag, k)
+    for m in range(n_tgt, M):
+        assert int(got[m][:, P2:].abs().max()) == 0          # (a stream no target feeds keeps the loop's blanks)
+    # sampled decode: the uniforms the network drew are not visible from outside, so the plan is driven directly
+    temp = torch.full((B,), 0.8)
+    uni = torch.rand(n_tgt, B, n2, generator=gen)
+    tens = [torch.cat([p, torch.zeros(B, n2, dtype=torch.int64)], 1).to(device) for p in pr]
+    net.before_generate(tuple(x[:, :P2] for x in tens), None)
+    u_dev = (uni if n_tgt > 1 else uni[0]).contiguous().to(device)
+    if tag.startswith("srnn"):
+        net._plan.generate(tuple(tens), P2, n2, temp.to(device), u_dev)
+    else:
+        net._plan.generate(tens[0], tens[1:], P2, n2, temp.to(device), u_dev)
+    torch.cuda.synchronize()
+    got = [x.cpu() for x in tens]
+    _, raw3 = oracle(got, temperature=temp, uniforms=uni)
+    for k in range(n_tgt):
+        ok3, exact = H.sampled_picks_ok(raw3[k], temp, uni[k], got[k][:, P2:])
+        assert bool(ok3.all()) and float(exact.float().mean()) > 0.99, (tag, k)

@@ -259,3 +259,25 @@ def test_sample_rnn_options_oracle_matches_reference(tag):
     out, raw = o.generate(H.T(g[f"{tag}_prompt"]), 40, keep_logits=True)
     assert torch.equal(out, H.T(g[f"{tag}_out"]))
     assert torch.allclose(raw, H.T(g[f"{tag}_raw"]).reshape(raw.shape), rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("tag", list(H.MULTI_IO))
+def test_multi_input_multi_target_oracle_matches_reference(tag):
+    """networks of several inputs and targets through the reference's loop (output k is written into input k): ZipReduceVariables
+    over the inputs of a SampleRNN (sum / mean / static_mix), one output module per target; a WaveNet whose conditioning inputs
+    are class streams through EmbeddingIO modules, with and without skips, more inputs than targets included"""
+    g = H.golden("multi_io.npz")
+    _, sd, arch, classes = H.multi_io(tag)
+    prompts = tuple(H.T(g[f"{tag}_prompt{m}"]) for m in range(len(classes)))
+    if tag.startswith("srnn"):
+        outs, raws = O.SampleRNNOracle(sd, **arch).generate(prompts, 24, keep_logits=True)
+    else:
+        ks, ds, kw = arch
+        n_tgt = len(kw["heads_n_hidden"])       # (the loop fills every tensor with blanks behind the prompt; only the first n_tgt are written)
+        blank = tuple(torch.cat([p, torch.zeros(p.size(0), 24, dtype=p.dtype)], 1) for p in prompts[n_tgt:])
+        outs, raws = O.wavenet_generate_streams(sd, prompts[:n_tgt] + blank, 24, ks, ds, keep_logits=True, **kw)
+        outs = outs + blank
+    for m in range(len(classes)):
+        assert torch.equal(outs[m], H.T(g[f"{tag}_out{m}"])), (tag, m)
+    for k, raw in enumerate(raws):
+        assert torch.allclose(raw, H.T(g[f"{tag}_raw{k}"]).reshape(raw.shape), rtol=1e-5, atol=1e-5), (tag, k)
