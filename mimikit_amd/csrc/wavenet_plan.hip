@@ -1465,7 +1465,7 @@ extern "C" int mmk_wavenet_sync_status(mmk_wavenet_plan* p, mmk_stream_t stream)
   {
     const char* senv = diag_only("MMK_WN_STAMPS");
     if (senv && senv[0] == '1') {
-      unsigned long long st[176];
+      unsigned long long st[256];
       MMK_HIP(hipMemcpy(st, p->tau + 8, p->spipe ? sizeof(st) : 24 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
       if (p->spipe) {
         fprintf(stderr, "[mmk stamps] last stage-pipeline launch, chain wave 0 of CU 0 of stage MMK_WN_STAMP_STAGE (default 1), shader cycles per visit: "
@@ -1475,6 +1475,11 @@ extern "C" int mmk_wavenet_sync_status(mmk_wavenet_plan* p, mmk_stream_t stream)
                         "their hand-over (rest of the poll + store)=%.0f; rows landed=%.0f; bias products=%.0f\n",
                 st[3] ? (double)st[6] / (double)st[3] : 0.0, st[3] ? (double)st[7] / (double)st[3] : 0.0, st[3] ? (double)st[8] / (double)st[3] : 0.0,
                 st[3] ? (double)st[9] / (double)st[3] : 0.0, st[3] ? (double)st[10] / (double)st[3] : 0.0, st[3] ? (double)st[11] / (double)st[3] : 0.0);
+        if (const char* d = diag_only("MMK_WN_SPIPE_DBG"); d && (atoi(d) & 4)) {
+          fprintf(stderr, "[mmk stamps] FREE RUN (nothing waits for a message; wrong results): ns per visit of stage s when its inbox is never empty:");
+          for (int l = 0; l <= p->L; ++l) fprintf(stderr, " %d:%.0f", l, st[3] ? 10.0 * (double)(st[144 + l] - st[182 + l]) / (double)st[3] * (l == p->L ? 8.0 : 1.0) : 0.0);
+          fprintf(stderr, " (the last entry: the head, one of its eight workgroups x 8)\n");
+        }
         fprintf(stderr, "[mmk stamps] extra looks per visit=%.2f; clip 0, last step, publish time of stage s minus stage s - 1 in 10 ns ticks:",
                 st[3] ? (double)st[4] / (double)st[3] : 0.0);
         for (int l = 1; l < p->L; ++l) fprintf(stderr, " %lld", (long long)(st[16 + l] - st[16 + l - 1]));

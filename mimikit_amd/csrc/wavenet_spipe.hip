@@ -71,9 +71,6 @@ constexpr int kSlotShift = MMK_SP_SLOT_SHIFT;
 #ifndef MMK_SP_LAG
 #define MMK_SP_LAG 1           // the biases run four iterations behind the messages ...
 #endif
-#ifndef MMK_SP_LAG_DIL
-#define MMK_SP_LAG_DIL 0       // ... and, from eight clips on, in the stages with a dilation up to this
-#endif
 #ifndef MMK_SP_LAG_CLIPS
 #define MMK_SP_LAG_CLIPS 40    // ... from this many clips on (>= 8).  Measured on one box, cfg 4, us per step: 32 clips 53.2 with the lag, 52.0 without; 64 clips
                                // (with the early looks) 92.1 with it, 97.3 without: the lag pays where the clips queue up, and costs where one clip's latency binds
@@ -102,6 +99,15 @@ constexpr int kSlotShift = MMK_SP_SLOT_SHIFT;
 #ifndef MMK_SP_EARLY
 #define MMK_SP_EARLY 0         // a helper looks for its next message already while it waits for the one before (staged by another helper): cfg 4, 64 clips 99.2 -> 92.1 us
                                // per step before the next-duty helper looked first; with that, 32 clips 44.9 without the early looks, 46.4 - 47.4 with them
+#endif
+#ifndef MMK_SP_LAG1
+#define MMK_SP_LAG1 1          // where the delayed input cannot be asked for early (dilation 1 and 2), its rows are staged TWO iterations after the request instead of one
+#endif
+#ifndef MMK_SP_BIASSHIFT
+#define MMK_SP_BIASSHIFT 1     // the bias of a visit is multiplied one iteration after its rows were staged (no helper waits for another one's staging inside an iteration)
+#endif
+#ifndef MMK_SP_NOARRWAIT
+#define MMK_SP_NOARRWAIT 1     // helpers off duty do not wait for the current message (16 clips or more: the rings' own counters bound how far they run ahead)
 #endif
 #ifndef MMK_SP_WAKEUP
 #define MMK_SP_WAKEUP 1        // the looking helper wakes the chain waves out of their s_sleep when it has staged a message
@@ -332,6 +338,11 @@ __device__ void chain_role(const WnSpipeArgs& a, Lds& S, int stage, int p, int q
         const u64 t = __builtin_amdgcn_s_memtime(); st.t_wait += t - t0c; t0c = t;
         if (a.stamps && c == 0 && s + 1 == n_steps && p == 0 && q == 0 && lane == 0) a.stamps[112 + stage] = __builtin_amdgcn_s_memrealtime();
       }
+      if (STAMPS && (a.dbg & 16)) {          // (diagnostic build, timing only: the chain waves do nothing - what the helpers' loop takes alone)
+        lds_signal(&S.hdone[q], v + 1, lane);
+        st.visits += 1;
+        continue;
+      }
       // what the helper prepared a step ahead: W0 x[t - d] + conditioning + biases
       const float bzv = S.bias[bias_off(q, s & 1, c, j, Bcap)];
       const float* xb = S.xy[v & (kXyRing - 1)];
@@ -471,7 +482,9 @@ __device__ void chain_role(const WnSpipeArgs& a, Lds& S, int stage, int p, int q
 // s - 1 of clip c has left the head - every visit up to (c, s - 1) is complete on every CU of this stage.  Row t_{s+1} - d of clip c was
 // written by visit (c, s + 1 - d): covered iff d >= 2.  d = 1 polls the stage's own newest message instead (its ring entry has no
 // arrival check).  Step 0's biases (rows the warm-up wrote) are prepared before the loop.
-template <bool STAMPS>
+// LAG4: the launch's biases run four iterations behind the messages (40 clips or more).  A template argument, not a run-time flag: with
+// both forms of the loop in one body the 32-clip step took 44.0 us instead of 42.2 (the compiler's schedule of the common part changes)
+template <bool STAMPS, bool LAG4>
 __device__ void helper_role(const WnSpipeArgs& a, Lds& S, int stage, int p, int h, int lane) {
   const int W = 4 * p + h;
   const int ks = lane & 15;                     // K slice of 16 of the delayed input and the conditioning row (4 gate rows per lane)
@@ -511,10 +524,14 @@ __device__ void helper_role(const WnSpipeArgs& a, Lds& S, int stage, int p, int 
   // stage's own output of the visit before (which the chain waves may still be working on when the next message is already staged:
   // with the bias of visit it + B made in iteration it + 1, the helpers - and with them the staging of the next messages - went at the
   // pace of chain visit + look round trip + bias products: 1.7 us per visit in front of stages 10 and 20, the ring's beat).
-  const int lag = (MMK_SP_LAG && B >= 8 && (B >= MMK_SP_LAG_CLIPS || d <= MMK_SP_LAG_DIL)) ? 4 : 0;
+  // (one iteration behind where the rows cannot be asked for ahead of time - dilation 1 and 2: a row asked for at the end of the duty
+  //  iteration and staged at the start of the next one is waited for, ~0.3 us in front of everything that helper does in that iteration;
+  //  in a free run - nothing waits for messages - those stages take 1.60 - 1.66 us per visit against 1.54, and the slowest stage is the ring's beat)
+  const int lag = LAG4 ? 4 : ((MMK_SP_LAG1 && B >= 8 && ahead == 0) ? 1 : 0);
+  const int roff = lag == 4 ? B - 1 : B + ahead;          // the rows of visit it + roff are asked for in iteration it
   // who asks for (and stages) the rows of visit v: the helper that looks in iteration v - B + 1 (lag 4) or v - B - ahead (no lag), right after
   // its look duty
-  auto rows_mine = [&](int v) { return (((unsigned)(lag ? v - B + 1 : v - B - ahead)) & 3u) == (unsigned)h; };
+  auto rows_mine = [&](int v) { return (((unsigned)(v - roff)) & 3u) == (unsigned)h; };
   // ---- looking for messages -----------------------------------------------------------------------------------------------------------------
   const __amdgpu_buffer_rsrc_t inbox = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned*>(a.msg + (int64_t)stage * stage_words), 0, -1, 0x00020000);
   const int look_off = 32 * lane;                                       // bytes inside one message
@@ -524,7 +541,12 @@ __device__ void helper_role(const WnSpipeArgs& a, Lds& S, int stage, int p, int 
     lo = __builtin_amdgcn_raw_buffer_load_b128(inbox, byte_off, 0, 16);
     hi = __builtin_amdgcn_raw_buffer_load_b128(inbox, byte_off + 16, 0, 16);
   };
+  // (diagnostic build, dbg 4: nothing waits for a message - every stage runs at the pace of its own work; results are wrong, the
+  //  per-stage times say what a stage's service time is when its inbox is never empty)
+  const bool freerun = STAMPS && (a.dbg & 4);
+  if (STAMPS && a.stamps && freerun && p == 0 && h == 0 && lane == 0) a.stamps[182 + stage] = __builtin_amdgcn_s_memrealtime();
   auto landed = [&](const u32x4s& lo, const u32x4s& hi) {
+    if (freerun) return true;
     const bool ok = lo[0] != kSpPoison && lo[1] != kSpPoison && lo[2] != kSpPoison && lo[3] != kSpPoison && hi[0] != kSpPoison &&
                     hi[1] != kSpPoison && hi[2] != kSpPoison && hi[3] != kSpPoison;
     return __all(ok) != 0;
@@ -569,6 +591,10 @@ __device__ void helper_role(const WnSpipeArgs& a, Lds& S, int stage, int p, int 
   // the bias of visit v3 = (c2, s2): W0 x_s[t - d] + W_1x1 c[t] + constants, into the LDS image the chain wave reads
   auto bias_of = [&](unsigned v3, int s2, int c2) -> bool {
     if (!lds_wait1(&S.rows_ready[v3 & (kRowRing - 1)], v3 + 1, a.err_flag)) return false;
+    if (STAMPS && (a.dbg & 8)) {             // (diagnostic build, timing only: no bias products - what the rest of the helpers' loop takes)
+      lds_signal(&S.ready[h], v3 + 1, lane);
+      return true;
+    }
     const float* xs = &S.rows[v3 & (kRowRing - 1)][0][kRowSlice * ks];
     f32x2 acc[4][2];
 #pragma unroll
@@ -613,7 +639,6 @@ __device__ void helper_role(const WnSpipeArgs& a, Lds& S, int stage, int p, int 
   }
   int s = 0, c = 0;                               // visit it = (c, s)
   int sp = 0, cp = B - 1 - lag;                   // visit it - 1 - lag + B = (cp, sp): the bias that is due in iteration it
-  const int roff = lag ? B - 1 : B + ahead;
   int sa = roff / B, ca = roff % B;               // visit it + roff = (ca, sa): the rows asked for in iteration it
   int sl = 4 / B, cl = 4 % B;                     // visit it + 4 = (cl, sl): the message whose first look goes out in iteration it
   if (lag == 0 && ahead > 0)                      // (what iterations -2 and -1 would have asked for: positions the warm-up wrote)
@@ -626,6 +651,8 @@ __device__ void helper_role(const WnSpipeArgs& a, Lds& S, int stage, int p, int 
   // fewer clips, four visits ahead is up to four STEPS ahead - a slot that still holds the message of four steps ago.
   const bool lookahead = B >= 4;
   bool staged_next = false;                       // my next message is staged already (in the iteration before the duty)
+  constexpr int shift = (MMK_SP_BIASSHIFT && LAG4) ? 1 : 0;      // the biases one iteration behind their rows' staging (with the four-iteration lag: 64 clips 84.9 -> 82.7 us per step)
+  int spb = 0, cpb = 0;                           // (the visit staged in the iteration before)
   // this stage's message comes from another XCD (or, stage 0, from the head): a look is a ~0.8-us round trip there, ~0.3 inside an XCD
   const bool remote_in = stage == 0 ? ((a.L + slot_shift(a)) >> 2) != (slot_shift(a) >> 2) : ((stage - 1 + slot_shift(a)) >> 2) != ((stage + slot_shift(a)) >> 2);
   if (lookahead && h < n_visits) look(((((h % B) * kSpSlots + ((h / B) & 3)) * kMsgFloats) * 4) + look_off, pre_lo, pre_hi);   // the first look at "my" first message
@@ -638,11 +665,15 @@ __device__ void helper_role(const WnSpipeArgs& a, Lds& S, int stage, int p, int 
     // ... and behind it the hidden units' hand-over of the stage below for the same visit (this CU's 16 units), for the chain waves' sums
     auto fetch_hid = [&](int vv, int cc, int ss) -> bool {
       if (!hid_chain_in) return true;
+      if (STAMPS && (a.dbg & 32)) {          // (diagnostic build, timing only: the hidden sums' hand-over is not fetched)
+        lds_signal(&S.hidin_ready[vv & 3], (unsigned)vv + 1, lane);
+        return true;
+      }
       const unsigned* src = a.hidmsg + (int64_t)stage * hid_words + ((int64_t)cc * kSpSlots + (ss & 3)) * kH1 + 16 * p + (lane & 15);
       unsigned w, spins = 0;
       for (;;) {
         w = msg_load(src);
-        if (__all(w != kSpPoison)) break;
+        if (__all(w != kSpPoison) || freerun) break;
         if (++spins > kSpinLimit || ((spins & 1023u) == 0 && __hip_atomic_load(a.err_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
           atomicExch(a.err_flag, 1);
           return false;
@@ -734,7 +765,7 @@ __device__ void helper_role(const WnSpipeArgs& a, Lds& S, int stage, int p, int 
         if (kPollGap > 0) __builtin_amdgcn_s_sleep(kPollGap);
       }
       __atomic_signal_fence(__ATOMIC_SEQ_CST);
-    } else if (!lds_wait1(&S.arrived[it & 3], (unsigned)it + 1, a.err_flag)) return;
+    } else if (!(MMK_SP_NOARRWAIT && (LAG4 || B >= 16)) && !lds_wait1(&S.arrived[it & 3], (unsigned)it + 1, a.err_flag)) return;
     hstamp(1);
     // ---- 2. the bias of visit it - 1 - lag + B (its rows were asked for one, three or four iterations ago) -------------------------------------
     if (it >= 1 + lag && it - 1 - lag + B < n_visits) {
@@ -742,7 +773,7 @@ __device__ void helper_role(const WnSpipeArgs& a, Lds& S, int stage, int p, int 
       if (rows_mine((int)v3)) {
         if (d == 1) {
           unsigned spins = 0;
-          while (!__all(xr[0] != kSpPoison && xr[1] != kSpPoison && xr[2] != kSpPoison && xr[3] != kSpPoison)) {
+          while (!freerun && !__all(xr[0] != kSpPoison && xr[1] != kSpPoison && xr[2] != kSpPoison && xr[3] != kSpPoison)) {
             if (++spins > kSpinLimit || ((spins & 1023u) == 0 && __hip_atomic_load(a.err_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
               atomicExch(a.err_flag, 1);
               return;
@@ -779,7 +810,13 @@ __device__ void helper_role(const WnSpipeArgs& a, Lds& S, int stage, int p, int 
       staged_next = true;
     }
 #endif
-    if (it >= 1 + lag && it - 1 - lag + B < n_visits) {
+    if (shift) {
+      if (it >= 2 + lag && it - 2 - lag + B < n_visits) {
+        if (!bias_of((unsigned)(it - 2 - lag + B), spb, cpb)) return;
+        hstamp(5);
+      }
+      spb = sp; cpb = cp;
+    } else if (it >= 1 + lag && it - 1 - lag + B < n_visits) {
       const unsigned v3 = (unsigned)(it - 1 - lag + B);
       if (!bias_of(v3, sp, cp)) return;
       hstamp(5);
@@ -792,6 +829,7 @@ __device__ void helper_role(const WnSpipeArgs& a, Lds& S, int stage, int p, int 
     hstamp(0);
     if (++c == B) { c = 0; ++s; }
   }
+  if (STAMPS && a.stamps && freerun && p == 0 && h == 0 && lane == 0) a.stamps[144 + stage] = __builtin_amdgcn_s_memrealtime();
   if (STAMPS && a.stamps && stage == a.stamp_stage && p == 0 && h == 0 && lane == 0) {
     for (int k = 0; k < 6; ++k) a.stamps[6 + k] = hs_t[k];
     a.stamps[4] = 4 * n_polls;          // (helper 0 looks for a quarter of the visits)
@@ -872,7 +910,7 @@ __device__ void head_role(const WnSpipeArgs& a, int p) {
     unsigned w1 = 0, spins = 0;
     for (;;) {
       if (mine) w1 = msg_load(src);
-      if (__all(!mine || w1 != kSpPoison)) break;
+      if (__all(!mine || w1 != kSpPoison) || (STAMPS && (a.dbg & 4))) break;
       if (++spins > kSpinLimit || ((spins & 1023u) == 0 && __hip_atomic_load(a.err_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
         atomicExch(a.err_flag, 1);
         s_fail = 1;
@@ -885,6 +923,7 @@ __device__ void head_role(const WnSpipeArgs& a, int p) {
   if (wave == 0)
     for (int c = p; c < a.B; c += kCuPerStage) publish_class(c, 0, (int)a.idx[(int64_t)c * a.idx_rs + a.t0 - 1]);
   __syncthreads();
+  if (STAMPS && a.stamps && (a.dbg & 4) && p == 0 && tid == 0) a.stamps[182 + a.L] = __builtin_amdgcn_s_memrealtime();
   for (int s = 0; s < (int)a.n_steps; ++s) {
     const int64_t tau = a.t0 - 1 + s;
     const int slot = s & 3;
@@ -913,7 +952,7 @@ __device__ void head_role(const WnSpipeArgs& a, int p) {
           if (want_h) wh1 = msg_load(hlast);
           asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(w4) : "v"(src) : "memory");
           const bool ok = w4[0] != kSpPoison && w4[1] != kSpPoison && w4[2] != kSpPoison && w4[3] != kSpPoison && (!want_h || wh1 != kSpPoison);
-          if (__all(ok)) break;
+          if (__all(ok) || (STAMPS && (a.dbg & 4))) break;
           if (++spins > kSpinLimit || ((spins & 1023u) == 0 && __hip_atomic_load(a.err_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
             atomicExch(a.err_flag, 1);
             s_fail = 1;
@@ -1035,9 +1074,10 @@ __device__ void head_role(const WnSpipeArgs& a, int p) {
   }
   if (STAMPS && a.stamps && p == 0 && tid == 0)
     for (int k = 0; k < 6; ++k) a.stamps[176 + k] = hs_t[k];
+  if (STAMPS && a.stamps && (a.dbg & 4) && p == 0 && tid == 0) a.stamps[144 + a.L] = __builtin_amdgcn_s_memrealtime();
 }
 
-template <bool STAMPS>
+template <bool STAMPS, bool LAG4>
 __global__ __launch_bounds__(kThreads) void wavenet_spipe_kernel(const WnSpipeArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char spipe_lds[];      // Lds + the bias image of bias_cap(B) clips (launch_wavenet_spipe sizes it)
   Lds& S = *reinterpret_cast<Lds*>(spipe_lds);
@@ -1071,7 +1111,7 @@ __global__ __launch_bounds__(kThreads) void wavenet_spipe_kernel(const WnSpipeAr
   if (wave < 4) {
     chain_role<STAMPS>(a, S, stage, p, wave, lane);
   } else {
-    helper_role<STAMPS>(a, S, stage, p, wave - 4, lane);
+    helper_role<STAMPS, LAG4>(a, S, stage, p, wave - 4, lane);
   }
 }
 
@@ -1202,19 +1242,24 @@ int launch_wavenet_spipe(const WnSpipeArgs& a, hipStream_t stream) {
   const size_t lds = sizeof(Lds) + (size_t)4 * 2 * bias_cap(a.B) * 16 * sizeof(float);
   {      // (more than 64 KB of dynamic LDS has to be asked for; per launch: the attribute belongs to the current device)
     const size_t lds_max = sizeof(Lds) + (size_t)4 * 2 * kSpMaxClips * 16 * sizeof(float);
-    MMK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&wavenet_spipe_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
+    MMK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&wavenet_spipe_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
+    MMK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&wavenet_spipe_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
 #ifdef MMK_DIAG
-    MMK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&wavenet_spipe_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
+    MMK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&wavenet_spipe_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
+    MMK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&wavenet_spipe_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
 #endif
   }
+  const bool lag4 = MMK_SP_LAG && a.B >= MMK_SP_LAG_CLIPS && a.B >= 12;      // (the biases four iterations behind the messages: helper_role)
 #ifdef MMK_DIAG
   if (a.stamps) {      // the stamped instantiation (and its timing switches) exist in the diagnostic build only
-    hipLaunchKernelGGL(wavenet_spipe_kernel<true>, dim3(256), dim3(kThreads), lds, stream, a);
+    if (lag4) hipLaunchKernelGGL((wavenet_spipe_kernel<true, true>), dim3(256), dim3(kThreads), lds, stream, a);
+    else hipLaunchKernelGGL((wavenet_spipe_kernel<true, false>), dim3(256), dim3(kThreads), lds, stream, a);
     MMK_HIP(hipGetLastError());
     return MMK_OK;
   }
 #endif
-  hipLaunchKernelGGL(wavenet_spipe_kernel<false>, dim3(256), dim3(kThreads), lds, stream, a);
+  if (lag4) hipLaunchKernelGGL((wavenet_spipe_kernel<false, true>), dim3(256), dim3(kThreads), lds, stream, a);
+  else hipLaunchKernelGGL((wavenet_spipe_kernel<false, false>), dim3(256), dim3(kThreads), lds, stream, a);
   MMK_HIP(hipGetLastError());
   return MMK_OK;
 }
