@@ -100,6 +100,12 @@ constexpr int kSlotShift = MMK_SP_SLOT_SHIFT;
 #define MMK_SP_EARLY 0         // a helper looks for its next message already while it waits for the one before (staged by another helper): cfg 4, 64 clips 99.2 -> 92.1 us
                                // per step before the next-duty helper looked first; with that, 32 clips 44.9 without the early looks, 46.4 - 47.4 with them
 #endif
+#ifndef MMK_SP_CHAIN_SLEEP_BY_MODE
+#define MMK_SP_CHAIN_SLEEP_BY_MODE 1
+#endif
+#ifndef MMK_SP_POLL_GAP_BY_MODE
+#define MMK_SP_POLL_GAP_BY_MODE 1
+#endif
 #ifndef MMK_SP_LAG1
 #define MMK_SP_LAG1 1          // where the delayed input cannot be asked for early (dilation 1 and 2), its rows are staged TWO iterations after the request instead of one
 #endif
@@ -251,13 +257,14 @@ struct Stamps {
 // ------------------------------------------------------------------------------------------------------------------------------------
 // the two things a chain wave waits for in LDS before it computes visit v, read together: the message staged by the polling helper, this
 // wave's bias prepared
+template <int SLEEP>
 __device__ __forceinline__ bool chain_wait(const Lds& S, int q, unsigned v, int32_t* err) {
   unsigned spins = 0;
   for (;;) {
     const unsigned arr = __hip_atomic_load(&S.arrived[v & 3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     const unsigned rd = __hip_atomic_load(&S.ready[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     if (arr >= v + 1 && rd >= v + 1) break;
-    if (kChainSleep > 0) __builtin_amdgcn_s_sleep(kChainSleep);
+    if (SLEEP > 0) __builtin_amdgcn_s_sleep(SLEEP);
     if (++spins > kSpinLimit || ((spins & 4095u) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
       atomicExch(err, 1);
       return false;
@@ -267,7 +274,9 @@ __device__ __forceinline__ bool chain_wait(const Lds& S, int q, unsigned v, int3
   return true;
 }
 
-template <bool STAMPS>
+// (LAG4 - 40 clips or more, the ring goes at the stages' beat: the chain waves sleep between two looks at their counters and leave the issue
+//  slots to the helpers, 64 clips 71.9 -> 71.2 us per step; with fewer clips the step is one clip's trip and they look without a pause, 32 clips 42.0 -> 41.5)
+template <bool STAMPS, bool LAG4>
 __device__ void chain_role(const WnSpipeArgs& a, Lds& S, int stage, int p, int q, int lane) {
   const int W = 4 * p + q;
   // products: a lane holds 4 gate rows x one K slice of 32 of [x | y] (and 2 residual rows x 16 of y); the rows' totals come out of a
@@ -332,7 +341,7 @@ __device__ void chain_role(const WnSpipeArgs& a, Lds& S, int stage, int p, int q
     const int slot = s & 3, pslot = (s + 2) & 3;
     for (int c = 0; c < B; ++c, ++v) {
       if (STAMPS) t0c = __builtin_amdgcn_s_memtime();
-      if (!chain_wait(S, q, v, a.err_flag)) return;
+      if (!chain_wait<MMK_SP_CHAIN_SLEEP_BY_MODE ? (LAG4 ? kChainSleep : 0) : kChainSleep>(S, q, v, a.err_flag)) return;
       __builtin_amdgcn_s_setprio(MMK_SP_CHAIN_PRIO);              // (low while it spins: the helper wave of this SIMD gets the issue slots)
       if (STAMPS) {
         const u64 t = __builtin_amdgcn_s_memtime(); st.t_wait += t - t0c; t0c = t;
@@ -543,6 +552,7 @@ __device__ void helper_role(const WnSpipeArgs& a, Lds& S, int stage, int p, int 
   };
   // (diagnostic build, dbg 4: nothing waits for a message - every stage runs at the pace of its own work; results are wrong, the
   //  per-stage times say what a stage's service time is when its inbox is never empty)
+  constexpr int kGap = MMK_SP_POLL_GAP_BY_MODE ? (LAG4 ? kPollGap : 0) : kPollGap;
   const bool freerun = STAMPS && (a.dbg & 4);
   if (STAMPS && a.stamps && freerun && p == 0 && h == 0 && lane == 0) a.stamps[182 + stage] = __builtin_amdgcn_s_memrealtime();
   auto landed = [&](const u32x4s& lo, const u32x4s& hi) {
@@ -705,7 +715,7 @@ __device__ void helper_role(const WnSpipeArgs& a, Lds& S, int stage, int p, int 
             atomicExch(a.err_flag, 1);
             return;
           }
-          if (kPollGap > 0 && spins > 1) __builtin_amdgcn_s_sleep(kPollGap);
+          if (kGap > 0 && spins > 1) __builtin_amdgcn_s_sleep(kGap);
           look(off, pre_lo, pre_hi);
         }
         if (STAMPS) n_polls += spins;
@@ -801,7 +811,7 @@ __device__ void helper_role(const WnSpipeArgs& a, Lds& S, int stage, int p, int 
           atomicExch(a.err_flag, 1);
           return;
         }
-        if (kPollGap > 0 && spins > 1) __builtin_amdgcn_s_sleep(kPollGap);
+        if (kGap > 0 && spins > 1) __builtin_amdgcn_s_sleep(kGap);
         look(off, pre_lo, pre_hi);
       }
       if (STAMPS) n_polls += spins;
@@ -1109,7 +1119,7 @@ __global__ __launch_bounds__(kThreads) void wavenet_spipe_kernel(const WnSpipeAr
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   if (wave < 4) {
-    chain_role<STAMPS>(a, S, stage, p, wave, lane);
+    chain_role<STAMPS, LAG4>(a, S, stage, p, wave, lane);
   } else {
     helper_role<STAMPS, LAG4>(a, S, stage, p, wave - 4, lane);
   }
