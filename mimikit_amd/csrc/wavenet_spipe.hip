@@ -72,7 +72,7 @@ constexpr int kSlotShift = MMK_SP_SLOT_SHIFT;
 #define MMK_SP_LAG 1           // the biases run four iterations behind the messages ...
 #endif
 #ifndef MMK_SP_LAG_CLIPS
-#define MMK_SP_LAG_CLIPS 40    // ... from this many clips on (>= 8).  Measured on one box, cfg 4, us per step: 32 clips 53.2 with the lag, 52.0 without; 64 clips
+#define MMK_SP_LAG_CLIPS 36    // ... from this many clips on (>= 8).  Measured on one box, cfg 4, us per step: 32 clips 53.2 with the lag, 52.0 without; 64 clips
                                // (with the early looks) 92.1 with it, 97.3 without: the lag pays where the clips queue up, and costs where one clip's latency binds
 #endif
 #ifndef MMK_SP_CHAIN_PRIO
