@@ -340,10 +340,10 @@ __device__ void chain_role(const WnSpipeArgs& a, Lds& S, int stage, int p, int q
     const int64_t tau = a.t0 - 1 + s;
     const int slot = s & 3, pslot = (s + 2) & 3;
     for (int c = 0; c < B; ++c, ++v) {
-      if (STAMPS) t0c = __builtin_amdgcn_s_memtime();
+      if (STAMPS && !(a.dbg & 64)) t0c = __builtin_amdgcn_s_memtime();
       if (!chain_wait<MMK_SP_CHAIN_SLEEP_BY_MODE ? (LAG4 ? kChainSleep : 0) : kChainSleep>(S, q, v, a.err_flag)) return;
       __builtin_amdgcn_s_setprio(MMK_SP_CHAIN_PRIO);              // (low while it spins: the helper wave of this SIMD gets the issue slots)
-      if (STAMPS) {
+      if (STAMPS && !(a.dbg & 64)) {
         const u64 t = __builtin_amdgcn_s_memtime(); st.t_wait += t - t0c; t0c = t;
         if (a.stamps && c == 0 && s + 1 == n_steps && p == 0 && q == 0 && lane == 0) a.stamps[112 + stage] = __builtin_amdgcn_s_memrealtime();
       }
@@ -425,7 +425,7 @@ __device__ void chain_role(const WnSpipeArgs& a, Lds& S, int stage, int p, int q
         unsigned* dst = msg_out + ((int64_t)c * kSpSlots + slot) * kMsgFloats + pub_off;
         msg_store(dst, msg_bits((lane & 1) ? y : xnew), local_next);
       }
-      if (STAMPS) {
+      if (STAMPS && !(a.dbg & 64)) {
         const u64 t = __builtin_amdgcn_s_memtime(); st.t_compute += t - t0c; t0c = t;
         // wall clock (100 MHz, one counter for the chip) of clip 0's publish in the last step, per stage: the chain's time line
         if (a.stamps && c == 0 && s + 1 == n_steps && p == 0 && q == 0 && lane == 0) a.stamps[16 + stage] = __builtin_amdgcn_s_memrealtime();
@@ -459,7 +459,8 @@ __device__ void chain_role(const WnSpipeArgs& a, Lds& S, int stage, int p, int q
         }
       }
       lds_signal(&S.hdone[q], v + 1, lane);        // this wave is through with the LDS image of visit v
-      if (STAMPS) { const u64 t = __builtin_amdgcn_s_memtime(); st.t_post += t - t0c; st.visits += 1; }
+      if (STAMPS && !(a.dbg & 64)) { const u64 t = __builtin_amdgcn_s_memtime(); st.t_post += t - t0c; }
+      if (STAMPS) st.visits += 1;
     }
   }
   if (STAMPS && a.stamps && stage == a.stamp_stage && p == 0 && q == 0 && lane == 0) {
@@ -568,7 +569,7 @@ __device__ void helper_role(const WnSpipeArgs& a, Lds& S, int stage, int p, int 
   const bool cond_lane = 4 * lane < a.C1;       // (C1 is a multiple of 16)
   u64 hs_t[6] = {0, 0, 0, 0, 0, 0}, hs_t0 = 0;      // diagnostic build: cycles in the phases of an iteration
   auto hstamp = [&](int k) {
-    if (STAMPS) { const u64 t = __builtin_amdgcn_s_memtime(); hs_t[k] += t - hs_t0; hs_t0 = t; }
+    if (STAMPS && !(a.dbg & 64)) { const u64 t = __builtin_amdgcn_s_memtime(); hs_t[k] += t - hs_t0; hs_t0 = t; }
   };
   // request the rows of the bias of visit (c2, s2).  x: this stage's input at position t_{s2} - d, from the history ring (zeros
   // in front of the sequence) - or, d = 1 past step 0, from this stage's newest message: channels 4 l .. + 3 are words (l / 2) 16 +
@@ -668,7 +669,7 @@ __device__ void helper_role(const WnSpipeArgs& a, Lds& S, int stage, int p, int 
   if (lookahead && h < n_visits) look(((((h % B) * kSpSlots + ((h / B) & 3)) * kMsgFloats) * 4) + look_off, pre_lo, pre_hi);   // the first look at "my" first message
   else pre_lo[0] = kSpPoison;
   for (int it = 0; it < n_visits; ++it) {
-    if (STAMPS) hs_t0 = __builtin_amdgcn_s_memtime();
+    if (STAMPS && !(a.dbg & 64)) hs_t0 = __builtin_amdgcn_s_memtime();
     const bool duty = (it & 3) == h;
     // ---- 1. the visit's message ------------------------------------------------------------------------------------------------------------
     // a landed message (in the look registers) into the LDS image of visit vv = (cc, ss); the chain waves are told
@@ -896,7 +897,7 @@ __device__ void head_role(const WnSpipeArgs& a, int p) {
   const bool last_mine = L >= 2 && ((g_last - g_first) & 3) == kq;
   u64 hs_t[8] = {0, 0, 0, 0, 0, 0, 0, 0}, hs_t0 = 0;      // diagnostic build: cycles in the phases of a visit (workgroup 0)
   auto hstamp = [&](int k) {
-    if (STAMPS) { const u64 t = __builtin_amdgcn_s_memtime(); hs_t[k] += t - hs_t0; hs_t0 = t; }
+    if (STAMPS && !(a.dbg & 64)) { const u64 t = __builtin_amdgcn_s_memtime(); hs_t[k] += t - hs_t0; hs_t0 = t; }
   };
   // wave 0: the embedded class as stage 0's message of step s1 (x = E[class], y = 0), in the producers' layout (per 8 channels: 8 x | 8 y)
   auto publish_class = [&](int c, int s1, int cls) {
