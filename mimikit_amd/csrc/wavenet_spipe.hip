@@ -28,6 +28,8 @@
 // the gates' and the head's reciprocals on v_rcp_f32 (1 ulp): the correctly rounded division is ten instructions on every stage's
 // critical path (55.64 -> 55.28 us per cfg-4 step)
 #define MMK_FAST_RCP 1
+#include <type_traits>
+
 #include "wavenet_spipe.h"
 #include "sampler256.h"
 
@@ -72,7 +74,7 @@ constexpr int kSlotShift = MMK_SP_SLOT_SHIFT;
 #define MMK_SP_LAG 1           // the biases run four iterations behind the messages ...
 #endif
 #ifndef MMK_SP_LAG_CLIPS
-#define MMK_SP_LAG_CLIPS 36    // ... from this many clips on (>= 8).  Measured on one box, cfg 4, us per step: 32 clips 53.2 with the lag, 52.0 without; 64 clips
+#define MMK_SP_LAG_CLIPS 40    // ... from this many clips on (>= 8).  Measured on one box, cfg 4, us per step: 32 clips 53.2 with the lag, 52.0 without; 64 clips
                                // (with the early looks) 92.1 with it, 97.3 without: the lag pays where the clips queue up, and costs where one clip's latency binds
 #endif
 #ifndef MMK_SP_CHAIN_PRIO
@@ -105,6 +107,9 @@ constexpr int kSlotShift = MMK_SP_SLOT_SHIFT;
 #endif
 #ifndef MMK_SP_POLL_GAP_BY_MODE
 #define MMK_SP_POLL_GAP_BY_MODE 1
+#endif
+#ifndef MMK_SP_MFMA_BIAS
+#define MMK_SP_MFMA_BIAS 1     // four-behind mode: the biases of FOUR consecutive visits as one batch of v_mfma_f32_4x4x1 (helper_role)
 #endif
 #ifndef MMK_SP_LAG1
 #define MMK_SP_LAG1 1          // where the delayed input cannot be asked for early (dilation 1 and 2), its rows are staged TWO iterations after the request instead of one
@@ -234,9 +239,11 @@ __device__ __forceinline__ unsigned msg_load(const unsigned* p) { return __hip_a
 constexpr int kRowRing = 4;                   // (= the number of helper waves: helper v mod 4 stages visit v) visits whose rows (delayed input | conditioning) the loading helper keeps staged
 constexpr int kRowSlice = 20;                 // a K slice of 16 floats + 4 of padding: the 16 slices' 16-byte reads fall on different banks
 constexpr int kRowPad = 16 * kRowSlice;
+constexpr int kBRow = 528;                    // 512 floats + 16: the four visits' rows start 64 B apart modulo the 256 B of the banks
 struct Lds {
   float xy[kXyRing][2 * kHalf];               // the newest messages of this stage: [x padded | y padded]
   float rows[kRowRing][2][kRowPad];           // [visit][x_s[t - d] | c[t]]: what the biases of the next visits are multiplied with
+  float rowsb[2][4][kBRow];                   // the same rows of a BATCH of four visits, [x_s[t - d] (256) | c[t] (256)] + padding, two batches (MMK_SP_MFMA_BIAS)
   unsigned arrived[4];                        // [v mod 4]: v + 1 once the message of visit v is staged into xy (by helper v mod 4)
   unsigned hdone[4];                          // per chain wave: visits whose xy image it no longer needs
   unsigned rows_ready[4];                     // [v mod 4]: v + 1 once the rows of visit v are staged (by helper v mod 4: every word has ONE writer, so it only grows)
@@ -499,15 +506,35 @@ __device__ void helper_role(const WnSpipeArgs& a, Lds& S, int stage, int p, int 
   const int W = 4 * p + h;
   const int ks = lane & 15;                     // K slice of 16 of the delayed input and the conditioning row (4 gate rows per lane)
   const int j = lane >> 2;
+  // MF (four-behind mode): the biases of four consecutive visits are ONE batch of v_mfma_f32_4x4x1: 16 blocks = 4 groups of 4 gate rows x
+  // 4 K residues; lane 4 b + i carries row 4 (b & 3) + i as the A operand and visit i of the batch as the B operand, block b's share of K
+  // is the floats 16 m + 4 (b >> 2) .. + 3 of every 16.  128 products per batch and helper on the matrix pipe (which the chain wave of the
+  // SIMD does not use) instead of 4 x 64 packed FMAs + 4 reduce-scatters on the vector ALU it shares with it, and one hand-shake per four visits.
+  constexpr bool MF = LAG4 && (MMK_SP_MFMA_BIAS != 0);
   f32x4s w0[16], wc[16];
   {
-    const f32x4s* img = reinterpret_cast<const f32x4s*>(a.img_helper) + ((int64_t)stage * kWavesPerStage + W) * kHelperRegs * 64 + lane;
+    const f32x4s* img = reinterpret_cast<const f32x4s*>(a.img_helper) + ((int64_t)stage * kWavesPerStage + W) * kHelperRegs * 64;
+    if constexpr (MF) {
+      // the same image, read in the matrix operand's order: register m (e = 0 .. 3) = W[row 4 g + i][half 256 + 16 (m & 15) + 4 ksub + e]
+      const int g = (lane >> 2) & 3, i = lane & 3, ksub = lane >> 4;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) w0[i] = img[i * 64];
+      for (int m = 0; m < 16; ++m) w0[m] = img[(i * 4 + ksub) * 64 + 16 * g + m];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) wc[i] = img[(16 + i) * 64];
+      for (int m = 0; m < 16; ++m) wc[m] = img[(16 + i * 4 + ksub) * 64 + 16 * g + m];
+    } else {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) w0[i] = img[i * 64 + lane];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) wc[i] = img[(16 + i) * 64 + lane];
+    }
   }
   float bz = a.cst_helper[((int64_t)stage * kWavesPerStage + W) * 64 + lane];
+  f32x4s bz4 = f32x4s{0.f, 0.f, 0.f, 0.f};          // MF: the constants of rows 4 g .. 4 g + 3 (lane 4 j of the table holds row j's)
+  if constexpr (MF) {
+    const float* cst = a.cst_helper + ((int64_t)stage * kWavesPerStage + W) * 64 + 16 * ((lane >> 2) & 3);
+    bz4 = f32x4s{cst[0], cst[4], cst[8], cst[12]};
+    asm volatile("" : "+v"(bz4));
+  }
   // (in their registers before the loop, as in the chain role)
 #pragma unroll
   for (int i = 0; i < 16; ++i) asm volatile("" : "+v"(w0[i]));
@@ -592,6 +619,15 @@ __device__ void helper_role(const WnSpipeArgs& a, Lds& S, int stage, int p, int 
   };
   // the requested rows into the LDS slot of visit v3, once every helper is through with the visit that used the slot before
   auto stage_rows = [&](unsigned v3, const u32x4s& xr, const f32x4s& cr) -> bool {
+    if constexpr (MF) {      // into the batch's buffer, once every helper is through with the batch that used it before
+      const unsigned kb = v3 >> 2;
+      if (kb >= 2 && !lds_wait4(S.ready, 4 * kb - 4, a.err_flag)) return false;
+      float* dst = &S.rowsb[kb & 1][v3 & 3][4 * lane];
+      *reinterpret_cast<f32x4s*>(dst) = f32x4s{__uint_as_float(xr[0]), __uint_as_float(xr[1]), __uint_as_float(xr[2]), __uint_as_float(xr[3])};
+      *reinterpret_cast<f32x4s*>(dst + 256) = cr;
+      lds_signal(&S.rows_ready[v3 & 3], v3 + 1, lane);
+      return true;
+    }
     if (v3 >= (unsigned)kRowRing && !lds_wait4(S.ready, v3 - kRowRing + 1, a.err_flag)) return false;
     float* dst = &S.rows[v3 & (kRowRing - 1)][0][kRowSlice * (lane >> 2) + 4 * (lane & 3)];
     *reinterpret_cast<f32x4s*>(dst) = f32x4s{__uint_as_float(xr[0]), __uint_as_float(xr[1]), __uint_as_float(xr[2]), __uint_as_float(xr[3])};
@@ -638,15 +674,83 @@ __device__ void helper_role(const WnSpipeArgs& a, Lds& S, int stage, int p, int 
     lds_signal(&S.ready[h], v3 + 1, lane);
     return true;
   };
+  // MF: a quarter of batch kb's products (chunk 0 waits for the batch's rows and clears the sums, chunk 3 adds up the K residues, adds the
+  // constants and hands the four biases to the chain waves); only visits in [v_lo, v_hi) exist
+  f32x4s macc[4] = {f32x4s{0.f, 0.f, 0.f, 0.f}, f32x4s{0.f, 0.f, 0.f, 0.f}, f32x4s{0.f, 0.f, 0.f, 0.f}, f32x4s{0.f, 0.f, 0.f, 0.f}};      // four sums in turn: a product does not wait for the one before
+  auto mf_chunk = [&](int kb, int ch, int v_lo, int v_hi) -> bool {
+    if (ch == 0) {
+      const int vv = 4 * kb + (lane & 3);
+      const bool need = vv >= v_lo && vv < v_hi;
+      unsigned spins = 0;
+      while (!__all(!need || __hip_atomic_load(&S.rows_ready[lane & 3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= (unsigned)vv + 1)) {
+        if (kLdsSleep > 0) __builtin_amdgcn_s_sleep(kLdsSleep);
+        if (++spins > kSpinLimit || ((spins & 4095u) == 0 && __hip_atomic_load(a.err_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+          atomicExch(a.err_flag, 1);
+          return false;
+        }
+      }
+      __atomic_signal_fence(__ATOMIC_SEQ_CST);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) macc[e] = f32x4s{0.f, 0.f, 0.f, 0.f};
+    }
+    // (the chunk as a compile-time constant: a register array indexed by a run-time value lives in scratch memory)
+    auto products = [&](auto chc) {
+      constexpr int CH = decltype(chc)::value;
+      const float* xb = &S.rowsb[kb & 1][lane & 3][(CH >> 1) * 256 + 4 * (lane >> 4)];
+#pragma unroll
+      for (int mm = 0; mm < 8; ++mm) {
+        constexpr int m0 = (CH & 1) * 8;
+        const f32x4s xv = *reinterpret_cast<const f32x4s*>(xb + 16 * (m0 + mm));
+        const f32x4s wv = (CH >> 1) ? wc[m0 + mm] : w0[m0 + mm];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) macc[e] = __builtin_amdgcn_mfma_f32_4x4x1f32(wv[e], xv[e], macc[e], 0, 0, 0);
+      }
+    };
+    switch (ch) {
+      case 0: products(std::integral_constant<int, 0>{}); break;
+      case 1: products(std::integral_constant<int, 1>{}); break;
+      case 2: if (a.C1 > 0) products(std::integral_constant<int, 2>{}); break;
+      default: if (a.C1 > 0) products(std::integral_constant<int, 3>{}); break;
+    }
+    if (ch == 3) {
+      f32x4s tot;
+      const f32x4s msum = (macc[0] + macc[1]) + (macc[2] + macc[3]);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {          // the four K residues sit 16, 32 and 48 lanes apart
+        const auto s16 = __builtin_amdgcn_permlane16_swap(__float_as_uint(msum[r]), __float_as_uint(msum[r]), false, false);
+        const float y = __uint_as_float(s16[0]) + __uint_as_float(s16[1]);
+        const auto s32 = __builtin_amdgcn_permlane32_swap(__float_as_uint(y), __float_as_uint(y), false, false);
+        tot[r] = __uint_as_float(s32[0]) + __uint_as_float(s32[1]);
+      }
+      const int vv = 4 * kb + (lane & 3);
+      if (lane < 16 && vv >= v_lo && vv < v_hi) {
+        const int s2 = vv / B, c2 = vv - s2 * B;
+        *reinterpret_cast<f32x4s*>(&S.bias[bias_off(h, s2 & 1, c2, 4 * (lane >> 2), Bcap)]) = tot + bz4;
+      }
+      lds_signal(&S.ready[h], (unsigned)(4 * kb + 4 < v_hi ? 4 * kb + 4 : v_hi), lane);
+    }
+    return true;
+  };
   u32x4s xr = u32x4s{0, 0, 0, 0};
   f32x4s cr = f32x4s{0.f, 0.f, 0.f, 0.f};
   // ---- step 0: the rows the warm-up wrote, one clip after the other -------------------------------------------------------------------------
-  for (int c0 = 0; c0 < B; ++c0) {
-    if (rows_mine(c0)) {
-      request_rows(0, c0, false, xr, cr);
-      if (!stage_rows((unsigned)c0, xr, cr)) return;
+  if constexpr (MF) {
+    for (int kb = 0; 4 * kb < B; ++kb) {
+      if (4 * kb + h < B) {
+        request_rows(0, 4 * kb + h, false, xr, cr);
+        if (!stage_rows((unsigned)(4 * kb + h), xr, cr)) return;
+      }
+      for (int ch = 0; ch < 4; ++ch)
+        if (!mf_chunk(kb, ch, 0, B)) return;
     }
-    if (!bias_of((unsigned)c0, 0, c0)) return;
+  } else {
+    for (int c0 = 0; c0 < B; ++c0) {
+      if (rows_mine(c0)) {
+        request_rows(0, c0, false, xr, cr);
+        if (!stage_rows((unsigned)c0, xr, cr)) return;
+      }
+      if (!bias_of((unsigned)c0, 0, c0)) return;
+    }
   }
   int s = 0, c = 0;                               // visit it = (c, s)
   int sp = 0, cp = B - 1 - lag;                   // visit it - 1 - lag + B = (cp, sp): the bias that is due in iteration it
@@ -752,7 +856,7 @@ __device__ void helper_role(const WnSpipeArgs& a, Lds& S, int stage, int p, int 
         }
       }
       __atomic_signal_fence(__ATOMIC_SEQ_CST);
-    } else if (MMK_SP_BACKUP && ((it + 2) & 3) == h && it >= 2) {
+    } else if (MMK_SP_BACKUP && (MMK_SP_BACKUP == 1 || remote_in) && ((it + 2) & 3) == h && it >= 2) {
       // Halfway between two look duties: a SECOND pair of eyes on message `it`, half a look's round trip behind the helper on duty, in
       // registers of its own (the first look at this helper's next message is in flight in the others).  A CU then looks twice per round
       // trip, and what a stage waits for is the slowest of its eight CUs: the mean of that maximum shrinks with the looks' period.
@@ -821,7 +925,14 @@ __device__ void helper_role(const WnSpipeArgs& a, Lds& S, int stage, int p, int 
       staged_next = true;
     }
 #endif
-    if (shift) {
+    if constexpr (MF) {
+      // the batch before the one that visit it + B - 5 (staged in this iteration) belongs to: a quarter of its products per iteration
+      const int u = it + B - 5, kbc = (u >> 2) - 1;
+      if (it >= 5 && kbc >= (B >> 2) && 4 * kbc < n_visits) {
+        if (!mf_chunk(kbc, u & 3, B, n_visits)) return;
+        hstamp(5);
+      }
+    } else if (shift) {
       if (it >= 2 + lag && it - 2 - lag + B < n_visits) {
         if (!bias_of((unsigned)(it - 2 - lag + B), spb, cpb)) return;
         hstamp(5);
