@@ -56,6 +56,9 @@ int mmk_abi_version(void);
 /* sizeof the config struct as this library was compiled: 0 mmk_wavenet_config, 1 mmk_srnn_config, 2 mmk_s2s_config; -1 for any other number -
  * what a binding that mirrors the structs by hand (ctypes, cgo, JNI) compares its own layout with before the first call */
 int64_t mmk_config_bytes(int which);
+/* a digest of the sources this library was compiled from (mimikit_amd/build.py: sha256 over every translation unit and header,
+ * 32 hex digits; "unknown" for a build outside that script): how a caller tells a stale prebuilt library from a current one */
+const char* mmk_build_digest(void);
 const char* mmk_last_error(void);
 /* Diagnostic: weight re-packing kernels (`*_commit`, mmk_pack_weight_f32) launched since the library was loaded.
  * The host mirror re-commits a plan only when a parameter changed (in the reference `before_generate` never

@@ -3,6 +3,7 @@
 ``python -m mimikit_amd.build`` or :func:`build`.  hipcc cross-compiles without
 a GPU; the resulting shared object travels with the source tree.
 """
+import hashlib
 import os
 import shutil
 import subprocess
@@ -25,12 +26,35 @@ def _hipcc() -> str:
     raise RuntimeError("hipcc not found (set HIPCC or install ROCm under /opt/rocm)")
 
 
+def source_digest() -> str:
+    """sha256 over the names and contents of every translation unit and header the library is made of - compiled into the library
+    (``mmk_build_digest``), so that a ``libmmk_hip.so`` found in the tree can be told from one built from other sources"""
+    h = hashlib.sha256()
+    for name in sorted(SOURCES + HEADERS):
+        h.update(os.path.basename(name).encode() + b"\0")
+        with open(os.path.join(CSRC, name), "rb") as f:
+            h.update(f.read())
+        h.update(b"\0")
+    return h.hexdigest()[:32]
+
+
+def library_digest(lib_path: str = LIB_PATH):
+    """the digest a built library carries, or None (missing file, a library from before the digest); read out of the file, not through
+    dlopen: a path that is loaded already would answer for the old image"""
+    if not os.path.exists(lib_path):
+        return None
+    with open(lib_path, "rb") as f:
+        blob = f.read()
+    at = blob.find(b"mmk-source-digest:")
+    if at < 0:
+        return None
+    return blob[at + 18:at + 50].split(b"\0")[0].decode(errors="replace")
+
+
 def _stale() -> bool:
-    if not os.path.exists(LIB_PATH):
-        return True
-    built = os.path.getmtime(LIB_PATH)
-    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS]
-    return any(os.path.getmtime(d) > built for d in deps)
+    # by CONTENT, not by modification time: a prebuilt library that travelled with the tree is used only if it was compiled from
+    # exactly these sources
+    return library_digest(LIB_PATH) != source_digest()
 
 
 def build(force: bool = False, verbose: bool = False, diag: bool = False) -> str:
@@ -51,7 +75,8 @@ def _build(lib_path: str, obj_dir: str, defines, verbose: bool) -> str:
     for src in SOURCES:
         obj = os.path.join(obj_dir, src.replace(".hip", ".o"))
         objs.append(obj)
-        cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", *defines, "-c", os.path.join(CSRC, src), "-o", obj]
+        extra = [f'-DMMK_SOURCE_DIGEST="{source_digest()}"'] if src == "kernels.hip" else []
+        cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", *defines, *extra, "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))

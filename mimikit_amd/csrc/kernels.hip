@@ -329,6 +329,12 @@ int launch_rnn_tanh_cell(const float* g, float* h, int M, int H, hipStream_t str
 }  // namespace mmk
 
 extern "C" int mmk_abi_version(void) { return MMK_ABI_VERSION; }
+#ifndef MMK_SOURCE_DIGEST
+#define MMK_SOURCE_DIGEST "unknown"
+#endif
+// (behind a marker: the build script reads the digest out of the FILE - a dlopen of a path that is loaded already returns the old image)
+static const char kBuildDigest[] = "mmk-source-digest:" MMK_SOURCE_DIGEST;
+extern "C" const char* mmk_build_digest(void) { return kBuildDigest + 18; }
 extern "C" int64_t mmk_config_bytes(int which) {
   return which == 0 ? (int64_t)sizeof(mmk_wavenet_config) : which == 1 ? (int64_t)sizeof(mmk_srnn_config) : which == 2 ? (int64_t)sizeof(mmk_s2s_config) : -1;
 }

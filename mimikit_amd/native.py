@@ -85,6 +85,7 @@ class S2SConfig(C.Structure):
 _SIGNATURES = {
     "mmk_abi_version": (i32, []),
     "mmk_config_bytes": (i64, [i32]),
+    "mmk_build_digest": (cp, []),
     "mmk_last_error": (cp, []),
     "mmk_pack_launch_count": (i64, []),
     "mmk_fingerprint_u32": (i32, [vp, i64, vp, vp]),
@@ -173,6 +174,12 @@ def load_library(path: Optional[str] = None):
     if lib.mmk_abi_version() != ABI_VERSION:
         raise NativeError(f"ABI version mismatch: library reports {lib.mmk_abi_version()}, binding expects {ABI_VERSION} "
                           "(a stale libmmk_hip.so: rebuild with `python -m mimikit_amd.build`)")
+    if os.environ.get("MMK_DIAG_LIB") != "1":       # (the product library must be the one these sources make; scripts that swap in
+        from .build import source_digest             #  variants compiled with other -D flags keep the digest: it covers sources only)
+        have, want = lib.mmk_build_digest().decode(), source_digest()
+        if have != want:
+            raise NativeError(f"{path} was built from other sources (digest {have}, the tree's is {want}): rebuild with "
+                              "`python -m mimikit_amd.build`")
     for which, struct in enumerate((WaveNetConfig, SrnnConfig, S2SConfig)):
         if lib.mmk_config_bytes(which) != C.sizeof(struct):
             raise NativeError(f"{struct.__name__} is {C.sizeof(struct)} bytes here and {lib.mmk_config_bytes(which)} in the library "

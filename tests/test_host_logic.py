@@ -440,3 +440,13 @@ def test_checkpoint_round_trip_and_reference_yaml_layout(tmp_path):
     # our own emitter writes that layout: no `type` under the statically typed keys
     y = net.config.serialize()
     assert "type: IOSpec" not in y and "type: InputSpec" not in y and "type: Objective" not in y and "type: SampleRNN.Config" in y
+
+
+def test_library_in_the_tree_was_built_from_these_sources():
+    """the library carries a digest of the sources it was compiled from (mimikit_amd/build.py, `mmk_build_digest`): a prebuilt
+    libmmk_hip.so that travelled with the tree is used only if that digest is the tree's - by content, not by modification time"""
+    from mimikit_amd import build as hip_build
+    assert hip_build.library_digest() == hip_build.source_digest() and len(hip_build.source_digest()) == 32
+    lib = native.load_library()
+    assert lib.mmk_build_digest().decode() == hip_build.source_digest()
+    assert not hip_build._stale()
