@@ -119,6 +119,10 @@ struct mmk_wavenet_plan {
   unsigned *sp_msg = nullptr, *sp_hidmsg = nullptr, *sp_hidgrp = nullptr;
   WnSpRaw* sp_raw = nullptr;
   const float *sp_fc2_w = nullptr, *sp_fc2_b = nullptr;
+  // the stage pipeline's head is 128 hidden units x 256 classes and its helpers multiply ONE conditioning row: a narrower head is padded
+  // (zero rows / columns, -inf bias for the classes that do not exist), two conditioning inputs' projections and 1x1 matrices laid side by side
+  float *sp_f0p = nullptr, *sp_fb0p = nullptr, *sp_fc2p = nullptr, *sp_fc2bp = nullptr, *sp_w1cat = nullptr, *sp_b1cat = nullptr, *sp_logits = nullptr;
+  static constexpr int kSpH1 = 128, kSpQ = 256, kSpLogitsLd = 260;
 
   void layout_persistent(Carver& c) {
     layer_tab = c.take<WnLayerTab>(L);
@@ -157,8 +161,17 @@ struct mmk_wavenet_plan {
       sp_img_helper = c.take<float>(wn_spipe_img_helper_floats(L, C));
       sp_cst_chain = c.take<float>(wn_spipe_cst_floats(L, C));
       sp_cst_helper = c.take<float>(wn_spipe_cst_floats(L, C));
-      sp_head_w0 = c.take<float>((int64_t)cfg.mlp_hidden * C);
-      sp_head_b0 = c.take<float>(cfg.mlp_hidden);
+      sp_head_w0 = c.take<float>((int64_t)kSpH1 * C);
+      sp_head_b0 = c.take<float>(kSpH1);
+      sp_f0p = c.take<float>((int64_t)kSpH1 * C);
+      sp_fb0p = c.take<float>(kSpH1);
+      sp_fc2p = c.take<float>((int64_t)(kSpQ + 1) * kSpH1);
+      sp_fc2bp = c.take<float>(kSpLogitsLd);
+      sp_logits = c.take<float>((int64_t)Bmax * kSpLogitsLd);
+      if (n_cond == 2) {
+        sp_w1cat = c.take<float>((int64_t)L * 2 * C * C1);
+        sp_b1cat = c.take<float>((int64_t)L * 2 * C);
+      }
       sp_msg = c.take<unsigned>(wn_spipe_msg_words(L, C, Bmax) + wn_spipe_hidmsg_words(L, Bmax) + wn_spipe_hidgrp_words(Bmax));   // one block: poisoned by one memset
       sp_hidmsg = sp_msg + (sp_msg ? wn_spipe_msg_words(L, C, Bmax) : 0);
       sp_hidgrp = sp_hidmsg + (sp_msg ? wn_spipe_hidmsg_words(L, Bmax) : 0);
@@ -362,13 +375,15 @@ static int derive(mmk_wavenet_plan* p) {
   // channels.  Anything else stays on the per-layer launch path.
   const char* env = p->tune.get("MMK_WN_PERSISTENT");
   bool ok = !(env && env[0] == '0') && c.exec_mode != 1;     // (exec_mode 1: the caller asks for the per-layer launch path)
-  ok = ok && c.gated && c.q_levels > 0 && c.head_kind == 0 && c.mlp_n_hidden == 0 && c.n_cond <= 1;
+  ok = ok && c.gated && c.q_levels > 0 && c.head_kind == 0 && c.mlp_n_hidden == 0 && c.n_cond <= 2;
   ok = ok && !multi;            // class conditioning streams and further targets: the launch path (a step's conditioning row depends on the step before)
   ok = ok && p->C % 32 == 0 && p->C <= 256 && p->S == p->C && c.residuals_dim == p->C && !c.layerwise_inputs && !c.with_affine_residuals;
   for (int l = 0; l < p->L; ++l) ok = ok && (p->has_res[l] != 0) == (l != p->L - 1);   // (reverse_layer_order: launch path)
-  ok = ok && c.mlp_hidden % 16 == 0 && c.mlp_hidden >= 16;
-  if (c.n_cond == 1) ok = ok && c.cond_dim[0] % 16 == 0;
+  for (int j = 0; j < c.n_cond; ++j) ok = ok && c.cond_dim[j] % 16 == 0;
   for (int l = 0; l < p->L; ++l) ok = ok && p->ksz[l] == 2;
+  // (the stage pipeline takes any head of up to 128 hidden units and two conditioning inputs; the other persistent kernels whole tiles of 16 and one)
+  const bool ok_sp = ok && c.mlp_hidden >= 1;
+  ok = ok && c.mlp_hidden % 16 == 0 && c.mlp_hidden >= 16 && c.n_cond <= 1;
   p->persistent = false;
   // The persistent kernels need every workgroup of their grid resident at once (one per CU: their LDS carve does not leave room
   // for a second), and the XCD-local / pipelined placements one stage or clip group per XCD of an 8-XCD device: ask the device
@@ -445,14 +460,17 @@ static int derive(mmk_wavenet_plan* p) {
   // chip and the warm-up as a prefill into the launch path's rings.  MMK_WN_SPIPE=0, or forcing another kernel (MMK_WN_PIPE=1 /
   // MMK_WN_CHAIN=1), turns it off.
   p->spipe = false;
-  if (ok) {
+  if (ok_sp) {
     const char* senv = p->tune.get("MMK_WN_SPIPE");
     const char* fenv = p->tune.get("MMK_WN_PREFILL");
     const char* penv = p->tune.get("MMK_WN_PIPE");
     const char* cenv = p->tune.get("MMK_WN_CHAIN");
     bool ok5 = !(senv && senv[0] == '0') && !(fenv && fenv[0] == '0') && !(penv && penv[0] == '1') && !(cenv && cenv[0] == '1');
-    ok5 = ok5 && n_xcc == 8 && n_cu == 256 && c.q_levels == 256;
-    ok5 = ok5 && wn_spipe_supported(p->C, p->S, c.mlp_hidden, c.out_dim, p->L, c.n_cond, c.n_cond == 1 ? c.cond_dim[0] : 0, p->Bmax);
+    int cond_total = 0;
+    for (int j = 0; j < c.n_cond; ++j) cond_total += c.cond_dim[j];
+    // (the classes the network is fed are the ones it draws, and the first one - the prompt's last sample - is clamped to the head's 256)
+    ok5 = ok5 && n_xcc == 8 && n_cu == 256 && c.q_levels <= 256 && c.out_dim <= c.q_levels;
+    ok5 = ok5 && wn_spipe_supported(p->C, p->S, c.mlp_hidden, c.out_dim, p->L, c.n_cond, cond_total, p->Bmax);
     // A ring of few stages is beat-bound early (one clip's trip: ~1.3 us per stage; ~1.25 us per clip once the clips queue up): 10 layers x 32 clips
     // 38 us per step against 31 on the two-hand-off kernel, x 64 clips 74 against 43 (round 4's sweep).  Asked for by name
     // (MMK_WN_SPIPE=1) it is taken all the same.
@@ -461,7 +479,8 @@ static int derive(mmk_wavenet_plan* p) {
       p->spipe = true;
       p->persistent = true;
       p->xcd_local = false;
-      p->C1 = c.n_cond == 1 ? c.cond_dim[0] : 0;
+      p->chain = p->pipe = false;
+      p->C1 = cond_total;
       p->n_logits_pad = (int)round_up(c.out_dim + (c.learn_temp ? 1 : 0), 16);
       p->ring_offset.assign(p->L, 0);
       p->ring_mask.assign(p->L, 0);
@@ -588,6 +607,11 @@ extern "C" size_t mmk_wavenet_workspace_bytes(const mmk_wavenet_plan* p) {
   Carver c(nullptr);
   tmp.layout(c);
   return c.used();
+}
+
+__global__ void vec_add_kernel(const float* __restrict__ a, const float* __restrict__ b, int n, float* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = a[i] + b[i];
 }
 
 extern "C" int mmk_wavenet_commit(mmk_wavenet_plan* p, void* workspace, size_t workspace_bytes, mmk_stream_t stream) {
@@ -791,6 +815,28 @@ extern "C" int mmk_wavenet_commit(mmk_wavenet_plan* p, void* workspace, size_t w
       r.bd = bias ? b.need(ly + "conv_dil.0.0.bias", 2 * C) : nullptr;
       r.w1 = p->n_cond == 1 ? b.need(ly + "conv_1x1.0.0.weight", (int64_t)2 * C * p->C1) : nullptr;
       r.b1 = (bias && p->n_cond == 1) ? b.need(ly + "conv_1x1.0.0.bias", 2 * C) : nullptr;
+      if (p->n_cond == 2) {      // sum_j conv_1x1_j(c_j) (wavenet_v2.py:141-147) = [W_0 | W_1] [c_0 ; c_1]: the two matrices side by side, the biases added up
+        float* wcat = p->sp_w1cat + (int64_t)l * 2 * C * p->C1;
+        float* bcat = p->sp_b1cat + (int64_t)l * 2 * C;
+        int col = 0;
+        for (int j = 0; j < 2; ++j) {
+          const int dj = c.cond_dim[j];
+          const float* wj = b.need(ly + "conv_1x1." + std::to_string(j) + ".0.weight", (int64_t)2 * C * dj);
+          if (wj) MMK_HIP(hipMemcpy2DAsync(wcat + col, (size_t)p->C1 * sizeof(float), wj, (size_t)dj * sizeof(float), (size_t)dj * sizeof(float), 2 * C,
+                                           hipMemcpyDeviceToDevice, st));
+          col += dj;
+        }
+        r.w1 = wcat;
+        if (bias) {
+          const float* b0 = b.need(ly + "conv_1x1.0.0.bias", 2 * C);
+          const float* b1 = b.need(ly + "conv_1x1.1.0.bias", 2 * C);
+          if (b0 && b1) {
+            hipLaunchKernelGGL(vec_add_kernel, dim3((2 * C + 255) / 256), dim3(256), 0, st, b0, b1, 2 * C, bcat);
+            MMK_HIP(hipGetLastError());
+          }
+          r.b1 = bcat;
+        }
+      }
       r.wr = p->has_res[l] ? b.need(ly + "conv_res.weight", (int64_t)C * C) : nullptr;
       r.br = (bias && p->has_res[l]) ? b.need(ly + "conv_res.bias", C) : nullptr;
       r.ws = b.need(ly + "conv_skip.weight", (int64_t)C * C);
@@ -802,9 +848,24 @@ extern "C" int mmk_wavenet_commit(mmk_wavenet_plan* p, void* workspace, size_t w
     p->sp_fc2_w = b.need("output_modules.0.estimator.0.fc.2.weight", (int64_t)(c.out_dim + (c.learn_temp ? 1 : 0)) * H1);
     p->sp_fc2_b = b.need("output_modules.0.estimator.0.fc.2.bias", c.out_dim + (c.learn_temp ? 1 : 0));
     if (b.missing().empty()) {
+      // the head as the kernel knows it: 128 hidden units x 256 classes (+ the temperature row at index 256).  Hidden units that do not exist
+      // have zero rows in fc0 and zero columns in fc2 (Mish(0) = 0 anyway), classes that do not exist a zero row and a bias of -inf: never the
+      // maximum, probability 0 in a draw (the workspace was cleared at the start of this commit)
+      constexpr int PH = mmk_wavenet_plan::kSpH1, PQ = mmk_wavenet_plan::kSpQ;
+      const int Q = c.out_dim;
+      MMK_HIP(hipMemcpyAsync(p->sp_f0p, f0, (size_t)H1 * C * sizeof(float), hipMemcpyDeviceToDevice, st));
+      MMK_HIP(hipMemcpyAsync(p->sp_fb0p, fb0, (size_t)H1 * sizeof(float), hipMemcpyDeviceToDevice, st));
+      MMK_HIP(hipMemcpy2DAsync(p->sp_fc2p, (size_t)PH * sizeof(float), p->sp_fc2_w, (size_t)H1 * sizeof(float), (size_t)H1 * sizeof(float), Q,
+                               hipMemcpyDeviceToDevice, st));
+      MMK_TRY(launch_fill(p->sp_fc2bp, -INFINITY, mmk_wavenet_plan::kSpLogitsLd, st));
+      MMK_HIP(hipMemcpyAsync(p->sp_fc2bp, p->sp_fc2_b, (size_t)Q * sizeof(float), hipMemcpyDeviceToDevice, st));
+      if (c.learn_temp) {
+        MMK_HIP(hipMemcpyAsync(p->sp_fc2p + (int64_t)PQ * PH, p->sp_fc2_w + (int64_t)Q * H1, (size_t)H1 * sizeof(float), hipMemcpyDeviceToDevice, st));
+        MMK_HIP(hipMemcpyAsync(p->sp_fc2bp + PQ, p->sp_fc2_b + Q, sizeof(float), hipMemcpyDeviceToDevice, st));
+      }
       MMK_HIP(hipMemcpyAsync(p->sp_raw, raw.data(), sizeof(WnSpRaw) * L, hipMemcpyHostToDevice, st));
-      MMK_TRY(wn_spipe_build_image(p->sp_raw, L, C, p->C1, f0, fb0, p->sp_img_chain, p->sp_img_helper, p->sp_cst_chain, p->sp_cst_helper, p->sp_head_w0,
-                                   p->sp_head_b0, st));
+      MMK_TRY(wn_spipe_build_image(p->sp_raw, L, C, p->C1, p->sp_f0p, p->sp_fb0p, p->sp_img_chain, p->sp_img_helper, p->sp_cst_chain, p->sp_cst_helper,
+                                   p->sp_head_w0, p->sp_head_b0, st));
       MMK_HIP(hipStreamSynchronize(st));   // `raw` is host-local
     }
   }
@@ -1057,16 +1118,16 @@ static int run_persistent(mmk_wavenet_plan* p, const WnCall& call, int64_t tau0,
     if (p->C1 > 0) {
       // c[b, tau, :] = LinearIO(cond[b, tau, :]) for the block's positions (modules/io.py:115-122)
       g_prof_tag = 2;
-      {   // all clips in one launch: row m = position m % nb of clip m / nb
-        LinearArgs a = {};
-        p->cond_lin[0].fill(a);
-        a.seg[0].x = addr_static(call.cond[0] + tau_b * c.cond_in_dim[0]);
-        a.seg[0].ld = c.cond_in_dim[0];
+      for (int j = 0, col = 0; j < p->n_cond; col += c.cond_dim[j], ++j) {   // all clips in one launch: row m = position m % nb of clip m / nb
+        LinearArgs a = {};                                                     // (two inputs - stage pipeline only: side by side in a row of C1)
+        p->cond_lin[j].fill(a);
+        a.seg[0].x = addr_static(call.cond[j] + tau_b * c.cond_in_dim[j]);
+        a.seg[0].ld = c.cond_in_dim[j];
         a.M = (int)(nb * call.M); a.tau_ptr = nullptr; a.tau_off = 0;
         a.epilogue = EPI_STORE; a.act = ACT_NONE;
-        a.out = addr_static(p->cproj);
+        a.out = addr_static(p->cproj + col);
         a.out_ld = p->C1;
-        a.row_group = (int)nb; a.x_group_stride = call.cond_rs[0]; a.out_group_stride = (int64_t)p->kCondBlock * p->C1;
+        a.row_group = (int)nb; a.x_group_stride = call.cond_rs[j]; a.out_group_stride = (int64_t)p->kCondBlock * p->C1;
         MMK_TRY(launch_linear(a, st));
       }
       // every layer's conv_1x1(c) for the same positions (wavenet_v2.py:140-150): off the per-sample chain; one
@@ -1114,14 +1175,14 @@ static int run_persistent(mmk_wavenet_plan* p, const WnCall& call, int64_t tau0,
       k.learn_temp = c.learn_temp; k.min_temp = c.min_temp; k.Bmax = p->Bmax;
       k.t0 = tau_b + 1; k.n_steps = nb;
       k.img_chain = p->sp_img_chain; k.img_helper = p->sp_img_helper; k.cst_chain = p->sp_cst_chain; k.cst_helper = p->sp_cst_helper;
-      k.head_w0 = p->sp_head_w0; k.head_b0 = p->sp_head_b0; k.fc2_w = p->sp_fc2_w; k.fc2_b = p->sp_fc2_b;
+      k.head_w0 = p->sp_head_w0; k.head_b0 = p->sp_head_b0; k.fc2_w = p->sp_fc2p; k.fc2_b = p->sp_fc2bp;
       for (int l = 0; l < p->L; ++l) { k.hist[l] = p->hist[l]; k.ring[l] = p->ring[l]; k.dil[l] = p->dil[l]; }
       k.emb = p->emb; k.idx = (int64_t*)call.in0; k.idx_rs = call.in0_rs;
       k.cproj = p->cproj; k.cond_steps = p->kCondBlock;
       k.temperature = call.temperature;
       k.uniforms = call.uniforms ? call.uniforms + done : nullptr;
       k.uni_ld = call.uni_ld;
-      k.logits_out = p->logits; k.logits_ld = p->logits_ld;
+      k.logits_out = p->sp_logits; k.logits_ld = mmk_wavenet_plan::kSpLogitsLd;      // (256 classes + the temperature: mmk_wavenet_last_logits picks the network's own columns)
       k.msg = p->sp_msg; k.hidmsg = p->sp_hidmsg; k.hidgrp = p->sp_hidgrp; k.xcd_count = p->xcd_count; k.err_flag = p->err_flag;
       k.stamps = (stamp_env && stamp_env[0] == '1') ? reinterpret_cast<unsigned long long*>(p->tau + 8) : nullptr;
       k.stamp_stage = diag_only("MMK_WN_STAMP_STAGE") ? atoi(diag_only("MMK_WN_STAMP_STAGE")) : 1;
@@ -1226,17 +1287,18 @@ static int prefill(mmk_wavenet_plan* p, const WnCall& call, int64_t t_begin, int
   MMK_TRY(launch_wn_prefill_embed((const int64_t*)call.in0, call.in0_rs, t_begin, p->emb, c.q_levels, C, (int)n, p->pf_h[0],
                                   P * C, B, st));
   if (C1 > 0) {
-    for (int b = 0; b < B; ++b) {   // c[b, t, :] = LinearIO(cond[b, t, :])   (modules/io.py:115-122)
-      LinearArgs a = {};
-      p->cond_lin[0].fill(a);
-      a.seg[0].x = addr_static(call.cond[0] + (int64_t)b * call.cond_rs[0] + t_begin * c.cond_in_dim[0]);
-      a.seg[0].ld = c.cond_in_dim[0];
-      a.M = (int)n; a.tau_ptr = nullptr; a.tau_off = 0;
-      a.epilogue = EPI_STORE; a.act = ACT_NONE;
-      a.out = addr_static(p->pf_c + (int64_t)b * P * C1);
-      a.out_ld = C1;
-      MMK_TRY(launch_linear(a, st));
-    }
+    for (int j = 0, col = 0; j < p->n_cond; col += c.cond_dim[j], ++j)
+      for (int b = 0; b < B; ++b) {   // c[b, t, :] = LinearIO(cond[b, t, :])   (modules/io.py:115-122); two inputs' rows side by side
+        LinearArgs a = {};
+        p->cond_lin[j].fill(a);
+        a.seg[0].x = addr_static(call.cond[j] + (int64_t)b * call.cond_rs[j] + t_begin * c.cond_in_dim[j]);
+        a.seg[0].ld = c.cond_in_dim[j];
+        a.M = (int)n; a.tau_ptr = nullptr; a.tau_off = 0;
+        a.epilogue = EPI_STORE; a.act = ACT_NONE;
+        a.out = addr_static(p->pf_c + (int64_t)b * P * C1 + col);
+        a.out_ld = C1;
+        MMK_TRY(launch_linear(a, st));
+      }
   }
   std::vector<int64_t> sfx(L, 0);   // sfx[l] = sum of the dilations above layer l
   for (int l = L - 2; l >= 0; --l) sfx[l] = sfx[l + 1] + p->dil[l + 1];
@@ -1388,6 +1450,15 @@ extern "C" int mmk_wavenet_last_logits(mmk_wavenet_plan* p, int32_t batch, float
   if (!p->committed) return fail(MMK_ERR_STATE, "wavenet_last_logits: plan not committed");
   if (p->cfg.head_kind != 0) return fail(MMK_ERR_UNSUPPORTED, "wavenet_last_logits: only for the MLP head");
   const int n = p->cfg.out_dim + (p->cfg.learn_temp ? 1 : 0);
+  if (p->spipe) {      // the stage pipeline's head writes 256 classes + the temperature at column 256: the network's classes, then its temperature
+    constexpr int PQ = mmk_wavenet_plan::kSpQ, PLD = mmk_wavenet_plan::kSpLogitsLd;
+    MMK_HIP(hipMemcpy2DAsync(out, ld * sizeof(float), p->sp_logits, PLD * sizeof(float), p->cfg.out_dim * sizeof(float), batch, hipMemcpyDeviceToDevice,
+                             (hipStream_t)stream));
+    if (p->cfg.learn_temp)
+      MMK_HIP(hipMemcpy2DAsync(out + p->cfg.out_dim, ld * sizeof(float), p->sp_logits + PQ, PLD * sizeof(float), sizeof(float), batch,
+                               hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return MMK_OK;
+  }
   MMK_HIP(hipMemcpy2DAsync(out, ld * sizeof(float), p->logits, p->logits_ld * sizeof(float), n * sizeof(float), batch,
                            hipMemcpyDeviceToDevice, (hipStream_t)stream));
   return MMK_OK;

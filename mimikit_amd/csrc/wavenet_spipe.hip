@@ -1339,8 +1339,12 @@ __global__ __launch_bounds__(256) void spipe_image_kernel(const WnSpRaw* __restr
 
 bool wn_spipe_supported(int C, int S, int H1, int n_classes, int L, int n_cond, int cond_dim, int batch) {
   // (the helper waves multiply 16 K slices of 16 conditioning channels: at most 256 of them, in whole slices)
-  const bool cond_ok = n_cond == 0 || (n_cond == 1 && cond_dim > 0 && cond_dim <= kC && cond_dim % 16 == 0);
-  return C == kC && S == kC && H1 == kH1 && n_classes == kQ && cond_ok && L >= 1 && L <= kSpMaxLayers && batch >= 1 && batch <= kSpMaxClips;
+  // (cond_dim: the widths of ALL conditioning inputs together - the plan hands their projections over side by side, as one row)
+  // (a head of fewer hidden units or classes runs as the 128 x 256 one: the plan pads its matrices with zero rows / columns and gives the
+  //  missing classes a bias of -inf)
+  const bool cond_ok = n_cond == 0 || (n_cond >= 1 && n_cond <= 2 && cond_dim > 0 && cond_dim <= kC && cond_dim % 16 == 0);
+  return C == kC && S == kC && H1 >= 1 && H1 <= kH1 && n_classes >= 2 && n_classes <= kQ && cond_ok && L >= 1 && L <= kSpMaxLayers && batch >= 1 &&
+         batch <= kSpMaxClips;
 }
 int64_t wn_spipe_img_chain_floats(int L, int C) { return (int64_t)L * (C / 8) * kChainRegs * 64 * 4; }
 int64_t wn_spipe_img_helper_floats(int L, int C) { return (int64_t)L * (C / 8) * kHelperRegs * 64 * 4; }

@@ -1485,3 +1485,57 @@ def test_multi_input_multi_target_matches_reference_golden(tag, device):
     for k in range(n_tgt):
         ok3, exact = H.sampled_picks_ok(raw3[k], temp, uni[k], got[k][:, P2:])
         assert bool(ok3.all()) and float(exact.float().mean()) > 0.99, (tag, k)
+
+
+@pytest.mark.parametrize("q,mlp_dim,cond_dims,blocks,B", [(128, 64, (), (3, 2), 5), (64, 40, (16,), (4,), 9), (256, 128, (16, 32), (3, 1), 6),
+                                                          (200, 100, (32, 16), (2, 2, 1), 33)])
+def test_wavenet_stage_pipeline_takes_narrower_heads_and_two_conditioning_inputs(device, monkeypatch, q, mlp_dim, cond_dims, blocks, B):
+    """the stage pipeline beyond BASELINE's exact head: fewer classes (input and target), fewer hidden units (not a multiple of 16 either) - the
+    plan pads the head to the kernel's 128 x 256 with zero rows / columns and a bias of -inf for the classes that do not exist - and TWO
+    conditioning inputs, whose projections and 1x1 matrices it lays side by side.  Against the oracle, teacher-forced on the device's own
+    history: greedy classes, the last step's raw outputs (the network's own columns), and a sampled generation (every pick inside the
+    oracle's CDF interval - a class that does not exist must never be drawn)"""
+    from oracle.weights import load_recipe
+    for k in SPIPE_ENV:
+        monkeypatch.delitem(mmk.native.PLAN_TUNING, k, raising=False)
+    monkeypatch.setitem(mmk.native.PLAN_TUNING, "MMK_WN_SPIPE", "1")
+    io = H.mu_emb(mlp_dim=mlp_dim, q_levels=q)
+    ext = mmk.Extractor("signal", mmk.FileToSignal(16000))
+    extra = tuple(mmk.InputSpec("signal", mmk.MagSpec(22, 4, center=False), mmk.LinearIO()).bind_to(ext) for _ in cond_dims)
+    io = mmk.IOSpec(inputs=(io.inputs[0], *extra), targets=io.targets)
+    net = mmk.WaveNet.from_config(mmk.WaveNet.Config(io_spec=io, blocks=blocks, dims_dilated=(256,), dims_1x1=tuple(cond_dims), residuals_dim=256,
+                                                     skips_dim=256)).eval()
+    sd = load_recipe(net, seed=500 + q + B, gain=2.0)
+    dil = [2 ** i for b in blocks for i in range(b)]
+    arch = dict(kernels=[2] * len(dil), dilations=dil, has_skips=True, residuals=True)
+    net = net.to(device)
+    gen = torch.Generator().manual_seed(q + B)
+    rf, n = net.rf, 40
+    P = rf + 3
+    prompt = torch.randint(0, q, (B, P), generator=gen)
+    conds = tuple(torch.rand(B, P + n, 12, generator=gen) for _ in cond_dims)
+    conds_d = tuple(c.to(device) for c in conds)
+    idx = torch.cat([prompt, torch.zeros(B, n, dtype=torch.int64)], 1).to(device)
+    net.generate_block((idx, *conds_d), P, n)
+    net.after_generate((idx,), None)
+    assert net._plan.stage_pipelined
+    got = idx.cpu()
+    assert int(got.max()) < q
+    last = net._plan.last_logits(B).cpu()
+    assert last.shape == (B, q + 1)
+    want, raw = O.wavenet_generate(sd, prompt, conds, n, keep_logits=True, forced=got, **arch)
+    ok = H.margin_ok(raw.numpy())
+    assert bool(((got[:, P:] == want[:, P:]) | ~ok).all()) and float(ok.float().mean()) > 0.95
+    assert torch.allclose(last[ok[:, -1]], raw[:, -1][ok[:, -1]], **LOGIT_TOL)
+    # sampled: the plan driven directly, so that the uniforms are known
+    temp = torch.full((B,), 0.9)
+    uni = torch.rand(B, n, generator=gen)
+    idx = torch.cat([prompt, torch.zeros(B, n, dtype=torch.int64)], 1).to(device)
+    net.before_generate((idx[:, :P], *(c[:, :P] for c in conds_d)), None)
+    net._plan.generate(idx, conds_d, P, n, temp.to(device), uni.to(device))
+    torch.cuda.synchronize()
+    got = idx.cpu()
+    assert int(got.max()) < q
+    _, raw = O.wavenet_generate(sd, prompt, conds, n, keep_logits=True, forced=got, temperature=temp, uniforms=uni, **arch)
+    ok3, exact = H.sampled_picks_ok(raw, temp, uni, got[:, P:])
+    assert bool(ok3.all()) and float(exact.float().mean()) > 0.99
