@@ -89,6 +89,8 @@ struct mmk_wavenet_plan {
   int64_t pipe_gran_words = 0;  // the pipelined kernel's extra exchange buffers (their own block)
   float* h_rings = nullptr;     // per workgroup: past inputs of every layer (the delayed tap reads them)
   float* cproj = nullptr;       // (Bmax, kCondBlock, C1) conditioning after its LinearIO
+  float* cpad = nullptr;        // the block's (or the prompt's) conditioning rows of all clips, compact, every row padded to whole 16-float chunks:
+  int64_t cpad_rows = 0;        // what the tiled GEMM multiplies (513 bins per row as they arrive cannot be read 16 bytes at a time)
   float* condall = nullptr;     // (Bmax, kCondBlock, L, 2C) every layer's conditioning product, packed gate order
   float* zero_pad = nullptr;    // 64 floats that stay zero
   // warm-up as a prefill (wavenet_prefill.hip): two ping-pong layer inputs, the gated output, the projected
@@ -179,6 +181,13 @@ struct mmk_wavenet_plan {
     }
     h_rings = spipe ? nullptr : c.take<float>((int64_t)(pipe ? 8 : Gc) * Gn * ring_floats_per_wg);
     cproj = C1 > 0 ? c.take<float>((int64_t)Bmax * kCondBlock * C1) : nullptr;
+    if (C1 > 0) {
+      int kmax = 16;
+      for (int j = 0; j < n_cond; ++j) kmax = (int)round_up(cfg.cond_in_dim[j], 16) > kmax ? (int)round_up(cfg.cond_in_dim[j], 16) : kmax;
+      const int64_t prompt_rows = round_up(rf, 32);      // (= pf_P, set further down)
+      cpad_rows = (int64_t)Bmax * (prompt_rows > kCondBlock ? prompt_rows : kCondBlock);
+      cpad = c.take<float>(cpad_rows * kmax);
+    }
     // (the stage pipeline multiplies the layers' conditioning products itself, from cproj)
     condall = (C1 > 0 && !spipe) ? c.take<float>((int64_t)Bmax * kCondBlock * L * 2 * C) : nullptr;
     if (C1 > 0 && !spipe) cond_all.carve(c, false);
@@ -1106,6 +1115,45 @@ static int emit_step(mmk_wavenet_plan* p, const WnCall& call, int64_t tau_off, b
 
 static constexpr int kGraphSteps = 8;
 
+// rows (clip b, position t0 + i), i < n, of a (batch, T, K) tensor -> compact rows b n + i of Kp = K rounded up to 16 floats, zero padded
+__global__ void cond_compact_kernel(const float* __restrict__ src, int64_t clip_stride, int64_t t0, int K, int Kp, int n, int B, float* __restrict__ dst) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= (int64_t)B * n * Kp) return;
+  const int k = (int)(e % Kp);
+  const int64_t row = e / Kp;
+  const int b = (int)(row / n), i = (int)(row - (int64_t)b * n);
+  dst[e] = k < K ? src[(int64_t)b * clip_stride + (t0 + i) * K + k] : 0.f;
+}
+
+// c[b, t0 + i, :] = LinearIO_j(cond_j[b, t0 + i, :]) (modules/io.py:115-122) for i < n and all clips -> out + (b out_clip_stride + i) C1 + col:
+// the rows made compact and 16-float aligned, then ONE tiled GEMM over them (the row-tile kernel on the rows as they lie - 513 floats apart,
+// readable 4 bytes at a time - ran the cfg-4 block's 32 768 x 513 x 256 product in 528 us, 20 TFLOP/s; MMK_WN_COND_GEMM=0: that form)
+static int project_cond(mmk_wavenet_plan* p, const WnCall& call, int j, int col, int64_t t0, int64_t n, float* out, int64_t out_clip_stride, hipStream_t st) {
+  const mmk_wavenet_config& c = p->cfg;
+  const int K = c.cond_in_dim[j], Kp = (int)round_up(K, 16), B = call.M;
+  const char* genv = p->tune.get("MMK_WN_COND_GEMM");
+  const int64_t M = (int64_t)B * n;
+  if (!(genv && genv[0] == '0') && p->cpad && M <= p->cpad_rows && M < ((int64_t)1 << 31) && gemm_bias_act_supported(p->cpad, Kp, (int)M, K)) {
+    const int64_t total = M * Kp;
+    hipLaunchKernelGGL(cond_compact_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, call.cond[j], call.cond_rs[j], t0, K, Kp, (int)n, B, p->cpad);
+    MMK_HIP(hipGetLastError());
+    GemmRowMap rm;
+    rm.group = (int)n; rm.kept = (int)n; rm.group_stride = out_clip_stride * p->C1; rm.row_stride = p->C1;
+    return launch_gemm_bias_act(p->cpad, Kp, p->cond_lin[j].Wp, p->cond_lin[j].bias, p->cond_lin[j].n_tiles, p->cond_lin[j].k_chunks, c.cond_dim[j], K,
+                                out + col, p->C1, (int)M, ACT_NONE, st, rm);
+  }
+  LinearArgs a = {};      // all clips in one launch: row m = position m % n of clip m / n
+  p->cond_lin[j].fill(a);
+  a.seg[0].x = addr_static(call.cond[j] + t0 * K);
+  a.seg[0].ld = K;
+  a.M = (int)M; a.tau_ptr = nullptr; a.tau_off = 0;
+  a.epilogue = EPI_STORE; a.act = ACT_NONE;
+  a.out = addr_static(out + col);
+  a.out_ld = p->C1;
+  a.row_group = (int)n; a.x_group_stride = call.cond_rs[j]; a.out_group_stride = out_clip_stride * p->C1;
+  return launch_linear(a, st);
+}
+
 // persistent mode: blocks of up to kCondBlock positions, each = (conditioning projection GEMMs) +
 // (clear of the hand-off words) + ONE kernel that runs every step of the block
 static int run_persistent(mmk_wavenet_plan* p, const WnCall& call, int64_t tau0, int64_t n, bool with_head, hipStream_t st) {
@@ -1118,18 +1166,8 @@ static int run_persistent(mmk_wavenet_plan* p, const WnCall& call, int64_t tau0,
     if (p->C1 > 0) {
       // c[b, tau, :] = LinearIO(cond[b, tau, :]) for the block's positions (modules/io.py:115-122)
       g_prof_tag = 2;
-      for (int j = 0, col = 0; j < p->n_cond; col += c.cond_dim[j], ++j) {   // all clips in one launch: row m = position m % nb of clip m / nb
-        LinearArgs a = {};                                                     // (two inputs - stage pipeline only: side by side in a row of C1)
-        p->cond_lin[j].fill(a);
-        a.seg[0].x = addr_static(call.cond[j] + tau_b * c.cond_in_dim[j]);
-        a.seg[0].ld = c.cond_in_dim[j];
-        a.M = (int)(nb * call.M); a.tau_ptr = nullptr; a.tau_off = 0;
-        a.epilogue = EPI_STORE; a.act = ACT_NONE;
-        a.out = addr_static(p->cproj + col);
-        a.out_ld = p->C1;
-        a.row_group = (int)nb; a.x_group_stride = call.cond_rs[j]; a.out_group_stride = (int64_t)p->kCondBlock * p->C1;
-        MMK_TRY(launch_linear(a, st));
-      }
+      for (int j = 0, col = 0; j < p->n_cond; col += c.cond_dim[j], ++j)      // (two inputs - stage pipeline only: side by side in a row of C1)
+        MMK_TRY(project_cond(p, call, j, col, tau_b, nb, p->cproj, p->kCondBlock, st));
       // every layer's conv_1x1(c) for the same positions (wavenet_v2.py:140-150): off the per-sample chain; one
       // GEMM over all clips (M = positions, N = L x 2C, K = C1)
       if (!p->spipe) MMK_TRY(launch_gemm_f32(p->cproj, p->C1, (int64_t)p->kCondBlock * p->C1, p->cond_all.Wp, p->cond_all.n_tiles,
@@ -1287,18 +1325,8 @@ static int prefill(mmk_wavenet_plan* p, const WnCall& call, int64_t t_begin, int
   MMK_TRY(launch_wn_prefill_embed((const int64_t*)call.in0, call.in0_rs, t_begin, p->emb, c.q_levels, C, (int)n, p->pf_h[0],
                                   P * C, B, st));
   if (C1 > 0) {
-    for (int j = 0, col = 0; j < p->n_cond; col += c.cond_dim[j], ++j)
-      for (int b = 0; b < B; ++b) {   // c[b, t, :] = LinearIO(cond[b, t, :])   (modules/io.py:115-122); two inputs' rows side by side
-        LinearArgs a = {};
-        p->cond_lin[j].fill(a);
-        a.seg[0].x = addr_static(call.cond[j] + (int64_t)b * call.cond_rs[j] + t_begin * c.cond_in_dim[j]);
-        a.seg[0].ld = c.cond_in_dim[j];
-        a.M = (int)n; a.tau_ptr = nullptr; a.tau_off = 0;
-        a.epilogue = EPI_STORE; a.act = ACT_NONE;
-        a.out = addr_static(p->pf_c + (int64_t)b * P * C1 + col);
-        a.out_ld = C1;
-        MMK_TRY(launch_linear(a, st));
-      }
+    for (int j = 0, col = 0; j < p->n_cond; col += c.cond_dim[j], ++j)      // c[b, t, :] = LinearIO(cond[b, t, :]); two inputs' rows side by side
+      MMK_TRY(project_cond(p, call, j, col, t_begin, n, p->pf_c, P, st));
   }
   std::vector<int64_t> sfx(L, 0);   // sfx[l] = sum of the dilations above layer l
   for (int l = L - 2; l >= 0; --l) sfx[l] = sfx[l + 1] + p->dil[l + 1];
