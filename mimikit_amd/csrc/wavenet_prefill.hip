@@ -20,55 +20,64 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef const __attribute__((address_space(1))) f32x4* gf32x4_ptr;
 
 constexpr int kPfThreads = 512;
-constexpr int kPfBM = 32, kPfBN = 128;
+constexpr int kPfBM = 64, kPfBN = 128;      // (round 4: 64 rows, staged one K segment at a time - see the kernel)
 
 template <int EPI>   // 0: gate (bias, tanh * sigmoid of adjacent columns) -> y ; 1: residual (bias + res_in) -> out
 __global__ __launch_bounds__(kPfThreads) void wn_prefill_kernel(const WnPrefillArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   float* as = reinterpret_cast<float*>(smem_raw);
-  const int k_chunks = a.k_chunks;
-  const int ldk = k_chunks * 16 + 4;
+  int kmax = 16;
+  for (int s = 0; s < a.nseg; ++s) kmax = a.seg_k[s] > kmax ? a.seg_k[s] : kmax;
+  const int ldk = kmax + 4;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int m_first = blockIdx.y * kPfBM;
   const int tile = blockIdx.x * (kPfBN / 16) + wave;
   const int b = blockIdx.z;
-  // ---- the rows of every segment -> LDS, side by side ------------------------------------------------------
-  int k0 = 0;
+  const bool live = tile < a.n_tiles;
+  // Round 4: 64 rows per workgroup, ONE K segment in LDS at a time (66 KB: two workgroups per CU, one staging while the other multiplies).
+  // The first form staged all of K for 32 rows (99 KB, one workgroup per CU): a weight fragment fetched from L2 met 32 rows - 12.8 FLOP per
+  // byte of L2 traffic, and nothing ran beside the staging; 60 TFLOP/s on the full-size layers of cfg 4.
+  gf32x4_ptr w = (gf32x4_ptr)(uintptr_t)a.wp + (int64_t)(live ? tile : 0) * a.k_chunks * 64 + lane;
+  const float* x = as + (lane & 15) * ldk + 4 * (lane >> 4);
+  f32x4 acc[4] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+  int c0 = 0;
   for (int s = 0; s < a.nseg; ++s) {
     const int K = a.seg_k[s];                                  // multiple of 16
     const float* base = a.seg[s] + (int64_t)b * a.seg_batch[s];
     const int k4 = K / 4;
+    if (s > 0) __syncthreads();                                // (every wave is through with the segment before)
     for (int q = tid; q < kPfBM * k4; q += kPfThreads) {
       const int m = q / k4, c = (q - m * k4) * 4;
       f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
       if (m_first + m < a.M) v = *reinterpret_cast<const f32x4*>(base + (int64_t)(m_first + m) * a.seg_ld[s] + c);
-      *reinterpret_cast<f32x4*>(as + m * ldk + k0 + c) = v;
+      *reinterpret_cast<f32x4*>(as + m * ldk + c) = v;
     }
-    k0 += K;
-  }
-  __syncthreads();
-  if (tile >= a.n_tiles) return;
-  gf32x4_ptr w = (gf32x4_ptr)(uintptr_t)a.wp + (int64_t)tile * k_chunks * 64 + lane;
-  const float* x = as + (lane & 15) * ldk + 4 * (lane >> 4);
-  f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-  f32x4 wv = w[0];
-  for (int c = 0; c < k_chunks; ++c) {
-    const f32x4 wn = w[(int64_t)(c + 1 < k_chunks ? c + 1 : c) * 64];   // next fragment in flight
-    const f32x4 x0 = *reinterpret_cast<const f32x4*>(x + c * 16);
-    const f32x4 x1 = *reinterpret_cast<const f32x4*>(x + 16 * ldk + c * 16);
+    __syncthreads();
+    if (live) {
+      const int kc = K / 16;
+      f32x4 wv = w[(int64_t)c0 * 64];
+      for (int c = 0; c < kc; ++c) {
+        const f32x4 wn = w[(int64_t)(c0 + (c + 1 < kc ? c + 1 : c)) * 64];   // next fragment in flight
+        f32x4 xr[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(x0[i], wv[i], acc[0], 0, 0, 0);
-      acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(x1[i], wv[i], acc[1], 0, 0, 0);
+        for (int rt = 0; rt < 4; ++rt) xr[rt] = *reinterpret_cast<const f32x4*>(x + rt * 16 * ldk + c * 16);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+          for (int rt = 0; rt < 4; ++rt) acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(xr[rt][i], wv[i], acc[rt], 0, 0, 0);
+        }
+        wv = wn;
+      }
     }
-    wv = wn;
+    c0 += K / 16;
   }
+  if (!live) return;
   // ---- D: column lane & 15, rows 4 (lane >> 4) + r of each 16-row tile ------------------------------------------
   const int n = lane & 15, col = tile * 16 + n;
   const float bias = (a.bias && col < a.N) ? a.bias[col] : 0.f;
 #pragma unroll
-  for (int mt = 0; mt < 2; ++mt) {
+  for (int mt = 0; mt < 4; ++mt) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int m = m_first + mt * 16 + 4 * (lane >> 4) + r;
@@ -91,7 +100,9 @@ __global__ __launch_bounds__(kPfThreads) void wn_prefill_kernel(const WnPrefillA
 
 int launch_wn_prefill(const WnPrefillArgs& a, int epilogue, int batch, hipStream_t stream) {
   if (a.M <= 0 || batch <= 0 || a.n_tiles <= 0) return MMK_OK;
-  const size_t lds = (size_t)kPfBM * (a.k_chunks * 16 + 4) * sizeof(float);
+  int kmax = 16;
+  for (int s = 0; s < a.nseg; ++s) kmax = a.seg_k[s] > kmax ? a.seg_k[s] : kmax;
+  const size_t lds = (size_t)kPfBM * (kmax + 4) * sizeof(float);
   if (lds > 160 * 1024) return fail(MMK_ERR_UNSUPPORTED, "wavenet prefill: K does not fit the LDS stage");
   dim3 grid((a.n_tiles + kPfBN / 16 - 1) / (kPfBN / 16), (a.M + kPfBM - 1) / kPfBM, batch), block(kPfThreads);
   if (epilogue == 0) hipLaunchKernelGGL((wn_prefill_kernel<0>), grid, block, lds, stream, a);
