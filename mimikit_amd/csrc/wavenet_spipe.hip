@@ -445,6 +445,7 @@ __device__ void chain_role(const WnSpipeArgs& a, Lds& S, int stage, int p, int q
       // ---- the hidden units' sum, handed on ---------------------------------------------------------------------------------------------------
       if (stage >= 1) {
         f32x2 hc[2] = {f32x2{0.f, 0.f}, f32x2{0.f, 0.f}};
+        if (!(STAMPS && (a.dbg & 128)))      // (diagnostic build, timing only: dbg 128 no hidden-unit products, dbg 256 nor the wait for the sum so far)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {      // (the y slice of the residual product, read again: 16 registers kept across the gate would not fit)
           const f32x4s yv = *reinterpret_cast<const f32x4s*>(xb + xr_off + i * 4);
@@ -456,7 +457,7 @@ __device__ void chain_role(const WnSpipeArgs& a, Lds& S, int stage, int p, int q
         // the chain waves load NOTHING from memory - a load's data is waited for with a count that also covers the stores before it,
         // i.e. every visit would wait for its own publish to be acknowledged (a written-through one: ~1 us)
         float hin = 0.f;
-        if (hid_chain_in) {
+        if (hid_chain_in && !(STAMPS && (a.dbg & 256))) {
           if (!lds_wait1(&S.hidin_ready[v & 3], v + 1, a.err_flag)) return;
           hin = S.hidin[v & (kXyRing - 1)][4 * q + (lane >> 4)];
         }
