@@ -339,7 +339,9 @@ void wn_lpipe_split(int L, int32_t (&first)[kLpStages + 1]) {
 }
 
 bool wn_lpipe_supported(int C, int S, int H1, int n_classes, int L, int n_cond, int batch) {
-  return C == kC && S == kC && H1 == kH1 && n_classes == kQ && n_cond == 0 && L >= kLpStages && L <= kLpMaxLayers && batch >= 1 && batch <= 64;
+  // (a head of fewer hidden units or classes runs as the 128 x 256 one: the plan pads its matrices - zero rows / columns, -inf bias for classes that do not exist)
+  return C == kC && S == kC && H1 >= 16 && H1 <= kH1 && H1 % 16 == 0 && n_classes >= 2 && n_classes <= kQ && n_cond == 0 && L >= kLpStages && L <= kLpMaxLayers &&
+         batch >= 1 && batch <= 64;
 }
 
 int launch_wavenet_lpipe(const WnLpipeArgs& a, hipStream_t stream) {

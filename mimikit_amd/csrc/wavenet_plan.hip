@@ -125,6 +125,7 @@ struct mmk_wavenet_plan {
   // (zero rows / columns, -inf bias for the classes that do not exist), two conditioning inputs' projections and 1x1 matrices laid side by side
   float *sp_f0p = nullptr, *sp_fb0p = nullptr, *sp_fc2p = nullptr, *sp_fc2bp = nullptr, *sp_w1cat = nullptr, *sp_b1cat = nullptr, *sp_logits = nullptr;
   static constexpr int kSpH1 = 128, kSpQ = 256, kSpLogitsLd = 260;
+  PackedLinear lp_mlp0, lp_mlp1;      // the layer pipeline's copy of the same padded head, in the packed layout it reads
 
   void layout_persistent(Carver& c) {
     layer_tab = c.take<WnLayerTab>(L);
@@ -154,6 +155,15 @@ struct mmk_wavenet_plan {
       pipe_gran_words = extra;
     }
     if (lpipe) {
+      sp_f0p = c.take<float>((int64_t)kSpH1 * C);
+      sp_fb0p = c.take<float>(kSpH1);
+      sp_fc2p = c.take<float>((int64_t)(kSpQ + 1) * kSpH1);
+      sp_fc2bp = c.take<float>(kSpLogitsLd);
+      sp_logits = c.take<float>((int64_t)Bmax * kSpLogitsLd);
+      lp_mlp0.set_geometry(kSpH1, {C});
+      lp_mlp1.set_geometry(kSpQ + 1, {kSpH1});
+      lp_mlp0.carve(c, true);
+      lp_mlp1.carve(c, true);
       lp_gran_words = (int64_t)(kLpStages + 1) * Bmax * 128 + (int64_t)Bmax * 16 + (int64_t)Bmax * 2;   // x | skip, class (a line per clip), XCC ids
       lp_xg = c.take<unsigned long long>(lp_gran_words);
       lp_cg = lp_xg + (lp_xg ? (int64_t)(kLpStages + 1) * Bmax * 128 : 0);
@@ -570,7 +580,7 @@ static int derive(mmk_wavenet_plan* p) {
   if (p->persistent && !p->pipe && !p->spipe) {
     const char* lenv = p->tune.get("MMK_WN_LPIPE");
     const char* fenv = p->tune.get("MMK_WN_PREFILL");
-    bool ok4 = !(lenv && lenv[0] == '0') && !(fenv && fenv[0] == '0') && n_xcc == 8 && 32 * ((p->Bmax + 7) / 8) <= n_cu && c.q_levels == 256;
+    bool ok4 = !(lenv && lenv[0] == '0') && !(fenv && fenv[0] == '0') && n_xcc == 8 && 32 * ((p->Bmax + 7) / 8) <= n_cu && c.q_levels <= 256 && c.out_dim <= c.q_levels;
     ok4 = ok4 && wn_lpipe_supported(p->C, p->S, c.mlp_hidden, c.out_dim, p->L, c.n_cond, p->Bmax);
     for (int l = 0; l + 1 < p->L; ++l) ok4 = ok4 && p->has_res[l];
     p->lpipe = ok4;
@@ -896,6 +906,31 @@ extern "C" int mmk_wavenet_commit(mmk_wavenet_plan* p, void* workspace, size_t w
     if (w) MMK_TRY(pack_rect(m.Wp, m.k_chunks, 0, 1, m.N, 0, m.segK[0], w, m.segK[0], 1, st));
     if (bb) MMK_TRY(pack_bias(m.bias, 0, 1, m.N, bb, 0, st));
   }
+  if (p->lpipe) {      // the layer pipeline's head is 128 hidden units x 256 classes too: the padded head (as for the stage pipeline), packed
+    constexpr int PH = mmk_wavenet_plan::kSpH1, PQ = mmk_wavenet_plan::kSpQ;
+    const int H1 = c.mlp_hidden, Q = c.out_dim;
+    const float* f0 = b.need("output_modules.0.estimator.0.fc.0.weight", (int64_t)H1 * C);
+    const float* fb0 = b.need("output_modules.0.estimator.0.fc.0.bias", H1);
+    const float* f2 = b.need("output_modules.0.estimator.0.fc.2.weight", (int64_t)(Q + (c.learn_temp ? 1 : 0)) * H1);
+    const float* fb2 = b.need("output_modules.0.estimator.0.fc.2.bias", Q + (c.learn_temp ? 1 : 0));
+    if (f0 && fb0 && f2 && fb2) {
+      MMK_HIP(hipMemcpyAsync(p->sp_f0p, f0, (size_t)H1 * C * sizeof(float), hipMemcpyDeviceToDevice, st));
+      MMK_HIP(hipMemcpyAsync(p->sp_fb0p, fb0, (size_t)H1 * sizeof(float), hipMemcpyDeviceToDevice, st));
+      MMK_HIP(hipMemcpy2DAsync(p->sp_fc2p, (size_t)PH * sizeof(float), f2, (size_t)H1 * sizeof(float), (size_t)H1 * sizeof(float), Q, hipMemcpyDeviceToDevice, st));
+      MMK_TRY(launch_fill(p->sp_fc2bp, -INFINITY, mmk_wavenet_plan::kSpLogitsLd, st));
+      MMK_HIP(hipMemcpyAsync(p->sp_fc2bp, fb2, (size_t)Q * sizeof(float), hipMemcpyDeviceToDevice, st));
+      if (c.learn_temp) {
+        MMK_HIP(hipMemcpyAsync(p->sp_fc2p + (int64_t)PQ * PH, f2 + (int64_t)Q * H1, (size_t)H1 * sizeof(float), hipMemcpyDeviceToDevice, st));
+        MMK_HIP(hipMemcpyAsync(p->sp_fc2bp + PQ, fb2 + Q, sizeof(float), hipMemcpyDeviceToDevice, st));
+      } else {
+        MMK_TRY(launch_fill(p->sp_fc2bp + PQ, 0.f, 1, st));
+      }
+      MMK_TRY(pack_rect(p->lp_mlp0.Wp, p->lp_mlp0.k_chunks, 0, 1, PH, 0, C, p->sp_f0p, C, 1, st));
+      MMK_TRY(pack_bias(p->lp_mlp0.bias, 0, 1, PH, p->sp_fb0p, 0, st));
+      MMK_TRY(pack_rect(p->lp_mlp1.Wp, p->lp_mlp1.k_chunks, 0, 1, PQ + 1, 0, PH, p->sp_fc2p, PH, 1, st));
+      MMK_TRY(pack_bias(p->lp_mlp1.bias, 0, 1, PQ + 1, p->sp_fc2bp, 0, st));
+    }
+  }
   for (size_t k = 0; k < p->xheads.size(); ++k) {
     WnHead& h = p->xheads[k];
     for (size_t i = 0; i < h.mlp.size(); ++i) {
@@ -1189,11 +1224,11 @@ static int run_persistent(mmk_wavenet_plan* p, const WnCall& call, int64_t tau0,
       for (int l = 0; l < p->L; ++l) { k.hist[l] = p->hist[l]; k.ring[l] = p->ring[l]; }
       k.Bmax = p->Bmax;
       k.emb = p->emb; k.idx = (int64_t*)call.in0; k.idx_rs = call.in0_rs;
-      k.fc0_wp = p->mlp[0].Wp; k.fc0_bias = p->mlp[0].bias; k.fc2_wp = p->mlp[1].Wp; k.fc2_bias = p->mlp[1].bias;
+      k.fc0_wp = p->lp_mlp0.Wp; k.fc0_bias = p->lp_mlp0.bias; k.fc2_wp = p->lp_mlp1.Wp; k.fc2_bias = p->lp_mlp1.bias;
       k.temperature = call.temperature;
       k.uniforms = call.uniforms ? call.uniforms + done : nullptr;
       k.uni_ld = call.uni_ld;
-      k.logits_out = p->logits; k.logits_ld = p->logits_ld;
+      k.logits_out = p->sp_logits; k.logits_ld = mmk_wavenet_plan::kSpLogitsLd;
       k.xg = p->lp_xg; k.cg = p->lp_cg; k.err_flag = p->err_flag;
       k.xcc_ids = reinterpret_cast<unsigned*>(p->lp_cg + (int64_t)p->Bmax * 16);
       {
@@ -1478,7 +1513,7 @@ extern "C" int mmk_wavenet_last_logits(mmk_wavenet_plan* p, int32_t batch, float
   if (!p->committed) return fail(MMK_ERR_STATE, "wavenet_last_logits: plan not committed");
   if (p->cfg.head_kind != 0) return fail(MMK_ERR_UNSUPPORTED, "wavenet_last_logits: only for the MLP head");
   const int n = p->cfg.out_dim + (p->cfg.learn_temp ? 1 : 0);
-  if (p->spipe) {      // the stage pipeline's head writes 256 classes + the temperature at column 256: the network's classes, then its temperature
+  if (p->spipe || p->lpipe) {      // these kernels' head writes 256 classes + the temperature at column 256: the network's classes, then its temperature
     constexpr int PQ = mmk_wavenet_plan::kSpQ, PLD = mmk_wavenet_plan::kSpLogitsLd;
     MMK_HIP(hipMemcpy2DAsync(out, ld * sizeof(float), p->sp_logits, PLD * sizeof(float), p->cfg.out_dim * sizeof(float), batch, hipMemcpyDeviceToDevice,
                              (hipStream_t)stream));

@@ -1539,3 +1539,46 @@ def test_wavenet_stage_pipeline_takes_narrower_heads_and_two_conditioning_inputs
     _, raw = O.wavenet_generate(sd, prompt, conds, n, keep_logits=True, forced=got, temperature=temp, uniforms=uni, **arch)
     ok3, exact = H.sampled_picks_ok(raw, temp, uni, got[:, P:])
     assert bool(ok3.all()) and float(exact.float().mean()) > 0.99
+
+
+@pytest.mark.parametrize("q,mlp_dim,blocks,B", [(128, 64, (10,), 8), (64, 32, (4, 3), 13), (200, 112, (4,), 40)])
+def test_wavenet_layer_pipeline_takes_narrower_heads(device, monkeypatch, q, mlp_dim, blocks, B):
+    """the layer pipeline (the cfg-2 kernel) beyond BASELINE's exact head: fewer classes and fewer hidden units, padded by the plan to
+    the kernel's 128 x 256 (zero rows / columns, -inf bias for the classes that do not exist).  Greedy against the oracle, the last
+    step's raw outputs (the network's own columns), sampled picks inside the oracle's CDF intervals - never a class that does not exist"""
+    from oracle.weights import load_recipe
+    for k in ("MMK_WN_XCD_LOCAL", "MMK_WN_PERSISTENT", "MMK_WN_GROUPS", "MMK_WN_SMALL", "MMK_WN_PREFILL", "MMK_WN_CHAIN", "MMK_WN_PIPE", "MMK_WN_LPIPE"):
+        monkeypatch.delitem(mmk.native.PLAN_TUNING, k, raising=False)
+    net = mmk.WaveNet.from_config(mmk.WaveNet.Config(io_spec=H.mu_emb(mlp_dim=mlp_dim, q_levels=q), blocks=blocks, dims_dilated=(64,), residuals_dim=64,
+                                                     skips_dim=64)).eval()
+    sd = load_recipe(net, seed=700 + q, gain=2.0)
+    dil = [2 ** i for b in blocks for i in range(b)]
+    arch = dict(kernels=[2] * len(dil), dilations=dil, has_skips=True, residuals=True)
+    net = net.to(device)
+    gen = torch.Generator().manual_seed(q + B)
+    rf, n = net.rf, 45
+    P = rf + 6
+    prompt = torch.randint(0, q, (B, P), generator=gen)
+    idx = torch.cat([prompt, torch.zeros(B, n, dtype=torch.int64)], 1).to(device)
+    net.generate_block((idx,), P, n)
+    net.after_generate((idx,), None)
+    assert net._plan.layer_pipelined
+    got = idx.cpu()
+    assert int(got.max()) < q
+    last = net._plan.last_logits(B).cpu()
+    assert last.shape == (B, q + 1)
+    want, raw = O.wavenet_generate(sd, prompt, (), n, keep_logits=True, forced=got, **arch)
+    ok = H.margin_ok(raw.numpy())
+    assert bool(((got[:, P:] == want[:, P:]) | ~ok).all()) and float(ok.float().mean()) > 0.9
+    assert torch.allclose(last[ok[:, -1]], raw[:, -1][ok[:, -1]], **LOGIT_TOL)
+    temp = torch.linspace(0.6, 1.4, B)
+    uni = torch.rand(B, n, generator=gen)
+    idx = torch.cat([prompt, torch.zeros(B, n, dtype=torch.int64)], 1).to(device)
+    net.before_generate((idx[:, :P],), None)
+    net._plan.generate(idx, (), P, n, temp.to(device), uni.to(device))
+    torch.cuda.synchronize()
+    got = idx.cpu()
+    assert int(got.max()) < q
+    _, raw = O.wavenet_generate(sd, prompt, (), n, keep_logits=True, forced=got, temperature=temp, uniforms=uni, **arch)
+    ok3, exact = H.sampled_picks_ok(raw, temp, uni, got[:, P:])
+    assert bool(ok3.all()) and float(exact.float().mean()) > 0.97
