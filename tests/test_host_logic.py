@@ -450,3 +450,36 @@ def test_library_in_the_tree_was_built_from_these_sources():
     lib = native.load_library()
     assert lib.mmk_build_digest().decode() == hip_build.source_digest()
     assert not hip_build._stale()
+
+
+def _wavenet_plan_mode(channels, layers, clips, mlp_hidden, classes, cond_dims=(), tuning=b""):
+    lib = native.load_library()
+    cfg = native.WaveNetConfig()
+    cfg.n_layers, cfg.dim_dilated, cfg.residuals_dim, cfg.skips_dim, cfg.max_batch, cfg.q_levels = layers, channels, channels, channels, clips, classes
+    for l in range(layers):
+        cfg.kernel_size[l], cfg.dilation[l] = 2, 2 ** (l % 10)
+    cfg.n_cond = len(cond_dims)
+    for j, d in enumerate(cond_dims):
+        cfg.cond_in_dim[j], cfg.cond_dim[j] = 513, d
+    cfg.mlp_hidden, cfg.out_dim, cfg.learn_temp, cfg.gated, cfg.bias = mlp_hidden, classes, 1, 1, 1
+    cfg.tuning = tuning
+    handle = native.vp()
+    assert lib.mmk_wavenet_plan_create(native.C.byref(cfg), native.C.byref(handle)) == 0, lib.mmk_last_error()
+    mode = lib.mmk_wavenet_mode(handle)
+    lib.mmk_wavenet_plan_destroy(handle)
+    return mode
+
+
+def test_flagship_step_kernels_are_not_cut_to_the_baseline_head():
+    """which step path a plan takes for heads and conditioning other than BASELINE's (the plan pads a narrower head to the kernels' 128 x 256
+    and lays two conditioning inputs side by side - DESIGN 5.6): decided at plan creation, which needs no GPU"""
+    SPIPE, LPIPE = 5, 4
+    assert _wavenet_plan_mode(256, 30, 32, 128, 256, (256,)) == SPIPE                     # BASELINE config 4
+    assert _wavenet_plan_mode(256, 30, 32, 40, 64, (16,)) == SPIPE                        # 40 hidden units (not a multiple of 16), 64 classes
+    assert _wavenet_plan_mode(256, 30, 32, 128, 256, (128, 128)) == SPIPE                 # two conditioning inputs, 256 channels together
+    assert _wavenet_plan_mode(256, 30, 32, 128, 256, (256, 16)) != SPIPE                  # ... more than the helpers' 256 K slots
+    assert _wavenet_plan_mode(256, 30, 32, 256, 256, ()) != SPIPE                         # a head wider than the kernel's
+    assert _wavenet_plan_mode(64, 10, 8, 128, 256) == LPIPE                               # BASELINE config 2
+    assert _wavenet_plan_mode(64, 10, 8, 64, 128) == LPIPE                                # a narrower head in whole tiles of 16
+    assert _wavenet_plan_mode(64, 10, 8, 40, 128) != LPIPE
+    assert _wavenet_plan_mode(64, 10, 8, 128, 256, (16,)) != LPIPE                        # (conditioned small networks: the one-hand-off kernel)
