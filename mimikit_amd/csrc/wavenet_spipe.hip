@@ -767,7 +767,10 @@ __device__ void helper_role(const WnSpipeArgs& a, Lds& S, int stage, int p, int 
   // fewer clips, four visits ahead is up to four STEPS ahead - a slot that still holds the message of four steps ago.
   const bool lookahead = B >= 4;
   bool staged_next = false;                       // my next message is staged already (in the iteration before the duty)
-  constexpr int shift = (MMK_SP_BIASSHIFT && LAG4) ? 1 : 0;      // the biases one iteration behind their rows' staging (with the four-iteration lag: 64 clips 84.9 -> 82.7 us per step)
+#ifndef MMK_SP_SHIFT_ALL
+#define MMK_SP_SHIFT_ALL 0      // (experiment: the shift below 40 clips too - valid from 9 clips on only)
+#endif
+  constexpr int shift = (MMK_SP_BIASSHIFT && (LAG4 || MMK_SP_SHIFT_ALL)) ? 1 : 0;      // the biases one iteration behind their rows' staging (with the four-iteration lag: 64 clips 84.9 -> 82.7 us per step)
   int spb = 0, cpb = 0;                           // (the visit staged in the iteration before)
   // this stage's message comes from another XCD (or, stage 0, from the head): a look is a ~0.8-us round trip there, ~0.3 inside an XCD
   const bool remote_in = stage == 0 ? ((a.L + slot_shift(a)) >> 2) != (slot_shift(a) >> 2) : ((stage - 1 + slot_shift(a)) >> 2) != ((stage + slot_shift(a)) >> 2);
