@@ -82,6 +82,46 @@ __device__ __forceinline__ int wave_argmax_first(float best, int bi) {
   return ri;
 }
 
+// The greedy pick of 256 logits that a head divides by ONE positive number (the learned temperature, networks/mlp.py:60-62) before
+// the argmax (modules/targets.py:37-52), lane i holding classes 4 i .. 4 i + 3: the division keeps the order, so the first maximum of the
+// RAW logits is the answer - unless it rounds an earlier, slightly smaller logit onto the maximum's quotient (the first maximum wins).
+// Only when another logit lies within 4 ulp of the maximum are the four quotients formed and compared.  A NaN logit: the first one
+// (torch.argmax).  One DPP maximum, four ballots and scalar bit scans instead of four IEEE divisions and an (index, value) reduction.
+__device__ __forceinline__ int greedy_256(const float* lg, bool divided, float temp_logit, float min_temp, int lane) {
+  typedef float f32x4_g __attribute__((ext_vector_type(4)));
+  const f32x4_g v4 = *reinterpret_cast<const f32x4_g*>(lg + lane * 4);
+  const float m = wave_max_dpp(fmaxf(fmaxf(v4[0], v4[1]), fmaxf(v4[2], v4[3])));
+  int result = 0x7fffffff;
+  bool odd = false, near = false;
+  const float lim = m - fmaxf(fabsf(m) * 4.8e-7f, 1e-37f);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const unsigned long long mk = __ballot(v4[k] == m);
+    if (mk) result = min(result, 4 * (int)__builtin_ctzll(mk) + k);
+    odd = odd || v4[k] != v4[k];
+    near = near || (v4[k] != m && v4[k] >= lim);
+  }
+  if (__any(odd)) {
+    int cand = 0x7fffffff;
+#pragma unroll
+    for (int k = 3; k >= 0; --k)
+      if (v4[k] != v4[k]) cand = lane * 4 + k;
+    result = wave_min_dpp(cand);
+  } else if (divided && __any(near)) {
+    const float denom = fmaxf(1.0f / (1.0f + expf(-temp_logit)), min_temp);
+    float best = v4[0] / denom;
+    int bi = lane * 4;
+#pragma unroll
+    for (int k = 1; k < 4; ++k) {
+      const float q = v4[k] / denom;
+      if (q > best) { best = q; bi = lane * 4 + k; }
+    }
+    result = wave_argmax_first(best, bi);
+  }
+  return result > 255 ? 255 : result;
+}
+
+
 // lg: the row's 256 class logits (16-byte aligned, LDS or global); scale_by_denom: the learned-temperature divisor applies
 __device__ __forceinline__ int sample_256(const float* lg, bool scale_by_denom, float denom, float T, float uniform, int lane) {
   typedef float f32x4_ __attribute__((ext_vector_type(4)));

@@ -21,6 +21,23 @@
 
 namespace mmk {
 
+// eight partial sums per lane, 16 lanes (one DPP row) that each hold a different K slice: lanes 2 c, 2 c + 1 of the row end with column c's
+// total (own + mirror partner, + half-mirror partner, + the lane two further, + the neighbour: a fixed order) - as in wavenet_spipe.hip's head
+__device__ __forceinline__ float bot_reduce_scatter8(const float (&v)[8], int ks) {
+  auto mirror = [](float x) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x140, 0xf, 0xf, false)); };
+  auto half_mirror = [](float x) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x141, 0xf, 0xf, false)); };
+  const bool b3 = (ks & 8) != 0, b2 = (ks & 4) != 0, b1 = (ks & 2) != 0;
+  float k4[4], k2[2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) k4[i] = (b3 ? v[4 + i] : v[i]) + mirror(b3 ? v[i] : v[4 + i]);
+#pragma unroll
+  for (int i = 0; i < 2; ++i) k2[i] = (b2 ? k4[2 + i] : k4[i]) + half_mirror(b2 ? k4[i] : k4[2 + i]);
+  float r = (b1 ? k2[1] : k2[0]) + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(b1 ? k2[0] : k2[1]), 0x4E, 0xf, 0xf, false));   // quad_perm [2,3,0,1]
+  r += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(r), 0xB1, 0xf, 0xf, false));                                             // quad_perm [1,0,3,2]
+  return r;
+}
+
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef const __attribute__((address_space(1))) f32x4* gf32x4_ptr;
 
@@ -408,7 +425,8 @@ __global__ __launch_bounds__(kBotThreads) void srnn_bottom1_kernel(const SrnnBot
   // the lane that ends up with a column's total after the row reduction keeps its bias: lane ks == j of the row for fc0
   // (j < 4), ks == j for fc2 (j < 8)
   const float fc0_b = (ks < 4 && cg * 4 + ks < Hm) ? a.fc0_bias[cg * 4 + ks] : 0.f;
-  const float fc2_b = (ks < 8 && cg * 8 + ks < n_out) ? a.fc2_bias[cg * 8 + ks] : 0.f;
+  // (the row's reduce-scatter below leaves class cg 8 + c in lanes 2 c, 2 c + 1: the even one writes it)
+  const float fc2_b = ((ks & 1) == 0 && cg * 8 + (ks >> 1) < n_out) ? a.fc2_bias[cg * 8 + (ks >> 1)] : 0.f;
   // composed mode (srnn_plan.hip: W0 wb_i and W0 bb + b0 pre-multiplied at commit): this lane's unit
   constexpr bool composed = COMPOSED;
   const float a_c0 = (composed && ks < 4 && cg * 4 + ks < Hm) ? a.a_comp[cg * 4 + ks] : 0.f;
@@ -475,16 +493,18 @@ __global__ __launch_bounds__(kBotThreads) void srnn_bottom1_kernel(const SrnnBot
   auto fc2_phase = [&]() {
     const f32x4* h4 = reinterpret_cast<const f32x4*>(hid + ks * kPad2);
     const f32x4 h0 = h4[0], h1 = h4[1];
-    float mine = 0.f;
+    // eight partial sums per lane, added up across the 16 lanes of the row as ONE reduce-scatter (seven DPP steps; eight row sums of
+    // four dependent steps each before: the sampler of every step waits for this)
+    float part[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       f32x4 acc = h0 * w2[j][0];
       acc += h1 * w2[j][1];
-      const float tj = row_sum((acc[0] + acc[1]) + (acc[2] + acc[3]));
-      mine = ks == j ? tj : mine;
+      part[j] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
     }
-    const int c = cg * 8 + ks;
-    if (ks < 8 && c < n_out) lbuf[c] = mine + fc2_b;
+    const float mine = bot_reduce_scatter8(part, ks);            // (class cg 8 + ks / 2, in two lanes)
+    const int c = cg * 8 + (ks >> 1);
+    if ((ks & 1) == 0 && c < n_out) lbuf[c] = mine + fc2_b;
     for (int r = wave; r < n_extra; r += kBotThreads / 64) {      // rows past 256: one wave each, lanes over k
       float p = 0.f;
       for (int k = lane; k < Hm; k += 64) p = fmaf(hid[(k / KS2) * kPad2 + k % KS2], wx[r * Hm + k], p);
@@ -502,20 +522,14 @@ __global__ __launch_bounds__(kBotThreads) void srnn_bottom1_kernel(const SrnnBot
     if (a.logits_out && s + 1 == a.n_steps)
       for (int c = lane; c < n_out; c += 64) a.logits_out[(int64_t)clip * a.logits_ld + c] = lg[c];
     float denom = 1.f;
-    if (a.learn_temp) denom = fmaxf(sigmoidf_(lg[nc]), a.min_temp);   // mlp.py:60-62
+    if (a.learn_temp && (a.temperature != nullptr || nc != 256)) denom = fmaxf(sigmoidf_(lg[nc]), a.min_temp);   // mlp.py:60-62 (the greedy pick of 256 classes divides only when it has to)
     int result;
     if (a.temperature == nullptr) {
       float best = -INFINITY;
       int bi = 0x7fffffff;
       if (nc == 256) {
-        const f32x4 v4 = *reinterpret_cast<const f32x4*>(lg + lane * 4);
-        float vv[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) vv[q] = a.learn_temp ? v4[q] / denom : v4[q];
-        best = vv[0]; bi = lane * 4;
-#pragma unroll
-        for (int q = 1; q < 4; ++q)
-          if (vv[q] > best) { best = vv[q]; bi = lane * 4 + q; }
+        bi = greedy_256(lg, a.learn_temp != 0, lg[nc], a.min_temp, lane);      // (no division where the raw order decides: sampler256.h)
+        best = 0.f;
       } else {
         for (int q = 0; q < per; ++q) {
           const int c = lane * per + q;
@@ -525,7 +539,7 @@ __global__ __launch_bounds__(kBotThreads) void srnn_bottom1_kernel(const SrnnBot
           }
         }
       }
-      bi = wave_argmax_first(best, bi);        // first maximum wins (torch.argmax)
+      if (nc != 256) bi = wave_argmax_first(best, bi);        // first maximum wins (torch.argmax)
       result = bi;
     } else if (nc == 256) {
       result = sample_256(lg, a.learn_temp != 0, denom, a.temperature[clip], a.uniforms[(int64_t)clip * a.uni_ld + t + a.uni_off], lane);

@@ -262,21 +262,12 @@ __device__ void run_stage(const WnLpipeArgs& a, int clip, int stage, int l0, flo
       __syncthreads();
       if (wave == 0) {
         float denom = 1.f;
-        if (a.learn_temp) denom = fmaxf(sigmoidf_(lg[kQ]), a.min_temp);       // mlp.py:60-62
+        if (a.learn_temp && a.temperature != nullptr) denom = fmaxf(sigmoidf_(lg[kQ]), a.min_temp);       // mlp.py:60-62 (the greedy pick divides only when it has to)
         if (a.logits_out && s + 1 == (int)a.n_steps)
           for (int c = lane; c < kQ + (a.learn_temp ? 1 : 0); c += 64) a.logits_out[(int64_t)clip * a.logits_ld + c] = lg[c];
         int result;
         if (a.temperature == nullptr) {
-          const f32x4_lp v4 = *reinterpret_cast<const f32x4_lp*>(lg + lane * 4);
-          float vv[4];
-#pragma unroll
-          for (int j = 0; j < 4; ++j) vv[j] = a.learn_temp ? v4[j] / denom : v4[j];
-          float best = vv[0];
-          int bi = lane * 4;
-#pragma unroll
-          for (int j = 1; j < 4; ++j)
-            if (vv[j] > best) { best = vv[j]; bi = lane * 4 + j; }
-          result = wave_argmax_first(best, bi);
+          result = greedy_256(lg, a.learn_temp != 0, lg[kQ], a.min_temp, lane);      // (no division where the raw order decides: sampler256.h)
         } else {
           result = sample_256(lg, a.learn_temp != 0, denom, a.temperature[clip], a.uniforms[(int64_t)clip * a.uni_ld + s], lane);
         }
