@@ -469,6 +469,7 @@ __global__ __launch_bounds__(kBotThreads) void srnn_bottom1_kernel(const SrnnBot
   };
   __syncthreads();
   stamp(0);
+  int first_cls = s_win[0];
 
   // W0 . xs for this lane's K slice of its four hidden units, slices summed across the DPP row (no bias, no activation)
   auto fc0_product = [&]() -> float {
@@ -514,8 +515,27 @@ __global__ __launch_bounds__(kBotThreads) void srnn_bottom1_kernel(const SrnnBot
     }
   };
   // temperature column + argmax / inverse-CDF sample: wave 0
+  // Greedy decode of 256 classes with a frame of one sample (cfg 3's bottom tier): EVERY wave picks the class itself from the logits in LDS
+  // (the same deterministic pick eight times) and keeps it in a register - the barrier behind the sampler, which only handed wave 0's class
+  // to the other waves, is gone (three barriers per step -> two)
+  const bool every_wave_picks = a.temperature == nullptr && a.fs == 1 && a.Q == 256;
+  int cur_cls = first_cls;
   auto sampler_phase = [&](int s, int64_t t) {
-  if (wave == 0) {
+  if (every_wave_picks) {
+    const int result = greedy_256(lbuf, a.learn_temp != 0, lbuf[256], a.min_temp, lane);
+    cur_cls = result;
+    if (wave == 0) {
+      if (a.logits_out && s + 1 == a.n_steps)
+        for (int c = lane; c < n_out; c += 64) a.logits_out[(int64_t)clip * a.logits_ld + c] = lbuf[c];
+      if (lane == 0) {
+        s_win[0] = result;
+        a.idx[(int64_t)clip * a.idx_rs + t] = result;
+        if (a.resident)    // for the tier kernels running beside this launch
+          __hip_atomic_store(a.cls_gran + (int64_t)clip * 256 + (t & 255), ((u64)(unsigned)(t + 1) << 32) | (unsigned)result, __ATOMIC_RELAXED,
+                             __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+  } else if (wave == 0) {
     const float* lg = lbuf;
     const int nc = a.Q;
     const int per = (nc + 63) / 64;
@@ -619,7 +639,7 @@ __global__ __launch_bounds__(kBotThreads) void srnn_bottom1_kernel(const SrnnBot
     if (tid < H) {
       float acc = 0.f;
       if (a.fs == 1) {
-        acc = fmaf((((float)s_win[0] / a.class_size) - .5f) * 2.f, wb0, 0.f);   // Linearizer, modules/io.py:106-112
+        acc = fmaf((((float)(every_wave_picks ? cur_cls : s_win[0]) / a.class_size) - .5f) * 2.f, wb0, 0.f);   // Linearizer, modules/io.py:106-112
       } else {
         for (int i = 0; i < a.fs; ++i) acc = fmaf((((float)s_win[i] / a.class_size) - .5f) * 2.f, wb_col[i], acc);
       }
@@ -643,7 +663,7 @@ __global__ __launch_bounds__(kBotThreads) void srnn_bottom1_kernel(const SrnnBot
     __syncthreads();
     stamp(3);
     sampler_phase(s, t);
-    __syncthreads();
+    if (!every_wave_picks) __syncthreads();
     stamp(4);
   }
   } else {
@@ -685,7 +705,7 @@ __global__ __launch_bounds__(kBotThreads) void srnn_bottom1_kernel(const SrnnBot
       if (ks < 4 && hid_u < Hm) {
         float pre = p_cur;
         if (a.fs == 1) {
-          pre = fmaf((((float)s_win[0] / a.class_size) - .5f) * 2.f, a_c0, pre);
+          pre = fmaf((((float)(every_wave_picks ? cur_cls : s_win[0]) / a.class_size) - .5f) * 2.f, a_c0, pre);
         } else {
           for (int i = 0; i < a.fs; ++i) pre = fmaf((((float)s_win[i] / a.class_size) - .5f) * 2.f, a.a_comp[i * Hm + hid_u], pre);
         }
@@ -704,7 +724,7 @@ __global__ __launch_bounds__(kBotThreads) void srnn_bottom1_kernel(const SrnnBot
       __syncthreads();
       stamp(3);
       sampler_phase(s, t);
-      __syncthreads();
+      if (!every_wave_picks) __syncthreads();
       stamp(4);
       have_p = ahead;
       p_cur = p_next;
