@@ -7,6 +7,9 @@ namespace mmk {
 struct SrnnGruArgs {
   int32_t B, H, fs;                         // clips, hidden, frame size of this tier
   int32_t up_mod, div;                      // slots of the tier above per own step (0: top tier), own frame size
+  int32_t n_updates;                        // 0 / 1: one update per launch.  > 1 (resident mode, the tier that feeds the bottom kernel, fused up-sampler):
+                                            // that many consecutive updates in ONE launch - the gate matrices are loaded once, every further update
+                                            // takes its old state from the rows the up-sampler phase has just collected
   float class_size;
   const int64_t* tau_ptr; int64_t tau_off;  // t = *tau_ptr + tau_off
   const int64_t* idx; int64_t idx_rs; int64_t shift;   // window idx[:, t + shift - fs : t + shift]

@@ -588,14 +588,31 @@ static SrnnBottomArgs bottom_args(mmk_srnn_plan* p, const SrnnCall& call, int64_
 // enqueue step t = *tau + tau_off, whose residue modulo frame_sizes[0] is `phase`
 // bottom_steps: 0 = no bottom tier here (warm-up, or covered by an earlier fused launch), 1 = this step,
 // > 1 = this and the following steps in one fused launch (no tier above fires inside the range)
-static int emit_step(mmk_srnn_plan* p, const SrnnCall& call, int64_t tau_off, int phase, int bottom_steps, hipStream_t st) {
+// steps_left: steps of the enqueued range from this one on (>= 1); covered: steps (from this one on) whose updates of the last tier an
+// earlier launch of the range has taken already (in / out)
+static int emit_step(mmk_srnn_plan* p, const SrnnCall& call, int64_t tau_off, int phase, int bottom_steps, hipStream_t st, int64_t steps_left = 1,
+                     int64_t* covered = nullptr) {
   const mmk_srnn_config& c = p->cfg;
   const int H = p->H, G = p->G, M = call.M;
   for (int i = 0; i < p->n_rnn_tiers; ++i) {
     SrnnTier& t = p->tiers[i];
     if (phase % t.fs != 0) continue;  // `if t % fs[i] == 0`, sample_rnn_v2.py:246
+    // Resident mode, the tier that feeds the bottom kernel (which runs beside this stream and hands the classes over as granules): ALL its
+    // updates up to the next update of the tier above in ONE launch (srnn_gru.hip: the gate matrices loaded once) - launched where the tier
+    // above updates, or where the enqueued range begins
+    int n_updates = 1;
+    // (measured on cfg 3 and NOT the default, tuning MMK_SRNN_MULTI_UPDATE=1: 112 - 118 ms per pass against 97 with one launch per update - the
+    //  kernel then keeps W_hh through the up-sampler phase, whose tiles it has to stream, and spills 48 address registers)
+    if (p->fused_gru && call.gate && i == p->n_rnn_tiers - 1 && i > 0 && p->tune.get("MMK_SRNN_MULTI_UPDATE") && p->tune.get("MMK_SRNN_MULTI_UPDATE")[0] == '1') {
+      const int parent = p->tiers[i - 1].fs;
+      if (covered && *covered > 0) continue;                          // taken by the launch at the parent's update (or at the range's first update)
+      const int64_t to_parent = (parent - phase % parent) / t.fs, in_range = (steps_left + t.fs - 1) / t.fs;
+      n_updates = (int)(to_parent < in_range ? to_parent : in_range);
+      if (covered) *covered = (int64_t)n_updates * t.fs;
+    }
     if (p->fused_gru) {
       SrnnGruArgs g = {};
+      g.n_updates = n_updates;
       g.B = M; g.H = H; g.fs = t.fs; g.div = t.fs; g.class_size = (float)c.q_levels;
       g.tau_ptr = p->tau; g.tau_off = tau_off;
       g.idx = call.idx; g.idx_rs = call.idx_rs; g.shift = call.shift;
@@ -812,6 +829,7 @@ static int emit_range(mmk_srnn_plan* p, const SrnnCall& call, int64_t first, int
   const int period = p->cfg.frame_size[0];
   const int slots = p->tiers[p->n_rnn_tiers - 1].up;          // frame_sizes[-2]
   int64_t covered = 0;                                        // bottom steps already inside a fused launch
+  int64_t tier_covered = 0;                                   // steps whose last-tier updates a multi-update launch has taken
   for (int64_t s = 0; s < count; ++s) {
     const int ph = (int)((phase + s) % period);
     int bottom = 0;
@@ -824,7 +842,8 @@ static int emit_range(mmk_srnn_plan* p, const SrnnCall& call, int64_t first, int
         covered = bottom;
       }
     }
-    MMK_TRY(emit_step(p, call, first + s, ph, bottom, st));
+    MMK_TRY(emit_step(p, call, first + s, ph, bottom, st, count - s, &tier_covered));
+    if (tier_covered > 0) --tier_covered;
     if (covered > 0) --covered;
   }
   return MMK_OK;

@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 4: the greedy pick without divisions in the SampleRNN bottom kernel and the layer pipeline: parity, then the two bench lines
+# round 4: SampleRNN / layer-pipeline changes: parity, then the two bench lines
 export TMPDIR=/tmp
 mkdir -p gpurun_out/r04d
 timeout 1800 python -m pytest tests/test_gpu_networks.py tests/test_gpu_baseline_configs.py tests/test_gpu_callers.py -q -x -k "sample_rnn or srnn or cfg1 or cfg3 or cfg2 or layer_pipeline or lpipe or chunks or callback or ensemble or multi_input" 2>&1 | tail -5

@@ -359,6 +359,39 @@ def test_sample_rnn_resident_mode_geometries(device, monkeypatch, frame_sizes, b
     assert torch.equal(ref[:, P:][ok], got[:, P:][ok])
 
 
+@pytest.mark.parametrize("frame_sizes,batch,hidden,kind,blocks", [((16, 4, 1), 21, 256, "gru", (37, 43, 80)), ((32, 8, 2), 33, 128, "gru", (160,)),
+                                                                ((16, 4, 1), 16, 256, "lstm", (160,)), ((64, 16, 4, 4), 5, 128, "lstm", (200,))])
+def test_sample_rnn_several_updates_per_tier_launch(device, monkeypatch, frame_sizes, batch, hidden, kind, blocks):
+    """resident mode with the tier that feeds the bottom kernel running ALL its updates up to the next update of the tier above in one launch
+    (tuning MMK_SRNN_MULTI_UPDATE=1; srnn_gru.hip, the MULTI instantiation: W_hh stays in registers, the old state of the second update on
+    comes from the rows the up-sampler phase collected): identical to the one-launch-per-update generation, blocks that start mid-frame
+    included, and equal to the oracle teacher-forced on the device's history"""
+    monkeypatch.setitem(mmk.native.PLAN_TUNING, "MMK_SRNN_FUSED", "1")
+    gen = torch.Generator().manual_seed(57)
+    rf = frame_sizes[0]
+    P = 2 * rf + 3
+    prompt = torch.randint(0, 256, (batch, P), generator=gen)
+    n = sum(blocks)
+    outs = []
+    for multi in ("1", "0"):
+        monkeypatch.setitem(mmk.native.PLAN_TUNING, "MMK_SRNN_MULTI_UPDATE", multi)
+        net, sd, arch = H.srnn("big", hidden=hidden, mlp_dim=64, seed=97, frame_sizes=frame_sizes, kind=kind)
+        net = net.to(device)
+        idx = torch.cat([prompt, torch.zeros(batch, n, dtype=torch.int64)], 1).to(device)
+        net.before_generate((idx[:, :P],), None)
+        t = P
+        for nb in blocks:
+            net.generate_block((idx,), t, nb)
+            t += nb
+        _resident_or_skip(net)
+        net.after_generate((idx,), None)
+        outs.append(idx.cpu())
+    assert torch.equal(outs[0], outs[1])
+    ref, raw = O.SampleRNNOracle(sd, **arch).generate(prompt, n, keep_logits=True, forced=outs[0])
+    ok = H.margin_ok(raw)
+    assert float(ok.float().mean()) > 0.9 and torch.equal(ref[:, P:][ok], outs[0][:, P:][ok])
+
+
 def test_sample_rnn_timeout_is_redone_in_turns(device, monkeypatch):
     """a timed-out wait of the resident mode (injected through mmk_srnn_inject_sync_error) must not return invalid samples: the batch
     is regenerated with the kernels in turns, with a warning, and equals an undisturbed generation"""
