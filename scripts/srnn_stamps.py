@@ -8,6 +8,9 @@ os.environ["MMK_DIAG_LIB"] = "1"          # the diagnostic build: python -m mimi
 os.environ["MMK_SRNN_STAMPS"] = "1"
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench  # noqa: E402
+import mimikit_amd as mmk
+if os.environ.get("SRNN_MULTI") == "1":
+    mmk.native.PLAN_TUNING["MMK_SRNN_MULTI_UPDATE"] = "1"
 
 torch.set_grad_enabled(False)
 
