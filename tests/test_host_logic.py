@@ -483,3 +483,33 @@ def test_flagship_step_kernels_are_not_cut_to_the_baseline_head():
     assert _wavenet_plan_mode(64, 10, 8, 64, 128) == LPIPE                                # a narrower head in whole tiles of 16
     assert _wavenet_plan_mode(64, 10, 8, 40, 128) != LPIPE
     assert _wavenet_plan_mode(64, 10, 8, 128, 256, (16,)) != LPIPE                        # (conditioned small networks: the one-hand-off kernel)
+
+
+def test_several_inputs_and_targets_are_described_or_refused_by_name():
+    """the plan description of networks of several inputs / targets (host logic, no GPU): class sizes per input, the ZipReduceVariables mode,
+    one head per target; what the HIP path cannot take is refused with the option's name (more targets than inputs - the loop's
+    `zip(tensors, outputs)` would drop them -, a further target on a stream that is not a class stream)"""
+    mu = lambda q, kind="framed_linear", **kw: mmk.IOSpec.mulaw_io(mmk.IOSpec.MuLawIOConfig(q_levels=q, input_module_type=kind, **kw))
+    a, b = mu(256, mlp_dim=32), mu(64, mlp_dim=48, n_mlp_layers=1)
+    io = mmk.IOSpec(inputs=(a.inputs[0], b.inputs[0]), targets=(a.targets[0], b.targets[0]))
+    net = mmk.SampleRNN.from_config(mmk.SampleRNN.Config(io_spec=io, frame_sizes=(16, 4, 1), hidden_dim=32, rnn_class="gru", inputs_mode="static_mix")).eval()
+    c = net._describe(4)
+    assert (c.n_inputs, c.n_targets, c.inputs_mode) == (2, 2, 2) and list(c.in_class)[:2] == [256, 64]
+    assert (c.q_levels, c.x_q_levels[1], c.x_mlp_hidden[1], c.x_mlp_n_hidden[1]) == (256, 64, 48, 1)
+    io_bad = mmk.IOSpec(inputs=(a.inputs[0],), targets=(a.targets[0], b.targets[0]))
+    net = mmk.SampleRNN.from_config(mmk.SampleRNN.Config(io_spec=io_bad, frame_sizes=(16, 4, 1), hidden_dim=32, rnn_class="gru")).eval()
+    with pytest.raises(NotImplementedError, match="more targets than inputs"):
+        net._describe(4)
+    # WaveNet: a class stream as conditioning input (EmbeddingIO) that a second target feeds
+    a, b = mu(256, "embedding", mlp_dim=32), mu(64, "embedding", mlp_dim=16)
+    io = mmk.IOSpec(inputs=(a.inputs[0], b.inputs[0]), targets=(a.targets[0], b.targets[0]))
+    wn = mmk.WaveNet.from_config(mmk.WaveNet.Config(io_spec=io, blocks=(3,), dims_dilated=(32,), dims_1x1=(16,), residuals_dim=32, skips_dim=32)).eval()
+    c = wn._describe(4)
+    assert (c.n_cond, c.cond_q_levels[0], c.cond_dim[0], c.n_targets, c.x_out_dim[1], c.x_mlp_hidden[1]) == (1, 64, 16, 2, 64, 16)
+    # ... and a second target whose input is NOT a class stream
+    ext = mmk.Extractor("signal", mmk.FileToSignal(16000))
+    io_bad = mmk.IOSpec(inputs=(a.inputs[0], mmk.InputSpec("signal", mmk.MagSpec(22, 4, center=False), mmk.LinearIO()).bind_to(ext)),
+                        targets=(a.targets[0], b.targets[0]))
+    wn = mmk.WaveNet.from_config(mmk.WaveNet.Config(io_spec=io_bad, blocks=(3,), dims_dilated=(32,), dims_1x1=(16,), residuals_dim=32, skips_dim=32)).eval()
+    with pytest.raises(NotImplementedError, match="target 1"):
+        wn._describe(4)
