@@ -19,20 +19,9 @@ struct SrnnBottomArgs {
   const float* temperature; const float* uniforms; int64_t uni_ld, uni_off;
   float* logits_out; int64_t logits_ld;     // logits of the launch's last step
   unsigned long long* stamps;               // diagnostic: phase totals (100 MHz ticks) + launch count, or nullptr
-  // Resident mode (srnn_plan.hip: run_resident): ONE launch for a whole generate block while the tier kernels of the block
-  // run on another stream.  The two sides meet through data-tagged 8-byte granules {epoch : 32, value : 32} written with
-  // agent-scope stores and polled with agent-scope loads - one hop per hand-over, no flag behind an acknowledged store:
-  // the tier above publishes its up-sampled rows as up_gran[clip][slot][column] with epoch = t / up_slots + 1 of its update,
-  // the clip's workgroup publishes every new class as cls_gran[clip][t & 255] with epoch = t + 1.
-  int32_t resident;
-  int64_t t_first;                          // first step (the device counter belongs to the tier stream in this mode)
-  const unsigned long long* up_gran;
-  unsigned long long* cls_gran;
-  int* err;                                 // sticky error word (a wait that timed out)
 };
 
 bool srnn_bottom_supported(int H, int Hm, int n_out, int fs);
-bool srnn_bottom_resident_supported(const SrnnBottomArgs& a);
 int launch_srnn_bottom(const SrnnBottomArgs& a, hipStream_t stream);
 
 }  // namespace mmk

@@ -374,7 +374,7 @@ __global__ __launch_bounds__(kBotThreads) void srnn_bottom1_kernel(const SrnnBot
   const int Hm = a.Hm;
   const int n_out = a.n_out;
   const int clip = blockIdx.x;
-  const int64_t t0 = a.resident ? a.t_first : *a.tau_ptr + a.tau_off;
+  const int64_t t0 = *a.tau_ptr + a.tau_off;
   const bool stamping = a.stamps != nullptr && blockIdx.x == 0 && tid == 0;
   unsigned long long st_prev = stamping ? wall_clock64() : 0, st_acc[5] = {0, 0, 0, 0, 0};
   const unsigned long long clk0 = stamping ? clock64() : 0, wall0 = st_prev;
@@ -451,14 +451,7 @@ __global__ __launch_bounds__(kBotThreads) void srnn_bottom1_kernel(const SrnnBot
   const float wb0 = wb_col[0];
   const int u0 = (int)(t0 % a.up_slots);                      // outputs[-1][:, (t % fs[-2]) - fs[-2]]   (:257)
   auto upper_at = [&](int step) -> float { return a.upper[((int64_t)clip * a.up_slots + (u0 + step) % a.up_slots) * H + xc]; };
-  // resident mode: the rows come as granules from a kernel that is still running; a granule is requested a step ahead and
-  // checked (polled, if need be) when it is used
-  typedef unsigned long long u64;
-  auto gran_at = [&](int step) -> u64 {
-    return __hip_atomic_load(a.up_gran + ((int64_t)clip * a.up_slots + (u0 + step) % a.up_slots) * H + xc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  };
-  float up_next = a.resident ? 0.f : upper_at(0);
-  u64 up_g = (a.resident && tid < H) ? gran_at(0) : 0;
+  float up_next = upper_at(0);
   // sum over the 16 lanes of a DPP row, every lane ends with the total (fixed order)
   auto row_sum = [](float v) -> float {
     v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, false));    // quad_perm [1,0,3,2]
@@ -530,9 +523,6 @@ __global__ __launch_bounds__(kBotThreads) void srnn_bottom1_kernel(const SrnnBot
       if (lane == 0) {
         s_win[0] = result;
         a.idx[(int64_t)clip * a.idx_rs + t] = result;
-        if (a.resident)    // for the tier kernels running beside this launch
-          __hip_atomic_store(a.cls_gran + (int64_t)clip * 256 + (t & 255), ((u64)(unsigned)(t + 1) << 32) | (unsigned)result, __ATOMIC_RELAXED,
-                             __HIP_MEMORY_SCOPE_AGENT);
       }
     }
   } else if (wave == 0) {
@@ -608,12 +598,7 @@ __global__ __launch_bounds__(kBotThreads) void srnn_bottom1_kernel(const SrnnBot
       const int keep = lane + 1 < a.fs ? s_win[lane + 1] : result;
       s_win[lane] = keep;     // wave-synchronous shift: every lane read before any lane writes
     }
-    if (lane == 0) {
-      a.idx[(int64_t)clip * a.idx_rs + t] = result;
-      if (a.resident)    // for the tier kernels running beside this launch
-        __hip_atomic_store(a.cls_gran + (int64_t)clip * 256 + (t & 255), ((u64)(unsigned)(t + 1) << 32) | (unsigned)result, __ATOMIC_RELAXED,
-                           __HIP_MEMORY_SCOPE_AGENT);
-    }
+    if (lane == 0) a.idx[(int64_t)clip * a.idx_rs + t] = result;
   }
   };
   const int hid_u = cg * 4 + ks;                              // the hidden unit lane ks < 4 of a row finishes
@@ -621,20 +606,6 @@ __global__ __launch_bounds__(kBotThreads) void srnn_bottom1_kernel(const SrnnBot
   if constexpr (!composed) {
   for (int s = 0; s < a.n_steps; ++s) {
     const int64_t t = t0 + s;
-    if (a.resident && tid < H) {
-      const unsigned epoch = (unsigned)(t / a.up_slots) + 1u;      // of the update this step's row belongs to
-      unsigned spins = 0;
-      while ((unsigned)(up_g >> 32) != epoch) {
-        // ~1 s: the tier stream is not running beside this kernel (or another wait has already failed: do not pile up)
-        if (++spins > (1u << 20) || ((spins & 255u) == 0 && a.err && __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
-          if (a.err) atomicExch(a.err, 4);
-          break;
-        }
-        __builtin_amdgcn_s_sleep(1);
-        up_g = gran_at(s);
-      }
-      up_next = __uint_as_float((unsigned)up_g);
-    }
     // ---- x = conv(linearize(window)) + bias + upper tier output -----------------------------------------
     if (tid < H) {
       float acc = 0.f;
@@ -645,10 +616,7 @@ __global__ __launch_bounds__(kBotThreads) void srnn_bottom1_kernel(const SrnnBot
       }
       xs[xs_at] = (acc + xb) + up_next;
     }
-    if (s + 1 < a.n_steps) {
-      if (!a.resident) up_next = upper_at(s + 1);
-      else if (tid < H) up_g = gran_at(s + 1);
-    }
+    if (s + 1 < a.n_steps) up_next = upper_at(s + 1);
     __syncthreads();
     stamp(1);
     // ---- fc0 + Mish ---------------------------------------------------------------------------------------------
@@ -672,36 +640,17 @@ __global__ __launch_bounds__(kBotThreads) void srnn_bottom1_kernel(const SrnnBot
     // latency-bound products side by side), and the x phase with its barrier is gone.  Three barriers per step instead of four.
     float p_cur = 0.f;                                        // W0 up of the current step (lanes ks < 4)
     bool have_p = false;
-    u64 g_next = 0;                                           // resident mode: the next step's row granule, requested a phase ahead
-    auto in_frame = [&](int s) -> bool {                      // step s + 1 reads a row that is there when step s runs
-      return s + 1 < a.n_steps && !(a.resident && (t0 + s + 1) % a.up_slots == 0);
-    };
-    auto row_value = [&](int s, u64 g) -> float {             // the row of step s for this thread's column (tid < H)
-      if (!a.resident) return upper_at(s);
-      const unsigned epoch = (unsigned)((t0 + s) / a.up_slots) + 1u;
-      unsigned spins = 0;
-      while ((unsigned)(g >> 32) != epoch) {
-        if (++spins > (1u << 20) || ((spins & 255u) == 0 && a.err && __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
-          if (a.err) atomicExch(a.err, 4);
-          break;
-        }
-        __builtin_amdgcn_s_sleep(1);
-        g = gran_at(s);
-      }
-      return __uint_as_float((unsigned)g);
-    };
     for (int s = 0; s < a.n_steps; ++s) {
       const int64_t t = t0 + s;
       if (!have_p) {                                          // first step of the launch / of a frame: its row, then its product
-        if (tid < H) xs[xs_at] = row_value(s, (a.resident ? gran_at(s) : 0));
+        if (tid < H) xs[xs_at] = upper_at(s);
         __syncthreads();
         p_cur = fc0_product();
-        if (a.resident && tid < H && in_frame(s)) g_next = gran_at(s + 1);
         __syncthreads();                                      // xs is rewritten below
       }
       stamp(1);
       // ---- hidden units of step s; the next step's row -> LDS -------------------------------------------------------
-      const bool ahead = in_frame(s);
+      const bool ahead = s + 1 < a.n_steps;
       if (ks < 4 && hid_u < Hm) {
         float pre = p_cur;
         if (a.fs == 1) {
@@ -711,16 +660,13 @@ __global__ __launch_bounds__(kBotThreads) void srnn_bottom1_kernel(const SrnnBot
         }
         hid[hid_at] = mish_fast(pre + b_c);
       }
-      if (ahead && tid < H) xs[xs_at] = row_value(s + 1, g_next);
+      if (ahead && tid < H) xs[xs_at] = upper_at(s + 1);
       __syncthreads();
       stamp(2);
       // ---- fc2 of step s next to W0 up of step s + 1 --------------------------------------------------------------
       fc2_phase();
       float p_next = 0.f;
-      if (ahead) {
-        p_next = fc0_product();
-        if (a.resident && tid < H && in_frame(s + 1)) g_next = gran_at(s + 2);
-      }
+      if (ahead) p_next = fc0_product();
       __syncthreads();
       stamp(3);
       sampler_phase(s, t);
@@ -765,13 +711,8 @@ bool srnn_bottom_supported(int H, int Hm, int n_out, int fs) {
   return srnn_bottom_lds_bytes(a) <= 160 * 1024;
 }
 
-bool srnn_bottom_resident_supported(const SrnnBottomArgs& a) {
-  return srnn_bottom_supported(a.H, a.Hm, a.n_out, a.fs) && srnn_bottom1_applies(a);
-}
-
 int launch_srnn_bottom(const SrnnBottomArgs& a, hipStream_t stream) {
   if (!srnn_bottom_supported(a.H, a.Hm, a.n_out, a.fs)) return fail(MMK_ERR_UNSUPPORTED, "srnn bottom kernel: geometry H=%d Hm=%d", a.H, a.Hm);
-  if (a.resident && !srnn_bottom1_applies(a)) return fail(MMK_ERR_UNSUPPORTED, "srnn bottom kernel: resident mode needs the one-clip-per-workgroup kernel");
   if (srnn_bottom1_applies(a)) {
     const size_t lds1 = srnn_bottom1_lds_bytes(a);
     dim3 grid1(a.B), block1(kBotThreads);

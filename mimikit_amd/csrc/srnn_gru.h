@@ -7,9 +7,6 @@ namespace mmk {
 struct SrnnGruArgs {
   int32_t B, H, fs;                         // clips, hidden, frame size of this tier
   int32_t up_mod, div;                      // slots of the tier above per own step (0: top tier), own frame size
-  int32_t n_updates;                        // 0 / 1: one update per launch.  > 1 (resident mode, the tier that feeds the bottom kernel, fused up-sampler):
-                                            // that many consecutive updates in ONE launch - the gate matrices are loaded once, every further update
-                                            // takes its old state from the rows the up-sampler phase has just collected
   float class_size;
   const int64_t* tau_ptr; int64_t tau_off;  // t = *tau_ptr + tau_off
   const int64_t* idx; int64_t idx_rs; int64_t shift;   // window idx[:, t + shift - fs : t + shift]
@@ -29,11 +26,6 @@ struct SrnnGruArgs {
   const float* ups_wp; const float* ups_bias; int32_t ups_n_tiles; int32_t ups_n;
   float* ups_out; int64_t ups_out_ld;
   int* err;                                 // sticky error word (a barrier that timed out), or nullptr
-  // Resident mode (the bottom tier runs beside this launch as one long kernel on another stream; granules: srnn_bottom.h):
-  // the newest classes of the window are polled from `gate_cls`, and - for the tier right above the bottom - the up-sampled
-  // rows are also published as granules `up_gran` [B][up][H] with epoch t / fs + 1
-  const unsigned long long* gate_cls;
-  unsigned long long* up_gran;
 };
 
 bool srnn_gru_supported(int H, int fs, bool lstm);

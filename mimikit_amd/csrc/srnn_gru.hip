@@ -17,10 +17,7 @@
 // Round 2.  (1) Second phase in the same launch: the tier's up-sampler, out = W_up h' + b.  The new state goes out as data-tagged
 // granules {update number, value}; a workgroup polls the state of ITS OWN 16 clips (32 KB at H = 512; a light sentinel poll by one
 // wave first) and multiplies its `up` column tiles, slot 0 - the row the tier below needs first - ahead of the others.
-// (2) Resident mode (srnn_plan.hip: run_resident): the bottom tier runs beside this launch as one long kernel; its newest classes
-// are polled as granules (`gate_cls`), and the up-sampled rows are published as granules (`up_gran`) as well.  Everything that
-// does not depend on the newest classes - weights, W_hh h, biases, up-sampler tiles - is done before that poll.
-// (3) Composed mode (frame sizes <= 16): W_ih x = W_ih (b_in + upper) + (W_ih W_in) lin(window); the first product joins the
+// (2) Composed mode (frame sizes <= 16): W_ih x = W_ih (b_in + upper) + (W_ih W_in) lin(window); the first product joins the
 // work ahead of the poll, the second is a K = fs dot product per (clip, gate unit) in the cell.
 #include <type_traits>
 
@@ -35,9 +32,7 @@ typedef const __attribute__((address_space(1))) f32x4* gf32x4_ptr;
 constexpr int kGruThreads = 512;
 constexpr int kGruWaves = kGruThreads / 64;
 
-// MULTI: several updates per launch (a.n_updates > 1).  An instantiation of its own: the gate matrices then stay in their registers through the
-// up-sampler phase, whose first tiles can no longer be kept preloaded beside them (488 bytes of scratch per thread when both were) - they are streamed
-template <int KC, bool LSTM, bool MULTI>   // KC = H / 16 K-chunks; each of the 8 waves takes KC / 8 of them
+template <int KC, bool LSTM>   // KC = H / 16 K-chunks; each of the 8 waves takes KC / 8 of them
 __global__ __launch_bounds__(kGruThreads) void srnn_gru_kernel(const SrnnGruArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   constexpr int H = KC * 16;
@@ -49,9 +44,8 @@ __global__ __launch_bounds__(kGruThreads) void srnn_gru_kernel(const SrnnGruArgs
   const int ub = blockIdx.x % KC;                  // block of 16 hidden units
   const int m_first = (blockIdx.x / KC) * 16;      // first clip of this workgroup's row tile
   const int mg = min(16, a.B - m_first);
-  const int64_t t_first = *a.tau_ptr + a.tau_off;
-  const int64_t cnt_first = *a.cnt;
-  const int n_updates = MULTI ? (a.n_updates > 1 ? a.n_updates : 1) : 1;
+  const int64_t t = *a.tau_ptr + a.tau_off;
+  const int64_t cnt = *a.cnt;
 
   // diagnostic (MMK_SRNN_STAMPS=1): 100 MHz wall-clock totals per phase of thread 0 of workgroup 0
   const bool stamping = a.stamps != nullptr && blockIdx.x == 0 && tid == 0;
@@ -81,7 +75,7 @@ __global__ __launch_bounds__(kGruThreads) void srnn_gru_kernel(const SrnnGruArgs
       gf32x4_ptr wh = (gf32x4_ptr)(uintptr_t)a.whh_wp + ((int64_t)(g * KC + ub) * a.w_tile_chunks + c0) * 64 + lane;
 #pragma unroll
       for (int u = 0; u < CPW; ++u) {
-        if (!MULTI) w[g][u] = wi[u * 64];      // (MULTI: the input half is asked for again at the top of every update, see there)
+        w[g][u] = wi[u * 64];
         w[NG + g][u] = wh[u * 64];
       }
     }
@@ -91,8 +85,8 @@ __global__ __launch_bounds__(kGruThreads) void srnn_gru_kernel(const SrnnGruArgs
   // slot 0 - the row the tier below needs first - is every workgroup's first tile and goes out on its own
   constexpr int UB = (LSTM && KC == 32) ? 2 : 4;   // tiles per batch (registers, partial-sum buffer)
   const int up_tiles = a.ups_wp != nullptr ? a.ups_n_tiles / KC : 0;
-  f32x4 wu0[MULTI ? 1 : UB][CPW];
-  if (!MULTI && a.ups_wp != nullptr) {
+  f32x4 wu0[UB][CPW];
+  if (a.ups_wp != nullptr) {
 #pragma unroll
     for (int j = 0; j < UB; ++j) {
       const int tile = min(j, up_tiles - 1) * KC + ub;
@@ -119,28 +113,8 @@ __global__ __launch_bounds__(kGruThreads) void srnn_gru_kernel(const SrnnGruArgs
     }
   }
   const int kci = (a.fs + 15) / 16, ldl = kci * 16 + 4;
-  // Several updates per launch (n_updates > 1: the tier that feeds the resident bottom kernel, launched once per update of the tier above):
-  // the gate matrices - 25 MB per launch at H = 512, 7 us, and they do not survive in the L2s until the next launch - are loaded ONCE; from
-  // the second update on the old state is what the up-sampler phase of the update before has collected (the whole rows of this workgroup's
-  // clips, as granules of the other workgroups), written back into the LDS image.  The tier stream took 5 launches of ~16 us per 16 steps
-  // of cfg 3 and was what the bottom kernel waited for.
-  for (int upd = 0; upd < n_updates; ++upd) {
-  const int64_t t = t_first + (int64_t)upd * a.fs;
-  const int64_t cnt = cnt_first + upd;
   const float* h_old = a.h_ring + (cnt & 1) * a.h_slot_stride;
   float* h_new = a.h_ring + ((cnt + 1) & 1) * a.h_slot_stride;
-  if (MULTI) {
-    // W_hh stays in its registers for the launch; W_ih is asked for again here - its product comes before the wait for the frame's classes,
-    // which hides the fetch, and half of the matrices then need no registers through the cell and the up-sampler phase (both halves resident:
-    // 216 - 364 bytes of scratch per thread)
-    const int c0 = wave * CPW;
-#pragma unroll
-    for (int g = 0; g < NG; ++g) {
-      gf32x4_ptr wi = (gf32x4_ptr)(uintptr_t)a.wih_wp + ((int64_t)(g * KC + ub) * a.w_tile_chunks + c0) * 64 + lane;
-#pragma unroll
-      for (int u = 0; u < CPW; ++u) w[g][u] = wi[u * 64];
-    }
-  }
   // ---- the input projection's operands of this wave's column tiles (frame sizes <= 16: one K-chunk): requested now,
   //      with the gate weights, instead of one round trip per tile inside the x phase ------------------------------------
   constexpr int XT = KC / kGruWaves;                 // column tiles of x per wave
@@ -168,8 +142,7 @@ __global__ __launch_bounds__(kGruThreads) void srnn_gru_kernel(const SrnnGruArgs
       if (!composed) x_w[j] = ((gf32x4_ptr)(uintptr_t)a.win_wp)[(int64_t)tile * 64 + lane];
     }
   }
-  // ---- old state rows -> LDS (first update of the launch; afterwards they are there already) ----------------------
-  if (upd == 0)
+  // ---- old state rows -> LDS -------------------------------------------------------------------------------------
   for (int q = tid; q < 16 * (H / 4); q += kGruThreads) {
     const int m = q / (H / 4), c = (q - m * (H / 4)) * 4;
     f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -230,53 +203,20 @@ __global__ __launch_bounds__(kGruThreads) void srnn_gru_kernel(const SrnnGruArgs
     for (int g = 0; g < 2 * NG; ++g) red[(g * kGruWaves + wave) * 64 + lane] = acc[g];
   };
   if (composed) input_half();
-  const bool gated = a.gate_cls != nullptr;
   stamp(0);   // weights requested, old state in LDS, recurrent half multiplied
   // ---- the window, linearized (modules/io.py:106-112), zero padded to whole K-chunks ----------------------------
-  if (gated && n_updates > 1) {
-    // Several updates per launch: the wait for the frame's classes is long (the bottom kernel makes them meanwhile) - ONE lane per clip looks
-    // at the frame's LAST class, with pauses, instead of every thread polling its own granule (the bottom kernel's loads share the fabric)
-    if (tid < mg) {
-      const int64_t pos = t + a.shift - 1;
-      const unsigned long long* src = a.gate_cls + (int64_t)(m_first + tid) * 256 + (pos & 255);
-      unsigned spins = 0;
-      while ((unsigned)(__hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 32) != (unsigned)(pos + 1)) {
-        if (++spins > (1u << 18) || ((spins & 255u) == 0 && a.err && __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) break;   // (the loop below reports it)
-        __builtin_amdgcn_s_sleep(8);
-      }
-    }
-    __syncthreads();
-  }
   for (int e = tid; e < 16 * kci * 16; e += kGruThreads) {
     const int m = e / (kci * 16), i = e - m * (kci * 16);
     float v = 0.f;
     if (m < mg && i < a.fs) {
       const int64_t pos = t + a.shift - a.fs + i;
-      int64_t cls;
-      if (!gated) {
-        cls = a.idx[(int64_t)(m_first + m) * a.idx_rs + pos];
-      } else {
-        // resident mode: the newest classes come from the bottom kernel running beside this launch, as granules
-        const unsigned long long* src = a.gate_cls + (int64_t)(m_first + m) * 256 + (pos & 255);
-        unsigned long long g = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        unsigned spins = 0;
-        while ((unsigned)(g >> 32) != (unsigned)(pos + 1)) {
-          // ~1 s: the bottom kernel is not running beside this launch (or another wait has already failed)
-          if (++spins > (1u << 20) || ((spins & 255u) == 0 && a.err && __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
-            if (a.err) atomicExch(a.err, 5);
-            break;
-          }
-          __builtin_amdgcn_s_sleep(1);
-          g = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        cls = (int64_t)(unsigned)g;
-      }
+      const int64_t cls = a.idx[(int64_t)(m_first + m) * a.idx_rs + pos];
       v = (((float)cls / a.class_size) - .5f) * 2.f;
     }
     s_lin[m * ldl + i] = v;
   }
   __syncthreads();
-  stamp(4);   // window (resident mode: incl. the wait for the bottom kernel)
+  stamp(4);   // window
   // ---- x = W_in lin + b_in (+ upper): 16 x 16 tiles over the waves, K = fs (same MFMA order as the launch path) ----
   if (composed) {
     // nothing: x never exists in this mode
@@ -399,7 +339,7 @@ __global__ __launch_bounds__(kGruThreads) void srnn_gru_kernel(const SrnnGruArgs
     for (int i = 0; i < 5; ++i) a.stamps[i] += st_acc[i];
     a.stamps[7] += 1;
   }
-  if (tid == 0 && upd + 1 == n_updates) {      // (the update counter is read at the START of a launch only: published once, by the last workgroup through)
+  if (tid == 0) {
     if (!fused_up) __threadfence();
     const unsigned ticket = atomicAdd(a.done, 1u);
     if (ticket == gridDim.x - 1) {
@@ -479,7 +419,7 @@ __global__ __launch_bounds__(kGruThreads) void srnn_gru_kernel(const SrnnGruArgs
           f32x4 wu[CPW];
           if constexpr (PB >= 0) {
 #pragma unroll
-            for (int u = 0; u < CPW; ++u) wu[u] = wu0[(!MULTI && (PB + j) < UB) ? (PB + j) : 0][u];
+            for (int u = 0; u < CPW; ++u) wu[u] = wu0[(PB + j) < UB ? (PB + j) : 0][u];
           } else {
             gf32x4_ptr wsrc = (gf32x4_ptr)(uintptr_t)a.ups_wp + ((int64_t)((jb + j) * KC + ub) * KC + c0) * 64 + lane;
 #pragma unroll
@@ -508,9 +448,6 @@ __global__ __launch_bounds__(kGruThreads) void srnn_gru_kernel(const SrnnGruArgs
           const float bias = (PB == 0 && nb == 1) ? ups_b[0] : ((PB == 1 && e < kGruThreads) ? ups_b[1] : (a.ups_bias ? a.ups_bias[col] : 0.f));
           const float o = v + bias;
           *dst = o;
-          if (a.up_gran)    // read by the resident bottom kernel
-            __hip_atomic_store(a.up_gran + (int64_t)(m_first + r) * a.ups_out_ld + col,
-                               ((unsigned long long)((unsigned)(t / a.fs) + 1u) << 32) | __float_as_uint(o), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
       }
       __syncthreads();
@@ -518,27 +455,15 @@ __global__ __launch_bounds__(kGruThreads) void srnn_gru_kernel(const SrnnGruArgs
 #ifndef MMK_SRNN_UP_ONE
 #define MMK_SRNN_UP_ONE 0      // all preloaded tiles as ONE batch (one reduction round instead of two; slot 0 goes out later, the launch ends sooner)
 #endif
-    if (MULTI) {      // every tile streamed: slot 0 on its own (the row the bottom kernel needs first), then the others
-      run_batch(std::integral_constant<int, -1>{}, 0, 1);
-      for (int jb = 1; jb < up_tiles; jb += UB) run_batch(std::integral_constant<int, -1>{}, jb, min(UB, up_tiles - jb));
+    if (MMK_SRNN_UP_ONE) {
+      run_batch(std::integral_constant<int, 0>{}, 0, min(up_tiles, UB));
     } else {
-      if (MMK_SRNN_UP_ONE) {
-        run_batch(std::integral_constant<int, 0>{}, 0, min(up_tiles, UB));
-      } else {
-        run_batch(std::integral_constant<int, 0>{}, 0, 1);
-        if (up_tiles > 1) run_batch(std::integral_constant<int, 1>{}, 1, min(up_tiles, UB) - 1);
-      }
-      for (int jb = UB; jb < up_tiles; jb += UB) run_batch(std::integral_constant<int, -1>{}, jb, min(UB, up_tiles - jb));
+      run_batch(std::integral_constant<int, 0>{}, 0, 1);
+      if (up_tiles > 1) run_batch(std::integral_constant<int, 1>{}, 1, min(up_tiles, UB) - 1);
     }
-    if (upd + 1 < n_updates) {      // the new rows of this workgroup's clips -> the LDS image the next update's products and cell read
-      float* hw = hs + (lane & 15) * ldx + c0 * 16 + 4 * (lane >> 4);
-#pragma unroll
-      for (int u = 0; u < CPW; ++u) *reinterpret_cast<f32x4*>(hw + u * 16) = hv[u];
-      __syncthreads();
-    }
+    for (int jb = UB; jb < up_tiles; jb += UB) run_batch(std::integral_constant<int, -1>{}, jb, min(UB, up_tiles - jb));
   }
   stamp(6);   // up-sampler
-  }   // (the updates of this launch)
   if (stamping) {
     for (int i = 0; i < 7; ++i) a.stamps[i] += st_acc[i];
     a.stamps[7] += 1;
@@ -571,14 +496,10 @@ int launch_srnn_gru(const SrnnGruArgs& a, hipStream_t stream) {
   const size_t lds = srnn_gru_lds_bytes(a.H, a.fs, lstm);
   dim3 grid((a.H / 16) * ((a.B + 15) / 16)), block(kGruThreads);
   if (a.ups_wp && !srnn_gru_grid_resident(a.H, a.B)) return fail(MMK_ERR_INVALID, "srnn tier kernel: fused up-sampler on a grid that is not resident at once");
-  if (a.n_updates > 1 && (!a.ups_wp || !a.gate_cls)) return fail(MMK_ERR_INVALID, "srnn tier kernel: several updates per launch need the fused up-sampler and the class granules");
-#define MMK_GRU(KC_)                                                                                    \
-  do {                                                                                                  \
-    if (a.n_updates > 1) {                                                                              \
-      if (lstm) hipLaunchKernelGGL((srnn_gru_kernel<KC_, true, true>), grid, block, lds, stream, a);    \
-      else hipLaunchKernelGGL((srnn_gru_kernel<KC_, false, true>), grid, block, lds, stream, a);        \
-    } else if (lstm) hipLaunchKernelGGL((srnn_gru_kernel<KC_, true, false>), grid, block, lds, stream, a); \
-    else hipLaunchKernelGGL((srnn_gru_kernel<KC_, false, false>), grid, block, lds, stream, a);         \
+#define MMK_GRU(KC_)                                                                              \
+  do {                                                                                            \
+    if (lstm) hipLaunchKernelGGL((srnn_gru_kernel<KC_, true>), grid, block, lds, stream, a);       \
+    else hipLaunchKernelGGL((srnn_gru_kernel<KC_, false>), grid, block, lds, stream, a);           \
   } while (0)
   switch (a.H) {
     case 128: MMK_GRU(8); break;

@@ -9,6 +9,7 @@
 #include "plan_util.h"
 #include "srnn_bottom.h"
 #include "srnn_gru.h"
+#include "srnn_resident.h"
 
 using namespace mmk;
 
@@ -25,7 +26,6 @@ struct SrnnCall {
   const float* uniforms = nullptr;
   int64_t uni_ld = 0;
   int64_t uni_off = 0;
-  bool gate = false;     // resident mode: the tier kernels poll the bottom kernel's class granules (run_resident)
 };
 
 // a stacked recurrent layer above the first one of a tier (n_rnn > 1): its input is the layer below's new state
@@ -53,6 +53,11 @@ struct SrnnTier {
   unsigned* done = nullptr;
   unsigned long long* h_gran = nullptr;               // [Bmax][H]: the new state as granules (fused up-sampler phase)
   float* v_comp = nullptr;                            // [G H][16]: W_ih W_in, zero padded (frame sizes <= 16; srnn_gru.hip composed mode)
+  // resident mode (srnn_resident.hip): the input half's matrix and constants composed at commit, the granule arrays of the block
+  float* v_full = nullptr;                            // [G H][fsp]: W_ih W_in for any frame size
+  float* gconst = nullptr;                            // [2][G H]: W_ih b_in + b_ih (LSTM: + b_hh) | GRU: b_hh
+  unsigned long long* rh_gran = nullptr;              // [2][Bmax][H]
+  unsigned long long* rout_gran = nullptr;            // [Bmax][up][H] (last recurrent tier: [Bmax][S][Hm])
 };
 
 struct mmk_srnn_plan {
@@ -75,14 +80,17 @@ struct mmk_srnn_plan {
   int64_t* tau = nullptr;
   hipStream_t cap_stream = nullptr;
   GraphCache gc;
-  // resident mode: the bottom tier as ONE launch per generate block on the caller's stream, the tier kernels of the block on
-  // side_stream; both sides meet through data-tagged granules (srnn_bottom.h)
-  hipStream_t side_stream = nullptr;
-  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-  bool streams_overlap = false;                 // probed at commit: kernels of the two streams do run side by side
+  // resident mode (srnn_resident.hip): ONE launch per generate block, every tier and the bottom tier resident with their weights in registers
   int64_t resident_blocks = 0;
-  unsigned long long *up_gran = nullptr, *cls_gran = nullptr;   // [Bmax][up of the last tier][H], [Bmax][256]
-  unsigned* probe = nullptr;
+  unsigned long long* cls_gran = nullptr;       // [Bmax][256]
+  unsigned long long* res_gran = nullptr;       // the tiers' granule arrays, one region (cleared at the start of every resident block)
+  int64_t res_gran_count = 0;
+  unsigned long long* res_stamps = nullptr;     // diagnostic build: phase totals per role
+  float* cp_wp = nullptr;                       // last recurrent tier: W0 W_up[slot] for the slots 1 .. S - 1, packed tiles (rpb rows per unit block)
+  float* cp0 = nullptr;                         // (Hm, H): W0 W_up[slot 0]
+  float* bcs = nullptr;                         // (S, Hm): W0 (b_up[slot] + bb) + b0
+  int cp_rpb = 0, cp_tiles = 0;
+  bool resident_ready = false;                  // every composed operand of the mode was built at commit
   // fused bottom tier (srnn_bottom.hip): chosen at create time when the geometry allows it
   bool fused_bottom = false;
   bool fused_gru = false;                       // srnn_gru.hip: input linear + both gate products + cell in one launch
@@ -106,6 +114,8 @@ struct mmk_srnn_plan {
       t.done = c.take<unsigned>(4);
       t.h_gran = c.take<unsigned long long>((int64_t)Bmax * H);
       t.v_comp = c.take<float>((int64_t)G * H * 16);
+      t.v_full = c.take<float>((int64_t)G * H * round_up(t.fs, 4));
+      t.gconst = c.take<float>((int64_t)2 * G * H);
       t.out = c.take<float>((int64_t)Bmax * t.up * H);
       for (auto& d : t.deep) {
         d.gates.carve(c, bias);
@@ -135,9 +145,34 @@ struct mmk_srnn_plan {
     logits_ld = (int)round_up(cfg.q_levels + (cfg.learn_temp ? 1 : 0), 4);
     logits = c.take<float>((int64_t)Bmax * logits_ld);
     tau = c.take<int64_t>(32);
-    up_gran = c.take<unsigned long long>((int64_t)Bmax * tiers.back().up * H);
     cls_gran = c.take<unsigned long long>((int64_t)Bmax * 256);
-    probe = reinterpret_cast<unsigned*>(tau + 24);
+    {
+      // the tiers' granule arrays of resident mode, one region: [2][Bmax][H] of new state per tier, then its rows for the tier below
+      // ([Bmax][up][H]; the last recurrent tier: [Bmax][S][mlp_hidden] rows composed with the head's first layer)
+      res_gran_count = 0;
+      for (size_t i = 0; i < tiers.size(); ++i) {
+        const bool last = i + 1 == tiers.size();
+        res_gran_count += (int64_t)2 * Bmax * H + (last ? (int64_t)Bmax * tiers[i].up * cfg.mlp_hidden : (int64_t)Bmax * tiers[i].up * H);
+      }
+      res_gran = c.take<unsigned long long>(res_gran_count);
+      unsigned long long* at = res_gran;
+      for (size_t i = 0; i < tiers.size(); ++i) {
+        const bool last = i + 1 == tiers.size();
+        tiers[i].rh_gran = at;
+        if (at) at += (int64_t)2 * Bmax * H;
+        tiers[i].rout_gran = at;
+        if (at) at += last ? (int64_t)Bmax * tiers[i].up * cfg.mlp_hidden : (int64_t)Bmax * tiers[i].up * H;
+      }
+    }
+    res_stamps = c.take<unsigned long long>(8 * (1 + kResMaxTiers));
+    {
+      const int S = tiers.back().up, KC = (H + 15) / 16;
+      cp_rpb = ((S - 1) * cfg.mlp_hidden + KC - 1) / KC;
+      cp_tiles = (cp_rpb + 15) / 16;
+      cp_wp = c.take<float>((int64_t)KC * cp_tiles * KC * 256);
+      cp0 = c.take<float>((int64_t)cfg.mlp_hidden * H);
+      bcs = c.take<float>((int64_t)S * cfg.mlp_hidden);
+    }
     a_comp = c.take<float>((int64_t)cfg.frame_size[cfg.n_tiers - 1] * cfg.mlp_hidden);
     b_comp = c.take<float>(cfg.mlp_hidden);
     wb_raw = c.take<float>((int64_t)H * cfg.frame_size[cfg.n_tiers - 1]);
@@ -258,9 +293,6 @@ extern "C" void mmk_srnn_plan_destroy(mmk_srnn_plan* p) {
   if (!p) return;
   p->gc.reset();
   if (p->cap_stream) (void)hipStreamDestroy(p->cap_stream);
-  if (p->side_stream) (void)hipStreamDestroy(p->side_stream);
-  if (p->ev_fork) (void)hipEventDestroy(p->ev_fork);
-  if (p->ev_join) (void)hipEventDestroy(p->ev_join);
   delete p;
 }
 
@@ -276,8 +308,6 @@ extern "C" size_t mmk_srnn_workspace_bytes(const mmk_srnn_plan* p) {
   mmk_srnn_plan tmp = *p;
   tmp.gc = GraphCache();
   tmp.cap_stream = nullptr;
-  tmp.side_stream = nullptr;
-  tmp.ev_fork = tmp.ev_join = nullptr;
   Carver c(nullptr);
   tmp.layout(c);
   return c.used();
@@ -328,12 +358,62 @@ __global__ void srnn_compose_bottom_kernel(const float* __restrict__ w0, const f
   }
 }
 
-// ---- resident mode helpers ---------------------------------------------------------------------------------------------
-// Start of a resident block at step t_begin: the class ring holds the 256 positions before it, the row granules are cleared
-// (a granule of an earlier generation could carry the epoch this one waits for) - or, when the block starts between two
-// updates of the tier above, rebuilt from that tier's float rows with the epoch of its last update
-__global__ void srnn_resident_init_kernel(unsigned long long* cls_gran, unsigned long long* up_gran, const int64_t* idx, int64_t idx_rs,
-                                          const float* up_out, int B, int64_t n_up, int64_t t_begin, int up_slots) {
+// ---- resident mode (srnn_resident.hip): operands composed at commit, fp64 accumulation, rounded once -----------------------------
+// V[r][i] = sum_k W_ih[r][k] W_in[k][i] for any frame size (rows of fsp = fs rounded up to 4, zero padded)
+__global__ void srnn_compose_v_kernel(const float* __restrict__ wih, const float* __restrict__ win, int rows, int H, int fs, int fsp, float* __restrict__ V) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= (int64_t)rows * fsp) return;
+  const int r = (int)(e / fsp), i = (int)(e - (int64_t)r * fsp);
+  double acc = 0.0;
+  if (i < fs)
+    for (int k = 0; k < H; ++k) acc += (double)wih[(int64_t)r * H + k] * (double)win[(int64_t)k * fs + i];
+  V[e] = (float)acc;
+}
+// gc[r] = sum_k W_ih[r][k] b_in[k] + b_ih[r] (+ b_hh[r] when `sum_hh`: the LSTM cell adds both), gc[rows + r] = b_hh[r] otherwise (the GRU cell
+// keeps the recurrent bias inside r (W_hn h + b_hn)); null biases count as zero
+__global__ void srnn_compose_gconst_kernel(const float* __restrict__ wih, const float* __restrict__ bin, const float* __restrict__ bih,
+                                           const float* __restrict__ bhh, int rows, int H, int sum_hh, float* __restrict__ gc) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= rows) return;
+  double acc = 0.0;
+  for (int k = 0; k < H; ++k) acc += (double)wih[(int64_t)r * H + k] * (double)bin[k];
+  if (bih) acc += (double)bih[r];
+  if (sum_hh && bhh) acc += (double)bhh[r];
+  gc[r] = (float)acc;
+  gc[rows + r] = (!sum_hh && bhh) ? bhh[r] : 0.f;
+}
+// The head's first layer through the last recurrent tier's up-sampler: C[j][u][k] = sum_m W0[u][m] W_up[j H + m][k].  Slot 0 goes out row-major
+// (Hm, H) - the clip's own workgroup multiplies it -, the slots 1 .. S - 1 as packed MFMA tiles (linear.hip's order) of `rpb` rows per unit
+// block: row g = (j - 1) Hm + u sits in unit block g / rpb at row g % rpb of that block's `tiles` tiles.
+__global__ void srnn_compose_cp_kernel(const float* __restrict__ w0, const float* __restrict__ wup, int Hm, int H, int S, int rpb, int tiles,
+                                       float* __restrict__ cp0, float* __restrict__ cp_wp) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= (int64_t)S * Hm * H) return;
+  const int k = (int)(e % H);
+  const int64_t ju = e / H;
+  const int u = (int)(ju % Hm), j = (int)(ju / Hm);
+  double acc = 0.0;
+  for (int m = 0; m < H; ++m) acc += (double)w0[(int64_t)u * H + m] * (double)wup[((int64_t)j * H + m) * H + k];
+  if (j == 0) {
+    cp0[(int64_t)u * H + k] = (float)acc;
+    return;
+  }
+  const int g = (j - 1) * Hm + u, ub = g / rpb, r = g - ub * rpb;
+  const int KC = H / 16, prow = ub * tiles * 16 + r, tile = prow >> 4, rin = prow & 15, c = k >> 4, k16 = k & 15;
+  cp_wp[((((int64_t)tile * KC + c) * 64) + (k16 >> 2) * 16 + rin) * 4 + (k16 & 3)] = (float)acc;
+}
+// bcs[j][u] = sum_m W0[u][m] (b_up[j H + m] + bb[m]) + b0[u]
+__global__ void srnn_compose_bcs_kernel(const float* __restrict__ w0, const float* __restrict__ b0, const float* __restrict__ bup,
+                                        const float* __restrict__ bb, int Hm, int H, int S, float* __restrict__ bcs) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= S * Hm) return;
+  const int j = e / Hm, u = e - j * Hm;
+  double acc = 0.0;
+  for (int m = 0; m < H; ++m) acc += (double)w0[(int64_t)u * H + m] * ((double)bup[(int64_t)j * H + m] + (double)bb[m]);
+  bcs[e] = (float)(acc + (double)b0[u]);
+}
+// Start of a resident block at step t_begin: the class ring holds the 256 positions before it
+__global__ void srnn_resident_init_kernel(unsigned long long* cls_gran, const int64_t* idx, int64_t idx_rs, int B, int64_t t_begin) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < (int64_t)B * 256) {
     const int c = (int)(i >> 8), slot = (int)(i & 255);
@@ -341,40 +421,6 @@ __global__ void srnn_resident_init_kernel(unsigned long long* cls_gran, unsigned
     if (pos >= t_begin) pos -= 256;
     cls_gran[i] = pos >= 0 ? (((unsigned long long)(unsigned)(pos + 1) << 32) | (unsigned)idx[(int64_t)c * idx_rs + pos]) : 0ull;
   }
-  if (i < (int64_t)B * n_up) {
-    unsigned long long g = 0;
-    if (t_begin % up_slots != 0) g = ((unsigned long long)((unsigned)(t_begin / up_slots) + 1u) << 32) | __float_as_uint(up_out[i]);
-    up_gran[i] = g;
-  }
-}
-
-// Do kernels of two streams run side by side here?  A waits (bounded) for a word that only B writes; launched A first.
-__global__ void srnn_probe_wait_kernel(unsigned* flags) {
-  unsigned spins = 0;
-  while (__hip_atomic_load(flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
-    if (++spins > (1u << 17)) {
-      __hip_atomic_store(flags + 1, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      return;
-    }
-    __builtin_amdgcn_s_sleep(8);
-  }
-  __hip_atomic_store(flags + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__global__ void srnn_probe_post_kernel(unsigned* flags) { __hip_atomic_store(flags, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-
-static int probe_stream_overlap(mmk_srnn_plan* p, hipStream_t st) {
-  unsigned* flags = p->probe;
-  MMK_HIP(hipMemsetAsync(flags, 0, 2 * sizeof(unsigned), st));
-  MMK_HIP(hipStreamSynchronize(st));
-  hipLaunchKernelGGL(srnn_probe_wait_kernel, dim3(1), dim3(1), 0, st, flags);
-  hipLaunchKernelGGL(srnn_probe_post_kernel, dim3(1), dim3(1), 0, p->side_stream, flags);
-  MMK_HIP(hipGetLastError());
-  MMK_HIP(hipStreamSynchronize(p->side_stream));
-  MMK_HIP(hipStreamSynchronize(st));
-  unsigned out[2] = {0, 0};
-  MMK_HIP(hipMemcpy(out, flags, sizeof(out), hipMemcpyDeviceToHost));
-  p->streams_overlap = out[1] == 1u;
-  return MMK_OK;
 }
 
 extern "C" int mmk_srnn_reset(mmk_srnn_plan* p, mmk_stream_t stream) {
@@ -387,8 +433,8 @@ extern "C" int mmk_srnn_reset(mmk_srnn_plan* p, mmk_stream_t stream) {
     MMK_HIP(hipStreamSynchronize(st));
     if (err != 0) {
       MMK_HIP(hipMemsetAsync(p->tau + 4, 0, sizeof(int64_t), st));
-      return fail(MMK_ERR_STATE, "srnn: a wait inside the tier / bottom kernels timed out during the previous generation (code %lld: 3 grid barrier, "
-                  "4 bottom kernel waiting for the tiers, 5 tier kernel waiting for the bottom kernel; MMK_SRNN_RESIDENT=0 runs the tiers and the bottom in turns)", (long long)err);
+      return fail(MMK_ERR_STATE, "srnn: a wait inside the tier / bottom kernels timed out during the previous generation (code %lld: 3 grid barrier of the tier kernel, "
+                  "6 bottom role / 7 tier role of the resident kernel; MMK_SRNN_RESIDENT=0 runs the tiers and the bottom in turns)", (long long)err);
     }
   }
   for (auto& t : p->tiers) {
@@ -448,6 +494,8 @@ extern "C" int mmk_srnn_commit(mmk_srnn_plan* p, void* workspace, size_t workspa
   b.clear_missing();
   const int H = p->H, G = p->G;
   const bool bias = c.rnn_bias != 0;
+  const float *last_wu = nullptr, *last_bu = nullptr;      // the last recurrent tier's up-sampler as bound (composed with the head below)
+  p->resident_ready = false;
   for (int i = 0; i < p->n_rnn_tiers; ++i) {
     SrnnTier& t = p->tiers[i];
     const std::string tb = "tiers." + std::to_string(i) + ".";
@@ -470,6 +518,13 @@ extern "C" int mmk_srnn_commit(mmk_srnn_plan* p, void* workspace, size_t workspa
     }
     const float* bih = bias ? b.need(tb + "rnn.bias_ih_l0", (int64_t)G * H) : nullptr;
     const float* bhh = bias ? b.need(tb + "rnn.bias_hh_l0", (int64_t)G * H) : nullptr;
+    if (wih && w && bb && p->fused_gru && (!bias || (bih && bhh))) {   // resident mode: the input half of the gates without its input Linear
+      const int fsp = (int)round_up(t.fs, 4);
+      hipLaunchKernelGGL(srnn_compose_v_kernel, dim3((unsigned)(((int64_t)G * H * fsp + 255) / 256)), dim3(256), 0, st, wih, w, G * H, H, t.fs, fsp, t.v_full);
+      hipLaunchKernelGGL(srnn_compose_gconst_kernel, dim3((unsigned)((G * H + 255) / 256)), dim3(256), 0, st, wih, bb, bih, bhh, G * H, H,
+                         c.rnn_kind == 0 ? 1 : 0, t.gconst);
+      MMK_HIP(hipGetLastError());
+    }
     if (c.rnn_kind == 1) {
       if (wih) MMK_TRY(pack_rect(t.gates.Wp, t.gates.k_chunks, 0, 1, G * H, 0, H, wih, H, 1, st));
       if (whh) MMK_TRY(pack_rect(t.gates_hh.Wp, t.gates_hh.k_chunks, 0, 1, G * H, 0, H, whh, H, 1, st));
@@ -504,6 +559,7 @@ extern "C" int mmk_srnn_commit(mmk_srnn_plan* p, void* workspace, size_t workspa
     const float* bu = b.need(tb + "up_sampler.fc.bias", (int64_t)H * t.up);
     if (wu) MMK_TRY(pack_rect(t.up_lin.Wp, t.up_lin.k_chunks, 0, 1, H * t.up, 0, H, wu, H, 1, st));
     if (bu) MMK_TRY(pack_bias(t.up_lin.bias, 0, 1, H * t.up, bu, 0, st));
+    if (i == p->n_rnn_tiers - 1) { last_wu = wu; last_bu = bu; }
   }
   {
     // bottom tier: FramedConv1dIO -> heads.0 = Sequential(Linearizer, Unfold, Sequential(Flatten, Unsqueeze, Conv1dResampler))
@@ -534,6 +590,15 @@ extern "C" int mmk_srnn_commit(mmk_srnn_plan* p, void* workspace, size_t workspa
                          H, fsl, p->a_comp, p->b_comp);
       MMK_HIP(hipGetLastError());
       p->bottom_composed = true;
+      if (p->fused_gru && last_wu && last_bu) {
+        // resident mode: the head's first layer through the last recurrent tier's up-sampler (srnn_resident.hip)
+        const int S = p->tiers.back().up, Hm = m.N;
+        hipLaunchKernelGGL(srnn_compose_cp_kernel, dim3((unsigned)(((int64_t)S * Hm * H + 255) / 256)), dim3(256), 0, st, w, last_wu, Hm, H, S,
+                           p->cp_rpb, p->cp_tiles, p->cp0, p->cp_wp);
+        hipLaunchKernelGGL(srnn_compose_bcs_kernel, dim3((S * Hm + 255) / 256), dim3(256), 0, st, w, bb, last_bu, p->bb_raw, Hm, H, S, p->bcs);
+        MMK_HIP(hipGetLastError());
+        p->resident_ready = true;
+      }
     }
   }
   for (size_t k = 0; k < p->xheads.size(); ++k) {
@@ -550,10 +615,6 @@ extern "C" int mmk_srnn_commit(mmk_srnn_plan* p, void* workspace, size_t workspa
   if (!b.missing().empty()) return fail(MMK_ERR_KEY, "srnn_commit: state_dict tensor %s", b.missing().c_str());
   if (!p->cap_stream) MMK_HIP(hipStreamCreateWithFlags(&p->cap_stream, hipStreamNonBlocking));
   MMK_HIP(hipMemsetAsync(p->tau, 0, 32 * sizeof(int64_t), st));     // position counter, error word, diagnostic stamps
-  if (!p->side_stream) MMK_HIP(hipStreamCreateWithFlags(&p->side_stream, hipStreamNonBlocking));
-  if (!p->ev_fork) MMK_HIP(hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming));
-  if (!p->ev_join) MMK_HIP(hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming));
-  if (p->fused_bottom && p->fused_gru) MMK_TRY(probe_stream_overlap(p, st));
   p->committed = true;
   return mmk_srnn_reset(p, stream);
 }
@@ -588,31 +649,14 @@ static SrnnBottomArgs bottom_args(mmk_srnn_plan* p, const SrnnCall& call, int64_
 // enqueue step t = *tau + tau_off, whose residue modulo frame_sizes[0] is `phase`
 // bottom_steps: 0 = no bottom tier here (warm-up, or covered by an earlier fused launch), 1 = this step,
 // > 1 = this and the following steps in one fused launch (no tier above fires inside the range)
-// steps_left: steps of the enqueued range from this one on (>= 1); covered: steps (from this one on) whose updates of the last tier an
-// earlier launch of the range has taken already (in / out)
-static int emit_step(mmk_srnn_plan* p, const SrnnCall& call, int64_t tau_off, int phase, int bottom_steps, hipStream_t st, int64_t steps_left = 1,
-                     int64_t* covered = nullptr) {
+static int emit_step(mmk_srnn_plan* p, const SrnnCall& call, int64_t tau_off, int phase, int bottom_steps, hipStream_t st) {
   const mmk_srnn_config& c = p->cfg;
   const int H = p->H, G = p->G, M = call.M;
   for (int i = 0; i < p->n_rnn_tiers; ++i) {
     SrnnTier& t = p->tiers[i];
     if (phase % t.fs != 0) continue;  // `if t % fs[i] == 0`, sample_rnn_v2.py:246
-    // Resident mode, the tier that feeds the bottom kernel (which runs beside this stream and hands the classes over as granules): ALL its
-    // updates up to the next update of the tier above in ONE launch (srnn_gru.hip: the gate matrices loaded once) - launched where the tier
-    // above updates, or where the enqueued range begins
-    int n_updates = 1;
-    // (measured on cfg 3 and NOT the default, tuning MMK_SRNN_MULTI_UPDATE=1: 112 - 118 ms per pass against 97 with one launch per update - the
-    //  kernel then keeps W_hh through the up-sampler phase, whose tiles it has to stream, and spills 48 address registers)
-    if (p->fused_gru && call.gate && i == p->n_rnn_tiers - 1 && i > 0 && p->tune.get("MMK_SRNN_MULTI_UPDATE") && p->tune.get("MMK_SRNN_MULTI_UPDATE")[0] == '1') {
-      const int parent = p->tiers[i - 1].fs;
-      if (covered && *covered > 0) continue;                          // taken by the launch at the parent's update (or at the range's first update)
-      const int64_t to_parent = (parent - phase % parent) / t.fs, in_range = (steps_left + t.fs - 1) / t.fs;
-      n_updates = (int)(to_parent < in_range ? to_parent : in_range);
-      if (covered) *covered = (int64_t)n_updates * t.fs;
-    }
     if (p->fused_gru) {
       SrnnGruArgs g = {};
-      g.n_updates = n_updates;
       g.B = M; g.H = H; g.fs = t.fs; g.div = t.fs; g.class_size = (float)c.q_levels;
       g.tau_ptr = p->tau; g.tau_off = tau_off;
       g.idx = call.idx; g.idx_rs = call.idx_rs; g.shift = call.shift;
@@ -647,12 +691,6 @@ static int emit_step(mmk_srnn_plan* p, const SrnnCall& call, int64_t tau_off, in
         g.ups_wp = t.up_lin.Wp; g.ups_bias = t.up_lin.bias; g.ups_n_tiles = t.up_lin.n_tiles; g.ups_n = t.up_lin.N;
         g.ups_out = t.out; g.ups_out_ld = (int64_t)t.up * H;
         g.err = reinterpret_cast<int*>(p->tau + 4);      // sticky word, read by the next mmk_srnn_reset
-        if (call.gate) {
-          g.gate_cls = p->cls_gran;
-          if (i == p->n_rnn_tiers - 1) g.up_gran = p->up_gran;
-        }
-      } else if (call.gate) {
-        return fail(MMK_ERR_STATE, "srnn: resident mode without the fused up-sampler");
       }
       MMK_TRY(launch_srnn_gru(g, st));
       if (fused_up) continue;
@@ -829,7 +867,6 @@ static int emit_range(mmk_srnn_plan* p, const SrnnCall& call, int64_t first, int
   const int period = p->cfg.frame_size[0];
   const int slots = p->tiers[p->n_rnn_tiers - 1].up;          // frame_sizes[-2]
   int64_t covered = 0;                                        // bottom steps already inside a fused launch
-  int64_t tier_covered = 0;                                   // steps whose last-tier updates a multi-update launch has taken
   for (int64_t s = 0; s < count; ++s) {
     const int ph = (int)((phase + s) % period);
     int bottom = 0;
@@ -842,17 +879,15 @@ static int emit_range(mmk_srnn_plan* p, const SrnnCall& call, int64_t first, int
         covered = bottom;
       }
     }
-    MMK_TRY(emit_step(p, call, first + s, ph, bottom, st, count - s, &tier_covered));
-    if (tier_covered > 0) --tier_covered;
+    MMK_TRY(emit_step(p, call, first + s, ph, bottom, st));
     if (covered > 0) --covered;
   }
   return MMK_OK;
 }
 
 // The graph of one period (frame_sizes[0] steps from residue phase0) for this call, captured when the cached one is another;
-// `st` / `also_sync`: streams replays of the old graph may still be queued on
-static int prepare_period_graph(mmk_srnn_plan* p, const SrnnCall& call, int64_t t_begin, int64_t n, bool with_bottom, hipStream_t st,
-                                hipStream_t also_sync) {
+// `st`: the stream replays of the old graph may still be queued on
+static int prepare_period_graph(mmk_srnn_plan* p, const SrnnCall& call, int64_t t_begin, int64_t n, bool with_bottom, hipStream_t st) {
   const int period = p->cfg.frame_size[0];
   if (n < 2 * period) return MMK_OK;
   const int phase0 = (int)(t_begin % period);
@@ -860,14 +895,13 @@ static int prepare_period_graph(mmk_srnn_plan* p, const SrnnCall& call, int64_t 
   const int periods = n >= 16 * (int64_t)period ? 4 : 1;
   std::vector<int64_t> key = {call.M, (int64_t)(uintptr_t)call.idx, call.idx_rs, call.shift, with_bottom ? 1 : 0,
                               (int64_t)(uintptr_t)call.temperature, (int64_t)(uintptr_t)call.uniforms, call.uni_ld,
-                              call.uni_off, phase0, call.gate ? 1 : 0, periods};
+                              call.uni_off, phase0, periods};
   for (int m = 1; m < p->n_in; ++m) {
     key.push_back((int64_t)(uintptr_t)call.xidx[m]);
     key.push_back(call.xidx_rs[m]);
   }
   if (p->gc.exec && p->gc.key == key) return MMK_OK;
   MMK_HIP(hipStreamSynchronize(st));
-  if (also_sync) MMK_HIP(hipStreamSynchronize(also_sync));
   p->gc.reset();
   MMK_HIP(hipStreamBeginCapture(p->cap_stream, hipStreamCaptureModeThreadLocal));
   int rc = emit_range(p, call, 0, (int64_t)period * periods, phase0, with_bottom, p->cap_stream);
@@ -902,58 +936,99 @@ static int enqueue_steps(mmk_srnn_plan* p, const SrnnCall& call, int64_t t_begin
   return MMK_OK;
 }
 
-// Resident mode applies when both fused kernels do, the two streams were seen to overlap, every tier's grid plus one
-// workgroup per clip fit the chip together, and the block is long enough to be worth a fork / join (MMK_SRNN_RESIDENT=0: never)
-static bool resident_applies(mmk_srnn_plan* p, const SrnnCall& call, int64_t n) {
+// Resident mode (srnn_resident.hip: ONE launch per block, every tier resident) applies when the fused kernels' geometry does, the composed
+// operands were built at commit, every workgroup of the launch has a CU of its own, and the block - from the next multiple of frame_sizes[0] on,
+// where every tier updates - is at least one period long (MMK_SRNN_RESIDENT=0, or exec_mode 1 - the caller's redo path -: never)
+static int resident_grid(mmk_srnn_plan* p, const SrnnCall& call, int64_t n_res, int* mt) {
+  const mmk_srnn_config& c = p->cfg;
   const char* renv = p->tune.get("MMK_SRNN_RESIDENT");
-  const char* uenv = p->tune.get("MMK_SRNN_FUSED_UP");
-  const bool off = (renv && renv[0] == '0') || p->cfg.exec_mode == 1, up_off = uenv && uenv[0] == '0';     // (exec_mode 1: the caller asks for the kernels in turns)
-  static const int n_cu = [] {
-    int dev = 0, v = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
-    return v;
-  }();
-  if (off || up_off || !p->streams_overlap || !p->fused_bottom || !p->fused_gru || n < p->cfg.frame_size[0]) return false;
-  if (!srnn_gru_grid_resident(p->H, call.M)) return false;
-  const int tier_grid = (p->H / 16) * ((call.M + 15) / 16);
-  if (tier_grid + call.M > n_cu) return false;
-  return srnn_bottom_resident_supported(bottom_args(p, call, 0, n));
+  if ((renv && renv[0] == '0') || c.exec_mode == 1) return 0;
+  if (!p->fused_bottom || !p->fused_gru || !p->resident_ready || n_res < c.frame_size[0]) return 0;
+  const int S = p->tiers.back().up;
+  if (S < 2 || !srnn_resident_supported(p->H, c.rnn_kind == 0, c.mlp_hidden, c.q_levels + (c.learn_temp ? 1 : 0), c.q_levels, c.frame_size[c.n_tiers - 1], S)) return 0;
+  for (auto& t : p->tiers)
+    if (t.fs > 128) return 0;                                 // the class ring holds 256 positions
+  return srnn_resident_grid(p->H, call.M, p->n_rnn_tiers, mt);
 }
 
-static int run_resident(mmk_srnn_plan* p, const SrnnCall& call, int64_t t_begin, int64_t n, hipStream_t st) {
-  SrnnCall tiers = call;
-  tiers.gate = true;
-  // (before the bottom kernel is queued: a capture synchronises the streams, and that kernel only ends with the tiers' help)
-  MMK_TRY(prepare_period_graph(p, tiers, t_begin, n, false, st, p->side_stream));
-  MMK_TRY(launch_set_i64(p->tau, t_begin, st));
-  {
-    SrnnTier& last = p->tiers[p->n_rnn_tiers - 1];
-    const int64_t n_up = (int64_t)last.up * p->H;
-    const int64_t n_el = (int64_t)call.M * (n_up > 256 ? n_up : 256);
-    hipLaunchKernelGGL(srnn_resident_init_kernel, dim3((unsigned)((n_el + 255) / 256)), dim3(256), 0, st, p->cls_gran, p->up_gran, call.idx,
-                       call.idx_rs, last.out, call.M, n_up, t_begin, last.up);
-    MMK_HIP(hipGetLastError());
+static int run_resident(mmk_srnn_plan* p, const SrnnCall& call, int64_t t_begin, int64_t n, int mt, hipStream_t st) {
+  const mmk_srnn_config& c = p->cfg;
+  const int H = p->H, G = p->G, KC = H / 16, M = call.M;
+  MMK_HIP(hipMemsetAsync(p->res_gran, 0, (size_t)p->res_gran_count * sizeof(unsigned long long), st));   // (a granule of an earlier block could carry the number this one waits for)
+  hipLaunchKernelGGL(srnn_resident_init_kernel, dim3((unsigned)(((int64_t)M * 256 + 255) / 256)), dim3(256), 0, st, p->cls_gran, call.idx, call.idx_rs, M, t_begin);
+  MMK_HIP(hipGetLastError());
+  SrnnResArgs a = {};
+  a.B = M; a.H = H; a.n_tiers = p->n_rnn_tiers; a.lstm = c.rnn_kind == 0 ? 1 : 0;
+  a.n_steps = (int32_t)n; a.t_begin = t_begin; a.class_size = (float)c.q_levels;
+  int block0 = M;
+  for (int i = 0; i < p->n_rnn_tiers; ++i) {
+    SrnnTier& t = p->tiers[i];
+    SrnnResTier& r = a.tier[i];
+    const bool last = i == p->n_rnn_tiers - 1;
+    r.fs = t.fs; r.up = t.up; r.up_mod = i > 0 ? p->tiers[i - 1].up : 0;
+    r.n_tiles = last ? p->cp_tiles : t.up; r.rpb = last ? p->cp_rpb : 0;
+    r.block0 = block0;
+    block0 += KC * ((M + 16 * mt - 1) / (16 * mt));
+    r.fsp = (int32_t)round_up(t.fs, 4);
+    if (c.rnn_kind == 1) {
+      r.wih_wp = t.gates.Wp; r.whh_wp = t.gates_hh.Wp; r.w_tile_chunks = t.gates.k_chunks;
+    } else {   // LSTM: one packed matrix, K = [x | h]
+      r.wih_wp = t.gates.Wp; r.whh_wp = t.gates.Wp + (int64_t)t.gates.seg_chunk0[1] * 256; r.w_tile_chunks = t.gates.k_chunks;
+    }
+    r.gconst = t.gconst; r.v_full = t.v_full;
+    r.out_wp = last ? p->cp_wp : t.up_lin.Wp; r.out_bias = last ? nullptr : t.up_lin.bias;
+    r.h_ring = t.h; r.h_slot_stride = (int64_t)p->Bmax * H; r.c = t.c; r.cnt = t.cnt;
+    r.out_rows = last ? nullptr : t.out;
+    r.h_gran = t.rh_gran; r.out_gran = t.rout_gran;
+    r.upper_gran = i > 0 ? p->tiers[i - 1].rout_gran : nullptr;
   }
-  MMK_HIP(hipEventRecord(p->ev_fork, st));
-  MMK_HIP(hipStreamWaitEvent(p->side_stream, p->ev_fork, 0));
-  SrnnBottomArgs a = bottom_args(p, call, 0, n);
-  a.resident = 1;
-  a.t_first = t_begin;
-  a.up_gran = p->up_gran;
+  (void)G;
+  a.Hm = c.mlp_hidden; a.Q = c.q_levels; a.n_out = c.q_levels + (c.learn_temp ? 1 : 0); a.learn_temp = c.learn_temp; a.min_temp = c.min_temp;
+  a.fsb = c.frame_size[c.n_tiers - 1]; a.S = p->tiers.back().up;
+  a.idx = const_cast<int64_t*>(call.idx); a.idx_rs = call.idx_rs;
+  a.cp0 = p->cp0; a.a_comp = p->a_comp; a.bcs = p->bcs;
+  a.fc2_raw = p->mlp_raw[1]; a.fc2_bias = p->mlp[1].bias;
+  a.temperature = call.temperature; a.uniforms = call.uniforms; a.uni_ld = call.uni_ld; a.uni_off = call.uni_off;
+  a.logits_out = p->logits; a.logits_ld = p->logits_ld;
   a.cls_gran = p->cls_gran;
   a.err = reinterpret_cast<int*>(p->tau + 4);
-  MMK_TRY(launch_srnn_bottom(a, st));
-  MMK_TRY(enqueue_steps(p, tiers, t_begin, n, false, p->side_stream));
-  MMK_HIP(hipEventRecord(p->ev_join, p->side_stream));
-  MMK_HIP(hipStreamWaitEvent(st, p->ev_join, 0));
+  {
+    const char* senv = diag_only("MMK_SRNN_STAMPS");
+    a.stamps = (senv && senv[0] == '1') ? p->res_stamps : nullptr;
+  }
+  MMK_TRY(launch_srnn_resident(a, mt, st));
+  {
+    // the last recurrent tier's up-sampler never ran inside the launch (its rows reach the bottom tier composed with the head's first layer): once,
+    // on the state the launch left, for whoever continues between two of that tier's updates
+    SrnnTier& t = p->tiers.back();
+    LinearArgs u = {};
+    t.up_lin.fill(u);
+    u.seg[0].x = addr_time(t.h, (int64_t)p->Bmax * H, 0, 1, 2); u.seg[0].ld = H;
+    u.M = M; u.tau_ptr = t.cnt; u.tau_off = 0;
+    u.epilogue = EPI_STORE; u.act = ACT_NONE;
+    u.out = addr_static(t.out); u.out_ld = (int64_t)t.up * H;
+    MMK_TRY(launch_linear(u, st));
+  }
   ++p->resident_blocks;
   return MMK_OK;
 }
 
 static int run_steps(mmk_srnn_plan* p, const SrnnCall& call, int64_t t_begin, int64_t n, bool with_bottom, hipStream_t st) {
   if (n <= 0) return MMK_OK;
-  if (with_bottom && resident_applies(p, call, n)) return run_resident(p, call, t_begin, n, st);
-  MMK_TRY(prepare_period_graph(p, call, t_begin, n, with_bottom, st, p->side_stream));
+  if (with_bottom) {
+    const int period = p->cfg.frame_size[0];
+    const int64_t head = (period - t_begin % period) % period;      // steps up to the next update of the top tier, run with the kernels in turns
+    int mt = 1;
+    if (n > head && resident_grid(p, call, n - head, &mt) > 0) {
+      if (head > 0) {
+        MMK_TRY(launch_set_i64(p->tau, t_begin, st));
+        MMK_TRY(emit_range(p, call, 0, head, (int)(t_begin % period), true, st));
+      }
+      MMK_TRY(run_resident(p, call, t_begin + head, n - head, mt, st));
+      return launch_set_i64(p->tau, t_begin + n, st);
+    }
+  }
+  MMK_TRY(prepare_period_graph(p, call, t_begin, n, with_bottom, st));
   MMK_TRY(launch_set_i64(p->tau, t_begin, st));
   return enqueue_steps(p, call, t_begin, n, with_bottom, st);
 }
@@ -1031,8 +1106,8 @@ extern "C" int mmk_srnn_sync_status(mmk_srnn_plan* p, mmk_stream_t stream) {
   MMK_HIP(hipMemcpy(&err, p->tau + 4, sizeof(err), hipMemcpyDeviceToHost));
   if (err != 0) {
     MMK_HIP(hipMemset(p->tau + 4, 0, sizeof(int64_t)));
-    return fail(MMK_ERR_STATE, "srnn: a wait inside the tier / bottom kernels timed out (code %lld: 3 tier hand-over, 4 bottom kernel waiting for the tiers, "
-                "5 tier kernel waiting for the bottom kernel) - the kernels were not running side by side; the samples of this generation are invalid",
+    return fail(MMK_ERR_STATE, "srnn: a wait inside the tier / bottom kernels timed out (code %lld: 3 tier hand-over, 6 bottom role / 7 tier role of the resident kernel) - "
+                "its workgroups were not all running side by side; the samples of this generation are invalid",
                 (long long)err);
   }
   return MMK_OK;
@@ -1051,6 +1126,24 @@ extern "C" int mmk_srnn_last_logits(mmk_srnn_plan* p, int32_t batch, float* out,
     fprintf(stderr, "[mmk stamps] srnn bottom kernel, workgroup 0, us per launch over %llu launches: prologue=%.2f x=%.2f fc0=%.2f fc2=%.2f sampler=%.2f; shader clock %.0f MHz\n",
             st[7], st[0] * 1e-2 / n, st[1] * 1e-2 / n, st[2] * 1e-2 / n, st[3] * 1e-2 / n, st[4] * 1e-2 / n,
             st[6] ? 100.0 * (double)st[5] / (double)st[6] : 0.0);
+    {
+      unsigned long long rs[8 * (1 + kResMaxTiers)];
+      MMK_HIP(hipMemcpy(rs, p->res_stamps, sizeof(rs), hipMemcpyDeviceToHost));
+      if (rs[7]) {
+        const double nb = (double)rs[7];
+        fprintf(stderr, "[mmk stamps] srnn resident kernel, bottom role of clip 0, us per step over %llu steps: prologue(total)=%.2f wait for the state row=%.3f "
+                "slot-0 product / wait for the composed row=%.3f hidden=%.3f fc2=%.3f draw=%.3f\n", rs[7], rs[0] * 1e-2, rs[1] * 1e-2 / nb, rs[2] * 1e-2 / nb,
+                rs[3] * 1e-2 / nb, rs[4] * 1e-2 / nb, rs[5] * 1e-2 / nb);
+        for (int i = 0; i < p->n_rnn_tiers; ++i) {
+          const unsigned long long* r = rs + 8 * (1 + i);
+          const double nu = r[7] ? (double)r[7] : 1.0;
+          fprintf(stderr, "[mmk stamps] srnn resident kernel, tier %d workgroup 0, us per update over %llu updates: gate products (+ wait for the row above)=%.2f "
+                  "window (wait for the classes)=%.2f cell=%.2f all-gather=%.2f output tiles=%.2f\n", i, r[7], r[0] * 1e-2 / nu, r[1] * 1e-2 / nu, r[2] * 1e-2 / nu,
+                  r[3] * 1e-2 / nu, r[4] * 1e-2 / nu);
+        }
+        MMK_HIP(hipMemset(p->res_stamps, 0, sizeof(rs)));
+      }
+    }
     MMK_HIP(hipMemcpy(st, p->tau + 16, sizeof(st), hipMemcpyDeviceToHost));
     const double ng = st[7] ? (double)st[7] : 1.0;
     fprintf(stderr, "[mmk stamps] srnn gru kernel, workgroup 0, us per launch over %llu launches: loads=%.2f wait for the bottom kernel=%.2f x=%.2f mfma=%.2f cell=%.2f grid barrier=%.2f up-sampler=%.2f\n",

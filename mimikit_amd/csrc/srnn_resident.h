@@ -1,0 +1,66 @@
+// Arguments of the all-resident SampleRNN kernel (see srnn_resident.hip): every tier of the network, the bottom tier and the
+// head in ONE launch per generate block, workgroup roles by blockIdx.
+#pragma once
+#include "mmk_common.h"
+
+namespace mmk {
+
+constexpr int kResMaxTiers = MMK_MAX_TIERS - 1;     // recurrent tiers (the last entry of frame_sizes is the bottom tier)
+
+// One recurrent tier (SampleRNNTier.forward, sample_rnn_v2.py:83-99) as the kernel sees it.  Its workgroups own 16 hidden units x
+// 16 MT clips each; block0 is the first blockIdx of the role.
+struct SrnnResTier {
+  int32_t fs;                 // frame size: the tier updates at every t % fs == 0
+  int32_t up;                 // slots of its up-sampler, fs / (frame size of the tier below), or fs for the last recurrent tier
+  int32_t up_mod;             // slots of the tier ABOVE per update of that tier (0: top tier); its frame size is fs * up_mod
+  int32_t n_tiles;            // 16-row output tiles per workgroup: `up` (the up-sampler's rows j H + 16 ub ..) - or, for the last recurrent
+                              // tier, the tiles of the rows composed with the head's first layer (rpb rows per unit block, see out_wp)
+  int32_t rpb;                // last recurrent tier: composed rows per unit block, row g = ub rpb + r -> (slot 1 + g / Hm, hidden unit g % Hm)
+  int32_t block0;
+  int32_t w_tile_chunks;      // K-chunks per packed gate tile (H / 16 for separate matrices, 2 H / 16 for the LSTM's [x | h])
+  int32_t fsp;                // fs rounded up to 4: row length of v_full
+  const float* whh_wp;        // packed (linear.hip) recurrent gate matrix, tiles g KC + ub
+  const float* wih_wp;        // packed input gate matrix (tiers with a tier above only: the top tier's input half is all in v_full / gconst)
+  const float* gconst;        // [2][G H]: W_ih b_in + b_ih (LSTM: + b_hh) | GRU: b_hh
+  const float* v_full;        // [G H][fsp]: W_ih W_in (fp64, rounded once), zero padded
+  const float* out_wp;        // packed output tiles: the up-sampler W_up (tile j KC + ub) - last recurrent tier: W0 W_up[slot] (tile ub n_tiles + i)
+  const float* out_bias;      // up-sampler bias in row order (last recurrent tier: null, the constant sits in the bottom role's table)
+  float* h_ring;              // [2][Bmax][H]: slot (cnt & 1) holds the state at the start, every update writes the other one
+  int64_t h_slot_stride;
+  float* c;                   // LSTM cell state (Bmax, H), read at the start, written at the end
+  int64_t* cnt;               // update counter of the tier (srnn_gru.hip keeps the same one)
+  float* out_rows;            // (B, up, H) float rows of the up-sampler for whoever runs after this launch (null for the last recurrent tier:
+                              // the plan runs that up-sampler once, after the launch)
+  unsigned long long* h_gran;        // [2][B][H] granules {update number, new state}, parity = update number & 1
+  unsigned long long* out_gran;      // [B][up][H] granules {update number, row} - last recurrent tier: [B][S][Hm] {update number, W0-composed row}
+  const unsigned long long* upper_gran;   // out_gran of the tier above, or null
+};
+
+struct SrnnResArgs {
+  int32_t B, H, n_tiers, lstm;       // clips, hidden, recurrent tiers, rnn kind
+  int32_t n_steps;
+  int64_t t_begin;                   // first step of the block, a multiple of frame_sizes[0]
+  float class_size;
+  SrnnResTier tier[kResMaxTiers];
+  // bottom tier + head: one workgroup per clip, blockIdx < B (sample_rnn_v2.py:252-260, networks/mlp.py, modules/targets.py)
+  int32_t Hm, Q, n_out, learn_temp, fsb, S;      // MLP hidden, classes, classes + temperature column, bottom frame size, frame_sizes[-2]
+  float min_temp;
+  int64_t* idx; int64_t idx_rs;      // (B, T) classes, written in place
+  const float* cp0;                  // (Hm, H) row-major: W0 W_up[slot 0] of the last recurrent tier (fp64, rounded once)
+  const float* a_comp;               // (fsb, Hm): W0 wb_i
+  const float* bcs;                  // (S, Hm): W0 (b_up[slot] + bb) + b0
+  const float* fc2_raw; const float* fc2_bias;   // (n_out, Hm) row-major as bound
+  const float* temperature; const float* uniforms; int64_t uni_ld, uni_off;
+  float* logits_out; int64_t logits_ld;          // logits of the block's last step
+  unsigned long long* cls_gran;      // [B][256] granules {position + 1, class}
+  int* err;                          // sticky error word: a wait that timed out (6 bottom role, 7 tier role)
+  unsigned long long* stamps;        // diagnostic: [role][8] phase totals in 100 MHz ticks, or null
+};
+
+bool srnn_resident_supported(int H, bool lstm, int Hm, int n_out, int Q, int fsb, int S);
+// workgroups of the launch for B clips (0: the geometry does not fit the chip); mt_out: clips per tier workgroup / 16
+int srnn_resident_grid(int H, int B, int n_tiers, int* mt_out);
+size_t srnn_resident_lds_bytes(const SrnnResArgs& a, int mt);
+int launch_srnn_resident(const SrnnResArgs& a, int mt, hipStream_t stream);
+
+}  // namespace mmk

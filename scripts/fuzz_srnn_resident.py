@@ -1,6 +1,7 @@
-"""One-off stress of the SampleRNN resident mode: random geometries / batch sizes / block splits, resident against non-resident
-(same kernels, same arithmetic: the classes must be identical) and repeated runs against each other (hand-over races would show
-as differences).  python scripts/fuzz_srnn_resident.py [n_cases]"""
+"""One-off stress of the SampleRNN resident mode (csrc/srnn_resident.hip): random geometries / batch sizes / block splits; repeated runs
+against each other (bit-identical: a hand-over race would show as a difference), and every run - resident, resident in two blocks, kernels in
+turns - against the oracle teacher-forced on its own history wherever the oracle's pick is clear (greedy cases).
+python scripts/fuzz_srnn_resident.py [n_cases]"""
 import os
 import random
 import sys
@@ -11,6 +12,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import mimikit_amd as mmk  # noqa: E402
 mmk.native.PLAN_TUNING["MMK_SRNN_FUSED"] = "1"          # (execution switches travel in the plan config: include/mmk.h `tuning`)
 from tests import helpers as H  # noqa: E402
+from oracle import torch_ref as O  # noqa: E402
 
 torch.set_grad_enabled(False)
 device = torch.device("cuda", 0)
@@ -31,7 +33,7 @@ for case in range(n_cases):
     outs = []
     for resident, split in (("1", False), ("1", True), ("1", False), ("0", False)):
         mmk.native.PLAN_TUNING["MMK_SRNN_RESIDENT"] = resident
-        net, _, _ = H.srnn("big", hidden=hidden, mlp_dim=128, seed=200 + case, frame_sizes=fs, kind=kind)
+        net, sd, arch = H.srnn("big", hidden=hidden, mlp_dim=128, seed=200 + case, frame_sizes=fs, kind=kind)
         net = net.to(device)
         idx = torch.cat([prompt, torch.zeros(B, n, dtype=torch.int64)], 1).to(device)
         torch.manual_seed(1000 + case)
@@ -43,7 +45,12 @@ for case in range(n_cases):
             net.generate_block((idx,), P, n, **({} if temp is None else {"temperature": temp}))
         net.after_generate((idx,), None)
         outs.append(idx.cpu())
-    same = all(torch.equal(o, outs[0]) for o in outs[1:])
+    same = torch.equal(outs[0], outs[2])
+    if temp is None:
+        for o in outs:
+            ref, raw = O.SampleRNNOracle(sd, **arch).generate(prompt, n, keep_logits=True, forced=o)
+            ok = H.margin_ok(raw)
+            same = same and bool(torch.equal(ref[:, P:][ok], o[:, P:][ok])) and float(ok.float().mean()) > 0.9
     print(f"case {case:2d}: fs={fs} H={hidden} {kind} B={B} P={P} n={n} cut={cut} sampled={temp is not None}: {'ok' if same else 'MISMATCH'}")
     bad += 0 if same else 1
 print("mismatching cases:", bad)
