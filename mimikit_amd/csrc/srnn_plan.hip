@@ -55,9 +55,11 @@ struct SrnnTier {
   float* v_comp = nullptr;                            // [G H][16]: W_ih W_in, zero padded (frame sizes <= 16; srnn_gru.hip composed mode)
   // resident mode (srnn_resident.hip): the input half's matrix and constants composed at commit, the granule arrays of the block
   float* v_full = nullptr;                            // [G H][fsp]: W_ih W_in for any frame size
-  float* gconst = nullptr;                            // [2][G H]: W_ih b_in + b_ih (LSTM: + b_hh) | GRU: b_hh
+  float* gconst = nullptr;                            // [2][G H]: the gates' input-half constant (top tier: W_ih b_in + b_ih; else with slot 0 of the link) | GRU: b_hh
+  float* link_wp = nullptr;                           // tiers with a tier above: packed W_ih W_up,above, rows j G H + g H + u, K = H
+  float* link_bias = nullptr;                         // [up,above][G H]: W_ih (b_in + b_up,above[slot]) + b_ih (LSTM: + b_hh)
   unsigned long long* rh_gran = nullptr;              // [2][Bmax][H]
-  unsigned long long* rout_gran = nullptr;            // [Bmax][up][H] (last recurrent tier: [Bmax][S][Hm])
+  unsigned long long* rout_gran = nullptr;            // [Bmax][up][G H] gate rows for the tier below (last recurrent tier: [Bmax][S][Hm])
 };
 
 struct mmk_srnn_plan {
@@ -116,6 +118,12 @@ struct mmk_srnn_plan {
       t.v_comp = c.take<float>((int64_t)G * H * 16);
       t.v_full = c.take<float>((int64_t)G * H * round_up(t.fs, 4));
       t.gconst = c.take<float>((int64_t)2 * G * H);
+      {
+        const size_t ti = (size_t)(&t - tiers.data());
+        const int up_above = ti > 0 ? tiers[ti - 1].up : 0;
+        t.link_wp = c.take<float>((int64_t)up_above * G * H * H);
+        t.link_bias = c.take<float>((int64_t)up_above * G * H);
+      }
       t.out = c.take<float>((int64_t)Bmax * t.up * H);
       for (auto& d : t.deep) {
         d.gates.carve(c, bias);
@@ -148,11 +156,11 @@ struct mmk_srnn_plan {
     cls_gran = c.take<unsigned long long>((int64_t)Bmax * 256);
     {
       // the tiers' granule arrays of resident mode, one region: [2][Bmax][H] of new state per tier, then its rows for the tier below
-      // ([Bmax][up][H]; the last recurrent tier: [Bmax][S][mlp_hidden] rows composed with the head's first layer)
+      // ([Bmax][up][G H] gate rows; the last recurrent tier: [Bmax][S][mlp_hidden] rows composed with the head's first layer)
       res_gran_count = 0;
       for (size_t i = 0; i < tiers.size(); ++i) {
         const bool last = i + 1 == tiers.size();
-        res_gran_count += (int64_t)2 * Bmax * H + (last ? (int64_t)Bmax * tiers[i].up * cfg.mlp_hidden : (int64_t)Bmax * tiers[i].up * H);
+        res_gran_count += (int64_t)2 * Bmax * H + (last ? (int64_t)Bmax * tiers[i].up * cfg.mlp_hidden : (int64_t)Bmax * tiers[i].up * G * H);
       }
       res_gran = c.take<unsigned long long>(res_gran_count);
       unsigned long long* at = res_gran;
@@ -161,7 +169,7 @@ struct mmk_srnn_plan {
         tiers[i].rh_gran = at;
         if (at) at += (int64_t)2 * Bmax * H;
         tiers[i].rout_gran = at;
-        if (at) at += last ? (int64_t)Bmax * tiers[i].up * cfg.mlp_hidden : (int64_t)Bmax * tiers[i].up * H;
+        if (at) at += last ? (int64_t)Bmax * tiers[i].up * cfg.mlp_hidden : (int64_t)Bmax * tiers[i].up * G * H;
       }
     }
     res_stamps = c.take<unsigned long long>(8 * (1 + kResMaxTiers));
@@ -369,18 +377,34 @@ __global__ void srnn_compose_v_kernel(const float* __restrict__ wih, const float
     for (int k = 0; k < H; ++k) acc += (double)wih[(int64_t)r * H + k] * (double)win[(int64_t)k * fs + i];
   V[e] = (float)acc;
 }
-// gc[r] = sum_k W_ih[r][k] b_in[k] + b_ih[r] (+ b_hh[r] when `sum_hh`: the LSTM cell adds both), gc[rows + r] = b_hh[r] otherwise (the GRU cell
-// keeps the recurrent bias inside r (W_hn h + b_hn)); null biases count as zero
-__global__ void srnn_compose_gconst_kernel(const float* __restrict__ wih, const float* __restrict__ bin, const float* __restrict__ bih,
-                                           const float* __restrict__ bhh, int rows, int H, int sum_hh, float* __restrict__ gc) {
-  const int r = blockIdx.x * blockDim.x + threadIdx.x;
-  if (r >= rows) return;
+// gc[j][r] = sum_k W_ih[r][k] (b_in[k] + b_up[j H + k]) + b_ih[r] (+ b_hh[r] when `sum_hh`: the LSTM cell adds both) for the slots j < n_slots of the
+// tier above (b_up null, n_slots 1: the top tier); hh[r] = b_hh[r] otherwise (the GRU cell keeps the recurrent bias inside r (W_hn h + b_hn)), when
+// `hh` is given; null biases count as zero
+__global__ void srnn_compose_gconst_kernel(const float* __restrict__ wih, const float* __restrict__ bin, const float* __restrict__ bup,
+                                           const float* __restrict__ bih, const float* __restrict__ bhh, int rows, int H, int n_slots, int sum_hh,
+                                           float* __restrict__ gc, float* __restrict__ hh) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= rows * n_slots) return;
+  const int j = e / rows, r = e - j * rows;
   double acc = 0.0;
-  for (int k = 0; k < H; ++k) acc += (double)wih[(int64_t)r * H + k] * (double)bin[k];
+  for (int k = 0; k < H; ++k) acc += (double)wih[(int64_t)r * H + k] * ((double)bin[k] + (bup ? (double)bup[(int64_t)j * H + k] : 0.0));
   if (bih) acc += (double)bih[r];
   if (sum_hh && bhh) acc += (double)bhh[r];
-  gc[r] = (float)acc;
-  gc[rows + r] = (!sum_hh && bhh) ? bhh[r] : 0.f;
+  gc[e] = (float)acc;
+  if (hh && j == 0) hh[r] = (!sum_hh && bhh) ? bhh[r] : 0.f;
+}
+// The link of a tier to the tier above: L[j G H + r][k] = sum_m W_ih[r][m] W_up[j H + m][k] - the gates' input half as a function of the tier above's
+// STATE, slot by slot -, as packed MFMA tiles (linear.hip's order), K = H
+__global__ void srnn_compose_link_kernel(const float* __restrict__ wih, const float* __restrict__ wup, int GH, int H, int n_slots, float* __restrict__ link_wp) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= (int64_t)n_slots * GH * H) return;
+  const int k = (int)(e % H);
+  const int64_t R = e / H;
+  const int r = (int)(R % GH), j = (int)(R / GH);
+  double acc = 0.0;
+  for (int m = 0; m < H; ++m) acc += (double)wih[(int64_t)r * H + m] * (double)wup[((int64_t)j * H + m) * H + k];
+  const int KC = H / 16, k16 = k & 15;
+  link_wp[((((R >> 4) * KC + (k >> 4)) * 64) + (k16 >> 2) * 16 + (R & 15)) * 4 + (k16 & 3)] = (float)acc;
 }
 // The head's first layer through the last recurrent tier's up-sampler: C[j][u][k] = sum_m W0[u][m] W_up[j H + m][k].  Slot 0 goes out row-major
 // (Hm, H) - the clip's own workgroup multiplies it -, the slots 1 .. S - 1 as packed MFMA tiles (linear.hip's order) of `rpb` rows per unit
@@ -495,6 +519,8 @@ extern "C" int mmk_srnn_commit(mmk_srnn_plan* p, void* workspace, size_t workspa
   const int H = p->H, G = p->G;
   const bool bias = c.rnn_bias != 0;
   const float *last_wu = nullptr, *last_bu = nullptr;      // the last recurrent tier's up-sampler as bound (composed with the head below)
+  const float *prev_wu = nullptr, *prev_bu = nullptr;      // the up-sampler of the tier above the one being committed (composed with its gates)
+  int links_built = 0;
   p->resident_ready = false;
   for (int i = 0; i < p->n_rnn_tiers; ++i) {
     SrnnTier& t = p->tiers[i];
@@ -518,12 +544,21 @@ extern "C" int mmk_srnn_commit(mmk_srnn_plan* p, void* workspace, size_t workspa
     }
     const float* bih = bias ? b.need(tb + "rnn.bias_ih_l0", (int64_t)G * H) : nullptr;
     const float* bhh = bias ? b.need(tb + "rnn.bias_hh_l0", (int64_t)G * H) : nullptr;
-    if (wih && w && bb && p->fused_gru && (!bias || (bih && bhh))) {   // resident mode: the input half of the gates without its input Linear
-      const int fsp = (int)round_up(t.fs, 4);
+    if (wih && w && bb && p->fused_gru && (!bias || (bih && bhh)) && (i == 0 || (prev_wu && prev_bu))) {
+      // resident mode: the input half of the gates without its input Linear - and, below the top tier, without the up-sampler of the tier above
+      const int fsp = (int)round_up(t.fs, 4), up_above = i > 0 ? p->tiers[i - 1].up : 0;
       hipLaunchKernelGGL(srnn_compose_v_kernel, dim3((unsigned)(((int64_t)G * H * fsp + 255) / 256)), dim3(256), 0, st, wih, w, G * H, H, t.fs, fsp, t.v_full);
-      hipLaunchKernelGGL(srnn_compose_gconst_kernel, dim3((unsigned)((G * H + 255) / 256)), dim3(256), 0, st, wih, bb, bih, bhh, G * H, H,
-                         c.rnn_kind == 0 ? 1 : 0, t.gconst);
+      if (i == 0) {
+        hipLaunchKernelGGL(srnn_compose_gconst_kernel, dim3((unsigned)((G * H + 255) / 256)), dim3(256), 0, st, wih, bb, (const float*)nullptr, bih, bhh, G * H, H, 1,
+                           c.rnn_kind == 0 ? 1 : 0, t.gconst, t.gconst + G * H);
+      } else {
+        hipLaunchKernelGGL(srnn_compose_gconst_kernel, dim3((unsigned)((up_above * G * H + 255) / 256)), dim3(256), 0, st, wih, bb, prev_bu, bih, bhh, G * H, H, up_above,
+                           c.rnn_kind == 0 ? 1 : 0, t.link_bias, t.gconst + G * H);
+        MMK_HIP(hipMemcpyAsync(t.gconst, t.link_bias, (size_t)G * H * sizeof(float), hipMemcpyDeviceToDevice, st));     // slot 0: the tier multiplies it itself
+        hipLaunchKernelGGL(srnn_compose_link_kernel, dim3((unsigned)(((int64_t)up_above * G * H * H + 255) / 256)), dim3(256), 0, st, wih, prev_wu, G * H, H, up_above, t.link_wp);
+      }
       MMK_HIP(hipGetLastError());
+      ++links_built;
     }
     if (c.rnn_kind == 1) {
       if (wih) MMK_TRY(pack_rect(t.gates.Wp, t.gates.k_chunks, 0, 1, G * H, 0, H, wih, H, 1, st));
@@ -560,6 +595,7 @@ extern "C" int mmk_srnn_commit(mmk_srnn_plan* p, void* workspace, size_t workspa
     if (wu) MMK_TRY(pack_rect(t.up_lin.Wp, t.up_lin.k_chunks, 0, 1, H * t.up, 0, H, wu, H, 1, st));
     if (bu) MMK_TRY(pack_bias(t.up_lin.bias, 0, 1, H * t.up, bu, 0, st));
     if (i == p->n_rnn_tiers - 1) { last_wu = wu; last_bu = bu; }
+    prev_wu = wu; prev_bu = bu;
   }
   {
     // bottom tier: FramedConv1dIO -> heads.0 = Sequential(Linearizer, Unfold, Sequential(Flatten, Unsqueeze, Conv1dResampler))
@@ -590,7 +626,7 @@ extern "C" int mmk_srnn_commit(mmk_srnn_plan* p, void* workspace, size_t workspa
                          H, fsl, p->a_comp, p->b_comp);
       MMK_HIP(hipGetLastError());
       p->bottom_composed = true;
-      if (p->fused_gru && last_wu && last_bu) {
+      if (p->fused_gru && last_wu && last_bu && links_built == p->n_rnn_tiers) {
         // resident mode: the head's first layer through the last recurrent tier's up-sampler (srnn_resident.hip)
         const int S = p->tiers.back().up, Hm = m.N;
         hipLaunchKernelGGL(srnn_compose_cp_kernel, dim3((unsigned)(((int64_t)S * Hm * H + 255) / 256)), dim3(256), 0, st, w, last_wu, Hm, H, S,
@@ -951,7 +987,7 @@ static int resident_grid(mmk_srnn_plan* p, const SrnnCall& call, int64_t n_res, 
   return srnn_resident_grid(p->H, call.M, p->n_rnn_tiers, mt);
 }
 
-static int run_resident(mmk_srnn_plan* p, const SrnnCall& call, int64_t t_begin, int64_t n, int mt, hipStream_t st) {
+static int run_resident(mmk_srnn_plan* p, const SrnnCall& call, int64_t t_begin, int64_t n, const int* mt, hipStream_t st) {
   const mmk_srnn_config& c = p->cfg;
   const int H = p->H, G = p->G, KC = H / 16, M = call.M;
   MMK_HIP(hipMemsetAsync(p->res_gran, 0, (size_t)p->res_gran_count * sizeof(unsigned long long), st));   // (a granule of an earlier block could carry the number this one waits for)
@@ -966,23 +1002,23 @@ static int run_resident(mmk_srnn_plan* p, const SrnnCall& call, int64_t t_begin,
     SrnnResTier& r = a.tier[i];
     const bool last = i == p->n_rnn_tiers - 1;
     r.fs = t.fs; r.up = t.up; r.up_mod = i > 0 ? p->tiers[i - 1].up : 0;
-    r.n_tiles = last ? p->cp_tiles : t.up; r.rpb = last ? p->cp_rpb : 0;
-    r.block0 = block0;
-    block0 += KC * ((M + 16 * mt - 1) / (16 * mt));
+    r.n_tiles = last ? p->cp_tiles : G * (t.up - 1); r.rpb = last ? p->cp_rpb : 0;
+    r.block0 = block0; r.mt = mt[i];
+    block0 += KC * ((M + 16 * mt[i] - 1) / (16 * mt[i]));
     r.fsp = (int32_t)round_up(t.fs, 4);
     if (c.rnn_kind == 1) {
-      r.wih_wp = t.gates.Wp; r.whh_wp = t.gates_hh.Wp; r.w_tile_chunks = t.gates.k_chunks;
+      r.whh_wp = t.gates_hh.Wp; r.w_tile_chunks = t.gates.k_chunks;
     } else {   // LSTM: one packed matrix, K = [x | h]
-      r.wih_wp = t.gates.Wp; r.whh_wp = t.gates.Wp + (int64_t)t.gates.seg_chunk0[1] * 256; r.w_tile_chunks = t.gates.k_chunks;
+      r.whh_wp = t.gates.Wp + (int64_t)t.gates.seg_chunk0[1] * 256; r.w_tile_chunks = t.gates.k_chunks;
     }
+    r.link_wp = i > 0 ? t.link_wp : nullptr;
     r.gconst = t.gconst; r.v_full = t.v_full;
-    r.out_wp = last ? p->cp_wp : t.up_lin.Wp; r.out_bias = last ? nullptr : t.up_lin.bias;
+    r.out_wp = last ? p->cp_wp : p->tiers[i + 1].link_wp; r.out_bias = last ? nullptr : p->tiers[i + 1].link_bias;
     r.h_ring = t.h; r.h_slot_stride = (int64_t)p->Bmax * H; r.c = t.c; r.cnt = t.cnt;
-    r.out_rows = last ? nullptr : t.out;
     r.h_gran = t.rh_gran; r.out_gran = t.rout_gran;
     r.upper_gran = i > 0 ? p->tiers[i - 1].rout_gran : nullptr;
+    r.upper_h_gran = i > 0 ? p->tiers[i - 1].rh_gran : nullptr;
   }
-  (void)G;
   a.Hm = c.mlp_hidden; a.Q = c.q_levels; a.n_out = c.q_levels + (c.learn_temp ? 1 : 0); a.learn_temp = c.learn_temp; a.min_temp = c.min_temp;
   a.fsb = c.frame_size[c.n_tiers - 1]; a.S = p->tiers.back().up;
   a.idx = const_cast<int64_t*>(call.idx); a.idx_rs = call.idx_rs;
@@ -996,11 +1032,10 @@ static int run_resident(mmk_srnn_plan* p, const SrnnCall& call, int64_t t_begin,
     const char* senv = diag_only("MMK_SRNN_STAMPS");
     a.stamps = (senv && senv[0] == '1') ? p->res_stamps : nullptr;
   }
-  MMK_TRY(launch_srnn_resident(a, mt, st));
-  {
-    // the last recurrent tier's up-sampler never ran inside the launch (its rows reach the bottom tier composed with the head's first layer): once,
-    // on the state the launch left, for whoever continues between two of that tier's updates
-    SrnnTier& t = p->tiers.back();
+  MMK_TRY(launch_srnn_resident(a, st));
+  for (auto& t : p->tiers) {
+    // no up-sampler ran inside the launch (its rows reach the tier below composed with that tier's gates, or with the head's first layer): once per
+    // tier, on the state the launch left, for whoever continues between two updates
     LinearArgs u = {};
     t.up_lin.fill(u);
     u.seg[0].x = addr_time(t.h, (int64_t)p->Bmax * H, 0, 1, 2); u.seg[0].ld = H;
@@ -1018,8 +1053,8 @@ static int run_steps(mmk_srnn_plan* p, const SrnnCall& call, int64_t t_begin, in
   if (with_bottom) {
     const int period = p->cfg.frame_size[0];
     const int64_t head = (period - t_begin % period) % period;      // steps up to the next update of the top tier, run with the kernels in turns
-    int mt = 1;
-    if (n > head && resident_grid(p, call, n - head, &mt) > 0) {
+    int mt[kResMaxTiers];
+    if (n > head && resident_grid(p, call, n - head, mt) > 0) {
       if (head > 0) {
         MMK_TRY(launch_set_i64(p->tau, t_begin, st));
         MMK_TRY(emit_range(p, call, 0, head, (int)(t_begin % period), true, st));
@@ -1137,9 +1172,9 @@ extern "C" int mmk_srnn_last_logits(mmk_srnn_plan* p, int32_t batch, float* out,
         for (int i = 0; i < p->n_rnn_tiers; ++i) {
           const unsigned long long* r = rs + 8 * (1 + i);
           const double nu = r[7] ? (double)r[7] : 1.0;
-          fprintf(stderr, "[mmk stamps] srnn resident kernel, tier %d workgroup 0, us per update over %llu updates: gate products (+ wait for the row above)=%.2f "
-                  "window (wait for the classes)=%.2f cell=%.2f all-gather=%.2f output tiles=%.2f\n", i, r[7], r[0] * 1e-2 / nu, r[1] * 1e-2 / nu, r[2] * 1e-2 / nu,
-                  r[3] * 1e-2 / nu, r[4] * 1e-2 / nu);
+          fprintf(stderr, "[mmk stamps] srnn resident kernel, tier %d workgroup 0, us per update over %llu updates: input half (state / rows of the tier above)=%.2f "
+                  "window (wait for the classes)=%.2f cell=%.2f all-gather=%.2f output tiles=%.2f recurrent product=%.2f\n", i, r[7], r[0] * 1e-2 / nu, r[1] * 1e-2 / nu,
+                  r[2] * 1e-2 / nu, r[3] * 1e-2 / nu, r[4] * 1e-2 / nu, r[5] * 1e-2 / nu);
         }
         MMK_HIP(hipMemset(p->res_stamps, 0, sizeof(rs)));
       }

@@ -13,27 +13,31 @@ struct SrnnResTier {
   int32_t fs;                 // frame size: the tier updates at every t % fs == 0
   int32_t up;                 // slots of its up-sampler, fs / (frame size of the tier below), or fs for the last recurrent tier
   int32_t up_mod;             // slots of the tier ABOVE per update of that tier (0: top tier); its frame size is fs * up_mod
-  int32_t n_tiles;            // 16-row output tiles per workgroup: `up` (the up-sampler's rows j H + 16 ub ..) - or, for the last recurrent
-                              // tier, the tiles of the rows composed with the head's first layer (rpb rows per unit block, see out_wp)
+  int32_t n_tiles;            // 16-row output tiles per workgroup: G (up - 1) link tiles of the tier below (gate rows of its slots 1 .. up - 1) - or,
+                              // for the last recurrent tier, the tiles of the rows composed with the head's first layer (rpb rows per unit block)
   int32_t rpb;                // last recurrent tier: composed rows per unit block, row g = ub rpb + r -> (slot 1 + g / Hm, hidden unit g % Hm)
   int32_t block0;
+  int32_t mt;                 // row tiles of 16 clips per workgroup: 1, 2 - or 4, top tier only
   int32_t w_tile_chunks;      // K-chunks per packed gate tile (H / 16 for separate matrices, 2 H / 16 for the LSTM's [x | h])
   int32_t fsp;                // fs rounded up to 4: row length of v_full
   const float* whh_wp;        // packed (linear.hip) recurrent gate matrix, tiles g KC + ub
-  const float* wih_wp;        // packed input gate matrix (tiers with a tier above only: the top tier's input half is all in v_full / gconst)
-  const float* gconst;        // [2][G H]: W_ih b_in + b_ih (LSTM: + b_hh) | GRU: b_hh
+  const float* link_wp;       // tiers with a tier above: packed W_ih W_up,above, rows j G H + g H + u (slot j of the tier above), K = H; the tier itself
+                              // multiplies slot 0 (tiles g KC + ub, in registers), the tier above streams the others (its out_wp)
+  const float* gconst;        // [2][G H]: the constant of the gates' input half - top tier: W_ih b_in + b_ih, else W_ih (b_in + b_up,0) + b_ih (slot 0 of
+                              // the link); LSTM: + b_hh | GRU: b_hh
   const float* v_full;        // [G H][fsp]: W_ih W_in (fp64, rounded once), zero padded
-  const float* out_wp;        // packed output tiles: the up-sampler W_up (tile j KC + ub) - last recurrent tier: W0 W_up[slot] (tile ub n_tiles + i)
-  const float* out_bias;      // up-sampler bias in row order (last recurrent tier: null, the constant sits in the bottom role's table)
+  const float* out_wp;        // packed output tiles: link_wp of the tier below - last recurrent tier: W0 W_up[slot] (tile ub n_tiles + i)
+  const float* out_bias;      // [up][G H] constants of the tier below's link rows, W_ih,below (b_in,below + b_up[slot]) + b_ih,below (LSTM: + b_hh) -
+                              // last recurrent tier: null, the constant sits in the bottom role's table
   float* h_ring;              // [2][Bmax][H]: slot (cnt & 1) holds the state at the start, every update writes the other one
   int64_t h_slot_stride;
   float* c;                   // LSTM cell state (Bmax, H), read at the start, written at the end
   int64_t* cnt;               // update counter of the tier (srnn_gru.hip keeps the same one)
-  float* out_rows;            // (B, up, H) float rows of the up-sampler for whoever runs after this launch (null for the last recurrent tier:
-                              // the plan runs that up-sampler once, after the launch)
   unsigned long long* h_gran;        // [2][B][H] granules {update number, new state}, parity = update number & 1
-  unsigned long long* out_gran;      // [B][up][H] granules {update number, row} - last recurrent tier: [B][S][Hm] {update number, W0-composed row}
-  const unsigned long long* upper_gran;   // out_gran of the tier above, or null
+  unsigned long long* out_gran;      // [B][up][G H] granules {update number, gate row of the tier below} (slot 0 unused) - last recurrent tier:
+                                     // [B][S][Hm] {update number, W0-composed row}
+  const unsigned long long* upper_gran;     // out_gran of the tier above, or null
+  const unsigned long long* upper_h_gran;   // h_gran of the tier above, or null
 };
 
 struct SrnnResArgs {
@@ -58,9 +62,9 @@ struct SrnnResArgs {
 };
 
 bool srnn_resident_supported(int H, bool lstm, int Hm, int n_out, int Q, int fsb, int S);
-// workgroups of the launch for B clips (0: the geometry does not fit the chip); mt_out: clips per tier workgroup / 16
+// workgroups of the launch for B clips (0: the geometry does not fit the chip); mt_out[tier]: clips per workgroup of that tier / 16
 int srnn_resident_grid(int H, int B, int n_tiers, int* mt_out);
-size_t srnn_resident_lds_bytes(const SrnnResArgs& a, int mt);
-int launch_srnn_resident(const SrnnResArgs& a, int mt, hipStream_t stream);
+size_t srnn_resident_lds_bytes(const SrnnResArgs& a);
+int launch_srnn_resident(const SrnnResArgs& a, hipStream_t stream);
 
 }  // namespace mmk

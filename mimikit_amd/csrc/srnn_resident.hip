@@ -16,12 +16,15 @@
 //
 // Same arithmetic in another association (as srnn_gru.hip / srnn_bottom.hip's composed modes, pinned by the same goldens and oracle
 // tests): products of two weight matrices that meet without a non-linearity between them are multiplied at commit (fp64, rounded once):
-//   W_ih x                = (W_ih W_in) lin(window) + W_ih up + (W_ih b_in + b_ih)          the input Linear never runs
-//   fc0(conv(lin) + up_j) = (W0 W_up,j) h' + (W0 wb) lin(window) + (W0 (b_up,j + bb) + b0)   the last tier's up-sampler never runs
-// The second line takes the up-sampler of the last recurrent tier AND the head's first layer off the per-step chain: for slot 0 the
-// clip's bottom workgroup multiplies (W0 W_up,0) h' itself as soon as h' is out (one hop behind the cell), the rows of slots 1 .. S - 1
-// are made by the tier's workgroups from their register tiles meanwhile.  What sits between the draw of a frame's last class and the
-// next step's hidden layer is then: class granule -> one FMA + the cell -> state granules -> a 128 x 512 product in the clip's workgroup.
+//   W_ih x, x = W_in lin + b_in + up_j,  up_j = W_up,j h'_above + b_up,j  (the tier above's slot j):
+//                         = (W_ih W_in) lin(window) + (W_ih W_up,j) h'_above + (W_ih (b_in + b_up,j) + b_ih)
+//   fc0(conv(lin) + up_j) = (W0 W_up,j) h' + (W0 wb) lin(window) + (W0 (b_up,j + bb) + b0)
+// No input Linear and no up-sampler ever runs: a tier (and the head) multiplies the STATE of the tier above.  For slot 0 - the slot on the
+// chain: the tier above has just updated - the consumer itself multiplies (. W_up,0) h'_above as soon as that state is out, one hop behind
+// the cell (the tier's workgroups from register tiles; the clip's bottom workgroup its 128 x 512 product); the rows of the slots j >= 1,
+// needed one or more frames later, are made by the PRODUCING tier's workgroups meanwhile (whole gate rows for the tier below, streamed
+// link tiles; hidden-layer rows for the head, register tiles).  What sits between the draw of a frame's last class and the next step's
+// hidden layer is then: class granule -> one FMA + the cell -> state granules -> a product in the consumer.
 //
 // Hazards of running free (no launch boundary orders anything): a granule array is only ever rewritten by an update that cannot
 // start before every reader of the previous value is through (class -> cell -> rows -> class is a cycle through every role), except
@@ -136,19 +139,22 @@ struct ResStamp {
 };
 
 // ---- tier role -------------------------------------------------------------------------------------------------------------
-// KC = H / 16 unit blocks; MT row tiles of 16 clips per workgroup; HAS_UPPER: a tier above feeds this one (the top tier's input half
-// is a K = fs dot product and a constant, its W_ih registers hold up-sampler tiles instead)
-template <int KC, bool LSTM, int MT, bool HAS_UPPER>
-__device__ __forceinline__ void res_tier_role(const SrnnResArgs& a, const SrnnResTier& T, const int tier_index, const bool last, char* smem_raw) {
+// KC = H / 16 unit blocks; MT row tiles of 16 clips per workgroup; HAS_UPPER: a tier above feeds this one; LAST: the tier right above
+// the bottom tier.  Registers for the block: W_hh (NG tiles), the link tiles of slot 0 (HAS_UPPER, NG tiles: W_ih W_up[slot 0] of the
+// tier above - this tier multiplies them with that tier's new STATE, one hop behind its cell, instead of waiting for its up-sampler),
+// the first tiles of the rows composed with the head (LAST), the state of the own clips as MFMA operands.  What a tier makes for the
+// tier below besides its state - W_ih,below (W_up[slot j] h' + b) for the slots j >= 1, whole gate rows - is streamed: those slots are
+// only needed one or more frames of the tier below later.
+template <int KC, bool LSTM, int MT, bool HAS_UPPER, bool LAST>
+__device__ __forceinline__ void res_tier_role(const SrnnResArgs& a, const SrnnResTier& T, const int tier_index, char* smem_raw) {
   constexpr int H = KC * 16;
   constexpr int CPW = KC / kResWaves;              // K-chunks per wave
   constexpr int NG = LSTM ? 4 : 3;
-  constexpr int RU = KC == 32 ? 1 : 4;             // output tiles kept in registers beside both gate matrices
-  constexpr int NRU = HAS_UPPER ? RU : RU + NG;
+  constexpr int GH = NG * H;
   constexpr int NP = MT >= 2 ? MT / 2 : 1;         // (clip, unit) pairs per thread in the cell
-  constexpr int RED = 2 * NG * MT;                 // partial-sum images of 8 KB in LDS
-  constexpr int BT = 4;                            // streamed output tiles per batch
-  static_assert(BT * MT <= RED && (NRU - 1) * MT <= RED, "partial-sum buffer");
+  constexpr int RED = NG * MT;                     // partial-sum images of 8 KB in LDS
+  constexpr int BT = NG;                           // output tiles per batch (BT MT <= RED)
+  constexpr int NRU = LAST ? (KC == 32 ? 1 : BT) : 0;   // output tiles kept in registers
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wg = blockIdx.x - T.block0;
@@ -167,25 +173,29 @@ __device__ __forceinline__ void res_tier_role(const SrnnResArgs& a, const SrnnRe
   float* s_lin = (float*)sp;  sp += (size_t)16 * MT * ldl * 4;
   float* vs = (float*)sp;                                          // (W_ih W_in) rows of this workgroup's units: [NG][16][fsp]
 
-  // ---- once per block: every weight this workgroup multiplies, into registers ---------------------------------------------------
-  f32x4 whh[NG][CPW], wih[HAS_UPPER ? NG : 1][CPW], wup[NRU][CPW];
-  auto tile_of = [&](int i) -> int64_t { return last ? (int64_t)ub * T.n_tiles + i : (int64_t)i * KC + ub; };
+  // ---- once per block: every weight this workgroup multiplies at every update, into registers --------------------------------------
+  f32x4 whh[NG][CPW], win0[HAS_UPPER ? NG : 1][CPW], wout[NRU > 0 ? NRU : 1][CPW];
 #pragma unroll
   for (int g = 0; g < NG; ++g) {
     gf32x4_ptr wh = (gf32x4_ptr)(uintptr_t)T.whh_wp + ((int64_t)(g * KC + ub) * T.w_tile_chunks + c0) * 64 + lane;
 #pragma unroll
     for (int u = 0; u < CPW; ++u) whh[g][u] = wh[u * 64];
-    if constexpr (HAS_UPPER) {
-      gf32x4_ptr wi = (gf32x4_ptr)(uintptr_t)T.wih_wp + ((int64_t)(g * KC + ub) * T.w_tile_chunks + c0) * 64 + lane;
+    if constexpr (HAS_UPPER) {     // slot 0 of the link from the tier above: rows g H + 16 ub .. of W_ih W_up[0]
+      gf32x4_ptr wi = (gf32x4_ptr)(uintptr_t)T.link_wp + ((int64_t)(g * KC + ub) * KC + c0) * 64 + lane;
 #pragma unroll
-      for (int u = 0; u < CPW; ++u) wih[g][u] = wi[u * 64];
+      for (int u = 0; u < CPW; ++u) win0[g][u] = wi[u * 64];
     }
   }
+  // output tiles of this workgroup: LAST - tile i of the rows composed with the head's first layer (ub n_tiles + i); otherwise the link
+  // of the tier below, slot 1 + i / NG, gate i % NG: tile ((1 + i / NG) NG + i % NG) KC + ub of W_ih,below W_up
+  auto tile_of = [&](int i) -> int64_t { return LAST ? (int64_t)ub * T.n_tiles + i : (int64_t)(NG + i) * KC + ub; };
+  if constexpr (NRU > 0) {
 #pragma unroll
-  for (int i = 0; i < NRU; ++i) {
-    gf32x4_ptr ws = (gf32x4_ptr)(uintptr_t)T.out_wp + (tile_of(min(i, T.n_tiles - 1)) * KC + c0) * 64 + lane;
+    for (int i = 0; i < NRU; ++i) {
+      gf32x4_ptr ws = (gf32x4_ptr)(uintptr_t)T.out_wp + (tile_of(min(i, T.n_tiles - 1)) * KC + c0) * 64 + lane;
 #pragma unroll
-    for (int u = 0; u < CPW; ++u) wup[i][u] = ws[u * 64];
+      for (int u = 0; u < CPW; ++u) wout[i][u] = ws[u * 64];
+    }
   }
   for (int e = tid; e < NG * 16 * fsp; e += kResThreads) {
     const int g = e / (16 * fsp), r = e - g * 16 * fsp, n = r / fsp, i = r - n * fsp;
@@ -193,7 +203,7 @@ __device__ __forceinline__ void res_tier_role(const SrnnResArgs& a, const SrnnRe
   }
   // the cell's (clip, unit) pairs of this thread: constants, old state
   const int64_t cnt0 = *T.cnt;
-  float cst[NP][2 * NG], hprev[NP], cprev[NP];
+  float cst_in[NP][NG], cst_hh[NP][NG], hprev[NP], cprev[NP];
   int p_m[NP], p_clip[NP];                         // row inside the workgroup (mt 16 + m), clip; p_clip < 0: no such pair / no such clip
   const int pn = tid & 15;
   const int unit = ub * 16 + pn;
@@ -205,8 +215,8 @@ __device__ __forceinline__ void res_tier_role(const SrnnResArgs& a, const SrnnRe
     p_clip[k] = (has && p_m[k] < mg) ? m_first + p_m[k] : -1;
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
-      cst[k][g] = T.gconst[g * H + unit];
-      cst[k][NG + g] = LSTM ? 0.f : T.gconst[(NG + g) * H + unit];
+      cst_in[k][g] = T.gconst[g * H + unit];       // top tier: W_ih b_in + b_ih; else: the constant of the link's slot 0
+      cst_hh[k][g] = LSTM ? 0.f : T.gconst[(NG + g) * H + unit];
     }
     const int64_t o = (int64_t)(p_clip[k] < 0 ? m_first : p_clip[k]) * H + unit;
     hprev[k] = T.h_ring[(cnt0 & 1) * T.h_slot_stride + o];
@@ -221,6 +231,54 @@ __device__ __forceinline__ void res_tier_role(const SrnnResArgs& a, const SrnnRe
 #pragma unroll
     for (int u = 0; u < CPW; ++u) hv[mt][u] = *reinterpret_cast<const f32x4*>(hr + u * 16);
   }
+  // products of NG tiles with a slice of rows: partial sums of this wave's K range -> LDS
+  auto gate_products = [&](const f32x4 (&w)[NG][CPW], const f32x4 (&x)[CPW], int mt) {
+    f32x4 acc[NG];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < CPW; ++u) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int g = 0; g < NG; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(x[u][i], w[g][u][i], acc[g], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int g = 0; g < NG; ++g) red[((mt * NG + g) * kResWaves + wave) * 64 + lane] = acc[g];
+  };
+  // the sums over the waves for the cell's pairs (fixed order)
+  auto gate_sums = [&](float (&s)[NP][NG]) {
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+      const int m = p_m[k] & 15, mt = p_m[k] >> 4;
+      const int frag = ((m >> 2) * 16 + pn) * 4 + (m & 3);        // (row m, col n) of a 16x16 accumulator image
+#pragma unroll
+      for (int g = 0; g < NG; ++g) {
+        const float* f = reinterpret_cast<const float*>(red + (mt * NG + g) * kResWaves * 64) + frag;
+        float v = 0.f;
+#pragma unroll
+        for (int wv = 0; wv < kResWaves; ++wv) v += f[wv * 256];
+        s[k][g] = v;
+      }
+    }
+  };
+  // a slice of rows of granules (this wave's K range of the clips of row tile mt), preceded by a light poll - one granule per lane: the
+  // last unit of a producing workgroup for one clip - so that the whole slice (64 KB per row tile) is not requested over and over
+  // while the producers' stores are still on their way
+  auto gather = [&](const u64* base, unsigned tag, int mt, f32x4 (&out)[CPW]) {
+    const int m = mt * 16 + (lane & 15);
+    const u64* row = base + (int64_t)(m_first + (m < mg ? m : mg - 1)) * H;
+    (void)res_wait(row + (c0 + (lane >> 4) % CPW) * 16 + 15, tag, a.err, 7);
+    res_poll_slice<CPW>(row + c0 * 16 + 4 * (lane >> 4), tag, out, a.err, 7);
+  };
+  // W_hh h of the state the block starts from
+  float s_hh[NP][NG];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+    if (mt * 16 < mg) gate_products(whh, hv[mt], mt);
+  __syncthreads();
+  gate_sums(s_hh);
   __syncthreads();
 
   const int n_upd = (a.n_steps + fs - 1) / fs;
@@ -228,60 +286,43 @@ __device__ __forceinline__ void res_tier_role(const SrnnResArgs& a, const SrnnRe
     const int64_t t = a.t_begin + (int64_t)upd * fs;
     const unsigned epoch = (unsigned)(t / fs) + 1u;
     const int64_t par = (int64_t)(epoch & 1u) * BH;
-    // ---- gate products: W_hh h, and W_ih (row of the tier above) once that row is out -------------------------------------------
+    // ---- the input half of the gates but for the window's part ------------------------------------------------------------------------
+    float s_in[NP][NG];
+    if constexpr (HAS_UPPER) {
+      const int slot = (int)((t / fs) % T.up_mod);                             // outputs[i-1][:, (t // fs) % ...]   (:251)
+      const unsigned uep = (unsigned)(t / ((int64_t)fs * T.up_mod)) + 1u;      // the update of the tier above this slot belongs to
+      if (slot == 0) {
+        // that tier's new state, one hop behind its cell, times W_ih W_up[0]
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-      if (mt * 16 < mg) {
-        f32x4 acc[2 * NG];
-#pragma unroll
-        for (int g = 0; g < 2 * NG; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int u = 0; u < CPW; ++u) {
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-#pragma unroll
-            for (int g = 0; g < NG; ++g) acc[NG + g] = __builtin_amdgcn_mfma_f32_16x16x4f32(hv[mt][u][i], whh[g][u][i], acc[NG + g], 0, 0, 0);
+        for (int mt = 0; mt < MT; ++mt) {
+          if (mt * 16 < mg) {
+            f32x4 xv[CPW];
+            gather(T.upper_h_gran + (int64_t)(uep & 1u) * BH, uep, mt, xv);
+            gate_products(win0, xv, mt);
           }
         }
-        if constexpr (HAS_UPPER) {
-          const int slot = (int)((t / fs) % T.up_mod);                           // outputs[i-1][:, (t // fs) % ...]   (:251)
-          const unsigned uep = (unsigned)(t / ((int64_t)fs * T.up_mod)) + 1u;
-          const int m = mt * 16 + (lane & 15);
-          const u64* xr = T.upper_gran + ((int64_t)(m_first + (m < mg ? m : mg - 1)) * T.up_mod + slot) * H + c0 * 16 + 4 * (lane >> 4);
-          f32x4 xv[CPW];
-          res_poll_slice<CPW>(xr, uep, xv, a.err, 7);
+        __syncthreads();
+        gate_sums(s_in);
 #pragma unroll
-          for (int u = 0; u < CPW; ++u) {
+        for (int k = 0; k < NP; ++k)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+          for (int g = 0; g < NG; ++g) s_in[k][g] += cst_in[k][g];
+      } else {
+        // whole gate rows from the tier above (its streamed link tiles, constants included)
 #pragma unroll
-              for (int g = 0; g < NG; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[u][i], wih[g][u][i], acc[g], 0, 0, 0);
-            }
-          }
+        for (int k = 0; k < NP; ++k) {
+          const u64* src = T.upper_gran + ((int64_t)(p_clip[k] < 0 ? m_first : p_clip[k]) * T.up_mod + slot) * GH + unit;
+#pragma unroll
+          for (int g = 0; g < NG; ++g) s_in[k][g] = __uint_as_float(res_wait(src + g * H, uep, a.err, 7));
         }
-#pragma unroll
-        for (int g = HAS_UPPER ? 0 : NG; g < 2 * NG; ++g) red[((mt * 2 * NG + g) * kResWaves + wave) * 64 + lane] = acc[g];
       }
+    } else {
+#pragma unroll
+      for (int k = 0; k < NP; ++k)
+#pragma unroll
+        for (int g = 0; g < NG; ++g) s_in[k][g] = cst_in[k][g];
     }
-    __syncthreads();
     st.at(0);
-    // ---- the partial sums of the cell's pairs, ahead of the wait for the frame's last class --------------------------------------
-    float s[NP][2 * NG];
-#pragma unroll
-    for (int k = 0; k < NP; ++k) {
-      const int m = p_m[k] & 15, mt = p_m[k] >> 4;
-      const int frag = ((m >> 2) * 16 + pn) * 4 + (m & 3);        // (row m, col n) of a 16x16 accumulator image
-#pragma unroll
-      for (int g = 0; g < 2 * NG; ++g) {
-        float v = 0.f;
-        if (HAS_UPPER || g >= NG) {
-          const float* f = reinterpret_cast<const float*>(red + (mt * 2 * NG + g) * kResWaves * 64) + frag;
-#pragma unroll
-          for (int wv = 0; wv < kResWaves; ++wv) v += f[wv * 256];
-        }
-        s[k][g] = v;
-      }
-    }
     // ---- the window, linearized (modules/io.py:106-112): the classes come from the bottom role as granules -------------------------
     for (int e = tid; e < 16 * MT * fsp; e += kResThreads) {
       const int m = e / fsp, i = e - m * fsp;
@@ -299,29 +340,27 @@ __device__ __forceinline__ void res_tier_role(const SrnnResArgs& a, const SrnnRe
 #pragma unroll
     for (int k = 0; k < NP; ++k) {
       const f32x4* l4 = reinterpret_cast<const f32x4*>(s_lin + p_m[k] * ldl);
+      float gi[NG];
 #pragma unroll
       for (int g = 0; g < NG; ++g) {
         const f32x4* v4 = reinterpret_cast<const f32x4*>(vs + (g * 16 + pn) * fsp);
         f32x4 p = l4[0] * v4[0];
         for (int c = 1; c < fsp / 4; ++c) p += l4[c] * v4[c];
-        s[k][g] += (p[0] + p[1]) + (p[2] + p[3]);
+        gi[g] = s_in[k][g] + ((p[0] + p[1]) + (p[2] + p[3]));
       }
       float hn;
       if (LSTM) {
-        // gates = (W_ih x + W_hh h) + (b_ih + b_hh); i, f, o = s(.), g = tanh(.); c' = f c + i g; h' = o tanh(c')
-        float gt[4];
-#pragma unroll
-        for (int g = 0; g < 4; ++g) gt[g] = (s[k][g] + s[k][NG + g]) + cst[k][g];
-        const float ig = sigmoid_fast(gt[0]), fg = sigmoid_fast(gt[1]), cg = tanh_fast(gt[2]), og = sigmoid_fast(gt[3]);
+        // gates = (W_ih x + b_ih + b_hh) + W_hh h; i, f, o = s(.), g = tanh(.); c' = f c + i g; h' = o tanh(c')
+        const float ig = sigmoid_fast(gi[0] + s_hh[k][0]), fg = sigmoid_fast(gi[1] + s_hh[k][1]);
+        const float cg = tanh_fast(gi[2] + s_hh[k][2]), og = sigmoid_fast(gi[NG - 1] + s_hh[k][NG - 1]);
         const float cn = fg * cprev[k] + ig * cg;
         cprev[k] = cn;
         hn = og * tanh_fast(cn);
       } else {
-        const float gi_r = s[k][0] + cst[k][0], gi_z = s[k][1] + cst[k][1], gi_n = s[k][2] + cst[k][2];
-        const float gh_r = s[k][3] + cst[k][NG], gh_z = s[k][4] + cst[k][NG + 1], gh_n = s[k][5] + cst[k][NG + 2];
-        const float r = sigmoid_fast(gh_r + gi_r);
-        const float z = sigmoid_fast(gh_z + gi_z);
-        const float nn = tanh_fast(gi_n + gh_n * r);
+        const float gh_r = s_hh[k][0] + cst_hh[k][0], gh_z = s_hh[k][1] + cst_hh[k][1], gh_n = s_hh[k][2] + cst_hh[k][2];
+        const float r = sigmoid_fast(gh_r + gi[0]);
+        const float z = sigmoid_fast(gh_z + gi[1]);
+        const float nn = tanh_fast(gi[2] + gh_n * r);
         hn = (hprev[k] - nn) * z + nn;
       }
       hprev[k] = hn;
@@ -332,18 +371,12 @@ __device__ __forceinline__ void res_tier_role(const SrnnResArgs& a, const SrnnRe
       }
     }
     st.at(2);
-    // ---- the new state of the own clips, this wave's K range (from the KC workgroups of the row tile) -----------------------------
+    // ---- the new state of the own clips, this wave's K range (from the CPW workgroups that own those units) ---------------------------
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-      if (mt * 16 < mg) {
-        const int m = mt * 16 + (lane & 15);
-        const u64* hr = T.h_gran + par + (int64_t)(m_first + (m < mg ? m : mg - 1)) * H + c0 * 16 + 4 * (lane >> 4);
-        res_poll_slice<CPW>(hr, epoch, hv[mt], a.err, 7);
-      }
-    }
+    for (int mt = 0; mt < MT; ++mt)
+      if (mt * 16 < mg) gather(T.h_gran + par, epoch, mt, hv[mt]);
     st.at(3);
-    // ---- output tiles: the up-sampler's rows (last recurrent tier: the rows composed with the head's first layer) -------------------
-    // batches: {0} (the slot that is needed first), {1 .. NRU - 1} - both from registers -, then BT at a time streamed
+    // ---- output tiles, batches of at most BT: partial sums -> LDS, summed over the waves, published as granules ------------------------
     auto run_batch = [&](auto pb, int jb, int nb) {
       constexpr int PB = decltype(pb)::value;               // first register tile of the batch, or -1: streamed
       constexpr int NB = PB == 0 ? 1 : (PB > 0 ? (NRU - 1 > 0 ? NRU - 1 : 1) : BT);
@@ -353,7 +386,7 @@ __device__ __forceinline__ void res_tier_role(const SrnnResArgs& a, const SrnnRe
           f32x4 wt[CPW];
           if constexpr (PB >= 0) {
 #pragma unroll
-            for (int u = 0; u < CPW; ++u) wt[u] = wup[(PB + j) < NRU ? (PB + j) : 0][u];
+            for (int u = 0; u < CPW; ++u) wt[u] = wout[(PB + j) < NRU ? (PB + j) : 0][u];
           } else {
             gf32x4_ptr ws = (gf32x4_ptr)(uintptr_t)T.out_wp + (tile_of(jb + j) * KC + c0) * 64 + lane;
 #pragma unroll
@@ -376,19 +409,17 @@ __device__ __forceinline__ void res_tier_role(const SrnnResArgs& a, const SrnnRe
       __syncthreads();
       for (int e = tid; e < nb * MT * 256; e += kResThreads) {
         const int j = e / (MT * 256), r = (e >> 4) % (16 * MT), n = e & 15;
-        const int mt = r >> 4, m = r & 15;
         if (r < mg) {
+          const int m = r & 15;
           const int frag = ((m >> 2) * 16 + n) * 4 + (m & 3);
-          const float* f = reinterpret_cast<const float*>(red + (j * MT + mt) * kResWaves * 64) + frag;
+          const float* f = reinterpret_cast<const float*>(red + (j * MT + (r >> 4)) * kResWaves * 64) + frag;
           float v = 0.f;
 #pragma unroll
           for (int wv = 0; wv < kResWaves; ++wv) v += f[wv * 256];
           const int64_t clip = m_first + r;
-          if (!last) {
-            const int col = (jb + j) * H + ub * 16 + n;                        // slot jb + j, column 16 ub + n
-            const float o = v + T.out_bias[col];
-            res_gstore(T.out_gran + clip * ((int64_t)T.up * H) + col, epoch, __float_as_uint(o));
-            T.out_rows[clip * ((int64_t)T.up * H) + col] = o;
+          if constexpr (!LAST) {
+            const int row = (NG + jb + j) * H + ub * 16 + n;                   // slot (NG + jb + j) / NG, gate row (jb + j) % NG H + unit
+            res_gstore(T.out_gran + clip * ((int64_t)T.up * GH) + row, epoch, __float_as_uint(v + T.out_bias[row]));
           } else {
             const int rr = (jb + j) * 16 + n;                                  // row of this unit block
             const int gidx = ub * T.rpb + rr;
@@ -399,14 +430,24 @@ __device__ __forceinline__ void res_tier_role(const SrnnResArgs& a, const SrnnRe
       }
       __syncthreads();
     };
-    if (T.n_tiles > 0) {
-      run_batch(std::integral_constant<int, 0>{}, 0, 1);
+    if constexpr (NRU > 0) {
+      if (T.n_tiles > 0) run_batch(std::integral_constant<int, 0>{}, 0, 1);
       if constexpr (NRU > 1) {
         if (T.n_tiles > 1) run_batch(std::integral_constant<int, 1>{}, 1, min(T.n_tiles, NRU) - 1);
       }
-      for (int jb = NRU; jb < T.n_tiles; jb += BT) run_batch(std::integral_constant<int, -1>{}, jb, min(BT, T.n_tiles - jb));
     }
+    for (int jb = NRU; jb < T.n_tiles; jb += BT) run_batch(std::integral_constant<int, -1>{}, jb, min(BT, T.n_tiles - jb));
     st.at(4);
+    // ---- W_hh h' for the next update ----------------------------------------------------------------------------------------------------
+    if (upd + 1 < n_upd) {
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+        if (mt * 16 < mg) gate_products(whh, hv[mt], mt);
+      __syncthreads();
+      gate_sums(s_hh);
+      __syncthreads();
+    }
+    st.at(5);
   }
   if (LSTM) {
 #pragma unroll
@@ -707,7 +748,7 @@ __device__ __forceinline__ void res_bottom_role(const SrnnResArgs& a, char* smem
   st.end(a.n_steps);
 }
 
-template <int KC, bool LSTM, int MT>
+template <int KC, bool LSTM>
 __global__ __launch_bounds__(kResThreads) void srnn_resident_kernel(const SrnnResArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   const int b = blockIdx.x;
@@ -720,8 +761,23 @@ __global__ __launch_bounds__(kResThreads) void srnn_resident_kernel(const SrnnRe
   for (int i = 1; i < kResMaxTiers; ++i)
     if (i < a.n_tiers && b >= a.tier[i].block0) ti = i;
   const bool last = ti == a.n_tiers - 1;
-  if (ti == 0) res_tier_role<KC, LSTM, MT, false>(a, a.tier[0], 0, last, smem_raw);
-  else res_tier_role<KC, LSTM, MT, true>(a, a.tier[ti], ti, last, smem_raw);
+  const int mt = a.tier[ti].mt;           // row tiles of 16 clips per workgroup: the tiers with time to spare take more, on fewer CUs
+  if (ti == 0) {
+    if (last) {
+      if (mt == 1) res_tier_role<KC, LSTM, 1, false, true>(a, a.tier[0], 0, smem_raw);
+      else res_tier_role<KC, LSTM, 2, false, true>(a, a.tier[0], 0, smem_raw);
+    } else {
+      if (mt == 1) res_tier_role<KC, LSTM, 1, false, false>(a, a.tier[0], 0, smem_raw);
+      else if (mt == 2) res_tier_role<KC, LSTM, 2, false, false>(a, a.tier[0], 0, smem_raw);
+      else res_tier_role<KC, LSTM, 4, false, false>(a, a.tier[0], 0, smem_raw);
+    }
+  } else if (last) {
+    if (mt == 1) res_tier_role<KC, LSTM, 1, true, true>(a, a.tier[ti], ti, smem_raw);
+    else res_tier_role<KC, LSTM, 2, true, true>(a, a.tier[ti], ti, smem_raw);
+  } else {
+    if (mt == 1) res_tier_role<KC, LSTM, 1, true, false>(a, a.tier[ti], ti, smem_raw);
+    else res_tier_role<KC, LSTM, 2, true, false>(a, a.tier[ti], ti, smem_raw);
+  }
 }
 
 // ---- host side -------------------------------------------------------------------------------------------------------------
@@ -742,24 +798,34 @@ bool srnn_resident_supported(int H, bool lstm, int Hm, int n_out, int Q, int fsb
   return n_out <= 1024 && Q <= 256 && n_out >= Q;
 }
 
-// every workgroup of the launch waits for others: they must all be resident at once, one per CU (a few CUs are left to whatever else runs)
+// Every workgroup of the launch waits for others: they must all be resident at once, one per CU (a few CUs are left to whatever else
+// runs).  A tier's workgroup owns 16 units x 16 mt clips: the tiers start at mt = 1 and, while the launch does not fit, the topmost tier
+// that can still grow doubles its row tiles (it updates least often: its products have the most time; the top tier up to 4, the others 2).
 int srnn_resident_grid(int H, int B, int n_tiers, int* mt_out) {
   const int n_cu = res_cu_count(), KC = H / 16;
-  for (int mt = 1; mt <= 2; mt *= 2) {
-    const int grid = B + n_tiers * KC * ((B + 16 * mt - 1) / (16 * mt));
+  int mt[kResMaxTiers];
+  for (int i = 0; i < n_tiers; ++i) mt[i] = 1;
+  for (;;) {
+    int grid = B;
+    for (int i = 0; i < n_tiers; ++i) grid += KC * ((B + 16 * mt[i] - 1) / (16 * mt[i]));
     if (grid <= n_cu - 8) {
-      if (mt_out) *mt_out = mt;
+      for (int i = 0; i < n_tiers && mt_out; ++i) mt_out[i] = mt[i];
       return grid;
     }
+    int grow = -1;
+    for (int i = 0; i < n_tiers && grow < 0; ++i)
+      if (mt[i] < (i == 0 ? 4 : 2) && 16 * mt[i] < B) grow = i;
+    if (grow < 0) return 0;
+    mt[grow] *= 2;
   }
-  return 0;
 }
 
-size_t srnn_resident_lds_bytes(const SrnnResArgs& a, int mt) {
+size_t srnn_resident_lds_bytes(const SrnnResArgs& a) {
   const int NG = a.lstm ? 4 : 3;
   size_t tier = 0;
   for (int i = 0; i < a.n_tiers; ++i) {
-    const size_t b = (size_t)2 * NG * mt * kResWaves * 64 * 16 + (size_t)16 * mt * (a.tier[i].fsp + 4) * 4 + (size_t)NG * 16 * a.tier[i].fsp * 4;
+    const int mt = a.tier[i].mt;
+    const size_t b = (size_t)NG * mt * kResWaves * 64 * 16 + (size_t)16 * mt * (a.tier[i].fsp + 4) * 4 + (size_t)NG * 16 * a.tier[i].fsp * 4;
     tier = b > tier ? b : tier;
   }
   const int n_extra = a.n_out > 256 ? a.n_out - 256 : 0;
@@ -769,41 +835,33 @@ size_t srnn_resident_lds_bytes(const SrnnResArgs& a, int mt) {
   return lds;
 }
 
-int launch_srnn_resident(const SrnnResArgs& a, int mt, hipStream_t stream) {
+int launch_srnn_resident(const SrnnResArgs& a, hipStream_t stream) {
   const bool lstm = a.lstm != 0;
   if (!srnn_resident_supported(a.H, lstm, a.Hm, a.n_out, a.Q, a.fsb, a.S)) return fail(MMK_ERR_UNSUPPORTED, "srnn resident kernel: geometry H=%d Hm=%d", a.H, a.Hm);
   if (a.n_tiers < 1 || a.n_tiers > kResMaxTiers) return fail(MMK_ERR_INVALID, "srnn resident kernel: %d recurrent tiers", a.n_tiers);
   const int KC = a.H / 16;
   int grid = a.B;
   for (int i = 0; i < a.n_tiers; ++i) {
+    const int mt = a.tier[i].mt;
+    if (!(mt == 1 || mt == 2 || (mt == 4 && i == 0))) return fail(MMK_ERR_INVALID, "srnn resident kernel: %d row tiles per workgroup of tier %d", mt, i);
     if (a.tier[i].block0 != grid) return fail(MMK_ERR_INVALID, "srnn resident kernel: tier %d starts at workgroup %d, %d expected", i, a.tier[i].block0, grid);
     grid += KC * ((a.B + 16 * mt - 1) / (16 * mt));
   }
   if (grid > res_cu_count()) return fail(MMK_ERR_INVALID, "srnn resident kernel: %d workgroups on %d CUs", grid, res_cu_count());
-  const size_t lds = srnn_resident_lds_bytes(a, mt);
+  const size_t lds = srnn_resident_lds_bytes(a);
   if (lds > 160 * 1024) return fail(MMK_ERR_UNSUPPORTED, "srnn resident kernel: %zu bytes of LDS", lds);
   dim3 g(grid), block(kResThreads);
-#define MMK_RES(KC_, MT_)                                                                                   \
-  do {                                                                                                      \
-    if constexpr (KC_ < 32) {                                                                               \
-      if (lstm) hipLaunchKernelGGL((srnn_resident_kernel<KC_, true, MT_>), g, block, lds, stream, a);        \
-    }                                                                                                       \
-    if (!lstm) hipLaunchKernelGGL((srnn_resident_kernel<KC_, false, MT_>), g, block, lds, stream, a);       \
+#define MMK_RES(KC_)                                                                                   \
+  do {                                                                                                 \
+    if constexpr (KC_ < 32) {                                                                          \
+      if (lstm) hipLaunchKernelGGL((srnn_resident_kernel<KC_, true>), g, block, lds, stream, a);        \
+    }                                                                                                  \
+    if (!lstm) hipLaunchKernelGGL((srnn_resident_kernel<KC_, false>), g, block, lds, stream, a);       \
   } while (0)
-  if (mt == 1) {
-    switch (a.H) {
-      case 128: MMK_RES(8, 1); break;
-      case 256: MMK_RES(16, 1); break;
-      default: MMK_RES(32, 1); break;
-    }
-  } else if (mt == 2) {
-    switch (a.H) {
-      case 128: MMK_RES(8, 2); break;
-      case 256: MMK_RES(16, 2); break;
-      default: MMK_RES(32, 2); break;
-    }
-  } else {
-    return fail(MMK_ERR_INVALID, "srnn resident kernel: %d row tiles per workgroup", mt);
+  switch (a.H) {
+    case 128: MMK_RES(8); break;
+    case 256: MMK_RES(16); break;
+    default: MMK_RES(32); break;
   }
 #undef MMK_RES
   MMK_HIP(hipGetLastError());
