@@ -60,7 +60,27 @@ def parse():
                     help="> 0: sampled decode at this temperature (throughput only: the CPU check needs greedy decode)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline sample")
+    ap.add_argument("--tuning", default="", help="execution switches of the plans of this run, NAME=VALUE[;NAME=VALUE...] (include/mmk.h `tuning`): "
+                    "the library reads no environment variable - this is the only way to A/B a kernel choice from the command line")
     return ap.parse_args()
+
+
+def apply_tuning(text):
+    """--tuning -> mimikit_amd.native.PLAN_TUNING, before any plan is built; an MMK_* variable in the environment is refused: it would be ignored
+    by the product library and an A/B run would silently compare two identical configurations"""
+    stray = sorted(k for k in os.environ if k.startswith("MMK_") and k not in ("MMK_DIAG_LIB",) and os.environ.get("MMK_DIAG_LIB") != "1")
+    if stray:
+        raise SystemExit(f"bench.py: {', '.join(stray)} set in the environment - the library does not read it; use --tuning NAME=VALUE")
+    if not text:
+        return
+    from mimikit_amd import native
+    for item in text.split(";"):
+        if not item:
+            continue
+        name, eq, value = item.partition("=")
+        if not eq or not name.startswith("MMK_"):
+            raise SystemExit(f"bench.py: --tuning item {item!r} is not MMK_NAME=VALUE")
+        native.PLAN_TUNING[name] = value
 
 
 # ----------------------------------------------------------------------------- workloads
@@ -154,7 +174,8 @@ class WaveNetJob:
                   # --pmc passes) - taken from profiles/traffic.json, and only if that entry was collected on THIS kernel
                 with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
                     entry = json.load(f).get(self.name, {}).get("persistent", {})
-                if entry.get("bytes_per_step") and str(entry.get("kernel", "")).startswith(kshort):
+                # ... and at THIS clip count (an entry without one was collected at the BASELINE share of 32 clips)
+                if entry.get("bytes_per_step") and str(entry.get("kernel", "")).startswith(kshort) and int(entry.get("clips", 32)) == int(self.clips):
                     traffic = int(entry["bytes_per_step"] * n)
                     traffic_source = (f"profiles/traffic.json, build {entry.get('build')} (commit {entry.get('commit')}): rocprofv3 --pmc "
                                       f"FETCH_SIZE / WRITE_SIZE passes of {entry.get('kernel')}, scaled to {n} steps; not re-measured in this run")
@@ -291,7 +312,8 @@ class SrnnJob:
         return int(total + state)
 
     def roofline(self):
-        """the step is a chain of small launches: HIP events around one whole generate block on the launch stream"""
+        """one generate block is ONE launch (srnn_resident_kernel: every tier, the bottom tier and the head resident, csrc/srnn_resident.hip) plus the
+        class-ring fill in front of it and one up-sampler GEMM per tier behind it: HIP events around the whole block on the launch stream"""
         n = min(self.n_steps, 1600)
         self.net.before_generate((self.idx[:, :self.prompt_len],), None)
         torch.cuda.synchronize()
@@ -300,21 +322,24 @@ class SrnnJob:
         self.net.generate_block((self.idx,), self.prompt_len, n)
         stop.record()
         torch.cuda.synchronize()
+        resident = self.net._plan.resident_blocks() > 0
         self.net.after_generate((self.idx,), None)
         us = start.elapsed_time(stop) * 1e3
         nbytes = self.step_bytes() * n
         achieved = nbytes / (us * 1e-6) / 1e9
         traffic, traffic_source = None, None
-        try:  # PMC-derived HBM bytes per step (separate rocprofv3 --pmc passes with the kernels in turns, profiles/): not measured in this run
+        try:  # PMC-derived HBM bytes per step (separate rocprofv3 --pmc passes over the same 1600-step block, profiles/): not measured in this run
             with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
-                entry = json.load(f).get("srnn_cfg3", {}).get("step_chain", {})
-            if entry.get("bytes_per_step"):
+                entry = json.load(f).get("srnn_cfg3", {}).get("resident" if resident else "step_chain", {})
+            if entry.get("bytes_per_step") and entry.get("clips", self.clips) == self.clips:
                 traffic = int(entry["bytes_per_step"] * n)
                 traffic_source = (f"profiles/traffic.json, build {entry.get('build')} (commit {entry.get('commit')}): rocprofv3 --pmc FETCH_SIZE / "
-                                  f"WRITE_SIZE passes of {entry.get('kernel')} with the kernels in turns, scaled to {n} steps; not re-measured in this run")
+                                  f"WRITE_SIZE passes of {entry.get('kernel')}, {entry.get('clips', self.clips)} clips, scaled to {n} steps; not re-measured in this run")
         except (OSError, ValueError):
             pass
-        return {"bound": "hbm", "kernel": "SampleRNN step chain (srnn_bottom_kernel + srnn_gru_kernel + up-sampler GEMM), one generate block",
+        kernel = ("srnn_resident_kernel<32, false> (all tiers + bottom tier + head, one launch per generate block)" if resident else
+                  "SampleRNN step chain (srnn_bottom_kernel + srnn_gru_kernel, the kernels in turns), one generate block")
+        return {"bound": "hbm", "kernel": kernel,
                 "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
                 "traffic": traffic, "traffic_source": traffic_source, "algorithmic_bytes_per_launch": nbytes, "avg_launch_us": round(us, 1), "launches_timed": 1,
                 "steps_per_launch": n, "us_per_step": round(us / n, 2)}
@@ -629,6 +654,7 @@ def main():
         if world > 1:
             dist.init_process_group(backend="nccl", device_id=device)     # RCCL over xGMI
     torch.set_grad_enabled(False)
+    apply_tuning(args.tuning)
 
     job = JOBS[args.workload](args, device, rank)
     job.to_device()

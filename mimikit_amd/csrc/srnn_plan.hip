@@ -984,7 +984,10 @@ static int resident_grid(mmk_srnn_plan* p, const SrnnCall& call, int64_t n_res, 
   if (S < 2 || !srnn_resident_supported(p->H, c.rnn_kind == 0, c.mlp_hidden, c.q_levels + (c.learn_temp ? 1 : 0), c.q_levels, c.frame_size[c.n_tiers - 1], S)) return 0;
   for (auto& t : p->tiers)
     if (t.fs > 128) return 0;                                 // the class ring holds 256 positions
-  return srnn_resident_grid(p->H, call.M, p->n_rnn_tiers, mt);
+  // (MMK_SRNN_SPARE_CUS: CUs the launch leaves alone; every workgroup of it must be resident at once, and a wait that times out - the CUs were
+  //  held by something else for a second - is reported by mmk_srnn_sync_status and redone in turns by the caller)
+  const char* senv = p->tune.get("MMK_SRNN_SPARE_CUS");
+  return srnn_resident_grid(p->H, call.M, p->n_rnn_tiers, senv ? atoi(senv) : 0, mt);
 }
 
 static int run_resident(mmk_srnn_plan* p, const SrnnCall& call, int64_t t_begin, int64_t n, const int* mt, hipStream_t st) {

@@ -63,7 +63,7 @@ struct SrnnResArgs {
 
 bool srnn_resident_supported(int H, bool lstm, int Hm, int n_out, int Q, int fsb, int S);
 // workgroups of the launch for B clips (0: the geometry does not fit the chip); mt_out[tier]: clips per workgroup of that tier / 16
-int srnn_resident_grid(int H, int B, int n_tiers, int* mt_out);
+int srnn_resident_grid(int H, int B, int n_tiers, int spare_cus, int* mt_out);
 size_t srnn_resident_lds_bytes(const SrnnResArgs& a);
 int launch_srnn_resident(const SrnnResArgs& a, hipStream_t stream);
 

@@ -105,6 +105,36 @@ __device__ __forceinline__ void res_poll_slice(const u64* hr, unsigned tag, f32x
     out[u] = f32x4{__uint_as_float(g[2 * u][0]), __uint_as_float(g[2 * u][2]), __uint_as_float(g[2 * u + 1][0]), __uint_as_float(g[2 * u + 1][2])};
 }
 
+// two rows' slices in one round trip (H = 512: 16 loads in flight per lane); the tags of both are checked, either may be re-read
+__device__ __forceinline__ void res_poll_slice_pair(const u64* h0, const u64* h1, unsigned tag, f32x4 (&o0)[4], f32x4 (&o1)[4], int* err, int code) {
+  u32x4v g[16];
+  unsigned spins = 0;
+  for (;;) {
+    asm volatile("global_load_dwordx4 %0, %16, off sc1\n\tglobal_load_dwordx4 %1, %16, off offset:16 sc1\n\t"
+                 "global_load_dwordx4 %2, %16, off offset:128 sc1\n\tglobal_load_dwordx4 %3, %16, off offset:144 sc1\n\t"
+                 "global_load_dwordx4 %4, %16, off offset:256 sc1\n\tglobal_load_dwordx4 %5, %16, off offset:272 sc1\n\t"
+                 "global_load_dwordx4 %6, %16, off offset:384 sc1\n\tglobal_load_dwordx4 %7, %16, off offset:400 sc1\n\t"
+                 "global_load_dwordx4 %8, %17, off sc1\n\tglobal_load_dwordx4 %9, %17, off offset:16 sc1\n\t"
+                 "global_load_dwordx4 %10, %17, off offset:128 sc1\n\tglobal_load_dwordx4 %11, %17, off offset:144 sc1\n\t"
+                 "global_load_dwordx4 %12, %17, off offset:256 sc1\n\tglobal_load_dwordx4 %13, %17, off offset:272 sc1\n\t"
+                 "global_load_dwordx4 %14, %17, off offset:384 sc1\n\tglobal_load_dwordx4 %15, %17, off offset:400 sc1\n\ts_waitcnt vmcnt(0)"
+                 : "=&v"(g[0]), "=&v"(g[1]), "=&v"(g[2]), "=&v"(g[3]), "=&v"(g[4]), "=&v"(g[5]), "=&v"(g[6]), "=&v"(g[7]),
+                   "=&v"(g[8]), "=&v"(g[9]), "=&v"(g[10]), "=&v"(g[11]), "=&v"(g[12]), "=&v"(g[13]), "=&v"(g[14]), "=&v"(g[15])
+                 : "v"(h0), "v"(h1) : "memory");
+    bool all = true;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) all = all && g[k][1] == tag && g[k][3] == tag;
+    if (all) break;
+    if (res_give_up(spins, err, code)) break;
+    __builtin_amdgcn_s_sleep(1);
+  }
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    o0[u] = f32x4{__uint_as_float(g[2 * u][0]), __uint_as_float(g[2 * u][2]), __uint_as_float(g[2 * u + 1][0]), __uint_as_float(g[2 * u + 1][2])};
+    o1[u] = f32x4{__uint_as_float(g[8 + 2 * u][0]), __uint_as_float(g[8 + 2 * u][2]), __uint_as_float(g[9 + 2 * u][0]), __uint_as_float(g[9 + 2 * u][2])};
+  }
+}
+
 // phase totals of thread 0 of a role's first workgroup, 100 MHz ticks: the diagnostic build only (-DMMK_DIAG) - in the product kernel the
 // 64-bit totals would cost every lane 18 registers next to the resident weights
 struct ResStamp {
@@ -263,14 +293,35 @@ __device__ __forceinline__ void res_tier_role(const SrnnResArgs& a, const SrnnRe
       }
     }
   };
-  // a slice of rows of granules (this wave's K range of the clips of row tile mt), preceded by a light poll - one granule per lane: the
-  // last unit of a producing workgroup for one clip - so that the whole slice (64 KB per row tile) is not requested over and over
-  // while the producers' stores are still on their way
-  auto gather = [&](const u64* base, unsigned tag, int mt, f32x4 (&out)[CPW]) {
+  // Slices of rows of granules (this wave's K range of the clips of a row tile), preceded by a light poll - one granule per lane and row tile: the
+  // last unit of a producing workgroup for one clip - so that the whole slices (64 KB per row tile at H = 512) are not requested over and over
+  // while the producers' stores are still on their way; two row tiles per round trip where the registers allow (H = 512)
+  auto row_of = [&](const u64* base, int mt) -> const u64* {
     const int m = mt * 16 + (lane & 15);
-    const u64* row = base + (int64_t)(m_first + (m < mg ? m : mg - 1)) * H;
-    (void)res_wait(row + (c0 + (lane >> 4) % CPW) * 16 + 15, tag, a.err, 7);
-    res_poll_slice<CPW>(row + c0 * 16 + 4 * (lane >> 4), tag, out, a.err, 7);
+    return base + (int64_t)(m_first + (m < mg ? m : mg - 1)) * H;
+  };
+  auto light_poll = [&](const u64* base, unsigned tag, int mt) {
+    (void)res_wait(row_of(base, mt) + (c0 + (lane >> 4) % CPW) * 16 + 15, tag, a.err, 7);
+  };
+  auto gather = [&](const u64* base, unsigned tag, int mt, f32x4 (&out)[CPW]) {
+    light_poll(base, tag, mt);
+    res_poll_slice<CPW>(row_of(base, mt) + c0 * 16 + 4 * (lane >> 4), tag, out, a.err, 7);
+  };
+  auto gather_own = [&](const u64* base, unsigned tag) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+      if (mt * 16 < mg) light_poll(base, tag, mt);
+    if constexpr (CPW == 4 && MT >= 2) {
+#pragma unroll
+      for (int mt = 0; mt < MT; mt += 2) {
+        if ((mt + 1) * 16 < mg) res_poll_slice_pair(row_of(base, mt) + c0 * 16 + 4 * (lane >> 4), row_of(base, mt + 1) + c0 * 16 + 4 * (lane >> 4), tag, hv[mt], hv[mt + 1], a.err, 7);
+        else if (mt * 16 < mg) res_poll_slice<CPW>(row_of(base, mt) + c0 * 16 + 4 * (lane >> 4), tag, hv[mt], a.err, 7);
+      }
+    } else {
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+        if (mt * 16 < mg) res_poll_slice<CPW>(row_of(base, mt) + c0 * 16 + 4 * (lane >> 4), tag, hv[mt], a.err, 7);
+    }
   };
   // W_hh h of the state the block starts from
   float s_hh[NP][NG];
@@ -371,27 +422,32 @@ __device__ __forceinline__ void res_tier_role(const SrnnResArgs& a, const SrnnRe
       }
     }
     st.at(2);
-    // ---- the new state of the own clips, this wave's K range (from the CPW workgroups that own those units) ---------------------------
+    // ---- the new state of the own clips, this wave's K range (from the CPW workgroups that own those units); the first streamed output tiles
+    //      are asked for ahead of it --------------------------------------------------------------------------------------------------------
+    f32x4 wt[BT][CPW];                                                         // streamed tiles of a batch
+    auto stream_batch = [&](int jb, int nb) {
+      if (jb >= T.n_tiles) return;
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-      if (mt * 16 < mg) gather(T.h_gran + par, epoch, mt, hv[mt]);
+      for (int j = 0; j < BT; ++j) {
+        gf32x4_ptr ws = (gf32x4_ptr)(uintptr_t)T.out_wp + (tile_of(jb + (j < nb ? j : 0)) * KC + c0) * 64 + lane;
+#pragma unroll
+        for (int u = 0; u < CPW; ++u) wt[j][u] = ws[u * 64];
+      }
+    };
+    // (LAST: the urgent tiles are in registers, further ones are asked for when their turn comes; four row tiles: their slices need the registers)
+    if constexpr (!LAST && MT < 4) stream_batch(0, min(BT, T.n_tiles));
+    gather_own(T.h_gran + par, epoch);
+    if constexpr (!LAST && MT >= 4) stream_batch(0, min(BT, T.n_tiles));
     st.at(3);
     // ---- output tiles, batches of at most BT: partial sums -> LDS, summed over the waves, published as granules ------------------------
+    // (PB: first register tile of the batch, or -1: the streamed tiles in wt; the tiles of the NEXT streamed batch are asked for before this one's sums)
     auto run_batch = [&](auto pb, int jb, int nb) {
-      constexpr int PB = decltype(pb)::value;               // first register tile of the batch, or -1: streamed
+      constexpr int PB = decltype(pb)::value;
       constexpr int NB = PB == 0 ? 1 : (PB > 0 ? (NRU - 1 > 0 ? NRU - 1 : 1) : BT);
+      if constexpr (PB < 0 && LAST) stream_batch(jb, nb);
 #pragma unroll
       for (int j = 0; j < NB; ++j) {
         if (j < nb) {
-          f32x4 wt[CPW];
-          if constexpr (PB >= 0) {
-#pragma unroll
-            for (int u = 0; u < CPW; ++u) wt[u] = wout[(PB + j) < NRU ? (PB + j) : 0][u];
-          } else {
-            gf32x4_ptr ws = (gf32x4_ptr)(uintptr_t)T.out_wp + (tile_of(jb + j) * KC + c0) * 64 + lane;
-#pragma unroll
-            for (int u = 0; u < CPW; ++u) wt[u] = ws[u * 64];
-          }
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt) {
             if (mt * 16 < mg) {
@@ -399,13 +455,17 @@ __device__ __forceinline__ void res_tier_role(const SrnnResArgs& a, const SrnnRe
 #pragma unroll
               for (int u = 0; u < CPW; ++u) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) ua = __builtin_amdgcn_mfma_f32_16x16x4f32(hv[mt][u][i], wt[u][i], ua, 0, 0, 0);
+                for (int i = 0; i < 4; ++i) {
+                  if constexpr (PB >= 0) ua = __builtin_amdgcn_mfma_f32_16x16x4f32(hv[mt][u][i], wout[(PB + j) < NRU ? (PB + j) : 0][u][i], ua, 0, 0, 0);
+                  else ua = __builtin_amdgcn_mfma_f32_16x16x4f32(hv[mt][u][i], wt[j][u][i], ua, 0, 0, 0);
+                }
               }
               red[((j * MT + mt) * kResWaves + wave) * 64 + lane] = ua;
             }
           }
         }
       }
+      if constexpr (PB < 0 && !LAST) stream_batch(jb + BT, min(BT, T.n_tiles - jb - BT));
       __syncthreads();
       for (int e = tid; e < nb * MT * 256; e += kResThreads) {
         const int j = e / (MT * 256), r = (e >> 4) % (16 * MT), n = e & 15;
@@ -798,17 +858,17 @@ bool srnn_resident_supported(int H, bool lstm, int Hm, int n_out, int Q, int fsb
   return n_out <= 1024 && Q <= 256 && n_out >= Q;
 }
 
-// Every workgroup of the launch waits for others: they must all be resident at once, one per CU (a few CUs are left to whatever else
+// Every workgroup of the launch waits for others: they must all be resident at once, one per CU (`spare_cus` are left to whatever else
 // runs).  A tier's workgroup owns 16 units x 16 mt clips: the tiers start at mt = 1 and, while the launch does not fit, the topmost tier
 // that can still grow doubles its row tiles (it updates least often: its products have the most time; the top tier up to 4, the others 2).
-int srnn_resident_grid(int H, int B, int n_tiers, int* mt_out) {
-  const int n_cu = res_cu_count(), KC = H / 16;
+int srnn_resident_grid(int H, int B, int n_tiers, int spare_cus, int* mt_out) {
+  const int n_cu = res_cu_count() - spare_cus, KC = H / 16;
   int mt[kResMaxTiers];
   for (int i = 0; i < n_tiers; ++i) mt[i] = 1;
   for (;;) {
     int grid = B;
     for (int i = 0; i < n_tiers; ++i) grid += KC * ((B + 16 * mt[i] - 1) / (16 * mt[i]));
-    if (grid <= n_cu - 8) {
+    if (grid <= n_cu) {
       for (int i = 0; i < n_tiers && mt_out; ++i) mt_out[i] = mt[i];
       return grid;
     }

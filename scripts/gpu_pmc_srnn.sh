@@ -1,13 +1,14 @@
 #!/bin/bash
-# HBM traffic counters of the SampleRNN cfg-3 step kernels.  Counter collection serialises kernels, so the resident mode (two kernels
-# side by side) cannot run under it: the pass runs the tier and bottom kernels in turns (MMK_SRNN_RESIDENT=0), 1600 steps.
+# HBM traffic counters of the SampleRNN cfg-3 generate block: ONE resident launch (srnn_resident_kernel), so counter collection sees a single dispatch;
+# 1600 steps.  TUNING (optional) travels through bench.py --tuning (the library reads no environment variable).
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-$(pwd)}
+T=${TUNING:+--tuning $TUNING}
 cd /tmp
 for C in FETCH_SIZE WRITE_SIZE; do
   rm -rf $R/gpurun_out/pmcs_srnn_$C      # a fresh directory per pass: the summary globs whatever lies in it
-  MMK_SRNN_RESIDENT=0 timeout 200 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $R/gpurun_out/pmcs_srnn_$C -- python3 $R/bench.py --workload srnn_cfg3 --steps 1 --warmup 0 --seconds 0.1 --no-cpu-baseline > $R/gpurun_out/pmcs_srnn_$C.log 2>&1
+  timeout 200 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $R/gpurun_out/pmcs_srnn_$C -- python3 $R/bench.py $T --workload srnn_cfg3 --steps 1 --warmup 0 --seconds 0.1 --no-cpu-baseline > $R/gpurun_out/pmcs_srnn_$C.log 2>&1
   echo "pmc srnn $C exit: $?"
 done
 cd $R

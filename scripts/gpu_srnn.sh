@@ -6,4 +6,4 @@ echo "pytest exit: $?" >> gpurun_out/pytest_srnn.log
 tail -25 gpurun_out/pytest_srnn.log
 timeout 300 python bench.py --workload srnn_cfg3 --no-cpu-baseline --steps 2 --warmup 1 > gpurun_out/bench_srnn.json 2> gpurun_out/bench_srnn.err; echo "bench exit $?"
 grep -o '"value".\{0,30\}\|"us_per_ar_step".\{0,10\}\|"us_per_step".\{0,10\}' gpurun_out/bench_srnn.json
-MMK_SRNN_BOTTOM_MFMA=1 timeout 300 python bench.py --workload srnn_cfg3 --no-cpu-baseline --steps 2 --warmup 1 2>/dev/null | grep -o '"value".\{0,30\}\|"us_per_step".\{0,10\}'
+timeout 300 python bench.py --tuning MMK_SRNN_RESIDENT=0 --workload srnn_cfg3 --no-cpu-baseline --steps 2 --warmup 1 2>/dev/null | grep -o '"value".\{0,30\}\|"us_per_step".\{0,10\}'
