@@ -91,6 +91,13 @@ __device__ __forceinline__ int64_t mulaw_code_pairs(float x, float mu, float C, 
 typedef float mu_f32x4 __attribute__((ext_vector_type(4)));
 typedef long long mu_i64x2 __attribute__((ext_vector_type(2)));
 
+// Stores: a lane's four codes are 32 bytes of the output; written as the lane's own two 16-byte stores, a store INSTRUCTION covers 64 pieces of
+// 16 bytes that lie 32 bytes apart - half of every 128-byte line, the other half coming with the next instruction.  A read-4-write-8 stream with
+// that pattern moves 5.2 - 5.4 TB/s on this chip, with store instructions that cover 1 KB of consecutive lanes each 6.0 - 6.2
+// (scripts/probes/rw_mix.hip; copy 5.9, fill 6.8, read 7.2).  So the wave first passes the codes between lanes (in-range codes are < q <= 4096: two
+// per 32-bit word, two ds_bpermute per store): store A takes samples 2 l, 2 l + 1 of the wave's 256 from lane l / 2, store B samples
+// 128 + 2 l .. from lane 32 + l / 2.  A wave that holds an out-of-range sample (codes beyond 16 bits: the reference does not clamp), or
+// that reaches past the end, keeps the lane's own stores for that round.
 __global__ __launch_bounds__(256) void mulaw_compress_stream_kernel(const mu_f32x4* __restrict__ x4, mu_i64x2* __restrict__ codes2, int64_t n4, int q,
                                                                    float C, const float* __restrict__ edges) {
   extern __shared__ float2 s_pairs[];
@@ -100,6 +107,7 @@ __global__ __launch_bounds__(256) void mulaw_compress_stream_kernel(const mu_f32
   const float mu = (float)(q - 1);
   const float inv_log = 1.f / log1pf(mu * C);
   constexpr int kU = 4;
+  const int lane = threadIdx.x & 63;
   const int64_t tile = (int64_t)blockDim.x * kU;                    // float4s per workgroup and round
   for (int64_t base = (int64_t)blockIdx.x * tile; base < n4; base += (int64_t)gridDim.x * tile) {
     mu_f32x4 v[kU];
@@ -111,14 +119,23 @@ __global__ __launch_bounds__(256) void mulaw_compress_stream_kernel(const mu_f32
 #pragma unroll
     for (int k = 0; k < kU; ++k) {
       const int64_t i = base + k * blockDim.x + threadIdx.x;
-      if (i < n4) {
-        mu_i64x2 o0, o1;
-        o0[0] = mulaw_code_pairs(v[k][0], mu, C, inv_log, s_pairs, edges, q);
-        o0[1] = mulaw_code_pairs(v[k][1], mu, C, inv_log, s_pairs, edges, q);
-        o1[0] = mulaw_code_pairs(v[k][2], mu, C, inv_log, s_pairs, edges, q);
-        o1[1] = mulaw_code_pairs(v[k][3], mu, C, inv_log, s_pairs, edges, q);
-        codes2[2 * i] = o0;
-        codes2[2 * i + 1] = o1;
+      const int64_t w0 = base + k * blockDim.x + (threadIdx.x & ~63);       // the wave's first float4 of this round
+      const bool in_range = fabsf(v[k][0]) <= 1.f && fabsf(v[k][1]) <= 1.f && fabsf(v[k][2]) <= 1.f && fabsf(v[k][3]) <= 1.f;
+      const bool exchange = w0 + 64 <= n4 && __all(in_range);               // (wave-uniform)
+      long long c[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) c[e] = mulaw_code_pairs(v[k][e], mu, C, inv_log, s_pairs, edges, q);
+      if (exchange) {
+        const int lo = (int)c[0] | ((int)c[1] << 16), hi = (int)c[2] | ((int)c[3] << 16);
+        const int src_a = (lane >> 1) << 2, src_b = (32 + (lane >> 1)) << 2;
+        const int a_lo = __builtin_amdgcn_ds_bpermute(src_a, lo), a_hi = __builtin_amdgcn_ds_bpermute(src_a, hi);
+        const int b_lo = __builtin_amdgcn_ds_bpermute(src_b, lo), b_hi = __builtin_amdgcn_ds_bpermute(src_b, hi);
+        const int pa = (lane & 1) ? a_hi : a_lo, pb = (lane & 1) ? b_hi : b_lo;
+        codes2[2 * w0 + lane] = mu_i64x2{(long long)(pa & 0xffff), (long long)((unsigned)pa >> 16)};
+        codes2[2 * w0 + 64 + lane] = mu_i64x2{(long long)(pb & 0xffff), (long long)((unsigned)pb >> 16)};
+      } else if (i < n4) {
+        codes2[2 * i] = mu_i64x2{c[0], c[1]};
+        codes2[2 * i + 1] = mu_i64x2{c[2], c[3]};
       }
     }
   }
@@ -213,7 +230,7 @@ extern "C" int mmk_mulaw_compress_f32_i64(const float* x, int64_t* codes, int64_
   if (edges && aligned && q_levels <= kMuLawLdsLevels / 2 && n >= (1 << 16)) {
     const int64_t n4 = n >> 2;
     int64_t sblocks = (n4 + 1023) / 1024;
-    sblocks = sblocks > 2048 ? 2048 : sblocks;       // 8 workgroups per CU: every CU's 32 wave slots taken, grid-stride beyond
+    sblocks = sblocks > 8192 ? 8192 : sblocks;       // (1024 .. 8192 workgroups: +3 % from the first to the last, scripts/probes/rw_mix.hip)
     hipLaunchKernelGGL(mulaw_compress_stream_kernel, dim3((unsigned)sblocks), dim3(256), (size_t)q_levels * sizeof(float2), (hipStream_t)stream,
                        reinterpret_cast<const mu_f32x4*>(x), reinterpret_cast<mu_i64x2*>(codes), n4, q_levels, compression, edges);
     MMK_HIP(hipGetLastError());

@@ -78,10 +78,25 @@ constexpr int kFftWaveLds = 16 * 68;      // complex elements of a wave's privat
 // whose lanes walk k = lane + 64 j reads conflict-free as before (lane -> fft_swz(lane) is a permutation inside each group of 16).
 __device__ __forceinline__ int fft_swz(int k) { return k ^ (((k >> 4) & 3) << 2); }
 
+// The twiddles of a lane for the whole kernel: t1[k1 - 1] = W1024^{lane k1} (pass 1), t2[c - 1] = W64^{(lane & 3) c} (pass 2), k1, c = 1 .. 15.
+// Read from the table once per kernel instead of 30 LDS reads (the pass-1 ones with strides lane k1: 2- to 8-way bank conflicts for even k1)
+// and their address arithmetic per transform; 60 registers.
+struct FftLaneTw {
+  cf32 t1[15], t2[15];
+  __device__ __forceinline__ void load(const cf32* tw, int lane) {
+#pragma unroll
+    for (int k = 1; k < 16; ++k) {
+      t1[k - 1] = tw[(lane * k) & 1023];
+      t2[k - 1] = tw[(16 * (lane & 3) * k) & 1023];
+    }
+  }
+};
+
 // Forward DFT of 1024 points.  In: v[r] = x[lane + 64 r].  Out: X[k] in natural order in buf[0..1023] (SWZ: at buf[fft_swz(k)];
-// wave-private LDS, kFftWaveLds complex); tw[m] = exp(-2 pi i m / 1024).  Wave-synchronous: no workgroup barrier.
-template <bool SWZ = false>
-__device__ __forceinline__ void fft1024_wave(cf32 (&v)[16], cf32* buf, const cf32* tw, int lane) {
+// wave-private LDS, kFftWaveLds complex); tw[m] = exp(-2 pi i m / 1024), or ltw: the lane's twiddles in registers.  Wave-synchronous: no
+// workgroup barrier.
+template <bool SWZ, bool REGTW>
+__device__ __forceinline__ void fft1024_wave_impl(cf32 (&v)[16], cf32* buf, const cf32* tw, int lane, const FftLaneTw& ltw) {
   constexpr int N = 1024;
   const int k1b = lane >> 2, lo2 = lane & 3;                  // (k1, b) of pass 2 = (k1, c mod 4) of pass 3
   // ---- pass 1: DFT over n1, twiddle W1024^{n' k1}, transpose ---------------------------------------------------------
@@ -89,7 +104,7 @@ __device__ __forceinline__ void fft1024_wave(cf32 (&v)[16], cf32* buf, const cf3
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
     const int k1 = (i >> 2) + 4 * (i & 3);
-    if (k1 != 0) v[i] = cmul(v[i], tw[(lane * k1) & (N - 1)]);
+    if (k1 != 0) v[i] = cmul(v[i], REGTW ? ltw.t1[k1 - 1 < 0 ? 0 : k1 - 1] : tw[(lane * k1) & (N - 1)]);
     buf[k1 * 68 + lane] = v[i];
   }
   __builtin_amdgcn_wave_barrier();
@@ -101,7 +116,7 @@ __device__ __forceinline__ void fft1024_wave(cf32 (&v)[16], cf32* buf, const cf3
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
     const int c = (i >> 2) + 4 * (i & 3);
-    if (c != 0) v[i] = cmul(v[i], tw[(16 * lo2 * c) & (N - 1)]);
+    if (c != 0) v[i] = cmul(v[i], REGTW ? ltw.t2[c - 1 < 0 ? 0 : c - 1] : tw[(16 * lo2 * c) & (N - 1)]);
     buf[lane * 17 + c] = v[i];                              // row (k1, b)
   }
   __builtin_amdgcn_wave_barrier();
@@ -118,6 +133,16 @@ __device__ __forceinline__ void fft1024_wave(cf32 (&v)[16], cf32* buf, const cf3
     for (int d = 0; d < 4; ++d) buf[(SWZ ? (k1b ^ (lo2 << 2)) : k1b) + 16 * (lo2 + 4 * g) + 256 * d] = v[4 * g + d];
   }
   __builtin_amdgcn_wave_barrier();
+}
+
+template <bool SWZ = false>
+__device__ __forceinline__ void fft1024_wave(cf32 (&v)[16], cf32* buf, const cf32* tw, int lane) {
+  FftLaneTw none;
+  fft1024_wave_impl<SWZ, false>(v, buf, tw, lane, none);
+}
+template <bool SWZ = false>
+__device__ __forceinline__ void fft1024_wave_regtw(cf32 (&v)[16], cf32* buf, const FftLaneTw& ltw, int lane) {
+  fft1024_wave_impl<SWZ, true>(v, buf, nullptr, lane, ltw);
 }
 
 }  // namespace mmk

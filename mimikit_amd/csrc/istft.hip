@@ -10,6 +10,7 @@
 // All three are HBM-bound: a frame pair is 8 KiB of spectrum in, 8 KiB of windowed frames out (ISTFT), then the overlap-add
 // reads every windowed sample once.  Two real inverse transforms share one complex FFT:
 //       Z = A + i B  (A, B Hermitian-extended half spectra)   =>   ifft(Z) = a + i b ,   ifft(Z) = conj(fft(conj Z)) / N.
+#include <mutex>
 #include <vector>
 
 #include "mmk_common.h"
@@ -62,14 +63,56 @@ __device__ __forceinline__ void istft_load(IstftRaw<MODE>& raw, const float* __r
 
 constexpr int kRing = 2048;
 
-__device__ __forceinline__ float hann2(int m) {             // squared periodic Hann of length 1024
-  const float w = 0.5f - 0.5f * cospif(2.0f * (float)m / 1024.0f);
-  return w * w;
+// ---- the tables of spectral_util.h ------------------------------------------------------------------------------------------------
+__device__ cf32 g_tw1024[1024];
+__device__ float g_hann1024[1024];
+__device__ float g_hann2048[2048];
+__device__ cf32 g_w2048[1088];
+
+__global__ void spectral_tables_kernel() {
+  const int m = blockIdx.x * blockDim.x + threadIdx.x;
+  if (m < 1024) {
+    float sn, cs;
+    sincospif(-2.0f * (float)m / 1024.0f, &sn, &cs);
+    g_tw1024[m] = cf32{cs, sn};
+    g_hann1024[m] = 0.5f - 0.5f * cospif(2.0f * (float)m / 1024.0f);          // periodic Hann (functionals.py:513)
+  }
+  if (m < 2048) g_hann2048[m] = 0.5f - 0.5f * cospif((float)m / 1024.0f);
+  if (m < 1088) {
+    float sn, cs;
+    sincospif(-(float)m / 1024.0f, &sn, &cs);
+    g_w2048[m] = cf32{cs, sn};
+  }
+}
+
+int spectral_tables(hipStream_t stream, SpectralTables* out) {
+  constexpr int kMaxDevices = 64;
+  static SpectralTables tables[kMaxDevices];
+  static bool ready[kMaxDevices];
+  static std::mutex lock;
+  int dev = 0;
+  MMK_HIP(hipGetDevice(&dev));
+  if (dev < 0 || dev >= kMaxDevices) return fail(MMK_ERR_INVALID, "spectral tables: device %d", dev);
+  std::lock_guard<std::mutex> guard(lock);
+  if (!ready[dev]) {
+    SpectralTables t;
+    MMK_HIP(hipGetSymbolAddress((void**)&t.tw1024, HIP_SYMBOL(g_tw1024)));
+    MMK_HIP(hipGetSymbolAddress((void**)&t.hann1024, HIP_SYMBOL(g_hann1024)));
+    MMK_HIP(hipGetSymbolAddress((void**)&t.hann2048, HIP_SYMBOL(g_hann2048)));
+    MMK_HIP(hipGetSymbolAddress((void**)&t.w2048, HIP_SYMBOL(g_w2048)));
+    hipLaunchKernelGGL(spectral_tables_kernel, dim3(8), dim3(256), 0, stream);
+    MMK_HIP(hipGetLastError());
+    MMK_HIP(hipStreamSynchronize(stream));      // once per device and process: later launches may come on any stream
+    tables[dev] = t;
+    ready[dev] = true;
+  }
+  *out = tables[dev];
+  return MMK_OK;
 }
 
 // One transformed pair (a[m] = Re(Y[m]) / N, b[m] = -Im(Y[m]) / N in buf) into the ring at its positions, then
 // everything below `upto` (the next pair's first sample) is final: divided by the window envelope, written, zeroed.
-__device__ __forceinline__ void ola_pair(float* ring, const cf32* buf, const float (&win)[16], const float* envt, int64_t f, int hop,
+__device__ __forceinline__ void ola_pair(float* ring, const cf32* buf, const float (&win)[16], const float* envt, const float* __restrict__ hann, int64_t f, int hop,
                                          bool has_b, int64_t frontier, int64_t upto, int64_t t0, int64_t t1, int64_t n_frames,
                                          float* __restrict__ orow, int lane) {
   constexpr int N = 1024;
@@ -107,7 +150,10 @@ __device__ __forceinline__ void ola_pair(float* ring, const cf32* buf, const flo
         g_hi = g_hi < n_frames - 1 ? g_hi : n_frames - 1;
         const int64_t g_lo = (t - N + 1 <= 0) ? 0 : (t - N + hop) / hop;
         env = 0.f;
-        for (int64_t g = g_lo; g <= g_hi; ++g) env += hann2((int)(t - g * hop));
+        for (int64_t g = g_lo; g <= g_hi; ++g) {
+          const float w = hann[t - g * hop];
+          env += w * w;
+        }
       }
       orow[t] = acc / env;
     }
@@ -116,7 +162,7 @@ __device__ __forceinline__ void ola_pair(float* ring, const cf32* buf, const flo
 
 template <int MODE>
 __global__ __launch_bounds__(64 * kIstftWaves) __attribute__((amdgpu_waves_per_eu(2, 2)))
-void istft1024_kernel(const float* __restrict__ spec, const float* __restrict__ mag, int64_t n_frames, int hop, int seg_hops,
+void istft1024_kernel(const SpectralTables T, const float* __restrict__ spec, const float* __restrict__ mag, int64_t n_frames, int hop, int seg_hops,
                       int segs_per_clip, int64_t total_tasks, int64_t n_out, float* __restrict__ out) {
   constexpr int N = 1024;
   __shared__ cf32 tw[N];
@@ -125,15 +171,18 @@ void istft1024_kernel(const float* __restrict__ spec, const float* __restrict__ 
   __shared__ float rings[kIstftWaves * kRing];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  make_twiddles(tw, tid, 64 * kIstftWaves);
+  load_twiddles(tw, T.tw1024, tid, 64 * kIstftWaves);
   for (int r = tid; r < hop; r += 64 * kIstftWaves) {       // (two workgroups per CU: no room for a separate w^2 table)
     float e = 0.f;
-    for (int o = r; o < N; o += hop) e += hann2(o);
+    for (int o = r; o < N; o += hop) {
+      const float w = T.hann1024[o];
+      e += w * w;
+    }
     envt[r] = e;
   }
   float win[16];                                            // periodic Hann / N at n = lane + 64 r
 #pragma unroll
-  for (int r = 0; r < 16; ++r) win[r] = (0.5f - 0.5f * cospif(2.0f * (float)(lane + 64 * r) / (float)N)) * (1.0f / (float)N);
+  for (int r = 0; r < 16; ++r) win[r] = T.hann1024[lane + 64 * r] * (1.0f / (float)N);
   __syncthreads();
   cf32* buf = bufs + wave * kFftWaveLds;
   float* ring = rings + wave * kRing;
@@ -180,9 +229,187 @@ void istft1024_kernel(const float* __restrict__ spec, const float* __restrict__ 
       fft1024_wave<true>(v, buf, tw, lane);
       const bool more = f + 2 <= f_hi;
       const int64_t upto = more ? (f + 2) * hop : t1;             // the ring is cleared again by the next segment
-      ola_pair(ring, buf, win, envt, f, hop, has_b, frontier, upto, t0, t1, n_frames, orow, lane);
+      ola_pair(ring, buf, win, envt, T.hann1024, f, hop, has_b, frontier, upto, t0, t1, n_frames, orow, lane);
       frontier = upto;
       __builtin_amdgcn_wave_barrier();
+    }
+  }
+}
+
+// ---- the same for hop = n_fft / 4 (the reference's ratio), without the ring ------------------------------------------------------------------
+// With hop = 256 a lane that reads the transformed frame as samples n = 4 lane + i + 256 j (i, j < 4) holds, for EVERY frame, the same four
+// positions of each of the four output blocks the frame covers: the overlap-add is a shift register of 3 x 4 partial sums per lane - no LDS ring,
+// no read-modify-write (64 LDS accesses per pair), same summation order as the ring (frame order).  A block is final when its fourth frame has
+// been added: times the reciprocal of the window envelope (one IEEE division per lane and kernel instead of one per output sample), one
+// 16-byte store per lane.  The spectrum side: every bin is loaded and turned from polar to cartesian ONCE, by the lane that owns it
+// (k = lane + 64 j); the mirrored half of the transform's input (bins N - n) comes from lane 64 - lane through ds_bpermute - the kernel above
+// loads and converts the bins 1 .. 511 twice (32 sincos per pair and lane instead of 18).
+template <int MODE>
+struct IstftBins {
+  cf32 a[9], b[9];
+  float ma[9], mb[9];                                        // MODE 2 only (dead otherwise)
+};
+template <int MODE>
+__device__ __forceinline__ void istft_load_bins(IstftBins<MODE>& raw, const float* __restrict__ spec, const float* __restrict__ mag, int64_t fa,
+                                                int64_t fb, int lane) {
+  const cf32* sa = reinterpret_cast<const cf32*>(spec) + fa * 513 + lane;
+  const cf32* sb = reinterpret_cast<const cf32*>(spec) + fb * 513 + lane;
+#pragma unroll
+  for (int j = 0; j < 9; ++j) {
+    const int o = (j < 8 || lane == 0) ? 64 * j : 0;          // bin 512 exists in lane 0 only (clamped: an unconditional load)
+    raw.a[j] = sa[o];
+    raw.b[j] = sb[o];
+    if (MODE == 2) {
+      raw.ma[j] = mag[fa * 513 + lane + o];
+      raw.mb[j] = mag[fb * 513 + lane + o];
+    }
+  }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(64 * kIstftWaves) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void istft1024q_kernel(const SpectralTables T, const float* __restrict__ spec, const float* __restrict__ mag, int64_t n_frames, int seg_hops,
+                       int segs_per_clip, int64_t total_tasks, int64_t n_out, float* __restrict__ out) {
+  constexpr int N = 1024, hop = N / 4;
+  typedef float f32x4q __attribute__((ext_vector_type(4)));
+  __shared__ cf32 tw[N];
+  __shared__ cf32 bufs[kIstftWaves * kFftWaveLds];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  load_twiddles(tw, T.tw1024, tid, 64 * kIstftWaves);
+  float win[4][4], renv[4];                                 // periodic Hann / N at n = 256 j + 4 lane + i; 1 / envelope at t mod hop = 4 lane + i
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    float e = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float w = T.hann1024[256 * j + 4 * lane + i];
+      win[j][i] = w * (1.0f / (float)N);
+      e += w * w;                                            // (the order of the table the ring kernel builds: o = r, r + hop, ...)
+    }
+    renv[i] = 1.0f / e;
+  }
+  __syncthreads();
+  cf32* buf = bufs + wave * kFftWaveLds;
+  const int64_t t_end = N / 2 + n_out;                      // positions t are in the untrimmed overlap-add signal
+  const int mirror = ((64 - lane) & 63) << 2;               // ds_bpermute address of the lane that owns bin N - n
+
+  for (int64_t task = (int64_t)blockIdx.x * kIstftWaves + wave; task < total_tasks; task += (int64_t)gridDim.x * kIstftWaves) {
+    const int64_t b = task / segs_per_clip;
+    const int64_t sgm = task - b * segs_per_clip;
+    const int64_t t0 = N / 2 + sgm * seg_hops * hop;
+    int64_t t1 = t0 + (int64_t)seg_hops * hop;
+    t1 = t1 < t_end ? t1 : t_end;
+    if (t0 >= t1) continue;
+    const int64_t f_lo = (t0 - N + 1 <= 0) ? 0 : (t0 - N + hop) / hop;          // first frame that covers t0
+    int64_t f_hi = (t1 - 1) / hop;                                             // last frame that covers t1 - 1
+    f_hi = f_hi < n_frames - 1 ? f_hi : n_frames - 1;
+    const int64_t fbase = b * n_frames;
+    float* orow = out + b * n_out - N / 2;
+    float R[3][4];                                           // partial sums of the three blocks still waiting for frames
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) R[q][i] = 0.f;
+    // a block of hop samples is final once frame `blk` has been added: envelope, one 16-byte store per lane
+    auto finish = [&](int64_t blk, const float (&e)[4]) {
+      const int64_t t = blk * hop + 4 * lane;
+      if (t < t0 || t >= t1) return;                          // (t0, t1 are multiples of hop: whole blocks)
+      f32x4q o;
+      if (blk >= 4 && blk <= n_frames - 1) {                  // every frame that covers the block exists
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i] = e[i] * renv[i];
+      } else {                                                // the first / last n_fft samples of a clip
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int64_t ti = t + i;
+          int64_t g_hi = ti / hop;
+          g_hi = g_hi < n_frames - 1 ? g_hi : n_frames - 1;
+          const int64_t g_lo = (ti - N + 1 <= 0) ? 0 : (ti - N + hop) / hop;
+          float env = 0.f;
+          for (int64_t g = g_lo; g <= g_hi; ++g) {
+            const float w = T.hann1024[ti - g * hop];
+            env += w * w;
+          }
+          o[i] = e[i] / env;
+        }
+      }
+      *reinterpret_cast<f32x4q*>(orow + t) = o;
+    };
+    // pairs are always (even, odd) frames, whatever the segment: two real transforms that share a complex one pick up
+    // each other's rounding, so a fixed pairing makes every frame's samples independent of the launch geometry
+    const int64_t f_first = f_lo & ~(int64_t)1, f_last = n_frames - 1;
+    int64_t next_blk = f_first;                               // the first block no frame has completed yet
+    IstftBins<MODE> raw;
+    istft_load_bins<MODE>(raw, spec, mag, fbase + f_first, fbase + (f_first + 1 <= f_last ? f_first + 1 : f_first), lane);
+    for (int64_t f = f_first; f <= f_hi; f += 2) {
+      const bool has_b = f + 1 <= f_last;
+      // Z = A + i B (n <= 512) or conj(A) + i conj(B) (bins N - n); the FFT input is conj(Z)
+      cf32 v[16], mz[9];
+#pragma unroll
+      for (int j = 0; j < 9; ++j) {
+        cf32 A = istft_bin<MODE>(raw.a[j], raw.ma[j]);
+        cf32 B = istft_bin<MODE>(raw.b[j], raw.mb[j]);
+        if ((j == 0 || j == 8) && lane == 0) A.y = 0.f, B.y = 0.f;   // DC / Nyquist of a real signal: the C2R transform ignores them
+        if (!has_b) B = cf32{0.f, 0.f};
+        if (j < 8) v[j] = cf32{A.x - B.y, -(A.y + B.x)};
+        mz[j] = cf32{A.x + B.y, -(B.x - A.y)};                 // what the slot of bin N - k takes
+      }
+      {   // next pair's bins: in flight under this pair's transform (clamped, so unconditional)
+        const int64_t na = f + 2 <= f_last ? f + 2 : f_last;
+        const int64_t nb = f + 3 <= f_last ? f + 3 : f_last;
+        istft_load_bins<MODE>(raw, spec, mag, fbase + na, fbase + nb, lane);
+      }
+#pragma unroll
+      for (int r = 8; r < 16; ++r) {
+        // slot n = lane + 64 r takes bin k = N - n = (64 - lane) + 64 (15 - r): lane 64 - lane's bin 15 - r; lane 0: its own bin 64 (16 - r)
+        const cf32 src = mz[15 - r];
+        const float x = __int_as_float(__builtin_amdgcn_ds_bpermute(mirror, __float_as_int(src.x)));
+        const float y = __int_as_float(__builtin_amdgcn_ds_bpermute(mirror, __float_as_int(src.y)));
+        v[r] = lane == 0 ? mz[16 - r] : cf32{x, y};
+      }
+      fft1024_wave<true>(v, buf, tw, lane);
+      // the two frames' samples n = 256 j + 4 lane + i: a[n] = Re(Y[n]) / N, b[n] = -Im(Y[n]) / N
+      cf32 y[4][4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const cf32* src = buf + fft_swz(4 * lane) + 256 * j;       // (the swizzle keeps four consecutive points together)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) y[j][i] = src[i];
+      }
+      float e[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        e[i] = fmaf(y[0][i].x, win[0][i], R[0][i]);
+        R[0][i] = fmaf(y[1][i].x, win[1][i], R[1][i]);
+        R[1][i] = fmaf(y[2][i].x, win[2][i], R[2][i]);
+        R[2][i] = y[3][i].x * win[3][i];
+      }
+      finish(f, e);
+      if (has_b) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          e[i] = fmaf(-y[0][i].y, win[0][i], R[0][i]);
+          R[0][i] = fmaf(-y[1][i].y, win[1][i], R[1][i]);
+          R[1][i] = fmaf(-y[2][i].y, win[2][i], R[2][i]);
+          R[2][i] = -y[3][i].y * win[3][i];
+        }
+        finish(f + 1, e);
+      }
+      __builtin_amdgcn_wave_barrier();                      // buf is rewritten by the next pair
+      next_blk = f + (has_b ? 2 : 1);
+    }
+    // the clip's end: the blocks behind its last frame are what the shift register still holds
+    for (; next_blk * hop < t1; ++next_blk) {
+      float e[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        e[i] = R[0][i];
+        R[0][i] = R[1][i];
+        R[1][i] = R[2][i];
+        R[2][i] = 0.f;
+      }
+      finish(next_blk, e);
     }
   }
 }
@@ -240,7 +467,7 @@ __device__ __forceinline__ void stft_load(StftRaw& raw, const float* __restrict_
 // exist in HBM (12 KB per frame-iteration instead of 20.5).  wave and tprev are ping-pong buffers, so the frames a segment
 // recomputes for its left edge read the same inputs as their owner and write the same values.
 __global__ __launch_bounds__(64 * kIstftWaves) __attribute__((amdgpu_waves_per_eu(2, 2)))
-void gla1024_iter_kernel(const float* __restrict__ wave_in, const float* __restrict__ mag, const float* __restrict__ tprev_in,
+void gla1024_iter_kernel(const SpectralTables T, const float* __restrict__ wave_in, const float* __restrict__ mag, const float* __restrict__ tprev_in,
                          float* __restrict__ tprev_out, float momentum, int64_t n_frames, int hop, int seg_hops, int segs_per_clip,
                          int64_t total_tasks, int64_t n_out, float* __restrict__ wave_out) {
   constexpr int N = 1024, bins = 513;
@@ -250,16 +477,19 @@ void gla1024_iter_kernel(const float* __restrict__ wave_in, const float* __restr
   __shared__ float rings[kIstftWaves * kRing];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  make_twiddles(tw, tid, 64 * kIstftWaves);
+  load_twiddles(tw, T.tw1024, tid, 64 * kIstftWaves);
   for (int r = tid; r < hop; r += 64 * kIstftWaves) {
     float e = 0.f;
-    for (int o = r; o < N; o += hop) e += hann2(o);
+    for (int o = r; o < N; o += hop) {
+      const float w = T.hann1024[o];
+      e += w * w;
+    }
     envt[r] = e;
   }
   float win[16], win_n[16];                                 // periodic Hann at n = lane + 64 r, and the same / N
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
-    win[r] = 0.5f - 0.5f * cospif(2.0f * (float)(lane + 64 * r) / (float)N);
+    win[r] = T.hann1024[lane + 64 * r];
     win_n[r] = win[r] * (1.0f / (float)N);
   }
   __syncthreads();
@@ -348,7 +578,7 @@ void gla1024_iter_kernel(const float* __restrict__ wave_in, const float* __restr
       fft1024_wave<true>(v, buf, tw, lane);
       const bool more = f + 2 <= f_hi;
       const int64_t upto = more ? (f + 2) * hop : t1;
-      ola_pair(ring, buf, win_n, envt, f, hop, has_b, frontier, upto, t0, t1, n_frames, orow, lane);
+      ola_pair(ring, buf, win_n, envt, T.hann1024, f, hop, has_b, frontier, upto, t0, t1, n_frames, orow, lane);
       frontier = upto;
       __builtin_amdgcn_wave_barrier();
     }
@@ -365,36 +595,73 @@ constexpr int kStftWaves = MMK_STFT_WAVES;      // waves (= frame pairs in fligh
 
 template <int OUT>
 __global__ __launch_bounds__(64 * kStftWaves) __attribute__((amdgpu_waves_per_eu(MMK_STFT_WPE, MMK_STFT_WPE)))
-void stft1024_kernel(const float* __restrict__ x, int64_t x_row_stride, int64_t n_samples, int hop, int center, int reflect,
+void stft1024_kernel(const SpectralTables T, const float* __restrict__ x, int64_t x_row_stride, int64_t n_samples, int hop, int center, int reflect,
                      int64_t n_frames, int64_t total_pairs, float* __restrict__ out, float* __restrict__ tprev, float momentum) {
   constexpr int N = 1024, bins = 513;
-  __shared__ cf32 tw[N];
+#ifndef MMK_STFT_REGTW
+#define MMK_STFT_REGTW 1      // the lane's 30 twiddles in registers for the whole kernel (no table in LDS at all)
+#endif
+  __shared__ cf32 tw[MMK_STFT_REGTW ? 1 : N];
   __shared__ cf32 bufs[kStftWaves * kFftWaveLds];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  make_twiddles(tw, tid, 64 * kStftWaves);
   float win[16];                                            // periodic Hann at n = lane + 64 r (functionals.py:513)
 #pragma unroll
-  for (int r = 0; r < 16; ++r) win[r] = 0.5f - 0.5f * cospif(2.0f * (float)(lane + 64 * r) / (float)N);
-  __syncthreads();
+  for (int r = 0; r < 16; ++r) win[r] = T.hann1024[lane + 64 * r];
+  FftLaneTw ltw;
+  if (MMK_STFT_REGTW) {
+    ltw.load(T.tw1024, lane);
+  } else {
+    load_twiddles(tw, T.tw1024, tid, 64 * kStftWaves);
+    __syncthreads();
+  }
   cf32* buf = bufs + wave * kFftWaveLds;
   const int64_t pairs_per_row = (n_frames + 1) >> 1;
   const int64_t pad = center ? N / 2 : 0;
   const int64_t stride = (int64_t)gridDim.x * kStftWaves;
 
   const bool small = total_pairs < (1ll << 31);            // (32-bit division of the pair index where it fits: an int64 division is ~100 vector instructions)
-  for (int64_t pair = (int64_t)blockIdx.x * kStftWaves + wave; pair < total_pairs; pair += stride) {
-    const int64_t b = small ? (int64_t)((unsigned)pair / (unsigned)pairs_per_row) : pair / pairs_per_row;
-    const int64_t f0 = (pair - b * pairs_per_row) * 2;
-    const bool has_b = (f0 + 1) < n_frames;
-    // (loading the next pair before this transform was measured: slower, the kernel is bound by vector-ALU issue)
-    StftRaw raw;
+#ifndef MMK_STFT_PREFETCH
+#define MMK_STFT_PREFETCH 0   // the NEXT pair's samples are asked for before this pair's transform
+#endif
+  // A wave's pairs are a chain of load -> transform -> store: with the loads of pair i + 1 issued only after the stores of pair i, every pair paid
+  // the whole memory latency (~2 us under load) on top of its ~4 us of arithmetic - and taking 3000 vector instructions of table building out of
+  // every wave changed nothing.  The samples of the next pair are requested first; their 20 registers live through the transform.
+  auto pair_start = [&](int64_t pair, int64_t& b, int64_t& f0) {
+    b = small ? (int64_t)((unsigned)pair / (unsigned)pairs_per_row) : pair / pairs_per_row;
+    f0 = (pair - b * pairs_per_row) * 2;
+  };
+  StftRaw raw;
+  int64_t pair = (int64_t)blockIdx.x * kStftWaves + wave;
+  if (MMK_STFT_PREFETCH && pair < total_pairs) {
+    int64_t b, f0;
+    pair_start(pair, b, f0);
     stft_load(raw, x + b * x_row_stride, f0 * hop - pad, hop, n_samples, reflect, lane);
+  }
+  for (; pair < total_pairs; pair += stride) {
+    int64_t b, f0;
+    pair_start(pair, b, f0);
+    const bool has_b = (f0 + 1) < n_frames;
+    if (!MMK_STFT_PREFETCH) stft_load(raw, x + b * x_row_stride, f0 * hop - pad, hop, n_samples, reflect, lane);
     cf32 v[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) v[r] = cf32{raw.a[r] * win[r], has_b ? raw.b[r] * win[r] : 0.f};   // frame f0 -> re, f0 + 1 -> im
+    if (MMK_STFT_PREFETCH) {
+      const int64_t np = pair + stride < total_pairs ? pair + stride : pair;      // (clamped: an unconditional load)
+      int64_t nb, nf0;
+      pair_start(np, nb, nf0);
+      stft_load(raw, x + nb * x_row_stride, nf0 * hop - pad, hop, n_samples, reflect, lane);
+    }
     const int64_t ea = (b * n_frames + f0) * bins;
-    fft1024_wave<true>(v, buf, tw, lane);
+#ifndef MMK_STFT_ABL
+#define MMK_STFT_ABL 0        // timing experiments only: 1 no stores, 2 no transform (the window's values written straight to LDS), 3 both
+#endif
+    if (MMK_STFT_ABL & 2) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) buf[lane + 64 * r] = v[r];
+      __builtin_amdgcn_wave_barrier();
+    } else if (MMK_STFT_REGTW) fft1024_wave_regtw<true>(v, buf, ltw, lane);
+    else fft1024_wave<true>(v, buf, tw, lane);
     // the two real spectra:  A[k] = (Z[k] + conj(Z[N-k])) / 2 ,  B[k] = (Z[k] - conj(Z[N-k])) / (2i)
 #pragma unroll
     for (int jj = 0; jj < 9; ++jj) {
@@ -410,6 +677,7 @@ void stft1024_kernel(const float* __restrict__ x, int64_t x_row_stride, int64_t 
           const cf32 pz = z + zc, mz = z - zc;
           const cf32 pp = pz * pz, mm = mz * mz;
           float* o = out + ea;
+          if ((MMK_STFT_ABL & 1) && pp.x != 1.2345f) continue;
           o[k] = 0.5f * __builtin_amdgcn_sqrtf(pp.x + mm.y);
           if (has_b) o[bins + k] = 0.5f * __builtin_amdgcn_sqrtf(pp.y + mm.x);
           continue;
@@ -718,8 +986,15 @@ static int launch_istft(const float* spec, const float* mag, int mode, int batch
   const int64_t total_tasks = (int64_t)batch * segs_per_clip;
   const int64_t wgs = (total_tasks + kIstftWaves - 1) / kIstftWaves;
   const dim3 grid((unsigned)(wgs < 512 ? wgs : 512)), block(64 * kIstftWaves);   // 2 workgroups per CU, all resident
-#define MMK_ISTFT_LAUNCH(M) \
-  hipLaunchKernelGGL((istft1024_kernel<M>), grid, block, 0, stream, spec, mag, n_frames, hop, seg_hops, segs_per_clip, total_tasks, n_out, out)
+  SpectralTables T;
+  MMK_TRY(spectral_tables(stream, &T));
+#define MMK_ISTFT_LAUNCH(M)                                                                                                                     \
+  do {                                                                                                                                        \
+    if (hop == 256 && (reinterpret_cast<uintptr_t>(out) & 15) == 0)                                                                            \
+      hipLaunchKernelGGL((istft1024q_kernel<M>), grid, block, 0, stream, T, spec, mag, n_frames, seg_hops, segs_per_clip, total_tasks, n_out, out); \
+    else                                                                                                                                      \
+      hipLaunchKernelGGL((istft1024_kernel<M>), grid, block, 0, stream, T, spec, mag, n_frames, hop, seg_hops, segs_per_clip, total_tasks, n_out, out); \
+  } while (0)
   if (mode == 0) MMK_ISTFT_LAUNCH(0);
   else if (mode == 1) MMK_ISTFT_LAUNCH(1);
   else MMK_ISTFT_LAUNCH(2);
@@ -735,8 +1010,10 @@ int launch_stft1024(const float* x, int64_t x_row_stride, int batch, int64_t n_s
   const int64_t wgs = (total_pairs + kStftWaves - 1) / kStftWaves;
   const int64_t resident = 256 * (4 * MMK_STFT_WPE / kStftWaves);          // workgroups that are resident together on the chip
   const dim3 grid((unsigned)(wgs < resident ? wgs : resident)), block(64 * kStftWaves);
+  SpectralTables T;
+  MMK_TRY(spectral_tables(stream, &T));
 #define MMK_STFT_LAUNCH(O) \
-  hipLaunchKernelGGL((stft1024_kernel<O>), grid, block, 0, stream, x, x_row_stride, n_samples, hop, center, reflect, n_frames, \
+  hipLaunchKernelGGL((stft1024_kernel<O>), grid, block, 0, stream, T, x, x_row_stride, n_samples, hop, center, reflect, n_frames, \
                      total_pairs, out, tprev, momentum)
   switch (out_mode) {
     case 0: MMK_STFT_LAUNCH(0); break;
@@ -901,10 +1178,12 @@ extern "C" int mmk_gla_f32(const float* mag, const float* init, int32_t batch, i
     float* wave_other = wave_b;
     const float* tin = tprev_a;
     float* tout = tprev_b;
+    SpectralTables T;
+    MMK_TRY(spectral_tables(s, &T));
     for (int it = 0; it < n_iter; ++it) {
       float* dst = it == n_iter - 1 ? out : wave_other;
       if (n_fft == 1024) {
-        hipLaunchKernelGGL(gla1024_iter_kernel, grid, block, 0, s, wave_in, mag, tin, tout, m, n_frames, hop, seg_hops, segs_per_clip,
+        hipLaunchKernelGGL(gla1024_iter_kernel, grid, block, 0, s, T, wave_in, mag, tin, tout, m, n_frames, hop, seg_hops, segs_per_clip,
                            total_tasks, n_out, dst);
         MMK_HIP(hipGetLastError());
       } else if (int rc = launch_gla2048_iter(wave_in, mag, tin, tout, m, batch, n_frames, hop, dst, s)) {

@@ -20,14 +20,7 @@ namespace mmk {
 constexpr int kN = 1024, kN2 = 2048, kBins2 = 1025;
 constexpr int kRing2 = 4096;                                // live window of a frame: n_fft + hop <= 4095 samples
 
-__device__ __forceinline__ float hann2048(int m) { return 0.5f - 0.5f * cospif((float)m / 1024.0f); }
-
-// W^k for the bins a lane touches
-__device__ __forceinline__ cf32 w2048(int k) {
-  float sn, cs;
-  sincospif(-(float)k / 1024.0f, &sn, &cs);
-  return cf32{cs, sn};
-}
+// (the periodic Hann window of 2048 samples and W^k for the bins a lane touches: tables of spectral_util.h, T.hann2048 / T.w2048)
 
 // the 2048 samples of a frame as z[n] = (x[2n], x[2n+1]), n = lane + 64 r; zero or reflect padding at the clip's ends
 __device__ __forceinline__ void load_frame2048(cf32 (&v)[16], const float* __restrict__ xr, int64_t start, int64_t n_samples, int reflect,
@@ -78,19 +71,19 @@ __device__ __forceinline__ cf32 tangle_conj(cf32 a, cf32 b, cf32 w) {
 // OUT 0: (re, im)   OUT 1: (|S|, angle S)   OUT 2: angle S   OUT 4: |S|  (MagSpec)
 template <int OUT>
 __global__ __launch_bounds__(64 * kIstftWaves) __attribute__((amdgpu_waves_per_eu(2, 2)))
-void stft2048_kernel(const float* __restrict__ x, int64_t x_row_stride, int64_t n_samples, int hop, int center, int reflect,
+void stft2048_kernel(const SpectralTables T, const float* __restrict__ x, int64_t x_row_stride, int64_t n_samples, int hop, int center, int reflect,
                      int64_t n_frames, int64_t total_frames, float* __restrict__ out) {
   __shared__ cf32 tw[kN];
   __shared__ cf32 bufs[kIstftWaves * kFftWaveLds];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  make_twiddles(tw, tid, 64 * kIstftWaves);
+  load_twiddles(tw, T.tw1024, tid, 64 * kIstftWaves);
   cf32 win[16];                                             // periodic Hann of 2048 at samples 2n, 2n + 1
 #pragma unroll
-  for (int r = 0; r < 16; ++r) win[r] = cf32{hann2048(2 * (lane + 64 * r)), hann2048(2 * (lane + 64 * r) + 1)};
+  for (int r = 0; r < 16; ++r) win[r] = cf32{T.hann2048[2 * (lane + 64 * r)], T.hann2048[2 * (lane + 64 * r) + 1]};
   cf32 wk[17];                                              // W^k of this lane's bins k = lane + 64 j
 #pragma unroll
-  for (int j = 0; j < 17; ++j) wk[j] = w2048(lane + 64 * j);
+  for (int j = 0; j < 17; ++j) wk[j] = T.w2048[lane + 64 * j];
   __syncthreads();
   cf32* buf = bufs + wave * kFftWaveLds;
   const int64_t pad = center ? kN2 / 2 : 0;
@@ -120,7 +113,7 @@ void stft2048_kernel(const float* __restrict__ x, int64_t x_row_stride, int64_t 
 
 // ---- overlap-add of one transformed frame + emission of what is final ---------------------------------------------------------
 // buf holds Y = FFT(conj Z): x[2m] = Re Y[m] / N, x[2m + 1] = -Im Y[m] / N; win = the window of those samples / N
-__device__ __forceinline__ void ola_frame2048(float* ring, const cf32* buf, const cf32 (&win)[16], const float* envt, int64_t f, int hop,
+__device__ __forceinline__ void ola_frame2048(float* ring, const cf32* buf, const cf32 (&win)[16], const float* envt, const float* __restrict__ hann, int64_t f, int hop,
                                               int64_t frontier, int64_t upto, int64_t t0, int64_t t1, int64_t n_frames,
                                               float* __restrict__ orow, int lane) {
   const int pa = (int)((f * hop) & (kRing2 - 1));
@@ -149,7 +142,7 @@ __device__ __forceinline__ void ola_frame2048(float* ring, const cf32* buf, cons
         const int64_t g_lo = (t - kN2 + 1 <= 0) ? 0 : (t - kN2 + hop) / hop;
         env = 0.f;
         for (int64_t g = g_lo; g <= g_hi; ++g) {
-          const float w = hann2048((int)(t - g * hop));
+          const float w = hann[t - g * hop];
           env += w * w;
         }
       }
@@ -158,11 +151,11 @@ __device__ __forceinline__ void ola_frame2048(float* ring, const cf32* buf, cons
   }
 }
 
-__device__ __forceinline__ void envelope_table2048(float* envt, int hop, int tid, int nthreads) {
+__device__ __forceinline__ void envelope_table2048(float* envt, const float* __restrict__ hann, int hop, int tid, int nthreads) {
   for (int r = tid; r < hop; r += nthreads) {
     float e = 0.f;
     for (int o = r; o < kN2; o += hop) {
-      const float w = hann2048(o);
+      const float w = hann[o];
       e += w * w;
     }
     envt[r] = e;
@@ -188,7 +181,7 @@ __device__ __forceinline__ bool segment2048(Seg2048& s, int64_t task, int segs_p
 // MODE 0: spec = (batch, frames, 1025) complex (re, im);  MODE 1: (abs, angle) pairs;  MODE 2: mag plane x complex plane.
 template <int MODE>
 __global__ __launch_bounds__(64 * kIstftWaves) __attribute__((amdgpu_waves_per_eu(1, 1)))
-void istft2048_kernel(const float* __restrict__ spec, const float* __restrict__ mag, int64_t n_frames, int hop, int seg_hops,
+void istft2048_kernel(const SpectralTables T, const float* __restrict__ spec, const float* __restrict__ mag, int64_t n_frames, int hop, int seg_hops,
                       int segs_per_clip, int64_t total_tasks, int64_t n_out, float* __restrict__ out) {
   __shared__ cf32 tw[kN];
   __shared__ float envt[kN2];
@@ -196,14 +189,14 @@ void istft2048_kernel(const float* __restrict__ spec, const float* __restrict__ 
   __shared__ float rings[kIstftWaves * kRing2];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  make_twiddles(tw, tid, 64 * kIstftWaves);
-  envelope_table2048(envt, hop, tid, 64 * kIstftWaves);
+  load_twiddles(tw, T.tw1024, tid, 64 * kIstftWaves);
+  envelope_table2048(envt, T.hann2048, hop, tid, 64 * kIstftWaves);
   cf32 win[16], wn[16];                                     // window / N at samples 2n, 2n + 1; W^n, n = lane + 64 r
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int n = lane + 64 * r;
-    win[r] = cf32{hann2048(2 * n) * (1.0f / kN), hann2048(2 * n + 1) * (1.0f / kN)};
-    wn[r] = w2048(n);
+    win[r] = cf32{T.hann2048[2 * n] * (1.0f / kN), T.hann2048[2 * n + 1] * (1.0f / kN)};
+    wn[r] = T.w2048[n];
   }
   __syncthreads();
   cf32* buf = bufs + wave * kFftWaveLds;
@@ -250,7 +243,7 @@ void istft2048_kernel(const float* __restrict__ spec, const float* __restrict__ 
       load_bins(f + 1 <= sg.f_hi ? f + 1 : sg.f_hi);         // next frame's bins: in flight under this transform
       fft1024_wave(v, buf, tw, lane);
       const int64_t upto = f + 1 <= sg.f_hi ? (f + 1) * hop : sg.t1;
-      ola_frame2048(ring, buf, win, envt, f, hop, frontier, upto, sg.t0, sg.t1, n_frames, orow, lane);
+      ola_frame2048(ring, buf, win, envt, T.hann2048, f, hop, frontier, upto, sg.t0, sg.t1, n_frames, orow, lane);
       frontier = upto;
       __builtin_amdgcn_wave_barrier();
     }
@@ -260,7 +253,7 @@ void istft2048_kernel(const float* __restrict__ spec, const float* __restrict__ 
 // ---- one whole Griffin-Lim iteration: stft -> phase update -> istft, per output segment ---------------------------------------
 //   rebuilt = stft(wave_in) ; angles = normalise(rebuilt - m tprev_in) ; tprev_out = rebuilt ; wave_out = istft(mag angles)
 __global__ __launch_bounds__(64 * kIstftWaves) __attribute__((amdgpu_waves_per_eu(1, 1)))
-void gla2048_iter_kernel(const float* __restrict__ wave_in, const float* __restrict__ mag, const float* __restrict__ tprev_in,
+void gla2048_iter_kernel(const SpectralTables T, const float* __restrict__ wave_in, const float* __restrict__ mag, const float* __restrict__ tprev_in,
                          float* __restrict__ tprev_out, float momentum, int64_t n_frames, int hop, int seg_hops, int segs_per_clip,
                          int64_t total_tasks, int64_t n_out, float* __restrict__ wave_out) {
   __shared__ cf32 tw[kN];
@@ -269,17 +262,17 @@ void gla2048_iter_kernel(const float* __restrict__ wave_in, const float* __restr
   __shared__ float rings[kIstftWaves * kRing2];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  make_twiddles(tw, tid, 64 * kIstftWaves);
-  envelope_table2048(envt, hop, tid, 64 * kIstftWaves);
+  load_twiddles(tw, T.tw1024, tid, 64 * kIstftWaves);
+  envelope_table2048(envt, T.hann2048, hop, tid, 64 * kIstftWaves);
   cf32 win[16], win_n[16], wn[16];
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int n = lane + 64 * r;
-    win[r] = cf32{hann2048(2 * n), hann2048(2 * n + 1)};
+    win[r] = cf32{T.hann2048[2 * n], T.hann2048[2 * n + 1]};
     win_n[r] = win[r] * (1.0f / kN);
-    wn[r] = w2048(n);                                       // W^k for k = lane + 64 j, j < 16, as well
+    wn[r] = T.w2048[n];                                       // W^k for k = lane + 64 j, j < 16, as well
   }
-  const cf32 w_last = w2048(1024);                           // bin 1024 (lane 0 only)
+  const cf32 w_last = T.w2048[1024];                           // bin 1024 (lane 0 only)
   __syncthreads();
   cf32* buf = bufs + wave * kFftWaveLds;
   float* ring = rings + wave * kRing2;
@@ -341,7 +334,7 @@ void gla2048_iter_kernel(const float* __restrict__ wave_in, const float* __restr
       __builtin_amdgcn_wave_barrier();
       fft1024_wave(v, buf, tw, lane);
       const int64_t upto = f + 1 <= sg.f_hi ? (f + 1) * hop : sg.t1;
-      ola_frame2048(ring, buf, win_n, envt, f, hop, frontier, upto, sg.t0, sg.t1, n_frames, orow, lane);
+      ola_frame2048(ring, buf, win_n, envt, T.hann2048, f, hop, frontier, upto, sg.t0, sg.t1, n_frames, orow, lane);
       frontier = upto;
       __builtin_amdgcn_wave_barrier();
     }
@@ -368,8 +361,10 @@ int launch_stft2048(const float* x, int64_t x_row_stride, int batch, int64_t n_s
   const int64_t total = (int64_t)batch * n_frames;
   const int64_t wgs = (total + kIstftWaves - 1) / kIstftWaves;
   const dim3 grid((unsigned)(wgs < 512 ? wgs : 512)), block(64 * kIstftWaves);   // 2 workgroups per CU (200 registers)
+  SpectralTables T;
+  MMK_TRY(spectral_tables(stream, &T));
 #define MMK_STFT_LAUNCH(O) \
-  hipLaunchKernelGGL((stft2048_kernel<O>), grid, block, 0, stream, x, x_row_stride, n_samples, hop, center, reflect, n_frames, total, out)
+  hipLaunchKernelGGL((stft2048_kernel<O>), grid, block, 0, stream, T, x, x_row_stride, n_samples, hop, center, reflect, n_frames, total, out)
   switch (out_mode) {
     case 0: MMK_STFT_LAUNCH(0); break;
     case 1: MMK_STFT_LAUNCH(1); break;
@@ -389,8 +384,10 @@ int launch_istft2048(const float* spec, const float* mag, int mode, int batch, i
   const int64_t total_tasks = (int64_t)batch * segs_per_clip;
   const int64_t wgs = (total_tasks + kIstftWaves - 1) / kIstftWaves;
   const dim3 grid((unsigned)(wgs < 256 ? wgs : 256)), block(64 * kIstftWaves);
+  SpectralTables T;
+  MMK_TRY(spectral_tables(stream, &T));
 #define MMK_ISTFT_LAUNCH(M) \
-  hipLaunchKernelGGL((istft2048_kernel<M>), grid, block, 0, stream, spec, mag, n_frames, hop, seg_hops, segs_per_clip, total_tasks, n_out, out)
+  hipLaunchKernelGGL((istft2048_kernel<M>), grid, block, 0, stream, T, spec, mag, n_frames, hop, seg_hops, segs_per_clip, total_tasks, n_out, out)
   if (mode == 0) MMK_ISTFT_LAUNCH(0);
   else if (mode == 1) MMK_ISTFT_LAUNCH(1);
   else MMK_ISTFT_LAUNCH(2);
@@ -407,7 +404,9 @@ int launch_gla2048_iter(const float* wave_in, const float* mag, const float* tpr
   const int64_t total_tasks = (int64_t)batch * segs_per_clip;
   const int64_t wgs = (total_tasks + kIstftWaves - 1) / kIstftWaves;
   const dim3 grid((unsigned)(wgs < 256 ? wgs : 256)), block(64 * kIstftWaves);
-  hipLaunchKernelGGL(gla2048_iter_kernel, grid, block, 0, stream, wave_in, mag, tprev_in, tprev_out, momentum, n_frames, hop, seg_hops,
+  SpectralTables T;
+  MMK_TRY(spectral_tables(stream, &T));
+  hipLaunchKernelGGL(gla2048_iter_kernel, grid, block, 0, stream, T, wave_in, mag, tprev_in, tprev_out, momentum, n_frames, hop, seg_hops,
                      segs_per_clip, total_tasks, n_out, wave_out);
   MMK_HIP(hipGetLastError());
   return MMK_OK;

@@ -6,12 +6,20 @@ namespace mmk {
 
 constexpr int kIstftWaves = 4;
 
-__device__ __forceinline__ void make_twiddles(cf32* tw, int tid, int nthreads) {
-  for (int m = tid; m < 1024; m += nthreads) {
-    float sn, cs;
-    sincospif(-2.0f * (float)m / 1024.0f, &sn, &cs);
-    tw[m] = cf32{cs, sn};
-  }
+// The tables every n_fft = 1024 / 2048 kernel needs - the twiddles exp(-2 pi i m / 1024), the periodic Hann windows of 1024 and 2048 samples, the
+// untangling factors exp(-pi i k / 1024) of the 2048-point transforms - are made ONCE per device by a small kernel (sincospif / cospif: the same
+// values the kernels used to compute for themselves) into arrays of the code object, and read from L2 afterwards.  Computed per workgroup they were
+// ~3000 vector instructions per wave in front of the ~500 per frame pair of a wave that handles nine pairs: 40 % of the STFT kernel.
+struct SpectralTables {
+  const cf32* tw1024;        // [1024]
+  const float* hann1024;     // [1024]
+  const float* hann2048;     // [2048]
+  const cf32* w2048;         // [1088]: exp(-pi i k / 1024), k <= 1087 (the bins lane + 64 j of a lane, j <= 16)
+};
+int spectral_tables(hipStream_t stream, SpectralTables* out);     // (istft.hip)
+
+__device__ __forceinline__ void load_twiddles(cf32* tw, const cf32* __restrict__ table, int tid, int nthreads) {
+  for (int m = tid; m < 1024; m += nthreads) tw[m] = table[m];
 }
 
 // sin / cos of an angle in radians: three-constant Cody-Waite reduction to |r| <= pi/4 and the cephes single-precision
