@@ -585,6 +585,190 @@ void gla1024_iter_kernel(const SpectralTables T, const float* __restrict__ wave_
   }
 }
 
+// ---- the same for hop = n_fft / 4: no ring, no second trip of the new spectra through LDS ------------------------------------------------------
+// The inverse half as in istft1024q_kernel (shift-register overlap-add, reciprocal envelope, 16-byte stores, the mirrored bins from lane
+// 64 - lane through ds_bpermute instead of an LDS image of both spectra); the phase normalisation multiplies by one reciprocal per bin instead of
+// dividing both components.
+__global__ __launch_bounds__(64 * kIstftWaves) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void gla1024q_iter_kernel(const SpectralTables T, const float* __restrict__ wave_in, const float* __restrict__ mag, const float* __restrict__ tprev_in,
+                          float* __restrict__ tprev_out, float momentum, int64_t n_frames, int seg_hops, int segs_per_clip, int64_t total_tasks,
+                          int64_t n_out, float* __restrict__ wave_out) {
+  constexpr int N = 1024, bins = 513, hop = N / 4;
+  typedef float f32x4q __attribute__((ext_vector_type(4)));
+  __shared__ cf32 tw[N];
+  __shared__ cf32 bufs[kIstftWaves * kFftWaveLds];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  load_twiddles(tw, T.tw1024, tid, 64 * kIstftWaves);
+  float win[16];                                            // periodic Hann at n = lane + 64 r (the forward transform's load order)
+#pragma unroll
+  for (int r = 0; r < 16; ++r) win[r] = T.hann1024[lane + 64 * r];
+  float win_n[4][4], renv[4];                               // Hann / N at n = 256 j + 4 lane + i; 1 / envelope at t mod hop = 4 lane + i
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    float e = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float w = T.hann1024[256 * j + 4 * lane + i];
+      win_n[j][i] = w * (1.0f / (float)N);
+      e += w * w;
+    }
+    renv[i] = 1.0f / e;
+  }
+  __syncthreads();
+  cf32* buf = bufs + wave * kFftWaveLds;
+  const int64_t t_end = N / 2 + n_out;
+  const int mirror = ((64 - lane) & 63) << 2;
+
+  for (int64_t task = (int64_t)blockIdx.x * kIstftWaves + wave; task < total_tasks; task += (int64_t)gridDim.x * kIstftWaves) {
+    const int64_t b = task / segs_per_clip;
+    const int64_t sgm = task - b * segs_per_clip;
+    const int64_t t0 = N / 2 + sgm * seg_hops * hop;
+    int64_t t1 = t0 + (int64_t)seg_hops * hop;
+    t1 = t1 < t_end ? t1 : t_end;
+    if (t0 >= t1) continue;
+    const int64_t f_lo = (t0 - N + 1 <= 0) ? 0 : (t0 - N + hop) / hop;
+    int64_t f_hi = (t1 - 1) / hop;
+    f_hi = f_hi < n_frames - 1 ? f_hi : n_frames - 1;
+    const float* xr = wave_in + b * n_out;
+    float* orow = wave_out + b * n_out - N / 2;
+    float R[3][4];
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) R[q][i] = 0.f;
+    auto finish = [&](int64_t blk, const float (&e)[4]) {
+      const int64_t t = blk * hop + 4 * lane;
+      if (t < t0 || t >= t1) return;
+      f32x4q o;
+      if (blk >= 4 && blk <= n_frames - 1) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i] = e[i] * renv[i];
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int64_t ti = t + i;
+          int64_t g_hi = ti / hop;
+          g_hi = g_hi < n_frames - 1 ? g_hi : n_frames - 1;
+          const int64_t g_lo = (ti - N + 1 <= 0) ? 0 : (ti - N + hop) / hop;
+          float env = 0.f;
+          for (int64_t g = g_lo; g <= g_hi; ++g) {
+            const float w = T.hann1024[ti - g * hop];
+            env += w * w;
+          }
+          o[i] = e[i] / env;
+        }
+      }
+      *reinterpret_cast<f32x4q*>(orow + t) = o;
+    };
+    // (even, odd) pairs whatever the segment: a frame that two segments compute gets bit-identical values in both
+    const int64_t f_first = f_lo & ~(int64_t)1;
+    int64_t next_blk = f_first;
+    for (int64_t f = f_first; f <= f_hi; f += 2) {
+      const bool has_b = f + 1 < n_frames;
+      const int64_t ea = (b * n_frames + f) * bins;
+      // ---- forward: frames f, f + 1 of the current waveform (center, reflect) -------------------------------------------------
+      StftRaw raw;
+      stft_load(raw, xr, f * hop - N / 2, hop, n_out, 1, lane);
+      cf32 v[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) v[r] = cf32{raw.a[r] * win[r], has_b ? raw.b[r] * win[r] : 0.f};
+      // previous spectra and magnitudes of the bins this lane updates: in flight under the transform
+      cf32 tpa[9], tpb[9];
+      const int64_t eb = has_b ? ea + bins : ea;
+#pragma unroll
+      for (int jj = 0; jj < 9; ++jj) {
+        const int k = lane + 64 * jj;
+        const int kc = k < bins ? k : 0;                    // clamped: unconditional loads
+        tpa[jj] = *reinterpret_cast<const cf32*>(tprev_in + 2 * (ea + kc));
+        tpb[jj] = *reinterpret_cast<const cf32*>(tprev_in + 2 * (eb + kc));
+      }
+      fft1024_wave<true>(v, buf, tw, lane);
+      float mga[9], mgb[9];                                  // (asked for behind the transform: 18 registers less to carry through it)
+#pragma unroll
+      for (int jj = 0; jj < 9; ++jj) {
+        const int k = lane + 64 * jj;
+        const int kc = k < bins ? k : 0;
+        mga[jj] = mag[ea + kc];
+        mgb[jj] = mag[eb + kc];
+      }
+      // ---- phase update on the two real spectra; the inverse transform's input straight from the registers ------------------------
+      cf32 mz[9];
+#pragma unroll
+      for (int jj = 0; jj < 9; ++jj) {
+        const int k = lane + 64 * jj;
+        cf32 za = cf32{0.f, 0.f}, zb = cf32{0.f, 0.f};
+        if (k < bins) {
+          const cf32 z = buf[fft_swz(lane) + 64 * jj];
+          const cf32 zc = buf[(((N - k) & (N - 1)) & ~63) | fft_swz((64 - lane) & 63)];
+          const cf32 sa = cf32{0.5f * (z.x + zc.x), 0.5f * (z.y - zc.y)};
+          const cf32 sb = cf32{0.5f * (z.y + zc.y), -0.5f * (z.x - zc.x)};
+          const cf32 ga = cf32{sa.x - momentum * tpa[jj].x, sa.y - momentum * tpa[jj].y};
+          const cf32 gb = cf32{sb.x - momentum * tpb[jj].x, sb.y - momentum * tpb[jj].y};
+          const float ra = mga[jj] / (sqrtf(ga.x * ga.x + ga.y * ga.y) + 1e-16f), rb = mgb[jj] / (sqrtf(gb.x * gb.x + gb.y * gb.y) + 1e-16f);
+          za = cf32{ga.x * ra, ga.y * ra};
+          zb = cf32{gb.x * rb, gb.y * rb};
+          if (k == 0 || k == 512) za.y = 0.f, zb.y = 0.f;    // DC / Nyquist: the C2R transform ignores them
+          *reinterpret_cast<cf32*>(tprev_out + 2 * (ea + k)) = sa;
+          if (has_b) *reinterpret_cast<cf32*>(tprev_out + 2 * (ea + bins + k)) = sb;
+          else zb = cf32{0.f, 0.f};
+        }
+        // Z = A + i B (n <= 512) or conj(A) + i conj(B) (bins N - n); the FFT input is conj(Z)
+        if (jj < 8) v[jj] = cf32{za.x - zb.y, -(za.y + zb.x)};
+        mz[jj] = cf32{za.x + zb.y, -(zb.x - za.y)};
+      }
+      __builtin_amdgcn_wave_barrier();                      // every lane has read its bins of the forward transform
+#pragma unroll
+      for (int r = 8; r < 16; ++r) {
+        const cf32 src = mz[15 - r];
+        const float x = __int_as_float(__builtin_amdgcn_ds_bpermute(mirror, __float_as_int(src.x)));
+        const float y = __int_as_float(__builtin_amdgcn_ds_bpermute(mirror, __float_as_int(src.y)));
+        v[r] = lane == 0 ? mz[16 - r] : cf32{x, y};
+      }
+      fft1024_wave<true>(v, buf, tw, lane);
+      cf32 y[4][4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const cf32* src = buf + fft_swz(4 * lane) + 256 * j;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) y[j][i] = src[i];
+      }
+      float e[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        e[i] = fmaf(y[0][i].x, win_n[0][i], R[0][i]);
+        R[0][i] = fmaf(y[1][i].x, win_n[1][i], R[1][i]);
+        R[1][i] = fmaf(y[2][i].x, win_n[2][i], R[2][i]);
+        R[2][i] = y[3][i].x * win_n[3][i];
+      }
+      finish(f, e);
+      if (has_b) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          e[i] = fmaf(-y[0][i].y, win_n[0][i], R[0][i]);
+          R[0][i] = fmaf(-y[1][i].y, win_n[1][i], R[1][i]);
+          R[1][i] = fmaf(-y[2][i].y, win_n[2][i], R[2][i]);
+          R[2][i] = -y[3][i].y * win_n[3][i];
+        }
+        finish(f + 1, e);
+      }
+      __builtin_amdgcn_wave_barrier();
+      next_blk = f + (has_b ? 2 : 1);
+    }
+    for (; next_blk * hop < t1; ++next_blk) {                // the clip's end: the blocks behind its last frame
+      float e[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        e[i] = R[0][i];
+        R[0][i] = R[1][i];
+        R[1][i] = R[2][i];
+        R[2][i] = 0.f;
+      }
+      finish(next_blk, e);
+    }
+  }
+}
+
 #ifndef MMK_STFT_WAVES
 #define MMK_STFT_WAVES 4
 #endif
@@ -1182,7 +1366,10 @@ extern "C" int mmk_gla_f32(const float* mag, const float* init, int32_t batch, i
     MMK_TRY(spectral_tables(s, &T));
     for (int it = 0; it < n_iter; ++it) {
       float* dst = it == n_iter - 1 ? out : wave_other;
-      if (n_fft == 1024) {
+      if (n_fft == 1024 && hop == 256 && (reinterpret_cast<uintptr_t>(dst) & 15) == 0) {
+        hipLaunchKernelGGL(gla1024q_iter_kernel, grid, block, 0, s, T, wave_in, mag, tin, tout, m, n_frames, seg_hops, segs_per_clip, total_tasks, n_out, dst);
+        MMK_HIP(hipGetLastError());
+      } else if (n_fft == 1024) {
         hipLaunchKernelGGL(gla1024_iter_kernel, grid, block, 0, s, T, wave_in, mag, tin, tout, m, n_frames, hop, seg_hops, segs_per_clip,
                            total_tasks, n_out, dst);
         MMK_HIP(hipGetLastError());
