@@ -514,16 +514,16 @@ class FeatureJob:
         frames = self.units_per_pass()
         # algorithmic bytes: what any implementation must read and write
         if self.name == "mulaw":
-            nbytes, kernel = self.x.numel() * 12, "mulaw_compress_kernel"
+            nbytes, kernel = self.x.numel() * 12, "mulaw_compress_stream_kernel"
         elif self.name == "stft":
             nbytes, kernel = frames * (4 * 256 + 4 * 513), "stft1024_kernel"
         elif self.name == "istft":      # a frame's complex bins in, hop samples out
-            nbytes, kernel = frames * (8 * 513 + 4 * 256), "istft1024_kernel"
+            nbytes, kernel = frames * (8 * 513 + 4 * 256), "istft1024q_kernel"
         else:   # per iteration: magnitudes, previous spectrum and waveform in; spectrum and waveform out (the phase estimates
             # themselves never need to exist in HBM); plus the first inverse transform of mag x initial phases
             it = 32
             nbytes = frames * (it * (20 * 513 + 2 * 4 * 256) + 12 * 513 + 4 * 256)
-            kernel = "Griffin-Lim chain: istft1024_kernel + 32 x gla1024_iter_kernel (stft -> phase update -> istft per launch)"
+            kernel = "Griffin-Lim chain: istft1024q_kernel + 32 x gla1024q_iter_kernel (stft -> phase update -> istft per launch)"
         achieved = nbytes / (us * 1e-6) / 1e9
         traffic = None
         try:  # PMC-derived HBM bytes per launch of this workload's shapes (separate rocprofv3 --pmc passes, profiles/)

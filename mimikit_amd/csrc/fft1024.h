@@ -92,10 +92,23 @@ struct FftLaneTw {
   }
 };
 
+// The twiddles in LDS, laid out by what a lane reads: t1[(k1 - 1) 64 + lane] = W1024^{lane k1} (pass 1: consecutive lanes on consecutive entries - read
+// out of the plain table exp(-2 pi i m / 1024) at m = lane k1 the even k1 are 2- to 8-way bank conflicts, 20 % of the inverse kernels' LDS cycles),
+// then t2[(c - 1) 4 + b] = W64^{b c} (pass 2: four distinct entries per read).  kFftTwLds complex entries.
+constexpr int kFftTwLds = 15 * 64 + 15 * 4;
+__device__ __forceinline__ void fill_twiddles_by_pass(cf32* twl, const cf32* __restrict__ table, int tid, int nthreads) {
+  for (int e = tid; e < kFftTwLds; e += nthreads) {
+    int m;
+    if (e < 15 * 64) m = ((e & 63) * ((e >> 6) + 1)) & 1023;
+    else m = (16 * ((e - 15 * 64) & 3) * (((e - 15 * 64) >> 2) + 1)) & 1023;
+    twl[e] = table[m];
+  }
+}
+
 // Forward DFT of 1024 points.  In: v[r] = x[lane + 64 r].  Out: X[k] in natural order in buf[0..1023] (SWZ: at buf[fft_swz(k)];
 // wave-private LDS, kFftWaveLds complex); tw[m] = exp(-2 pi i m / 1024), or ltw: the lane's twiddles in registers.  Wave-synchronous: no
 // workgroup barrier.
-template <bool SWZ, bool REGTW>
+template <bool SWZ, bool REGTW, bool BYPASS = false>
 __device__ __forceinline__ void fft1024_wave_impl(cf32 (&v)[16], cf32* buf, const cf32* tw, int lane, const FftLaneTw& ltw) {
   constexpr int N = 1024;
   const int k1b = lane >> 2, lo2 = lane & 3;                  // (k1, b) of pass 2 = (k1, c mod 4) of pass 3
@@ -104,7 +117,7 @@ __device__ __forceinline__ void fft1024_wave_impl(cf32 (&v)[16], cf32* buf, cons
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
     const int k1 = (i >> 2) + 4 * (i & 3);
-    if (k1 != 0) v[i] = cmul(v[i], REGTW ? ltw.t1[k1 - 1 < 0 ? 0 : k1 - 1] : tw[(lane * k1) & (N - 1)]);
+    if (k1 != 0) v[i] = cmul(v[i], REGTW ? ltw.t1[k1 - 1 < 0 ? 0 : k1 - 1] : (BYPASS ? tw[(k1 - 1) * 64 + lane] : tw[(lane * k1) & (N - 1)]));
     buf[k1 * 68 + lane] = v[i];
   }
   __builtin_amdgcn_wave_barrier();
@@ -116,7 +129,7 @@ __device__ __forceinline__ void fft1024_wave_impl(cf32 (&v)[16], cf32* buf, cons
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
     const int c = (i >> 2) + 4 * (i & 3);
-    if (c != 0) v[i] = cmul(v[i], REGTW ? ltw.t2[c - 1 < 0 ? 0 : c - 1] : tw[(16 * lo2 * c) & (N - 1)]);
+    if (c != 0) v[i] = cmul(v[i], REGTW ? ltw.t2[c - 1 < 0 ? 0 : c - 1] : (BYPASS ? tw[15 * 64 + (c - 1) * 4 + lo2] : tw[(16 * lo2 * c) & (N - 1)]));
     buf[lane * 17 + c] = v[i];                              // row (k1, b)
   }
   __builtin_amdgcn_wave_barrier();
@@ -139,6 +152,12 @@ template <bool SWZ = false>
 __device__ __forceinline__ void fft1024_wave(cf32 (&v)[16], cf32* buf, const cf32* tw, int lane) {
   FftLaneTw none;
   fft1024_wave_impl<SWZ, false>(v, buf, tw, lane, none);
+}
+// (twl: the table of fill_twiddles_by_pass)
+template <bool SWZ = false>
+__device__ __forceinline__ void fft1024_wave_bypass(cf32 (&v)[16], cf32* buf, const cf32* twl, int lane) {
+  FftLaneTw none;
+  fft1024_wave_impl<SWZ, false, true>(v, buf, twl, lane, none);
 }
 template <bool SWZ = false>
 __device__ __forceinline__ void fft1024_wave_regtw(cf32 (&v)[16], cf32* buf, const FftLaneTw& ltw, int lane) {

@@ -272,11 +272,11 @@ void istft1024q_kernel(const SpectralTables T, const float* __restrict__ spec, c
                        int segs_per_clip, int64_t total_tasks, int64_t n_out, float* __restrict__ out) {
   constexpr int N = 1024, hop = N / 4;
   typedef float f32x4q __attribute__((ext_vector_type(4)));
-  __shared__ cf32 tw[N];
+  __shared__ cf32 tw[kFftTwLds];
   __shared__ cf32 bufs[kIstftWaves * kFftWaveLds];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  load_twiddles(tw, T.tw1024, tid, 64 * kIstftWaves);
+  fill_twiddles_by_pass(tw, T.tw1024, tid, 64 * kIstftWaves);
   float win[4][4], renv[4];                                 // periodic Hann / N at n = 256 j + 4 lane + i; 1 / envelope at t mod hop = 4 lane + i
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
@@ -368,7 +368,7 @@ void istft1024q_kernel(const SpectralTables T, const float* __restrict__ spec, c
         const float y = __int_as_float(__builtin_amdgcn_ds_bpermute(mirror, __float_as_int(src.y)));
         v[r] = lane == 0 ? mz[16 - r] : cf32{x, y};
       }
-      fft1024_wave<true>(v, buf, tw, lane);
+      fft1024_wave_bypass<true>(v, buf, tw, lane);
       // the two frames' samples n = 256 j + 4 lane + i: a[n] = Re(Y[n]) / N, b[n] = -Im(Y[n]) / N
       cf32 y[4][4];
 #pragma unroll
@@ -595,11 +595,11 @@ void gla1024q_iter_kernel(const SpectralTables T, const float* __restrict__ wave
                           int64_t n_out, float* __restrict__ wave_out) {
   constexpr int N = 1024, bins = 513, hop = N / 4;
   typedef float f32x4q __attribute__((ext_vector_type(4)));
-  __shared__ cf32 tw[N];
+  __shared__ cf32 tw[kFftTwLds];
   __shared__ cf32 bufs[kIstftWaves * kFftWaveLds];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  load_twiddles(tw, T.tw1024, tid, 64 * kIstftWaves);
+  fill_twiddles_by_pass(tw, T.tw1024, tid, 64 * kIstftWaves);
   float win[16];                                            // periodic Hann at n = lane + 64 r (the forward transform's load order)
 #pragma unroll
   for (int r = 0; r < 16; ++r) win[r] = T.hann1024[lane + 64 * r];
@@ -683,7 +683,7 @@ void gla1024q_iter_kernel(const SpectralTables T, const float* __restrict__ wave
         tpa[jj] = *reinterpret_cast<const cf32*>(tprev_in + 2 * (ea + kc));
         tpb[jj] = *reinterpret_cast<const cf32*>(tprev_in + 2 * (eb + kc));
       }
-      fft1024_wave<true>(v, buf, tw, lane);
+      fft1024_wave_bypass<true>(v, buf, tw, lane);
       float mga[9], mgb[9];                                  // (asked for behind the transform: 18 registers less to carry through it)
 #pragma unroll
       for (int jj = 0; jj < 9; ++jj) {
@@ -725,7 +725,7 @@ void gla1024q_iter_kernel(const SpectralTables T, const float* __restrict__ wave
         const float y = __int_as_float(__builtin_amdgcn_ds_bpermute(mirror, __float_as_int(src.y)));
         v[r] = lane == 0 ? mz[16 - r] : cf32{x, y};
       }
-      fft1024_wave<true>(v, buf, tw, lane);
+      fft1024_wave_bypass<true>(v, buf, tw, lane);
       cf32 y[4][4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -780,7 +780,7 @@ constexpr int kStftWaves = MMK_STFT_WAVES;      // waves (= frame pairs in fligh
 template <int OUT>
 __global__ __launch_bounds__(64 * kStftWaves) __attribute__((amdgpu_waves_per_eu(MMK_STFT_WPE, MMK_STFT_WPE)))
 void stft1024_kernel(const SpectralTables T, const float* __restrict__ x, int64_t x_row_stride, int64_t n_samples, int hop, int center, int reflect,
-                     int64_t n_frames, int64_t total_pairs, float* __restrict__ out, float* __restrict__ tprev, float momentum) {
+                     int64_t n_frames, int64_t total_pairs, int runs_per_row, float* __restrict__ out, float* __restrict__ tprev, float momentum) {
   constexpr int N = 1024, bins = 513;
 #ifndef MMK_STFT_REGTW
 #define MMK_STFT_REGTW 1      // the lane's 30 twiddles in registers for the whole kernel (no table in LDS at all)
@@ -804,38 +804,49 @@ void stft1024_kernel(const SpectralTables T, const float* __restrict__ x, int64_
   const int64_t pad = center ? N / 2 : 0;
   const int64_t stride = (int64_t)gridDim.x * kStftWaves;
 
-  const bool small = total_pairs < (1ll << 31);            // (32-bit division of the pair index where it fits: an int64 division is ~100 vector instructions)
-#ifndef MMK_STFT_PREFETCH
-#define MMK_STFT_PREFETCH 0   // the NEXT pair's samples are asked for before this pair's transform
-#endif
-  // A wave's pairs are a chain of load -> transform -> store: with the loads of pair i + 1 issued only after the stores of pair i, every pair paid
-  // the whole memory latency (~2 us under load) on top of its ~4 us of arithmetic - and taking 3000 vector instructions of table building out of
-  // every wave changed nothing.  The samples of the next pair are requested first; their 20 registers live through the transform.
-  auto pair_start = [&](int64_t pair, int64_t& b, int64_t& f0) {
-    b = small ? (int64_t)((unsigned)pair / (unsigned)pairs_per_row) : pair / pairs_per_row;
-    f0 = (pair - b * pairs_per_row) * 2;
-  };
-  StftRaw raw;
-  int64_t pair = (int64_t)blockIdx.x * kStftWaves + wave;
-  if (MMK_STFT_PREFETCH && pair < total_pairs) {
-    int64_t b, f0;
-    pair_start(pair, b, f0);
-    stft_load(raw, x + b * x_row_stride, f0 * hop - pad, hop, n_samples, reflect, lane);
-  }
-  for (; pair < total_pairs; pair += stride) {
-    int64_t b, f0;
-    pair_start(pair, b, f0);
+  // A wave takes RUNS of consecutive pairs of one clip.  The pairs of a clip overlap - a pair reads 1280 samples, 768 of them the next pair's too -
+  // and with the pairs dealt out one by one, neighbours landed on different XCDs: every L2 fetched the overlap for itself, 2.5 x the bytes over the
+  // fabric (141 MB for 56 MB of samples; that load phase alone took 22 of the kernel's 55 us - its bytes at the rate the fabric gives).  Inside a run
+  // with hop = n_fft / 4 the window slides through the wave's registers: the 20 rows of 64 samples of a pair are rows 8 .. 19 of the pair before and
+  // 8 new ones - 8 loads per pair instead of 20.
+  const int run_len = (int)((pairs_per_row + runs_per_row - 1) / runs_per_row);
+  const int64_t total_runs = (int64_t)(total_pairs / pairs_per_row) * runs_per_row;
+  for (int64_t run = (int64_t)blockIdx.x * kStftWaves + wave; run < total_runs; run += stride) {
+    const int64_t b = (int64_t)((unsigned)run / (unsigned)runs_per_row);
+    const int64_t p0 = (run - b * runs_per_row) * run_len;
+    const int64_t p1 = p0 + run_len < pairs_per_row ? p0 + run_len : pairs_per_row;
+    const float* xr = x + b * x_row_stride;
+    float rows[20];                                          // rows[r] = x[start + lane + 64 r] of the pair at hand (hop = N / 4)
+    bool slid = false;                                       // rows holds the pair before this one
+  for (int64_t pr = p0; pr < p1; ++pr) {
+    const int64_t f0 = pr * 2;
     const bool has_b = (f0 + 1) < n_frames;
-    if (!MMK_STFT_PREFETCH) stft_load(raw, x + b * x_row_stride, f0 * hop - pad, hop, n_samples, reflect, lane);
+    const int64_t start = f0 * hop - pad;
+    StftRaw raw;
+    if (hop == N / 4 && start >= 0 && start + hop + N <= n_samples) {
+      const float* pa = xr + start + lane;
+      if (slid) {
+#pragma unroll
+        for (int r = 0; r < 12; ++r) rows[r] = rows[r + 8];
+#pragma unroll
+        for (int r = 12; r < 20; ++r) rows[r] = pa[64 * r];
+      } else {
+#pragma unroll
+        for (int r = 0; r < 20; ++r) rows[r] = pa[64 * r];
+      }
+      slid = true;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        raw.a[r] = rows[r];
+        raw.b[r] = rows[r + 4];                               // frame B starts a quarter frame later
+      }
+    } else {
+      stft_load(raw, xr, start, hop, n_samples, reflect, lane);
+      slid = false;
+    }
     cf32 v[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) v[r] = cf32{raw.a[r] * win[r], has_b ? raw.b[r] * win[r] : 0.f};   // frame f0 -> re, f0 + 1 -> im
-    if (MMK_STFT_PREFETCH) {
-      const int64_t np = pair + stride < total_pairs ? pair + stride : pair;      // (clamped: an unconditional load)
-      int64_t nb, nf0;
-      pair_start(np, nb, nf0);
-      stft_load(raw, x + nb * x_row_stride, nf0 * hop - pad, hop, n_samples, reflect, lane);
-    }
     const int64_t ea = (b * n_frames + f0) * bins;
 #ifndef MMK_STFT_ABL
 #define MMK_STFT_ABL 0        // timing experiments only: 1 no stores, 2 no transform (the window's values written straight to LDS), 3 both
@@ -887,6 +898,7 @@ void stft1024_kernel(const SpectralTables T, const float* __restrict__ x, int64_
       }
     }
     __builtin_amdgcn_wave_barrier();                        // buf is rewritten by the next pair
+  }
   }
 }
 
@@ -1190,15 +1202,25 @@ static int launch_istft(const float* spec, const float* mag, int mode, int batch
 int launch_stft1024(const float* x, int64_t x_row_stride, int batch, int64_t n_samples, int hop, int center, int reflect, int out_mode,
                     float* out, float* tprev, float momentum, hipStream_t stream) {
   const int64_t n_frames = mmk_stft_n_frames(n_samples, 1024, hop, center);
-  const int64_t total_pairs = (int64_t)batch * ((n_frames + 1) / 2);
-  const int64_t wgs = (total_pairs + kStftWaves - 1) / kStftWaves;
+  const int64_t pairs_per_row = (n_frames + 1) / 2;
+  const int64_t total_pairs = (int64_t)batch * pairs_per_row;
   const int64_t resident = 256 * (4 * MMK_STFT_WPE / kStftWaves);          // workgroups that are resident together on the chip
+  // runs of consecutive pairs per clip: about one run per resident wave (at least 2 pairs per run where a clip has them, at most the clip)
+  int64_t runs_per_row = (resident * kStftWaves + batch - 1) / batch;
+  runs_per_row = runs_per_row > (pairs_per_row + 1) / 2 ? (pairs_per_row + 1) / 2 : runs_per_row;
+  runs_per_row = runs_per_row < 1 ? 1 : runs_per_row;
+  {   // (whole run lengths: no run is empty)
+    const int64_t run_len = (pairs_per_row + runs_per_row - 1) / runs_per_row;
+    runs_per_row = (pairs_per_row + run_len - 1) / run_len;
+  }
+  const int64_t total_runs = (int64_t)batch * runs_per_row;
+  const int64_t wgs = (total_runs + kStftWaves - 1) / kStftWaves;
   const dim3 grid((unsigned)(wgs < resident ? wgs : resident)), block(64 * kStftWaves);
   SpectralTables T;
   MMK_TRY(spectral_tables(stream, &T));
 #define MMK_STFT_LAUNCH(O) \
   hipLaunchKernelGGL((stft1024_kernel<O>), grid, block, 0, stream, T, x, x_row_stride, n_samples, hop, center, reflect, n_frames, \
-                     total_pairs, out, tprev, momentum)
+                     total_pairs, (int)runs_per_row, out, tprev, momentum)
   switch (out_mode) {
     case 0: MMK_STFT_LAUNCH(0); break;
     case 1: MMK_STFT_LAUNCH(1); break;
