@@ -60,6 +60,8 @@ def parse():
                     help="> 0: sampled decode at this temperature (throughput only: the CPU check needs greedy decode)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline sample")
+    ap.add_argument("--force-dist", action="store_true", help="with --gpus 1: initialise the RCCL process group of ONE rank all the same and run the path's "
+                    "collectives (weight broadcast, fenced max-over-ranks clock) on it - what an N-GPU run does, on a 1-GPU box")
     ap.add_argument("--tuning", default="", help="execution switches of the plans of this run, NAME=VALUE[;NAME=VALUE...] (include/mmk.h `tuning`): "
                     "the library reads no environment variable - this is the only way to A/B a kernel choice from the command line")
     return ap.parse_args()
@@ -593,16 +595,38 @@ JOBS = {"stub": StubJob, "wavenet_cfg4": WaveNetJob, "wavenet_cfg2": WaveNetJob,
 
 
 # ----------------------------------------------------------------------------- main
+def visible_gpus():
+    """GPUs of this node WITHOUT touching HIP (the launcher must not initialise the GPU it hands to its ranks): the KFD topology nodes with
+    SIMDs, cut down by a ROCR / HIP visible-devices list; 0 where there is no KFD topology (no AMD GPU driver on this node)"""
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        if os.environ.get(var, "") != "":
+            return len([d for d in os.environ[var].split(",") if d.strip() != ""])
+    root = "/sys/class/kfd/kfd/topology/nodes"
+    try:
+        count = 0
+        for node in os.listdir(root):
+            with open(os.path.join(root, node, "properties")) as f:
+                props = dict(line.split(None, 1) for line in f.read().splitlines() if " " in line)
+            if int(props.get("simd_count", "0")) > 0:
+                count += 1
+        return count
+    except (OSError, ValueError):
+        return 0
+
+
 def launch_ranks(args) -> int:
     """`bench.py --gpus N` without a launcher around it (WORLD_SIZE unset): start N ranks of this file, one per GPU, and pass rank 0's
-    JSON line on.  The parent never initialises the GPU (`device_count` only counts) and never re-execs; fewer than N visible
-    devices, or any rank failing, is a non-zero exit - never a silent single-GPU run."""
+    JSON line on.  The parent makes no HIP call at all (the GPUs are counted from sysfs) and never re-execs; fewer than N visible
+    devices, or any rank failing, is a non-zero exit - never a silent single-GPU run.  Every rank is polled: the first one that fails
+    ends the others (a rank waiting in a collective for a dead peer would otherwise sit there until the process group times out)."""
     import socket
     import subprocess
+    import threading
+    import time
     n = args.gpus
     stub = args.workload == "stub"
     if not stub:
-        have = torch.cuda.device_count()
+        have = visible_gpus()
         if have < n:
             print(f"bench.py: --gpus {n} but only {have} GPU(s) are visible on this node", file=sys.stderr)
             return 2
@@ -616,15 +640,26 @@ def launch_ranks(args) -> int:
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # (dmabuf IPC: what RCCL needs on this driver)
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *sys.argv[1:]], env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
-    out0, _ = procs[0].communicate()
-    codes = [procs[0].returncode] + [pr.wait() for pr in procs[1:]]
+    out0 = []
+    reader = threading.Thread(target=lambda: out0.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    codes = [None] * n
+    while any(c is None for c in codes):
+        for r, pr in enumerate(procs):
+            if codes[r] is None:
+                codes[r] = pr.poll()
+        if any(c not in (None, 0) for c in codes):
+            for r, pr in enumerate(procs):
+                if codes[r] is None:
+                    pr.kill()
+                    codes[r] = pr.wait()
+            break
+        time.sleep(0.05)
+    reader.join(timeout=5)
     if any(codes):
         print(f"bench.py: rank exit codes {codes}", file=sys.stderr)
-        for pr in procs:
-            if pr.poll() is None:
-                pr.kill()
         return 1
-    sys.stdout.write(out0)
+    sys.stdout.write("".join(out0))
     sys.stdout.flush()
     return 0
 
@@ -651,14 +686,25 @@ def main():
             raise SystemExit(f"rank {rank}: no GPU {local_rank} on this node ({torch.cuda.device_count()} visible)")
         torch.cuda.set_device(local_rank)
         device, sync = torch.device("cuda", local_rank), torch.cuda.synchronize
-        if world > 1:
-            dist.init_process_group(backend="nccl", device_id=device)     # RCCL over xGMI
+        if world > 1 or args.force_dist:
+            if world == 1:                                                  # (--force-dist: a process group of one rank, on a free local port)
+                import socket
+                os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+                if "MASTER_PORT" not in os.environ:
+                    with socket.socket() as sock:
+                        sock.bind(("127.0.0.1", 0))
+                        os.environ["MASTER_PORT"] = str(sock.getsockname()[1])
+                os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            dist.init_process_group(backend="nccl", device_id=device, rank=rank, world_size=world)     # RCCL over xGMI
+            if args.force_dist:
+                from mimikit_amd import shard
+                shard.FORCE_COLLECTIVES = True
     torch.set_grad_enabled(False)
     apply_tuning(args.tuning)
 
     job = JOBS[args.workload](args, device, rank)
     job.to_device()
-    if world > 1 and hasattr(job, "net"):
+    if (world > 1 or args.force_dist) and hasattr(job, "net"):
         from mimikit_amd.shard import broadcast_weights
         broadcast_weights(job.net, src=0)          # the path's only collective
         job.broadcasts = 1
@@ -675,6 +721,9 @@ def main():
         "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": job.dtype, "data": "synthetic", "config": job.config(world),
     }
+    if args.force_dist and not stub:
+        line["collectives"] = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "weight_broadcasts": getattr(job, "broadcasts", 0),
+                               "clock": "barrier + all_reduce(MAX) on the device"}
     if rank == 0:
         if hasattr(job, "step_bytes"):
             steps_per_s = value / (job.clips * world)
@@ -690,7 +739,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline and not args.temperature > 0:    # N = 1 only; the CPU leg re-checks the GREEDY samples
             line["cpu_baseline"] = job.cpu_baseline(args.cpu_seconds)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if world > 1 or (args.force_dist and dist.is_initialized()):
         dist.barrier()
         dist.destroy_process_group()
 

@@ -13,6 +13,16 @@ import torch.distributed as dist
 
 __all__ = ["clip_slice", "broadcast_weights", "gather_clips", "timed_passes"]
 
+# True: the collectives run on an initialised process group of ONE rank as well (bench.py --force-dist: the RCCL calls of an N-GPU run,
+# exercised on a 1-GPU box); by default a single rank skips them
+FORCE_COLLECTIVES = False
+
+
+def _collectives(group=None) -> bool:
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return FORCE_COLLECTIVES or dist.get_world_size(group) > 1
+
 
 def clip_slice(n_clips: int, rank: int, world_size: int) -> Tuple[int, int]:
     """[start, stop) of the clips owned by `rank`: contiguous, sizes differ by at most one"""
@@ -30,7 +40,7 @@ def broadcast_weights(module: torch.nn.Module, src: int = 0, group=None) -> int:
     if not tensors:
         return 0
     flat = torch.cat([t.detach().reshape(-1).to(torch.float32) for t in tensors])
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    if _collectives(group):
         dist.broadcast(flat, src=src, group=group)
     offset = 0
     with torch.no_grad():
@@ -68,7 +78,7 @@ def timed_passes(one_pass: Callable[[], None], steps: int, warmup: int, sync: Ca
     """the bench contract's timing (bench.py): `warmup` untimed passes, then EXACTLY `steps` passes between two fences
     (device sync + barrier + device sync), elapsed time = MAX over ranks.  `sync` waits for the local device."""
     import time
-    multi = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+    multi = _collectives(group)
 
     def fence():
         sync()

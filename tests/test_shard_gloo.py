@@ -116,9 +116,26 @@ def test_bench_launches_its_own_ranks():
     assert abs(line["value"] - 8 / (line["ms_per_step"] * 1e-3)) / line["value"] < 1e-3
 
 
+def test_launcher_counts_gpus_without_hip(monkeypatch):
+    """the launcher's device count comes from the visible-devices list or the KFD topology in sysfs - never from a HIP call in the parent"""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_for_test", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "0,2,5")
+    assert bench.visible_gpus() == 3
+    monkeypatch.delenv("HIP_VISIBLE_DEVICES")
+    monkeypatch.delenv("ROCR_VISIBLE_DEVICES", raising=False)
+    monkeypatch.delenv("CUDA_VISIBLE_DEVICES", raising=False)
+    assert bench.visible_gpus() >= torch.cuda.device_count()       # (0 on a box without the driver; a container may see fewer than the node has)
+    import inspect
+    assert "device_count" not in inspect.getsource(bench.launch_ranks)
+
+
 def test_bench_refuses_more_gpus_than_the_node_has():
     """a box with fewer devices than --gpus must fail loudly, never report a single-GPU number as the N-GPU one"""
-    n = torch.cuda.device_count() + 7
+    n = torch.cuda.device_count() + 64
     rc, line, err = _run_bench("--gpus", str(n), "--steps", "1", "--warmup", "0")
     assert rc != 0 and line is None
     assert f"--gpus {n}" in err and "visible" in err
