@@ -68,8 +68,20 @@ def build(force: bool = False, verbose: bool = False, diag: bool = False) -> str
 
 
 def _build(lib_path: str, obj_dir: str, defines, verbose: bool) -> str:
-    hipcc = _hipcc()
+    """one build at a time per tree (a file lock: conftest, __graft_entry__.build and load_library may all ask for one), and the library is
+    linked beside its final name and moved over it in one step - a process that has the old image mapped keeps its (unlinked) file"""
+    import fcntl
     os.makedirs(obj_dir, exist_ok=True)
+    with open(os.path.join(obj_dir, ".lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            return _build_locked(lib_path, obj_dir, defines, verbose)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+
+def _build_locked(lib_path: str, obj_dir: str, defines, verbose: bool) -> str:
+    hipcc = _hipcc()
     objs = []
     procs = []
     for src in SOURCES:
@@ -84,10 +96,14 @@ def _build(lib_path: str, obj_dir: str, defines, verbose: bool) -> str:
         out, _ = pr.communicate()
         if pr.returncode != 0:
             raise RuntimeError(f"hipcc failed on {src}:\n{out}")
-    cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", lib_path] + objs
+    tmp_path = f"{lib_path}.{os.getpid()}.tmp"
+    cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", tmp_path] + objs
     res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if res.returncode != 0:
+        if os.path.exists(tmp_path):
+            os.remove(tmp_path)
         raise RuntimeError(f"link failed:\n{res.stdout}")
+    os.replace(tmp_path, lib_path)
     return lib_path
 
 

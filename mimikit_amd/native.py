@@ -688,6 +688,8 @@ def make_wavenet_plan(describe, batch: int, device) -> "WaveNetPlan":
         size = -(-batch // n)
         first = WaveNetPlan(describe(size), device)
         if first.stage_pipelined:
+            # (the set slices clips along dimension 0 of every per-clip tensor; with several targets the uniforms are (targets, clips, steps))
+            assert max(int(first.cfg.n_targets), 1) == 1, "a plan set slices clips along dimension 0: one target only"
             sizes = [size] * (n - 1) + [batch - size * (n - 1)]
             return WaveNetPlanSet([first] + [WaveNetPlan(describe(sz), device) for sz in sizes[1:]], sizes)
     return WaveNetPlan(describe(batch), device)

@@ -163,6 +163,8 @@ class Seq2SeqLSTMNetwork(ARMWithHidden, nn.Module):
         self._plan = None
         self._plan_batch = 0
         self._weights = native.WeightsTracker()
+        self.exec_tuning = {}   # execution switches of THIS network's plans ({"MMK_...": "0"}: include/mmk.h `tuning`); merged over native.PLAN_TUNING
+        self._plan_tuning = None            # the tuning text the plan at hand was built with
 
     # -- ARM properties -----------------------------------------------------------
     @property
@@ -263,7 +265,6 @@ class Seq2SeqLSTMNetwork(ARMWithHidden, nn.Module):
 
     _blocks = ()            # generate_block calls since before_generate: (tensor, t0, n_steps)
     _exec_mode = 0          # 1 while a call is being redone with one launch per frame (mmk_s2s_config.exec_mode)
-    exec_tuning: dict = {}   # execution switches of THIS network's plans ({"MMK_...": "0"}: include/mmk.h `tuning`); merged over native.PLAN_TUNING
     _resident_seen = 0
     _plan_stale = False     # the plan is the one-launch-per-frame plan of a repeated call: replaced at the next _ensure_plan
 
@@ -273,10 +274,12 @@ class Seq2SeqLSTMNetwork(ARMWithHidden, nn.Module):
             raise RuntimeError("Seq2SeqLSTMNetwork generates on the MI355X only: move the network to the HIP device "
                                "('cuda'); there is no CPU implementation in this package")
         rebuilt = False
-        if self._plan is None or self._plan_batch < batch or self._plan.device != device or (self._plan_stale and self._exec_mode == 0):
+        tuning = native.tuning_text(native.PLAN_TUNING, self.exec_tuning)
+        if self._plan is None or self._plan_tuning != tuning or self._plan_batch < batch or self._plan.device != device or (self._plan_stale and self._exec_mode == 0):
             self._plan_stale = False
             self._plan = native.S2SPlan(self._describe(max(batch, 1)), device)
             self._plan_batch = max(batch, 1)
+            self._plan_tuning = tuning
             self._resident_seen = 0
             rebuilt = True
         # every call: a step keeps no state between calls, but the plan holds a re-packed copy of the weights, and eval

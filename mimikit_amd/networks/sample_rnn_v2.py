@@ -156,6 +156,8 @@ class SampleRNN(ARMWithHidden, nn.Module):
         self._plan: Optional[native.SrnnPlan] = None
         self._plan_batch = 0
         self._weights = native.WeightsTracker()
+        self.exec_tuning = {}   # execution switches of THIS network's plans ({"MMK_...": "0"}: include/mmk.h `tuning`); merged over native.PLAN_TUNING
+        self._plan_tuning = None            # the tuning text the plan at hand was built with
         self._state_batch = 0
         self._next_t: Optional[int] = None
 
@@ -204,7 +206,6 @@ class SampleRNN(ARMWithHidden, nn.Module):
 
     # -- HIP plan ---------------------------------------------------------------------
     _exec_mode = 0          # 1 while a batch is being redone with the kernels in turns (mmk_srnn_config.exec_mode)
-    exec_tuning: dict = {}   # execution switches of THIS network's plans ({"MMK_...": "0"}: include/mmk.h `tuning`); merged over native.PLAN_TUNING
 
     def _describe(self, max_batch: int) -> native.SrnnConfig:
         cfg, io = self._config, self._config.io_spec
@@ -276,9 +277,11 @@ class SampleRNN(ARMWithHidden, nn.Module):
             raise RuntimeError("SampleRNN generates on the MI355X only: move the network to the HIP device ('cuda'); "
                                "there is no CPU implementation in this package")
         rebuilt = False
-        if self._plan is None or self._plan_batch < batch or self._plan.device != device:
+        tuning = native.tuning_text(native.PLAN_TUNING, self.exec_tuning)
+        if self._plan is None or self._plan_tuning != tuning or self._plan_batch < batch or self._plan.device != device:
             self._plan = native.SrnnPlan(self._describe(max(batch, 1)), device)
             self._plan_batch = max(batch, 1)
+            self._plan_tuning = tuning
             self._resident_seen = 0                          # (the new plan's resident-block counter starts over)
             rebuilt = True
         if rebuilt or refresh_weights:

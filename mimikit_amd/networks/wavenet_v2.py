@@ -221,6 +221,8 @@ class WaveNet(ARM, nn.Module):
         self._plan: Optional[native.WaveNetPlan] = None
         self._plan_batch = 0
         self._weights = native.WeightsTracker()
+        self.exec_tuning = {}   # execution switches of THIS network's plans ({"MMK_...": "0"}: include/mmk.h `tuning`); merged over native.PLAN_TUNING
+        self._plan_tuning = None            # the tuning text the plan at hand was built with
         self._next_t: Optional[int] = None   # absolute time the queues are ready to produce
         self._state_batch = 0
 
@@ -294,7 +296,6 @@ class WaveNet(ARM, nn.Module):
 
     # -- HIP plan ---------------------------------------------------------------------
     _exec_mode = 0          # 1 while a batch is being redone on the per-layer launch path (mmk_wavenet_config.exec_mode)
-    exec_tuning: dict = {}   # execution switches of THIS network's plans ({"MMK_...": "0"}: include/mmk.h `tuning`); merged over native.PLAN_TUNING
 
     def _describe(self, max_batch: int) -> native.WaveNetConfig:
         cfg, io = self._config, self._config.io_spec
@@ -399,9 +400,11 @@ class WaveNet(ARM, nn.Module):
             raise RuntimeError("WaveNet generates on the MI355X only: move the network to the HIP device ('cuda'); "
                                "there is no CPU implementation in this package")
         rebuilt = False
-        if self._plan is None or self._plan_batch < batch or self._plan.device != device:
+        tuning = native.tuning_text(native.PLAN_TUNING, self.exec_tuning)
+        if self._plan is None or self._plan_tuning != tuning or self._plan_batch < batch or self._plan.device != device:
             self._plan = native.make_wavenet_plan(self._describe, max(batch, 1), device)
             self._plan_batch = max(batch, 1)
+            self._plan_tuning = tuning
             rebuilt = True
         if rebuilt or refresh_weights:
             # the plan holds a re-packed copy of the weights: redo it only when a parameter changed since (optimiser step,
