@@ -13,7 +13,6 @@
 
 #include "plan_util.h"
 #include "wavenet_chain.h"
-#include "wavenet_pipe.h"
 #include "wavenet_lpipe.h"
 #include "wavenet_persist.h"
 #include "wavenet_prefill.h"
@@ -86,7 +85,6 @@ struct mmk_wavenet_plan {
   unsigned long long *gran_h = nullptr, *gran_y = nullptr, *gran_skip = nullptr, *gran_hid = nullptr,
                      *gran_logit = nullptr, *gran_idx = nullptr;
   int64_t gran_words = 0;       // contiguous block [gran_h .. gran_idx] + err word, zeroed before every launch
-  int64_t pipe_gran_words = 0;  // the pipelined kernel's extra exchange buffers (their own block)
   float* h_rings = nullptr;     // per workgroup: past inputs of every layer (the delayed tap reads them)
   float* cproj = nullptr;       // (Bmax, kCondBlock, C1) conditioning after its LinearIO
   float* cpad = nullptr;        // the block's (or the prompt's) conditioning rows of all clips, compact, every row padded to whole 16-float chunks:
@@ -103,16 +101,11 @@ struct mmk_wavenet_plan {
   // one hand-off per layer (wavenet_chain.hip): gate matrices with the K segments [tap 0 | tap 1 | tap 1 . W_res of the
   // layer below], pre-multiplied at commit
   bool chain = false;
-  // layers spread over the XCDs, weights resident on chip, clip groups pipelined through the stages (wavenet_pipe.hip)
-  bool pipe = false;
-  int pipe_nit = 0;
   // four workgroups per clip that own whole layers (wavenet_lpipe.hip): small networks (C = S = 64, H1 = 128, 256 classes)
   bool lpipe = false;
   unsigned long long *lp_xg = nullptr, *lp_cg = nullptr;
   int64_t lp_gran_words = 0;
-  unsigned long long *px_yl = nullptr, *px_hl = nullptr, *px_hown = nullptr, *px_yx = nullptr, *px_hx = nullptr, *px_skipfwd = nullptr;
   std::vector<PackedLinear> Ac;
-  std::vector<PackedLinear> Bh;       // pipelined mode: rows [res ; head fc0 . W_skip] of every layer (the head's first Linear folded in)
   WnChainIter* iter_tab = nullptr;
   float* compose_scratch = nullptr;   // (2C, C) product + 2C bias terms of one layer
   // one layer per stage of 8 CUs, clips streamed through one at a time (wavenet_spipe.hip): C = 256, <= 31 layers, <= 32 clips
@@ -142,18 +135,6 @@ struct mmk_wavenet_plan {
     gran_idx = gran_logit + (base ? n_l : 0);
     xcd_count = reinterpret_cast<unsigned*>(gran_idx + (base ? n_i : 0));
     err_flag = reinterpret_cast<int32_t*>(gran_idx + (base ? n_i + 8 : 0));
-    if (pipe) {   // stage-local and stage-to-stage exchange buffers (see wavenet_pipe.h), zeroed with the block above: re-take it
-      const int64_t n_loc = (int64_t)8 * Gc * 2 * 16 * C, n_own = (int64_t)8 * Gc * 16 * C, n_x = (int64_t)Gc * 2 * 16 * C;
-      const int64_t extra = 2 * n_loc + n_own + 3 * n_x;
-      unsigned long long* more = c.take<unsigned long long>(extra);   // directly behind the block above (both 256-byte aligned sizes)
-      px_yl = more;
-      px_hl = px_yl + (more ? n_loc : 0);
-      px_hown = px_hl + (more ? n_loc : 0);
-      px_yx = px_hown + (more ? n_own : 0);
-      px_hx = px_yx + (more ? n_x : 0);
-      px_skipfwd = px_hx + (more ? n_x : 0);
-      pipe_gran_words = extra;
-    }
     if (lpipe) {
       sp_f0p = c.take<float>((int64_t)kSpH1 * C);
       sp_fb0p = c.take<float>(kSpH1);
@@ -189,7 +170,7 @@ struct mmk_wavenet_plan {
       sp_hidgrp = sp_hidmsg + (sp_msg ? wn_spipe_hidmsg_words(L, Bmax) : 0);
       sp_raw = c.take<WnSpRaw>(L);
     }
-    h_rings = spipe ? nullptr : c.take<float>((int64_t)(pipe ? 8 : Gc) * Gn * ring_floats_per_wg);
+    h_rings = spipe ? nullptr : c.take<float>((int64_t)Gc * Gn * ring_floats_per_wg);
     cproj = C1 > 0 ? c.take<float>((int64_t)Bmax * kCondBlock * C1) : nullptr;
     if (C1 > 0) {
       int kmax = 16;
@@ -201,12 +182,10 @@ struct mmk_wavenet_plan {
     // (the stage pipeline multiplies the layers' conditioning products itself, from cproj)
     condall = (C1 > 0 && !spipe) ? c.take<float>((int64_t)Bmax * kCondBlock * L * 2 * C) : nullptr;
     if (C1 > 0 && !spipe) cond_all.carve(c, false);
-    if (pipe)
-      for (auto& pl : Bh) pl.carve(c, true);
-    if (chain || pipe) {
+    if (chain) {
       for (auto& pl : Ac) pl.carve(c, true);
       iter_tab = c.take<WnChainIter>(L + 1);
-      compose_scratch = c.take<float>((int64_t)2 * C * C + 2 * C);     // (the pipelined mode's H1 x C products fit: H1 <= C there)
+      compose_scratch = c.take<float>((int64_t)2 * C * C + 2 * C);
     }
     zero_pad = c.take<float>(64);
     pf_P = round_up(rf, 32);
@@ -263,7 +242,7 @@ struct mmk_wavenet_plan {
 // and R (C x C), r (C) a 1x1 convolution of the layer below.  Accumulated in fp64 and rounded once: the pre-multiplied
 // matrix is as close to the exact product as fp32 allows.  Used for
 //   * tap 1 of a k = 2 dilated convolution (2C rows, a = wd + 1, a_rs = 2C, a_cs = 2) times the residual convolution, and
-//   * the head's first Linear (H1 rows) times a layer's skip convolution (wavenet_pipe.hip).
+//   * the head's first Linear (H1 rows) times a layer's skip convolution (the stage pipeline).
 __global__ __launch_bounds__(256) void compose_kernel(const float* __restrict__ a, int64_t a_rs, int64_t a_cs, int N,
                                                      const float* __restrict__ wr, const float* __restrict__ br,
                                                      float* __restrict__ out, float* __restrict__ out_bias, int C) {
@@ -498,7 +477,7 @@ static int derive(mmk_wavenet_plan* p) {
       p->spipe = true;
       p->persistent = true;
       p->xcd_local = false;
-      p->chain = p->pipe = false;
+      p->chain = false;
       p->C1 = cond_total;
       p->n_logits_pad = (int)round_up(c.out_dim + (c.learn_temp ? 1 : 0), 16);
       p->ring_offset.assign(p->L, 0);
@@ -526,58 +505,10 @@ static int derive(mmk_wavenet_plan* p) {
       for (auto& pl : p->Ac) pl.set_geometry(2 * p->C, {p->C, p->C, p->C});
     }
   }
-  // Layer sets that do not fit an XCD's L2: spread the LAYERS over the XCDs (weights resident on chip) and pipeline the
-  // clip groups through them (wavenet_pipe.hip).  Needs the same structure as the chain kernel, at most 8 groups of 4
-  // clips, at most 4 iterations per XCD, one workgroup per CU and XCD (8 Gn <= 256), and the warm-up as a prefill (its
-  // history rings are laid out per stage, the teacher-forced mode of wavenet_persist.hip cannot fill them).
-  p->pipe = false;
-  if (p->persistent && !p->chain && !p->spipe) {
-    const char* penv = p->tune.get("MMK_WN_PIPE");
-    const char* fenv = p->tune.get("MMK_WN_PREFILL");
-    const bool fits_l2 = (int64_t)p->L * 8 * p->C * p->C * 4 <= ((int64_t)3 << 20);
-    // (default: 256-channel networks whose layer set does not fit an L2 and that the stage pipeline does not take - more than 31 layers, another
-    //  head width; at 128 channels and below it loses to the one- and the two-hand-off kernel everywhere)
-    //  (and from ~22 layers on: 256 x 10 x 32 clips 41.7 us per step against 31.2 on the two-hand-off kernel, 256 x 30 65 - 76 against 74 - 87: the
-    //   pipeline gains 1.35 us per layer, the two-hand-off kernel 2.3)
-    bool ok3 = (penv ? penv[0] != '0' : (!fits_l2 && p->C > 128 && p->L >= 22)) && !(fenv && fenv[0] == '0') && n_xcc == 8 && 8 * p->Gn <= n_cu && p->Bmax <= 32;
-    for (int l = 0; l + 1 < p->L; ++l) ok3 = ok3 && p->has_res[l];
-    const int mg = (p->Bmax + 7) / 8, gc = (p->Bmax + mg - 1) / mg;
-    ok3 = ok3 && wn_pipe_supported(p->C, mg, gc, p->L) && c.mlp_hidden <= p->C;   // (the skip-row owners take the H1 / 16 hidden-unit tiles)
-    if (ok3) {
-      WnPipeArgs probe = {};
-      probe.C = p->C; probe.H1 = c.mlp_hidden; probe.n_logits_pad = p->n_logits_pad; probe.L = p->L; probe.Gn = p->Gn;
-      ok3 = wn_pipe_lds_bytes(probe) <= 160 * 1024;
-    }
-    if (ok3) {
-      p->pipe = true;
-      p->xcd_local = false;
-      p->Mg = mg;
-      p->Gc = gc;
-      p->pipe_nit = wn_pipe_iters_per_stage(p->L);
-      p->Ac.resize(p->L);
-      for (auto& pl : p->Ac) pl.set_geometry(2 * p->C, {p->C, p->C, p->C});
-      p->Bh.resize(p->L);
-      for (int l = 0; l < p->L; ++l) p->Bh[l].set_geometry((p->has_res[l] ? p->C : 0) + c.mlp_hidden, {p->C});
-      // rings: per stage workgroup, the stage's layers x slots x (all Gc Mg clips) x C
-      const int64_t Bp = (int64_t)gc * mg;
-      int64_t worst = 0;
-      for (int x = 0; x * p->pipe_nit < p->L; ++x) {
-        int64_t off = 0;
-        for (int l = x * p->pipe_nit; l < (x + 1) * p->pipe_nit && l < p->L; ++l) {
-          p->ring_offset[l] = off;
-          off += (int64_t)(p->ring_mask[l] + 1) * Bp * p->C;
-        }
-        worst = off > worst ? off : worst;
-      }
-      p->ring_floats_per_wg = worst;
-      if (worst * 4 >= ((int64_t)1 << 32)) p->pipe = false;    // 32-bit byte offsets in the kernel
-      if (!p->pipe) return fail(MMK_ERR_UNSUPPORTED, "wavenet: history rings of %lld bytes per workgroup", (long long)worst * 4);
-    }
-  }
   // ---- layer pipeline (wavenet_lpipe.hip): small networks whose layers fit a fraction of a CU's registers; 32 workgroups per 8 clips,
   // all resident, four per clip on one XCD; the warm-up is the prefill, scattered into the launch path's rings.  MMK_WN_LPIPE=0: off.
   p->lpipe = false;
-  if (p->persistent && !p->pipe && !p->spipe) {
+  if (p->persistent && !p->spipe) {
     const char* lenv = p->tune.get("MMK_WN_LPIPE");
     const char* fenv = p->tune.get("MMK_WN_PREFILL");
     bool ok4 = !(lenv && lenv[0] == '0') && !(fenv && fenv[0] == '0') && n_xcc == 8 && 32 * ((p->Bmax + 7) / 8) <= n_cu && c.q_levels <= 256 && c.out_dim <= c.q_levels;
@@ -757,7 +688,7 @@ extern "C" int mmk_wavenet_commit(mmk_wavenet_plan* p, void* workspace, size_t w
     }
   }
   // one-hand-off-per-layer mode: gate matrices [tap 0 | tap 1 | tap 1 . W_res(l-1)], bias + tap 1 . b_res(l-1)
-  if (p->chain || p->pipe) {
+  if (p->chain) {
     for (int l = 0; l < L; ++l) {
       const std::string ly = "layers." + std::to_string(l) + ".";
       const float* wd = b.need(ly + "conv_dil.0.0.weight", (int64_t)2 * C * C * 2);
@@ -793,34 +724,6 @@ extern "C" int mmk_wavenet_commit(mmk_wavenet_plan* p, void* workspace, size_t w
           MMK_TRY(pack_bias(A.bias, 0, 2, C, pbias, 1, st));
           MMK_TRY(pack_bias(A.bias, 1, 2, C, pbias + C, 1, st));
         }
-      }
-    }
-  }
-  // pipelined mode: [res ; fc0 . W_skip] per layer - the skip sums only ever feed the head's first Linear, so its product with
-  // every layer's skip convolution is taken once here and the layers accumulate the HIDDEN units' pre-activations directly
-  // (one exchange less per step, H1 instead of C rows to multiply and to hand from stage to stage)
-  if (p->pipe) {
-    const int H1 = c.mlp_hidden;
-    const float* f0 = b.need("output_modules.0.estimator.0.fc.0.weight", (int64_t)H1 * C);
-    for (int l = 0; l < L && f0; ++l) {
-      const std::string ly = "layers." + std::to_string(l) + ".";
-      PackedLinear& Bh = p->Bh[l];
-      const int n_res = p->has_res[l] ? C : 0;
-      if (p->has_res[l]) {
-        const float* wr = b.need(ly + "conv_res.weight", (int64_t)C * C);
-        const float* br = bias ? b.need(ly + "conv_res.bias", C) : nullptr;
-        if (wr) MMK_TRY(pack_rect(Bh.Wp, Bh.k_chunks, 0, 1, C, 0, C, wr, C, 1, st));
-        if (br) MMK_TRY(pack_bias(Bh.bias, 0, 1, C, br, 0, st));
-      }
-      const float* ws = b.need(ly + "conv_skip.weight", (int64_t)C * C);
-      const float* bs = bias ? b.need(ly + "conv_skip.bias", C) : nullptr;
-      if (ws) {
-        float* prod = p->compose_scratch;
-        float* pbias = prod + (int64_t)2 * C * C;
-        hipLaunchKernelGGL(compose_kernel, dim3(512), dim3(256), 0, st, f0, (int64_t)C, (int64_t)1, H1, ws, bs, prod, pbias, C);
-        MMK_HIP(hipGetLastError());
-        MMK_TRY(pack_rect(Bh.Wp, Bh.k_chunks, n_res, 1, H1, 0, C, prod, C, 1, st));
-        MMK_TRY(pack_bias(Bh.bias, n_res, 1, H1, pbias, 0, st));
       }
     }
   }
@@ -964,12 +867,12 @@ extern "C" int mmk_wavenet_commit(mmk_wavenet_plan* p, void* workspace, size_t w
 #endif
     MMK_HIP(hipMemcpyAsync(p->layer_tab, tab.data(), sizeof(WnLayerTab) * L, hipMemcpyHostToDevice, st));
     std::vector<WnChainIter> it(L + 1);
-    if (p->chain || p->pipe) {
+    if (p->chain) {
       for (int i = 0; i <= L; ++i) {
         const int la = i < L ? i : 0;
         it[i].A_wp = p->Ac[la].Wp;
         it[i].A_bias = p->Ac[la].bias;
-        const PackedLinear* Bsrc = i >= 1 ? (p->pipe ? &p->Bh[i - 1] : &p->Bm[i - 1]) : nullptr;
+        const PackedLinear* Bsrc = i >= 1 ? &p->Bm[i - 1] : nullptr;
         it[i].B_wp = Bsrc ? Bsrc->Wp : nullptr;
         it[i].B_bias = Bsrc ? Bsrc->bias : nullptr;
         it[i].ring_offset = p->ring_offset[la];
@@ -1264,35 +1167,6 @@ static int run_persistent(mmk_wavenet_plan* p, const WnCall& call, int64_t tau0,
       done += nb;
       continue;
     }
-    if (p->pipe) {
-      if (!with_head) return fail(MMK_ERR_STATE, "wavenet: the pipelined kernel has no teacher-forced mode (warm-up is a prefill)");
-      MMK_HIP(hipMemsetAsync(p->px_yl, 0, (size_t)p->pipe_gran_words * sizeof(unsigned long long), st));
-      WnPipeArgs k = {};
-      k.B = call.M; k.Gc = (call.M + p->Mg - 1) / p->Mg; k.Gn = p->Gn; k.Mg = p->Mg;
-      k.L = p->L; k.C = p->C; k.C1 = p->C1; k.n_it = p->pipe_nit;
-      k.q_levels = c.q_levels; k.H1 = c.mlp_hidden; k.n_classes = c.out_dim; k.n_logits_pad = p->n_logits_pad;
-      k.learn_temp = c.learn_temp; k.min_temp = c.min_temp;
-      k.t0 = tau_b + 1; k.n_steps = nb;
-      k.iters = p->iter_tab; k.ring_floats_per_wg = p->ring_floats_per_wg;
-      k.emb = p->emb; k.idx = (int64_t*)call.in0; k.idx_rs = call.in0_rs;
-      k.condall = p->condall; k.cond_steps = p->kCondBlock; k.zeros = p->zero_pad;
-      k.fc0_wp = p->mlp[0].Wp; k.fc0_bias = p->mlp[0].bias; k.fc2_wp = p->mlp[1].Wp; k.fc2_bias = p->mlp[1].bias;
-      k.temperature = call.temperature;
-      k.uniforms = call.uniforms ? call.uniforms + done : nullptr;
-      k.uni_ld = call.uni_ld;
-      k.logits_out = p->logits; k.logits_ld = p->logits_ld;
-      k.gran_yl = p->px_yl; k.gran_hl = p->px_hl; k.gran_hown = p->px_hown; k.gran_yx = p->px_yx; k.gran_hx = p->px_hx;
-      k.gran_skipfwd = p->px_skipfwd;
-      k.gran_skip = p->gran_skip; k.gran_hid = p->gran_hid; k.gran_logit = p->gran_logit; k.gran_idx = p->gran_idx;
-      k.h_rings = p->h_rings; k.err_flag = p->err_flag; k.xcd_count = p->xcd_count;
-      k.stamps = (stamp_env && stamp_env[0] == '1') ? reinterpret_cast<unsigned long long*>(p->tau + 8) : nullptr;
-      k.stamp_stage = p->tune.get("MMK_WN_STAMP_STAGE") ? atoi(p->tune.get("MMK_WN_STAMP_STAGE")) : 1;
-      k.stamp_owner = p->tune.get("MMK_WN_STAMP_OWNER") ? atoi(p->tune.get("MMK_WN_STAMP_OWNER")) : 1;
-      k.stamp_wave = p->tune.get("MMK_WN_STAMP_WAVE") ? atoi(p->tune.get("MMK_WN_STAMP_WAVE")) : 0;
-      MMK_TRY(launch_wavenet_pipe(k, st));
-      done += nb;
-      continue;
-    }
     if (p->chain && with_head) {
       WnChainArgs k = {};
       k.B = call.M; k.Gc = p->Gc; k.Gn = p->Gn; k.Mg = p->Mg;
@@ -1372,10 +1246,6 @@ static int prefill(mmk_wavenet_plan* p, const WnCall& call, int64_t t_begin, int
     const int64_t t_lo = t_end - d > t_begin ? t_end - d : t_begin;
     if (p->lpipe || p->spipe)  // the launch path's rings: [slot][Bmax][C]
       MMK_TRY(launch_wn_lpipe_scatter(p->pf_h[cur], P * C, t_begin, t_lo, (int)(t_end - t_lo), C, B, p->Bmax, p->hist[l], p->ring[l], st));
-    else if (p->pipe)   // the rings of layer l live with the workgroups of its stage and hold all clips per slot
-      MMK_TRY(launch_wn_prefill_scatter(p->pf_h[cur], P * C, t_begin, t_lo, (int)(t_end - t_lo), C, B, p->Gc * p->Mg, 1, p->Gn,
-                                        p->h_rings + (int64_t)(l / p->pipe_nit) * p->Gn * p->ring_floats_per_wg, p->ring_floats_per_wg,
-                                        p->ring_offset[l], p->ring_mask[l], st));
     else
       MMK_TRY(launch_wn_prefill_scatter(p->pf_h[cur], P * C, t_begin, t_lo, (int)(t_end - t_lo), C, B, p->Mg, p->Gc, p->Gn, p->h_rings,
                                         p->ring_floats_per_wg, p->ring_offset[l], p->ring_mask[l], st));
@@ -1479,7 +1349,7 @@ extern "C" int mmk_wavenet_warmup(mmk_wavenet_plan* p, int32_t batch, const void
   call.in0_rs = in0_row_stride;
   if (t_begin < 0 || t_end < t_begin) return fail(MMK_ERR_INVALID, "wavenet_warmup: bad range [%lld, %lld)", (long long)t_begin, (long long)t_end);
   const char* penv = p->tune.get("MMK_WN_PREFILL");
-  if (p->pipe || p->lpipe || p->spipe) {
+  if (p->lpipe || p->spipe) {
     // the stage-owned rings are only filled by the prefill; a longer window than the receptive field adds nothing to the
     // ring entries generation reads (each is determined by the rf - 1 positions before t_end)
     if (t_end - t_begin > p->rf - 1) t_begin = t_end - (p->rf - 1);
@@ -1572,7 +1442,7 @@ extern "C" int mmk_wavenet_profile_steps(mmk_wavenet_plan* p, int32_t batch, voi
 }
 
 extern "C" int mmk_wavenet_mode(const mmk_wavenet_plan* p) {
-  return (p && p->persistent) ? (p->spipe ? 5 : (p->lpipe ? 4 : (p->pipe ? 3 : (p->chain ? 2 : 1)))) : 0;
+  return (p && p->persistent) ? (p->spipe ? 5 : (p->lpipe ? 4 : (p->chain ? 2 : 1))) : 0;
 }
 
 extern "C" int mmk_wavenet_inject_sync_error(mmk_wavenet_plan* p, mmk_stream_t stream) {
@@ -1653,16 +1523,6 @@ extern "C" int mmk_wavenet_sync_status(mmk_wavenet_plan* p, mmk_stream_t stream)
           }
           fprintf(stderr, "\n");
         }
-        return MMK_OK;
-      }
-      if (p->pipe) {
-        fprintf(stderr, "[mmk stamps] last pipelined launch, lane 0 of one wave (MMK_WN_STAMP_STAGE / _OWNER / _WAVE, default 1 / 1 / 0), totals in ms: visit start (own h + wait for the "
-                        "group's inputs)=%.3f; request issue=%.3f; operands from LDS=%.3f; MFMA + partial sums=%.3f; wait B1=%.3f; epilogues + publish=%.3f; small operands + ring store=%.3f; "
-                        "wait y/h=%.3f; head [publish hidden=%.3f, wait hidden=%.3f, fc2=%.3f, wait logits=%.3f, sampler=%.3f, rest=%.3f]; "
-                        "whole launch=%.3f; shader clock=%.0f MHz\n",
-                st[7] * 1e-5, st[4] * 1e-5, st[5] * 1e-5, st[9] * 1e-5, st[0] * 1e-5, st[1] * 1e-5, st[2] * 1e-5, st[3] * 1e-5, st[10] * 1e-5, st[11] * 1e-5,
-                st[12] * 1e-5, st[13] * 1e-5, st[8] * 1e-5, st[6] * 1e-5, st[15] * 1e-5,
-                st[15] ? 100.0 * (double)st[14] / (double)st[15] : 0.0);
         return MMK_OK;
       }
       if (p->chain) {

@@ -11,7 +11,7 @@
 // with W1 R and fc0 W_skip pre-multiplied at commit (fp64 accumulation, one rounding).
 //
 // Why this shape.  A step of one clip is a chain of L + 1 dependent all-to-all exchanges; arithmetic (0.75 GFLOP per step and batch)
-// and bytes are a tenth of it.  wavenet_pipe.hip spreads a layer over 32 CUs and moves groups of 4 clips: 2.3 us per layer, of which
+// and bytes are a tenth of it.  the XCD-pipelined kernel of rounds 2 - 4 (removed) spread a layer over 32 CUs and moved groups of 4 clips: 2.3 us per layer, of which
 // two workgroup barriers, the K-split reduction through LDS and a 32-way gather are most.  Here
 //   * a layer lives on 8 CUs (the whole net on 30 x 8 + 8 = 248 of the 256 CUs, 4 stages per XCD: 7 of 8 exchanges stay in one L2);
 //   * a visit is ONE clip: per wave 16 gate rows x 512 inputs = 128 weights per lane, all in registers, packed-fp32 FMAs out of a

@@ -563,11 +563,6 @@ class WaveNetPlan(_Plan):
         return self._lib.mmk_wavenet_mode(self.handle) == 2
 
     @property
-    def pipelined(self) -> bool:
-        """persistent mode with the layers spread over the XCDs and the clip groups pipelined through them (csrc/wavenet_pipe.hip)"""
-        return self._lib.mmk_wavenet_mode(self.handle) == 3
-
-    @property
     def layer_pipelined(self) -> bool:
         """persistent mode with four workgroups per clip that own whole layers (csrc/wavenet_lpipe.hip)"""
         return self._lib.mmk_wavenet_mode(self.handle) == 4
@@ -655,7 +650,6 @@ class WaveNetPlanSet:
 
     persistent = property(lambda self: self.plans[0].persistent)
     chain = property(lambda self: self.plans[0].chain)
-    pipelined = property(lambda self: self.plans[0].pipelined)
     layer_pipelined = property(lambda self: self.plans[0].layer_pipelined)
     stage_pipelined = property(lambda self: self.plans[0].stage_pipelined)
 

@@ -14,17 +14,16 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import mimikit_amd as mmk  # noqa: E402
 
 torch.set_grad_enabled(False)
-KNOBS = ("MMK_WN_PERSISTENT", "MMK_WN_CHAIN", "MMK_WN_PIPE", "MMK_WN_LPIPE", "MMK_WN_SPIPE")
+KNOBS = ("MMK_WN_PERSISTENT", "MMK_WN_CHAIN", "MMK_WN_LPIPE", "MMK_WN_SPIPE")
 PATHS = {                   # forced through the plan's `tuning` switches (native.PLAN_TUNING)
     "launch": dict(MMK_WN_PERSISTENT="0"),
-    "persist": dict(MMK_WN_SPIPE="0", MMK_WN_CHAIN="0", MMK_WN_PIPE="0", MMK_WN_LPIPE="0"),
+    "persist": dict(MMK_WN_SPIPE="0", MMK_WN_CHAIN="0", MMK_WN_LPIPE="0"),
     "chain": dict(MMK_WN_SPIPE="0", MMK_WN_CHAIN="1"),
-    "pipe": dict(MMK_WN_SPIPE="0", MMK_WN_CHAIN="0", MMK_WN_PIPE="1"),
-    "lpipe": dict(MMK_WN_SPIPE="0", MMK_WN_CHAIN="0", MMK_WN_PIPE="0", MMK_WN_LPIPE="1"),
+    "lpipe": dict(MMK_WN_SPIPE="0", MMK_WN_CHAIN="0", MMK_WN_LPIPE="1"),
     "spipe": dict(MMK_WN_SPIPE="1"),
     "default": None,        # whatever the plan picks on its own
 }
-MODE_NAMES = {0: "launch", 1: "persist", 2: "chain", 3: "pipe", 4: "lpipe", 5: "spipe"}
+MODE_NAMES = {0: "launch", 1: "persist", 2: "chain", 4: "lpipe", 5: "spipe"}
 
 
 def network(C, blocks, cond):

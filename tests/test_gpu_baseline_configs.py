@@ -245,7 +245,7 @@ def test_cfg4_composed_products_against_the_reference_association(device, monkey
     cond = torch.rand(B, rf + 1, 513, generator=gen)
     raws = {}
     for mode, env in (("composed", {}), ("reference association", {"MMK_WN_PERSISTENT": "0"})):
-        for k in ("MMK_WN_PERSISTENT", "MMK_WN_SPIPE", "MMK_WN_PIPE", "MMK_WN_CHAIN"):
+        for k in ("MMK_WN_PERSISTENT", "MMK_WN_SPIPE", "MMK_WN_CHAIN"):
             monkeypatch.delitem(mmk.native.PLAN_TUNING, k, raising=False)
         for k, v in env.items():
             monkeypatch.setitem(mmk.native.PLAN_TUNING, k, v)

@@ -960,14 +960,14 @@ def _cond_net(seed=21):
 MODES = {"persistent_xcd": {}, "persistent_agent": {"MMK_WN_XCD_LOCAL": "0"}, "persistent_tiles": {"MMK_WN_SMALL": "0", "MMK_WN_CHAIN": "0"},
          "persistent_step_warmup": {"MMK_WN_PREFILL": "0"}, "launches": {"MMK_WN_PERSISTENT": "0"},
          "two_handoffs_xcd": {"MMK_WN_CHAIN": "0"}, "two_handoffs_agent": {"MMK_WN_CHAIN": "0", "MMK_WN_XCD_LOCAL": "0"},
-         "two_handoffs_step_warmup": {"MMK_WN_CHAIN": "0", "MMK_WN_PREFILL": "0"}, "pipelined": {"MMK_WN_PIPE": "1"}}
+         "two_handoffs_step_warmup": {"MMK_WN_CHAIN": "0", "MMK_WN_PREFILL": "0"}}
 
 
 def test_wavenet_timeout_is_redone_on_launch_path(device, monkeypatch):
     """a hand-off timeout reported by the persistent kernel (injected through mmk_wavenet_inject_sync_error) must not return
     blanks: the batch is regenerated on the per-layer launch path, with a warning; both generations are held to the oracle the way
     the modes test does (the two paths associate their sums differently)"""
-    for k in ("MMK_WN_XCD_LOCAL", "MMK_WN_PERSISTENT", "MMK_WN_GROUPS", "MMK_WN_SMALL", "MMK_WN_PREFILL", "MMK_WN_CHAIN", "MMK_WN_PIPE"):
+    for k in ("MMK_WN_XCD_LOCAL", "MMK_WN_PERSISTENT", "MMK_WN_GROUPS", "MMK_WN_SMALL", "MMK_WN_PREFILL", "MMK_WN_CHAIN"):
         monkeypatch.delitem(mmk.native.PLAN_TUNING, k, raising=False)
     net, sd, arch = _cond_net()
     net = net.to(device)
@@ -994,7 +994,7 @@ def test_wavenet_modes_agree_with_oracle(device, mode, monkeypatch):
     """the persistent kernels - one hand-off per layer (wavenet_chain.hip) and two (wavenet_persist.hip), XCD-local and
     agent-scope hand-offs, 4x4 MFMA blocks and 16-row tiles, warm-up as a prefill and step by step - and the per-layer launch
     path all reproduce the oracle: conditioned net, batch 5 (ragged clip groups), prompt longer than rf, 70 steps, greedy + sampled"""
-    for k in ("MMK_WN_XCD_LOCAL", "MMK_WN_PERSISTENT", "MMK_WN_GROUPS", "MMK_WN_SMALL", "MMK_WN_PREFILL", "MMK_WN_CHAIN", "MMK_WN_PIPE"):
+    for k in ("MMK_WN_XCD_LOCAL", "MMK_WN_PERSISTENT", "MMK_WN_GROUPS", "MMK_WN_SMALL", "MMK_WN_PREFILL", "MMK_WN_CHAIN"):
         monkeypatch.delitem(mmk.native.PLAN_TUNING, k, raising=False)
     for k, v in MODES[mode].items():
         monkeypatch.setitem(mmk.native.PLAN_TUNING, k, v)
@@ -1010,7 +1010,6 @@ def test_wavenet_modes_agree_with_oracle(device, mode, monkeypatch):
     net.after_generate((idx,), None)
     assert net._plan.persistent == (mode != "launches")
     assert net._plan.chain == (mode in ("persistent_xcd", "persistent_agent", "persistent_step_warmup"))
-    assert net._plan.pipelined == (mode == "pipelined")
     ok = H.margin_ok(raw.numpy())
     first_bad = (~ok).float().cumsum(1) > 0
     same = idx.cpu()[:, prompt.size(1):] == want[:, prompt.size(1):]
@@ -1049,7 +1048,7 @@ def test_wavenet_layer_pipeline_agrees_with_oracle(device, monkeypatch, blocks, 
     3 + 3 + 3 + 2, 1 + 1 + 1 + 1 layers per stage), 8 / 13 / 3 / 64 clips (a ragged last group of eight; every CU slot of the grid),
     prompt longer than rf, two generate blocks, greedy against the oracle (classes exact where the oracle's margin allows, last
     logits within tolerance) and sampled against the oracle's CDF intervals; and the same net with the mode switched off"""
-    for k in ("MMK_WN_XCD_LOCAL", "MMK_WN_PERSISTENT", "MMK_WN_GROUPS", "MMK_WN_SMALL", "MMK_WN_PREFILL", "MMK_WN_CHAIN", "MMK_WN_PIPE", "MMK_WN_LPIPE"):
+    for k in ("MMK_WN_XCD_LOCAL", "MMK_WN_PERSISTENT", "MMK_WN_GROUPS", "MMK_WN_SMALL", "MMK_WN_PREFILL", "MMK_WN_CHAIN", "MMK_WN_LPIPE"):
         monkeypatch.delitem(mmk.native.PLAN_TUNING, k, raising=False)
     for k, v in env.items():                 # (MMK_WN_XCD_LOCAL=0: every hand-over written through to memory)
         monkeypatch.setitem(mmk.native.PLAN_TUNING, k, v)
@@ -1129,7 +1128,7 @@ def test_wavenet_persistent_kernel_shapes(device, monkeypatch, C, B, env):
     agent-scope groups with a ragged last group, 256 channels with 5 clips per group; the one-hand-off kernel at 96 / 160 /
     224 / 64 / 256 channels (3 / 5 / 7 / 2 / 8 K-chunks per matrix wave, odd counts split 2 + 1 ... between the two
     weight pieces), full and ragged groups of up to 4 clips, XCD-local and agent-scope"""
-    for k in ("MMK_WN_XCD_LOCAL", "MMK_WN_PERSISTENT", "MMK_WN_GROUPS", "MMK_WN_SMALL", "MMK_WN_PREFILL", "MMK_WN_CHAIN", "MMK_WN_PIPE"):
+    for k in ("MMK_WN_XCD_LOCAL", "MMK_WN_PERSISTENT", "MMK_WN_GROUPS", "MMK_WN_SMALL", "MMK_WN_PREFILL", "MMK_WN_CHAIN"):
         monkeypatch.delitem(mmk.native.PLAN_TUNING, k, raising=False)
     for k, v in env.items():
         monkeypatch.setitem(mmk.native.PLAN_TUNING, k, v)
@@ -1256,50 +1255,6 @@ def test_sample_rnn_protocol_details(device):
     assert s(logits.reshape(5, 1, 256), temperature=0.7).shape == (5, 1)
 
 
-@pytest.mark.parametrize("blocks,C,B,n", [((4, 4), 64, 32, 40), ((10, 8), 32, 13, 30), ((3,), 96, 3, 12), ((10, 10, 10), 32, 8, 1100),
-                                          ((10, 10, 10, 1), 64, 29, 20)])
-def test_wavenet_pipelined_kernel_shapes(device, monkeypatch, blocks, C, B, n):
-    """the XCD-pipelined, weight-stationary kernel (wavenet_pipe.hip) against the oracle: 2 / 3 / 1 / 4 iterations per stage
-    (9 / 19 / 4 / 31 / 32 iterations over 5 / 7 / 4 / 8 / 8 stages), full and ragged groups, one to eight groups in flight,
-    more steps than one conditioning block (two launches chained through the stage-owned history rings), conditioned"""
-    for k in ("MMK_WN_XCD_LOCAL", "MMK_WN_PERSISTENT", "MMK_WN_GROUPS", "MMK_WN_SMALL", "MMK_WN_PREFILL", "MMK_WN_CHAIN", "MMK_WN_PIPE"):
-        monkeypatch.delitem(mmk.native.PLAN_TUNING, k, raising=False)
-    monkeypatch.setitem(mmk.native.PLAN_TUNING, "MMK_WN_PIPE", "1")
-    from oracle.weights import load_recipe
-    io = H.mu_emb(mlp_dim=32)
-    ext = mmk.Extractor("signal", mmk.FileToSignal(16000))
-    io = mmk.IOSpec(inputs=(io.inputs[0], mmk.InputSpec("signal", mmk.MagSpec(22, 4, center=False), mmk.LinearIO()).bind_to(ext)),
-                    targets=io.targets)
-    net = mmk.WaveNet.from_config(mmk.WaveNet.Config(io_spec=io, blocks=blocks, dims_dilated=(C,), dims_1x1=(16,),
-                                                     residuals_dim=C, skips_dim=C)).eval()
-    sd = load_recipe(net, seed=70 + C + B, gain=2.0)
-    L = sum(blocks)
-    arch = dict(kernels=[2] * L, dilations=[2 ** i for b in blocks for i in range(b)], has_skips=True, residuals=True)
-    net = net.to(device)
-    gen = torch.Generator().manual_seed(C + B)
-    rf = net.rf
-    prompt = torch.randint(0, 256, (B, rf + 3), generator=gen)
-    cond = torch.rand(B, rf + 3 + n, 12, generator=gen)
-    idx = torch.cat([prompt, torch.zeros(B, n, dtype=torch.int64)], 1).to(device)
-    net.generate_block((idx, cond.to(device)), prompt.size(1), n)
-    net.after_generate((idx,), None)
-    assert net._plan.pipelined
-    got = idx.cpu()
-    P = prompt.size(1)
-    steps = list(range(n)) if n <= 40 else list(range(0, 6)) + list(range(1020, 1030)) + list(range(n - 6, n))
-    n_ok = 0
-    for s_ in steps:       # teacher-forced on the device's own history: every checked step of every clip
-        t = P + s_
-        raw = O.wavenet_window_forward(sd, (got[:, t - rf:t], cond[:, t - rf:t]), n_cond=1, **arch)
-        pick = O.categorical(O.mlp_logits(raw))[:, 0]
-        gap_ok = H.margin_ok(raw.numpy())[:, 0]
-        assert bool(((pick == got[:, t]) | ~gap_ok).all()), f"step {s_}"
-        n_ok += int(gap_ok.sum())
-        if s_ == n - 1:
-            assert torch.allclose(net._plan.last_logits(B).cpu()[gap_ok], raw[:, 0][gap_ok], **LOGIT_TOL)
-    assert n_ok > 0.9 * len(steps) * B
-
-
 def _cfg4_family_net(blocks, seed, cond):
     """the geometry family of BASELINE config 4: 256 channels, kernel 2, gated, skips 256, embedding in, MLP head 128 -> 256 (+ temperature),
     optionally one conditioning input (12 -> 16 channels)"""
@@ -1318,7 +1273,7 @@ def _cfg4_family_net(blocks, seed, cond):
     return net, sd, arch
 
 
-SPIPE_ENV = ("MMK_WN_XCD_LOCAL", "MMK_WN_PERSISTENT", "MMK_WN_GROUPS", "MMK_WN_SMALL", "MMK_WN_PREFILL", "MMK_WN_CHAIN", "MMK_WN_PIPE", "MMK_WN_LPIPE",
+SPIPE_ENV = ("MMK_WN_XCD_LOCAL", "MMK_WN_PERSISTENT", "MMK_WN_GROUPS", "MMK_WN_SMALL", "MMK_WN_PREFILL", "MMK_WN_CHAIN", "MMK_WN_LPIPE",
              "MMK_WN_SPIPE")
 
 
@@ -1574,7 +1529,7 @@ def test_wavenet_layer_pipeline_takes_narrower_heads(device, monkeypatch, q, mlp
     the kernel's 128 x 256 (zero rows / columns, -inf bias for the classes that do not exist).  Greedy against the oracle, the last
     step's raw outputs (the network's own columns), sampled picks inside the oracle's CDF intervals - never a class that does not exist"""
     from oracle.weights import load_recipe
-    for k in ("MMK_WN_XCD_LOCAL", "MMK_WN_PERSISTENT", "MMK_WN_GROUPS", "MMK_WN_SMALL", "MMK_WN_PREFILL", "MMK_WN_CHAIN", "MMK_WN_PIPE", "MMK_WN_LPIPE"):
+    for k in ("MMK_WN_XCD_LOCAL", "MMK_WN_PERSISTENT", "MMK_WN_GROUPS", "MMK_WN_SMALL", "MMK_WN_PREFILL", "MMK_WN_CHAIN", "MMK_WN_LPIPE"):
         monkeypatch.delitem(mmk.native.PLAN_TUNING, k, raising=False)
     net = mmk.WaveNet.from_config(mmk.WaveNet.Config(io_spec=H.mu_emb(mlp_dim=mlp_dim, q_levels=q), blocks=blocks, dims_dilated=(64,), residuals_dim=64,
                                                      skips_dim=64)).eval()

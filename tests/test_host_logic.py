@@ -202,8 +202,7 @@ def test_execution_switches_travel_in_the_config_not_in_the_environment(monkeypa
     """which kernel a plan gets is decided by its config's `tuning` text (include/mmk.h) - an environment variable of the same name
     changes nothing (round 3's library read ~35 of them at plan creation)"""
     assert _cfg4_plan_mode(b"") == 5                                  # the stage pipeline
-    assert _cfg4_plan_mode(b"MMK_WN_SPIPE=0") == 3                    # the XCD-pipelined kernel
-    assert _cfg4_plan_mode(b"MMK_WN_SPIPE=0;MMK_WN_PIPE=0") in (1, 2)
+    assert _cfg4_plan_mode(b"MMK_WN_SPIPE=0") in (1, 2)               # the two- or one-hand-off persistent kernel
     assert _cfg4_plan_mode(b"MMK_WN_PERSISTENT=0") == 0               # the per-layer launch path
     monkeypatch.setenv("MMK_WN_SPIPE", "0")
     monkeypatch.setenv("MMK_WN_PERSISTENT", "0")
