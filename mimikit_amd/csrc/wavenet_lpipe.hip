@@ -1,6 +1,8 @@
 // WaveNet generation as a PIPELINE OF WORKGROUPS THAT OWN WHOLE LAYERS (gfx950) - for networks small enough that a layer's matrices
-// fit a fraction of a CU's registers: C = S = 64 channels, kernel 2, gated, MLP head 64 -> 128 -> 256 (+ temperature), no conditioning
-// (BASELINE config 2: ten layers, dilations 1 .. 512, 8 clips).
+// fit a fraction of a CU's registers: C = S = 64 channels, kernel 2, gated, MLP head 64 -> 128 -> 256 (+ temperature)
+// (BASELINE config 2: ten layers, dilations 1 .. 512, 8 clips), with or without one conditioning input - whose products conv_1x1(c)
+// (wavenet_v2.py:141-147) the plan forms for a block of positions ahead of the launch, as for the other persistent kernels: a thread reads
+// its gate row's term with the delayed taps, off the step's chain.
 //
 // Reference: WaveNet.forward / WNLayer.forward (wavenet_v2.py:120-180, :277-296), MLP head and CategoricalSampler (networks/mlp.py:58-63,
 // modules/targets.py:37-52) - the same arithmetic as the other step kernels, on the launch path's packed matrices.
@@ -56,9 +58,11 @@ __device__ __forceinline__ u64 poll(const u64* p, unsigned epoch, int32_t* err) 
   return g;
 }
 
-template <int NL, bool HEAD, bool FIRST>
-__device__ void run_stage(const WnLpipeArgs& a, int clip, int stage, int l0, float* embs) {
-  __shared__ __attribute__((aligned(16))) float xs[2][kC], taps[3][kC], zs[kC], sk[kC], hid[kH1], lg[kQ + 4];
+// (forced inline: left as a function, a stage takes the argument block by address and the compiler copies all of it to scratch - every
+//  pointer and count read from it afterwards then sits in vector registers the matrices need)
+template <int NL, bool HEAD, bool FIRST, bool COND>
+__device__ __forceinline__ void run_stage(const WnLpipeArgs& a, int clip, int stage, int l0, float* embs) {
+  __shared__ __attribute__((aligned(16))) float xs[2][kC], taps[3][kC], zs[kC], sk[kC], hid[kH1], lg[kQ + 4], cnds[COND ? 3 : 1][2 * kC];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int o = tid >> 2, kq = tid & 3;
@@ -71,8 +75,8 @@ __device__ void run_stage(const WnLpipeArgs& a, int clip, int stage, int l0, flo
 #pragma unroll
   for (int i = 0; i < NL; ++i) {
     const WnLayerTab lt = a.layers[l0 + i];
-    dil[i] = lt.dil;
-    has_res[i] = lt.has_res;
+    dil[i] = __builtin_amdgcn_readfirstlane(lt.dil);            // (wave-uniform: scalar registers - the vector ones are all taken by the matrices)
+    has_res[i] = __builtin_amdgcn_readfirstlane(lt.has_res);
     // (f, g) rows in packed (interleaved) order: quad 2 u holds f of unit u, quad 2 u + 1 its g - four lanes apart, so the gate needs
     // no LDS round trip; K = [x(t - d) | x(t)]
     const int ra = o;
@@ -80,8 +84,8 @@ __device__ void run_stage(const WnLpipeArgs& a, int clip, int stage, int l0, flo
     // every layer's product is formed before the step's input arrives
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
-      wc[i][k] = packed_at(lt.A_wp, 8, ra, kq * 16 + k);
-      wc[i][16 + k] = packed_at(lt.A_wp, 8, ra, kC + kq * 16 + k);
+      wc[i][k] = packed_at(lt.A_wp, a.kcA, ra, kq * 16 + k);
+      wc[i][16 + k] = packed_at(lt.A_wp, a.kcA, ra, kC + kq * 16 + k);
     }
     bc[i] = lt.A_bias ? lt.A_bias[ra] : 0.f;
     // [res ; skip] rows: without residual rows (the last layer) the skip rows come first
@@ -145,19 +149,34 @@ __device__ void run_stage(const WnLpipeArgs& a, int clip, int stage, int l0, flo
   const u64* in_g = a.xg + ((int64_t)stage * a.Bmax + clip) * 128;
   u64* out_g = a.xg + ((int64_t)(stage + 1) * a.Bmax + clip) * 128;
   const int64_t slot_stride = (int64_t)a.Bmax * kC;
+  float cnd_next = 0.f;
+  if constexpr (COND) {
+    if (wave < 2 * NL) cnd_next = a.condall[((int64_t)clip * a.cond_steps) * ((int64_t)a.L * 2 * kC) + (int64_t)(l0 + (wave >> 1)) * 2 * kC + (tid & 127)];
+  }
   for (int s = 0; s < (int)a.n_steps; ++s) {
     const int64_t tau = a.t0 - 1 + s;                    // the input position of this step; the class it produces goes to tau + 1
     // ---- the delayed taps of my layers (addresses known) ------------------------------------------------------------------------
     float tap = 0.f;
-    if (tid < kC * NL) {
-      const int i = tid >> 6;
-      const int64_t tp = tau - dil[i];
+    if (wave < NL) {
+      const int i = wave;                                 // (wave-uniform: the ring's pointer and size are scalar loads from the kernel's arguments)
+      const int d = dil[i], rm = a.ring[l0 + i] - 1;
+      const float* hp = a.hist[l0 + i];
+      const int64_t tp = tau - d;
       // (past this CU's L1: the slot was read a ring ago and rewritten since)
-      tap = tp >= 0 ? __hip_atomic_load(a.hist[l0 + i] + (tp & (a.ring[l0 + i] - 1)) * slot_stride + (int64_t)clip * kC + lane, __ATOMIC_RELAXED,
+      tap = tp >= 0 ? __hip_atomic_load(hp + (tp & rm) * slot_stride + (int64_t)clip * kC + lane, __ATOMIC_RELAXED,
                                         __HIP_MEMORY_SCOPE_AGENT)
                     : 0.f;
     }
-    if (tid < kC * NL) taps[tid >> 6][lane] = tap;
+    // conv_1x1(c[tau]) of every gate row of the stage's layers (:141-147): staged in LDS with the taps; the row of the NEXT step is asked for
+    // here and rides in one register through this step (read at the step's start it would come from HBM in front of the barrier)
+    if constexpr (COND) {
+      if (wave < 2 * NL) {
+        cnds[wave >> 1][tid & 127] = cnd_next;
+        const int64_t sn = s + 1 < (int)a.n_steps ? s + 1 : s;
+        cnd_next = a.condall[((int64_t)clip * a.cond_steps + sn) * ((int64_t)a.L * 2 * kC) + (int64_t)(l0 + (wave >> 1)) * 2 * kC + (tid & 127)];
+      }
+    }
+    if (wave < NL) taps[wave][lane] = tap;
     __syncthreads();
     float ptap[NL];                                       // W_tap x(t - d) of my rows, off the step's chain
 #pragma unroll
@@ -166,6 +185,7 @@ __device__ void run_stage(const WnLpipeArgs& a, int clip, int stage, int l0, flo
 #pragma unroll
       for (int k = 0; k < 16; ++k) p4[k & 3] = fmaf(wc[i][k], taps[i][kq * 16 + k], p4[k & 3]);
       ptap[i] = (p4[0] + p4[1]) + (p4[2] + p4[3]);
+      if constexpr (COND) ptap[i] += kq == 0 ? cnds[i][o] : 0.f;      // (the quad's sum takes the term once)
     }
     // ---- this step's input -----------------------------------------------------------------------------------------------------------
     if constexpr (FIRST) {
@@ -204,6 +224,7 @@ __device__ void run_stage(const WnLpipeArgs& a, int clip, int stage, int l0, flo
       float* xn = xs[(i + 1) & 1];
       // the layer's input at tau goes to its ring for later taps (and for the launch path, should the batch be redone there)
       if (tid < kC) a.hist[l0 + i][(tau & (a.ring[l0 + i] - 1)) * slot_stride + (int64_t)clip * kC + tid] = xc[tid];
+
       float acc4[4] = {ptap[i], 0.f, 0.f, 0.f};                              // four chains of 4
 #pragma unroll
       for (int k = 0; k < 16; ++k) acc4[k & 3] = fmaf(wc[i][16 + k], xc[kq * 16 + k], acc4[k & 3]);
@@ -283,24 +304,37 @@ __device__ void run_stage(const WnLpipeArgs& a, int clip, int stage, int l0, flo
   }
 }
 
+template <bool COND>
+__device__ __forceinline__ void stage_of(const WnLpipeArgs& a, int clip, int stage, int l0, int nl, float* embs) {
+  if (stage == 0) {
+    if (nl == 3) run_stage<3, false, true, COND>(a, clip, stage, l0, embs);
+    else if (nl == 2) run_stage<2, false, true, COND>(a, clip, stage, l0, embs);
+    else run_stage<1, false, true, COND>(a, clip, stage, l0, embs);
+  } else if (stage < kLpStages - 1) {
+    if (nl == 3) run_stage<3, false, false, COND>(a, clip, stage, l0, embs);
+    else if (nl == 2) run_stage<2, false, false, COND>(a, clip, stage, l0, embs);
+    else run_stage<1, false, false, COND>(a, clip, stage, l0, embs);
+  } else {
+    if (nl == 2) run_stage<2, true, false, COND>(a, clip, stage, l0, embs);
+    else run_stage<1, true, false, COND>(a, clip, stage, l0, embs);
+  }
+}
+
+// (two kernels: the conditioned stages carry a few registers more through the step - 15 spilled against 3 - and the unconditioned
+//  BASELINE config 2 keeps the allocation it had)
+template <bool COND>
 __global__ __launch_bounds__(kLpThreads) void wavenet_lpipe_kernel(const WnLpipeArgs a) {
   __shared__ float embs[kQ * kC];                    // stage 0's copy of the embedding table (64 KiB)
   const int b = blockIdx.x;
   const int clip = (b & 7) + 8 * (b >> 5), stage = (b >> 3) & 3;
   if (clip >= a.B) return;
-  const int l0 = a.first[stage], nl = a.first[stage + 1] - l0;
-  if (stage == 0) {
-    if (nl == 3) run_stage<3, false, true>(a, clip, stage, l0, embs);
-    else if (nl == 2) run_stage<2, false, true>(a, clip, stage, l0, embs);
-    else run_stage<1, false, true>(a, clip, stage, l0, embs);
-  } else if (stage < kLpStages - 1) {
-    if (nl == 3) run_stage<3, false, false>(a, clip, stage, l0, embs);
-    else if (nl == 2) run_stage<2, false, false>(a, clip, stage, l0, embs);
-    else run_stage<1, false, false>(a, clip, stage, l0, embs);
-  } else {
-    if (nl == 2) run_stage<2, true, false>(a, clip, stage, l0, embs);
-    else run_stage<1, true, false>(a, clip, stage, l0, embs);
-  }
+  // (the stage's layer range by selects on constant indices, in scalar registers)
+  int l0 = a.first[0], l1 = a.first[1];
+  if (stage == 1) { l0 = a.first[1]; l1 = a.first[2]; }
+  if (stage == 2) { l0 = a.first[2]; l1 = a.first[3]; }
+  if (stage == 3) { l0 = a.first[3]; l1 = a.first[4]; }
+  l0 = __builtin_amdgcn_readfirstlane(l0);
+  stage_of<COND>(a, clip, stage, l0, __builtin_amdgcn_readfirstlane(l1 - l0), embs);
 }
 
 __global__ __launch_bounds__(256) void wn_lpipe_scatter_kernel(const float* __restrict__ h, int64_t h_batch, int64_t t_begin, int64_t t_lo, int n_pos,
@@ -331,7 +365,7 @@ void wn_lpipe_split(int L, int32_t (&first)[kLpStages + 1]) {
 
 bool wn_lpipe_supported(int C, int S, int H1, int n_classes, int L, int n_cond, int batch) {
   // (a head of fewer hidden units or classes runs as the 128 x 256 one: the plan pads its matrices - zero rows / columns, -inf bias for classes that do not exist)
-  return C == kC && S == kC && H1 >= 16 && H1 <= kH1 && H1 % 16 == 0 && n_classes >= 2 && n_classes <= kQ && n_cond == 0 && L >= kLpStages && L <= kLpMaxLayers &&
+  return C == kC && S == kC && H1 >= 16 && H1 <= kH1 && H1 % 16 == 0 && n_classes >= 2 && n_classes <= kQ && n_cond <= 1 && L >= kLpStages && L <= kLpMaxLayers &&
          batch >= 1 && batch <= 64;
 }
 
@@ -343,7 +377,8 @@ int launch_wavenet_lpipe(const WnLpipeArgs& a, hipStream_t stream) {
     if (nl < 1 || nl > 3 || (s == kLpStages - 1 && nl > 2)) return fail(MMK_ERR_UNSUPPORTED, "wavenet layer pipeline: stage %d would own %d layers", s, nl);
   }
   const int grid = 32 * ((a.B + 7) / 8);
-  hipLaunchKernelGGL(wavenet_lpipe_kernel, dim3(grid), dim3(kLpThreads), 0, stream, a);
+  if (a.condall != nullptr) hipLaunchKernelGGL(wavenet_lpipe_kernel<true>, dim3(grid), dim3(kLpThreads), 0, stream, a);
+  else hipLaunchKernelGGL(wavenet_lpipe_kernel<false>, dim3(grid), dim3(kLpThreads), 0, stream, a);
   MMK_HIP(hipGetLastError());
   return MMK_OK;
 }

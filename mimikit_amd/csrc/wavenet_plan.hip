@@ -1097,8 +1097,8 @@ static int project_cond(mmk_wavenet_plan* p, const WnCall& call, int j, int col,
 static int run_persistent(mmk_wavenet_plan* p, const WnCall& call, int64_t tau0, int64_t n, bool with_head, hipStream_t st) {
   const mmk_wavenet_config& c = p->cfg;
   for (int64_t done = 0; done < n;) {
-    // (the layer pipeline has no conditioning block to prepare: one launch reads its weights once for up to 2^20 steps)
-    const int64_t block = p->lpipe ? ((int64_t)1 << 20) : (int64_t)p->kCondBlock;
+    // (the layer pipeline without conditioning has no block to prepare: one launch reads its weights once for up to 2^20 steps)
+    const int64_t block = (p->lpipe && p->C1 == 0) ? ((int64_t)1 << 20) : (int64_t)p->kCondBlock;
     const int64_t nb = (n - done) < block ? (n - done) : block;
     const int64_t tau_b = tau0 + done;
     if (p->C1 > 0) {
@@ -1126,6 +1126,8 @@ static int run_persistent(mmk_wavenet_plan* p, const WnCall& call, int64_t tau0,
       k.layers = p->layer_tab;
       for (int l = 0; l < p->L; ++l) { k.hist[l] = p->hist[l]; k.ring[l] = p->ring[l]; }
       k.Bmax = p->Bmax;
+      k.condall = p->C1 > 0 ? p->condall : nullptr; k.cond_steps = p->kCondBlock;
+      k.kcA = 2 * (p->C / 16) + (int)round_up(p->C1, 16) / 16;
       k.emb = p->emb; k.idx = (int64_t*)call.in0; k.idx_rs = call.in0_rs;
       k.fc0_wp = p->lp_mlp0.Wp; k.fc0_bias = p->lp_mlp0.bias; k.fc2_wp = p->lp_mlp1.Wp; k.fc2_bias = p->lp_mlp1.bias;
       k.temperature = call.temperature;

@@ -18,7 +18,7 @@ KNOBS = ("MMK_WN_PERSISTENT", "MMK_WN_CHAIN", "MMK_WN_LPIPE", "MMK_WN_SPIPE")
 PATHS = {                   # forced through the plan's `tuning` switches (native.PLAN_TUNING)
     "launch": dict(MMK_WN_PERSISTENT="0"),
     "persist": dict(MMK_WN_SPIPE="0", MMK_WN_CHAIN="0", MMK_WN_LPIPE="0"),
-    "chain": dict(MMK_WN_SPIPE="0", MMK_WN_CHAIN="1"),
+    "chain": dict(MMK_WN_SPIPE="0", MMK_WN_CHAIN="1", MMK_WN_LPIPE="0"),
     "lpipe": dict(MMK_WN_SPIPE="0", MMK_WN_CHAIN="0", MMK_WN_LPIPE="1"),
     "spipe": dict(MMK_WN_SPIPE="1"),
     "default": None,        # whatever the plan picks on its own
