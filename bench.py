@@ -169,7 +169,7 @@ class WaveNetJob:
             us = start.elapsed_time(stop) * 1e3
             nbytes = self.step_bytes() * n
             achieved = nbytes / (us * 1e-6) / 1e9
-            kshort = ("wavenet_spipe_kernel" if plan.stage_pipelined
+            kshort = ("wavenet_bpipe_kernel" if getattr(plan, "batch_pipelined", False) else "wavenet_spipe_kernel" if plan.stage_pipelined
                       else "wavenet_lpipe_kernel" if plan.layer_pipelined else "wavenet_chain_kernel" if plan.chain else "wavenet_persist_kernel")
             traffic, traffic_source = None, None
             try:  # PMC-derived HBM bytes of one 1024-step launch: NOT measured in this run (counters need their own rocprofv3
@@ -183,7 +183,8 @@ class WaveNetJob:
                                       f"FETCH_SIZE / WRITE_SIZE passes of {entry.get('kernel')}, scaled to {n} steps; not re-measured in this run")
             except (OSError, ValueError):
                 pass
-            kname = ("wavenet_spipe_kernel (one layer per stage of 8 CUs, weights in registers, clips streamed through one at a time)" if plan.stage_pipelined
+            kname = ("wavenet_bpipe_kernel (one layer per stage of 8 CUs, weights in registers as MFMA A operands, clips in groups of 16 per visit)" if getattr(plan, "batch_pipelined", False)
+                     else "wavenet_spipe_kernel (one layer per stage of 8 CUs, weights in registers, clips streamed through one at a time)" if plan.stage_pipelined
                      else "wavenet_lpipe_kernel (four workgroups per clip that own whole layers, weights in registers)" if plan.layer_pipelined
                      else "wavenet_chain_kernel (one hand-off per layer)" if plan.chain else "wavenet_persist_kernel")
             return {"bound": "hbm", "kernel": kname + ": all layers + head of every step of a block",

@@ -1,0 +1,709 @@
+// WaveNet generation as a pipeline of layer stages whose visits are GROUPS OF 16 CLIPS on the matrix pipe (gfx950): the large-batch form of
+// wavenet_spipe.hip.  BASELINE config 4 (30 layers x 256 channels, conditioned) with more clips per GPU than the one-clip ring serves at its
+// beat (~1.1 us per clip and stage: 256 clips = 271 us per step).
+//
+// Reference: WaveNet.forward / WNLayer.forward (wavenet_v2.py:131-182, :276-293), MLP head and CategoricalSampler (networks/mlp.py:58-63,
+// modules/targets.py:37-52).  The arithmetic is the stage pipeline's one-hand-off form:
+//   x_s   = x_{s-1} + R_{s-1} y_{s-1} + br_{s-1}
+//   z_s   = W0_s x_s[t - d_s] + W1_s x_{s-1} + (W1_s R_{s-1}) y_{s-1} + Wc_s c[t] + b
+//   y_s   = tanh(z_f) sigmoid(z_g)
+//   hid  += (fc0 W_skip_{s-1}) y_{s-1}
+// with W1 R and fc0 W_skip composed at commit (fp64 accumulation, one rounding).
+//
+// Shape.  A layer is a stage of 8 CUs (4 stages per XCD, roles from where a workgroup runs, as in the stage pipeline); a CU owns 32 units:
+// 64 gate rows, 32 residual rows, 16 of the head's hidden units - 77,824 weights, in registers for the whole launch as A operands of
+// v_mfma_f32_16x16x4_f32 (152 per lane).  A visit takes the message of one group of 16 clips - x | y | running hidden pre-activations, 40 KB,
+// laid out as the B operand wants it - and costs the CU 1,216 matrix instructions (4.05 us at the fp32 matrix rate) of which 160 per SIMD are
+// on the group's chain:
+//   waves 0-3  gather the message (a quarter each, looking at the words until none is the poison word), multiply a gate tile
+//              (rows: f of 8 units | g of the same 8) with [x | y] (K = 512), add the tile of everything known a visit ahead, gate
+//              (the g half sits 32 lanes up: one cross-half read), publish y;
+//   waves 4-7  multiply a residual tile with a K half of y, add the halves, publish x_s (to the next stage and to the layer's
+//              history ring); then, off the chain: the hidden units' tile (K quarters, added up by wave 4, handed on beside the message)
+//              and the NEXT visit's known terms W0 x_s[t - d] + Wc c[t] + b from rows they stage themselves (history ring - or, d = 1, the
+//              stage's own newest message; the conditioning row).
+// Messages are the stage pipeline's: raw floats against a poison word, four generations per (stage, group), the producer re-poisons its own
+// words two steps ahead.  The head stage's CU p serves groups p, p + 8, ..: hidden tile, fc2 tiles and the temperature row as matrix
+// products, one wave per clip for the draw, the embedded classes as stage 0's next message.
+//
+// A group's step is a trip of L + 1 visits of ~3.5 us: the kernel pays from ~8 groups on (128 clips) and is trip-bound up to 32 groups.
+#define MMK_FAST_RCP 1
+#include "wavenet_bpipe.h"
+#include "sampler256.h"
+
+namespace mmk {
+
+namespace {
+
+typedef float f32x4b __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4b __attribute__((ext_vector_type(4)));
+typedef unsigned long long u64;
+
+constexpr int kC = 256, kH1 = 128, kQ = 256;
+constexpr int kThreads = 512;
+constexpr int kG = kBpGroup;
+constexpr unsigned kSpin = 1u << 22;
+constexpr int kLgStride = 260;
+
+// word of element (k, n) - channel / unit k, clip n of the group - in a B-operand image of 16 n: the lane (k % 4 / 1 .. = K sub-step, n) of
+// k-step k / 4 reads it in one 16-byte read together with the three k-steps beside it
+__device__ __forceinline__ int pos_of(int k, int n) { return (((k >> 4) * 64) + (k & 3) * 16 + n) * 4 + ((k >> 2) & 3); }
+
+struct BpLds {
+  float xy[2][8192];              // [visit parity][x image | y image]
+  float tc[8192];                 // delayed x | conditioning row of the visit whose known terms are being made
+  float biasT[2][4][256];         // [visit parity][gate tile]: the known terms, in the product's output layout [register][lane]
+  float rpart[2][256];            // residual tiles: the second K half's partial
+  float hpart[4][256];            // hidden-unit tile: the K quarters' partials
+  unsigned arr[4];                // chain wave w: visits whose quarter of the message it has staged
+  unsigned done[8];               // wave: visits whose xy image it reads no more
+  unsigned rp[2], rp_used[2];     // residual tile: partials written / taken
+  unsigned hp[4], hp_used[1];
+  unsigned rows[4], bdone[4];     // helper: visits whose rows it has staged / whose known-term products it has finished
+  unsigned bias_ready[4], bias_used[4];
+};
+
+__device__ __forceinline__ void sig(unsigned* p, unsigned v, int lane) {
+  __atomic_signal_fence(__ATOMIC_SEQ_CST);
+  if (lane == 0) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  __atomic_signal_fence(__ATOMIC_SEQ_CST);
+}
+template <int N>
+__device__ __forceinline__ bool wait_min(const unsigned* p, unsigned want, int32_t* err) {
+  unsigned spins = 0;
+  for (;;) {
+    unsigned m = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#pragma unroll
+    for (int i = 1; i < N; ++i) m = min(m, __hip_atomic_load(p + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+    if (m >= want) break;
+    __builtin_amdgcn_s_sleep(1);
+    if (++spins > kSpin || ((spins & 4095u) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+      atomicExch(err, 1);
+      return false;
+    }
+  }
+  __atomic_signal_fence(__ATOMIC_SEQ_CST);
+  return true;
+}
+
+__device__ __forceinline__ void msg_put(unsigned* p, unsigned v, bool local) {
+  if (local) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);      // stays in this XCD's L2
+  else __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ unsigned bits_of(float v) { return min(__float_as_uint(v), 0xFFFFFFFEu); }     // (never the poison word: wavenet_spipe.hip)
+__device__ __forceinline__ bool clean(const u32x4b& v) { return v[0] != kSpPoison && v[1] != kSpPoison && v[2] != kSpPoison && v[3] != kSpPoison; }
+
+// four 16-byte loads past the L1, 1 KB apart (a wave's 4 KB of a message)
+__device__ __forceinline__ void load4_sc1(const unsigned* p, u32x4b& r0, u32x4b& r1, u32x4b& r2, u32x4b& r3) {
+  asm volatile(
+      "global_load_dwordx4 %0, %4, off sc1\n\tglobal_load_dwordx4 %1, %4, off offset:1024 sc1\n\tglobal_load_dwordx4 %2, %4, off offset:2048 sc1\n\t"
+      "global_load_dwordx4 %3, %4, off offset:3072 sc1\n\ts_waitcnt vmcnt(0)"
+      : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3)
+      : "v"(p)
+      : "memory");
+}
+__device__ __forceinline__ void load1_sc1(const unsigned* p, u32x4b& r0) {
+  asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(r0) : "v"(p) : "memory");
+}
+// four 16-byte loads past the L1, 64 B apart (a lane's part of a ring row)
+__device__ __forceinline__ void load4_ring(const float* p, u32x4b& r0, u32x4b& r1, u32x4b& r2, u32x4b& r3) {
+  asm volatile(
+      "global_load_dwordx4 %0, %4, off sc1\n\tglobal_load_dwordx4 %1, %4, off offset:64 sc1\n\tglobal_load_dwordx4 %2, %4, off offset:128 sc1\n\t"
+      "global_load_dwordx4 %3, %4, off offset:192 sc1\n\ts_waitcnt vmcnt(0)"
+      : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3)
+      : "v"(p)
+      : "memory");
+}
+
+__device__ __forceinline__ f32x4b mfma4(float a, float b, f32x4b c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+
+// a wave's part of a message (n4 x 4 KB, word offset w0 of the message) into an LDS image, looked at until no word of it is the poison word
+template <int N4>
+__device__ __forceinline__ bool gather(const unsigned* src, float* dst, int lane, int32_t* err) {
+  u32x4b r[4 * N4];
+  unsigned spins = 0;
+  for (;;) {
+    load4_sc1(src + 4 * lane, r[0], r[1], r[2], r[3]);
+    bool ok = clean(r[0]) && clean(r[1]) && clean(r[2]) && clean(r[3]);
+    if (__all(ok)) {
+#pragma unroll
+      for (int j = 1; j < N4; ++j) {
+        load4_sc1(src + j * 1024 + 4 * lane, r[4 * j], r[4 * j + 1], r[4 * j + 2], r[4 * j + 3]);
+        ok = ok && clean(r[4 * j]) && clean(r[4 * j + 1]) && clean(r[4 * j + 2]) && clean(r[4 * j + 3]);
+      }
+      if (__all(ok)) break;
+    }
+    __builtin_amdgcn_s_sleep(2);
+    if (++spins > kSpin || ((spins & 1023u) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+      atomicExch(err, 1);
+      return false;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 4 * N4; ++j)
+    *reinterpret_cast<u32x4b*>(dst + j * 256 + 4 * lane) = r[j];
+  return true;
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------------
+// layer stage, waves 0-3: gate tile w of the CU = rows [f of units 32 p + 8 w .. + 7 | g of the same units]
+// ------------------------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void chain_role(const WnBpipeArgs& a, BpLds& S, int stage, int p, int w, int lane) {
+  float wa[128];
+  {
+    const float* img = a.img + ((int64_t)stage * 8 + p) * kBpCuFloats + (int64_t)w * 128 * 64 + lane;
+#pragma unroll
+    for (int i = 0; i < 128; ++i) wa[i] = img[i * 64];
+#pragma unroll
+    for (int i = 0; i < 128; ++i) asm volatile("" : "+v"(wa[i]));
+  }
+  const int G = (a.B + kG - 1) / kG;
+  const int n = lane & 15, q = lane >> 4;
+  const bool local_next = ((stage + 1) >> 2) == (stage >> 2);
+  const int64_t stage_words = (int64_t)((a.Bmax + kG - 1) / kG) * kSpSlots * kBpMsgWords;
+  const unsigned* inbox = a.msg + (int64_t)stage * stage_words;
+  unsigned* outbox = a.msg + (int64_t)(stage + 1) * stage_words;
+  const int64_t V = a.n_steps * G;
+  int t = 0, g = 0;
+  for (int64_t v = 0; v < V; ++v) {
+    const int slot = t & 3, buf = (int)(v & 1);
+    const unsigned uv = (unsigned)v;
+    if (v >= 2 && !wait_min<8>(S.done, uv - 1, a.err_flag)) return;
+    if (!gather<2>(inbox + ((int64_t)g * kSpSlots + slot) * kBpMsgWords + 2048 * w, S.xy[buf] + 2048 * w, lane, a.err_flag)) return;
+    sig(&S.arr[w], uv + 1, lane);
+    if (!wait_min<4>(S.arr, uv + 1, a.err_flag)) return;
+    f32x4b acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    const f32x4b* xb = reinterpret_cast<const f32x4b*>(S.xy[buf]) + lane;
+#pragma unroll
+    for (int k4 = 0; k4 < 32; ++k4) {
+      const f32x4b b = xb[k4 * 64];
+      acc0 = mfma4(wa[4 * k4 + 0], b[0], acc0);
+      acc1 = mfma4(wa[4 * k4 + 1], b[1], acc1);
+      acc0 = mfma4(wa[4 * k4 + 2], b[2], acc0);
+      acc1 = mfma4(wa[4 * k4 + 3], b[3], acc1);
+    }
+    sig(&S.done[w], uv + 1, lane);
+    if (!wait_min<1>(&S.bias_ready[w], uv + 1, a.err_flag)) return;
+    float z[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) z[i] = (acc0[i] + acc1[i]) + S.biasT[buf][w][i * 64 + lane];
+    sig(&S.bias_used[w], uv + 1, lane);
+    // tanh(f) sigmoid(g) (wavenet_v2.py:151): the g rows of a unit sit 32 lanes above its f rows
+    unsigned* dst = outbox + ((int64_t)g * kSpSlots + slot) * kBpMsgWords + 4096;
+    unsigned* psn = outbox + ((int64_t)g * kSpSlots + ((t + 2) & 3)) * kBpMsgWords + 4096;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float zg = __shfl_xor(z[i], 32);
+      const float y = tanh_fast(z[i]) * sigmoid_fast(zg);
+      if (q < 2) {
+        const int word = pos_of(32 * p + 8 * w + 4 * q + i, n);
+        msg_put(dst + word, bits_of(y), local_next);
+        msg_put(psn + word, kSpPoison, local_next);
+      }
+    }
+    if (++g == G) { g = 0; ++t; }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------------
+// layer stage, waves 4-7
+// ------------------------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void helper_role(const WnBpipeArgs& a, BpLds& S, int stage, int p, int h, int lane) {
+  float wb[128], wr[32], wh[16];
+  const int r2 = h & 1, kh = h >> 1;
+  {
+    const float* cu = a.img + ((int64_t)stage * 8 + p) * kBpCuFloats;
+    const float* ib = cu + (4 * 128 + h * 128) * 64 + lane;
+    const float* ir = cu + (8 * 128 + h * 32) * 64 + lane;
+    const float* ih = cu + (8 * 128 + 4 * 32 + h * 16) * 64 + lane;
+#pragma unroll
+    for (int i = 0; i < 128; ++i) wb[i] = ib[i * 64];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) wr[i] = ir[i * 64];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) wh[i] = ih[i * 64];
+#pragma unroll
+    for (int i = 0; i < 128; ++i) asm volatile("" : "+v"(wb[i]));
+#pragma unroll
+    for (int i = 0; i < 32; ++i) asm volatile("" : "+v"(wr[i]));
+#pragma unroll
+    for (int i = 0; i < 16; ++i) asm volatile("" : "+v"(wh[i]));
+  }
+  float bz[4], br[4];
+  {
+    const float* cst = a.cst + ((int64_t)stage * 8 + p) * kBpCstFloats;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      bz[i] = cst[h * 256 + i * 64 + lane];
+      br[i] = cst[(4 + r2) * 256 + i * 64 + lane];
+    }
+  }
+  const int G = (a.B + kG - 1) / kG;
+  const int n = lane & 15, q = lane >> 4;
+  const bool local_next = ((stage + 1) >> 2) == (stage >> 2);
+  const int64_t stage_words = (int64_t)((a.Bmax + kG - 1) / kG) * kSpSlots * kBpMsgWords;
+  const unsigned* inbox = a.msg + (int64_t)stage * stage_words;
+  unsigned* outbox = a.msg + (int64_t)(stage + 1) * stage_words;
+  float* ring = a.hist[stage];
+  const int ring_mask = a.ring[stage] - 1, d = a.dil[stage];
+  const int64_t slot_stride = (int64_t)a.Bmax * kC;
+  const int C1 = a.C1;
+  const int64_t V = a.n_steps * G;
+
+  // everything of visit v1's z that does not depend on its message: W0 x_s[t - d] + Wc c[t] + b, tile h
+  auto make_bias = [&](int64_t v1, int t1, int g1) -> bool {
+    const unsigned u1 = (unsigned)v1;
+    if (v1 >= 1 && !wait_min<4>(S.bdone, u1, a.err_flag)) return false;      // the image's last readers
+    const int clip = kG * g1 + n;
+    if (d == 1 && t1 >= 1) {
+      // the stage's own message of the step before (x part, this wave's quarter), already in the image's layout
+      if (!gather<1>(outbox + ((int64_t)g1 * kSpSlots + ((t1 - 1) & 3)) * kBpMsgWords + 1024 * h, S.tc + 1024 * h, lane, a.err_flag)) return false;
+    } else {
+      const int64_t tp = a.t0 - 1 + t1 - d;
+      u32x4b r[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+      // lane (n, q): clip n, channels 16 (4 h + jj) + 4 q .. + 3 for jj = 0 .. 3
+      if (tp >= 0 && clip < a.B) load4_ring(ring + (tp & ring_mask) * slot_stride + (int64_t)clip * kC + 64 * h + 4 * q, r[0], r[1], r[2], r[3]);
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) S.tc[(((4 * h + jj) * 64) + e * 16 + n) * 4 + q] = __uint_as_float(r[jj][e]);
+    }
+    if (C1 > 0) {
+      const float* crow = a.cproj + ((int64_t)clip * a.cond_steps + t1) * C1;
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) {
+        const int k = 16 * (4 * h + jj) + 4 * q;
+        f32x4b cv = {0.f, 0.f, 0.f, 0.f};
+        if (clip < a.B && k < C1) cv = *reinterpret_cast<const f32x4b*>(crow + k);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) S.tc[4096 + (((4 * h + jj) * 64) + e * 16 + n) * 4 + q] = cv[e];
+      }
+    }
+    sig(&S.rows[h], u1 + 1, lane);
+    if (!wait_min<4>(S.rows, u1 + 1, a.err_flag)) return false;
+    f32x4b acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    const f32x4b* tb = reinterpret_cast<const f32x4b*>(S.tc) + lane;
+#pragma unroll
+    for (int k4 = 0; k4 < 16; ++k4) {
+      const f32x4b b = tb[k4 * 64];
+      acc0 = mfma4(wb[4 * k4 + 0], b[0], acc0);
+      acc1 = mfma4(wb[4 * k4 + 1], b[1], acc1);
+      acc0 = mfma4(wb[4 * k4 + 2], b[2], acc0);
+      acc1 = mfma4(wb[4 * k4 + 3], b[3], acc1);
+    }
+    if (C1 > 0) {
+#pragma unroll
+      for (int k4 = 16; k4 < 32; ++k4) {
+        const f32x4b b = tb[k4 * 64];
+        acc0 = mfma4(wb[4 * k4 + 0], b[0], acc0);
+        acc1 = mfma4(wb[4 * k4 + 1], b[1], acc1);
+        acc0 = mfma4(wb[4 * k4 + 2], b[2], acc0);
+        acc1 = mfma4(wb[4 * k4 + 3], b[3], acc1);
+      }
+    }
+    sig(&S.bdone[h], u1 + 1, lane);
+    if (v1 >= 2 && !wait_min<1>(&S.bias_used[h], u1 - 1, a.err_flag)) return false;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) S.biasT[v1 & 1][h][i * 64 + lane] = (acc0[i] + acc1[i]) + bz[i];
+    sig(&S.bias_ready[h], u1 + 1, lane);
+    return true;
+  };
+
+  if (!make_bias(0, 0, 0)) return;
+  int t = 0, g = 0;
+  for (int64_t v = 0; v < V; ++v) {
+    const int slot = t & 3, buf = (int)(v & 1);
+    const unsigned uv = (unsigned)v;
+    const int64_t tau = a.t0 - 1 + t;
+    if (!wait_min<4>(S.arr, uv + 1, a.err_flag)) return;
+    const f32x4b* yb = reinterpret_cast<const f32x4b*>(S.xy[buf] + 4096) + lane;
+    // ---- x_s = x_{s-1} + R y_{s-1} + br: residual tile r2 (channels 32 p + 16 r2 ..), K half kh ----------------------------------------
+    {
+      f32x4b acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int k4 = 0; k4 < 8; ++k4) {
+        const f32x4b b = yb[(8 * kh + k4) * 64];
+        acc0 = mfma4(wr[4 * k4 + 0], b[0], acc0);
+        acc1 = mfma4(wr[4 * k4 + 1], b[1], acc1);
+        acc0 = mfma4(wr[4 * k4 + 2], b[2], acc0);
+        acc1 = mfma4(wr[4 * k4 + 3], b[3], acc1);
+      }
+      if (kh == 1) {
+        if (v >= 1 && !wait_min<1>(&S.rp_used[r2], uv, a.err_flag)) return;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) S.rpart[r2][i * 64 + lane] = acc0[i] + acc1[i];
+        sig(&S.rp[r2], uv + 1, lane);
+      } else {
+        if (!wait_min<1>(&S.rp[r2], uv + 1, a.err_flag)) return;
+        float xs[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float xprev = S.xy[buf][(((2 * p + r2) * 64) + i * 16 + n) * 4 + q];
+          xs[i] = xprev + (((acc0[i] + acc1[i]) + S.rpart[r2][i * 64 + lane]) + br[i]);
+        }
+        sig(&S.rp_used[r2], uv + 1, lane);
+        unsigned* dst = outbox + ((int64_t)g * kSpSlots + slot) * kBpMsgWords;
+        unsigned* psn = outbox + ((int64_t)g * kSpSlots + ((t + 2) & 3)) * kBpMsgWords;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int word = (((2 * p + r2) * 64) + i * 16 + n) * 4 + q;
+          msg_put(dst + word, bits_of(xs[i]), local_next);
+          msg_put(psn + word, kSpPoison, local_next);
+        }
+        // the layer's input at tau into its ring (later taps; the launch path, should the batch be redone there)
+        const int clip = kG * g + n;
+        if (clip < a.B)
+          *reinterpret_cast<f32x4b*>(ring + (tau & ring_mask) * slot_stride + (int64_t)clip * kC + 32 * p + 16 * r2 + 4 * q) = f32x4b{xs[0], xs[1], xs[2], xs[3]};
+      }
+    }
+    // ---- hid_s = hid_{s-1} + (fc0 W_skip_{s-1}) y_{s-1}: units 16 p .., K quarter h -------------------------------------------------------
+    {
+      f32x4b acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int k4 = 0; k4 < 4; ++k4) {
+        const f32x4b b = yb[(4 * h + k4) * 64];
+        acc0 = mfma4(wh[4 * k4 + 0], b[0], acc0);
+        acc1 = mfma4(wh[4 * k4 + 1], b[1], acc1);
+        acc0 = mfma4(wh[4 * k4 + 2], b[2], acc0);
+        acc1 = mfma4(wh[4 * k4 + 3], b[3], acc1);
+      }
+      sig(&S.done[4 + h], uv + 1, lane);
+      if (h != 0) {
+        if (v >= 1 && !wait_min<1>(S.hp_used, uv, a.err_flag)) return;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) S.hpart[h][i * 64 + lane] = acc0[i] + acc1[i];
+        sig(&S.hp[h], uv + 1, lane);
+      } else {
+        if (!wait_min<3>(S.hp + 1, uv + 1, a.err_flag)) return;
+        float hs[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) hs[i] = ((acc0[i] + acc1[i]) + S.hpart[1][i * 64 + lane]) + (S.hpart[2][i * 64 + lane] + S.hpart[3][i * 64 + lane]);
+        sig(S.hp_used, uv + 1, lane);
+        if (stage >= 1) {      // the sum so far: 4 words per lane of the message, looked at until they are there
+          const unsigned* src = inbox + ((int64_t)g * kSpSlots + slot) * kBpMsgWords + 8192;
+          unsigned spins = 0;
+          for (;;) {
+            unsigned wv[4];
+            bool ok = true;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              wv[i] = __hip_atomic_load(src + ((p * 64) + i * 16 + n) * 4 + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              ok = ok && wv[i] != kSpPoison;
+            }
+            if (__all(ok)) {
+#pragma unroll
+              for (int i = 0; i < 4; ++i) hs[i] += __uint_as_float(wv[i]);
+              break;
+            }
+            __builtin_amdgcn_s_sleep(2);
+            if (++spins > kSpin || ((spins & 1023u) == 0 && __hip_atomic_load(a.err_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+              atomicExch(a.err_flag, 1);
+              return;
+            }
+          }
+        }
+        unsigned* dst = outbox + ((int64_t)g * kSpSlots + slot) * kBpMsgWords + 8192;
+        unsigned* psn = outbox + ((int64_t)g * kSpSlots + ((t + 2) & 3)) * kBpMsgWords + 8192;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int word = ((p * 64) + i * 16 + n) * 4 + q;
+          msg_put(dst + word, bits_of(hs[i]), local_next);
+          msg_put(psn + word, kSpPoison, local_next);
+        }
+      }
+    }
+    int t1 = t, g1 = g + 1;
+    if (g1 == G) { g1 = 0; ++t1; }
+    if (v + 1 < V && !make_bias(v + 1, t1, g1)) return;
+    t = t1; g = g1;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------------
+// head stage: CU p serves groups p, p + 8, ..
+// ------------------------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void head_role(const WnBpipeArgs& a, unsigned char* lds_raw, int p) {
+  float* yimg = reinterpret_cast<float*>(lds_raw);      // 4096: y of the last layer
+  float* hin = yimg + 4096;                             // 2048: the hidden units' sum so far
+  float* hidb = hin + 2048;                             // 2048: Mish(hidden), B image of fc2
+  float* lg = hidb + 2048;                              // 16 x kLgStride logits
+  int* cls = reinterpret_cast<int*>(lg + kG * kLgStride);
+  int* s_fail = cls + kG;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n = lane & 15, q = lane >> 4;
+  float w0[64], w2[64], wt[32];
+  // A operands: lane (q, m) of k-step kk holds row m, column 4 kk + q
+#pragma unroll
+  for (int kk = 0; kk < 64; ++kk) w0[kk] = a.head_w0[(int64_t)(16 * w + n) * kC + 4 * kk + q];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int kk = 0; kk < 32; ++kk) w2[32 * j + kk] = a.fc2_w[(int64_t)(16 * (w + 8 * j) + n) * kH1 + 4 * kk + q];
+#pragma unroll
+  for (int kk = 0; kk < 32; ++kk) wt[kk] = (w == 0 && n == 0 && a.learn_temp) ? a.fc2_w[(int64_t)kQ * kH1 + 4 * kk + q] : 0.f;
+  float b0[4], b2[2][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    b0[i] = a.head_b0[16 * w + 4 * q + i];
+    b2[0][i] = a.fc2_b[16 * w + 4 * q + i];
+    b2[1][i] = a.fc2_b[16 * (w + 8) + 4 * q + i];
+  }
+  const float bt = a.learn_temp ? a.fc2_b[kQ] : 0.f;
+#pragma unroll
+  for (int i = 0; i < 64; ++i) { asm volatile("" : "+v"(w0[i])); asm volatile("" : "+v"(w2[i])); }
+#pragma unroll
+  for (int i = 0; i < 32; ++i) asm volatile("" : "+v"(wt[i]));
+  if (tid == 0) *s_fail = 0;
+  const int G = (a.B + kG - 1) / kG;
+  const int64_t stage_words = (int64_t)((a.Bmax + kG - 1) / kG) * kSpSlots * kBpMsgWords;
+  const unsigned* inbox = a.msg + (int64_t)a.L * stage_words;
+  unsigned* outbox = a.msg;      // stage 0's (another XCD: written through)
+  // the embedded classes of cls[] as stage 0's message of step s1: x = E[class], y = 0
+  auto emit = [&](int g, int s1) {
+    u64* dst = reinterpret_cast<u64*>(outbox + ((int64_t)g * kSpSlots + (s1 & 3)) * kBpMsgWords);
+    u64* psn = reinterpret_cast<u64*>(outbox + ((int64_t)g * kSpSlots + ((s1 + 2) & 3)) * kBpMsgWords);
+    const u64 pp = ((u64)kSpPoison << 32) | kSpPoison;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const int g4 = tid + r * kThreads;                                   // 16-byte group of the x image: clip g4 % 16, channels k0 + 4 e
+      const int k0 = (g4 >> 6) * 16 + ((g4 >> 4) & 3), c = cls[g4 & 15];
+      const float* e = a.emb + (int64_t)c * kC + k0;
+      __hip_atomic_store(dst + 2 * g4, ((u64)bits_of(e[4]) << 32) | bits_of(e[0]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(dst + 2 * g4 + 1, ((u64)bits_of(e[12]) << 32) | bits_of(e[8]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(dst + 2048 + 2 * g4, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(dst + 2048 + 2 * g4 + 1, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(psn + 2 * g4, pp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(psn + 2 * g4 + 1, pp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(psn + 2048 + 2 * g4, pp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(psn + 2048 + 2 * g4 + 1, pp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  };
+  for (int g = p; g < G; g += 8) {
+    if (tid < kG) {
+      const int c = kG * g + tid;
+      int k = c < a.B ? (int)a.idx[(int64_t)c * a.idx_rs + a.t0 - 1] : 0;
+      cls[tid] = k < 0 ? 0 : (k >= kQ ? kQ - 1 : k);
+    }
+    __syncthreads();
+    emit(g, 0);
+    __syncthreads();
+  }
+  for (int s = 0; s < (int)a.n_steps; ++s) {
+    const int64_t tau = a.t0 - 1 + s;
+    for (int g = p; g < G; g += 8) {
+      // ---- y of the last layer and the hidden units' sum: 6144 words, 3 KB per wave ----------------------------------------------------
+      {
+        const unsigned* src = inbox + ((int64_t)g * kSpSlots + (s & 3)) * kBpMsgWords + 4096 + 768 * w + 4 * lane;
+        u32x4b r[3];
+        unsigned spins = 0;
+        for (;;) {
+          asm volatile("global_load_dwordx4 %0, %3, off sc1\n\tglobal_load_dwordx4 %1, %3, off offset:1024 sc1\n\tglobal_load_dwordx4 %2, %3, off offset:2048 sc1\n\t"
+                       "s_waitcnt vmcnt(0)"
+                       : "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2])
+                       : "v"(src)
+                       : "memory");
+          if (__all(clean(r[0]) && clean(r[1]) && clean(r[2]))) break;
+          __builtin_amdgcn_s_sleep(2);
+          if (++spins > kSpin || ((spins & 1023u) == 0 && __hip_atomic_load(a.err_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+            atomicExch(a.err_flag, 1);
+            *s_fail = 1;
+            break;
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < 3; ++j) *reinterpret_cast<u32x4b*>(yimg + 768 * w + j * 256 + 4 * lane) = r[j];
+      }
+      __syncthreads();
+      if (*s_fail) return;
+      // ---- hidden units 16 w ..: (fc0 W_skip of the last layer) y + the sum so far + bias, Mish -----------------------------------------
+      {
+        f32x4b acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+        const f32x4b* yb = reinterpret_cast<const f32x4b*>(yimg) + lane;
+#pragma unroll
+        for (int k4 = 0; k4 < 16; ++k4) {
+          const f32x4b b = yb[k4 * 64];
+          acc0 = mfma4(w0[4 * k4 + 0], b[0], acc0);
+          acc1 = mfma4(w0[4 * k4 + 1], b[1], acc1);
+          acc0 = mfma4(w0[4 * k4 + 2], b[2], acc0);
+          acc1 = mfma4(w0[4 * k4 + 3], b[3], acc1);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int word = ((w * 64) + i * 16 + n) * 4 + q;      // pos_of(16 w + 4 q + i, n)
+          hidb[word] = mish_fast(((acc0[i] + acc1[i]) + hin[word]) + b0[i]);
+        }
+      }
+      __syncthreads();
+      // ---- logits: class tiles w and w + 8, the temperature row on wave 0 ---------------------------------------------------------------
+      {
+        const f32x4b* hb = reinterpret_cast<const f32x4b*>(hidb) + lane;
+        f32x4b q0 = {0.f, 0.f, 0.f, 0.f}, q1 = {0.f, 0.f, 0.f, 0.f}, qt = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k4 = 0; k4 < 8; ++k4) {
+          const f32x4b b = hb[k4 * 64];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            q0 = mfma4(w2[4 * k4 + e], b[e], q0);
+            q1 = mfma4(w2[32 + 4 * k4 + e], b[e], q1);
+          }
+          if (w == 0) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) qt = mfma4(wt[4 * k4 + e], b[e], qt);
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          lg[n * kLgStride + 16 * w + 4 * q + i] = q0[i] + b2[0][i];
+          lg[n * kLgStride + 16 * (w + 8) + 4 * q + i] = q1[i] + b2[1][i];
+        }
+        if (w == 0 && q == 0) lg[n * kLgStride + kQ] = qt[0] + bt;
+      }
+      __syncthreads();
+      // ---- the draw: a wave per clip -------------------------------------------------------------------------------------------------------
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        const int cn = w + 8 * r, c = kG * g + cn;
+        const float* l = lg + cn * kLgStride;
+        int result = 0;
+        if (c < a.B) {
+          if (a.logits_out && s + 1 == (int)a.n_steps)
+            for (int k = lane; k < kQ + (a.learn_temp ? 1 : 0); k += 64) a.logits_out[(int64_t)c * a.logits_ld + k] = l[k];
+          if (a.temperature == nullptr) {
+            result = greedy_256(l, a.learn_temp != 0, l[kQ], a.min_temp, lane);
+          } else {
+            float denom = 1.f;
+            if (a.learn_temp) denom = fmaxf(sigmoidf_(l[kQ]), a.min_temp);       // mlp.py:60-62
+            result = sample_256(l, a.learn_temp != 0, denom, a.temperature[c], a.uniforms[(int64_t)c * a.uni_ld + s], lane);
+          }
+          if (lane == 0) a.idx[(int64_t)c * a.idx_rs + tau + 1] = result;
+        }
+        if (lane == 0) cls[cn] = result;
+      }
+      __syncthreads();
+      if (s + 1 < (int)a.n_steps) emit(g, s + 1);
+      __syncthreads();
+    }
+  }
+}
+
+__global__ __launch_bounds__(kThreads) void wavenet_bpipe_kernel(const WnBpipeArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char bpipe_lds[];
+  BpLds& S = *reinterpret_cast<BpLds*>(bpipe_lds);
+  __shared__ int s_role;
+  const int tid = threadIdx.x;
+  // roles from where the workgroup RUNS: XCD x hosts stages 4 x .. 4 x + 3, eight workgroups each, in arrival order (wavenet_spipe.hip)
+  if (tid == 0) {
+    unsigned id;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(id));
+    id &= 0xf;
+    const unsigned ticket = atomicAdd(a.xcd_count + (id & 7), 1u);
+    int role = -1;
+    if (id >= 8 || ticket >= 32) atomicExch(a.err_flag, 2);
+    else role = (int)(id * 32 + ticket);
+    s_role = role;
+  }
+  if (tid < (int)((sizeof(BpLds) - offsetof(BpLds, arr)) / 4)) (&S.arr[0])[tid] = 0;
+  __syncthreads();
+  const int role = s_role;
+  if (role < 0) return;
+  const int stage = role >> 3, p = role & 7;
+  if (stage > a.L) return;
+  if (stage == a.L) {
+    head_role(a, bpipe_lds, p);
+    return;
+  }
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  if (wave < 4) chain_role(a, S, stage, p, wave, lane);
+  else helper_role(a, S, stage, p, wave - 4, lane);
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------------
+// commit: the A-operand images.  Lane (q, m) of register kk holds row m of the tile, column 4 kk + q.  Composed entries (W1 R, fc0 W_skip)
+// are fp64 dot products of length 256, rounded once.
+// ------------------------------------------------------------------------------------------------------------------------------------
+__device__ double dot_strided(const float* arow, int64_t a_stride, const float* bcol, int64_t b_stride, int n) {
+  double acc = 0.0;
+  for (int c = 0; c < n; ++c) acc += (double)arow[c * a_stride] * (double)bcol[c * b_stride];
+  return acc;
+}
+// raw row of conv_dil (2C, C, 2) for row m of gate tile (p, w): f rows of units 32 p + 8 w .. + 7, then the g rows of the same units
+__device__ __forceinline__ int gate_row(int p, int w, int m) { return m < 8 ? 32 * p + 8 * w + m : kC + 32 * p + 8 * w + (m - 8); }
+
+__global__ __launch_bounds__(256) void bpipe_image_kernel(const WnSpRaw* __restrict__ raw, int L, int C1, const float* __restrict__ f0, float* __restrict__ img,
+                                                          float* __restrict__ cst) {
+  const int64_t n_img = (int64_t)L * 8 * kBpCuFloats, n_cst = (int64_t)L * 8 * kBpCstFloats;
+  for (int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; id < n_img + n_cst; id += (int64_t)gridDim.x * blockDim.x) {
+    if (id < n_img) {
+      const int s = (int)(id / (8 * (int64_t)kBpCuFloats)), p = (int)((id / kBpCuFloats) % 8);
+      const int r = (int)(id % kBpCuFloats), lane = r & 63, reg = r >> 6, q = lane >> 4, m = lane & 15;
+      const WnSpRaw rw = raw[s];
+      const bool below = s >= 1 && raw[s - 1].wr != nullptr;
+      float out = 0.f;
+      if (reg < 512) {                       // gate tile w x [x_{s-1} | y_{s-1}]
+        const int w = reg >> 7, k = 4 * (reg & 127) + q, nrow = gate_row(p, w, m);
+        if (k < kC) out = rw.wd[((int64_t)nrow * kC + k) * 2 + 1];                                                                // W1[n][k]
+        else if (below) out = (float)dot_strided(rw.wd + (int64_t)nrow * kC * 2 + 1, 2, raw[s - 1].wr + (k - kC), kC, kC);         // (W1 R)[n][k]
+      } else if (reg < 1024) {               // gate tile h x [x_s[t - d] | c[t]]
+        const int h = (reg - 512) >> 7, k = 4 * ((reg - 512) & 127) + q, nrow = gate_row(p, h, m);
+        if (k < kC) out = rw.wd[((int64_t)nrow * kC + k) * 2 + 0];                                                                // W0[n][k]
+        else if (rw.w1 && k - kC < C1) out = rw.w1[(int64_t)nrow * C1 + (k - kC)];
+      } else if (reg < 1024 + 128) {         // residual tile r2, K half kh of y
+        const int h = (reg - 1024) >> 5, kk = (reg - 1024) & 31, r2 = h & 1, kh = h >> 1;
+        if (below) out = raw[s - 1].wr[(int64_t)(32 * p + 16 * r2 + m) * kC + 128 * kh + 4 * kk + q];
+      } else {                               // hidden units 16 p .., K quarter h of y
+        const int h = (reg - 1152) >> 4, kk = (reg - 1152) & 15;
+        if (s >= 1) out = (float)dot_strided(f0 + (int64_t)(16 * p + m) * kC, 1, raw[s - 1].ws + 64 * h + 4 * kk + q, kC, kC);    // (fc0 W_skip)[u][k]
+      }
+      img[id] = out;
+    } else {
+      const int64_t t = id - n_img;
+      const int s = (int)(t / (8 * kBpCstFloats)), p = (int)((t / kBpCstFloats) % 8);
+      const int r = (int)(t % kBpCstFloats), tile = r >> 8, i = (r >> 6) & 3, lane = r & 63, q = lane >> 4;
+      const WnSpRaw rw = raw[s];
+      const bool below = s >= 1 && raw[s - 1].wr != nullptr;
+      float out = 0.f;
+      if (tile < 4) {      // b_dil + b_1x1, then tap 1 . b_res of the layer below: the order the one-hand-off kernels add them in
+        const int nrow = gate_row(p, tile, 4 * q + i);
+        out = (rw.bd ? rw.bd[nrow] : 0.f) + (rw.b1 ? rw.b1[nrow] : 0.f);
+        if (below && raw[s - 1].br) out += (float)dot_strided(rw.wd + (int64_t)nrow * kC * 2 + 1, 2, raw[s - 1].br, 1, kC);
+      } else if (below && raw[s - 1].br) {
+        out = raw[s - 1].br[32 * p + 16 * (tile - 4) + 4 * q + i];
+      }
+      cst[t] = out;
+    }
+  }
+}
+
+}  // namespace
+
+bool wn_bpipe_supported(int C, int S, int H1, int n_classes, int L, int n_cond, int cond_dim, int batch) {
+  // (the stage pipeline's networks; cond_dim: the widths of all conditioning inputs together, whole 16-byte groups of a row)
+  const bool cond_ok = n_cond == 0 || (n_cond >= 1 && n_cond <= 2 && cond_dim > 0 && cond_dim <= kC && cond_dim % 16 == 0);
+  return C == kC && S == kC && H1 >= 1 && H1 <= kH1 && n_classes >= 2 && n_classes <= kQ && cond_ok && L >= 1 && L <= kSpMaxLayers && batch >= 1 &&
+         batch <= kBpMaxClips;
+}
+int64_t wn_bpipe_img_floats(int L) { return (int64_t)L * 8 * kBpCuFloats; }
+int64_t wn_bpipe_cst_floats(int L) { return (int64_t)L * 8 * kBpCstFloats; }
+int64_t wn_bpipe_msg_words(int L, int Bmax) { return (int64_t)(L + 1) * ((Bmax + kG - 1) / kG) * kSpSlots * kBpMsgWords; }
+
+int wn_bpipe_build_image(const WnSpRaw* raw_dev, int L, int C1, const float* f0, float* img, float* cst, hipStream_t stream) {
+  if (L < 1 || L > kSpMaxLayers || C1 < 0 || C1 > kC) return fail(MMK_ERR_UNSUPPORTED, "wavenet batched stage pipeline: L = %d, C1 = %d", L, C1);
+  hipLaunchKernelGGL(bpipe_image_kernel, dim3(4096), dim3(256), 0, stream, raw_dev, L, C1, f0, img, cst);
+  MMK_HIP(hipGetLastError());
+  return MMK_OK;
+}
+
+int launch_wavenet_bpipe(const WnBpipeArgs& a, hipStream_t stream) {
+  if (a.n_steps <= 0 || a.B <= 0) return MMK_OK;
+  if (a.B > kBpMaxClips || a.L > kSpMaxLayers) return fail(MMK_ERR_UNSUPPORTED, "wavenet batched stage pipeline: %d clips, %d layers", a.B, a.L);
+  const size_t head_lds = (size_t)(4096 + 2048 + 2048 + kG * kLgStride) * sizeof(float) + (kG + 4) * sizeof(int);
+  const size_t lds = sizeof(BpLds) > head_lds ? sizeof(BpLds) : head_lds;
+  MMK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&wavenet_bpipe_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(wavenet_bpipe_kernel, dim3(256), dim3(kThreads), lds, stream, a);
+  MMK_HIP(hipGetLastError());
+  return MMK_OK;
+}
+
+}  // namespace mmk

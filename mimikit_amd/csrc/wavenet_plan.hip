@@ -17,8 +17,11 @@
 #include "wavenet_persist.h"
 #include "wavenet_prefill.h"
 #include "wavenet_spipe.h"
+#include "wavenet_bpipe.h"
 
 using namespace mmk;
+
+constexpr int kBpipeMinClips = 112;      // clips from which the stage pipeline's networks run in groups of 16 on the matrix pipe (wavenet_bpipe.hip)
 
 struct WnCall {
   int M = 0;
@@ -110,6 +113,11 @@ struct mmk_wavenet_plan {
   float* compose_scratch = nullptr;   // (2C, C) product + 2C bias terms of one layer
   // one layer per stage of 8 CUs, clips streamed through one at a time (wavenet_spipe.hip): C = 256, <= 31 layers, <= 32 clips
   bool spipe = false;
+  // the same stages, the clips in groups of 16 on the matrix pipe (wavenet_bpipe.hip): the stage pipeline's large batches, <= 512 clips.  A
+  // sub-mode of `spipe` (prefill into the launch path's rings, padded head, redo path are shared)
+  bool bpipe = false;
+  float *bp_img = nullptr, *bp_cst = nullptr;
+  unsigned* bp_msg = nullptr;
   float *sp_img_chain = nullptr, *sp_img_helper = nullptr, *sp_cst_chain = nullptr, *sp_cst_helper = nullptr, *sp_head_w0 = nullptr, *sp_head_b0 = nullptr;
   unsigned *sp_msg = nullptr, *sp_hidmsg = nullptr, *sp_hidgrp = nullptr;
   WnSpRaw* sp_raw = nullptr;
@@ -165,9 +173,15 @@ struct mmk_wavenet_plan {
         sp_w1cat = c.take<float>((int64_t)L * 2 * C * C1);
         sp_b1cat = c.take<float>((int64_t)L * 2 * C);
       }
-      sp_msg = c.take<unsigned>(wn_spipe_msg_words(L, C, Bmax) + wn_spipe_hidmsg_words(L, Bmax) + wn_spipe_hidgrp_words(Bmax));   // one block: poisoned by one memset
-      sp_hidmsg = sp_msg + (sp_msg ? wn_spipe_msg_words(L, C, Bmax) : 0);
-      sp_hidgrp = sp_hidmsg + (sp_msg ? wn_spipe_hidmsg_words(L, Bmax) : 0);
+      if (bpipe) {
+        bp_img = c.take<float>(wn_bpipe_img_floats(L));
+        bp_cst = c.take<float>(wn_bpipe_cst_floats(L));
+        bp_msg = c.take<unsigned>(wn_bpipe_msg_words(L, Bmax));
+      } else {
+        sp_msg = c.take<unsigned>(wn_spipe_msg_words(L, C, Bmax) + wn_spipe_hidmsg_words(L, Bmax) + wn_spipe_hidgrp_words(Bmax));   // one block: poisoned by one memset
+        sp_hidmsg = sp_msg + (sp_msg ? wn_spipe_msg_words(L, C, Bmax) : 0);
+        sp_hidgrp = sp_hidmsg + (sp_msg ? wn_spipe_hidmsg_words(L, Bmax) : 0);
+      }
       sp_raw = c.take<WnSpRaw>(L);
     }
     h_rings = spipe ? nullptr : c.take<float>((int64_t)Gc * Gn * ring_floats_per_wg);
@@ -468,13 +482,20 @@ static int derive(mmk_wavenet_plan* p) {
     for (int j = 0; j < c.n_cond; ++j) cond_total += c.cond_dim[j];
     // (the classes the network is fed are the ones it draws, and the first one - the prompt's last sample - is clamped to the head's 256)
     ok5 = ok5 && n_xcc == 8 && n_cu == 256 && c.q_levels <= 256 && c.out_dim <= c.q_levels;
-    ok5 = ok5 && wn_spipe_supported(p->C, p->S, c.mlp_hidden, c.out_dim, p->L, c.n_cond, cond_total, p->Bmax);
+    // Groups of 16 clips on the matrix pipe (wavenet_bpipe.hip) where the one-clip ring is beat-bound: a group's step is a trip of L + 1 visits of
+    // ~3.5 us whatever the batch (up to 32 groups), the ring's is ~1.1 us per clip.  MMK_WN_BPIPE=0 turns it off, =1 takes it for any batch.
+    const char* benv = p->tune.get("MMK_WN_BPIPE");
+    bool ok6 = ok5 && !(benv && benv[0] == '0') && wn_bpipe_supported(p->C, p->S, c.mlp_hidden, c.out_dim, p->L, c.n_cond, cond_total, p->Bmax);
+    ok6 = ok6 && ((benv && benv[0] == '1') || (p->Bmax >= kBpipeMinClips && p->L >= 16));
+    ok5 = ok5 && (ok6 || wn_spipe_supported(p->C, p->S, c.mlp_hidden, c.out_dim, p->L, c.n_cond, cond_total, p->Bmax));
+    p->bpipe = false;
     // A ring of few stages is beat-bound early (one clip's trip: ~1.3 us per stage; ~1.25 us per clip once the clips queue up): 10 layers x 32 clips
     // 38 us per step against 31 on the two-hand-off kernel, x 64 clips 74 against 43 (round 4's sweep).  Asked for by name
     // (MMK_WN_SPIPE=1) it is taken all the same.
-    if (!(senv && senv[0] == '1') && p->L <= 15 && 1.25 * p->Bmax > 3.0 * p->L + 8.0) ok5 = false;
+    if (!(senv && senv[0] == '1') && !ok6 && p->L <= 15 && 1.25 * p->Bmax > 3.0 * p->L + 8.0) ok5 = false;
     if (ok5) {
       p->spipe = true;
+      p->bpipe = ok6;
       p->persistent = true;
       p->xcd_local = false;
       p->chain = false;
@@ -788,6 +809,7 @@ extern "C" int mmk_wavenet_commit(mmk_wavenet_plan* p, void* workspace, size_t w
       MMK_HIP(hipMemcpyAsync(p->sp_raw, raw.data(), sizeof(WnSpRaw) * L, hipMemcpyHostToDevice, st));
       MMK_TRY(wn_spipe_build_image(p->sp_raw, L, C, p->C1, p->sp_f0p, p->sp_fb0p, p->sp_img_chain, p->sp_img_helper, p->sp_cst_chain, p->sp_cst_helper,
                                    p->sp_head_w0, p->sp_head_b0, st));
+      if (p->bpipe) MMK_TRY(wn_bpipe_build_image(p->sp_raw, L, p->C1, p->sp_f0p, p->bp_img, p->bp_cst, st));
       MMK_HIP(hipStreamSynchronize(st));   // `raw` is host-local
     }
   }
@@ -1144,6 +1166,27 @@ static int run_persistent(mmk_wavenet_plan* p, const WnCall& call, int64_t tau0,
       done += nb;
       continue;
     }
+    if (p->bpipe) {
+      if (!with_head) return fail(MMK_ERR_STATE, "wavenet: the stage-pipeline kernels have no teacher-forced mode (warm-up is a prefill)");
+      MMK_HIP(hipMemsetAsync(p->bp_msg, 0xFF, (size_t)wn_bpipe_msg_words(p->L, p->Bmax) * sizeof(unsigned), st));      // every word "not arrived"
+      WnBpipeArgs k = {};
+      k.B = call.M; k.L = p->L; k.C1 = p->C1;
+      k.learn_temp = c.learn_temp; k.min_temp = c.min_temp; k.Bmax = p->Bmax;
+      k.t0 = tau_b + 1; k.n_steps = nb;
+      k.img = p->bp_img; k.cst = p->bp_cst;
+      k.head_w0 = p->sp_head_w0; k.head_b0 = p->sp_head_b0; k.fc2_w = p->sp_fc2p; k.fc2_b = p->sp_fc2bp;
+      for (int l = 0; l < p->L; ++l) { k.hist[l] = p->hist[l]; k.ring[l] = p->ring[l]; k.dil[l] = p->dil[l]; }
+      k.emb = p->emb; k.idx = (int64_t*)call.in0; k.idx_rs = call.in0_rs;
+      k.cproj = p->cproj; k.cond_steps = p->kCondBlock;
+      k.temperature = call.temperature;
+      k.uniforms = call.uniforms ? call.uniforms + done : nullptr;
+      k.uni_ld = call.uni_ld;
+      k.logits_out = p->sp_logits; k.logits_ld = mmk_wavenet_plan::kSpLogitsLd;
+      k.msg = p->bp_msg; k.xcd_count = p->xcd_count; k.err_flag = p->err_flag;
+      MMK_TRY(launch_wavenet_bpipe(k, st));
+      done += nb;
+      continue;
+    }
     if (p->spipe) {
       if (!with_head) return fail(MMK_ERR_STATE, "wavenet: the stage-pipeline kernel has no teacher-forced mode (warm-up is a prefill)");
       // every message word starts as poison (0xFFFFFFFF): "not arrived"
@@ -1444,7 +1487,7 @@ extern "C" int mmk_wavenet_profile_steps(mmk_wavenet_plan* p, int32_t batch, voi
 }
 
 extern "C" int mmk_wavenet_mode(const mmk_wavenet_plan* p) {
-  return (p && p->persistent) ? (p->spipe ? 5 : (p->lpipe ? 4 : (p->chain ? 2 : 1))) : 0;
+  return (p && p->persistent) ? (p->bpipe ? 6 : p->spipe ? 5 : (p->lpipe ? 4 : (p->chain ? 2 : 1))) : 0;
 }
 
 extern "C" int mmk_wavenet_inject_sync_error(mmk_wavenet_plan* p, mmk_stream_t stream) {

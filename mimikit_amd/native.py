@@ -569,8 +569,14 @@ class WaveNetPlan(_Plan):
 
     @property
     def stage_pipelined(self) -> bool:
-        """persistent mode with one layer per stage of 8 CUs and the clips streamed through one at a time (csrc/wavenet_spipe.hip)"""
-        return self._lib.mmk_wavenet_mode(self.handle) == 5
+        """persistent mode with one layer per stage of 8 CUs: the clips streamed through one at a time (csrc/wavenet_spipe.hip) or,
+        large batches, in groups of 16 (csrc/wavenet_bpipe.hip)"""
+        return self._lib.mmk_wavenet_mode(self.handle) in (5, 6)
+
+    @property
+    def batch_pipelined(self) -> bool:
+        """the stage pipeline with groups of 16 clips per visit on the matrix pipe (csrc/wavenet_bpipe.hip)"""
+        return self._lib.mmk_wavenet_mode(self.handle) == 6
 
     def sync_status(self):
         """wait for the stream and raise if a hand-off inside the persistent kernel timed out"""
@@ -602,6 +608,7 @@ class WaveNetPlan(_Plan):
 
 
 SPIPE_MAX_CLIPS = 128      # clips one ring of the stage pipeline streams (csrc/wavenet_spipe.h: kSpMaxClips)
+BPIPE_MAX_CLIPS = 512      # clips one launch of its large-batch form takes, in groups of 16 (csrc/wavenet_bpipe.h: kBpMaxClips)
 
 
 class WaveNetPlanSet:
@@ -652,6 +659,7 @@ class WaveNetPlanSet:
     chain = property(lambda self: self.plans[0].chain)
     layer_pipelined = property(lambda self: self.plans[0].layer_pipelined)
     stage_pipelined = property(lambda self: self.plans[0].stage_pipelined)
+    batch_pipelined = property(lambda self: self.plans[0].batch_pipelined)
 
     def sync_status(self):
         err = None
@@ -674,10 +682,21 @@ class WaveNetPlanSet:
 
 
 def make_wavenet_plan(describe, batch: int, device) -> "WaveNetPlan":
-    """``describe(max_batch)`` -> :class:`WaveNetConfig`.  One plan for the batch, unless the batch is beyond one ring of the
-    stage pipeline and the network is one that kernel runs: then evenly sized slices of at most ``SPIPE_MAX_CLIPS`` clips."""
+    """``describe(max_batch)`` -> :class:`WaveNetConfig`.  One plan for the batch, unless the batch is beyond what one launch of the
+    stage pipeline takes and the network is one that kernel runs: then evenly sized slices - of at most ``BPIPE_MAX_CLIPS`` clips where
+    the plan takes the large-batch form (groups of 16 clips), else of at most ``SPIPE_MAX_CLIPS``."""
     batch = max(int(batch), 1)
     if batch > SPIPE_MAX_CLIPS:
+        n = -(-batch // BPIPE_MAX_CLIPS)
+        size = -(-batch // n)
+        first = WaveNetPlan(describe(size), device)
+        if first.batch_pipelined:
+            if n == 1:
+                return first
+            assert max(int(first.cfg.n_targets), 1) == 1, "a plan set slices clips along dimension 0: one target only"
+            sizes = [size] * (n - 1) + [batch - size * (n - 1)]
+            return WaveNetPlanSet([first] + [WaveNetPlan(describe(sz), device) for sz in sizes[1:]], sizes)
+        del first
         n = -(-batch // SPIPE_MAX_CLIPS)
         size = -(-batch // n)
         first = WaveNetPlan(describe(size), device)

@@ -23,7 +23,7 @@ PATHS = {                   # forced through the plan's `tuning` switches (nativ
     "spipe": dict(MMK_WN_SPIPE="1"),
     "default": None,        # whatever the plan picks on its own
 }
-MODE_NAMES = {0: "launch", 1: "persist", 2: "chain", 4: "lpipe", 5: "spipe"}
+MODE_NAMES = {0: "launch", 1: "persist", 2: "chain", 4: "lpipe", 5: "spipe", 6: "bpipe"}
 
 
 def network(C, blocks, cond):

@@ -131,12 +131,14 @@ def test_cfg4_wavenet_30x256_conditioned_32_clips(device):
     assert n_exact >= 0.97 * n_all
 
 
-def _cfg4_greedy_against_oracle(device, B, n, n_last, n_mid, seed, expect_set=None):
+def _cfg4_greedy_against_oracle(device, B, n, n_last, n_mid, seed, expect_set=None, tuning=None, expect_batched=False):
     """cfg 4 at ``B`` clips: ``n`` free-running greedy steps, twice (bit-identical), then the oracle teacher-forced on the device's
     own history: the last ``n_last`` steps of all clips, the steps around the start and the first launch boundary for eight clips,
     ``n_mid`` random mid-block steps for four clips each"""
     net, sd, arch = cfg4_network()
     net = net.to(device)
+    if tuning:
+        net.exec_tuning = dict(tuning)
     rf, P = net.rf, 3072
     gen = torch.Generator().manual_seed(seed)
     prompt = torch.randint(0, 256, (B, P), generator=gen)
@@ -151,7 +153,7 @@ def _cfg4_greedy_against_oracle(device, B, n, n_last, n_mid, seed, expect_set=No
         return idx.cpu(), net._plan.last_logits(B).cpu()
 
     hist, last_raw = run()
-    assert net._plan.stage_pipelined
+    assert net._plan.stage_pipelined and net._plan.batch_pipelined == expect_batched
     if expect_set is not None:
         assert isinstance(net._plan, mmk.native.WaveNetPlanSet) == expect_set
     hist2, _ = run()
@@ -197,14 +199,26 @@ def test_cfg4_wavenet_64_clips_in_one_ring(device):
 
 
 def test_cfg4_wavenet_128_clips_in_one_ring(device):
-    """R = 2: 128 clips per GPU, the most one ring takes (the bias image of a stage CU is 64 KB of its LDS then)"""
-    _cfg4_greedy_against_oracle(device, B=128, n=600, n_last=1, n_mid=12, seed=4128, expect_set=False)
+    """R = 2: 128 clips per GPU, the most one ring takes (the bias image of a stage CU is 64 KB of its LDS then); the one-clip ring by name
+    (from 112 clips on the plan takes groups of 16 clips on the matrix pipe: the tests below)"""
+    _cfg4_greedy_against_oracle(device, B=128, n=600, n_last=1, n_mid=12, seed=4128, expect_set=False, tuning={"MMK_WN_BPIPE": "0"})
 
 
 def test_cfg4_wavenet_more_clips_than_one_ring(device):
     """the reference's loop takes any batch (loops/generate.py:207-219): 136 clips run as two passes of 68 through the stage
-    pipeline (native.WaveNetPlanSet), never on the round-1 fallback kernel"""
-    _cfg4_greedy_against_oracle(device, B=136, n=1030, n_last=1, n_mid=10, seed=4136, expect_set=True)
+    pipeline (native.WaveNetPlanSet), never on the round-1 fallback kernel (the one-clip ring by name)"""
+    _cfg4_greedy_against_oracle(device, B=136, n=1030, n_last=1, n_mid=10, seed=4136, expect_set=True, tuning={"MMK_WN_BPIPE": "0"})
+
+
+def test_cfg4_wavenet_256_clips_in_groups_of_16(device):
+    """SURVEY 8(e) at R = 1: the whole 256-clip job on one GPU.  The plan takes the stage pipeline's large-batch form (wavenet_bpipe.hip: 16 groups
+    of 16 clips, a visit is a set of 16x16x4 matrix products): 1030 free-running steps across a launch boundary, against the oracle"""
+    _cfg4_greedy_against_oracle(device, B=256, n=1030, n_last=1, n_mid=10, seed=4256, expect_set=False, expect_batched=True)
+
+
+def test_cfg4_wavenet_ragged_groups_of_16(device):
+    """150 clips: nine whole groups and one of six clips (the lanes of the clips that do not exist compute on class 0 and store nothing)"""
+    _cfg4_greedy_against_oracle(device, B=150, n=300, n_last=1, n_mid=8, seed=4150, expect_set=False, expect_batched=True)
 
 
 def test_cfg4_nan_with_the_poison_payload_is_a_value_not_a_missing_word(device):

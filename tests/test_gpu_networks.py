@@ -1326,7 +1326,7 @@ def _cfg4_family_net(blocks, seed, cond):
 
 
 SPIPE_ENV = ("MMK_WN_XCD_LOCAL", "MMK_WN_PERSISTENT", "MMK_WN_GROUPS", "MMK_WN_SMALL", "MMK_WN_PREFILL", "MMK_WN_CHAIN", "MMK_WN_LPIPE",
-             "MMK_WN_SPIPE")
+             "MMK_WN_SPIPE", "MMK_WN_BPIPE")
 
 
 @pytest.mark.parametrize("blocks,B,cond,n", [((3,), 1, False, 40), ((4, 2), 5, True, 60), ((1,), 3, True, 24), ((2, 1, 1), 32, True, 30),
@@ -1337,9 +1337,24 @@ def test_wavenet_stage_pipeline_agrees_with_oracle(device, monkeypatch, blocks, 
     teacher-forced on the device's own history: 1 - 31 layers (1 - 8 XCDs in use, layers with d = 1 first, in the middle and last),
     1 - 32 clips, with and without conditioning, more steps than one conditioning block (two launches chained through the rings);
     greedy, then sampled with the uniforms generate_block draws; the same generation twice is bit-identical"""
+    _stage_pipeline_against_oracle(device, monkeypatch, blocks, B, cond, n, batched=False)
+
+
+@pytest.mark.parametrize("blocks,B,cond,n", [((3,), 1, False, 40), ((4, 2), 5, True, 60), ((1,), 3, True, 24), ((2, 1, 1), 40, True, 30),
+                                             ((10, 10, 10, 1), 20, False, 6), ((5, 3), 17, True, 1100), ((6,), 70, True, 12), ((2,), 150, False, 20),
+                                             ((1, 1), 16, True, 33), ((4, 4, 3), 33, False, 50)])
+def test_wavenet_batch_pipeline_agrees_with_oracle(device, monkeypatch, blocks, B, cond, n):
+    """the stage pipeline's large-batch form (wavenet_bpipe.hip: the clips travel in groups of 16, a visit is a set of 16x16x4 matrix products)
+    against the oracle, as above: 1 - 31 layers, 1 - 10 groups with ragged last groups (1, 5, 3, 8, 4, 1, 6 clips), exactly one group, with and
+    without conditioning, two launches chained through the rings; greedy, sampled, twice bit-identical"""
+    _stage_pipeline_against_oracle(device, monkeypatch, blocks, B, cond, n, batched=True)
+
+
+def _stage_pipeline_against_oracle(device, monkeypatch, blocks, B, cond, n, batched):
     for k in SPIPE_ENV:
         monkeypatch.delitem(mmk.native.PLAN_TUNING, k, raising=False)
     monkeypatch.setitem(mmk.native.PLAN_TUNING, "MMK_WN_SPIPE", "1")      # (by name: a ring of few stages is not the default for many clips)
+    monkeypatch.setitem(mmk.native.PLAN_TUNING, "MMK_WN_BPIPE", "1" if batched else "0")
     net, sd, arch = _cfg4_family_net(blocks, 300 + len(blocks) + B, cond)
     net = net.to(device)
     gen = torch.Generator().manual_seed(B + n)
@@ -1356,7 +1371,7 @@ def test_wavenet_stage_pipeline_agrees_with_oracle(device, monkeypatch, blocks, 
         return idx.cpu()
 
     got = run()
-    assert net._plan.stage_pipelined
+    assert net._plan.stage_pipelined and net._plan.batch_pipelined == batched
     last = net._plan.last_logits(B).cpu()
     assert torch.equal(got, run())
     steps = list(range(n)) if n <= 60 else list(range(0, 4)) + list(range(1020, 1030)) + list(range(n - 4, n))
@@ -1521,9 +1536,10 @@ def test_multi_input_multi_target_matches_reference_golden(tag, device):
         assert bool(ok3.all()) and float(exact.float().mean()) > 0.99, (tag, k)
 
 
+@pytest.mark.parametrize("batched", [False, True])
 @pytest.mark.parametrize("q,mlp_dim,cond_dims,blocks,B", [(128, 64, (), (3, 2), 5), (64, 40, (16,), (4,), 9), (256, 128, (16, 32), (3, 1), 6),
                                                           (200, 100, (32, 16), (2, 2, 1), 33)])
-def test_wavenet_stage_pipeline_takes_narrower_heads_and_two_conditioning_inputs(device, monkeypatch, q, mlp_dim, cond_dims, blocks, B):
+def test_wavenet_stage_pipeline_takes_narrower_heads_and_two_conditioning_inputs(device, monkeypatch, q, mlp_dim, cond_dims, blocks, B, batched):
     """the stage pipeline beyond BASELINE's exact head: fewer classes (input and target), fewer hidden units (not a multiple of 16 either) - the
     plan pads the head to the kernel's 128 x 256 with zero rows / columns and a bias of -inf for the classes that do not exist - and TWO
     conditioning inputs, whose projections and 1x1 matrices it lays side by side.  Against the oracle, teacher-forced on the device's own
@@ -1533,6 +1549,7 @@ def test_wavenet_stage_pipeline_takes_narrower_heads_and_two_conditioning_inputs
     for k in SPIPE_ENV:
         monkeypatch.delitem(mmk.native.PLAN_TUNING, k, raising=False)
     monkeypatch.setitem(mmk.native.PLAN_TUNING, "MMK_WN_SPIPE", "1")
+    monkeypatch.setitem(mmk.native.PLAN_TUNING, "MMK_WN_BPIPE", "1" if batched else "0")      # (both forms of the stage pipeline: one clip / 16 clips per visit)
     io = H.mu_emb(mlp_dim=mlp_dim, q_levels=q)
     ext = mmk.Extractor("signal", mmk.FileToSignal(16000))
     extra = tuple(mmk.InputSpec("signal", mmk.MagSpec(22, 4, center=False), mmk.LinearIO()).bind_to(ext) for _ in cond_dims)
@@ -1552,7 +1569,7 @@ def test_wavenet_stage_pipeline_takes_narrower_heads_and_two_conditioning_inputs
     idx = torch.cat([prompt, torch.zeros(B, n, dtype=torch.int64)], 1).to(device)
     net.generate_block((idx, *conds_d), P, n)
     net.after_generate((idx,), None)
-    assert net._plan.stage_pipelined
+    assert net._plan.stage_pipelined and net._plan.batch_pipelined == batched
     got = idx.cpu()
     assert int(got.max()) < q
     last = net._plan.last_logits(B).cpu()

@@ -181,11 +181,11 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(native.EXPORTED_SYMBOLS), declared ^ set(native.EXPORTED_SYMBOLS)
 
 
-def _cfg4_plan_mode(tuning: bytes) -> int:
+def _cfg4_plan_mode(tuning: bytes, clips: int = 32) -> int:
     """create (not commit) a plan of BASELINE config 4's geometry and say which step path it chose (mmk_wavenet_mode)"""
     lib = native.load_library()
     cfg = native.WaveNetConfig()
-    cfg.n_layers, cfg.dim_dilated, cfg.residuals_dim, cfg.skips_dim, cfg.max_batch, cfg.q_levels = 30, 256, 256, 256, 32, 256
+    cfg.n_layers, cfg.dim_dilated, cfg.residuals_dim, cfg.skips_dim, cfg.max_batch, cfg.q_levels = 30, 256, 256, 256, clips, 256
     for l in range(30):
         cfg.kernel_size[l], cfg.dilation[l] = 2, 2 ** (l % 10)
     cfg.n_cond, cfg.cond_in_dim[0], cfg.cond_dim[0] = 1, 513, 256
@@ -207,6 +207,10 @@ def test_execution_switches_travel_in_the_config_not_in_the_environment(monkeypa
     monkeypatch.setenv("MMK_WN_SPIPE", "0")
     monkeypatch.setenv("MMK_WN_PERSISTENT", "0")
     assert _cfg4_plan_mode(b"") == 5
+    # many clips per GPU: the same stages with groups of 16 clips per visit on the matrix pipe (wavenet_bpipe.hip), up to 512 clips a launch
+    assert _cfg4_plan_mode(b"", clips=64) == 5 and _cfg4_plan_mode(b"", clips=256) == 6 and _cfg4_plan_mode(b"", clips=512) == 6
+    assert _cfg4_plan_mode(b"MMK_WN_BPIPE=0", clips=128) == 5 and _cfg4_plan_mode(b"MMK_WN_BPIPE=1", clips=8) == 6
+    assert _cfg4_plan_mode(b"MMK_WN_BPIPE=0", clips=256) not in (5, 6) and _cfg4_plan_mode(b"", clips=513) not in (5, 6)
     assert native.tuning_text({"A": "1"}, {"B": "0", "A": "2"}) == b"A=2;B=0"
     with pytest.raises(ValueError):
         native.tuning_text({f"MMK_SWITCH_{i}": "1" for i in range(40)})
