@@ -59,6 +59,7 @@ def parse():
     ap.add_argument("--temperature", type=float, default=0.0,
                     help="> 0: sampled decode at this temperature (throughput only: the CPU check needs greedy decode)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-strong-leg", action="store_true", help="wavenet_cfg4: skip the strong-scaling leg (256 clips / N ranks) after the timed region")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline sample")
     ap.add_argument("--force-dist", action="store_true", help="with --gpus 1: initialise the RCCL process group of ONE rank all the same and run the path's "
                     "collectives (weight broadcast, fenced max-over-ranks clock) on it - what an N-GPU run does, on a 1-GPU box")
@@ -118,7 +119,10 @@ class WaveNetJob:
         gen = torch.Generator().manual_seed(1234 + rank)
         audio = torch.rand(self.clips, self.prompt_len, generator=gen) * 2 - 1
         total = self.prompt_len + self.n_steps
-        self.cond_cpu = torch.rand(self.clips, total, cond_dim, generator=gen) if cond_dim else None
+        # (device_data: the strong-scaling leg - its inputs are drawn on the device, nothing of it is checked on the CPU)
+        self.device_data = bool(getattr(args, "device_data", False))
+        self.cond_dim, self.total = cond_dim, total
+        self.cond_cpu = torch.rand(self.clips, total, cond_dim, generator=gen) if (cond_dim and not self.device_data) else None
         self.audio_cpu = audio
         self.expand = mmk.MuLawExpand(256)
         self.name = args.workload
@@ -131,6 +135,8 @@ class WaveNetJob:
         prompt = self.mmk.MuLawCompress(256)(self.audio_cpu.to(self.device))
         self.idx = torch.cat([prompt, torch.zeros(self.clips, self.n_steps, dtype=torch.int64, device=self.device)], 1)
         self.cond = (self.cond_cpu.to(self.device),) if self.cond_cpu is not None else ()
+        if self.device_data and self.cond_dim:
+            self.cond = (torch.rand(self.clips, self.total, self.cond_dim, device=self.device),)
         self.prompt_cpu = prompt.cpu()
 
     def one_pass(self):
@@ -175,7 +181,8 @@ class WaveNetJob:
             try:  # PMC-derived HBM bytes of one 1024-step launch: NOT measured in this run (counters need their own rocprofv3
                   # --pmc passes) - taken from profiles/traffic.json, and only if that entry was collected on THIS kernel
                 with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
-                    entry = json.load(f).get(self.name, {}).get("persistent", {})
+                    entries = json.load(f).get(self.name, {})
+                    entry = entries.get(f"persistent_clips{int(self.clips)}") or entries.get("persistent", {})
                 # ... and at THIS clip count (an entry without one was collected at the BASELINE share of 32 clips)
                 if entry.get("bytes_per_step") and str(entry.get("kernel", "")).startswith(kshort) and int(entry.get("clips", 32)) == int(self.clips):
                     traffic = int(entry["bytes_per_step"] * n)
@@ -664,6 +671,32 @@ def launch_ranks(args) -> int:
     return 0
 
 
+STRONG_GLOBAL_CLIPS = 256      # BASELINE config 4's whole job (256 clips, partitioned over the ranks)
+
+
+def strong_scaling_leg(args, device, rank, world, sync):
+    """The SAME total job on any number of GPUs: BASELINE config 4's 256 clips divided over the ranks (R = 1: 256 clips on this GPU - groups of 16
+    on the matrix pipe; R = 8: 32 per GPU, the weak-scaling line's share).  After the timed region, same fences and --seconds of audio, 1 + 2 passes;
+    every rank runs it, rank 0 reports it as an extra key."""
+    import copy
+    from mimikit_amd.shard import timed_passes, clip_slice
+    a2 = copy.copy(args)
+    lo, hi = clip_slice(STRONG_GLOBAL_CLIPS, rank, world)
+    a2.clips, a2.device_data = hi - lo, True
+    job = WaveNetJob(a2, device, rank)
+    job.to_device()
+    steps, warmup = 2, 1
+    elapsed = timed_passes(job.one_pass, steps, warmup, sync)
+    plan = job.net._plan
+    kernel = ("wavenet_bpipe_kernel" if getattr(plan, "batch_pipelined", False) else "wavenet_spipe_kernel" if plan.stage_pipelined else "other")
+    out = {"global_clips": STRONG_GLOBAL_CLIPS, "n_gpus": world, "clips_on_rank_0": hi - lo, "generated_samples_per_clip": job.n_steps,
+           "steps": steps, "warmup": warmup, "value": round(STRONG_GLOBAL_CLIPS * job.n_steps * steps / elapsed, 1), "unit": job.unit,
+           "us_per_ar_step": round(1e6 * elapsed / (steps * job.n_steps), 2), "kernel": kernel, "decode": job.decode}
+    del job
+    torch.cuda.empty_cache()
+    return out
+
+
 def main():
     args = parse()
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -714,6 +747,7 @@ def main():
 
     units = job.units_per_pass() * args.steps * world
     value = units / elapsed
+    strong = strong_scaling_leg(args, device, rank, world, sync) if (args.workload == "wavenet_cfg4" and not args.no_strong_leg) else None
     line = {
         "metric": "audio samples/sec generated (WaveNet 256-ch mu-law, 16kHz)" if args.workload == "wavenet_cfg4"
         else f"{job.unit} ({args.workload})",
@@ -736,6 +770,8 @@ def main():
         roof = job.roofline()
         if roof is not None:
             line["roofline"] = roof
+        if strong is not None:
+            line["strong_scaling"] = strong
         if world == 1 and not args.no_cpu_baseline and not args.temperature > 0:    # N = 1 only; the CPU leg re-checks the GREEDY samples
             line["cpu_baseline"] = job.cpu_baseline(args.cpu_seconds)
         print(json.dumps(line), flush=True)

@@ -37,6 +37,8 @@ struct WnBpipeArgs {
   unsigned* msg;                      // [L + 1][groups][4][kBpMsgWords]: every word 0xFFFFFFFF before every launch
   unsigned* xcd_count;                // [8] arrivals per XCD (zeroed before every launch)
   int32_t* err_flag;
+  unsigned long long* stamps;         // diagnostic build only: phase totals of stage stamp_stage's CU 0 (10 ns ticks)
+  int32_t stamp_stage;
 };
 
 bool wn_bpipe_supported(int C, int S, int H1, int n_classes, int L, int n_cond, int cond_dim, int batch);

@@ -44,6 +44,9 @@ constexpr int kThreads = 512;
 constexpr int kG = kBpGroup;
 constexpr unsigned kSpin = 1u << 22;
 constexpr int kLgStride = 260;
+#ifndef MMK_BP_CHAIN_PRIO
+#define MMK_BP_CHAIN_PRIO 2
+#endif
 
 // word of element (k, n) - channel / unit k, clip n of the group - in a B-operand image of 16 n: the lane (k % 4 / 1 .. = K sub-step, n) of
 // k-step k / 4 reads it in one 16-byte read together with the three k-steps beside it
@@ -53,11 +56,12 @@ struct BpLds {
   float xy[2][8192];              // [visit parity][x image | y image]
   float tc[8192];                 // delayed x | conditioning row of the visit whose known terms are being made
   float biasT[2][4][256];         // [visit parity][gate tile]: the known terms, in the product's output layout [register][lane]
-  float rpart[2][256];            // residual tiles: the second K half's partial
+  float rpart[4][256];            // residual tiles: [K half][tile] partial products, in the output layout
   float hpart[4][256];            // hidden-unit tile: the K quarters' partials
-  unsigned arr[4];                // chain wave w: visits whose quarter of the message it has staged
+  unsigned arr[4];                // chain wave w: visits whose quarter of the message's y it has staged (its quarter of x before that)
+  unsigned arrx[4];               // ... of x
   unsigned done[8];               // wave: visits whose xy image it reads no more
-  unsigned rp[2], rp_used[2];     // residual tile: partials written / taken
+  unsigned rp[4], rp_used[2];     // residual partial of chain wave w written / tile's partials taken (by helper r2)
   unsigned hp[4], hp_used[1];
   unsigned rows[4], bdone[4];     // helper: visits whose rows it has staged / whose known-term products it has finished
   unsigned bias_ready[4], bias_used[4];
@@ -115,24 +119,35 @@ __device__ __forceinline__ void load4_ring(const float* p, u32x4b& r0, u32x4b& r
       : "memory");
 }
 
+// diagnostic build: time (10 ns ticks) spent in the phases of a visit, totals per launch
+struct BpStamp {
+#ifdef MMK_DIAG
+  u64 acc[16] = {}, last = 0;
+  bool on = false;
+  __device__ __forceinline__ void start() { if (on) last = __builtin_amdgcn_s_memrealtime(); }
+  __device__ __forceinline__ void mark(int k) { if (on) { const u64 t = __builtin_amdgcn_s_memrealtime(); acc[k] += t - last; last = t; } }
+  __device__ __forceinline__ void flush(unsigned long long* dst, int lane) const {
+    if (on && lane == 0)
+      for (int k = 0; k < 16; ++k) dst[k] = acc[k];
+  }
+#else
+  bool on = false;
+  __device__ __forceinline__ void start() {}
+  __device__ __forceinline__ void mark(int) {}
+  __device__ __forceinline__ void flush(unsigned long long*, int) const {}
+#endif
+};
+
 __device__ __forceinline__ f32x4b mfma4(float a, float b, f32x4b c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 
-// a wave's part of a message (n4 x 4 KB, word offset w0 of the message) into an LDS image, looked at until no word of it is the poison word
-template <int N4>
+// a wave's 4 KB of a message into an LDS image, looked at until no word of it is the poison word (every look is the whole part: one trip to
+// the L2 once it is there)
 __device__ __forceinline__ bool gather(const unsigned* src, float* dst, int lane, int32_t* err) {
-  u32x4b r[4 * N4];
+  u32x4b r[4];
   unsigned spins = 0;
   for (;;) {
     load4_sc1(src + 4 * lane, r[0], r[1], r[2], r[3]);
-    bool ok = clean(r[0]) && clean(r[1]) && clean(r[2]) && clean(r[3]);
-    if (__all(ok)) {
-#pragma unroll
-      for (int j = 1; j < N4; ++j) {
-        load4_sc1(src + j * 1024 + 4 * lane, r[4 * j], r[4 * j + 1], r[4 * j + 2], r[4 * j + 3]);
-        ok = ok && clean(r[4 * j]) && clean(r[4 * j + 1]) && clean(r[4 * j + 2]) && clean(r[4 * j + 3]);
-      }
-      if (__all(ok)) break;
-    }
+    if (__all(clean(r[0]) && clean(r[1]) && clean(r[2]) && clean(r[3]))) break;
     __builtin_amdgcn_s_sleep(2);
     if (++spins > kSpin || ((spins & 1023u) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
       atomicExch(err, 1);
@@ -140,8 +155,7 @@ __device__ __forceinline__ bool gather(const unsigned* src, float* dst, int lane
     }
   }
 #pragma unroll
-  for (int j = 0; j < 4 * N4; ++j)
-    *reinterpret_cast<u32x4b*>(dst + j * 256 + 4 * lane) = r[j];
+  for (int j = 0; j < 4; ++j) *reinterpret_cast<u32x4b*>(dst + j * 256 + 4 * lane) = r[j];
   return true;
 }
 
@@ -149,13 +163,20 @@ __device__ __forceinline__ bool gather(const unsigned* src, float* dst, int lane
 // layer stage, waves 0-3: gate tile w of the CU = rows [f of units 32 p + 8 w .. + 7 | g of the same units]
 // ------------------------------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void chain_role(const WnBpipeArgs& a, BpLds& S, int stage, int p, int w, int lane) {
-  float wa[128];
+  float wa[128], wr[32];
+  const int r2 = w & 1, kh = w >> 1;      // the residual tile (channels 32 p + 16 r2 ..) and K half of y this wave multiplies besides
   {
-    const float* img = a.img + ((int64_t)stage * 8 + p) * kBpCuFloats + (int64_t)w * 128 * 64 + lane;
+    const float* cu = a.img + ((int64_t)stage * 8 + p) * kBpCuFloats;
+    const float* img = cu + (int64_t)w * 128 * 64 + lane;
+    const float* ir = cu + (8 * 128 + w * 32) * 64 + lane;
 #pragma unroll
     for (int i = 0; i < 128; ++i) wa[i] = img[i * 64];
 #pragma unroll
+    for (int i = 0; i < 32; ++i) wr[i] = ir[i * 64];
+#pragma unroll
     for (int i = 0; i < 128; ++i) asm volatile("" : "+v"(wa[i]));
+#pragma unroll
+    for (int i = 0; i < 32; ++i) asm volatile("" : "+v"(wr[i]));
   }
   const int G = (a.B + kG - 1) / kG;
   const int n = lane & 15, q = lane >> 4;
@@ -165,25 +186,76 @@ __device__ __forceinline__ void chain_role(const WnBpipeArgs& a, BpLds& S, int s
   unsigned* outbox = a.msg + (int64_t)(stage + 1) * stage_words;
   const int64_t V = a.n_steps * G;
   int t = 0, g = 0;
+  __builtin_amdgcn_s_setprio(MMK_BP_CHAIN_PRIO);      // (ahead of the helper wave of the same SIMD, whose products mostly are off the chain)
+  BpStamp st;
+  st.on = a.stamps != nullptr && stage == a.stamp_stage && p == 0 && w == 0;
   for (int64_t v = 0; v < V; ++v) {
     const int slot = t & 3, buf = (int)(v & 1);
     const unsigned uv = (unsigned)v;
+    st.start();
     if (v >= 2 && !wait_min<8>(S.done, uv - 1, a.err_flag)) return;
-    if (!gather<2>(inbox + ((int64_t)g * kSpSlots + slot) * kBpMsgWords + 2048 * w, S.xy[buf] + 2048 * w, lane, a.err_flag)) return;
-    sig(&S.arr[w], uv + 1, lane);
-    if (!wait_min<4>(S.arr, uv + 1, a.err_flag)) return;
+    st.mark(0);
+    // x of the stage below is published ahead of its y (a 32-instruction product against 128 and the gate): the x half of the products runs
+    // while y is on its way
+    const unsigned* msg = inbox + ((int64_t)g * kSpSlots + slot) * kBpMsgWords;
     f32x4b acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
     const f32x4b* xb = reinterpret_cast<const f32x4b*>(S.xy[buf]) + lane;
+    if (!gather(msg + 1024 * w, S.xy[buf] + 1024 * w, lane, a.err_flag)) return;
+    st.mark(1);
+    sig(&S.arrx[w], uv + 1, lane);
+    if (!wait_min<4>(S.arrx, uv + 1, a.err_flag)) return;
+    st.mark(2);
 #pragma unroll
-    for (int k4 = 0; k4 < 32; ++k4) {
+    for (int k4 = 0; k4 < 16; ++k4) {
       const f32x4b b = xb[k4 * 64];
       acc0 = mfma4(wa[4 * k4 + 0], b[0], acc0);
       acc1 = mfma4(wa[4 * k4 + 1], b[1], acc1);
       acc0 = mfma4(wa[4 * k4 + 2], b[2], acc0);
       acc1 = mfma4(wa[4 * k4 + 3], b[3], acc1);
     }
+    st.mark(3);
+    if (!gather(msg + 4096 + 1024 * w, S.xy[buf] + 4096 + 1024 * w, lane, a.err_flag)) return;
+    st.mark(4);
+    sig(&S.arr[w], uv + 1, lane);
+    if (!wait_min<4>(S.arr, uv + 1, a.err_flag)) return;
+    st.mark(5);
+    // x_s = x_{s-1} + R y_{s-1} + br FIRST - 32 products into the matrix pipe ahead of the 64 of the gate tile's y half (the pipe takes a SIMD's
+    // products in the order they were issued: as a helper wave's work these waited behind the gate tile's, and x_s reached the next stage
+    // together with y_s instead of a product's time ahead of it): residual tile r2, K half kh
+    f32x4b rc0 = {0.f, 0.f, 0.f, 0.f}, rc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k4 = 0; k4 < 8; ++k4) {
+      const f32x4b b = xb[(16 + 8 * kh + k4) * 64];
+      rc0 = mfma4(wr[4 * k4 + 0], b[0], rc0);
+      rc1 = mfma4(wr[4 * k4 + 1], b[1], rc1);
+      rc0 = mfma4(wr[4 * k4 + 2], b[2], rc0);
+      rc1 = mfma4(wr[4 * k4 + 3], b[3], rc1);
+    }
+#pragma unroll
+    for (int k4 = 16; k4 < 20; ++k4) {
+      const f32x4b b = xb[k4 * 64];
+      acc0 = mfma4(wa[4 * k4 + 0], b[0], acc0);
+      acc1 = mfma4(wa[4 * k4 + 1], b[1], acc1);
+      acc0 = mfma4(wa[4 * k4 + 2], b[2], acc0);
+      acc1 = mfma4(wa[4 * k4 + 3], b[3], acc1);
+    }
+    // (the residual products are through the pipe by now) this wave's half to helper wave r2, which adds the halves up and publishes x_s
+    if (v >= 1 && !wait_min<1>(&S.rp_used[r2], uv, a.err_flag)) return;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) S.rpart[w][i * 64 + lane] = rc0[i] + rc1[i];
+    sig(&S.rp[w], uv + 1, lane);
+#pragma unroll
+    for (int k4 = 20; k4 < 32; ++k4) {
+      const f32x4b b = xb[k4 * 64];
+      acc0 = mfma4(wa[4 * k4 + 0], b[0], acc0);
+      acc1 = mfma4(wa[4 * k4 + 1], b[1], acc1);
+      acc0 = mfma4(wa[4 * k4 + 2], b[2], acc0);
+      acc1 = mfma4(wa[4 * k4 + 3], b[3], acc1);
+    }
+    st.mark(6);
     sig(&S.done[w], uv + 1, lane);
     if (!wait_min<1>(&S.bias_ready[w], uv + 1, a.err_flag)) return;
+    st.mark(7);
     float z[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) z[i] = (acc0[i] + acc1[i]) + S.biasT[buf][w][i * 64 + lane];
@@ -201,35 +273,32 @@ __device__ __forceinline__ void chain_role(const WnBpipeArgs& a, BpLds& S, int s
         msg_put(psn + word, kSpPoison, local_next);
       }
     }
+    st.mark(8);
     if (++g == G) { g = 0; ++t; }
   }
+  st.flush(a.stamps, lane);
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------------
 // layer stage, waves 4-7
 // ------------------------------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void helper_role(const WnBpipeArgs& a, BpLds& S, int stage, int p, int h, int lane) {
-  float wb[128], wr[32], wh[16];
-  const int r2 = h & 1, kh = h >> 1;
+  float wb[128], wh[16];
   {
     const float* cu = a.img + ((int64_t)stage * 8 + p) * kBpCuFloats;
     const float* ib = cu + (4 * 128 + h * 128) * 64 + lane;
-    const float* ir = cu + (8 * 128 + h * 32) * 64 + lane;
     const float* ih = cu + (8 * 128 + 4 * 32 + h * 16) * 64 + lane;
 #pragma unroll
     for (int i = 0; i < 128; ++i) wb[i] = ib[i * 64];
-#pragma unroll
-    for (int i = 0; i < 32; ++i) wr[i] = ir[i * 64];
 #pragma unroll
     for (int i = 0; i < 16; ++i) wh[i] = ih[i * 64];
 #pragma unroll
     for (int i = 0; i < 128; ++i) asm volatile("" : "+v"(wb[i]));
 #pragma unroll
-    for (int i = 0; i < 32; ++i) asm volatile("" : "+v"(wr[i]));
-#pragma unroll
     for (int i = 0; i < 16; ++i) asm volatile("" : "+v"(wh[i]));
   }
   float bz[4], br[4];
+  const int r2 = h & 1;
   {
     const float* cst = a.cst + ((int64_t)stage * 8 + p) * kBpCstFloats;
 #pragma unroll
@@ -249,15 +318,18 @@ __device__ __forceinline__ void helper_role(const WnBpipeArgs& a, BpLds& S, int 
   const int64_t slot_stride = (int64_t)a.Bmax * kC;
   const int C1 = a.C1;
   const int64_t V = a.n_steps * G;
+  BpStamp st;
+  st.on = a.stamps != nullptr && stage == a.stamp_stage && p == 0 && h == 0;
 
   // everything of visit v1's z that does not depend on its message: W0 x_s[t - d] + Wc c[t] + b, tile h
   auto make_bias = [&](int64_t v1, int t1, int g1) -> bool {
     const unsigned u1 = (unsigned)v1;
     if (v1 >= 1 && !wait_min<4>(S.bdone, u1, a.err_flag)) return false;      // the image's last readers
+    st.mark(3);
     const int clip = kG * g1 + n;
     if (d == 1 && t1 >= 1) {
       // the stage's own message of the step before (x part, this wave's quarter), already in the image's layout
-      if (!gather<1>(outbox + ((int64_t)g1 * kSpSlots + ((t1 - 1) & 3)) * kBpMsgWords + 1024 * h, S.tc + 1024 * h, lane, a.err_flag)) return false;
+      if (!gather(outbox + ((int64_t)g1 * kSpSlots + ((t1 - 1) & 3)) * kBpMsgWords + 1024 * h, S.tc + 1024 * h, lane, a.err_flag)) return false;
     } else {
       const int64_t tp = a.t0 - 1 + t1 - d;
       u32x4b r[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
@@ -279,8 +351,10 @@ __device__ __forceinline__ void helper_role(const WnBpipeArgs& a, BpLds& S, int 
         for (int e = 0; e < 4; ++e) S.tc[4096 + (((4 * h + jj) * 64) + e * 16 + n) * 4 + q] = cv[e];
       }
     }
+    st.mark(4);
     sig(&S.rows[h], u1 + 1, lane);
     if (!wait_min<4>(S.rows, u1 + 1, a.err_flag)) return false;
+    st.mark(5);
     f32x4b acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
     const f32x4b* tb = reinterpret_cast<const f32x4b*>(S.tc) + lane;
 #pragma unroll
@@ -303,6 +377,7 @@ __device__ __forceinline__ void helper_role(const WnBpipeArgs& a, BpLds& S, int 
     }
     sig(&S.bdone[h], u1 + 1, lane);
     if (v1 >= 2 && !wait_min<1>(&S.bias_used[h], u1 - 1, a.err_flag)) return false;
+    st.mark(6);
 #pragma unroll
     for (int i = 0; i < 4; ++i) S.biasT[v1 & 1][h][i * 64 + lane] = (acc0[i] + acc1[i]) + bz[i];
     sig(&S.bias_ready[h], u1 + 1, lane);
@@ -315,47 +390,34 @@ __device__ __forceinline__ void helper_role(const WnBpipeArgs& a, BpLds& S, int 
     const int slot = t & 3, buf = (int)(v & 1);
     const unsigned uv = (unsigned)v;
     const int64_t tau = a.t0 - 1 + t;
+    st.start();
     if (!wait_min<4>(S.arr, uv + 1, a.err_flag)) return;
+    st.mark(0);
     const f32x4b* yb = reinterpret_cast<const f32x4b*>(S.xy[buf] + 4096) + lane;
-    // ---- x_s = x_{s-1} + R y_{s-1} + br: residual tile r2 (channels 32 p + 16 r2 ..), K half kh ----------------------------------------
-    {
-      f32x4b acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    // ---- x_s = x_{s-1} + R y_{s-1} + br (helpers 0, 1: residual tile h): the K halves come from chain waves h and h + 2 ------------------------
+    if (h < 2) {
+      if (!wait_min<1>(&S.rp[h], uv + 1, a.err_flag) || !wait_min<1>(&S.rp[h + 2], uv + 1, a.err_flag)) return;
+      float xs[4];
 #pragma unroll
-      for (int k4 = 0; k4 < 8; ++k4) {
-        const f32x4b b = yb[(8 * kh + k4) * 64];
-        acc0 = mfma4(wr[4 * k4 + 0], b[0], acc0);
-        acc1 = mfma4(wr[4 * k4 + 1], b[1], acc1);
-        acc0 = mfma4(wr[4 * k4 + 2], b[2], acc0);
-        acc1 = mfma4(wr[4 * k4 + 3], b[3], acc1);
+      for (int i = 0; i < 4; ++i) {
+        const float xprev = S.xy[buf][(((2 * p + r2) * 64) + i * 16 + n) * 4 + q];
+        xs[i] = xprev + ((S.rpart[h][i * 64 + lane] + S.rpart[h + 2][i * 64 + lane]) + br[i]);
       }
-      if (kh == 1) {
-        if (v >= 1 && !wait_min<1>(&S.rp_used[r2], uv, a.err_flag)) return;
+      sig(&S.rp_used[r2], uv + 1, lane);
+      unsigned* dx = outbox + ((int64_t)g * kSpSlots + slot) * kBpMsgWords;
+      unsigned* px = outbox + ((int64_t)g * kSpSlots + ((t + 2) & 3)) * kBpMsgWords;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) S.rpart[r2][i * 64 + lane] = acc0[i] + acc1[i];
-        sig(&S.rp[r2], uv + 1, lane);
-      } else {
-        if (!wait_min<1>(&S.rp[r2], uv + 1, a.err_flag)) return;
-        float xs[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const float xprev = S.xy[buf][(((2 * p + r2) * 64) + i * 16 + n) * 4 + q];
-          xs[i] = xprev + (((acc0[i] + acc1[i]) + S.rpart[r2][i * 64 + lane]) + br[i]);
-        }
-        sig(&S.rp_used[r2], uv + 1, lane);
-        unsigned* dst = outbox + ((int64_t)g * kSpSlots + slot) * kBpMsgWords;
-        unsigned* psn = outbox + ((int64_t)g * kSpSlots + ((t + 2) & 3)) * kBpMsgWords;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int word = (((2 * p + r2) * 64) + i * 16 + n) * 4 + q;
-          msg_put(dst + word, bits_of(xs[i]), local_next);
-          msg_put(psn + word, kSpPoison, local_next);
-        }
-        // the layer's input at tau into its ring (later taps; the launch path, should the batch be redone there)
-        const int clip = kG * g + n;
-        if (clip < a.B)
-          *reinterpret_cast<f32x4b*>(ring + (tau & ring_mask) * slot_stride + (int64_t)clip * kC + 32 * p + 16 * r2 + 4 * q) = f32x4b{xs[0], xs[1], xs[2], xs[3]};
+      for (int i = 0; i < 4; ++i) {
+        const int word = (((2 * p + r2) * 64) + i * 16 + n) * 4 + q;
+        msg_put(dx + word, bits_of(xs[i]), local_next);
+        msg_put(px + word, kSpPoison, local_next);
       }
+      // the layer's input at tau into its ring (later taps; the launch path, should the batch be redone there)
+      const int clip = kG * g + n;
+      if (clip < a.B)
+        *reinterpret_cast<f32x4b*>(ring + (tau & ring_mask) * slot_stride + (int64_t)clip * kC + 32 * p + 16 * r2 + 4 * q) = f32x4b{xs[0], xs[1], xs[2], xs[3]};
     }
+    st.mark(1);
     // ---- hid_s = hid_{s-1} + (fc0 W_skip_{s-1}) y_{s-1}: units 16 p .., K quarter h -------------------------------------------------------
     {
       f32x4b acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
@@ -412,11 +474,14 @@ __device__ __forceinline__ void helper_role(const WnBpipeArgs& a, BpLds& S, int 
         }
       }
     }
+    st.mark(2);
     int t1 = t, g1 = g + 1;
     if (g1 == G) { g1 = 0; ++t1; }
     if (v + 1 < V && !make_bias(v + 1, t1, g1)) return;
+    st.mark(7);
     t = t1; g = g1;
   }
+  st.flush(a.stamps + 16, lane);
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------------

@@ -21,7 +21,9 @@
 
 using namespace mmk;
 
-constexpr int kBpipeMinClips = 112;      // clips from which the stage pipeline's networks run in groups of 16 on the matrix pipe (wavenet_bpipe.hip)
+// clips from which the stage pipeline's networks run in groups of 16 on the matrix pipe (wavenet_bpipe.hip): beyond one ring of the one-clip form.
+// Measured on cfg 4, us per step: 128 clips 153 against the ring's 136; 144 clips 2 x 72 through the ring ~ 156 against 154; 256 clips 155 against 272
+constexpr int kBpipeMinClips = 129;
 
 struct WnCall {
   int M = 0;
@@ -483,7 +485,7 @@ static int derive(mmk_wavenet_plan* p) {
     // (the classes the network is fed are the ones it draws, and the first one - the prompt's last sample - is clamped to the head's 256)
     ok5 = ok5 && n_xcc == 8 && n_cu == 256 && c.q_levels <= 256 && c.out_dim <= c.q_levels;
     // Groups of 16 clips on the matrix pipe (wavenet_bpipe.hip) where the one-clip ring is beat-bound: a group's step is a trip of L + 1 visits of
-    // ~3.5 us whatever the batch (up to 32 groups), the ring's is ~1.1 us per clip.  MMK_WN_BPIPE=0 turns it off, =1 takes it for any batch.
+    // ~4.9 us whatever the batch (up to 16 groups; 32 groups are beat-bound at ~8 us per visit), the ring's is ~1.1 us per clip.  MMK_WN_BPIPE=0 turns it off, =1 takes it for any batch.
     const char* benv = p->tune.get("MMK_WN_BPIPE");
     bool ok6 = ok5 && !(benv && benv[0] == '0') && wn_bpipe_supported(p->C, p->S, c.mlp_hidden, c.out_dim, p->L, c.n_cond, cond_total, p->Bmax);
     ok6 = ok6 && ((benv && benv[0] == '1') || (p->Bmax >= kBpipeMinClips && p->L >= 16));
@@ -1183,6 +1185,8 @@ static int run_persistent(mmk_wavenet_plan* p, const WnCall& call, int64_t tau0,
       k.uni_ld = call.uni_ld;
       k.logits_out = p->sp_logits; k.logits_ld = mmk_wavenet_plan::kSpLogitsLd;
       k.msg = p->bp_msg; k.xcd_count = p->xcd_count; k.err_flag = p->err_flag;
+      k.stamps = (stamp_env && stamp_env[0] == '1') ? reinterpret_cast<unsigned long long*>(p->tau + 8) : nullptr;
+      k.stamp_stage = diag_only("MMK_WN_STAMP_STAGE") ? atoi(diag_only("MMK_WN_STAMP_STAGE")) : 1;
       MMK_TRY(launch_wavenet_bpipe(k, st));
       done += nb;
       continue;
@@ -1516,7 +1520,13 @@ extern "C" int mmk_wavenet_sync_status(mmk_wavenet_plan* p, mmk_stream_t stream)
     if (senv && senv[0] == '1') {
       unsigned long long st[256];
       MMK_HIP(hipMemcpy(st, p->tau + 8, p->spipe ? sizeof(st) : 24 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-      if (p->spipe) {
+      if (p->bpipe) {      // (wavenet_bpipe.hip: the marks of chain wave 0 and helper wave 4 of CU 0 of stage MMK_WN_STAMP_STAGE, totals of the last launch)
+        fprintf(stderr, "[mmk stamps] batched stage pipeline, us per mark - chain wave 0:");
+        for (int k = 0; k < 16; ++k) fprintf(stderr, " [%d]=%.0f", k, (double)st[k] * 0.01);
+        fprintf(stderr, "\n[mmk stamps] helper wave 4:");
+        for (int k = 0; k < 16; ++k) fprintf(stderr, " [%d]=%.0f", k, (double)st[16 + k] * 0.01);
+        fprintf(stderr, "\n");
+      } else if (p->spipe) {
         fprintf(stderr, "[mmk stamps] last stage-pipeline launch, chain wave 0 of CU 0 of stage MMK_WN_STAMP_STAGE (default 1), shader cycles per visit: "
                         "wait for the message=%.0f; products + gate + publish=%.0f; poison + ring store=%.0f; visits=%llu\n",
                 st[3] ? (double)st[0] / (double)st[3] : 0.0, st[3] ? (double)st[1] / (double)st[3] : 0.0, st[3] ? (double)st[2] / (double)st[3] : 0.0, st[3]);

@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--clips", type=int, default=256)
     ap.add_argument("--steps", type=int, default=64)
     ap.add_argument("--prompt", type=int, default=3072)
+    ap.add_argument("--only", default="", help="bpipe | spipe: run one of the two (no comparison)")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
     net, sd, arch = cfg4_network()
@@ -30,6 +31,8 @@ def main():
     cond = torch.rand(B, P + n, 513, generator=gen).to(dev)
     out = {}
     for name, tuning in (("bpipe", {"MMK_WN_BPIPE": "1"}), ("spipe", {"MMK_WN_BPIPE": "0"})):
+        if args.only and name != args.only:
+            continue
         net.exec_tuning = dict(tuning)
         net._plan = None
         best = None
@@ -46,6 +49,8 @@ def main():
         mode = "set" if hasattr(net._plan, "plans") else int(net._plan._lib.mmk_wavenet_mode(net._plan.handle))
         out[name] = idx.cpu()
         print(f"{name}: mode {mode}, {best / n * 1e6:.1f} us per step, {B * n / best / 1e3:.0f} k samples/s", flush=True)
+    if args.only:
+        return
     a, b = out["bpipe"][:, P:], out["spipe"][:, P:]
     same = (a == b)
     print(f"classes equal: {same.float().mean().item() * 100:.2f} % ; first step equal: {same[:, 0].float().mean().item() * 100:.2f} % ; "

@@ -10,7 +10,7 @@ for path in glob.glob(root + "/**/*counter_collection.csv", recursive=True):
     with open(path) as f:
         for r in csv.DictReader(f):
             name = r.get("Kernel_Name", "")
-            short = name.split("(")[0][-60:]
+            short = name.replace("(anonymous namespace)::", "").split("(")[0][-60:]
             key = (short, r.get("Grid_Size", ""), r.get("Workgroup_Size", ""), r.get("Counter_Name", ""))
             rows[key][0] += float(r.get("Counter_Value", 0) or 0)
             rows[key][1] += 1

@@ -12,7 +12,7 @@ torch.set_grad_enabled(False)
 
 class A:
     workload = os.environ.get("WORKLOAD", "wavenet_cfg4")
-    clips = 0
+    clips = int(os.environ.get("CLIPS", "0"))
     seconds = 0.07
 
 

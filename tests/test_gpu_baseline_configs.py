@@ -200,8 +200,8 @@ def test_cfg4_wavenet_64_clips_in_one_ring(device):
 
 def test_cfg4_wavenet_128_clips_in_one_ring(device):
     """R = 2: 128 clips per GPU, the most one ring takes (the bias image of a stage CU is 64 KB of its LDS then); the one-clip ring by name
-    (from 112 clips on the plan takes groups of 16 clips on the matrix pipe: the tests below)"""
-    _cfg4_greedy_against_oracle(device, B=128, n=600, n_last=1, n_mid=12, seed=4128, expect_set=False, tuning={"MMK_WN_BPIPE": "0"})
+    (beyond it the plan takes groups of 16 clips on the matrix pipe: the tests below)"""
+    _cfg4_greedy_against_oracle(device, B=128, n=600, n_last=1, n_mid=12, seed=4128, expect_set=False)
 
 
 def test_cfg4_wavenet_more_clips_than_one_ring(device):
