@@ -272,7 +272,7 @@ int mmk_wavenet_profile_steps(mmk_wavenet_plan* plan, int32_t batch, void* in0, 
                               int64_t n_steps, double* ms_total, int64_t* launches, mmk_stream_t stream);
 
 /* > 0 when the plan runs all steps of a call inside one persistent kernel (1 csrc/wavenet_persist.hip, 2 wavenet_chain.hip,
- * 4 wavenet_lpipe.hip, 5 wavenet_spipe.hip; 3 was the XCD-pipelined kernel, removed in round 5: no geometry where it ran and won), 0 when it enqueues one fused kernel per layer half (hipGraph-replayed) */
+ * 4 wavenet_lpipe.hip, 5 wavenet_spipe.hip, 6 wavenet_bpipe.hip; 3 was the XCD-pipelined kernel, removed in round 5: no geometry where it ran and won), 0 when it enqueues one fused kernel per layer half (hipGraph-replayed) */
 int mmk_wavenet_mode(const mmk_wavenet_plan* plan);
 /* waits for `stream`; MMK_ERR_STATE if a hand-off inside the persistent kernel timed out */
 int mmk_wavenet_sync_status(mmk_wavenet_plan* plan, mmk_stream_t stream);

@@ -140,6 +140,25 @@ struct BpStamp {
 
 __device__ __forceinline__ f32x4b mfma4(float a, float b, f32x4b c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 
+// acc0 / acc1 += A registers w[0 .. 4 N) x the N 16-byte B reads b[0], b[64], ..: the B read two ahead is asked for before the current one's four
+// products (read, wait, eight products, read again left the matrix pipe idle for an LDS round trip in every eight: 41 cycles per product, not 32)
+template <int N>
+__device__ __forceinline__ void mfma_sweep(const float* w, const f32x4b* b, f32x4b& acc0, f32x4b& acc1) {
+  f32x4b q0 = b[0], q1 = N > 1 ? b[64] : b[0];
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    f32x4b q2 = q1;
+    if (k + 2 < N) q2 = b[(k + 2) * 64];
+    __builtin_amdgcn_sched_barrier(0);      // (the scheduler otherwise sinks the read behind the products it was meant to run under)
+    acc0 = mfma4(w[4 * k + 0], q0[0], acc0);
+    acc1 = mfma4(w[4 * k + 1], q0[1], acc1);
+    acc0 = mfma4(w[4 * k + 2], q0[2], acc0);
+    acc1 = mfma4(w[4 * k + 3], q0[3], acc1);
+    q0 = q1;
+    q1 = q2;
+  }
+}
+
 // a wave's 4 KB of a message into an LDS image, looked at until no word of it is the poison word (every look is the whole part: one trip to
 // the L2 once it is there)
 __device__ __forceinline__ bool gather(const unsigned* src, float* dst, int lane, int32_t* err) {
@@ -205,53 +224,29 @@ __device__ __forceinline__ void chain_role(const WnBpipeArgs& a, BpLds& S, int s
     sig(&S.arrx[w], uv + 1, lane);
     if (!wait_min<4>(S.arrx, uv + 1, a.err_flag)) return;
     st.mark(2);
-#pragma unroll
-    for (int k4 = 0; k4 < 16; ++k4) {
-      const f32x4b b = xb[k4 * 64];
-      acc0 = mfma4(wa[4 * k4 + 0], b[0], acc0);
-      acc1 = mfma4(wa[4 * k4 + 1], b[1], acc1);
-      acc0 = mfma4(wa[4 * k4 + 2], b[2], acc0);
-      acc1 = mfma4(wa[4 * k4 + 3], b[3], acc1);
-    }
+    mfma_sweep<16>(wa, xb, acc0, acc1);
     st.mark(3);
     if (!gather(msg + 4096 + 1024 * w, S.xy[buf] + 4096 + 1024 * w, lane, a.err_flag)) return;
     st.mark(4);
     sig(&S.arr[w], uv + 1, lane);
     if (!wait_min<4>(S.arr, uv + 1, a.err_flag)) return;
     st.mark(5);
+#ifdef MMK_DIAG
+    // the chain's time line: group 0 of the launch's last step, wall clock (100 MHz, one counter for the chip) when y was complete here ...
+    if (a.stamps && g == 0 && t + 1 == (int)a.n_steps && p == 0 && w == 0 && lane == 0) a.stamps[64 + 2 * stage] = __builtin_amdgcn_s_memrealtime();
+#endif
     // x_s = x_{s-1} + R y_{s-1} + br FIRST - 32 products into the matrix pipe ahead of the 64 of the gate tile's y half (the pipe takes a SIMD's
     // products in the order they were issued: as a helper wave's work these waited behind the gate tile's, and x_s reached the next stage
     // together with y_s instead of a product's time ahead of it): residual tile r2, K half kh
     f32x4b rc0 = {0.f, 0.f, 0.f, 0.f}, rc1 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int k4 = 0; k4 < 8; ++k4) {
-      const f32x4b b = xb[(16 + 8 * kh + k4) * 64];
-      rc0 = mfma4(wr[4 * k4 + 0], b[0], rc0);
-      rc1 = mfma4(wr[4 * k4 + 1], b[1], rc1);
-      rc0 = mfma4(wr[4 * k4 + 2], b[2], rc0);
-      rc1 = mfma4(wr[4 * k4 + 3], b[3], rc1);
-    }
-#pragma unroll
-    for (int k4 = 16; k4 < 20; ++k4) {
-      const f32x4b b = xb[k4 * 64];
-      acc0 = mfma4(wa[4 * k4 + 0], b[0], acc0);
-      acc1 = mfma4(wa[4 * k4 + 1], b[1], acc1);
-      acc0 = mfma4(wa[4 * k4 + 2], b[2], acc0);
-      acc1 = mfma4(wa[4 * k4 + 3], b[3], acc1);
-    }
+    mfma_sweep<8>(wr, xb + (16 + 8 * kh) * 64, rc0, rc1);
+    mfma_sweep<4>(wa + 64, xb + 16 * 64, acc0, acc1);
     // (the residual products are through the pipe by now) this wave's half to helper wave r2, which adds the halves up and publishes x_s
     if (v >= 1 && !wait_min<1>(&S.rp_used[r2], uv, a.err_flag)) return;
 #pragma unroll
     for (int i = 0; i < 4; ++i) S.rpart[w][i * 64 + lane] = rc0[i] + rc1[i];
     sig(&S.rp[w], uv + 1, lane);
-#pragma unroll
-    for (int k4 = 20; k4 < 32; ++k4) {
-      const f32x4b b = xb[k4 * 64];
-      acc0 = mfma4(wa[4 * k4 + 0], b[0], acc0);
-      acc1 = mfma4(wa[4 * k4 + 1], b[1], acc1);
-      acc0 = mfma4(wa[4 * k4 + 2], b[2], acc0);
-      acc1 = mfma4(wa[4 * k4 + 3], b[3], acc1);
-    }
+    mfma_sweep<12>(wa + 80, xb + 20 * 64, acc0, acc1);
     st.mark(6);
     sig(&S.done[w], uv + 1, lane);
     if (!wait_min<1>(&S.bias_ready[w], uv + 1, a.err_flag)) return;
@@ -260,20 +255,33 @@ __device__ __forceinline__ void chain_role(const WnBpipeArgs& a, BpLds& S, int s
 #pragma unroll
     for (int i = 0; i < 4; ++i) z[i] = (acc0[i] + acc1[i]) + S.biasT[buf][w][i * 64 + lane];
     sig(&S.bias_used[w], uv + 1, lane);
-    // tanh(f) sigmoid(g) (wavenet_v2.py:151): the g rows of a unit sit 32 lanes above its f rows
-    unsigned* dst = outbox + ((int64_t)g * kSpSlots + slot) * kBpMsgWords + 4096;
-    unsigned* psn = outbox + ((int64_t)g * kSpSlots + ((t + 2) & 3)) * kBpMsgWords + 4096;
+    // tanh(f) sigmoid(g) (wavenet_v2.py:151): the g rows of a unit sit 32 lanes above its f rows (v_permlane32_swap: the upper half's values in both halves)
+    unsigned* dst = outbox + ((int64_t)g * kSpSlots + slot) * kBpMsgWords + 4096 + pos_of(32 * p + 8 * w + 4 * (q & 1), n);
+    unsigned* psn = outbox + ((int64_t)g * kSpSlots + ((t + 2) & 3)) * kBpMsgWords + 4096 + pos_of(32 * p + 8 * w + 4 * (q & 1), n);
+    unsigned yb4[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const float zg = __shfl_xor(z[i], 32);
-      const float y = tanh_fast(z[i]) * sigmoid_fast(zg);
-      if (q < 2) {
-        const int word = pos_of(32 * p + 8 * w + 4 * q + i, n);
-        msg_put(dst + word, bits_of(y), local_next);
-        msg_put(psn + word, kSpPoison, local_next);
+      const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(z[i]), __float_as_uint(z[i]), false, false);
+      yb4[i] = bits_of(tanh_fast(z[i]) * sigmoid_fast(__uint_as_float(sw[1])));
+    }
+    // (channel k + i of a lane: word + 64 i - pos_of; the data words first, the poison for two steps ahead behind them)
+    if (q < 2) {
+      if (local_next) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) __hip_atomic_store(dst + 64 * i, yb4[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) __hip_atomic_store(psn + 64 * i, kSpPoison, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) __hip_atomic_store(dst + 64 * i, yb4[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) __hip_atomic_store(psn + 64 * i, kSpPoison, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
     st.mark(8);
+#ifdef MMK_DIAG
+    if (a.stamps && g == 0 && t + 1 == (int)a.n_steps && p == 0 && w == 0 && lane == 0) a.stamps[64 + 2 * stage + 1] = __builtin_amdgcn_s_memrealtime();      // ... and when y_s had been stored
+#endif
     if (++g == G) { g = 0; ++t; }
   }
   st.flush(a.stamps, lane);
@@ -357,23 +365,9 @@ __device__ __forceinline__ void helper_role(const WnBpipeArgs& a, BpLds& S, int 
     st.mark(5);
     f32x4b acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
     const f32x4b* tb = reinterpret_cast<const f32x4b*>(S.tc) + lane;
-#pragma unroll
-    for (int k4 = 0; k4 < 16; ++k4) {
-      const f32x4b b = tb[k4 * 64];
-      acc0 = mfma4(wb[4 * k4 + 0], b[0], acc0);
-      acc1 = mfma4(wb[4 * k4 + 1], b[1], acc1);
-      acc0 = mfma4(wb[4 * k4 + 2], b[2], acc0);
-      acc1 = mfma4(wb[4 * k4 + 3], b[3], acc1);
-    }
+    mfma_sweep<16>(wb, tb, acc0, acc1);
     if (C1 > 0) {
-#pragma unroll
-      for (int k4 = 16; k4 < 32; ++k4) {
-        const f32x4b b = tb[k4 * 64];
-        acc0 = mfma4(wb[4 * k4 + 0], b[0], acc0);
-        acc1 = mfma4(wb[4 * k4 + 1], b[1], acc1);
-        acc0 = mfma4(wb[4 * k4 + 2], b[2], acc0);
-        acc1 = mfma4(wb[4 * k4 + 3], b[3], acc1);
-      }
+      mfma_sweep<16>(wb + 64, tb + 16 * 64, acc0, acc1);
     }
     sig(&S.bdone[h], u1 + 1, lane);
     if (v1 >= 2 && !wait_min<1>(&S.bias_used[h], u1 - 1, a.err_flag)) return false;
