@@ -10,9 +10,10 @@ namespace mmk {
 constexpr int kBpGroup = 16;                       // clips per visit: the N of the 16x16x4 product
 constexpr int kBpMaxClips = 512;                   // 32 groups: as many as there are stages
 constexpr int kBpMsgWords = 2 * 4096 + 2048;       // what a stage receives per group and step: x (256 x 16) | y (256 x 16) | running hidden pre-activations (128 x 16)
-// A-operand images per CU of a layer stage (floats): gate tiles x [x | y] (4 waves x 128 registers) | gate tiles x [delayed x | c] (4 x 128) |
-// residual tiles x a K half of y (4 x 32) | hidden-unit tile x a K quarter of y (4 x 16), each register 64 lanes
-constexpr int kBpCuFloats = (4 * 128 + 4 * 128 + 4 * 32 + 4 * 16) * 64;
+// A-operand images per CU of a layer stage (floats): gate tiles x [x_{s-2} | y_{s-2} | y_{s-1}] (4 chain waves x 192 registers) | gate tiles x [delayed x | c]
+// (4 helper waves x 128) | residual tiles x a K half of y_{s-1} (4 x 32) | hidden-unit tile x a K quarter of y_{s-1} (4 x 16), each register 64 lanes
+constexpr int kBpChainRegs = 192;
+constexpr int kBpCuFloats = (4 * kBpChainRegs + 4 * 128 + 4 * 32 + 4 * 16) * 64;
 constexpr int kBpCstFloats = (4 + 2) * 256;        // per CU: gate bias of the 4 tiles | residual bias of the 2 tiles, in the products' output layout
 
 struct WnBpipeArgs {

@@ -1,32 +1,37 @@
 // WaveNet generation as a pipeline of layer stages whose visits are GROUPS OF 16 CLIPS on the matrix pipe (gfx950): the large-batch form of
 // wavenet_spipe.hip.  BASELINE config 4 (30 layers x 256 channels, conditioned) with more clips per GPU than the one-clip ring serves at its
-// beat (~1.1 us per clip and stage: 256 clips = 271 us per step).
+// beat (~1.06 us per clip and stage: 128 clips = 136 us per step, 256 = 272).
 //
 // Reference: WaveNet.forward / WNLayer.forward (wavenet_v2.py:131-182, :276-293), MLP head and CategoricalSampler (networks/mlp.py:58-63,
-// modules/targets.py:37-52).  The arithmetic is the stage pipeline's one-hand-off form:
-//   x_s   = x_{s-1} + R_{s-1} y_{s-1} + br_{s-1}
-//   z_s   = W0_s x_s[t - d_s] + W1_s x_{s-1} + (W1_s R_{s-1}) y_{s-1} + Wc_s c[t] + b
+// modules/targets.py:37-52).  The arithmetic is the stage pipeline's one-hand-off form, taken one stage further back:
+//   x_s   = x_{s-1} + R_{s-1} y_{s-1} + br_{s-1}                                                       (off the chain)
+//   z_s   = W0_s x_s[t - d_s] + Wc_s c[t] + b                                                           (a visit ahead)
+//         + W1_s x_{s-2} + (W1_s R_{s-2}) y_{s-2}                                                       (early: what the stage BELOW received)
+//         + (W1_s R_{s-1}) y_{s-1}                                                                      (on the chain)
 //   y_s   = tanh(z_f) sigmoid(z_g)
-//   hid  += (fc0 W_skip_{s-1}) y_{s-1}
-// with W1 R and fc0 W_skip composed at commit (fp64 accumulation, one rounding).
+//   hid  += (fc0 W_skip_{s-1}) y_{s-1}                                                                  (off the chain)
+// with W1 R and fc0 W_skip composed at commit (fp64 accumulation, one rounding).  Only the last product of z_s, the gate and the store of y_s lie
+// between the arrival of y_{s-1} and the departure of y_s: x_s is needed by the stage after next only (and by this layer's history ring).
 //
 // Shape.  A layer is a stage of 8 CUs (4 stages per XCD, roles from where a workgroup runs, as in the stage pipeline); a CU owns 32 units:
-// 64 gate rows, 32 residual rows, 16 of the head's hidden units - 77,824 weights, in registers for the whole launch as A operands of
-// v_mfma_f32_16x16x4_f32 (152 per lane).  A visit takes the message of one group of 16 clips - x | y | running hidden pre-activations, 40 KB,
-// laid out as the B operand wants it - and costs the CU 1,216 matrix instructions (4.05 us at the fp32 matrix rate) of which 160 per SIMD are
-// on the group's chain:
-//   waves 0-3  gather the message (a quarter each, looking at the words until none is the poison word), multiply a gate tile
-//              (rows: f of 8 units | g of the same 8) with [x | y] (K = 512), add the tile of everything known a visit ahead, gate
-//              (the g half sits 32 lanes up: one cross-half read), publish y;
-//   waves 4-7  multiply a residual tile with a K half of y, add the halves, publish x_s (to the next stage and to the layer's
-//              history ring); then, off the chain: the hidden units' tile (K quarters, added up by wave 4, handed on beside the message)
-//              and the NEXT visit's known terms W0 x_s[t - d] + Wc c[t] + b from rows they stage themselves (history ring - or, d = 1, the
-//              stage's own newest message; the conditioning row).
+// 64 gate rows, 32 residual rows, 16 of the head's hidden units - 94,208 weights, in registers for the whole launch as A operands of
+// v_mfma_f32_16x16x4_f32 (192 per lane in waves 0 - 3, 176 in waves 4 - 7).  A message is x | y | running hidden pre-activations of one group of 16
+// clips (40 KB) in the B operand's layout; a stage reads the message of the stage below too (its x and y parts), so x and y are stored with plain
+// stores only where the next TWO stages sit on this XCD.
+//   waves 0-3  per visit: the early products of a gate tile (rows: f of 8 units | g of the same 8) from the stage below's message - gathered and
+//              multiplied while y_{s-1} is still on its way -, then a quarter each of y_{s-1} (looked at until no word is the poison word), 64
+//              products, the tile of the known terms added, the gate (the g half sits 32 lanes up: v_permlane32_swap), y_s stored;
+//   waves 4-7  off the chain: a residual tile x a K half of y_{s-1} (the halves meet in LDS; waves 6, 7 add x_{s-1} - their own look at the message's
+//              x part - and store x_s to the next stage's message and to the layer's history ring), the hidden units' tile (K quarters, added up by
+//              wave 4 and handed on beside the message), and the NEXT visit's known terms W0 x_s[t - d] + Wc c[t] + b: the rows (history ring, conditioning)
+//              come by LDS-DMA, asked for a visit ahead into a double-buffered image (no registers, no staging instructions); d = 1: the stage's own
+//              newest message instead.
 // Messages are the stage pipeline's: raw floats against a poison word, four generations per (stage, group), the producer re-poisons its own
 // words two steps ahead.  The head stage's CU p serves groups p, p + 8, ..: hidden tile, fc2 tiles and the temperature row as matrix
 // products, one wave per clip for the draw, the embedded classes as stage 0's next message.
 //
-// A group's step is a trip of L + 1 visits of ~3.5 us: the kernel pays from ~8 groups on (128 clips) and is trip-bound up to 32 groups.
+// A group's step is a trip of L + 1 visits of ~3.5 us (the exchange ~2, the products on the chain ~1.5): 109 us per step from 7 to ~10 groups;
+// beyond, a stage's ~9.5 us per visit (368 matrix instructions per SIMD = 4.9 us at the pipe's rate, plus what the two waves of a SIMD wait for) is the beat.
 #define MMK_FAST_RCP 1
 #include "wavenet_bpipe.h"
 #include "sampler256.h"
@@ -53,15 +58,16 @@ constexpr int kLgStride = 260;
 __device__ __forceinline__ int pos_of(int k, int n) { return (((k >> 4) * 64) + (k & 3) * 16 + n) * 4 + ((k >> 2) & 3); }
 
 struct BpLds {
-  float xy[2][8192];              // [visit parity][x image | y image]
-  float tc[8192];                 // delayed x | conditioning row of the visit whose known terms are being made
+  float ye[8192];                 // what the stage below received, x_{s-2} | y_{s-2}: the B images of the early products
+  float yl[2][4096];              // [visit parity] the newest message's y_{s-1} (stage 0: x, the embedded class): B image of the products on the chain
+  float tc[2][8192];              // [visit parity] delayed x | conditioning row of a visit, written by LDS-DMA a visit ahead: element (channel 4 kk + e, clip n) at kk 64 + 4 n + e
   float biasT[2][4][256];         // [visit parity][gate tile]: the known terms, in the product's output layout [register][lane]
-  float rpart[4][256];            // residual tiles: [K half][tile] partial products, in the output layout
+  float rpart[2][256];            // residual tiles: the first K half's partial
   float hpart[4][256];            // hidden-unit tile: the K quarters' partials
-  unsigned arr[4];                // chain wave w: visits whose quarter of the message's y it has staged (its quarter of x before that)
-  unsigned arrx[4];               // ... of x
-  unsigned done[8];               // wave: visits whose xy image it reads no more
-  unsigned rp[4], rp_used[2];     // residual partial of chain wave w written / tile's partials taken (by helper r2)
+  unsigned arr[4];                // chain wave w: visits whose quarter of the newest y it has staged
+  unsigned earr[4], edone[4];     // ... whose quarters of the early images it has staged / whose early products it has issued
+  unsigned done[8];               // wave: visits whose yl image it reads no more
+  unsigned rp[2], rp_used[2];     // residual tile: second half's partial written / taken
   unsigned hp[4], hp_used[1];
   unsigned rows[4], bdone[4];     // helper: visits whose rows it has staged / whose known-term products it has finished
   unsigned bias_ready[4], bias_used[4];
@@ -73,7 +79,7 @@ __device__ __forceinline__ void sig(unsigned* p, unsigned v, int lane) {
   __atomic_signal_fence(__ATOMIC_SEQ_CST);
 }
 template <int N>
-__device__ __forceinline__ bool wait_min(const unsigned* p, unsigned want, int32_t* err) {
+__device__ __forceinline__ bool wait_min(const unsigned* p, unsigned want, int32_t* err, int tag = 0) {
   unsigned spins = 0;
   for (;;) {
     unsigned m = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -82,7 +88,7 @@ __device__ __forceinline__ bool wait_min(const unsigned* p, unsigned want, int32
     if (m >= want) break;
     __builtin_amdgcn_s_sleep(1);
     if (++spins > kSpin || ((spins & 4095u) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
-      atomicExch(err, 1);
+      atomicCAS(err, 0, 1);
       return false;
     }
   }
@@ -138,6 +144,11 @@ struct BpStamp {
 #endif
 };
 
+// 16 bytes per lane from global memory straight into LDS (no registers): lane l's bytes land at dst + 16 l
+__device__ __forceinline__ void glds16(const float* src, float* dst) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+}
+
 __device__ __forceinline__ f32x4b mfma4(float a, float b, f32x4b c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 
 // acc0 / acc1 += A registers w[0 .. 4 N) x the N 16-byte B reads b[0], b[64], ..: the B read two ahead is asked for before the current one's four
@@ -159,9 +170,27 @@ __device__ __forceinline__ void mfma_sweep(const float* w, const f32x4b* b, f32x
   }
 }
 
+// the same over an image in the LDS-DMA's order: k-step kk of lane (e, n) is the float at kk 64 + 4 n + e
+template <int N>
+__device__ __forceinline__ void mfma_sweep_lin(const float* w, const float* b, f32x4b& acc0, f32x4b& acc1) {
+  float q[6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) q[i] = b[(i < N ? i : 0) * 64];
+#pragma unroll
+  for (int k = 0; k < N; k += 2) {
+    float n0 = q[4], n1 = q[5];
+    if (k + 6 < N) n0 = b[(k + 6) * 64];
+    if (k + 7 < N) n1 = b[(k + 7) * 64];
+    __builtin_amdgcn_sched_barrier(0);
+    acc0 = mfma4(w[k], q[0], acc0);
+    acc1 = mfma4(w[k + 1], q[1], acc1);
+    q[0] = q[2]; q[1] = q[3]; q[2] = q[4]; q[3] = q[5]; q[4] = n0; q[5] = n1;
+  }
+}
+
 // a wave's 4 KB of a message into an LDS image, looked at until no word of it is the poison word (every look is the whole part: one trip to
 // the L2 once it is there)
-__device__ __forceinline__ bool gather(const unsigned* src, float* dst, int lane, int32_t* err) {
+__device__ __forceinline__ bool gather(const unsigned* src, float* dst, int lane, int32_t* err, int tag = 0) {
   u32x4b r[4];
   unsigned spins = 0;
   for (;;) {
@@ -169,7 +198,7 @@ __device__ __forceinline__ bool gather(const unsigned* src, float* dst, int lane
     if (__all(clean(r[0]) && clean(r[1]) && clean(r[2]) && clean(r[3]))) break;
     __builtin_amdgcn_s_sleep(2);
     if (++spins > kSpin || ((spins & 1023u) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
-      atomicExch(err, 1);
+      atomicMax(err, 0x10000 | tag);      // (diagnosis: which look never saw its message)
       return false;
     }
   }
@@ -179,78 +208,67 @@ __device__ __forceinline__ bool gather(const unsigned* src, float* dst, int lane
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------------
-// layer stage, waves 0-3: gate tile w of the CU = rows [f of units 32 p + 8 w .. + 7 | g of the same units]
+// layer stage, waves 0-3: gate tile w of the CU = rows [f of units 32 p + 8 w .. + 7 | g of the same units], K = [x_{s-2} | y_{s-2} | y_{s-1}]
 // ------------------------------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void chain_role(const WnBpipeArgs& a, BpLds& S, int stage, int p, int w, int lane) {
-  float wa[128], wr[32];
-  const int r2 = w & 1, kh = w >> 1;      // the residual tile (channels 32 p + 16 r2 ..) and K half of y this wave multiplies besides
+  float wa[kBpChainRegs];      // [W1 (x_{s-2}) | W1 R_{s-2} (y_{s-2}) | W1 R_{s-1} (y_{s-1})] of the tile's rows
   {
-    const float* cu = a.img + ((int64_t)stage * 8 + p) * kBpCuFloats;
-    const float* img = cu + (int64_t)w * 128 * 64 + lane;
-    const float* ir = cu + (8 * 128 + w * 32) * 64 + lane;
+    const float* img = a.img + ((int64_t)stage * 8 + p) * kBpCuFloats + (int64_t)w * kBpChainRegs * 64 + lane;
 #pragma unroll
-    for (int i = 0; i < 128; ++i) wa[i] = img[i * 64];
+    for (int i = 0; i < kBpChainRegs; ++i) wa[i] = img[i * 64];
 #pragma unroll
-    for (int i = 0; i < 32; ++i) wr[i] = ir[i * 64];
-#pragma unroll
-    for (int i = 0; i < 128; ++i) asm volatile("" : "+v"(wa[i]));
-#pragma unroll
-    for (int i = 0; i < 32; ++i) asm volatile("" : "+v"(wr[i]));
+    for (int i = 0; i < kBpChainRegs; ++i) asm volatile("" : "+v"(wa[i]));
   }
   const int G = (a.B + kG - 1) / kG;
   const int n = lane & 15, q = lane >> 4;
-  const bool local_next = ((stage + 1) >> 2) == (stage >> 2);
+  // (x and y are read by the next stage AND the one after it: plain stores only where both sit on this XCD)
+  const bool local_next = ((stage + 2) >> 2) == (stage >> 2);
   const int64_t stage_words = (int64_t)((a.Bmax + kG - 1) / kG) * kSpSlots * kBpMsgWords;
   const unsigned* inbox = a.msg + (int64_t)stage * stage_words;
+  const unsigned* below = a.msg + (int64_t)(stage > 0 ? stage - 1 : 0) * stage_words;      // what the stage below received
   unsigned* outbox = a.msg + (int64_t)(stage + 1) * stage_words;
+  const int late_off = stage == 0 ? 0 : 4096;      // stage 0's newest operand is the embedded class (the x part of its message)
   const int64_t V = a.n_steps * G;
   int t = 0, g = 0;
-  __builtin_amdgcn_s_setprio(MMK_BP_CHAIN_PRIO);      // (ahead of the helper wave of the same SIMD, whose products mostly are off the chain)
+  __builtin_amdgcn_s_setprio(MMK_BP_CHAIN_PRIO);      // (ahead of the helper wave of the same SIMD, whose products are off the chain)
   BpStamp st;
   st.on = a.stamps != nullptr && stage == a.stamp_stage && p == 0 && w == 0;
   for (int64_t v = 0; v < V; ++v) {
     const int slot = t & 3, buf = (int)(v & 1);
     const unsigned uv = (unsigned)v;
     st.start();
-    if (v >= 2 && !wait_min<8>(S.done, uv - 1, a.err_flag)) return;
-    st.mark(0);
-    // x of the stage below is published ahead of its y (a 32-instruction product against 128 and the gate): the x half of the products runs
-    // while y is on its way
-    const unsigned* msg = inbox + ((int64_t)g * kSpSlots + slot) * kBpMsgWords;
     f32x4b acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-    const f32x4b* xb = reinterpret_cast<const f32x4b*>(S.xy[buf]) + lane;
-    if (!gather(msg + 1024 * w, S.xy[buf] + 1024 * w, lane, a.err_flag)) return;
-    st.mark(1);
-    sig(&S.arrx[w], uv + 1, lane);
-    if (!wait_min<4>(S.arrx, uv + 1, a.err_flag)) return;
+    // ---- early: W1 x_{s-2} + (W1 R_{s-2}) y_{s-2} - what the stage BELOW received for this visit, there a whole visit before y_{s-1} ---------------
+    // (asked for by LDS-DMA behind the previous visit's early products instead: 128 clips 109 -> 119 us per step - the look at y_{s-1} then waits for it too)
+    if (stage >= 1) {
+      const unsigned* em = below + ((int64_t)g * kSpSlots + slot) * kBpMsgWords;
+      if (v >= 1 && !wait_min<4>(S.edone, uv, a.err_flag, 64 * 1 + stage)) return;
+      if (!gather(em + 1024 * w, S.ye + 1024 * w, lane, a.err_flag, 64 * 14 + stage)) return;
+      if (!gather(em + 4096 + 1024 * w, S.ye + 4096 + 1024 * w, lane, a.err_flag, 64 * 15 + stage)) return;
+      sig(&S.earr[w], uv + 1, lane);
+      if (!wait_min<4>(S.earr, uv + 1, a.err_flag, 64 * 2 + stage)) return;
+      st.mark(0);
+      mfma_sweep<32>(wa, reinterpret_cast<const f32x4b*>(S.ye) + lane, acc0, acc1);
+      sig(&S.edone[w], uv + 1, lane);
+      st.mark(1);
+    }
+    // ---- on the chain: (W1 R_{s-1}) y_{s-1} -------------------------------------------------------------------------------------------------------
+    if (v >= 2 && !wait_min<8>(S.done, uv - 1, a.err_flag, 64 * 3 + stage)) return;
     st.mark(2);
-    mfma_sweep<16>(wa, xb, acc0, acc1);
+    if (!gather(inbox + ((int64_t)g * kSpSlots + slot) * kBpMsgWords + late_off + 1024 * w, S.yl[buf] + 1024 * w, lane, a.err_flag, 64 * 16 + stage)) return;
     st.mark(3);
-    if (!gather(msg + 4096 + 1024 * w, S.xy[buf] + 4096 + 1024 * w, lane, a.err_flag)) return;
-    st.mark(4);
     sig(&S.arr[w], uv + 1, lane);
-    if (!wait_min<4>(S.arr, uv + 1, a.err_flag)) return;
-    st.mark(5);
+    if (!wait_min<4>(S.arr, uv + 1, a.err_flag, 64 * 4 + stage)) return;
+    st.mark(4);
 #ifdef MMK_DIAG
     // the chain's time line: group 0 of the launch's last step, wall clock (100 MHz, one counter for the chip) when y was complete here ...
     if (a.stamps && g == 0 && t + 1 == (int)a.n_steps && p == 0 && w == 0 && lane == 0) a.stamps[64 + 2 * stage] = __builtin_amdgcn_s_memrealtime();
 #endif
-    // x_s = x_{s-1} + R y_{s-1} + br FIRST - 32 products into the matrix pipe ahead of the 64 of the gate tile's y half (the pipe takes a SIMD's
-    // products in the order they were issued: as a helper wave's work these waited behind the gate tile's, and x_s reached the next stage
-    // together with y_s instead of a product's time ahead of it): residual tile r2, K half kh
-    f32x4b rc0 = {0.f, 0.f, 0.f, 0.f}, rc1 = {0.f, 0.f, 0.f, 0.f};
-    mfma_sweep<8>(wr, xb + (16 + 8 * kh) * 64, rc0, rc1);
-    mfma_sweep<4>(wa + 64, xb + 16 * 64, acc0, acc1);
-    // (the residual products are through the pipe by now) this wave's half to helper wave r2, which adds the halves up and publishes x_s
-    if (v >= 1 && !wait_min<1>(&S.rp_used[r2], uv, a.err_flag)) return;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) S.rpart[w][i * 64 + lane] = rc0[i] + rc1[i];
-    sig(&S.rp[w], uv + 1, lane);
-    mfma_sweep<12>(wa + 80, xb + 20 * 64, acc0, acc1);
-    st.mark(6);
+    mfma_sweep<16>(wa + 128, reinterpret_cast<const f32x4b*>(S.yl[buf]) + lane, acc0, acc1);
+    st.mark(5);
     sig(&S.done[w], uv + 1, lane);
-    if (!wait_min<1>(&S.bias_ready[w], uv + 1, a.err_flag)) return;
-    st.mark(7);
+    if (!wait_min<1>(&S.bias_ready[w], uv + 1, a.err_flag, 64 * 5 + stage)) return;
+    st.mark(6);
     float z[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) z[i] = (acc0[i] + acc1[i]) + S.biasT[buf][w][i * 64 + lane];
@@ -278,7 +296,7 @@ __device__ __forceinline__ void chain_role(const WnBpipeArgs& a, BpLds& S, int s
         for (int i = 0; i < 4; ++i) __hip_atomic_store(psn + 64 * i, kSpPoison, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
-    st.mark(8);
+    st.mark(7);
 #ifdef MMK_DIAG
     if (a.stamps && g == 0 && t + 1 == (int)a.n_steps && p == 0 && w == 0 && lane == 0) a.stamps[64 + 2 * stage + 1] = __builtin_amdgcn_s_memrealtime();      // ... and when y_s had been stored
 #endif
@@ -291,22 +309,27 @@ __device__ __forceinline__ void chain_role(const WnBpipeArgs& a, BpLds& S, int s
 // layer stage, waves 4-7
 // ------------------------------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void helper_role(const WnBpipeArgs& a, BpLds& S, int stage, int p, int h, int lane) {
-  float wb[128], wh[16];
+  float wb[128], wr[32], wh[16];
   {
     const float* cu = a.img + ((int64_t)stage * 8 + p) * kBpCuFloats;
-    const float* ib = cu + (4 * 128 + h * 128) * 64 + lane;
-    const float* ih = cu + (8 * 128 + 4 * 32 + h * 16) * 64 + lane;
+    const float* ib = cu + (4 * kBpChainRegs + h * 128) * 64 + lane;
+    const float* ir = cu + (4 * kBpChainRegs + 4 * 128 + h * 32) * 64 + lane;
+    const float* ih = cu + (4 * kBpChainRegs + 4 * 128 + 4 * 32 + h * 16) * 64 + lane;
 #pragma unroll
     for (int i = 0; i < 128; ++i) wb[i] = ib[i * 64];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) wr[i] = ir[i * 64];
 #pragma unroll
     for (int i = 0; i < 16; ++i) wh[i] = ih[i * 64];
 #pragma unroll
     for (int i = 0; i < 128; ++i) asm volatile("" : "+v"(wb[i]));
 #pragma unroll
+    for (int i = 0; i < 32; ++i) asm volatile("" : "+v"(wr[i]));
+#pragma unroll
     for (int i = 0; i < 16; ++i) asm volatile("" : "+v"(wh[i]));
   }
   float bz[4], br[4];
-  const int r2 = h & 1;
+  const int r2 = h & 1, kh = h >> 1;      // the residual tile (channels 32 p + 16 r2 ..) and K half of y this wave multiplies
   {
     const float* cst = a.cst + ((int64_t)stage * 8 + p) * kBpCstFloats;
 #pragma unroll
@@ -317,7 +340,8 @@ __device__ __forceinline__ void helper_role(const WnBpipeArgs& a, BpLds& S, int 
   }
   const int G = (a.B + kG - 1) / kG;
   const int n = lane & 15, q = lane >> 4;
-  const bool local_next = ((stage + 1) >> 2) == (stage >> 2);
+  const bool local_next = ((stage + 2) >> 2) == (stage >> 2);      // x_s: read by the next two stages
+  const bool local_hid = ((stage + 1) >> 2) == (stage >> 2);       // the hidden units' sum: by the next one
   const int64_t stage_words = (int64_t)((a.Bmax + kG - 1) / kG) * kSpSlots * kBpMsgWords;
   const unsigned* inbox = a.msg + (int64_t)stage * stage_words;
   unsigned* outbox = a.msg + (int64_t)(stage + 1) * stage_words;
@@ -329,48 +353,63 @@ __device__ __forceinline__ void helper_role(const WnBpipeArgs& a, BpLds& S, int 
   BpStamp st;
   st.on = a.stamps != nullptr && stage == a.stamp_stage && p == 0 && h == 0;
 
-  // everything of visit v1's z that does not depend on its message: W0 x_s[t - d] + Wc c[t] + b, tile h
-  auto make_bias = [&](int64_t v1, int t1, int g1) -> bool {
-    const unsigned u1 = (unsigned)v1;
-    if (v1 >= 1 && !wait_min<4>(S.bdone, u1, a.err_flag)) return false;      // the image's last readers
-    st.mark(3);
-    const int clip = kG * g1 + n;
-    if (d == 1 && t1 >= 1) {
-      // the stage's own message of the step before (x part, this wave's quarter), already in the image's layout
-      if (!gather(outbox + ((int64_t)g1 * kSpSlots + ((t1 - 1) & 3)) * kBpMsgWords + 1024 * h, S.tc + 1024 * h, lane, a.err_flag)) return false;
-    } else {
+  // everything of visit v1's z that does not depend on its message: W0 x_s[t - d] + Wc c[t] + b, tile h.  The rows are asked for (ask_rows: LDS-DMA, no
+  // registers) at the top of the visit before and waited for after its other work: a ring row a ring ago and a conditioning row come from HBM
+  auto ask_rows = [&](int64_t v1, int t1, int g1) {
+    float* img = S.tc[v1 & 1];
+    const int clip = min(kG * g1 + n, a.B - 1);      // (the lanes of clips that do not exist read the last one's rows: their columns are never stored)
+    if (!(d == 1 && t1 >= 1)) {
       const int64_t tp = a.t0 - 1 + t1 - d;
-      u32x4b r[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
-      // lane (n, q): clip n, channels 16 (4 h + jj) + 4 q .. + 3 for jj = 0 .. 3
-      if (tp >= 0 && clip < a.B) load4_ring(ring + (tp & ring_mask) * slot_stride + (int64_t)clip * kC + 64 * h + 4 * q, r[0], r[1], r[2], r[3]);
+      if (tp >= 0) {
+        // lane (q, n): clip n, channels 16 (4 h + jj) + 4 q .. + 3 - the k-step 4 (4 h + jj) + q of the image
+        const float* src = ring + (tp & ring_mask) * slot_stride + (int64_t)clip * kC + 64 * h + 4 * q;
 #pragma unroll
-      for (int jj = 0; jj < 4; ++jj)
+        for (int jj = 0; jj < 4; ++jj) glds16(src + 16 * jj, img + (4 * h + jj) * 256);
+      } else {      // in front of the sequence: zeros
 #pragma unroll
-        for (int e = 0; e < 4; ++e) S.tc[(((4 * h + jj) * 64) + e * 16 + n) * 4 + q] = __uint_as_float(r[jj][e]);
-    }
-    if (C1 > 0) {
-      const float* crow = a.cproj + ((int64_t)clip * a.cond_steps + t1) * C1;
-#pragma unroll
-      for (int jj = 0; jj < 4; ++jj) {
-        const int k = 16 * (4 * h + jj) + 4 * q;
-        f32x4b cv = {0.f, 0.f, 0.f, 0.f};
-        if (clip < a.B && k < C1) cv = *reinterpret_cast<const f32x4b*>(crow + k);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) S.tc[4096 + (((4 * h + jj) * 64) + e * 16 + n) * 4 + q] = cv[e];
+        for (int jj = 0; jj < 4; ++jj) *reinterpret_cast<f32x4b*>(img + (4 * h + jj) * 256 + 4 * lane) = f32x4b{0.f, 0.f, 0.f, 0.f};
       }
     }
+    if (C1 > 0) {
+      const float* crow = a.cproj + ((int64_t)clip * a.cond_steps + t1) * C1 + 64 * h + 4 * q;
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj)
+        if (64 * h + 16 * jj < C1) glds16(crow + 16 * jj, img + 4096 + (4 * h + jj) * 256);      // (C1 in whole 16s; the blocks above it stay zero)
+    }
+  };
+  auto make_bias = [&](int64_t v1, int t1, int g1) -> bool {
+    const unsigned u1 = (unsigned)v1;
+    float* img = S.tc[v1 & 1];
+    st.mark(3);
+    if (d == 1 && t1 >= 1) {
+      // the stage's own message of the step before (x part, this wave's quarter): 16-byte groups (channels 16 (4 h + j) + 4 q' + e for q' = 0 .. 3, clip n)
+      const unsigned* src = outbox + ((int64_t)g1 * kSpSlots + ((t1 - 1) & 3)) * kBpMsgWords + 1024 * h;
+      u32x4b r[4];
+      unsigned spins = 0;
+      for (;;) {
+        load4_sc1(src + 4 * lane, r[0], r[1], r[2], r[3]);
+        if (__all(clean(r[0]) && clean(r[1]) && clean(r[2]) && clean(r[3]))) break;
+        __builtin_amdgcn_s_sleep(2);
+        if (++spins > kSpin || ((spins & 1023u) == 0 && __hip_atomic_load(a.err_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+          atomicMax(a.err_flag, 0x10000 | (64 * 17 + stage));
+          return false;
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq) img[(16 * h + 4 * j + qq) * 64 + 4 * n + q] = __uint_as_float(r[j][qq]);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the rows asked for a visit ago
     st.mark(4);
     sig(&S.rows[h], u1 + 1, lane);
-    if (!wait_min<4>(S.rows, u1 + 1, a.err_flag)) return false;
+    if (!wait_min<4>(S.rows, u1 + 1, a.err_flag, 64 * 7 + stage)) return false;
     st.mark(5);
     f32x4b acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-    const f32x4b* tb = reinterpret_cast<const f32x4b*>(S.tc) + lane;
-    mfma_sweep<16>(wb, tb, acc0, acc1);
-    if (C1 > 0) {
-      mfma_sweep<16>(wb + 64, tb + 16 * 64, acc0, acc1);
-    }
-    sig(&S.bdone[h], u1 + 1, lane);
-    if (v1 >= 2 && !wait_min<1>(&S.bias_used[h], u1 - 1, a.err_flag)) return false;
+    const float* tb = img + 4 * n + q;
+    mfma_sweep_lin<64>(wb, tb, acc0, acc1);
+    if (C1 > 0) mfma_sweep_lin<64>(wb + 64, tb + 4096, acc0, acc1);
+    if (v1 >= 2 && !wait_min<1>(&S.bias_used[h], u1 - 1, a.err_flag, 64 * 8 + stage)) return false;
     st.mark(6);
 #pragma unroll
     for (int i = 0; i < 4; ++i) S.biasT[v1 & 1][h][i * 64 + lane] = (acc0[i] + acc1[i]) + bz[i];
@@ -378,6 +417,13 @@ __device__ __forceinline__ void helper_role(const WnBpipeArgs& a, BpLds& S, int 
     return true;
   };
 
+  // (conditioning blocks above C1 are never written: zero once)
+#pragma unroll
+  for (int jj = 0; jj < 4; ++jj) {
+    *reinterpret_cast<f32x4b*>(S.tc[0] + 4096 + (4 * h + jj) * 256 + 4 * lane) = f32x4b{0.f, 0.f, 0.f, 0.f};
+    *reinterpret_cast<f32x4b*>(S.tc[1] + 4096 + (4 * h + jj) * 256 + 4 * lane) = f32x4b{0.f, 0.f, 0.f, 0.f};
+  }
+  ask_rows(0, 0, 0);
   if (!make_bias(0, 0, 0)) return;
   int t = 0, g = 0;
   for (int64_t v = 0; v < V; ++v) {
@@ -385,31 +431,63 @@ __device__ __forceinline__ void helper_role(const WnBpipeArgs& a, BpLds& S, int 
     const unsigned uv = (unsigned)v;
     const int64_t tau = a.t0 - 1 + t;
     st.start();
-    if (!wait_min<4>(S.arr, uv + 1, a.err_flag)) return;
+    int t1 = t, g1 = g + 1;
+    if (g1 == G) { g1 = 0; ++t1; }
+    if (v + 1 < V) ask_rows(v + 1, t1, g1);
+    if (!wait_min<4>(S.arr, uv + 1, a.err_flag, 64 * 9 + stage)) return;
     st.mark(0);
-    const f32x4b* yb = reinterpret_cast<const f32x4b*>(S.xy[buf] + 4096) + lane;
-    // ---- x_s = x_{s-1} + R y_{s-1} + br (helpers 0, 1: residual tile h): the K halves come from chain waves h and h + 2 ------------------------
-    if (h < 2) {
-      if (!wait_min<1>(&S.rp[h], uv + 1, a.err_flag) || !wait_min<1>(&S.rp[h + 2], uv + 1, a.err_flag)) return;
-      float xs[4];
+    const f32x4b* yb = reinterpret_cast<const f32x4b*>(S.yl[buf]) + lane;
+    // ---- x_s = x_{s-1} + R y_{s-1} + br, off the chain (the next stage but one multiplies with it, a visit from now): residual tile r2, K half kh ----
+    {
+      f32x4b rc0 = {0.f, 0.f, 0.f, 0.f}, rc1 = {0.f, 0.f, 0.f, 0.f};
+      mfma_sweep<8>(wr, yb + 8 * kh * 64, rc0, rc1);
+      if (kh == 0) {      // (the second halves' waves publish: wave 4 has the hidden units' hand-over to do)
+        if (v >= 1 && !wait_min<1>(&S.rp_used[r2], uv, a.err_flag, 64 * 10 + stage)) return;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const float xprev = S.xy[buf][(((2 * p + r2) * 64) + i * 16 + n) * 4 + q];
-        xs[i] = xprev + ((S.rpart[h][i * 64 + lane] + S.rpart[h + 2][i * 64 + lane]) + br[i]);
-      }
-      sig(&S.rp_used[r2], uv + 1, lane);
-      unsigned* dx = outbox + ((int64_t)g * kSpSlots + slot) * kBpMsgWords;
-      unsigned* px = outbox + ((int64_t)g * kSpSlots + ((t + 2) & 3)) * kBpMsgWords;
+        for (int i = 0; i < 4; ++i) S.rpart[r2][i * 64 + lane] = rc0[i] + rc1[i];
+        sig(&S.rp[r2], uv + 1, lane);
+      } else {
+        // x_{s-1}: my 4 words per lane of the newest message's x part (published behind its y), looked at until they are there
+        const unsigned* src = inbox + ((int64_t)g * kSpSlots + slot) * kBpMsgWords;
+        float xprev[4];
+        unsigned spins = 0;
+        for (;;) {
+          unsigned wv[4];
+          bool ok = true;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int word = (((2 * p + r2) * 64) + i * 16 + n) * 4 + q;
-        msg_put(dx + word, bits_of(xs[i]), local_next);
-        msg_put(px + word, kSpPoison, local_next);
+          for (int i = 0; i < 4; ++i) {
+            wv[i] = __hip_atomic_load(src + (((2 * p + r2) * 64) + i * 16 + n) * 4 + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            ok = ok && wv[i] != kSpPoison;
+          }
+          if (__all(ok)) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) xprev[i] = __uint_as_float(wv[i]);
+            break;
+          }
+          __builtin_amdgcn_s_sleep(2);
+          if (++spins > kSpin || ((spins & 1023u) == 0 && __hip_atomic_load(a.err_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+            atomicCAS(a.err_flag, 0, 0x20000 | stage);
+            return;
+          }
+        }
+        if (!wait_min<1>(&S.rp[r2], uv + 1, a.err_flag, 64 * 11 + stage)) return;
+        float xs[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) xs[i] = xprev[i] + ((S.rpart[r2][i * 64 + lane] + (rc0[i] + rc1[i])) + br[i]);
+        sig(&S.rp_used[r2], uv + 1, lane);
+        unsigned* dx = outbox + ((int64_t)g * kSpSlots + slot) * kBpMsgWords;
+        unsigned* px = outbox + ((int64_t)g * kSpSlots + ((t + 2) & 3)) * kBpMsgWords;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int word = (((2 * p + r2) * 64) + i * 16 + n) * 4 + q;
+          msg_put(dx + word, bits_of(xs[i]), local_next);
+          msg_put(px + word, kSpPoison, local_next);
+        }
+        // the layer's input at tau into its ring (later taps; the launch path, should the batch be redone there)
+        const int clip = kG * g + n;
+        if (clip < a.B)
+          *reinterpret_cast<f32x4b*>(ring + (tau & ring_mask) * slot_stride + (int64_t)clip * kC + 32 * p + 16 * r2 + 4 * q) = f32x4b{xs[0], xs[1], xs[2], xs[3]};
       }
-      // the layer's input at tau into its ring (later taps; the launch path, should the batch be redone there)
-      const int clip = kG * g + n;
-      if (clip < a.B)
-        *reinterpret_cast<f32x4b*>(ring + (tau & ring_mask) * slot_stride + (int64_t)clip * kC + 32 * p + 16 * r2 + 4 * q) = f32x4b{xs[0], xs[1], xs[2], xs[3]};
     }
     st.mark(1);
     // ---- hid_s = hid_{s-1} + (fc0 W_skip_{s-1}) y_{s-1}: units 16 p .., K quarter h -------------------------------------------------------
@@ -425,12 +503,12 @@ __device__ __forceinline__ void helper_role(const WnBpipeArgs& a, BpLds& S, int 
       }
       sig(&S.done[4 + h], uv + 1, lane);
       if (h != 0) {
-        if (v >= 1 && !wait_min<1>(S.hp_used, uv, a.err_flag)) return;
+        if (v >= 1 && !wait_min<1>(S.hp_used, uv, a.err_flag, 64 * 12 + stage)) return;
 #pragma unroll
         for (int i = 0; i < 4; ++i) S.hpart[h][i * 64 + lane] = acc0[i] + acc1[i];
         sig(&S.hp[h], uv + 1, lane);
       } else {
-        if (!wait_min<3>(S.hp + 1, uv + 1, a.err_flag)) return;
+        if (!wait_min<3>(S.hp + 1, uv + 1, a.err_flag, 64 * 13 + stage)) return;
         float hs[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) hs[i] = ((acc0[i] + acc1[i]) + S.hpart[1][i * 64 + lane]) + (S.hpart[2][i * 64 + lane] + S.hpart[3][i * 64 + lane]);
@@ -453,7 +531,7 @@ __device__ __forceinline__ void helper_role(const WnBpipeArgs& a, BpLds& S, int 
             }
             __builtin_amdgcn_s_sleep(2);
             if (++spins > kSpin || ((spins & 1023u) == 0 && __hip_atomic_load(a.err_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
-              atomicExch(a.err_flag, 1);
+              atomicCAS(a.err_flag, 0, 0x20000 | stage);
               return;
             }
           }
@@ -463,14 +541,12 @@ __device__ __forceinline__ void helper_role(const WnBpipeArgs& a, BpLds& S, int 
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const int word = ((p * 64) + i * 16 + n) * 4 + q;
-          msg_put(dst + word, bits_of(hs[i]), local_next);
-          msg_put(psn + word, kSpPoison, local_next);
+          msg_put(dst + word, bits_of(hs[i]), local_hid);
+          msg_put(psn + word, kSpPoison, local_hid);
         }
       }
     }
     st.mark(2);
-    int t1 = t, g1 = g + 1;
-    if (g1 == G) { g1 = 0; ++t1; }
     if (v + 1 < V && !make_bias(v + 1, t1, g1)) return;
     st.mark(7);
     t = t1; g = g1;
@@ -565,7 +641,7 @@ __device__ __forceinline__ void head_role(const WnBpipeArgs& a, unsigned char* l
           if (__all(clean(r[0]) && clean(r[1]) && clean(r[2]))) break;
           __builtin_amdgcn_s_sleep(2);
           if (++spins > kSpin || ((spins & 1023u) == 0 && __hip_atomic_load(a.err_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
-            atomicExch(a.err_flag, 1);
+            atomicCAS(a.err_flag, 0, 0x20000 | a.L);
             *s_fail = 1;
             break;
           }
@@ -700,19 +776,28 @@ __global__ __launch_bounds__(256) void bpipe_image_kernel(const WnSpRaw* __restr
       const WnSpRaw rw = raw[s];
       const bool below = s >= 1 && raw[s - 1].wr != nullptr;
       float out = 0.f;
-      if (reg < 512) {                       // gate tile w x [x_{s-1} | y_{s-1}]
-        const int w = reg >> 7, k = 4 * (reg & 127) + q, nrow = gate_row(p, w, m);
-        if (k < kC) out = rw.wd[((int64_t)nrow * kC + k) * 2 + 1];                                                                // W1[n][k]
-        else if (below) out = (float)dot_strided(rw.wd + (int64_t)nrow * kC * 2 + 1, 2, raw[s - 1].wr + (k - kC), kC, kC);         // (W1 R)[n][k]
-      } else if (reg < 1024) {               // gate tile h x [x_s[t - d] | c[t]]
-        const int h = (reg - 512) >> 7, k = 4 * ((reg - 512) & 127) + q, nrow = gate_row(p, h, m);
+      const bool below2 = s >= 2 && raw[s - 2].wr != nullptr;
+      constexpr int kCh = 4 * kBpChainRegs;
+      if (reg < kCh) {                       // gate tile w x [x_{s-2} | y_{s-2} | y_{s-1}] (stage 0: the last third x the embedded class)
+        const int w = reg / kBpChainRegs, kk = reg % kBpChainRegs, part = kk >> 6, k = 4 * (kk & 63) + q, nrow = gate_row(p, w, m);
+        const float* w1row = rw.wd + (int64_t)nrow * kC * 2 + 1;      // W1[n][.]: stride 2
+        if (part == 0) {
+          if (s >= 1) out = w1row[2 * k];                                                                                        // W1[n][k]
+        } else if (part == 1) {
+          if (below2) out = (float)dot_strided(w1row, 2, raw[s - 2].wr + k, kC, kC);                                           // (W1 R_{s-2})[n][k]
+        } else {
+          if (s == 0) out = w1row[2 * k];
+          else if (below) out = (float)dot_strided(w1row, 2, raw[s - 1].wr + k, kC, kC);                                       // (W1 R_{s-1})[n][k]
+        }
+      } else if (reg < kCh + 512) {          // gate tile h x [x_s[t - d] | c[t]]
+        const int h = (reg - kCh) >> 7, k = 4 * ((reg - kCh) & 127) + q, nrow = gate_row(p, h, m);
         if (k < kC) out = rw.wd[((int64_t)nrow * kC + k) * 2 + 0];                                                                // W0[n][k]
         else if (rw.w1 && k - kC < C1) out = rw.w1[(int64_t)nrow * C1 + (k - kC)];
-      } else if (reg < 1024 + 128) {         // residual tile r2, K half kh of y
-        const int h = (reg - 1024) >> 5, kk = (reg - 1024) & 31, r2 = h & 1, kh = h >> 1;
+      } else if (reg < kCh + 512 + 128) {    // residual tile r2, K half kh of y
+        const int h = (reg - kCh - 512) >> 5, kk = (reg - kCh - 512) & 31, r2 = h & 1, kh = h >> 1;
         if (below) out = raw[s - 1].wr[(int64_t)(32 * p + 16 * r2 + m) * kC + 128 * kh + 4 * kk + q];
       } else {                               // hidden units 16 p .., K quarter h of y
-        const int h = (reg - 1152) >> 4, kk = (reg - 1152) & 15;
+        const int h = (reg - kCh - 640) >> 4, kk = (reg - kCh - 640) & 15;
         if (s >= 1) out = (float)dot_strided(f0 + (int64_t)(16 * p + m) * kC, 1, raw[s - 1].ws + 64 * h + 4 * kk + q, kC, kC);    // (fc0 W_skip)[u][k]
       }
       img[id] = out;
@@ -727,6 +812,7 @@ __global__ __launch_bounds__(256) void bpipe_image_kernel(const WnSpRaw* __restr
         const int nrow = gate_row(p, tile, 4 * q + i);
         out = (rw.bd ? rw.bd[nrow] : 0.f) + (rw.b1 ? rw.b1[nrow] : 0.f);
         if (below && raw[s - 1].br) out += (float)dot_strided(rw.wd + (int64_t)nrow * kC * 2 + 1, 2, raw[s - 1].br, 1, kC);
+        if (s >= 2 && raw[s - 2].wr && raw[s - 2].br) out += (float)dot_strided(rw.wd + (int64_t)nrow * kC * 2 + 1, 2, raw[s - 2].br, 1, kC);      // x_{s-1} = x_{s-2} + R y + br
       } else if (below && raw[s - 1].br) {
         out = raw[s - 1].br[32 * p + 16 * (tile - 4) + 4 * q + i];
       }

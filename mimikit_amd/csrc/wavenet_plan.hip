@@ -21,9 +21,10 @@
 
 using namespace mmk;
 
-// clips from which the stage pipeline's networks run in groups of 16 on the matrix pipe (wavenet_bpipe.hip): beyond one ring of the one-clip form.
-// Measured on cfg 4, us per step: 128 clips 153 against the ring's 136; 144 clips 2 x 72 through the ring ~ 156 against 154; 256 clips 155 against 272
-constexpr int kBpipeMinClips = 129;
+// clips from which the stage pipeline's networks run in groups of 16 on the matrix pipe (wavenet_bpipe.hip).  Measured on cfg 4, us per step: a group's trip
+// is 109 whatever the batch up to ~10 groups (128 clips 109 against the one-clip ring's 136, 256 clips 153 against 272 as two passes); the ring's beat is
+// 1.06 per clip: 104 clips are where the two meet
+constexpr int kBpipeMinClips = 105;
 
 struct WnCall {
   int M = 0;
@@ -485,7 +486,7 @@ static int derive(mmk_wavenet_plan* p) {
     // (the classes the network is fed are the ones it draws, and the first one - the prompt's last sample - is clamped to the head's 256)
     ok5 = ok5 && n_xcc == 8 && n_cu == 256 && c.q_levels <= 256 && c.out_dim <= c.q_levels;
     // Groups of 16 clips on the matrix pipe (wavenet_bpipe.hip) where the one-clip ring is beat-bound: a group's step is a trip of L + 1 visits of
-    // ~4.9 us whatever the batch (up to 16 groups; 32 groups are beat-bound at ~8 us per visit), the ring's is ~1.1 us per clip.  MMK_WN_BPIPE=0 turns it off, =1 takes it for any batch.
+    // ~3.5 us whatever the batch (up to ~10 groups; beyond, a stage's ~9.5 us per visit is the beat), the ring's is ~1.1 us per clip.  MMK_WN_BPIPE=0 turns it off, =1 takes it for any batch.
     const char* benv = p->tune.get("MMK_WN_BPIPE");
     bool ok6 = ok5 && !(benv && benv[0] == '0') && wn_bpipe_supported(p->C, p->S, c.mlp_hidden, c.out_dim, p->L, c.n_cond, cond_total, p->Bmax);
     ok6 = ok6 && ((benv && benv[0] == '1') || (p->Bmax >= kBpipeMinClips && p->L >= 16));
@@ -1513,8 +1514,8 @@ extern "C" int mmk_wavenet_sync_status(mmk_wavenet_plan* p, mmk_stream_t stream)
   if (flag == 2)
     return fail(MMK_ERR_STATE, "wavenet: the persistent kernel's workgroups were not spread 8 x %d over the XCDs; rerun with MMK_WN_XCD_LOCAL=0 (agent-scope hand-offs)", p->Gn);
   if (flag != 0)
-    return fail(MMK_ERR_STATE, "wavenet: a hand-off inside the persistent kernel timed out - its workgroups were not all resident (another kernel "
-                "holding CUs?); the samples of this call are invalid, rerun it (MMK_WN_PERSISTENT=0 selects the per-layer launch path)");
+    return fail(MMK_ERR_STATE, "wavenet: a hand-off inside the persistent kernel timed out (error word 0x%x) - its workgroups were not all resident (another kernel "
+                "holding CUs?); the samples of this call are invalid, rerun it (MMK_WN_PERSISTENT=0 selects the per-layer launch path)", (unsigned)flag);
   {
     const char* senv = diag_only("MMK_WN_STAMPS");
     if (senv && senv[0] == '1') {

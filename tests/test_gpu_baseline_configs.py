@@ -200,8 +200,8 @@ def test_cfg4_wavenet_64_clips_in_one_ring(device):
 
 def test_cfg4_wavenet_128_clips_in_one_ring(device):
     """R = 2: 128 clips per GPU, the most one ring takes (the bias image of a stage CU is 64 KB of its LDS then); the one-clip ring by name
-    (beyond it the plan takes groups of 16 clips on the matrix pipe: the tests below)"""
-    _cfg4_greedy_against_oracle(device, B=128, n=600, n_last=1, n_mid=12, seed=4128, expect_set=False)
+    (by name: from 105 clips on the plan takes groups of 16 clips on the matrix pipe - the tests below)"""
+    _cfg4_greedy_against_oracle(device, B=128, n=600, n_last=1, n_mid=12, seed=4128, expect_set=False, tuning={"MMK_WN_BPIPE": "0"})
 
 
 def test_cfg4_wavenet_more_clips_than_one_ring(device):
@@ -214,6 +214,11 @@ def test_cfg4_wavenet_256_clips_in_groups_of_16(device):
     """SURVEY 8(e) at R = 1: the whole 256-clip job on one GPU.  The plan takes the stage pipeline's large-batch form (wavenet_bpipe.hip: 16 groups
     of 16 clips, a visit is a set of 16x16x4 matrix products): 1030 free-running steps across a launch boundary, against the oracle"""
     _cfg4_greedy_against_oracle(device, B=256, n=1030, n_last=1, n_mid=10, seed=4256, expect_set=False, expect_batched=True)
+
+
+def test_cfg4_wavenet_128_clips_in_groups_of_16(device):
+    """R = 2 of the 256-clip job: 128 clips per GPU as eight groups of 16 (the plan's default from 105 clips on)"""
+    _cfg4_greedy_against_oracle(device, B=128, n=1030, n_last=1, n_mid=8, seed=41280, expect_set=False, expect_batched=True)
 
 
 def test_cfg4_wavenet_ragged_groups_of_16(device):
