@@ -49,6 +49,9 @@ constexpr int kThreads = 512;
 constexpr int kG = kBpGroup;
 constexpr unsigned kSpin = 1u << 22;
 constexpr int kLgStride = 260;
+#ifndef MMK_BP_ABL
+#define MMK_BP_ABL 0      // timing experiments (results wrong): 1 no known-term products, 2 no hidden-unit products, 4 no early products, 8 no early gather either, 16 no residual products
+#endif
 #ifndef MMK_BP_CHAIN_PRIO
 #define MMK_BP_CHAIN_PRIO 2
 #endif
@@ -243,12 +246,14 @@ __device__ __forceinline__ void chain_role(const WnBpipeArgs& a, BpLds& S, int s
     if (stage >= 1) {
       const unsigned* em = below + ((int64_t)g * kSpSlots + slot) * kBpMsgWords;
       if (v >= 1 && !wait_min<4>(S.edone, uv, a.err_flag, 64 * 1 + stage)) return;
-      if (!gather(em + 1024 * w, S.ye + 1024 * w, lane, a.err_flag, 64 * 14 + stage)) return;
-      if (!gather(em + 4096 + 1024 * w, S.ye + 4096 + 1024 * w, lane, a.err_flag, 64 * 15 + stage)) return;
+      if (!(MMK_BP_ABL & 8)) {
+        if (!gather(em + 1024 * w, S.ye + 1024 * w, lane, a.err_flag, 64 * 14 + stage)) return;
+        if (!gather(em + 4096 + 1024 * w, S.ye + 4096 + 1024 * w, lane, a.err_flag, 64 * 15 + stage)) return;
+      }
       sig(&S.earr[w], uv + 1, lane);
       if (!wait_min<4>(S.earr, uv + 1, a.err_flag, 64 * 2 + stage)) return;
       st.mark(0);
-      mfma_sweep<32>(wa, reinterpret_cast<const f32x4b*>(S.ye) + lane, acc0, acc1);
+      if (!(MMK_BP_ABL & 12)) mfma_sweep<32>(wa, reinterpret_cast<const f32x4b*>(S.ye) + lane, acc0, acc1);
       sig(&S.edone[w], uv + 1, lane);
       st.mark(1);
     }
@@ -407,8 +412,10 @@ __device__ __forceinline__ void helper_role(const WnBpipeArgs& a, BpLds& S, int 
     st.mark(5);
     f32x4b acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
     const float* tb = img + 4 * n + q;
-    mfma_sweep_lin<64>(wb, tb, acc0, acc1);
-    if (C1 > 0) mfma_sweep_lin<64>(wb + 64, tb + 4096, acc0, acc1);
+    if (!(MMK_BP_ABL & 1)) {
+      mfma_sweep_lin<64>(wb, tb, acc0, acc1);
+      if (C1 > 0) mfma_sweep_lin<64>(wb + 64, tb + 4096, acc0, acc1);
+    }
     if (v1 >= 2 && !wait_min<1>(&S.bias_used[h], u1 - 1, a.err_flag, 64 * 8 + stage)) return false;
     st.mark(6);
 #pragma unroll
@@ -440,7 +447,7 @@ __device__ __forceinline__ void helper_role(const WnBpipeArgs& a, BpLds& S, int 
     // ---- x_s = x_{s-1} + R y_{s-1} + br, off the chain (the next stage but one multiplies with it, a visit from now): residual tile r2, K half kh ----
     {
       f32x4b rc0 = {0.f, 0.f, 0.f, 0.f}, rc1 = {0.f, 0.f, 0.f, 0.f};
-      mfma_sweep<8>(wr, yb + 8 * kh * 64, rc0, rc1);
+      if (!(MMK_BP_ABL & 16)) mfma_sweep<8>(wr, yb + 8 * kh * 64, rc0, rc1);
       if (kh == 0) {      // (the second halves' waves publish: wave 4 has the hidden units' hand-over to do)
         if (v >= 1 && !wait_min<1>(&S.rp_used[r2], uv, a.err_flag, 64 * 10 + stage)) return;
 #pragma unroll
@@ -494,7 +501,7 @@ __device__ __forceinline__ void helper_role(const WnBpipeArgs& a, BpLds& S, int 
     {
       f32x4b acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int k4 = 0; k4 < 4; ++k4) {
+      for (int k4 = 0; k4 < ((MMK_BP_ABL & 2) ? 0 : 4); ++k4) {
         const f32x4b b = yb[(4 * h + k4) * 64];
         acc0 = mfma4(wh[4 * k4 + 0], b[0], acc0);
         acc1 = mfma4(wh[4 * k4 + 1], b[1], acc1);
