@@ -1,6 +1,6 @@
 // WaveNet generation as a PIPELINE OF WORKGROUPS THAT OWN WHOLE LAYERS (gfx950) - for networks small enough that a layer's matrices
 // fit a fraction of a CU's registers: C = S = 64 channels, kernel 2, gated, MLP head 64 -> 128 -> 256 (+ temperature)
-// (BASELINE config 2: ten layers, dilations 1 .. 512, 8 clips), with or without one conditioning input - whose products conv_1x1(c)
+// (BASELINE config 2: ten layers, dilations 1 .. 512, 8 clips), with up to two conditioning inputs - whose products sum_j conv_1x1_j(c_j)
 // (wavenet_v2.py:141-147) the plan forms for a block of positions ahead of the launch, as for the other persistent kernels: a thread reads
 // its gate row's term with the delayed taps, off the step's chain.
 //
@@ -365,7 +365,7 @@ void wn_lpipe_split(int L, int32_t (&first)[kLpStages + 1]) {
 
 bool wn_lpipe_supported(int C, int S, int H1, int n_classes, int L, int n_cond, int batch) {
   // (a head of fewer hidden units or classes runs as the 128 x 256 one: the plan pads its matrices - zero rows / columns, -inf bias for classes that do not exist)
-  return C == kC && S == kC && H1 >= 16 && H1 <= kH1 && H1 % 16 == 0 && n_classes >= 2 && n_classes <= kQ && n_cond <= 1 && L >= kLpStages && L <= kLpMaxLayers &&
+  return C == kC && S == kC && H1 >= 16 && H1 <= kH1 && H1 % 16 == 0 && n_classes >= 2 && n_classes <= kQ && n_cond <= 2 && L >= kLpStages && L <= kLpMaxLayers &&
          batch >= 1 && batch <= 64;
 }
 

@@ -398,7 +398,8 @@ static int derive(mmk_wavenet_plan* p) {
   for (int l = 0; l < p->L; ++l) ok = ok && p->ksz[l] == 2;
   // (the stage pipeline takes any head of up to 128 hidden units and two conditioning inputs; the other persistent kernels whole tiles of 16 and one)
   const bool ok_sp = ok && c.mlp_hidden >= 1;
-  ok = ok && c.mlp_hidden % 16 == 0 && c.mlp_hidden >= 16 && c.n_cond <= 1;
+  // (two conditioning inputs: the layer pipeline only - their projections side by side in a row, the 1x1 matrices side by side in the GEMM's K; decided below)
+  ok = ok && c.mlp_hidden % 16 == 0 && c.mlp_hidden >= 16 && (c.n_cond <= 1 || (c.n_cond == 2 && p->C == 64));
   p->persistent = false;
   // The persistent kernels need every workgroup of their grid resident at once (one per CU: their LDS carve does not leave room
   // for a second), and the XCD-local / pipelined placements one stage or clip group per XCD of an 8-XCD device: ask the device
@@ -445,7 +446,8 @@ static int derive(mmk_wavenet_plan* p) {
       p->Gc = 8;
       p->Mg = (p->Bmax + 7) / 8;
     }
-    p->C1 = c.n_cond == 1 ? c.cond_dim[0] : 0;
+    p->C1 = 0;
+    for (int j = 0; j < c.n_cond; ++j) p->C1 += c.cond_dim[j];
     p->n_logits_pad = (int)round_up(c.out_dim + (c.learn_temp ? 1 : 0), 16);
     if (p->Mg <= mg_cap && p->Gc * p->Gn <= n_cu) {
       p->persistent = true;
@@ -539,6 +541,11 @@ static int derive(mmk_wavenet_plan* p) {
     ok4 = ok4 && wn_lpipe_supported(p->C, p->S, c.mlp_hidden, c.out_dim, p->L, c.n_cond, p->Bmax);
     for (int l = 0; l + 1 < p->L; ++l) ok4 = ok4 && p->has_res[l];
     p->lpipe = ok4;
+  }
+  if (p->persistent && !p->spipe && !p->lpipe && c.n_cond > 1) {      // two inputs without the layer pipeline: the launch path
+    p->persistent = false;
+    p->chain = false;
+    p->Ac.clear();
   }
   return MMK_OK;
 }
@@ -677,9 +684,11 @@ extern "C" int mmk_wavenet_commit(mmk_wavenet_plan* p, void* workspace, size_t w
         if (c.gated) {
           MMK_TRY(pack_rect(A.Wp, A.k_chunks, 0, 2, C, A.seg_chunk0[k + j], cd, w1, cd, 1, st));
           MMK_TRY(pack_rect(A.Wp, A.k_chunks, 1, 2, C, A.seg_chunk0[k + j], cd, w1 + (int64_t)C * cd, cd, 1, st));
-          if (p->persistent && p->C1 > 0 && !p->spipe) {   // same gate-interleaved rows, all layers stacked (bias stays in A.bias)
-            MMK_TRY(pack_rect(p->cond_all.Wp, p->cond_all.k_chunks, l * 2 * C, 2, C, 0, cd, w1, cd, 1, st));
-            MMK_TRY(pack_rect(p->cond_all.Wp, p->cond_all.k_chunks, l * 2 * C + 1, 2, C, 0, cd, w1 + (int64_t)C * cd, cd, 1, st));
+          if (p->persistent && p->C1 > 0 && !p->spipe) {   // same gate-interleaved rows, all layers stacked (bias stays in A.bias); input j's columns behind input j - 1's
+            int kc0 = 0;
+            for (int jj = 0; jj < j; ++jj) kc0 += c.cond_dim[jj] / 16;
+            MMK_TRY(pack_rect(p->cond_all.Wp, p->cond_all.k_chunks, l * 2 * C, 2, C, kc0, cd, w1, cd, 1, st));
+            MMK_TRY(pack_rect(p->cond_all.Wp, p->cond_all.k_chunks, l * 2 * C + 1, 2, C, kc0, cd, w1 + (int64_t)C * cd, cd, 1, st));
           }
         } else {
           MMK_TRY(pack_rect(A.Wp, A.k_chunks, 0, 1, C, A.seg_chunk0[k + j], cd, w1, cd, 1, st));

@@ -1107,12 +1107,14 @@ def test_wavenet_layer_pipeline_agrees_with_oracle(device, monkeypatch, blocks, 
 
 
 def _small_cond_net(blocks, cond_dim, seed):
-    """_small_net with one conditioning input (a LinearIO on spectrogram-like frames, a 1x1 convolution of it in every layer)"""
+    """_small_net with one conditioning input - or two (cond_dim a tuple) - (a LinearIO on spectrogram-like frames, a 1x1 convolution of it in every layer)"""
     from oracle.weights import load_recipe
+    dims = cond_dim if isinstance(cond_dim, tuple) else (cond_dim,)
     io = H.mu_emb(mlp_dim=128)
     ext = mmk.Extractor("signal", mmk.FileToSignal(16000))
-    io = mmk.IOSpec(inputs=(io.inputs[0], mmk.InputSpec("signal", mmk.MagSpec(22, 4, center=False), mmk.LinearIO()).bind_to(ext)), targets=io.targets)
-    net = mmk.WaveNet.from_config(mmk.WaveNet.Config(io_spec=io, blocks=blocks, dims_dilated=(64,), dims_1x1=(cond_dim,), residuals_dim=64,
+    extra = tuple(mmk.InputSpec("signal", mmk.MagSpec(22, 4, center=False), mmk.LinearIO()).bind_to(ext) for _ in dims)
+    io = mmk.IOSpec(inputs=(io.inputs[0], *extra), targets=io.targets)
+    net = mmk.WaveNet.from_config(mmk.WaveNet.Config(io_spec=io, blocks=blocks, dims_dilated=(64,), dims_1x1=dims, residuals_dim=64,
                                                      skips_dim=64)).eval()
     sd = load_recipe(net, seed=seed, gain=2.0)
     dil = [2 ** i for b in blocks for i in range(b)]
@@ -1120,28 +1122,31 @@ def _small_cond_net(blocks, cond_dim, seed):
     return net, sd, arch
 
 
-@pytest.mark.parametrize("blocks,B,cond_dim", [((10,), 8, 64), ((4, 3), 13, 16), ((4,), 33, 48)])
+@pytest.mark.parametrize("blocks,B,cond_dim", [((10,), 8, 64), ((4, 3), 13, 16), ((4,), 33, 48), ((5, 2), 9, (32, 16)), ((4,), 20, (16, 48))])
 def test_wavenet_layer_pipeline_with_conditioning(device, monkeypatch, blocks, B, cond_dim):
     """the layer pipeline on CONDITIONED 64-channel networks (the FreqNet kind: demos/freqnet.py:47-63): every layer's conv_1x1(c) comes from the
     plan's block GEMM, a thread adds its gate row's term with the delayed taps.  Two generate blocks that straddle nothing and a third call past
     the first conditioning block's positions are not needed to cover the indexing - the block is 1024 positions - so one net generates 1100 steps
-    against the device's own history through the oracle (teacher-forced), the others 45 steps free-running; greedy + sampled"""
+    against the device's own history through the oracle (teacher-forced), the others 45 steps free-running; greedy + sampled.  Two conditioning
+    inputs (wavenet_v2.py:141-147: their 1x1 products are summed): projections side by side in a row, matrices side by side in the GEMM's K"""
     for k in ("MMK_WN_XCD_LOCAL", "MMK_WN_PERSISTENT", "MMK_WN_GROUPS", "MMK_WN_SMALL", "MMK_WN_PREFILL", "MMK_WN_CHAIN", "MMK_WN_LPIPE"):
         monkeypatch.delitem(mmk.native.PLAN_TUNING, k, raising=False)
     net, sd, arch = _small_cond_net(blocks, cond_dim, seed=70 + len(blocks))
     net = net.to(device)
+    n_in = len(cond_dim) if isinstance(cond_dim, tuple) else 1
     gen = torch.Generator().manual_seed(41 + B)
     rf = net.rf
     n = 1100 if blocks == (4,) else 45                 # (rf 16: 1100 steps cross the 1024-position conditioning block cheaply)
     prompt = torch.randint(0, 256, (B, rf + 6), generator=gen)
-    cond = torch.rand(B, rf + 6 + n, 12, generator=gen)
+    conds = tuple(torch.rand(B, rf + 6 + n, 12, generator=gen) for _ in range(n_in))
+    conds_d = tuple(c.to(device) for c in conds)
     idx = torch.cat([prompt, torch.zeros(B, n, dtype=torch.int64)], 1).to(device)
-    net.generate_block((idx, cond.to(device)), prompt.size(1), 20)
-    net.generate_block((idx, cond.to(device)), prompt.size(1) + 20, n - 20)
+    net.generate_block((idx, *conds_d), prompt.size(1), 20)
+    net.generate_block((idx, *conds_d), prompt.size(1) + 20, n - 20)
     assert net._plan.layer_pipelined
     net.after_generate((idx,), None)
     got = idx.cpu()
-    want, raw = O.wavenet_generate(sd, prompt, (cond,), n, keep_logits=True, forced=got, **arch)
+    want, raw = O.wavenet_generate(sd, prompt, conds, n, keep_logits=True, forced=got, **arch)
     ok = H.margin_ok(raw.numpy())
     assert float(ok.float().mean()) > 0.9
     assert torch.equal(want[:, prompt.size(1):][ok], got[:, prompt.size(1):][ok])
@@ -1150,10 +1155,10 @@ def test_wavenet_layer_pipeline_with_conditioning(device, monkeypatch, blocks, B
     u = torch.rand((B, 45), device=device)
     torch.manual_seed(6)
     idx2 = torch.cat([prompt, torch.zeros(B, 45, dtype=torch.int64)], 1).to(device)
-    net.generate_block((idx2, cond[:, :rf + 6 + 45].to(device)), prompt.size(1), 45, temperature=temp)
+    net.generate_block((idx2, *(c[:, :rf + 6 + 45] for c in conds_d)), prompt.size(1), 45, temperature=temp)
     net.after_generate((idx2,), None)
     got2 = idx2.cpu()
-    _, raw2 = O.wavenet_generate(sd, prompt, (cond[:, :rf + 6 + 45],), 45, keep_logits=True, forced=got2, **arch)
+    _, raw2 = O.wavenet_generate(sd, prompt, tuple(c[:, :rf + 6 + 45] for c in conds), 45, keep_logits=True, forced=got2, **arch)
     okp, exact = H.sampled_picks_ok(raw2, temp, u.cpu(), got2[:, prompt.size(1):])
     assert bool(okp.all()) and float(exact.float().mean()) > 0.97
 

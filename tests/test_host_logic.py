@@ -486,7 +486,9 @@ def test_flagship_step_kernels_are_not_cut_to_the_baseline_head():
     assert _wavenet_plan_mode(64, 10, 8, 64, 128) == LPIPE                                # a narrower head in whole tiles of 16
     assert _wavenet_plan_mode(64, 10, 8, 40, 128) != LPIPE
     assert _wavenet_plan_mode(64, 10, 8, 128, 256, (16,)) == LPIPE                        # one conditioning input: its products come from the plan's GEMM
-    assert _wavenet_plan_mode(64, 10, 8, 128, 256, (16, 16)) != LPIPE                     # two
+    assert _wavenet_plan_mode(64, 10, 8, 128, 256, (16, 32)) == LPIPE                     # two: side by side
+    assert _wavenet_plan_mode(64, 10, 8, 128, 256, (16, 32), b"MMK_WN_LPIPE=0") == 0      # ... which only the layer pipeline takes: else the launch path
+    assert _wavenet_plan_mode(128, 10, 8, 128, 256, (16, 32)) == 0
 
 
 def test_several_inputs_and_targets_are_described_or_refused_by_name():
