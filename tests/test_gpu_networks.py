@@ -1347,11 +1347,12 @@ def test_wavenet_stage_pipeline_agrees_with_oracle(device, monkeypatch, blocks, 
 
 @pytest.mark.parametrize("blocks,B,cond,n", [((3,), 1, False, 40), ((4, 2), 5, True, 60), ((1,), 3, True, 24), ((2, 1, 1), 40, True, 30),
                                              ((10, 10, 10, 1), 20, False, 6), ((5, 3), 17, True, 1100), ((6,), 70, True, 12), ((2,), 150, False, 20),
-                                             ((1, 1), 16, True, 33), ((4, 4, 3), 33, False, 50)])
+                                             ((1, 1), 16, True, 33), ((4, 4, 3), 33, False, 50), ((2,), 530, False, 6)])
 def test_wavenet_batch_pipeline_agrees_with_oracle(device, monkeypatch, blocks, B, cond, n):
     """the stage pipeline's large-batch form (wavenet_bpipe.hip: the clips travel in groups of 16, a visit is a set of 16x16x4 matrix products)
     against the oracle, as above: 1 - 31 layers, 1 - 10 groups with ragged last groups (1, 5, 3, 8, 4, 1, 6 clips), exactly one group, with and
-    without conditioning, two launches chained through the rings; greedy, sampled, twice bit-identical"""
+    without conditioning, two launches chained through the rings, more clips than one launch takes (530: two plans of 265, `native.WaveNetPlanSet`);
+    greedy, sampled, twice bit-identical"""
     _stage_pipeline_against_oracle(device, monkeypatch, blocks, B, cond, n, batched=True)
 
 
