@@ -17,7 +17,7 @@ from oracle.weights import load_recipe  # noqa: E402
 
 torch.set_grad_enabled(False)
 dev = torch.device("cuda", 0)
-rng = random.Random(23)
+rng = random.Random(int(os.environ.get("FUZZ_SEED", "23")))
 mmk.native.PLAN_TUNING["MMK_WN_SPIPE"] = "1"
 mmk.native.PLAN_TUNING["MMK_WN_BPIPE"] = "1"
 bad = 0
@@ -28,7 +28,7 @@ for case in range(int(sys.argv[1]) if len(sys.argv) > 1 else 16):
         b = rng.randint(1, min(left, 5))
         blocks.append(b)
         left -= b
-    B = rng.choice([1, 3, 15, 16, 17, 33, 48, 70, 90])
+    B = rng.choice([1, 3, 15, 16, 17, 33, 48, 70, 90, 150, 260, 300])
     cond_dims = rng.choice([(), (), (16,), (48,), (32, 16)])
     q, mlp_dim = rng.choice([(256, 128), (256, 128), (128, 64), (200, 100)])
     io = H.mu_emb(mlp_dim=mlp_dim, q_levels=q)
