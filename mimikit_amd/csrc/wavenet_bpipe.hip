@@ -115,20 +115,10 @@ __device__ __forceinline__ void load4_sc1(const unsigned* p, u32x4b& r0, u32x4b&
       : "v"(p)
       : "memory");
 }
-__device__ __forceinline__ void load1_sc1(const unsigned* p, u32x4b& r0) {
-  asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(r0) : "v"(p) : "memory");
-}
-// four 16-byte loads past the L1, 64 B apart (a lane's part of a ring row)
-__device__ __forceinline__ void load4_ring(const float* p, u32x4b& r0, u32x4b& r1, u32x4b& r2, u32x4b& r3) {
-  asm volatile(
-      "global_load_dwordx4 %0, %4, off sc1\n\tglobal_load_dwordx4 %1, %4, off offset:64 sc1\n\tglobal_load_dwordx4 %2, %4, off offset:128 sc1\n\t"
-      "global_load_dwordx4 %3, %4, off offset:192 sc1\n\ts_waitcnt vmcnt(0)"
-      : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3)
-      : "v"(p)
-      : "memory");
-}
-
-// diagnostic build: time (10 ns ticks) spent in the phases of a visit, totals per launch
+// diagnostic build: time (10 ns ticks) spent in the phases of a visit, totals per launch (mmk_wavenet_sync_status prints them).  Chain wave 0 of the stamped
+// stage's CU 0: [0] early operands seen and staged (incl. the wait), [1] early products issued, [2] image free, [3] y_{s-1} seen and staged (incl. the wait), [4] all
+// quarters, [5] products issued, [6] known terms there, [7] gate + stores.  Helper wave 4: [0] y_{s-1} staged, [1] residual tile + x_s stored, [2] hidden units + handed on,
+// [3] the rows' wait, [4] rows in the image, [5] all rows, [6] products + tile free, [7] tile written
 struct BpStamp {
 #ifdef MMK_DIAG
   u64 acc[16] = {}, last = 0;
