@@ -1402,6 +1402,17 @@ def _stage_pipeline_against_oracle(device, monkeypatch, blocks, B, cond, n, batc
     _, raw2 = O.wavenet_generate(sd, prompt, conds, n, keep_logits=True, forced=got2, **arch)
     okp, exact = H.sampled_picks_ok(raw2, temp, u.cpu(), got2[:, P:])
     assert bool(okp.all()) and float(exact.float().mean()) > 0.97
+    # a hand-off time-out reported by the kernel (injected): the batch is redone on the launch path from the same rings
+    idx = torch.cat([prompt, torch.zeros(B, n, dtype=torch.int64)], 1).to(device)
+    net.generate_block((idx, *conds_d), P, n)
+    assert net._plan.batch_pipelined == batched
+    net._plan.inject_sync_error()
+    with pytest.warns(UserWarning, match="launch path"):
+        net.after_generate((idx,), None)
+    redone = idx.cpu()
+    _, raw3 = O.wavenet_generate(sd, prompt, conds, n, keep_logits=True, forced=redone, **arch)
+    ok3 = H.margin_ok(raw3.numpy())
+    assert bool(((O.categorical(O.mlp_logits(raw3)) == redone[:, P:]) | ~ok3).all())
 
 
 @pytest.mark.parametrize("tag", list(H.WAVENET_OPTIONS))
