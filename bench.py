@@ -194,11 +194,20 @@ class WaveNetJob:
                      else "wavenet_spipe_kernel (one layer per stage of 8 CUs, weights in registers, clips streamed through one at a time)" if plan.stage_pipelined
                      else "wavenet_lpipe_kernel (four workgroups per clip that own whole layers, weights in registers)" if plan.layer_pipelined
                      else "wavenet_chain_kernel (one hand-off per layer)" if plan.chain else "wavenet_persist_kernel")
+            tflops = self.step_flops() * n / (us * 1e-6) / 1e12
+            if getattr(plan, "batch_pipelined", False):
+                # 16 clips per visit on the matrix pipe: the weights never leave the registers and the arithmetic is what the launch does - the fp32
+                # matrix peak bounds it (the HBM figure of the one-clip kernels stays in the line as hbm_nominal_frac)
+                return {"bound": "mfma", "kernel": kname + ": all layers + head of every step of a block",
+                        "achieved": round(tflops, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tflops / MFMA_F32_PEAK_TFLOPS, 5),
+                        "traffic": traffic, "traffic_source": traffic_source, "algorithmic_flops_per_launch": self.step_flops() * n,
+                        "algorithmic_bytes_per_launch": nbytes, "hbm_nominal_frac": round(achieved / HBM_PEAK_GBS, 5), "avg_launch_us": round(us, 1),
+                        "launches_timed": 1, "steps_per_launch": n, "us_per_step_in_kernel": round(us / n, 2)}
             return {"bound": "hbm", "kernel": kname + ": all layers + head of every step of a block",
                     "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_source,
                     "algorithmic_bytes_per_launch": nbytes, "avg_launch_us": round(us, 1), "launches_timed": 1,
-                    "steps_per_launch": n, "us_per_step_in_kernel": round(us / n, 2)}
+                    "steps_per_launch": n, "us_per_step_in_kernel": round(us / n, 2), "fp32_tflops": round(tflops, 2)}
         stats = plan.profile_steps(self.idx, self.cond, p, 48)
         net.after_generate((self.idx,), None)
         c, B = plan.cfg, self.clips
@@ -234,6 +243,12 @@ class WaveNetJob:
         w += c.dim_dilated                    # one embedding row per clip is negligible; count one
         state = self.clips * (2 * c.dim_dilated * 4 * c.n_layers + sum(c.cond_in_dim[j] for j in range(c.n_cond)) * 4)
         return 4 * w + state
+
+    def step_flops(self):
+        """algorithmic fp32 FLOPs of one auto-regressive step of the local batch: every weight of the network meets every clip once (2 per multiply-add) -
+        the layers' dilated, 1x1, residual and skip convolutions, the conditioning LinearIO, the MLP head (wavenet_v2.py:131-182, mlp.py:58-63)"""
+        w = sum(p.numel() for n, p in self.net.named_parameters() if p.dim() >= 2 and not n.startswith("input_modules.0."))
+        return 2 * w * self.clips
 
     def cpu_baseline(self, budget_s):
         from oracle import torch_ref as O
