@@ -489,6 +489,7 @@ __device__ __forceinline__ void helper_role(const WnBpipeArgs& a, BpLds& S, int 
     }
     st.mark(1);
     // ---- hid_s = hid_{s-1} + (fc0 W_skip_{s-1}) y_{s-1}: units 16 p .., K quarter h -------------------------------------------------------
+    float hs[4] = {0.f, 0.f, 0.f, 0.f};
     {
       f32x4b acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -507,46 +508,56 @@ __device__ __forceinline__ void helper_role(const WnBpipeArgs& a, BpLds& S, int 
         sig(&S.hp[h], uv + 1, lane);
       } else {
         if (!wait_min<3>(S.hp + 1, uv + 1, a.err_flag, 64 * 13 + stage)) return;
-        float hs[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) hs[i] = ((acc0[i] + acc1[i]) + S.hpart[1][i * 64 + lane]) + (S.hpart[2][i * 64 + lane] + S.hpart[3][i * 64 + lane]);
         sig(S.hp_used, uv + 1, lane);
+      }
+    }
+    // wave 4: the hidden units' sum handed on.  Where the stages run at their beat (more than 10 groups) BEHIND the next visit's known terms - chain wave 0 waits
+    // for those, the sum is needed by the head only, and every stage adds its part a visit's length behind its y, so the hand-over's own latency shows once per
+    // step, in front of the head (256 clips 153 -> 144 us per step); where a step is one group's trip, in front of them (128 clips 109.5 against 111.2)
+    auto hand_on = [&]() -> bool {
+      if (h == 0) {
         if (stage >= 1) {      // the sum so far: 4 words per lane of the message, looked at until they are there
           const unsigned* src = inbox + ((int64_t)g * kSpSlots + slot) * kBpMsgWords + 8192;
           unsigned spins = 0;
           for (;;) {
             unsigned wv[4];
             bool ok = true;
-#pragma unroll
+  #pragma unroll
             for (int i = 0; i < 4; ++i) {
               wv[i] = __hip_atomic_load(src + ((p * 64) + i * 16 + n) * 4 + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
               ok = ok && wv[i] != kSpPoison;
             }
             if (__all(ok)) {
-#pragma unroll
+  #pragma unroll
               for (int i = 0; i < 4; ++i) hs[i] += __uint_as_float(wv[i]);
               break;
             }
             __builtin_amdgcn_s_sleep(2);
             if (++spins > kSpin || ((spins & 1023u) == 0 && __hip_atomic_load(a.err_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
               atomicCAS(a.err_flag, 0, 0x20000 | stage);
-              return;
+              return false;
             }
           }
         }
         unsigned* dst = outbox + ((int64_t)g * kSpSlots + slot) * kBpMsgWords + 8192;
         unsigned* psn = outbox + ((int64_t)g * kSpSlots + ((t + 2) & 3)) * kBpMsgWords + 8192;
-#pragma unroll
+  #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const int word = ((p * 64) + i * 16 + n) * 4 + q;
           msg_put(dst + word, bits_of(hs[i]), local_hid);
           msg_put(psn + word, kSpPoison, local_hid);
         }
       }
-    }
+      return true;
+    };
     st.mark(2);
+    const bool late_hand_on = G > 10;
+    if (!late_hand_on && !hand_on()) return;
     if (v + 1 < V && !make_bias(v + 1, t1, g1)) return;
     st.mark(7);
+    if (late_hand_on && !hand_on()) return;
     t = t1; g = g1;
   }
   st.flush(a.stamps + 16, lane);
