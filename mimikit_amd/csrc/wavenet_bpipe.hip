@@ -68,7 +68,8 @@ struct BpLds {
   float rpart[2][256];            // residual tiles: the first K half's partial
   float hpart[4][256];            // hidden-unit tile: the K quarters' partials
   unsigned arr[4];                // chain wave w: visits whose quarter of the newest y it has staged
-  unsigned earr[4], edone[4];     // ... whose quarters of the early images it has staged / whose early products it has issued
+  unsigned earr[4], edone[4];     // ... whose quarter of the early x image it has staged (its quarter of the early y image: earry, before that) / whose early products it has issued
+  unsigned earry[4];
   unsigned done[8];               // wave: visits whose yl image it reads no more
   unsigned rp[2], rp_used[2];     // residual tile: second half's partial written / taken
   unsigned hp[4], hp_used[1];
@@ -236,14 +237,17 @@ __device__ __forceinline__ void chain_role(const WnBpipeArgs& a, BpLds& S, int s
     if (stage >= 1) {
       const unsigned* em = below + ((int64_t)g * kSpSlots + slot) * kBpMsgWords;
       if (v >= 1 && !wait_min<4>(S.edone, uv, a.err_flag, 64 * 1 + stage)) return;
-      if (!(MMK_BP_ABL & 8)) {
-        if (!gather(em + 1024 * w, S.ye + 1024 * w, lane, a.err_flag, 64 * 14 + stage)) return;
-        if (!gather(em + 4096 + 1024 * w, S.ye + 4096 + 1024 * w, lane, a.err_flag, 64 * 15 + stage)) return;
-      }
+      // y_{s-2} first: it left its stage a visit before x_{s-2} does (x_{s-2} = x_{s-3} + R y_{s-3} is made off the chain, behind y_{s-2}'s own products),
+      // so these 64 products run while x_{s-2} is still on its way
+      if (!(MMK_BP_ABL & 8) && !gather(em + 4096 + 1024 * w, S.ye + 4096 + 1024 * w, lane, a.err_flag, 64 * 15 + stage)) return;
+      sig(&S.earry[w], uv + 1, lane);
+      if (!wait_min<4>(S.earry, uv + 1, a.err_flag, 64 * 20 + stage)) return;
+      if (!(MMK_BP_ABL & 12)) mfma_sweep<16>(wa + 64, reinterpret_cast<const f32x4b*>(S.ye + 4096) + lane, acc0, acc1);
+      if (!(MMK_BP_ABL & 8) && !gather(em + 1024 * w, S.ye + 1024 * w, lane, a.err_flag, 64 * 14 + stage)) return;
       sig(&S.earr[w], uv + 1, lane);
       if (!wait_min<4>(S.earr, uv + 1, a.err_flag, 64 * 2 + stage)) return;
       st.mark(0);
-      if (!(MMK_BP_ABL & 12)) mfma_sweep<32>(wa, reinterpret_cast<const f32x4b*>(S.ye) + lane, acc0, acc1);
+      if (!(MMK_BP_ABL & 12)) mfma_sweep<16>(wa, reinterpret_cast<const f32x4b*>(S.ye) + lane, acc0, acc1);
       sig(&S.edone[w], uv + 1, lane);
       st.mark(1);
     }
