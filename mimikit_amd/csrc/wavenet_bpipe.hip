@@ -441,7 +441,9 @@ __device__ __forceinline__ void helper_role(const WnBpipeArgs& a, BpLds& S, int 
     // ---- x_s = x_{s-1} + R y_{s-1} + br, off the chain (the next stage but one multiplies with it, a visit from now): residual tile r2, K half kh ----
     {
       f32x4b rc0 = {0.f, 0.f, 0.f, 0.f}, rc1 = {0.f, 0.f, 0.f, 0.f};
-      // (started behind the 64 products of this SIMD's chain wave instead: 128 clips 109.3 -> 111.4 us per step)
+      // where a step is one group's trip (up to 10 groups): behind the 64 products of this SIMD's chain wave - the pipe takes the two waves' products in the order
+      // they were issued, and those 64 are on the chain (128 clips 109.1 -> 107.4 us per step; at 16 groups x_s would leave too late: 141 -> 144)
+      if (G <= 10 && !wait_min<1>(&S.done[h], uv + 1, a.err_flag, 64 * 18 + stage)) return;
       if (!(MMK_BP_ABL & 16)) mfma_sweep<8>(wr, yb + 8 * kh * 64, rc0, rc1);
       if (kh == 0) {      // (the second halves' waves publish: wave 4 has the hidden units' hand-over to do)
         if (v >= 1 && !wait_min<1>(&S.rp_used[r2], uv, a.err_flag, 64 * 10 + stage)) return;
