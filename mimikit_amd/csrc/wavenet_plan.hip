@@ -22,7 +22,7 @@
 using namespace mmk;
 
 // clips from which the stage pipeline's networks run in groups of 16 on the matrix pipe (wavenet_bpipe.hip).  Measured on cfg 4, us per step: a group's trip
-// is 109 whatever the batch up to ~10 groups (128 clips 109 against the one-clip ring's 136, 256 clips 153 against 272 as two passes); the ring's beat is
+// is 107 whatever the batch up to ~10 groups (128 clips 107 against the one-clip ring's 136, 256 clips 140 against 272 as two passes); the ring's beat is
 // 1.06 per clip: 104 clips are where the two meet
 constexpr int kBpipeMinClips = 105;
 
