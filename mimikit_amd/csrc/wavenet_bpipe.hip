@@ -250,6 +250,9 @@ __device__ __forceinline__ void chain_role(const WnBpipeArgs& a, BpLds& S, int s
       if (!(MMK_BP_ABL & 12)) mfma_sweep<16>(wa, reinterpret_cast<const f32x4b*>(S.ye) + lane, acc0, acc1);
       sig(&S.edone[w], uv + 1, lane);
       st.mark(1);
+#ifdef MMK_DIAG
+      if (a.stamps && g == 0 && t + 1 == (int)a.n_steps && p == 0 && w == 0 && lane == 0) a.stamps[128 + stage] = __builtin_amdgcn_s_memrealtime();      // early products out
+#endif
     }
     // ---- on the chain: (W1 R_{s-1}) y_{s-1} -------------------------------------------------------------------------------------------------------
     if (v >= 2 && !wait_min<8>(S.done, uv - 1, a.err_flag, 64 * 3 + stage)) return;

@@ -1537,6 +1537,8 @@ extern "C" int mmk_wavenet_sync_status(mmk_wavenet_plan* p, mmk_stream_t stream)
         for (int k = 0; k < 16; ++k) fprintf(stderr, " [%d]=%.0f", k, (double)st[16 + k] * 0.01);
         fprintf(stderr, "\n[mmk stamps] group 0, last step, per stage [y of the stage below stored -> y complete here | -> y stored], 10 ns ticks:");
         for (int l = 1; l < p->L; ++l) fprintf(stderr, " %d:[%lld|%lld]", l, (long long)(st[64 + 2 * l] - st[64 + 2 * (l - 1) + 1]), (long long)(st[64 + 2 * l + 1] - st[64 + 2 * l]));
+        fprintf(stderr, "\n[mmk stamps] the same group: early products out minus y of the stage below stored (negative: the early half was waiting for y), 10 ns ticks:");
+        for (int l = 1; l < p->L; ++l) fprintf(stderr, " %d:%lld", l, (long long)(st[128 + l] - st[64 + 2 * (l - 1) + 1]));
         fprintf(stderr, "\n");
       } else if (p->spipe) {
         fprintf(stderr, "[mmk stamps] last stage-pipeline launch, chain wave 0 of CU 0 of stage MMK_WN_STAMP_STAGE (default 1), shader cycles per visit: "
