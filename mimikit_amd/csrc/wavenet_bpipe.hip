@@ -52,6 +52,9 @@ constexpr int kLgStride = 260;
 #ifndef MMK_BP_ABL
 #define MMK_BP_ABL 0      // timing experiments (results wrong): 1 no known-term products, 2 no hidden-unit products, 4 no early products, 8 no early gather either, 16 no residual products
 #endif
+#ifndef MMK_BP_LOOK_SLEEP
+#define MMK_BP_LOOK_SLEEP 0      // s_sleep units (64 cycles) between two looks at a message part that is not complete (a look is a whole L2 round trip: 0 / 2 / 6 -> 106.9 / 107.4 / 108.0 us per step at 128 clips)
+#endif
 #ifndef MMK_BP_CHAIN_PRIO
 #define MMK_BP_CHAIN_PRIO 2
 #endif
@@ -190,7 +193,7 @@ __device__ __forceinline__ bool gather(const unsigned* src, float* dst, int lane
   for (;;) {
     load4_sc1(src + 4 * lane, r[0], r[1], r[2], r[3]);
     if (__all(clean(r[0]) && clean(r[1]) && clean(r[2]) && clean(r[3]))) break;
-    __builtin_amdgcn_s_sleep(2);
+    if (MMK_BP_LOOK_SLEEP > 0) __builtin_amdgcn_s_sleep(MMK_BP_LOOK_SLEEP);
     if (++spins > kSpin || ((spins & 1023u) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
       atomicMax(err, 0x10000 | tag);      // (diagnosis: which look never saw its message)
       return false;
