@@ -71,7 +71,10 @@ def parse():
 def apply_tuning(text):
     """--tuning -> mimikit_amd.native.PLAN_TUNING, before any plan is built; an MMK_* variable in the environment is refused: it would be ignored
     by the product library and an A/B run would silently compare two identical configurations"""
-    stray = sorted(k for k in os.environ if k.startswith("MMK_") and k not in ("MMK_DIAG_LIB",) and os.environ.get("MMK_DIAG_LIB") != "1")
+    # (only the names that look like the library's execution switches: MMK_REFERENCE_ROOT and the like are other programs' business; a diagnostic
+    # build - MMK_DIAG_LIB set - does read its MMK_* variables)
+    switches = ("MMK_WN_", "MMK_SRNN_", "MMK_S2S_", "MMK_BP_", "MMK_SP_", "MMK_LSTM_", "MMK_FEAT_")
+    stray = sorted(k for k in os.environ if k.startswith(switches) and not os.environ.get("MMK_DIAG_LIB"))
     if stray:
         raise SystemExit(f"bench.py: {', '.join(stray)} set in the environment - the library does not read it; use --tuning NAME=VALUE")
     if not text:

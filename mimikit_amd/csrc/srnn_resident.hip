@@ -860,7 +860,8 @@ bool srnn_resident_supported(int H, bool lstm, int Hm, int n_out, int Q, int fsb
 
 // Every workgroup of the launch waits for others: they must all be resident at once, one per CU (`spare_cus` are left to whatever else
 // runs).  A tier's workgroup owns 16 units x 16 mt clips: the tiers start at mt = 1 and, while the launch does not fit, the topmost tier
-// that can still grow doubles its row tiles (it updates least often: its products have the most time; the top tier up to 4, the others 2).
+// that can still grow doubles its row tiles (it updates least often: its products have the most time; the top tier up to 4 - unless it is
+// also the last recurrent tier, whose role exists for 1 and 2 row tiles -, the others 2).
 int srnn_resident_grid(int H, int B, int n_tiers, int spare_cus, int* mt_out) {
   const int n_cu = res_cu_count() - spare_cus, KC = H / 16;
   int mt[kResMaxTiers];
@@ -874,7 +875,7 @@ int srnn_resident_grid(int H, int B, int n_tiers, int spare_cus, int* mt_out) {
     }
     int grow = -1;
     for (int i = 0; i < n_tiers && grow < 0; ++i)
-      if (mt[i] < (i == 0 ? 4 : 2) && 16 * mt[i] < B) grow = i;
+      if (mt[i] < ((i == 0 && n_tiers > 1) ? 4 : 2) && 16 * mt[i] < B) grow = i;     // (a LAST tier is instantiated for 1 and 2 row tiles only)
     if (grow < 0) return 0;
     mt[grow] *= 2;
   }
@@ -903,7 +904,7 @@ int launch_srnn_resident(const SrnnResArgs& a, hipStream_t stream) {
   int grid = a.B;
   for (int i = 0; i < a.n_tiers; ++i) {
     const int mt = a.tier[i].mt;
-    if (!(mt == 1 || mt == 2 || (mt == 4 && i == 0))) return fail(MMK_ERR_INVALID, "srnn resident kernel: %d row tiles per workgroup of tier %d", mt, i);
+    if (!(mt == 1 || mt == 2 || (mt == 4 && i == 0 && a.n_tiers > 1))) return fail(MMK_ERR_INVALID, "srnn resident kernel: %d row tiles per workgroup of tier %d", mt, i);
     if (a.tier[i].block0 != grid) return fail(MMK_ERR_INVALID, "srnn resident kernel: tier %d starts at workgroup %d, %d expected", i, a.tier[i].block0, grid);
     grid += KC * ((a.B + 16 * mt - 1) / (16 * mt));
   }

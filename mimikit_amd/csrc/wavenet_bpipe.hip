@@ -146,6 +146,10 @@ __device__ __forceinline__ void glds16(const float* src, float* dst) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
 }
 
+__device__ __forceinline__ void glds16_sc1(const float* src, float* dst) {      // ... past this CU's L1 (cache policy bit 4 = sc1: agent scope)
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)dst, 16, 0, 16);
+}
+
 __device__ __forceinline__ f32x4b mfma4(float a, float b, f32x4b c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 
 // acc0 / acc1 += A registers w[0 .. 4 N) x the N 16-byte B reads b[0], b[64], ..: the B read two ahead is asked for before the current one's four
@@ -220,7 +224,7 @@ __device__ __forceinline__ void chain_role(const WnBpipeArgs& a, BpLds& S, int s
   const int n = lane & 15, q = lane >> 4;
   // (x and y are read by the next stage AND the one after it: plain stores only where both sit on this XCD)
   const bool local_next = ((stage + 2) >> 2) == (stage >> 2);
-  const int64_t stage_words = (int64_t)((a.Bmax + kG - 1) / kG) * kSpSlots * kBpMsgWords;
+  const int64_t stage_words = (int64_t)G * kSpSlots * kBpMsgWords;      // (the blocks of a launch are laid out for ITS groups: the plan poisons only those)
   const unsigned* inbox = a.msg + (int64_t)stage * stage_words;
   const unsigned* below = a.msg + (int64_t)(stage > 0 ? stage - 1 : 0) * stage_words;      // what the stage below received
   unsigned* outbox = a.msg + (int64_t)(stage + 1) * stage_words;
@@ -347,7 +351,7 @@ __device__ __forceinline__ void helper_role(const WnBpipeArgs& a, BpLds& S, int 
   const int n = lane & 15, q = lane >> 4;
   const bool local_next = ((stage + 2) >> 2) == (stage >> 2);      // x_s: read by the next two stages
   const bool local_hid = ((stage + 1) >> 2) == (stage >> 2);       // the hidden units' sum: by the next one
-  const int64_t stage_words = (int64_t)((a.Bmax + kG - 1) / kG) * kSpSlots * kBpMsgWords;
+  const int64_t stage_words = (int64_t)G * kSpSlots * kBpMsgWords;      // (the blocks of a launch are laid out for ITS groups: the plan poisons only those)
   const unsigned* inbox = a.msg + (int64_t)stage * stage_words;
   unsigned* outbox = a.msg + (int64_t)(stage + 1) * stage_words;
   float* ring = a.hist[stage];
@@ -355,6 +359,7 @@ __device__ __forceinline__ void helper_role(const WnBpipeArgs& a, BpLds& S, int 
   const int64_t slot_stride = (int64_t)a.Bmax * kC;
   const int C1 = a.C1;
   const int64_t V = a.n_steps * G;
+  const bool late_rows = d >= 2 && (d - 1) * G < 2;
   BpStamp st;
   st.on = a.stamps != nullptr && stage == a.stamp_stage && p == 0 && h == 0;
 
@@ -369,7 +374,7 @@ __device__ __forceinline__ void helper_role(const WnBpipeArgs& a, BpLds& S, int 
         // lane (q, n): clip n, channels 16 (4 h + jj) + 4 q .. + 3 - the k-step 4 (4 h + jj) + q of the image
         const float* src = ring + (tp & ring_mask) * slot_stride + (int64_t)clip * kC + 64 * h + 4 * q;
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj) glds16(src + 16 * jj, img + (4 * h + jj) * 256);
+        for (int jj = 0; jj < 4; ++jj) glds16_sc1(src + 16 * jj, img + (4 * h + jj) * 256);      // (written by the sibling CUs: never this CU's L1 copy of the slot)
       } else {      // in front of the sequence: zeros
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) *reinterpret_cast<f32x4b*>(img + (4 * h + jj) * 256 + 4 * lane) = f32x4b{0.f, 0.f, 0.f, 0.f};
@@ -440,8 +445,14 @@ __device__ __forceinline__ void helper_role(const WnBpipeArgs& a, BpLds& S, int 
     st.start();
     int t1 = t, g1 = g + 1;
     if (g1 == G) { g1 = 0; ++t1; }
-    if (v + 1 < V) ask_rows(v + 1, t1, g1);
+    // The ring row x_s[t1 - d] of visit v + 1 was stored by ALL 8 CUs of this stage (d G) visits before it.  What orders this CU's read behind a sibling's
+    // store is the chain itself: y_{s-1} of visit w is here => the class of w's step was drawn => every CU had handed on its hidden units' sum of the
+    // step before, which its waves 6 / 7 do behind their ring store.  At the top of visit v that covers the rows up to visit v - 1 - G: enough where
+    // (d - 1) G >= 2; a launch of ONE group on the d = 2 stage (row of visit v - 1) asks behind y_{s-1} of visit v instead (covers v - G) and its
+    // siblings complete their ring stores before they hand on (the release below)
+    if (v + 1 < V && !late_rows) ask_rows(v + 1, t1, g1);
     if (!wait_min<4>(S.arr, uv + 1, a.err_flag, 64 * 9 + stage)) return;
+    if (v + 1 < V && late_rows) ask_rows(v + 1, t1, g1);
     st.mark(0);
     const f32x4b* yb = reinterpret_cast<const f32x4b*>(S.yl[buf]) + lane;
     // ---- x_s = x_{s-1} + R y_{s-1} + br, off the chain (the next stage but one multiplies with it, a visit from now): residual tile r2, K half kh ----
@@ -497,6 +508,7 @@ __device__ __forceinline__ void helper_role(const WnBpipeArgs& a, BpLds& S, int 
         const int clip = kG * g + n;
         if (clip < a.B)
           *reinterpret_cast<f32x4b*>(ring + (tau & ring_mask) * slot_stride + (int64_t)clip * kC + 32 * p + 16 * r2 + 4 * q) = f32x4b{xs[0], xs[1], xs[2], xs[3]};
+        if (G == 1) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");      // (one group: the row is read a visit from now - see late_rows; the wait is off the beat there)
       }
     }
     st.mark(1);
@@ -612,7 +624,7 @@ __device__ __forceinline__ void head_role(const WnBpipeArgs& a, unsigned char* l
   for (int i = 0; i < 32; ++i) asm volatile("" : "+v"(wt[i]));
   if (tid == 0) *s_fail = 0;
   const int G = (a.B + kG - 1) / kG;
-  const int64_t stage_words = (int64_t)((a.Bmax + kG - 1) / kG) * kSpSlots * kBpMsgWords;
+  const int64_t stage_words = (int64_t)G * kSpSlots * kBpMsgWords;      // (the blocks of a launch are laid out for ITS groups: the plan poisons only those)
   const unsigned* inbox = a.msg + (int64_t)a.L * stage_words;
   unsigned* outbox = a.msg;      // stage 0's (another XCD: written through)
   // the embedded classes of cls[] as stage 0's message of step s1: x = E[class], y = 0

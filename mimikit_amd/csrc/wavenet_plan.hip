@@ -1180,7 +1180,7 @@ static int run_persistent(mmk_wavenet_plan* p, const WnCall& call, int64_t tau0,
     }
     if (p->bpipe) {
       if (!with_head) return fail(MMK_ERR_STATE, "wavenet: the stage-pipeline kernels have no teacher-forced mode (warm-up is a prefill)");
-      MMK_HIP(hipMemsetAsync(p->bp_msg, 0xFF, (size_t)wn_bpipe_msg_words(p->L, p->Bmax) * sizeof(unsigned), st));      // every word "not arrived"
+      MMK_HIP(hipMemsetAsync(p->bp_msg, 0xFF, (size_t)wn_bpipe_msg_words(p->L, call.M) * sizeof(unsigned), st));      // every word of THIS call's groups "not arrived" (the kernel lays the blocks out for them)
       WnBpipeArgs k = {};
       k.B = call.M; k.L = p->L; k.C1 = p->C1;
       k.learn_temp = c.learn_temp; k.min_temp = c.min_temp; k.Bmax = p->Bmax;

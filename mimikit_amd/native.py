@@ -12,9 +12,16 @@ from typing import Dict, Optional, Sequence
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# MMK_DIAG_LIB=1 (read once, at import) selects the diagnostic build (`python -m mimikit_amd.build --diag`): the same library with
-# in-kernel phase stamps and the timing experiments compiled in; the product library contains neither
-LIB_PATH = os.path.join(_HERE, "libmmk_hip_diag.so" if os.environ.get("MMK_DIAG_LIB") == "1" else "libmmk_hip.so")
+# MMK_DIAG_LIB (read once, at import): "1" selects the diagnostic build (`python -m mimikit_amd.build --diag`): the same library with
+# in-kernel phase stamps and the timing experiments compiled in; the path of a `.so` selects that file (the A/B variants of
+# scripts/build_variant.sh: loaded from where they lie, the product library is never overwritten).  Unset or empty: the product library,
+# which contains neither and must carry the digest of the tree's sources
+_DIAG = os.environ.get("MMK_DIAG_LIB", "")
+DIAGNOSTIC = _DIAG != ""
+LIB_PATH = (os.path.join(_HERE, "libmmk_hip_diag.so") if _DIAG == "1" else os.path.abspath(_DIAG) if _DIAG.endswith(".so")
+            else os.path.join(_HERE, "libmmk_hip.so"))
+if DIAGNOSTIC and _DIAG != "1" and not _DIAG.endswith(".so"):
+    raise ImportError(f"MMK_DIAG_LIB={_DIAG!r}: expected 1 (the diagnostic build) or the path of a library variant (*.so)")
 
 MAX_LAYERS, MAX_COND, MAX_TIERS, MAX_STREAMS = 128, 4, 8, 4
 ABI_VERSION = 3          # include/mmk.h: MMK_ABI_VERSION (bumped whenever a config struct or a signature changes)
@@ -27,6 +34,7 @@ class NativeError(RuntimeError):
     pass
 
 
+WN_BPIPE_MIN_CLIPS = 105  # csrc/wavenet_plan.hip: kBpipeMinClips (tests/test_host_logic.py holds the two together)
 TUNING_CHARS = 256        # include/mmk.h: MMK_TUNING_CHARS
 
 # Execution switches handed to every plan this process creates, as {"MMK_WN_CHAIN": "0", ...} (merged under a network's own
@@ -174,8 +182,8 @@ def load_library(path: Optional[str] = None):
     if lib.mmk_abi_version() != ABI_VERSION:
         raise NativeError(f"ABI version mismatch: library reports {lib.mmk_abi_version()}, binding expects {ABI_VERSION} "
                           "(a stale libmmk_hip.so: rebuild with `python -m mimikit_amd.build`)")
-    if os.environ.get("MMK_DIAG_LIB") != "1":       # (the product library must be the one these sources make; scripts that swap in
-        from .build import source_digest             #  variants compiled with other -D flags keep the digest: it covers sources only)
+    if not DIAGNOSTIC or path != LIB_PATH:          # (the product library must be the one these sources make; a diagnostic build or a
+        from .build import source_digest             #  variant is asked for by name through MMK_DIAG_LIB and is never found under the product's name)
         have, want = lib.mmk_build_digest().decode(), source_digest()
         if have != want:
             raise NativeError(f"{path} was built from other sources (digest {have}, the tree's is {want}): rebuild with "

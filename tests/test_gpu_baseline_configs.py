@@ -226,6 +226,32 @@ def test_cfg4_wavenet_ragged_groups_of_16(device):
     _cfg4_greedy_against_oracle(device, B=150, n=300, n_last=1, n_mid=8, seed=4150, expect_set=False, expect_batched=True)
 
 
+def test_cfg4_a_small_batch_after_a_large_one_gets_the_one_clip_ring(device):
+    """the step kernel follows the CALL's batch: a network that generated 112 clips in groups of 16 (wavenet_bpipe.hip) and is then asked for 6
+    clips runs them on the one-clip ring (a new plan), not as one group of 16 on the large-batch kernel - and back; every generation equals the
+    oracle at its last step"""
+    net, sd, arch = cfg4_network()
+    net = net.to(device)
+    rf, P, n = net.rf, 3072, 24
+    for B, batched in ((112, True), (6, False), (112, True)):
+        gen = torch.Generator().manual_seed(4000 + B)
+        prompt = torch.randint(0, 256, (B, P), generator=gen)
+        cond = torch.rand(B, P + n, 513, generator=gen)
+        cond_d = cond.to(device)
+        idx = torch.cat([prompt, torch.zeros(B, n, dtype=torch.int64)], 1).to(device)
+        net.before_generate((idx[:, :P], cond_d[:, :P]), None)
+        net.generate_block((idx, cond_d), P, n)
+        net.after_generate((idx,), None)
+        assert net._plan.stage_pipelined and net._plan.batch_pipelined == batched
+        hist = idx.cpu()
+        clips = list(range(0, B, max(B // 6, 1)))[:6]
+        t = P + n - 1
+        with host_threads(32):
+            raw = O.wavenet_window_forward(sd, (hist[clips, t - rf:t], cond[clips, t - rf:t]), n_cond=1, **arch)
+        gap_ok = H.margin_ok(raw.numpy())[:, 0]
+        assert bool(((O.categorical(O.mlp_logits(raw))[:, 0] == hist[clips, t]) | ~gap_ok).all()) and int(gap_ok.sum()) >= 4
+
+
 def test_cfg4_nan_with_the_poison_payload_is_a_value_not_a_missing_word(device):
     """the stage pipeline's messages mark "not arrived" with 0xFFFFFFFF - which is also a NaN.  A weight that carries exactly that
     NaN (here: one embedding entry of a class the prompt contains) must flow through the ring as the value it is: no hand-off

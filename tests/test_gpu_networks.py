@@ -358,6 +358,25 @@ def test_sample_rnn_resident_mode_geometries(device, monkeypatch, frame_sizes, b
     assert torch.equal(ref[:, P:][ok], got[:, P:][ok])
 
 
+@pytest.mark.parametrize("batch,want_resident", [(170, 1), (220, 0)])
+def test_sample_rnn_one_tier_many_clips(device, monkeypatch, batch, want_resident):
+    """ONE recurrent tier (it is the top AND the last tier) with more clips than row tiles of 16 fit the chip: the tier's workgroups take two
+    row tiles (170 clips) - never four, a last tier has no such role: at 220 clips the launch does not fit and the kernels run in turns.
+    Every clip, the ones of the last row tile included, equals the oracle teacher-forced on the device's history"""
+    monkeypatch.setitem(mmk.native.PLAN_TUNING, "MMK_SRNN_FUSED", "1")
+    net, sd, arch = H.srnn("big", hidden=128, mlp_dim=64, seed=97, frame_sizes=(4, 1), kind="gru")
+    net = net.to(device)
+    P, n = 11, 17
+    prompt = torch.randint(0, 256, (batch, P), generator=torch.Generator().manual_seed(19))
+    got, count = _srnn_blocks(net, device, prompt, n, (n,))
+    assert count == want_resident
+    ref, raw = O.SampleRNNOracle(sd, **arch).generate(prompt, n, keep_logits=True, forced=got)
+    ok = H.margin_ok(raw)
+    assert float(ok.float().mean()) > 0.9
+    assert torch.equal(ref[:, P:][ok], got[:, P:][ok])
+    assert bool((got[-16:, P:] != 0).any())          # (the last row tile was generated at all)
+
+
 def test_sample_rnn_resident_mode_last_logits_and_state_hand_back(device, monkeypatch):
     """what a resident launch leaves behind is what the kernels in turns would have left: the logits of the block's last step, and the tiers'
     states, counters and up-sampled rows - a block that ends between two updates of every tier, continued step by step through generate_step
