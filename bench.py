@@ -61,6 +61,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-strong-leg", action="store_true", help="wavenet_cfg4: skip the strong-scaling leg (256 clips / N ranks) after the timed region")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline sample")
+    ap.add_argument("--no-others", action="store_true", help="wavenet_cfg4 at N = 1: skip the short passes of the other BASELINE workloads (`other_workloads` key)")
     ap.add_argument("--force-dist", action="store_true", help="with --gpus 1: initialise the RCCL process group of ONE rank all the same and run the path's "
                     "collectives (weight broadcast, fenced max-over-ranks clock) on it - what an N-GPU run does, on a 1-GPU box")
     ap.add_argument("--tuning", default="", help="execution switches of the plans of this run, NAME=VALUE[;NAME=VALUE...] (include/mmk.h `tuning`): "
@@ -715,6 +716,44 @@ def strong_scaling_leg(args, device, rank, world, sync):
     return out
 
 
+OTHER_WORKLOADS = (("wavenet_cfg2", 2, 1), ("srnn_cfg3", 3, 1), ("s2s_cfg5", 5, 2), ("mulaw", 10, 2), ("stft", 10, 2), ("istft", 10, 2), ("gla", 2, 1))
+
+
+def other_workloads(args, device, sync):
+    """Every other BASELINE config and the feature kernels on the SAME clock as the headline: after the timed region of the default run (N = 1), one
+    short fenced run of each - the same Job classes `--workload NAME` runs, the same fences (shard.timed_passes), its dominant kernel's roofline from
+    HIP events, a small CPU sample of the oracle - so that the figures DESIGN.md quotes for them are lines the driver saw.  ~40 s in all."""
+    import copy
+    from mimikit_amd.shard import timed_passes
+    out = {}
+    for name, steps, warmup in OTHER_WORKLOADS:
+        a2 = copy.copy(args)
+        a2.workload, a2.clips, a2.seconds, a2.temperature = name, 0, 1.0, 0.0
+        t_start = time.perf_counter()
+        try:
+            job = JOBS[name](a2, device, 0)
+            job.to_device()
+            elapsed = timed_passes(job.one_pass, steps, warmup, sync)
+            entry = {"value": round(job.units_per_pass() * steps / elapsed, 1), "unit": job.unit, "steps": steps, "warmup": warmup,
+                     "ms_per_step": round(1e3 * elapsed / steps, 3), "config": job.config(1)}
+            if hasattr(job, "clips") and hasattr(job, "n_steps") and name != "s2s_cfg5":
+                entry["us_per_ar_step"] = round(1e6 * elapsed / (steps * job.n_steps), 3)
+            roof = job.roofline()
+            entry["roofline"] = {k: roof[k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_us") if k in roof}
+            for k in ("us_per_step_in_kernel", "us_per_step", "us_per_generate_step"):
+                if k in roof:
+                    entry["roofline"][k] = roof[k]
+            cpu = job.cpu_baseline(3.0)
+            entry["cpu_baseline"] = {k: cpu[k] for k in ("value", "unit", "cores", "kind", "sample", "matches_gpu_output") if k in cpu}
+        except Exception as e:      # (a failing side workload must not take the headline line with it: it is reported as what it is)
+            entry = {"error": f"{type(e).__name__}: {e}"[:300]}
+        entry["wall_s"] = round(time.perf_counter() - t_start, 2)
+        out[name] = entry
+        job = None
+        torch.cuda.empty_cache()
+    return out
+
+
 def main():
     args = parse()
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -792,6 +831,8 @@ def main():
             line["strong_scaling"] = strong
         if world == 1 and not args.no_cpu_baseline and not args.temperature > 0:    # N = 1 only; the CPU leg re-checks the GREEDY samples
             line["cpu_baseline"] = job.cpu_baseline(args.cpu_seconds)
+        if world == 1 and args.workload == "wavenet_cfg4" and not args.no_others and not args.clips and not args.temperature > 0 and not args.tuning:
+            line["other_workloads"] = other_workloads(args, device, sync)
         print(json.dumps(line), flush=True)
     if world > 1 or (args.force_dist and dist.is_initialized()):
         dist.barrier()

@@ -1535,6 +1535,17 @@ extern "C" int mmk_wavenet_sync_status(mmk_wavenet_plan* p, mmk_stream_t stream)
         for (int k = 0; k < 16; ++k) fprintf(stderr, " [%d]=%.0f", k, (double)st[k] * 0.01);
         fprintf(stderr, "\n[mmk stamps] helper wave 4:");
         for (int k = 0; k < 16; ++k) fprintf(stderr, " [%d]=%.0f", k, (double)st[16 + k] * 0.01);
+        {
+          static const char* role[4] = {"chain wave 0", "chain wave 2", "helper wave 4", "helper wave 6"};
+          const unsigned long long t0 = st[160];
+          for (int r = 0; r < 4; ++r) {
+            fprintf(stderr, "\n[mmk trace] %s, three visits in the middle of the launch, marks 0 .. 7 in 10 ns ticks from chain wave 0's first:", role[r]);
+            for (int v = 0; v < 3; ++v) {
+              fprintf(stderr, " |");
+              for (int k = 0; k < 8; ++k) fprintf(stderr, " %lld", (long long)(st[160 + 24 * r + 8 * v + k] - t0));
+            }
+          }
+        }
         fprintf(stderr, "\n[mmk stamps] group 0, last step, per stage [y of the stage below stored -> y complete here | -> y stored], 10 ns ticks:");
         for (int l = 1; l < p->L; ++l) fprintf(stderr, " %d:[%lld|%lld]", l, (long long)(st[64 + 2 * l] - st[64 + 2 * (l - 1) + 1]), (long long)(st[64 + 2 * l + 1] - st[64 + 2 * l]));
         fprintf(stderr, "\n[mmk stamps] the same group: early products out minus y of the stage below stored (negative: the early half was waiting for y), 10 ns ticks:");

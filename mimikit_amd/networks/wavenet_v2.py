@@ -404,7 +404,7 @@ class WaveNet(ARM, nn.Module):
         stale = self._plan is None or self._plan_tuning != tuning or self._plan_batch < batch or self._plan.device != device
         # the step kernel is chosen for the batch a plan is made for: one made for >= 105 clips serves groups of 16 clips per visit (~107 us per step
         # whatever the batch), which a later call of a few clips must not pay - it gets a plan of its own size (the one-clip ring: ~1.1 us per clip)
-        if not stale and batch < native.WN_BPIPE_MIN_CLIPS and getattr(self._plan, "batch_pipelined", False) and "MMK_WN_BPIPE=1" not in tuning:
+        if not stale and batch < native.WN_BPIPE_MIN_CLIPS and getattr(self._plan, "batch_pipelined", False) and b"MMK_WN_BPIPE=1" not in tuning:
             stale = True
         if stale:
             self._plan = native.make_wavenet_plan(self._describe, max(batch, 1), device)

@@ -11,7 +11,7 @@
 #   mfma [CLIPS ...]           SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CYCLES / GRBM_GUI_ACTIVE of the cfg-4 launch at the given clip counts
 #   sq WORKLOAD                SQ wave / wait / LDS counters of a feature kernel
 #   soak CLIPS [PASSES]        PASSES (20) full passes of cfg 4 at CLIPS per GPU; counts redone batches (a timed-out hand-off)
-#   stamps CLIPS [STAGE]       diagnostic build: phase stamps of one stage's waves (scripts/bpipe_check.py / bench.py with MMK_WN_STAMPS=1)
+#   stamps CLIPS [STAGE]       diagnostic build (LIB=<variant built with `build_variant.sh .. diag`> for another): phase stamps of one stage's waves
 #   ab CLIPS_A CLIPS_B [STEPS] every library under mimikit_amd/variants/ (scripts/build_variant.sh) against the product library: us per AR step of
 #                              scripts/bpipe_check.py.  Variants are loaded BY PATH (MMK_DIAG_LIB=<file>): the product library is never overwritten
 export TMPDIR=/tmp
@@ -100,7 +100,7 @@ soak)
   ;;
 stamps)
   n=$1; st=${2:-13}
-  MMK_DIAG_LIB=1 MMK_WN_STAMPS=1 MMK_WN_STAMP_STAGE=$st timeout 600 python scripts/bpipe_check.py --only ${ONLY:-bpipe} --clips $n --steps ${STEPS:-256} 2>&1 | grep -v amdgpu.ids | tee $O/stamps_clips${n}_stage$st.log | cut -c1-1800
+  MMK_DIAG_LIB=${LIB:-1} MMK_WN_STAMPS=1 MMK_WN_STAMP_STAGE=$st timeout 600 python scripts/bpipe_check.py --only ${ONLY:-bpipe} --clips $n --steps ${STEPS:-256} 2>&1 | grep -v amdgpu.ids | tee $O/stamps_clips${n}_stage$st.log | cut -c1-1800
   ;;
 ab)
   a=$1; b=$2; steps=${3:-256}
