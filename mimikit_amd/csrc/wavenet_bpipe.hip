@@ -127,15 +127,34 @@ struct BpStamp {
 #ifdef MMK_DIAG
   u64 acc[16] = {}, last = 0;
   bool on = false;
-  __device__ __forceinline__ void start() { if (on) last = __builtin_amdgcn_s_memrealtime(); }
-  __device__ __forceinline__ void mark(int k) { if (on) { const u64 t = __builtin_amdgcn_s_memrealtime(); acc[k] += t - last; last = t; } }
+  // trace: the wall-clock time of every mark of three consecutive visits in the middle of the launch, for two SIMD pairs of the stamped CU (chain waves 0 and 2,
+  // helper waves 4 and 6: a.stamps[160 + 24 role + 8 visit + mark]) - who waits for whom inside a visit
+  unsigned long long* tr = nullptr;
+  bool tv = false;
+  int lane0 = 1;
+  __device__ __forceinline__ void start(int64_t v = -1, int64_t v0 = 0) {
+    if (on) last = __builtin_amdgcn_s_memrealtime();
+    tv = tr != nullptr && v >= v0 && v < v0 + 3;
+    if (tv) tr += 0;
+    vrel = (int)(v - v0);
+  }
+  int vrel = 0;
+  __device__ __forceinline__ void mark(int k) {
+    if (on || tv) {
+      const u64 t = __builtin_amdgcn_s_memrealtime();
+      if (on) { acc[k] += t - last; last = t; }
+      if (tv && lane0 == 0) tr[8 * vrel + k] = t;
+    }
+  }
   __device__ __forceinline__ void flush(unsigned long long* dst, int lane) const {
     if (on && lane == 0)
       for (int k = 0; k < 16; ++k) dst[k] = acc[k];
   }
 #else
   bool on = false;
-  __device__ __forceinline__ void start() {}
+  unsigned long long* tr = nullptr;
+  int lane0 = 1;
+  __device__ __forceinline__ void start(int64_t = -1, int64_t = 0) {}
   __device__ __forceinline__ void mark(int) {}
   __device__ __forceinline__ void flush(unsigned long long*, int) const {}
 #endif
@@ -234,10 +253,12 @@ __device__ __forceinline__ void chain_role(const WnBpipeArgs& a, BpLds& S, int s
   __builtin_amdgcn_s_setprio(MMK_BP_CHAIN_PRIO);      // (ahead of the helper wave of the same SIMD, whose products are off the chain)
   BpStamp st;
   st.on = a.stamps != nullptr && stage == a.stamp_stage && p == 0 && w == 0;
+  if (a.stamps != nullptr && stage == a.stamp_stage && p == 0 && (w == 0 || w == 2)) st.tr = a.stamps + 160 + 24 * (w >> 1);
+  st.lane0 = lane;
   for (int64_t v = 0; v < V; ++v) {
     const int slot = t & 3, buf = (int)(v & 1);
     const unsigned uv = (unsigned)v;
-    st.start();
+    st.start(v, V / 2);
     f32x4b acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
     // ---- early: W1 x_{s-2} + (W1 R_{s-2}) y_{s-2} - what the stage BELOW received for this visit, there a whole visit before y_{s-1} ---------------
     // (asked for by LDS-DMA behind the previous visit's early products instead: 128 clips 109 -> 119 us per step - the look at y_{s-1} then waits for it too)
@@ -362,6 +383,8 @@ __device__ __forceinline__ void helper_role(const WnBpipeArgs& a, BpLds& S, int 
   const bool late_rows = d >= 2 && (d - 1) * G < 2;
   BpStamp st;
   st.on = a.stamps != nullptr && stage == a.stamp_stage && p == 0 && h == 0;
+  if (a.stamps != nullptr && stage == a.stamp_stage && p == 0 && (h == 0 || h == 2)) st.tr = a.stamps + 160 + 48 + 24 * (h >> 1);
+  st.lane0 = lane;
 
   // everything of visit v1's z that does not depend on its message: W0 x_s[t - d] + Wc c[t] + b, tile h.  The rows are asked for (ask_rows: LDS-DMA, no
   // registers) at the top of the visit before and waited for after its other work: a ring row a ring ago and a conditioning row come from HBM
@@ -442,7 +465,7 @@ __device__ __forceinline__ void helper_role(const WnBpipeArgs& a, BpLds& S, int 
     const int slot = t & 3, buf = (int)(v & 1);
     const unsigned uv = (unsigned)v;
     const int64_t tau = a.t0 - 1 + t;
-    st.start();
+    st.start(v, V / 2);
     int t1 = t, g1 = g + 1;
     if (g1 == G) { g1 = 0; ++t1; }
     // The ring row x_s[t1 - d] of visit v + 1 was stored by ALL 8 CUs of this stage (d G) visits before it.  What orders this CU's read behind a sibling's
