@@ -12,6 +12,7 @@
 #   sq WORKLOAD                SQ wave / wait / LDS counters of a feature kernel
 #   soak CLIPS [PASSES]        PASSES (20) full passes of cfg 4 at CLIPS per GPU; counts redone batches (a timed-out hand-off)
 #   stamps CLIPS [STAGE]       diagnostic build (LIB=<variant built with `build_variant.sh .. diag`> for another): phase stamps of one stage's waves
+#   abw "WORKLOADS"            every library under mimikit_amd/variants/ against the product library on bench.py workloads (dominant kernel's launch time)
 #   ab CLIPS_A CLIPS_B [STEPS] every library under mimikit_amd/variants/ (scripts/build_variant.sh) against the product library: us per AR step of
 #                              scripts/bpipe_check.py.  Variants are loaded BY PATH (MMK_DIAG_LIB=<file>): the product library is never overwritten
 export TMPDIR=/tmp
@@ -42,7 +43,8 @@ line)
   ;;
 lines)
   for wl in wavenet_cfg2 srnn_cfg3 s2s_cfg5 mulaw stft istft gla; do
-    timeout 600 python bench.py --workload $wl --no-others > $O/bench_$wl.json 2> $O/bench_$wl.err
+    case $wl in mulaw|stft|istft) k="--steps 20 --warmup 5";; *) k="";; esac      # (sub-millisecond passes: two of them would time the launch overhead)
+    timeout 600 python bench.py --workload $wl --no-others $k > $O/bench_$wl.json 2> $O/bench_$wl.err
     echo "$wl exit $?: $(fields $O/bench_$wl.json)"
   done
   for n in 64 128 256; do
@@ -110,6 +112,20 @@ ab)
       r1=$(MMK_DIAG_LIB=$lib timeout 300 python scripts/bpipe_check.py --only ${ONLY:-bpipe} --clips $a --steps $steps 2>/dev/null | grep -o "[0-9.]* us per step")
       r2=$(MMK_DIAG_LIB=$lib timeout 300 python scripts/bpipe_check.py --only ${ONLY:-bpipe} --clips $b --steps $steps 2>/dev/null | grep -o "[0-9.]* us per step")
       echo "$(basename $v) $a: $r1 | $b: $r2" | tee -a $O/ab.log
+    done
+  done
+  ;;
+abw)
+  # every variant against the product library on bench workloads: scripts/gpu_evidence.sh abw "stft istft gla"
+  for rep in 1 2; do
+    for v in mimikit_amd/libmmk_hip.so mimikit_amd/variants/libmmk_*.so; do
+      lib=$([ $v = mimikit_amd/libmmk_hip.so ] && echo "" || echo $R/$v)
+      line="$(basename $v)"
+      for wl in $1; do
+        r=$(MMK_DIAG_LIB=$lib timeout 300 python bench.py --workload $wl --steps 5 --warmup 2 --no-cpu-baseline --no-others 2>/dev/null | grep -o '"avg_launch_us": [0-9.]*\|"us_per_step[a-z_]*": [0-9.]*\|"us_per_generate_step": [0-9.]*' | head -2 | tr '\n' ' ')
+        line="$line | $wl: $r"
+      done
+      echo "$line" | tee -a $O/abw.log
     done
   done
   ;;
