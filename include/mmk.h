@@ -32,8 +32,19 @@
 extern "C" {
 #endif
 
-#define MMK_ABI_VERSION 3   /* 2: exec_mode in the WaveNet / SampleRNN / Seq2Seq configs, mmk_*_sync_status for all three, mmk_*_inject_sync_error;
-                              * 3: `tuning` text at the end of the three configs - the library reads no environment variable */
+#define MMK_ABI_VERSION 4   /* 2: exec_mode in the WaveNet / SampleRNN / Seq2Seq configs, mmk_*_sync_status for all three, mmk_*_inject_sync_error;
+                              * 3: `tuning` text at the end of the three configs - the library reads no environment variable;
+                              * 4: act_f / act_g in the WaveNet config */
+/* activations (mimikit/modules/activations.py: ActivationEnum, the members the HIP path evaluates) */
+#define MMK_ACT_IDENTITY 0
+#define MMK_ACT_TANH 1
+#define MMK_ACT_SIGMOID 2
+#define MMK_ACT_MISH 3
+#define MMK_ACT_ABS 4
+#define MMK_ACT_RELU 5
+#define MMK_ACT_SOFTPLUS 6
+#define MMK_ACT_SIN 7
+#define MMK_ACT_COS 8
 #define MMK_TUNING_CHARS 256
 
 #define MMK_OK 0
@@ -198,7 +209,9 @@ typedef struct mmk_wavenet_config {
   int32_t cond_q_levels[MMK_MAX_COND];     /* > 0: input 1+j is a stream of class indices through an EmbeddingIO (no bias) of that many
                                             * classes - cond[j] of the calls below is then int64 (batch, T); 0: fp32 features through a LinearIO */
   int32_t bias;                            /* Config.bias */
-  int32_t gated;                           /* act_g is not None (Sigmoid) ; act_f = Tanh */
+  int32_t gated;                           /* act_g is not None */
+  int32_t act_f, act_g;                    /* Config.act_f / act_g as MMK_ACT_* codes (act_g ignored when gated == 0).  Anything but Tanh / Sigmoid runs
+                                            * on the launch path (the persistent kernels and the prefill have the default gate built in) */
   int32_t head_kind;                       /* 0: MLPIO + categorical sampler, 1: linear + Abs (magspec), 2: linear */
   int32_t mlp_hidden;                      /* MLPIO.hidden_dim */
   int32_t mlp_n_hidden;                    /* MLPIO.n_hidden_layers */

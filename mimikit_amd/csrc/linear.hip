@@ -161,7 +161,7 @@ __global__ __launch_bounds__(1024) void linear_kernel(const LinearArgs a) {
         const int m = mbase + j;
         if (!(n & 1) && n < a.N && m < a.M) {
           float* o = (float*)a.out.base + ooff + (int64_t)m * a.out_ld + (n >> 1);
-          *o = tanhf(f) * sigmoidf_(g);
+          *o = apply_act(f, a.act) * apply_act(g, a.act2);      // act_f(z_f) act_g(z_g), wavenet_v2.py:151 (Tanh / Sigmoid: tanhf, the exact sigmoid - as before)
         }
       }
     } else if (a.epilogue == EPI_RES_SKIP) {

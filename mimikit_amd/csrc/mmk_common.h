@@ -95,7 +95,7 @@ __device__ __forceinline__ float mmk_rcp(float x) {
 #endif
 }
 
-enum Act : int32_t { ACT_NONE = 0, ACT_TANH = 1, ACT_SIGMOID = 2, ACT_MISH = 3, ACT_ABS = 4, ACT_RELU = 5 };
+enum Act : int32_t { ACT_NONE = 0, ACT_TANH = 1, ACT_SIGMOID = 2, ACT_MISH = 3, ACT_ABS = 4, ACT_RELU = 5, ACT_SOFTPLUS = 6, ACT_SIN = 7, ACT_COS = 8 };      // (include/mmk.h: MMK_ACT_*)
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 __device__ __forceinline__ float mishf_(float x) { return x * tanhf(log1pf(expf(x))); }
@@ -120,6 +120,9 @@ __device__ __forceinline__ float apply_act(float v, int act) {
     case ACT_MISH: return mishf_(v);
     case ACT_ABS: return fabsf(v);
     case ACT_RELU: return v > 0.f ? v : 0.f;
+    case ACT_SOFTPLUS: return v > 20.f ? v : log1pf(expf(v));      // nn.Softplus(beta=1, threshold=20)
+    case ACT_SIN: return sinf(v);
+    case ACT_COS: return cosf(v);
     default: return v;
   }
 }
@@ -158,7 +161,8 @@ struct LinearArgs {
   const int64_t* tau_ptr;
   int64_t tau_off;
   int32_t epilogue;
-  int32_t act;
+  int32_t act;          // EPI_STORE: of the output; EPI_GATE: act_f, of the f columns
+  int32_t act2;         // EPI_GATE: act_g, of the g columns
   // EPI_STORE
   Addr out; int64_t out_ld;
   Addr add; int64_t add_ld; int32_t has_add; int32_t accumulate;

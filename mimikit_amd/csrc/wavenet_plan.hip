@@ -390,7 +390,7 @@ static int derive(mmk_wavenet_plan* p) {
   // channels.  Anything else stays on the per-layer launch path.
   const char* env = p->tune.get("MMK_WN_PERSISTENT");
   bool ok = !(env && env[0] == '0') && c.exec_mode != 1;     // (exec_mode 1: the caller asks for the per-layer launch path)
-  ok = ok && c.gated && c.q_levels > 0 && c.head_kind == 0 && c.mlp_n_hidden == 0 && c.n_cond <= 2;
+  ok = ok && c.gated && c.act_f == ACT_TANH && c.act_g == ACT_SIGMOID && c.q_levels > 0 && c.head_kind == 0 && c.mlp_n_hidden == 0 && c.n_cond <= 2;      // (the default gate is built into the persistent kernels and the prefill)
   ok = ok && !multi;            // class conditioning streams and further targets: the launch path (a step's conditioning row depends on the step before)
   ok = ok && p->C % 32 == 0 && p->C <= 256 && p->S == p->C && c.residuals_dim == p->C && !c.layerwise_inputs && !c.with_affine_residuals;
   for (int l = 0; l < p->L; ++l) ok = ok && (p->has_res[l] != 0) == (l != p->L - 1);   // (reverse_layer_order: launch path)
@@ -552,6 +552,7 @@ static int derive(mmk_wavenet_plan* p) {
 
 extern "C" int mmk_wavenet_plan_create(const mmk_wavenet_config* cfg, mmk_wavenet_plan** out) {
   if (!cfg || !out) return fail(MMK_ERR_INVALID, "wavenet_plan_create: null argument");
+  if (cfg->act_f < 0 || cfg->act_f > ACT_COS || cfg->act_g < 0 || cfg->act_g > ACT_COS) return fail(MMK_ERR_INVALID, "wavenet_plan_create: act_f / act_g outside MMK_ACT_*");
   mmk_wavenet_plan* p = new mmk_wavenet_plan();
   p->cfg = *cfg;
   p->tune.parse(cfg->tuning, sizeof(cfg->tuning));
@@ -984,7 +985,8 @@ static int emit_step(mmk_wavenet_plan* p, const WnCall& call, int64_t tau_off, b
       }
       a.M = M; a.tau_ptr = p->tau; a.tau_off = tau_off;
       a.epilogue = c.gated ? EPI_GATE : EPI_STORE;
-      a.act = c.gated ? ACT_NONE : ACT_TANH;
+      a.act = c.act_f;                      // act_f(z_f) act_g(z_g) / act_f(z) (wavenet_v2.py:151, :163)
+      a.act2 = c.act_g;
       a.out = p->y_addr(l); a.out_ld = C;
       g_prof_tag = 0;
       MMK_TRY(launch_linear(a, st));

@@ -24,8 +24,8 @@ if DIAGNOSTIC and _DIAG != "1" and not _DIAG.endswith(".so"):
     raise ImportError(f"MMK_DIAG_LIB={_DIAG!r}: expected 1 (the diagnostic build) or the path of a library variant (*.so)")
 
 MAX_LAYERS, MAX_COND, MAX_TIERS, MAX_STREAMS = 128, 4, 8, 4
-ABI_VERSION = 3          # include/mmk.h: MMK_ABI_VERSION (bumped whenever a config struct or a signature changes)
-ACT = {"none": 0, None: 0, "Identity": 0, "Tanh": 1, "Sigmoid": 2, "Mish": 3, "Abs": 4, "ReLU": 5}
+ABI_VERSION = 4          # include/mmk.h: MMK_ABI_VERSION (bumped whenever a config struct or a signature changes)
+ACT = {"none": 0, None: 0, "Identity": 0, "Tanh": 1, "Sigmoid": 2, "Mish": 3, "Abs": 4, "ReLU": 5, "Softplus": 6, "Sin": 7, "Cos": 8}      # include/mmk.h: MMK_ACT_*
 
 i32, i64, f32, vp, cp = C.c_int32, C.c_int64, C.c_float, C.c_void_p, C.c_char_p
 
@@ -58,7 +58,7 @@ class WaveNetConfig(C.Structure):
         ("n_layers", i32), ("kernel_size", i32 * MAX_LAYERS), ("dilation", i32 * MAX_LAYERS),
         ("q_levels", i32), ("in_dim", i32), ("dim_dilated", i32), ("residuals_dim", i32), ("skips_dim", i32),
         ("n_cond", i32), ("cond_in_dim", i32 * MAX_COND), ("cond_dim", i32 * MAX_COND), ("cond_q_levels", i32 * MAX_COND),
-        ("bias", i32), ("gated", i32), ("head_kind", i32), ("mlp_hidden", i32), ("mlp_n_hidden", i32),
+        ("bias", i32), ("gated", i32), ("act_f", i32), ("act_g", i32), ("head_kind", i32), ("mlp_hidden", i32), ("mlp_n_hidden", i32),
         ("out_dim", i32), ("learn_temp", i32), ("min_temp", f32), ("max_batch", i32),
         ("res_explicit", i32), ("layer_has_res", i32 * MAX_LAYERS), ("layerwise_inputs", i32), ("exec_mode", i32), ("with_affine_residuals", i32),
         ("n_targets", i32), ("x_out_dim", i32 * MAX_STREAMS), ("x_mlp_hidden", i32 * MAX_STREAMS), ("x_mlp_n_hidden", i32 * MAX_STREAMS),

@@ -308,8 +308,8 @@ class WaveNet(ARM, nn.Module):
             unsupported.append("stride != 1")
         if cfg.with_affine_residuals and (cfg.pad_side != 0 or cfg.layerwise_inputs or (cfg.act_g is None and cfg.dims_1x1)):
             unsupported.append("with_affine_residuals together with pad_side, layerwise_inputs, or conditioning inputs of an ungated network")
-        if str(cfg.act_f) != "Tanh" or (cfg.act_g is not None and str(cfg.act_g) != "Sigmoid"):
-            unsupported.append("activations other than Tanh / Sigmoid")
+        if str(cfg.act_f) not in native.ACT or (cfg.act_g is not None and str(cfg.act_g) not in native.ACT):
+            unsupported.append("act_f / act_g other than " + " / ".join(k for k in native.ACT if isinstance(k, str) and k != "none"))
         if len(cfg.dims_dilated) != 1:
             unsupported.append("more than one dilated path")
         n_tgt = len(io.targets)
@@ -351,6 +351,7 @@ class WaveNet(ARM, nn.Module):
                 continue
             c.cond_in_dim[j], c.cond_dim[j] = lin.in_features, lin.out_features
         c.bias, c.gated = int(cfg.bias), int(cfg.act_g is not None)
+        c.act_f, c.act_g = native.ACT.get(str(cfg.act_f), 0), native.ACT.get(str(cfg.act_g), 0) if cfg.act_g is not None else 0
         head = self.output_modules[0]
         if isinstance(head, OutputWrapper) and isinstance(head.estimator[0], MLP) and len(head.estimator) == 1:
             mlp: MLP = head.estimator[0]

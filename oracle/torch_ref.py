@@ -213,12 +213,19 @@ def wavenet_rf(kernels: Sequence[int], dilations: Sequence[int]) -> int:
     return sum((k - 1) * d for k, d in zip(kernels, dilations)) + 1
 
 
+# the members of mimikit's ActivationEnum (modules/activations.py:25-39) that are plain element-wise functions: nn.<name>() of torch, Abs / Sin / Cos of
+# the reference's own three-line modules (:66-78)
+ACTIVATIONS = {"Tanh": torch.tanh, "Sigmoid": torch.sigmoid, "Mish": F.mish, "ReLU": torch.relu, "Softplus": F.softplus, "Identity": lambda v: v,
+               "Abs": torch.abs, "Sin": torch.sin, "Cos": torch.cos}
+
+
 def wavenet_window_forward(sd: SD, inputs: Tuple[torch.Tensor, ...], kernels: Sequence[int], dilations: Sequence[int],
                            n_cond: int = 0, has_skips: bool = True, residuals: bool = True,
                            n_mlp_hidden: int = 0, embedding: bool = True, groups: int = 1, head: str = "mlp",
                            gated: bool = True, layerwise_inputs: bool = False,
                            res_layers: Optional[Sequence[bool]] = None, affine: bool = False,
-                           cond_classes: Optional[Sequence[int]] = None, heads_n_hidden: Optional[Sequence[int]] = None):
+                           cond_classes: Optional[Sequence[int]] = None, heads_n_hidden: Optional[Sequence[int]] = None,
+                           act_f: str = "Tanh", act_g: str = "Sigmoid"):
     """Full-window eval forward (wavenet_v2.py:276-293 with WNLayer.forward :131-176, pad_side=0):
     returns the RAW head outputs (B, 1, q+1) of the FIRST computable position (eval_slice, :273).
     ``groups`` applies to the dilated convolutions only (:93); ``head`` "linear" / "linear_abs" is the
@@ -231,7 +238,9 @@ def wavenet_window_forward(sd: SD, inputs: Tuple[torch.Tensor, ...], kernels: Se
     residual sum see the transformed input - and, without gated units, every conditioning input c becomes aff(c) + c.
     ``cond_classes[j]`` > 0: conditioning input j is a stream of class indices through an EmbeddingIO (from_config :231-234 builds
     the module of EVERY input from its spec); ``heads_n_hidden`` (one entry per target): the network has that many output modules
-    (:240-243) and the function returns the tuple of their raw outputs (:293)."""
+    (:240-243) and the function returns the tuple of their raw outputs (:293).  ``act_f`` / ``act_g``: Config.act_f / act_g by their
+    ActivationEnum names (modules/activations.py:25-39; WNLayer.forward :151 / :163 applies whatever modules they name)."""
+    f_act, g_act = ACTIVATIONS[act_f], ACTIVATIONS[act_g]
     if embedding:
         h = F.embedding(inputs[0], sd["input_modules.0.0.weight"])
     else:
@@ -267,9 +276,9 @@ def wavenet_window_forward(sd: SD, inputs: Tuple[torch.Tensor, ...], kernels: Se
         z = z + cond_sum
         if gated:
             z_f, z_g = torch.chunk(z, 2, dim=1)
-            y = torch.tanh(z_f) * torch.sigmoid(z_g)
+            y = f_act(z_f) * g_act(z_g)
         else:
-            y = torch.tanh(z)
+            y = f_act(z)
         if has_skips:
             s = F.conv1d(y, sd[p + "conv_skip.weight"], sd.get(p + "conv_skip.bias"))
             skips = s if skips is None else s + skips[:, :, cause:]

@@ -232,6 +232,49 @@ def make_wavenet_options():
     save("wavenet_options.npz", **arrays)
 
 
+WAVENET_ACTS = {
+    "mish_tanh": dict(act_f="Mish", act_g="Tanh"),
+    "relu_nogate": dict(act_f="ReLU", act_g=None),
+    "sin_sig_cond": dict(act_f="Sin", act_g="Sigmoid", cond=True),
+    "softplus_abs": dict(act_f="Softplus", act_g="Abs"),
+    "id_cos_noskip": dict(act_f="Identity", act_g="Cos", skips_dim=None),
+    "abs_nogate_cond": dict(act_f="Abs", act_g=None, cond=True),
+}
+
+
+def make_wavenet_acts():
+    """Config.act_f / act_g other than Tanh / Sigmoid (wavenet_v2.py:198-199; WNLayer.forward :151, :163): 16 free-running steps through the
+    reference's loop per case, as make_wavenet_options"""
+    g = torch.Generator().manual_seed(31)
+    arrays = {}
+    for tag, kw in WAVENET_ACTS.items():
+        kw = dict(kw)
+        io = ref.IOSpec.mulaw_io(ref.IOSpec.MuLawIOConfig(input_module_type="embedding", mlp_dim=32))
+        cond = kw.pop("cond", False)
+        if cond:
+            mag = ref.functionals.MagSpec(22, 4, center=False)
+            ext = ref.extractor.Extractor("signal", ref.functionals.FileToSignal(16000))
+            io = ref.IOSpec(inputs=(io.inputs[0], ref.io_spec.InputSpec("signal", mag, ref.io.LinearIO()).bind_to(ext)), targets=io.targets)
+            kw["dims_1x1"] = (8,)
+        kw.setdefault("skips_dim", 16)
+        cfg = ref.WaveNet.Config(io_spec=io, blocks=(3, 2), dims_dilated=(16,), residuals_dim=16, **kw)
+        net = ref.WaveNet.from_config(cfg).eval()
+        load_recipe(net, seed=200 + len(tag), gain=1.5)
+        rf = net.rf
+        n = 16
+        prompt = torch.randint(0, 256, (3, rf + 4), generator=g)
+        prompts = (prompt,)
+        if cond:
+            c = torch.rand(3, rf + 4, 12, generator=g)
+            prompts = (prompt, c)
+            arrays[f"{tag}_cond"] = c
+        log, h = capture_raw(net)
+        out = run_loop(net, prompts, n)
+        h.remove()
+        arrays.update({f"{tag}_prompt": prompt, f"{tag}_out": out[0], f"{tag}_raw": torch.cat(log, 1)})
+    save("wavenet_acts.npz", **arrays)
+
+
 def make_freqnet():
     """WaveNet over magnitude frames (demos/freqnet.py:34-63 at reduced size): linear frame input and output, no residual
     and no skip path, grouped dilated convolutions"""
@@ -559,6 +602,7 @@ if __name__ == "__main__":
     make_istft()
     make_wavenet()
     make_wavenet_options()
+    make_wavenet_acts()
     make_freqnet()
     make_wavenet_padded()
     make_srnn()

@@ -81,6 +81,34 @@ WAVENET_OPTIONS = {       # tests/golden/make_golden.py: make_wavenet_options
 }
 
 
+WAVENET_ACTS = {          # tests/golden/make_golden.py: make_wavenet_acts
+    "mish_tanh": dict(act_f="Mish", act_g="Tanh"),
+    "relu_nogate": dict(act_f="ReLU", act_g=None),
+    "sin_sig_cond": dict(act_f="Sin", act_g="Sigmoid", cond=True),
+    "softplus_abs": dict(act_f="Softplus", act_g="Abs"),
+    "id_cos_noskip": dict(act_f="Identity", act_g="Cos", skips_dim=None),
+    "abs_nogate_cond": dict(act_f="Abs", act_g=None, cond=True),
+}
+
+
+def wavenet_act(tag):
+    """the network of one wavenet_acts.npz case and the matching oracle arguments"""
+    kw = dict(WAVENET_ACTS[tag])
+    io = mu_emb(mlp_dim=32)
+    cond = kw.pop("cond", False)
+    if cond:
+        ext = mmk.Extractor("signal", mmk.FileToSignal(16000))
+        io = mmk.IOSpec(inputs=(io.inputs[0], mmk.InputSpec("signal", mmk.MagSpec(22, 4, center=False), mmk.LinearIO()).bind_to(ext)),
+                        targets=io.targets)
+        kw["dims_1x1"] = (8,)
+    kw.setdefault("skips_dim", 16)
+    net = mmk.WaveNet.from_config(mmk.WaveNet.Config(io_spec=io, blocks=(3, 2), dims_dilated=(16,), residuals_dim=16, **kw))
+    sd = load_recipe(net, seed=200 + len(tag), gain=1.5)
+    arch = dict(kernels=[2] * 5, dilations=[1, 2, 4, 1, 2], has_skips=kw["skips_dim"] is not None, residuals=True,
+                gated=kw["act_g"] is not None, n_cond=int(cond), act_f=kw["act_f"], act_g=kw["act_g"] or "Sigmoid")
+    return net.eval(), sd, arch
+
+
 def wavenet_option(tag):
     """the network of one wavenet_options.npz case and the matching oracle arguments"""
     kw = dict(WAVENET_OPTIONS[tag])

@@ -1462,6 +1462,43 @@ def test_wavenet_options_match_reference_golden(device, tag):
     assert bool(((got[:, p2.size(1):] == want[:, p2.size(1):]) | ~ok).all()) and float(ok.float().mean()) > 0.9
 
 
+@pytest.mark.parametrize("tag", list(H.WAVENET_ACTS))
+def test_wavenet_activations_match_reference_golden(device, tag):
+    """Config.act_f / act_g other than Tanh / Sigmoid on the HIP path (the launch path: the persistent kernels have the default gate built in) against the
+    reference's loop: classes bit-exact, raw head outputs within the logit tolerance; then a batch of 9 against the oracle, teacher-forced on the device's
+    history"""
+    g = H.golden("wavenet_acts.npz")
+    net, sd, arch = H.wavenet_act(tag)
+    n_cond = arch.pop("n_cond")
+    prompt = H.T(g[f"{tag}_prompt"])
+    prompts = (prompt,) if not n_cond else (prompt, H.T(g[f"{tag}_cond"]))
+    out = run_loop(net, prompts, 16)
+    assert torch.equal(out[0].cpu(), H.T(g[f"{tag}_out"]))
+    assert not net._plan.persistent
+    assert torch.allclose(net._plan.last_logits(3).cpu(), H.T(g[f"{tag}_raw"])[:, -1], **LOGIT_TOL)
+    net = net.to(device)
+    gen = torch.Generator().manual_seed(len(tag))
+    rf, B, n = net.rf, 9, 24
+    p2 = torch.randint(0, 256, (B, rf + 2), generator=gen)
+    cond = (torch.rand(B, rf + 2 + n, 12, generator=gen),) if n_cond else ()
+    idx = torch.cat([p2, torch.zeros(B, n, dtype=torch.int64)], 1).to(device)
+    net.generate_block((idx, *[c.to(device) for c in cond]), p2.size(1), n)
+    net.after_generate((idx,), None)
+    got = idx.cpu()
+    want, raw = O.wavenet_generate(sd, p2, cond, n, keep_logits=True, forced=got, **arch)
+    ok = H.margin_ok(raw.numpy())
+    assert bool(((got[:, p2.size(1):] == want[:, p2.size(1):]) | ~ok).all()) and float(ok.float().mean()) > 0.9
+
+
+def test_wavenet_refuses_activations_it_does_not_evaluate(device):
+    """PhaseA / GLU / Softmax and the like (modules/activations.py:25-39) are named in the refusal, not run as something else"""
+    io = H.mu_emb(mlp_dim=32)
+    net = mmk.WaveNet.from_config(mmk.WaveNet.Config(io_spec=io, blocks=(2,), dims_dilated=(16,), residuals_dim=16, skips_dim=16, act_g="Softmax")).eval().to(device)
+    idx = torch.zeros(2, net.rf + 4, dtype=torch.int64, device=device)
+    with pytest.raises(NotImplementedError, match="act_f / act_g"):
+        net.generate_block((idx,), net.rf, 4)
+
+
 @pytest.mark.parametrize("tag", list(H.SRNN_OPTIONS))
 def test_sample_rnn_options_match_reference_golden(device, tag):
     """stacked recurrent layers per tier, deeper MLP heads, inputs_mode mean / static_mix (one input), h0_init='ones' on the HIP

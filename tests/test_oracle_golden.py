@@ -250,6 +250,25 @@ def test_wavenet_options_oracle_matches_reference(tag):
     assert bool(H.margin_ok(g[f"{tag}_raw"]).all())
 
 
+@pytest.mark.parametrize("tag", list(H.WAVENET_ACTS))
+def test_wavenet_activations_oracle_matches_reference(tag):
+    """Config.act_f / act_g other than Tanh / Sigmoid (Mish, ReLU, Sin, Softplus, Identity, Abs for f; Tanh, Abs, Cos, none for g): the oracle's loop
+    against the reference's (classes exact, raw head outputs 1e-5) on the committed fixture"""
+    g = H.golden("wavenet_acts.npz")
+    _, sd, arch = H.wavenet_act(tag)
+    n_cond = arch.pop("n_cond")
+    prompt = H.T(g[f"{tag}_prompt"])
+    n = 16
+    cond = ()
+    if n_cond:
+        c = H.T(g[f"{tag}_cond"])
+        cond = (torch.cat([c, torch.zeros(c.size(0), n, c.size(2))], 1),)     # the loop leaves blanks in the generated region
+    out, raw = O.wavenet_generate(sd, prompt, cond, n, keep_logits=True, **arch)
+    assert torch.equal(out, H.T(g[f"{tag}_out"]))
+    assert torch.allclose(raw, H.T(g[f"{tag}_raw"]), rtol=1e-5, atol=1e-5)
+    assert bool(H.margin_ok(g[f"{tag}_raw"]).all())
+
+
 @pytest.mark.parametrize("tag", list(H.SRNN_OPTIONS))
 def test_sample_rnn_options_oracle_matches_reference(tag):
     """stacked recurrent layers (n_rnn 2 / 3), deeper MLP head, inputs_mode mean / static_mix, h0_init ones"""
