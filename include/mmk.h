@@ -34,7 +34,7 @@ extern "C" {
 
 #define MMK_ABI_VERSION 4   /* 2: exec_mode in the WaveNet / SampleRNN / Seq2Seq configs, mmk_*_sync_status for all three, mmk_*_inject_sync_error;
                               * 3: `tuning` text at the end of the three configs - the library reads no environment variable;
-                              * 4: act_f / act_g in the WaveNet config */
+                              * 4: act_f / act_g in the WaveNet config, mlp_act in all three */
 /* activations (mimikit/modules/activations.py: ActivationEnum, the members the HIP path evaluates) */
 #define MMK_ACT_IDENTITY 0
 #define MMK_ACT_TANH 1
@@ -215,6 +215,7 @@ typedef struct mmk_wavenet_config {
   int32_t head_kind;                       /* 0: MLPIO + categorical sampler, 1: linear + Abs (magspec), 2: linear */
   int32_t mlp_hidden;                      /* MLPIO.hidden_dim */
   int32_t mlp_n_hidden;                    /* MLPIO.n_hidden_layers */
+  int32_t mlp_act;                         /* MLPIO.activation of every MLP head as an MMK_ACT_* code (modules/io.py:205: Mish); anything else: the launch path */
   int32_t out_dim;                         /* q_levels of the target, or n_bins */
   int32_t learn_temp;                      /* MLP.learn_temperature */
   float min_temp;
@@ -305,6 +306,7 @@ typedef struct mmk_srnn_config {
   int32_t h0_ones;                         /* h0_init == "ones" */
   int32_t q_levels;
   int32_t mlp_hidden, mlp_n_hidden, learn_temp;
+  int32_t mlp_act;                         /* MLPIO.activation of every MLP head as an MMK_ACT_* code (Mish; anything else: the kernels in turns) */
   float min_temp;
   int32_t max_batch;
   int32_t n_rnn;                           /* Config.n_rnn: stacked recurrent layers per tier (:65, nn.LSTM / GRU num_layers); 0 = 1 */
@@ -381,6 +383,7 @@ typedef struct mmk_s2s_config {
   int32_t head_kind;                       /* 0: Linear [+ Abs] to out_dim bins; 1: MLP (networks/mlp.py:42-63) over out_dim
                                               classes, then the argmax of CategoricalSampler (modules/targets.py:43-44) */
   int32_t mlp_hidden, mlp_n_hidden;        /* head_kind 1: width, number of extra hidden blocks (0 .. 4) */
+  int32_t mlp_act;                         /* head_kind 1: MLPIO.activation as an MMK_ACT_* code (Mish) */
   int32_t learn_temp;                      /* head_kind 1: one more output, logits / max(sigmoid(it), min_temp) */
   float min_temp;
   int32_t exec_mode;                       /* 0 = the library chooses (one resident launch per bi-LSTM layer where its workgroups are

@@ -629,7 +629,7 @@ static int s2s_step(mmk_s2s_plan* p, int M, const S2SIo& io, int n_out, hipStrea
       const bool last = i + 1 == p->mlp.size();
       float* o = last ? p->logits : p->hid[i & 1];
       const int64_t o_ld = last ? p->logits_ld : c.mlp_hidden;
-      MMK_TRY(plain_linear(p->mlp[i], hx, hx_ld, rows, o, o_ld, last ? ACT_NONE : ACT_MISH, st, p->gemm_partial, p->gemm_ksplit));   // MLPIO's default activation (modules/io.py:205)
+      MMK_TRY(plain_linear(p->mlp[i], hx, hx_ld, rows, o, o_ld, last ? (int)ACT_NONE : c.mlp_act, st, p->gemm_partial, p->gemm_ksplit));   // MLPIO.activation (modules/io.py:205: Mish by default)
       hx = o;
       hx_ld = o_ld;
     }

@@ -273,7 +273,7 @@ static int derive(mmk_srnn_plan* p) {
     p->xheads.push_back(h);
   }
   const char* fenv = p->tune.get("MMK_SRNN_FUSED");
-  p->fused_bottom = !(fenv && fenv[0] == '0') && c.mlp_n_hidden == 0 &&
+  p->fused_bottom = !(fenv && fenv[0] == '0') && c.mlp_n_hidden == 0 && c.mlp_act == ACT_MISH &&      // (the fused and resident kernels have Mish built in)
                     srnn_bottom_supported(p->H, c.mlp_hidden, c.q_levels + (c.learn_temp ? 1 : 0), c.frame_size[c.n_tiers - 1]);
   p->fused_gru = !(fenv && fenv[0] == '0') && (c.rnn_kind == 1 || c.rnn_kind == 0);   // GRU or LSTM tiers
   for (auto& t : p->tiers) p->fused_gru = p->fused_gru && srnn_gru_supported(p->H, t.fs, c.rnn_kind == 0);
@@ -873,7 +873,7 @@ static int emit_step(mmk_srnn_plan* p, const SrnnCall& call, int64_t tau_off, in
       mlp[i].fill(a);
       a.seg[0].x = addr_static(x); a.seg[0].ld = x_ld;
       a.M = M; a.tau_ptr = p->tau; a.tau_off = tau_off;
-      a.epilogue = EPI_STORE; a.act = last ? ACT_NONE : ACT_MISH;
+      a.epilogue = EPI_STORE; a.act = last ? (int)ACT_NONE : c.mlp_act;      // MLPIO.activation (modules/io.py:205)
       float* o = last ? logits : p->hid[i & 1];
       a.out = addr_static(o);
       a.out_ld = last ? logits_ld : hidden;

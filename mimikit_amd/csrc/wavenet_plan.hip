@@ -390,7 +390,7 @@ static int derive(mmk_wavenet_plan* p) {
   // channels.  Anything else stays on the per-layer launch path.
   const char* env = p->tune.get("MMK_WN_PERSISTENT");
   bool ok = !(env && env[0] == '0') && c.exec_mode != 1;     // (exec_mode 1: the caller asks for the per-layer launch path)
-  ok = ok && c.gated && c.act_f == ACT_TANH && c.act_g == ACT_SIGMOID && c.q_levels > 0 && c.head_kind == 0 && c.mlp_n_hidden == 0 && c.n_cond <= 2;      // (the default gate is built into the persistent kernels and the prefill)
+  ok = ok && c.gated && c.act_f == ACT_TANH && c.act_g == ACT_SIGMOID && c.mlp_act == ACT_MISH && c.q_levels > 0 && c.head_kind == 0 && c.mlp_n_hidden == 0 && c.n_cond <= 2;      // (the default gate is built into the persistent kernels and the prefill)
   ok = ok && !multi;            // class conditioning streams and further targets: the launch path (a step's conditioning row depends on the step before)
   ok = ok && p->C % 32 == 0 && p->C <= 256 && p->S == p->C && c.residuals_dim == p->C && !c.layerwise_inputs && !c.with_affine_residuals;
   for (int l = 0; l < p->L; ++l) ok = ok && (p->has_res[l] != 0) == (l != p->L - 1);   // (reverse_layer_order: launch path)
@@ -552,7 +552,8 @@ static int derive(mmk_wavenet_plan* p) {
 
 extern "C" int mmk_wavenet_plan_create(const mmk_wavenet_config* cfg, mmk_wavenet_plan** out) {
   if (!cfg || !out) return fail(MMK_ERR_INVALID, "wavenet_plan_create: null argument");
-  if (cfg->act_f < 0 || cfg->act_f > ACT_COS || cfg->act_g < 0 || cfg->act_g > ACT_COS) return fail(MMK_ERR_INVALID, "wavenet_plan_create: act_f / act_g outside MMK_ACT_*");
+  if (cfg->act_f < 0 || cfg->act_f > ACT_COS || cfg->act_g < 0 || cfg->act_g > ACT_COS || cfg->mlp_act < 0 || cfg->mlp_act > ACT_COS)
+    return fail(MMK_ERR_INVALID, "wavenet_plan_create: act_f / act_g / mlp_act outside MMK_ACT_*");
   mmk_wavenet_plan* p = new mmk_wavenet_plan();
   p->cfg = *cfg;
   p->tune.parse(cfg->tuning, sizeof(cfg->tuning));
@@ -1028,7 +1029,7 @@ static int emit_step(mmk_wavenet_plan* p, const WnCall& call, int64_t tau_off, b
       a.seg[0].ld = x_ld;
       a.M = M; a.tau_ptr = p->tau; a.tau_off = tau_off;
       a.epilogue = EPI_STORE;
-      a.act = last ? ACT_NONE : ACT_MISH;  // MLPIO default activation (modules/io.py:205)
+      a.act = last ? (int)ACT_NONE : c.mlp_act;  // MLPIO.activation (modules/io.py:205: Mish unless the spec says otherwise)
       float* o = last ? p->logits : p->hid[i & 1];
       a.out = addr_static(o);
       a.out_ld = last ? p->logits_ld : c.mlp_hidden;
@@ -1056,7 +1057,7 @@ static int emit_step(mmk_wavenet_plan* p, const WnCall& call, int64_t tau_off, b
         a.seg[0].ld = xk_ld;
         a.M = M; a.tau_ptr = p->tau; a.tau_off = tau_off;
         a.epilogue = EPI_STORE;
-        a.act = last ? ACT_NONE : ACT_MISH;
+        a.act = last ? (int)ACT_NONE : c.mlp_act;
         float* o = last ? h.logits : p->hid[i & 1];
         a.out = addr_static(o);
         a.out_ld = last ? h.logits_ld : h.hidden;

@@ -30,6 +30,37 @@ ACT = {"none": 0, None: 0, "Identity": 0, "Tanh": 1, "Sigmoid": 2, "Mish": 3, "A
 i32, i64, f32, vp, cp = C.c_int32, C.c_int64, C.c_float, C.c_void_p, C.c_char_p
 
 
+def mlp_head_problem(mlp, training: bool):
+    """what keeps an MLP head (networks/mlp.py:20-63) off the HIP path, or None: its activation must be one the kernels evaluate (ACT), its Linears need their
+    bias, and Dropout / Dropout1d modules are identities only in eval mode (where the generate loop runs a network, loops/generate.py)"""
+    if type(mlp.activation).__name__ not in ACT:
+        return f"MLP head activation {type(mlp.activation).__name__}"
+    if not mlp.bias:
+        return "MLP head without bias"
+    if (mlp.dropout or mlp.dropout1d) and training:
+        return "MLP head with dropout in training mode"
+    return None
+
+
+def mlp_act(mlp) -> int:
+    return ACT[type(mlp.activation).__name__]
+
+
+def mlp_linear_keys(sd: dict, prefix: str, mlp) -> dict:
+    """``fc`` of an MLP is Sequential(Linear, act, *dropouts, [Linear, act, *dropouts] * n, Linear) (networks/mlp.py:42-53): with dropout modules in it the
+    Linears sit at indices i (2 + n_dropouts), and the plans bind ``fc.{2 i}``.  Returns ``sd`` with the head's keys under the names the plans know."""
+    n_dp = int(mlp.dropout > 0) + int(mlp.dropout1d > 0)
+    if n_dp == 0:
+        return sd
+    out = {k: v for k, v in sd.items() if not k.startswith(prefix + "fc.")}
+    for i in range(mlp.n_hidden_layers + 2):
+        for leaf in ("weight", "bias"):
+            src = f"{prefix}fc.{i * (2 + n_dp)}.{leaf}"
+            if src in sd:
+                out[f"{prefix}fc.{2 * i}.{leaf}"] = sd[src]
+    return out
+
+
 class NativeError(RuntimeError):
     pass
 
@@ -58,7 +89,7 @@ class WaveNetConfig(C.Structure):
         ("n_layers", i32), ("kernel_size", i32 * MAX_LAYERS), ("dilation", i32 * MAX_LAYERS),
         ("q_levels", i32), ("in_dim", i32), ("dim_dilated", i32), ("residuals_dim", i32), ("skips_dim", i32),
         ("n_cond", i32), ("cond_in_dim", i32 * MAX_COND), ("cond_dim", i32 * MAX_COND), ("cond_q_levels", i32 * MAX_COND),
-        ("bias", i32), ("gated", i32), ("act_f", i32), ("act_g", i32), ("head_kind", i32), ("mlp_hidden", i32), ("mlp_n_hidden", i32),
+        ("bias", i32), ("gated", i32), ("act_f", i32), ("act_g", i32), ("head_kind", i32), ("mlp_hidden", i32), ("mlp_n_hidden", i32), ("mlp_act", i32),
         ("out_dim", i32), ("learn_temp", i32), ("min_temp", f32), ("max_batch", i32),
         ("res_explicit", i32), ("layer_has_res", i32 * MAX_LAYERS), ("layerwise_inputs", i32), ("exec_mode", i32), ("with_affine_residuals", i32),
         ("n_targets", i32), ("x_out_dim", i32 * MAX_STREAMS), ("x_mlp_hidden", i32 * MAX_STREAMS), ("x_mlp_n_hidden", i32 * MAX_STREAMS),
@@ -71,7 +102,7 @@ class SrnnConfig(C.Structure):
     _fields_ = [
         ("n_tiers", i32), ("frame_size", i32 * MAX_TIERS), ("hidden_dim", i32), ("rnn_kind", i32),
         ("rnn_bias", i32), ("h0_ones", i32), ("q_levels", i32), ("mlp_hidden", i32), ("mlp_n_hidden", i32),
-        ("learn_temp", i32), ("min_temp", f32), ("max_batch", i32), ("n_rnn", i32), ("exec_mode", i32),
+        ("learn_temp", i32), ("mlp_act", i32), ("min_temp", f32), ("max_batch", i32), ("n_rnn", i32), ("exec_mode", i32),
         ("n_inputs", i32), ("n_targets", i32), ("inputs_mode", i32), ("in_class", i32 * MAX_STREAMS),
         ("x_q_levels", i32 * MAX_STREAMS), ("x_mlp_hidden", i32 * MAX_STREAMS), ("x_mlp_n_hidden", i32 * MAX_STREAMS),
         ("x_learn_temp", i32 * MAX_STREAMS), ("x_min_temp", f32 * MAX_STREAMS),
@@ -84,7 +115,7 @@ class S2SConfig(C.Structure):
         ("in_dim", i32), ("out_dim", i32), ("model_dim", i32), ("hop", i32), ("enc_n_lstm", i32),
         ("dec_n_lstm", i32), ("out_abs", i32), ("max_batch", i32), ("enc_downsampling", i32), ("dec_upsampling", i32),
         ("enc_apply_residuals", i32), ("dec_apply_residuals", i32),
-        ("in_classes", i32), ("head_kind", i32), ("mlp_hidden", i32), ("mlp_n_hidden", i32), ("learn_temp", i32), ("min_temp", f32),
+        ("in_classes", i32), ("head_kind", i32), ("mlp_hidden", i32), ("mlp_n_hidden", i32), ("mlp_act", i32), ("learn_temp", i32), ("min_temp", f32),
         ("exec_mode", i32),
         ("tuning", C.c_char * TUNING_CHARS),
     ]

@@ -234,11 +234,10 @@ class Seq2SeqLSTMNetwork(ARMWithHidden, nn.Module):
             mlp = est[0] if isinstance(est, nn.Sequential) and len(est) == 1 else None
             if not isinstance(mlp, MLP) or not isinstance(getattr(head, "sampler", None), CategoricalSampler):
                 unsupported.append("discrete inputs with a head other than MLPIO + CategoricalSampler")
-            elif not isinstance(mlp.activation, nn.Mish) or mlp.dropout > 0 or mlp.dropout1d > 0 or not mlp.bias \
-                    or mlp.n_hidden_layers > 4:
-                unsupported.append("MLP head with a non-Mish activation, dropout, no bias or more than 4 hidden blocks")
+            elif native.mlp_head_problem(mlp, self.training) or mlp.n_hidden_layers > 4:
+                unsupported.append(native.mlp_head_problem(mlp, self.training) or "MLP head with more than 4 hidden blocks")
             else:
-                c.head_kind, c.mlp_hidden, c.mlp_n_hidden = 1, mlp.hidden_dim, mlp.n_hidden_layers
+                c.head_kind, c.mlp_hidden, c.mlp_n_hidden, c.mlp_act = 1, mlp.hidden_dim, mlp.n_hidden_layers, native.mlp_act(mlp)
                 c.learn_temp = int(mlp.learn_temperature)
                 c.min_temp = float(mlp.min_temp) if mlp.learn_temperature else 0.
                 c.out_dim = mlp.out_dim - int(mlp.learn_temperature)
@@ -288,6 +287,10 @@ class Seq2SeqLSTMNetwork(ARMWithHidden, nn.Module):
         # the host-side identity, which training steps and load_state_dict change)
         if rebuilt or self._weights.changed(self, content=refresh_weights):
             sd = self.state_dict()
+            for k, head in enumerate(getattr(self.output_module, "heads", [])):      # (a head with dropout modules between its Linears: the plan knows `fc.{2 i}`)
+                est = getattr(head, "estimator", None)
+                if isinstance(est, nn.Sequential) and len(est) == 1 and isinstance(est[0], MLP):
+                    sd = native.mlp_linear_keys(sd, f"output_module.heads.{k}.estimator.0.", est[0])
             self._plan.bind_state_dict(fold_weight_norm(sd) if any(k.endswith("_g") for k in sd) else sd)
             self._plan.commit()
             self._weights.committed(self)

@@ -228,8 +228,10 @@ class SampleRNN(ARMWithHidden, nn.Module):
         c = native.SrnnConfig()
         if isinstance(head, OutputWrapper) and isinstance(head.estimator[0], MLP) and len(head.estimator) == 1:
             mlp: MLP = head.estimator[0]
-            if not isinstance(mlp.activation, nn.Mish) or not mlp.bias or mlp.dropout or mlp.dropout1d:
-                unsupported.append("MLP head with a non-Mish activation, no bias or dropout")
+            if native.mlp_head_problem(mlp, self.training):
+                unsupported.append(native.mlp_head_problem(mlp, self.training))
+            else:
+                c.mlp_act = native.mlp_act(mlp)
             if mlp.n_hidden_layers > 4:
                 unsupported.append("n_mlp_layers > 4")
             c.mlp_hidden, c.mlp_n_hidden, c.learn_temp = mlp.hidden_dim, mlp.n_hidden_layers, int(mlp.learn_temperature)
@@ -248,8 +250,8 @@ class SampleRNN(ARMWithHidden, nn.Module):
                 unsupported.append(f"output module {k} of type {type(hk).__name__}")
                 continue
             mlp = hk.estimator[0]
-            if not isinstance(mlp.activation, nn.Mish) or not mlp.bias or mlp.dropout or mlp.dropout1d or mlp.n_hidden_layers > 4:
-                unsupported.append(f"target {k}: MLP head with a non-Mish activation, no bias, dropout or more than 4 hidden layers")
+            if native.mlp_head_problem(mlp, self.training) or mlp.n_hidden_layers > 4 or native.mlp_act(mlp) != c.mlp_act:
+                unsupported.append(f"target {k}: {native.mlp_head_problem(mlp, self.training) or 'more than 4 hidden layers, or another activation than target 0'}")
             c.x_mlp_hidden[k], c.x_mlp_n_hidden[k], c.x_learn_temp[k] = mlp.hidden_dim, mlp.n_hidden_layers, int(mlp.learn_temperature)
             c.x_q_levels[k] = mlp.out_dim - c.x_learn_temp[k]
             c.x_min_temp[k] = float(mlp.min_temp) if mlp.learn_temperature else 0.
@@ -287,6 +289,10 @@ class SampleRNN(ARMWithHidden, nn.Module):
         if rebuilt or refresh_weights:
             if rebuilt or self._weights.changed(self, content=True):      # re-pack only when a parameter changed since the last commit
                 sd = self.state_dict()
+                for k, head in enumerate(self.output_modules):      # (a head with dropout modules between its Linears: the plans know `fc.{2 i}`)
+                    est = getattr(head, "estimator", None)
+                    if isinstance(est, nn.Sequential) and len(est) == 1 and isinstance(est[0], MLP):
+                        sd = native.mlp_linear_keys(sd, f"output_modules.{k}.estimator.0.", est[0])
                 self._plan.bind_state_dict(fold_weight_norm(sd) if self._config.weight_norm else sd)
                 self._plan.commit()
                 self._weights.committed(self)

@@ -355,8 +355,10 @@ class WaveNet(ARM, nn.Module):
         head = self.output_modules[0]
         if isinstance(head, OutputWrapper) and isinstance(head.estimator[0], MLP) and len(head.estimator) == 1:
             mlp: MLP = head.estimator[0]
-            if not isinstance(mlp.activation, nn.Mish) or not mlp.bias or mlp.dropout or mlp.dropout1d:
-                unsupported.append("MLP head with a non-Mish activation, no bias or dropout")
+            if native.mlp_head_problem(mlp, self.training):
+                unsupported.append(native.mlp_head_problem(mlp, self.training))
+            else:
+                c.mlp_act = native.mlp_act(mlp)
             c.head_kind, c.mlp_hidden, c.mlp_n_hidden = 0, mlp.hidden_dim, mlp.n_hidden_layers
             c.learn_temp = int(mlp.learn_temperature)
             c.out_dim = mlp.out_dim - c.learn_temp
@@ -383,8 +385,8 @@ class WaveNet(ARM, nn.Module):
                 unsupported.append(f"target {k}: several targets need MLP heads with samplers")
                 continue
             mlp = hk.estimator[0]
-            if not isinstance(mlp.activation, nn.Mish) or not mlp.bias or mlp.dropout or mlp.dropout1d or mlp.n_hidden_layers > 4:
-                unsupported.append(f"target {k}: MLP head with a non-Mish activation, no bias, dropout or more than 4 hidden layers")
+            if native.mlp_head_problem(mlp, self.training) or mlp.n_hidden_layers > 4 or native.mlp_act(mlp) != c.mlp_act:
+                unsupported.append(f"target {k}: {native.mlp_head_problem(mlp, self.training) or 'more than 4 hidden layers, or another activation than target 0'}")
             c.x_mlp_hidden[k], c.x_mlp_n_hidden[k], c.x_learn_temp[k] = mlp.hidden_dim, mlp.n_hidden_layers, int(mlp.learn_temperature)
             c.x_out_dim[k] = mlp.out_dim - c.x_learn_temp[k]
             c.x_min_temp[k] = float(mlp.min_temp) if mlp.learn_temperature else 0.
@@ -427,6 +429,10 @@ class WaveNet(ARM, nn.Module):
         handed over as the block-diagonal dense matrix it is: the kernels multiply whole channel tiles, and a zero
         weight adds exactly 0 to a sum, so the result is that of the grouped convolution."""
         sd = self.state_dict()
+        for k, head in enumerate(self.output_modules):      # (a head with dropout modules between its Linears: the plans know `fc.{2 i}`)
+            est = getattr(head, "estimator", None)
+            if isinstance(est, nn.Sequential) and len(est) == 1 and isinstance(est[0], MLP):
+                sd = native.mlp_linear_keys(sd, f"output_modules.{k}.estimator.0.", est[0])
         groups = self._config.groups
         if groups == 1:
             return sd

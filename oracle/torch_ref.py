@@ -162,13 +162,23 @@ def resample(x: torch.Tensor, orig_sr: int, target_sr: int, lowpass_filter_width
 # ---------------------------------------------------------------------------
 # head: MLP with learned temperature + categorical sampler
 # ---------------------------------------------------------------------------
-def mlp_raw(sd: SD, prefix: str, x: torch.Tensor, n_hidden: int = 0) -> torch.Tensor:
-    """MLP.fc (networks/mlp.py:42-53): Linear, Mish, [Linear, Mish]*n, Linear -> (.., q+1) raw outputs"""
-    h = F.mish(F.linear(x, sd[prefix + "fc.0.weight"], sd[prefix + "fc.0.bias"]))
+# the members of mimikit's ActivationEnum (modules/activations.py:25-39) that are plain element-wise functions: nn.<name>() of torch, Abs / Sin / Cos of
+# the reference's own three-line modules (:66-78)
+ACTIVATIONS = {"Tanh": torch.tanh, "Sigmoid": torch.sigmoid, "Mish": F.mish, "ReLU": torch.relu, "Softplus": F.softplus, "Identity": lambda v: v,
+               "Abs": torch.abs, "Sin": torch.sin, "Cos": torch.cos}
+
+
+def mlp_raw(sd: SD, prefix: str, x: torch.Tensor, n_hidden: int = 0, act: str = "Mish", n_dropouts: int = 0) -> torch.Tensor:
+    """MLP.fc (networks/mlp.py:42-53): Linear, act, [Linear, act]*n, Linear -> (.., q+1) raw outputs.  ``act``: MLPIO.activation by its ActivationEnum name
+    (modules/io.py:205: Mish); ``n_dropouts``: Dropout / Dropout1d modules behind every activation (:36-40: identities in eval mode, but they shift the
+    Linears' indices in the Sequential - and with them the state_dict keys)"""
+    f = ACTIVATIONS[act]
+    step = 2 + n_dropouts
+    h = f(F.linear(x, sd[prefix + "fc.0.weight"], sd[prefix + "fc.0.bias"]))
     for i in range(n_hidden):
-        k = prefix + f"fc.{2 * (i + 1)}."
-        h = F.mish(F.linear(h, sd[k + "weight"], sd[k + "bias"]))
-    k = prefix + f"fc.{2 * (n_hidden + 1)}."
+        k = prefix + f"fc.{step * (i + 1)}."
+        h = f(F.linear(h, sd[k + "weight"], sd[k + "bias"]))
+    k = prefix + f"fc.{step * (n_hidden + 1)}."
     return F.linear(h, sd[k + "weight"], sd[k + "bias"])
 
 
@@ -213,19 +223,13 @@ def wavenet_rf(kernels: Sequence[int], dilations: Sequence[int]) -> int:
     return sum((k - 1) * d for k, d in zip(kernels, dilations)) + 1
 
 
-# the members of mimikit's ActivationEnum (modules/activations.py:25-39) that are plain element-wise functions: nn.<name>() of torch, Abs / Sin / Cos of
-# the reference's own three-line modules (:66-78)
-ACTIVATIONS = {"Tanh": torch.tanh, "Sigmoid": torch.sigmoid, "Mish": F.mish, "ReLU": torch.relu, "Softplus": F.softplus, "Identity": lambda v: v,
-               "Abs": torch.abs, "Sin": torch.sin, "Cos": torch.cos}
-
-
 def wavenet_window_forward(sd: SD, inputs: Tuple[torch.Tensor, ...], kernels: Sequence[int], dilations: Sequence[int],
                            n_cond: int = 0, has_skips: bool = True, residuals: bool = True,
                            n_mlp_hidden: int = 0, embedding: bool = True, groups: int = 1, head: str = "mlp",
                            gated: bool = True, layerwise_inputs: bool = False,
                            res_layers: Optional[Sequence[bool]] = None, affine: bool = False,
                            cond_classes: Optional[Sequence[int]] = None, heads_n_hidden: Optional[Sequence[int]] = None,
-                           act_f: str = "Tanh", act_g: str = "Sigmoid"):
+                           act_f: str = "Tanh", act_g: str = "Sigmoid", mlp_act: str = "Mish", mlp_dropouts: int = 0):
     """Full-window eval forward (wavenet_v2.py:276-293 with WNLayer.forward :131-176, pad_side=0):
     returns the RAW head outputs (B, 1, q+1) of the FIRST computable position (eval_slice, :273).
     ``groups`` applies to the dilated convolutions only (:93); ``head`` "linear" / "linear_abs" is the
@@ -291,9 +295,9 @@ def wavenet_window_forward(sd: SD, inputs: Tuple[torch.Tensor, ...], kernels: Se
         conds = [c[:, :, cause:] for c in conds]
     y = (skips if has_skips else h).transpose(1, 2).contiguous()[:, 0:1]
     if heads_n_hidden is not None:
-        return tuple(mlp_raw(sd, f"output_modules.{k}.estimator.0.", y, n) for k, n in enumerate(heads_n_hidden))
+        return tuple(mlp_raw(sd, f"output_modules.{k}.estimator.0.", y, n, mlp_act, mlp_dropouts) for k, n in enumerate(heads_n_hidden))
     if head == "mlp":
-        return mlp_raw(sd, "output_modules.0.estimator.0.", y, n_mlp_hidden)
+        return mlp_raw(sd, "output_modules.0.estimator.0.", y, n_mlp_hidden, mlp_act, mlp_dropouts)
     out = F.linear(y, sd["output_modules.0.0.weight"], sd["output_modules.0.0.bias"])
     return out.abs() if head == "linear_abs" else out
 
@@ -411,12 +415,14 @@ class SampleRNNOracle:
     def __init__(self, sd: SD, frame_sizes: Sequence[int], hidden_dim: int, rnn_class: str = "lstm",
                  q_levels: int = 256, n_mlp_hidden: int = 0, min_temp: Optional[float] = 1e-4, h0: str = "zeros",
                  n_rnn: int = 1, in_classes: Optional[Sequence[int]] = None, inputs_mode: str = "sum",
-                 heads: Optional[Sequence[dict]] = None):
-        """``in_classes`` (one class size per input) / ``inputs_mode``: a network of several inputs - every tier's input module is
+                 heads: Optional[Sequence[dict]] = None, mlp_act: str = "Mish", mlp_dropouts: int = 0):
+        """``mlp_act`` / ``mlp_dropouts``: MLPIO.activation and the number of dropout modules behind it (see mlp_raw).
+        ``in_classes`` (one class size per input) / ``inputs_mode``: a network of several inputs - every tier's input module is
         a ZipReduceVariables over one framed linear per input (from_config :141-145, :160-173; modules/io.py:289-313);
         ``heads`` (one dict(n_mlp_hidden=, min_temp=) per target): several output modules on the bottom tier's vector (:181-182, :259).
         With either, windows / prompts / results are tuples of streams and output k goes into input k (loops/generate.py:213-218)."""
         self.in_classes = None if in_classes is None else tuple(in_classes)
+        self.mlp_act, self.mlp_dropouts = mlp_act, mlp_dropouts
         self.inputs_mode = inputs_mode
         self.heads = None if heads is None else [dict(h) for h in heads]
         self.sd, self.fs, self.H, self.kind = sd, tuple(frame_sizes), hidden_dim, rnn_class
@@ -487,11 +493,11 @@ class SampleRNNOracle:
         x = self._zip(n - 1, tuple(x[:, -fs[-1]:] for x in streams), "2.2.cv.")
         x = x + self.outputs[-1][:, (t % fs[-2]) - fs[-2]]
         if self.heads is not None:
-            raws = tuple(mlp_raw(sd, f"output_modules.{k}.estimator.0.", x, h.get("n_mlp_hidden", 0)) for k, h in enumerate(self.heads))
+            raws = tuple(mlp_raw(sd, f"output_modules.{k}.estimator.0.", x, h.get("n_mlp_hidden", 0), self.mlp_act, self.mlp_dropouts) for k, h in enumerate(self.heads))
             self.last_raw = raws
             return tuple(categorical(mlp_logits(raw, h.get("min_temp", 1e-4)), temperature, None if uniforms is None else uniforms[k])
                          for k, (raw, h) in enumerate(zip(raws, self.heads)))
-        raw = mlp_raw(sd, "output_modules.0.estimator.0.", x, self.n_mlp_hidden)
+        raw = mlp_raw(sd, "output_modules.0.estimator.0.", x, self.n_mlp_hidden, self.mlp_act, self.mlp_dropouts)
         self.last_raw = raw
         return categorical(mlp_logits(raw, self.min_temp), temperature, uniforms)
 

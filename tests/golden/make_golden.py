@@ -275,6 +275,44 @@ def make_wavenet_acts():
     save("wavenet_acts.npz", **arrays)
 
 
+MLP_HEADS = {
+    "wn_relu_dp": ("wavenet", dict(activation="ReLU", dropout=0.1)),
+    "wn_tanh_2": ("wavenet", dict(activation="Tanh", n_hidden_layers=2)),
+    "srnn_softplus_dp1d": ("srnn", dict(activation="Softplus", dropout1d=0.2)),
+    "srnn_sigmoid": ("srnn", dict(activation="Sigmoid")),
+}
+
+
+def make_mlp_heads():
+    """MLPIO.activation other than Mish and heads with Dropout / Dropout1d modules (modules/io.py:200-219, networks/mlp.py:36-53; identities in eval mode,
+    where the loop runs a network - but they move the Linears' state_dict keys): a WaveNet and a SampleRNN through the reference's loop"""
+    g = torch.Generator().manual_seed(37)
+    arrays = {}
+    for tag, (kind, head) in MLP_HEADS.items():
+        head = dict(head)
+        act = head.pop("activation")
+        if kind == "wavenet":
+            io = ref.IOSpec.mulaw_io(ref.IOSpec.MuLawIOConfig(input_module_type="embedding", mlp_dim=32))
+        else:
+            io = ref.IOSpec.mulaw_io(ref.IOSpec.MuLawIOConfig(mlp_dim=32))
+        io.targets[0].module.activation = ref.io.ActivationConfig(act)      # (a user's IOSpec with MLPIO(activation=..., dropout=...) - `set` refuses fields that have a value)
+        for k, v in head.items():
+            setattr(io.targets[0].module, k, v)
+        if kind == "wavenet":
+            net = ref.WaveNet.from_config(ref.WaveNet.Config(io_spec=io, blocks=(3, 2), dims_dilated=(16,), residuals_dim=16, skips_dim=16)).eval()
+            n, P = 16, None
+        else:
+            net = ref.SampleRNN.from_config(ref.SampleRNN.Config(io_spec=io, frame_sizes=(8, 2, 2), hidden_dim=32, rnn_class="gru")).eval()
+            n, P = 24, 21
+        load_recipe(net, seed=300 + len(tag), gain=2.0 if kind == "wavenet" else 8.0)
+        prompt = torch.randint(0, 256, (3, (net.rf + 4) if P is None else P), generator=g)
+        log, h = capture_raw(net)
+        out = run_loop(net, (prompt,), n)
+        h.remove()
+        arrays.update({f"{tag}_prompt": prompt, f"{tag}_out": out[0], f"{tag}_raw": torch.cat(log, 1)})
+    save("mlp_heads.npz", **arrays)
+
+
 def make_freqnet():
     """WaveNet over magnitude frames (demos/freqnet.py:34-63 at reduced size): linear frame input and output, no residual
     and no skip path, grouped dilated convolutions"""
@@ -603,6 +641,7 @@ if __name__ == "__main__":
     make_wavenet()
     make_wavenet_options()
     make_wavenet_acts()
+    make_mlp_heads()
     make_freqnet()
     make_wavenet_padded()
     make_srnn()

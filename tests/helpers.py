@@ -109,6 +109,37 @@ def wavenet_act(tag):
     return net.eval(), sd, arch
 
 
+MLP_HEADS = {             # tests/golden/make_golden.py: make_mlp_heads
+    "wn_relu_dp": ("wavenet", dict(activation="ReLU", dropout=0.1)),
+    "wn_tanh_2": ("wavenet", dict(activation="Tanh", n_hidden_layers=2)),
+    "srnn_softplus_dp1d": ("srnn", dict(activation="Softplus", dropout1d=0.2)),
+    "srnn_sigmoid": ("srnn", dict(activation="Sigmoid")),
+}
+
+
+def mlp_head_case(tag):
+    """the network of one mlp_heads.npz case, its state_dict, the kind ("wavenet" / "srnn") and the oracle's arguments"""
+    kind, head = MLP_HEADS[tag]
+    head = dict(head)
+    act = head.pop("activation")
+    io = mu_emb(mlp_dim=32) if kind == "wavenet" else mu_lin(mlp_dim=32)
+    io.targets[0].module.activation = mmk.ActivationConfig(act)
+    for k, v in head.items():
+        setattr(io.targets[0].module, k, v)
+    n_dp = int(head.get("dropout", 0) > 0) + int(head.get("dropout1d", 0) > 0)
+    if kind == "wavenet":
+        net = mmk.WaveNet.from_config(mmk.WaveNet.Config(io_spec=io, blocks=(3, 2), dims_dilated=(16,), residuals_dim=16, skips_dim=16))
+        load_recipe(net, seed=300 + len(tag), gain=2.0)
+        sd = {k: v.detach().clone() for k, v in net.state_dict().items()}      # (the hidden blocks of a deeper head share ONE Linear: what it ended up with)
+        arch = dict(kernels=[2] * 5, dilations=[1, 2, 4, 1, 2], has_skips=True, residuals=True, n_mlp_hidden=head.get("n_hidden_layers", 0),
+                    mlp_act=act, mlp_dropouts=n_dp)
+    else:
+        net = mmk.SampleRNN.from_config(mmk.SampleRNN.Config(io_spec=io, frame_sizes=(8, 2, 2), hidden_dim=32, rnn_class="gru"))
+        sd = load_recipe(net, seed=300 + len(tag), gain=8.0)
+        arch = dict(frame_sizes=(8, 2, 2), hidden_dim=32, rnn_class="gru", mlp_act=act, mlp_dropouts=n_dp)
+    return net.eval(), sd, kind, arch
+
+
 def wavenet_option(tag):
     """the network of one wavenet_options.npz case and the matching oracle arguments"""
     kw = dict(WAVENET_OPTIONS[tag])

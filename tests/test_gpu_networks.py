@@ -1490,6 +1490,33 @@ def test_wavenet_activations_match_reference_golden(device, tag):
     assert bool(((got[:, p2.size(1):] == want[:, p2.size(1):]) | ~ok).all()) and float(ok.float().mean()) > 0.9
 
 
+@pytest.mark.parametrize("tag", list(H.MLP_HEADS))
+def test_mlp_head_variants_match_reference_golden(device, tag):
+    """MLP heads with another activation than Mish and / or dropout modules (eval mode: identities) on the HIP path - the kernels in turns: the fused and
+    resident kernels have Mish built in - against the reference's loop: classes bit-exact, the last step's raw head outputs within the logit tolerance"""
+    g = H.golden("mlp_heads.npz")
+    net, sd, kind, arch = H.mlp_head_case(tag)
+    prompt = H.T(g[f"{tag}_prompt"])
+    n = 16 if kind == "wavenet" else 24
+    out = run_loop(net, (prompt,), n)
+    assert torch.equal(out[0].cpu(), H.T(g[f"{tag}_out"]))
+    raw = H.T(g[f"{tag}_raw"]).reshape(3, -1, 257)
+    assert torch.allclose(net._plan.last_logits(3).cpu(), raw[:, -1], **LOGIT_TOL)
+    if kind == "wavenet":
+        assert not net._plan.persistent
+    else:
+        assert net._plan.resident_blocks() == 0
+
+
+def test_mlp_head_with_dropout_is_refused_in_training_mode(device):
+    """a Dropout module is an identity only in eval mode: a network left in training mode is refused by name, not run without its dropout"""
+    net, sd, kind, arch = H.mlp_head_case("wn_relu_dp")
+    net = net.to(device).train()
+    idx = torch.zeros(2, net.rf + 4, dtype=torch.int64, device=device)
+    with pytest.raises(NotImplementedError, match="dropout in training mode"):
+        net._describe(2)
+
+
 def test_wavenet_refuses_activations_it_does_not_evaluate(device):
     """PhaseA / GLU / Softmax and the like (modules/activations.py:25-39) are named in the refusal, not run as something else"""
     io = H.mu_emb(mlp_dim=32)

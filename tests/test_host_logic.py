@@ -190,7 +190,7 @@ def _cfg4_plan_mode(tuning: bytes, clips: int = 32) -> int:
         cfg.kernel_size[l], cfg.dilation[l] = 2, 2 ** (l % 10)
     cfg.n_cond, cfg.cond_in_dim[0], cfg.cond_dim[0] = 1, 513, 256
     cfg.mlp_hidden, cfg.out_dim, cfg.learn_temp, cfg.gated, cfg.bias = 128, 256, 1, 1, 1
-    cfg.act_f, cfg.act_g = native.ACT['Tanh'], native.ACT['Sigmoid']
+    cfg.act_f, cfg.act_g, cfg.mlp_act = native.ACT['Tanh'], native.ACT['Sigmoid'], native.ACT['Mish']
     cfg.tuning = tuning
     handle = native.vp()
     assert lib.mmk_wavenet_plan_create(native.C.byref(cfg), native.C.byref(handle)) == 0, lib.mmk_last_error()
@@ -234,7 +234,7 @@ def test_abi_argument_validation_needs_no_gpu():
     cfg.kernel_size[0] = cfg.kernel_size[1] = 2
     cfg.dilation[0], cfg.dilation[1] = 1, 2
     cfg.mlp_hidden, cfg.out_dim, cfg.learn_temp, cfg.gated, cfg.bias = 8, 256, 1, 1, 1
-    cfg.act_f, cfg.act_g = native.ACT['Tanh'], native.ACT['Sigmoid']
+    cfg.act_f, cfg.act_g, cfg.mlp_act = native.ACT['Tanh'], native.ACT['Sigmoid'], native.ACT['Mish']
     assert lib.mmk_wavenet_plan_create(native.C.byref(cfg), native.C.byref(handle)) == 0
     assert lib.mmk_wavenet_receptive_field(handle) == 4
     assert lib.mmk_wavenet_workspace_bytes(handle) > 0
@@ -469,7 +469,7 @@ def _wavenet_plan_mode(channels, layers, clips, mlp_hidden, classes, cond_dims=(
     for j, d in enumerate(cond_dims):
         cfg.cond_in_dim[j], cfg.cond_dim[j] = 513, d
     cfg.mlp_hidden, cfg.out_dim, cfg.learn_temp, cfg.gated, cfg.bias = mlp_hidden, classes, 1, 1, 1
-    cfg.act_f, cfg.act_g = native.ACT['Tanh'], native.ACT['Sigmoid']
+    cfg.act_f, cfg.act_g, cfg.mlp_act = native.ACT['Tanh'], native.ACT['Sigmoid'], native.ACT['Mish']
     cfg.tuning = tuning
     handle = native.vp()
     assert lib.mmk_wavenet_plan_create(native.C.byref(cfg), native.C.byref(handle)) == 0, lib.mmk_last_error()

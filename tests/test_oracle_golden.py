@@ -269,6 +269,22 @@ def test_wavenet_activations_oracle_matches_reference(tag):
     assert bool(H.margin_ok(g[f"{tag}_raw"]).all())
 
 
+@pytest.mark.parametrize("tag", list(H.MLP_HEADS))
+def test_mlp_head_variants_oracle_matches_reference(tag):
+    """MLPIO.activation other than Mish (ReLU, Tanh, Softplus, Sigmoid) and heads with Dropout / Dropout1d modules between their Linears (identities in
+    eval mode; the Linears' state_dict keys move): the oracle's loops against the reference's on the committed fixture"""
+    g = H.golden("mlp_heads.npz")
+    _, sd, kind, arch = H.mlp_head_case(tag)
+    prompt = H.T(g[f"{tag}_prompt"])
+    if kind == "wavenet":
+        out, raw = O.wavenet_generate(sd, prompt, (), 16, keep_logits=True, **arch)
+    else:
+        out, raw = O.SampleRNNOracle(sd, **arch).generate(prompt, 24, keep_logits=True)
+    assert torch.equal(out, H.T(g[f"{tag}_out"]))
+    assert torch.allclose(raw.reshape(-1), H.T(g[f"{tag}_raw"]).reshape(-1), rtol=1e-5, atol=1e-5)
+    assert bool(H.margin_ok(g[f"{tag}_raw"].reshape(3, -1, 257)).all())
+
+
 @pytest.mark.parametrize("tag", list(H.SRNN_OPTIONS))
 def test_sample_rnn_options_oracle_matches_reference(tag):
     """stacked recurrent layers (n_rnn 2 / 3), deeper MLP head, inputs_mode mean / static_mix, h0_init ones"""
