@@ -30,6 +30,13 @@ ACT = {"none": 0, None: 0, "Identity": 0, "Tanh": 1, "Sigmoid": 2, "Mish": 3, "A
 i32, i64, f32, vp, cp = C.c_int32, C.c_int64, C.c_float, C.c_void_p, C.c_char_p
 
 
+def only_mlp(estimator) -> bool:
+    """an MLPIO's estimator: Sequential(MLP) - or Sequential(MLP, Dropout[, Dropout1d]): IOModule.wrap hangs the spec's dropout modules behind the core as
+    well (modules/io.py:94-97); identities in eval mode, which mlp_head_problem insists on"""
+    return (isinstance(estimator, torch.nn.Sequential) and len(estimator) >= 1 and type(estimator[0]).__name__ == "MLP"
+            and all(isinstance(m, (torch.nn.Dropout, torch.nn.Dropout1d)) for m in list(estimator)[1:]))
+
+
 def mlp_head_problem(mlp, training: bool):
     """what keeps an MLP head (networks/mlp.py:20-63) off the HIP path, or None: its activation must be one the kernels evaluate (ACT), its Linears need their
     bias, and Dropout / Dropout1d modules are identities only in eval mode (where the generate loop runs a network, loops/generate.py)"""

@@ -231,7 +231,7 @@ class Seq2SeqLSTMNetwork(ARMWithHidden, nn.Module):
         elif discrete:
             head = heads[0]
             est = getattr(head, "estimator", None)
-            mlp = est[0] if isinstance(est, nn.Sequential) and len(est) == 1 else None
+            mlp = est[0] if native.only_mlp(est) else None
             if not isinstance(mlp, MLP) or not isinstance(getattr(head, "sampler", None), CategoricalSampler):
                 unsupported.append("discrete inputs with a head other than MLPIO + CategoricalSampler")
             elif native.mlp_head_problem(mlp, self.training) or mlp.n_hidden_layers > 4:
@@ -289,7 +289,7 @@ class Seq2SeqLSTMNetwork(ARMWithHidden, nn.Module):
             sd = self.state_dict()
             for k, head in enumerate(getattr(self.output_module, "heads", [])):      # (a head with dropout modules between its Linears: the plan knows `fc.{2 i}`)
                 est = getattr(head, "estimator", None)
-                if isinstance(est, nn.Sequential) and len(est) == 1 and isinstance(est[0], MLP):
+                if native.only_mlp(est):
                     sd = native.mlp_linear_keys(sd, f"output_module.heads.{k}.estimator.0.", est[0])
             self._plan.bind_state_dict(fold_weight_norm(sd) if any(k.endswith("_g") for k in sd) else sd)
             self._plan.commit()

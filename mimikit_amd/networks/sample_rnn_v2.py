@@ -226,7 +226,7 @@ class SampleRNN(ARMWithHidden, nn.Module):
             unsupported.append("too many tiers")
         head = self.output_modules[0]
         c = native.SrnnConfig()
-        if isinstance(head, OutputWrapper) and isinstance(head.estimator[0], MLP) and len(head.estimator) == 1:
+        if isinstance(head, OutputWrapper) and native.only_mlp(head.estimator):
             mlp: MLP = head.estimator[0]
             if native.mlp_head_problem(mlp, self.training):
                 unsupported.append(native.mlp_head_problem(mlp, self.training))
@@ -246,7 +246,7 @@ class SampleRNN(ARMWithHidden, nn.Module):
             c.in_class[m] = spec.elem_type.size
         for k in range(1, min(n_tgt, native.MAX_STREAMS)):
             hk = self.output_modules[k]
-            if not (isinstance(hk, OutputWrapper) and isinstance(hk.estimator[0], MLP) and len(hk.estimator) == 1):
+            if not (isinstance(hk, OutputWrapper) and native.only_mlp(hk.estimator)):
                 unsupported.append(f"output module {k} of type {type(hk).__name__}")
                 continue
             mlp = hk.estimator[0]
@@ -291,7 +291,7 @@ class SampleRNN(ARMWithHidden, nn.Module):
                 sd = self.state_dict()
                 for k, head in enumerate(self.output_modules):      # (a head with dropout modules between its Linears: the plans know `fc.{2 i}`)
                     est = getattr(head, "estimator", None)
-                    if isinstance(est, nn.Sequential) and len(est) == 1 and isinstance(est[0], MLP):
+                    if native.only_mlp(est):
                         sd = native.mlp_linear_keys(sd, f"output_modules.{k}.estimator.0.", est[0])
                 self._plan.bind_state_dict(fold_weight_norm(sd) if self._config.weight_norm else sd)
                 self._plan.commit()

@@ -353,7 +353,7 @@ class WaveNet(ARM, nn.Module):
         c.bias, c.gated = int(cfg.bias), int(cfg.act_g is not None)
         c.act_f, c.act_g = native.ACT.get(str(cfg.act_f), 0), native.ACT.get(str(cfg.act_g), 0) if cfg.act_g is not None else 0
         head = self.output_modules[0]
-        if isinstance(head, OutputWrapper) and isinstance(head.estimator[0], MLP) and len(head.estimator) == 1:
+        if isinstance(head, OutputWrapper) and native.only_mlp(head.estimator):
             mlp: MLP = head.estimator[0]
             if native.mlp_head_problem(mlp, self.training):
                 unsupported.append(native.mlp_head_problem(mlp, self.training))
@@ -381,7 +381,7 @@ class WaveNet(ARM, nn.Module):
         c.n_targets = n_tgt
         for k in range(1, min(n_tgt, native.MAX_STREAMS)):
             hk = self.output_modules[k]
-            if not (isinstance(hk, OutputWrapper) and isinstance(hk.estimator[0], MLP) and len(hk.estimator) == 1) or c.head_kind != 0:
+            if not (isinstance(hk, OutputWrapper) and native.only_mlp(hk.estimator)) or c.head_kind != 0:
                 unsupported.append(f"target {k}: several targets need MLP heads with samplers")
                 continue
             mlp = hk.estimator[0]
@@ -431,7 +431,7 @@ class WaveNet(ARM, nn.Module):
         sd = self.state_dict()
         for k, head in enumerate(self.output_modules):      # (a head with dropout modules between its Linears: the plans know `fc.{2 i}`)
             est = getattr(head, "estimator", None)
-            if isinstance(est, nn.Sequential) and len(est) == 1 and isinstance(est[0], MLP):
+            if native.only_mlp(est):
                 sd = native.mlp_linear_keys(sd, f"output_modules.{k}.estimator.0.", est[0])
         groups = self._config.groups
         if groups == 1:
