@@ -34,7 +34,7 @@ extern "C" {
 
 #define MMK_ABI_VERSION 4   /* 2: exec_mode in the WaveNet / SampleRNN / Seq2Seq configs, mmk_*_sync_status for all three, mmk_*_inject_sync_error;
                               * 3: `tuning` text at the end of the three configs - the library reads no environment variable;
-                              * 4: act_f / act_g in the WaveNet config, mlp_act in all three */
+                              * 4: act_f / act_g in the WaveNet config, mlp_act in all three, mmk_srnn_resident_warmups */
 /* activations (mimikit/modules/activations.py: ActivationEnum, the members the HIP path evaluates) */
 #define MMK_ACT_IDENTITY 0
 #define MMK_ACT_TANH 1
@@ -361,6 +361,9 @@ int mmk_srnn_inject_sync_error(mmk_srnn_plan* plan, mmk_stream_t stream);
 /* diagnostic: generate blocks this plan has run in resident mode (the bottom tier as one launch beside the tier kernels of a
  * second stream) since it was created; tests assert that the mode they mean to cover is the one that ran */
 int64_t mmk_srnn_resident_blocks(const mmk_srnn_plan* plan);
+/* diagnostic: warm-ups (mmk_srnn_warmup: SampleRNN.before_generate, sample_rnn_v2.py:226-234) this plan has run as ONE teacher-forced resident launch - the
+ * tiers with their matrices in registers, windows from the prompt, no bottom tier - instead of one launch per tier update */
+int64_t mmk_srnn_resident_warmups(const mmk_srnn_plan* plan);
 
 /* ------------------------------------------------------------------------
  * Seq2SeqLSTMNetwork (mimikit/networks/s2s_lstm_v2.py)

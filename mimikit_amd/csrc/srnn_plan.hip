@@ -84,9 +84,11 @@ struct mmk_srnn_plan {
   GraphCache gc;
   // resident mode (srnn_resident.hip): ONE launch per generate block, every tier and the bottom tier resident with their weights in registers
   int64_t resident_blocks = 0;
+  int64_t resident_warmups = 0;                 // warm-ups that ran as one teacher-forced resident launch
   unsigned long long* cls_gran = nullptr;       // [Bmax][256]
   unsigned long long* res_gran = nullptr;       // the tiers' granule arrays, one region (cleared at the start of every resident block)
   int64_t res_gran_count = 0;
+  unsigned long long* res_prog = nullptr;       // [kResMaxTiers] progress words of a teacher-forced launch, inside res_gran (cleared with it)
   unsigned long long* res_stamps = nullptr;     // diagnostic build: phase totals per role
   float* cp_wp = nullptr;                       // last recurrent tier: W0 W_up[slot] for the slots 1 .. S - 1, packed tiles (rpb rows per unit block)
   float* cp0 = nullptr;                         // (Hm, H): W0 W_up[slot 0]
@@ -162,6 +164,7 @@ struct mmk_srnn_plan {
         const bool last = i + 1 == tiers.size();
         res_gran_count += (int64_t)2 * Bmax * H + (last ? (int64_t)Bmax * tiers[i].up * cfg.mlp_hidden : (int64_t)Bmax * tiers[i].up * G * H);
       }
+      res_gran_count += kResMaxTiers;      // + a progress word per tier (teacher-forced launches)
       res_gran = c.take<unsigned long long>(res_gran_count);
       unsigned long long* at = res_gran;
       for (size_t i = 0; i < tiers.size(); ++i) {
@@ -171,6 +174,7 @@ struct mmk_srnn_plan {
         tiers[i].rout_gran = at;
         if (at) at += last ? (int64_t)Bmax * tiers[i].up * cfg.mlp_hidden : (int64_t)Bmax * tiers[i].up * G * H;
       }
+      res_prog = at;
     }
     res_stamps = c.take<unsigned long long>(8 * (1 + kResMaxTiers));
     {
@@ -990,13 +994,17 @@ static int resident_grid(mmk_srnn_plan* p, const SrnnCall& call, int64_t n_res, 
   return srnn_resident_grid(p->H, call.M, p->n_rnn_tiers, senv ? atoi(senv) : 0, mt);
 }
 
-static int run_resident(mmk_srnn_plan* p, const SrnnCall& call, int64_t t_begin, int64_t n, const int* mt, hipStream_t st) {
+static int run_resident(mmk_srnn_plan* p, const SrnnCall& call, int64_t t_begin, int64_t n, const int* mt, hipStream_t st, bool teacher = false) {
   const mmk_srnn_config& c = p->cfg;
   const int H = p->H, G = p->G, KC = H / 16, M = call.M;
   MMK_HIP(hipMemsetAsync(p->res_gran, 0, (size_t)p->res_gran_count * sizeof(unsigned long long), st));   // (a granule of an earlier block could carry the number this one waits for)
-  hipLaunchKernelGGL(srnn_resident_init_kernel, dim3((unsigned)(((int64_t)M * 256 + 255) / 256)), dim3(256), 0, st, p->cls_gran, call.idx, call.idx_rs, M, t_begin);
-  MMK_HIP(hipGetLastError());
+  if (!teacher) {
+    hipLaunchKernelGGL(srnn_resident_init_kernel, dim3((unsigned)(((int64_t)M * 256 + 255) / 256)), dim3(256), 0, st, p->cls_gran, call.idx, call.idx_rs, M, t_begin);
+    MMK_HIP(hipGetLastError());
+  }
   SrnnResArgs a = {};
+  a.teacher = teacher ? 1 : 0;
+  a.shift = call.shift;
   a.B = M; a.H = H; a.n_tiers = p->n_rnn_tiers; a.lstm = c.rnn_kind == 0 ? 1 : 0;
   a.n_steps = (int32_t)n; a.t_begin = t_begin; a.class_size = (float)c.q_levels;
   int block0 = M;
@@ -1021,6 +1029,7 @@ static int run_resident(mmk_srnn_plan* p, const SrnnCall& call, int64_t t_begin,
     r.h_gran = t.rh_gran; r.out_gran = t.rout_gran;
     r.upper_gran = i > 0 ? p->tiers[i - 1].rout_gran : nullptr;
     r.upper_h_gran = i > 0 ? p->tiers[i - 1].rh_gran : nullptr;
+    r.prog = p->res_prog + i;
   }
   a.Hm = c.mlp_hidden; a.Q = c.q_levels; a.n_out = c.q_levels + (c.learn_temp ? 1 : 0); a.learn_temp = c.learn_temp; a.min_temp = c.min_temp;
   a.fsb = c.frame_size[c.n_tiers - 1]; a.S = p->tiers.back().up;
@@ -1063,6 +1072,20 @@ static int run_steps(mmk_srnn_plan* p, const SrnnCall& call, int64_t t_begin, in
         MMK_TRY(emit_range(p, call, 0, head, (int)(t_begin % period), true, st));
       }
       MMK_TRY(run_resident(p, call, t_begin + head, n - head, mt, st));
+      return launch_set_i64(p->tau, t_begin + n, st);
+    }
+  }
+  if (!with_bottom && p->n_in == 1) {
+    // The warm-up (sample_rnn_v2.py:229-234: generate_step over the prompt, outputs dropped) as ONE teacher-forced resident launch: the tiers with their
+    // matrices in registers, windows from the prompt, no bottom tier - where the block starts on an update of the top tier and is whole periods long
+    // (round 5: 155 launches of 17 us each for a 512-sample prompt at cfg 3)
+    const int period = p->cfg.frame_size[0];
+    const char* wenv = p->tune.get("MMK_SRNN_RESIDENT_WARMUP");
+    int mt[kResMaxTiers];
+    if (!(wenv && wenv[0] == '0') && t_begin % period == 0 && n % period == 0 && resident_grid(p, call, n, mt) > 0) {
+      MMK_TRY(run_resident(p, call, t_begin, n, mt, st, true));
+      --p->resident_blocks;      // (the counter says how many GENERATE blocks ran resident)
+      ++p->resident_warmups;
       return launch_set_i64(p->tau, t_begin + n, st);
     }
   }
@@ -1152,6 +1175,7 @@ extern "C" int mmk_srnn_sync_status(mmk_srnn_plan* p, mmk_stream_t stream) {
 }
 
 extern "C" int64_t mmk_srnn_resident_blocks(const mmk_srnn_plan* p) { return p ? p->resident_blocks : 0; }
+extern "C" int64_t mmk_srnn_resident_warmups(const mmk_srnn_plan* p) { return p ? p->resident_warmups : 0; }
 
 extern "C" int mmk_srnn_last_logits(mmk_srnn_plan* p, int32_t batch, float* out, int64_t ld, mmk_stream_t stream) {
   if (!p || !out) return fail(MMK_ERR_INVALID, "srnn_last_logits: null argument");

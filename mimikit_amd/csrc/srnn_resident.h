@@ -38,11 +38,17 @@ struct SrnnResTier {
                                      // [B][S][Hm] {update number, W0-composed row}
   const unsigned long long* upper_gran;     // out_gran of the tier above, or null
   const unsigned long long* upper_h_gran;   // h_gran of the tier above, or null
+  unsigned long long* prog;                 // teacher-forced launches: updates whose input half this tier's workgroups have read, summed over the workgroups
+                                            // (zero at the start of a launch) - what paces the tier above where no drawn class does
 };
 
 struct SrnnResArgs {
   int32_t B, H, n_tiers, lstm;       // clips, hidden, recurrent tiers, rnn kind
   int32_t n_steps;
+  int32_t teacher;                   // 1: the warm-up - the tiers take their windows from idx (positions + shift) instead of the bottom role's classes, the bottom
+                                     // role does not run (sample_rnn_v2.py:229-234: generate_step over the prompt, its outputs dropped); the tiers pace
+                                     // each other by `prog`
+  int64_t shift;                     // teacher: the window of step t starts at position t - fs + shift (the prompt's offset, :230)
   int64_t t_begin;                   // first step of the block, a multiple of frame_sizes[0]
   float class_size;
   SrnnResTier tier[kResMaxTiers];

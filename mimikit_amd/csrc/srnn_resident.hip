@@ -380,13 +380,30 @@ __device__ __forceinline__ void res_tier_role(const SrnnResArgs& a, const SrnnRe
       float v = 0.f;
       if (m < mg && i < fs) {
         const int64_t pos = t - fs + i;
-        const unsigned cls = res_wait(a.cls_gran + (int64_t)(m_first + m) * 256 + (pos & 255), (unsigned)(pos + 1), a.err, 7);
+        const unsigned cls = a.teacher ? (unsigned)a.idx[(int64_t)(m_first + m) * a.idx_rs + pos + a.shift]
+                                       : res_wait(a.cls_gran + (int64_t)(m_first + m) * 256 + (pos & 255), (unsigned)(pos + 1), a.err, 7);
         v = (((float)cls / a.class_size) - .5f) * 2.f;
       }
       s_lin[m * ldl + i] = v;
     }
     __syncthreads();
     st.at(1);
+    if (a.teacher) {
+      // Teacher-forced (the warm-up): no drawn class paces the tiers.  This update's rows of the tier above are read: say so; and before anything of this update
+      // is published, the tier BELOW must have read everything of the update before (its rows are one buffer per slot, not two)
+      if (tid == 0) atomicAdd(T.prog, 1ull);
+      if constexpr (!LAST) {
+        if (upd >= 1) {
+          const SrnnResTier& TB = a.tier[tier_index + 1];
+          const unsigned long long want = (unsigned long long)(KC * ((a.B + 16 * TB.mt - 1) / (16 * TB.mt))) * (unsigned long long)upd * (unsigned long long)T.up;
+          unsigned spins = 0;
+          while (res_gload(TB.prog) < want) {
+            if (res_give_up(spins, a.err, 7)) break;
+            __builtin_amdgcn_s_sleep(2);
+          }
+        }
+      }
+    }
     // ---- cell: (W_ih W_in) lin(window), gates, new state ------------------------------------------------------------------------
 #pragma unroll
     for (int k = 0; k < NP; ++k) {
@@ -813,7 +830,7 @@ __global__ __launch_bounds__(kResThreads) void srnn_resident_kernel(const SrnnRe
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   const int b = blockIdx.x;
   if (b < a.B) {
-    res_bottom_role<KC>(a, smem_raw);
+    if (!a.teacher) res_bottom_role<KC>(a, smem_raw);      // (teacher-forced: the tiers only - the warm-up drops the head's outputs)
     return;
   }
   int ti = 0;

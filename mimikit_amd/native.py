@@ -180,6 +180,7 @@ _SIGNATURES = {
     "mmk_srnn_generate_multi": (i32, [vp, i32, C.POINTER(vp), C.POINTER(i64), i64, i64, vp, vp, vp]),
     "mmk_srnn_last_logits_of": (i32, [vp, i32, i32, vp, i64, vp]),
     "mmk_srnn_resident_blocks": (i64, [vp]),
+    "mmk_srnn_resident_warmups": (i64, [vp]),
     "mmk_srnn_sync_status": (i32, [vp, vp]),
     "mmk_srnn_inject_sync_error": (i32, [vp, vp]),
     "mmk_s2s_plan_create": (i32, [C.POINTER(S2SConfig), C.POINTER(vp)]),
@@ -808,6 +809,10 @@ class SrnnPlan(_Plan):
     def resident_blocks(self) -> int:
         """generate blocks run in resident mode so far (diagnostic, see include/mmk.h)"""
         return int(self._lib.mmk_srnn_resident_blocks(self.handle))
+
+    def resident_warmups(self) -> int:
+        """warm-ups run as one teacher-forced resident launch so far (diagnostic, see include/mmk.h)"""
+        return int(self._lib.mmk_srnn_resident_warmups(self.handle))
 
     def last_logits(self, batch: int, target: int = 0) -> torch.Tensor:
         c = self.cfg

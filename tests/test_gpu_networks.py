@@ -305,6 +305,32 @@ def _srnn_blocks(net, device, prompt, n, parts, **params):
     return idx.cpu(), count
 
 
+def test_sample_rnn_warmup_as_one_resident_launch(device, monkeypatch):
+    """the warm-up over the prompt (before_generate, sample_rnn_v2.py:226-234) as ONE teacher-forced resident launch - the tiers pace each other by their
+    progress words instead of by drawn classes - against the same warm-up with one launch per tier update: the generation that follows is bit-identical,
+    with a prompt that is not a multiple of rf (the shifted window), GRU and LSTM tiers, a ragged row tile; and equal to the oracle"""
+    monkeypatch.setitem(mmk.native.PLAN_TUNING, "MMK_SRNN_FUSED", "1")
+    for kind, hidden, fs, B in (("gru", 512, (16, 4, 1), 40), ("lstm", 128, (32, 8, 2), 21), ("gru", 128, (4, 1), 5)):
+        rf = fs[0]
+        P, n = 5 * rf + 7, 2 * rf + 3
+        prompt = torch.randint(0, 256, (B, P), generator=torch.Generator().manual_seed(B))
+        outs = []
+        for flag in ("1", "0"):
+            monkeypatch.setitem(mmk.native.PLAN_TUNING, "MMK_SRNN_RESIDENT_WARMUP", flag)
+            net, sd, arch = H.srnn("big", hidden=hidden, mlp_dim=64, seed=77, frame_sizes=fs, kind=kind)
+            net = net.to(device)
+            idx = torch.cat([prompt, torch.zeros(B, n, dtype=torch.int64)], 1).to(device)
+            net.before_generate((idx[:, :P],), None)
+            assert net._plan.resident_warmups() == (1 if flag == "1" else 0), (kind, flag)
+            net.generate_block((idx,), P, n)
+            net.after_generate((idx,), None)
+            outs.append(idx.cpu())
+        assert torch.equal(outs[0], outs[1]), kind
+        ref, raw = O.SampleRNNOracle(sd, **arch).generate(prompt, n, keep_logits=True, forced=outs[0])
+        ok = H.margin_ok(raw)
+        assert float(ok.float().mean()) > 0.9 and torch.equal(ref[:, P:][ok], outs[0][:, P:][ok])
+
+
 @pytest.mark.parametrize("kind", ["gru", "lstm"])
 def test_sample_rnn_resident_mode_blocks_and_oracle(device, monkeypatch, kind):
     """resident mode (every tier, the bottom tier and the head as ONE launch per block, weights in registers): blocks that start between two
