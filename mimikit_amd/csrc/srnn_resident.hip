@@ -507,13 +507,15 @@ __device__ __forceinline__ void res_tier_role(const SrnnResArgs& a, const SrnnRe
       }
       __syncthreads();
     };
+    // (teacher-forced: the last recurrent tier's rows are for the bottom role, which does not run - the tier below a non-last tier does need its rows)
+    const int n_tiles_run = (LAST && a.teacher) ? 0 : T.n_tiles;
     if constexpr (NRU > 0) {
-      if (T.n_tiles > 0) run_batch(std::integral_constant<int, 0>{}, 0, 1);
+      if (n_tiles_run > 0) run_batch(std::integral_constant<int, 0>{}, 0, 1);
       if constexpr (NRU > 1) {
-        if (T.n_tiles > 1) run_batch(std::integral_constant<int, 1>{}, 1, min(T.n_tiles, NRU) - 1);
+        if (n_tiles_run > 1) run_batch(std::integral_constant<int, 1>{}, 1, min(n_tiles_run, NRU) - 1);
       }
     }
-    for (int jb = NRU; jb < T.n_tiles; jb += BT) run_batch(std::integral_constant<int, -1>{}, jb, min(BT, T.n_tiles - jb));
+    for (int jb = NRU; jb < n_tiles_run; jb += BT) run_batch(std::integral_constant<int, -1>{}, jb, min(BT, n_tiles_run - jb));
     st.at(4);
     // ---- W_hh h' for the next update ----------------------------------------------------------------------------------------------------
     if (upd + 1 < n_upd) {
