@@ -25,6 +25,10 @@ using namespace mmk;
 // is 107 whatever the batch up to ~10 groups (128 clips 107 against the one-clip ring's 136, 256 clips 140 against 272 as two passes); the ring's beat is
 // 1.06 per clip: 104 clips are where the two meet
 constexpr int kBpipeMinClips = 105;
+// Round 6: the ring with TWO clips per visit (wavenet_spipe_pair.inc) takes 128 clips in 100 us per step and 112 in 88, so up to the ring's 128 clips the groups of 16
+// are left with the clip counts the pair form does not take (not a multiple of 4)
+constexpr int kBpipeAlwaysClips = kSpMaxClips + 1;
+static bool bpipe_by_default(int B) { return B >= kBpipeAlwaysClips || (B >= kBpipeMinClips && B % 4 != 0); }
 
 struct WnCall {
   int M = 0;
@@ -116,6 +120,7 @@ struct mmk_wavenet_plan {
   float* compose_scratch = nullptr;   // (2C, C) product + 2C bias terms of one layer
   // one layer per stage of 8 CUs, clips streamed through one at a time (wavenet_spipe.hip): C = 256, <= 31 layers, <= 32 clips
   bool spipe = false;
+  int last_pair = 0;           // the last stage-pipeline launch took two clips per visit (wavenet_spipe_pair.inc)
   // the same stages, the clips in groups of 16 on the matrix pipe (wavenet_bpipe.hip): the stage pipeline's large batches, <= 512 clips.  A
   // sub-mode of `spipe` (prefill into the launch path's rings, padded head, redo path are shared)
   bool bpipe = false;
@@ -491,7 +496,7 @@ static int derive(mmk_wavenet_plan* p) {
     // ~3.5 us whatever the batch (up to ~10 groups; beyond, a stage's ~9.5 us per visit is the beat), the ring's is ~1.1 us per clip.  MMK_WN_BPIPE=0 turns it off, =1 takes it for any batch.
     const char* benv = p->tune.get("MMK_WN_BPIPE");
     bool ok6 = ok5 && !(benv && benv[0] == '0') && wn_bpipe_supported(p->C, p->S, c.mlp_hidden, c.out_dim, p->L, c.n_cond, cond_total, p->Bmax);
-    ok6 = ok6 && ((benv && benv[0] == '1') || (p->Bmax >= kBpipeMinClips && p->L >= 16));
+    ok6 = ok6 && ((benv && benv[0] == '1') || (bpipe_by_default(p->Bmax) && p->L >= 16));
     ok5 = ok5 && (ok6 || wn_spipe_supported(p->C, p->S, c.mlp_hidden, c.out_dim, p->L, c.n_cond, cond_total, p->Bmax));
     p->bpipe = false;
     // A ring of few stages is beat-bound early (one clip's trip: ~1.3 us per stage; ~1.25 us per clip once the clips queue up): 10 layers x 32 clips
@@ -1225,6 +1230,8 @@ static int run_persistent(mmk_wavenet_plan* p, const WnCall& call, int64_t tau0,
       k.stamps = (stamp_env && stamp_env[0] == '1') ? reinterpret_cast<unsigned long long*>(p->tau + 8) : nullptr;
       k.stamp_stage = diag_only("MMK_WN_STAMP_STAGE") ? atoi(diag_only("MMK_WN_STAMP_STAGE")) : 1;
       k.dbg = (k.stamps && diag_only("MMK_WN_SPIPE_DBG")) ? atoi(diag_only("MMK_WN_SPIPE_DBG")) : 0;
+      { const char* pe = p->tune.get("MMK_WN_SPIPE_PAIR"); k.pair = pe ? (pe[0] == '1' ? 1 : 0) : -1; }
+      p->last_pair = wn_spipe_pair_form(k.B, k.pair) ? 1 : 0;
       MMK_TRY(launch_wavenet_spipe(k, st));
       done += nb;
       continue;
@@ -1506,6 +1513,8 @@ extern "C" int mmk_wavenet_profile_steps(mmk_wavenet_plan* p, int32_t batch, voi
 extern "C" int mmk_wavenet_mode(const mmk_wavenet_plan* p) {
   return (p && p->persistent) ? (p->bpipe ? 6 : p->spipe ? 5 : (p->lpipe ? 4 : (p->chain ? 2 : 1))) : 0;
 }
+
+extern "C" int mmk_wavenet_pair_visits(const mmk_wavenet_plan* p) { return p ? p->last_pair : 0; }
 
 extern "C" int mmk_wavenet_inject_sync_error(mmk_wavenet_plan* p, mmk_stream_t stream) {
   if (!p) return fail(MMK_ERR_INVALID, "wavenet_inject_sync_error: null plan");

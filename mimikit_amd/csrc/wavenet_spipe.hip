@@ -120,6 +120,10 @@ constexpr int kSlotShift = MMK_SP_SLOT_SHIFT;
 #ifndef MMK_SP_NOARRWAIT
 #define MMK_SP_NOARRWAIT 1     // helpers off duty do not wait for the current message (16 clips or more: the rings' own counters bound how far they run ahead)
 #endif
+#ifndef MMK_SP_ABL
+#define MMK_SP_ABL 0           // timing builds only (results are wrong): the diagnostic build's dbg bits 1 / 2 / 4 / 8 / 16 / 32 / 128 / 256 as a compile-time mask of the product kernel
+#endif
+#define SP_ABL(bit) ((STAMPS && (a.dbg & (bit))) || (MMK_SP_ABL & (bit)))
 #ifndef MMK_SP_WAKEUP
 #define MMK_SP_WAKEUP 1        // the looking helper wakes the chain waves out of their s_sleep when it has staged a message
 #endif
@@ -354,7 +358,7 @@ __device__ void chain_role(const WnSpipeArgs& a, Lds& S, int stage, int p, int q
         const u64 t = __builtin_amdgcn_s_memtime(); st.t_wait += t - t0c; t0c = t;
         if (a.stamps && c == 0 && s + 1 == n_steps && p == 0 && q == 0 && lane == 0) a.stamps[112 + stage] = __builtin_amdgcn_s_memrealtime();
       }
-      if (STAMPS && (a.dbg & 16)) {          // (diagnostic build, timing only: the chain waves do nothing - what the helpers' loop takes alone)
+      if SP_ABL(16) {          // (diagnostic build, timing only: the chain waves do nothing - what the helpers' loop takes alone)
         lds_signal(&S.hdone[q], v + 1, lane);
         st.visits += 1;
         continue;
@@ -445,7 +449,7 @@ __device__ void chain_role(const WnSpipeArgs& a, Lds& S, int stage, int p, int q
       // ---- the hidden units' sum, handed on ---------------------------------------------------------------------------------------------------
       if (stage >= 1) {
         f32x2 hc[2] = {f32x2{0.f, 0.f}, f32x2{0.f, 0.f}};
-        if (!(STAMPS && (a.dbg & 128)))      // (diagnostic build, timing only: dbg 128 no hidden-unit products, dbg 256 nor the wait for the sum so far)
+        if (!SP_ABL(128))      // (diagnostic build, timing only: dbg 128 no hidden-unit products, dbg 256 nor the wait for the sum so far)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {      // (the y slice of the residual product, read again: 16 registers kept across the gate would not fit)
           const f32x4s yv = *reinterpret_cast<const f32x4s*>(xb + xr_off + i * 4);
@@ -457,7 +461,7 @@ __device__ void chain_role(const WnSpipeArgs& a, Lds& S, int stage, int p, int q
         // the chain waves load NOTHING from memory - a load's data is waited for with a count that also covers the stores before it,
         // i.e. every visit would wait for its own publish to be acknowledged (a written-through one: ~1 us)
         float hin = 0.f;
-        if (hid_chain_in && !(STAMPS && (a.dbg & 256))) {
+        if (hid_chain_in && !SP_ABL(256)) {
           if (!lds_wait1(&S.hidin_ready[v & 3], v + 1, a.err_flag)) return;
           hin = S.hidin[v & (kXyRing - 1)][4 * q + (lane >> 4)];
         }
@@ -582,7 +586,7 @@ __device__ void helper_role(const WnSpipeArgs& a, Lds& S, int stage, int p, int 
   // (diagnostic build, dbg 4: nothing waits for a message - every stage runs at the pace of its own work; results are wrong, the
   //  per-stage times say what a stage's service time is when its inbox is never empty)
   constexpr int kGap = MMK_SP_POLL_GAP_BY_MODE ? (LAG4 ? kPollGap : 0) : kPollGap;
-  const bool freerun = STAMPS && (a.dbg & 4);
+  const bool freerun = SP_ABL(4);
   if (STAMPS && a.stamps && freerun && p == 0 && h == 0 && lane == 0) a.stamps[182 + stage] = __builtin_amdgcn_s_memrealtime();
   auto landed = [&](const u32x4s& lo, const u32x4s& hi) {
     if (freerun) return true;
@@ -608,14 +612,14 @@ __device__ void helper_role(const WnSpipeArgs& a, Lds& S, int stage, int p, int 
       const int off = (((c2 * kSpSlots + ((s2 - 1) & 3)) * kMsgFloats) + (lane >> 1) * 16 + (lane & 1) * 4) * 4;
       xr = __builtin_amdgcn_raw_buffer_load_b128(own, off, 0, 16);
     } else {
-      const int64_t tp = (STAMPS && (a.dbg & 2)) ? a.t0 - 1 + s2 - 2 : a.t0 - 1 + s2 - d;     // (dbg 2: diagnostic build, timing only)
+      const int64_t tp = SP_ABL(2) ? a.t0 - 1 + s2 - 2 : a.t0 - 1 + s2 - d;     // (dbg 2: diagnostic build, timing only)
       if (tp >= 0) xr = __builtin_amdgcn_raw_buffer_load_b128(ring, (int)(((tp & ring_mask) * slot_stride + (int64_t)c2 * kC + 4 * lane) * 4), 0, 16);
       else xr = u32x4s{0, 0, 0, 0};
     }
     // (a repeated look at the stage's own message does not ask for the conditioning row again: that one comes from HBM, and the look
     //  behind it would wait for it - a wave's loads return in order)
     if (!with_cond) return;
-    if (cond_lane && !(STAMPS && (a.dbg & 1))) cr = *reinterpret_cast<const f32x4s*>(a.cproj + ((int64_t)c2 * a.cond_steps + s2) * a.C1 + 4 * lane);
+    if (cond_lane && !SP_ABL(1)) cr = *reinterpret_cast<const f32x4s*>(a.cproj + ((int64_t)c2 * a.cond_steps + s2) * a.C1 + 4 * lane);
     else cr = f32x4s{0.f, 0.f, 0.f, 0.f};
   };
   // the requested rows into the LDS slot of visit v3, once every helper is through with the visit that used the slot before
@@ -639,7 +643,7 @@ __device__ void helper_role(const WnSpipeArgs& a, Lds& S, int stage, int p, int 
   // the bias of visit v3 = (c2, s2): W0 x_s[t - d] + W_1x1 c[t] + constants, into the LDS image the chain wave reads
   auto bias_of = [&](unsigned v3, int s2, int c2) -> bool {
     if (!lds_wait1(&S.rows_ready[v3 & (kRowRing - 1)], v3 + 1, a.err_flag)) return false;
-    if (STAMPS && (a.dbg & 8)) {             // (diagnostic build, timing only: no bias products - what the rest of the helpers' loop takes)
+    if SP_ABL(8) {             // (diagnostic build, timing only: no bias products - what the rest of the helpers' loop takes)
       lds_signal(&S.ready[h], v3 + 1, lane);
       return true;
     }
@@ -707,6 +711,7 @@ __device__ void helper_role(const WnSpipeArgs& a, Lds& S, int stage, int p, int 
         for (int e = 0; e < 4; ++e) macc[e] = __builtin_amdgcn_mfma_f32_4x4x1f32(wv[e], xv[e], macc[e], 0, 0, 0);
       }
     };
+    if (!SP_ABL(8))
     switch (ch) {
       case 0: products(std::integral_constant<int, 0>{}); break;
       case 1: products(std::integral_constant<int, 1>{}); break;
@@ -784,7 +789,7 @@ __device__ void helper_role(const WnSpipeArgs& a, Lds& S, int stage, int p, int 
     // ... and behind it the hidden units' hand-over of the stage below for the same visit (this CU's 16 units), for the chain waves' sums
     auto fetch_hid = [&](int vv, int cc, int ss) -> bool {
       if (!hid_chain_in) return true;
-      if (STAMPS && (a.dbg & 32)) {          // (diagnostic build, timing only: the hidden sums' hand-over is not fetched)
+      if SP_ABL(32) {          // (diagnostic build, timing only: the hidden sums' hand-over is not fetched)
         lds_signal(&S.hidin_ready[vv & 3], (unsigned)vv + 1, lane);
         return true;
       }
@@ -1036,7 +1041,7 @@ __device__ void head_role(const WnSpipeArgs& a, int p) {
     unsigned w1 = 0, spins = 0;
     for (;;) {
       if (mine) w1 = msg_load(src);
-      if (__all(!mine || w1 != kSpPoison) || (STAMPS && (a.dbg & 4))) break;
+      if (__all(!mine || w1 != kSpPoison) || SP_ABL(4)) break;
       if (++spins > kSpinLimit || ((spins & 1023u) == 0 && __hip_atomic_load(a.err_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
         atomicExch(a.err_flag, 1);
         s_fail = 1;
@@ -1078,7 +1083,7 @@ __device__ void head_role(const WnSpipeArgs& a, int p) {
           if (want_h) wh1 = msg_load(hlast);
           asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(w4) : "v"(src) : "memory");
           const bool ok = w4[0] != kSpPoison && w4[1] != kSpPoison && w4[2] != kSpPoison && w4[3] != kSpPoison && (!want_h || wh1 != kSpPoison);
-          if (__all(ok) || (STAMPS && (a.dbg & 4))) break;
+          if (__all(ok) || SP_ABL(4)) break;
           if (++spins > kSpinLimit || ((spins & 1023u) == 0 && __hip_atomic_load(a.err_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
             atomicExch(a.err_flag, 1);
             s_fail = 1;
@@ -1202,6 +1207,8 @@ __device__ void head_role(const WnSpipeArgs& a, int p) {
     for (int k = 0; k < 6; ++k) a.stamps[176 + k] = hs_t[k];
   if (STAMPS && a.stamps && (a.dbg & 4) && p == 0 && tid == 0) a.stamps[144 + a.L] = __builtin_amdgcn_s_memrealtime();
 }
+
+#include "wavenet_spipe_pair.inc"
 
 template <bool STAMPS, bool LAG4>
 __global__ __launch_bounds__(kThreads) void wavenet_spipe_kernel(const WnSpipeArgs a) {
@@ -1378,6 +1385,17 @@ int launch_wavenet_spipe(const WnSpipeArgs& a, hipStream_t stream) {
     MMK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&wavenet_spipe_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
     MMK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&wavenet_spipe_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
 #endif
+  }
+  // two clips per visit (wavenet_spipe_pair.inc) where the ring goes at the stages' beat: a.pair 1 asks for it, 0 refuses it, < 0 leaves it to the clip count
+  // (diagnostic build: the pair form takes the two wall-clock stamps per visit only; the phase stamps belong to the one-clip form: MMK_WN_SPIPE_PAIR=0)
+  const bool pair = wn_spipe_pair_form(a.B, a.pair);
+  if (pair) {
+    const size_t lds2 = sizeof(Lds2) + (size_t)4 * 2 * bias_cap(a.B) * 16 * sizeof(float);
+    MMK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&wavenet_spipe_pair_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)(sizeof(Lds2) + (size_t)4 * 2 * kSpMaxClips * 16 * sizeof(float))));
+    hipLaunchKernelGGL(wavenet_spipe_pair_kernel, dim3(256), dim3(kThreads), lds2, stream, a);
+    MMK_HIP(hipGetLastError());
+    return MMK_OK;
   }
   const bool lag4 = MMK_SP_LAG && a.B >= MMK_SP_LAG_CLIPS && a.B >= 12;      // (the biases four iterations behind the messages: helper_role)
 #ifdef MMK_DIAG

@@ -73,6 +73,13 @@ class NativeError(RuntimeError):
 
 
 WN_BPIPE_MIN_CLIPS = 105  # csrc/wavenet_plan.hip: kBpipeMinClips (tests/test_host_logic.py holds the two together)
+WN_BPIPE_ALWAYS_CLIPS = 129  # csrc/wavenet_plan.hip: kBpipeAlwaysClips = one more than a ring takes
+
+
+def wn_bpipe_by_default(batch: int) -> bool:
+    """csrc/wavenet_plan.hip: bpipe_by_default - which batches of a stage-pipeline network run in groups of 16 clips (wavenet_bpipe.hip) unless the plan
+    switch MMK_WN_BPIPE says otherwise: more than one ring's 128, and from 105 on the counts the ring's two-clip visits do not take (not a multiple of 4)"""
+    return batch >= WN_BPIPE_ALWAYS_CLIPS or (batch >= WN_BPIPE_MIN_CLIPS and batch % 4 != 0)
 TUNING_CHARS = 256        # include/mmk.h: MMK_TUNING_CHARS
 
 # Execution switches handed to every plan this process creates, as {"MMK_WN_CHAIN": "0", ...} (merged under a network's own
@@ -165,6 +172,7 @@ _SIGNATURES = {
     "mmk_wavenet_profile_steps": (i32, [vp, i32, vp, i64, C.POINTER(vp), C.POINTER(i64), i64, i64,
                                         C.POINTER(C.c_double), C.POINTER(i64), vp]),
     "mmk_wavenet_mode": (i32, [vp]),
+    "mmk_wavenet_pair_visits": (i32, [vp]),
     "mmk_wavenet_sync_status": (i32, [vp, vp]),
     "mmk_wavenet_inject_sync_error": (i32, [vp, vp]),
     "mmk_srnn_plan_create": (i32, [C.POINTER(SrnnConfig), C.POINTER(vp)]),
@@ -619,6 +627,11 @@ class WaveNetPlan(_Plan):
         """persistent mode with one layer per stage of 8 CUs: the clips streamed through one at a time (csrc/wavenet_spipe.hip) or,
         large batches, in groups of 16 (csrc/wavenet_bpipe.hip)"""
         return self._lib.mmk_wavenet_mode(self.handle) in (5, 6)
+
+    @property
+    def pair_visits(self) -> bool:
+        """the last launch of the one-clip ring took two clips per visit (csrc/wavenet_spipe_pair.inc)"""
+        return bool(self._lib.mmk_wavenet_pair_visits(self.handle))
 
     @property
     def batch_pipelined(self) -> bool:

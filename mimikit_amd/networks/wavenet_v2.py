@@ -405,9 +405,9 @@ class WaveNet(ARM, nn.Module):
         rebuilt = False
         tuning = native.tuning_text(native.PLAN_TUNING, self.exec_tuning)
         stale = self._plan is None or self._plan_tuning != tuning or self._plan_batch < batch or self._plan.device != device
-        # the step kernel is chosen for the batch a plan is made for: one made for >= 105 clips serves groups of 16 clips per visit (~107 us per step
-        # whatever the batch), which a later call of a few clips must not pay - it gets a plan of its own size (the one-clip ring: ~1.1 us per clip)
-        if not stale and batch < native.WN_BPIPE_MIN_CLIPS and getattr(self._plan, "batch_pipelined", False) and b"MMK_WN_BPIPE=1" not in tuning:
+        # the step kernel is chosen for the batch a plan is made for: one made for more than 128 clips serves groups of 16 clips per visit (~107 us per step
+        # whatever the batch), which a later call of fewer clips must not pay - it gets a plan of its own size (the ring: ~1.1 us per clip, 0.8 from 60 clips on)
+        if not stale and not native.wn_bpipe_by_default(batch) and getattr(self._plan, "batch_pipelined", False) and b"MMK_WN_BPIPE=1" not in tuning:
             stale = True
         if stale:
             self._plan = native.make_wavenet_plan(self._describe, max(batch, 1), device)

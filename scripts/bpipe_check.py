@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--steps", type=int, default=64)
     ap.add_argument("--prompt", type=int, default=3072)
     ap.add_argument("--only", default="", help="bpipe | spipe: run one of the two (no comparison)")
+    ap.add_argument("--pair", default="", help="0 | 1: the one-clip ring with / without two clips per visit (MMK_WN_SPIPE_PAIR); default: by the clip count")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
     net, sd, arch = cfg4_network()
@@ -34,6 +35,8 @@ def main():
         if args.only and name != args.only:
             continue
         net.exec_tuning = dict(tuning)
+        if args.pair and name == "spipe":
+            net.exec_tuning["MMK_WN_SPIPE_PAIR"] = args.pair
         net._plan = None
         best = None
         for rep in range(2):

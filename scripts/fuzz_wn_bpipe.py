@@ -1,6 +1,7 @@
 """Random geometries of the batched stage pipeline (wavenet_bpipe.hip) against the oracle (GPU box): 1 .. 31 layers in random blocks (dilation 1 in
 the middle of the net included), 1 .. 90 clips (ragged last groups), zero / one / two conditioning inputs of random widths, narrower heads, random prompt
-lengths and block splits; greedy classes wherever the oracle's margin allows, then a sampled run.  python scripts/fuzz_wn_bpipe.py [cases]"""
+lengths and block splits; greedy classes wherever the oracle's margin allows, then a sampled run.  python scripts/fuzz_wn_bpipe.py [cases]
+FUZZ_FORM=pair: the same for the ring with two clips per visit (wavenet_spipe_pair.inc): 24 .. 128 clips, multiples of 4."""
 import os
 import random
 import sys
@@ -18,8 +19,11 @@ from oracle.weights import load_recipe  # noqa: E402
 torch.set_grad_enabled(False)
 dev = torch.device("cuda", 0)
 rng = random.Random(int(os.environ.get("FUZZ_SEED", "23")))
+PAIR = os.environ.get("FUZZ_FORM", "") == "pair"
 mmk.native.PLAN_TUNING["MMK_WN_SPIPE"] = "1"
-mmk.native.PLAN_TUNING["MMK_WN_BPIPE"] = "1"
+mmk.native.PLAN_TUNING["MMK_WN_BPIPE"] = "0" if PAIR else "1"
+if PAIR:
+    mmk.native.PLAN_TUNING["MMK_WN_SPIPE_PAIR"] = "1"
 bad = 0
 for case in range(int(sys.argv[1]) if len(sys.argv) > 1 else 16):
     L = rng.choice([1, 2, 3, 5, 8, 12, 20, 31])
@@ -28,7 +32,7 @@ for case in range(int(sys.argv[1]) if len(sys.argv) > 1 else 16):
         b = rng.randint(1, min(left, 5))
         blocks.append(b)
         left -= b
-    B = rng.choice([1, 3, 15, 16, 17, 33, 48, 70, 90, 150, 260, 300])
+    B = rng.choice([24, 28, 36, 44, 60, 64, 72, 100, 128]) if PAIR else rng.choice([1, 3, 15, 16, 17, 33, 48, 70, 90, 150, 260, 300])
     cond_dims = rng.choice([(), (), (16,), (48,), (32, 16)])
     q, mlp_dim = rng.choice([(256, 128), (256, 128), (128, 64), (200, 100)])
     io = H.mu_emb(mlp_dim=mlp_dim, q_levels=q)
@@ -56,7 +60,7 @@ for case in range(int(sys.argv[1]) if len(sys.argv) > 1 else 16):
     got = idx.cpu()
     want, raw = O.wavenet_generate(sd, prompt, conds, n, keep_logits=True, forced=got, **arch)
     ok = H.margin_ok(raw.numpy())
-    good = bool(((got[:, P:] == want[:, P:]) | ~ok).all()) and float(ok.float().mean()) > 0.9 and net._plan.batch_pipelined and int(got.max()) < q
+    good = bool(((got[:, P:] == want[:, P:]) | ~ok).all()) and float(ok.float().mean()) > 0.9 and (net._plan.pair_visits if PAIR else net._plan.batch_pipelined) and int(got.max()) < q
     # sampled: the plan driven directly, so that the uniforms are known
     temp = torch.full((B,), 0.9)
     uni = torch.rand(B, n, generator=g)

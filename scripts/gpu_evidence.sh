@@ -95,6 +95,20 @@ sq)
   python3 scripts/pmc_summary.py --raw $O/sq_$wl $O/pmc_sq_${wl}_summary.csv | head -8
   trim
   ;;
+sqring)
+  # SQ counters of the cfg-4 step kernel at CLIPS clips with plan switches: sqring 128 "MMK_WN_BPIPE=0,MMK_WN_SPIPE_PAIR=1" [name]
+  n=$1; tun=$2; name=${3:-ring}
+  cd /tmp
+  i=0
+  for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_LDS SQ_WAIT_INST_LDS" "SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_ANY SQ_LDS_ADDR_CONFLICT"; do
+    i=$((i+1)); rm -rf $O/sq_${name}_$i
+    CLIPS=$n TUNING="$tun" timeout 600 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $O/sq_${name}_$i -- python3 $R/scripts/pmc_target.py > $O/sq_${name}_$i.log 2>&1
+    echo "set $i exit $?"
+  done
+  cd $R
+  python3 scripts/pmc_summary.py --raw $O $O/pmc_sq_${name}_clips${n}_summary.csv | grep "pipe" | head -14
+  trim
+  ;;
 soak)
   n=$1; passes=${2:-20}
   timeout 2400 python bench.py --clips $n --steps $passes --warmup 1 --no-cpu-baseline --no-strong-leg --no-others > $O/soak_$n.json 2> $O/soak_$n.err

@@ -20,6 +20,9 @@ job = bench.WaveNetJob(A, torch.device("cuda", 0), 0)
 job.to_device()
 p = job.prompt_len
 net = job.net
+for kv in os.environ.get("TUNING", "").split(","):          # plan switches of this run: TUNING="MMK_WN_BPIPE=0,MMK_WN_SPIPE_PAIR=1"
+    if "=" in kv:
+        net.exec_tuning[kv.split("=")[0]] = kv.split("=")[1]
 net._ensure_plan(job.clips, refresh_weights=True)
 if net._plan.persistent:
     # one warm-up launch of 12 positions, then ONE persistent launch of 1024 steps with head: the launch that

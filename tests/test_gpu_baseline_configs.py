@@ -131,7 +131,7 @@ def test_cfg4_wavenet_30x256_conditioned_32_clips(device):
     assert n_exact >= 0.97 * n_all
 
 
-def _cfg4_greedy_against_oracle(device, B, n, n_last, n_mid, seed, expect_set=None, tuning=None, expect_batched=False):
+def _cfg4_greedy_against_oracle(device, B, n, n_last, n_mid, seed, expect_set=None, tuning=None, expect_batched=False, expect_pair=None):
     """cfg 4 at ``B`` clips: ``n`` free-running greedy steps, twice (bit-identical), then the oracle teacher-forced on the device's
     own history: the last ``n_last`` steps of all clips, the steps around the start and the first launch boundary for eight clips,
     ``n_mid`` random mid-block steps for four clips each"""
@@ -156,6 +156,9 @@ def _cfg4_greedy_against_oracle(device, B, n, n_last, n_mid, seed, expect_set=No
     assert net._plan.stage_pipelined and net._plan.batch_pipelined == expect_batched
     if expect_set is not None:
         assert isinstance(net._plan, mmk.native.WaveNetPlanSet) == expect_set
+    if expect_pair is not None:
+        plans = net._plan.plans if isinstance(net._plan, mmk.native.WaveNetPlanSet) else [net._plan]
+        assert all(pl.pair_visits == expect_pair for pl in plans)
     hist2, _ = run()
     assert torch.equal(hist, hist2)
     assert int(hist[:, P:].min()) >= 0 and int(hist[:, P:].max()) < 256
@@ -195,19 +198,40 @@ def _cfg4_greedy_against_oracle(device, B, n, n_last, n_mid, seed, expect_set=No
 def test_cfg4_wavenet_64_clips_in_one_ring(device):
     """R = 4 GPUs of the 256-clip job give 64 clips per GPU.  The stage pipeline streams them through ONE ring (two
     clips per stage slot on average): 1100 free-running steps across a launch boundary, against the oracle"""
-    _cfg4_greedy_against_oracle(device, B=64, n=1100, n_last=2, n_mid=16, seed=464, expect_set=False)
+    _cfg4_greedy_against_oracle(device, B=64, n=1100, n_last=2, n_mid=16, seed=464, expect_set=False, expect_pair=True)
+
+
+def test_cfg4_wavenet_64_clips_one_clip_per_visit(device):
+    """the same 64 clips with the ring's two-clip visits refused (MMK_WN_SPIPE_PAIR=0): the one-clip form of 40 clips and more
+    (biases four visits behind, on the matrix pipe) - what 41 to 59 clips and the counts that are no multiple of 4 run on"""
+    _cfg4_greedy_against_oracle(device, B=64, n=300, n_last=1, n_mid=8, seed=4640, expect_set=False, tuning={"MMK_WN_SPIPE_PAIR": "0"}, expect_pair=False)
+
+
+def test_cfg4_wavenet_two_clips_per_visit_sizes(device):
+    """wavenet_spipe_pair.inc at the edges of its range: 24 clips (the fewest, by name: 12 visits per step, fewer than stages), 60 (the first count the plan
+    gives it), 100 (a multiple of 4 that is none of 8 or 16: the last batch of four biases of a step is followed by the next step's first);
+    62 clips (no multiple of 4) stay on the one-clip form"""
+    _cfg4_greedy_against_oracle(device, B=24, n=260, n_last=1, n_mid=6, seed=4024, expect_set=False, tuning={"MMK_WN_SPIPE_PAIR": "1"}, expect_pair=True)
+    _cfg4_greedy_against_oracle(device, B=60, n=260, n_last=1, n_mid=6, seed=4060, expect_set=False, expect_pair=True)
+    _cfg4_greedy_against_oracle(device, B=100, n=1030, n_last=1, n_mid=8, seed=4100, expect_set=False, expect_pair=True)
+    _cfg4_greedy_against_oracle(device, B=62, n=200, n_last=1, n_mid=4, seed=4062, expect_set=False, expect_pair=False)
 
 
 def test_cfg4_wavenet_128_clips_in_one_ring(device):
-    """R = 2: 128 clips per GPU, the most one ring takes (the bias image of a stage CU is 64 KB of its LDS then); the one-clip ring by name
-    (by name: from 105 clips on the plan takes groups of 16 clips on the matrix pipe - the tests below)"""
-    _cfg4_greedy_against_oracle(device, B=128, n=600, n_last=1, n_mid=12, seed=4128, expect_set=False, tuning={"MMK_WN_BPIPE": "0"})
+    """R = 2: 128 clips per GPU, the most one ring takes (the bias image of a stage CU is 64 KB of its LDS then), two clips per visit: the plan's
+    default for 128 clips since round 6 (100 us per step against the 16-clip groups' 108)"""
+    _cfg4_greedy_against_oracle(device, B=128, n=1030, n_last=1, n_mid=12, seed=4128, expect_set=False, expect_pair=True)
+
+
+def test_cfg4_wavenet_128_clips_one_clip_per_visit(device):
+    """... and one clip per visit, by name"""
+    _cfg4_greedy_against_oracle(device, B=128, n=300, n_last=1, n_mid=6, seed=41281, expect_set=False, tuning={"MMK_WN_SPIPE_PAIR": "0"}, expect_pair=False)
 
 
 def test_cfg4_wavenet_more_clips_than_one_ring(device):
     """the reference's loop takes any batch (loops/generate.py:207-219): 136 clips run as two passes of 68 through the stage
     pipeline (native.WaveNetPlanSet), never on the round-1 fallback kernel (the one-clip ring by name)"""
-    _cfg4_greedy_against_oracle(device, B=136, n=1030, n_last=1, n_mid=10, seed=4136, expect_set=True, tuning={"MMK_WN_BPIPE": "0"})
+    _cfg4_greedy_against_oracle(device, B=136, n=1030, n_last=1, n_mid=10, seed=4136, expect_set=True, tuning={"MMK_WN_BPIPE": "0"}, expect_pair=True)
 
 
 def test_cfg4_wavenet_256_clips_in_groups_of_16(device):
@@ -217,8 +241,8 @@ def test_cfg4_wavenet_256_clips_in_groups_of_16(device):
 
 
 def test_cfg4_wavenet_128_clips_in_groups_of_16(device):
-    """R = 2 of the 256-clip job: 128 clips per GPU as eight groups of 16 (the plan's default from 105 clips on)"""
-    _cfg4_greedy_against_oracle(device, B=128, n=1030, n_last=1, n_mid=8, seed=41280, expect_set=False, expect_batched=True)
+    """128 clips as eight groups of 16, by name (the plan's default above 128 clips, and from 105 on for the counts that are no multiple of 4)"""
+    _cfg4_greedy_against_oracle(device, B=128, n=1030, n_last=1, n_mid=8, seed=41280, expect_set=False, expect_batched=True, tuning={"MMK_WN_BPIPE": "1"})
 
 
 def test_cfg4_wavenet_ragged_groups_of_16(device):
@@ -227,13 +251,13 @@ def test_cfg4_wavenet_ragged_groups_of_16(device):
 
 
 def test_cfg4_a_small_batch_after_a_large_one_gets_the_one_clip_ring(device):
-    """the step kernel follows the CALL's batch: a network that generated 112 clips in groups of 16 (wavenet_bpipe.hip) and is then asked for 6
+    """the step kernel follows the CALL's batch: a network that generated 144 clips in groups of 16 (wavenet_bpipe.hip) and is then asked for 6
     clips runs them on the one-clip ring (a new plan), not as one group of 16 on the large-batch kernel - and back; every generation equals the
     oracle at its last step"""
     net, sd, arch = cfg4_network()
     net = net.to(device)
     rf, P, n = net.rf, 3072, 24
-    for B, batched in ((112, True), (6, False), (112, True)):
+    for B, batched in ((144, True), (6, False), (144, True)):
         gen = torch.Generator().manual_seed(4000 + B)
         prompt = torch.randint(0, 256, (B, P), generator=gen)
         cond = torch.rand(B, P + n, 513, generator=gen)
