@@ -179,7 +179,8 @@ class WaveNetJob:
             us = start.elapsed_time(stop) * 1e3
             nbytes = self.step_bytes() * n
             achieved = nbytes / (us * 1e-6) / 1e9
-            kshort = ("wavenet_bpipe_kernel" if getattr(plan, "batch_pipelined", False) else "wavenet_spipe_kernel" if plan.stage_pipelined
+            kshort = ("wavenet_bpipe_kernel" if getattr(plan, "batch_pipelined", False) else "wavenet_spipe_pair_kernel" if getattr(plan, "pair_visits", False)
+                      else "wavenet_spipe_kernel" if plan.stage_pipelined
                       else "wavenet_lpipe_kernel" if plan.layer_pipelined else "wavenet_chain_kernel" if plan.chain else "wavenet_persist_kernel")
             traffic, traffic_source = None, None
             try:  # PMC-derived HBM bytes of one 1024-step launch: NOT measured in this run (counters need their own rocprofv3
@@ -195,6 +196,7 @@ class WaveNetJob:
             except (OSError, ValueError):
                 pass
             kname = ("wavenet_bpipe_kernel (one layer per stage of 8 CUs, weights in registers as MFMA A operands, clips in groups of 16 per visit)" if getattr(plan, "batch_pipelined", False)
+                     else "wavenet_spipe_pair_kernel (one layer per stage of 8 CUs, weights in registers, clips streamed through two at a time)" if getattr(plan, "pair_visits", False)
                      else "wavenet_spipe_kernel (one layer per stage of 8 CUs, weights in registers, clips streamed through one at a time)" if plan.stage_pipelined
                      else "wavenet_lpipe_kernel (four workgroups per clip that own whole layers, weights in registers)" if plan.layer_pipelined
                      else "wavenet_chain_kernel (one hand-off per layer)" if plan.chain else "wavenet_persist_kernel")
@@ -707,7 +709,8 @@ def strong_scaling_leg(args, device, rank, world, sync):
     steps, warmup = 2, 1
     elapsed = timed_passes(job.one_pass, steps, warmup, sync)
     plan = job.net._plan
-    kernel = ("wavenet_bpipe_kernel" if getattr(plan, "batch_pipelined", False) else "wavenet_spipe_kernel" if plan.stage_pipelined else "other")
+    kernel = ("wavenet_bpipe_kernel" if getattr(plan, "batch_pipelined", False) else "wavenet_spipe_pair_kernel" if getattr(plan, "pair_visits", False)
+              else "wavenet_spipe_kernel" if plan.stage_pipelined else "other")
     out = {"global_clips": STRONG_GLOBAL_CLIPS, "n_gpus": world, "clips_on_rank_0": hi - lo, "generated_samples_per_clip": job.n_steps,
            "steps": steps, "warmup": warmup, "value": round(STRONG_GLOBAL_CLIPS * job.n_steps * steps / elapsed, 1), "unit": job.unit,
            "us_per_ar_step": round(1e6 * elapsed / (steps * job.n_steps), 2), "kernel": kernel, "decode": job.decode}

@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(HERE, "libmmk_hip.so")
 SOURCES = ["kernels.hip", "linear.hip", "gemm.hip", "skinny.hip", "features.hip", "wavenet_plan.hip", "wavenet_persist.hip", "wavenet_chain.hip", "wavenet_lpipe.hip", "wavenet_spipe.hip", "wavenet_bpipe.hip", "wavenet_prefill.hip", "srnn_plan.hip",
            "srnn_bottom.hip", "srnn_gru.hip", "srnn_resident.hip", "lstm_step.hip", "lstm_seq.hip", "lstm_inproj.hip", "istft.hip", "spectral2048.hip", "s2s_plan.hip"]
 # every header under csrc/ (a header missing from a hand-kept list once left a stale library behind) + the C ABI
-HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith(".h")) + [os.path.join("..", "..", "include", "mmk.h")]
+HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith((".h", ".inc"))) + [os.path.join("..", "..", "include", "mmk.h")]
 ARCH = "gfx950"
 
 

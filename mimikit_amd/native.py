@@ -720,6 +720,7 @@ class WaveNetPlanSet:
     layer_pipelined = property(lambda self: self.plans[0].layer_pipelined)
     stage_pipelined = property(lambda self: self.plans[0].stage_pipelined)
     batch_pipelined = property(lambda self: self.plans[0].batch_pipelined)
+    pair_visits = property(lambda self: all(plan.pair_visits for plan in self.plans))
 
     def sync_status(self):
         err = None

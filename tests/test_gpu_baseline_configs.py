@@ -157,8 +157,7 @@ def _cfg4_greedy_against_oracle(device, B, n, n_last, n_mid, seed, expect_set=No
     if expect_set is not None:
         assert isinstance(net._plan, mmk.native.WaveNetPlanSet) == expect_set
     if expect_pair is not None:
-        plans = net._plan.plans if isinstance(net._plan, mmk.native.WaveNetPlanSet) else [net._plan]
-        assert all(pl.pair_visits == expect_pair for pl in plans)
+        assert net._plan.pair_visits == expect_pair
     hist2, _ = run()
     assert torch.equal(hist, hist2)
     assert int(hist[:, P:].min()) >= 0 and int(hist[:, P:].max()) < 256
