@@ -48,8 +48,14 @@ constexpr int kThreads = 512;
 constexpr int kCuPerStage = kC / 32;          // 8
 constexpr int kWavesPerStage = kC / 8;        // 32 chain waves (and as many helpers)
 constexpr int kMsgFloats = 2 * kC;            // 512
+#ifndef MMK_SP_XSLICE20
+#define MMK_SP_XSLICE20 1      // the LDS image of a message as 16 slices of 16 channels + 4 floats of padding (the chain lanes' 16-byte reads of 16 different slices then
+                               // cover the 64 banks once); 0: round 3's blocks of 32 channels + 4, whose slices collide pairwise (31 % of the LDS-active cycles at 128 clips:
+                               // profiles/r06_v2_pmc_sq_single_clips128_summary.csv)
+#endif
 constexpr int kPadBlk = 36;                   // 32 channels + 4 floats of padding: the K slices of a broadcast read fall on different banks
-constexpr int kHalf = (kC / 32) * kPadBlk;    // 288 floats: one padded vector of C channels
+constexpr int kXSlice = 20;                   // 16 channels + 4 floats of padding
+constexpr int kHalf = MMK_SP_XSLICE20 ? 16 * kXSlice : (kC / 32) * kPadBlk;    // 320 (288) floats: one padded vector of C channels
 constexpr int kXyRing = 8;
 constexpr int kChainRegs = 44, kHelperRegs = 32;   // float4 registers per lane in the stage images
 constexpr unsigned kSpinLimit = 1u << 22;
@@ -127,7 +133,8 @@ constexpr int kSlotShift = MMK_SP_SLOT_SHIFT;
 #ifndef MMK_SP_WAKEUP
 #define MMK_SP_WAKEUP 1        // the looking helper wakes the chain waves out of their s_sleep when it has staged a message
 #endif
-__device__ __forceinline__ int pad_of(int ch) { return (ch >> 5) * kPadBlk + (ch & 31); }
+__device__ __forceinline__ int pad_of(int ch) { return MMK_SP_XSLICE20 ? (ch >> 4) * kXSlice + (ch & 15) : (ch >> 5) * kPadBlk + (ch & 31); }
+static_assert(!MMK_SP_XSLICE20 || MMK_SP_ROWS8, "the 20-float slices belong to the 8-row form of the chain products");
 
 __device__ __forceinline__ float dpp_quad_sum(float v) {
   v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, false));   // quad_perm [1,0,3,2]
