@@ -26,9 +26,9 @@ using namespace mmk;
 // 1.06 per clip: 104 clips are where the two meet
 constexpr int kBpipeMinClips = 105;
 // Round 6: the ring with TWO clips per visit (wavenet_spipe_pair.inc) takes 128 clips in 100 us per step and 112 in 88, so up to the ring's 128 clips the groups of 16
-// are left with the clip counts the pair form does not take (not a multiple of 4)
+// are left with the clip counts the pair form does not take (odd ones)
 constexpr int kBpipeAlwaysClips = kSpMaxClips + 1;
-static bool bpipe_by_default(int B) { return B >= kBpipeAlwaysClips || (B >= kBpipeMinClips && B % 4 != 0); }
+static bool bpipe_by_default(int B) { return B >= kBpipeAlwaysClips || (B >= kBpipeMinClips && B % 2 != 0); }
 
 struct WnCall {
   int M = 0;

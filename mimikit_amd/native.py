@@ -78,8 +78,8 @@ WN_BPIPE_ALWAYS_CLIPS = 129  # csrc/wavenet_plan.hip: kBpipeAlwaysClips = one mo
 
 def wn_bpipe_by_default(batch: int) -> bool:
     """csrc/wavenet_plan.hip: bpipe_by_default - which batches of a stage-pipeline network run in groups of 16 clips (wavenet_bpipe.hip) unless the plan
-    switch MMK_WN_BPIPE says otherwise: more than one ring's 128, and from 105 on the counts the ring's two-clip visits do not take (not a multiple of 4)"""
-    return batch >= WN_BPIPE_ALWAYS_CLIPS or (batch >= WN_BPIPE_MIN_CLIPS and batch % 4 != 0)
+    switch MMK_WN_BPIPE says otherwise: more than one ring's 128, and from 105 on the counts the ring's two-clip visits do not take (odd ones)"""
+    return batch >= WN_BPIPE_ALWAYS_CLIPS or (batch >= WN_BPIPE_MIN_CLIPS and batch % 2 != 0)
 TUNING_CHARS = 256        # include/mmk.h: MMK_TUNING_CHARS
 
 # Execution switches handed to every plan this process creates, as {"MMK_WN_CHAIN": "0", ...} (merged under a network's own

@@ -1,7 +1,7 @@
 """Random geometries of the batched stage pipeline (wavenet_bpipe.hip) against the oracle (GPU box): 1 .. 31 layers in random blocks (dilation 1 in
 the middle of the net included), 1 .. 90 clips (ragged last groups), zero / one / two conditioning inputs of random widths, narrower heads, random prompt
 lengths and block splits; greedy classes wherever the oracle's margin allows, then a sampled run.  python scripts/fuzz_wn_bpipe.py [cases]
-FUZZ_FORM=pair: the same for the ring with two clips per visit (wavenet_spipe_pair.inc): 24 .. 128 clips, multiples of 4."""
+FUZZ_FORM=pair: the same for the ring with two clips per visit (wavenet_spipe_pair.inc): 24 .. 128 clips, even counts."""
 import os
 import random
 import sys
@@ -32,7 +32,7 @@ for case in range(int(sys.argv[1]) if len(sys.argv) > 1 else 16):
         b = rng.randint(1, min(left, 5))
         blocks.append(b)
         left -= b
-    B = rng.choice([24, 28, 36, 44, 60, 64, 72, 100, 128]) if PAIR else rng.choice([1, 3, 15, 16, 17, 33, 48, 70, 90, 150, 260, 300])
+    B = rng.choice([24, 26, 30, 36, 44, 46, 60, 62, 64, 70, 100, 102, 126, 128]) if PAIR else rng.choice([1, 3, 15, 16, 17, 33, 48, 70, 90, 150, 260, 300])
     cond_dims = rng.choice([(), (), (16,), (48,), (32, 16)])
     q, mlp_dim = rng.choice([(256, 128), (256, 128), (128, 64), (200, 100)])
     io = H.mu_emb(mlp_dim=mlp_dim, q_levels=q)

@@ -202,18 +202,19 @@ def test_cfg4_wavenet_64_clips_in_one_ring(device):
 
 def test_cfg4_wavenet_64_clips_one_clip_per_visit(device):
     """the same 64 clips with the ring's two-clip visits refused (MMK_WN_SPIPE_PAIR=0): the one-clip form of 40 clips and more
-    (biases four visits behind, on the matrix pipe) - what 41 to 59 clips and the counts that are no multiple of 4 run on"""
+    (biases four visits behind, on the matrix pipe) - what 41 to 59 clips and the odd counts run on"""
     _cfg4_greedy_against_oracle(device, B=64, n=300, n_last=1, n_mid=8, seed=4640, expect_set=False, tuning={"MMK_WN_SPIPE_PAIR": "0"}, expect_pair=False)
 
 
 def test_cfg4_wavenet_two_clips_per_visit_sizes(device):
     """wavenet_spipe_pair.inc at the edges of its range: 24 clips (the fewest, by name: 12 visits per step, fewer than stages), 60 (the first count the plan
     gives it), 100 (a multiple of 4 that is none of 8 or 16: the last batch of four biases of a step is followed by the next step's first);
-    62 clips (no multiple of 4) stay on the one-clip form"""
+    62 clips (even, no multiple of 4: the last batch of four biases of a step holds two clips of the next); 63 clips stay on the one-clip form"""
     _cfg4_greedy_against_oracle(device, B=24, n=260, n_last=1, n_mid=6, seed=4024, expect_set=False, tuning={"MMK_WN_SPIPE_PAIR": "1"}, expect_pair=True)
     _cfg4_greedy_against_oracle(device, B=60, n=260, n_last=1, n_mid=6, seed=4060, expect_set=False, expect_pair=True)
     _cfg4_greedy_against_oracle(device, B=100, n=1030, n_last=1, n_mid=8, seed=4100, expect_set=False, expect_pair=True)
-    _cfg4_greedy_against_oracle(device, B=62, n=200, n_last=1, n_mid=4, seed=4062, expect_set=False, expect_pair=False)
+    _cfg4_greedy_against_oracle(device, B=62, n=260, n_last=1, n_mid=6, seed=4062, expect_set=False, expect_pair=True)
+    _cfg4_greedy_against_oracle(device, B=63, n=200, n_last=1, n_mid=4, seed=4063, expect_set=False, expect_pair=False)
 
 
 def test_cfg4_wavenet_128_clips_in_one_ring(device):

@@ -210,8 +210,8 @@ def test_execution_switches_travel_in_the_config_not_in_the_environment(monkeypa
     assert _cfg4_plan_mode(b"") == 5
     # many clips per GPU: the same stages with groups of 16 clips per visit on the matrix pipe (wavenet_bpipe.hip), up to 512 clips a launch
     assert _cfg4_plan_mode(b"", clips=104) == 5 and _cfg4_plan_mode(b"", clips=105) == 6 and _cfg4_plan_mode(b"", clips=512) == 6
-    # ... except where the ring takes the clips two per visit (a multiple of 4, up to its 128 clips): round 6
-    assert _cfg4_plan_mode(b"", clips=108) == 5 and _cfg4_plan_mode(b"", clips=128) == 5 and _cfg4_plan_mode(b"", clips=129) == 6 and _cfg4_plan_mode(b"", clips=130) == 6
+    # ... except where the ring takes the clips two per visit (an even count, up to its 128 clips): round 6
+    assert _cfg4_plan_mode(b"", clips=106) == 5 and _cfg4_plan_mode(b"", clips=128) == 5 and _cfg4_plan_mode(b"", clips=129) == 6 and _cfg4_plan_mode(b"", clips=130) == 6
     for clips in (1, 32, 64, 104, 105, 106, 107, 108, 127, 128, 129, 132, 256):      # (what wavenet_v2._ensure_plan re-plans a smaller batch by)
         assert (_cfg4_plan_mode(b"", clips=clips) == 6) == native.wn_bpipe_by_default(clips), clips
     assert _cfg4_plan_mode(b"MMK_WN_BPIPE=0", clips=128) == 5 and _cfg4_plan_mode(b"MMK_WN_BPIPE=1", clips=8) == 6
