@@ -48,6 +48,9 @@ constexpr int kThreads = 512;
 constexpr int kCuPerStage = kC / 32;          // 8
 constexpr int kWavesPerStage = kC / 8;        // 32 chain waves (and as many helpers)
 constexpr int kMsgFloats = 2 * kC;            // 512
+#ifndef MMK_SP_EARLY_Y
+#define MMK_SP_EARLY_Y 1
+#endif
 #ifndef MMK_SP_XSLICE20
 #define MMK_SP_XSLICE20 1      // the LDS image of a message as 16 slices of 16 channels + 4 floats of padding (the chain lanes' 16-byte reads of 16 different slices then
                                // cover the 64 banks once); 0: round 3's blocks of 32 channels + 4, whose slices collide pairwise (31 % of the LDS-active cycles at 128 clips:
@@ -380,9 +383,25 @@ __device__ void chain_role(const WnSpipeArgs& a, Lds& S, int stage, int p, int q
       f32x2 acc8[8];
 #pragma unroll
       for (int cc = 0; cc < 8; ++cc) acc8[cc] = f32x2{0.f, 0.f};
+#if MMK_SP_EARLY_Y
+      // the y slice of the residual product and the layer's own input are asked for NOW, with the gate products' reads: left to the compiler they go out behind the
+      // 64 gate products (it re-uses their registers) and are waited for at once - an LDS round trip in front of the residual product, on every visit's chain
+      f32x4s xv4[4], yv4[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) xv4[i] = *reinterpret_cast<const f32x4s*>(xb + kso + i * 4);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) yv4[i] = *reinterpret_cast<const f32x4s*>(xb + xr_off + i * 4);
+      const float xin_early = xb[xin_off];
+      __builtin_amdgcn_sched_barrier(0);
+#endif
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
+#if MMK_SP_EARLY_Y
+        const f32x4s xv = xv4[i];
+#else
         const f32x4s xv = *reinterpret_cast<const f32x4s*>(xb + kso + i * 4);
+#endif
 #pragma unroll
         for (int cc = 0; cc < 8; ++cc) {
           acc8[cc] = fma2(f32x2{wz[cc * 4 + i][0], wz[cc * 4 + i][1]}, f32x2{xv[0], xv[1]}, acc8[cc]);
@@ -410,14 +429,22 @@ __device__ void chain_role(const WnSpipeArgs& a, Lds& S, int stage, int p, int q
       for (int cc = 0; cc < 2; ++cc) rac[cc][0] = rac[cc][1] = f32x2{0.f, 0.f};
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
+#if MMK_SP_EARLY_Y && MMK_SP_ROWS8
+        const f32x4s yv = yv4[i];
+#else
         const f32x4s yv = *reinterpret_cast<const f32x4s*>(xb + xr_off + i * 4);
+#endif
 #pragma unroll
         for (int cc = 0; cc < 2; ++cc) {
           rac[cc][0] = fma2(f32x2{wr[cc * 4 + i][0], wr[cc * 4 + i][1]}, f32x2{yv[0], yv[1]}, rac[cc][0]);
           rac[cc][1] = fma2(f32x2{wr[cc * 4 + i][2], wr[cc * 4 + i][3]}, f32x2{yv[2], yv[3]}, rac[cc][1]);
         }
       }
+#if MMK_SP_EARLY_Y && MMK_SP_ROWS8
+      const float xin = xin_early;
+#else
       const float xin = xb[xin_off];
+#endif
       float zc[4];
 #if MMK_SP_ROWS8
 #pragma unroll
