@@ -51,6 +51,9 @@ constexpr int kMsgFloats = 2 * kC;            // 512
 #ifndef MMK_SP_EARLY_Y
 #define MMK_SP_EARLY_Y 1
 #endif
+#ifndef MMK_SP_HOIST_ADDR
+#define MMK_SP_HOIST_ADDR 1
+#endif
 #ifndef MMK_SP_XSLICE20
 #define MMK_SP_XSLICE20 1      // the LDS image of a message as 16 slices of 16 channels + 4 floats of padding (the chain lanes' 16-byte reads of 16 different slices then
                                // cover the 64 banks once); 0: round 3's blocks of 32 channels + 4, whose slices collide pairwise (31 % of the LDS-active cycles at 128 clips:
@@ -362,6 +365,17 @@ __device__ void chain_role(const WnSpipeArgs& a, Lds& S, int stage, int p, int q
     const int slot = s & 3, pslot = (s + 2) & 3;
     for (int c = 0; c < B; ++c, ++v) {
       if (STAMPS && !(a.dbg & 64)) t0c = __builtin_amdgcn_s_memtime();
+#if MMK_SP_HOIST_ADDR
+      // where this visit reads and writes, worked out BEFORE the wait for its message (the compiler puts these eight scalar / vector instructions behind the wait,
+      // in front of the first LDS read - on every visit's chain)
+      typedef const __attribute__((address_space(3))) float* lds_cf;
+      typedef const __attribute__((address_space(3))) f32x4s* lds_cf4;
+      const int o_img = (int)(v & (kXyRing - 1)) * 2 * kHalf;
+      lds_cf p_z = (lds_cf)(&S.xy[0][0] + o_img + kso), p_y = (lds_cf)(&S.xy[0][0] + o_img + xr_off), p_in = (lds_cf)(&S.xy[0][0] + o_img + xin_off);
+      lds_cf p_b = (lds_cf)(&S.bias[bias_off(q, s & 1, c, j, Bcap)]);
+      int64_t o_dst = ((int64_t)c * kSpSlots + slot) * kMsgFloats + pub_off;
+      asm volatile("" : "+v"(p_z), "+v"(p_y), "+v"(p_in), "+v"(p_b), "+v"(o_dst));
+#endif
       if (!chain_wait<MMK_SP_CHAIN_SLEEP_BY_MODE ? (LAG4 ? kChainSleep : 0) : kChainSleep>(S, q, v, a.err_flag)) return;
       __builtin_amdgcn_s_setprio(MMK_SP_CHAIN_PRIO);              // (low while it spins: the helper wave of this SIMD gets the issue slots)
       if (STAMPS && !(a.dbg & 64)) {
@@ -374,8 +388,13 @@ __device__ void chain_role(const WnSpipeArgs& a, Lds& S, int stage, int p, int q
         continue;
       }
       // what the helper prepared a step ahead: W0 x[t - d] + conditioning + biases
+#if MMK_SP_HOIST_ADDR
+      const float bzv = *p_b;
+      const float* xb = &S.xy[0][0] + o_img;
+#else
       const float bzv = S.bias[bias_off(q, s & 1, c, j, Bcap)];
       const float* xb = S.xy[v & (kXyRing - 1)];
+#endif
 #if MMK_SP_ROWS8
       // ---- z = [W1 | W1 R] . [x ; y]: 8 gate rows x ONE K slice of 16 per lane: 4 reads of 4 inputs (half of what 4 rows x 32 inputs read:
       //      the four chain waves' reads share one LDS), 64 packed FMAs; the two rows of 16 lanes that hold the same 8 gate rows swap
@@ -387,12 +406,21 @@ __device__ void chain_role(const WnSpipeArgs& a, Lds& S, int stage, int p, int q
       // the y slice of the residual product and the layer's own input are asked for NOW, with the gate products' reads: left to the compiler they go out behind the
       // 64 gate products (it re-uses their registers) and are waited for at once - an LDS round trip in front of the residual product, on every visit's chain
       f32x4s xv4[4], yv4[4];
+#if MMK_SP_HOIST_ADDR
+#pragma unroll
+      for (int i = 0; i < 4; ++i) xv4[i] = ((lds_cf4)p_z)[i];
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) yv4[i] = ((lds_cf4)p_y)[i];
+      const float xin_early = *p_in;
+#else
 #pragma unroll
       for (int i = 0; i < 4; ++i) xv4[i] = *reinterpret_cast<const f32x4s*>(xb + kso + i * 4);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int i = 0; i < 4; ++i) yv4[i] = *reinterpret_cast<const f32x4s*>(xb + xr_off + i * 4);
       const float xin_early = xb[xin_off];
+#endif
       __builtin_amdgcn_sched_barrier(0);
 #endif
 #pragma unroll
@@ -467,7 +495,11 @@ __device__ void chain_role(const WnSpipeArgs& a, Lds& S, int stage, int p, int q
       const float y = act * other;
       // ---- publish 8 x | 8 y, re-poison the same words two steps ahead, keep x_s for the delayed taps -------------------------------------
       if (pub_lane) {
+#if MMK_SP_HOIST_ADDR
+        unsigned* dst = msg_out + o_dst;
+#else
         unsigned* dst = msg_out + ((int64_t)c * kSpSlots + slot) * kMsgFloats + pub_off;
+#endif
         msg_store(dst, msg_bits((lane & 1) ? y : xnew), local_next);
       }
       if (STAMPS && !(a.dbg & 64)) {
