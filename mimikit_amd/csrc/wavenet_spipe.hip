@@ -281,9 +281,56 @@ struct Stamps {
 // ------------------------------------------------------------------------------------------------------------------------------------
 // the two things a chain wave waits for in LDS before it computes visit v, read together: the message staged by the polling helper, this
 // wave's bias prepared
+#ifndef MMK_SP_TIGHT_WAIT
+#define MMK_SP_TIGHT_WAIT 1
+#endif
+// up to 4096 looks at ONE LDS counter in a loop of six instructions (read, wait, compare, branch out / count, branch back); returns the last value read.  The compiler's
+// form of the loop below - two reads, a minimum, the time-out's bookkeeping and three exits - leaves ~10 scalar instructions between the look that sees the message
+// and the first LDS read of the visit, on every visit's chain.
+__device__ __forceinline__ unsigned lds_spin_ge(const unsigned* p, unsigned want) {
+  const unsigned addr = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) unsigned*)p;
+  unsigned val, cnt;
+  asm volatile(
+      "s_movk_i32 %1, 0x1000\n"
+      "1:\n\t"
+      "ds_read_b32 %0, %2\n\t"
+      "s_waitcnt lgkmcnt(0)\n\t"
+      "v_cmp_le_u32 vcc, %3, %0\n\t"
+      "s_cbranch_vccnz 2f\n\t"
+      "s_sub_u32 %1, %1, 1\n\t"
+      "s_cmp_lg_u32 %1, 0\n\t"
+      "s_cbranch_scc1 1b\n"
+      "2:"
+      : "=&v"(val), "=&s"(cnt)
+      : "v"(addr), "s"(want)
+      : "vcc", "scc", "memory");
+  return (unsigned)__builtin_amdgcn_readfirstlane((int)val);      // (every lane read the same word: a scalar for the caller's branch)
+}
+
 template <int SLEEP>
 __device__ __forceinline__ bool chain_wait(const Lds& S, int q, unsigned v, int32_t* err) {
   unsigned spins = 0;
+#if MMK_SP_TIGHT_WAIT
+  if (SLEEP == 0) {      // (the trip-bound regime: no pause between two looks)
+    // the bias of a visit is made a step ahead: it is there, or it is waited for first - then ONE counter is looked at
+    while (__hip_atomic_load(&S.ready[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < v + 1) {
+      if (++spins > kSpinLimit || ((spins & 4095u) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+        atomicExch(err, 1);
+        return false;
+      }
+    }
+    for (;;) {
+      if (lds_spin_ge(&S.arrived[v & 3], v + 1) >= v + 1) break;
+      spins += 4096;
+      if (spins > kSpinLimit || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+        atomicExch(err, 1);
+        return false;
+      }
+    }
+    __atomic_signal_fence(__ATOMIC_SEQ_CST);
+    return true;
+  }
+#endif
   for (;;) {
     const unsigned arr = __hip_atomic_load(&S.arrived[v & 3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     const unsigned rd = __hip_atomic_load(&S.ready[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
