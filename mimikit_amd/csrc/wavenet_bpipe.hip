@@ -109,6 +109,15 @@ __device__ __forceinline__ void msg_put(unsigned* p, unsigned v, bool local) {
 }
 __device__ __forceinline__ unsigned bits_of(float v) { return min(__float_as_uint(v), 0xFFFFFFFEu); }     // (never the poison word: wavenet_spipe.hip)
 __device__ __forceinline__ bool clean(const u32x4b& v) { return v[0] != kSpPoison && v[1] != kSpPoison && v[2] != kSpPoison && v[3] != kSpPoison; }
+// the poison word is the largest unsigned: "no word of these is poison" as maxima and ONE compare (16 compares and their ands were ~35 instructions between a look's
+// return and the copy of its message into LDS)
+// (ONE running maximum: the kernel sits at its 256 registers, a tree's temporaries spill into the visit loop)
+__device__ __forceinline__ bool clean4(const u32x4b& a, const u32x4b& b, const u32x4b& c, const u32x4b& d) {
+  unsigned mx = max(max(a[0], a[1]), a[2]);
+  mx = max(max(mx, a[3]), b[0]); mx = max(max(mx, b[1]), b[2]); mx = max(max(mx, b[3]), c[0]); mx = max(max(mx, c[1]), c[2]);
+  mx = max(max(mx, c[3]), d[0]); mx = max(max(mx, d[1]), d[2]); mx = max(mx, d[3]);
+  return mx != kSpPoison;
+}
 
 // four 16-byte loads past the L1, 1 KB apart (a wave's 4 KB of a message)
 __device__ __forceinline__ void load4_sc1(const unsigned* p, u32x4b& r0, u32x4b& r1, u32x4b& r2, u32x4b& r3) {
@@ -215,7 +224,7 @@ __device__ __forceinline__ bool gather(const unsigned* src, float* dst, int lane
   unsigned spins = 0;
   for (;;) {
     load4_sc1(src + 4 * lane, r[0], r[1], r[2], r[3]);
-    if (__all(clean(r[0]) && clean(r[1]) && clean(r[2]) && clean(r[3]))) break;
+    if (__all(clean4(r[0], r[1], r[2], r[3]))) break;
     if (MMK_BP_LOOK_SLEEP > 0) __builtin_amdgcn_s_sleep(MMK_BP_LOOK_SLEEP);
     if (++spins > kSpin || ((spins & 1023u) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
       atomicMax(err, 0x10000 | tag);      // (diagnosis: which look never saw its message)
@@ -421,7 +430,7 @@ __device__ __forceinline__ void helper_role(const WnBpipeArgs& a, BpLds& S, int 
       unsigned spins = 0;
       for (;;) {
         load4_sc1(src + 4 * lane, r[0], r[1], r[2], r[3]);
-        if (__all(clean(r[0]) && clean(r[1]) && clean(r[2]) && clean(r[3]))) break;
+        if (__all(clean4(r[0], r[1], r[2], r[3]))) break;
         __builtin_amdgcn_s_sleep(2);
         if (++spins > kSpin || ((spins & 1023u) == 0 && __hip_atomic_load(a.err_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
           atomicMax(a.err_flag, 0x10000 | (64 * 17 + stage));
@@ -694,7 +703,7 @@ __device__ __forceinline__ void head_role(const WnBpipeArgs& a, unsigned char* l
                        : "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2])
                        : "v"(src)
                        : "memory");
-          if (__all(clean(r[0]) && clean(r[1]) && clean(r[2]))) break;
+          if (__all(clean4(r[0], r[1], r[2], r[2]))) break;
           __builtin_amdgcn_s_sleep(2);
           if (++spins > kSpin || ((spins & 1023u) == 0 && __hip_atomic_load(a.err_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
             atomicCAS(a.err_flag, 0, 0x20000 | a.L);
