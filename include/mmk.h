@@ -289,7 +289,7 @@ int mmk_wavenet_profile_steps(mmk_wavenet_plan* plan, int32_t batch, void* in0, 
  * 4 wavenet_lpipe.hip, 5 wavenet_spipe.hip, 6 wavenet_bpipe.hip; 3 was the XCD-pipelined kernel, removed in round 5: no geometry where it ran and won), 0 when it enqueues one fused kernel per layer half (hipGraph-replayed) */
 int mmk_wavenet_mode(const mmk_wavenet_plan* plan);
 /* 1 when the plan's last mode-5 launch streamed the clips through the stages two at a time (csrc/wavenet_spipe_pair.inc: an even number of clips,
- * 60 to 128 of them; the plan switch MMK_WN_SPIPE_PAIR=0 / 1 refuses / asks for it from 24 clips on), 0 otherwise */
+ * 54 to 128 of them; the plan switch MMK_WN_SPIPE_PAIR=0 / 1 refuses / asks for it from 24 clips on), 0 otherwise */
 int mmk_wavenet_pair_visits(const mmk_wavenet_plan* plan);
 /* waits for `stream`; MMK_ERR_STATE if a hand-off inside the persistent kernel timed out */
 int mmk_wavenet_sync_status(mmk_wavenet_plan* plan, mmk_stream_t stream);

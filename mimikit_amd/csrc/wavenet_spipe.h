@@ -58,8 +58,8 @@ struct WnSpipeArgs {
 };
 
 constexpr int kSpMaxClips = 128;        // clips in the ring (the LDS image of the prepared gate terms is 512 B per clip)
-constexpr int kSpPairMinClips = 60;     // two clips per visit from this many clips on (wavenet_spipe_pair.inc; measured on cfg 4, us per step, one / two clips per visit:
-                                        // 56 clips 62.4 / 66.0, 64 clips 69.9 / 66.4, 80 clips 85.9 / 68.7, 96 clips 102.5 / 81.2, 128 clips 135.5 / 99.9)
+constexpr int kSpPairMinClips = 54;     // two clips per visit from this many clips on (wavenet_spipe_pair.inc; measured on cfg 4, us per step, one / two clips per visit:
+                                        // 48 clips 53.0 / 58.6, 56 clips 60.3 / 58.7, 64 clips 68 / 58.7, 96 clips 100 / 77.4, 128 clips 133 / 98.8)
 // which form a launch of B clips takes: pair > 0 asks for two clips per visit, 0 refuses it, < 0 leaves it to the clip count (an even number of clips, at least 24)
 inline bool wn_spipe_pair_form(int B, int pair) { return B % 2 == 0 && B >= 24 && B <= kSpMaxClips && (pair > 0 || (pair < 0 && B >= kSpPairMinClips)); }
 
