@@ -284,14 +284,14 @@ struct Stamps {
 #ifndef MMK_SP_TIGHT_WAIT
 #define MMK_SP_TIGHT_WAIT 1
 #endif
-// up to 4096 looks at ONE LDS counter in a loop of six instructions (read, wait, compare, branch out / count, branch back); returns the last value read.  The compiler's
+// up to 2^22 looks (~0.2 s) at ONE LDS counter in a loop of six instructions (read, wait, compare, branch out / count, branch back); returns the last value read.  The compiler's
 // form of the loop below - two reads, a minimum, the time-out's bookkeeping and three exits - leaves ~10 scalar instructions between the look that sees the message
 // and the first LDS read of the visit, on every visit's chain.
 __device__ __forceinline__ unsigned lds_spin_ge(const unsigned* p, unsigned want) {
   const unsigned addr = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) unsigned*)p;
   unsigned val, cnt;
   asm volatile(
-      "s_movk_i32 %1, 0x1000\n"
+      "s_mov_b32 %1, 0x400000\n"
       "1:\n\t"
       "ds_read_b32 %0, %2\n\t"
       "s_waitcnt lgkmcnt(0)\n\t"
@@ -319,13 +319,12 @@ __device__ __forceinline__ bool chain_wait(const Lds& S, int q, unsigned v, int3
         return false;
       }
     }
-    for (;;) {
-      if (lds_spin_ge(&S.arrived[v & 3], v + 1) >= v + 1) break;
-      spins += 4096;
-      if (spins > kSpinLimit || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
-        atomicExch(err, 1);
-        return false;
-      }
+    // (ONE loop with the whole time-out in it and one test behind it: an outer loop that looked at the error word every 4096 polls left a dozen scalar instructions
+    //  and three taken branches between the poll that sees the message and the visit's first LDS read; a wave that gives up still raises the error word, the others
+    //  run into their own time-out at about the same moment)
+    if (__builtin_expect(lds_spin_ge(&S.arrived[v & 3], v + 1) < v + 1, 0)) {
+      atomicExch(err, 1);
+      return false;
     }
     __atomic_signal_fence(__ATOMIC_SEQ_CST);
     return true;
