@@ -936,9 +936,11 @@ __device__ void helper_role(const WnSpipeArgs& a, Lds& S, int stage, int p, int 
         // (the LDS image of visit it - 8 is overwritten: every chain wave has to be through with it)
         if (it >= kXyRing - 2 && !lds_wait4(S.hdone, (unsigned)it - (kXyRing - 2) + 1, a.err_flag)) return;
         const int off = ((c * kSpSlots + (s & 3)) * kMsgFloats) * 4 + look_off;
+        // (one exit besides the message: the time-out.  With the error word looked at every 1024 polls the loop left by three ways and carried their flags
+        //  to the staging - a wave that gives up still raises the word, the others run into their own time-out at about the same moment)
         unsigned spins = 0;
         while (!landed(pre_lo, pre_hi)) {
-          if (++spins > kSpinLimit || ((spins & 1023u) == 0 && __hip_atomic_load(a.err_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+          if (++spins > kSpinLimit) {
             atomicExch(a.err_flag, 1);
             return;
           }
@@ -1034,7 +1036,7 @@ __device__ void helper_role(const WnSpipeArgs& a, Lds& S, int stage, int p, int 
       const int off = ((cn * kSpSlots + (sn & 3)) * kMsgFloats) * 4 + look_off;
       unsigned spins = 0;
       while (!landed(pre_lo, pre_hi)) {
-        if (++spins > kSpinLimit || ((spins & 1023u) == 0 && __hip_atomic_load(a.err_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+        if (++spins > kSpinLimit) {
           atomicExch(a.err_flag, 1);
           return;
         }
