@@ -1197,9 +1197,9 @@ __device__ void head_role(const WnSpipeArgs& a, int p) {
         for (;;) {
           if (want_h) wh1 = msg_load(hlast);
           asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(w4) : "v"(src) : "memory");
-          const bool ok = w4[0] != kSpPoison && w4[1] != kSpPoison && w4[2] != kSpPoison && w4[3] != kSpPoison && (!want_h || wh1 != kSpPoison);
-          if (__all(ok) || SP_ABL(4)) break;
-          if (++spins > kSpinLimit || ((spins & 1023u) == 0 && __hip_atomic_load(a.err_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+          const unsigned mx = max(max(max(w4[0], w4[1]), max(w4[2], w4[3])), want_h ? wh1 : 0u);      // (poison is the largest unsigned: one maximum, one compare)
+          if (__all(mx != kSpPoison) || SP_ABL(4)) break;
+          if (++spins > kSpinLimit) {
             atomicExch(a.err_flag, 1);
             s_fail = 1;
             break;
