@@ -271,7 +271,7 @@ __global__ __launch_bounds__(kSqThreads) void lstm_seq_kernel(const LstmSeqArgs 
 #pragma unroll
                 for (int v = u; v < CPW; ++v) asm volatile("" : "+v"(hv[rb][v]));
                 if (STAMPS) ++rerequests;
-                if (++spins > kSqSpinLimit || ((spins & 63u) == 0 && __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+                if (++spins > kSqSpinLimit || (MMK_WAIT_ERR_LOOK && (spins & 63u) == 0 && __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
                   if (lane == 0) atomicOr(a.err, 1u);
                   check = false;
                   break;

@@ -1,5 +1,12 @@
 // Shared host/device declarations of libmmk_hip (gfx950 only).
 #pragma once
+// A wave that waits for a hand-off inside a persistent kernel gives up after its OWN time-out and raises the plan's error word.  1: it also looks at that word
+// every few hundred polls and follows a wave that has given up.  Measured (round 6): that second way out of every wait loop costs the loops their shape - a dozen scalar
+// instructions and taken branches between the poll that succeeds and the next instruction (SampleRNN cfg 3 3.63 -> 3.44 us per step without it) - and buys little:
+// the waves of a launch that has lost a hand-off run into their time-outs at about the same moment anyway.
+#ifndef MMK_WAIT_ERR_LOOK
+#define MMK_WAIT_ERR_LOOK 0
+#endif
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>

@@ -398,7 +398,7 @@ __global__ __launch_bounds__(kGruThreads) void srnn_gru_kernel(const SrnnGruArgs
         for (int k = 0; k < 2 * CPW; ++k) all = all && g[k][1] == epoch && g[k][3] == epoch;
         if (all) break;
         // ~1 s: a workgroup of the grid never became resident (the launcher checks the grid against the CU count)
-        if (++spins > (1u << 20) || ((spins & 255u) == 0 && a.err && __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+        if (++spins > (1u << 20) || (MMK_WAIT_ERR_LOOK && (spins & 255u) == 0 && a.err && __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
           if (a.err) atomicExch(a.err, 3);
           break;
         }

@@ -50,11 +50,19 @@ __device__ __forceinline__ u64 res_gload(const u64* p) { return __hip_atomic_loa
 __device__ __forceinline__ void res_gstore(u64* p, unsigned tag, unsigned bits) {
   __hip_atomic_store(p, ((u64)tag << 32) | (u64)bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+#ifndef MMK_SRNN_RES_POLL_SLEEP
+#define MMK_SRNN_RES_POLL_SLEEP 1      // s_sleep units between two looks at a granule that is not there yet
+#endif
+#ifndef MMK_SRNN_RES_ERR_LOOK
+#define MMK_SRNN_RES_ERR_LOOK 0        // 1: a waiting wave looks at the error word every 256 polls; 0: its own time-out only - one exit less in every wait loop (cfg 3: 3.63 -> 3.44 us per step)
+#endif
+__device__ __forceinline__ void res_pause() { if (MMK_SRNN_RES_POLL_SLEEP > 0) __builtin_amdgcn_s_sleep(MMK_SRNN_RES_POLL_SLEEP); }
 __device__ __forceinline__ bool res_give_up(unsigned& spins, int* err, int code) {
   if (++spins > kResSpinLimit) {
     if (err) atomicCAS(err, 0, code);
     return true;
   }
+  if (!MMK_SRNN_RES_ERR_LOOK) return false;
   return (spins & 255u) == 0 && err && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;   // another wait has failed: do not pile up
 }
 // one granule, polled until its tag is `tag`
@@ -63,7 +71,7 @@ __device__ __forceinline__ unsigned res_wait(const u64* src, unsigned tag, int* 
   unsigned spins = 0;
   while ((unsigned)(g >> 32) != tag) {
     if (res_give_up(spins, err, code)) break;
-    __builtin_amdgcn_s_sleep(1);
+    res_pause();
     g = res_gload(src);
   }
   return (unsigned)g;
@@ -93,12 +101,17 @@ __device__ __forceinline__ void res_poll_slice(const u64* hr, unsigned tag, f32x
                    : "=&v"(g[0]), "=&v"(g[1]), "=&v"(g[2]), "=&v"(g[3]), "=&v"(g[4]), "=&v"(g[5]), "=&v"(g[6]), "=&v"(g[7])
                    : "v"(hr) : "memory");
     }
-    bool all = true;
+    // every tag == `tag`  <=>  their minimum and their maximum are: two running three-operand min / max chains and two compares instead of 4 CPW compares
+    // and as many ands between the loads' return and the first product (the ring's poison check taught this: docs/history.md, round 6)
+    unsigned tmin = g[0][1], tmax = g[0][1];
 #pragma unroll
-    for (int k = 0; k < 2 * CPW; ++k) all = all && g[k][1] == tag && g[k][3] == tag;
-    if (all) break;
+    for (int k = 0; k < 2 * CPW; ++k) {
+      tmin = min(min(tmin, g[k][1]), g[k][3]);
+      tmax = max(max(tmax, g[k][1]), g[k][3]);
+    }
+    if (tmin == tag && tmax == tag) break;
     if (res_give_up(spins, err, code)) break;
-    __builtin_amdgcn_s_sleep(1);
+    res_pause();
   }
 #pragma unroll
   for (int u = 0; u < CPW; ++u)
@@ -121,12 +134,15 @@ __device__ __forceinline__ void res_poll_slice_pair(const u64* h0, const u64* h1
                  : "=&v"(g[0]), "=&v"(g[1]), "=&v"(g[2]), "=&v"(g[3]), "=&v"(g[4]), "=&v"(g[5]), "=&v"(g[6]), "=&v"(g[7]),
                    "=&v"(g[8]), "=&v"(g[9]), "=&v"(g[10]), "=&v"(g[11]), "=&v"(g[12]), "=&v"(g[13]), "=&v"(g[14]), "=&v"(g[15])
                  : "v"(h0), "v"(h1) : "memory");
-    bool all = true;
+    unsigned tmin = g[0][1], tmax = g[0][1];      // (as in res_poll_slice)
 #pragma unroll
-    for (int k = 0; k < 16; ++k) all = all && g[k][1] == tag && g[k][3] == tag;
-    if (all) break;
+    for (int k = 0; k < 16; ++k) {
+      tmin = min(min(tmin, g[k][1]), g[k][3]);
+      tmax = max(max(tmax, g[k][1]), g[k][3]);
+    }
+    if (tmin == tag && tmax == tag) break;
     if (res_give_up(spins, err, code)) break;
-    __builtin_amdgcn_s_sleep(1);
+    res_pause();
   }
 #pragma unroll
   for (int u = 0; u < 4; ++u) {

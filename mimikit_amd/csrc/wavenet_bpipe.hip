@@ -94,7 +94,7 @@ __device__ __forceinline__ bool wait_min(const unsigned* p, unsigned want, int32
     for (int i = 1; i < N; ++i) m = min(m, __hip_atomic_load(p + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
     if (m >= want) break;
     __builtin_amdgcn_s_sleep(1);
-    if (++spins > kSpin || ((spins & 4095u) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+    if (++spins > kSpin || (MMK_WAIT_ERR_LOOK && (spins & 4095u) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
       atomicCAS(err, 0, 1);
       return false;
     }
@@ -226,7 +226,7 @@ __device__ __forceinline__ bool gather(const unsigned* src, float* dst, int lane
     load4_sc1(src + 4 * lane, r[0], r[1], r[2], r[3]);
     if (__all(clean4(r[0], r[1], r[2], r[3]))) break;
     if (MMK_BP_LOOK_SLEEP > 0) __builtin_amdgcn_s_sleep(MMK_BP_LOOK_SLEEP);
-    if (++spins > kSpin || ((spins & 1023u) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+    if (++spins > kSpin || (MMK_WAIT_ERR_LOOK && (spins & 1023u) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
       atomicMax(err, 0x10000 | tag);      // (diagnosis: which look never saw its message)
       return false;
     }
@@ -432,7 +432,7 @@ __device__ __forceinline__ void helper_role(const WnBpipeArgs& a, BpLds& S, int 
         load4_sc1(src + 4 * lane, r[0], r[1], r[2], r[3]);
         if (__all(clean4(r[0], r[1], r[2], r[3]))) break;
         __builtin_amdgcn_s_sleep(2);
-        if (++spins > kSpin || ((spins & 1023u) == 0 && __hip_atomic_load(a.err_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+        if (++spins > kSpin || (MMK_WAIT_ERR_LOOK && (spins & 1023u) == 0 && __hip_atomic_load(a.err_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
           atomicMax(a.err_flag, 0x10000 | (64 * 17 + stage));
           return false;
         }
@@ -518,7 +518,7 @@ __device__ __forceinline__ void helper_role(const WnBpipeArgs& a, BpLds& S, int 
             break;
           }
           __builtin_amdgcn_s_sleep(2);
-          if (++spins > kSpin || ((spins & 1023u) == 0 && __hip_atomic_load(a.err_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+          if (++spins > kSpin || (MMK_WAIT_ERR_LOOK && (spins & 1023u) == 0 && __hip_atomic_load(a.err_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
             atomicCAS(a.err_flag, 0, 0x20000 | stage);
             return;
           }
@@ -591,7 +591,7 @@ __device__ __forceinline__ void helper_role(const WnBpipeArgs& a, BpLds& S, int 
               break;
             }
             __builtin_amdgcn_s_sleep(2);
-            if (++spins > kSpin || ((spins & 1023u) == 0 && __hip_atomic_load(a.err_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+            if (++spins > kSpin || (MMK_WAIT_ERR_LOOK && (spins & 1023u) == 0 && __hip_atomic_load(a.err_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
               atomicCAS(a.err_flag, 0, 0x20000 | stage);
               return false;
             }
@@ -705,7 +705,7 @@ __device__ __forceinline__ void head_role(const WnBpipeArgs& a, unsigned char* l
                        : "memory");
           if (__all(clean4(r[0], r[1], r[2], r[2]))) break;
           __builtin_amdgcn_s_sleep(2);
-          if (++spins > kSpin || ((spins & 1023u) == 0 && __hip_atomic_load(a.err_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+          if (++spins > kSpin || (MMK_WAIT_ERR_LOOK && (spins & 1023u) == 0 && __hip_atomic_load(a.err_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
             atomicCAS(a.err_flag, 0, 0x20000 | a.L);
             *s_fail = 1;
             break;

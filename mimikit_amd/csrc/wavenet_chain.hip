@@ -74,7 +74,7 @@ __device__ __forceinline__ bool sweep_pair(const u64* gy, const u64* gh, bool wi
                        h0[3] == epoch && h1[1] == epoch && h1[3] == epoch;
       if (all) break;
       ++spins;
-      if (spins > kSpinLimit || ((spins & 255u) == 0 && __hip_atomic_load(err_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+      if (spins > kSpinLimit || (MMK_WAIT_ERR_LOOK && (spins & 255u) == 0 && __hip_atomic_load(err_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
         ok = false;
         break;
       }
@@ -454,7 +454,7 @@ __global__ __launch_bounds__(kChThreads) void wavenet_chain_kernel(const WnChain
             v = gran_load(gran_idx + tid);
             if ((unsigned)(v >> 32) == (unsigned)s) break;
             ++spins;
-            if (spins > kSpinLimit || ((spins & 255u) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+            if (spins > kSpinLimit || (MMK_WAIT_ERR_LOOK && (spins & 255u) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
               *s_fail = 1;
               atomicExch(err, 1);
               break;

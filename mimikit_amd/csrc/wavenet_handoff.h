@@ -74,7 +74,7 @@ __device__ __forceinline__ bool sweep(const u64* gran, int count, unsigned epoch
         for (int k = 0; k < 4; ++k) all = all && ((unsigned)(v[k] >> 32) == epoch);
         if (all) break;
         ++spins;
-        if (spins > kSpinLimit || ((spins & 255u) == 0 && __hip_atomic_load(err_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+        if (spins > kSpinLimit || (MMK_WAIT_ERR_LOOK && (spins & 255u) == 0 && __hip_atomic_load(err_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
           ok = false;
           break;
         }

@@ -49,7 +49,7 @@ __device__ __forceinline__ u64 poll(const u64* p, unsigned epoch, int32_t* err) 
   unsigned spins = 0;
   while ((unsigned)(g >> 32) != epoch) {
     // ~1 s: the other stages are not running beside this one (or another wait has already failed: do not pile up)
-    if (++spins > kLpSpinLimit || ((spins & 1023u) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+    if (++spins > kLpSpinLimit || (MMK_WAIT_ERR_LOOK && (spins & 1023u) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
       atomicExch(err, 3);
       break;
     }
@@ -207,7 +207,7 @@ __device__ __forceinline__ void run_stage(const WnLpipeArgs& a, int clip, int st
       for (;;) {
         asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(gp) : "memory");
         if (v[1] == (unsigned)(s + 1) && v[3] == (unsigned)(s + 1)) break;
-        if (++spins > kLpSpinLimit || ((spins & 1023u) == 0 && __hip_atomic_load(a.err_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+        if (++spins > kLpSpinLimit || (MMK_WAIT_ERR_LOOK && (spins & 1023u) == 0 && __hip_atomic_load(a.err_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
           atomicExch(a.err_flag, 3);
           break;
         }

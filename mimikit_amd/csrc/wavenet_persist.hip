@@ -364,7 +364,7 @@ __global__ __launch_bounds__(wn_threads(KC)) void wavenet_persist_kernel(const W
           v = gran_load(gran_idx + tid);
           if ((unsigned)(v >> 32) == (unsigned)s) break;
           ++spins;
-          if (spins > kSpinLimit || ((spins & 255u) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+          if (spins > kSpinLimit || (MMK_WAIT_ERR_LOOK && (spins & 255u) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
             *s_fail = 1;
             atomicExch(err, 1);
             break;
