@@ -284,14 +284,14 @@ struct Stamps {
 #ifndef MMK_SP_TIGHT_WAIT
 #define MMK_SP_TIGHT_WAIT 1
 #endif
-// up to 2^22 looks (~0.2 s) at ONE LDS counter in a loop of six instructions (read, wait, compare, branch out / count, branch back); returns the last value read.  The compiler's
+// up to 2^24 looks (~1 s) at ONE LDS counter in a loop of six instructions (read, wait, compare, branch out / count, branch back); returns the last value read.  The compiler's
 // form of the loop below - two reads, a minimum, the time-out's bookkeeping and three exits - leaves ~10 scalar instructions between the look that sees the message
 // and the first LDS read of the visit, on every visit's chain.
 __device__ __forceinline__ unsigned lds_spin_ge(const unsigned* p, unsigned want) {
   const unsigned addr = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) unsigned*)p;
   unsigned val, cnt;
   asm volatile(
-      "s_mov_b32 %1, 0x400000\n"
+      "s_mov_b32 %1, 0x1000000\n"
       "1:\n\t"
       "ds_read_b32 %0, %2\n\t"
       "s_waitcnt lgkmcnt(0)\n\t"
